@@ -1,0 +1,171 @@
+/*
+ * lfpsqp_hip.h -- C ABI of liblfpsqp_hip.so, the MI355X (gfx950) implementation
+ * of the LFPSQP inner-loop hot path (projected CG, retractions, the tall-skinny
+ * fp64 linear algebra under them).
+ *
+ * This is the drop-in boundary: every entry point below names
+ * the reference call site it replaces (paths into ksil/LFPSQP.jl).  The
+ * reference reaches its native code through two Fortran-ABI ccalls
+ * (src/la_helper.jl:22 dgesvd_, :37 dgemv_) plus LinearAlgebra.BLAS/mul!; a
+ * Julia maintainer binds the functions here with `ccall((:name, liblfpsqp_hip),
+ * Cint, (...), ...)` -- see INTEGRATION.md and julia/LFPSQPHip.jl.
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw pointers, sizes as int64_t; no exceptions.
+ *   - every function returns an int status: 0 = ok, < 0 = error
+ *     (lfpsqp_last_error(ctx) gives the text).  Numerical outcomes (negative
+ *     curvature, retraction flags, ...) are OUTPUT values, never errors, exactly
+ *     as in the reference (SURVEY §8b "error conventions").
+ *   - one context per process and GPU.  Multi-GPU = one process per GPU; each
+ *     context owns the rows [row0, row0+n_loc) of every n-vector and of the
+ *     n x m matrices (lfpsqp_shard_range), m-sized data is replicated, and the
+ *     library all-reduces the m-vector / CG scalars itself over RCCL
+ *     (lfpsqp_comm_init_rccl) -- SURVEY §8e.
+ *   - host arrays stay caller-owned; device memory is library-owned.
+ *   - everything is fp64, matrices are column-major with unit row stride
+ *     (Julia's layout), 0-based sizes/counters.
+ */
+#ifndef LFPSQP_HIP_H
+#define LFPSQP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFPSQP_OK 0
+#define LFPSQP_ERR_ARG (-1)
+#define LFPSQP_ERR_HIP (-2)
+#define LFPSQP_ERR_COMM (-3)
+#define LFPSQP_ERR_NUMERIC (-4)
+#define LFPSQP_ERR_UNSUPPORTED (-5)
+
+typedef struct lfpsqp_ctx lfpsqp_ctx; /* one GPU + stream + workspaces + communicator */
+typedef struct lfpsqp_vec lfpsqp_vec; /* device fp64 vector (sharded n-vector or replicated m-vector) */
+typedef struct lfpsqp_mat lfpsqp_mat; /* device fp64 column-major n_loc x m matrix */
+
+/* ---- context ------------------------------------------------------------ */
+int lfpsqp_ctx_create(int device, lfpsqp_ctx** out);
+int lfpsqp_ctx_destroy(lfpsqp_ctx* ctx);
+int lfpsqp_ctx_sync(lfpsqp_ctx* ctx); /* wait for the context's stream */
+const char* lfpsqp_last_error(const lfpsqp_ctx* ctx);
+/* name of the device the context runs on ("cpu-emulator" only in the test build) */
+int lfpsqp_device_name(const lfpsqp_ctx* ctx, char* buf, int64_t buflen);
+/* HIP-event timing on the context's stream: begin .. end -> milliseconds */
+int lfpsqp_timer_begin(lfpsqp_ctx* ctx);
+int lfpsqp_timer_end(lfpsqp_ctx* ctx, double* ms);
+
+/* ---- multi-GPU ---------------------------------------------- */
+/* rows [*row0, *row1) of a global length-n vector owned by `rank` of `nranks` */
+int lfpsqp_shard_range(int64_t n, int rank, int nranks, int64_t* row0, int64_t* row1);
+/* RCCL: rank 0 calls unique_id (128 bytes), ships it to the other processes by
+ * any means (torch.distributed / MPI.jl / a file), then every rank calls init. */
+int lfpsqp_comm_unique_id(lfpsqp_ctx* ctx, void* id128);
+int lfpsqp_comm_init_rccl(lfpsqp_ctx* ctx, int rank, int nranks, const void* id128);
+/* Alternative transport: the host supplies the all-reduce (e.g. torch.distributed).
+ * `buf` is a DEVICE pointer to `count` doubles, reduced in place (op 0 = sum, 1 = max),
+ * ordered on `stream` (a hipStream_t). */
+typedef int (*lfpsqp_allreduce_fn)(void* user, double* buf, int64_t count, int op, void* stream);
+int lfpsqp_comm_init_callback(lfpsqp_ctx* ctx, int rank, int nranks, lfpsqp_allreduce_fn fn, void* user);
+int lfpsqp_comm_info(const lfpsqp_ctx* ctx, int* rank, int* nranks);
+
+/* ---- buffers ------------------------------------------------------------- */
+int lfpsqp_vec_alloc(lfpsqp_ctx* ctx, int64_t n, lfpsqp_vec** out); /* zero-filled */
+int lfpsqp_vec_free(lfpsqp_ctx* ctx, lfpsqp_vec* v);
+int64_t lfpsqp_vec_len(const lfpsqp_vec* v);
+int lfpsqp_vec_upload(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t offset, const double* host, int64_t count);
+int lfpsqp_vec_download(lfpsqp_ctx* ctx, const lfpsqp_vec* v, int64_t offset, double* host, int64_t count);
+int lfpsqp_vec_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, double value);
+int lfpsqp_vec_copy(lfpsqp_ctx* ctx, lfpsqp_vec* dst, const lfpsqp_vec* src); /* dst .= src */
+int lfpsqp_mat_alloc(lfpsqp_ctx* ctx, int64_t n, int64_t m, lfpsqp_mat** out); /* zero-filled */
+int lfpsqp_mat_free(lfpsqp_ctx* ctx, lfpsqp_mat* M);
+int lfpsqp_mat_shape(const lfpsqp_mat* M, int64_t* n, int64_t* m);
+/* host is column-major with leading dimension ldh (>= n); columns [col0, col0+ncols) */
+int lfpsqp_mat_upload(lfpsqp_ctx* ctx, lfpsqp_mat* M, int64_t col0, int64_t ncols, const double* host, int64_t ldh);
+int lfpsqp_mat_download(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t col0, int64_t ncols, double* host, int64_t ldh);
+int lfpsqp_mat_copy(lfpsqp_ctx* ctx, lfpsqp_mat* dst, const lfpsqp_mat* src);
+/* synthetic inputs of SURVEY §8(d): v[i] = u(seed, offset+i);
+ * M[i,j] = u(seed, j*n_global + row0 + i)  (splitmix64-finaliser hash in [-1,1)) */
+int lfpsqp_vec_hash_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, uint64_t seed, int64_t offset, double scale, double shift);
+int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global);
+
+/* ---- BLAS-1/2 primitives on the tall-skinny layout ------------------------ */
+/* Replace the reference's mul!/gemv!/kgemv!/dot/norm/axpy!/broadcast call sites
+ * (src/projcg.jl:55-118, src/la_helper.jl:36-44, src/retractions.jl:140-160,
+ * 213-235).  n-vectors are sharded, results of reductions are global
+ * (all-reduced) and replicated. */
+/* t[0:ncols] = M[:, 0:ncols]' * v            (kgemv!('T', rank, 1, M, v, 0, t); mul!(t, U', v)) */
+int lfpsqp_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* v, lfpsqp_vec* t);
+/* y = alpha * M[:, 0:ncols] * t + beta * y    (kgemv!('N', ...); mul!(y, U, t, alpha, beta)) */
+int lfpsqp_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, double alpha, const lfpsqp_vec* t, double beta, lfpsqp_vec* y);
+int lfpsqp_dot(lfpsqp_ctx* ctx, const lfpsqp_vec* x, const lfpsqp_vec* y, double* out);  /* dot(x, y) */
+int lfpsqp_nrm2(lfpsqp_ctx* ctx, const lfpsqp_vec* x, double* out);                      /* norm(x) */
+int lfpsqp_amax(lfpsqp_ctx* ctx, const lfpsqp_vec* x, double* out);                      /* norm(x, Inf) */
+int lfpsqp_axpby(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double b, lfpsqp_vec* y); /* y = a*x + b*y */
+/* z = a*x + b*y (z may alias x or y) */
+int lfpsqp_waxpby(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double b, const lfpsqp_vec* y, lfpsqp_vec* z);
+/* y = d .* x (diagonal operator apply; z may alias) */
+int lfpsqp_vmul(lfpsqp_ctx* ctx, const lfpsqp_vec* d, const lfpsqp_vec* x, lfpsqp_vec* y);
+/* sum-all-reduce a replicated-partials device vector across ranks (no-op for 1 rank) */
+int lfpsqp_allreduce(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t count);
+
+/* ---- projected CG (src/projcg.jl:40-121) --------------------------------- */
+/* The symmetric operator A of the QP ("B*p", the Lagrangian Hessian action that the
+ * reference wraps in a LinearMap at src/optimize.jl:228-230).  Device-resident
+ * forms: A = a0*I + diag(dg)  (dg may be NULL).  Covers hess_lag_vec! for
+ * quadratic f with linear/ball constraints and augmented_hess_lag_vec!
+ * (src/inequality_helper.jl:144-158), whose bound terms are diagonal. */
+typedef struct lfpsqp_diag_op {
+    double a0;
+    const lfpsqp_vec* dg; /* optional, length n */
+} lfpsqp_diag_op;
+
+/* The orthonormal operator U of projcg! ("Qview", src/optimize.jl:366-372):
+ *   plain   : U = Z[:, 0:ncols]                         (view(U, :, 1:rank))
+ *   stacked : Q = [[diag Dx; diag Dy], [sx .* Z; sy .* Z][:, 0:ncols]]
+ *             (InequalityDecompProject, src/inequality_helper.jl:161-212, with
+ *             the 2N x M factor stored as row scalings of one N x M matrix; vectors
+ *             are [x-half; y-half], each half of length n_half = rows(Z)). */
+typedef struct lfpsqp_basis {
+    const lfpsqp_mat* Z;
+    int64_t ncols;
+    const lfpsqp_vec* Dx; /* NULL => plain */
+    const lfpsqp_vec* Dy;
+    const lfpsqp_vec* sx;
+    const lfpsqp_vec* sy;
+} lfpsqp_basis;
+
+/* ProjCGWork (src/projcg.jl:1-11): caller-owned scratch, allocated once.
+ * Only three n-vectors are needed on the device (r == g throughout, gp and Ad
+ * are never materialised) plus the m-vector Utr. */
+typedef struct lfpsqp_projcg_work {
+    lfpsqp_vec* g;
+    lfpsqp_vec* d;
+    lfpsqp_vec* rp;
+    lfpsqp_vec* Utr;
+} lfpsqp_projcg_work;
+
+#define LFPSQP_PROJCG_WANT_LAMBDA 1 /* compute lambda = U'(b - A x) (src/projcg.jl:115-118) */
+
+/* projcg!(x, lambda, A, U, b, c; tol, maxit, work) -> (iters, nr).
+ * c == NULL means c = 0 (always the case in optimize, src/optimize.jl:213,368,371).
+ * n_global = length(b) summed over ranks; the loop bound is min(maxit, n_global + m).
+ * Exit semantics are the reference's: negative curvature => x = d/||d||,
+ * lambda = NaN, *nr = +Inf; rg <= 0 => break; nr < tol => break. */
+int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A,
+                  const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
+                  int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr);
+
+/* per-kernel-family device time (ms) accumulated by the last lfpsqp_projcg call when
+ * the context was created with profiling on (lfpsqp_ctx_set_profiling); used by
+ * bench.py for the roofline object.  slots: 0 = K1 (direction update + d'Ad),
+ * 1 = K2 (x/rp update fused with U' rp), 2 = K3 (gp = rp - U t fused with dots),
+ * 3 = small reductions/posts, counts[] = launches per slot. */
+int lfpsqp_ctx_set_profiling(lfpsqp_ctx* ctx, int on);
+int lfpsqp_profile_read(lfpsqp_ctx* ctx, double ms[8], int64_t counts[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFPSQP_HIP_H */

@@ -1,0 +1,9 @@
+"""lfpsqp.jl_amd -- MI355X-native hot path of LFPSQP (projected CG + retractions).
+
+Host-side mirror of the reference's operator interface over the C ABI of
+``liblfpsqp_hip.so`` (include/lfpsqp_hip.h).  Import as ``lfpsqp_jl_amd``.
+"""
+from ._capi import LfpsqpError, load_library, header_functions  # noqa: F401
+from .device import (Context, DeviceMatrix, DeviceVector, amax, axpby, dot, gemv_n, gemv_t, nrm2, vmul,  # noqa: F401
+                     waxpby)
+from .projcg import DeviceBasis, DiagOperator, ProjCGWork, projcg_  # noqa: F401

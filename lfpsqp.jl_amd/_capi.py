@@ -1,0 +1,119 @@
+"""ctypes binding of liblfpsqp_hip.so (include/lfpsqp_hip.h) -- the same C ABI a
+Julia host binds with ccall.  There is NO CPU fallback: if the HIP
+library is missing or no GPU is visible, everything here fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "liblfpsqp_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "lfpsqp_hip.h")
+
+c_i64 = C.c_int64
+c_dbl = C.c_double
+P = C.c_void_p
+PD = C.POINTER(C.c_double)
+
+
+class DiagOp(C.Structure):  # lfpsqp_diag_op
+    _fields_ = [("a0", c_dbl), ("dg", P)]
+
+
+class Basis(C.Structure):  # lfpsqp_basis
+    _fields_ = [("Z", P), ("ncols", c_i64), ("Dx", P), ("Dy", P), ("sx", P), ("sy", P)]
+
+
+class ProjCGWorkC(C.Structure):  # lfpsqp_projcg_work
+    _fields_ = [("g", P), ("d", P), ("rp", P), ("Utr", P)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, P, P, c_i64, C.c_int, P)
+
+_SIGS = {
+    "lfpsqp_ctx_create": [C.c_int, C.POINTER(P)],
+    "lfpsqp_ctx_destroy": [P],
+    "lfpsqp_ctx_sync": [P],
+    "lfpsqp_device_name": [P, C.c_char_p, c_i64],
+    "lfpsqp_timer_begin": [P],
+    "lfpsqp_timer_end": [P, PD],
+    "lfpsqp_shard_range": [c_i64, C.c_int, C.c_int, C.POINTER(c_i64), C.POINTER(c_i64)],
+    "lfpsqp_comm_unique_id": [P, P],
+    "lfpsqp_comm_init_rccl": [P, C.c_int, C.c_int, P],
+    "lfpsqp_comm_init_callback": [P, C.c_int, C.c_int, ALLREDUCE_FN, P],
+    "lfpsqp_comm_info": [P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "lfpsqp_vec_alloc": [P, c_i64, C.POINTER(P)],
+    "lfpsqp_vec_free": [P, P],
+    "lfpsqp_vec_upload": [P, P, c_i64, P, c_i64],
+    "lfpsqp_vec_download": [P, P, c_i64, P, c_i64],
+    "lfpsqp_vec_fill": [P, P, c_dbl],
+    "lfpsqp_vec_copy": [P, P, P],
+    "lfpsqp_mat_alloc": [P, c_i64, c_i64, C.POINTER(P)],
+    "lfpsqp_mat_free": [P, P],
+    "lfpsqp_mat_shape": [P, C.POINTER(c_i64), C.POINTER(c_i64)],
+    "lfpsqp_mat_upload": [P, P, c_i64, c_i64, P, c_i64],
+    "lfpsqp_mat_download": [P, P, c_i64, c_i64, P, c_i64],
+    "lfpsqp_mat_copy": [P, P, P],
+    "lfpsqp_vec_hash_fill": [P, P, C.c_uint64, c_i64, c_dbl, c_dbl],
+    "lfpsqp_mat_hash_fill": [P, P, C.c_uint64, c_i64, c_i64],
+    "lfpsqp_gemv_t": [P, P, c_i64, P, P],
+    "lfpsqp_gemv_n": [P, P, c_i64, c_dbl, P, c_dbl, P],
+    "lfpsqp_dot": [P, P, P, PD],
+    "lfpsqp_nrm2": [P, P, PD],
+    "lfpsqp_amax": [P, P, PD],
+    "lfpsqp_axpby": [P, c_dbl, P, c_dbl, P],
+    "lfpsqp_waxpby": [P, c_dbl, P, c_dbl, P, P],
+    "lfpsqp_vmul": [P, P, P, P],
+    "lfpsqp_allreduce": [P, P, c_i64],
+    "lfpsqp_projcg": [P, P, P, C.POINTER(DiagOp), C.POINTER(Basis), P, P, c_dbl, c_i64, c_i64, C.c_int,
+                      C.POINTER(ProjCGWorkC), C.POINTER(c_i64), PD],
+    "lfpsqp_ctx_set_profiling": [P, C.c_int],
+    "lfpsqp_profile_read": [P, PD, C.POINTER(c_i64)],
+}
+
+
+class LfpsqpError(RuntimeError):
+    pass
+
+
+def header_functions(header: str = HEADER):
+    """Names of every function include/lfpsqp_hip.h declares."""
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lfpsqp_[a-z0-9_]+)\s*\(", text)) - {"lfpsqp_allreduce_fn"})
+
+
+class Library:
+    def __init__(self, path: str | None = None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise LfpsqpError(
+                f"HIP extension not built: {path} is missing (run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "There is no CPU fallback.")
+        self.path = path
+        self.lib = C.CDLL(path)
+        self.lib.lfpsqp_last_error.restype = C.c_char_p
+        self.lib.lfpsqp_last_error.argtypes = [P]
+        self.lib.lfpsqp_vec_len.restype = c_i64
+        self.lib.lfpsqp_vec_len.argtypes = [P]
+        for name, sig in _SIGS.items():
+            fn = getattr(self.lib, name)
+            fn.restype = C.c_int
+            fn.argtypes = sig
+
+    def __getattr__(self, name):
+        return getattr(self.lib, name)
+
+
+_default: Library | None = None
+
+
+def load_library(path: str | None = None) -> Library:
+    """Load (once) the HIP library.  ``path`` is for the test-suite's emulator build only."""
+    global _default
+    if path is not None:
+        return Library(path)
+    if _default is None:
+        _default = Library()
+    return _default

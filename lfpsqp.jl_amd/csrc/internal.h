@@ -1,0 +1,203 @@
+// Host-side internals shared by the translation units of liblfpsqp_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lfpsqp_hip.h"
+#include "kernels.h"
+
+struct lfpsqp_vec {
+    double* p = nullptr;
+    int64_t n = 0;    // logical length (local part of a sharded vector)
+    int64_t cap = 0;  // allocated doubles: n rounded up to whole tiles, padding kept finite
+};
+
+struct lfpsqp_mat {
+    double* p = nullptr;
+    int64_t n = 0, m = 0;
+    int64_t ld = 0;  // rows rounded up to whole tiles; padding rows are zero and never written
+};
+
+namespace lfpsqp {
+
+constexpr int kProfSlots = 8;
+constexpr int kProfEvents = 128;  // event pairs kept per slot
+
+struct Comm {
+    int rank = 0, nranks = 1;
+    enum Kind { NONE, RCCL, CALLBACK } kind = NONE;
+    void* rccl_lib = nullptr;
+    void* nccl_comm = nullptr;
+    int (*ncclAllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, void*, hipStream_t) = nullptr;
+    int (*ncclCommDestroy)(void*) = nullptr;
+    const char* (*ncclGetErrorString)(int) = nullptr;
+    lfpsqp_allreduce_fn cb = nullptr;
+    void* cb_user = nullptr;
+};
+
+}  // namespace lfpsqp
+
+struct lfpsqp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string devname;
+    lfpsqp::Comm comm;
+
+    // reduction workspace: partial sums [rows][ld] (device)
+    double* part = nullptr;
+    size_t part_cap = 0;  // doubles
+    // small device blocks: solver scalars / status, and their pinned host mirrors
+    double* scal = nullptr;    // 64 doubles
+    int64_t* istat = nullptr;  // 16 int64
+    double* h_scal = nullptr;  // pinned: 4 slots x 64
+    int64_t* h_istat = nullptr;  // pinned: 4 slots x 16
+    hipEvent_t ev_slot[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+
+    // optional per-kernel-family profiling with HIP events on `stream`
+    bool profiling = false;
+    hipEvent_t prof_ev[lfpsqp::kProfSlots][lfpsqp::kProfEvents][2];
+    int prof_used[lfpsqp::kProfSlots] = {0};
+    int64_t prof_count[lfpsqp::kProfSlots] = {0};
+    double prof_ms[lfpsqp::kProfSlots] = {0};
+    bool prof_init = false;
+};
+
+namespace lfpsqp {
+
+int set_err(lfpsqp_ctx* ctx, int code, const char* fmt, ...);
+int ensure_part(lfpsqp_ctx* ctx, size_t doubles);
+int allreduce_dev(lfpsqp_ctx* ctx, double* buf, int64_t count, int op = 0);  // in place, stream ordered; op 0 sum / 1 max; no-op for 1 rank
+
+// profiling helpers: bracket one launch of slot `s`
+void prof_begin(lfpsqp_ctx* ctx, int s);
+void prof_end(lfpsqp_ctx* ctx, int s);
+void prof_collect(lfpsqp_ctx* ctx);  // after a stream sync: fold event pairs into prof_ms
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+inline int64_t ntiles_of(int64_t n) { return (n + kTileRows - 1) / kTileRows; }
+
+#define LF_HIP(ctx, expr)                                                                              \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return lfpsqp::set_err((ctx), LFPSQP_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
+                                   hipGetErrorString(e__), __FILE__, __LINE__);                        \
+    } while (0)
+
+#define LF_TRY(expr)               \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+#define LF_ARG(ctx, cond)                                                                               \
+    do {                                                                                                \
+        if (!(cond)) return lfpsqp::set_err((ctx), LFPSQP_ERR_ARG, "invalid argument: %s (%s:%d)", #cond, \
+                                            __FILE__, __LINE__);                                        \
+    } while (0)
+
+#define LF_LAUNCH_CHECK(ctx) LF_HIP(ctx, hipGetLastError())
+
+// ---- generic launchers (templates, so they live in the header) -------------
+
+// second stage of a reduction: out[0:ncols] = reduce over `nrows` partial rows
+template <class POST>
+int launch_reduce(lfpsqp_ctx* ctx, int64_t nrows, int ncols, int part_ld, unsigned ismax, double* out, POST post) {
+    const int grid = (ncols + 31) / 32;
+    hipLaunchKernelGGL((reduce_rows_kernel<POST>), dim3(grid), dim3(1024), 0, ctx->stream, ctx->part, nrows, ncols, part_ld,
+                       ismax, out, post);
+    LF_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// t_out[0:ncols] = M[:, :ncols]' * vp  (global: all-reduced over ranks).  The producer runs
+// (with its fused stores) even when ncols == 0, so solvers need no special case for an
+// empty basis (reference: projcg! with an n x 0 U).
+template <class VP>
+int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp, double* t_out, int prof_slot = -1) {
+    const int64_t tiles = ntiles_of(n);
+    const int part_ld = (int)round_up(ncols > 0 ? ncols : 1, 32);
+    if (tiles > 0) {
+        LF_TRY(ensure_part(ctx, (size_t)tiles * part_ld));
+        if (prof_slot >= 0) prof_begin(ctx, prof_slot);
+        hipLaunchKernelGGL((gemv_t_kernel<VP>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, M ? M->p : nullptr,
+                           M ? M->ld : 0, ncols, n, vp, ctx->part, part_ld);
+        if (prof_slot >= 0) prof_end(ctx, prof_slot);
+        LF_LAUNCH_CHECK(ctx);
+    }
+    if (ncols == 0) return 0;
+    if (tiles > 0) LF_TRY(launch_reduce(ctx, tiles, ncols, part_ld, 0u, t_out, NoPost()));
+    else LF_HIP(ctx, hipMemsetAsync(t_out, 0, sizeof(double) * ncols, ctx->stream));
+    return allreduce_dev(ctx, t_out, ncols);
+}
+
+// fused y-side consumer of M[:, :ncols] * t; reductions (NRED sums) land in red_out (global)
+// when POST is given it runs after the (all-reduced) sums are final.
+template <class EP, int NRED, class POST>
+int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const double* t, EP ep, double* red_out, POST post,
+               int prof_slot = -1) {
+    const int64_t tiles = ntiles_of(n);
+    if (tiles > 0) {
+        LF_TRY(ensure_part(ctx, (size_t)tiles * kMaxRed));
+        if (prof_slot >= 0) prof_begin(ctx, prof_slot);
+        hipLaunchKernelGGL((gemv_n_kernel<EP, NRED>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, M ? M->p : nullptr,
+                           M ? M->ld : 0, ncols, n, t, ep, ctx->part);
+        if (prof_slot >= 0) prof_end(ctx, prof_slot);
+        LF_LAUNCH_CHECK(ctx);
+    }
+    if (NRED > 0) {
+        if (tiles == 0) LF_HIP(ctx, hipMemsetAsync(red_out, 0, sizeof(double) * NRED, ctx->stream));
+        if (ctx->comm.nranks == 1) {
+            if (tiles > 0) LF_TRY(launch_reduce(ctx, tiles, NRED, kMaxRed, 0u, red_out, post));
+            else {
+                hipLaunchKernelGGL((post_kernel<POST>), dim3(1), dim3(1), 0, ctx->stream, red_out, post);
+                LF_LAUNCH_CHECK(ctx);
+            }
+        } else {
+            if (tiles > 0) LF_TRY(launch_reduce(ctx, tiles, NRED, kMaxRed, 0u, red_out, NoPost()));
+            LF_TRY(allreduce_dev(ctx, red_out, NRED));
+            hipLaunchKernelGGL((post_kernel<POST>), dim3(1), dim3(1), 0, ctx->stream, red_out, post);
+            LF_LAUNCH_CHECK(ctx);
+        }
+    }
+    return 0;
+}
+
+inline int vec_grid(int64_t n) {
+    int64_t t = (n + kSlabRows - 1) / kSlabRows;
+    return (int)(t < 2048 ? (t < 1 ? 1 : t) : 2048);
+}
+
+// elementwise map with NRED reductions (sum, or max where ismax bit set) -> red_out (global)
+template <class F, int NRED, class POST>
+int run_vec(lfpsqp_ctx* ctx, int64_t n, F f, unsigned ismax, double* red_out, POST post, int prof_slot = -1) {
+    const int grid = vec_grid(n);
+    if (NRED > 0) LF_TRY(ensure_part(ctx, (size_t)grid * kMaxRed));
+    if (prof_slot >= 0) prof_begin(ctx, prof_slot);
+    hipLaunchKernelGGL((vec_kernel<F, NRED>), dim3(grid), dim3(kThreads), 0, ctx->stream, f, n, ismax, ctx->part);
+    if (prof_slot >= 0) prof_end(ctx, prof_slot);
+    LF_LAUNCH_CHECK(ctx);
+    if (NRED > 0) {
+        if (ctx->comm.nranks == 1) {
+            LF_TRY(launch_reduce(ctx, grid, NRED, kMaxRed, ismax, red_out, post));
+        } else {
+            const unsigned all = (1u << NRED) - 1u;
+            if (ismax != 0 && ismax != all) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "mixed sum/max reduction across ranks");
+            LF_TRY(launch_reduce(ctx, grid, NRED, kMaxRed, ismax, red_out, NoPost()));
+            LF_TRY(allreduce_dev(ctx, red_out, NRED, ismax ? 1 : 0));
+            hipLaunchKernelGGL((post_kernel<POST>), dim3(1), dim3(1), 0, ctx->stream, red_out, post);
+            LF_LAUNCH_CHECK(ctx);
+        }
+    }
+    return 0;
+}
+
+// read `count` doubles of device memory back after everything queued so far
+int read_back(lfpsqp_ctx* ctx, const double* dev, double* host, int64_t count);
+
+}  // namespace lfpsqp

@@ -1,0 +1,275 @@
+// Device-side building blocks of liblfpsqp_hip (gfx950 / CDNA4, wave64).
+//
+// Every big operation of the hot path is one of three streaming shapes over the
+// tall-skinny column-major layout:
+//   gemv_t_kernel : t = M' v      -- v produced on the fly by a functor (fused vector updates)
+//   gemv_n_kernel : y = M t       -- consumed on the fly by a functor (fused updates + dot partials)
+//   vec_kernel    : elementwise map + up to 4 sum/max reductions
+// plus reduce_rows_kernel, the fixed-order second stage of every reduction.
+//
+// A thread owns kS double2 row-pairs of a kTileRows tile and streams them over all
+// columns: lanes read consecutive 16-byte pieces (global_load_dwordx4, 1 KiB per wave
+// instruction), kS*kColUnroll loads are in flight per lane, nothing is staged through
+// LDS (each matrix byte is used exactly once -- guide: "GEMV / M<=16: load straight to
+// VGPRs, deep unroll").  All reductions are two-stage and atomics-free so results are
+// bit-reproducible for a given (n_loc, m).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lfpsqp {
+
+constexpr int kThreads = 256;                 // 4 waves
+constexpr int kWaves = kThreads / 64;
+constexpr int kS = 2;                         // double2 slabs per thread
+constexpr int kSlabRows = kThreads * 2;       // 512 rows: one 16-byte piece per lane
+constexpr int kTileRows = kSlabRows * kS;     // 1024 rows per workgroup
+constexpr int kColChunk = 256;                // columns reduced per LDS flush
+constexpr int kMaxRed = 4;                    // scalar reductions per kernel
+
+__device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Block reduction of NRED per-thread values; thread 0 gets the result and writes
+// dst[k].  `ismax` bit k selects max instead of sum for slot k.  Fixed order.
+template <int NRED>
+__device__ __forceinline__ void block_reduce_store(double (&red)[NRED], unsigned ismax, double* dst) {
+    __shared__ double sm[kWaves][kMaxRed];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) {
+        double r = ((ismax >> k) & 1u) ? wave_max(red[k]) : wave_sum(red[k]);
+        if (lane == 0) sm[wave][k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NRED; ++k) {
+            if ((ismax >> k) & 1u)
+                dst[k] = fmax(fmax(sm[0][k], sm[1][k]), fmax(sm[2][k], sm[3][k]));
+            else
+                dst[k] = (sm[0][k] + sm[1][k]) + (sm[2][k] + sm[3][k]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GEMV-T: part[tile][j] = sum over the tile's rows of M[row, j] * v[row]
+//   VP::load(row, valid0, valid1) returns (v[row], v[row+1]) and may store fused
+//   side outputs; rows >= n must return 0 (the tile is padded, matrix padding is 0).
+//   VP::skip() (uniform) makes the whole launch a no-op (solver already finished).
+// grid.x = number of tiles.  part has leading dimension part_ld >= ncols.
+// ---------------------------------------------------------------------------
+template <class VP>
+__global__ __launch_bounds__(kThreads) void gemv_t_kernel(const double* __restrict__ M, int64_t ld, int ncols, int64_t n,
+                                                           VP vp, double* __restrict__ part, int part_ld) {
+    if (vp.skip()) return;
+    __shared__ double red[kWaves][kColChunk];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * kTileRows + (int64_t)threadIdx.x * 2;
+    double2 v[kS];
+#pragma unroll
+    for (int s = 0; s < kS; ++s) {
+        const int64_t r = row0 + (int64_t)s * kSlabRows;
+        v[s] = vp.load(r, r < n, r + 1 < n);
+    }
+    const double* base = M + row0;
+    double* prow = part + (int64_t)blockIdx.x * part_ld;
+    for (int j0 = 0; j0 < ncols; j0 += kColChunk) {
+        const int jn = (ncols - j0 < kColChunk) ? (ncols - j0) : kColChunk;
+        for (int j = 0; j < jn; j += 4) {
+            double p[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int jj = (j + c < jn) ? (j + c) : (jn - 1);   // clamp: ragged last group re-reads a valid column
+                const double* col = base + (int64_t)(j0 + jj) * ld;
+                double acc = 0.0;
+#pragma unroll
+                for (int s = 0; s < kS; ++s) {
+                    const double2 a = ld2(col + (int64_t)s * kSlabRows);
+                    acc = fma(a.x, v[s].x, acc);
+                    acc = fma(a.y, v[s].y, acc);
+                }
+                p[c] = acc;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = wave_sum(p[c]);
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (j + c < jn) red[wave][j + c] = p[c];
+            }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < jn; j += kThreads)
+            prow[j0 + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GEMV-N: acc[row] = sum_j M[row, j] * t[j], handed to EP::apply(row, acc0, acc1,
+// valid0, valid1, red) which does the fused stores and adds its reduction terms
+// into red[0..NRED).  part[tile][k] receives the tile's reduction partials.
+// ---------------------------------------------------------------------------
+template <class EP, int NRED>
+__global__ __launch_bounds__(kThreads) void gemv_n_kernel(const double* __restrict__ M, int64_t ld, int ncols, int64_t n,
+                                                           const double* __restrict__ t, EP ep, double* __restrict__ part) {
+    if (ep.skip()) return;
+    __shared__ double ts[kColChunk];
+    const int64_t row0 = (int64_t)blockIdx.x * kTileRows + (int64_t)threadIdx.x * 2;
+    const double* base = M + row0;
+    double2 acc[kS];
+#pragma unroll
+    for (int s = 0; s < kS; ++s) acc[s] = make_double2(0.0, 0.0);
+    for (int j0 = 0; j0 < ncols; j0 += kColChunk) {
+        const int jn = (ncols - j0 < kColChunk) ? (ncols - j0) : kColChunk;
+        __syncthreads();
+        for (int j = threadIdx.x; j < jn; j += kThreads) ts[j] = t[j0 + j];
+        __syncthreads();
+        int j = 0;
+        for (; j + 8 <= jn; j += 8) {
+            double2 a[8][kS];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const double* col = base + (int64_t)(j0 + j + c) * ld;
+#pragma unroll
+                for (int s = 0; s < kS; ++s) a[c][s] = ld2(col + (int64_t)s * kSlabRows);
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const double tj = ts[j + c];
+#pragma unroll
+                for (int s = 0; s < kS; ++s) {
+                    acc[s].x = fma(a[c][s].x, tj, acc[s].x);
+                    acc[s].y = fma(a[c][s].y, tj, acc[s].y);
+                }
+            }
+        }
+        for (; j < jn; ++j) {
+            const double* col = base + (int64_t)(j0 + j) * ld;
+            const double tj = ts[j];
+#pragma unroll
+            for (int s = 0; s < kS; ++s) {
+                const double2 a = ld2(col + (int64_t)s * kSlabRows);
+                acc[s].x = fma(a.x, tj, acc[s].x);
+                acc[s].y = fma(a.y, tj, acc[s].y);
+            }
+        }
+    }
+    double red[NRED > 0 ? NRED : 1];
+#pragma unroll
+    for (int k = 0; k < (NRED > 0 ? NRED : 1); ++k) red[k] = 0.0;
+#pragma unroll
+    for (int s = 0; s < kS; ++s) {
+        const int64_t r = row0 + (int64_t)s * kSlabRows;
+        ep.apply(r, acc[s], r < n, r + 1 < n, red);
+    }
+    if (NRED > 0) block_reduce_store<(NRED > 0 ? NRED : 1)>(red, 0u, part + (int64_t)blockIdx.x * kMaxRed);
+}
+
+// ---------------------------------------------------------------------------
+// Elementwise map + reductions.  F::apply(i, valid0, valid1, red) handles the
+// row pair (i, i+1).  Static tile -> block assignment (tile = block + k*grid) and
+// a fixed in-block order keep the sums reproducible.  part[block][k].
+// ---------------------------------------------------------------------------
+template <class F, int NRED>
+__global__ __launch_bounds__(kThreads) void vec_kernel(F f, int64_t n, unsigned ismax, double* __restrict__ part) {
+    if (f.skip()) return;
+    double red[NRED > 0 ? NRED : 1];
+#pragma unroll
+    for (int k = 0; k < (NRED > 0 ? NRED : 1); ++k) red[k] = 0.0;
+    const int64_t ntiles = (n + kSlabRows - 1) / kSlabRows;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t i = tile * kSlabRows + (int64_t)threadIdx.x * 2;
+        f.apply(i, i < n, i + 1 < n, red);
+    }
+    if (NRED > 0) block_reduce_store<(NRED > 0 ? NRED : 1)>(red, ismax, part + (int64_t)blockIdx.x * kMaxRed);
+}
+
+// ---------------------------------------------------------------------------
+// Second stage: out[j] = sum (or max) over rows of part[row][j], fixed order.
+// Block = 1024 threads = 32 columns x 32 row groups; grid.x = ceil(ncols/32).
+// POST::run(out) is executed by one thread after the sums are visible when the
+// launch has a single block (scalar reductions: computes alpha/beta/status ...).
+// ---------------------------------------------------------------------------
+template <class POST>
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const double* __restrict__ part, int64_t nrows, int ncols, int part_ld,
+                                                            unsigned ismax, double* __restrict__ out, POST post) {
+    if (post.skip()) return;
+    __shared__ double sm[32][33];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
+    const bool mx = (ismax >> (col < 32 ? col : 31)) & 1u;
+    double acc = 0.0;
+    if (col < ncols) {
+        if (mx) {
+            for (int64_t r = g; r < nrows; r += 32) acc = fmax(acc, part[r * part_ld + col]);
+        } else {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int64_t r = g;
+            for (; r + 96 < nrows; r += 128) {
+                a0 += part[r * part_ld + col];
+                a1 += part[(r + 32) * part_ld + col];
+                a2 += part[(r + 64) * part_ld + col];
+                a3 += part[(r + 96) * part_ld + col];
+            }
+            for (; r < nrows; r += 32) a0 += part[r * part_ld + col];
+            acc = (a0 + a1) + (a2 + a3);
+        }
+    }
+    sm[g][c] = acc;
+    __syncthreads();
+    if (g == 0 && col < ncols) {
+        double r = sm[0][c];
+        if (mx) {
+            for (int k = 1; k < 32; ++k) r = fmax(r, sm[k][c]);
+        } else {
+            // pairwise over the 32 groups
+            double s[32];
+            for (int k = 0; k < 32; ++k) s[k] = sm[k][c];
+            for (int w = 16; w > 0; w >>= 1)
+                for (int k = 0; k < w; ++k) s[k] = s[k] + s[k + w];
+            r = s[0];
+        }
+        out[col] = r;
+    }
+    if (gridDim.x == 1) {
+        __syncthreads();
+        if (threadIdx.x == 0) post.run(out);
+    }
+}
+
+struct NoPost {
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void run(double*) const {}
+};
+
+// 1-thread launch used when an all-reduce sits between the reduction and its post-op
+template <class POST>
+__global__ void post_kernel(double* out, POST post) {
+    if (post.skip()) return;
+    if (threadIdx.x == 0 && blockIdx.x == 0) post.run(out);
+}
+
+// splitmix64 finaliser as a hash of the flat index -> [-1, 1)   
+__device__ __forceinline__ double hash_u(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * 0x1.0p-52 - 1.0;
+}
+
+}  // namespace lfpsqp

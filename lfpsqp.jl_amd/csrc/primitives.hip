@@ -1,0 +1,212 @@
+// BLAS-1/2 primitives of the C ABI on the tall-skinny layout, and the synthetic
+// input generators.  Replaces the reference's mul!/gemv!/kgemv!/dot/norm/axpy!
+// call sites one-for-one (see include/lfpsqp_hip.h); the fused solvers in
+// projcg.hip / retract.hip reuse the same kernels with richer functors.
+#include "internal.h"
+
+namespace lfpsqp {
+
+// ---- GEMV-T producers / GEMV-N consumers ------------------------------------
+struct PlainV {  // v straight from memory
+    const double* v;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double2 a = ld2(v + r);
+        return make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0);
+    }
+};
+
+struct AxpbyEpi {  // y = alpha*acc + beta*y   (beta == 0 never reads y: BLAS semantics)
+    double* y;
+    double alpha, beta;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double*) const {
+        double2 o;
+        if (beta == 0.0) {
+            o = make_double2(alpha * acc.x, alpha * acc.y);
+        } else {
+            const double2 yy = ld2(y + r);
+            o = make_double2(fma(alpha, acc.x, beta * yy.x), fma(alpha, acc.y, beta * yy.y));
+        }
+        if (v1) st2(y + r, o);
+        else if (v0) y[r] = o.x;
+    }
+};
+
+// ---- elementwise functors ------------------------------------------------------
+struct DotF {
+    const double *x, *y;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double2 a = ld2(x + i), b = ld2(y + i);
+        double s = 0.0;
+        if (v0) s = a.x * b.x;
+        if (v1) s = fma(a.y, b.y, s);
+        red[0] += s;
+    }
+};
+struct AmaxF {
+    const double* x;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double2 a = ld2(x + i);
+        if (v0) red[0] = fmax(red[0], fabs(a.x));
+        if (v1) red[0] = fmax(red[0], fabs(a.y));
+    }
+};
+struct WaxpbyF {  // z = a*x + b*y
+    double a, b;
+    const double *x, *y;
+    double* z;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        double2 o;
+        if (b == 0.0) {
+            const double2 xx = ld2(x + i);
+            o = make_double2(a * xx.x, a * xx.y);
+        } else if (a == 0.0) {
+            const double2 yy = ld2(y + i);
+            o = make_double2(b * yy.x, b * yy.y);
+        } else {
+            const double2 xx = ld2(x + i), yy = ld2(y + i);
+            o = make_double2(fma(a, xx.x, b * yy.x), fma(a, xx.y, b * yy.y));
+        }
+        if (v1) st2(z + i, o);
+        else if (v0) z[i] = o.x;
+    }
+};
+struct VmulF {  // y = d .* x
+    const double *d, *x;
+    double* y;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 dd = ld2(d + i), xx = ld2(x + i);
+        const double2 o = make_double2(dd.x * xx.x, dd.y * xx.y);
+        if (v1) st2(y + i, o);
+        else if (v0) y[i] = o.x;
+    }
+};
+struct FillF {
+    double* x;
+    double value;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        if (v1) st2(x + i, make_double2(value, value));
+        else if (v0) x[i] = value;
+    }
+};
+struct HashVecF {  // x[i] = scale*u(seed, offset+i) + shift
+    double* x;
+    uint64_t seed;
+    int64_t offset;
+    double scale, shift;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double a = fma(scale, hash_u(seed, (uint64_t)(offset + i)), shift);
+        const double b = fma(scale, hash_u(seed, (uint64_t)(offset + i + 1)), shift);
+        if (v1) st2(x + i, make_double2(a, b));
+        else if (v0) x[i] = a;
+    }
+};
+
+// M[i, j] = u(seed, j*n_global + row0 + i): one workgroup per (row tile, column)
+__global__ __launch_bounds__(kThreads) void hash_mat_kernel(double* M, int64_t ld, int64_t n, uint64_t seed, int64_t row0,
+                                                             int64_t n_global) {
+    const int64_t j = blockIdx.y;
+    double* col = M + j * ld;
+    const uint64_t base = (uint64_t)j * (uint64_t)n_global + (uint64_t)row0;
+#pragma unroll
+    for (int s = 0; s < kS; ++s) {
+        const int64_t r = (int64_t)blockIdx.x * kTileRows + (int64_t)s * kSlabRows + (int64_t)threadIdx.x * 2;
+        if (r + 1 < n) st2(col + r, make_double2(hash_u(seed, base + (uint64_t)r), hash_u(seed, base + (uint64_t)r + 1)));
+        else if (r < n) col[r] = hash_u(seed, base + (uint64_t)r);
+    }
+}
+
+}  // namespace lfpsqp
+
+using namespace lfpsqp;
+
+extern "C" {
+
+int lfpsqp_vec_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, double value) {
+    LF_ARG(ctx, ctx && v);
+    if (v->n == 0) return 0;
+    return run_vec<FillF, 0, NoPost>(ctx, v->n, FillF{v->p, value}, 0u, nullptr, NoPost());
+}
+
+int lfpsqp_vec_copy(lfpsqp_ctx* ctx, lfpsqp_vec* dst, const lfpsqp_vec* src) {
+    LF_ARG(ctx, ctx && dst && src && dst->n == src->n);
+    if (src->n == 0 || dst->p == src->p) return 0;
+    LF_HIP(ctx, hipMemcpyAsync(dst->p, src->p, sizeof(double) * src->n, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int lfpsqp_vec_hash_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, uint64_t seed, int64_t offset, double scale, double shift) {
+    LF_ARG(ctx, ctx && v);
+    if (v->n == 0) return 0;
+    return run_vec<HashVecF, 0, NoPost>(ctx, v->n, HashVecF{v->p, seed, offset, scale, shift}, 0u, nullptr, NoPost());
+}
+
+int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global) {
+    LF_ARG(ctx, ctx && M && row0 >= 0 && n_global >= M->n);
+    if (M->n == 0 || M->m == 0) return 0;
+    LF_ARG(ctx, M->m <= 65535);
+    hipLaunchKernelGGL(hash_mat_kernel, dim3((unsigned)ntiles_of(M->n), (unsigned)M->m), dim3(kThreads), 0, ctx->stream, M->p, M->ld,
+                       M->n, seed, row0, n_global);
+    LF_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int lfpsqp_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* v, lfpsqp_vec* t) {
+    LF_ARG(ctx, ctx && M && v && t && ncols >= 0 && ncols <= M->m && v->n == M->n && t->n >= ncols);
+    return run_gemv_t(ctx, M, (int)ncols, M->n, PlainV{v->p}, t->p);
+}
+
+int lfpsqp_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, double alpha, const lfpsqp_vec* t, double beta, lfpsqp_vec* y) {
+    LF_ARG(ctx, ctx && M && y && ncols >= 0 && ncols <= M->m && y->n == M->n && (ncols == 0 || (t && t->n >= ncols)));
+    return run_gemv_n<AxpbyEpi, 0, NoPost>(ctx, M, (int)ncols, M->n, t ? t->p : nullptr, AxpbyEpi{y->p, alpha, beta}, nullptr, NoPost());
+}
+
+int lfpsqp_dot(lfpsqp_ctx* ctx, const lfpsqp_vec* x, const lfpsqp_vec* y, double* out) {
+    LF_ARG(ctx, ctx && x && y && out && x->n == y->n);
+    LF_TRY((run_vec<DotF, 1, NoPost>(ctx, x->n, DotF{x->p, y->p}, 0u, ctx->scal + 32, NoPost())));
+    return read_back(ctx, ctx->scal + 32, out, 1);
+}
+
+int lfpsqp_nrm2(lfpsqp_ctx* ctx, const lfpsqp_vec* x, double* out) {
+    LF_ARG(ctx, ctx && x && out);
+    double s = 0.0;
+    LF_TRY(lfpsqp_dot(ctx, x, x, &s));
+    *out = sqrt(s);
+    return 0;
+}
+
+int lfpsqp_amax(lfpsqp_ctx* ctx, const lfpsqp_vec* x, double* out) {
+    LF_ARG(ctx, ctx && x && out);
+    LF_TRY((run_vec<AmaxF, 1, NoPost>(ctx, x->n, AmaxF{x->p}, 1u, ctx->scal + 32, NoPost())));
+    return read_back(ctx, ctx->scal + 32, out, 1);
+}
+
+int lfpsqp_waxpby(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double b, const lfpsqp_vec* y, lfpsqp_vec* z) {
+    LF_ARG(ctx, ctx && x && y && z && x->n == y->n && x->n == z->n);
+    if (z->n == 0) return 0;
+    return run_vec<WaxpbyF, 0, NoPost>(ctx, z->n, WaxpbyF{a, b, x->p, y->p, z->p}, 0u, nullptr, NoPost());
+}
+
+int lfpsqp_axpby(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double b, lfpsqp_vec* y) {
+    return lfpsqp_waxpby(ctx, a, x, b, y, y);
+}
+
+int lfpsqp_vmul(lfpsqp_ctx* ctx, const lfpsqp_vec* d, const lfpsqp_vec* x, lfpsqp_vec* y) {
+    LF_ARG(ctx, ctx && d && x && y && d->n == x->n && x->n == y->n);
+    if (y->n == 0) return 0;
+    return run_vec<VmulF, 0, NoPost>(ctx, y->n, VmulF{d->p, x->p, y->p}, 0u, nullptr, NoPost());
+}
+
+int lfpsqp_allreduce(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t count) {
+    LF_ARG(ctx, ctx && v && count >= 0 && count <= v->n);
+    return allreduce_dev(ctx, v->p, count, 0);
+}
+
+}  // extern "C"

@@ -1,0 +1,292 @@
+// Projected conjugate gradient on the device -- the reference's projcg!
+// (src/projcg.jl:40-121) as three fused streaming kernels per iteration:
+//
+//   K1  d = beta*d - g ; partial d'(A d)                      (vec_kernel)     :99, :74-75
+//   K2  alpha = rg/dAd ; x += alpha d ; rp = g + alpha A d ;
+//       partial U' rp                                          (gemv_t_kernel)  :91-96
+//   K3  gp = rp - U (U' rp) ; g = gp ; partial rp'gp, gp'gp    (gemv_n_kernel)  :97-103
+//
+// r == g throughout the reference loop (:61, :100-101), so r is not stored; gp and
+// Ad are never materialised.  HBM traffic per iteration = two passes over U plus
+// 12 n-vector passes = 16 n m + 96 n bytes, against ~27 unfused vector
+// passes in the reference.  All scalars (alpha, beta, rg, nr), the iteration counter
+// and the exit status live in device memory; every kernel starts with a uniform
+// "already finished?" test, so the host may enqueue one iteration ahead of the
+// status it has seen (no pipeline bubble) and extra launches are no-ops.
+#include <math.h>
+
+#include "internal.h"
+
+namespace lfpsqp {
+
+enum { S_DAD = 0, S_RG = 1, S_ALPHA = 2, S_RPGP = 3, S_GPGP = 4, S_BETA = 5, S_NR = 6, S_TOL = 7, S_DD = 8 };
+enum { I_STATUS = 0, I_ITER = 1, I_MAXIT = 2 };
+enum { ST_RUNNING = 0, ST_CONVERGED = 1, ST_RG_BREAK = 2, ST_NEGCURV = 3, ST_MAXIT = 4 };
+
+struct AOpD {  // A = a0*I + diag(dg)
+    double a0;
+    const double* dg;
+    __device__ __forceinline__ double2 apply(int64_t i, double2 d) const {
+        if (dg) {
+            const double2 q = ld2(dg + i);
+            return make_double2((a0 + q.x) * d.x, (a0 + q.y) * d.y);
+        }
+        return make_double2(a0 * d.x, a0 * d.y);
+    }
+};
+
+// ---- K1 -----------------------------------------------------------------------
+struct PcgDirF {
+    double* d;
+    const double* g;
+    AOpD A;
+    const double* scal;
+    const int64_t* istat;
+    int first;
+    __device__ __forceinline__ bool skip() const { return istat[I_STATUS] != ST_RUNNING; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        double2 dd = ld2(d + i);
+        if (!first) {
+            const double beta = scal[S_BETA];
+            const double2 gg = ld2(g + i);
+            dd = make_double2(beta * dd.x - gg.x, beta * dd.y - gg.y);   // src/projcg.jl:99
+            if (v1) st2(d + i, dd);
+            else if (v0) d[i] = dd.x;
+        }
+        const double2 ad = A.apply(i, dd);                                // :74
+        double s = 0.0;
+        if (v0) s = dd.x * ad.x;
+        if (v1) s = fma(dd.y, ad.y, s);
+        red[0] += s;                                                      // :75
+    }
+};
+struct PcgPost1 {  // after d'Ad is final: iteration count, exits, alpha  (:72-91)
+    double* scal;
+    int64_t* istat;
+    __device__ __forceinline__ bool skip() const { return istat[I_STATUS] != ST_RUNNING; }
+    __device__ __forceinline__ void run(double*) const {
+        istat[I_ITER] += 1;
+        const double dAd = scal[S_DAD], rg = scal[S_RG];
+        if (dAd <= 0.0) istat[I_STATUS] = ST_NEGCURV;
+        else if (rg <= 0.0) istat[I_STATUS] = ST_RG_BREAK;
+        else scal[S_ALPHA] = rg / dAd;
+    }
+};
+
+// ---- K2 (producer of v = rp for U' rp) ------------------------------------------
+struct PcgStepV {
+    double* x;
+    const double* d;
+    const double* g;
+    double* rp;
+    AOpD A;
+    const double* scal;
+    const int64_t* istat;
+    __device__ __forceinline__ bool skip() const { return istat[I_STATUS] != ST_RUNNING; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double alpha = scal[S_ALPHA];
+        const double2 dd = ld2(d + r), gg = ld2(g + r);
+        double2 xx = ld2(x + r);
+        const double2 ad = A.apply(r, dd);
+        xx = make_double2(fma(alpha, dd.x, xx.x), fma(alpha, dd.y, xx.y));      // :92
+        const double2 rr = make_double2(fma(alpha, ad.x, gg.x), fma(alpha, ad.y, gg.y));  // :93
+        if (v1) { st2(x + r, xx); st2(rp + r, rr); }
+        else if (v0) { x[r] = xx.x; rp[r] = rr.x; }
+        return make_double2(v0 ? rr.x : 0.0, v1 ? rr.y : 0.0);
+    }
+};
+
+// ---- K3 (consumer of U*Utr) -------------------------------------------------------
+struct PcgProjE {
+    const double* rp;
+    double* g;
+    double* d;  // written (d = -g) only by the initial projection
+    const int64_t* istat;
+    int init;
+    __device__ __forceinline__ bool skip() const { return istat[I_STATUS] != ST_RUNNING; }
+    __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
+        const double2 rr = ld2(rp + r);
+        const double2 gp = make_double2(rr.x - acc.x, rr.y - acc.y);      // :97 (alpha=-1, beta=1)
+        if (v1) st2(g + r, gp);
+        else if (v0) g[r] = gp.x;
+        if (init) {
+            const double2 nd = make_double2(-gp.x, -gp.y);                // :62
+            if (v1) st2(d + r, nd);
+            else if (v0) d[r] = nd.x;
+        }
+        double s0 = 0.0, s1 = 0.0;
+        if (v0) { s0 = rr.x * gp.x; s1 = gp.x * gp.x; }
+        if (v1) { s0 = fma(rr.y, gp.y, s0); s1 = fma(gp.y, gp.y, s1); }
+        red[0] += s0;                                                     // :98 rp'gp
+        red[1] += s1;                                                     // :84/:103 (r == g): rg, nr^2
+    }
+};
+struct PcgPost3 {  // beta, next rg, nr, convergence / iteration-limit exits (:98-111, :71)
+    double* scal;
+    int64_t* istat;
+    int init;
+    __device__ __forceinline__ bool skip() const { return istat[I_STATUS] != ST_RUNNING; }
+    __device__ __forceinline__ void run(double*) const {
+        const double rpgp = scal[S_RPGP], gpgp = scal[S_GPGP];
+        if (init) {
+            scal[S_RG] = gpgp;
+            if (istat[I_MAXIT] <= 0) istat[I_STATUS] = ST_MAXIT;
+            return;
+        }
+        scal[S_BETA] = rpgp / scal[S_RG];
+        scal[S_RG] = gpgp;
+        const double nr = sqrt(gpgp);
+        scal[S_NR] = nr;
+        if (nr < scal[S_TOL]) istat[I_STATUS] = ST_CONVERGED;
+        else if (istat[I_ITER] >= istat[I_MAXIT]) istat[I_STATUS] = ST_MAXIT;
+    }
+};
+
+// ---- setup / teardown functors --------------------------------------------------
+struct ResidualV {  // v = sgn*(A x - b), optionally stored   (:56-57 with sgn=+1, :115-116 with sgn=-1)
+    const double* x;
+    const double* b;
+    double* out;  // may be null
+    AOpD A;
+    double sgn;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double2 xx = ld2(x + r), bb = ld2(b + r);
+        const double2 ax = A.apply(r, xx);
+        const double2 rr = make_double2(sgn * (ax.x - bb.x), sgn * (ax.y - bb.y));
+        if (out) {
+            if (v1) st2(out + r, rr);
+            else if (v0) out[r] = rr.x;
+        }
+        return make_double2(v0 ? rr.x : 0.0, v1 ? rr.y : 0.0);
+    }
+};
+struct InitState {
+    double* scal;
+    int64_t* istat;
+    double tol;
+    int64_t maxit;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void run(double*) const {
+        for (int k = 0; k < 16; ++k) scal[k] = 0.0;
+        scal[S_TOL] = tol;
+        scal[S_NR] = INFINITY;                    // src/projcg.jl:69
+        istat[I_STATUS] = ST_RUNNING;
+        istat[I_ITER] = 0;
+        istat[I_MAXIT] = maxit;
+    }
+};
+struct SumSqF {
+    const double* x;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double2 a = ld2(x + i);
+        double s = 0.0;
+        if (v0) s = a.x * a.x;
+        if (v1) s = fma(a.y, a.y, s);
+        red[0] += s;
+    }
+};
+struct NormalizeIntoF {  // x = d / sqrt(dd)    (:79)
+    double* x;
+    const double* d;
+    const double* dd;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double nrm = sqrt(*dd);
+        const double2 a = ld2(d + i);
+        const double2 o = make_double2(a.x / nrm, a.y / nrm);
+        if (v1) st2(x + i, o);
+        else if (v0) x[i] = o.x;
+    }
+};
+
+static int snapshot(lfpsqp_ctx* ctx, int slot) {
+    LF_HIP(ctx, hipMemcpyAsync(ctx->h_istat + 16 * slot, ctx->istat, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    LF_HIP(ctx, hipMemcpyAsync(ctx->h_scal + 64 * slot, ctx->scal, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    LF_HIP(ctx, hipEventRecord(ctx->ev_slot[slot], ctx->stream));
+    return 0;
+}
+
+}  // namespace lfpsqp
+
+using namespace lfpsqp;
+
+extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, const lfpsqp_basis* U,
+                             const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit, int64_t n_global, int flags,
+                             const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
+    LF_ARG(ctx, ctx && x && A && U && b && work && iters && nr);
+    LF_ARG(ctx, work->g && work->d && work->rp && work->Utr);
+    if (U->Dx || U->Dy || U->sx || U->sy)
+        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "stacked (bound-constrained) basis: use lfpsqp_projcg_stacked");
+    const int64_t n = b->n;
+    const int m = (int)U->ncols;
+    LF_ARG(ctx, x->n == n && work->g->n == n && work->d->n == n && work->rp->n == n);
+    LF_ARG(ctx, m >= 0 && (m == 0 || (U->Z && U->Z->n == n && m <= U->Z->m && work->Utr->n >= m)));
+    LF_ARG(ctx, !A->dg || A->dg->n == n);
+    LF_ARG(ctx, !c || c->n >= m);
+    LF_ARG(ctx, !(flags & LFPSQP_PROJCG_WANT_LAMBDA) || (lambda && lambda->n >= m));
+    LF_ARG(ctx, n_global >= n);
+
+    const AOpD Ad{A->a0, A->dg ? A->dg->p : nullptr};
+    double* scal = ctx->scal;
+    int64_t* istat = ctx->istat;
+    double* g = work->g->p;
+    double* d = work->d->p;
+    double* rp = work->rp->p;
+    double* Utr = work->Utr->p;
+    const lfpsqp_mat* Z = m > 0 ? U->Z : nullptr;
+    int64_t maxit_eff = maxit < n_global + m ? maxit : n_global + m;   // src/projcg.jl:71
+    if (maxit_eff < 0) maxit_eff = 0;
+
+    hipLaunchKernelGGL((post_kernel<InitState>), dim3(1), dim3(1), 0, ctx->stream, scal, InitState{scal, istat, tol, maxit_eff});
+    LF_LAUNCH_CHECK(ctx);
+
+    // x = U c (:55); c == NULL is the all-zero c of optimize
+    if (c && m > 0) {
+        LF_TRY(lfpsqp_gemv_n(ctx, Z, m, 1.0, c, 0.0, x));
+    } else {
+        LF_TRY(lfpsqp_vec_fill(ctx, x, 0.0));
+    }
+    // r = A x - b (kept in rp), Utr = U' r, g = r - U Utr, d = -g, rg = g'g   (:56-62)
+    LF_TRY(run_gemv_t(ctx, Z, m, n, ResidualV{x->p, b->p, rp, Ad, 1.0}, Utr));
+    LF_TRY((run_gemv_n<PcgProjE, 2, PcgPost3>(ctx, Z, m, n, Utr, PcgProjE{rp, g, d, istat, 1}, scal + S_RPGP,
+                                               PcgPost3{scal, istat, 1})));
+
+    int64_t it = 0;
+    bool done = false;
+    while (!done && it < maxit_eff) {
+        LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, n, PcgDirF{d, g, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
+                                              PcgPost1{scal, istat}, 0)));
+        LF_TRY(run_gemv_t(ctx, Z, m, n, PcgStepV{x->p, d, g, rp, Ad, scal, istat}, Utr, 1));
+        LF_TRY((run_gemv_n<PcgProjE, 2, PcgPost3>(ctx, Z, m, n, Utr, PcgProjE{rp, g, d, istat, 0}, scal + S_RPGP,
+                                                   PcgPost3{scal, istat, 0}, 2)));
+        LF_TRY(snapshot(ctx, (int)(it & 1)));
+        if (it >= 1) {  // look at the status of the PREVIOUS iteration: the GPU is never left idle
+            const int slot = (int)((it - 1) & 1);
+            LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[slot]));
+            if (ctx->h_istat[16 * slot + I_STATUS] != ST_RUNNING) done = true;
+        }
+        ++it;
+    }
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LF_TRY(snapshot(ctx, 2));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t status = ctx->h_istat[16 * 2 + I_STATUS];
+    *iters = ctx->h_istat[16 * 2 + I_ITER];
+    *nr = ctx->h_scal[64 * 2 + S_NR];
+
+    if (status == ST_NEGCURV) {   // :77-82
+        LF_TRY((run_vec<SumSqF, 1, NoPost>(ctx, n, SumSqF{d}, 0u, scal + S_DD, NoPost())));
+        LF_TRY((run_vec<NormalizeIntoF, 0, NoPost>(ctx, n, NormalizeIntoF{x->p, d, scal + S_DD}, 0u, nullptr, NoPost())));
+        if (lambda) LF_TRY(lfpsqp_vec_fill(ctx, lambda, NAN));
+        *nr = INFINITY;
+    } else if ((flags & LFPSQP_PROJCG_WANT_LAMBDA) && m > 0) {   // :115-118
+        LF_TRY(run_gemv_t(ctx, Z, m, n, ResidualV{x->p, b->p, nullptr, Ad, -1.0}, lambda->p));
+    }
+    if (ctx->profiling) {
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        prof_collect(ctx);
+    }
+    return 0;
+}

@@ -1,0 +1,234 @@
+"""Device context and buffers (thin object layer over the C ABI)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import LfpsqpError, P, c_i64
+
+
+class Context:
+    """One GPU, one HIP stream, one communicator (lfpsqp_ctx)."""
+
+    def __init__(self, device: int = 0, lib: _capi.Library | None = None):
+        self.L = lib or _capi.load_library()
+        h = P()
+        rc = self.L.lfpsqp_ctx_create(device, C.byref(h))
+        if rc != 0 or not h:
+            raise LfpsqpError(f"lfpsqp_ctx_create(device={device}) failed (status {rc}): no usable MI355X/HIP device; "
+                              "the product path has no CPU fallback")
+        self.h = h
+        self.rank, self.nranks = 0, 1
+        self._cb_keep = None
+
+    # -- plumbing
+    def check(self, rc: int):
+        if rc != 0:
+            raise LfpsqpError(f"status {rc}: {self.L.lfpsqp_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lfpsqp_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self.check(self.L.lfpsqp_ctx_sync(self.h))
+
+    @property
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self.check(self.L.lfpsqp_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def timer_begin(self):
+        self.check(self.L.lfpsqp_timer_begin(self.h))
+
+    def timer_end(self) -> float:
+        ms = C.c_double()
+        self.check(self.L.lfpsqp_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on: bool):
+        self.check(self.L.lfpsqp_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * 8)()
+        cnt = (c_i64 * 8)()
+        self.check(self.L.lfpsqp_profile_read(self.h, ms, cnt))
+        return list(ms), list(cnt)
+
+    # -- sharding / communicator
+    def shard_range(self, n: int, rank: int | None = None, nranks: int | None = None):
+        r0, r1 = c_i64(), c_i64()
+        rc = self.L.lfpsqp_shard_range(n, self.rank if rank is None else rank,
+                                       self.nranks if nranks is None else nranks, C.byref(r0), C.byref(r1))
+        if rc != 0:
+            raise LfpsqpError("lfpsqp_shard_range: bad arguments")
+        return r0.value, r1.value
+
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self.check(self.L.lfpsqp_comm_unique_id(self.h, buf))
+        return buf.raw
+
+    def comm_init_rccl(self, rank: int, nranks: int, uid: bytes):
+        buf = C.create_string_buffer(uid, 128)
+        self.check(self.L.lfpsqp_comm_init_rccl(self.h, rank, nranks, buf))
+        self.rank, self.nranks = rank, nranks
+
+    def comm_init_callback(self, rank: int, nranks: int, fn):
+        """fn(ptr:int, count:int, op:int, stream:int) -> int; all-reduce `count` doubles at device pointer `ptr`."""
+        def tramp(user, buf, count, op, stream):
+            try:
+                return int(fn(buf, count, op, stream) or 0)
+            except Exception as e:  # never unwind through C
+                print("all-reduce callback failed:", e)
+                return 1
+        cb = _capi.ALLREDUCE_FN(tramp)
+        self._cb_keep = cb
+        self.check(self.L.lfpsqp_comm_init_callback(self.h, rank, nranks, cb, None))
+        self.rank, self.nranks = rank, nranks
+
+    # -- buffers
+    def vector(self, n: int, data=None) -> "DeviceVector":
+        v = DeviceVector(self, n)
+        if data is not None:
+            v.upload(data)
+        return v
+
+    def matrix(self, n: int, m: int, data=None) -> "DeviceMatrix":
+        M = DeviceMatrix(self, n, m)
+        if data is not None:
+            M.upload(data)
+        return M
+
+
+class DeviceVector:
+    def __init__(self, ctx: Context, n: int):
+        self.ctx, self.n = ctx, int(n)
+        h = P()
+        ctx.check(ctx.L.lfpsqp_vec_alloc(ctx.h, self.n, C.byref(h)))
+        self.h = h
+
+    def __len__(self):
+        return self.n
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.lfpsqp_vec_free(self.ctx.h, self.h)
+        self.h = None
+
+    def upload(self, data, offset: int = 0):
+        a = np.ascontiguousarray(data, dtype=np.float64)
+        self.ctx.check(self.ctx.L.lfpsqp_vec_upload(self.ctx.h, self.h, offset, a.ctypes.data, a.size))
+        return self
+
+    def download(self, count: int | None = None, offset: int = 0) -> np.ndarray:
+        count = self.n - offset if count is None else count
+        out = np.empty(count, dtype=np.float64)
+        self.ctx.check(self.ctx.L.lfpsqp_vec_download(self.ctx.h, self.h, offset, out.ctypes.data, count))
+        return out
+
+    def fill(self, value: float):
+        self.ctx.check(self.ctx.L.lfpsqp_vec_fill(self.ctx.h, self.h, float(value)))
+        return self
+
+    def copy_from(self, src: "DeviceVector"):
+        self.ctx.check(self.ctx.L.lfpsqp_vec_copy(self.ctx.h, self.h, src.h))
+        return self
+
+    def hash_fill(self, seed: int, offset: int = 0, scale: float = 1.0, shift: float = 0.0):
+        self.ctx.check(self.ctx.L.lfpsqp_vec_hash_fill(self.ctx.h, self.h, seed, offset, scale, shift))
+        return self
+
+
+class DeviceMatrix:
+    """Column-major n_loc x m matrix, every column contiguous (SURVEY §7 layout)."""
+
+    def __init__(self, ctx: Context, n: int, m: int):
+        self.ctx, self.n, self.m = ctx, int(n), int(m)
+        h = P()
+        ctx.check(ctx.L.lfpsqp_mat_alloc(ctx.h, self.n, self.m, C.byref(h)))
+        self.h = h
+
+    @property
+    def shape(self):
+        return (self.n, self.m)
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.lfpsqp_mat_free(self.ctx.h, self.h)
+        self.h = None
+
+    def upload(self, data, col0: int = 0):
+        a = np.asfortranarray(data, dtype=np.float64)
+        if a.ndim != 2 or a.shape[0] != self.n:
+            raise ValueError("matrix upload: shape mismatch")
+        self.ctx.check(self.ctx.L.lfpsqp_mat_upload(self.ctx.h, self.h, col0, a.shape[1], a.ctypes.data, max(a.shape[0], 1)))
+        return self
+
+    def download(self, col0: int = 0, ncols: int | None = None) -> np.ndarray:
+        ncols = self.m - col0 if ncols is None else ncols
+        out = np.empty((self.n, ncols), dtype=np.float64, order='F')
+        self.ctx.check(self.ctx.L.lfpsqp_mat_download(self.ctx.h, self.h, col0, ncols, out.ctypes.data, max(self.n, 1)))
+        return out
+
+    def copy_from(self, src: "DeviceMatrix"):
+        self.ctx.check(self.ctx.L.lfpsqp_mat_copy(self.ctx.h, self.h, src.h))
+        return self
+
+    def hash_fill(self, seed: int, row0: int = 0, n_global: int | None = None):
+        self.ctx.check(self.ctx.L.lfpsqp_mat_hash_fill(self.ctx.h, self.h, seed, row0, self.n if n_global is None else n_global))
+        return self
+
+
+# ---- BLAS-1/2 primitives (mirror of the reference's mul!/dot/norm/axpy! call sites) -------
+
+def gemv_t(M: DeviceMatrix, v: DeviceVector, t: DeviceVector, ncols: int | None = None):
+    """t[:ncols] = M[:, :ncols]' v  (kgemv!('T', rank, ...), src/la_helper.jl:36-44)."""
+    c = M.ctx
+    c.check(c.L.lfpsqp_gemv_t(c.h, M.h, M.m if ncols is None else ncols, v.h, t.h))
+    return t
+
+
+def gemv_n(M: DeviceMatrix, t: DeviceVector, y: DeviceVector, alpha=1.0, beta=0.0, ncols: int | None = None):
+    """y = alpha M[:, :ncols] t + beta y  (kgemv!('N', ...) / mul!(y, U, t, alpha, beta))."""
+    c = M.ctx
+    c.check(c.L.lfpsqp_gemv_n(c.h, M.h, M.m if ncols is None else ncols, float(alpha), t.h, float(beta), y.h))
+    return y
+
+
+def dot(x: DeviceVector, y: DeviceVector) -> float:
+    out = C.c_double()
+    x.ctx.check(x.ctx.L.lfpsqp_dot(x.ctx.h, x.h, y.h, C.byref(out)))
+    return out.value
+
+
+def nrm2(x: DeviceVector) -> float:
+    out = C.c_double()
+    x.ctx.check(x.ctx.L.lfpsqp_nrm2(x.ctx.h, x.h, C.byref(out)))
+    return out.value
+
+
+def amax(x: DeviceVector) -> float:
+    out = C.c_double()
+    x.ctx.check(x.ctx.L.lfpsqp_amax(x.ctx.h, x.h, C.byref(out)))
+    return out.value
+
+
+def axpby(a: float, x: DeviceVector, b: float, y: DeviceVector):
+    """y = a x + b y."""
+    x.ctx.check(x.ctx.L.lfpsqp_axpby(x.ctx.h, float(a), x.h, float(b), y.h))
+    return y
+
+
+def waxpby(a: float, x: DeviceVector, b: float, y: DeviceVector, z: DeviceVector):
+    x.ctx.check(x.ctx.L.lfpsqp_waxpby(x.ctx.h, float(a), x.h, float(b), y.h, z.h))
+    return z
+
+
+def vmul(d: DeviceVector, x: DeviceVector, y: DeviceVector):
+    x.ctx.check(x.ctx.L.lfpsqp_vmul(x.ctx.h, d.h, x.h, y.h))
+    return y

@@ -1,0 +1,168 @@
+"""projcg! (reference src/projcg.jl) on the device.
+
+``projcg_(x, lam, A, U, b, c, tol=, maxit=, work=)`` keeps the reference's signature and
+return value ``(i, nr)`` and, like Julia's method dispatch, picks an implementation
+from the operator types:
+
+  * ``A`` a :class:`DiagOperator` and ``U`` a :class:`DeviceBasis`  -> one C call
+    (``lfpsqp_projcg``): the fused three-kernel iteration, scalars on the device;
+  * anything else supporting the ``mul_`` protocol -> the generic loop below, the
+    reference's statement order on device vectors with the BLAS-1/2 primitives
+    (what a Julia host gets by defining ``mul!`` on device arrays).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+from . import _capi
+from .device import (Context, DeviceMatrix, DeviceVector, axpby, dot, gemv_n, gemv_t, nrm2, vmul, waxpby)
+
+WANT_LAMBDA = 1
+
+
+class DiagOperator:
+    """A = a0*I + diag(dg): device-resident Lagrangian-Hessian action (lfpsqp_diag_op)."""
+
+    def __init__(self, a0: float = 0.0, dg: DeviceVector | None = None):
+        self.a0, self.dg = float(a0), dg
+
+    def _c(self):
+        return _capi.DiagOp(self.a0, self.dg.h if self.dg is not None else None)
+
+    # mul! protocol (generic path / tests)
+    def mul_(self, dest: DeviceVector, v: DeviceVector, a=None, b=None):
+        if a is None:
+            a, b = 1.0, 0.0
+        if self.dg is None:
+            return waxpby(a * self.a0, v, b, dest, dest)
+        tmp = DeviceVector(dest.ctx, dest.n)
+        vmul(self.dg, v, tmp)
+        axpby(self.a0, v, 1.0, tmp)
+        waxpby(a, tmp, b, dest, dest)
+        tmp.free()
+        return dest
+
+    def adjoint(self):
+        return self
+
+
+class DeviceBasis:
+    """Orthonormal U = Z[:, :ncols] (``view(U, :, 1:rank)``, src/optimize.jl:370)."""
+
+    def __init__(self, Z: DeviceMatrix, ncols: int | None = None):
+        self.Z = Z
+        self.ncols = Z.m if ncols is None else int(ncols)
+
+    def _c(self):
+        return _capi.Basis(self.Z.h, self.ncols, None, None, None, None)
+
+    def mul_(self, dest, v, a=None, b=None):
+        if a is None:
+            a, b = 1.0, 0.0
+        return gemv_n(self.Z, v, dest, a, b, self.ncols)
+
+    def adjoint(self):
+        return _BasisAdjoint(self)
+
+
+class _BasisAdjoint:
+    def __init__(self, basis):
+        self.basis = basis
+
+    def mul_(self, dest, v, a=None, b=None):
+        assert a is None
+        return gemv_t(self.basis.Z, v, dest, self.basis.ncols)
+
+    def adjoint(self):
+        return self.basis
+
+
+class ProjCGWork:
+    """ProjCGWork(n, m) (src/projcg.jl:1-11); only g, d, rp, Utr exist on the device."""
+
+    def __init__(self, ctx: Context, n: int, m: int):
+        self.g, self.d, self.rp = (DeviceVector(ctx, n) for _ in range(3))
+        self.Utr = DeviceVector(ctx, max(m, 1))
+        # extra scratch for the generic (unfused) path, allocated on demand
+        self._extra = None
+
+    def _c(self):
+        return _capi.ProjCGWorkC(self.g.h, self.d.h, self.rp.h, self.Utr.h)
+
+
+def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c: DeviceVector | None,
+            tol: float = 1e-6, maxit: int | None = None, work: ProjCGWork | None = None, n_global: int | None = None,
+            want_lambda: bool = True):
+    ctx = x.ctx
+    n = b.n
+    m = U.ncols if hasattr(U, "ncols") else (c.n if c is not None else 0)
+    if n_global is None:
+        n_global = n
+    if maxit is None:
+        maxit = n_global + m
+    if work is None:
+        work = ProjCGWork(ctx, n, m)
+    if isinstance(A, DiagOperator) and isinstance(U, DeviceBasis):
+        iters = _capi.c_i64()
+        nr = C.c_double()
+        a_c, u_c, w_c = A._c(), U._c(), work._c()
+        flags = WANT_LAMBDA if (want_lambda and lam is not None) else 0
+        ctx.check(ctx.L.lfpsqp_projcg(ctx.h, x.h, lam.h if lam is not None else None, C.byref(a_c), C.byref(u_c), b.h,
+                                      c.h if c is not None else None, float(tol), int(maxit), int(n_global), flags,
+                                      C.byref(w_c), C.byref(iters), C.byref(nr)))
+        return iters.value, nr.value
+    return _projcg_generic(x, lam, A, U, b, c, tol, maxit, work, n_global, m)
+
+
+def _projcg_generic(x, lam, A, U, b, c, tol, maxit, work, n_global, m):
+    """src/projcg.jl:55-120 statement by statement on device vectors."""
+    ctx = x.ctx
+    n = b.n
+    if work._extra is None:
+        work._extra = (DeviceVector(ctx, n), DeviceVector(ctx, n))
+    Ad, r = work._extra
+    g, d, rp, Utr = work.g, work.d, work.rp, work.Utr
+    Ut = U.adjoint()
+    if c is not None:
+        U.mul_(x, c)
+    else:
+        x.fill(0.0)
+    r.copy_from(b)
+    A.mul_(r, x, 1.0, -1.0)
+    g.copy_from(r)
+    Ut.mul_(Utr, r)
+    U.mul_(g, Utr, -1.0, 1.0)
+    r.copy_from(g)
+    waxpby(-1.0, g, 0.0, g, d)
+    i = 0
+    nr = math.inf
+    while i < min(maxit, n_global + m):
+        i += 1
+        A.mul_(Ad, d)
+        dAd = dot(d, Ad)
+        if dAd <= 0:
+            waxpby(1.0 / nrm2(d), d, 0.0, d, x)
+            if lam is not None:
+                lam.fill(math.nan)
+            return i, math.inf
+        rg = dot(r, g)
+        if rg <= 0:
+            break
+        alpha = rg / dAd
+        axpby(alpha, d, 1.0, x)
+        waxpby(1.0, r, alpha, Ad, rp)
+        g.copy_from(rp)                      # gp lives in g
+        Ut.mul_(Utr, rp)
+        U.mul_(g, Utr, -1.0, 1.0)
+        beta = dot(rp, g) / rg
+        waxpby(beta, d, -1.0, g, d)
+        r.copy_from(g)
+        nr = nrm2(g)
+        if nr < tol:
+            break
+    r.copy_from(b)
+    A.mul_(r, x, -1.0, 1.0)
+    if lam is not None:
+        Ut.mul_(lam, r)
+    return i, nr

@@ -1,4 +1,5 @@
 import os
+import subprocess
 import sys
 
 import pytest
@@ -7,6 +8,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "liblfpsqp_emu.so")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """The product's C-ABI sources compiled against the CPU HIP emulator (tests/emu) --
+    test infrastructure only; the product never loads it."""
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "tests", "emu")])
+    import lfpsqp_jl_amd as L
+    return L.load_library(EMU_LIB)
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    import lfpsqp_jl_amd as L
+    return L.load_library()   # raises loudly if the HIP extension is not built
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def dev_ctx(request):
+    import lfpsqp_jl_amd as L
+    if request.param == "emu":
+        lib = request.getfixturevalue("emu_lib")
+    else:
+        lib = request.getfixturevalue("gpu_lib")
+    ctx = L.Context(0, lib)
+    if request.param == "gpu":
+        assert "emulator" not in ctx.device_name
+    yield ctx
+    ctx.close()

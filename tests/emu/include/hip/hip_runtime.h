@@ -1,0 +1,229 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny CPU emulation of the slice of the HIP
+// runtime + device language that lfpsqp.jl_amd/csrc uses, so the *same* kernel
+// and host sources can be compiled with g++ and exercised (logic, indexing,
+// reduction order, host orchestration, sharding) in the GPU-less build
+// container and under CPU sanitizers.  It is reached only by putting
+// tests/emu/include in front of the include path (tests/emu/Makefile); the
+// product build (hipcc, __graft_entry__.build) never sees it, and the product
+// Python package refuses to run without the real HIP library.
+//
+// Model: one ucontext fiber per GPU thread, a block's fibers are scheduled
+// round-robin on one OS thread, __syncthreads()/wave shuffles are cooperative
+// yields; blocks are distributed over a small pool of OS threads.  Wave = 64.
+#pragma once
+#include <ucontext.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define LFPSQP_HIP_EMULATED 1
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
+typedef struct emuStream_st* hipStream_t;
+struct emuEvent_st { std::chrono::steady_clock::time_point t; };
+typedef emuEvent_st* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipHostMallocDefault = 0, hipEventDisableTiming = 2, hipStreamNonBlocking = 1 };
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct double2 { double x, y; };
+static inline double2 make_double2(double a, double b) { return double2{a, b}; }
+
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };
+
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated HIP error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    std::memset(p, 0, sizeof(*p)); std::strcpy(p->name, "cpu-emulator"); std::strcpy(p->gcnArchName, "emu");
+    p->multiProcessorCount = 4; p->totalGlobalMem = size_t(8) << 30; return hipSuccess;
+}
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
+static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
+    for (size_t r = 0; r < h; ++r) std::memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+    return hipSuccess;
+}
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent_st(); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess;
+}
+
+// ------------------------------------------------------------------ device side
+namespace hipemu {
+struct Idx { unsigned x, y, z; };
+struct BlockState {
+    unsigned nthreads = 0, live = 0, arrived = 0, gen = 0;
+    unsigned w_arrived[16] = {0}, w_gen[16] = {0}, w_live[16] = {0};
+    double scratch[1024];
+    ucontext_t main_ctx;
+    std::vector<ucontext_t> fibers;
+    std::vector<char*> stacks;
+    std::vector<char> done;
+    unsigned cur = 0;
+    const std::function<void()>* body = nullptr;
+};
+inline thread_local BlockState* g_blk = nullptr;
+inline thread_local Idx g_tid{0, 0, 0}, g_bid{0, 0, 0}, g_bdim{1, 1, 1}, g_gdim{1, 1, 1};
+constexpr size_t kStack = 256 * 1024;
+
+inline void yield_() { BlockState* b = g_blk; swapcontext(&b->fibers[b->cur], &b->main_ctx); }
+
+inline void syncthreads() {
+    BlockState* b = g_blk;
+    unsigned my = b->gen;
+    if (++b->arrived >= b->live) { b->arrived = 0; b->gen++; return; }
+    while (b->gen == my) yield_();
+}
+inline void wave_sync() {
+    BlockState* b = g_blk;
+    unsigned w = g_tid.x >> 6;
+    unsigned my = b->w_gen[w];
+    if (++b->w_arrived[w] >= b->w_live[w]) { b->w_arrived[w] = 0; b->w_gen[w]++; return; }
+    while (b->w_gen[w] == my) yield_();
+}
+inline void trampoline() {
+    BlockState* b = g_blk;
+    (*b->body)();
+    unsigned t = b->cur;
+    b->done[t] = 1;
+    b->live--;
+    b->w_live[t >> 6]--;
+    // a thread that exits releases barriers the remaining threads are waiting on
+    if (b->live > 0 && b->arrived >= b->live) { b->arrived = 0; b->gen++; }
+    unsigned w = t >> 6;
+    if (b->w_live[w] > 0 && b->w_arrived[w] >= b->w_live[w]) { b->w_arrived[w] = 0; b->w_gen[w]++; }
+    swapcontext(&b->fibers[t], &b->main_ctx);
+}
+inline void run_block(BlockState& b, unsigned nthreads, const std::function<void()>& body) {
+    if (b.fibers.size() < nthreads) {
+        size_t old = b.fibers.size();
+        b.fibers.resize(nthreads);
+        b.stacks.resize(nthreads, nullptr);
+        for (size_t i = old; i < nthreads; ++i) b.stacks[i] = (char*)std::malloc(kStack);
+    }
+    b.done.assign(nthreads, 0);
+    b.nthreads = b.live = nthreads;
+    b.arrived = 0;
+    for (unsigned w = 0; w < 16; ++w) {
+        b.w_arrived[w] = 0;
+        unsigned lo = w * 64;
+        b.w_live[w] = nthreads > lo ? (nthreads - lo > 64 ? 64 : nthreads - lo) : 0;
+    }
+    b.body = &body;
+    g_blk = &b;
+    for (unsigned t = 0; t < nthreads; ++t) {
+        getcontext(&b.fibers[t]);
+        b.fibers[t].uc_stack.ss_sp = b.stacks[t];
+        b.fibers[t].uc_stack.ss_size = kStack;
+        b.fibers[t].uc_link = &b.main_ctx;
+        makecontext(&b.fibers[t], (void (*)())trampoline, 0);
+    }
+    while (b.live > 0) {
+        for (unsigned t = 0; t < nthreads; ++t) {
+            if (b.done[t]) continue;
+            b.cur = t;
+            g_tid = Idx{t % g_bdim.x, (t / g_bdim.x) % g_bdim.y, t / (g_bdim.x * g_bdim.y)};
+            swapcontext(&b.main_ctx, &b.fibers[t]);
+        }
+    }
+}
+inline int num_workers() {
+    const char* e = std::getenv("HIPEMU_THREADS");
+    int n = e ? std::atoi(e) : 4;
+    return n < 1 ? 1 : n;
+}
+template <class K, class... Args>
+void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+    unsigned nblocks = grid.x * grid.y * grid.z;
+    unsigned nthreads = block.x * block.y * block.z;
+    if (nblocks == 0 || nthreads == 0) return;
+    std::function<void()> body = [=]() { kernel(args...); };
+    std::atomic<unsigned> next{0};
+    auto worker = [&]() {
+        static thread_local BlockState bs;
+        g_bdim = Idx{block.x, block.y, block.z};
+        g_gdim = Idx{grid.x, grid.y, grid.z};
+        for (;;) {
+            unsigned bidx = next.fetch_add(1);
+            if (bidx >= nblocks) break;
+            g_bid = Idx{bidx % grid.x, (bidx / grid.x) % grid.y, bidx / (grid.x * grid.y)};
+            run_block(bs, nthreads, body);
+        }
+    };
+    int nw = num_workers();
+    if ((unsigned)nw > nblocks) nw = (int)nblocks;
+    if (nw <= 1) { worker(); return; }
+    std::vector<std::thread> th;
+    for (int i = 1; i < nw; ++i) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+}
+template <class T> inline T shfl_generic(T v, unsigned src_lane_in_wave) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    BlockState* b = g_blk;
+    unsigned t = g_tid.x;  // 1-D blocks only
+    std::memcpy(&b->scratch[t], &v, sizeof(T));
+    wave_sync();
+    T r;
+    std::memcpy(&r, &b->scratch[(t & ~63u) | (src_lane_in_wave & 63u)], sizeof(T));
+    wave_sync();
+    return r;
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g_tid)
+#define blockIdx (hipemu::g_bid)
+#define blockDim (hipemu::g_bdim)
+#define gridDim (hipemu::g_gdim)
+#define warpSize 64
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch(kernel, dim3(grid), dim3(block), ##__VA_ARGS__)
+
+static inline void __syncthreads() { hipemu::syncthreads(); }
+template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return hipemu::shfl_generic(v, (threadIdx.x & 63) ^ (unsigned)mask); }
+template <class T> static inline T __shfl_down(T v, unsigned d, int = 64) { unsigned l = threadIdx.x & 63; return hipemu::shfl_generic(v, l + d < 64 ? l + d : l); }
+template <class T> static inline T __shfl(T v, int src, int = 64) { return hipemu::shfl_generic(v, (unsigned)src); }
+static inline double __builtin_nontemporal_load(const double* p) { return *p; }
+static inline void __builtin_nontemporal_store(double v, double* p) { *p = v; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }

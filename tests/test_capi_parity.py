@@ -1,0 +1,190 @@
+"""Parity of the C-ABI library against the oracle.
+
+Every case runs twice: on the CPU HIP emulator build of the SAME sources
+(tests/emu, `-m "not gpu"`: host logic, indexing, reduction order, exit semantics) and
+on the real MI355X library (`-m gpu`, the parity tests proper).  Tolerances: fp64
+reductions in a different order than OpenBLAS => a few ulp on each primitive, 1e-10
+relative on iterates (BASELINE.json north_star), iteration counts equal."""
+import math
+
+import numpy as np
+import pytest
+
+import lfpsqp_jl_amd as L
+from oracle import lfpsqp_ref as R
+from oracle import port, synth
+
+from .helpers import DiagOpRef
+
+
+def test_primitives(dev_ctx):
+    ctx = dev_ctx
+    rng = np.random.default_rng(0)
+    for n, m in ((1, 1), (1023, 3), (1024, 4), (1025, 5), (5000, 37), (2049, 130)):
+        Mh = np.asfortranarray(rng.standard_normal((n, m)))
+        vh = rng.standard_normal(n)
+        th = rng.standard_normal(m)
+        M, v, t = ctx.matrix(n, m, Mh), ctx.vector(n, vh), ctx.vector(m, th)
+        out = ctx.vector(m)
+        L.gemv_t(M, v, out)
+        np.testing.assert_allclose(out.download(), Mh.T @ vh, rtol=0, atol=1e-13 * np.sqrt(n) * 10)
+        np.testing.assert_array_equal(M.download(), Mh)
+        y = ctx.vector(n, vh)
+        L.gemv_n(M, t, y, 2.0, 3.0)
+        np.testing.assert_allclose(y.download(), 2 * (Mh @ th) + 3 * vh, atol=1e-13 * m)
+        L.gemv_n(M, t, y, 1.0, 0.0)
+        np.testing.assert_allclose(y.download(), Mh @ th, atol=1e-13 * m)
+        # leading-`rank` columns only (kgemv!, src/la_helper.jl:36-44)
+        r = max(m - 2, 0)
+        out.fill(7.0)
+        L.gemv_t(M, v, out, ncols=r)
+        got = out.download()
+        np.testing.assert_allclose(got[:r], Mh[:, :r].T @ vh, atol=1e-12 * np.sqrt(n))
+        assert np.all(got[r:] == 7.0)
+        assert L.dot(v, v) == pytest.approx(vh @ vh, rel=1e-14)
+        assert L.nrm2(v) == pytest.approx(np.linalg.norm(vh), rel=1e-14)
+        assert L.amax(v) == np.abs(vh).max()
+        w = ctx.vector(n, rng.standard_normal(n))
+        wh = w.download()
+        L.axpby(0.5, v, -2.0, w)
+        np.testing.assert_allclose(w.download(), 0.5 * vh - 2 * wh, atol=1e-15 * 8)
+        L.vmul(v, w, w)
+        np.testing.assert_allclose(w.download(), vh * (0.5 * vh - 2 * wh), rtol=1e-15, atol=1e-300)
+        for obj in (M, v, t, out, y, w):
+            obj.free()
+
+
+def test_empty_and_ragged(dev_ctx):
+    ctx = dev_ctx
+    v = ctx.vector(0)
+    assert L.dot(v, v) == 0.0 and L.amax(v) == 0.0
+    M = ctx.matrix(5, 0)
+    y = ctx.vector(5, np.arange(5.0))
+    L.gemv_n(M, ctx.vector(1), y, 1.0, 2.0, ncols=0)      # n x 0 operator: y = beta*y
+    np.testing.assert_array_equal(y.download(), 2 * np.arange(5.0))
+
+
+def test_hash_generators_bit_exact(dev_ctx):
+    ctx = dev_ctx
+    n, m = 3001, 7
+    np.testing.assert_array_equal(ctx.matrix(n, m).hash_fill(1).download(), synth.hash_matrix(1, n, m))
+    # sharded generation: rows 1024.. of a taller matrix
+    np.testing.assert_array_equal(ctx.matrix(n - 1024, m).hash_fill(1, 1024, n).download(), synth.hash_matrix(1, n, m)[1024:])
+    np.testing.assert_array_equal(ctx.vector(n).hash_fill(3, 5, 4.0, 5.0).download(), 4.0 * synth.hash_vector(3, n, 5) + 5.0)
+    np.testing.assert_array_equal(port.hash_matrix(1, n, m), synth.hash_matrix(1, n, m))
+
+
+def _cg_problem(n, m, seed=0):
+    Uh, _ = np.linalg.qr(synth.hash_matrix(1 + seed, n, m)) if m > 0 else (np.zeros((n, 0)), None)
+    a = 4.0 * synth.hash_vector(3 + seed, n) + 5.0       # A = diag(a), a in [1, 9)
+    b = synth.hash_vector(4 + seed, n)
+    return np.asfortranarray(Uh), a, b
+
+
+@pytest.mark.parametrize("n,m", [(1000, 10), (3000, 1), (2500, 33), (1024, 0)])
+def test_projcg_matches_oracle(dev_ctx, n, m):
+    """test_cg.jl:21-30 on the device + trajectory parity with the oracle."""
+    ctx = dev_ctx
+    Uh, a, bh = _cg_problem(n, m)
+    rng = np.random.default_rng(3)
+    U = L.DeviceBasis(ctx.matrix(n, m, Uh))
+    A = L.DiagOperator(0.0, ctx.vector(n, a))
+    b = ctx.vector(n, bh)
+    work = L.ProjCGWork(ctx, n, m)
+    for ch in (None, rng.standard_normal(m)):
+        for tol in (1e-6, 1e-10, 1e-14):
+            x0, l0 = np.zeros(n), np.zeros(m)
+            i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), Uh, bh, np.zeros(m) if ch is None else ch, tol=tol)
+            x, lam = ctx.vector(n), ctx.vector(max(m, 1))
+            c = None if ch is None else ctx.vector(max(m, 1), ch if m else np.zeros(1))
+            i1, nr1 = L.projcg_(x, lam, A, U, b, c, tol=tol, work=work)
+            xd, ld = x.download(), lam.download()[:m]
+            assert i1 == i0
+            assert nr1 < tol and nr1 == pytest.approx(nr0, rel=1e-6)
+            assert np.linalg.norm(xd - x0) <= 1e-10 * np.linalg.norm(x0)
+            if m:
+                assert np.abs(ld - l0).max() < 1e-11
+                cc = np.zeros(m) if ch is None else ch
+                assert np.linalg.norm(Uh.T @ xd - cc) < 1e-13          # test_cg.jl:27
+                K = np.concatenate([a * xd + Uh @ ld - bh, Uh.T @ xd - cc])
+                assert np.linalg.norm(K) < max(tol, 1e-12)               # test_cg.jl:28
+
+
+def test_projcg_negative_curvature(dev_ctx):
+    """test_cg.jl:39-55: indefinite A => (i, Inf), lambda = NaN, x a unit direction with x'Ax <= 0."""
+    ctx = dev_ctx
+    n, m = 2000, 10
+    Uh, a, bh = _cg_problem(n, m)
+    a = a.copy()
+    a[::3] *= -1.0
+    x0, l0 = np.zeros(n), np.zeros(m)
+    i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), Uh, bh, np.zeros(m), tol=1e-20)
+    x, lam = ctx.vector(n), ctx.vector(m)
+    i1, nr1 = L.projcg_(x, lam, L.DiagOperator(0.0, ctx.vector(n, a)), L.DeviceBasis(ctx.matrix(n, m, Uh)), ctx.vector(n, bh), None,
+                        tol=1e-20)
+    xd = x.download()
+    assert math.isinf(nr1) and math.isinf(nr0) and i1 == i0
+    assert np.all(np.isnan(lam.download()))
+    assert np.linalg.norm(Uh.T @ xd) < 1e-13
+    assert xd @ (a * xd) <= 0.0
+    assert np.linalg.norm(xd - x0) < 1e-10
+
+
+def test_projcg_iteration_limit_and_identity_operator(dev_ctx):
+    """maxit semantics (src/projcg.jl:71) and the a0*I operator (hess_lag_vec! = 2v of configs 2-5)."""
+    ctx = dev_ctx
+    n, m = 1500, 6
+    Uh, a, bh = _cg_problem(n, m)
+    U = L.DeviceBasis(ctx.matrix(n, m, Uh))
+    b = ctx.vector(n, bh)
+    x, lam = ctx.vector(n), ctx.vector(m)
+    for maxit in (0, 1, 3):
+        x0, l0 = np.zeros(n), np.zeros(m)
+        i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), Uh, bh, np.zeros(m), tol=1e-300, maxit=maxit)
+        i1, nr1 = L.projcg_(x, lam, L.DiagOperator(0.0, ctx.vector(n, a)), U, b, None, tol=1e-300, maxit=maxit)
+        assert i1 == i0 == maxit
+        assert (math.isinf(nr1) and math.isinf(nr0)) or nr1 == pytest.approx(nr0, rel=1e-9)
+        assert np.linalg.norm(x.download() - x0) <= 1e-12 * max(np.linalg.norm(x0), 1.0)
+    # A = 2I converges in one iteration (SURVEY "hard parts")
+    x0, l0 = np.zeros(n), np.zeros(m)
+    i0, nr0 = R.projcg_(x0, l0, DiagOpRef(2.0 * np.ones(n)), Uh, bh, np.zeros(m), tol=1e-8)
+    i1, nr1 = L.projcg_(x, lam, L.DiagOperator(2.0), U, b, None, tol=1e-8)
+    assert i1 == i0 == 1
+    assert np.linalg.norm(x.download() - x0) <= 1e-13 * np.linalg.norm(x0)
+
+
+def test_projcg_generic_operator_path(dev_ctx):
+    """Duck-typed A (the LinearMap case, src/optimize.jl:228-230) goes through the unfused loop."""
+    ctx = dev_ctx
+    n, m = 1200, 5
+    Uh, a, bh = _cg_problem(n, m)
+
+    class UserOp:
+        def __init__(self, dg):
+            self.inner = L.DiagOperator(0.0, dg)
+
+        def mul_(self, dest, v, al=None, be=None):
+            return self.inner.mul_(dest, v, al, be)
+
+        def adjoint(self):
+            return self
+
+    x0, l0 = np.zeros(n), np.zeros(m)
+    ch = np.linspace(-1, 1, m)
+    i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), Uh, bh, ch, tol=1e-10)
+    x, lam = ctx.vector(n), ctx.vector(m)
+    i1, nr1 = L.projcg_(x, lam, UserOp(ctx.vector(n, a)), L.DeviceBasis(ctx.matrix(n, m, Uh)), ctx.vector(n, bh), ctx.vector(m, ch),
+                        tol=1e-10)
+    assert i1 == i0
+    assert np.linalg.norm(x.download() - x0) <= 1e-10 * np.linalg.norm(x0)
+    assert np.abs(lam.download() - l0).max() < 1e-11
+
+
+def test_c_port_agrees_with_numpy_oracle():
+    n, m = 4000, 9
+    Uh, a, bh = _cg_problem(n, m)
+    x, lam, it, nr = port.projcg(a, Uh, bh, None, 1e-10, 500)
+    x0, l0 = np.zeros(n), np.zeros(m)
+    i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), Uh, bh, np.zeros(m), tol=1e-10, maxit=500)
+    assert it == i0 and nr == pytest.approx(nr0, rel=1e-8)
+    assert np.linalg.norm(x - x0) <= 1e-12 * np.linalg.norm(x0)
