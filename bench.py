@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: projected-CG iterations/s at n=1e7, m=128, fp64
+(BASELINE.json metric), with the achieved HBM GB/s of the J / J' matvec kernels.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one projected-CG iteration (src/projcg.jl:71-112 of the reference) on the
+synthetic sustained-iteration workload of SURVEY §8(d): U = n x m basis, A = diag(5+4u)
+(seed 3), b = u (seed 4), c = 0, tol = 1e-300 so exactly K iterations run inside one
+`lfpsqp_projcg` call; everything is resident in HBM before the timed region.  For N > 1
+the SAME global problem is row-sharded over the N GPUs (one process per GPU, m-vector and
+CG scalars all-reduced over RCCL) => "scaling": "strong".
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main(argv=None, lib=None):
+    """`lib` is injected only by tests/test_bench_harness.py (emulator build, tiny sizes)."""
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=float, default=1e7)
+    ap.add_argument("--m", type=int, default=128)
+    ap.add_argument("--basis", choices=["orthonormal", "scaled-hash"], default="orthonormal")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=float, default=2e6)
+    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl")
+    args = ap.parse_args(argv)
+    n, m, K, W = int(args.n), args.m, args.steps, args.warmup
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
+
+    import lfpsqp_jl_amd as L
+
+    ctx = L.Context(local_rank, lib)
+    if world > 1:
+        if args.comm == "rccl":
+            box = [ctx.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init_rccl(rank, world, box[0])
+        else:
+            from lfpsqp_jl_amd.distributed import torch_allreduce_callback
+            ctx.comm_init_callback(rank, world, torch_allreduce_callback(local_rank))
+    r0, r1 = ctx.shard_range(n, rank, world)
+    n_loc = r1 - r0
+
+    # ---- workload, generated on the device -------------------------------
+    Z = ctx.matrix(n_loc, m)
+    if args.basis == "orthonormal" and hasattr(L, "orthonormalize_"):
+        Z.hash_fill(1, r0, n, 1.0)
+        L.orthonormalize_(Z, n_global=n)
+        basis_desc = "orthonormalised hash matrix (CholeskyQR2 on device)"
+    else:
+        scale = 2.0 ** math.floor(math.log2(math.sqrt(3.0 / n)))
+        Z.hash_fill(1, r0, n, scale)
+        basis_desc = "scaled hash matrix (columns orthonormal to O(sqrt(m/n)))"
+    U = L.DeviceBasis(Z)
+    A = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.0, 5.0))
+    b = ctx.vector(n_loc).hash_fill(4, r0)
+    x = ctx.vector(n_loc)
+    work = L.ProjCGWork(ctx, n_loc, m)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warmup ------------------------------------------------------------------------
+    if W > 0:
+        L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=W, work=work, n_global=n, want_lambda=False)
+    ctx.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    iters, nr = L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=K, work=work, n_global=n, want_lambda=False)
+    ctx.sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof_ms, prof_cnt = ctx.profile_read()
+    ctx.set_profiling(False)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    assert iters == K, f"expected {K} iterations, got {iters} (nr={nr})"
+    assert math.isfinite(nr)
+
+    # ---- per-kernel roofline numbers (HIP events on the library's stream) ---------------
+    def avg(slot):
+        return prof_ms[slot] / prof_cnt[slot] if prof_cnt[slot] else float("nan")
+    k1, k2, k3 = avg(0), avg(1), avg(2)
+    bytes_k1 = 32.0 * n_loc
+    bytes_k2 = 8.0 * n_loc * m + 48.0 * n_loc + 8.0 * m
+    bytes_k3 = 8.0 * n_loc * m + 16.0 * n_loc + 8.0 * m
+    gbs = lambda by, ms: by / (ms * 1e-3) / 1e9
+    # plain matvecs (the "achieved HBM GB/s on J matvec" half of the metric)
+    v = ctx.vector(n_loc).hash_fill(5, r0)
+    tt = ctx.vector(m).hash_fill(6)
+    y = ctx.vector(n_loc)
+    reps = 5
+    L.gemv_t(Z, v, tt); L.gemv_n(Z, tt, y)
+    ctx.timer_begin()
+    for _ in range(reps):
+        L.gemv_t(Z, v, tt)
+    ms_t = ctx.timer_end() / reps
+    ctx.timer_begin()
+    for _ in range(reps):
+        L.gemv_n(Z, tt, y, 1.0, 1.0)
+    ms_n = ctx.timer_end() / reps
+    bytes_t = 8.0 * n_loc * m + 8.0 * n_loc + 8.0 * m
+    bytes_n = 8.0 * n_loc * m + 16.0 * n_loc + 8.0 * m
+
+    out = {
+        "metric": "projected-CG iters/sec at n=1e7, m=128 fp64",
+        "value": K / elapsed,
+        "unit": "iters/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"sustained projcg, dense basis n={n}, m={m}, A=diag(5+4u), tol=1e-300 (BASELINE configs[2] shape)",
+                   "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
+                   "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
+                   "comm": args.comm if world > 1 else "none", "device": ctx.device_name},
+        "roofline": {"bound": "hbm", "kernel": "gemv_t_kernel<PcgStepV> (K2: x/rp update fused with U'rp)",
+                     "achieved": gbs(bytes_k2, k2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbs(bytes_k2, k2) / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": k2, "algorithmic_bytes": bytes_k2},
+        "kernels": {"K1_dir_dAd": {"ms": k1, "GBs": gbs(bytes_k1, k1)},
+                    "K2_step_UTrp": {"ms": k2, "GBs": gbs(bytes_k2, k2)},
+                    "K3_proj_dots": {"ms": k3, "GBs": gbs(bytes_k3, k3)},
+                    "iteration_algorithmic_GB": (bytes_k1 + bytes_k2 + bytes_k3) / 1e9,
+                    "iteration_GBs": (bytes_k1 + bytes_k2 + bytes_k3) * K / elapsed / 1e9},
+        "matvec": {"gemv_t": {"ms": ms_t, "GBs": gbs(bytes_t, ms_t), "frac": gbs(bytes_t, ms_t) / HBM_PEAK_GBS},
+                   "gemv_n": {"ms": ms_n, "GBs": gbs(bytes_n, ms_n), "frac": gbs(bytes_n, ms_n) / HBM_PEAK_GBS}},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_n), m, n)
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return out
+
+
+def cpu_baseline(ns, m, n_full):
+    """The oracle's C/OpenMP restatement of the reference's (unfused) projcg! call sequence,
+    timed on this box's host cores on a bounded sample: n_s rows instead of n, same m, same
+    generator; iterations/s is rescaled by n_s/n (the loop is linear in n)."""
+    from oracle import port
+    threads = port.lib().port_num_threads()
+    scale = 2.0 ** math.floor(math.log2(math.sqrt(3.0 / ns)))
+    U = port.hash_matrix(1, ns, m, scale=scale)
+    a = port.hash_vector(3, ns, 0, 4.0, 5.0)
+    b = port.hash_vector(4, ns)
+    port.projcg(a, U, b, None, 1e-300, 1)                     # touch everything once
+    k = 3
+    t0 = time.perf_counter()
+    _, _, it, _ = port.projcg(a, U, b, None, 1e-300, k)
+    dt = time.perf_counter() - t0
+    k = max(3, min(40, int(12.0 / (dt / k))))                  # ~12 s of CPU work
+    t0 = time.perf_counter()
+    _, _, it, _ = port.projcg(a, U, b, None, 1e-300, k)
+    dt = time.perf_counter() - t0
+    return {"value": (it / dt) * (ns / n_full), "unit": "iters/s", "cores": threads, "kind": "port",
+            "sample": f"{it} iterations at n={ns}, m={m} (same generator), rate scaled by {ns}/{n_full}; "
+                      f"measured {it / dt:.3f} it/s on the sample; unfused reference call sequence, OpenMP on all loops"}
+
+
+if __name__ == "__main__":
+    main()

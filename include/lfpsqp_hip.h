@@ -86,9 +86,10 @@ int lfpsqp_mat_upload(lfpsqp_ctx* ctx, lfpsqp_mat* M, int64_t col0, int64_t ncol
 int lfpsqp_mat_download(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t col0, int64_t ncols, double* host, int64_t ldh);
 int lfpsqp_mat_copy(lfpsqp_ctx* ctx, lfpsqp_mat* dst, const lfpsqp_mat* src);
 /* synthetic inputs of SURVEY §8(d): v[i] = u(seed, offset+i);
- * M[i,j] = u(seed, j*n_global + row0 + i)  (splitmix64-finaliser hash in [-1,1)) */
+ * M[i,j] = scale * u(seed, j*n_global + row0 + i)  (splitmix64-finaliser hash in [-1,1));
+ * a power-of-two scale keeps the values bit-identical to the numpy generator */
 int lfpsqp_vec_hash_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, uint64_t seed, int64_t offset, double scale, double shift);
-int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global);
+int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global, double scale);
 
 /* ---- BLAS-1/2 primitives on the tall-skinny layout ------------------------ */
 /* Replace the reference's mul!/gemv!/kgemv!/dot/norm/axpy!/broadcast call sites

@@ -111,15 +111,15 @@ struct HashVecF {  // x[i] = scale*u(seed, offset+i) + shift
 
 // M[i, j] = u(seed, j*n_global + row0 + i): one workgroup per (row tile, column)
 __global__ __launch_bounds__(kThreads) void hash_mat_kernel(double* M, int64_t ld, int64_t n, uint64_t seed, int64_t row0,
-                                                             int64_t n_global) {
+                                                             int64_t n_global, double scale) {
     const int64_t j = blockIdx.y;
     double* col = M + j * ld;
     const uint64_t base = (uint64_t)j * (uint64_t)n_global + (uint64_t)row0;
 #pragma unroll
     for (int s = 0; s < kS; ++s) {
         const int64_t r = (int64_t)blockIdx.x * kTileRows + (int64_t)s * kSlabRows + (int64_t)threadIdx.x * 2;
-        if (r + 1 < n) st2(col + r, make_double2(hash_u(seed, base + (uint64_t)r), hash_u(seed, base + (uint64_t)r + 1)));
-        else if (r < n) col[r] = hash_u(seed, base + (uint64_t)r);
+        if (r + 1 < n) st2(col + r, make_double2(scale * hash_u(seed, base + (uint64_t)r), scale * hash_u(seed, base + (uint64_t)r + 1)));
+        else if (r < n) col[r] = scale * hash_u(seed, base + (uint64_t)r);
     }
 }
 
@@ -148,12 +148,12 @@ int lfpsqp_vec_hash_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, uint64_t seed, int64_t 
     return run_vec<HashVecF, 0, NoPost>(ctx, v->n, HashVecF{v->p, seed, offset, scale, shift}, 0u, nullptr, NoPost());
 }
 
-int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global) {
+int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global, double scale) {
     LF_ARG(ctx, ctx && M && row0 >= 0 && n_global >= M->n);
     if (M->n == 0 || M->m == 0) return 0;
     LF_ARG(ctx, M->m <= 65535);
     hipLaunchKernelGGL(hash_mat_kernel, dim3((unsigned)ntiles_of(M->n), (unsigned)M->m), dim3(kThreads), 0, ctx->stream, M->p, M->ld,
-                       M->n, seed, row0, n_global);
+                       M->n, seed, row0, n_global, scale);
     LF_LAUNCH_CHECK(ctx);
     return 0;
 }

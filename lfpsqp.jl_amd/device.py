@@ -179,8 +179,9 @@ class DeviceMatrix:
         self.ctx.check(self.ctx.L.lfpsqp_mat_copy(self.ctx.h, self.h, src.h))
         return self
 
-    def hash_fill(self, seed: int, row0: int = 0, n_global: int | None = None):
-        self.ctx.check(self.ctx.L.lfpsqp_mat_hash_fill(self.ctx.h, self.h, seed, row0, self.n if n_global is None else n_global))
+    def hash_fill(self, seed: int, row0: int = 0, n_global: int | None = None, scale: float = 1.0):
+        self.ctx.check(self.ctx.L.lfpsqp_mat_hash_fill(self.ctx.h, self.h, seed, row0, self.n if n_global is None else n_global,
+                                                       float(scale)))
         return self
 
 
