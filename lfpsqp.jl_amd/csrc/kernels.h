@@ -28,6 +28,16 @@ constexpr int kColChunk = 256;                // columns reduced per LDS flush
 constexpr int kMaxRed = 4;                    // scalar reductions per kernel
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+
+// Solver scalars / status words are written by one kernel (a reduction's post-op) and read,
+// at a wave-uniform address, by every workgroup of the following kernels in the stream.
+// A plain load of such a word compiles to s_load (scalar cache), and on MI355X / ROCm 7.2
+// that path was observed to return the PREVIOUS kernel generation's value in roughly half
+// of all processes (DESIGN.md §6 "stale scalar-cache reads"); agent-scope relaxed atomic
+// loads (global_load ... sc1) always see the value.  Every cross-kernel scalar read goes
+// through these two helpers.
+__device__ __forceinline__ double ld_scal(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int64_t ld_stat(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void vec_kernel(F f, int64_t n, unsigned 
 // ---------------------------------------------------------------------------
 template <class POST>
 __global__ __launch_bounds__(1024) void reduce_rows_kernel(const double* __restrict__ part, int64_t nrows, int ncols, int part_ld,
-                                                            unsigned ismax, double* __restrict__ out, POST post) {
+                                                            unsigned ismax, double* out, POST post) {
     if (post.skip()) return;
     __shared__ double sm[32][33];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;

@@ -43,11 +43,11 @@ struct PcgDirF {
     const double* scal;
     const int64_t* istat;
     int first;
-    __device__ __forceinline__ bool skip() const { return istat[I_STATUS] != ST_RUNNING; }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
         double2 dd = ld2(d + i);
         if (!first) {
-            const double beta = scal[S_BETA];
+            const double beta = ld_scal(scal + S_BETA);
             const double2 gg = ld2(g + i);
             dd = make_double2(beta * dd.x - gg.x, beta * dd.y - gg.y);   // src/projcg.jl:99
             if (v1) st2(d + i, dd);
@@ -63,10 +63,10 @@ struct PcgDirF {
 struct PcgPost1 {  // after d'Ad is final: iteration count, exits, alpha  (:72-91)
     double* scal;
     int64_t* istat;
-    __device__ __forceinline__ bool skip() const { return istat[I_STATUS] != ST_RUNNING; }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ void run(double*) const {
-        istat[I_ITER] += 1;
-        const double dAd = scal[S_DAD], rg = scal[S_RG];
+        istat[I_ITER] = ld_stat(istat + I_ITER) + 1;
+        const double dAd = ld_scal(scal + S_DAD), rg = ld_scal(scal + S_RG);
         if (dAd <= 0.0) istat[I_STATUS] = ST_NEGCURV;
         else if (rg <= 0.0) istat[I_STATUS] = ST_RG_BREAK;
         else scal[S_ALPHA] = rg / dAd;
@@ -82,9 +82,9 @@ struct PcgStepV {
     AOpD A;
     const double* scal;
     const int64_t* istat;
-    __device__ __forceinline__ bool skip() const { return istat[I_STATUS] != ST_RUNNING; }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
-        const double alpha = scal[S_ALPHA];
+        const double alpha = ld_scal(scal + S_ALPHA);
         const double2 dd = ld2(d + r), gg = ld2(g + r);
         double2 xx = ld2(x + r);
         const double2 ad = A.apply(r, dd);
@@ -103,7 +103,7 @@ struct PcgProjE {
     double* d;  // written (d = -g) only by the initial projection
     const int64_t* istat;
     int init;
-    __device__ __forceinline__ bool skip() const { return istat[I_STATUS] != ST_RUNNING; }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
         const double2 rr = ld2(rp + r);
         const double2 gp = make_double2(rr.x - acc.x, rr.y - acc.y);      // :97 (alpha=-1, beta=1)
@@ -125,20 +125,20 @@ struct PcgPost3 {  // beta, next rg, nr, convergence / iteration-limit exits (:9
     double* scal;
     int64_t* istat;
     int init;
-    __device__ __forceinline__ bool skip() const { return istat[I_STATUS] != ST_RUNNING; }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ void run(double*) const {
-        const double rpgp = scal[S_RPGP], gpgp = scal[S_GPGP];
+        const double rpgp = ld_scal(scal + S_RPGP), gpgp = ld_scal(scal + S_GPGP);
         if (init) {
             scal[S_RG] = gpgp;
-            if (istat[I_MAXIT] <= 0) istat[I_STATUS] = ST_MAXIT;
+            if (ld_stat(istat + I_MAXIT) <= 0) istat[I_STATUS] = ST_MAXIT;
             return;
         }
-        scal[S_BETA] = rpgp / scal[S_RG];
+        scal[S_BETA] = rpgp / ld_scal(scal + S_RG);
         scal[S_RG] = gpgp;
         const double nr = sqrt(gpgp);
         scal[S_NR] = nr;
-        if (nr < scal[S_TOL]) istat[I_STATUS] = ST_CONVERGED;
-        else if (istat[I_ITER] >= istat[I_MAXIT]) istat[I_STATUS] = ST_MAXIT;
+        if (nr < ld_scal(scal + S_TOL)) istat[I_STATUS] = ST_CONVERGED;
+        else if (ld_stat(istat + I_ITER) >= ld_stat(istat + I_MAXIT)) istat[I_STATUS] = ST_MAXIT;
     }
 };
 
@@ -193,7 +193,7 @@ struct NormalizeIntoF {  // x = d / sqrt(dd)    (:79)
     const double* dd;
     __device__ __forceinline__ bool skip() const { return false; }
     __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
-        const double nrm = sqrt(*dd);
+        const double nrm = sqrt(ld_scal(dd));
         const double2 a = ld2(d + i);
         const double2 o = make_double2(a.x / nrm, a.y / nrm);
         if (v1) st2(x + i, o);

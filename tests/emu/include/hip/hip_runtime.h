@@ -226,4 +226,7 @@ static inline double __builtin_nontemporal_load(const double* p) { return *p; }
 static inline void __builtin_nontemporal_store(double v, double* p) { *p = v; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }

@@ -1,0 +1,19 @@
+"""Regression guard for the stale-scalar-cache hazard: the failure mode was
+per PROCESS (about one process in three returned wrong iterates on tiny problems, where the
+kernels are a few microseconds long), so the stress loop runs in several fresh processes."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("proc", range(4))
+def test_many_tiny_solves_in_a_fresh_process(proc):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_small.py"), "6"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "bad 0 of" in out.stdout, out.stdout[-2000:]
