@@ -111,6 +111,30 @@ int lfpsqp_vmul(lfpsqp_ctx* ctx, const lfpsqp_vec* d, const lfpsqp_vec* x, lfpsq
 /* sum-all-reduce a replicated-partials device vector across ranks (no-op for 1 rank) */
 int lfpsqp_allreduce(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t count);
 
+/* ---- tangent setup: the replacement of ksvd! ----------------------------------- */
+/* The reference factors the n x m constraint-gradient matrix with LAPACK dgesvd every
+ * outer iteration (src/la_helper.jl:8-34, called at src/optimize.jl:291/293, O(n m^2)) and
+ * then only uses: the projector U_r U_r', lambda = V S^-1 U_r'd, and NR's D = S^-1 Vt.  On
+ * the device this is a Gram-based factorisation (the "(JJ') normal-equation solve" of the
+ * north star): G = A' diag(w2) A on the device, small eigen/SVD problems on the host,
+ * Z = A * W on the device, one re-orthonormalisation pass.
+ *
+ * G_host (ncols x ncols, column-major) = M[:, :ncols]' diag(w2) M[:, :ncols], all-reduced.
+ * w2 == NULL means unit weights. */
+int lfpsqp_gram(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* w2, double* G_host);
+/* Out[:, :rcols] = In[:, :kcols] * W   (W_host: kcols x rcols, column-major).  Out != In. */
+int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const double* W_host, int64_t rcols, lfpsqp_mat* Out);
+/* Thin factorisation A = diag(sqrt(w2)) * Jct = U S Vt with U = diag(sqrt(w2)) * Z:
+ *   Z (n x m, device, Z != Jct): Z' diag(w2) Z = I on the leading `rank` columns, the rest zero
+ *   Sigma[m] (host, descending), Vt[m*m] (host, column-major; rows >= rank are zero),
+ *   rank = #{Sigma_j >= max(eps_rank, 5e-7 * Sigma_1)}  (reference: Sigma_j >= eps_rank,
+ *   src/optimize.jl:297-302; a Gram-based method cannot resolve below ~1e-8 * Sigma_1).
+ * With w2 == NULL, Z is the U of ksvd! up to the sign/rotation freedom of the SVD, to which
+ * every use in the reference is invariant.  With bounds, w2 = Dy.^2 and the reference's
+ * 2N x M factor of PJct (src/optimize.jl:288-291) is [Dy.^2 .* Z ; -Dx.*Dy .* Z]. */
+int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
+                     int64_t* rank, double eps_rank);
+
 /* ---- projected CG (src/projcg.jl:40-121) --------------------------------- */
 /* The symmetric operator A of the QP ("B*p", the Lagrangian Hessian action that the
  * reference wraps in a LinearMap at src/optimize.jl:228-230).  Device-resident

@@ -7,3 +7,4 @@ from ._capi import LfpsqpError, load_library, header_functions  # noqa: F401
 from .device import (Context, DeviceMatrix, DeviceVector, amax, axpby, dot, gemv_n, gemv_t, nrm2, vmul,  # noqa: F401
                      waxpby)
 from .projcg import DeviceBasis, DiagOperator, ProjCGWork, projcg_  # noqa: F401
+from .factorize import gram, ksvd_, orthonormalize_, rmul  # noqa: F401

@@ -33,6 +33,17 @@ int ensure_part(lfpsqp_ctx* ctx, size_t doubles) {
     return 0;
 }
 
+int ensure_small(lfpsqp_ctx* ctx, size_t doubles) {
+    if (doubles <= ctx->small_cap) return 0;
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->small) LF_HIP(ctx, hipFree(ctx->small));
+    ctx->small = nullptr;
+    ctx->small_cap = 0;
+    LF_HIP(ctx, hipMalloc((void**)&ctx->small, doubles * sizeof(double)));
+    ctx->small_cap = doubles;
+    return 0;
+}
+
 int allreduce_dev(lfpsqp_ctx* ctx, double* buf, int64_t count, int op) {
     Comm& c = ctx->comm;
     if (c.nranks <= 1 || count == 0) return 0;
@@ -137,6 +148,7 @@ int lfpsqp_ctx_destroy(lfpsqp_ctx* ctx) {
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
     if (ctx->part) (void)hipFree(ctx->part);
+    if (ctx->small) (void)hipFree(ctx->small);
     if (ctx->scal) (void)hipFree(ctx->scal);
     if (ctx->istat) (void)hipFree(ctx->istat);
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);

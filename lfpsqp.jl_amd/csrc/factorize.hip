@@ -1,0 +1,302 @@
+// Tangent setup on the device: weighted Gram matrix, right-multiplication by a small
+// matrix, and the thin factorisation built from them (replaces the reference's per-outer-
+// iteration LAPACK dgesvd, src/la_helper.jl:8-34).  Both kernels are the same register-tiled
+// contraction C[i][j] += sum_k A[k][i] * B[k][j] on 128 x 128 output tiles with a 16-deep K
+// step staged through LDS (fp64 FMA; AI = m/4 flop/B, compute-bound for m >= 128).
+// Round-1 note: VALU FMAs, not yet v_mfma_f64_16x16x4_f64 -- the tile shape was chosen so
+// the MFMA version is a drop-in for tile_fma() ("next").
+#include <math.h>
+
+#include <vector>
+
+#include "internal.h"
+#include "smallla.h"
+
+namespace lfpsqp {
+
+constexpr int kPanel = 128;
+constexpr int kKStep = 16;
+
+// thread (ti = tid % 16, tj = tid / 16) owns C rows ti*8..+8 (index i) and columns tj*8..+8 (index j)
+__device__ __forceinline__ void tile_fma(const double (*As)[kPanel], const double (*Bs)[kPanel], double (&acc)[8][8], int ti, int tj) {
+#pragma unroll 4
+    for (int k = 0; k < kKStep; ++k) {
+        double a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = As[k][ti * 8 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b[q] = Bs[k][tj * 8 + q];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+    }
+}
+
+// Gram partials.  grid = (G row-step groups, npan*npan panel pairs).  Block (g, pp) sums the
+// 16-row steps g, g+G, ... of panel pair (pi, pj) and writes its 128 x 128 partial to
+// part[g][pp*16384 + j*128 + i]  (i = row of G within panel pi, j = column within panel pj).
+__global__ __launch_bounds__(kThreads) void gram_kernel(const double* __restrict__ M, int64_t ld, int64_t n, int ncols, int npan,
+                                                         const double* __restrict__ w2, double* __restrict__ part, int64_t part_ld) {
+    __shared__ double As[kKStep][kPanel];
+    __shared__ double Bs[kKStep][kPanel];
+    const int pi = blockIdx.y / npan, pj = blockIdx.y % npan;
+    const int tid = threadIdx.x, ti = tid % 16, tj = tid / 16;
+    double acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
+    const int64_t nsteps = (n + kKStep - 1) / kKStep;
+    // staging role: column c = tid / 2 of the panel, rows kh..kh+8 of the step
+    const int c = tid >> 1, kh = (tid & 1) * 8;
+    const int64_t colA = (int64_t)pi * kPanel + c, colB = (int64_t)pj * kPanel + c;
+    for (int64_t step = blockIdx.x; step < nsteps; step += gridDim.x) {
+        const int64_t r0 = step * kKStep + kh;
+        double va[8], vb[8];
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            const int64_t r = r0 + q;
+            double2 a = make_double2(0.0, 0.0), b = make_double2(0.0, 0.0);
+            if (colA < ncols) a = ld2(M + colA * ld + r);      // rows >= n are zero padding
+            if (pi != pj && colB < ncols) b = ld2(M + colB * ld + r);
+            if (w2) {
+                const double2 w = ld2(w2 + r);
+                a.x *= (r < n) ? w.x : 0.0;
+                a.y *= (r + 1 < n) ? w.y : 0.0;
+            }
+            va[q] = a.x; va[q + 1] = a.y;
+            vb[q] = b.x; vb[q + 1] = b.y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            As[kh + q][c] = va[q];
+            if (pi != pj) Bs[kh + q][c] = vb[q];
+        }
+        __syncthreads();
+        if (pi != pj) {
+            tile_fma(As, Bs, acc, ti, tj);
+        } else if (w2) {
+            // diagonal panel with weights: B side must be the UNWEIGHTED rows
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                double2 b = make_double2(0.0, 0.0);
+                if (colA < ncols) b = ld2(M + colA * ld + r0 + q);
+                Bs[kh + q][c] = b.x;
+                Bs[kh + q + 1][c] = b.y;
+            }
+            __syncthreads();
+            tile_fma(As, Bs, acc, ti, tj);
+        } else {
+            tile_fma(As, As, acc, ti, tj);
+        }
+    }
+    double* out = part + (int64_t)blockIdx.x * part_ld + (int64_t)blockIdx.y * (kPanel * kPanel);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; i += 2)
+            st2(out + (tj * 8 + j) * kPanel + ti * 8 + i, make_double2(acc[i][j], acc[i + 1][j]));
+}
+
+// Out[row0 + i, c0 + j] = sum_k In[row0 + i, k] * W[k, c0 + j]; grid = (row tiles of 128, column panels)
+__global__ __launch_bounds__(kThreads) void rmul_kernel(const double* __restrict__ In, int64_t ld_in, int64_t n, int kcols,
+                                                         const double* __restrict__ W, int ldw, int rcols, double* __restrict__ Out,
+                                                         int64_t ld_out) {
+    __shared__ double As[kKStep][kPanel];
+    __shared__ double Bs[kKStep][kPanel];
+    const int tid = threadIdx.x, ti = tid % 16, tj = tid / 16;
+    const int64_t row0 = (int64_t)blockIdx.x * kPanel;
+    const int c0 = blockIdx.y * kPanel;
+    double acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
+    // staging roles: A: k = tid / 16, rows (tid % 16)*8..+8 ; B: column tid / 2, k half (tid & 1)*8
+    const int ka = tid / 16, ra = (tid % 16) * 8;
+    const int cb = tid >> 1, kb = (tid & 1) * 8;
+    for (int k0 = 0; k0 < kcols; k0 += kKStep) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            double2 a = make_double2(0.0, 0.0);
+            if (k0 + ka < kcols) a = ld2(In + (int64_t)(k0 + ka) * ld_in + row0 + ra + q);   // padded rows are zero
+            va[q] = a.x; va[q + 1] = a.y;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + kb + q;
+            vb[q] = (k < kcols && c0 + cb < rcols) ? W[(int64_t)(c0 + cb) * ldw + k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            As[ka][ra + q] = va[q];
+            Bs[kb + q][cb] = vb[q];
+        }
+        __syncthreads();
+        tile_fma(As, Bs, acc, ti, tj);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int col = c0 + tj * 8 + j;
+        if (col >= rcols) continue;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const int64_t r = row0 + ti * 8 + i;
+            double* dst = Out + (int64_t)col * ld_out + r;
+            if (r + 1 < n) st2(dst, make_double2(acc[i][j], acc[i + 1][j]));
+            else if (r < n) dst[0] = acc[i][j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void zero_cols_kernel(double* M, int64_t ld, int64_t n, int c0) {
+    double* col = M + (int64_t)(c0 + blockIdx.y) * ld;
+    for (int64_t r = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 2; r < n; r += (int64_t)gridDim.x * kThreads * 2) {
+        if (r + 1 < n) st2(col + r, make_double2(0.0, 0.0));
+        else col[r] = 0.0;
+    }
+}
+
+static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, const double* w2, std::vector<double>& G) {
+    G.assign((size_t)ncols * ncols, 0.0);
+    if (ncols == 0) return 0;
+    const int npan = (ncols + kPanel - 1) / kPanel;
+    const int64_t pp = (int64_t)npan * npan * kPanel * kPanel;
+    const int64_t nsteps = (M->n + kKStep - 1) / kKStep;
+    int groups = (int)(nsteps < 256 ? (nsteps < 1 ? 1 : nsteps) : 256);
+    LF_TRY(ensure_part(ctx, (size_t)groups * pp));
+    LF_TRY(ensure_small(ctx, (size_t)pp));
+    hipLaunchKernelGGL(gram_kernel, dim3(groups, npan * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2,
+                       ctx->part, pp);
+    LF_LAUNCH_CHECK(ctx);
+    // reduce the `groups` partials (ncols = pp may exceed int range only for m > ~46000)
+    hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3((unsigned)((pp + 31) / 32)), dim3(1024), 0, ctx->stream, ctx->part,
+                       (int64_t)groups, (int)pp, (int)pp, 0u, ctx->small, NoPost());
+    LF_LAUNCH_CHECK(ctx);
+    LF_TRY(allreduce_dev(ctx, ctx->small, pp, 0));
+    std::vector<double> h((size_t)pp);
+    LF_HIP(ctx, hipMemcpyAsync(h.data(), ctx->small, sizeof(double) * pp, hipMemcpyDeviceToHost, ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int pi = 0; pi < npan; ++pi)
+        for (int pj = 0; pj < npan; ++pj) {
+            const double* blk = h.data() + ((size_t)pi * npan + pj) * kPanel * kPanel;
+            for (int j = 0; j < kPanel; ++j) {
+                const int gj = pj * kPanel + j;
+                if (gj >= ncols) break;
+                for (int i = 0; i < kPanel; ++i) {
+                    const int gi = pi * kPanel + i;
+                    if (gi >= ncols) break;
+                    G[(size_t)gj * ncols + gi] = blk[j * kPanel + i];
+                }
+            }
+        }
+    // G is symmetric up to rounding of the two summation orders; symmetrise
+    for (int j = 0; j < ncols; ++j)
+        for (int i = 0; i < j; ++i) {
+            const double v = 0.5 * (G[(size_t)j * ncols + i] + G[(size_t)i * ncols + j]);
+            G[(size_t)j * ncols + i] = G[(size_t)i * ncols + j] = v;
+        }
+    return 0;
+}
+
+static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const double* W_host, int rcols, lfpsqp_mat* Out) {
+    if (rcols == 0 || In->n == 0) return 0;
+    LF_TRY(ensure_small(ctx, (size_t)kcols * rcols + 16));
+    LF_HIP(ctx, hipMemcpyAsync(ctx->small, W_host, sizeof(double) * (size_t)kcols * rcols, hipMemcpyHostToDevice, ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // W_host is caller-owned pageable memory
+    hipLaunchKernelGGL(rmul_kernel, dim3((unsigned)((In->n + kPanel - 1) / kPanel), (unsigned)((rcols + kPanel - 1) / kPanel)),
+                       dim3(kThreads), 0, ctx->stream, In->p, In->ld, In->n, kcols, ctx->small, kcols, rcols, Out->p, Out->ld);
+    LF_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+}  // namespace lfpsqp
+
+using namespace lfpsqp;
+
+extern "C" {
+
+int lfpsqp_gram(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* w2, double* G_host) {
+    LF_ARG(ctx, ctx && M && G_host && ncols >= 0 && ncols <= M->m && (!w2 || w2->n == M->n));
+    std::vector<double> G;
+    LF_TRY(gram_impl(ctx, M, (int)ncols, w2 ? w2->p : nullptr, G));
+    for (size_t i = 0; i < G.size(); ++i) G_host[i] = G[i];
+    return 0;
+}
+
+int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const double* W_host, int64_t rcols, lfpsqp_mat* Out) {
+    LF_ARG(ctx, ctx && In && Out && W_host && In->p != Out->p && kcols >= 0 && kcols <= In->m && rcols >= 0 && rcols <= Out->m &&
+                    In->n == Out->n);
+    return rmul_impl(ctx, In, (int)kcols, W_host, (int)rcols, Out);
+}
+
+int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
+                     int64_t* rank_out, double eps_rank) {
+    LF_ARG(ctx, ctx && Jct && Z && Sigma && Vt && rank_out && Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m &&
+                    (!w2 || w2->n == Jct->n));
+    const int m = (int)Jct->m;
+    *rank_out = 0;
+    if (m == 0) return 0;
+    const double* w2p = w2 ? w2->p : nullptr;
+    // 1. G = A'A, eigen-decomposition (SVD of a PSD matrix)
+    std::vector<double> G, Ug, lam, V;
+    LF_TRY(gram_impl(ctx, Jct, m, w2p, G));
+    for (double g : G)
+        if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix");
+    jacobi_svd(m, m, G, Ug, lam, V);
+    std::vector<double> sig(m);
+    for (int j = 0; j < m; ++j) sig[j] = sqrt(lam[j] > 0 ? lam[j] : 0.0);
+    const double thr = fmax(eps_rank, 5e-7 * sig[0]);
+    int r = 0;
+    while (r < m && sig[r] >= thr && sig[r] > 0) ++r;
+    for (int j = 0; j < m; ++j) Sigma[j] = sig[j];
+    for (size_t i = 0; i < (size_t)m * m; ++i) Vt[i] = 0.0;
+    *rank_out = r;
+    hipLaunchKernelGGL(zero_cols_kernel, dim3(256, (unsigned)Z->m), dim3(kThreads), 0, ctx->stream, Z->p, Z->ld, Z->n, 0);
+    LF_LAUNCH_CHECK(ctx);
+    if (r == 0) return 0;
+    // 2. Q1 = A V_r S_r^-1
+    std::vector<double> W1((size_t)m * r);
+    for (int j = 0; j < r; ++j)
+        for (int i = 0; i < m; ++i) W1[(size_t)j * m + i] = V[(size_t)j * m + i] / sig[j];
+    LF_TRY(rmul_impl(ctx, Jct, m, W1.data(), r, Z));
+    // 3. re-orthonormalise: G2 = Q1'Q1 = V2 L2 V2', W2 = G2^-1/2 (symmetric), B = G2^1/2 S_r V_r'
+    std::vector<double> G2, U2, l2, V2;
+    LF_TRY(gram_impl(ctx, Z, r, w2p, G2));
+    jacobi_svd(r, r, G2, U2, l2, V2);
+    if (!(l2[r - 1] > 0.25)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: basis lost orthogonality (min eig %g)", l2[r - 1]);
+    std::vector<double> W2((size_t)r * r, 0.0), H2((size_t)r * r, 0.0);
+    for (int k = 0; k < r; ++k) {
+        const double is = 1.0 / sqrt(l2[k]), s = sqrt(l2[k]);
+        for (int j = 0; j < r; ++j) {
+            const double vjk = V2[(size_t)k * r + j];
+            for (int i = 0; i < r; ++i) {
+                const double vik = V2[(size_t)k * r + i];
+                W2[(size_t)j * r + i] += vik * is * vjk;
+                H2[(size_t)j * r + i] += vik * s * vjk;
+            }
+        }
+    }
+    // B' (m x r) = V_r S_r H2  ->  SVD  B' = Vb S Ub'
+    std::vector<double> VS((size_t)m * r), Bt, Vb, S, Ub;
+    for (int j = 0; j < r; ++j)
+        for (int i = 0; i < m; ++i) VS[(size_t)j * m + i] = V[(size_t)j * m + i] * sig[j];
+    matmul(m, r, r, VS, H2, Bt);
+    jacobi_svd(m, r, Bt, Vb, S, Ub);
+    // 4. Z = A (W1 W2 Ub)
+    std::vector<double> T, Wtot;
+    matmul(r, r, r, W2, Ub, T);
+    matmul(m, r, r, W1, T, Wtot);
+    LF_TRY(rmul_impl(ctx, Jct, m, Wtot.data(), r, Z));
+    for (int j = 0; j < r; ++j) Sigma[j] = S[j];
+    for (int k = 0; k < r; ++k)
+        for (int j = 0; j < m; ++j) Vt[(size_t)j * m + k] = Vb[(size_t)k * m + j];   // Vt[k, j] = Vb[j, k]
+    return 0;
+}
+
+}  // extern "C"

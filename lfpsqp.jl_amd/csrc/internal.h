@@ -50,6 +50,9 @@ struct lfpsqp_ctx {
     // reduction workspace: partial sums [rows][ld] (device)
     double* part = nullptr;
     size_t part_cap = 0;  // doubles
+    // small replicated device scratch (Gram matrices, m x m factors)
+    double* small = nullptr;
+    size_t small_cap = 0;
     // small device blocks: solver scalars / status, and their pinned host mirrors
     double* scal = nullptr;    // 64 doubles
     int64_t* istat = nullptr;  // 16 int64
@@ -71,6 +74,7 @@ namespace lfpsqp {
 
 int set_err(lfpsqp_ctx* ctx, int code, const char* fmt, ...);
 int ensure_part(lfpsqp_ctx* ctx, size_t doubles);
+int ensure_small(lfpsqp_ctx* ctx, size_t doubles);
 int allreduce_dev(lfpsqp_ctx* ctx, double* buf, int64_t count, int op = 0);  // in place, stream ordered; op 0 sum / 1 max; no-op for 1 rank
 
 // profiling helpers: bracket one launch of slot `s`

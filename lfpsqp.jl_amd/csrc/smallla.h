@@ -1,0 +1,92 @@
+// Host-side dense linear algebra on m x m problems (m = number of constraints, 1..~1000):
+// the replicated small factor of the tangent setup.  One-sided (Hestenes) Jacobi is used for
+// both the symmetric eigenproblem of a Gram matrix and the SVD of the small factor; it is
+// simple, accurate to high relative accuracy and needs no external LAPACK.
+#pragma once
+#include <math.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+namespace lfpsqp {
+
+// A: rows x cols, column-major, leading dimension rows (rows >= 1, cols >= 0).
+// On exit U (rows x cols, orthonormal columns where S > 0), S (cols, descending, >= 0),
+// V (cols x cols, orthogonal), with A = U diag(S) V'.
+inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::vector<double>& U, std::vector<double>& S,
+                       std::vector<double>& V) {
+    std::vector<double> A(Ain);
+    V.assign((size_t)cols * cols, 0.0);
+    for (int j = 0; j < cols; ++j) V[(size_t)j * cols + j] = 1.0;
+    const double eps = 1e-16;
+    for (int sweep = 0; sweep < 80; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < cols - 1; ++p) {
+            double* ap = &A[(size_t)p * rows];
+            for (int q = p + 1; q < cols; ++q) {
+                double* aq = &A[(size_t)q * rows];
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int i = 0; i < rows; ++i) {
+                    alpha += ap[i] * ap[i];
+                    beta += aq[i] * aq[i];
+                    gamma += ap[i] * aq[i];
+                }
+                if (gamma == 0.0) continue;
+                const double lim = sqrt(alpha * beta);
+                if (fabs(gamma) <= eps * lim) continue;
+                off = std::max(off, fabs(gamma) / (lim > 0 ? lim : 1.0));
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < rows; ++i) {
+                    const double x = ap[i], y = aq[i];
+                    ap[i] = c * x - s * y;
+                    aq[i] = s * x + c * y;
+                }
+                double* vp = &V[(size_t)p * cols];
+                double* vq = &V[(size_t)q * cols];
+                for (int i = 0; i < cols; ++i) {
+                    const double x = vp[i], y = vq[i];
+                    vp[i] = c * x - s * y;
+                    vq[i] = s * x + c * y;
+                }
+            }
+        }
+        if (off <= 1e-15) break;
+    }
+    std::vector<double> nrm(cols);
+    for (int j = 0; j < cols; ++j) {
+        double s = 0.0;
+        for (int i = 0; i < rows; ++i) s += A[(size_t)j * rows + i] * A[(size_t)j * rows + i];
+        nrm[j] = sqrt(s);
+    }
+    std::vector<int> idx(cols);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return nrm[a] > nrm[b]; });
+    U.assign((size_t)rows * cols, 0.0);
+    S.assign(cols, 0.0);
+    std::vector<double> Vs((size_t)cols * cols);
+    for (int jj = 0; jj < cols; ++jj) {
+        const int j = idx[jj];
+        S[jj] = nrm[j];
+        for (int i = 0; i < rows; ++i) U[(size_t)jj * rows + i] = nrm[j] > 0 ? A[(size_t)j * rows + i] / nrm[j] : 0.0;
+        for (int i = 0; i < cols; ++i) Vs[(size_t)jj * cols + i] = V[(size_t)j * cols + i];
+    }
+    V.swap(Vs);
+}
+
+// C (ra x cb) = A (ra x ca) * B (ca x cb), all column-major, tight leading dimensions
+inline void matmul(int ra, int ca, int cb, const std::vector<double>& A, const std::vector<double>& B, std::vector<double>& C) {
+    C.assign((size_t)ra * cb, 0.0);
+    for (int j = 0; j < cb; ++j)
+        for (int k = 0; k < ca; ++k) {
+            const double b = B[(size_t)j * ca + k];
+            if (b == 0.0) continue;
+            const double* a = &A[(size_t)k * ra];
+            double* c = &C[(size_t)j * ra];
+            for (int i = 0; i < ra; ++i) c[i] += a[i] * b;
+        }
+}
+
+}  // namespace lfpsqp

@@ -1,0 +1,47 @@
+"""Tangent setup on the device -- the replacement of ``ksvd!`` (reference src/la_helper.jl:8-34,
+called every outer iteration at src/optimize.jl:291/293)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._capi import c_i64
+from .device import DeviceMatrix, DeviceVector
+
+
+def gram(M: DeviceMatrix, ncols: int | None = None, w2: DeviceVector | None = None) -> np.ndarray:
+    """M[:, :ncols]' diag(w2) M[:, :ncols] (replicated, all-reduced)."""
+    ncols = M.m if ncols is None else ncols
+    G = np.empty((ncols, ncols), order='F')
+    M.ctx.check(M.ctx.L.lfpsqp_gram(M.ctx.h, M.h, ncols, w2.h if w2 is not None else None, G.ctypes.data))
+    return G
+
+
+def rmul(In: DeviceMatrix, W: np.ndarray, Out: DeviceMatrix) -> DeviceMatrix:
+    """Out[:, :W.shape[1]] = In[:, :W.shape[0]] @ W."""
+    W = np.asfortranarray(W, dtype=np.float64)
+    In.ctx.check(In.ctx.L.lfpsqp_rmul(In.ctx.h, In.h, W.shape[0], W.ctypes.data, W.shape[1], Out.h))
+    return Out
+
+
+def ksvd_(Jct: DeviceMatrix, Z: DeviceMatrix, w2: DeviceVector | None = None, eps_rank: float = 1e-10):
+    """Thin factorisation diag(sqrt(w2)) Jct = U S Vt with U = diag(sqrt(w2)) Z.
+    Returns (Sigma, Vt, rank); Z is overwritten (Jct is NOT destroyed, unlike dgesvd)."""
+    m = Jct.m
+    S = np.zeros(m)
+    Vt = np.zeros((m, m), order='F')
+    rank = c_i64()
+    Jct.ctx.check(Jct.ctx.L.lfpsqp_factorize(Jct.ctx.h, Jct.h, w2.h if w2 is not None else None, Z.h, S.ctypes.data,
+                                             Vt.ctypes.data, C.byref(rank), float(eps_rank)))
+    return S, Vt, rank.value
+
+
+def orthonormalize_(Z: DeviceMatrix, n_global: int | None = None) -> DeviceMatrix:
+    """Replace the columns of Z by an orthonormal basis of their span (in place from the caller's
+    point of view; uses one scratch matrix of the same size)."""
+    tmp = DeviceMatrix(Z.ctx, Z.n, Z.m)
+    tmp.copy_from(Z)
+    ksvd_(tmp, Z)
+    tmp.free()
+    return Z

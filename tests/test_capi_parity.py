@@ -188,3 +188,81 @@ def test_c_port_agrees_with_numpy_oracle():
     i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), Uh, bh, np.zeros(m), tol=1e-10, maxit=500)
     assert it == i0 and nr == pytest.approx(nr0, rel=1e-8)
     assert np.linalg.norm(x - x0) <= 1e-12 * np.linalg.norm(x0)
+
+
+# ----------------------------------------------------------------------------- tangent setup
+@pytest.mark.parametrize("n,m", [(700, 5), (2049, 16), (1500, 130)])
+def test_gram_and_rmul(dev_ctx, n, m):
+    ctx = dev_ctx
+    rng = np.random.default_rng(11)
+    Mh = np.asfortranarray(rng.standard_normal((n, m)))
+    wh = rng.random(n) + 0.1
+    M, w = ctx.matrix(n, m, Mh), ctx.vector(n, wh)
+    np.testing.assert_allclose(L.gram(M), Mh.T @ Mh, atol=1e-12 * n)
+    np.testing.assert_allclose(L.gram(M, w2=w), Mh.T @ (wh[:, None] * Mh), atol=1e-12 * n)
+    np.testing.assert_allclose(L.gram(M, ncols=m - 1), (Mh.T @ Mh)[:m - 1, :m - 1], atol=1e-12 * n)
+    W = rng.standard_normal((m, max(m - 2, 1)))
+    O = ctx.matrix(n, m)
+    L.rmul(M, W, O)
+    np.testing.assert_allclose(O.download()[:, :W.shape[1]], Mh @ W, atol=1e-12 * m)
+
+
+@pytest.mark.parametrize("n,m", [(1000, 10), (3000, 40), (1030, 129)])
+def test_factorize_replaces_ksvd(dev_ctx, n, m):
+    """ksvd! (dgesvd) parity through the quantities the reference actually uses: singular values,
+    the projector U U', U S Vt = Jct, and lambda = V S^-1 U'd (src/optimize.jl:335-342)."""
+    ctx = dev_ctx
+    Jh = synth.hash_matrix(1, n, m)
+    U0 = np.empty((n, m), order='F'); S0 = np.empty(m); Vt0 = np.empty((m, m), order='F')
+    R.ksvd_(Jh.copy(order='F'), U0, S0, Vt0)
+    J, Z = ctx.matrix(n, m, Jh), ctx.matrix(n, m)
+    S, Vt, rank = L.ksvd_(J, Z)
+    Zh = Z.download()
+    assert rank == m
+    np.testing.assert_array_equal(J.download(), Jh)                 # input is not destroyed
+    np.testing.assert_allclose(S, S0, rtol=1e-12)
+    np.testing.assert_allclose(Zh.T @ Zh, np.eye(m), atol=5e-14)
+    np.testing.assert_allclose((Zh * S) @ Vt, Jh, atol=1e-12)
+    d = synth.hash_vector(9, n)
+    np.testing.assert_allclose(Zh @ (Zh.T @ d), U0 @ (U0.T @ d), atol=1e-12)
+    lam0 = Vt0.T @ ((U0.T @ d) / S0)
+    lam1 = Vt.T @ ((Zh.T @ d) / S)
+    np.testing.assert_allclose(lam1, lam0, rtol=1e-9, atol=1e-12)
+
+
+def test_factorize_weighted_is_the_bound_projected_factor(dev_ctx):
+    """With bounds the reference factors PJct = [(1-Dx^2).*Jct; -Dy.*Dx.*Jct] (src/optimize.jl:288-291);
+    on the device that is the weighted factorisation with w2 = Dy^2 and U = [Dy^2.*Z; -Dx.*Dy.*Z]."""
+    ctx = dev_ctx
+    n, m = 1200, 7
+    rng = np.random.default_rng(5)
+    Jh = synth.hash_matrix(1, n, m)
+    th = rng.uniform(0, 2 * np.pi, n)
+    Dx, Dy = np.cos(th), np.sin(th)
+    PJ = np.vstack([(1 - Dx * Dx)[:, None] * Jh, (-Dy * Dx)[:, None] * Jh])
+    U0, S0, Vt0 = np.linalg.svd(PJ, full_matrices=False)
+    J, Z = ctx.matrix(n, m, Jh), ctx.matrix(n, m)
+    S, Vt, rank = L.ksvd_(J, Z, w2=ctx.vector(n, Dy * Dy))
+    Zh = Z.download()
+    Ufull = np.vstack([(Dy * Dy)[:, None] * Zh, (-Dx * Dy)[:, None] * Zh])
+    assert rank == m
+    np.testing.assert_allclose(S, S0, rtol=1e-12)
+    np.testing.assert_allclose(Ufull.T @ Ufull, np.eye(m), atol=5e-14)
+    np.testing.assert_allclose(Ufull @ Ufull.T @ np.ones(2 * n), U0 @ (U0.T @ np.ones(2 * n)), atol=1e-11)
+    np.testing.assert_allclose((Ufull * S) @ Vt, PJ, atol=1e-12)
+
+
+def test_factorize_rank_deficient(dev_ctx):
+    """rank < m (src/optimize.jl:297-302): duplicated constraints give zero singular values."""
+    ctx = dev_ctx
+    n, m = 1500, 8
+    Jh = synth.hash_matrix(1, n, m)
+    Jh[:, 5] = Jh[:, 1] + Jh[:, 2]
+    Jh[:, 7] = 2 * Jh[:, 0]
+    J, Z = ctx.matrix(n, m, Jh), ctx.matrix(n, m)
+    S, Vt, rank = L.ksvd_(J, Z)
+    Zh = Z.download()
+    assert rank == 6 and np.all(S[6:] < 1e-5)
+    np.testing.assert_allclose(Zh[:, :6].T @ Zh[:, :6], np.eye(6), atol=5e-14)
+    assert np.all(Zh[:, 6:] == 0.0)
+    np.testing.assert_allclose((Zh * S) @ Vt, Jh, atol=1e-11)
