@@ -111,6 +111,35 @@ int lfpsqp_vmul(lfpsqp_ctx* ctx, const lfpsqp_vec* d, const lfpsqp_vec* x, lfpsq
 /* sum-all-reduce a replicated-partials device vector across ranks (no-op for 1 rank) */
 int lfpsqp_allreduce(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t count);
 
+/* ---- bound manifolds (src/inequality_helper.jl, src/retractions.jl:451-500) ------- */
+/* With bounds the reference doubles the variables: xaug = [x; y] (length 2N), each bounded
+ * x_i living with its partner y_i on a line / parabola / circle.  On the device such a
+ * "stacked" vector keeps the x-half at [0, N) and the y-half at [hs, hs + N) with
+ * hs = lfpsqp_half_stride(N) (N rounded up to whole tiles, gap kept zero), so both halves are
+ * tile-aligned and every BLAS-1 primitive above works on it unchanged (length hs + N). */
+int64_t lfpsqp_half_stride(int64_t N);
+/* InequalityData(xl, xu) (src/inequality_helper.jl:39-89): per-variable q, r, s, t (N-vectors);
+ * the curve type is implied (s == 0 line, q == 0 parabola, else circle).  xl/xu use +-Inf. */
+typedef struct lfpsqp_ineq_data {
+    const lfpsqp_vec* q;
+    const lfpsqp_vec* r;
+    const lfpsqp_vec* s;
+    const lfpsqp_vec* t;
+    int64_t n; /* N */
+} lfpsqp_ineq_data;
+int lfpsqp_ineq_data_build(lfpsqp_ctx* ctx, const lfpsqp_vec* xl, const lfpsqp_vec* xu, lfpsqp_vec* q, lfpsqp_vec* r, lfpsqp_vec* s,
+                           lfpsqp_vec* t);
+/* generate_initial_y! (:92-109): fills the y-half of the stacked xaug */
+int lfpsqp_generate_initial_y(lfpsqp_ctx* ctx, lfpsqp_vec* xaug, const lfpsqp_ineq_data* id);
+/* calculate_h! (:112-122): h[0:N) (N-vector), *hmax = norm(h, Inf) (hmax may be NULL) */
+int lfpsqp_calculate_h(lfpsqp_ctx* ctx, lfpsqp_vec* h, const lfpsqp_vec* xaug, const lfpsqp_ineq_data* id, double* hmax);
+/* inequality_gradient! (:125-141): Dx, Dy, S; additionally the row scalings of the stacked
+ * basis, sx = Dy.^2 and sy = -Dx.*Dy (so U = [sx .* Z; sy .* Z], see lfpsqp_factorize) */
+int lfpsqp_inequality_gradient(lfpsqp_ctx* ctx, const lfpsqp_vec* xaug, const lfpsqp_ineq_data* id, lfpsqp_vec* Dx, lfpsqp_vec* Dy,
+                               lfpsqp_vec* S, lfpsqp_vec* sx, lfpsqp_vec* sy);
+/* y_retract!(xnewaug, xaug, idata) (src/retractions.jl:451-500) */
+int lfpsqp_y_retract(lfpsqp_ctx* ctx, lfpsqp_vec* xnewaug, const lfpsqp_vec* xaug, const lfpsqp_ineq_data* id);
+
 /* ---- tangent setup: the replacement of ksvd! ----------------------------------- */
 /* The reference factors the n x m constraint-gradient matrix with LAPACK dgesvd every
  * outer iteration (src/la_helper.jl:8-34, called at src/optimize.jl:291/293, O(n m^2)) and
@@ -161,6 +190,15 @@ typedef struct lfpsqp_basis {
     const lfpsqp_vec* sy;
 } lfpsqp_basis;
 
+/* mul!(dest, Q', v) (src/inequality_helper.jl:197-212): w[0:N) = Dx.*vx + Dy.*vy,
+ * t[0:ncols) = Z'(sx.*vx + sy.*vy)  -- ONE pass over the N x M matrix Z (the reference makes a
+ * pass over a 2N x M matrix).  For a plain basis (Dx == NULL) this is lfpsqp_gemv_t and w is unused. */
+int lfpsqp_q_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, const lfpsqp_vec* v, lfpsqp_vec* w, lfpsqp_vec* t);
+/* mul!(y, Q, [w; t], alpha, beta) (:161-194): y = alpha * Q [w; t] + beta * y, y stacked; w may be
+ * NULL (treated as zero, e.g. the Newton-retraction update xnew += U*delta, src/retractions.jl:141) */
+int lfpsqp_q_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, double alpha, const lfpsqp_vec* w, const lfpsqp_vec* t, double beta,
+                    lfpsqp_vec* y);
+
 /* ProjCGWork (src/projcg.jl:1-11): caller-owned scratch, allocated once.
  * Only three n-vectors are needed on the device (r == g throughout, gp and Ad
  * are never materialised) plus the m-vector Utr. */
@@ -169,6 +207,7 @@ typedef struct lfpsqp_projcg_work {
     lfpsqp_vec* d;
     lfpsqp_vec* rp;
     lfpsqp_vec* Utr;
+    lfpsqp_vec* w; /* N-vector, only for a stacked basis (the diagonal block of Q'r); else NULL */
 } lfpsqp_projcg_work;
 
 #define LFPSQP_PROJCG_WANT_LAMBDA 1 /* compute lambda = U'(b - A x) (src/projcg.jl:115-118) */

@@ -8,3 +8,5 @@ from .device import (Context, DeviceMatrix, DeviceVector, amax, axpby, dot, gemv
                      waxpby)
 from .projcg import DeviceBasis, DiagOperator, ProjCGWork, projcg_  # noqa: F401
 from .factorize import gram, ksvd_, orthonormalize_, rmul  # noqa: F401
+from .inequality import (InequalityData, InequalityDecomp, InequalityDecompProject, StackedVector, calculate_h_,  # noqa: F401
+                         generate_initial_y_, half_stride, inequality_gradient_, y_retract_)

@@ -25,8 +25,12 @@ class Basis(C.Structure):  # lfpsqp_basis
     _fields_ = [("Z", P), ("ncols", c_i64), ("Dx", P), ("Dy", P), ("sx", P), ("sy", P)]
 
 
+class IneqData(C.Structure):  # lfpsqp_ineq_data
+    _fields_ = [("q", P), ("r", P), ("s", P), ("t", P), ("n", c_i64)]
+
+
 class ProjCGWorkC(C.Structure):  # lfpsqp_projcg_work
-    _fields_ = [("g", P), ("d", P), ("rp", P), ("Utr", P)]
+    _fields_ = [("g", P), ("d", P), ("rp", P), ("Utr", P), ("w", P)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, P, P, c_i64, C.c_int, P)
@@ -66,6 +70,13 @@ _SIGS = {
     "lfpsqp_waxpby": [P, c_dbl, P, c_dbl, P, P],
     "lfpsqp_vmul": [P, P, P, P],
     "lfpsqp_allreduce": [P, P, c_i64],
+    "lfpsqp_ineq_data_build": [P, P, P, P, P, P, P],
+    "lfpsqp_generate_initial_y": [P, P, C.POINTER(IneqData)],
+    "lfpsqp_calculate_h": [P, P, P, C.POINTER(IneqData), PD],
+    "lfpsqp_inequality_gradient": [P, P, C.POINTER(IneqData), P, P, P, P, P],
+    "lfpsqp_y_retract": [P, P, P, C.POINTER(IneqData)],
+    "lfpsqp_q_gemv_t": [P, C.POINTER(Basis), P, P, P],
+    "lfpsqp_q_gemv_n": [P, C.POINTER(Basis), c_dbl, P, P, c_dbl, P],
     "lfpsqp_gram": [P, P, c_i64, P, P],
     "lfpsqp_rmul": [P, P, c_i64, P, c_i64, P],
     "lfpsqp_factorize": [P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],
@@ -100,6 +111,8 @@ class Library:
         self.lib.lfpsqp_last_error.argtypes = [P]
         self.lib.lfpsqp_vec_len.restype = c_i64
         self.lib.lfpsqp_vec_len.argtypes = [P]
+        self.lib.lfpsqp_half_stride.restype = c_i64
+        self.lib.lfpsqp_half_stride.argtypes = [c_i64]
         for name, sig in _SIGS.items():
             fn = getattr(self.lib, name)
             fn.restype = C.c_int

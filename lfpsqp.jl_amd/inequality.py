@@ -1,0 +1,128 @@
+"""Bound manifolds on the device (reference src/inequality_helper.jl and
+src/retractions.jl:451-500).  Names and argument order mirror the reference; arrays are
+device buffers.  ``xaug = [x; y]`` vectors use the stacked layout of include/lfpsqp_hip.h:
+x-half at [0, N), y-half at [hs, hs+N)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .device import Context, DeviceMatrix, DeviceVector
+
+
+def half_stride(ctx: Context, N: int) -> int:
+    return int(ctx.L.lfpsqp_half_stride(N))
+
+
+class StackedVector(DeviceVector):
+    """A length-2N ``[x; y]`` vector of the reference, both halves tile-aligned on the device."""
+
+    def __init__(self, ctx: Context, N: int):
+        self.N = int(N)
+        self.hs = half_stride(ctx, N)
+        super().__init__(ctx, self.hs + self.N)
+
+    def upload2(self, host):
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        assert host.size == 2 * self.N
+        self.upload(host[:self.N], 0)
+        self.upload(host[self.N:], self.hs)
+        return self
+
+    def download2(self) -> np.ndarray:
+        return np.concatenate([self.download(self.N, 0), self.download(self.N, self.hs)])
+
+
+class InequalityData:
+    """InequalityData(xl, xu) (src/inequality_helper.jl:39-89), device-resident q, r, s, t."""
+
+    def __init__(self, ctx: Context, xl, xu):
+        xl = np.asarray(xl, dtype=np.float64)
+        xu = np.asarray(xu, dtype=np.float64)
+        if len(xl) != len(xu):
+            raise ValueError("xl and xu are of different lengths")
+        self.ctx, self.n = ctx, len(xl)
+        self.q, self.r, self.s, self.t = (DeviceVector(ctx, self.n) for _ in range(4))
+        dxl, dxu = ctx.vector(self.n, xl), ctx.vector(self.n, xu)
+        ctx.check(ctx.L.lfpsqp_ineq_data_build(ctx.h, dxl.h, dxu.h, self.q.h, self.r.h, self.s.h, self.t.h))
+        dxl.free()
+        dxu.free()
+
+    def _c(self):
+        return _capi.IneqData(self.q.h, self.r.h, self.s.h, self.t.h, self.n)
+
+
+def generate_initial_y_(xaug: StackedVector, idata: InequalityData):
+    c = xaug.ctx
+    d = idata._c()
+    c.check(c.L.lfpsqp_generate_initial_y(c.h, xaug.h, C.byref(d)))
+    return xaug
+
+
+def calculate_h_(h: DeviceVector, xaug: StackedVector, idata: InequalityData, want_max: bool = True):
+    """h[:N] = bound-constraint values; returns norm(h, Inf) (None if not wanted)."""
+    c = xaug.ctx
+    d = idata._c()
+    hm = C.c_double()
+    c.check(c.L.lfpsqp_calculate_h(c.h, h.h, xaug.h, C.byref(d), C.byref(hm) if want_max else None))
+    return hm.value if want_max else None
+
+
+class InequalityDecomp:
+    """InequalityDecomp (src/inequality_helper.jl:10-19).  ``U`` of the reference (2N x M) is held
+    as the N x M matrix ``Z`` plus the row scalings sx = Dy^2, sy = -Dx*Dy."""
+
+    def __init__(self, ctx: Context, N: int, M: int, Jct: DeviceMatrix | None = None):
+        self.ctx, self.N, self.M = ctx, N, M
+        self.Z = DeviceMatrix(ctx, N, M)
+        self.Sigma = np.zeros(M)
+        self.Vt = np.zeros((M, M), order='F')
+        self.Dx, self.Dy, self.S, self.sx, self.sy = (DeviceVector(ctx, N) for _ in range(5))
+        self.Jct = Jct if Jct is not None else DeviceMatrix(ctx, N, M)
+        self.rank = M
+
+    def basis_c(self):
+        return _capi.Basis(self.Z.h, self.rank, self.Dx.h, self.Dy.h, self.sx.h, self.sy.h)
+
+
+def inequality_gradient_(idecomp: InequalityDecomp, xaug: StackedVector, idata: InequalityData):
+    c = xaug.ctx
+    d = idata._c()
+    c.check(c.L.lfpsqp_inequality_gradient(c.h, xaug.h, C.byref(d), idecomp.Dx.h, idecomp.Dy.h, idecomp.S.h, idecomp.sx.h,
+                                           idecomp.sy.h))
+
+
+def y_retract_(xnewaug: StackedVector, xaug: StackedVector, idata: InequalityData):
+    c = xaug.ctx
+    d = idata._c()
+    c.check(c.L.lfpsqp_y_retract(c.h, xnewaug.h, xaug.h, C.byref(d)))
+    return xnewaug
+
+
+class InequalityDecompProject:
+    """Q = [[diag Dx; diag Dy], U[:, :rank]] (src/inequality_helper.jl:25-27, 161-212).
+    Coefficient vectors [w; t] are kept as two device vectors: w (N) and t (rank)."""
+
+    def __init__(self, idecomp: InequalityDecomp):
+        self.idecomp = idecomp
+
+    @property
+    def ncols(self):
+        return self.idecomp.rank
+
+    def _c(self):
+        return self.idecomp.basis_c()
+
+    def mul_t(self, w: DeviceVector, t: DeviceVector, v: StackedVector):
+        """[w; t] = Q' v."""
+        c = v.ctx
+        b = self._c()
+        c.check(c.L.lfpsqp_q_gemv_t(c.h, C.byref(b), v.h, w.h, t.h))
+
+    def mul_n(self, y: StackedVector, w: DeviceVector | None, t: DeviceVector, alpha=1.0, beta=0.0):
+        """y = alpha Q [w; t] + beta y."""
+        c = y.ctx
+        b = self._c()
+        c.check(c.L.lfpsqp_q_gemv_n(c.h, C.byref(b), float(alpha), w.h if w is not None else None, t.h, float(beta), y.h))

@@ -84,11 +84,12 @@ class ProjCGWork:
     def __init__(self, ctx: Context, n: int, m: int):
         self.g, self.d, self.rp = (DeviceVector(ctx, n) for _ in range(3))
         self.Utr = DeviceVector(ctx, max(m, 1))
+        self.w = None
         # extra scratch for the generic (unfused) path, allocated on demand
         self._extra = None
 
     def _c(self):
-        return _capi.ProjCGWorkC(self.g.h, self.d.h, self.rp.h, self.Utr.h)
+        return _capi.ProjCGWorkC(self.g.h, self.d.h, self.rp.h, self.Utr.h, self.w.h if self.w is not None else None)
 
 
 def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c: DeviceVector | None,

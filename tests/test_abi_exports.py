@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported(built):
     for name in names:
         assert hasattr(built.lib, name), f"{name} declared in include/lfpsqp_hip.h but not exported"
     # and the ctypes table binds exactly the declared surface
-    assert set(_capi._SIGS) | {"lfpsqp_last_error", "lfpsqp_vec_len"} == set(names)
+    assert set(_capi._SIGS) | {"lfpsqp_last_error", "lfpsqp_vec_len", "lfpsqp_half_stride"} == set(names)
 
 
 def test_code_object_targets_gfx950(built):

@@ -1,0 +1,110 @@
+"""Device versions of the reference's test/test_inequalities.jl, checked against the oracle."""
+import numpy as np
+import pytest
+
+import lfpsqp_jl_amd as L
+from oracle import lfpsqp_ref as R
+from oracle import synth
+
+
+def _setup(ctx, n, m, seed=7):
+    rng = np.random.default_rng(seed)
+    i = np.arange(n)
+    kind = i % 4                                   # none / lower / upper / both (test_inequalities.jl:6-9)
+    lo = rng.standard_normal(n) - 1.0
+    hi = lo + 0.5 + 2 * rng.random(n)
+    xl = np.where((kind == 1) | (kind == 3), lo, -np.inf)
+    xu = np.where((kind == 2) | (kind == 3), hi, np.inf)
+    x = np.where(kind == 0, rng.standard_normal(n),
+                 np.where(kind == 1, lo + 2 * rng.random(n), np.where(kind == 2, hi - 2 * rng.random(n), lo + rng.random(n) * (hi - lo))))
+    xaug = np.zeros(2 * n)
+    xaug[:n] = x
+    idata0 = R.InequalityData(xl, xu)
+    R.generate_initial_y_(xaug, idata0)
+    idata = L.InequalityData(ctx, xl, xu)
+    X = L.StackedVector(ctx, n).upload2(xaug)
+    return rng, xl, xu, xaug, idata0, idata, X
+
+
+@pytest.mark.parametrize("n,m", [(16, 5), (1027, 9), (3000, 4)])
+def test_inequality_data_y_h_gradient(dev_ctx, n, m):
+    ctx = dev_ctx
+    rng, xl, xu, xaug, idata0, idata, X = _setup(ctx, n, m)
+    for name in "qrst":
+        np.testing.assert_array_equal(getattr(idata, name).download(), getattr(idata0, name))
+    # generate_initial_y! on the device
+    X2 = L.StackedVector(ctx, n).upload2(np.concatenate([xaug[:n], np.zeros(n)]))
+    L.generate_initial_y_(X2, idata)
+    np.testing.assert_allclose(X2.download2(), xaug, rtol=1e-15, atol=1e-15)
+    # calculate_h!
+    h = ctx.vector(n)
+    hmax = L.calculate_h_(h, X, idata)
+    c0 = np.zeros(n + m)
+    R.calculate_h_(c0, xaug, idata0)
+    np.testing.assert_allclose(h.download(), c0[:n], atol=4e-15)
+    assert hmax == pytest.approx(np.abs(h.download()).max(), abs=0) and hmax < 1e-14
+    # inequality_gradient!
+    idc0 = R.InequalityDecomp(None, None, None, np.empty(n), np.empty(n), np.empty(n), None, m)
+    R.inequality_gradient_(idc0, xaug, idata0)
+    idc = L.InequalityDecomp(ctx, n, m)
+    L.inequality_gradient_(idc, X, idata)
+    np.testing.assert_allclose(idc.Dx.download(), idc0.Dx, rtol=1e-15, atol=1e-16)
+    np.testing.assert_allclose(idc.Dy.download(), idc0.Dy, rtol=1e-15, atol=1e-16)
+    np.testing.assert_allclose(idc.S.download(), idc0.S, rtol=1e-15)
+    np.testing.assert_allclose(idc.sx.download(), idc0.Dy ** 2, rtol=1e-15, atol=1e-16)
+    np.testing.assert_allclose(idc.sy.download(), -idc0.Dx * idc0.Dy, rtol=1e-15, atol=1e-16)
+
+
+@pytest.mark.parametrize("n,m", [(16, 5), (2050, 12)])
+def test_projection_operator_and_y_retraction(dev_ctx, n, m):
+    """test_inequalities.jl:92-141 (Q mul!) and :180-199 (y_retract!) against the oracle's operators."""
+    ctx = dev_ctx
+    rng, xl, xu, xaug, idata0, idata, X = _setup(ctx, n, m)
+    Jh = np.asfortranarray(rng.standard_normal((n, m)))
+    # oracle decomposition (dgesvd of PJct)
+    idc0 = R.InequalityDecomp(np.empty((2 * n, m), order='F'), np.empty(m), np.empty((m, m), order='F'),
+                              np.empty(n), np.empty(n), np.empty(n), Jh, m)
+    R.inequality_gradient_(idc0, xaug, idata0)
+    PJ = np.asfortranarray(np.vstack([(1 - idc0.Dx ** 2)[:, None] * Jh, (-idc0.Dy * idc0.Dx)[:, None] * Jh]))
+    R.ksvd_(PJ, idc0.U, idc0.Sigma, idc0.Vt)
+    P0 = R.InequalityDecompProject(idc0)
+    # device decomposition
+    idc = L.InequalityDecomp(ctx, n, m, ctx.matrix(n, m, Jh))
+    L.inequality_gradient_(idc, X, idata)
+    w2 = ctx.vector(n, idc0.Dy ** 2)
+    idc.Sigma, idc.Vt, idc.rank = L.ksvd_(idc.Jct, idc.Z, w2=w2)
+    assert idc.rank == m
+    np.testing.assert_allclose(idc.Sigma, idc0.Sigma, rtol=1e-11)
+    P = L.InequalityDecompProject(idc)
+    # projector I - QQ' applied to a random vector must agree (basis-rotation invariant)
+    d = rng.standard_normal(2 * n)
+    tmp0 = np.zeros(n + m)
+    R.mul_(tmp0, R.adj(P0), d)
+    d0 = d.copy()
+    R.mul_(d0, P0, tmp0, -1.0, 1.0)
+    D = L.StackedVector(ctx, n).upload2(d)
+    w, t = ctx.vector(n), ctx.vector(m)
+    P.mul_t(w, t, D)
+    np.testing.assert_allclose(w.download(), tmp0[:n], atol=1e-14)
+    np.testing.assert_allclose(np.linalg.norm(t.download()), np.linalg.norm(tmp0[n:]), rtol=1e-11)
+    P.mul_n(D, w, t, -1.0, 1.0)
+    np.testing.assert_allclose(D.download2(), d0, atol=1e-12)
+    # the gap between the halves stays zero
+    if D.hs > n:
+        assert np.all(D.download(D.hs - n, n) == 0.0)
+    # alpha/beta form with w = None (Newton-retraction update)
+    Y = L.StackedVector(ctx, n).upload2(np.ones(2 * n))
+    P.mul_n(Y, None, t, 2.0, 3.0)
+    Zh = idc.Z.download()
+    Ufull = np.vstack([idc.sx.download()[:, None] * Zh, idc.sy.download()[:, None] * Zh])
+    np.testing.assert_allclose(Y.download2(), 2 * Ufull @ t.download() + 3, atol=1e-12)
+    # y_retract! after a tangent step (test_inequalities.jl:180-199)
+    xnew0 = xaug + d0
+    R.y_retract_(xnew0, xaug, idata0)
+    Xn = L.StackedVector(ctx, n).upload2(xaug + d0)
+    L.y_retract_(Xn, X, idata)
+    got = Xn.download2()
+    np.testing.assert_allclose(got, xnew0, rtol=1e-12, atol=1e-12)
+    h = ctx.vector(n)
+    assert L.calculate_h_(h, Xn, idata) < 1e-11
+    np.testing.assert_array_equal(X.download2(), xaug)
