@@ -89,7 +89,8 @@ int lfpsqp_mat_copy(lfpsqp_ctx* ctx, lfpsqp_mat* dst, const lfpsqp_mat* src);
  * M[i,j] = scale * u(seed, j*n_global + row0 + i)  (splitmix64-finaliser hash in [-1,1));
  * a power-of-two scale keeps the values bit-identical to the numpy generator */
 int lfpsqp_vec_hash_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, uint64_t seed, int64_t offset, double scale, double shift);
-int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global, double scale);
+int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global, double scale, int64_t nrows,
+                         int64_t ncols); /* only the leading nrows x ncols block is written */
 
 /* ---- BLAS-1/2 primitives on the tall-skinny layout ------------------------ */
 /* Replace the reference's mul!/gemv!/kgemv!/dot/norm/axpy!/broadcast call sites
@@ -101,6 +102,8 @@ int lfpsqp_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfp
 /* y = alpha * M[:, 0:ncols] * t + beta * y    (kgemv!('N', ...); mul!(y, U, t, alpha, beta)) */
 int lfpsqp_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, double alpha, const lfpsqp_vec* t, double beta, lfpsqp_vec* y);
 int lfpsqp_dot(lfpsqp_ctx* ctx, const lfpsqp_vec* x, const lfpsqp_vec* y, double* out);  /* dot(x, y) */
+/* dot over the first `count` local entries only (norm(view(step, 1:n)), src/linesearch.jl:66) */
+int lfpsqp_dot_head(lfpsqp_ctx* ctx, const lfpsqp_vec* x, const lfpsqp_vec* y, int64_t count, double* out);
 int lfpsqp_nrm2(lfpsqp_ctx* ctx, const lfpsqp_vec* x, double* out);                      /* norm(x) */
 int lfpsqp_amax(lfpsqp_ctx* ctx, const lfpsqp_vec* x, double* out);                      /* norm(x, Inf) */
 int lfpsqp_axpby(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double b, lfpsqp_vec* y); /* y = a*x + b*y */
@@ -108,6 +111,12 @@ int lfpsqp_axpby(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double b, lfpsq
 int lfpsqp_waxpby(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double b, const lfpsqp_vec* y, lfpsqp_vec* z);
 /* y = d .* x (diagonal operator apply; z may alias) */
 int lfpsqp_vmul(lfpsqp_ctx* ctx, const lfpsqp_vec* d, const lfpsqp_vec* x, lfpsqp_vec* y);
+/* v[offset : offset+count) = value */
+int lfpsqp_vec_fill_range(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t offset, int64_t count, double value);
+/* y[i] = a*x[i] + c for i < count (entries >= count untouched): gradients of quadratic objectives */
+int lfpsqp_affine_head(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double c, int64_t count, lfpsqp_vec* y);
+/* *out = sum_{i < count} (x[i] - c)^2   (all-reduced): quadratic objectives */
+int lfpsqp_sumsq_shift(lfpsqp_ctx* ctx, const lfpsqp_vec* x, int64_t count, double c, double* out);
 /* sum-all-reduce a replicated-partials device vector across ranks (no-op for 1 rank) */
 int lfpsqp_allreduce(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t count);
 
@@ -137,6 +146,13 @@ int lfpsqp_calculate_h(lfpsqp_ctx* ctx, lfpsqp_vec* h, const lfpsqp_vec* xaug, c
  * basis, sx = Dy.^2 and sy = -Dx.*Dy (so U = [sx .* Z; sy .* Z], see lfpsqp_factorize) */
 int lfpsqp_inequality_gradient(lfpsqp_ctx* ctx, const lfpsqp_vec* xaug, const lfpsqp_ineq_data* id, lfpsqp_vec* Dx, lfpsqp_vec* Dy,
                                lfpsqp_vec* S, lfpsqp_vec* sx, lfpsqp_vec* sy);
+/* calculate_lambda_kkt! second half (src/inequality_helper.jl:302-305):
+ * lamy = (-Dx .* (Jct * lam) + w) ./ S   with lam (device, ncols) and w = (Q'd)[0:N] */
+int lfpsqp_calculate_lambda_y(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, int64_t ncols, const lfpsqp_vec* lam, const lfpsqp_vec* Dx,
+                              const lfpsqp_vec* S, const lfpsqp_vec* w, lfpsqp_vec* lamy);
+/* augmented_hess_lag_vec! for a diagonal Lagrangian Hessian (src/inequality_helper.jl:144-158):
+ * a (stacked) = [hx + 2 lamy.*q ; 2 lamy.*s]   (hx = diag of the user's Hessian on the x-half) */
+int lfpsqp_augmented_diag(lfpsqp_ctx* ctx, const lfpsqp_vec* hx, const lfpsqp_vec* lamy, const lfpsqp_ineq_data* id, lfpsqp_vec* a);
 /* y_retract!(xnewaug, xaug, idata) (src/retractions.jl:451-500) */
 int lfpsqp_y_retract(lfpsqp_ctx* ctx, lfpsqp_vec* xnewaug, const lfpsqp_vec* xaug, const lfpsqp_ineq_data* id);
 
@@ -214,12 +230,52 @@ typedef struct lfpsqp_projcg_work {
 
 /* projcg!(x, lambda, A, U, b, c; tol, maxit, work) -> (iters, nr).
  * c == NULL means c = 0 (always the case in optimize, src/optimize.jl:213,368,371).
- * n_global = length(b) summed over ranks; the loop bound is min(maxit, n_global + m).
+ * n_global = length(b) of the reference summed over ranks (2N for a stacked basis); the loop
+ * bound is min(maxit, length(b) + length(c)).  For a stacked basis all n-vectors (x, b, work,
+ * A.dg) are stacked [x-half | gap | y-half], c must be NULL and lambda (if wanted) has length
+ * >= N + ncols and receives [Dx.*rx + Dy.*ry ; U'r] like the reference's lambda.
  * Exit semantics are the reference's: negative curvature => x = d/||d||,
  * lambda = NaN, *nr = +Inf; rg <= 0 => break; nr < tol => break. */
 int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A,
                   const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
                   int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr);
+
+/* ---- retractions (src/retractions.jl) ---------------------------------------------- */
+/* Device-resident equality constraints of the BASELINE configs:
+ *     c(x) = [ J x - b ;  sum_{i < n_x} x_i^2 - R2 - x[slack_row] ]
+ * Jct is the N x M constraint-gradient matrix (the reference's Jct, src/optimize.jl:190,284);
+ * its first m_lin columns are the constant gradients of the linear equalities; when has_ball,
+ * column m_lin is the ball gradient [2x; -1] (refreshed by lfpsqp_constraints_jac) and the
+ * inequality x'x <= R2 has been turned into an equality with a slack variable
+ * (src/optimize.jl:23-51).  n_x / slack_row are LOCAL row indices on this rank
+ * (slack_row = -1 if another rank owns the slack variable). */
+typedef struct lfpsqp_constraints {
+    const lfpsqp_mat* Jct;
+    int64_t m_lin;
+    const double* b; /* host, m_lin */
+    int has_ball;
+    double R2;
+    int64_t n_x;
+    int64_t slack_row;
+} lfpsqp_constraints;
+/* c!(cval, x): cval (host, m_lin + has_ball).  x has >= rows(Jct) entries (the x-half of a
+ * stacked vector is fine). */
+int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval);
+/* jac!(J, cval, x): refreshes the x-dependent column(s) of Jct in place and evaluates cval */
+int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval);
+/* A user c!: x is the DEVICE vector (download it if the function is host code); return 0. */
+typedef int (*lfpsqp_cfun)(void* user, const lfpsqp_vec* x, double* cval);
+
+/* retract!(cval, xnew, c!, xtilde, x, method::NR) (src/retractions.jl:75-177): Newton-Raphson on
+ * c(xtilde + U delta) with the inverse Jacobian Sigma^-1 Vt frozen at x and good-Broyden updates.
+ * U / Sigma / Vt are the factors of lfpsqp_factorize (NR.U, NR.Sigma, NR.Vt); idata != NULL means
+ * bounds are present (NR.ineq): vectors are stacked and y_retract! runs before every c!.
+ * Exactly one of cons / cfun is used (cfun wins if non-NULL).
+ * Outputs: xnew, cval[m] (== c!(xnew) on exit), *flag (0 ok, 1 = maxiter reached), *iters. */
+int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m,
+                      const lfpsqp_constraints* cons, lfpsqp_cfun cfun, void* cuser, const lfpsqp_ineq_data* idata,
+                      const lfpsqp_vec* xtilde, const lfpsqp_vec* x, lfpsqp_vec* xnew, double tol, int64_t maxiter, double* cval,
+                      int* flag, int64_t* iters);
 
 /* per-kernel-family device time (ms) accumulated by the last lfpsqp_projcg call when
  * the context was created with profiling on (lfpsqp_ctx_set_profiling); used by

@@ -29,6 +29,13 @@ class IneqData(C.Structure):  # lfpsqp_ineq_data
     _fields_ = [("q", P), ("r", P), ("s", P), ("t", P), ("n", c_i64)]
 
 
+class Constraints(C.Structure):  # lfpsqp_constraints
+    _fields_ = [("Jct", P), ("m_lin", c_i64), ("b", P), ("has_ball", C.c_int), ("R2", c_dbl), ("n_x", c_i64), ("slack_row", c_i64)]
+
+
+CFUN = C.CFUNCTYPE(C.c_int, P, P, PD)
+
+
 class ProjCGWorkC(C.Structure):  # lfpsqp_projcg_work
     _fields_ = [("g", P), ("d", P), ("rp", P), ("Utr", P), ("w", P)]
 
@@ -60,23 +67,33 @@ _SIGS = {
     "lfpsqp_mat_download": [P, P, c_i64, c_i64, P, c_i64],
     "lfpsqp_mat_copy": [P, P, P],
     "lfpsqp_vec_hash_fill": [P, P, C.c_uint64, c_i64, c_dbl, c_dbl],
-    "lfpsqp_mat_hash_fill": [P, P, C.c_uint64, c_i64, c_i64, c_dbl],
+    "lfpsqp_mat_hash_fill": [P, P, C.c_uint64, c_i64, c_i64, c_dbl, c_i64, c_i64],
     "lfpsqp_gemv_t": [P, P, c_i64, P, P],
     "lfpsqp_gemv_n": [P, P, c_i64, c_dbl, P, c_dbl, P],
     "lfpsqp_dot": [P, P, P, PD],
+    "lfpsqp_dot_head": [P, P, P, c_i64, PD],
     "lfpsqp_nrm2": [P, P, PD],
     "lfpsqp_amax": [P, P, PD],
     "lfpsqp_axpby": [P, c_dbl, P, c_dbl, P],
     "lfpsqp_waxpby": [P, c_dbl, P, c_dbl, P, P],
     "lfpsqp_vmul": [P, P, P, P],
+    "lfpsqp_vec_fill_range": [P, P, c_i64, c_i64, c_dbl],
+    "lfpsqp_affine_head": [P, c_dbl, P, c_dbl, c_i64, P],
+    "lfpsqp_sumsq_shift": [P, P, c_i64, c_dbl, PD],
     "lfpsqp_allreduce": [P, P, c_i64],
     "lfpsqp_ineq_data_build": [P, P, P, P, P, P, P],
     "lfpsqp_generate_initial_y": [P, P, C.POINTER(IneqData)],
     "lfpsqp_calculate_h": [P, P, P, C.POINTER(IneqData), PD],
     "lfpsqp_inequality_gradient": [P, P, C.POINTER(IneqData), P, P, P, P, P],
     "lfpsqp_y_retract": [P, P, P, C.POINTER(IneqData)],
+    "lfpsqp_calculate_lambda_y": [P, P, c_i64, P, P, P, P, P],
+    "lfpsqp_augmented_diag": [P, P, P, C.POINTER(IneqData), P],
     "lfpsqp_q_gemv_t": [P, C.POINTER(Basis), P, P, P],
     "lfpsqp_q_gemv_n": [P, C.POINTER(Basis), c_dbl, P, P, c_dbl, P],
+    "lfpsqp_constraints_eval": [P, C.POINTER(Constraints), P, PD],
+    "lfpsqp_constraints_jac": [P, C.POINTER(Constraints), P, P, PD],
+    "lfpsqp_retract_nr": [P, C.POINTER(Basis), P, P, c_i64, C.POINTER(Constraints), CFUN, P, C.POINTER(IneqData), P, P, P, c_dbl, c_i64,
+                          PD, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_gram": [P, P, c_i64, P, P],
     "lfpsqp_rmul": [P, P, c_i64, P, c_i64, P],
     "lfpsqp_factorize": [P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],
@@ -95,7 +112,7 @@ def header_functions(header: str = HEADER):
     """Names of every function include/lfpsqp_hip.h declares."""
     text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(lfpsqp_[a-z0-9_]+)\s*\(", text)) - {"lfpsqp_allreduce_fn"})
+    return sorted(set(re.findall(r"\b(lfpsqp_[a-z0-9_]+)\s*\(", text)) - {"lfpsqp_allreduce_fn", "lfpsqp_cfun"})
 
 
 class Library:

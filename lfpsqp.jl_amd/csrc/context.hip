@@ -44,6 +44,21 @@ int ensure_small(lfpsqp_ctx* ctx, size_t doubles) {
     return 0;
 }
 
+int ensure_mvec(lfpsqp_ctx* ctx, size_t doubles) {
+    if (doubles <= ctx->m_cap) return 0;
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_m) LF_HIP(ctx, hipFree(ctx->d_m));
+    if (ctx->h_m) LF_HIP(ctx, hipHostFree(ctx->h_m));
+    ctx->d_m = nullptr; ctx->h_m = nullptr; ctx->m_cap = 0;
+    const size_t cap = (size_t)round_up((int64_t)doubles + 64, kTileRows);
+    LF_HIP(ctx, hipMalloc((void**)&ctx->d_m, cap * sizeof(double)));
+    LF_HIP(ctx, hipMemsetAsync(ctx->d_m, 0, cap * sizeof(double), ctx->stream));
+    LF_HIP(ctx, hipHostMalloc((void**)&ctx->h_m, cap * sizeof(double)));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->m_cap = cap;
+    return 0;
+}
+
 int allreduce_dev(lfpsqp_ctx* ctx, double* buf, int64_t count, int op) {
     Comm& c = ctx->comm;
     if (c.nranks <= 1 || count == 0) return 0;
@@ -149,6 +164,8 @@ int lfpsqp_ctx_destroy(lfpsqp_ctx* ctx) {
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
     if (ctx->part) (void)hipFree(ctx->part);
     if (ctx->small) (void)hipFree(ctx->small);
+    if (ctx->d_m) (void)hipFree(ctx->d_m);
+    if (ctx->h_m) (void)hipHostFree(ctx->h_m);
     if (ctx->scal) (void)hipFree(ctx->scal);
     if (ctx->istat) (void)hipFree(ctx->istat);
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);

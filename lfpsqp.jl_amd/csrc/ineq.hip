@@ -191,6 +191,36 @@ struct QApplyE {  // y = alpha*[Dx.*w + sx.*acc ; Dy.*w + sy.*acc] + beta*y
     }
 };
 
+struct LambdaYE {  // lamy = (w - Dx.*acc) ./ S
+    const double *Dx, *S, *w;
+    double* out;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double*) const {
+        const double2 dx = ld2(Dx + r), ss = ld2(S + r), ww = ld2(w + r);
+        // reference order: lamy = Jct*lam ; lamy *= -Dx/S ; lamy += w/S
+        const double2 o = make_double2(acc.x * (-1.0 * dx.x / ss.x) + ww.x / ss.x, acc.y * (-1.0 * dx.y / ss.y) + ww.y / ss.y);
+        if (v1) st2(out + r, o);
+        else if (v0) out[r] = o.x;
+    }
+};
+
+struct AugDiagF {
+    const double *hx, *lamy;
+    IneqD id;
+    double* a;
+    int64_t hs;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void one(int64_t i) const {
+        const double ly = lamy[i];
+        a[i] = hx[i] + 2.0 * ly * id.q[i];
+        a[hs + i] = 2.0 * ly * id.s[i];
+    }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        if (v0) one(i);
+        if (v1) one(i + 1);
+    }
+};
+
 }  // namespace lfpsqp
 
 using namespace lfpsqp;
@@ -236,6 +266,21 @@ int lfpsqp_inequality_gradient(lfpsqp_ctx* ctx, const lfpsqp_vec* xaug, const lf
     LF_ARG(ctx, xaug->n == hs + id->n);
     return run_vec<IneqGradF, 0, NoPost>(ctx, id->n, IneqGradF{xaug->p, hs, view(id), Dx->p, Dy->p, S->p, sx ? sx->p : nullptr, sy ? sy->p : nullptr},
                                          0u, nullptr, NoPost());
+}
+
+int lfpsqp_calculate_lambda_y(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, int64_t ncols, const lfpsqp_vec* lam, const lfpsqp_vec* Dx,
+                              const lfpsqp_vec* S, const lfpsqp_vec* w, lfpsqp_vec* lamy) {
+    LF_ARG(ctx, ctx && Jct && lam && Dx && S && w && lamy && ncols >= 0 && ncols <= Jct->m && lam->n >= ncols);
+    const int64_t N = Jct->n;
+    LF_ARG(ctx, Dx->n == N && S->n == N && w->n == N && lamy->n == N);
+    return run_gemv_n<LambdaYE, 0, NoPost>(ctx, Jct, (int)ncols, N, lam->p, LambdaYE{Dx->p, S->p, w->p, lamy->p}, nullptr, NoPost());
+}
+
+int lfpsqp_augmented_diag(lfpsqp_ctx* ctx, const lfpsqp_vec* hx, const lfpsqp_vec* lamy, const lfpsqp_ineq_data* id, lfpsqp_vec* a) {
+    LF_ARG(ctx, ctx && hx && lamy && a && ineq_ok(id) && hx->n == id->n && lamy->n == id->n);
+    const int64_t hs = lfpsqp_half_stride(id->n);
+    LF_ARG(ctx, a->n == hs + id->n);
+    return run_vec<AugDiagF, 0, NoPost>(ctx, id->n, AugDiagF{hx->p, lamy->p, view(id), a->p, hs}, 0u, nullptr, NoPost());
 }
 
 int lfpsqp_y_retract(lfpsqp_ctx* ctx, lfpsqp_vec* xnewaug, const lfpsqp_vec* xaug, const lfpsqp_ineq_data* id) {

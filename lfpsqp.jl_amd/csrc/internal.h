@@ -53,6 +53,10 @@ struct lfpsqp_ctx {
     // small replicated device scratch (Gram matrices, m x m factors)
     double* small = nullptr;
     size_t small_cap = 0;
+    // replicated m-vector staging: device + pinned host
+    double* d_m = nullptr;
+    double* h_m = nullptr;
+    size_t m_cap = 0;
     // small device blocks: solver scalars / status, and their pinned host mirrors
     double* scal = nullptr;    // 64 doubles
     int64_t* istat = nullptr;  // 16 int64
@@ -75,6 +79,7 @@ namespace lfpsqp {
 int set_err(lfpsqp_ctx* ctx, int code, const char* fmt, ...);
 int ensure_part(lfpsqp_ctx* ctx, size_t doubles);
 int ensure_small(lfpsqp_ctx* ctx, size_t doubles);
+int ensure_mvec(lfpsqp_ctx* ctx, size_t doubles);   // d_m / h_m, each `doubles` long
 int allreduce_dev(lfpsqp_ctx* ctx, double* buf, int64_t count, int op = 0);  // in place, stream ordered; op 0 sum / 1 max; no-op for 1 rank
 
 // profiling helpers: bracket one launch of slot `s`

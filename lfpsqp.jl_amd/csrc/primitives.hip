@@ -95,6 +95,39 @@ struct FillF {
         else if (v0) x[i] = value;
     }
 };
+struct FillRangeF {
+    double* x;
+    int64_t lo, hi;
+    double value;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        if (v0 && i >= lo && i < hi) x[i] = value;
+        if (v1 && i + 1 >= lo && i + 1 < hi) x[i + 1] = value;
+    }
+};
+struct AffineHeadF {
+    double a, c;
+    const double* x;
+    double* y;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 xx = ld2(x + i);
+        if (v1) st2(y + i, make_double2(fma(a, xx.x, c), fma(a, xx.y, c)));
+        else if (v0) y[i] = fma(a, xx.x, c);
+    }
+};
+struct SumSqShiftF {
+    const double* x;
+    double c;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double2 a = ld2(x + i);
+        double s = 0.0;
+        if (v0) s = (a.x - c) * (a.x - c);
+        if (v1) s = fma(a.y - c, a.y - c, s);
+        red[0] += s;
+    }
+};
 struct HashVecF {  // x[i] = scale*u(seed, offset+i) + shift
     double* x;
     uint64_t seed;
@@ -148,12 +181,13 @@ int lfpsqp_vec_hash_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, uint64_t seed, int64_t 
     return run_vec<HashVecF, 0, NoPost>(ctx, v->n, HashVecF{v->p, seed, offset, scale, shift}, 0u, nullptr, NoPost());
 }
 
-int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global, double scale) {
-    LF_ARG(ctx, ctx && M && row0 >= 0 && n_global >= M->n);
-    if (M->n == 0 || M->m == 0) return 0;
-    LF_ARG(ctx, M->m <= 65535);
-    hipLaunchKernelGGL(hash_mat_kernel, dim3((unsigned)ntiles_of(M->n), (unsigned)M->m), dim3(kThreads), 0, ctx->stream, M->p, M->ld,
-                       M->n, seed, row0, n_global, scale);
+int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global, double scale, int64_t nrows,
+                         int64_t ncols) {
+    LF_ARG(ctx, ctx && M && row0 >= 0 && nrows >= 0 && nrows <= M->n && ncols >= 0 && ncols <= M->m && n_global >= nrows);
+    if (nrows == 0 || ncols == 0) return 0;
+    LF_ARG(ctx, ncols <= 65535);
+    hipLaunchKernelGGL(hash_mat_kernel, dim3((unsigned)ntiles_of(nrows), (unsigned)ncols), dim3(kThreads), 0, ctx->stream, M->p, M->ld,
+                       nrows, seed, row0, n_global, scale);
     LF_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -171,6 +205,12 @@ int lfpsqp_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, double al
 int lfpsqp_dot(lfpsqp_ctx* ctx, const lfpsqp_vec* x, const lfpsqp_vec* y, double* out) {
     LF_ARG(ctx, ctx && x && y && out && x->n == y->n);
     LF_TRY((run_vec<DotF, 1, NoPost>(ctx, x->n, DotF{x->p, y->p}, 0u, ctx->scal + 32, NoPost())));
+    return read_back(ctx, ctx->scal + 32, out, 1);
+}
+
+int lfpsqp_dot_head(lfpsqp_ctx* ctx, const lfpsqp_vec* x, const lfpsqp_vec* y, int64_t count, double* out) {
+    LF_ARG(ctx, ctx && x && y && out && count >= 0 && count <= x->n && count <= y->n);
+    LF_TRY((run_vec<DotF, 1, NoPost>(ctx, count, DotF{x->p, y->p}, 0u, ctx->scal + 32, NoPost())));
     return read_back(ctx, ctx->scal + 32, out, 1);
 }
 
@@ -202,6 +242,24 @@ int lfpsqp_vmul(lfpsqp_ctx* ctx, const lfpsqp_vec* d, const lfpsqp_vec* x, lfpsq
     LF_ARG(ctx, ctx && d && x && y && d->n == x->n && x->n == y->n);
     if (y->n == 0) return 0;
     return run_vec<VmulF, 0, NoPost>(ctx, y->n, VmulF{d->p, x->p, y->p}, 0u, nullptr, NoPost());
+}
+
+int lfpsqp_vec_fill_range(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t offset, int64_t count, double value) {
+    LF_ARG(ctx, ctx && v && offset >= 0 && count >= 0 && offset + count <= v->n);
+    if (count == 0) return 0;
+    return run_vec<FillRangeF, 0, NoPost>(ctx, offset + count, FillRangeF{v->p, offset, offset + count, value}, 0u, nullptr, NoPost());
+}
+
+int lfpsqp_affine_head(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double c, int64_t count, lfpsqp_vec* y) {
+    LF_ARG(ctx, ctx && x && y && count >= 0 && count <= x->n && count <= y->n);
+    if (count == 0) return 0;
+    return run_vec<AffineHeadF, 0, NoPost>(ctx, count, AffineHeadF{a, c, x->p, y->p}, 0u, nullptr, NoPost());
+}
+
+int lfpsqp_sumsq_shift(lfpsqp_ctx* ctx, const lfpsqp_vec* x, int64_t count, double c, double* out) {
+    LF_ARG(ctx, ctx && x && out && count >= 0 && count <= x->n);
+    LF_TRY((run_vec<SumSqShiftF, 1, NoPost>(ctx, count, SumSqShiftF{x->p, c}, 0u, ctx->scal + 32, NoPost())));
+    return read_back(ctx, ctx->scal + 32, out, 1);
 }
 
 int lfpsqp_allreduce(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t count) {

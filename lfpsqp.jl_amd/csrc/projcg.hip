@@ -201,6 +201,54 @@ struct NormalizeIntoF {  // x = d / sqrt(dd)    (:79)
     }
 };
 
+// ---- stacked (bound-constrained) variants: Q = [[diag Dx; diag Dy], [sx.*Z; sy.*Z]] -------
+// One workgroup row r of the N x M matrix Z serves BOTH halves of the 2N-vectors, so the
+// whole projection costs one pass over Z where the reference streams a 2N x M factor.
+struct StackD {
+    int64_t hs;
+    const double *Dx, *Dy, *sx, *sy;
+    double* w;  // N-vector: diagonal block of Q'rp
+};
+struct PcgStepVS {
+    PcgStepV p;
+    StackD k;
+    __device__ __forceinline__ bool skip() const { return p.skip(); }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double2 rx = p.load(r, v0, v1);                 // x-half: updates x, rp
+        const double2 ry = p.load(r + k.hs, v0, v1);          // y-half
+        const double2 dx = ld2(k.Dx + r), dy = ld2(k.Dy + r), ax = ld2(k.sx + r), ay = ld2(k.sy + r);
+        const double2 ww = make_double2(dx.x * rx.x + dy.x * ry.x, dx.y * rx.y + dy.y * ry.y);
+        if (v1) st2(k.w + r, ww);
+        else if (v0) k.w[r] = ww.x;
+        return make_double2(ax.x * rx.x + ay.x * ry.x, ax.y * rx.y + ay.y * ry.y);
+    }
+};
+struct ResidualVS {
+    ResidualV p;
+    StackD k;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double2 rx = p.load(r, v0, v1);
+        const double2 ry = p.load(r + k.hs, v0, v1);
+        const double2 dx = ld2(k.Dx + r), dy = ld2(k.Dy + r), ax = ld2(k.sx + r), ay = ld2(k.sy + r);
+        const double2 ww = make_double2(dx.x * rx.x + dy.x * ry.x, dx.y * rx.y + dy.y * ry.y);
+        if (v1) st2(k.w + r, ww);
+        else if (v0) k.w[r] = ww.x;
+        return make_double2(ax.x * rx.x + ay.x * ry.x, ax.y * rx.y + ay.y * ry.y);
+    }
+};
+struct PcgProjES {
+    PcgProjE p;
+    StackD k;
+    __device__ __forceinline__ bool skip() const { return p.skip(); }
+    __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
+        const double2 ww = ld2(k.w + r), dx = ld2(k.Dx + r), dy = ld2(k.Dy + r), ax = ld2(k.sx + r), ay = ld2(k.sy + r);
+        // (Q Q'rp) on the two halves; PcgProjE then forms gp = rp - that, stores g (and d), adds the dot terms
+        p.apply(r, make_double2(fma(ax.x, acc.x, dx.x * ww.x), fma(ax.y, acc.y, dx.y * ww.y)), v0, v1, red);
+        p.apply(r + k.hs, make_double2(fma(ay.x, acc.x, dy.x * ww.x), fma(ay.y, acc.y, dy.y * ww.y)), v0, v1, red);
+    }
+};
+
 static int snapshot(lfpsqp_ctx* ctx, int slot) {
     LF_HIP(ctx, hipMemcpyAsync(ctx->h_istat + 16 * slot, ctx->istat, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     LF_HIP(ctx, hipMemcpyAsync(ctx->h_scal + 64 * slot, ctx->scal, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -217,16 +265,26 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
                              const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
     LF_ARG(ctx, ctx && x && A && U && b && work && iters && nr);
     LF_ARG(ctx, work->g && work->d && work->rp && work->Utr);
-    if (U->Dx || U->Dy || U->sx || U->sy)
-        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "stacked (bound-constrained) basis: use lfpsqp_projcg_stacked");
-    const int64_t n = b->n;
+    const bool stacked = U->Dx != nullptr;
+    const int64_t nv = b->n;                       // length of the n-vectors (hs + N when stacked)
     const int m = (int)U->ncols;
-    LF_ARG(ctx, x->n == n && work->g->n == n && work->d->n == n && work->rp->n == n);
-    LF_ARG(ctx, m >= 0 && (m == 0 || (U->Z && U->Z->n == n && m <= U->Z->m && work->Utr->n >= m)));
-    LF_ARG(ctx, !A->dg || A->dg->n == n);
-    LF_ARG(ctx, !c || c->n >= m);
-    LF_ARG(ctx, !(flags & LFPSQP_PROJCG_WANT_LAMBDA) || (lambda && lambda->n >= m));
-    LF_ARG(ctx, n_global >= n);
+    LF_ARG(ctx, x->n == nv && work->g->n == nv && work->d->n == nv && work->rp->n == nv);
+    LF_ARG(ctx, m >= 0 && (m == 0 || (U->Z && m <= U->Z->m && work->Utr->n >= m)));
+    LF_ARG(ctx, !A->dg || A->dg->n == nv);
+    LF_ARG(ctx, n_global >= (stacked ? 0 : nv));
+    int64_t N = nv, hs = 0;                        // rows of Z
+    if (stacked) {
+        LF_ARG(ctx, U->Dy && U->sx && U->sy && work->w);
+        N = U->Dx->n;
+        hs = lfpsqp_half_stride(N);
+        LF_ARG(ctx, nv == hs + N && U->Dy->n == N && U->sx->n == N && U->sy->n == N && work->w->n == N && (m == 0 || U->Z->n == N));
+        if (c) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "stacked basis with c != 0 (never used by optimize, src/optimize.jl:368)");
+        LF_ARG(ctx, !(flags & LFPSQP_PROJCG_WANT_LAMBDA) || (lambda && lambda->n >= N + m));
+    } else {
+        LF_ARG(ctx, m == 0 || U->Z->n == nv);
+        LF_ARG(ctx, !c || c->n >= m);
+        LF_ARG(ctx, !(flags & LFPSQP_PROJCG_WANT_LAMBDA) || (lambda && lambda->n >= m));
+    }
 
     const AOpD Ad{A->a0, A->dg ? A->dg->p : nullptr};
     double* scal = ctx->scal;
@@ -236,8 +294,28 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     double* rp = work->rp->p;
     double* Utr = work->Utr->p;
     const lfpsqp_mat* Z = m > 0 ? U->Z : nullptr;
-    int64_t maxit_eff = maxit < n_global + m ? maxit : n_global + m;   // src/projcg.jl:71
+    const StackD sk = stacked ? StackD{hs, U->Dx->p, U->Dy->p, U->sx->p, U->sy->p, work->w->p} : StackD{0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // loop bound min(maxit, n + m) with the reference's n = length(b), m = length(c)   (src/projcg.jl:43-44,71)
+    const int64_t m_ref = stacked ? n_global / 2 + m : m;
+    int64_t maxit_eff = maxit < n_global + m_ref ? maxit : n_global + m_ref;
     if (maxit_eff < 0) maxit_eff = 0;
+
+    auto launch_residual = [&](double sgn, double* store, double* t_out) -> int {
+        const ResidualV rv{x->p, b->p, store, Ad, sgn};
+        if (stacked) return run_gemv_t(ctx, Z, m, N, ResidualVS{rv, StackD{hs, sk.Dx, sk.Dy, sk.sx, sk.sy, store ? sk.w : lambda->p}}, t_out);
+        return run_gemv_t(ctx, Z, m, N, rv, t_out);
+    };
+    auto launch_k2 = [&]() -> int {
+        const PcgStepV sv{x->p, d, g, rp, Ad, scal, istat};
+        if (stacked) return run_gemv_t(ctx, Z, m, N, PcgStepVS{sv, sk}, Utr, 1);
+        return run_gemv_t(ctx, Z, m, N, sv, Utr, 1);
+    };
+    auto launch_k3 = [&](int init) -> int {
+        const PcgProjE pe{rp, g, d, istat, init};
+        const PcgPost3 post{scal, istat, init};
+        if (stacked) return run_gemv_n<PcgProjES, 2, PcgPost3>(ctx, Z, m, N, Utr, PcgProjES{pe, sk}, scal + S_RPGP, post, init ? -1 : 2);
+        return run_gemv_n<PcgProjE, 2, PcgPost3>(ctx, Z, m, N, Utr, pe, scal + S_RPGP, post, init ? -1 : 2);
+    };
 
     hipLaunchKernelGGL((post_kernel<InitState>), dim3(1), dim3(1), 0, ctx->stream, scal, InitState{scal, istat, tol, maxit_eff});
     LF_LAUNCH_CHECK(ctx);
@@ -249,18 +327,16 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
         LF_TRY(lfpsqp_vec_fill(ctx, x, 0.0));
     }
     // r = A x - b (kept in rp), Utr = U' r, g = r - U Utr, d = -g, rg = g'g   (:56-62)
-    LF_TRY(run_gemv_t(ctx, Z, m, n, ResidualV{x->p, b->p, rp, Ad, 1.0}, Utr));
-    LF_TRY((run_gemv_n<PcgProjE, 2, PcgPost3>(ctx, Z, m, n, Utr, PcgProjE{rp, g, d, istat, 1}, scal + S_RPGP,
-                                               PcgPost3{scal, istat, 1})));
+    LF_TRY(launch_residual(1.0, rp, Utr));
+    LF_TRY(launch_k3(1));
 
     int64_t it = 0;
     bool done = false;
     while (!done && it < maxit_eff) {
-        LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, n, PcgDirF{d, g, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
+        LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, nv, PcgDirF{d, g, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
                                               PcgPost1{scal, istat}, 0)));
-        LF_TRY(run_gemv_t(ctx, Z, m, n, PcgStepV{x->p, d, g, rp, Ad, scal, istat}, Utr, 1));
-        LF_TRY((run_gemv_n<PcgProjE, 2, PcgPost3>(ctx, Z, m, n, Utr, PcgProjE{rp, g, d, istat, 0}, scal + S_RPGP,
-                                                   PcgPost3{scal, istat, 0}, 2)));
+        LF_TRY(launch_k2());
+        LF_TRY(launch_k3(0));
         LF_TRY(snapshot(ctx, (int)(it & 1)));
         if (it >= 1) {  // look at the status of the PREVIOUS iteration: the GPU is never left idle
             const int slot = (int)((it - 1) & 1);
@@ -277,12 +353,13 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     *nr = ctx->h_scal[64 * 2 + S_NR];
 
     if (status == ST_NEGCURV) {   // :77-82
-        LF_TRY((run_vec<SumSqF, 1, NoPost>(ctx, n, SumSqF{d}, 0u, scal + S_DD, NoPost())));
-        LF_TRY((run_vec<NormalizeIntoF, 0, NoPost>(ctx, n, NormalizeIntoF{x->p, d, scal + S_DD}, 0u, nullptr, NoPost())));
+        LF_TRY((run_vec<SumSqF, 1, NoPost>(ctx, nv, SumSqF{d}, 0u, scal + S_DD, NoPost())));
+        LF_TRY((run_vec<NormalizeIntoF, 0, NoPost>(ctx, nv, NormalizeIntoF{x->p, d, scal + S_DD}, 0u, nullptr, NoPost())));
         if (lambda) LF_TRY(lfpsqp_vec_fill(ctx, lambda, NAN));
         *nr = INFINITY;
-    } else if ((flags & LFPSQP_PROJCG_WANT_LAMBDA) && m > 0) {   // :115-118
-        LF_TRY(run_gemv_t(ctx, Z, m, n, ResidualV{x->p, b->p, nullptr, Ad, -1.0}, lambda->p));
+    } else if (flags & LFPSQP_PROJCG_WANT_LAMBDA) {   // :115-118  lambda = Q'(b - A x): [w (N); t (m)] when stacked
+        if (stacked) LF_TRY(launch_residual(-1.0, nullptr, lambda->p + N));
+        else if (m > 0) LF_TRY(launch_residual(-1.0, nullptr, lambda->p));
     }
     if (ctx->profiling) {
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));

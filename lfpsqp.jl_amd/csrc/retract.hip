@@ -1,0 +1,165 @@
+// Retractions onto the constraint manifold (reference src/retractions.jl).
+//   * device-resident constraint classes (linear equalities + ball with slack) so that c! and
+//     jac! need no n-sized PCIe traffic;
+//   * the Newton retraction retract!(..., ::NR) (:75-177): per iteration ONE pass over U
+//     (x += U*delta, stacked when bounds exist), the fused y_retract!, and ONE pass over Jct for c!;
+//     the m x m inverse-Jacobian / Broyden algebra (:126-130, :140, :156-160) is replicated
+//     host math on m-vectors.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "internal.h"
+
+namespace lfpsqp {
+
+struct BallF {  // partial of sum_{i<n_x} x_i^2 - x[slack_row]
+    const double* x;
+    int64_t n_x, slack_row;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double2 a = ld2(x + i);
+        double s = 0.0;
+        if (v0) s += (i < n_x) ? a.x * a.x : ((i == slack_row) ? -a.x : 0.0);
+        if (v1) s += (i + 1 < n_x) ? a.y * a.y : ((i + 1 == slack_row) ? -a.y : 0.0);
+        red[0] += s;
+    }
+};
+
+struct BallColF {  // Jct[:, m_lin] = [2x (i < n_x); -1 at slack_row; 0 elsewhere]
+    const double* x;
+    double* col;
+    int64_t n_x, slack_row;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double one(int64_t i, double xi) const { return i < n_x ? 2.0 * xi : (i == slack_row ? -1.0 : 0.0); }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 a = ld2(x + i);
+        if (v1) st2(col + i, make_double2(one(i, a.x), one(i + 1, a.y)));
+        else if (v0) col[i] = one(i, a.x);
+    }
+};
+
+struct PlainVec {  // GEMV-T producer reading the first N entries of a (possibly stacked) vector
+    const double* v;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double2 a = ld2(v + r);
+        return make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0);
+    }
+};
+
+int cons_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval) {
+    const lfpsqp_mat* J = cons->Jct;
+    const int ml = (int)cons->m_lin;
+    const int mt = ml + (cons->has_ball ? 1 : 0);
+    LF_TRY(ensure_mvec(ctx, (size_t)mt + 8));
+    if (ml > 0) LF_TRY(run_gemv_t(ctx, J, ml, J->n, PlainVec{x->p}, ctx->d_m));
+    if (cons->has_ball)
+        LF_TRY((run_vec<BallF, 1, NoPost>(ctx, J->n, BallF{x->p, cons->n_x, cons->slack_row}, 0u, ctx->d_m + ml, NoPost())));
+    if (mt > 0) {
+        LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * mt, hipMemcpyDeviceToHost, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    for (int j = 0; j < ml; ++j) cval[j] = ctx->h_m[j] - cons->b[j];
+    if (cons->has_ball) cval[ml] = ctx->h_m[ml] - cons->R2;
+    return 0;
+}
+
+}  // namespace lfpsqp
+
+using namespace lfpsqp;
+
+static bool cons_ok(const lfpsqp_constraints* c) {
+    return c && c->Jct && c->m_lin >= 0 && c->m_lin + (c->has_ball ? 1 : 0) <= c->Jct->m && (c->m_lin == 0 || c->b) &&
+           (!c->has_ball || (c->n_x >= 0 && c->n_x <= c->Jct->n && c->slack_row < c->Jct->n));
+}
+
+extern "C" {
+
+int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval) {
+    LF_ARG(ctx, ctx && cons_ok(cons) && x && cval && x->n >= cons->Jct->n);
+    return cons_eval(ctx, cons, x, cval);
+}
+
+int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval) {
+    LF_ARG(ctx, ctx && cons_ok(cons) && x && Jct && cval && x->n >= cons->Jct->n && Jct->p == cons->Jct->p);
+    if (cons->has_ball)
+        LF_TRY((run_vec<BallColF, 0, NoPost>(ctx, Jct->n, BallColF{x->p, Jct->p + cons->m_lin * Jct->ld, cons->n_x, cons->slack_row}, 0u,
+                                             nullptr, NoPost())));
+    return cons_eval(ctx, cons, x, cval);
+}
+
+int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m64,
+                      const lfpsqp_constraints* cons, lfpsqp_cfun cfun, void* cuser, const lfpsqp_ineq_data* idata,
+                      const lfpsqp_vec* xtilde, const lfpsqp_vec* x, lfpsqp_vec* xnew, double tol, int64_t maxiter, double* cval,
+                      int* flag, int64_t* iters) {
+    LF_ARG(ctx, ctx && U && Sigma && Vt && xtilde && x && xnew && cval && flag && iters && m64 >= 1 && U->ncols == m64);
+    LF_ARG(ctx, cfun || cons_ok(cons));
+    LF_ARG(ctx, xtilde->n == x->n && xnew->n == x->n && xnew->p != x->p && xnew->p != xtilde->p);
+    const int m = (int)m64;
+    const bool ineq = idata != nullptr;
+    LF_ARG(ctx, ineq == (U->Dx != nullptr));
+    LF_TRY(ensure_mvec(ctx, (size_t)2 * m + 8));
+
+    auto eval_c = [&](double* out) -> int {
+        if (cfun) {
+            int rc = cfun(cuser, xnew, out);
+            if (rc != 0) return set_err(ctx, LFPSQP_ERR_ARG, "user c! callback returned %d", rc);
+            return 0;
+        }
+        return cons_eval(ctx, cons, xnew, out);
+    };
+
+    LF_TRY(lfpsqp_vec_copy(ctx, xnew, xtilde));                       // :116
+    if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew, x, idata));          // :118-120
+    LF_TRY(eval_c(cval));
+    std::vector<double> D((size_t)m * m), tmp(m), tmp2(m), dc(m);
+    for (int j = 0; j < m; ++j)                                       // :126-130  D[k,j] = Vt[k,j] / Sigma[k]
+        for (int k = 0; k < m; ++k) D[(size_t)j * m + k] = Vt[(size_t)j * m + k] / Sigma[k];
+    // staging vector for delta on the device (offset past the slots cons_eval uses)
+    lfpsqp_vec tv;
+    tv.p = ctx->d_m + round_up(m + 8, 2);
+    tv.n = m;
+    tv.cap = m;
+    double* h_delta = ctx->h_m + round_up(m + 8, 2);
+
+    int64_t i = 0;
+    while (i < maxiter) {
+        double cmax = 0.0;
+        for (int k = 0; k < m; ++k) cmax = fmax(cmax, fabs(cval[k]));
+        if (cmax < tol) break;                                        // :135  (NaN compares false, like Julia)
+        for (int k = 0; k < m; ++k) {                                 // :140  tmp = -D cval
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s += D[(size_t)j * m + k] * cval[j];
+            tmp[k] = -s;
+            h_delta[k] = -s;
+        }
+        LF_HIP(ctx, hipMemcpyAsync(tv.p, h_delta, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+        LF_TRY(lfpsqp_q_gemv_n(ctx, U, 1.0, nullptr, &tv, 1.0, xnew));   // :141  xnew += U tmp
+        if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew, x, idata));      // :144-146
+        LF_TRY(eval_c(tmp2.data()));
+        for (int k = 0; k < m; ++k) { dc[k] = tmp2[k] - cval[k]; cval[k] = tmp2[k]; }   // :152-153
+        for (int k = 0; k < m; ++k) {                                 // :156  tmp2 = D' tmp
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s += D[(size_t)k * m + j] * tmp[j];
+            tmp2[k] = s;
+        }
+        for (int k = 0; k < m; ++k) {                                 // :157  tmp = tmp - D dc
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s += D[(size_t)j * m + k] * dc[j];
+            tmp[k] -= s;
+        }
+        double den = 0.0;
+        for (int k = 0; k < m; ++k) den += tmp2[k] * dc[k];
+        const double alpha = 1.0 / den;                               // :159
+        for (int j = 0; j < m; ++j)                                   // :160  D += alpha tmp tmp2'
+            for (int k = 0; k < m; ++k) D[(size_t)j * m + k] += alpha * tmp[k] * tmp2[j];
+        ++i;
+    }
+    *flag = (i == maxiter) ? 1 : 0;                                   // :171-174
+    *iters = i;
+    return 0;
+}
+
+}  // extern "C"

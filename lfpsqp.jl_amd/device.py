@@ -179,9 +179,12 @@ class DeviceMatrix:
         self.ctx.check(self.ctx.L.lfpsqp_mat_copy(self.ctx.h, self.h, src.h))
         return self
 
-    def hash_fill(self, seed: int, row0: int = 0, n_global: int | None = None, scale: float = 1.0):
-        self.ctx.check(self.ctx.L.lfpsqp_mat_hash_fill(self.ctx.h, self.h, seed, row0, self.n if n_global is None else n_global,
-                                                       float(scale)))
+    def hash_fill(self, seed: int, row0: int = 0, n_global: int | None = None, scale: float = 1.0, nrows: int | None = None,
+                  ncols: int | None = None):
+        nrows = self.n if nrows is None else nrows
+        ncols = self.m if ncols is None else ncols
+        self.ctx.check(self.ctx.L.lfpsqp_mat_hash_fill(self.ctx.h, self.h, seed, row0, nrows if n_global is None else n_global,
+                                                       float(scale), nrows, ncols))
         return self
 
 
@@ -211,6 +214,13 @@ def nrm2(x: DeviceVector) -> float:
     out = C.c_double()
     x.ctx.check(x.ctx.L.lfpsqp_nrm2(x.ctx.h, x.h, C.byref(out)))
     return out.value
+
+
+def nrm2_head(x: DeviceVector, count: int) -> float:
+    """norm(view(x, 1:count))."""
+    out = C.c_double()
+    x.ctx.check(x.ctx.L.lfpsqp_dot_head(x.ctx.h, x.h, x.h, int(count), C.byref(out)))
+    return float(np.sqrt(out.value))
 
 
 def amax(x: DeviceVector) -> float:

@@ -1,0 +1,266 @@
+"""The outer LFPSQP driver on device-resident state (reference src/optimize.jl:119-443).
+
+``optimize(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m, param, ctx=...)`` keeps the
+reference's explicit-derivative signature and return value
+``(x, obj_values, lam_kkt, TerminationInfo)``; only scalars and m-vectors cross PCIe per
+outer iteration.  Callback contract (the device analogue of the reference's):
+
+    f(x)                      -> float; x is the device iterate (stacked [x; y] when bounds exist,
+                                 f must only look at the first n entries)
+    grad_(g, x)               writes the first n entries of the device vector g
+    c_                        DeviceConstraints, or a host callable c_(cval, x_host)
+    jac_(Jct, cval, x)        refreshes the device n x m matrix Jct (= Jc' of the reference) and cval
+    hess_lag_vec_             either an object with ``diag_(hx, x, lam)`` filling the N-vector hx with
+                              the diagonal of the Lagrangian Hessian (fused projcg path), or a callable
+                              hess_lag_vec_(dest, src, x, lam) on device vectors (generic path)
+
+Deviations from the reference, all invisible in the iterates up to rounding: the thin SVD is the
+Gram-based factorisation of lfpsqp_factorize (basis rotation / sign freedom), ``Jct`` is not
+destroyed by it, and the 2N x M factor with bounds is never materialised."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .device import Context, DeviceMatrix, DeviceVector, amax, axpby, dot, gemv_n, gemv_t, nrm2, waxpby
+from .factorize import ksvd_
+from .inequality import (InequalityData, InequalityDecomp, InequalityDecompProject, StackedVector, generate_initial_y_,
+                         inequality_gradient_)
+from .linesearch import ArmijoWork, ExactLinesearchWork, armijo_, exact_linesearch_
+from .params import DisplayOption, LFPSQPParams, LinesearchOption, TerminationCondition, TerminationInfo
+from .projcg import DeviceBasis, DiagOperator, ProjCGWork, projcg_
+from .retractions import NR, Euclidean, NRWork, YRetract
+
+
+def _print_iter_header():
+    print("   step |          f     ||c||      |Δf|    ||Δx||  |   S iter      res  |   M   iter  (pcg)  |        α  flag")
+    print("-" * 110)
+
+
+def _print_first_line(fval, normc):
+    print("      0 | %10.3e  %8.1e                      |                    |                    |               " % (fval, normc))
+
+
+def _print_iter(i, fval, normc, fstep, normx, steptype, tn_iter, tn_res, methodtype, iter1, iter2, alpha, flag):
+    print("%7d | %10.3e  %8.1e  %8.1e  %8.1e  |  %s %4d %8.1e  |  %s %6d %6d  | %8.1e  %4d" %
+          (i, fval, normc, fstep, normx, "GD" if steptype == 0 else "TN", tn_iter, tn_res, "NR" if methodtype == 0 else "PP",
+           iter1, iter2, alpha, flag), flush=True)
+
+
+class _GenericHessian:
+    """LinearMap((dest, src) -> hess_lag_vec!(dest, src, x, lam)) (src/optimize.jl:230) for callables."""
+
+    def __init__(self, fn, x, lam):
+        self.fn, self.x, self.lam = fn, x, lam
+        self._tmp = None
+
+    def mul_(self, dest, v, a=None, b=None):
+        if a is None:
+            self.fn(dest, v, self.x, self.lam)
+        else:
+            if self._tmp is None:
+                self._tmp = DeviceVector(dest.ctx, dest.n)
+            self.fn(self._tmp, v, self.x, self.lam)
+            waxpby(a, self._tmp, b, dest, dest)
+        return dest
+
+    def adjoint(self):
+        return self
+
+
+def _amax_host(v):
+    return float(np.max(np.abs(v), initial=0.0))
+
+
+def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: LFPSQPParams | None = None, *, ctx: Context,
+                  n_global: int | None = None, trace=None):
+    """src/optimize.jl:119-443.  x0 / xl / xu are host arrays (this rank's shard)."""
+    from .projpenalty import ProjPenalty, ProjPenaltyWork
+    from . import _capi
+    import ctypes as C
+    param = param or LFPSQPParams()
+    x0 = np.asarray(x0, dtype=np.float64)
+    n = len(x0)
+    n_global = n if n_global is None else n_global
+    if xl is not None and xu is not None:
+        if not (len(xl) == len(xu) == len(x0)):
+            raise ValueError("xl, xu, and x0 must all be the same length")
+    if (xl is None and xu is None) or (np.all(np.asarray(xl) == -np.inf) and np.all(np.asarray(xu) == np.inf)):
+        ineq = False
+        ineqdata = None
+    else:
+        ineq = True
+        xl = np.asarray(xl, dtype=np.float64)
+        xu = np.asarray(xu, dtype=np.float64)
+        if np.any(xl > xu):
+            raise ValueError("Infeasible: lower bounds cannot be greater than upper bounds")
+        ineqdata = InequalityData(ctx, xl, xu)
+        lamy_kkt = DeviceVector(ctx, n)
+        hx = DeviceVector(ctx, n)
+
+    def newvec():
+        return StackedVector(ctx, n) if ineq else DeviceVector(ctx, n)
+
+    x = newvec()
+    x.upload(x0, 0)
+    if ineq:
+        generate_initial_y_(x, ineqdata)                                   # :179-182
+    obj_values = []
+    xnew, g, d, newton_d = newvec(), newvec(), newvec(), newvec()
+    # device-resident constraint classes own their (mostly constant) Jct; otherwise the driver allocates it
+    Jct = getattr(c_, "Jct", None) or DeviceMatrix(ctx, n, m)
+    assert Jct.n == n and Jct.m == m
+    tmp_m = DeviceVector(ctx, max(m, 1))
+    tmp_w = DeviceVector(ctx, n) if ineq else None
+    cval = np.zeros(m)
+    lam_kkt = np.zeros(m)
+    lam_dev = DeviceVector(ctx, max(m, 1))
+    term_cond = TerminationCondition.f_tol
+    projcgwork = ProjCGWork(ctx, n, m, n if ineq else None)
+    prev_grad_norm = 0.0
+
+    idecomp = InequalityDecomp(ctx, n, m, Jct)
+    Z = idecomp.Z
+    Sig, Vt = idecomp.Sigma, idecomp.Vt
+    ineqproject = InequalityDecompProject(idecomp) if ineq else None
+
+    diagonal_hessian = hasattr(hess_lag_vec_, "diag_")
+    if diagonal_hessian:
+        a_diag = newvec()
+        newton_map = DiagOperator(0.0, a_diag)
+    else:
+        if ineq:
+            raise NotImplementedError("generic (non-diagonal) Hessian callables with bounds: supply diag_ (DESIGN.md §8)")
+        newton_map = _GenericHessian(hess_lag_vec_, x, lam_dev)
+
+    nr = NR(None, Sig, Vt, param.eps_c, param.maxiter_retract, NRWork(m), ineq, ineqdata)
+    pp = ProjPenalty(jac_, None, Sig, Vt, m, param.mu0, param.eps_c, param.maxiter_retract, param.maxiter_pcg,
+                     ProjPenaltyWork(ctx, m, n, ineq), ineq, idecomp, ineqdata)
+    euc = Euclidean()
+    yr = YRetract(ineqdata) if ineq else None
+    armijo_work = ArmijoWork(x)
+    exact_work = ExactLinesearchWork(x) if param.linesearch == LinesearchOption.exact and not param.disable_linesearch else None
+
+    i = 0
+    f_diff = step_diff = kkt_diff = math.inf
+    fval = f(x)
+    obj_values.append(fval)
+    if m > 0:
+        if hasattr(c_, "c_"):
+            c_.c_(cval, x)
+        else:
+            c_(cval, x.download(n, 0))
+    disp = param.disp == DisplayOption.iter and ctx.rank == 0
+    if disp:
+        _print_iter_header()
+        _print_first_line(fval, _amax_host(cval))
+
+    while True:
+        grad_(g, x)                                                        # :259
+        waxpby(-1.0, g, 0.0, g, d)                                         # :262
+        if param.beta > 0:
+            raise NotImplementedError("random-noise steps (param.beta > 0, src/optimize.jl:264-273) are not on the device path")
+        if ineq:
+            inequality_gradient_(idecomp, x, ineqdata)                     # :277
+        rank = m
+        if m > 0:
+            jac_(Jct, cval, x)                                             # :283-284 (the device keeps only Jct)
+            S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank)   # :286-302
+            Sig[:] = S_
+            Vt[:, :] = Vt_
+            if not ineq:                                                   # :305-308
+                gemv_t(Z, d, tmp_m, ncols=rank)
+                gemv_n(Z, tmp_m, d, -1.0, 1.0, ncols=rank)
+        if ineq:                                                           # :312-318
+            idecomp.rank = rank
+            ineqproject.mul_t(tmp_w, tmp_m, d)
+            ineqproject.mul_n(d, tmp_w, tmp_m, -1.0, 1.0)
+        kkt_diff = amax(d)                                                 # :320
+        pp.rank = rank
+        steptype = 0
+        tn_iter = 0
+        tn_res = 0.0
+        if m > 0:                                                          # :331-343
+            th = tmp_m.download(m)
+            th[:rank] /= Sig[:rank]
+            th[rank:m] = 0.0
+            lam_kkt[:] = Vt.T @ th
+            lam_dev.upload(lam_kkt)
+        if ineq:                                                           # calculate_lambda_kkt!, :286-308
+            ctx.check(ctx.L.lfpsqp_calculate_lambda_y(ctx.h, Jct.h, m, lam_dev.h, idecomp.Dx.h, idecomp.S.h, tmp_w.h, lamy_kkt.h))
+
+        if trace is not None:
+            trace.append(dict(iter=i, x=(x.download2() if ineq else x.download()), fval=fval, kkt_diff=kkt_diff, rank=rank,
+                              lam_kkt=lam_kkt.copy(), cval=cval.copy()))
+
+        if f_diff <= param.eps_f:                                          # :347-359
+            term_cond = TerminationCondition.f_tol
+            break
+        elif step_diff <= param.eps_x:
+            term_cond = TerminationCondition.x_tol
+            break
+        elif i >= param.maxiter:
+            term_cond = TerminationCondition.max_iter
+            break
+        elif kkt_diff <= param.eps_kkt:
+            term_cond = TerminationCondition.kkt_tol
+            break
+
+        if param.do_newton:                                                # :364-390
+            if diagonal_hessian:
+                if ineq:
+                    hess_lag_vec_.diag_(hx, x, lam_kkt)
+                    idc = ineqdata._c()
+                    ctx.check(ctx.L.lfpsqp_augmented_diag(ctx.h, hx.h, lamy_kkt.h, C.byref(idc), a_diag.h))
+                else:
+                    hess_lag_vec_.diag_(a_diag, x, lam_kkt)
+            if ineq:
+                Qview = ineqproject
+            else:
+                Qview = DeviceBasis(Z, rank)
+            grad_norm = nrm2(d)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                ratio = float(np.float64(grad_norm) / np.float64(prev_grad_norm))
+            tol = param.tn_kappa * min(1.0, ratio) * grad_norm
+            if math.isnan(ratio):
+                tol = math.nan
+            prev_grad_norm = grad_norm
+            tn_iter, tn_res = projcg_(newton_d, None, newton_map, Qview, d, None, tol=tol, maxit=param.tn_maxiter,
+                                      work=projcgwork, n_global=(2 * n_global if ineq else n_global), want_lambda=False)
+            if dot(newton_d, d) > 0.0:
+                d.copy_from(newton_d)
+                steptype = 1
+            if trace is not None:
+                trace[-1].update(tn_iter=tn_iter, tn_res=tn_res, steptype=steptype, tn_tol=tol)
+
+        if m > 0:                                                          # :396-412
+            if rank == m and not param.do_project_retract:
+                nr.U = ineqproject if ineq else DeviceBasis(Z, rank)
+                retract_method, mtype = nr, 0
+            else:
+                retract_method, mtype = pp, 1
+        else:
+            retract_method, mtype = (yr, 0) if ineq else (euc, 0)
+
+        if param.linesearch == LinesearchOption.armijo or param.disable_linesearch:
+            flag, iter1, iter2, newf, f_diff, step_diff, alpha = armijo_(
+                xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, armijo_work)
+        else:
+            flag, iter1, iter2, newf, f_diff, step_diff, alpha = exact_linesearch_(
+                xnew, x, n, d, f, fval, retract_method, cval, c_, param, exact_work)
+
+        x.copy_from(xnew)                                                  # :424-427
+        fval = newf
+        obj_values.append(fval)
+        if disp:
+            _print_iter(i + 1, fval, _amax_host(cval), f_diff, step_diff, steptype, tn_iter, tn_res, mtype, iter1, iter2, alpha, flag)
+        if trace is not None:
+            trace[-1].update(mtype=mtype, retract_iter1=iter1, retract_iter2=iter2, alpha=alpha, ls_flag=flag)
+        i += 1
+        if param.callback is not None and i % param.callback_period == 0:
+            param.callback(i, x)
+
+    if i == param.maxiter and disp:
+        print("Warning: Maximum # of outer iterations reached")
+    return x.download(n, 0), np.array(obj_values), lam_kkt, TerminationInfo(term_cond, f_diff, step_diff, kkt_diff, i)

@@ -1,0 +1,65 @@
+"""LFPSQPParams, enums and TerminationInfo -- a 1:1 mirror of reference src/LFPSQP.jl:27-81
+(Greek field names transliterated: alpha, beta, t_beta, sigma, eps_c, ..., mu0, tn_kappa)."""
+from __future__ import annotations
+
+import enum
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+
+class DisplayOption(enum.Enum):
+    off = 0
+    iter = 1
+
+
+class LinesearchOption(enum.Enum):
+    armijo = 0
+    exact = 1
+
+
+class TerminationCondition(enum.Enum):
+    f_tol = 0
+    x_tol = 1
+    kkt_tol = 2
+    max_iter = 3
+    armijo_error = 4
+
+
+@dataclass
+class TerminationInfo:
+    condition: TerminationCondition
+    f_diff: float
+    step_diff: float
+    kkt_diff: float
+    iter: int
+
+    def __str__(self):
+        return (f"TerminationInfo:\ncondition = {self.condition.name}\n       Δf = {self.f_diff!r}\n"
+                f"   ||Δx|| = {self.step_diff!r}\n||P(∇f)|| = {self.kkt_diff!r}\n    iters = {self.iter}")
+
+
+@dataclass
+class LFPSQPParams:
+    alpha: float = 1.0
+    beta: float = 0.0
+    t_beta: int = 0
+    s: float = 0.5
+    sigma: float = 1e-4
+    eps_c: float = 1e-6
+    eps_f: float = 1e-6
+    eps_x: float = 0.0
+    eps_kkt: float = 1e-6
+    eps_rank: float = 1e-10
+    maxiter: int = 10000
+    maxiter_retract: int = 100
+    maxiter_pcg: int = 100
+    mu0: float = 1e-2
+    disable_linesearch: bool = False
+    do_project_retract: bool = True
+    disp: DisplayOption = DisplayOption.iter
+    callback: Optional[Callable] = None
+    callback_period: int = 100
+    linesearch: LinesearchOption = LinesearchOption.armijo
+    do_newton: bool = True
+    tn_maxiter: int = 10000
+    tn_kappa: float = 0.5

@@ -1,0 +1,145 @@
+"""Problem front-ends of ``optimize``.
+
+* :class:`QuadLinearBallBox` -- the device-resident problem class of BASELINE configs 2-5:
+  f = ||x - xc||^2, dense linear equalities J x = b, optional ball x'x <= R2 (turned into an
+  equality with a slack variable exactly as src/optimize.jl:23-51 does) and optional box bounds.
+  f, grad!, c!, jac! and the (diagonal) Lagrangian Hessian all run on the device.
+* :func:`optimize` -- the reference's method table (src/optimize.jl:13,83,88,107,112,119) for
+  arbitrary HOST callables: the "host-callback fallback".  Iterates are downloaded for every user
+  call, so it is for plumbing / small problems (config 1), not for the 1e7-variable configs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import numpy as np
+
+from .device import Context, DeviceMatrix, DeviceVector
+from .optimize import optimize_core
+from .params import LFPSQPParams
+from .retractions import DeviceConstraints
+
+
+class QuadLinearBallBox:
+    def __init__(self, ctx: Context, n: int, m: int, Jct: DeviceMatrix, b, R2: Optional[float] = None, xl=None, xu=None,
+                 xc: float = 0.0, n_global: Optional[int] = None):
+        """Jct: device matrix with n + p rows and m + p columns (p = 1 iff R2 is given) whose leading
+        n x m block holds the constraint gradients (row n and column m are managed here)."""
+        self.ctx, self.n, self.m, self.xc = ctx, n, m, float(xc)
+        self.p = 0 if R2 is None else 1
+        self.N, self.M = n + self.p, m + self.p
+        assert Jct.n == self.N and Jct.m == self.M
+        self.Jct = Jct
+        self.R2 = 0.0 if R2 is None else float(R2)
+        self.cons = DeviceConstraints(Jct, m, b, has_ball=self.p == 1, R2=self.R2, n_x=n, slack_row=n if self.p else -1)
+        self.xl = None if xl is None else np.asarray(xl, dtype=np.float64)
+        self.xu = None if xu is None else np.asarray(xu, dtype=np.float64)
+        self.n_global = n if n_global is None else n_global
+        self.is_diagonal = True
+
+    # -- callbacks in the contract of optimize_core -------------------------------------------
+    def f(self, x: DeviceVector) -> float:
+        out = C.c_double()
+        self.ctx.check(self.ctx.L.lfpsqp_sumsq_shift(self.ctx.h, x.h, self.n, self.xc, C.byref(out)))
+        return out.value
+
+    def grad_(self, g: DeviceVector, x: DeviceVector):
+        self.ctx.check(self.ctx.L.lfpsqp_affine_head(self.ctx.h, 2.0, x.h, -2.0 * self.xc, self.n, g.h))
+
+    def jac_(self, Jct, cval, x):
+        return self.cons.jac_(Jct, cval, x)
+
+    def diag_(self, hx: DeviceVector, x: DeviceVector, lam: np.ndarray):
+        """diag of grad^2 f + sum lam_i grad^2 c_i: 2 (+ 2 lam_ball) on the user's variables, 0 on the slack."""
+        h = 2.0 + (2.0 * float(lam[self.m]) if self.p else 0.0)
+        L = self.ctx.L
+        self.ctx.check(L.lfpsqp_vec_fill_range(self.ctx.h, hx.h, 0, self.n, h))
+        if self.p:
+            self.ctx.check(L.lfpsqp_vec_fill_range(self.ctx.h, hx.h, self.n, 1, 0.0))
+
+    # -- the slack transformation of src/optimize.jl:23-36 --------------------------------------
+    def aux_start(self, x0):
+        x0 = np.asarray(x0, dtype=np.float64)
+        if not self.p:
+            return x0, self.xl, self.xu
+        x0a = np.concatenate([x0, [float(x0 @ x0) - self.R2]])
+        xl = -np.inf * np.ones(self.n) if self.xl is None else self.xl
+        xu = np.inf * np.ones(self.n) if self.xu is None else self.xu
+        return x0a, np.concatenate([xl, [-np.inf]]), np.concatenate([xu, [0.0]])
+
+    def optimize(self, x0, param: LFPSQPParams | None = None, trace=None):
+        x0a, xl, xu = self.aux_start(x0)
+        x, obj, lam, ti = optimize_core(self.f, self.grad_, self.cons, self.jac_, self, x0a, xl, xu, self.M, param, ctx=self.ctx,
+                                        n_global=self.n_global + self.p, trace=trace)
+        return x[:self.n], obj, lam, ti
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Derivatives:
+    """Analytic derivatives in the user's variables (the reference gets them by AD,
+    src/autodiff_generators.jl -- out of scope).  All callables take HOST arrays."""
+    grad_: Callable
+    hess_lag_vec_: Callable
+    jac_c_: Optional[Callable] = None
+    jac_d_: Optional[Callable] = None
+
+
+def optimize(*args, derivatives: Optional[Derivatives] = None, ctx: Optional[Context] = None, trace=None):
+    """optimize(f, x0) / (f, c!, x0, m) / (f, c!, x0, xl, xu, m) / (f, c!, d!, x0, xl, xu, m, p) /
+    (f, c!, d!, dl, du, x0, xl, xu, m, p) / (f, grad!, c!, jac!, hess_lag_vec!, x0, xl, xu, m) with an
+    optional trailing LFPSQPParams -- host callables, device hot path (projcg!, retractions, tangent
+    setup run on the GPU; every user call costs one n-vector PCIe round trip)."""
+    args = list(args)
+    param = LFPSQPParams()
+    if args and isinstance(args[-1], LFPSQPParams):
+        param = args.pop()
+    if ctx is None:
+        ctx = Context(0)
+    k = len(args)
+    if k == 9:
+        f, grad_, c_, jac_, hlv_, x0, xl, xu, m = args
+        return _host_core(ctx, f, grad_, c_, jac_, hlv_, x0, xl, xu, m, param, trace)
+    if derivatives is None:
+        raise NotImplementedError("the AD generators (src/autodiff_generators.jl) are out of scope; pass derivatives=Derivatives(...)")
+    dv = derivatives
+    if k == 2:
+        f, x0 = args
+        return _host_core(ctx, f, dv.grad_, None, None, dv.hess_lag_vec_, x0, None, None, 0, param, trace)
+    if k == 4:
+        f, c_, x0, m = args
+        return _host_core(ctx, f, dv.grad_, c_, dv.jac_c_, dv.hess_lag_vec_, x0, None, None, m, param, trace)
+    if k == 6:
+        f, c_, x0, xl, xu, m = args
+        return _host_core(ctx, f, dv.grad_, c_, dv.jac_c_ if m > 0 else None, dv.hess_lag_vec_, x0, xl, xu, m, param, trace)
+    raise NotImplementedError(f"optimize with {k} positional arguments (general d! inequalities with host callables) is not on the "
+                              "device path yet; use QuadLinearBallBox or the explicit-derivative form")
+
+
+def _host_core(ctx, f, grad_, c_, jac_, hlv_, x0, xl, xu, m, param, trace):
+    """Adapters: host callables -> the device-vector contract of optimize_core (no bounds + general
+    Hessian: generic projcg path)."""
+    x0 = np.asarray(x0, dtype=np.float64)
+    n = len(x0)
+
+    def f_dev(x):
+        return float(f(x.download(n, 0)))
+
+    def grad_dev(g, x):
+        gh = np.zeros(n)
+        grad_(gh, x.download(n, 0))
+        g.upload(gh, 0)
+
+    def jac_dev(Jct, cval, x):
+        J = np.zeros((m, n), order='F')
+        jac_(J, cval, x.download(n, 0))
+        Jct.upload(np.asfortranarray(J.T))
+
+    def hlv_dev(dest, src, x, lam):
+        out = np.zeros(n)
+        hlv_(out, src.download(n, 0), x.download(n, 0), lam.download(max(m, 1))[:m])
+        dest.upload(out, 0)
+
+    return optimize_core(f_dev, grad_dev, c_, jac_dev if m > 0 else None, hlv_dev, x0, xl, xu, m, param, ctx=ctx, trace=trace)

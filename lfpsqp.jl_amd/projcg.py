@@ -81,10 +81,17 @@ class _BasisAdjoint:
 class ProjCGWork:
     """ProjCGWork(n, m) (src/projcg.jl:1-11); only g, d, rp, Utr exist on the device."""
 
-    def __init__(self, ctx: Context, n: int, m: int):
-        self.g, self.d, self.rp = (DeviceVector(ctx, n) for _ in range(3))
+    def __init__(self, ctx: Context, n: int, m: int, stacked_N: int | None = None):
+        """n = length of the n-vectors on this rank; with bounds pass stacked_N = N and the
+        vectors get the stacked [x | gap | y] layout (length hs + N)."""
+        if stacked_N is not None:
+            from .inequality import StackedVector
+            self.g, self.d, self.rp = (StackedVector(ctx, stacked_N) for _ in range(3))
+            self.w = DeviceVector(ctx, stacked_N)
+        else:
+            self.g, self.d, self.rp = (DeviceVector(ctx, n) for _ in range(3))
+            self.w = None
         self.Utr = DeviceVector(ctx, max(m, 1))
-        self.w = None
         # extra scratch for the generic (unfused) path, allocated on demand
         self._extra = None
 
@@ -102,9 +109,13 @@ def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c:
         n_global = n
     if maxit is None:
         maxit = n_global + m
+    from .inequality import InequalityDecompProject
+    stacked = isinstance(U, InequalityDecompProject)
+    if stacked and n_global == n:
+        n_global = 2 * U.idecomp.N          # the reference's length(b)
     if work is None:
-        work = ProjCGWork(ctx, n, m)
-    if isinstance(A, DiagOperator) and isinstance(U, DeviceBasis):
+        work = ProjCGWork(ctx, n, m, U.idecomp.N if stacked else None)
+    if isinstance(A, DiagOperator) and (isinstance(U, DeviceBasis) or stacked):
         iters = _capi.c_i64()
         nr = C.c_double()
         a_c, u_c, w_c = A._c(), U._c(), work._c()

@@ -1,0 +1,200 @@
+"""ProjPenalty retraction and its inner pcg! (reference src/retractions.jl:179-246, 265-441),
+the reference's DEFAULT retraction (do_project_retract = true).
+
+Round-1 form: the reference's statement order on device vectors with the BLAS-1/2 primitives
+(two passes over Jct per pcg! iteration, vector updates unfused).  With bounds the full Jacobian
+operator  [[diag(Dx.*S), Jct]; [diag(Dy.*S), 0]]  (InequalityDecomp, src/inequality_helper.jl:215-271)
+is the stacked-operator form of lfpsqp_q_gemv_t/_n with row scalings (1, 0), so it shares the
+kernels of the projection operator.  Reference quirks are reproduced (BUG-COMPAT notes)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from .device import Context, DeviceMatrix, DeviceVector, axpby, dot, gemv_n, gemv_t, nrm2, vmul, waxpby
+from .inequality import InequalityData, InequalityDecomp, StackedVector, calculate_h_, inequality_gradient_
+
+
+class ProjPenaltyWork:  # src/retractions.jl:21-33 (J itself is the shared device Jct)
+    def __init__(self, ctx: Context, m: int, n: int, ineq: bool):
+        mk = (lambda: StackedVector(ctx, n)) if ineq else (lambda: DeviceVector(ctx, n))
+        self.r, self.p, self.z, self.dx, self.g = mk(), mk(), mk(), mk(), mk()
+        self.tmp_m = DeviceVector(ctx, max(m, 1))
+        self.cval_dev = DeviceVector(ctx, max(m, 1))
+        if ineq:
+            self.tmp_w = DeviceVector(ctx, n)
+            self.h = DeviceVector(ctx, n)
+            self.DxS, self.DyS = DeviceVector(ctx, n), DeviceVector(ctx, n)
+            self.ones = DeviceVector(ctx, n).fill(1.0)
+            self.zeros = DeviceVector(ctx, n)
+
+
+@dataclass
+class ProjPenalty:  # src/retractions.jl:35-49
+    jac_: object
+    U: object
+    Sigma: np.ndarray
+    Vt: np.ndarray
+    rank: int
+    mu0: float
+    tol: float
+    maxiter: int
+    maxiter_pcg: int
+    work: ProjPenaltyWork
+    ineq: bool
+    idecomp: InequalityDecomp
+    idata: InequalityData | None
+
+
+class _JacPlain:
+    """J = Jct' (m x n): tmp = J p ; z = J' tmp + mu z."""
+
+    def __init__(self, Jct: DeviceMatrix, work: ProjPenaltyWork):
+        self.Jct, self.w = Jct, work
+
+    def apply(self, p):                       # mul!(tmp_m, J, p)       :221
+        gemv_t(self.Jct, p, self.w.tmp_m)
+
+    def apply_t(self, z, a, b, from_cval=False):   # mul!(z, J', tmp_m, a, b)   :222 / :369
+        gemv_n(self.Jct, self.w.cval_dev if from_cval else self.w.tmp_m, z, a, b)
+
+
+class _JacStacked:
+    """fulljac = idecomp' (InequalityDecompAdjoint): tmp = [S.*(Dx.*px + Dy.*py); Jct' px]."""
+
+    def __init__(self, idecomp: InequalityDecomp, work: ProjPenaltyWork):
+        self.idc, self.w = idecomp, work
+
+    def _basis(self):
+        w = self.w
+        return _capi.Basis(self.idc.Jct.h, self.idc.Jct.m, w.DxS.h, w.DyS.h, w.ones.h, w.zeros.h)
+
+    def refresh(self):
+        vmul(self.idc.Dx, self.idc.S, self.w.DxS)
+        vmul(self.idc.Dy, self.idc.S, self.w.DyS)
+
+    def apply(self, p):
+        c = p.ctx
+        b = self._basis()
+        c.check(c.L.lfpsqp_q_gemv_t(c.h, C.byref(b), p.h, self.w.tmp_w.h, self.w.tmp_m.h))
+
+    def apply_t(self, z, a, b_, from_cval=False):
+        c = z.ctx
+        b = self._basis()
+        wv = self.w.h if from_cval else self.w.tmp_w
+        tv = self.w.cval_dev if from_cval else self.w.tmp_m
+        c.check(c.L.lfpsqp_q_gemv_n(c.h, C.byref(b), float(a), wv.h, tv.h, float(b_), z.h))
+
+
+def no_precondition(z, r):  # :259-263
+    z.copy_from(r)
+    return z
+
+
+def pcg_(mu, J, M_, x, r, p, z, tmp_m, tol, maxiter):
+    """pcg!(mu, J, M!, x, r, p, z, tmp_m, tol, maxiter) (src/retractions.jl:179-246) -> (flag, i).
+    J is one of the operator adapters above (tmp_m lives inside it)."""
+    norm_res = math.inf
+    rho = 1.0
+    p.fill(0.0)
+    i = 0
+    while norm_res > tol and i < maxiter:
+        M_(z, r)                                   # :209
+        rho_prev = rho
+        rho = dot(z, r)                            # :213
+        beta = rho / rho_prev                      # :216
+        waxpby(1.0, z, beta, p, p)                 # :217  p = z + beta p
+        z.copy_from(p)                             # :220
+        J.apply(p)                                 # :221
+        J.apply_t(z, 1.0, mu)                      # :222
+        alpha = rho / dot(p, z)                    # :227
+        axpby(alpha, p, 1.0, x)                    # :232
+        axpby(-alpha, z, 1.0, r)                   # :233
+        norm_res = nrm2(r)                         # :235
+        i += 1
+    flag = 1 if i == maxiter else 0                # BUG-COMPAT :240-243
+    return flag, i
+
+
+def _call_c(c_, cval, xnew, n):
+    if hasattr(c_, "c_"):
+        c_.c_(cval, xnew)
+    else:
+        c_(cval, xnew.download(n, 0))
+
+
+def retract_pp(cval, xnew, c_, xtilde, x, method: ProjPenalty):
+    """retract!(cval, xnew, c!, xtilde, x, method::ProjPenalty) (src/retractions.jl:265-441)."""
+    w = method.work
+    idecomp, idata = method.idecomp, method.idata
+    Jct = idecomp.Jct
+    r, p, z, dx, g = w.r, w.p, w.z, w.dx, w.g
+    ineq = method.ineq
+    n = idecomp.N
+    m = len(method.Sigma)
+    J = _JacStacked(idecomp, w) if ineq else _JacPlain(Jct, w)
+    mu0, tol, maxiter, maxiter_pcg = method.mu0, method.tol, method.maxiter, method.maxiter_pcg
+    flag = 0
+    xnew.copy_from(xtilde)                                   # :329
+    mu = mu0
+    i = 0
+    pcg_iter_count = 0
+    hh = 0.0
+    while i < maxiter:
+        method.jac_(Jct, cval, xnew)                         # :340 (device Jct == transpose!(idecomp.Jct, J), :347)
+        curtol = float(np.max(np.abs(cval), initial=0.0))
+        if ineq:                                             # :343-353
+            inequality_gradient_(idecomp, xnew, idata)
+            J.refresh()
+            hmax = calculate_h_(w.h, xnew, idata)
+            curtol = max(curtol, hmax)
+            hh = dot(w.h, w.h)
+        if curtol < tol:                                     # :359
+            break
+        waxpby(1.0, xnew, -1.0, xtilde, g)                   # :364
+        cc = float(np.dot(cval, cval))
+        prev_obj_val = (hh + cc) + mu * dot(g, g)            # :366
+        w.cval_dev.upload(cval)
+        J.apply_t(g, 1.0, mu, from_cval=True)                # :369  g = fulljac' cvalaug + mu g
+        dx.fill(0.0)
+        r.copy_from(g)
+        pcg_flag, pcg_i = pcg_(mu, J, no_precondition, dx, r, p, z, None, tol, maxiter_pcg)   # :375
+        pcg_iter_count += pcg_i
+        if pcg_flag > 0:                                     # :377-381
+            flag = 2
+            break
+        p.copy_from(xnew)                                    # :384
+        ar_dot = -dot(g, dx)                                 # :385
+        alpha = 1.0
+        axpby(-alpha, dx, 1.0, xnew)                         # :389
+        waxpby(1.0, xnew, -1.0, xtilde, g)
+        dist2 = dot(g, g)
+        _call_c(c_, cval, xnew, n)                           # :392
+        if ineq:
+            calculate_h_(w.h, xnew, idata, want_max=False)
+            hh = dot(w.h, w.h)
+        cc = float(np.dot(cval, cval))                       # :399 cvalaug[end-m+1:end] = cval
+        armijo_count = 0
+        while (hh + cc) + mu * dist2 > prev_obj_val + 1e-4 * alpha * ar_dot:   # :403
+            alpha /= 2
+            waxpby(1.0, p, -alpha, dx, xnew)
+            waxpby(1.0, xnew, -1.0, xtilde, g)
+            dist2 = dot(g, g)
+            # BUG-COMPAT :410-417: c! is evaluated into cvalaug and then overwritten by the stale
+            # full-step cval, so only the bound part h and dist2 change; the (discarded) c! call is skipped.
+            if ineq:
+                calculate_h_(w.h, xnew, idata, want_max=False)
+                hh = dot(w.h, w.h)
+            armijo_count += 1
+            if armijo_count == 100:                          # :422-425 (leaves only the inner loop)
+                flag = 3
+                break
+        i += 1
+        mu = min(mu * 0.1, math.sqrt(hh + cc))               # :431
+    if i == maxiter:                                         # :435-437
+        flag = 1
+    return flag, i, pcg_iter_count

@@ -1,0 +1,132 @@
+"""Retractions (reference src/retractions.jl) on the device.
+
+``retract_(cval, xnew, c_, xtilde, x, method)`` dispatches on the method type like the
+reference's ``retract!``: Euclidean / YRetract / NR / ProjPenalty.  ``c_`` is either a
+:class:`DeviceConstraints` (device-resident c!, no PCIe traffic) or a Python callable
+``c_(cval, x_host)`` (arbitrary user code: x is downloaded for every evaluation)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from .device import Context, DeviceMatrix, DeviceVector
+from .inequality import InequalityData, InequalityDecompProject, y_retract_
+from .projcg import DeviceBasis
+
+
+class DeviceConstraints:
+    """c(x) = [J x - b ; sum_{i<n_x} x_i^2 - R2 - x[slack_row]] with Jct resident on the device
+    (lfpsqp_constraints).  Callable as c!(cval, x) and jac!(Jct, cval, x)."""
+
+    def __init__(self, Jct: DeviceMatrix, m_lin: int, b, has_ball: bool = False, R2: float = 0.0, n_x: int | None = None,
+                 slack_row: int = -1):
+        self.Jct, self.m_lin = Jct, int(m_lin)
+        self.b = np.ascontiguousarray(b, dtype=np.float64) if m_lin else np.zeros(1)
+        self.has_ball, self.R2 = bool(has_ball), float(R2)
+        self.n_x = Jct.n if n_x is None else int(n_x)
+        self.slack_row = int(slack_row)
+        self.m = self.m_lin + (1 if has_ball else 0)
+
+    def _c(self):
+        return _capi.Constraints(self.Jct.h, self.m_lin, self.b.ctypes.data, 1 if self.has_ball else 0, self.R2, self.n_x,
+                                 self.slack_row)
+
+    def c_(self, cval: np.ndarray, x: DeviceVector):
+        ctx = x.ctx
+        cc = self._c()
+        ctx.check(ctx.L.lfpsqp_constraints_eval(ctx.h, C.byref(cc), x.h, cval.ctypes.data_as(_capi.PD)))
+        return cval
+
+    __call__ = c_
+
+    def jac_(self, Jct: DeviceMatrix, cval: np.ndarray, x: DeviceVector):
+        ctx = x.ctx
+        cc = self._c()
+        ctx.check(ctx.L.lfpsqp_constraints_jac(ctx.h, C.byref(cc), x.h, Jct.h, cval.ctypes.data_as(_capi.PD)))
+        return cval
+
+
+class NRWork:
+    """NRWork(m) (src/retractions.jl:1-8): the m x m state lives inside lfpsqp_retract_nr."""
+
+    def __init__(self, m: int):
+        self.m = m
+
+
+@dataclass
+class NR:  # src/retractions.jl:10-19
+    U: object                 # DeviceBasis or InequalityDecompProject
+    Sigma: np.ndarray
+    Vt: np.ndarray
+    tol: float
+    maxiter: int
+    work: NRWork
+    ineq: bool
+    idata: InequalityData | None
+
+
+class Euclidean:  # :51-52
+    pass
+
+
+@dataclass
+class YRetract:  # :54-56
+    idata: InequalityData
+
+
+def retract_(cval: np.ndarray, xnew: DeviceVector, c_, xtilde: DeviceVector, x: DeviceVector, method):
+    """retract!(cval, xnew, c!, xtilde, x, method) -> (flag, iter1, iter2)."""
+    ctx = x.ctx
+    if isinstance(method, Euclidean):                     # :61-65
+        xnew.copy_from(xtilde)
+        return 0, 0, 0
+    if isinstance(method, YRetract):                      # :67-72
+        xnew.copy_from(xtilde)
+        y_retract_(xnew, x, method.idata)
+        return 0, 0, 0
+    if isinstance(method, NR):
+        return _retract_nr(cval, xnew, c_, xtilde, x, method)
+    from .projpenalty import ProjPenalty, retract_pp
+    if isinstance(method, ProjPenalty):
+        return retract_pp(cval, xnew, c_, xtilde, x, method)
+    raise TypeError(f"no retract_ method for {type(method)}")
+
+
+def _retract_nr(cval, xnew, c_, xtilde, x, method: NR):
+    ctx = x.ctx
+    m = len(method.Sigma)
+    U = method.U
+    bc = U._c()
+    flag = C.c_int()
+    iters = _capi.c_i64()
+    Sig = np.ascontiguousarray(method.Sigma, dtype=np.float64)
+    Vt = np.asfortranarray(method.Vt, dtype=np.float64)
+    idc = method.idata._c() if method.ineq else None
+    keep = None
+    if isinstance(c_, DeviceConstraints):
+        cons = c_._c()
+        cons_p, cfun, keep = C.byref(cons), _capi.CFUN(), (cons, c_)
+    else:
+        nrows = method.U.idecomp.N if method.ineq else x.n
+
+        def tramp(user, xvec_handle, cval_ptr):
+            try:
+                tmpv = DeviceVector.__new__(DeviceVector)
+                tmpv.ctx, tmpv.n, tmpv.h = ctx, nrows, C.c_void_p(xvec_handle)
+                xh = tmpv.download(nrows, 0)
+                out = np.ctypeslib.as_array(cval_ptr, shape=(m,))
+                c_(out, xh)
+                return 0
+            except Exception as e:  # never unwind through C
+                print("c! callback failed:", repr(e))
+                return 1
+        cfun = _capi.CFUN(tramp)
+        cons_p, keep = None, (cfun, tramp)
+    ctx.check(ctx.L.lfpsqp_retract_nr(ctx.h, C.byref(bc), Sig.ctypes.data, Vt.ctypes.data, m, cons_p, cfun, None,
+                                      C.byref(idc) if idc is not None else None, xtilde.h, x.h, xnew.h, float(method.tol),
+                                      int(method.maxiter), cval.ctypes.data_as(_capi.PD), C.byref(flag), C.byref(iters)))
+    del keep
+    return flag.value, iters.value, 0

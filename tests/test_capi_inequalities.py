@@ -108,3 +108,55 @@ def test_projection_operator_and_y_retraction(dev_ctx, n, m):
     h = ctx.vector(n)
     assert L.calculate_h_(h, Xn, idata) < 1e-11
     np.testing.assert_array_equal(X.download2(), xaug)
+
+
+@pytest.mark.parametrize("n,m", [(64, 5), (1500, 12)])
+def test_projcg_with_bounds_matches_oracle(dev_ctx, n, m):
+    """projcg! with U = InequalityDecompProject (src/optimize.jl:366-381) and the augmented diagonal
+    Hessian (augmented_hess_lag_vec!, src/inequality_helper.jl:144-158): fused stacked kernels vs oracle."""
+    from tests.helpers import DiagOpRef
+    ctx = dev_ctx
+    rng, xl, xu, xaug, idata0, idata, X = _setup(ctx, n, m)
+    Jh = synth.hash_matrix(1, n, m)
+    idc0 = R.InequalityDecomp(np.empty((2 * n, m), order='F'), np.empty(m), np.empty((m, m), order='F'),
+                              np.empty(n), np.empty(n), np.empty(n), Jh, m)
+    R.inequality_gradient_(idc0, xaug, idata0)
+    PJ = np.asfortranarray(np.vstack([(1 - idc0.Dx ** 2)[:, None] * Jh, (-idc0.Dy * idc0.Dx)[:, None] * Jh]))
+    R.ksvd_(PJ, idc0.U, idc0.Sigma, idc0.Vt)
+    P0 = R.InequalityDecompProject(idc0)
+    idc = L.InequalityDecomp(ctx, n, m, ctx.matrix(n, m, Jh))
+    L.inequality_gradient_(idc, X, idata)
+    idc.Sigma, idc.Vt, idc.rank = L.ksvd_(idc.Jct, idc.Z, w2=ctx.vector(n, idc0.Dy ** 2))
+    P = L.InequalityDecompProject(idc)
+    # A = diag: 2 + 2*lamy*q on the x-half, 2*lamy*s (+3 to keep it SPD) on the y-half
+    lamy = 0.3 * rng.random(n)
+    a = np.concatenate([2.0 + 2 * lamy * idata0.q, 3.0 + 2 * lamy * idata0.s])
+    bh = rng.standard_normal(2 * n)
+    tmp = np.zeros(n + m)
+    R.mul_(tmp, R.adj(P0), bh)
+    R.mul_(bh, P0, tmp, -1.0, 1.0)                      # rhs in the tangent space, like optimize's d
+    Adev = L.DiagOperator(0.0, L.StackedVector(ctx, n).upload2(a))
+    b = L.StackedVector(ctx, n).upload2(bh)
+    work = L.ProjCGWork(ctx, 0, m, stacked_N=n)
+    for tol, maxit in ((1e-8, None), (1e-300, 3)):
+        x0, l0 = np.zeros(2 * n), np.zeros(n + m)
+        i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), P0, bh, np.zeros(n + m), tol=tol, maxit=maxit)
+        x, lam = L.StackedVector(ctx, n), ctx.vector(n + m)
+        i1, nr1 = L.projcg_(x, lam, Adev, P, b, None, tol=tol, maxit=maxit, work=work)
+        assert i1 == i0 and nr1 == pytest.approx(nr0, rel=1e-6)
+        xd = x.download2()
+        assert np.linalg.norm(xd - x0) <= 1e-10 * np.linalg.norm(x0)
+        # Q'x = 0 (both blocks), checked with the oracle's operator
+        R.mul_(tmp, R.adj(P0), xd)
+        assert np.abs(tmp).max() < 1e-12
+        np.testing.assert_allclose(lam.download()[:n], l0[:n], atol=1e-10)          # diagonal block of lambda
+        assert np.linalg.norm(lam.download()[n:]) == pytest.approx(np.linalg.norm(l0[n:]), rel=1e-8, abs=1e-10)
+    # negative curvature through the stacked path
+    a2 = a.copy()
+    a2[::2] *= -1
+    x0, l0 = np.zeros(2 * n), np.zeros(n + m)
+    i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a2), P0, bh, np.zeros(n + m), tol=1e-12)
+    x, lam = L.StackedVector(ctx, n), ctx.vector(n + m)
+    i1, nr1 = L.projcg_(x, lam, L.DiagOperator(0.0, L.StackedVector(ctx, n).upload2(a2)), P, b, None, tol=1e-12, work=work)
+    assert i1 == i0 and np.isinf(nr1) and np.isinf(nr0) and np.all(np.isnan(lam.download()))
+    assert np.linalg.norm(x.download2() - x0) < 1e-10
