@@ -1,0 +1,229 @@
+"""Device versions of the reference's test/test_retractions.jl + test_linesearch.jl, and
+end-to-end `optimize` trajectories of BASELINE configs 1-4 against the oracle."""
+import math
+
+import numpy as np
+import pytest
+
+import lfpsqp_jl_amd as L
+from oracle import lfpsqp_ref as R
+from oracle import synth
+
+from .test_oracle_reference_properties import rosenbrock, sin_system
+
+
+def _is_emu(ctx):
+    return "emulator" in ctx.device_name
+
+
+@pytest.fixture
+def sin_setup(dev_ctx):
+    ctx = dev_ctx
+    rng = np.random.default_rng(99)
+    n, m = (1000, 100) if not _is_emu(ctx) else (300, 20)
+    x0, c_, jac_ = sin_system(n, m)
+    cval = np.zeros(m)
+    J = np.zeros((m, n), order='F')
+    jac_(J, cval, x0)
+    Jct = ctx.matrix(n, m, np.asfortranarray(J.T))
+    Z = ctx.matrix(n, m)
+    S, Vt, rank = L.ksvd_(Jct, Z)
+    assert rank == m
+    Zh = Z.download()
+    step = rng.standard_normal(n)
+    step -= Zh @ (Zh.T @ step)
+    step *= 5.0 / np.linalg.norm(step)
+    return ctx, n, m, x0, c_, jac_, Jct, Z, S, Vt, step, rng
+
+
+def test_newton_retraction_with_host_callback(sin_setup):
+    """test_retractions.jl:90-103: nonlinear c! as a host callable (x downloaded per evaluation)."""
+    ctx, n, m, x0, c_, jac_, Jct, Z, S, Vt, step, _ = sin_setup
+    nr = L.NR(L.DeviceBasis(Z), S, Vt, 1.0, 1000, L.NRWork(m), False, None)
+    xt_h = x0 + step
+    xtilde, x, xnew = ctx.vector(n, xt_h), ctx.vector(n, x0), ctx.vector(n)
+    cval, cval2 = np.zeros(m), np.zeros(m)
+    # oracle with the same factors
+    nr0 = R.NR(Z.download(), S, Vt, 1.0, 1000, R.NRWork(m), False, R.InequalityData())
+    for tol in (1e-6, 1e-8):
+        nr.tol = nr0.tol = tol
+        flag, i, _ = L.retract_(cval, xnew, c_, xtilde, x, nr)
+        xn = xnew.download()
+        c_(cval2, xn)
+        assert flag == 0 and np.max(np.abs(cval)) < tol
+        assert np.all(cval == cval2)                       # cval is c! evaluated at xnew
+        np.testing.assert_array_equal(xtilde.download(), xt_h)
+        assert abs(step @ (xn - xt_h)) < 1e-6
+        xn0, cv0 = np.zeros(n), np.zeros(m)
+        f0, i0, _ = R.retract_(cv0, xn0, c_, xt_h, x0, nr0)
+        assert (flag, i) == (f0, i0)
+        np.testing.assert_allclose(xn, xn0, atol=1e-12)
+
+
+def test_pcg_and_projection_penalty(sin_setup):
+    """test_retractions.jl:105-141 (pcg!) and :144-157 (ProjPenalty) on the device."""
+    from lfpsqp_jl_amd.projpenalty import _JacPlain
+    ctx, n, m, x0, c_, jac_, Jct, Z, S, Vt, step, rng = sin_setup
+    # pcg!: solve (mu I + J'J) x = b with a random J
+    Jr = rng.standard_normal((m, n))
+    Jd = ctx.matrix(n, m, np.asfortranarray(Jr.T))
+    w = L.ProjPenaltyWork(ctx, m, n, False)
+    for mu in (1e-1, 1e-2, 1e-4):
+        bh = rng.standard_normal(n)
+        x, r = ctx.vector(n), ctx.vector(n, bh)
+        flag, i = L.pcg_(mu, _JacPlain(Jd, w), L.no_precondition, x, r, w.p, w.z, None, 1e-6, 100)
+        x0h, r0 = np.zeros(n), bh.copy()
+        f0, i0 = R.pcg_(mu, Jr, R.no_precondition, x0h, r0, np.zeros(n), np.zeros(n), np.zeros(m), 1e-6, 100)
+        assert (flag, i) == (f0, i0) and flag == 0
+        xh = x.download()
+        assert np.linalg.norm(r.download()) < 1e-6
+        assert np.linalg.norm(mu * xh + Jr.T @ (Jr @ xh) - bh) < 1e-6
+        np.testing.assert_allclose(xh, x0h, atol=1e-10)
+
+    # ProjPenalty with a device-side jac! adapter around the host Jacobian
+    def jac_dev(Jct_, cval, xdev):
+        J = np.zeros((m, n), order='F')
+        jac_(J, cval, xdev.download(n, 0))
+        Jct_.upload(np.asfortranarray(J.T))
+
+    idc = L.InequalityDecomp(ctx, n, m, Jct)
+    pp = L.ProjPenalty(jac_dev, None, S, Vt, m, 0.01, 1.0, 100, 200, L.ProjPenaltyWork(ctx, m, n, False), False, idc, None)
+    J0 = np.zeros((m, n), order='F')
+    pp0 = R.ProjPenalty(jac_, Z.download(), S, Vt, m, 0.01, 1.0, 100, 200, R.ProjPenaltyWork(m, n, m, n), False,
+                        R.InequalityDecomp(np.zeros((0, 0)), *(np.zeros(0) for _ in range(5)), np.zeros((0, 0)), 0), R.InequalityData())
+    xt_h = x0 + step
+    xtilde, x, xnew = ctx.vector(n, xt_h), ctx.vector(n, x0), ctx.vector(n)
+    cval, cval2 = np.zeros(m), np.zeros(m)
+    for tol in (1e-6, 1e-8, 1e-10):
+        pp.tol = pp0.tol = tol
+        flag, i, pcg_i = L.retract_(cval, xnew, c_, xtilde, x, pp)
+        xn = xnew.download()
+        c_(cval2, xn)
+        assert flag == 0 and np.max(np.abs(cval)) < tol
+        assert np.all(cval == cval2)
+        np.testing.assert_array_equal(xtilde.download(), xt_h)
+        assert np.linalg.norm(step) >= np.linalg.norm(xn - x0) - tol
+        xn0, cv0 = np.zeros(n), np.zeros(m)
+        f0, i0, p0 = R.retract_(cv0, xn0, c_, xt_h, x0, pp0)
+        assert (flag, i, pcg_i) == (f0, i0, p0)
+        np.testing.assert_allclose(xn, xn0, atol=1e-11)
+
+
+def test_linesearch_known_answers(dev_ctx):
+    """test_linesearch.jl: f = x^2, x = -0.23, d = 1 => Armijo alpha = 0.25, exact alpha = 0.23."""
+    ctx = dev_ctx
+    f = lambda v: float(v.download()[0] ** 2)
+    x, xnew, d, g = ctx.vector(1, [-0.23]), ctx.vector(1), ctx.vector(1, [1.0]), ctx.vector(1, [-0.46])
+    fval = 0.23 ** 2
+    p = L.LFPSQPParams()
+    flag, t1, t2, newf, f_diff, step_diff, alpha = L.armijo_(xnew, x, 1, d, g, f, fval, L.Euclidean(), np.zeros(0), None, p, L.ArmijoWork(x))
+    assert flag == t1 == t2 == 0 and x.download()[0] == -0.23
+    assert newf == pytest.approx(f(xnew)) and f_diff == pytest.approx(fval - newf)
+    assert step_diff == pytest.approx(alpha) and alpha == pytest.approx(0.25)
+    flag, t1, t2, newf, f_diff, step_diff, alpha = L.exact_linesearch_(xnew, x, 1, d, f, fval, L.Euclidean(), np.zeros(0), None, p,
+                                                                       L.ExactLinesearchWork(x))
+    assert flag == t1 == t2 == 0 and x.download()[0] == -0.23
+    assert newf == pytest.approx(f(xnew)) and f_diff == pytest.approx(fval - newf)
+    assert step_diff == pytest.approx(alpha) and alpha == pytest.approx(0.23, abs=1e-6)
+
+
+# ------------------------------------------------------------------------------- end to end
+def _compare_traces(tr, tr0, rtol=1e-10):
+    assert len(tr) == len(tr0)
+    for a, b in zip(tr, tr0):
+        assert np.linalg.norm(a['x'] - b['x']) <= rtol * np.linalg.norm(b['x']), f"iterate {a['iter']} deviates"
+        for k in ('tn_iter', 'steptype', 'mtype', 'retract_iter1', 'retract_iter2', 'alpha', 'ls_flag', 'rank'):
+            assert a.get(k) == b.get(k), (a['iter'], k, a.get(k), b.get(k))
+
+
+def test_config1_rosenbrock_through_host_callbacks(dev_ctx):
+    """BASELINE configs[0] / README.md:18-37 through the device driver with host callables."""
+    f, dv = rosenbrock()
+    x, obj, lam, ti = L.optimize(f, np.zeros(2), L.LFPSQPParams(disp=L.DisplayOption.off),
+                                 derivatives=L.Derivatives(dv.grad_, dv.hess_lag_vec_), ctx=dev_ctx)
+    assert ti.condition == L.TerminationCondition.f_tol and ti.iter == 17 and len(obj) == 18
+    assert ti.kkt_diff == pytest.approx(4.332627751789361e-5, rel=1e-9)
+    assert ti.f_diff == pytest.approx(1.0898882046786806e-7, rel=1e-8)
+    assert ti.step_diff == pytest.approx(0.0007384068067118611, rel=1e-8)
+
+
+@pytest.mark.parametrize("do_project_retract", [False, True])
+def test_config2_single_linear_equality(dev_ctx, do_project_retract):
+    """BASELINE configs[1]: f = x'x, c = x_1 - 0.75 (README.md:42-53 pattern)."""
+    ctx = dev_ctx
+    n = 100_000 if not _is_emu(ctx) else 2000
+    prob0, x0 = synth.config2(n)
+    tr0, tr = [], []
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, None, None, 1,
+                                     R.LFPSQPParams(do_project_retract=do_project_retract, disp=R.DisplayOption.off), trace=tr0)
+    J = np.zeros((n, 1), order='F')
+    J[0, 0] = 1.0
+    P = L.QuadLinearBallBox(ctx, n, 1, ctx.matrix(n, 1, J), np.array([0.75]))
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=do_project_retract, disp=L.DisplayOption.off), trace=tr)
+    assert ti.condition.name == tir.condition.name and ti.iter == tir.iter
+    _compare_traces(tr, tr0)
+    np.testing.assert_allclose(lam, lamr, rtol=1e-9)
+    np.testing.assert_allclose(obj, objr, rtol=1e-12)
+
+
+@pytest.mark.parametrize("do_project_retract", [False, True])
+def test_config3_dense_linear_equalities(dev_ctx, do_project_retract):
+    """BASELINE configs[2] shape at oracle-sized n: trajectory parity, both retractions."""
+    ctx = dev_ctx
+    n, m = (20000, 32) if not _is_emu(ctx) else (2500, 6)
+    prob0, x0 = synth.config3(n, m)
+    tr0, tr = [], []
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, None, None, m,
+                                     R.LFPSQPParams(do_project_retract=do_project_retract, disp=R.DisplayOption.off), trace=tr0)
+    P = L.QuadLinearBallBox(ctx, n, m, ctx.matrix(n, m).hash_fill(1), prob0.b)
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=do_project_retract, disp=L.DisplayOption.off), trace=tr)
+    assert ti.condition.name == tir.condition.name and ti.iter == tir.iter
+    _compare_traces(tr, tr0)
+    assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
+    np.testing.assert_allclose(lam, lamr, rtol=1e-8, atol=1e-12)
+
+
+def test_config4_ball_box_newton_retraction(dev_ctx):
+    """BASELINE configs[3]: equalities + ball (slack form) + four-way bounds, NR retraction, Armijo."""
+    ctx = dev_ctx
+    emu = _is_emu(ctx)
+    n, m = (4000, 16) if not emu else (200, 4)
+    P0 = synth.BallBoxProblem(n, m)
+    x0 = P0.x0
+    if emu:   # start near the feasible point so the emulator is not asked for ~2000 Newton iterations
+        x0 = 0.97 * synth.hash_vector(2, n) + 0.03 * P0.x0
+    maxiter = 10000 if not emu else 3
+    tr0, tr = [], []
+    xr, objr, lamr, tir = R.optimize(P0.f, P0.c_, P0.d_, x0, P0.xl, P0.xu, P0.m, P0.p,
+                                     R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=maxiter),
+                                     derivatives=P0.derivatives(), trace=tr0)
+    Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+    P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=maxiter), trace=tr)
+    assert ti.condition.name == tir.condition.name and ti.iter == tir.iter
+    _compare_traces(tr, tr0)
+    assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
+    np.testing.assert_allclose(lam, lamr, rtol=1e-7, atol=1e-10)
+    # feasibility of the result (LFPSQP iterates are feasible)
+    if not emu:
+        assert np.abs(P0.eq.Jct.T @ x - P0.eq.b).max() < 1e-5 and x @ x <= P0.R2 + 1e-5
+        assert np.all(x >= P0.xl - 1e-9) and np.all(x <= P0.xu + 1e-9)
+
+
+def test_config4_default_projection_penalty_with_bounds(dev_ctx):
+    """Same problem through the reference's DEFAULT retraction (ProjPenalty + pcg! with the full
+    bound Jacobian operator, src/retractions.jl:324)."""
+    ctx = dev_ctx
+    emu = _is_emu(ctx)
+    n, m = (2000, 8) if not emu else (120, 3)
+    P0 = synth.BallBoxProblem(n, m)
+    x0 = 0.9 * synth.hash_vector(2, n) + 0.1 * P0.x0
+    maxiter = 4 if not emu else 2
+    tr0, tr = [], []
+    xr, objr, lamr, tir = R.optimize(P0.f, P0.c_, P0.d_, x0, P0.xl, P0.xu, P0.m, P0.p,
+                                     R.LFPSQPParams(disp=R.DisplayOption.off, maxiter=maxiter), derivatives=P0.derivatives(), trace=tr0)
+    Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+    P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(disp=L.DisplayOption.off, maxiter=maxiter), trace=tr)
+    assert ti.iter == tir.iter
+    _compare_traces(tr, tr0, rtol=1e-9)
