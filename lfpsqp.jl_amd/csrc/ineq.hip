@@ -69,12 +69,12 @@ struct CalcHF {
         if (v0) {
             const double v = h_of(x[i], x[hs + i], id.q[i], id.r[i], id.s[i], id.t[i]);
             h[i] = v;
-            red[0] = fmax(red[0], fabs(v));
+            red[0] = nanmax(red[0], fabs(v));
         }
         if (v1) {
             const double v = h_of(x[i + 1], x[hs + i + 1], id.q[i + 1], id.r[i + 1], id.s[i + 1], id.t[i + 1]);
             h[i + 1] = v;
-            red[0] = fmax(red[0], fabs(v));
+            red[0] = nanmax(red[0], fabs(v));
         }
     }
 };

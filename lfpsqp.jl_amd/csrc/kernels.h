@@ -40,6 +40,10 @@ __device__ __forceinline__ double ld_scal(const double* p) { return __hip_atomic
 __device__ __forceinline__ int64_t ld_stat(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
 
+// max that PROPAGATES NaN like Julia's max / norm(v, Inf) (fmax would drop it): a NaN constraint
+// value must read as "not converged" (reference src/retractions.jl:135, src/optimize.jl:320).
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : fmax(a, b)); }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -47,7 +51,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    for (int o = 32; o > 0; o >>= 1) v = nanmax(v, __shfl_xor(v, o));
     return v;
 }
 
@@ -67,7 +71,7 @@ __device__ __forceinline__ void block_reduce_store(double (&red)[NRED], unsigned
 #pragma unroll
         for (int k = 0; k < NRED; ++k) {
             if ((ismax >> k) & 1u)
-                dst[k] = fmax(fmax(sm[0][k], sm[1][k]), fmax(sm[2][k], sm[3][k]));
+                dst[k] = nanmax(nanmax(sm[0][k], sm[1][k]), nanmax(sm[2][k], sm[3][k]));
             else
                 dst[k] = (sm[0][k] + sm[1][k]) + (sm[2][k] + sm[3][k]);
         }
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const double* __restr
     double acc = 0.0;
     if (col < ncols) {
         if (mx) {
-            for (int64_t r = g; r < nrows; r += 32) acc = fmax(acc, part[r * part_ld + col]);
+            for (int64_t r = g; r < nrows; r += 32) acc = nanmax(acc, part[r * part_ld + col]);
         } else {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             int64_t r = g;
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const double* __restr
     if (g == 0 && col < ncols) {
         double r = sm[0][c];
         if (mx) {
-            for (int k = 1; k < 32; ++k) r = fmax(r, sm[k][c]);
+            for (int k = 1; k < 32; ++k) r = nanmax(r, sm[k][c]);
         } else {
             // pairwise over the 32 groups
             double s[32];

@@ -50,8 +50,8 @@ struct AmaxF {
     __device__ __forceinline__ bool skip() const { return false; }
     __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
         const double2 a = ld2(x + i);
-        if (v0) red[0] = fmax(red[0], fabs(a.x));
-        if (v1) red[0] = fmax(red[0], fabs(a.y));
+        if (v0) red[0] = nanmax(red[0], fabs(a.x));
+        if (v1) red[0] = nanmax(red[0], fabs(a.y));
     }
 };
 struct WaxpbyF {  // z = a*x + b*y

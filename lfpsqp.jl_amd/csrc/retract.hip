@@ -127,7 +127,10 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
     int64_t i = 0;
     while (i < maxiter) {
         double cmax = 0.0;
-        for (int k = 0; k < m; ++k) cmax = fmax(cmax, fabs(cval[k]));
+        for (int k = 0; k < m; ++k) {                                 // NaN-propagating, like norm(cval, Inf)
+            const double a = fabs(cval[k]);
+            cmax = (cmax != cmax) ? cmax : ((a != a) ? a : fmax(cmax, a));
+        }
         if (cmax < tol) break;                                        // :135  (NaN compares false, like Julia)
         for (int k = 0; k < m; ++k) {                                 // :140  tmp = -D cval
             double s = 0.0;

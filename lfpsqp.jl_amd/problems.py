@@ -24,16 +24,19 @@ from .retractions import DeviceConstraints
 
 class QuadLinearBallBox:
     def __init__(self, ctx: Context, n: int, m: int, Jct: DeviceMatrix, b, R2: Optional[float] = None, xl=None, xu=None,
-                 xc: float = 0.0, n_global: Optional[int] = None):
-        """Jct: device matrix with n + p rows and m + p columns (p = 1 iff R2 is given) whose leading
-        n x m block holds the constraint gradients (row n and column m are managed here)."""
+                 xc: float = 0.0, n_global: Optional[int] = None, owns_slack: bool = True):
+        """n = rows of this rank's shard.  Jct: device matrix with n + ploc rows and m + p columns
+        (p = 1 iff R2 is given; ploc = 1 on the rank that owns the slack variable -- the last one --
+        else 0) whose leading n x m block holds the constraint gradients; the slack row and the ball
+        column are managed here."""
         self.ctx, self.n, self.m, self.xc = ctx, n, m, float(xc)
         self.p = 0 if R2 is None else 1
-        self.N, self.M = n + self.p, m + self.p
+        self.ploc = self.p if owns_slack else 0
+        self.N, self.M = n + self.ploc, m + self.p
         assert Jct.n == self.N and Jct.m == self.M
         self.Jct = Jct
         self.R2 = 0.0 if R2 is None else float(R2)
-        self.cons = DeviceConstraints(Jct, m, b, has_ball=self.p == 1, R2=self.R2, n_x=n, slack_row=n if self.p else -1)
+        self.cons = DeviceConstraints(Jct, m, b, has_ball=self.p == 1, R2=self.R2, n_x=n, slack_row=n if self.ploc else -1)
         self.xl = None if xl is None else np.asarray(xl, dtype=np.float64)
         self.xu = None if xu is None else np.asarray(xu, dtype=np.float64)
         self.n_global = n if n_global is None else n_global
@@ -56,7 +59,7 @@ class QuadLinearBallBox:
         h = 2.0 + (2.0 * float(lam[self.m]) if self.p else 0.0)
         L = self.ctx.L
         self.ctx.check(L.lfpsqp_vec_fill_range(self.ctx.h, hx.h, 0, self.n, h))
-        if self.p:
+        if self.ploc:
             self.ctx.check(L.lfpsqp_vec_fill_range(self.ctx.h, hx.h, self.n, 1, 0.0))
 
     # -- the slack transformation of src/optimize.jl:23-36 --------------------------------------
@@ -64,10 +67,16 @@ class QuadLinearBallBox:
         x0 = np.asarray(x0, dtype=np.float64)
         if not self.p:
             return x0, self.xl, self.xu
-        x0a = np.concatenate([x0, [float(x0 @ x0) - self.R2]])
+        tmp = self.ctx.vector(self.n, x0)                       # global x0'x0 (all-reduced over the shards)
+        saved, self.xc = self.xc, 0.0
+        xx = self.f(tmp) if self.n else self.f(self.ctx.vector(0))
+        self.xc = saved
+        tmp.free()
         xl = -np.inf * np.ones(self.n) if self.xl is None else self.xl
         xu = np.inf * np.ones(self.n) if self.xu is None else self.xu
-        return x0a, np.concatenate([xl, [-np.inf]]), np.concatenate([xu, [0.0]])
+        if not self.ploc:                                       # another rank owns the slack variable
+            return x0, xl, xu
+        return np.concatenate([x0, [xx - self.R2]]), np.concatenate([xl, [-np.inf]]), np.concatenate([xu, [0.0]])
 
     def optimize(self, x0, param: LFPSQPParams | None = None, trace=None):
         x0a, xl, xu = self.aux_start(x0)

@@ -151,7 +151,7 @@ def retract_pp(cval, xnew, c_, xtilde, x, method: ProjPenalty):
             inequality_gradient_(idecomp, xnew, idata)
             J.refresh()
             hmax = calculate_h_(w.h, xnew, idata)
-            curtol = max(curtol, hmax)
+            curtol = hmax if (math.isnan(hmax) or hmax > curtol) else curtol     # Julia max propagates NaN
             hh = dot(w.h, w.h)
         if curtol < tol:                                     # :359
             break

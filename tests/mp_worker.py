@@ -1,0 +1,72 @@
+"""Worker of tests/test_multirank_gloo.py: rank `r` of `w` processes, emulator build of the C-ABI
+library, all-reduce callback over torch.distributed/gloo.  Writes its shard results to an .npz."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import lfpsqp_jl_amd as L  # noqa: E402
+from lfpsqp_jl_amd.distributed import torch_allreduce_callback  # noqa: E402
+from oracle import synth  # noqa: E402
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lib = L.load_library(os.path.join(ROOT, "tests", "emu", "_build", "liblfpsqp_emu.so"))
+    ctx = L.Context(0, lib)
+    ctx.comm_init_callback(rank, world, torch_allreduce_callback(None))
+    res = {}
+    # ---- sharded projcg on the bench workload -------------------------------------------------
+    n, m = 5000, 6
+    r0, r1 = ctx.shard_range(n)
+    nl = r1 - r0
+    J = ctx.matrix(nl, m).hash_fill(1, r0, n)
+    Z = ctx.matrix(nl, m)
+    S, Vt, rank_ = L.ksvd_(J, Z)
+    A = L.DiagOperator(0.0, ctx.vector(nl).hash_fill(3, r0, 4.0, 5.0))
+    b = ctx.vector(nl).hash_fill(4, r0)
+    x, lam = ctx.vector(nl), ctx.vector(m)
+    it, nr = L.projcg_(x, lam, A, L.DeviceBasis(Z), b, None, tol=1e-10, maxit=500, n_global=n)
+    res.update(r0=r0, r1=r1, S=S, x=x.download(), lam=lam.download(), it=it, nr=nr, Z=Z.download(), Vt=Vt)
+    # ---- sharded config 3 through the outer driver (NR and ProjPenalty) ----------------------
+    n3, m3 = 4000, 5
+    q0, q1 = ctx.shard_range(n3)
+    Jct = ctx.matrix(q1 - q0, m3).hash_fill(1, q0, n3)
+    xs = ctx.vector(q1 - q0).hash_fill(2, q0)
+    bb = ctx.vector(m3)
+    L.gemv_t(Jct, xs, bb)
+    for tag, dpr in (("nr", False), ("pp", True)):
+        P = L.QuadLinearBallBox(ctx, q1 - q0, m3, Jct, bb.download(), n_global=n3)
+        xo, obj, lamk, ti = P.optimize(np.ones(q1 - q0), L.LFPSQPParams(do_project_retract=dpr, disp=L.DisplayOption.off))
+        res.update({f"c3{tag}_x": xo, f"c3{tag}_obj": obj, f"c3{tag}_lam": lamk, f"c3{tag}_iter": ti.iter, "q0": q0, "q1": q1})
+    # ---- sharded config 4: the slack variable lives on the LAST rank --------------------------
+    n4, m4 = 3000, 4
+    s0, s1 = ctx.shard_range(n4)
+    last = rank == world - 1
+    p_loc = 1 if last else 0
+    J4 = ctx.matrix(s1 - s0 + p_loc, m4 + 1).hash_fill(1, s0, n4, 1.0, s1 - s0, m4)
+    xs4 = ctx.vector(s1 - s0 + p_loc).hash_fill(2, s0)
+    if last:
+        ctx.check(ctx.L.lfpsqp_vec_fill_range(ctx.h, xs4.h, s1 - s0, 1, 0.0))
+    b4 = ctx.vector(m4 + 1)
+    L.gemv_t(J4, xs4, b4, ncols=m4)
+    i = np.arange(s0, s1)
+    xl = np.where((i % 4 == 1) | (i % 4 == 3), -1.0, -np.inf)
+    xu = np.where((i % 4 == 2) | (i % 4 == 3), 1.0, np.inf)
+    x0 = 0.97 * synth.hash_vector(2, n4)[s0:s1] + 0.03 * 0.5
+    P4 = L.QuadLinearBallBox(ctx, s1 - s0, m4, J4, b4.download()[:m4], R2=n4 / 2.0, xl=xl, xu=xu, n_global=n4, owns_slack=last)
+    xo, obj, lamk, ti = P4.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=3))
+    res.update(c4_x=xo, c4_obj=obj, c4_lam=lamk, c4_iter=ti.iter, s0=s0, s1=s1)
+    np.savez(out, **res)
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

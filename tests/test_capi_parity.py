@@ -266,3 +266,14 @@ def test_factorize_rank_deficient(dev_ctx):
     np.testing.assert_allclose(Zh[:, :6].T @ Zh[:, :6], np.eye(6), atol=5e-14)
     assert np.all(Zh[:, 6:] == 0.0)
     np.testing.assert_allclose((Zh * S) @ Vt, Jh, atol=1e-11)
+
+
+def test_max_reductions_propagate_nan(dev_ctx):
+    """norm(v, Inf) in Julia is NaN if any entry is NaN; the retraction loops rely on that
+    ("NaN < tol" is false => keep iterating / report failure, src/retractions.jl:135)."""
+    ctx = dev_ctx
+    for n, pos in ((5, 3), (3000, 1777), (3000, 2999)):
+        h = np.ones(n)
+        h[pos] = np.nan
+        assert math.isnan(L.amax(ctx.vector(n, h)))
+    assert L.amax(ctx.vector(10, -np.arange(10.0))) == 9.0

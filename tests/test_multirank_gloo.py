@@ -1,0 +1,92 @@
+"""world_size-2 run of the sharded hot path on CPU: two processes, the emulator build of the C-ABI
+library, m-vector / CG-scalar all-reduces through torch.distributed (gloo) via the library's
+callback transport.  Checks the row-sharded results against the single-process oracle."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import lfpsqp_ref as R
+from oracle import synth
+
+from .helpers import DiagOpRef
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.fixture(scope="module")
+def two_ranks(emu_lib, tmp_path_factory):
+    d = tmp_path_factory.mktemp("mp")
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), str(r), "2", str(port), str(d / f"r{r}.npz")],
+                              cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [np.load(d / f"r{r}.npz") for r in range(2)]
+
+
+def test_shards_partition_the_rows(two_ranks):
+    a, b = two_ranks
+    assert a["r0"] == 0 and a["r1"] == b["r0"] and b["r1"] == 5000 and a["r1"] % 1024 == 0
+
+
+def test_sharded_factorize_and_projcg_match_single_process_oracle(two_ranks):
+    a, b = two_ranks
+    n, m = 5000, 6
+    Jh = synth.hash_matrix(1, n, m)
+    Z = np.vstack([a["Z"], b["Z"]])
+    np.testing.assert_array_equal(a["S"], b["S"])                        # replicated factors agree bit for bit
+    np.testing.assert_array_equal(a["lam"], b["lam"])
+    np.testing.assert_allclose(a["S"], np.linalg.svd(Jh, compute_uv=False), rtol=1e-12)
+    np.testing.assert_allclose(Z.T @ Z, np.eye(m), atol=1e-13)
+    np.testing.assert_allclose((Z * a["S"]) @ a["Vt"], Jh, atol=1e-12)
+    av = 4.0 * synth.hash_vector(3, n) + 5.0
+    bv = synth.hash_vector(4, n)
+    x0, l0 = np.zeros(n), np.zeros(m)
+    i0, nr0 = R.projcg_(x0, l0, DiagOpRef(av), np.asfortranarray(Z), bv, np.zeros(m), tol=1e-10, maxit=500)
+    x = np.concatenate([a["x"], b["x"]])
+    assert int(a["it"]) == int(b["it"]) == i0
+    assert np.linalg.norm(x - x0) <= 1e-10 * np.linalg.norm(x0)
+    np.testing.assert_allclose(a["lam"], l0, atol=1e-11)
+
+
+@pytest.mark.parametrize("tag,dpr", [("nr", False), ("pp", True)])
+def test_sharded_config3_driver(two_ranks, tag, dpr):
+    a, b = two_ranks
+    n, m = 4000, 5
+    prob0, x0 = synth.config3(n, m)
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, None, None, m,
+                                     R.LFPSQPParams(do_project_retract=dpr, disp=R.DisplayOption.off))
+    x = np.concatenate([a[f"c3{tag}_x"], b[f"c3{tag}_x"]])
+    assert int(a[f"c3{tag}_iter"]) == int(b[f"c3{tag}_iter"]) == tir.iter
+    assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
+    np.testing.assert_allclose(a[f"c3{tag}_lam"], lamr, rtol=1e-8, atol=1e-12)
+    np.testing.assert_array_equal(a[f"c3{tag}_lam"], b[f"c3{tag}_lam"])
+    np.testing.assert_allclose(a[f"c3{tag}_obj"], objr, rtol=1e-12)
+
+
+def test_sharded_config4_slack_on_last_rank(two_ranks):
+    a, b = two_ranks
+    n, m = 3000, 4
+    P0 = synth.BallBoxProblem(n, m)
+    x0 = 0.97 * synth.hash_vector(2, n) + 0.03 * 0.5
+    xr, objr, lamr, tir = R.optimize(P0.f, P0.c_, P0.d_, x0, P0.xl, P0.xu, m, 1,
+                                     R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=3),
+                                     derivatives=P0.derivatives())
+    x = np.concatenate([a["c4_x"], b["c4_x"]])
+    assert int(a["c4_iter"]) == int(b["c4_iter"]) == tir.iter
+    assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
+    np.testing.assert_allclose(a["c4_obj"], objr, rtol=1e-11)
+    np.testing.assert_allclose(a["c4_lam"], lamr, rtol=1e-7, atol=1e-10)

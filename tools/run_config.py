@@ -1,0 +1,31 @@
+"""Run a BASELINE config end to end on the GPU at full size:  python tools/run_config.py {2|3|4} [n] [m] [--pp]"""
+import sys, time; sys.path.insert(0, '.')
+import numpy as np
+import lfpsqp_jl_amd as L
+
+cfg = int(sys.argv[1]); args = [a for a in sys.argv[2:] if not a.startswith('--')]
+pp = '--pp' in sys.argv
+ctx = L.Context(0)
+t0 = time.perf_counter()
+if cfg == 2:
+    n = int(float(args[0])) if args else 1_000_000
+    J = ctx.matrix(n, 1); col = np.zeros((n, 1), order='F'); col[0, 0] = 1.0; J.upload(col)
+    P = L.QuadLinearBallBox(ctx, n, 1, J, np.array([0.75])); x0 = np.ones(n)
+elif cfg == 3:
+    n = int(float(args[0])) if args else 10_000_000; m = int(args[1]) if len(args) > 1 else 128
+    Jct = ctx.matrix(n, m).hash_fill(1)
+    xs = ctx.vector(n).hash_fill(2); b = ctx.vector(m); L.gemv_t(Jct, xs, b)
+    P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download()); x0 = np.ones(n)
+else:
+    n = int(float(args[0])) if args else 10_000_000; m = int(args[1]) if len(args) > 1 else 128
+    Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+    xs = ctx.vector(n + 1).hash_fill(2, 0, 1.0, 0.0); ctx.check(ctx.L.lfpsqp_vec_fill_range(ctx.h, xs.h, n, 1, 0.0))
+    b = ctx.vector(m + 1); L.gemv_t(Jct, xs, b, ncols=m)
+    i = np.arange(n)
+    xl = np.where((i % 4 == 1) | (i % 4 == 3), -1.0, -np.inf); xu = np.where((i % 4 == 2) | (i % 4 == 3), 1.0, np.inf)
+    P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download()[:m], R2=n / 2.0, xl=xl, xu=xu); x0 = 0.5 * np.ones(n)
+ctx.sync(); print(f"setup {time.perf_counter()-t0:.2f}s  device={ctx.device_name}", flush=True)
+t0 = time.perf_counter()
+x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=pp))
+dt = time.perf_counter() - t0
+print(ti); print(f"optimize wall {dt:.2f}s  f={obj[-1]:.6e}  |lam|max={np.abs(lam).max():.3e}")
