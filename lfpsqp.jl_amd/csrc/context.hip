@@ -61,7 +61,7 @@ int ensure_mvec(lfpsqp_ctx* ctx, size_t doubles) {
 
 int allreduce_dev(lfpsqp_ctx* ctx, double* buf, int64_t count, int op) {
     Comm& c = ctx->comm;
-    if (c.nranks <= 1 || count == 0) return 0;
+    if (c.kind == Comm::NONE || count == 0) return 0;
     if (c.kind == Comm::RCCL) {
         const int ncclFloat64 = 8, ncclSum = 0, ncclMax = 2;  // rccl.h enums
         int rc = c.ncclAllReduce(buf, buf, (size_t)count, ncclFloat64, op == 1 ? ncclMax : ncclSum, c.nccl_comm, ctx->stream);

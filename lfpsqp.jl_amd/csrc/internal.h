@@ -46,6 +46,9 @@ struct lfpsqp_ctx {
     std::string err;
     std::string devname;
     lfpsqp::Comm comm;
+    // an initialised communicator (even with one rank) routes every reduction through it, so the
+    // multi-GPU launch sequence can be exercised on a 1-GPU box
+    bool comm_active() const { return comm.kind != lfpsqp::Comm::NONE; }
 
     // reduction workspace: partial sums [rows][ld] (device)
     double* part = nullptr;
@@ -161,7 +164,7 @@ int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const
     }
     if (NRED > 0) {
         if (tiles == 0) LF_HIP(ctx, hipMemsetAsync(red_out, 0, sizeof(double) * NRED, ctx->stream));
-        if (ctx->comm.nranks == 1) {
+        if (!ctx->comm_active()) {
             if (tiles > 0) LF_TRY(launch_reduce(ctx, tiles, NRED, kMaxRed, 0u, red_out, post));
             else {
                 hipLaunchKernelGGL((post_kernel<POST>), dim3(1), dim3(1), 0, ctx->stream, red_out, post);
@@ -192,7 +195,7 @@ int run_vec(lfpsqp_ctx* ctx, int64_t n, F f, unsigned ismax, double* red_out, PO
     if (prof_slot >= 0) prof_end(ctx, prof_slot);
     LF_LAUNCH_CHECK(ctx);
     if (NRED > 0) {
-        if (ctx->comm.nranks == 1) {
+        if (!ctx->comm_active()) {
             LF_TRY(launch_reduce(ctx, grid, NRED, kMaxRed, ismax, red_out, post));
         } else {
             const unsigned all = (1u << NRED) - 1u;

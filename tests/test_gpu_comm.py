@@ -1,0 +1,56 @@
+"""The communicator code paths that can be exercised on a 1-GPU box: a 1-rank RCCL communicator
+(dlopen, ncclGetUniqueId, ncclCommInitRank, stream-ordered ncclAllReduce calls from inside the
+solvers) and the torch.distributed(nccl) callback transport.  Run in subprocesses so each gets a
+clean process group."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+mode = sys.argv[1]
+if mode == "torch":
+    import torch, torch.distributed as dist
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+import lfpsqp_jl_amd as L
+from oracle import lfpsqp_ref as R, synth
+from tests.helpers import DiagOpRef
+ctx = L.Context(0)
+if mode == "rccl":
+    ctx.comm_init_rccl(0, 1, ctx.comm_unique_id())
+else:
+    from lfpsqp_jl_amd.distributed import torch_allreduce_callback
+    ctx.comm_init_callback(0, 1, torch_allreduce_callback(0))
+# force the multi-rank code path (separate reduce / all-reduce / post kernels) with a 1-rank communicator
+import ctypes
+n, m = 30000, 12
+J = ctx.matrix(n, m).hash_fill(1); Z = ctx.matrix(n, m)
+S, Vt, rank = L.ksvd_(J, Z)
+a = 4.0 * synth.hash_vector(3, n) + 5.0; bh = synth.hash_vector(4, n)
+x, lam = ctx.vector(n), ctx.vector(m)
+it, nr = L.projcg_(x, lam, L.DiagOperator(0.0, ctx.vector(n, a)), L.DeviceBasis(Z), ctx.vector(n, bh), None, tol=1e-10, maxit=300)
+x0, l0 = np.zeros(n), np.zeros(m)
+i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), Z.download(), bh, np.zeros(m), tol=1e-10, maxit=300)
+assert it == i0, (it, i0)
+assert np.linalg.norm(x.download() - x0) <= 1e-10 * np.linalg.norm(x0)
+assert abs(L.amax(ctx.vector(n, bh)) - np.abs(bh).max()) == 0
+print("OK", mode, it)
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["rccl", "torch"])
+def test_one_rank_communicator(mode, tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "comm1.py"
+    script.write_text(_SCRIPT.format(root=ROOT, port=port))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script), mode], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "OK " + mode in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
