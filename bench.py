@@ -36,6 +36,7 @@ def main(argv=None, lib=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=float, default=2e6)
     ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl")
+    ap.add_argument("--lib", default=None, help="(development) alternative build of liblfpsqp_hip.so to load")
     args = ap.parse_args(argv)
     n, m, K, W = int(args.n), args.m, args.steps, args.warmup
 
@@ -55,6 +56,8 @@ def main(argv=None, lib=None):
 
     import lfpsqp_jl_amd as L
 
+    if args.lib:
+        lib = L.load_library(args.lib)
     ctx = L.Context(local_rank, lib)
     if world > 1:
         if args.comm == "rccl":
@@ -179,7 +182,8 @@ def cpu_baseline(ns, m, n_full):
     timed on this box's host cores on a bounded sample: n_s rows instead of n, same m, same
     generator; iterations/s is rescaled by n_s/n (the loop is linear in n)."""
     from oracle import port
-    threads = port.lib().port_num_threads()
+    threads = port.usable_cpus()
+    port.lib().port_set_num_threads(threads)
     scale = 2.0 ** math.floor(math.log2(math.sqrt(3.0 / ns)))
     U = port.hash_matrix(1, ns, m, scale=scale)
     a = port.hash_vector(3, ns, 0, 4.0, 5.0)

@@ -50,7 +50,7 @@ int ensure_mvec(lfpsqp_ctx* ctx, size_t doubles) {
     if (ctx->d_m) LF_HIP(ctx, hipFree(ctx->d_m));
     if (ctx->h_m) LF_HIP(ctx, hipHostFree(ctx->h_m));
     ctx->d_m = nullptr; ctx->h_m = nullptr; ctx->m_cap = 0;
-    const size_t cap = (size_t)round_up((int64_t)doubles + 64, kTileRows);
+    const size_t cap = (size_t)round_up((int64_t)doubles + 64, kPadRows);
     LF_HIP(ctx, hipMalloc((void**)&ctx->d_m, cap * sizeof(double)));
     LF_HIP(ctx, hipMemsetAsync(ctx->d_m, 0, cap * sizeof(double), ctx->stream));
     LF_HIP(ctx, hipHostMalloc((void**)&ctx->h_m, cap * sizeof(double)));
@@ -204,6 +204,14 @@ int lfpsqp_timer_end(lfpsqp_ctx* ctx, double* ms) {
     return 0;
 }
 
+int lfpsqp_ctx_set_tuning(lfpsqp_ctx* ctx, int ks, int nt) {
+    LF_ARG(ctx, ctx != nullptr && (ks == 2 || ks == 4));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tune_ks = ks;
+    ctx->tune_nt = nt != 0;
+    return 0;
+}
+
 int lfpsqp_ctx_set_profiling(lfpsqp_ctx* ctx, int on) {
     LF_ARG(ctx, ctx != nullptr);
     if (on && prof_lazy_init(ctx) != 0) return set_err(ctx, LFPSQP_ERR_HIP, "profiling event creation failed");
@@ -224,11 +232,11 @@ int lfpsqp_profile_read(lfpsqp_ctx* ctx, double ms[8], int64_t counts[8]) {
 int lfpsqp_shard_range(int64_t n, int rank, int nranks, int64_t* row0, int64_t* row1) {
     if (n < 0 || nranks <= 0 || rank < 0 || rank >= nranks || !row0 || !row1) return LFPSQP_ERR_ARG;
     // contiguous blocks; boundaries on whole tiles so no tile straddles two ranks
-    const int64_t tiles = (n + kTileRows - 1) / kTileRows;
+    const int64_t tiles = (n + kPadRows - 1) / kPadRows;
     const int64_t base = tiles / nranks, extra = tiles % nranks;
     const int64_t t0 = (int64_t)rank * base + (rank < extra ? rank : extra);
     const int64_t t1 = t0 + base + (rank < extra ? 1 : 0);
-    int64_t r0 = t0 * kTileRows, r1 = t1 * kTileRows;
+    int64_t r0 = t0 * kPadRows, r1 = t1 * kPadRows;
     if (r0 > n) r0 = n;
     if (r1 > n) r1 = n;
     *row0 = r0;
@@ -304,7 +312,7 @@ int lfpsqp_vec_alloc(lfpsqp_ctx* ctx, int64_t n, lfpsqp_vec** out) {
     LF_ARG(ctx, ctx != nullptr && out != nullptr && n >= 0);
     lfpsqp_vec* v = new lfpsqp_vec();
     v->n = n;
-    v->cap = round_up(n > 0 ? n : 1, kTileRows);
+    v->cap = round_up(n > 0 ? n : 1, kPadRows);
     hipError_t e = hipMalloc((void**)&v->p, sizeof(double) * v->cap);
     if (e != hipSuccess) { delete v; return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%lld doubles) failed: %s", (long long)n, hipGetErrorString(e)); }
     e = hipMemsetAsync(v->p, 0, sizeof(double) * v->cap, ctx->stream);
@@ -344,7 +352,7 @@ int lfpsqp_mat_alloc(lfpsqp_ctx* ctx, int64_t n, int64_t m, lfpsqp_mat** out) {
     lfpsqp_mat* M = new lfpsqp_mat();
     M->n = n;
     M->m = m;
-    M->ld = round_up(n > 0 ? n : 1, kTileRows);
+    M->ld = round_up(n > 0 ? n : 1, kPadRows);
     const size_t bytes = sizeof(double) * (size_t)M->ld * (size_t)(m > 0 ? m : 1);
     hipError_t e = hipMalloc((void**)&M->p, bytes);
     if (e != hipSuccess) { delete M; return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%lld x %lld matrix) failed: %s", (long long)n, (long long)m, hipGetErrorString(e)); }

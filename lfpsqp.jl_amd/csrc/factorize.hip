@@ -174,9 +174,9 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, const doub
     hipLaunchKernelGGL(gram_kernel, dim3(groups, npan * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2,
                        ctx->part, pp);
     LF_LAUNCH_CHECK(ctx);
-    // reduce the `groups` partials (ncols = pp may exceed int range only for m > ~46000)
-    hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3((unsigned)((pp + 31) / 32)), dim3(1024), 0, ctx->stream, ctx->part,
-                       (int64_t)groups, (int)pp, (int)pp, 0u, ctx->small, NoPost());
+    // reduce the `groups` partials (pp columns: 32 per workgroup)
+    hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3((unsigned)((pp + 31) / 32), 1), dim3(1024), 0, ctx->stream, ctx->part,
+                       (int64_t)groups, (int)pp, (int)pp, 0u, ctx->small, 0, (int64_t)groups, 5, NoPost());
     LF_LAUNCH_CHECK(ctx);
     LF_TRY(allreduce_dev(ctx, ctx->small, pp, 0));
     std::vector<double> h((size_t)pp);

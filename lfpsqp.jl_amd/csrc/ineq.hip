@@ -231,7 +231,7 @@ static bool ineq_ok(const lfpsqp_ineq_data* id) {
 
 extern "C" {
 
-int64_t lfpsqp_half_stride(int64_t N) { return round_up(N > 0 ? N : 1, kTileRows); }
+int64_t lfpsqp_half_stride(int64_t N) { return round_up(N > 0 ? N : 1, kPadRows); }
 
 int lfpsqp_ineq_data_build(lfpsqp_ctx* ctx, const lfpsqp_vec* xl, const lfpsqp_vec* xu, lfpsqp_vec* q, lfpsqp_vec* r, lfpsqp_vec* s,
                            lfpsqp_vec* t) {

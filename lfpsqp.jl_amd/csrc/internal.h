@@ -68,6 +68,10 @@ struct lfpsqp_ctx {
     hipEvent_t ev_slot[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
 
+    // streaming-kernel tuning (lfpsqp_ctx_set_tuning): row pairs per lane (2 or 4), non-temporal matrix loads
+    int tune_ks = 4;
+    bool tune_nt = true;
+
     // optional per-kernel-family profiling with HIP events on `stream`
     bool profiling = false;
     hipEvent_t prof_ev[lfpsqp::kProfSlots][lfpsqp::kProfEvents][2];
@@ -91,7 +95,7 @@ void prof_end(lfpsqp_ctx* ctx, int s);
 void prof_collect(lfpsqp_ctx* ctx);  // after a stream sync: fold event pairs into prof_ms
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
-inline int64_t ntiles_of(int64_t n) { return (n + kTileRows - 1) / kTileRows; }
+inline int64_t ntiles_of(int64_t n, int ks) { return (n + (int64_t)kSlabRows * ks - 1) / ((int64_t)kSlabRows * ks); }
 
 #define LF_HIP(ctx, expr)                                                                              \
     do {                                                                                               \
@@ -117,12 +121,31 @@ inline int64_t ntiles_of(int64_t n) { return (n + kTileRows - 1) / kTileRows; }
 
 // ---- generic launchers (templates, so they live in the header) -------------
 
-// second stage of a reduction: out[0:ncols] = reduce over `nrows` partial rows
+// second stage of a reduction: out[0:ncols] = reduce over `nrows` partial rows of ctx->part.
+// Many rows x many columns (the m-vector of a GEMV-T) go through two launches so that more than
+// ceil(ncols/32) workgroups share the work; the caller reserves kReduceScratchRows extra rows of
+// `part_ld` doubles behind the partials for the intermediate.
+constexpr int kReduceRowBlocks = 16;
+inline size_t reduce_scratch(int part_ld) { return (size_t)kReduceRowBlocks * part_ld; }
 template <class POST>
 int launch_reduce(lfpsqp_ctx* ctx, int64_t nrows, int ncols, int part_ld, unsigned ismax, double* out, POST post) {
-    const int grid = (ncols + 31) / 32;
-    hipLaunchKernelGGL((reduce_rows_kernel<POST>), dim3(grid), dim3(1024), 0, ctx->stream, ctx->part, nrows, ncols, part_ld,
-                       ismax, out, post);
+    int cw_log2 = 0;
+    while ((1 << cw_log2) < ncols && cw_log2 < 5) ++cw_log2;
+    const int cw = 1 << cw_log2;
+    const int gx = (ncols + cw - 1) / cw;
+    if (ncols >= 32 && nrows >= 2048) {
+        double* mid = ctx->part + (size_t)nrows * part_ld;
+        const int64_t chunk = (nrows + kReduceRowBlocks - 1) / kReduceRowBlocks;
+        hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3(gx, kReduceRowBlocks), dim3(1024), 0, ctx->stream, ctx->part, nrows, ncols,
+                           part_ld, ismax, mid, part_ld, chunk, cw_log2, NoPost());
+        LF_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL((reduce_rows_kernel<POST>), dim3(gx, 1), dim3(1024), 0, ctx->stream, mid, (int64_t)kReduceRowBlocks, ncols,
+                           part_ld, ismax, out, 0, (int64_t)kReduceRowBlocks, cw_log2, post);
+        LF_LAUNCH_CHECK(ctx);
+        return 0;
+    }
+    hipLaunchKernelGGL((reduce_rows_kernel<POST>), dim3(gx, 1), dim3(1024), 0, ctx->stream, ctx->part, nrows, ncols, part_ld, ismax, out,
+                       0, nrows, cw_log2, post);
     LF_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -132,13 +155,20 @@ int launch_reduce(lfpsqp_ctx* ctx, int64_t nrows, int ncols, int part_ld, unsign
 // empty basis (reference: projcg! with an n x 0 U).
 template <class VP>
 int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp, double* t_out, int prof_slot = -1) {
-    const int64_t tiles = ntiles_of(n);
+    const int ks = ctx->tune_ks;
+    const int64_t tiles = ntiles_of(n, ks);
     const int part_ld = (int)round_up(ncols > 0 ? ncols : 1, 32);
     if (tiles > 0) {
-        LF_TRY(ensure_part(ctx, (size_t)tiles * part_ld));
+        LF_TRY(ensure_part(ctx, (size_t)tiles * part_ld + reduce_scratch(part_ld)));
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);
-        hipLaunchKernelGGL((gemv_t_kernel<VP>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, M ? M->p : nullptr,
-                           M ? M->ld : 0, ncols, n, vp, ctx->part, part_ld);
+        const double* Mp = M ? M->p : nullptr;
+        const int64_t ld = M ? M->ld : 0;
+#define LF_GT(KS, NT)                                                                                                        \
+    hipLaunchKernelGGL((gemv_t_kernel<VP, KS, NT>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, Mp, ld, ncols, n, vp, \
+                       ctx->part, part_ld)
+        if (ks == 4) { if (ctx->tune_nt) LF_GT(4, true); else LF_GT(4, false); }
+        else         { if (ctx->tune_nt) LF_GT(2, true); else LF_GT(2, false); }
+#undef LF_GT
         if (prof_slot >= 0) prof_end(ctx, prof_slot);
         LF_LAUNCH_CHECK(ctx);
     }
@@ -153,12 +183,19 @@ int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp
 template <class EP, int NRED, class POST>
 int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const double* t, EP ep, double* red_out, POST post,
                int prof_slot = -1) {
-    const int64_t tiles = ntiles_of(n);
+    const int ks = ctx->tune_ks;
+    const int64_t tiles = ntiles_of(n, ks);
     if (tiles > 0) {
         LF_TRY(ensure_part(ctx, (size_t)tiles * kMaxRed));
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);
-        hipLaunchKernelGGL((gemv_n_kernel<EP, NRED>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, M ? M->p : nullptr,
-                           M ? M->ld : 0, ncols, n, t, ep, ctx->part);
+        const double* Mp = M ? M->p : nullptr;
+        const int64_t ld = M ? M->ld : 0;
+#define LF_GN(KS, NT)                                                                                                          \
+    hipLaunchKernelGGL((gemv_n_kernel<EP, NRED, KS, NT>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, Mp, ld, ncols, n, \
+                       t, ep, ctx->part)
+        if (ks == 4) { if (ctx->tune_nt) LF_GN(4, true); else LF_GN(4, false); }
+        else         { if (ctx->tune_nt) LF_GN(2, true); else LF_GN(2, false); }
+#undef LF_GN
         if (prof_slot >= 0) prof_end(ctx, prof_slot);
         LF_LAUNCH_CHECK(ctx);
     }

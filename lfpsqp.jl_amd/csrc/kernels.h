@@ -7,9 +7,9 @@
 //   vec_kernel    : elementwise map + up to 4 sum/max reductions
 // plus reduce_rows_kernel, the fixed-order second stage of every reduction.
 //
-// A thread owns kS double2 row-pairs of a kTileRows tile and streams them over all
+// A thread owns KS double2 row-pairs of a 512*KS-row tile and streams them over all
 // columns: lanes read consecutive 16-byte pieces (global_load_dwordx4, 1 KiB per wave
-// instruction), kS*kColUnroll loads are in flight per lane, nothing is staged through
+// instruction), >= 8 loads are in flight per lane, nothing is staged through
 // LDS (each matrix byte is used exactly once -- guide: "GEMV / M<=16: load straight to
 // VGPRs, deep unroll").  All reductions are two-stage and atomics-free so results are
 // bit-reproducible for a given (n_loc, m).
@@ -19,15 +19,29 @@
 
 namespace lfpsqp {
 
+// Tuning knobs are template parameters selected at run time per context (lfpsqp_ctx_set_tuning):
+//   KS  = 16-byte row pairs per lane (tile = 512*KS rows), NT = non-temporal matrix loads.
+// All buffers are padded to kPadRows so every variant is valid on the same allocation.
+#ifndef LFPSQP_TCOLS
+#define LFPSQP_TCOLS 4
+#endif
+
 constexpr int kThreads = 256;                 // 4 waves
 constexpr int kWaves = kThreads / 64;
-constexpr int kS = 2;                         // double2 slabs per thread
 constexpr int kSlabRows = kThreads * 2;       // 512 rows: one 16-byte piece per lane
-constexpr int kTileRows = kSlabRows * kS;     // 1024 rows per workgroup
+constexpr int kMaxKS = 4;
+constexpr int kPadRows = kSlabRows * kMaxKS;  // 2048: padding / shard-boundary granularity
+constexpr int kTC = LFPSQP_TCOLS;             // columns reduced together in gemv_t
 constexpr int kColChunk = 256;                // columns reduced per LDS flush
 constexpr int kMaxRed = 4;                    // scalar reductions per kernel
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+// matrix stream: every byte is read exactly once per pass, so it may bypass cache retention
+template <bool NT>
+__device__ __forceinline__ double2 ldm(const double* p) {
+    if (NT) return make_double2(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1));
+    return ld2(p);
+}
 
 // Solver scalars / status words are written by one kernel (a reduction's post-op) and read,
 // at a wave-uniform address, by every workgroup of the following kernels in the stream.
@@ -85,13 +99,13 @@ __device__ __forceinline__ void block_reduce_store(double (&red)[NRED], unsigned
 //   VP::skip() (uniform) makes the whole launch a no-op (solver already finished).
 // grid.x = number of tiles.  part has leading dimension part_ld >= ncols.
 // ---------------------------------------------------------------------------
-template <class VP>
+template <class VP, int kS, bool NT>
 __global__ __launch_bounds__(kThreads) void gemv_t_kernel(const double* __restrict__ M, int64_t ld, int ncols, int64_t n,
                                                            VP vp, double* __restrict__ part, int part_ld) {
     if (vp.skip()) return;
     __shared__ double red[kWaves][kColChunk];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * kTileRows + (int64_t)threadIdx.x * 2;
+    const int64_t row0 = (int64_t)blockIdx.x * (kSlabRows * kS) + (int64_t)threadIdx.x * 2;
     double2 v[kS];
 #pragma unroll
     for (int s = 0; s < kS; ++s) {
@@ -102,26 +116,26 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(const double* __restri
     double* prow = part + (int64_t)blockIdx.x * part_ld;
     for (int j0 = 0; j0 < ncols; j0 += kColChunk) {
         const int jn = (ncols - j0 < kColChunk) ? (ncols - j0) : kColChunk;
-        for (int j = 0; j < jn; j += 4) {
-            double p[4];
+        for (int j = 0; j < jn; j += kTC) {
+            double p[kTC];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < kTC; ++c) {
                 const int jj = (j + c < jn) ? (j + c) : (jn - 1);   // clamp: ragged last group re-reads a valid column
                 const double* col = base + (int64_t)(j0 + jj) * ld;
                 double acc = 0.0;
 #pragma unroll
                 for (int s = 0; s < kS; ++s) {
-                    const double2 a = ld2(col + (int64_t)s * kSlabRows);
+                    const double2 a = ldm<NT>(col + (int64_t)s * kSlabRows);
                     acc = fma(a.x, v[s].x, acc);
                     acc = fma(a.y, v[s].y, acc);
                 }
                 p[c] = acc;
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) p[c] = wave_sum(p[c]);
+            for (int c = 0; c < kTC; ++c) p[c] = wave_sum(p[c]);
             if (lane == 0) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < kTC; ++c)
                     if (j + c < jn) red[wave][j + c] = p[c];
             }
         }
@@ -137,12 +151,12 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(const double* __restri
 // valid0, valid1, red) which does the fused stores and adds its reduction terms
 // into red[0..NRED).  part[tile][k] receives the tile's reduction partials.
 // ---------------------------------------------------------------------------
-template <class EP, int NRED>
+template <class EP, int NRED, int kS, bool NT>
 __global__ __launch_bounds__(kThreads) void gemv_n_kernel(const double* __restrict__ M, int64_t ld, int ncols, int64_t n,
                                                            const double* __restrict__ t, EP ep, double* __restrict__ part) {
     if (ep.skip()) return;
     __shared__ double ts[kColChunk];
-    const int64_t row0 = (int64_t)blockIdx.x * kTileRows + (int64_t)threadIdx.x * 2;
+    const int64_t row0 = (int64_t)blockIdx.x * (kSlabRows * kS) + (int64_t)threadIdx.x * 2;
     const double* base = M + row0;
     double2 acc[kS];
 #pragma unroll
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(const double* __restri
             for (int c = 0; c < 8; ++c) {
                 const double* col = base + (int64_t)(j0 + j + c) * ld;
 #pragma unroll
-                for (int s = 0; s < kS; ++s) a[c][s] = ld2(col + (int64_t)s * kSlabRows);
+                for (int s = 0; s < kS; ++s) a[c][s] = ldm<NT>(col + (int64_t)s * kSlabRows);
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(const double* __restri
             const double tj = ts[j];
 #pragma unroll
             for (int s = 0; s < kS; ++s) {
-                const double2 a = ld2(col + (int64_t)s * kSlabRows);
+                const double2 a = ldm<NT>(col + (int64_t)s * kSlabRows);
                 acc[s].x = fma(a.x, tj, acc[s].x);
                 acc[s].y = fma(a.y, tj, acc[s].y);
             }
@@ -213,53 +227,55 @@ __global__ __launch_bounds__(kThreads) void vec_kernel(F f, int64_t n, unsigned 
 }
 
 // ---------------------------------------------------------------------------
-// Second stage: out[j] = sum (or max) over rows of part[row][j], fixed order.
-// Block = 1024 threads = 32 columns x 32 row groups; grid.x = ceil(ncols/32).
-// POST::run(out) is executed by one thread after the sums are visible when the
+// Second stage: out[by][j] = sum (or max) over the rows [by*row_chunk, (by+1)*row_chunk) of
+// part[row][j], fixed order.  A block of 1024 threads = cw columns x (1024/cw) row groups
+// (cw = 2^cw_log2 <= 32: few columns => many row groups, so scalar reductions use the whole
+// block); per-thread strided sums, then a fixed LDS tree over the groups.  grid = (ceil(ncols/cw),
+// row blocks).  POST::run(out) is executed by one thread after the sums are visible when the
 // launch has a single block (scalar reductions: computes alpha/beta/status ...).
 // ---------------------------------------------------------------------------
 template <class POST>
 __global__ __launch_bounds__(1024) void reduce_rows_kernel(const double* __restrict__ part, int64_t nrows, int ncols, int part_ld,
-                                                            unsigned ismax, double* out, POST post) {
+                                                            unsigned ismax, double* out, int out_ld, int64_t row_chunk, int cw_log2,
+                                                            POST post) {
     if (post.skip()) return;
-    __shared__ double sm[32][33];
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + c;
+    __shared__ double sm[1024];
+    const int cw = 1 << cw_log2, groups = 1024 >> cw_log2;
+    const int c = threadIdx.x & (cw - 1), g = threadIdx.x >> cw_log2;
+    const int col = blockIdx.x * cw + c;
     const bool mx = (ismax >> (col < 32 ? col : 31)) & 1u;
+    const int64_t r_begin = (int64_t)blockIdx.y * row_chunk;
+    const int64_t r_end = (r_begin + row_chunk < nrows) ? (r_begin + row_chunk) : nrows;
     double acc = 0.0;
     if (col < ncols) {
+        const double* pc = part + col;
         if (mx) {
-            for (int64_t r = g; r < nrows; r += 32) acc = nanmax(acc, part[r * part_ld + col]);
+            for (int64_t r = r_begin + g; r < r_end; r += groups) acc = nanmax(acc, pc[r * part_ld]);
         } else {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            int64_t r = g;
-            for (; r + 96 < nrows; r += 128) {
-                a0 += part[r * part_ld + col];
-                a1 += part[(r + 32) * part_ld + col];
-                a2 += part[(r + 64) * part_ld + col];
-                a3 += part[(r + 96) * part_ld + col];
+            int64_t r = r_begin + g;
+            const int64_t st = groups;
+            for (; r + 3 * st < r_end; r += 4 * st) {
+                a0 += pc[r * part_ld];
+                a1 += pc[(r + st) * part_ld];
+                a2 += pc[(r + 2 * st) * part_ld];
+                a3 += pc[(r + 3 * st) * part_ld];
             }
-            for (; r < nrows; r += 32) a0 += part[r * part_ld + col];
+            for (; r < r_end; r += st) a0 += pc[r * part_ld];
             acc = (a0 + a1) + (a2 + a3);
         }
     }
-    sm[g][c] = acc;
+    sm[threadIdx.x] = acc;
     __syncthreads();
-    if (g == 0 && col < ncols) {
-        double r = sm[0][c];
-        if (mx) {
-            for (int k = 1; k < 32; ++k) r = nanmax(r, sm[k][c]);
-        } else {
-            // pairwise over the 32 groups
-            double s[32];
-            for (int k = 0; k < 32; ++k) s[k] = sm[k][c];
-            for (int w = 16; w > 0; w >>= 1)
-                for (int k = 0; k < w; ++k) s[k] = s[k] + s[k + w];
-            r = s[0];
+    for (int s = groups >> 1; s > 0; s >>= 1) {
+        if (g < s) {
+            const double o = sm[threadIdx.x + s * cw];
+            sm[threadIdx.x] = mx ? nanmax(sm[threadIdx.x], o) : (sm[threadIdx.x] + o);
         }
-        out[col] = r;
+        __syncthreads();
     }
-    if (gridDim.x == 1) {
+    if (g == 0 && col < ncols) out[(int64_t)blockIdx.y * out_ld + col] = sm[c];
+    if (gridDim.x == 1 && gridDim.y == 1) {
         __syncthreads();
         if (threadIdx.x == 0) post.run(out);
     }

@@ -149,8 +149,8 @@ __global__ __launch_bounds__(kThreads) void hash_mat_kernel(double* M, int64_t l
     double* col = M + j * ld;
     const uint64_t base = (uint64_t)j * (uint64_t)n_global + (uint64_t)row0;
 #pragma unroll
-    for (int s = 0; s < kS; ++s) {
-        const int64_t r = (int64_t)blockIdx.x * kTileRows + (int64_t)s * kSlabRows + (int64_t)threadIdx.x * 2;
+    for (int s = 0; s < kMaxKS; ++s) {
+        const int64_t r = (int64_t)blockIdx.x * kPadRows + (int64_t)s * kSlabRows + (int64_t)threadIdx.x * 2;
         if (r + 1 < n) st2(col + r, make_double2(scale * hash_u(seed, base + (uint64_t)r), scale * hash_u(seed, base + (uint64_t)r + 1)));
         else if (r < n) col[r] = scale * hash_u(seed, base + (uint64_t)r);
     }
@@ -186,7 +186,7 @@ int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t 
     LF_ARG(ctx, ctx && M && row0 >= 0 && nrows >= 0 && nrows <= M->n && ncols >= 0 && ncols <= M->m && n_global >= nrows);
     if (nrows == 0 || ncols == 0) return 0;
     LF_ARG(ctx, ncols <= 65535);
-    hipLaunchKernelGGL(hash_mat_kernel, dim3((unsigned)ntiles_of(nrows), (unsigned)ncols), dim3(kThreads), 0, ctx->stream, M->p, M->ld,
+    hipLaunchKernelGGL(hash_mat_kernel, dim3((unsigned)((nrows + kPadRows - 1) / kPadRows), (unsigned)ncols), dim3(kThreads), 0, ctx->stream, M->p, M->ld,
                        nrows, seed, row0, n_global, scale);
     LF_LAUNCH_CHECK(ctx);
     return 0;

@@ -60,15 +60,29 @@ struct PcgDirF {
         red[0] += s;                                                      // :75
     }
 };
+// The post-ops also publish (status, iteration, nr) into a pinned HOST block with system-scope
+// stores, so the host follows the solve without any per-iteration device-to-host copy.
+struct HostMirror {
+    int64_t* hstat;  // [0] status, [1] iterations started
+    double* hnr;     // [0] nr
+    __device__ __forceinline__ void publish(int64_t status, int64_t iter, double nr) const {
+        __hip_atomic_store(hnr, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hstat + 1, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hstat, status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+};
+
 struct PcgPost1 {  // after d'Ad is final: iteration count, exits, alpha  (:72-91)
     double* scal;
     int64_t* istat;
+    HostMirror hm;
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ void run(double*) const {
-        istat[I_ITER] = ld_stat(istat + I_ITER) + 1;
+        const int64_t it = ld_stat(istat + I_ITER) + 1;
+        istat[I_ITER] = it;
         const double dAd = ld_scal(scal + S_DAD), rg = ld_scal(scal + S_RG);
-        if (dAd <= 0.0) istat[I_STATUS] = ST_NEGCURV;
-        else if (rg <= 0.0) istat[I_STATUS] = ST_RG_BREAK;
+        if (dAd <= 0.0) { istat[I_STATUS] = ST_NEGCURV; hm.publish(ST_NEGCURV, it, ld_scal(scal + S_NR)); }
+        else if (rg <= 0.0) { istat[I_STATUS] = ST_RG_BREAK; hm.publish(ST_RG_BREAK, it, ld_scal(scal + S_NR)); }
         else scal[S_ALPHA] = rg / dAd;
     }
 };
@@ -125,20 +139,27 @@ struct PcgPost3 {  // beta, next rg, nr, convergence / iteration-limit exits (:9
     double* scal;
     int64_t* istat;
     int init;
+    HostMirror hm;
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ void run(double*) const {
         const double rpgp = ld_scal(scal + S_RPGP), gpgp = ld_scal(scal + S_GPGP);
         if (init) {
             scal[S_RG] = gpgp;
-            if (ld_stat(istat + I_MAXIT) <= 0) istat[I_STATUS] = ST_MAXIT;
+            int64_t st0 = ST_RUNNING;
+            if (ld_stat(istat + I_MAXIT) <= 0) { istat[I_STATUS] = ST_MAXIT; st0 = ST_MAXIT; }
+            hm.publish(st0, 0, INFINITY);
             return;
         }
         scal[S_BETA] = rpgp / ld_scal(scal + S_RG);
         scal[S_RG] = gpgp;
         const double nr = sqrt(gpgp);
         scal[S_NR] = nr;
-        if (nr < ld_scal(scal + S_TOL)) istat[I_STATUS] = ST_CONVERGED;
-        else if (ld_stat(istat + I_ITER) >= ld_stat(istat + I_MAXIT)) istat[I_STATUS] = ST_MAXIT;
+        const int64_t it = ld_stat(istat + I_ITER);
+        int64_t st = ST_RUNNING;
+        if (nr < ld_scal(scal + S_TOL)) st = ST_CONVERGED;
+        else if (it >= ld_stat(istat + I_MAXIT)) st = ST_MAXIT;
+        if (st != ST_RUNNING) istat[I_STATUS] = st;
+        hm.publish(st, it, nr);
     }
 };
 
@@ -249,12 +270,6 @@ struct PcgProjES {
     }
 };
 
-static int snapshot(lfpsqp_ctx* ctx, int slot) {
-    LF_HIP(ctx, hipMemcpyAsync(ctx->h_istat + 16 * slot, ctx->istat, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    LF_HIP(ctx, hipMemcpyAsync(ctx->h_scal + 64 * slot, ctx->scal, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    LF_HIP(ctx, hipEventRecord(ctx->ev_slot[slot], ctx->stream));
-    return 0;
-}
 
 }  // namespace lfpsqp
 
@@ -300,6 +315,10 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     int64_t maxit_eff = maxit < n_global + m_ref ? maxit : n_global + m_ref;
     if (maxit_eff < 0) maxit_eff = 0;
 
+    const HostMirror hm{ctx->h_istat, ctx->h_scal};
+    volatile int64_t* hstat = ctx->h_istat;
+    hstat[0] = ST_RUNNING;
+    hstat[1] = 0;
     auto launch_residual = [&](double sgn, double* store, double* t_out) -> int {
         const ResidualV rv{x->p, b->p, store, Ad, sgn};
         if (stacked) return run_gemv_t(ctx, Z, m, N, ResidualVS{rv, StackD{hs, sk.Dx, sk.Dy, sk.sx, sk.sy, store ? sk.w : lambda->p}}, t_out);
@@ -312,7 +331,7 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     };
     auto launch_k3 = [&](int init) -> int {
         const PcgProjE pe{rp, g, d, istat, init};
-        const PcgPost3 post{scal, istat, init};
+        const PcgPost3 post{scal, istat, init, hm};
         if (stacked) return run_gemv_n<PcgProjES, 2, PcgPost3>(ctx, Z, m, N, Utr, PcgProjES{pe, sk}, scal + S_RPGP, post, init ? -1 : 2);
         return run_gemv_n<PcgProjE, 2, PcgPost3>(ctx, Z, m, N, Utr, pe, scal + S_RPGP, post, init ? -1 : 2);
     };
@@ -334,23 +353,19 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     bool done = false;
     while (!done && it < maxit_eff) {
         LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, nv, PcgDirF{d, g, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
-                                              PcgPost1{scal, istat}, 0)));
+                                              PcgPost1{scal, istat, hm}, 0)));
         LF_TRY(launch_k2());
         LF_TRY(launch_k3(0));
-        LF_TRY(snapshot(ctx, (int)(it & 1)));
-        if (it >= 1) {  // look at the status of the PREVIOUS iteration: the GPU is never left idle
-            const int slot = (int)((it - 1) & 1);
-            LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[slot]));
-            if (ctx->h_istat[16 * slot + I_STATUS] != ST_RUNNING) done = true;
-        }
+        // throttle: stay at most two iterations ahead of the GPU, then look at the pinned status block
+        LF_HIP(ctx, hipEventRecord(ctx->ev_slot[it & 3], ctx->stream));
+        if (it >= 2) LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[(it - 2) & 3]));
+        if (hstat[0] != ST_RUNNING) done = true;
         ++it;
     }
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    LF_TRY(snapshot(ctx, 2));
-    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t status = ctx->h_istat[16 * 2 + I_STATUS];
-    *iters = ctx->h_istat[16 * 2 + I_ITER];
-    *nr = ctx->h_scal[64 * 2 + S_NR];
+    const int64_t status = hstat[0];
+    *iters = hstat[1];
+    *nr = *(volatile double*)ctx->h_scal;
 
     if (status == ST_NEGCURV) {   // :77-82
         LF_TRY((run_vec<SumSqF, 1, NoPost>(ctx, nv, SumSqF{d}, 0u, scal + S_DD, NoPost())));

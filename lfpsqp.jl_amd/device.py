@@ -50,6 +50,9 @@ class Context:
         self.check(self.L.lfpsqp_timer_end(self.h, C.byref(ms)))
         return ms.value
 
+    def set_tuning(self, ks: int = 4, nt: bool = True):
+        self.check(self.L.lfpsqp_ctx_set_tuning(self.h, int(ks), 1 if nt else 0))
+
     def set_profiling(self, on: bool):
         self.check(self.L.lfpsqp_ctx_set_profiling(self.h, 1 if on else 0))
 

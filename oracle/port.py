@@ -14,6 +14,26 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def usable_cpus() -> int:
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a box can
+    report 256 hardware threads while the container is limited to a few)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -22,6 +42,7 @@ def lib():
         L = C.CDLL(_SO)
         i64, dbl, P = C.c_int64, C.c_double, C.c_void_p
         L.port_num_threads.restype = C.c_int
+        L.port_set_num_threads.argtypes = [C.c_int]
         L.port_hash_matrix.argtypes = [P, i64, i64, i64, C.c_uint64, i64, i64, dbl]
         L.port_hash_vector.argtypes = [P, i64, C.c_uint64, i64, dbl, dbl]
         L.port_gemv_t.argtypes = [i64, i64, P, i64, P, P]

@@ -25,6 +25,14 @@ int port_num_threads(void) {
 #endif
 }
 
+void port_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* splitmix64-finaliser hash -> [-1,1)  (SURVEY §8d), identical to oracle/synth.py */
 static inline double hash_u(uint64_t seed, uint64_t k) {
     uint64_t z = seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;

@@ -7,11 +7,11 @@
 // product build (hipcc, __graft_entry__.build) never sees it, and the product
 // Python package refuses to run without the real HIP library.
 //
-// Model: one ucontext fiber per GPU thread, a block's fibers are scheduled
+// Model: one fiber per GPU thread (hand-written x86-64 context switch: ucontext's swapcontext makes a
+// sigprocmask syscall per switch, ~50x slower), a block's fibers are scheduled
 // round-robin on one OS thread, __syncthreads()/wave shuffles are cooperative
 // yields; blocks are distributed over a small pool of OS threads.  Wave = 64.
 #pragma once
-#include <ucontext.h>
 
 #include <atomic>
 #include <chrono>
@@ -95,8 +95,8 @@ struct BlockState {
     unsigned nthreads = 0, live = 0, arrived = 0, gen = 0;
     unsigned w_arrived[16] = {0}, w_gen[16] = {0}, w_live[16] = {0};
     double scratch[1024];
-    ucontext_t main_ctx;
-    std::vector<ucontext_t> fibers;
+    void* main_sp = nullptr;
+    std::vector<void*> fibers;   // saved stack pointers
     std::vector<char*> stacks;
     std::vector<char> done;
     unsigned cur = 0;
@@ -106,7 +106,15 @@ inline thread_local BlockState* g_blk = nullptr;
 inline thread_local Idx g_tid{0, 0, 0}, g_bid{0, 0, 0}, g_bdim{1, 1, 1}, g_gdim{1, 1, 1};
 constexpr size_t kStack = 256 * 1024;
 
-inline void yield_() { BlockState* b = g_blk; swapcontext(&b->fibers[b->cur], &b->main_ctx); }
+// save callee-saved registers + stack pointer of the current context, load another one
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+__asm__(".text\n.weak hipemu_switch\n.type hipemu_switch,@function\nhipemu_switch:\n"
+        "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+        "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+        "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+        ".size hipemu_switch,.-hipemu_switch\n");
+
+inline void yield_() { BlockState* b = g_blk; hipemu_switch(&b->fibers[b->cur], b->main_sp); }
 
 inline void syncthreads() {
     BlockState* b = g_blk;
@@ -132,7 +140,8 @@ inline void trampoline() {
     if (b->live > 0 && b->arrived >= b->live) { b->arrived = 0; b->gen++; }
     unsigned w = t >> 6;
     if (b->w_live[w] > 0 && b->w_arrived[w] >= b->w_live[w]) { b->w_arrived[w] = 0; b->w_gen[w]++; }
-    swapcontext(&b->fibers[t], &b->main_ctx);
+    hipemu_switch(&b->fibers[t], b->main_sp);
+    __builtin_trap();   // a finished fiber is never resumed
 }
 inline void run_block(BlockState& b, unsigned nthreads, const std::function<void()>& body) {
     if (b.fibers.size() < nthreads) {
@@ -152,18 +161,21 @@ inline void run_block(BlockState& b, unsigned nthreads, const std::function<void
     b.body = &body;
     g_blk = &b;
     for (unsigned t = 0; t < nthreads; ++t) {
-        getcontext(&b.fibers[t]);
-        b.fibers[t].uc_stack.ss_sp = b.stacks[t];
-        b.fibers[t].uc_stack.ss_size = kStack;
-        b.fibers[t].uc_link = &b.main_ctx;
-        makecontext(&b.fibers[t], (void (*)())trampoline, 0);
+        // initial frame: six zeroed callee-saved registers, then `ret` into trampoline with the
+        // stack aligned as at a normal function entry (rsp == 8 mod 16)
+        uintptr_t top = ((uintptr_t)b.stacks[t] + kStack) & ~(uintptr_t)15;
+        void** sp = (void**)top;
+        *--sp = nullptr;                      // fake return address of trampoline
+        *--sp = (void*)&trampoline;           // ret target
+        for (int k = 0; k < 6; ++k) *--sp = nullptr;
+        b.fibers[t] = (void*)sp;
     }
     while (b.live > 0) {
         for (unsigned t = 0; t < nthreads; ++t) {
             if (b.done[t]) continue;
             b.cur = t;
             g_tid = Idx{t % g_bdim.x, (t / g_bdim.x) % g_bdim.y, t / (g_bdim.x * g_bdim.y)};
-            swapcontext(&b.main_ctx, &b.fibers[t]);
+            hipemu_switch(&b.main_sp, b.fibers[t]);
         }
     }
 }
@@ -229,4 +241,5 @@ static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __A
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T, class V> static inline void __hip_atomic_store(T* p, V v, int, int) { *p = (T)v; }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }

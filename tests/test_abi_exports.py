@@ -41,7 +41,7 @@ def test_shard_range_partitions_rows(built):
                 r0, r1 = ctypes.c_int64(), ctypes.c_int64()
                 assert built.lfpsqp_shard_range(n, r, nranks, ctypes.byref(r0), ctypes.byref(r1)) == 0
                 assert r0.value == prev and r1.value >= r0.value
-                assert r0.value % 1024 == 0 or r0.value == n      # shard boundaries on whole tiles
+                assert r0.value % 2048 == 0 or r0.value == n      # shard boundaries on whole tiles
                 prev = r1.value
             assert prev == n
     r0, r1 = ctypes.c_int64(), ctypes.c_int64()

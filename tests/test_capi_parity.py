@@ -69,7 +69,7 @@ def test_hash_generators_bit_exact(dev_ctx):
     n, m = 3001, 7
     np.testing.assert_array_equal(ctx.matrix(n, m).hash_fill(1).download(), synth.hash_matrix(1, n, m))
     # sharded generation: rows 1024.. of a taller matrix
-    np.testing.assert_array_equal(ctx.matrix(n - 1024, m).hash_fill(1, 1024, n).download(), synth.hash_matrix(1, n, m)[1024:])
+    np.testing.assert_array_equal(ctx.matrix(n - 2048, m).hash_fill(1, 2048, n).download(), synth.hash_matrix(1, n, m)[2048:])
     np.testing.assert_array_equal(ctx.vector(n).hash_fill(3, 5, 4.0, 5.0).download(), 4.0 * synth.hash_vector(3, n, 5) + 5.0)
     np.testing.assert_array_equal(port.hash_matrix(1, n, m), synth.hash_matrix(1, n, m))
 
@@ -277,3 +277,29 @@ def test_max_reductions_propagate_nan(dev_ctx):
         h[pos] = np.nan
         assert math.isnan(L.amax(ctx.vector(n, h)))
     assert L.amax(ctx.vector(10, -np.arange(10.0))) == 9.0
+
+
+def test_tuning_variants_agree(dev_ctx):
+    """lfpsqp_ctx_set_tuning: (ks, nt) variants of the streaming kernels give the same results
+    (bit-identical across nt; rounding-level across ks, whose summation order differs)."""
+    ctx = dev_ctx
+    n, m = 5000, 9
+    Uh, a, bh = _cg_problem(n, m)
+    U = L.DeviceBasis(ctx.matrix(n, m, Uh))
+    A = L.DiagOperator(0.0, ctx.vector(n, a))
+    b = ctx.vector(n, bh)
+    res = {}
+    for ks in (2, 4):
+        for nt in (False, True):
+            ctx.set_tuning(ks, nt)
+            x, lam = ctx.vector(n), ctx.vector(m)
+            it, nr = L.projcg_(x, lam, A, U, b, None, tol=1e-10)
+            res[(ks, nt)] = (it, x.download(), lam.download())
+    ctx.set_tuning(4, True)
+    for ks in (2, 4):
+        assert res[(ks, False)][0] == res[(ks, True)][0]
+        np.testing.assert_array_equal(res[(ks, False)][1], res[(ks, True)][1])
+    assert res[(2, True)][0] == res[(4, True)][0]
+    np.testing.assert_allclose(res[(2, True)][1], res[(4, True)][1], rtol=0, atol=1e-13)
+    with pytest.raises(L.LfpsqpError):
+        ctx.set_tuning(3, True)

@@ -39,7 +39,7 @@ def two_ranks(emu_lib, tmp_path_factory):
 
 def test_shards_partition_the_rows(two_ranks):
     a, b = two_ranks
-    assert a["r0"] == 0 and a["r1"] == b["r0"] and b["r1"] == 5000 and a["r1"] % 1024 == 0
+    assert a["r0"] == 0 and a["r1"] == b["r0"] and b["r1"] == 5000 and a["r1"] % 2048 == 0
 
 
 def test_sharded_factorize_and_projcg_match_single_process_oracle(two_ranks):
