@@ -116,9 +116,11 @@ def main(argv=None, lib=None):
     def avg(slot):
         return prof_ms[slot] / prof_cnt[slot] if prof_cnt[slot] else float("nan")
     k1, k2, k3 = avg(0), avg(1), avg(2)
-    bytes_k1 = 32.0 * n_loc
-    bytes_k2 = 8.0 * n_loc * m + 48.0 * n_loc + 8.0 * m
-    bytes_k3 = 8.0 * n_loc * m + 16.0 * n_loc + 8.0 * m
+    # algorithmic bytes per launch: K1 reads x,d,g,a writes x,d; K2 reads d,g,a + U;
+    # K3 reads d,g,a writes g + U
+    bytes_k1 = 48.0 * n_loc
+    bytes_k2 = 8.0 * n_loc * m + 24.0 * n_loc + 8.0 * m
+    bytes_k3 = 8.0 * n_loc * m + 32.0 * n_loc + 8.0 * m
     gbs = lambda by, ms: by / (ms * 1e-3) / 1e9
     # plain matvecs (the "achieved HBM GB/s on J matvec" half of the metric)
     v = ctx.vector(n_loc).hash_fill(5, r0)
@@ -154,7 +156,7 @@ def main(argv=None, lib=None):
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
                    "comm": args.comm if world > 1 else "none", "device": ctx.device_name},
-        "roofline": {"bound": "hbm", "kernel": "gemv_t_kernel<PcgStepV> (K2: x/rp update fused with U'rp)",
+        "roofline": {"bound": "hbm", "kernel": "gemv_t_kernel<PcgStepV> (K2: rp = g + alpha*A*d formed on the fly, fused with U'rp)",
                      "achieved": gbs(bytes_k2, k2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gbs(bytes_k2, k2) / HBM_PEAK_GBS, "traffic": None,
                      "avg_launch_ms": k2, "algorithmic_bytes": bytes_k2},
@@ -166,6 +168,20 @@ def main(argv=None, lib=None):
         "matvec": {"gemv_t": {"ms": ms_t, "GBs": gbs(bytes_t, ms_t), "frac": gbs(bytes_t, ms_t) / HBM_PEAK_GBS},
                    "gemv_n": {"ms": ms_n, "GBs": gbs(bytes_n, ms_n), "frac": gbs(bytes_n, ms_n) / HBM_PEAK_GBS}},
     }
+
+    # HBM traffic of the roofline kernel from the committed PMC passes of this same command
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; tools/pmc_summary.py applies the guide's
+    # gfx950 x2 correction to FETCH_SIZE).  PMC counters cannot be read from inside the timed run.
+    try:
+        pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("pmc_summary.json"))
+        if pmc and world == 1 and n == 10_000_000 and m == 128:
+            summ = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
+            for name, v in summ.items():
+                if "gemv_t_kernel<lfpsqp::PcgStepV" in name:
+                    out["roofline"]["traffic"] = v["traffic_GB"] * 1e9
+                    out["roofline"]["traffic_source"] = f"profiles/{pmc[-1]} ({v['launches']} launches)"
+    except (OSError, ValueError, KeyError):
+        pass
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_n), m, n)

@@ -220,14 +220,14 @@ int lfpsqp_q_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, double alpha, const 
                     lfpsqp_vec* y);
 
 /* ProjCGWork (src/projcg.jl:1-11): caller-owned scratch, allocated once.
- * Only three n-vectors are needed on the device (r == g throughout, gp and Ad
- * are never materialised) plus the m-vector Utr. */
+ * Only three n-vectors are needed on the device (r == g throughout; gp, Ad and -- inside the
+ * loop -- rp are never materialised; rp holds the initial residual) plus the m-vector Utr. */
 typedef struct lfpsqp_projcg_work {
     lfpsqp_vec* g;
     lfpsqp_vec* d;
     lfpsqp_vec* rp;
     lfpsqp_vec* Utr;
-    lfpsqp_vec* w; /* N-vector, only for a stacked basis (the diagonal block of Q'r); else NULL */
+    lfpsqp_vec* w; /* unused (kept for layout stability): the diagonal block of Q'r is recomputed on the fly */
 } lfpsqp_projcg_work;
 
 #define LFPSQP_PROJCG_WANT_LAMBDA 1 /* compute lambda = U'(b - A x) (src/projcg.jl:115-118) */

@@ -167,16 +167,17 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(const double* __restri
         for (int j = threadIdx.x; j < jn; j += kThreads) ts[j] = t[j0 + j];
         __syncthreads();
         int j = 0;
-        for (; j + 8 <= jn; j += 8) {
-            double2 a[8][kS];
+        constexpr int kCU = (kS >= 4) ? 4 : 8;     // columns in flight: 16 x 16-byte loads per lane either way
+        for (; j + kCU <= jn; j += kCU) {
+            double2 a[kCU][kS];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < kCU; ++c) {
                 const double* col = base + (int64_t)(j0 + j + c) * ld;
 #pragma unroll
                 for (int s = 0; s < kS; ++s) a[c][s] = ldm<NT>(col + (int64_t)s * kSlabRows);
             }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < kCU; ++c) {
                 const double tj = ts[j + c];
 #pragma unroll
                 for (int s = 0; s < kS; ++s) {

@@ -1,15 +1,17 @@
 // Projected conjugate gradient on the device -- the reference's projcg!
 // (src/projcg.jl:40-121) as three fused streaming kernels per iteration:
 //
-//   K1  d = beta*d - g ; partial d'(A d)                      (vec_kernel)     :99, :74-75
-//   K2  alpha = rg/dAd ; x += alpha d ; rp = g + alpha A d ;
-//       partial U' rp                                          (gemv_t_kernel)  :91-96
-//   K3  gp = rp - U (U' rp) ; g = gp ; partial rp'gp, gp'gp    (gemv_n_kernel)  :97-103
+//   K1  x += alpha_prev*d (deferred :92) ; d = beta*d - g ; partial d'(A d)   (vec_kernel)     :99, :74-75
+//   K2  alpha = rg/dAd ; rp = g + alpha A d formed on the fly ; partial U' rp (gemv_t_kernel)  :91-96
+//   K3  gp = rp - U (U' rp), rp recomputed ; g = gp ; partial rp'gp, gp'gp    (gemv_n_kernel)  :97-103
 //
-// r == g throughout the reference loop (:61, :100-101), so r is not stored; gp and
-// Ad are never materialised.  HBM traffic per iteration = two passes over U plus
-// 12 n-vector passes = 16 n m + 96 n bytes, against ~27 unfused vector
-// passes in the reference.  All scalars (alpha, beta, rg, nr), the iteration counter
+// r == g throughout the reference loop (:61, :100-101), so r is not stored; gp, Ad AND rp are
+// never materialised inside the loop: measured on MI355X, n-vector STORES issued inside the
+// matrix stream cost ~3-4x their bytes (K2 with its x/rp stores 1.83 ms, without 1.60 ms), so
+// the iteration is arranged to store only x, d (in the small vector kernel K1) and g (K3):
+// 3 n-vector writes + 10 n-vector reads + two passes over U = 16 n m + 104 n bytes
+// (SURVEY §8d's fused minimum is 16 n m + 96 n with 4 writes; the reference moves ~27 passes).
+// The x-update of iteration k is applied by K1 of iteration k+1 (or by a final flush).  All scalars (alpha, beta, rg, nr), the iteration counter
 // and the exit status live in device memory; every kernel starts with a uniform
 // "already finished?" test, so the host may enqueue one iteration ahead of the
 // status it has seen (no pipeline bubble) and extra launches are no-ops.
@@ -39,6 +41,7 @@ struct AOpD {  // A = a0*I + diag(dg)
 struct PcgDirF {
     double* d;
     const double* g;
+    double* x;
     AOpD A;
     const double* scal;
     const int64_t* istat;
@@ -47,6 +50,11 @@ struct PcgDirF {
     __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
         double2 dd = ld2(d + i);
         if (!first) {
+            const double alpha = ld_scal(scal + S_ALPHA);               // x += alpha d of the previous iteration (:92)
+            double2 xx = ld2(x + i);
+            xx = make_double2(fma(alpha, dd.x, xx.x), fma(alpha, dd.y, xx.y));
+            if (v1) st2(x + i, xx);
+            else if (v0) x[i] = xx.x;
             const double beta = ld_scal(scal + S_BETA);
             const double2 gg = ld2(g + i);
             dd = make_double2(beta * dd.x - gg.x, beta * dd.y - gg.y);   // src/projcg.jl:99
@@ -87,39 +95,37 @@ struct PcgPost1 {  // after d'Ad is final: iteration count, exits, alpha  (:72-9
     }
 };
 
-// ---- K2 (producer of v = rp for U' rp) ------------------------------------------
+// ---- K2 (producer of v = rp for U' rp; nothing is stored) -------------------------------
 struct PcgStepV {
-    double* x;
     const double* d;
     const double* g;
-    double* rp;
     AOpD A;
     const double* scal;
     const int64_t* istat;
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
-    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+    __device__ __forceinline__ double2 rp_at(int64_t r) const {
         const double alpha = ld_scal(scal + S_ALPHA);
         const double2 dd = ld2(d + r), gg = ld2(g + r);
-        double2 xx = ld2(x + r);
         const double2 ad = A.apply(r, dd);
-        xx = make_double2(fma(alpha, dd.x, xx.x), fma(alpha, dd.y, xx.y));      // :92
-        const double2 rr = make_double2(fma(alpha, ad.x, gg.x), fma(alpha, ad.y, gg.y));  // :93
-        if (v1) { st2(x + r, xx); st2(rp + r, rr); }
-        else if (v0) { x[r] = xx.x; rp[r] = rr.x; }
+        return make_double2(fma(alpha, ad.x, gg.x), fma(alpha, ad.y, gg.y));      // :93
+    }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double2 rr = rp_at(r);
         return make_double2(v0 ? rr.x : 0.0, v1 ? rr.y : 0.0);
     }
 };
 
 // ---- K3 (consumer of U*Utr) -------------------------------------------------------
 struct PcgProjE {
-    const double* rp;
+    const double* rp;   // stored residual: only the initial projection (init = 1) reads it
     double* g;
-    double* d;  // written (d = -g) only by the initial projection
+    double* d;          // written (d = -g) only by the initial projection
     const int64_t* istat;
     int init;
+    PcgStepV sv;        // recomputes rp = g + alpha A d inside the loop
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
-        const double2 rr = ld2(rp + r);
+        const double2 rr = init ? ld2(rp + r) : sv.rp_at(r);
         const double2 gp = make_double2(rr.x - acc.x, rr.y - acc.y);      // :97 (alpha=-1, beta=1)
         if (v1) st2(g + r, gp);
         else if (v0) g[r] = gp.x;
@@ -197,6 +203,20 @@ struct InitState {
         istat[I_MAXIT] = maxit;
     }
 };
+struct FlushXF {  // the x-update of the last completed iteration (:92)
+    double* x;
+    const double* d;
+    const double* scal;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double alpha = ld_scal(scal + S_ALPHA);
+        const double2 dd = ld2(d + i);
+        double2 xx = ld2(x + i);
+        xx = make_double2(fma(alpha, dd.x, xx.x), fma(alpha, dd.y, xx.y));
+        if (v1) st2(x + i, xx);
+        else if (v0) x[i] = xx.x;
+    }
+};
 struct SumSqF {
     const double* x;
     __device__ __forceinline__ bool skip() const { return false; }
@@ -228,33 +248,33 @@ struct NormalizeIntoF {  // x = d / sqrt(dd)    (:79)
 struct StackD {
     int64_t hs;
     const double *Dx, *Dy, *sx, *sy;
-    double* w;  // N-vector: diagonal block of Q'rp
 };
 struct PcgStepVS {
     PcgStepV p;
     StackD k;
     __device__ __forceinline__ bool skip() const { return p.skip(); }
     __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
-        const double2 rx = p.load(r, v0, v1);                 // x-half: updates x, rp
+        const double2 rx = p.load(r, v0, v1);                 // x-half of rp (recomputed, not stored)
         const double2 ry = p.load(r + k.hs, v0, v1);          // y-half
-        const double2 dx = ld2(k.Dx + r), dy = ld2(k.Dy + r), ax = ld2(k.sx + r), ay = ld2(k.sy + r);
-        const double2 ww = make_double2(dx.x * rx.x + dy.x * ry.x, dx.y * rx.y + dy.y * ry.y);
-        if (v1) st2(k.w + r, ww);
-        else if (v0) k.w[r] = ww.x;
+        const double2 ax = ld2(k.sx + r), ay = ld2(k.sy + r);
         return make_double2(ax.x * rx.x + ay.x * ry.x, ax.y * rx.y + ay.y * ry.y);
     }
 };
 struct ResidualVS {
     ResidualV p;
     StackD k;
+    double* wout;   // optional: the diagonal block Dx.*rx + Dy.*ry of Q'r (the first N entries of lambda)
     __device__ __forceinline__ bool skip() const { return false; }
     __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
         const double2 rx = p.load(r, v0, v1);
         const double2 ry = p.load(r + k.hs, v0, v1);
-        const double2 dx = ld2(k.Dx + r), dy = ld2(k.Dy + r), ax = ld2(k.sx + r), ay = ld2(k.sy + r);
-        const double2 ww = make_double2(dx.x * rx.x + dy.x * ry.x, dx.y * rx.y + dy.y * ry.y);
-        if (v1) st2(k.w + r, ww);
-        else if (v0) k.w[r] = ww.x;
+        const double2 ax = ld2(k.sx + r), ay = ld2(k.sy + r);
+        if (wout) {
+            const double2 dx = ld2(k.Dx + r), dy = ld2(k.Dy + r);
+            const double2 ww = make_double2(dx.x * rx.x + dy.x * ry.x, dx.y * rx.y + dy.y * ry.y);
+            if (v1) st2(wout + r, ww);
+            else if (v0) wout[r] = ww.x;
+        }
         return make_double2(ax.x * rx.x + ay.x * ry.x, ax.y * rx.y + ay.y * ry.y);
     }
 };
@@ -263,13 +283,26 @@ struct PcgProjES {
     StackD k;
     __device__ __forceinline__ bool skip() const { return p.skip(); }
     __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
-        const double2 ww = ld2(k.w + r), dx = ld2(k.Dx + r), dy = ld2(k.Dy + r), ax = ld2(k.sx + r), ay = ld2(k.sy + r);
-        // (Q Q'rp) on the two halves; PcgProjE then forms gp = rp - that, stores g (and d), adds the dot terms
-        p.apply(r, make_double2(fma(ax.x, acc.x, dx.x * ww.x), fma(ax.y, acc.y, dx.y * ww.y)), v0, v1, red);
-        p.apply(r + k.hs, make_double2(fma(ay.x, acc.x, dy.x * ww.x), fma(ay.y, acc.y, dy.y * ww.y)), v0, v1, red);
+        const double2 rx = p.init ? ld2(p.rp + r) : p.sv.rp_at(r);
+        const double2 ry = p.init ? ld2(p.rp + r + k.hs) : p.sv.rp_at(r + k.hs);
+        const double2 dx = ld2(k.Dx + r), dy = ld2(k.Dy + r), ax = ld2(k.sx + r), ay = ld2(k.sy + r);
+        const double2 ww = make_double2(dx.x * rx.x + dy.x * ry.x, dx.y * rx.y + dy.y * ry.y);   // diagonal block of Q'rp
+        // gp = rp - Q Q'rp on the two halves
+        const double2 gx = make_double2(rx.x - fma(ax.x, acc.x, dx.x * ww.x), rx.y - fma(ax.y, acc.y, dx.y * ww.y));
+        const double2 gy = make_double2(ry.x - fma(ay.x, acc.x, dy.x * ww.x), ry.y - fma(ay.y, acc.y, dy.y * ww.y));
+        if (v1) { st2(p.g + r, gx); st2(p.g + r + k.hs, gy); }
+        else if (v0) { p.g[r] = gx.x; p.g[r + k.hs] = gy.x; }
+        if (p.init) {
+            if (v1) { st2(p.d + r, make_double2(-gx.x, -gx.y)); st2(p.d + r + k.hs, make_double2(-gy.x, -gy.y)); }
+            else if (v0) { p.d[r] = -gx.x; p.d[r + k.hs] = -gy.x; }
+        }
+        double s0 = 0.0, s1 = 0.0;
+        if (v0) { s0 = rx.x * gx.x + ry.x * gy.x; s1 = gx.x * gx.x + gy.x * gy.x; }
+        if (v1) { s0 += rx.y * gx.y + ry.y * gy.y; s1 += gx.y * gx.y + gy.y * gy.y; }
+        red[0] += s0;
+        red[1] += s1;
     }
 };
-
 
 }  // namespace lfpsqp
 
@@ -289,10 +322,10 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     LF_ARG(ctx, n_global >= (stacked ? 0 : nv));
     int64_t N = nv, hs = 0;                        // rows of Z
     if (stacked) {
-        LF_ARG(ctx, U->Dy && U->sx && U->sy && work->w);
+        LF_ARG(ctx, U->Dy && U->sx && U->sy);
         N = U->Dx->n;
         hs = lfpsqp_half_stride(N);
-        LF_ARG(ctx, nv == hs + N && U->Dy->n == N && U->sx->n == N && U->sy->n == N && work->w->n == N && (m == 0 || U->Z->n == N));
+        LF_ARG(ctx, nv == hs + N && U->Dy->n == N && U->sx->n == N && U->sy->n == N && (m == 0 || U->Z->n == N));
         if (c) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "stacked basis with c != 0 (never used by optimize, src/optimize.jl:368)");
         LF_ARG(ctx, !(flags & LFPSQP_PROJCG_WANT_LAMBDA) || (lambda && lambda->n >= N + m));
     } else {
@@ -309,7 +342,7 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     double* rp = work->rp->p;
     double* Utr = work->Utr->p;
     const lfpsqp_mat* Z = m > 0 ? U->Z : nullptr;
-    const StackD sk = stacked ? StackD{hs, U->Dx->p, U->Dy->p, U->sx->p, U->sy->p, work->w->p} : StackD{0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const StackD sk = stacked ? StackD{hs, U->Dx->p, U->Dy->p, U->sx->p, U->sy->p} : StackD{0, nullptr, nullptr, nullptr, nullptr};
     // loop bound min(maxit, n + m) with the reference's n = length(b), m = length(c)   (src/projcg.jl:43-44,71)
     const int64_t m_ref = stacked ? n_global / 2 + m : m;
     int64_t maxit_eff = maxit < n_global + m_ref ? maxit : n_global + m_ref;
@@ -321,16 +354,16 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     hstat[1] = 0;
     auto launch_residual = [&](double sgn, double* store, double* t_out) -> int {
         const ResidualV rv{x->p, b->p, store, Ad, sgn};
-        if (stacked) return run_gemv_t(ctx, Z, m, N, ResidualVS{rv, StackD{hs, sk.Dx, sk.Dy, sk.sx, sk.sy, store ? sk.w : lambda->p}}, t_out);
+        if (stacked) return run_gemv_t(ctx, Z, m, N, ResidualVS{rv, sk, store ? nullptr : lambda->p}, t_out);
         return run_gemv_t(ctx, Z, m, N, rv, t_out);
     };
     auto launch_k2 = [&]() -> int {
-        const PcgStepV sv{x->p, d, g, rp, Ad, scal, istat};
+        const PcgStepV sv{d, g, Ad, scal, istat};
         if (stacked) return run_gemv_t(ctx, Z, m, N, PcgStepVS{sv, sk}, Utr, 1);
         return run_gemv_t(ctx, Z, m, N, sv, Utr, 1);
     };
     auto launch_k3 = [&](int init) -> int {
-        const PcgProjE pe{rp, g, d, istat, init};
+        const PcgProjE pe{rp, g, d, istat, init, PcgStepV{d, g, Ad, scal, istat}};
         const PcgPost3 post{scal, istat, init, hm};
         if (stacked) return run_gemv_n<PcgProjES, 2, PcgPost3>(ctx, Z, m, N, Utr, PcgProjES{pe, sk}, scal + S_RPGP, post, init ? -1 : 2);
         return run_gemv_n<PcgProjE, 2, PcgPost3>(ctx, Z, m, N, Utr, pe, scal + S_RPGP, post, init ? -1 : 2);
@@ -352,7 +385,7 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     int64_t it = 0;
     bool done = false;
     while (!done && it < maxit_eff) {
-        LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, nv, PcgDirF{d, g, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
+        LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, nv, PcgDirF{d, g, x->p, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
                                               PcgPost1{scal, istat, hm}, 0)));
         LF_TRY(launch_k2());
         LF_TRY(launch_k3(0));
@@ -367,6 +400,9 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     *iters = hstat[1];
     *nr = *(volatile double*)ctx->h_scal;
 
+    // the x-update of the last COMPLETED iteration is still pending (K1 of the next one would have applied it)
+    if ((status == ST_CONVERGED || status == ST_MAXIT) && *iters > 0)
+        LF_TRY((run_vec<FlushXF, 0, NoPost>(ctx, nv, FlushXF{x->p, d, scal}, 0u, nullptr, NoPost())));
     if (status == ST_NEGCURV) {   // :77-82
         LF_TRY((run_vec<SumSqF, 1, NoPost>(ctx, nv, SumSqF{d}, 0u, scal + S_DD, NoPost())));
         LF_TRY((run_vec<NormalizeIntoF, 0, NoPost>(ctx, nv, NormalizeIntoF{x->p, d, scal + S_DD}, 0u, nullptr, NoPost())));
