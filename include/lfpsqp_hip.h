@@ -281,6 +281,18 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
                       const lfpsqp_vec* xtilde, const lfpsqp_vec* x, lfpsqp_vec* xnew, double tol, int64_t maxiter, double* cval,
                       int* flag, int64_t* iters);
 
+/* pcg!(mu, J, no_precondition, x, r, p, z, tmp_m, tol, maxiter) (src/retractions.jl:179-246): CG on
+ * (J'J + mu I) x = b, the inner solve of the ProjPenalty retraction (:375), fused on the device
+ * (3 kernels per iteration, scalars and exit status in device memory).  J' is given in the
+ * lfpsqp_basis form: plain J' = Z[:, :ncols] (= Jct; no bounds), or stacked
+ * J' = [[diag Dx, sx.*Z]; [diag Dy, sy.*Z]] -- with Dx := Dx.*S, Dy := Dy.*S, sx = 1, sy = 0 this is
+ * the reference's InequalityDecomp (src/inequality_helper.jl:215-271, fulljac at src/retractions.jl:324).
+ * In: x = initial guess (the reference passes zeros), r = right-hand side.  Out: x, r = residual,
+ * *flag = 1 iff *iters == maxiter (reference quirk :240-243), *iters.  p, z: n-vector work;
+ * tmp_w: N-vector work (stacked only); tmp_m: >= ncols work. */
+int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, lfpsqp_vec* x, lfpsqp_vec* r, lfpsqp_vec* p, lfpsqp_vec* z,
+               lfpsqp_vec* tmp_w, lfpsqp_vec* tmp_m, double tol, int64_t maxiter, int* flag, int64_t* iters);
+
 /* per-kernel-family device time (ms) accumulated by the last lfpsqp_projcg call when
  * the context was created with profiling on (lfpsqp_ctx_set_profiling); used by
  * bench.py for the roofline object.  slots: 0 = K1 (direction update + d'Ad),

@@ -95,6 +95,7 @@ _SIGS = {
     "lfpsqp_constraints_jac": [P, C.POINTER(Constraints), P, P, PD],
     "lfpsqp_retract_nr": [P, C.POINTER(Basis), P, P, c_i64, C.POINTER(Constraints), CFUN, P, C.POINTER(IneqData), P, P, P, c_dbl, c_i64,
                           PD, C.POINTER(C.c_int), C.POINTER(c_i64)],
+    "lfpsqp_pcg": [P, c_dbl, C.POINTER(Basis), P, P, P, P, P, P, c_dbl, c_i64, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_gram": [P, P, c_i64, P, P],
     "lfpsqp_rmul": [P, P, c_i64, P, c_i64, P],
     "lfpsqp_factorize": [P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],

@@ -1,0 +1,222 @@
+// pcg! of the ProjPenalty retraction (reference src/retractions.jl:179-246) fused on the device:
+//
+//   P1  p = r + beta*p ; [w = Dx.*px + Dy.*py] ; partial J p          (gemv_t_kernel)  :209-221
+//   P2  z = J'(J p) + mu*p ; partial p'z                              (gemv_n_kernel)  :220-227
+//   P3  x += alpha*p ; r -= alpha*z ; partial r'r                     (vec_kernel)     :232-235
+//
+// z = M!(r) = r (no_precondition, the only preconditioner on the reference's live path, :374-375), so
+// rho = r'r is the previous iteration's residual norm squared and costs nothing.  Two passes over
+// Jct per iteration; scalars / status in device memory, published to the pinned host block.
+#include <math.h>
+
+#include "internal.h"
+
+namespace lfpsqp {
+
+enum { P_RHO = 16, P_BETA = 17, P_ALPHA = 18, P_PZ = 19, P_RR = 20, P_NRES = 21, P_TOL = 22 };
+enum { IP_STATUS = 4, IP_ITER = 5, IP_MAXIT = 6 };
+enum { PST_RUNNING = 0, PST_DONE = 1 };
+
+struct PcgHostMirror {
+    int64_t* hstat;  // [IP_STATUS], [IP_ITER]
+    __device__ __forceinline__ void publish(int64_t status, int64_t iter) const {
+        __hip_atomic_store(hstat + IP_ITER, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hstat + IP_STATUS, status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+};
+
+struct PInit {
+    double* scal;
+    int64_t* istat;
+    double tol;
+    int64_t maxit;
+    PcgHostMirror hm;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void run(double*) const {   // after rr0 = r'r : first rho, beta (rho_prev = 1, :203,212-216)
+        const double rr = ld_scal(scal + P_RR);
+        scal[P_RHO] = rr;
+        scal[P_BETA] = rr / 1.0;
+        scal[P_NRES] = INFINITY;                            // :202
+        scal[P_TOL] = tol;
+        istat[IP_ITER] = 0;
+        istat[IP_MAXIT] = maxit;
+        const int64_t st = (maxit > 0) ? PST_RUNNING : PST_DONE;   // while norm_res > tol && i < maxiter, norm_res = Inf
+        istat[IP_STATUS] = st;
+        hm.publish(st, 0);
+    }
+};
+
+struct P1V {  // p = r + beta p (stored); returns the new p
+    double* p;
+    const double* r;
+    const double* scal;
+    const int64_t* istat;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ double2 load(int64_t i, bool v0, bool v1) const {
+        const double beta = ld_scal(scal + P_BETA);
+        const double2 rr = ld2(r + i), pp = ld2(p + i);
+        const double2 o = make_double2(rr.x + beta * pp.x, rr.y + beta * pp.y);   // :217
+        if (v1) st2(p + i, o);
+        else if (v0) p[i] = o.x;
+        return make_double2(v0 ? o.x : 0.0, v1 ? o.y : 0.0);
+    }
+};
+struct PStack {
+    int64_t hs;
+    const double *Dx, *Dy, *sx, *sy;
+    double* w;
+};
+struct P1VS {
+    P1V b;
+    PStack k;
+    __device__ __forceinline__ bool skip() const { return b.skip(); }
+    __device__ __forceinline__ double2 load(int64_t i, bool v0, bool v1) const {
+        const double2 px = b.load(i, v0, v1), py = b.load(i + k.hs, v0, v1);
+        const double2 dx = ld2(k.Dx + i), dy = ld2(k.Dy + i), ax = ld2(k.sx + i), ay = ld2(k.sy + i);
+        const double2 ww = make_double2(dx.x * px.x + dy.x * py.x, dx.y * px.y + dy.y * py.y);
+        if (v1) st2(k.w + i, ww);
+        else if (v0) k.w[i] = ww.x;
+        return make_double2(ax.x * px.x + ay.x * py.x, ax.y * px.y + ay.y * py.y);
+    }
+};
+
+struct P2E {  // z = acc + mu p ; p'z
+    const double* p;
+    double* z;
+    double mu;
+    const int64_t* istat;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ void apply(int64_t i, double2 acc, bool v0, bool v1, double* red) const {
+        const double2 pp = ld2(p + i);
+        const double2 zz = make_double2(fma(mu, pp.x, acc.x), fma(mu, pp.y, acc.y));   // :222  z = J'tmp + mu z, z = p
+        if (v1) st2(z + i, zz);
+        else if (v0) z[i] = zz.x;
+        double s = 0.0;
+        if (v0) s = pp.x * zz.x;
+        if (v1) s = fma(pp.y, zz.y, s);
+        red[0] += s;
+    }
+};
+struct P2ES {
+    P2E b;
+    PStack k;
+    __device__ __forceinline__ bool skip() const { return b.skip(); }
+    __device__ __forceinline__ void apply(int64_t i, double2 acc, bool v0, bool v1, double* red) const {
+        const double2 ww = ld2(k.w + i), dx = ld2(k.Dx + i), dy = ld2(k.Dy + i), ax = ld2(k.sx + i), ay = ld2(k.sy + i);
+        b.apply(i, make_double2(fma(ax.x, acc.x, dx.x * ww.x), fma(ax.y, acc.y, dx.y * ww.y)), v0, v1, red);
+        b.apply(i + k.hs, make_double2(fma(ay.x, acc.x, dy.x * ww.x), fma(ay.y, acc.y, dy.y * ww.y)), v0, v1, red);
+    }
+};
+struct PPost2 {
+    double* scal;
+    const int64_t* istat;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ void run(double*) const { scal[P_ALPHA] = ld_scal(scal + P_RHO) / ld_scal(scal + P_PZ); }   // :227
+};
+
+struct P3F {  // x += alpha p ; r -= alpha z ; r'r
+    double* x;
+    double* r;
+    const double* p;
+    const double* z;
+    const double* scal;
+    const int64_t* istat;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double alpha = ld_scal(scal + P_ALPHA);
+        const double2 pp = ld2(p + i), zz = ld2(z + i);
+        double2 xx = ld2(x + i), rr = ld2(r + i);
+        xx = make_double2(fma(alpha, pp.x, xx.x), fma(alpha, pp.y, xx.y));     // :232
+        rr = make_double2(fma(-alpha, zz.x, rr.x), fma(-alpha, zz.y, rr.y));   // :233
+        if (v1) { st2(x + i, xx); st2(r + i, rr); }
+        else if (v0) { x[i] = xx.x; r[i] = rr.x; }
+        double s = 0.0;
+        if (v0) s = rr.x * rr.x;
+        if (v1) s = fma(rr.y, rr.y, s);
+        red[0] += s;
+    }
+};
+struct PPost3 {
+    double* scal;
+    int64_t* istat;
+    PcgHostMirror hm;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ void run(double*) const {
+        const double rr = ld_scal(scal + P_RR);
+        const double nres = sqrt(rr);                       // :235
+        scal[P_NRES] = nres;
+        const int64_t it = ld_stat(istat + IP_ITER) + 1;    // :237
+        istat[IP_ITER] = it;
+        const double rho_prev = ld_scal(scal + P_RHO);      // next iteration: rho = z'r = r'r, beta = rho / rho_prev (:212-216)
+        scal[P_RHO] = rr;
+        scal[P_BETA] = rr / rho_prev;
+        int64_t st = PST_RUNNING;
+        if (!(nres > ld_scal(scal + P_TOL)) || it >= ld_stat(istat + IP_MAXIT)) st = PST_DONE;   // :207 (NaN stops the loop)
+        if (st != PST_RUNNING) istat[IP_STATUS] = st;
+        hm.publish(st, it);
+    }
+};
+struct RRF {
+    const double* r;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double2 a = ld2(r + i);
+        double s = 0.0;
+        if (v0) s = a.x * a.x;
+        if (v1) s = fma(a.y, a.y, s);
+        red[0] += s;
+    }
+};
+
+}  // namespace lfpsqp
+
+using namespace lfpsqp;
+
+extern "C" int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, lfpsqp_vec* x, lfpsqp_vec* r, lfpsqp_vec* p, lfpsqp_vec* z,
+                          lfpsqp_vec* tmp_w, lfpsqp_vec* tmp_m, double tol, int64_t maxiter, int* flag, int64_t* iters) {
+    LF_ARG(ctx, ctx && Jop && x && r && p && z && tmp_m && flag && iters);
+    const bool stacked = Jop->Dx != nullptr;
+    const int m = (int)Jop->ncols;
+    const int64_t nv = r->n;
+    LF_ARG(ctx, x->n == nv && p->n == nv && z->n == nv && m >= 0 && (m == 0 || (Jop->Z && m <= Jop->Z->m)) && tmp_m->n >= m);
+    int64_t N = nv, hs = 0;
+    if (stacked) {
+        LF_ARG(ctx, Jop->Dy && Jop->sx && Jop->sy && tmp_w);
+        N = Jop->Dx->n;
+        hs = lfpsqp_half_stride(N);
+        LF_ARG(ctx, nv == hs + N && Jop->Dy->n == N && Jop->sx->n == N && Jop->sy->n == N && tmp_w->n == N && (m == 0 || Jop->Z->n == N));
+    } else {
+        LF_ARG(ctx, m == 0 || Jop->Z->n == nv);
+    }
+    double* scal = ctx->scal;
+    int64_t* istat = ctx->istat;
+    const lfpsqp_mat* Z = m > 0 ? Jop->Z : nullptr;
+    const PcgHostMirror hm{ctx->h_istat};
+    volatile int64_t* hstat = ctx->h_istat;
+    hstat[IP_STATUS] = PST_RUNNING;
+    hstat[IP_ITER] = 0;
+    const PStack sk = stacked ? PStack{hs, Jop->Dx->p, Jop->Dy->p, Jop->sx->p, Jop->sy->p, tmp_w->p} : PStack{0, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+    LF_TRY(lfpsqp_vec_fill(ctx, p, 0.0));                                                        // :204
+    LF_TRY((run_vec<RRF, 1, PInit>(ctx, nv, RRF{r->p}, 0u, scal + P_RR, PInit{scal, istat, tol, maxiter, hm})));
+    int64_t it = 0;
+    bool done = maxiter <= 0;
+    while (!done && it < maxiter) {
+        const P1V p1{p->p, r->p, scal, istat};
+        if (stacked) LF_TRY(run_gemv_t(ctx, Z, m, N, P1VS{p1, sk}, tmp_m->p, 4));
+        else LF_TRY(run_gemv_t(ctx, Z, m, N, p1, tmp_m->p, 4));
+        const P2E p2{p->p, z->p, mu, istat};
+        if (stacked) LF_TRY((run_gemv_n<P2ES, 1, PPost2>(ctx, Z, m, N, tmp_m->p, P2ES{p2, sk}, scal + P_PZ, PPost2{scal, istat}, 5)));
+        else LF_TRY((run_gemv_n<P2E, 1, PPost2>(ctx, Z, m, N, tmp_m->p, p2, scal + P_PZ, PPost2{scal, istat}, 5)));
+        LF_TRY((run_vec<P3F, 1, PPost3>(ctx, nv, P3F{x->p, r->p, p->p, z->p, scal, istat}, 0u, scal + P_RR, PPost3{scal, istat, hm}, 6)));
+        LF_HIP(ctx, hipEventRecord(ctx->ev_slot[it & 3], ctx->stream));
+        if (it >= 2) LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[(it - 2) & 3]));
+        if (hstat[IP_STATUS] != PST_RUNNING) done = true;
+        ++it;
+    }
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *iters = hstat[IP_ITER];
+    *flag = (*iters == maxiter) ? 1 : 0;                                                         // :240-243
+    if (ctx->profiling) prof_collect(ctx);
+    return 0;
+}

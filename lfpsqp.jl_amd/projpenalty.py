@@ -56,6 +56,9 @@ class _JacPlain:
     def __init__(self, Jct: DeviceMatrix, work: ProjPenaltyWork):
         self.Jct, self.w = Jct, work
 
+    def _basis(self):
+        return _capi.Basis(self.Jct.h, self.Jct.m, None, None, None, None)
+
     def apply(self, p):                       # mul!(tmp_m, J, p)       :221
         gemv_t(self.Jct, p, self.w.tmp_m)
 
@@ -97,7 +100,18 @@ def no_precondition(z, r):  # :259-263
 
 def pcg_(mu, J, M_, x, r, p, z, tmp_m, tol, maxiter):
     """pcg!(mu, J, M!, x, r, p, z, tmp_m, tol, maxiter) (src/retractions.jl:179-246) -> (flag, i).
-    J is one of the operator adapters above (tmp_m lives inside it)."""
+    J is one of the operator adapters above (tmp_m lives inside it).  With the reference's live
+    preconditioner (no_precondition, :375) the whole solve is ONE C call (lfpsqp_pcg, fused
+    kernels); any other M! runs the statement-by-statement loop below on the device primitives."""
+    if M_ is no_precondition:
+        ctx = x.ctx
+        flag = C.c_int()
+        iters = _capi.c_i64()
+        b = J._basis()
+        w = J.w
+        ctx.check(ctx.L.lfpsqp_pcg(ctx.h, float(mu), C.byref(b), x.h, r.h, p.h, z.h, w.tmp_w.h if hasattr(w, "tmp_w") else None,
+                                   w.tmp_m.h, float(tol), int(maxiter), C.byref(flag), C.byref(iters)))
+        return flag.value, iters.value
     norm_res = math.inf
     rho = 1.0
     p.fill(0.0)
