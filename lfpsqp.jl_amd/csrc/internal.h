@@ -217,6 +217,32 @@ int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const
     return 0;
 }
 
+// out[0 : n2 + NRED) = [ M2[:, :n2]' v ; reduction terms ], v produced by EP from M1[:, :n1] * t (all-reduced)
+template <class EP, int NRED>
+int run_gemv_nt(lfpsqp_ctx* ctx, const lfpsqp_mat* M1, int n1, const double* t, const lfpsqp_mat* M2, int n2, int64_t n, EP ep,
+                double* out) {
+    const int ks = ctx->tune_ks;
+    const int64_t tiles = ntiles_of(n, ks);
+    const int nout = n2 + NRED;
+    const int part_ld = (int)round_up(nout > 0 ? nout : 1, 32);
+    if (tiles > 0) {
+        LF_TRY(ensure_part(ctx, (size_t)tiles * part_ld + reduce_scratch(part_ld)));
+        const double* p1 = M1 ? M1->p : nullptr;
+        const double* p2 = M2 ? M2->p : nullptr;
+#define LF_GNT(KS, NT)                                                                                                           \
+    hipLaunchKernelGGL((gemv_nt_kernel<EP, NRED, KS, NT>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, p1, M1 ? M1->ld : 0, \
+                       n1, t, p2, M2 ? M2->ld : 0, n2, n, ep, ctx->part, part_ld)
+        if (ks == 4) { if (ctx->tune_nt) LF_GNT(4, true); else LF_GNT(4, false); }
+        else         { if (ctx->tune_nt) LF_GNT(2, true); else LF_GNT(2, false); }
+#undef LF_GNT
+        LF_LAUNCH_CHECK(ctx);
+    }
+    if (nout == 0) return 0;
+    if (tiles > 0) LF_TRY(launch_reduce(ctx, tiles, nout, part_ld, 0u, out, NoPost()));
+    else LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
+    return allreduce_dev(ctx, out, nout);
+}
+
 inline int vec_grid(int64_t n) {
     int64_t t = (n + kSlabRows - 1) / kSlabRows;
     return (int)(t < 2048 ? (t < 1 ? 1 : t) : 2048);

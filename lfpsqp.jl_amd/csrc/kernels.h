@@ -209,6 +209,104 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(const double* __restri
 }
 
 // ---------------------------------------------------------------------------
+// GEMV-N followed by GEMV-T on the SAME rows in one launch (the Newton-retraction step,
+// reference src/retractions.jl:140-149):  acc = M1[rows, :n1] * t  ->  EP::apply(row, acc, ...)
+// updates the iterate in registers, stores it once, returns v[row] and adds NRED reduction
+// terms; then part[tile][j] = sum_rows M2[row, j] * v[row] for j < n2 and
+// part[tile][n2 .. n2+NRED) = the block's reduction terms.  The intermediate vector never
+// goes back to HBM between the two products.
+// ---------------------------------------------------------------------------
+template <class EP, int NRED, int kS, bool NT>
+__global__ __launch_bounds__(kThreads) void gemv_nt_kernel(const double* __restrict__ M1, int64_t ld1, int n1,
+                                                            const double* __restrict__ t, const double* __restrict__ M2, int64_t ld2_,
+                                                            int n2, int64_t n, EP ep, double* __restrict__ part, int part_ld) {
+    __shared__ double ts[kColChunk];
+    __shared__ double red[kWaves][kColChunk];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * (kSlabRows * kS) + (int64_t)threadIdx.x * 2;
+    double2 acc[kS];
+#pragma unroll
+    for (int s = 0; s < kS; ++s) acc[s] = make_double2(0.0, 0.0);
+    {
+        const double* base = M1 + row0;
+        for (int j0 = 0; j0 < n1; j0 += kColChunk) {
+            const int jn = (n1 - j0 < kColChunk) ? (n1 - j0) : kColChunk;
+            __syncthreads();
+            for (int j = threadIdx.x; j < jn; j += kThreads) ts[j] = t[j0 + j];
+            __syncthreads();
+            constexpr int kCU = (kS >= 4) ? 4 : 8;
+            int j = 0;
+            for (; j + kCU <= jn; j += kCU) {
+                double2 a[kCU][kS];
+#pragma unroll
+                for (int c = 0; c < kCU; ++c)
+#pragma unroll
+                    for (int s = 0; s < kS; ++s) a[c][s] = ldm<NT>(base + (int64_t)(j0 + j + c) * ld1 + (int64_t)s * kSlabRows);
+#pragma unroll
+                for (int c = 0; c < kCU; ++c) {
+                    const double tj = ts[j + c];
+#pragma unroll
+                    for (int s = 0; s < kS; ++s) {
+                        acc[s].x = fma(a[c][s].x, tj, acc[s].x);
+                        acc[s].y = fma(a[c][s].y, tj, acc[s].y);
+                    }
+                }
+            }
+            for (; j < jn; ++j) {
+                const double tj = ts[j];
+#pragma unroll
+                for (int s = 0; s < kS; ++s) {
+                    const double2 a = ldm<NT>(base + (int64_t)(j0 + j) * ld1 + (int64_t)s * kSlabRows);
+                    acc[s].x = fma(a.x, tj, acc[s].x);
+                    acc[s].y = fma(a.y, tj, acc[s].y);
+                }
+            }
+        }
+    }
+    double rsum[NRED > 0 ? NRED : 1];
+#pragma unroll
+    for (int k = 0; k < (NRED > 0 ? NRED : 1); ++k) rsum[k] = 0.0;
+    double2 v[kS];
+#pragma unroll
+    for (int s = 0; s < kS; ++s) {
+        const int64_t r = row0 + (int64_t)s * kSlabRows;
+        v[s] = ep.apply(r, acc[s], r < n, r + 1 < n, rsum);
+    }
+    const double* base2 = M2 + row0;
+    double* prow = part + (int64_t)blockIdx.x * part_ld;
+    for (int j0 = 0; j0 < n2; j0 += kColChunk) {
+        const int jn = (n2 - j0 < kColChunk) ? (n2 - j0) : kColChunk;
+        for (int j = 0; j < jn; j += kTC) {
+            double p[kTC];
+#pragma unroll
+            for (int c = 0; c < kTC; ++c) {
+                const int jj = (j + c < jn) ? (j + c) : (jn - 1);
+                const double* col = base2 + (int64_t)(j0 + jj) * ld2_;
+                double a0 = 0.0;
+#pragma unroll
+                for (int s = 0; s < kS; ++s) {
+                    const double2 a = ldm<NT>(col + (int64_t)s * kSlabRows);
+                    a0 = fma(a.x, v[s].x, a0);
+                    a0 = fma(a.y, v[s].y, a0);
+                }
+                p[c] = a0;
+            }
+#pragma unroll
+            for (int c = 0; c < kTC; ++c) p[c] = wave_sum(p[c]);
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < kTC; ++c)
+                    if (j + c < jn) red[wave][j + c] = p[c];
+            }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < jn; j += kThreads) prow[j0 + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+        __syncthreads();
+    }
+    if (NRED > 0) block_reduce_store<(NRED > 0 ? NRED : 1)>(rsum, 0u, prow + n2);
+}
+
+// ---------------------------------------------------------------------------
 // Elementwise map + reductions.  F::apply(i, valid0, valid1, red) handles the
 // row pair (i, i+1).  Static tile -> block assignment (tile = block + k*grid) and
 // a fixed in-block order keep the sums reproducible.  part[block][k].

@@ -49,6 +49,73 @@ struct PlainVec {  // GEMV-T producer reading the first N entries of a (possibly
     }
 };
 
+// y_retract! for one variable -- defined in ineq.hip's translation unit as a device inline; repeated here
+// (same statements, src/retractions.jl:459-497) so the fused Newton step can apply it in registers.
+__device__ __forceinline__ void y_retract_one_nr(double& xn, double& yn, double xo, double yo, double qq, double rr, double ss, double tt) {
+    if (ss == 0.0) {
+        xn = yn;
+    } else if (qq == 0.0) {
+        const double g1 = -ss, g2 = -2.0 * (yo - rr);
+        const double ng = sqrt(g1 * g1 + g2 * g2);
+        const double ux = xo - xn + g1 / ng;
+        const double uy = yo - yn + g2 / ng;
+        const double a = ss * (uy * uy);
+        const double b = ux + 2.0 * ss * (yn - rr) * uy;
+        const double c = xn + ss * ((yn - rr) * (yn - rr)) - rr;
+        const double a1 = -b / (2.0 * a);
+        const double a2 = sqrt(b * b - 4.0 * a * c) / (2.0 * a);
+        const double gam = fmin(a1 + a2, a1 - a2);
+        xn += gam * ux;
+        yn += gam * uy;
+    } else {
+        const double c = rr, rho = sqrt(tt);
+        const double dist = sqrt((xn - c) * (xn - c) + (yn - c) * (yn - c));
+        const double y2 = c + rho * (yn - c) / dist;
+        const double x2 = c + rho * (xn - c) / dist;
+        yn = y2;
+        xn = x2;
+    }
+}
+
+// Fused Newton-retraction step (src/retractions.jl:141-149): xnew += U*delta (stacked when bounds exist),
+// y_retract!, and the value handed to the c! product; one reduction term = the ball partial.
+struct NRStepE {
+    double* xnew;
+    const double* xold;
+    int64_t hs;                      // 0 => no bounds (plain basis)
+    const double *sx, *sy;           // row scalings of the stacked basis
+    const double *q, *r, *s, *t;     // InequalityData
+    int64_t n_x, slack_row;          // ball term: sum_{i<n_x} x_i^2 - x[slack_row]  (slack_row < 0: none here)
+    int has_ball;
+    __device__ __forceinline__ double ball(int64_t i, double xi) const {
+        return !has_ball ? 0.0 : (i < n_x ? xi * xi : (i == slack_row ? -xi : 0.0));
+    }
+    __device__ __forceinline__ double2 apply(int64_t i, double2 acc, bool v0, bool v1, double* red) const {
+        double2 xn = ld2(xnew + i);
+        if (hs == 0) {
+            xn.x += acc.x; xn.y += acc.y;
+            if (v1) st2(xnew + i, xn);
+            else if (v0) xnew[i] = xn.x;
+        } else {
+            const double2 ax = ld2(sx + i), ay = ld2(sy + i);
+            double2 yn = ld2(xnew + hs + i);
+            xn.x += ax.x * acc.x; xn.y += ax.y * acc.y;
+            yn.x += ay.x * acc.x; yn.y += ay.y * acc.y;
+            const double2 xo = ld2(xold + i), yo = ld2(xold + hs + i);
+            const double2 qq = ld2(q + i), rr = ld2(r + i), ss = ld2(s + i), tt = ld2(t + i);
+            if (v0) y_retract_one_nr(xn.x, yn.x, xo.x, yo.x, qq.x, rr.x, ss.x, tt.x);
+            if (v1) y_retract_one_nr(xn.y, yn.y, xo.y, yo.y, qq.y, rr.y, ss.y, tt.y);
+            if (v1) { st2(xnew + i, xn); st2(xnew + hs + i, yn); }
+            else if (v0) { xnew[i] = xn.x; xnew[hs + i] = yn.x; }
+        }
+        double b = 0.0;
+        if (v0) b += ball(i, xn.x);
+        if (v1) b += ball(i + 1, xn.y);
+        red[0] += b;
+        return make_double2(v0 ? xn.x : 0.0, v1 ? xn.y : 0.0);
+    }
+};
+
 int cons_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval) {
     const lfpsqp_mat* J = cons->Jct;
     const int ml = (int)cons->m_lin;
@@ -139,9 +206,23 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
             h_delta[k] = -s;
         }
         LF_HIP(ctx, hipMemcpyAsync(tv.p, h_delta, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
-        LF_TRY(lfpsqp_q_gemv_n(ctx, U, 1.0, nullptr, &tv, 1.0, xnew));   // :141  xnew += U tmp
-        if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew, x, idata));      // :144-146
-        LF_TRY(eval_c(tmp2.data()));
+        if (!cfun) {
+            // fused step: xnew += U tmp (:141), y_retract! (:145), and the c! products (:146/148) in one launch
+            const int ml = (int)cons->m_lin;
+            const int64_t N = cons->Jct->n;
+            NRStepE ep{xnew->p, x->p, ineq ? lfpsqp_half_stride(N) : 0, ineq ? U->sx->p : nullptr, ineq ? U->sy->p : nullptr,
+                       ineq ? idata->q->p : nullptr, ineq ? idata->r->p : nullptr, ineq ? idata->s->p : nullptr,
+                       ineq ? idata->t->p : nullptr, cons->n_x, cons->slack_row, cons->has_ball ? 1 : 0};
+            LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, U->Z, m, tv.p, cons->Jct, ml, N, ep, ctx->d_m)));
+            LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * (ml + 1), hipMemcpyDeviceToHost, ctx->stream));
+            LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int j = 0; j < ml; ++j) tmp2[j] = ctx->h_m[j] - cons->b[j];
+            if (cons->has_ball) tmp2[ml] = ctx->h_m[ml] - cons->R2;
+        } else {
+            LF_TRY(lfpsqp_q_gemv_n(ctx, U, 1.0, nullptr, &tv, 1.0, xnew));   // :141  xnew += U tmp
+            if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew, x, idata));      // :144-146
+            LF_TRY(eval_c(tmp2.data()));
+        }
         for (int k = 0; k < m; ++k) { dc[k] = tmp2[k] - cval[k]; cval[k] = tmp2[k]; }   // :152-153
         for (int k = 0; k < m; ++k) {                                 // :156  tmp2 = D' tmp
             double s = 0.0;
