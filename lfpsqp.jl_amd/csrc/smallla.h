@@ -27,6 +27,7 @@ inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::
             for (int q = p + 1; q < cols; ++q) {
                 double* aq = &A[(size_t)q * rows];
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma omp simd reduction(+ : alpha, beta, gamma)
                 for (int i = 0; i < rows; ++i) {
                     alpha += ap[i] * ap[i];
                     beta += aq[i] * aq[i];
@@ -39,6 +40,7 @@ inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::
                 const double zeta = (beta - alpha) / (2.0 * gamma);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma omp simd
                 for (int i = 0; i < rows; ++i) {
                     const double x = ap[i], y = aq[i];
                     ap[i] = c * x - s * y;
@@ -46,6 +48,7 @@ inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::
                 }
                 double* vp = &V[(size_t)p * cols];
                 double* vq = &V[(size_t)q * cols];
+#pragma omp simd
                 for (int i = 0; i < cols; ++i) {
                     const double x = vp[i], y = vq[i];
                     vp[i] = c * x - s * y;

@@ -119,9 +119,15 @@ class DeviceVector:
         return self.n
 
     def free(self):
-        if self.h and self.ctx.h:
+        if getattr(self, "h", None) and self.ctx.h:
             self.ctx.L.lfpsqp_vec_free(self.ctx.h, self.h)
         self.h = None
+
+    def __del__(self):   # device memory is library-owned; release it with the Python handle
+        try:
+            self.free()
+        except Exception:
+            pass
 
     def upload(self, data, offset: int = 0):
         a = np.ascontiguousarray(data, dtype=np.float64)
@@ -161,9 +167,15 @@ class DeviceMatrix:
         return (self.n, self.m)
 
     def free(self):
-        if self.h and self.ctx.h:
+        if getattr(self, "h", None) and self.ctx.h:
             self.ctx.L.lfpsqp_mat_free(self.ctx.h, self.h)
         self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
     def upload(self, data, col0: int = 0):
         a = np.asfortranarray(data, dtype=np.float64)

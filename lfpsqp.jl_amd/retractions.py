@@ -117,6 +117,7 @@ def _retract_nr(cval, xnew, c_, xtilde, x, method: NR):
                 tmpv = DeviceVector.__new__(DeviceVector)
                 tmpv.ctx, tmpv.n, tmpv.h = ctx, nrows, C.c_void_p(xvec_handle)
                 xh = tmpv.download(nrows, 0)
+                tmpv.h = None                     # borrowed handle: the library owns this vector
                 out = np.ctypeslib.as_array(cval_ptr, shape=(m,))
                 c_(out, xh)
                 return 0
