@@ -1,10 +1,10 @@
-// Tangent setup on the device: weighted Gram matrix, right-multiplication by a small
-// matrix, and the thin factorisation built from them (replaces the reference's per-outer-
-// iteration LAPACK dgesvd, src/la_helper.jl:8-34).  Both kernels are the same register-tiled
-// contraction C[i][j] += sum_k A[k][i] * B[k][j] on 128 x 128 output tiles with a 16-deep K
-// step staged through LDS (fp64 FMA; AI = m/4 flop/B, compute-bound for m >= 128).
-// Round-1 note: VALU FMAs, not yet v_mfma_f64_16x16x4_f64 -- the tile shape was chosen so
-// the MFMA version is a drop-in for tile_fma() ("next").
+// Tangent setup on the device: weighted Gram matrix, right-multiplication by a small matrix, and
+// the thin factorisation built from them (replaces the reference's per-outer-iteration LAPACK dgesvd,
+// src/la_helper.jl:8-34).  These are the only genuinely contraction-shaped (compute-bound) operations
+// of the hot path (AI = m/4 flop/B), so they run on the matrix cores: both kernels are the same
+// 128 x 128 output tile  C[i][j] += sum_k A[k][i] * B[k][j]  with a 16-deep K step staged through LDS
+// and v_mfma_f64_16x16x4_f64 (lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D row = (l>>4)+4*reg,
+// col = l&15).  Each of the 4 waves owns two 16-row i-tiles x all eight j-tiles = 16 accumulators.
 #include <math.h>
 
 #include <vector>
@@ -16,20 +16,22 @@ namespace lfpsqp {
 
 constexpr int kPanel = 128;
 constexpr int kKStep = 16;
+constexpr int kLdsLd = 144;   // row stride 288 dwords = 32 mod 64: the two k-rows a half-wave reads hit disjoint banks
+typedef double f64x4 __attribute__((vector_size(32)));
 
-// thread (ti = tid % 16, tj = tid / 16) owns C rows ti*8..+8 (index i) and columns tj*8..+8 (index j)
-__device__ __forceinline__ void tile_fma(const double (*As)[kPanel], const double (*Bs)[kPanel], double (&acc)[8][8], int ti, int tj) {
-#pragma unroll 4
-    for (int k = 0; k < kKStep; ++k) {
-        double a[8], b[8];
+__device__ __forceinline__ void tile_mfma(const double (*As)[kLdsLd], const double (*Bs)[kLdsLd], f64x4 (&acc)[2][8], int wave, int lane) {
+    const int c = lane & 15;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] = As[k][ti * 8 + q];
+    for (int kk = 0; kk < kKStep; kk += 4) {
+        const int kr = kk + (lane >> 4);
+        const double a0 = As[kr][(2 * wave) * 16 + c];
+        const double a1 = As[kr][(2 * wave + 1) * 16 + c];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) b[q] = Bs[k][tj * 8 + q];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        for (int jt = 0; jt < 8; ++jt) {
+            const double b = Bs[kr][jt * 16 + c];
+            acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][jt], 0, 0, 0);
+            acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][jt], 0, 0, 0);
+        }
     }
 }
 
@@ -38,16 +40,17 @@ __device__ __forceinline__ void tile_fma(const double (*As)[kPanel], const doubl
 // part[g][pp*16384 + j*128 + i]  (i = row of G within panel pi, j = column within panel pj).
 __global__ __launch_bounds__(kThreads) void gram_kernel(const double* __restrict__ M, int64_t ld, int64_t n, int ncols, int npan,
                                                          const double* __restrict__ w2, double* __restrict__ part, int64_t part_ld) {
-    __shared__ double As[kKStep][kPanel];
-    __shared__ double Bs[kKStep][kPanel];
+    __shared__ double As[kKStep][kLdsLd];
+    __shared__ double Bs[kKStep][kLdsLd];
     const int pi = blockIdx.y / npan, pj = blockIdx.y % npan;
-    const int tid = threadIdx.x, ti = tid % 16, tj = tid / 16;
-    double acc[8][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f64x4 acc[2][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
+        for (int b = 0; b < 8; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
     const int64_t nsteps = (n + kKStep - 1) / kKStep;
+    const bool needB = (pi != pj) || (w2 != nullptr);   // diagonal unweighted panel: B is A itself
     // staging role: column c = tid / 2 of the panel, rows kh..kh+8 of the step
     const int c = tid >> 1, kh = (tid & 1) * 8;
     const int64_t colA = (int64_t)pi * kPanel + c, colB = (int64_t)pj * kPanel + c;
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(kThreads) void gram_kernel(const double* __restrict
             const int64_t r = r0 + q;
             double2 a = make_double2(0.0, 0.0), b = make_double2(0.0, 0.0);
             if (colA < ncols) a = ld2(M + colA * ld + r);      // rows >= n are zero padding
-            if (pi != pj && colB < ncols) b = ld2(M + colB * ld + r);
+            if (needB && colB < ncols) b = ld2(M + colB * ld + r);
             if (w2) {
                 const double2 w = ld2(w2 + r);
                 a.x *= (r < n) ? w.x : 0.0;
@@ -72,86 +75,77 @@ __global__ __launch_bounds__(kThreads) void gram_kernel(const double* __restrict
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             As[kh + q][c] = va[q];
-            if (pi != pj) Bs[kh + q][c] = vb[q];
+            if (needB) Bs[kh + q][c] = vb[q];
         }
         __syncthreads();
-        if (pi != pj) {
-            tile_fma(As, Bs, acc, ti, tj);
-        } else if (w2) {
-            // diagonal panel with weights: B side must be the UNWEIGHTED rows
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 8; q += 2) {
-                double2 b = make_double2(0.0, 0.0);
-                if (colA < ncols) b = ld2(M + colA * ld + r0 + q);
-                Bs[kh + q][c] = b.x;
-                Bs[kh + q + 1][c] = b.y;
-            }
-            __syncthreads();
-            tile_fma(As, Bs, acc, ti, tj);
-        } else {
-            tile_fma(As, As, acc, ti, tj);
-        }
+        tile_mfma(As, needB ? Bs : As, acc, wave, lane);
     }
     double* out = part + (int64_t)blockIdx.x * part_ld + (int64_t)blockIdx.y * (kPanel * kPanel);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int it = 0; it < 2; ++it)
 #pragma unroll
-        for (int i = 0; i < 8; i += 2)
-            st2(out + (tj * 8 + j) * kPanel + ti * 8 + i, make_double2(acc[i][j], acc[i + 1][j]));
+        for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = (2 * wave + it) * 16 + (lane >> 4) + 4 * r;
+                const int j = jt * 16 + (lane & 15);
+                out[j * kPanel + i] = acc[it][jt][r];
+            }
 }
 
-// Out[row0 + i, c0 + j] = sum_k In[row0 + i, k] * W[k, c0 + j]; grid = (row tiles of 128, column panels)
+// Out[row0 + r, c0 + c] = sum_k In[row0 + r, k] * W[k, c0 + c]; grid = (row tiles of 128, column panels).
+// The contraction is computed transposed (i = output column c, j = matrix row r) so that each
+// accumulator register stores 16 consecutive matrix rows (128 contiguous bytes per column).
 __global__ __launch_bounds__(kThreads) void rmul_kernel(const double* __restrict__ In, int64_t ld_in, int64_t n, int kcols,
                                                          const double* __restrict__ W, int ldw, int rcols, double* __restrict__ Out,
                                                          int64_t ld_out) {
-    __shared__ double As[kKStep][kPanel];
-    __shared__ double Bs[kKStep][kPanel];
-    const int tid = threadIdx.x, ti = tid % 16, tj = tid / 16;
+    __shared__ double As[kKStep][kLdsLd];   // As[k][c] = W[k0+k, c0+c]
+    __shared__ double Bs[kKStep][kLdsLd];   // Bs[k][r] = In[row0+r, k0+k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row0 = (int64_t)blockIdx.x * kPanel;
     const int c0 = blockIdx.y * kPanel;
-    double acc[8][8];
+    f64x4 acc[2][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
-    // staging roles: A: k = tid / 16, rows (tid % 16)*8..+8 ; B: column tid / 2, k half (tid & 1)*8
-    const int ka = tid / 16, ra = (tid % 16) * 8;
-    const int cb = tid >> 1, kb = (tid & 1) * 8;
+        for (int b = 0; b < 8; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // staging roles: In: k = tid / 16, rows (tid % 16)*8..+8 ; W: column tid / 2, k half (tid & 1)*8
+    const int kb = tid / 16, rb = (tid % 16) * 8;
+    const int ca = tid >> 1, ka = (tid & 1) * 8;
     for (int k0 = 0; k0 < kcols; k0 += kKStep) {
         double va[8], vb[8];
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
-            double2 a = make_double2(0.0, 0.0);
-            if (k0 + ka < kcols) a = ld2(In + (int64_t)(k0 + ka) * ld_in + row0 + ra + q);   // padded rows are zero
-            va[q] = a.x; va[q + 1] = a.y;
+            double2 b = make_double2(0.0, 0.0);
+            if (k0 + kb < kcols) b = ld2(In + (int64_t)(k0 + kb) * ld_in + row0 + rb + q);   // padded rows are zero
+            vb[q] = b.x; vb[q + 1] = b.y;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int k = k0 + kb + q;
-            vb[q] = (k < kcols && c0 + cb < rcols) ? W[(int64_t)(c0 + cb) * ldw + k] : 0.0;
+            const int k = k0 + ka + q;
+            va[q] = (k < kcols && c0 + ca < rcols) ? W[(int64_t)(c0 + ca) * ldw + k] : 0.0;
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            As[ka][ra + q] = va[q];
-            Bs[kb + q][cb] = vb[q];
+            As[ka + q][ca] = va[q];
+            Bs[kb][rb + q] = vb[q];
         }
         __syncthreads();
-        tile_fma(As, Bs, acc, ti, tj);
+        tile_mfma(As, Bs, acc, wave, lane);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int col = c0 + tj * 8 + j;
-        if (col >= rcols) continue;
+    for (int it = 0; it < 2; ++it)
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-            const int64_t r = row0 + ti * 8 + i;
-            double* dst = Out + (int64_t)col * ld_out + r;
-            if (r + 1 < n) st2(dst, make_double2(acc[i][j], acc[i + 1][j]));
-            else if (r < n) dst[0] = acc[i][j];
+        for (int r = 0; r < 4; ++r) {
+            const int col = c0 + (2 * wave + it) * 16 + (lane >> 4) + 4 * r;
+            if (col >= rcols) continue;
+#pragma unroll
+            for (int jt = 0; jt < 8; ++jt) {
+                const int64_t row = row0 + jt * 16 + (lane & 15);
+                if (row < n) Out[(int64_t)col * ld_out + row] = acc[it][jt][r];
+            }
         }
-    }
 }
 
 __global__ __launch_bounds__(kThreads) void zero_cols_kernel(double* M, int64_t ld, int64_t n, int c0) {

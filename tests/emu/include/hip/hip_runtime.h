@@ -95,6 +95,7 @@ struct BlockState {
     unsigned nthreads = 0, live = 0, arrived = 0, gen = 0;
     unsigned w_arrived[16] = {0}, w_gen[16] = {0}, w_live[16] = {0};
     double scratch[1024];
+    double scratch2[1024];
     void* main_sp = nullptr;
     std::vector<void*> fibers;   // saved stack pointers
     std::vector<char*> stacks;
@@ -221,8 +222,26 @@ template <class T> inline T shfl_generic(T v, unsigned src_lane_in_wave) {
     wave_sync();
     return r;
 }
+// v_mfma_f64_16x16x4_f64: lane l holds A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15]; D[row=(l>>4)+4*reg][col=l&15]
+typedef double f64x4_t __attribute__((vector_size(32)));
+inline f64x4_t mfma_f64_16x16x4(double a, double b, f64x4_t c) {
+    BlockState* blk = g_blk;
+    const unsigned t = g_tid.x, lane = t & 63u, base = t & ~63u;
+    blk->scratch[t] = a;
+    blk->scratch2[t] = b;
+    wave_sync();
+    for (int r = 0; r < 4; ++r) {
+        const unsigned row = (lane >> 4) + 4u * r, col = lane & 15u;
+        double s = 0.0;
+        for (unsigned k = 0; k < 4; ++k) s += blk->scratch[base + row + 16u * k] * blk->scratch2[base + col + 16u * k];
+        c[r] += s;
+    }
+    wave_sync();
+    return c;
+}
 }  // namespace hipemu
 
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) hipemu::mfma_f64_16x16x4((a), (b), (c))
 #define threadIdx (hipemu::g_tid)
 #define blockIdx (hipemu::g_bid)
 #define blockDim (hipemu::g_bdim)
