@@ -30,12 +30,15 @@ def main(argv=None, lib=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=float, default=1e7)
-    ap.add_argument("--m", type=int, default=128)
+    ap.add_argument("--rows", dest="n", type=float, default=1e7, help="global n (default: the metric's 1e7)")
+    ap.add_argument("--cols", dest="m", type=int, default=128, help="m (default 128)")
     ap.add_argument("--basis", choices=["orthonormal", "scaled-hash"], default="orthonormal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=float, default=2e6)
-    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl")
+    ap.add_argument("--comm", choices=["rccl", "torch", "host-gloo"], default="rccl",
+                    help="all-reduce transport for N > 1: rccl (library-native, default), torch (torch.distributed nccl callback), "
+                         "host-gloo (functional test only: ranks may share one GPU)")
+    ap.add_argument("--device", type=int, default=None, help="HIP device index (default: LOCAL_RANK)")
     ap.add_argument("--lib", default=None, help="(development) alternative build of liblfpsqp_hip.so to load")
     args = ap.parse_args(argv)
     n, m, K, W = int(args.n), args.m, args.steps, args.warmup
@@ -52,21 +55,27 @@ def main(argv=None, lib=None):
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
+        # control plane only (the data path is the library's own RCCL communicator); with --comm torch the
+        # callback needs an nccl group as well
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl" if args.comm == "torch" else "gloo", rank=rank, world_size=world)
 
     import lfpsqp_jl_amd as L
 
     if args.lib:
         lib = L.load_library(args.lib)
-    ctx = L.Context(local_rank, lib)
+    dev = local_rank if args.device is None else args.device
+    ctx = L.Context(dev, lib)
     if world > 1:
         if args.comm == "rccl":
             box = [ctx.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             ctx.comm_init_rccl(rank, world, box[0])
-        else:
+        elif args.comm == "torch":
             from lfpsqp_jl_amd.distributed import torch_allreduce_callback
-            ctx.comm_init_callback(rank, world, torch_allreduce_callback(local_rank))
+            ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev))
+        else:
+            from lfpsqp_jl_amd.distributed import host_staged_allreduce_callback
+            ctx.comm_init_callback(rank, world, host_staged_allreduce_callback(dev))
     r0, r1 = ctx.shard_range(n, rank, world)
     n_loc = r1 - r0
 
@@ -183,6 +192,7 @@ def main(argv=None, lib=None):
     except (OSError, ValueError, KeyError):
         pass
 
+    out["check"] = {"x_norm": L.nrm2(x), "nr": nr, "iters": iters}    # global ||x|| after the K timed iterations (sanity / N-rank agreement)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_n), m, n)
     if rank == 0:

@@ -45,3 +45,25 @@ def torch_allreduce_callback(device_index: int | None = None):
         return 0
 
     return fn
+
+
+def host_staged_allreduce_callback(device_index: int):
+    """FUNCTIONAL-TEST transport: stage the device buffer through the host and reduce it with the
+    gloo group.  Lets several ranks share ONE GPU (RCCL refuses duplicate devices), so the whole
+    multi-rank flow of bench.py can be exercised on a 1-GPU box.  Not a performance path."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(ptr: int, count: int, op: int, stream: int) -> int:
+        class _Holder:
+            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+        ext = torch.cuda.ExternalStream(stream, device=f"cuda:{device_index}") if stream else torch.cuda.current_stream()
+        with torch.cuda.stream(ext):
+            t = torch.as_tensor(_Holder(), device=f"cuda:{device_index}")
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+            t.copy_(h)
+            ext.synchronize()
+        return 0
+
+    return fn

@@ -18,11 +18,14 @@ mode = sys.argv[1]
 if mode == "torch":
     import torch, torch.distributed as dist
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+if mode == "rccl_after_torch":      # what bench.py does for N > 1: torch (gloo control plane) is loaded first
+    import torch, torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1)
 import lfpsqp_jl_amd as L
 from oracle import lfpsqp_ref as R, synth
 from tests.helpers import DiagOpRef
 ctx = L.Context(0)
-if mode == "rccl":
+if mode in ("rccl", "rccl_after_torch"):
     ctx.comm_init_rccl(0, 1, ctx.comm_unique_id())
 else:
     from lfpsqp_jl_amd.distributed import torch_allreduce_callback
@@ -45,7 +48,7 @@ print("OK", mode, it)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["rccl", "torch"])
+@pytest.mark.parametrize("mode", ["rccl", "rccl_after_torch", "torch"])
 def test_one_rank_communicator(mode, tmp_path):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -54,3 +57,30 @@ def test_one_rank_communicator(mode, tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, str(script), mode], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "OK " + mode in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """The whole N > 1 flow of bench.py (torch.distributed.run launch, row sharding, generator offsets,
+    all-reduce placement, max-over-ranks timing, single JSON line) with 2 ranks on ONE GPU through the
+    host-staged gloo transport; the 2-rank result must reproduce the 1-rank iterate norm."""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    common = ["--steps", "6", "--warmup", "1", "--rows", "600000", "--cols", "24", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "host-gloo",
+                          "--device", "0"] + common, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert two.returncode == 0, (two.stdout[-1500:], two.stderr[-3000:])
+    lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints exactly one JSON line
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["steps"] == 6
+    assert d2["config"]["rows_per_gpu"] < 600000
+    assert abs(d2["check"]["x_norm"] - d1["check"]["x_norm"]) <= 1e-10 * d1["check"]["x_norm"]
+    assert abs(d2["check"]["nr"] - d1["check"]["nr"]) <= 1e-8 * d1["check"]["nr"]
