@@ -98,6 +98,20 @@ def no_precondition(z, r):  # :259-263
     return z
 
 
+def proj_precondition_(z, r, mu, U, Sigma, rank, tmp_m):
+    """proj_precondition!(z, r, mu, U, Sigma, rank, tmp_m) (src/retractions.jl:248-257): the exact inverse of
+    U Sigma^2 U' + mu I applied to r.  Dead code on the reference's live path (its call is commented out at
+    :374) and untested there; provided for completeness on the kgemv! primitives.  U: DeviceMatrix."""
+    z.copy_from(r)
+    gemv_t(U, r, tmp_m, ncols=rank)                                   # kgemv!('T', rank, 1, U, r, 0, tmp_m)
+    t = tmp_m.download(rank)
+    s2 = np.asarray(Sigma[:rank]) ** 2
+    t *= s2 / (mu + s2)
+    tmp_m.upload(t)
+    gemv_n(U, tmp_m, z, -1.0 / mu, 1.0 / mu, ncols=rank)             # kgemv!('N', rank, -1/mu, U, tmp_m, 1/mu, z)
+    return z
+
+
 def pcg_(mu, J, M_, x, r, p, z, tmp_m, tol, maxiter):
     """pcg!(mu, J, M!, x, r, p, z, tmp_m, tol, maxiter) (src/retractions.jl:179-246) -> (flag, i).
     J is one of the operator adapters above (tmp_m lives inside it).  With the reference's live

@@ -303,3 +303,23 @@ def test_tuning_variants_agree(dev_ctx):
     np.testing.assert_allclose(res[(2, True)][1], res[(4, True)][1], rtol=0, atol=1e-13)
     with pytest.raises(L.LfpsqpError):
         ctx.set_tuning(3, True)
+
+
+def test_factorize_ill_conditioned(dev_ctx):
+    """Gram-based factorisation with the re-orthonormalisation pass on a matrix of condition number 1e5
+    (the reference's dgesvd is backward stable; SURVEY §7 'hard parts')."""
+    ctx = dev_ctx
+    n, m = 3000, 12
+    rng = np.random.default_rng(21)
+    Q1, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    sv = np.logspace(0, -5, m)
+    Jh = np.asfortranarray((Q1 * sv) @ Q2.T)
+    J, Z = ctx.matrix(n, m, Jh), ctx.matrix(n, m)
+    S, Vt, rank = L.ksvd_(J, Z)
+    Zh = Z.download()
+    assert rank == m
+    np.testing.assert_allclose(S, sv, rtol=1e-5)                       # kappa^2 * eps relative accuracy on sigma
+    np.testing.assert_allclose(Zh.T @ Zh, np.eye(m), atol=1e-10)      # orthonormal after the second pass
+    np.testing.assert_allclose((Zh * S) @ Vt, Jh, atol=1e-12)
+    np.testing.assert_allclose(Zh @ (Zh.T @ np.ones(n)), Q1 @ (Q1.T @ np.ones(n)), atol=1e-6)

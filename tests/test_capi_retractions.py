@@ -233,3 +233,58 @@ def test_config4_default_projection_penalty_with_bounds(dev_ctx):
     x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(disp=L.DisplayOption.off, maxiter=maxiter), trace=tr)
     assert ti.iter == tir.iter
     _compare_traces(tr, tr0, rtol=1e-9, pcg_slack=2)
+
+
+def test_pcg_with_exact_preconditioners(sin_setup):
+    """test_retractions.jl:127-139: with an exact-inverse preconditioner pcg! converges in exactly ONE
+    iteration (generic M! path), and proj_precondition! (src/retractions.jl:248-257) is that inverse
+    for J'J + mu I when (U, Sigma) factor J'."""
+    from lfpsqp_jl_amd.projpenalty import _JacPlain
+    ctx, n, m, x0, c_, jac_, Jct, Z, S, Vt, step, rng = sin_setup
+    w = L.ProjPenaltyWork(ctx, m, n, False)
+    Jh = Jct.download().T                       # m x n
+    for mu in (1e-1, 1e-2):
+        bh = rng.standard_normal(n)
+        Afull = mu * np.eye(n) + Jh.T @ Jh
+
+        def M_host(z, r):
+            z.upload(np.linalg.solve(Afull, r.download()))
+            return z
+        x, r = ctx.vector(n), ctx.vector(n, bh)
+        flag, i = L.pcg_(mu, _JacPlain(Jct, w), M_host, x, r, w.p, w.z, None, 1e-6, 100)
+        assert flag == 0 and i == 1
+        assert np.linalg.norm(r.download()) < 1e-6
+        assert np.linalg.norm(Afull @ x.download() - bh) < 1e-6
+        # proj_precondition! == the same exact inverse, on the device
+        tmp_m = ctx.vector(m)
+
+        def M_dev(z, r):
+            return L.proj_precondition_(z, r, mu, Z, S, m, tmp_m)
+        x, r = ctx.vector(n), ctx.vector(n, bh)
+        flag, i = L.pcg_(mu, _JacPlain(Jct, w), M_dev, x, r, w.p, w.z, None, 1e-6, 100)
+        assert flag == 0 and i == 1
+        assert np.linalg.norm(Afull @ x.download() - bh) < 1e-6
+        z0 = np.zeros(n)
+        R.proj_precondition_(z0, bh, mu, Z.download(), S, m, np.zeros(m))
+        zz = ctx.vector(n)
+        L.proj_precondition_(zz, ctx.vector(n, bh), mu, Z, S, m, tmp_m)
+        np.testing.assert_allclose(zz.download(), z0, rtol=1e-10, atol=1e-12)
+
+
+def test_exact_linesearch_through_the_driver(dev_ctx):
+    """param.linesearch = exact (src/optimize.jl:419 -> src/linesearch.jl:107-339) end to end, NR retraction."""
+    ctx = dev_ctx
+    n, m = (6000, 8) if not _is_emu(ctx) else (1500, 4)
+    prob0, x0 = synth.config3(n, m)
+    prob0.xc = 0.3                                              # objective ||x - 0.3||^2: the exact search has work to do
+    tr0, tr = [], []
+    par0 = R.LFPSQPParams(do_project_retract=False, linesearch=R.LinesearchOption.exact, disp=R.DisplayOption.off, maxiter=3)
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, None, None, m, par0, trace=tr0)
+    P = L.QuadLinearBallBox(ctx, n, m, ctx.matrix(n, m).hash_fill(1), prob0.b, xc=0.3)
+    par = L.LFPSQPParams(do_project_retract=False, linesearch=L.LinesearchOption.exact, disp=L.DisplayOption.off, maxiter=3)
+    x, obj, lam, ti = P.optimize(x0, par, trace=tr)
+    assert ti.iter == tir.iter and ti.condition.name == tir.condition.name
+    for a, b in zip(tr, tr0):
+        assert np.linalg.norm(a['x'] - b['x']) <= 1e-9 * np.linalg.norm(b['x'])
+        assert a.get('alpha') == pytest.approx(b.get('alpha'), rel=1e-6) or a.get('alpha') is None
+    np.testing.assert_allclose(obj, objr, rtol=1e-10)
