@@ -1,0 +1,12 @@
+# round-end evidence: GPU tests, bench line, rocprofv3 kernel stats, PMC traffic passes -> gpurun_out/final_*
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/final; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $O/pytest_gpu.txt
+python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cat $O/bench.json
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
+cd $R
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_summary.json | head -8
+find $O -name "*kernel_trace.csv" -delete
+f=$(find $O/stats -name "*kernel_stats.csv" | head -1); head -8 "$f" | cut -c1-180
