@@ -19,10 +19,10 @@ class ExactLinesearchWork:  # :7-14
         self.tmp_n1, self.tmp_n2, self.tmp_n3, self.tmp_n4 = mk(), mk(), mk(), mk()
 
 
-def _step_norm(step, n_head, tmp=None):
+def _step_norm(step, n_head):
     """norm(view(step, 1:n)) (src/linesearch.jl:66): only the first n entries."""
-    from . import device
-    return device.nrm2_head(step, n_head)
+    from .device import nrm2_head
+    return nrm2_head(step, n_head)
 
 
 def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):

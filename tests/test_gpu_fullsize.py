@@ -1,0 +1,77 @@
+"""BASELINE.json's FULL size (n = 1e7, m = 128, one MI355X) through size-independent properties: the
+oracle cannot run there in seconds, but linearity, projector idempotence, orthonormality and the CG
+invariants must hold at any size (parity protocol)."""
+import math
+
+import numpy as np
+import pytest
+
+import lfpsqp_jl_amd as L
+
+N, M = 10_000_000, 128
+
+
+@pytest.fixture(scope="module")
+def big():
+    ctx = L.Context(0)
+    Z = ctx.matrix(N, M).hash_fill(1)
+    L.orthonormalize_(Z)
+    yield ctx, Z
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_full_size_basis_is_orthonormal_and_gemv_linear(big):
+    ctx, Z = big
+    G = L.gram(Z)
+    assert np.abs(G - np.eye(M)).max() < 5e-14
+    v1, v2 = ctx.vector(N).hash_fill(11), ctx.vector(N).hash_fill(12)
+    t1, t2, t3 = ctx.vector(M), ctx.vector(M), ctx.vector(M)
+    L.gemv_t(Z, v1, t1)
+    L.gemv_t(Z, v2, t2)
+    v3 = ctx.vector(N)
+    L.waxpby(2.0, v1, -3.0, v2, v3)
+    L.gemv_t(Z, v3, t3)
+    np.testing.assert_allclose(t3.download(), 2.0 * t1.download() - 3.0 * t2.download(), atol=1e-11)
+    # <Z t, v> == <t, Z'v>  (adjoint identity ties GEMV-N to GEMV-T)
+    y = ctx.vector(N)
+    L.gemv_n(Z, t2, y)
+    assert L.dot(y, v1) == pytest.approx(float(t2.download() @ t1.download()), rel=1e-11)
+    # projector idempotence: P = I - ZZ';  P(Pv) == Pv and Z'(Pv) == 0
+    L.gemv_n(Z, t1, v1, -1.0, 1.0)                   # v1 <- P v1
+    L.gemv_t(Z, v1, t3)
+    assert np.abs(t3.download()).max() < 1e-10
+    before = L.nrm2(v1)
+    L.gemv_n(Z, t3, v1, -1.0, 1.0)
+    assert L.nrm2(v1) == pytest.approx(before, rel=1e-13)
+
+
+@pytest.mark.gpu
+def test_full_size_projcg_invariants(big):
+    """Solve the benchmark QP to convergence at n = 1e7 and check the KKT system the reference's test
+    asserts (test_cg.jl:24-28): U'x = c = 0, nr < tol, (I - UU')(Ax - b) = 0, lambda = U'(b - Ax)."""
+    ctx, Z = big
+    a = ctx.vector(N).hash_fill(3, 0, 4.0, 5.0)
+    b = ctx.vector(N).hash_fill(4)
+    x, lam = ctx.vector(N), ctx.vector(M)
+    tol = 1e-8
+    it, nr = L.projcg_(x, lam, L.DiagOperator(0.0, a), L.DeviceBasis(Z), b, None, tol=tol, maxit=500)
+    assert nr < tol and 10 < it < 200
+    t = ctx.vector(M)
+    L.gemv_t(Z, x, t)
+    assert np.abs(t.download()).max() < 1e-11              # U'x = 0
+    r = ctx.vector(N)
+    L.vmul(a, x, r)
+    L.axpby(1.0, b, -1.0, r)                                # r = b - A x
+    L.gemv_t(Z, r, t)
+    np.testing.assert_allclose(t.download(), lam.download(), atol=1e-9)    # lambda = U'(b - Ax)
+    L.gemv_n(Z, t, r, -1.0, 1.0)                            # projected residual
+    assert L.nrm2(r) < 10 * tol
+    # the same solve through the (2, non-NT) kernel variant agrees to rounding
+    ctx.set_tuning(2, False)
+    x2 = ctx.vector(N)
+    it2, nr2 = L.projcg_(x2, None, L.DiagOperator(0.0, a), L.DeviceBasis(Z), b, None, tol=tol, maxit=500, want_lambda=False)
+    ctx.set_tuning(4, True)
+    assert it2 == it
+    L.axpby(1.0, x, -1.0, x2)
+    assert L.nrm2(x2) <= 1e-10 * L.nrm2(x)
