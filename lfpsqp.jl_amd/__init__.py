@@ -8,8 +8,9 @@ from .device import (Context, DeviceMatrix, DeviceVector, amax, axpby, dot, gemv
                      waxpby)
 from .projcg import DeviceBasis, DiagOperator, ProjCGWork, projcg_  # noqa: F401
 from .factorize import gram, ksvd_, orthonormalize_, rmul  # noqa: F401
-from .inequality import (InequalityData, InequalityDecomp, InequalityDecompProject, StackedVector, calculate_h_,  # noqa: F401
-                         generate_initial_y_, half_stride, inequality_gradient_, y_retract_)
+from .inequality import (InequalityData, InequalityDecomp, InequalityDecompOp, InequalityDecompProject, StackedVector,  # noqa: F401
+                         augmented_hess_diag_, calculate_h_, calculate_lambda_kkt_, generate_initial_y_, half_stride,
+                         inequality_gradient_, y_retract_)
 from .params import DisplayOption, LFPSQPParams, LinesearchOption, TerminationCondition, TerminationInfo  # noqa: F401
 from .retractions import NR, DeviceConstraints, Euclidean, NRWork, YRetract, retract_  # noqa: F401
 from .projpenalty import ProjPenalty, ProjPenaltyWork, no_precondition, pcg_, proj_precondition_  # noqa: F401

@@ -126,3 +126,67 @@ class InequalityDecompProject:
         c = y.ctx
         b = self._c()
         c.check(c.L.lfpsqp_q_gemv_n(c.h, C.byref(b), float(alpha), w.h if w is not None else None, t.h, float(beta), y.h))
+
+
+class InequalityDecompOp:
+    """The full constraint-Jacobian-transpose operator  [[diag(Dx.*S), Jct]; [diag(Dy.*S), 0]]  and its
+    adjoint: the three mul! methods of InequalityDecomp / InequalityDecompAdjoint
+    (src/inequality_helper.jl:215-271) -- what pcg!/ProjPenalty use as `fulljac` when bounds exist
+    (src/retractions.jl:324).  It is the stacked-operator form with row scalings (1, 0), so it runs on the
+    same kernels as the projection operator.  Coefficient vectors [v_h; v_c] are two device vectors."""
+
+    def __init__(self, idecomp: InequalityDecomp):
+        from .device import vmul
+        self.idecomp = idecomp
+        ctx, N = idecomp.ctx, idecomp.N
+        self.DxS, self.DyS = DeviceVector(ctx, N), DeviceVector(ctx, N)
+        self.ones = DeviceVector(ctx, N).fill(1.0)
+        self.zeros = DeviceVector(ctx, N)
+        self.refresh()
+
+    def refresh(self):
+        """Recompute Dx.*S, Dy.*S after inequality_gradient_ changed the decomposition."""
+        from .device import vmul
+        vmul(self.idecomp.Dx, self.idecomp.S, self.DxS)
+        vmul(self.idecomp.Dy, self.idecomp.S, self.DyS)
+
+    def _c(self):
+        return _capi.Basis(self.idecomp.Jct.h, self.idecomp.Jct.m, self.DxS.h, self.DyS.h, self.ones.h, self.zeros.h)
+
+    def mul_n(self, dest: StackedVector, v_h: DeviceVector, v_c: DeviceVector, a=1.0, b=0.0):
+        """dest = a * idecomp * [v_h; v_c] + b * dest   (mul!(dest, idecomp, v[, a, b]), :215-251)."""
+        c = dest.ctx
+        bb = self._c()
+        c.check(c.L.lfpsqp_q_gemv_n(c.h, C.byref(bb), float(a), v_h.h, v_c.h, float(b), dest.h))
+
+    def mul_t(self, dest_h: DeviceVector, dest_c: DeviceVector, w: StackedVector):
+        """[dest_h; dest_c] = idecomp' * w   (mul!(dest, idecomp', w), :254-271)."""
+        c = w.ctx
+        bb = self._c()
+        c.check(c.L.lfpsqp_q_gemv_t(c.h, C.byref(bb), w.h, dest_h.h, dest_c.h))
+
+
+def calculate_lambda_kkt_(lam_kkt: np.ndarray, lamy_kkt: DeviceVector, Qt_w: DeviceVector, Qt_t: DeviceVector,
+                          idecomp: InequalityDecomp):
+    """calculate_lambda_kkt!(lam_kkt, lamy_kkt, Qt_grad_f, idecomp) (src/inequality_helper.jl:286-308) with
+    Qt_grad_f = [Qt_w (N); Qt_t (rank)] as produced by InequalityDecompProject.mul_t:
+    lam = Vt' Sigma^-1 Qt_t (replicated m x m host algebra), lamy = (-Dx .* (Jct lam) + Qt_w) ./ S."""
+    ctx = lamy_kkt.ctx
+    m, rank = idecomp.M, idecomp.rank
+    th = Qt_t.download(m)
+    th[:rank] /= idecomp.Sigma[:rank]
+    th[rank:m] = 0.0
+    lam_kkt[:] = idecomp.Vt.T @ th
+    lam_dev = ctx.vector(max(m, 1), lam_kkt if m else None)
+    ctx.check(ctx.L.lfpsqp_calculate_lambda_y(ctx.h, idecomp.Jct.h, m, lam_dev.h, idecomp.Dx.h, idecomp.S.h, Qt_w.h, lamy_kkt.h))
+    lam_dev.free()
+    return lam_kkt, lamy_kkt
+
+
+def augmented_hess_diag_(a: StackedVector, hx: DeviceVector, lamy_kkt: DeviceVector, idata: InequalityData):
+    """The diagonal of augmented_hess_lag_vec! (src/inequality_helper.jl:144-158) for a diagonal Lagrangian
+    Hessian hx: a = [hx + 2 lamy.*q ; 2 lamy.*s]."""
+    ctx = a.ctx
+    d = idata._c()
+    ctx.check(ctx.L.lfpsqp_augmented_diag(ctx.h, hx.h, lamy_kkt.h, C.byref(d), a.h))
+    return a

@@ -160,3 +160,52 @@ def test_projcg_with_bounds_matches_oracle(dev_ctx, n, m):
     i1, nr1 = L.projcg_(x, lam, L.DiagOperator(0.0, L.StackedVector(ctx, n).upload2(a2)), P, b, None, tol=1e-12, work=work)
     assert i1 == i0 and np.isinf(nr1) and np.isinf(nr0) and np.all(np.isnan(lam.download()))
     assert np.linalg.norm(x.download2() - x0) < 1e-10
+
+
+@pytest.mark.parametrize("n,m", [(16, 5), (2100, 7)])
+def test_full_jacobian_operator_multipliers_and_hessian_diag(dev_ctx, n, m):
+    """test_inequalities.jl:111-120 (InequalityDecomp mul! x3), :143-155 (calculate_lambda_kkt! == bigA \\ d)
+    and :157-177 (augmented Hessian action, diagonal case) on the device."""
+    ctx = dev_ctx
+    rng, xl, xu, xaug, idata0, idata, X = _setup(ctx, n, m)
+    Jh = np.asfortranarray(rng.standard_normal((n, m)))
+    idc0 = R.InequalityDecomp(np.empty((2 * n, m), order='F'), np.empty(m), np.empty((m, m), order='F'),
+                              np.empty(n), np.empty(n), np.empty(n), Jh, m)
+    R.inequality_gradient_(idc0, xaug, idata0)
+    PJ = np.asfortranarray(np.vstack([(1 - idc0.Dx ** 2)[:, None] * Jh, (-idc0.Dy * idc0.Dx)[:, None] * Jh]))
+    R.ksvd_(PJ, idc0.U, idc0.Sigma, idc0.Vt)
+    ghx, ghy = idc0.Dx * idc0.S, idc0.Dy * idc0.S
+    bigA = np.block([[np.diag(ghx), Jh], [np.diag(ghy), np.zeros((n, m))]])
+    idc = L.InequalityDecomp(ctx, n, m, ctx.matrix(n, m, Jh))
+    L.inequality_gradient_(idc, X, idata)
+    idc.Sigma, idc.Vt, idc.rank = L.ksvd_(idc.Jct, idc.Z, w2=idc.sx)
+    op = L.InequalityDecompOp(idc)
+    v = rng.standard_normal(n + m)
+    w = rng.standard_normal(2 * n)
+    vh, vc = ctx.vector(n, v[:n]), ctx.vector(m, v[n:])
+    dest = L.StackedVector(ctx, n)
+    op.mul_n(dest, vh, vc)
+    np.testing.assert_allclose(dest.download2(), bigA @ v, atol=1e-13 * max(1, m))
+    dest.upload2(np.ones(2 * n))
+    op.mul_n(dest, vh, vc, 2.0, 3.0)
+    np.testing.assert_allclose(dest.download2(), 2 * bigA @ v + 3, atol=1e-13 * max(1, m))
+    dh, dc = ctx.vector(n), ctx.vector(m)
+    op.mul_t(dh, dc, L.StackedVector(ctx, n).upload2(w))
+    np.testing.assert_allclose(np.concatenate([dh.download(), dc.download()]), bigA.T @ w, atol=1e-12 * np.sqrt(n))
+    # calculate_lambda_kkt!: [lamy; lam] == bigA \ d
+    d = rng.standard_normal(2 * n)
+    P = L.InequalityDecompProject(idc)
+    qw, qt = ctx.vector(n), ctx.vector(m)
+    P.mul_t(qw, qt, L.StackedVector(ctx, n).upload2(d))
+    lam, lamy = np.zeros(m), ctx.vector(n)
+    L.calculate_lambda_kkt_(lam, lamy, qw, qt, idc)
+    ref, *_ = np.linalg.lstsq(bigA, d, rcond=None)
+    np.testing.assert_allclose(np.concatenate([lamy.download(), lam]), ref, atol=1e-11)
+    # augmented Hessian diagonal vs the oracle's operator applied to unit-free data
+    hxh = 2.0 + rng.random(n)
+    a = L.StackedVector(ctx, n)
+    L.augmented_hess_diag_(a, ctx.vector(n, hxh), lamy, idata)
+    src = rng.standard_normal(2 * n)
+    dest0 = np.zeros(2 * n)
+    R.augmented_hess_lag_vec_(dest0, src, lambda de, sr, xx, ll: de.__setitem__(slice(None), hxh * sr), xaug, lam, lamy.download(), idata0)
+    np.testing.assert_allclose(a.download2() * src, dest0, rtol=1e-13, atol=1e-13)
