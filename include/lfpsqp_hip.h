@@ -82,6 +82,8 @@ int lfpsqp_vec_upload(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t offset, const doub
 int lfpsqp_vec_download(lfpsqp_ctx* ctx, const lfpsqp_vec* v, int64_t offset, double* host, int64_t count);
 int lfpsqp_vec_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, double value);
 int lfpsqp_vec_copy(lfpsqp_ctx* ctx, lfpsqp_vec* dst, const lfpsqp_vec* src); /* dst .= src */
+/* dst[dst_off : dst_off+count) = src[src_off : src_off+count)   (views such as view(x, 1:n)) */
+int lfpsqp_vec_copy_range(lfpsqp_ctx* ctx, lfpsqp_vec* dst, int64_t dst_off, const lfpsqp_vec* src, int64_t src_off, int64_t count);
 int lfpsqp_mat_alloc(lfpsqp_ctx* ctx, int64_t n, int64_t m, lfpsqp_mat** out); /* zero-filled */
 int lfpsqp_mat_free(lfpsqp_ctx* ctx, lfpsqp_mat* M);
 int lfpsqp_mat_shape(const lfpsqp_mat* M, int64_t* n, int64_t* m);

@@ -61,6 +61,7 @@ _SIGS = {
     "lfpsqp_vec_download": [P, P, c_i64, P, c_i64],
     "lfpsqp_vec_fill": [P, P, c_dbl],
     "lfpsqp_vec_copy": [P, P, P],
+    "lfpsqp_vec_copy_range": [P, P, c_i64, P, c_i64, c_i64],
     "lfpsqp_mat_alloc": [P, c_i64, c_i64, C.POINTER(P)],
     "lfpsqp_mat_free": [P, P],
     "lfpsqp_mat_shape": [P, C.POINTER(c_i64), C.POINTER(c_i64)],

@@ -175,6 +175,13 @@ int lfpsqp_vec_copy(lfpsqp_ctx* ctx, lfpsqp_vec* dst, const lfpsqp_vec* src) {
     return 0;
 }
 
+int lfpsqp_vec_copy_range(lfpsqp_ctx* ctx, lfpsqp_vec* dst, int64_t dst_off, const lfpsqp_vec* src, int64_t src_off, int64_t count) {
+    LF_ARG(ctx, ctx && dst && src && count >= 0 && dst_off >= 0 && src_off >= 0 && dst_off + count <= dst->n && src_off + count <= src->n);
+    if (count == 0) return 0;
+    LF_HIP(ctx, hipMemcpyAsync(dst->p + dst_off, src->p + src_off, sizeof(double) * count, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
 int lfpsqp_vec_hash_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, uint64_t seed, int64_t offset, double scale, double shift) {
     LF_ARG(ctx, ctx && v);
     if (v->n == 0) return 0;

@@ -148,6 +148,10 @@ class DeviceVector:
         self.ctx.check(self.ctx.L.lfpsqp_vec_copy(self.ctx.h, self.h, src.h))
         return self
 
+    def copy_range_from(self, src: "DeviceVector", count: int, dst_off: int = 0, src_off: int = 0):
+        self.ctx.check(self.ctx.L.lfpsqp_vec_copy_range(self.ctx.h, self.h, dst_off, src.h, src_off, count))
+        return self
+
     def hash_fill(self, seed: int, offset: int = 0, scale: float = 1.0, shift: float = 0.0):
         self.ctx.check(self.ctx.L.lfpsqp_vec_hash_fill(self.ctx.h, self.h, seed, offset, scale, shift))
         return self

@@ -101,12 +101,37 @@ def y_retract_(xnewaug: StackedVector, xaug: StackedVector, idata: InequalityDat
     return xnewaug
 
 
+class QCoeff:
+    """A coefficient vector [w; t] of Q (length N + rank in the reference) as two device vectors."""
+
+    def __init__(self, ctx: Context, N: int, m: int):
+        self.w, self.t = DeviceVector(ctx, N), DeviceVector(ctx, max(m, 1))
+
+    def fill(self, value: float):
+        self.w.fill(value)
+        self.t.fill(value)
+        return self
+
+
 class InequalityDecompProject:
     """Q = [[diag Dx; diag Dy], U[:, :rank]] (src/inequality_helper.jl:25-27, 161-212).
     Coefficient vectors [w; t] are kept as two device vectors: w (N) and t (rank)."""
 
     def __init__(self, idecomp: InequalityDecomp):
         self.idecomp = idecomp
+
+    # -- the mul! protocol of the generic projcg path (coefficients are QCoeff objects)
+    def new_coeff(self) -> "QCoeff":
+        return QCoeff(self.idecomp.ctx, self.idecomp.N, self.idecomp.M)
+
+    def mul_(self, dest, coeff: "QCoeff", a=None, b=None):
+        if a is None:
+            a, b = 1.0, 0.0
+        self.mul_n(dest, coeff.w, coeff.t, a, b)
+        return dest
+
+    def adjoint(self):
+        return _QAdjoint(self)
 
     @property
     def ncols(self):
@@ -126,6 +151,19 @@ class InequalityDecompProject:
         c = y.ctx
         b = self._c()
         c.check(c.L.lfpsqp_q_gemv_n(c.h, C.byref(b), float(alpha), w.h if w is not None else None, t.h, float(beta), y.h))
+
+
+class _QAdjoint:
+    def __init__(self, q):
+        self.q = q
+
+    def mul_(self, coeff: "QCoeff", v, a=None, b=None):
+        assert a is None
+        self.q.mul_t(coeff.w, coeff.t, v)
+        return coeff
+
+    def adjoint(self):
+        return self.q
 
 
 class InequalityDecompOp:

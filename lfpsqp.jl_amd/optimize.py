@@ -69,6 +69,44 @@ class _GenericHessian:
         return self
 
 
+class _GenericAugHessian:
+    """LinearMap((dest, src) -> augmented_hess_lag_vec!(dest, src, hess_lag_vec!, x, lam, lamy, idata))
+    (src/optimize.jl:228, src/inequality_helper.jl:144-158) for a general Hessian callable with bounds:
+    dest_x = H src_x + 2 lamy.*q.*src_x ; dest_y = 2 lamy.*s.*src_y.  Fallback path (extra vector passes)."""
+
+    def __init__(self, fn, x, lam_dev, lamy, idata, n):
+        self.fn, self.x, self.lam, self.lamy, self.idata, self.n = fn, x, lam_dev, lamy, idata, n
+        ctx = x.ctx
+        self.zero_hx = DeviceVector(ctx, n)
+        self.diag = StackedVector(ctx, n)
+        self.src_x, self.x_x, self.h_x = DeviceVector(ctx, n), DeviceVector(ctx, n), DeviceVector(ctx, n)
+        self.hfull = StackedVector(ctx, n)
+        self.tmp = StackedVector(ctx, n)
+
+    def _apply(self, dest, v):
+        from .device import vmul
+        from .inequality import augmented_hess_diag_
+        n = self.n
+        augmented_hess_diag_(self.diag, self.zero_hx, self.lamy, self.idata)       # [2 lamy q ; 2 lamy s]
+        self.src_x.copy_range_from(v, n)
+        self.x_x.copy_range_from(self.x, n)
+        self.fn(self.h_x, self.src_x, self.x_x, self.lam)                          # H src_x
+        self.hfull.copy_range_from(self.h_x, n)                                    # [H src_x ; 0]
+        vmul(self.diag, v, dest)
+        axpby(1.0, self.hfull, 1.0, dest)
+
+    def mul_(self, dest, v, a=None, b=None):
+        if a is None:
+            self._apply(dest, v)
+        else:
+            self._apply(self.tmp, v)
+            waxpby(a, self.tmp, b, dest, dest)
+        return dest
+
+    def adjoint(self):
+        return self
+
+
 def _amax_host(v):
     return float(np.max(np.abs(v), initial=0.0))
 
@@ -129,9 +167,9 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     if diagonal_hessian:
         a_diag = newvec()
         newton_map = DiagOperator(0.0, a_diag)
+    elif ineq:
+        newton_map = _GenericAugHessian(hess_lag_vec_, x, lam_dev, lamy_kkt, ineqdata, n)
     else:
-        if ineq:
-            raise NotImplementedError("generic (non-diagonal) Hessian callables with bounds: supply diag_ (DESIGN.md §8)")
         newton_map = _GenericHessian(hess_lag_vec_, x, lam_dev)
 
     nr = NR(None, Sig, Vt, param.eps_c, param.maxiter_retract, NRWork(m), ineq, ineqdata)

@@ -123,8 +123,59 @@ def optimize(*args, derivatives: Optional[Derivatives] = None, ctx: Optional[Con
     if k == 6:
         f, c_, x0, xl, xu, m = args
         return _host_core(ctx, f, dv.grad_, c_, dv.jac_c_ if m > 0 else None, dv.hess_lag_vec_, x0, xl, xu, m, param, trace)
-    raise NotImplementedError(f"optimize with {k} positional arguments (general d! inequalities with host callables) is not on the "
-                              "device path yet; use QuadLinearBallBox or the explicit-derivative form")
+    if k == 8:      # (f, c!, d!, x0, xl, xu, m, p)   d <= 0                         src/optimize.jl:83
+        f, c_, d_, x0, xl, xu, m, p = args
+        return _host_slack(ctx, f, c_, d_, -np.inf * np.ones(p), np.zeros(p), x0, xl, xu, m, p, param, dv, trace)
+    if k == 10:     # (f, c!, d!, dl, du, x0, xl, xu, m, p)                          src/optimize.jl:13
+        f, c_, d_, dl, du, x0, xl, xu, m, p = args
+        return _host_slack(ctx, f, c_, d_, dl, du, x0, xl, xu, m, p, param, dv, trace)
+    raise TypeError(f"no optimize method with {k} positional arguments")
+
+
+def _host_slack(ctx, f, c_, d_, dl, du, x0, xl, xu, m, p, param, dv, trace):
+    """src/optimize.jl:13-71: slack variables turn dl <= d(x) <= du into equalities d(x) - s = 0 with bounds on
+    s; n -> n+p, m -> m+p; the result is truncated to the user's n (:68)."""
+    if d_ is None or p == 0:
+        return optimize(f, c_, x0, xl, xu, m, param, derivatives=dv, ctx=ctx, trace=trace)
+    if not (len(dl) == len(du) == p):
+        raise ValueError("Bound vectors dl and du must be of size p")
+    x0 = np.asarray(x0, dtype=np.float64)
+    n = len(x0)
+    xl = -np.inf * np.ones(n) if xl is None else np.asarray(xl, dtype=np.float64)
+    xu = np.inf * np.ones(n) if xu is None else np.asarray(xu, dtype=np.float64)
+    x0_aux = np.empty(n + p)
+    x0_aux[:n] = x0
+    d_(x0_aux[n:], x0)
+    xl_aux, xu_aux = np.concatenate([xl, dl]), np.concatenate([xu, du])
+
+    def f_aux(x):
+        return f(x[:n])
+
+    def c_aux_(cval, x):
+        if m > 0:
+            c_(cval[:m], x[:n])
+        d_(cval[m:m + p], x[:n])
+        cval[m:m + p] -= x[n:n + p]
+        return cval
+
+    def grad_aux_(g, x):
+        dv.grad_(g[:n], x[:n])
+        g[n:] = 0.0
+
+    def jac_aux_(J, cval, x):
+        J[:, :] = 0.0
+        if m > 0:
+            dv.jac_c_(J[:m, :n], cval[:m], x[:n])
+        dv.jac_d_(J[m:m + p, :n], cval[m:m + p], x[:n])
+        cval[m:m + p] -= x[n:n + p]
+        J[m:m + p, n:n + p] = -np.eye(p)
+
+    def hlv_aux_(dest, src, x, lam):
+        dv.hess_lag_vec_(dest[:n], src[:n], x[:n], lam)
+        dest[n:] = 0.0
+
+    x, obj, lam, ti = _host_core(ctx, f_aux, grad_aux_, c_aux_, jac_aux_, hlv_aux_, x0_aux, xl_aux, xu_aux, m + p, param, trace)
+    return x[:n], obj, lam, ti
 
 
 def _host_core(ctx, f, grad_, c_, jac_, hlv_, x0, xl, xu, m, param, trace):

@@ -132,9 +132,13 @@ def _projcg_generic(x, lam, A, U, b, c, tol, maxit, work, n_global, m):
     ctx = x.ctx
     n = b.n
     if work._extra is None:
-        work._extra = (DeviceVector(ctx, n), DeviceVector(ctx, n))
+        mk = (lambda: g0.__class__(ctx, g0.N)) if hasattr(work.g, "N") else (lambda: DeviceVector(ctx, n))
+        g0 = work.g
+        work._extra = (mk(), mk())
     Ad, r = work._extra
-    g, d, rp, Utr = work.g, work.d, work.rp, work.Utr
+    g, d, rp = work.g, work.d, work.rp
+    # coefficient vectors are opaque to the loop: a device m-vector, or a [w; t] pair for the bound operator Q
+    Utr = U.new_coeff() if hasattr(U, "new_coeff") else work.Utr
     Ut = U.adjoint()
     if c is not None:
         U.mul_(x, c)

@@ -25,12 +25,10 @@ class ProjPenaltyWork:  # src/retractions.jl:21-33 (J itself is the shared devic
         self.r, self.p, self.z, self.dx, self.g = mk(), mk(), mk(), mk(), mk()
         self.tmp_m = DeviceVector(ctx, max(m, 1))
         self.cval_dev = DeviceVector(ctx, max(m, 1))
+        self.op = None                       # InequalityDecompOp, created on first use (bounds only)
         if ineq:
             self.tmp_w = DeviceVector(ctx, n)
             self.h = DeviceVector(ctx, n)
-            self.DxS, self.DyS = DeviceVector(ctx, n), DeviceVector(ctx, n)
-            self.ones = DeviceVector(ctx, n).fill(1.0)
-            self.zeros = DeviceVector(ctx, n)
 
 
 @dataclass
@@ -67,30 +65,27 @@ class _JacPlain:
 
 
 class _JacStacked:
-    """fulljac = idecomp' (InequalityDecompAdjoint): tmp = [S.*(Dx.*px + Dy.*py); Jct' px]."""
+    """fulljac = idecomp' (InequalityDecompAdjoint): tmp = [S.*(Dx.*px + Dy.*py); Jct' px] -- a thin adapter
+    over InequalityDecompOp that routes the coefficient vectors to the work struct."""
 
     def __init__(self, idecomp: InequalityDecomp, work: ProjPenaltyWork):
+        from .inequality import InequalityDecompOp
         self.idc, self.w = idecomp, work
+        if work.op is None:
+            work.op = InequalityDecompOp(idecomp)
+        self.op = work.op
 
     def _basis(self):
-        w = self.w
-        return _capi.Basis(self.idc.Jct.h, self.idc.Jct.m, w.DxS.h, w.DyS.h, w.ones.h, w.zeros.h)
+        return self.op._c()
 
     def refresh(self):
-        vmul(self.idc.Dx, self.idc.S, self.w.DxS)
-        vmul(self.idc.Dy, self.idc.S, self.w.DyS)
+        self.op.refresh()
 
     def apply(self, p):
-        c = p.ctx
-        b = self._basis()
-        c.check(c.L.lfpsqp_q_gemv_t(c.h, C.byref(b), p.h, self.w.tmp_w.h, self.w.tmp_m.h))
+        self.op.mul_t(self.w.tmp_w, self.w.tmp_m, p)
 
     def apply_t(self, z, a, b_, from_cval=False):
-        c = z.ctx
-        b = self._basis()
-        wv = self.w.h if from_cval else self.w.tmp_w
-        tv = self.w.cval_dev if from_cval else self.w.tmp_m
-        c.check(c.L.lfpsqp_q_gemv_n(c.h, C.byref(b), float(a), wv.h, tv.h, float(b_), z.h))
+        self.op.mul_n(z, self.w.h if from_cval else self.w.tmp_w, self.w.cval_dev if from_cval else self.w.tmp_m, a, b_)
 
 
 def no_precondition(z, r):  # :259-263

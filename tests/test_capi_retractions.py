@@ -288,3 +288,40 @@ def test_exact_linesearch_through_the_driver(dev_ctx):
         assert np.linalg.norm(a['x'] - b['x']) <= 1e-9 * np.linalg.norm(b['x'])
         assert a.get('alpha') == pytest.approx(b.get('alpha'), rel=1e-6) or a.get('alpha') is None
     np.testing.assert_allclose(obj, objr, rtol=1e-10)
+
+
+def test_optimize_surface_with_host_callables_inequalities_and_bounds(dev_ctx):
+    """The north-star surface optimize(f, c!, d!, x0, xl, xu, m, p) with arbitrary HOST callables:
+    slack transformation (src/optimize.jl:13-71), bounds, a general (non-diagonal) Hessian callable through
+    the generic projcg path with the bound operator Q, Newton retraction with a host c!."""
+    ctx = dev_ctx
+    emu = _is_emu(ctx)
+    n, m = (60, 3) if emu else (400, 6)
+    rng = np.random.default_rng(17)
+    P0 = synth.BallBoxProblem(n, m)
+    Bq = rng.standard_normal((n, 4)) * 0.3                       # f = ||x - 0.2||^2 + 0.5 ||B'x||^2 : non-diagonal Hessian
+    f = lambda x: float((x - 0.2) @ (x - 0.2) + 0.5 * np.sum((Bq.T @ x) ** 2))
+
+    def grad_(g, x):
+        g[:] = 2.0 * (x - 0.2) + Bq @ (Bq.T @ x)
+
+    dv0 = P0.derivatives()
+
+    def hlv_(dest, src, x, lam):
+        dest[:] = (2.0 + 2.0 * lam[m]) * src + Bq @ (Bq.T @ src)
+
+    x0 = 0.95 * synth.hash_vector(2, n) + 0.05 * 0.5
+    maxiter = 3 if emu else 6
+    dv = R.Derivatives(grad_=grad_, hess_lag_vec_=hlv_, jac_c_=dv0.jac_c_, jac_d_=dv0.jac_d_)
+    tr0, tr = [], []
+    xr, objr, lamr, tir = R.optimize(f, P0.c_, P0.d_, x0, P0.xl, P0.xu, m, 1,
+                                     R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=maxiter),
+                                     derivatives=dv, trace=tr0)
+    x, obj, lam, ti = L.optimize(f, P0.c_, P0.d_, x0, P0.xl, P0.xu, m, 1,
+                                 L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=maxiter),
+                                 derivatives=L.Derivatives(grad_=grad_, hess_lag_vec_=hlv_, jac_c_=dv0.jac_c_, jac_d_=dv0.jac_d_),
+                                 ctx=ctx, trace=tr)
+    assert ti.iter == tir.iter and ti.condition.name == tir.condition.name and len(x) == n
+    _compare_traces(tr, tr0, rtol=1e-9)
+    np.testing.assert_allclose(obj, objr, rtol=1e-10)
+    np.testing.assert_allclose(lam, lamr, rtol=1e-6, atol=1e-9)
