@@ -52,9 +52,9 @@ int lfpsqp_ctx_sync(lfpsqp_ctx* ctx); /* wait for the context's stream */
 const char* lfpsqp_last_error(const lfpsqp_ctx* ctx);
 /* name of the device the context runs on ("cpu-emulator" only in the test build) */
 int lfpsqp_device_name(const lfpsqp_ctx* ctx, char* buf, int64_t buflen);
-/* streaming-kernel variant: ks = 16-byte row pairs per lane (2 or 4; tile = 512*ks rows), nt != 0 =
- * non-temporal loads of the matrix stream.  Results are bit-identical across nt, and differ only in
- * summation order across ks.  Default (4, 1), the measured best on MI355X. */
+/* streaming-kernel variant: ks = 16-byte row pairs per lane (2 or 4; tile = 512*ks rows; 0 = auto: 4 for
+ * >= 4M local rows, else 2), nt != 0 = non-temporal loads of the matrix stream.  Results are bit-identical
+ * across nt, and differ only in summation order across ks.  Default (auto, 1), DESIGN.md §5. */
 int lfpsqp_ctx_set_tuning(lfpsqp_ctx* ctx, int ks, int nt);
 /* HIP-event timing on the context's stream: begin .. end -> milliseconds */
 int lfpsqp_timer_begin(lfpsqp_ctx* ctx);

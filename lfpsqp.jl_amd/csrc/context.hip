@@ -205,7 +205,7 @@ int lfpsqp_timer_end(lfpsqp_ctx* ctx, double* ms) {
 }
 
 int lfpsqp_ctx_set_tuning(lfpsqp_ctx* ctx, int ks, int nt) {
-    LF_ARG(ctx, ctx != nullptr && (ks == 2 || ks == 4));
+    LF_ARG(ctx, ctx != nullptr && (ks == 0 || ks == 2 || ks == 4));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tune_ks = ks;
     ctx->tune_nt = nt != 0;

@@ -69,8 +69,9 @@ struct lfpsqp_ctx {
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
 
     // streaming-kernel tuning (lfpsqp_ctx_set_tuning): row pairs per lane (2 or 4), non-temporal matrix loads
-    int tune_ks = 4;
+    int tune_ks = 0;   // 0 = auto: 4 for >= 4M local rows (measured best at n = 1e7), else 2 (better at the 8-GPU shard size 1.25e6)
     bool tune_nt = true;
+    int ks_for(int64_t n) const { return tune_ks ? tune_ks : (n >= 4000000 ? 4 : 2); }
 
     // optional per-kernel-family profiling with HIP events on `stream`
     bool profiling = false;
@@ -155,7 +156,7 @@ int launch_reduce(lfpsqp_ctx* ctx, int64_t nrows, int ncols, int part_ld, unsign
 // empty basis (reference: projcg! with an n x 0 U).
 template <class VP>
 int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp, double* t_out, int prof_slot = -1) {
-    const int ks = ctx->tune_ks;
+    const int ks = ctx->ks_for(n);
     const int64_t tiles = ntiles_of(n, ks);
     const int part_ld = (int)round_up(ncols > 0 ? ncols : 1, 32);
     if (tiles > 0) {
@@ -183,7 +184,7 @@ int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp
 template <class EP, int NRED, class POST>
 int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const double* t, EP ep, double* red_out, POST post,
                int prof_slot = -1) {
-    const int ks = ctx->tune_ks;
+    const int ks = ctx->ks_for(n);
     const int64_t tiles = ntiles_of(n, ks);
     if (tiles > 0) {
         LF_TRY(ensure_part(ctx, (size_t)tiles * kMaxRed));
@@ -221,7 +222,7 @@ int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const
 template <class EP, int NRED>
 int run_gemv_nt(lfpsqp_ctx* ctx, const lfpsqp_mat* M1, int n1, const double* t, const lfpsqp_mat* M2, int n2, int64_t n, EP ep,
                 double* out) {
-    const int ks = ctx->tune_ks;
+    const int ks = ctx->ks_for(n);
     const int64_t tiles = ntiles_of(n, ks);
     const int nout = n2 + NRED;
     const int part_ld = (int)round_up(nout > 0 ? nout : 1, 32);

@@ -50,7 +50,7 @@ class Context:
         self.check(self.L.lfpsqp_timer_end(self.h, C.byref(ms)))
         return ms.value
 
-    def set_tuning(self, ks: int = 4, nt: bool = True):
+    def set_tuning(self, ks: int = 0, nt: bool = True):
         self.check(self.L.lfpsqp_ctx_set_tuning(self.h, int(ks), 1 if nt else 0))
 
     def set_profiling(self, on: bool):

@@ -295,7 +295,7 @@ def test_tuning_variants_agree(dev_ctx):
             x, lam = ctx.vector(n), ctx.vector(m)
             it, nr = L.projcg_(x, lam, A, U, b, None, tol=1e-10)
             res[(ks, nt)] = (it, x.download(), lam.download())
-    ctx.set_tuning(4, True)
+    ctx.set_tuning(0, True)
     for ks in (2, 4):
         assert res[(ks, False)][0] == res[(ks, True)][0]
         np.testing.assert_array_equal(res[(ks, False)][1], res[(ks, True)][1])
