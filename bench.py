@@ -57,7 +57,7 @@ def main(argv=None, lib=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane only (the data path is the library's own RCCL communicator); with --comm torch the
         # callback needs an nccl group as well
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl" if args.comm == "torch" else "gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if args.comm == "host-gloo" else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
 
     import lfpsqp_jl_amd as L
 
@@ -65,17 +65,43 @@ def main(argv=None, lib=None):
         lib = L.load_library(args.lib)
     dev = local_rank if args.device is None else args.device
     ctx = L.Context(dev, lib)
+    comm_used = "none"
     if world > 1:
+        import torch
         if args.comm == "rccl":
-            box = [ctx.comm_unique_id() if rank == 0 else None]
+            # library-native RCCL communicator; the id travels over the gloo control plane.  If ANY rank fails
+            # to bring it up, all ranks agree (gloo) to fall back to the torch.distributed(nccl) callback.
+            ok = 1
+            try:
+                box = [ctx.comm_unique_id() if rank == 0 else None]
+            except L.LfpsqpError as e:
+                box, ok = [None], 0
+                print(f"[bench] rank {rank}: RCCL unique id failed: {e}", file=sys.stderr)
             dist.broadcast_object_list(box, src=0)
-            ctx.comm_init_rccl(rank, world, box[0])
+            if ok and box[0] is not None:
+                try:
+                    ctx.comm_init_rccl(rank, world, box[0])
+                except L.LfpsqpError as e:
+                    ok = 0
+                    print(f"[bench] rank {rank}: native RCCL init failed: {e}", file=sys.stderr)
+            else:
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 1:
+                comm_used = "rccl"
+            else:
+                from lfpsqp_jl_amd.distributed import torch_allreduce_callback
+                ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev))
+                comm_used = "torch-nccl-callback (fallback)"
         elif args.comm == "torch":
             from lfpsqp_jl_amd.distributed import torch_allreduce_callback
             ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev))
+            comm_used = "torch-nccl-callback"
         else:
             from lfpsqp_jl_amd.distributed import host_staged_allreduce_callback
             ctx.comm_init_callback(rank, world, host_staged_allreduce_callback(dev))
+            comm_used = "host-gloo (functional test)"
     r0, r1 = ctx.shard_range(n, rank, world)
     n_loc = r1 - r0
 
@@ -164,7 +190,7 @@ def main(argv=None, lib=None):
         "config": {"workload": f"sustained projcg, dense basis n={n}, m={m}, A=diag(5+4u), tol=1e-300 (BASELINE configs[2] shape)",
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
-                   "comm": args.comm if world > 1 else "none", "device": ctx.device_name},
+                   "comm": comm_used, "device": ctx.device_name},
         "roofline": {"bound": "hbm", "kernel": "gemv_t_kernel<PcgStepV> (K2: rp = g + alpha*A*d formed on the fly, fused with U'rp)",
                      "achieved": gbs(bytes_k2, k2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gbs(bytes_k2, k2) / HBM_PEAK_GBS, "traffic": None,
