@@ -17,10 +17,12 @@ enum { P_RHO = 16, P_BETA = 17, P_ALPHA = 18, P_PZ = 19, P_RR = 20, P_NRES = 21,
 enum { IP_STATUS = 4, IP_ITER = 5, IP_MAXIT = 6 };
 enum { PST_RUNNING = 0, PST_DONE = 1 };
 
+constexpr int kPRing = 8, kPRingOff = 16;   // per-iteration status ring (see HostMirror in projcg.hip)
 struct PcgHostMirror {
-    int64_t* hstat;  // [IP_STATUS], [IP_ITER]
+    int64_t* hstat;  // [IP_STATUS], [IP_ITER], [kPRingOff + (iter % kPRing)]
     __device__ __forceinline__ void publish(int64_t status, int64_t iter) const {
         __hip_atomic_store(hstat + IP_ITER, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hstat + kPRingOff + (iter % kPRing), status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(hstat + IP_STATUS, status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 };
@@ -195,6 +197,7 @@ extern "C" int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, l
     volatile int64_t* hstat = ctx->h_istat;
     hstat[IP_STATUS] = PST_RUNNING;
     hstat[IP_ITER] = 0;
+    for (int k = 0; k < kPRing; ++k) hstat[kPRingOff + k] = PST_RUNNING;
     const PStack sk = stacked ? PStack{hs, Jop->Dx->p, Jop->Dy->p, Jop->sx->p, Jop->sy->p, tmp_w->p} : PStack{0, nullptr, nullptr, nullptr, nullptr, nullptr};
 
     LF_TRY(lfpsqp_vec_fill(ctx, p, 0.0));                                                        // :204
@@ -209,9 +212,12 @@ extern "C" int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, l
         if (stacked) LF_TRY((run_gemv_n<P2ES, 1, PPost2>(ctx, Z, m, N, tmp_m->p, P2ES{p2, sk}, scal + P_PZ, PPost2{scal, istat}, 5)));
         else LF_TRY((run_gemv_n<P2E, 1, PPost2>(ctx, Z, m, N, tmp_m->p, p2, scal + P_PZ, PPost2{scal, istat}, 5)));
         LF_TRY((run_vec<P3F, 1, PPost3>(ctx, nv, P3F{x->p, r->p, p->p, z->p, scal, istat}, 0u, scal + P_RR, PPost3{scal, istat, hm}, 6)));
+        // rank-deterministic stop: the status of iteration it-2 (device iteration number it-1), after its event
         LF_HIP(ctx, hipEventRecord(ctx->ev_slot[it & 3], ctx->stream));
-        if (it >= 2) LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[(it - 2) & 3]));
-        if (hstat[IP_STATUS] != PST_RUNNING) done = true;
+        if (it >= 2) {
+            LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[(it - 2) & 3]));
+            if (hstat[kPRingOff + ((it - 1) % kPRing)] != PST_RUNNING) done = true;
+        }
         ++it;
     }
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));

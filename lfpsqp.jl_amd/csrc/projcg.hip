@@ -69,13 +69,20 @@ struct PcgDirF {
     }
 };
 // The post-ops also publish (status, iteration, nr) into a pinned HOST block with system-scope
-// stores, so the host follows the solve without any per-iteration device-to-host copy.
+// stores, so the host follows the solve without any per-iteration device-to-host copy.  Besides the
+// "latest" words there is a RING of per-iteration status words: the host decides whether to stop from
+// the entry of ONE fixed iteration (it - 2) after that iteration's event has completed, so the decision --
+// and with it the number of enqueued iterations and COLLECTIVE calls -- is identical on every rank no
+// matter how far each rank's GPU has run ahead (a "latest status" read would be rank-timing dependent
+// and could desynchronise the RCCL call sequence).
+constexpr int kRing = 8, kRingOff = 8;
 struct HostMirror {
-    int64_t* hstat;  // [0] status, [1] iterations started
+    int64_t* hstat;  // [0] status, [1] iterations started, [kRingOff + (iter % kRing)] status after iteration `iter`
     double* hnr;     // [0] nr
     __device__ __forceinline__ void publish(int64_t status, int64_t iter, double nr) const {
         __hip_atomic_store(hnr, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(hstat + 1, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hstat + kRingOff + (iter % kRing), status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(hstat, status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 };
@@ -352,6 +359,7 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     volatile int64_t* hstat = ctx->h_istat;
     hstat[0] = ST_RUNNING;
     hstat[1] = 0;
+    for (int k = 0; k < kRing; ++k) hstat[kRingOff + k] = ST_RUNNING;
     auto launch_residual = [&](double sgn, double* store, double* t_out) -> int {
         const ResidualV rv{x->p, b->p, store, Ad, sgn};
         if (stacked) return run_gemv_t(ctx, Z, m, N, ResidualVS{rv, sk, store ? nullptr : lambda->p}, t_out);
@@ -389,10 +397,13 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
                                               PcgPost1{scal, istat, hm}, 0)));
         LF_TRY(launch_k2());
         LF_TRY(launch_k3(0));
-        // throttle: stay at most two iterations ahead of the GPU, then look at the pinned status block
+        // throttle: stay at most two iterations ahead of the GPU; stop on the status of iteration it-2
+        // (device iteration number it-1), which is final once its event has completed -- see HostMirror
         LF_HIP(ctx, hipEventRecord(ctx->ev_slot[it & 3], ctx->stream));
-        if (it >= 2) LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[(it - 2) & 3]));
-        if (hstat[0] != ST_RUNNING) done = true;
+        if (it >= 2) {
+            LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[(it - 2) & 3]));
+            if (hstat[kRingOff + ((it - 1) % kRing)] != ST_RUNNING) done = true;
+        }
         ++it;
     }
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
