@@ -323,3 +323,27 @@ def test_factorize_ill_conditioned(dev_ctx):
     np.testing.assert_allclose(Zh.T @ Zh, np.eye(m), atol=1e-10)      # orthonormal after the second pass
     np.testing.assert_allclose((Zh * S) @ Vt, Jh, atol=1e-12)
     np.testing.assert_allclose(Zh @ (Zh.T @ np.ones(n)), Q1 @ (Q1.T @ np.ones(n)), atol=1e-6)
+
+
+@pytest.mark.parametrize("n,m", [(700, 300), (1500, 513)])
+def test_wide_matrices_cross_the_column_chunk(dev_ctx, n, m):
+    """m larger than the 256-column LDS chunk of the GEMV kernels and than one 128-column Gram panel
+    (BASELINE configs[4] has m = 512)."""
+    ctx = dev_ctx
+    if "emulator" in ctx.device_name and m > 400:
+        pytest.skip("kept small on the emulator")
+    rng = np.random.default_rng(4)
+    Mh = np.asfortranarray(rng.standard_normal((n, m)))
+    vh, th = rng.standard_normal(n), rng.standard_normal(m)
+    M, v, t, out, y = ctx.matrix(n, m, Mh), ctx.vector(n, vh), ctx.vector(m, th), ctx.vector(m), ctx.vector(n, vh)
+    L.gemv_t(M, v, out)
+    np.testing.assert_allclose(out.download(), Mh.T @ vh, atol=1e-11)
+    L.gemv_n(M, t, y, -1.0, 1.0)
+    np.testing.assert_allclose(y.download(), vh - Mh @ th, atol=1e-11)
+    np.testing.assert_allclose(L.gram(M), Mh.T @ Mh, atol=1e-10)
+    Z = ctx.matrix(n, m)
+    S, Vt, rank = L.ksvd_(M, Z)
+    Zh = Z.download()
+    assert rank == m
+    np.testing.assert_allclose(S, np.linalg.svd(Mh, compute_uv=False), rtol=1e-10)
+    np.testing.assert_allclose(Zh.T @ Zh, np.eye(m), atol=1e-12)
