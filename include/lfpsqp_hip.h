@@ -295,6 +295,29 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
 int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, lfpsqp_vec* x, lfpsqp_vec* r, lfpsqp_vec* p, lfpsqp_vec* z,
                lfpsqp_vec* tmp_w, lfpsqp_vec* tmp_m, double tol, int64_t maxiter, int* flag, int64_t* iters);
 
+/* A user jac!: refresh the DEVICE matrix Jct (rows(Jct) x m, the reference's Jct = Jc') and cval at x. */
+typedef int (*lfpsqp_jacfun)(void* user, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval);
+
+/* ProjPenaltyWork (src/retractions.jl:21-33): n-vectors r, p, z, dx, g (stacked when bounds exist), the
+ * m-vector tmp_m; with bounds additionally the N-vectors tmp_w, h, DxS, DyS, ones (filled with 1), zeros. */
+typedef struct lfpsqp_pp_work {
+    lfpsqp_vec *r, *p, *z, *dx, *g, *tmp_m;
+    lfpsqp_vec *tmp_w, *h, *DxS, *DyS, *ones, *zeros;
+} lfpsqp_pp_work;
+
+/* retract!(cval, xnew, c!, xtilde, x, method::ProjPenalty) (src/retractions.jl:265-441), the reference's
+ * DEFAULT retraction: Gauss-Newton on 1/2 |c(z)|^2 + mu/2 |z - xtilde|^2 with mu -> 0, inner lfpsqp_pcg,
+ * Armijo backtracking -- including the reference's quirks (stale cval in the backtracking test :417,
+ * flag 3 leaves only the inner loop :422-425, flag 1 iff iters == maxiter :435-437).
+ * Constraints: cons (device-resident) or the callbacks cfun + jacfun (both non-NULL).  With bounds
+ * (idata != NULL) Dx, Dy, S are the driver's decomposition vectors and are OVERWRITTEN at the trial points,
+ * exactly as the reference's shared `idecomp` is (src/optimize.jl:235, src/retractions.jl:344).
+ * Outputs: xnew, cval[m], *flag (0 ok, 1 maxiter, 2 pcg maxiter, 3 backtracking failed), *iters, *pcg_iters. */
+int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cfun cfun, lfpsqp_jacfun jacfun, void* user,
+                      lfpsqp_mat* Jct, int64_t m, const lfpsqp_ineq_data* idata, lfpsqp_vec* Dx, lfpsqp_vec* Dy, lfpsqp_vec* S,
+                      const lfpsqp_vec* xtilde, const lfpsqp_vec* x, lfpsqp_vec* xnew, double mu0, double tol, int64_t maxiter,
+                      int64_t maxiter_pcg, const lfpsqp_pp_work* work, double* cval, int* flag, int64_t* iters, int64_t* pcg_iters);
+
 /* per-kernel-family device time (ms) accumulated by the last lfpsqp_projcg call when
  * the context was created with profiling on (lfpsqp_ctx_set_profiling); used by
  * bench.py for the roofline object.  slots: 0 = K1 (direction update + d'Ad),

@@ -34,6 +34,11 @@ class Constraints(C.Structure):  # lfpsqp_constraints
 
 
 CFUN = C.CFUNCTYPE(C.c_int, P, P, PD)
+JACFUN = C.CFUNCTYPE(C.c_int, P, P, P, PD)
+
+
+class PPWork(C.Structure):  # lfpsqp_pp_work
+    _fields_ = [(k, P) for k in ("r", "p", "z", "dx", "g", "tmp_m", "tmp_w", "h", "DxS", "DyS", "ones", "zeros")]
 
 
 class ProjCGWorkC(C.Structure):  # lfpsqp_projcg_work
@@ -97,6 +102,8 @@ _SIGS = {
     "lfpsqp_retract_nr": [P, C.POINTER(Basis), P, P, c_i64, C.POINTER(Constraints), CFUN, P, C.POINTER(IneqData), P, P, P, c_dbl, c_i64,
                           PD, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_pcg": [P, c_dbl, C.POINTER(Basis), P, P, P, P, P, P, c_dbl, c_i64, C.POINTER(C.c_int), C.POINTER(c_i64)],
+    "lfpsqp_retract_pp": [P, C.POINTER(Constraints), CFUN, JACFUN, P, P, c_i64, C.POINTER(IneqData), P, P, P, P, P, P, c_dbl, c_dbl, c_i64,
+                          c_i64, C.POINTER(PPWork), PD, C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)],
     "lfpsqp_gram": [P, P, c_i64, P, P],
     "lfpsqp_rmul": [P, P, c_i64, P, c_i64, P],
     "lfpsqp_factorize": [P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],
@@ -115,7 +122,7 @@ def header_functions(header: str = HEADER):
     """Names of every function include/lfpsqp_hip.h declares."""
     text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(lfpsqp_[a-z0-9_]+)\s*\(", text)) - {"lfpsqp_allreduce_fn", "lfpsqp_cfun"})
+    return sorted(set(re.findall(r"\b(lfpsqp_[a-z0-9_]+)\s*\(", text)) - {"lfpsqp_allreduce_fn", "lfpsqp_cfun", "lfpsqp_jacfun"})
 
 
 class Library:

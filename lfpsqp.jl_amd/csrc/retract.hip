@@ -246,4 +246,126 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
     return 0;
 }
 
+
+int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cfun cfun, lfpsqp_jacfun jacfun, void* user,
+                      lfpsqp_mat* Jct, int64_t m64, const lfpsqp_ineq_data* idata, lfpsqp_vec* Dx, lfpsqp_vec* Dy, lfpsqp_vec* S,
+                      const lfpsqp_vec* xtilde, const lfpsqp_vec* x, lfpsqp_vec* xnew, double mu0, double tol, int64_t maxiter,
+                      int64_t maxiter_pcg, const lfpsqp_pp_work* w, double* cval, int* flag_out, int64_t* iters, int64_t* pcg_iters) {
+    LF_ARG(ctx, ctx && Jct && xtilde && x && xnew && w && cval && flag_out && iters && pcg_iters && m64 >= 1 && m64 <= Jct->m);
+    LF_ARG(ctx, (cfun && jacfun) || cons_ok(cons));
+    LF_ARG(ctx, w->r && w->p && w->z && w->dx && w->g && w->tmp_m && w->tmp_m->n >= m64);
+    const bool ineq = idata != nullptr;
+    const int m = (int)m64;
+    const int64_t N = Jct->n;
+    if (ineq) LF_ARG(ctx, Dx && Dy && S && w->tmp_w && w->h && w->DxS && w->DyS && w->ones && w->zeros && idata->n == N);
+    LF_TRY(ensure_mvec(ctx, (size_t)2 * m + 16));
+    lfpsqp_vec cdev;                       // replicated device copy of cval (rhs of J' c)
+    cdev.p = ctx->d_m + round_up(m + 8, 2);
+    cdev.n = m;
+    cdev.cap = m;
+    double* h_c = ctx->h_m + round_up(m + 8, 2);
+    // fulljac in lfpsqp_basis form (src/retractions.jl:324): plain Jct, or [[diag Dx.*S, Jct]; [diag Dy.*S, 0]]
+    lfpsqp_basis Jop;
+    Jop.Z = Jct;
+    Jop.ncols = m;
+    Jop.Dx = ineq ? w->DxS : nullptr;
+    Jop.Dy = ineq ? w->DyS : nullptr;
+    Jop.sx = ineq ? w->ones : nullptr;
+    Jop.sy = ineq ? w->zeros : nullptr;
+
+    auto eval_c = [&](double* out) -> int {
+        if (cfun) {
+            int rc = cfun(user, xnew, out);
+            if (rc != 0) return set_err(ctx, LFPSQP_ERR_ARG, "user c! callback returned %d", rc);
+            return 0;
+        }
+        return cons_eval(ctx, cons, xnew, out);
+    };
+    auto eval_jac = [&]() -> int {
+        if (jacfun) {
+            int rc = jacfun(user, xnew, Jct, cval);
+            if (rc != 0) return set_err(ctx, LFPSQP_ERR_ARG, "user jac! callback returned %d", rc);
+            return 0;
+        }
+        return lfpsqp_constraints_jac(ctx, cons, xnew, Jct, cval);
+    };
+    auto dist2_of_g = [&](double* out) -> int { return lfpsqp_dot(ctx, w->g, w->g, out); };
+    auto nanmax_h = [](double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); };
+
+    int flag = 0;
+    LF_TRY(lfpsqp_vec_copy(ctx, xnew, xtilde));                                   // :329
+    double mu = mu0;
+    int64_t i = 0, pcg_total = 0;
+    double hh = 0.0;
+    while (i < maxiter) {
+        LF_TRY(eval_jac());                                                       // :340 (+ transpose!, :347)
+        double curtol = 0.0;
+        for (int k = 0; k < m; ++k) curtol = nanmax_h(curtol, fabs(cval[k]));
+        if (ineq) {                                                               // :343-353
+            LF_TRY(lfpsqp_inequality_gradient(ctx, xnew, idata, Dx, Dy, S, nullptr, nullptr));
+            LF_TRY(lfpsqp_vmul(ctx, Dx, S, w->DxS));
+            LF_TRY(lfpsqp_vmul(ctx, Dy, S, w->DyS));
+            double hmax = 0.0;
+            LF_TRY(lfpsqp_calculate_h(ctx, w->h, xnew, idata, &hmax));
+            curtol = nanmax_h(curtol, hmax);
+            LF_TRY(lfpsqp_dot(ctx, w->h, w->h, &hh));
+        }
+        if (curtol < tol) break;                                                  // :359
+        LF_TRY(lfpsqp_waxpby(ctx, 1.0, xnew, -1.0, xtilde, w->g));                // :364
+        double cc = 0.0, gg = 0.0;
+        for (int k = 0; k < m; ++k) cc += cval[k] * cval[k];
+        LF_TRY(dist2_of_g(&gg));
+        const double prev_obj_val = (hh + cc) + mu * gg;                          // :366
+        for (int k = 0; k < m; ++k) h_c[k] = cval[k];
+        LF_HIP(ctx, hipMemcpyAsync(cdev.p, h_c, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+        LF_TRY(lfpsqp_q_gemv_n(ctx, &Jop, 1.0, ineq ? w->h : nullptr, &cdev, mu, w->g));   // :369  g = fulljac' cvalaug + mu g
+        LF_TRY(lfpsqp_vec_fill(ctx, w->dx, 0.0));
+        LF_TRY(lfpsqp_vec_copy(ctx, w->r, w->g));
+        int pcg_flag = 0;
+        int64_t pcg_i = 0;
+        LF_TRY(lfpsqp_pcg(ctx, mu, &Jop, w->dx, w->r, w->p, w->z, w->tmp_w, w->tmp_m, tol, maxiter_pcg, &pcg_flag, &pcg_i));   // :375
+        pcg_total += pcg_i;
+        if (pcg_flag > 0) { flag = 2; break; }                                    // :377-381
+        LF_TRY(lfpsqp_vec_copy(ctx, w->p, xnew));                                 // :384
+        double gdx = 0.0;
+        LF_TRY(lfpsqp_dot(ctx, w->g, w->dx, &gdx));
+        const double ar_dot = -gdx;                                               // :385
+        double alpha = 1.0;
+        LF_TRY(lfpsqp_axpby(ctx, -alpha, w->dx, 1.0, xnew));                      // :389
+        LF_TRY(lfpsqp_waxpby(ctx, 1.0, xnew, -1.0, xtilde, w->g));
+        double dist2 = 0.0;
+        LF_TRY(dist2_of_g(&dist2));
+        LF_TRY(eval_c(cval));                                                     // :392
+        if (ineq) {
+            LF_TRY(lfpsqp_calculate_h(ctx, w->h, xnew, idata, nullptr));
+            LF_TRY(lfpsqp_dot(ctx, w->h, w->h, &hh));
+        }
+        cc = 0.0;
+        for (int k = 0; k < m; ++k) cc += cval[k] * cval[k];                      // :399
+        int armijo_count = 0;
+        while ((hh + cc) + mu * dist2 > prev_obj_val + 1e-4 * alpha * ar_dot) {   // :403
+            alpha /= 2;
+            LF_TRY(lfpsqp_waxpby(ctx, 1.0, w->p, -alpha, w->dx, xnew));
+            LF_TRY(lfpsqp_waxpby(ctx, 1.0, xnew, -1.0, xtilde, w->g));
+            LF_TRY(dist2_of_g(&dist2));
+            // BUG-COMPAT :410-417: c! lands in cvalaug and is overwritten by the stale full-step cval; only h and
+            // dist2 change.  The discarded c! evaluation is skipped.
+            if (ineq) {
+                LF_TRY(lfpsqp_calculate_h(ctx, w->h, xnew, idata, nullptr));
+                LF_TRY(lfpsqp_dot(ctx, w->h, w->h, &hh));
+            }
+            if (++armijo_count == 100) { flag = 3; break; }                       // :422-425
+        }
+        ++i;
+        const double nrm = sqrt(hh + cc);
+        mu = (mu * 0.1 < nrm) ? mu * 0.1 : nrm;                                   // :431  min(0.1 mu, norm(cvalaug))
+    }
+    if (i == maxiter) flag = 1;                                                   // :435-437
+    *flag_out = flag;
+    *iters = i;
+    *pcg_iters = pcg_total;
+    return 0;
+}
+
 }  // extern "C"
+

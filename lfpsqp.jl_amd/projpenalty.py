@@ -25,10 +25,18 @@ class ProjPenaltyWork:  # src/retractions.jl:21-33 (J itself is the shared devic
         self.r, self.p, self.z, self.dx, self.g = mk(), mk(), mk(), mk(), mk()
         self.tmp_m = DeviceVector(ctx, max(m, 1))
         self.cval_dev = DeviceVector(ctx, max(m, 1))
-        self.op = None                       # InequalityDecompOp, created on first use (bounds only)
+        self.ineq = ineq
         if ineq:
             self.tmp_w = DeviceVector(ctx, n)
             self.h = DeviceVector(ctx, n)
+            self.DxS, self.DyS = DeviceVector(ctx, n), DeviceVector(ctx, n)
+            self.ones = DeviceVector(ctx, n).fill(1.0)
+            self.zeros = DeviceVector(ctx, n)
+
+    def _c(self):
+        g = lambda name: getattr(self, name).h if hasattr(self, name) else None
+        return _capi.PPWork(self.r.h, self.p.h, self.z.h, self.dx.h, self.g.h, self.tmp_m.h, g("tmp_w"), g("h"), g("DxS"), g("DyS"),
+                            g("ones"), g("zeros"))
 
 
 @dataclass
@@ -65,27 +73,31 @@ class _JacPlain:
 
 
 class _JacStacked:
-    """fulljac = idecomp' (InequalityDecompAdjoint): tmp = [S.*(Dx.*px + Dy.*py); Jct' px] -- a thin adapter
-    over InequalityDecompOp that routes the coefficient vectors to the work struct."""
+    """fulljac = idecomp' (InequalityDecompAdjoint): tmp = [S.*(Dx.*px + Dy.*py); Jct' px], in the
+    lfpsqp_basis form with row scalings (1, 0) on the work struct's vectors."""
 
     def __init__(self, idecomp: InequalityDecomp, work: ProjPenaltyWork):
-        from .inequality import InequalityDecompOp
         self.idc, self.w = idecomp, work
-        if work.op is None:
-            work.op = InequalityDecompOp(idecomp)
-        self.op = work.op
 
     def _basis(self):
-        return self.op._c()
+        w = self.w
+        return _capi.Basis(self.idc.Jct.h, self.idc.Jct.m, w.DxS.h, w.DyS.h, w.ones.h, w.zeros.h)
 
     def refresh(self):
-        self.op.refresh()
+        vmul(self.idc.Dx, self.idc.S, self.w.DxS)
+        vmul(self.idc.Dy, self.idc.S, self.w.DyS)
 
     def apply(self, p):
-        self.op.mul_t(self.w.tmp_w, self.w.tmp_m, p)
+        c = p.ctx
+        b = self._basis()
+        c.check(c.L.lfpsqp_q_gemv_t(c.h, C.byref(b), p.h, self.w.tmp_w.h, self.w.tmp_m.h))
 
     def apply_t(self, z, a, b_, from_cval=False):
-        self.op.mul_n(z, self.w.h if from_cval else self.w.tmp_w, self.w.cval_dev if from_cval else self.w.tmp_m, a, b_)
+        c = z.ctx
+        b = self._basis()
+        wv = self.w.h if from_cval else self.w.tmp_w
+        tv = self.w.cval_dev if from_cval else self.w.tmp_m
+        c.check(c.L.lfpsqp_q_gemv_n(c.h, C.byref(b), float(a), wv.h, tv.h, float(b_), z.h))
 
 
 def no_precondition(z, r):  # :259-263
@@ -151,7 +163,68 @@ def _call_c(c_, cval, xnew, n):
 
 
 def retract_pp(cval, xnew, c_, xtilde, x, method: ProjPenalty):
-    """retract!(cval, xnew, c!, xtilde, x, method::ProjPenalty) (src/retractions.jl:265-441)."""
+    """retract!(cval, xnew, c!, xtilde, x, method::ProjPenalty) (src/retractions.jl:265-441) -- ONE C call
+    (lfpsqp_retract_pp); c! / jac! are device-resident constraints or host callables behind trampolines."""
+    ctx = x.ctx
+    idecomp, idata = method.idecomp, method.idata
+    m = len(method.Sigma)
+    n = idecomp.N
+    flag, iters, pcg_iters = C.c_int(), _capi.c_i64(), _capi.c_i64()
+    wc = method.work._c()
+    idc = idata._c() if method.ineq else None
+    keep = []
+    from .retractions import DeviceConstraints
+    if isinstance(c_, DeviceConstraints):      # device-resident c!/jac! (the matching jac! is c_.jac_)
+        cons = c_._c()
+        keep.append(cons)
+        cons_p, cfun, jacfun = C.byref(cons), _capi.CFUN(), _capi.JACFUN()
+    else:
+        from .device import DeviceMatrix as DM
+
+        def borrow_vec(handle, length):
+            v = DeviceVector.__new__(DeviceVector)
+            v.ctx, v.n, v.h = ctx, length, C.c_void_p(handle)
+            return v
+
+        def c_tramp(user, xh, cval_ptr):
+            try:
+                v = borrow_vec(xh, x.n)
+                out = np.ctypeslib.as_array(cval_ptr, shape=(m,))
+                if hasattr(c_, "c_"):
+                    c_.c_(out, v)
+                else:
+                    c_(out, v.download(n, 0))
+                v.h = None
+                return 0
+            except Exception as e:   # never unwind through C
+                print("c! callback failed:", repr(e))
+                return 1
+
+        def j_tramp(user, xh, jh, cval_ptr):
+            try:
+                v = borrow_vec(xh, x.n)
+                out = np.ctypeslib.as_array(cval_ptr, shape=(m,))
+                method.jac_(idecomp.Jct, out, v)        # the library passes back the same Jct it was given
+                v.h = None
+                return 0
+            except Exception as e:
+                print("jac! callback failed:", repr(e))
+                return 1
+        cfun, jacfun = _capi.CFUN(c_tramp), _capi.JACFUN(j_tramp)
+        keep += [cfun, jacfun, c_tramp, j_tramp]
+        cons_p = None
+    ctx.check(ctx.L.lfpsqp_retract_pp(ctx.h, cons_p, cfun, jacfun, None, idecomp.Jct.h, m, C.byref(idc) if idc is not None else None,
+                                      idecomp.Dx.h if method.ineq else None, idecomp.Dy.h if method.ineq else None,
+                                      idecomp.S.h if method.ineq else None, xtilde.h, x.h, xnew.h, float(method.mu0), float(method.tol),
+                                      int(method.maxiter), int(method.maxiter_pcg), C.byref(wc), cval.ctypes.data_as(_capi.PD),
+                                      C.byref(flag), C.byref(iters), C.byref(pcg_iters)))
+    del keep
+    return flag.value, iters.value, pcg_iters.value
+
+
+def retract_pp_reference_loop(cval, xnew, c_, xtilde, x, method: ProjPenalty):
+    """The same retraction statement by statement in Python on the device primitives (kept as a readable
+    mirror of src/retractions.jl:265-441 and as a cross-check of the C implementation in the tests)."""
     w = method.work
     idecomp, idata = method.idecomp, method.idata
     Jct = idecomp.Jct

@@ -325,3 +325,36 @@ def test_optimize_surface_with_host_callables_inequalities_and_bounds(dev_ctx):
     _compare_traces(tr, tr0, rtol=1e-9)
     np.testing.assert_allclose(obj, objr, rtol=1e-10)
     np.testing.assert_allclose(lam, lamr, rtol=1e-6, atol=1e-9)
+
+
+def test_retract_pp_c_matches_python_mirror(dev_ctx):
+    """lfpsqp_retract_pp (C) against the statement-by-statement Python mirror of src/retractions.jl:265-441 on
+    the device primitives, with bounds (stacked operator) and the device-resident ball/linear constraints."""
+    from lfpsqp_jl_amd.projpenalty import retract_pp_reference_loop
+    ctx = dev_ctx
+    n, m = (1500, 5) if not _is_emu(ctx) else (150, 3)
+    P0 = synth.BallBoxProblem(n, m)
+    N, M = n + 1, m + 1
+    Jct = ctx.matrix(N, M).hash_fill(1, 0, n, 1.0, n, m)
+    P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
+    x0a, xl, xu = P.aux_start(0.9 * synth.hash_vector(2, n) + 0.05)
+    idata = L.InequalityData(ctx, xl, xu)
+    X = L.StackedVector(ctx, N)
+    X.upload(x0a, 0)
+    L.generate_initial_y_(X, idata)
+    xt = X.download2() + 0.01 * np.random.default_rng(3).standard_normal(2 * N)
+    res = []
+    for fn in (L.retract_, None):
+        idc = L.InequalityDecomp(ctx, N, M, Jct)
+        pp = L.ProjPenalty(P.jac_, None, np.ones(M), np.eye(M), M, 0.01, 1e-8, 100, 100, L.ProjPenaltyWork(ctx, M, N, True), True, idc, idata)
+        xtilde, xnew = L.StackedVector(ctx, N).upload2(xt), L.StackedVector(ctx, N)
+        cval = np.zeros(M)
+        if fn is None:
+            out = retract_pp_reference_loop(cval, xnew, P.cons, xtilde, X, pp)
+        else:
+            out = fn(cval, xnew, P.cons, xtilde, X, pp)
+        res.append((out, xnew.download2(), cval.copy()))
+    (o1, x1, c1), (o2, x2, c2) = res
+    assert o1[0] == o2[0] == 0 and o1[1] == o2[1] and abs(o1[2] - o2[2]) <= 2
+    np.testing.assert_allclose(x1, x2, rtol=1e-10, atol=1e-12)
+    assert np.max(np.abs(c1)) < 1e-8
