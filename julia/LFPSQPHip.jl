@@ -106,7 +106,6 @@ function dot(x::DeviceVector, y::DeviceVector)
 end
 function norm(x::DeviceVector, p::Real=2)
     r = Ref{Float64}(0.0)
-    f = p == Inf ? :lfpsqp_amax : :lfpsqp_nrm2
     if p == Inf
         check(x.ctx, ccall((:lfpsqp_amax, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), x.ctx.h, x.h, r))
     else
@@ -180,6 +179,47 @@ function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceV
     return Int(flag[]), Int(iters[]), 0      # (flag, iter1, iter2) as in the reference
 end
 
+# ---- ProjPenalty, the reference's DEFAULT retraction (src/retractions.jl:265-441) and its pcg! (:179-246) ------
+struct CPPWork
+    r::Ptr{Cvoid}; p::Ptr{Cvoid}; z::Ptr{Cvoid}; dx::Ptr{Cvoid}; g::Ptr{Cvoid}; tmp_m::Ptr{Cvoid}
+    tmp_w::Ptr{Cvoid}; h::Ptr{Cvoid}; DxS::Ptr{Cvoid}; DyS::Ptr{Cvoid}; ones::Ptr{Cvoid}; zeros::Ptr{Cvoid}
+end
+struct DevicePPWork            # ProjPenaltyWork(m, n, m_ineq, n_ineq) without bounds
+    r::DeviceVector; p::DeviceVector; z::DeviceVector; dx::DeviceVector; g::DeviceVector; tmp_m::DeviceVector
+end
+DevicePPWork(ctx::HipContext, n::Int, m::Int) =
+    DevicePPWork((DeviceVector(ctx, n) for _ in 1:5)..., DeviceVector(ctx, max(m, 1)))
+struct DevicePP                # ProjPenalty(jac!, U, Σ, Vt, rank, μ0, tol, maxiter, maxiter_pcg, work, ineq, idecomp, idata)
+    Jct::DeviceMatrix; m_lin::Int; b::Vector{Float64}; has_ball::Bool; R2::Float64; n_x::Int; slack_row::Int
+    μ0::Float64; tol::Float64; maxiter::Int; maxiter_pcg::Int; work::DevicePPWork
+end
+function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceVector, x::DeviceVector, pp::DevicePP)
+    flag = Ref{Cint}(0); iters = Ref{Int64}(0); pcg_iters = Ref{Int64}(0)
+    w = pp.work
+    wc = Ref(CPPWork(w.r.h, w.p.h, w.z.h, w.dx.h, w.g.h, w.tmp_m.h, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
+    GC.@preserve pp begin
+        cons = Ref(CConstraints(pp.Jct.h, pp.m_lin, pointer(pp.b), pp.has_ball ? 1 : 0, pp.R2, pp.n_x, pp.slack_row))
+        check(x.ctx, ccall((:lfpsqp_retract_pp, lib), Cint,
+                           (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid},
+                            Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int64, Int64,
+                            Ref{CPPWork}, Ptr{Float64}, Ref{Cint}, Ref{Int64}, Ref{Int64}),
+                           x.ctx.h, cons, C_NULL, C_NULL, C_NULL, pp.Jct.h, length(cval), C_NULL, C_NULL, C_NULL, C_NULL,
+                           xtilde.h, x.h, xnew.h, pp.μ0, pp.tol, pp.maxiter, pp.maxiter_pcg, wc, cval, flag, iters, pcg_iters))
+    end
+    return Int(flag[]), Int(iters[]), Int(pcg_iters[])      # (flag, iter1, iter2) as in the reference
+end
+# pcg!(μ, J, no_precondition, x, r, p, z, tmp_m, tol, maxiter) with J' = Jct given as a DeviceBasis
+function pcg!(μ::Float64, Jt::DeviceBasis, x::DeviceVector, r::DeviceVector, p::DeviceVector, z::DeviceVector,
+              tmp_m::DeviceVector, tol::Float64, maxiter::Int)
+    flag = Ref{Cint}(0); iters = Ref{Int64}(0)
+    u = Ref(CBasis(Jt.Z.h, Jt.ncols, C_NULL, C_NULL, C_NULL, C_NULL))
+    check(x.ctx, ccall((:lfpsqp_pcg, lib), Cint,
+                       (Ptr{Cvoid}, Float64, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                        Float64, Int64, Ref{Cint}, Ref{Int64}),
+                       x.ctx.h, μ, u, x.h, r.h, p.h, z.h, C_NULL, tmp_m.h, tol, maxiter, flag, iters))
+    return Int(flag[]), Int(iters[])
+end
+
 # ---- multi-GPU: one Julia process per GPU (e.g. under MPI.jl); rank 0 creates the id and broadcasts it --
 function comm_unique_id(ctx::HipContext)
     id = Vector{UInt8}(undef, 128)
@@ -189,7 +229,7 @@ end
 comm_init!(ctx::HipContext, rank::Integer, nranks::Integer, id::Vector{UInt8}) =
     check(ctx, ccall((:lfpsqp_comm_init_rccl, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx.h, rank, nranks, id))
 
-export HipContext, DeviceVector, DeviceMatrix, DeviceBasis, DiagOperator, ProjCGWork, DeviceNR,
-       upload!, download, projcg!, retract!, ksvd!, comm_unique_id, comm_init!
+export HipContext, DeviceVector, DeviceMatrix, DeviceBasis, DiagOperator, ProjCGWork, DeviceNR, DevicePP, DevicePPWork,
+       upload!, download, projcg!, retract!, pcg!, ksvd!, comm_unique_id, comm_init!
 
 end # module
