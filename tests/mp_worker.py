@@ -33,6 +33,16 @@ def main():
     x, lam = ctx.vector(nl), ctx.vector(m)
     it, nr = L.projcg_(x, lam, A, L.DeviceBasis(Z), b, None, tol=1e-10, maxit=500, n_global=n)
     res.update(r0=r0, r1=r1, S=S, x=x.download(), lam=lam.download(), it=it, nr=nr, Z=Z.download(), Vt=Vt)
+    # ---- a rank with ZERO rows (n smaller than one shard granule): collectives must still line up ----------
+    ne, me = 1500, 4
+    e0, e1 = ctx.shard_range(ne)
+    Je = ctx.matrix(e1 - e0, me).hash_fill(1, e0, ne)
+    Ze = ctx.matrix(e1 - e0, me)
+    Se, Vte, rke = L.ksvd_(Je, Ze)
+    xe, lame = ctx.vector(e1 - e0), ctx.vector(me)
+    ite, nre = L.projcg_(xe, lame, L.DiagOperator(0.0, ctx.vector(e1 - e0).hash_fill(3, e0, 4.0, 5.0)), L.DeviceBasis(Ze),
+                         ctx.vector(e1 - e0).hash_fill(4, e0), None, tol=1e-10, maxit=300, n_global=ne)
+    res.update(e0=e0, e1=e1, e_x=xe.download(), e_it=ite, e_S=Se, e_lam=lame.download())
     # ---- sharded config 3 through the outer driver (NR and ProjPenalty) ----------------------
     n3, m3 = 4000, 5
     q0, q1 = ctx.shard_range(n3)

@@ -90,3 +90,19 @@ def test_sharded_config4_slack_on_last_rank(two_ranks):
     assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
     np.testing.assert_allclose(a["c4_obj"], objr, rtol=1e-11)
     np.testing.assert_allclose(a["c4_lam"], lamr, rtol=1e-7, atol=1e-10)
+
+
+def test_rank_with_zero_rows(two_ranks):
+    """n = 1500 < 2048 (the shard granule): rank 1 owns no rows, yet every collective must still be entered."""
+    a, b = two_ranks
+    n, m = 1500, 4
+    assert (int(a["e0"]), int(a["e1"]), int(b["e0"]), int(b["e1"])) == (0, 1500, 1500, 1500)
+    Jh = synth.hash_matrix(1, n, m)
+    np.testing.assert_allclose(a["e_S"], np.linalg.svd(Jh, compute_uv=False), rtol=1e-12)
+    U, _ = np.linalg.qr(Jh)
+    av, bv = 4.0 * synth.hash_vector(3, n) + 5.0, synth.hash_vector(4, n)
+    x0, l0 = np.zeros(n), np.zeros(m)
+    i0, _ = R.projcg_(x0, l0, DiagOpRef(av), np.asfortranarray(U), bv, np.zeros(m), tol=1e-10, maxit=300)
+    assert int(a["e_it"]) == int(b["e_it"]) == i0 and len(b["e_x"]) == 0
+    assert np.linalg.norm(a["e_x"] - x0) <= 1e-10 * np.linalg.norm(x0)
+    np.testing.assert_array_equal(a["e_lam"], b["e_lam"])
