@@ -54,9 +54,10 @@ __global__ __launch_bounds__(kThreads) void gram_kernel(const double* __restrict
     // staging role: column c = tid / 2 of the panel, rows kh..kh+8 of the step
     const int c = tid >> 1, kh = (tid & 1) * 8;
     const int64_t colA = (int64_t)pi * kPanel + c, colB = (int64_t)pj * kPanel + c;
-    for (int64_t step = blockIdx.x; step < nsteps; step += gridDim.x) {
+    // software pipeline: the global loads of step s+1 are issued before the MFMAs of step s
+    double va[8], vb[8];
+    auto load_step = [&](int64_t step) {
         const int64_t r0 = step * kKStep + kh;
-        double va[8], vb[8];
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
             const int64_t r = r0 + q;
@@ -71,6 +72,10 @@ __global__ __launch_bounds__(kThreads) void gram_kernel(const double* __restrict
             va[q] = a.x; va[q + 1] = a.y;
             vb[q] = b.x; vb[q + 1] = b.y;
         }
+    };
+    int64_t step = blockIdx.x;
+    if (step < nsteps) load_step(step);
+    for (; step < nsteps; step += gridDim.x) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(kThreads) void gram_kernel(const double* __restrict
             if (needB) Bs[kh + q][c] = vb[q];
         }
         __syncthreads();
+        if (step + gridDim.x < nsteps) load_step(step + gridDim.x);
         tile_mfma(As, needB ? Bs : As, acc, wave, lane);
     }
     double* out = part + (int64_t)blockIdx.x * part_ld + (int64_t)blockIdx.y * (kPanel * kPanel);
@@ -112,8 +118,8 @@ __global__ __launch_bounds__(kThreads) void rmul_kernel(const double* __restrict
     // staging roles: In: k = tid / 16, rows (tid % 16)*8..+8 ; W: column tid / 2, k half (tid & 1)*8
     const int kb = tid / 16, rb = (tid % 16) * 8;
     const int ca = tid >> 1, ka = (tid & 1) * 8;
-    for (int k0 = 0; k0 < kcols; k0 += kKStep) {
-        double va[8], vb[8];
+    double va[8], vb[8];
+    auto load_step = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
             double2 b = make_double2(0.0, 0.0);
@@ -125,6 +131,9 @@ __global__ __launch_bounds__(kThreads) void rmul_kernel(const double* __restrict
             const int k = k0 + ka + q;
             va[q] = (k < kcols && c0 + ca < rcols) ? W[(int64_t)(c0 + ca) * ldw + k] : 0.0;
         }
+    };
+    if (kcols > 0) load_step(0);
+    for (int k0 = 0; k0 < kcols; k0 += kKStep) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -132,6 +141,7 @@ __global__ __launch_bounds__(kThreads) void rmul_kernel(const double* __restrict
             Bs[kb][rb + q] = vb[q];
         }
         __syncthreads();
+        if (k0 + kKStep < kcols) load_step(k0 + kKStep);   // next step's loads fly under this step's MFMAs
         tile_mfma(As, Bs, acc, wave, lane);
     }
 #pragma unroll
