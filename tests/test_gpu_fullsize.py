@@ -75,3 +75,27 @@ def test_full_size_projcg_invariants(big):
     assert it2 == it
     L.axpby(1.0, x, -1.0, x2)
     assert L.nrm2(x2) <= 1e-10 * L.nrm2(x)
+
+
+@pytest.mark.gpu
+def test_projcg_against_the_c_oracle_port_at_2e6():
+    """The largest size the C/OpenMP oracle port (oracle/projcg_port.c) finishes in seconds on the box's host
+    cores: n = 2e6, m = 64 -- iterates within 1e-10 relative, equal iteration count, lambda to 1e-9."""
+    from oracle import port
+    n, m = 2_000_000, 64
+    ctx = L.Context(0)
+    Z = ctx.matrix(n, m).hash_fill(1)
+    L.orthonormalize_(Z)
+    Uh = Z.download()                                   # the SAME orthonormal basis for both sides
+    a = port.hash_vector(3, n, 0, 4.0, 5.0)
+    b = port.hash_vector(4, n)
+    port.lib().port_set_num_threads(port.usable_cpus())
+    x0, l0, it0, nr0 = port.projcg(a, np.asfortranarray(Uh), b, None, 1e-9, 500)
+    x, lam = ctx.vector(n), ctx.vector(m)
+    it, nr = L.projcg_(x, lam, L.DiagOperator(0.0, ctx.vector(n).hash_fill(3, 0, 4.0, 5.0)), L.DeviceBasis(Z),
+                       ctx.vector(n).hash_fill(4), None, tol=1e-9, maxit=500)
+    assert it == it0 and nr == pytest.approx(nr0, rel=1e-5)
+    xd = x.download()
+    assert np.linalg.norm(xd - x0) <= 1e-10 * np.linalg.norm(x0)
+    np.testing.assert_allclose(lam.download(), l0, atol=1e-9)
+    ctx.close()
