@@ -12,9 +12,8 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _capi
-from .device import Context, DeviceMatrix, DeviceVector
-from .inequality import InequalityData, InequalityDecompProject, y_retract_
-from .projcg import DeviceBasis
+from .device import DeviceMatrix, DeviceVector
+from .inequality import InequalityData, y_retract_
 
 
 class DeviceConstraints:
