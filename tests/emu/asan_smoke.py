@@ -1,0 +1,23 @@
+"""Sanitizer smoke of the C-ABI sources on the CPU emulator (see tests/emu/Makefile target `asan`): odd sizes\n(padding / tails), factorize, projcg, NR and ProjPenalty with bounds.  Test infrastructure only."""
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import lfpsqp_jl_amd as L
+from oracle import synth
+lib=L.load_library('tests/emu/_build_asan/liblfpsqp_emu.so')
+ctx=L.Context(0,lib)
+# odd sizes to stress padding / tails
+for n,m in ((1,1),(1023,3),(2049,5),(4097,130)):
+    Mh=synth.hash_matrix(1,n,m); J=ctx.matrix(n,m,Mh); Z=ctx.matrix(n,m)
+    S,Vt,r=L.ksvd_(J,Z)
+    x,lam=ctx.vector(n),ctx.vector(m)
+    it,nr=L.projcg_(x,lam,L.DiagOperator(0.0,ctx.vector(n).hash_fill(3,0,4.0,5.0)),L.DeviceBasis(Z),ctx.vector(n).hash_fill(4),None,tol=1e-10,maxit=50)
+    print(n,m,r,it,nr)
+# bounds path
+n,m=301,4
+P0=synth.BallBoxProblem(n,m)
+Jct=ctx.matrix(n+1,m+1).hash_fill(1,0,n,1.0,n,m)
+P=L.QuadLinearBallBox(ctx,n,m,Jct,P0.eq.b,R2=P0.R2,xl=P0.xl,xu=P0.xu)
+for dpr in (False,True):
+    out=P.optimize(0.97*synth.hash_vector(2,n)+0.015,L.LFPSQPParams(do_project_retract=dpr,disp=L.DisplayOption.off,maxiter=2))
+    print('opt',dpr,out[3].iter)
+print("ASAN RUN DONE")
