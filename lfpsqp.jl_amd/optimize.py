@@ -157,6 +157,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     term_cond = TerminationCondition.f_tol
     projcgwork = ProjCGWork(ctx, n, m, n if ineq else None)
     prev_grad_norm = 0.0
+    noise = None
 
     idecomp = InequalityDecomp(ctx, n, m, Jct)
     Z = idecomp.Z
@@ -197,8 +198,16 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     while True:
         grad_(g, x)                                                        # :259
         waxpby(-1.0, g, 0.0, g, d)                                         # :262
-        if param.beta > 0:
-            raise NotImplementedError("random-noise steps (param.beta > 0, src/optimize.jl:264-273) are not on the device path")
+        if param.beta > 0:                                                 # :264-273 (randn! noise; Julia's RNG stream cannot be matched)
+            if noise is None:
+                noise = newvec()
+            z = np.random.standard_normal(2 * n if ineq else n)
+            if ineq:
+                noise.upload2(z)
+            else:
+                noise.upload(z)
+            scale = param.beta * max(1 - i / param.t_beta, 0.0) if param.t_beta > 0 else param.beta
+            axpby(scale, noise, 1.0, d)
         if ineq:
             inequality_gradient_(idecomp, x, ineqdata)                     # :277
         rank = m

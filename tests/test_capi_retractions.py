@@ -358,3 +358,16 @@ def test_retract_pp_c_matches_python_mirror(dev_ctx):
     assert o1[0] == o2[0] == 0 and o1[1] == o2[1] and abs(o1[2] - o2[2]) <= 2
     np.testing.assert_allclose(x1, x2, rtol=1e-10, atol=1e-12)
     assert np.max(np.abs(c1)) < 1e-8
+
+
+def test_noise_option_runs_and_stays_feasible(dev_ctx):
+    """param.beta > 0 (src/optimize.jl:264-273): random perturbation of the steepest-descent step; the RNG stream
+    of the reference cannot be matched, so only the invariants are checked (feasible iterates, descent)."""
+    ctx = dev_ctx
+    n, m = (3000, 5) if not _is_emu(ctx) else (1200, 3)
+    prob0, x0 = synth.config3(n, m)
+    P = L.QuadLinearBallBox(ctx, n, m, ctx.matrix(n, m).hash_fill(1), prob0.b)
+    np.random.seed(0)
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, beta=1e-3, t_beta=5, maxiter=4))
+    assert np.abs(prob0.Jct.T @ x - prob0.b).max() < 1e-5          # iterates are feasible
+    assert obj[-1] < obj[0]
