@@ -34,6 +34,7 @@ def main(argv=None, lib=None):
     ap.add_argument("--cols", dest="m", type=int, default=128, help="m (default 128)")
     ap.add_argument("--basis", choices=["orthonormal", "scaled-hash"], default="orthonormal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the tangent-setup / Newton-retraction timings (not part of `value`)")
     ap.add_argument("--cpu-sample-n", type=float, default=2e6)
     ap.add_argument("--comm", choices=["rccl", "torch", "host-gloo"], default="rccl",
                     help="all-reduce transport for N > 1: rccl (library-native, default), torch (torch.distributed nccl callback), "
@@ -218,6 +219,8 @@ def main(argv=None, lib=None):
     except (OSError, ValueError, KeyError):
         pass
 
+    if not args.no_extras:
+        out["extras"] = extras(ctx, L, n, m, n_loc, r0, Z, gbs)
     out["check"] = {"x_norm": L.nrm2(x), "nr": nr, "iters": iters}    # global ||x|| after the K timed iterations (sanity / N-rank agreement)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_n), m, n)
@@ -227,6 +230,37 @@ def main(argv=None, lib=None):
     if dist is not None:
         dist.destroy_process_group()
     return out
+
+
+def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
+    """Timings of the other hot-path rows at the bench size: the tangent setup
+    (lfpsqp_factorize: MFMA Gram + rmul + host m x m algebra) and one fused Newton-retraction step."""
+    import numpy as np
+    J = ctx.matrix(n_loc, m).hash_fill(1, r0, n)
+    Z2 = ctx.matrix(n_loc, m)
+    L.ksvd_(J, Z2)                                            # warm
+    ctx.sync(); t0 = time.perf_counter(); S, Vt, rank = L.ksvd_(J, Z2); ctx.sync(); fact_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); L.gram(J); gram_ms = (time.perf_counter() - t0) * 1e3
+    W = np.eye(m)
+    t0 = time.perf_counter(); L.rmul(J, W, Z2); ctx.sync(); rmul_ms = (time.perf_counter() - t0) * 1e3
+    L.ksvd_(J, Z2)
+    # Newton retraction on c(x) = J'x - b from a perturbed point: 24 iterations forced by tol = 0 (the initial c! pass is amortised)
+    xs = ctx.vector(n_loc).hash_fill(2, r0)
+    bdev = ctx.vector(m); L.gemv_t(J, xs, bdev)
+    cons = L.DeviceConstraints(J, m, bdev.download())
+    pert = ctx.vector(n_loc).hash_fill(7, r0, 1e-3, 0.0)
+    xt = ctx.vector(n_loc); L.waxpby(1.0, xs, 1.0, pert, xt)
+    nr = L.NR(L.DeviceBasis(Z2), S, Vt, 0.0, 24, L.NRWork(m), False, None)
+    xnew, cval = ctx.vector(n_loc), np.zeros(m)
+    L.retract_(cval, xnew, cons, xt, xs, nr)                  # warm
+    ctx.sync(); t0 = time.perf_counter(); flag, it, _ = L.retract_(cval, xnew, cons, xt, xs, nr); ctx.sync()
+    nr_ms = (time.perf_counter() - t0) * 1e3 / max(it, 1)
+    nr_bytes = 16.0 * n_loc * m + 24.0 * n_loc                # Z pass + Jct pass + xnew read/write + v
+    flop = 2.0 * n_loc * m * m
+    return {"factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs": flop / gram_ms / 1e9,
+            "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
+            "nr_step_ms": nr_ms, "nr_step_GBs": gbs(nr_bytes, nr_ms), "nr_iters_timed": int(it),
+            "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies"}
 
 
 def cpu_baseline(ns, m, n_full):

@@ -347,3 +347,30 @@ def test_wide_matrices_cross_the_column_chunk(dev_ctx, n, m):
     assert rank == m
     np.testing.assert_allclose(S, np.linalg.svd(Mh, compute_uv=False), rtol=1e-10)
     np.testing.assert_allclose(Zh.T @ Zh, np.eye(m), atol=1e-12)
+
+
+def test_argument_errors_are_status_codes_not_crashes(dev_ctx):
+    """Error conventions of the boundary: invalid arguments come back as negative status codes with a
+    message (raised as LfpsqpError by the host layer), never as crashes; numerical outcomes are never errors."""
+    ctx = dev_ctx
+    a, b = ctx.vector(10), ctx.vector(11)
+    with pytest.raises(L.LfpsqpError, match="invalid argument"):
+        L.dot(a, b)                                             # length mismatch
+    M = ctx.matrix(10, 3)
+    with pytest.raises(L.LfpsqpError):
+        L.gemv_t(M, b, ctx.vector(3))                           # v has the wrong length
+    with pytest.raises(L.LfpsqpError):
+        L.gemv_t(M, a, ctx.vector(3), ncols=4)                  # more columns than the matrix has
+    with pytest.raises(L.LfpsqpError):
+        a.upload(np.zeros(11))                                  # upload past the end
+    with pytest.raises(L.LfpsqpError):
+        L.ksvd_(M, M)                                           # factorize needs Z != Jct
+    with pytest.raises(ValueError, match="different lengths"):
+        L.InequalityData(ctx, np.zeros(3), np.zeros(4))         # src/inequality_helper.jl:42-44
+    # a NaN right-hand side is a numerical outcome, not an error: projcg returns, like the reference would
+    Uh = np.asfortranarray(np.linalg.qr(synth.hash_matrix(1, 600, 3))[0])
+    bh = synth.hash_vector(4, 600)
+    bh[5] = np.nan
+    x, lam = ctx.vector(600), ctx.vector(3)
+    it, nr = L.projcg_(x, lam, L.DiagOperator(2.0), L.DeviceBasis(ctx.matrix(600, 3, Uh)), ctx.vector(600, bh), None, tol=1e-8, maxit=5)
+    assert it == 5 and math.isnan(nr)
