@@ -220,6 +220,7 @@ template <class EP, int NRED, int kS, bool NT>
 __global__ __launch_bounds__(kThreads) void gemv_nt_kernel(const double* __restrict__ M1, int64_t ld1, int n1,
                                                             const double* __restrict__ t, const double* __restrict__ M2, int64_t ld2_,
                                                             int n2, int64_t n, EP ep, double* __restrict__ part, int part_ld) {
+    if (ep.skip()) return;
     __shared__ double ts[kColChunk];
     __shared__ double red[kWaves][kColChunk];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -14,6 +14,10 @@
 
 namespace lfpsqp {
 
+enum { I_NR_STATUS = 8, I_NR_ITER = 9, I_NR_FLAG = 10 };   // istat slots of the Newton retraction
+constexpr int kNRRing = 8, kNRRingOff = 24;                 // per-iteration host status ring (see projcg.hip HostMirror)
+constexpr int kNRMaxM = 1024;                               // m x m Broyden state handled by one workgroup
+
 struct BallF {  // partial of sum_{i<n_x} x_i^2 - x[slack_row]
     const double* x;
     int64_t n_x, slack_row;
@@ -87,6 +91,8 @@ struct NRStepE {
     const double *q, *r, *s, *t;     // InequalityData
     int64_t n_x, slack_row;          // ball term: sum_{i<n_x} x_i^2 - x[slack_row]  (slack_row < 0: none here)
     int has_ball;
+    const int64_t* istat;            // NR status word: a finished retraction turns further launches into no-ops
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_NR_STATUS) != 0; }
     __device__ __forceinline__ double ball(int64_t i, double xi) const {
         return !has_ball ? 0.0 : (i < n_x ? xi * xi : (i == slack_row ? -xi : 0.0));
     }
@@ -115,6 +121,102 @@ struct NRStepE {
         return make_double2(v0 ? xn.x : 0.0, v1 ? xn.y : 0.0);
     }
 };
+
+// The replicated m x m part of the Newton retraction on the device (src/retractions.jl:126-160): turns the raw
+// constraint products of the fused step into c(xnew), applies the good-Broyden update of the inverse Jacobian
+// D, tests ||c||_inf < tol / the iteration limit, and prepares delta = -D c for the next step.  One workgroup;
+// thread k owns row k of D (column-major, coalesced over k).
+struct NRSmall {
+    double* D;            // m x m
+    const double* Vt;     // m x m
+    const double* Sigma;  // m
+    const double* b;      // m_lin
+    double* cval;         // m (current constraint values)
+    double* delta;        // m (step coefficients, read by the fused step kernel)
+    const double* raw;    // m: [J'x (m_lin) ; ball partial]
+    int64_t* istat;
+    int64_t* hstat;       // pinned host block
+    int m, m_lin, has_ball;
+    double R2, tol;
+    int64_t maxiter;
+};
+__global__ __launch_bounds__(256) void nr_small_kernel(NRSmall s, int init) {
+    if (!init && ld_stat(s.istat + I_NR_STATUS) != 0) return;
+    __shared__ double cnew[kNRMaxM], del[kNRMaxM], t2[kNRMaxM], dcs[kNRMaxM], tv[kNRMaxM];
+    __shared__ double red[256];
+    const int m = s.m, tid = threadIdx.x;
+    for (int k = tid; k < m; k += 256) cnew[k] = s.raw[k] - (k < s.m_lin ? s.b[k] : s.R2);
+    __syncthreads();
+    int64_t iter = init ? 0 : ld_stat(s.istat + I_NR_ITER);
+    if (init) {
+        for (int k = tid; k < m; k += 256) {
+            s.cval[k] = cnew[k];
+            const double sg = s.Sigma[k];
+            for (int j = 0; j < m; ++j) s.D[(size_t)j * m + k] = s.Vt[(size_t)j * m + k] / sg;      // :126-130
+        }
+    } else {
+        for (int k = tid; k < m; k += 256) {
+            dcs[k] = cnew[k] - s.cval[k];                                                       // :152
+            s.cval[k] = cnew[k];                                                                // :153
+            del[k] = s.delta[k];
+        }
+        __syncthreads();
+        for (int j = tid; j < m; j += 256) {                                                    // :156  t2 = D' delta
+            double a = 0.0;
+            for (int k = 0; k < m; ++k) a += s.D[(size_t)j * m + k] * del[k];
+            t2[j] = a;
+        }
+        for (int k = tid; k < m; k += 256) {                                                    // :157  tv = delta - D dc
+            double a = 0.0;
+            for (int j = 0; j < m; ++j) a += s.D[(size_t)j * m + k] * dcs[j];
+            tv[k] = del[k] - a;
+        }
+        __syncthreads();
+        double part = 0.0;
+        for (int k = tid; k < m; k += 256) part += t2[k] * dcs[k];
+        red[tid] = part;
+        __syncthreads();
+        if (tid == 0) {
+            double den = 0.0;
+            for (int k = 0; k < 256; ++k) den += red[k];
+            red[0] = 1.0 / den;                                                                 // :159
+        }
+        __syncthreads();
+        const double alpha = red[0];
+        __syncthreads();
+        for (int k = tid; k < m; k += 256) {                                                    // :160  D += alpha tv t2'
+            const double a = alpha * tv[k];
+            for (int j = 0; j < m; ++j) s.D[(size_t)j * m + k] += a * t2[j];
+        }
+        iter += 1;                                                                              // :168
+    }
+    __syncthreads();
+    double mx = 0.0;
+    for (int k = tid; k < m; k += 256) mx = nanmax(mx, fabs(cnew[k]));
+    red[tid] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        double c = 0.0;
+        for (int k = 0; k < 256; ++k) c = nanmax(c, red[k]);
+        int64_t st = 0;
+        if (iter >= s.maxiter) { st = 1; s.istat[I_NR_FLAG] = 1; }      // :133 loop bound first: flag = (i == maxiter), :171-174
+        else if (c < s.tol) { st = 1; s.istat[I_NR_FLAG] = 0; }         // :135
+        s.istat[I_NR_ITER] = iter;
+        s.istat[I_NR_STATUS] = st;
+        __hip_atomic_store(s.hstat + I_NR_ITER, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(s.hstat + I_NR_FLAG, st ? s.istat[I_NR_FLAG] : (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(s.hstat + kNRRingOff + ((iter + 1) % kNRRing), st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(s.hstat + I_NR_STATUS, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        red[0] = (double)st;
+    }
+    __syncthreads();
+    if (red[0] != 0.0) return;
+    for (int k = tid; k < m; k += 256) {                                                        // :140  delta = -D cval
+        double a = 0.0;
+        for (int j = 0; j < m; ++j) a += s.D[(size_t)j * m + k] * cnew[j];
+        s.delta[k] = -a;
+    }
+}
 
 int cons_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval) {
     const lfpsqp_mat* J = cons->Jct;
@@ -169,6 +271,61 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
     LF_ARG(ctx, ineq == (U->Dx != nullptr));
     LF_TRY(ensure_mvec(ctx, (size_t)2 * m + 8));
 
+    if (!cfun && m <= kNRMaxM) {
+        // ---- device-resident loop: no host round trip per iteration ------------------------------------------
+        const int ml = (int)cons->m_lin;
+        const int64_t N = cons->Jct->n;
+        const size_t mm = (size_t)m * m;
+        LF_TRY(ensure_small(ctx, 2 * mm + 8 * (size_t)m + 256));
+        double* dD = ctx->small;
+        double* dVt = dD + mm;
+        double* dSig = dVt + mm;
+        double* db = dSig + m;
+        double* dcval = db + m;
+        double* ddelta = dcval + m;
+        double* draw = ddelta + m + (m & 1);          // keep the reduce output 16-byte aligned
+        LF_HIP(ctx, hipMemcpyAsync(dVt, Vt, sizeof(double) * mm, hipMemcpyHostToDevice, ctx->stream));
+        LF_HIP(ctx, hipMemcpyAsync(dSig, Sigma, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+        if (ml > 0) LF_HIP(ctx, hipMemcpyAsync(db, cons->b, sizeof(double) * ml, hipMemcpyHostToDevice, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // caller-owned pageable sources
+        volatile int64_t* hstat = ctx->h_istat;
+        for (int k = 0; k < kNRRing; ++k) hstat[kNRRingOff + k] = 0;
+        hstat[I_NR_STATUS] = 0;
+        const NRSmall sm{dD, dVt, dSig, db, dcval, ddelta, draw, ctx->istat, ctx->h_istat, m, ml, cons->has_ball ? 1 : 0,
+                         cons->R2, tol, maxiter};
+        LF_TRY(lfpsqp_vec_copy(ctx, xnew, xtilde));                                             // :116
+        if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew, x, idata));                                // :118-120
+        if (ml > 0) LF_TRY(run_gemv_t(ctx, cons->Jct, ml, N, PlainVec{xnew->p}, draw));         // c!(cval, xnew), raw products
+        if (cons->has_ball)
+            LF_TRY((run_vec<BallF, 1, NoPost>(ctx, N, BallF{xnew->p, cons->n_x, cons->slack_row}, 0u, draw + ml, NoPost())));
+        hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(256), 0, ctx->stream, sm, 1);
+        LF_LAUNCH_CHECK(ctx);
+        LF_HIP(ctx, hipEventRecord(ctx->ev_slot[0], ctx->stream));
+        const NRStepE ep{xnew->p, x->p, ineq ? lfpsqp_half_stride(N) : 0, ineq ? U->sx->p : nullptr, ineq ? U->sy->p : nullptr,
+                         ineq ? idata->q->p : nullptr, ineq ? idata->r->p : nullptr, ineq ? idata->s->p : nullptr,
+                         ineq ? idata->t->p : nullptr, cons->n_x, cons->slack_row, cons->has_ball ? 1 : 0, ctx->istat};
+        int64_t it = 0;
+        bool done = false;
+        while (!done && it < maxiter) {
+            // step `it`: xnew += U delta, y_retract!, raw c! products (one launch) ; Broyden + test + next delta (one workgroup)
+            if (cons->has_ball) LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
+            else LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
+            hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(256), 0, ctx->stream, sm, 0);
+            LF_LAUNCH_CHECK(ctx);
+            LF_HIP(ctx, hipEventRecord(ctx->ev_slot[(it + 1) & 3], ctx->stream));
+            // rank-deterministic stop: status after `it` completed steps (published by the previous kernel generation)
+            LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[it & 3]));
+            if (hstat[kNRRingOff + ((it + 1) % kNRRing)] != 0) done = true;
+            ++it;
+        }
+        LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, dcval, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < m; ++k) cval[k] = ctx->h_m[k];
+        *flag = (int)hstat[I_NR_FLAG];
+        *iters = hstat[I_NR_ITER];
+        return 0;
+    }
+
     auto eval_c = [&](double* out) -> int {
         if (cfun) {
             int rc = cfun(cuser, xnew, out);
@@ -212,7 +369,9 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
             const int64_t N = cons->Jct->n;
             NRStepE ep{xnew->p, x->p, ineq ? lfpsqp_half_stride(N) : 0, ineq ? U->sx->p : nullptr, ineq ? U->sy->p : nullptr,
                        ineq ? idata->q->p : nullptr, ineq ? idata->r->p : nullptr, ineq ? idata->s->p : nullptr,
-                       ineq ? idata->t->p : nullptr, cons->n_x, cons->slack_row, cons->has_ball ? 1 : 0};
+                       ineq ? idata->t->p : nullptr, cons->n_x, cons->slack_row, cons->has_ball ? 1 : 0, ctx->istat};
+            ctx->h_istat[I_NR_STATUS] = 0;
+            LF_HIP(ctx, hipMemsetAsync(ctx->istat + I_NR_STATUS, 0, sizeof(int64_t), ctx->stream));
             LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, U->Z, m, tv.p, cons->Jct, ml, N, ep, ctx->d_m)));
             LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * (ml + 1), hipMemcpyDeviceToHost, ctx->stream));
             LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
