@@ -238,29 +238,64 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     import numpy as np
     J = ctx.matrix(n_loc, m).hash_fill(1, r0, n)
     Z2 = ctx.matrix(n_loc, m)
-    L.ksvd_(J, Z2)                                            # warm
-    ctx.sync(); t0 = time.perf_counter(); S, Vt, rank = L.ksvd_(J, Z2); ctx.sync(); fact_ms = (time.perf_counter() - t0) * 1e3
+    Wg = np.zeros((m, m), order='F')
+    L.ksvd_(J, Z2, W=Wg)                                      # warm
+    ctx.sync(); t0 = time.perf_counter(); S, Vt, rank = L.ksvd_(J, Z2, W=Wg); ctx.sync(); fact_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter(); L.gram(J); gram_ms = (time.perf_counter() - t0) * 1e3
     W = np.eye(m)
     t0 = time.perf_counter(); L.rmul(J, W, Z2); ctx.sync(); rmul_ms = (time.perf_counter() - t0) * 1e3
-    L.ksvd_(J, Z2)
-    # Newton retraction on c(x) = J'x - b from a perturbed point: 24 iterations forced by tol = 0 (the initial c! pass is amortised)
+    L.ksvd_(J, Z2, W=Wg)
+    # Newton retraction on c(x) = J'x - b from a perturbed point: 24 iterations forced by tol = 0 (the initial c! pass is
+    # amortised).  "one stream": the basis carries its generator (Z = J*W), both products of a step run over J alone;
+    # "two streams": generator unknown, the step reads Z and J.
     xs = ctx.vector(n_loc).hash_fill(2, r0)
     bdev = ctx.vector(m); L.gemv_t(J, xs, bdev)
     cons = L.DeviceConstraints(J, m, bdev.download())
     pert = ctx.vector(n_loc).hash_fill(7, r0, 1e-3, 0.0)
     xt = ctx.vector(n_loc); L.waxpby(1.0, xs, 1.0, pert, xt)
-    nr = L.NR(L.DeviceBasis(Z2), S, Vt, 0.0, 24, L.NRWork(m), False, None)
     xnew, cval = ctx.vector(n_loc), np.zeros(m)
-    L.retract_(cval, xnew, cons, xt, xs, nr)                  # warm
-    ctx.sync(); t0 = time.perf_counter(); flag, it, _ = L.retract_(cval, xnew, cons, xt, xs, nr); ctx.sync()
-    nr_ms = (time.perf_counter() - t0) * 1e3 / max(it, 1)
-    nr_bytes = 16.0 * n_loc * m + 24.0 * n_loc                # Z pass + Jct pass + xnew read/write + v
+    nr_ms = {}
+    for label, basis in (("one_stream", L.DeviceBasis(Z2, generator=(J, Wg))), ("two_streams", L.DeviceBasis(Z2))):
+        nr = L.NR(basis, S, Vt, 0.0, 24, L.NRWork(m), False, None)
+        L.retract_(cval, xnew, cons, xt, xs, nr)                  # warm
+        ctx.sync(); t0 = time.perf_counter(); flag, it, _ = L.retract_(cval, xnew, cons, xt, xs, nr); ctx.sync()
+        nr_ms[label] = (time.perf_counter() - t0) * 1e3 / max(it, 1)
+    nr1_bytes = 8.0 * n_loc * m + 24.0 * n_loc                # J pass + xnew read/write + v
+    nr2_bytes = 16.0 * n_loc * m + 24.0 * n_loc               # Z pass + J pass + xnew read/write + v
     flop = 2.0 * n_loc * m * m
-    return {"factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs": flop / gram_ms / 1e9,
+    ceil = stream_ceilings(ctx, L)
+    return {"stream_ceilings": ceil, "factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs": flop / gram_ms / 1e9,
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
-            "nr_step_ms": nr_ms, "nr_step_GBs": gbs(nr_bytes, nr_ms), "nr_iters_timed": int(it),
+            "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
+            "nr_step_two_streams_ms": nr_ms["two_streams"], "nr_step_two_streams_GBs": gbs(nr2_bytes, nr_ms["two_streams"]),
+            "nr_iters_timed": int(it),
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies"}
+
+
+def stream_ceilings(ctx, L, nbig=400_000_000):
+    """What this box's HBM delivers to the library's own plain streaming kernels on 3.2 GB vectors (far beyond
+    the 256 MB infinity cache): read-only (nrm2, includes one host sync per call), copy (1 read + 1 write),
+    triad (waxpby: 2 reads + 1 write).  Context for the roofline fractions, which are quoted against 8 TB/s."""
+    a = ctx.vector(nbig).hash_fill(11)
+    b = ctx.vector(nbig).hash_fill(12)
+    c = ctx.vector(nbig)
+    reps = 5
+    L.nrm2(a); c.copy_from(a); L.waxpby(1.0, a, 2.0, b, c)
+    ctx.timer_begin()
+    for _ in range(reps):
+        L.nrm2(a)
+    ms_r = ctx.timer_end() / reps
+    ctx.timer_begin()
+    for _ in range(reps):
+        c.copy_from(a)
+    ms_c = ctx.timer_end() / reps
+    ctx.timer_begin()
+    for _ in range(reps):
+        L.waxpby(1.0, a, 2.0, b, c)
+    ms_t = ctx.timer_end() / reps
+    g = lambda nb, ms: nb * 8.0 * nbig / (ms * 1e-3) / 1e9
+    del a, b, c
+    return {"read_GBs": g(1, ms_r), "copy_GBs": g(2, ms_c), "triad_GBs": g(3, ms_t), "vector_GB": 8.0 * nbig / 1e9}
 
 
 def cpu_baseline(ns, m, n_full):

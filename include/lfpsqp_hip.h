@@ -182,9 +182,12 @@ int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const doub
  *   src/optimize.jl:297-302; a Gram-based method cannot resolve below ~1e-8 * Sigma_1).
  * With w2 == NULL, Z is the U of ksvd! up to the sign/rotation freedom of the SVD, to which
  * every use in the reference is invariant.  With bounds, w2 = Dy.^2 and the reference's
- * 2N x M factor of PJct (src/optimize.jl:288-291) is [Dy.^2 .* Z ; -Dx.*Dy .* Z]. */
+ * 2N x M factor of PJct (src/optimize.jl:288-291) is [Dy.^2 .* Z ; -Dx.*Dy .* Z].
+ * W (optional, host, m x m column-major): the small factor the basis was formed with, Z = Jct * W
+ * exactly as computed (columns >= rank are zero).  Handing it back through lfpsqp_basis.A / .W lets
+ * the Newton retraction run both of its products over Jct alone (one matrix stream instead of two). */
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
-                     int64_t* rank, double eps_rank);
+                     double* W, int64_t* rank, double eps_rank);
 
 /* ---- projected CG (src/projcg.jl:40-121) --------------------------------- */
 /* The symmetric operator A of the QP ("B*p", the Lagrangian Hessian action that the
@@ -210,6 +213,10 @@ typedef struct lfpsqp_basis {
     const lfpsqp_vec* Dy;
     const lfpsqp_vec* sx;
     const lfpsqp_vec* sy;
+    /* optional generator of the basis: Z[:, 0:ncols] == A * W with W host, (A->m) x ncols column-major
+     * (lfpsqp_factorize's W).  NULL/NULL when unknown; only an optimisation hint, never required. */
+    const lfpsqp_mat* A;
+    const double* W;
 } lfpsqp_basis;
 
 /* mul!(dest, Q', v) (src/inequality_helper.jl:197-212): w[0:N) = Dx.*vx + Dy.*vy,
@@ -277,6 +284,10 @@ typedef int (*lfpsqp_cfun)(void* user, const lfpsqp_vec* x, double* cval);
  * U / Sigma / Vt are the factors of lfpsqp_factorize (NR.U, NR.Sigma, NR.Vt); idata != NULL means
  * bounds are present (NR.ineq): vectors are stacked and y_retract! runs before every c!.
  * Exactly one of cons / cfun is used (cfun wins if non-NULL).
+ * Per Newton step the device-resident path streams U (x += U*delta) and Jct (c!) in one launch; when U carries
+ * its generator (U->A == cons->Jct, U->W from lfpsqp_factorize) the step is x += [sx;sy] .* (Jct*(W*delta)) and
+ * Jct is streamed ONCE per step, each row tile held in registers between the two products (same iterates up
+ * to rounding: Z*delta vs Jct*(W*delta)).
  * Outputs: xnew, cval[m] (== c!(xnew) on exit), *flag (0 ok, 1 = maxiter reached), *iters. */
 int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m,
                       const lfpsqp_constraints* cons, lfpsqp_cfun cfun, void* cuser, const lfpsqp_ineq_data* idata,

@@ -117,11 +117,14 @@ axpby!(a::Number, x::DeviceVector, b::Number, y::DeviceVector) =
     (check(y.ctx, ccall((:lfpsqp_axpby, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}), y.ctx.h, a, x.h, b, y.h)); y)
 
 # ---- tangent setup: replaces ksvd! (src/la_helper.jl:8-34), call sites src/optimize.jl:291/293 -----
-function ksvd!(Jct::DeviceMatrix, Z::DeviceMatrix, Σ::Vector{Float64}, Vt::Matrix{Float64}; w2=nothing, ϵ_rank::Float64=1e-10)
+# W (optional m×m): the small factor with Z == Jct*W; a DeviceBasis that carries (Jct, W) lets the Newton retraction
+# stream Jct once per step instead of Z and Jct.
+function ksvd!(Jct::DeviceMatrix, Z::DeviceMatrix, Σ::Vector{Float64}, Vt::Matrix{Float64}; w2=nothing, ϵ_rank::Float64=1e-10,
+               W::Union{Nothing,Matrix{Float64}}=nothing)
     rank = Ref{Int64}(0)
     check(Jct.ctx, ccall((:lfpsqp_factorize, lib), Cint,
-                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64),
-                         Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, Z.h, Σ, Vt, rank, ϵ_rank))
+                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64),
+                         Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, Z.h, Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
     return Int(rank[])
 end
 
@@ -133,7 +136,8 @@ end
 DiagOperator(a0::Real) = DiagOperator(Float64(a0), nothing)
 
 struct CDiagOp;  a0::Float64; dg::Ptr{Cvoid}; end
-struct CBasis;   Z::Ptr{Cvoid}; ncols::Int64; Dx::Ptr{Cvoid}; Dy::Ptr{Cvoid}; sx::Ptr{Cvoid}; sy::Ptr{Cvoid}; end
+struct CBasis;   Z::Ptr{Cvoid}; ncols::Int64; Dx::Ptr{Cvoid}; Dy::Ptr{Cvoid}; sx::Ptr{Cvoid}; sy::Ptr{Cvoid}; A::Ptr{Cvoid}; W::Ptr{Float64}; end
+CBasis(Z, ncols, Dx, Dy, sx, sy) = CBasis(Z, ncols, Dx, Dy, sx, sy, C_NULL, C_NULL)      # generator unknown
 struct CWork;    g::Ptr{Cvoid}; d::Ptr{Cvoid}; rp::Ptr{Cvoid}; Utr::Ptr{Cvoid}; w::Ptr{Cvoid}; end
 
 struct ProjCGWork              # ProjCGWork(n, m), src/projcg.jl:1-11 (three n-vectors suffice on the device)
@@ -164,11 +168,13 @@ end
 struct DeviceNR                # NR(U, Σ, Vt, tol, maxiter, work, ineq, idata) of the reference
     U::DeviceBasis; Σ::Vector{Float64}; Vt::Matrix{Float64}; tol::Float64; maxiter::Int
     Jct::DeviceMatrix; m_lin::Int; b::Vector{Float64}; has_ball::Bool; R2::Float64; n_x::Int; slack_row::Int
+    W::Union{Nothing,Matrix{Float64}}      # ksvd!'s W (U.Z == Jct*W): one matrix stream per Newton step; nothing = two streams
 end
 function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceVector, x::DeviceVector, method::DeviceNR)
     flag = Ref{Cint}(0); iters = Ref{Int64}(0)
-    u = Ref(CBasis(method.U.Z.h, method.U.ncols, C_NULL, C_NULL, C_NULL, C_NULL))
     GC.@preserve method begin
+        u = Ref(method.W === nothing ? CBasis(method.U.Z.h, method.U.ncols, C_NULL, C_NULL, C_NULL, C_NULL) :
+                CBasis(method.U.Z.h, method.U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, method.Jct.h, pointer(method.W)))
         cons = Ref(CConstraints(method.Jct.h, method.m_lin, pointer(method.b), method.has_ball ? 1 : 0, method.R2, method.n_x, method.slack_row))
         check(x.ctx, ccall((:lfpsqp_retract_nr, lib), Cint,
                            (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},

@@ -22,7 +22,7 @@ class DiagOp(C.Structure):  # lfpsqp_diag_op
 
 
 class Basis(C.Structure):  # lfpsqp_basis
-    _fields_ = [("Z", P), ("ncols", c_i64), ("Dx", P), ("Dy", P), ("sx", P), ("sy", P)]
+    _fields_ = [("Z", P), ("ncols", c_i64), ("Dx", P), ("Dy", P), ("sx", P), ("sy", P), ("A", P), ("W", P)]
 
 
 class IneqData(C.Structure):  # lfpsqp_ineq_data
@@ -106,7 +106,7 @@ _SIGS = {
                           c_i64, C.POINTER(PPWork), PD, C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)],
     "lfpsqp_gram": [P, P, c_i64, P, P],
     "lfpsqp_rmul": [P, P, c_i64, P, c_i64, P],
-    "lfpsqp_factorize": [P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],
+    "lfpsqp_factorize": [P, P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],
     "lfpsqp_projcg": [P, P, P, C.POINTER(DiagOp), C.POINTER(Basis), P, P, c_dbl, c_i64, c_i64, C.c_int,
                       C.POINTER(ProjCGWorkC), C.POINTER(c_i64), PD],
     "lfpsqp_ctx_set_profiling": [P, C.c_int],

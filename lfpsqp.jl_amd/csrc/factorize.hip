@@ -240,7 +240,7 @@ int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const doub
 }
 
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
-                     int64_t* rank_out, double eps_rank) {
+                     double* W, int64_t* rank_out, double eps_rank) {
     LF_ARG(ctx, ctx && Jct && Z && Sigma && Vt && rank_out && Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m &&
                     (!w2 || w2->n == Jct->n));
     const int m = (int)Jct->m;
@@ -260,6 +260,8 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
     while (r < m && sig[r] >= thr && sig[r] > 0) ++r;
     for (int j = 0; j < m; ++j) Sigma[j] = sig[j];
     for (size_t i = 0; i < (size_t)m * m; ++i) Vt[i] = 0.0;
+    if (W)
+        for (size_t i = 0; i < (size_t)m * m; ++i) W[i] = 0.0;
     *rank_out = r;
     hipLaunchKernelGGL(zero_cols_kernel, dim3(256, (unsigned)Z->m), dim3(kThreads), 0, ctx->stream, Z->p, Z->ld, Z->n, 0);
     LF_LAUNCH_CHECK(ctx);
@@ -297,6 +299,8 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
     matmul(r, r, r, W2, Ub, T);
     matmul(m, r, r, W1, T, Wtot);
     LF_TRY(rmul_impl(ctx, Jct, m, Wtot.data(), r, Z));
+    if (W)
+        for (size_t i = 0; i < (size_t)m * r; ++i) W[i] = Wtot[i];        // Z[:, :r] = Jct * W[:, :r]; columns >= r stay zero
     for (int j = 0; j < r; ++j) Sigma[j] = S[j];
     for (int k = 0; k < r; ++k)
         for (int j = 0; j < m; ++j) Vt[(size_t)j * m + k] = Vb[(size_t)k * m + j];   // Vt[k, j] = Vb[j, k]

@@ -72,6 +72,9 @@ struct lfpsqp_ctx {
     int tune_ks = 0;   // 0 = auto: 4 for >= 4M local rows (measured best at n = 1e7), else 2 (better at the 8-GPU shard size 1.25e6)
     bool tune_nt = true;
     int ks_for(int64_t n) const { return tune_ks ? tune_ks : (n >= 4000000 ? 4 : 2); }
+    // Newton-retraction one-stream step (retract.hip): 0 = auto, 2 / 4 = lane groups per row, -1 = always two streams.
+    // Development override: environment variable LFPSQP_NR_ONEPASS, read once at lfpsqp_ctx_create.
+    int tune_nr = 0;
 
     // optional per-kernel-family profiling with HIP events on `stream`
     bool profiling = false;

@@ -52,6 +52,16 @@ __device__ __forceinline__ double2 ldm(const double* p) {
 // through these two helpers.
 __device__ __forceinline__ double ld_scal(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int64_t ld_stat(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 8-byte load through a buffer descriptor: wave-uniform 64-bit base (scalar registers) + 32-bit per-lane byte
+// offset.  Unlike a flat/global load with a 64-bit per-lane address this costs no address registers, which is what
+// lets a kernel keep a whole matrix tile in registers (retract.hip).  NT = non-temporal (streamed once).
+template <bool NT>
+__device__ __forceinline__ double buf_load_f64(const void* uniform_base, uint32_t lane_byte_off) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_base), 0, 0xffffffff, 0x00020000);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_byte_off, 0, NT ? 2 : 0));
+}
+// compiler-only ordering point for memory operations (no instruction is emitted)
+__device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
 
 // max that PROPAGATES NaN like Julia's max / norm(v, Inf) (fmax would drop it): a NaN constraint

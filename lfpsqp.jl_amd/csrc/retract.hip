@@ -8,6 +8,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "internal.h"
@@ -120,12 +121,151 @@ struct NRStepE {
         red[0] += b;
         return make_double2(v0 ? xn.x : 0.0, v1 ? xn.y : 0.0);
     }
+    // one-row form for the one-stream step kernel: the inputs of a row are fetched a tile ahead of their use.
+    // `o` is the row's BYTE offset (uniform base + 32-bit lane offset: the scalar-base addressing mode).
+    struct Row { double xn, yn, xo, yo, ax, ay, q, r, s, t; };
+    static __device__ __forceinline__ double at(const double* base, uint32_t o) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
+    }
+    static __device__ __forceinline__ void put(double* base, uint32_t o, double v) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + o) = v;
+    }
+    template <bool ST>
+    __device__ __forceinline__ Row fetch1(uint32_t o) const {
+        Row w;
+        w.xn = at(xnew, o);
+        if (ST) {
+            w.yn = at(xnew + hs, o); w.xo = at(xold, o); w.yo = at(xold + hs, o); w.ax = at(sx, o); w.ay = at(sy, o);
+            w.q = at(q, o); w.r = at(r, o); w.s = at(s, o); w.t = at(t, o);
+        } else {
+            w.yn = w.xo = w.yo = w.ax = w.ay = w.q = w.r = w.s = w.t = 0.0;
+        }
+        return w;
+    }
+    template <bool ST>
+    __device__ __forceinline__ double apply1(int64_t i, uint32_t o, double acc, bool valid, bool owner, const Row& w, double& red) const {
+        double xn = w.xn;
+        if (!ST) {
+            xn += acc;
+            if (valid && owner) put(xnew, o, xn);
+        } else {
+            double yn = w.yn;
+            xn += w.ax * acc;
+            yn += w.ay * acc;
+            if (valid) y_retract_one_nr(xn, yn, w.xo, w.yo, w.q, w.r, w.s, w.t);
+            if (valid && owner) { put(xnew, o, xn); put(xnew + hs, o, yn); }
+        }
+        if (valid && owner) red += ball(i, xn);
+        return valid ? xn : 0.0;
+    }
 };
+
+// ---------------------------------------------------------------------------
+// One-stream Newton step.  When the basis was formed as Z = Jct * W (lfpsqp_factorize), the step product is
+// U*delta = [sx; sy] .* (Jct * (W*delta)), so BOTH products of a Newton step (src/retractions.jl:141 and the c! of
+// :146/148) run over the same rows of the same matrix.  A wave keeps a (64/CW)-row x (CW*CPL)-column tile of Jct in
+// registers between the two products -- lane (r, h) holds row r, columns h, h+CW, h+2CW, ... -- so Jct is streamed
+// from HBM once per step instead of Z once plus Jct once.  No LDS traffic and no barrier in the tile loop; the
+// next tile's loads are issued while the current tile's second product runs.  Addresses are a uniform (scalar)
+// column base plus a 32-bit lane offset, so the tile costs no address registers.  A workgroup owns kPadRows rows
+// (tiles interleaved over its 4 waves) and emits one partial row, like the other streaming kernels.
+//   t = W*delta (ncN entries); part[wg][0:ncT) = sum_rows Jct[row, j] * xnew[row]; part[wg][ncT] = ball partial.
+// ST = stacked vectors (bounds).  Host guarantees (CW-1)*ld*8 + kPadRows*8 < 2^32 and (n + kPadRows)*8 < 2^32.
+// ---------------------------------------------------------------------------
+template <int CPL, int CW, bool NT, bool ST>
+__global__ __launch_bounds__(kThreads) void nr_onepass_kernel(const double* __restrict__ J, int64_t ld, int ncN, int ncT, int64_t n,
+                                                               const double* __restrict__ t, NRStepE ep, double* __restrict__ part,
+                                                               int part_ld) {
+    if (ep.skip()) return;
+    constexpr int RW = 64 / CW;                      // rows per wave tile
+    constexpr int kStep = RW * kWaves;               // rows the workgroup advances per tile round
+    constexpr int kTiles = kPadRows / kStep;
+    constexpr int NC = CW * CPL;
+    static_assert(NC <= kColChunk, "column block must fit the LDS staging row");
+    __shared__ double ts[NC];
+    __shared__ double red[kWaves][NC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & (RW - 1), h = lane / RW;
+    // Column groups: group g < glast holds columns g*CW .. g*CW+CW-1; the last group is shifted back to the columns
+    // ncN-CW .. ncN-1 (all valid; the ones it shares with group glast-1 get a zero coefficient), groups past it
+    // re-read it with zero coefficients.  Slot s = g*CW + h of ts[] / red[] therefore maps to column col_of(s).
+    const int glast = (ncN - 1) / CW;                                            // host guarantees ncN >= CW
+    const int lastc0 = ncN - CW;
+    for (int j = threadIdx.x; j < NC; j += kThreads) {
+        const int g = j / CW, hh = j - g * CW;
+        double v = 0.0;
+        if (g < glast) v = t[j];
+        else if (g == glast && lastc0 + hh >= glast * CW) v = t[lastc0 + hh];
+        ts[j] = v;
+    }
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * kPadRows;                        // uniform
+    const int lrow = wave * RW + r;                                              // row within the block, tile 0
+    const uint32_t vo = (uint32_t)(lrow * 8) + (uint32_t)((int64_t)h * ld * 8);  // lane offset: row, and column within the group
+    const char* Jb = reinterpret_cast<const char*>(J + row0);
+    const int64_t cs = (int64_t)CW * ld * 8;
+    const int64_t last_off = (int64_t)lastc0 * ld * 8;
+    auto load_tile = [&](double (&a)[CPL], int k) {
+        const char* sb = Jb + (int64_t)k * (kStep * 8);                                  // wave-uniform
+        const char* lastb = sb + last_off;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            a[c] = buf_load_f64<NT>((c < glast) ? sb : lastb, vo);
+            sb += cs;
+        }
+    };
+    double a[CPL], p[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) p[c] = 0.0;
+    load_tile(a, 0);
+    uint32_t ro = (uint32_t)((row0 + lrow) * 8);
+    NRStepE::Row in = ep.fetch1<ST>(ro);
+    double rsum = 0.0;
+    auto tile_step = [&](int k, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        compiler_fence();               // re-read ts[] from LDS every tile instead of pinning 2*CPL registers on it
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc = fma(a[c], ts[c * CW + h], acc);
+#pragma unroll
+        for (int o = RW; o < 64; o <<= 1) acc += __shfl_xor(acc, o);          // commutative pairings: every lane of a row agrees
+        const int64_t row = row0 + lrow + (int64_t)k * kStep;
+        NRStepE::Row in_next = in;
+        if (MORE) in_next = ep.fetch1<ST>(ro + kStep * 8);
+        const double v = ep.apply1<ST>(row, ro, acc, row < n, h == 0, in, rsum);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) p[c] = fma(a[c], v, p[c]);
+        compiler_fence();               // the next tile's loads reuse a[]: keep them below its last use (no second buffer)
+        if (MORE) load_tile(a, k + 1);
+        in = in_next;
+        ro += kStep * 8;
+    };
+#pragma unroll 1
+    for (int k = 0; k < kTiles - 1; ++k) tile_step(k, std::true_type());
+    tile_step(kTiles - 1, std::false_type());
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        double s = p[c];
+#pragma unroll
+        for (int o = RW / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (r == 0) red[wave][c * CW + h] = s;
+    }
+    __syncthreads();
+    double* prow = part + (int64_t)blockIdx.x * part_ld;
+    for (int j = threadIdx.x; j < ncT; j += kThreads) {
+        const int sl = (j < glast * CW) ? j : (glast * CW + (j - lastc0));       // slot holding column j
+        prow[j] = (red[0][sl] + red[1][sl]) + (red[2][sl] + red[3][sl]);
+    }
+    double rs[1] = {rsum};
+    block_reduce_store<1>(rs, 0u, prow + ncT);
+}
 
 // The replicated m x m part of the Newton retraction on the device (src/retractions.jl:126-160): turns the raw
 // constraint products of the fused step into c(xnew), applies the good-Broyden update of the inverse Jacobian
-// D, tests ||c||_inf < tol / the iteration limit, and prepares delta = -D c for the next step.  One workgroup;
-// thread k owns row k of D (column-major, coalesced over k).
+// D, tests ||c||_inf < tol / the iteration limit, and prepares delta = -D c (and W*delta for the one-stream
+// step) for the next step.  One workgroup of 1024 threads; D is column-major, products over its rows are
+// coalesced over k with the column range split over thread groups, products over its columns use one wave
+// per column; all sums in a fixed order.
 struct NRSmall {
     double* D;            // m x m
     const double* Vt;     // m x m
@@ -134,70 +274,94 @@ struct NRSmall {
     double* cval;         // m (current constraint values)
     double* delta;        // m (step coefficients, read by the fused step kernel)
     const double* raw;    // m: [J'x (m_lin) ; ball partial]
+    const double* W;      // wm x m generator factor (Z = A*W) or nullptr
+    double* wdelta;       // wm: W * delta
     int64_t* istat;
     int64_t* hstat;       // pinned host block
-    int m, m_lin, has_ball;
+    int m, m_lin, has_ball, wm;
     double R2, tol;
     int64_t maxiter;
 };
-__global__ __launch_bounds__(256) void nr_small_kernel(NRSmall s, int init) {
+constexpr int kNRThreads = 1024;
+
+// y[k] = sum_j A[k + j*lda] * x[j], k < rows, j < cols (x in LDS); result left in y (LDS), valid after the trailing barrier
+__device__ __forceinline__ void small_matvec(const double* A, int lda, int rows, int cols, const double* x, double* y, double* scratch) {
+    int kw = 32;
+    while (kw < rows) kw <<= 1;                 // rows <= kNRMaxM = 1024
+    const int groups = kNRThreads / kw;
+    const int k = threadIdx.x & (kw - 1), g = threadIdx.x / kw;
+    double acc = 0.0;
+    if (k < rows)
+        for (int j = g; j < cols; j += groups) acc += A[(size_t)j * lda + k] * x[j];
+    scratch[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && k < rows) {
+        double sum = 0.0;
+        for (int q = 0; q < groups; ++q) sum += scratch[q * kw + k];
+        y[k] = sum;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kNRThreads) void nr_small_kernel(NRSmall s, int init) {
     if (!init && ld_stat(s.istat + I_NR_STATUS) != 0) return;
     __shared__ double cnew[kNRMaxM], del[kNRMaxM], t2[kNRMaxM], dcs[kNRMaxM], tv[kNRMaxM];
-    __shared__ double red[256];
+    __shared__ double scratch[kNRThreads];
     const int m = s.m, tid = threadIdx.x;
-    for (int k = tid; k < m; k += 256) cnew[k] = s.raw[k] - (k < s.m_lin ? s.b[k] : s.R2);
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < m; k += kNRThreads) cnew[k] = s.raw[k] - (k < s.m_lin ? s.b[k] : s.R2);
     __syncthreads();
     int64_t iter = init ? 0 : ld_stat(s.istat + I_NR_ITER);
     if (init) {
-        for (int k = tid; k < m; k += 256) {
-            s.cval[k] = cnew[k];
-            const double sg = s.Sigma[k];
-            for (int j = 0; j < m; ++j) s.D[(size_t)j * m + k] = s.Vt[(size_t)j * m + k] / sg;      // :126-130
-        }
+        for (int k = tid; k < m; k += kNRThreads) s.cval[k] = cnew[k];
+        for (size_t e = tid; e < (size_t)m * m; e += kNRThreads) s.D[e] = s.Vt[e] / s.Sigma[e % m];      // :126-130
     } else {
-        for (int k = tid; k < m; k += 256) {
+        for (int k = tid; k < m; k += kNRThreads) {
             dcs[k] = cnew[k] - s.cval[k];                                                       // :152
             s.cval[k] = cnew[k];                                                                // :153
             del[k] = s.delta[k];
         }
         __syncthreads();
-        for (int j = tid; j < m; j += 256) {                                                    // :156  t2 = D' delta
+        for (int j = wave; j < m; j += kNRThreads / 64) {                                       // :156  t2 = D' delta
             double a = 0.0;
-            for (int k = 0; k < m; ++k) a += s.D[(size_t)j * m + k] * del[k];
-            t2[j] = a;
+            for (int k = lane; k < m; k += 64) a += s.D[(size_t)j * m + k] * del[k];
+            a = wave_sum(a);
+            if (lane == 0) t2[j] = a;
         }
-        for (int k = tid; k < m; k += 256) {                                                    // :157  tv = delta - D dc
-            double a = 0.0;
-            for (int j = 0; j < m; ++j) a += s.D[(size_t)j * m + k] * dcs[j];
-            tv[k] = del[k] - a;
-        }
-        __syncthreads();
+        small_matvec(s.D, m, m, m, dcs, tv, scratch);                                           // :157  tv = delta - D dc
+        if (tid < m) tv[tid] = del[tid] - tv[tid];
         double part = 0.0;
-        for (int k = tid; k < m; k += 256) part += t2[k] * dcs[k];
-        red[tid] = part;
+        for (int k = tid; k < m; k += kNRThreads) part += t2[k] * dcs[k];
+        scratch[tid] = part;
         __syncthreads();
-        if (tid == 0) {
-            double den = 0.0;
-            for (int k = 0; k < 256; ++k) den += red[k];
-            red[0] = 1.0 / den;                                                                 // :159
+        for (int o = kNRThreads / 2; o > 0; o >>= 1) {
+            if (tid < o) scratch[tid] += scratch[tid + o];
+            __syncthreads();
         }
+        const double alpha = 1.0 / scratch[0];                                                  // :159
         __syncthreads();
-        const double alpha = red[0];
-        __syncthreads();
-        for (int k = tid; k < m; k += 256) {                                                    // :160  D += alpha tv t2'
-            const double a = alpha * tv[k];
-            for (int j = 0; j < m; ++j) s.D[(size_t)j * m + k] += a * t2[j];
+        {                                                                                       // :160  D += alpha tv t2'
+            int kw = 32;
+            while (kw < m) kw <<= 1;
+            const int groups = kNRThreads / kw, k = tid & (kw - 1), g = tid / kw;
+            if (k < m) {
+                const double a = alpha * tv[k];
+                for (int j = g; j < m; j += groups) s.D[(size_t)j * m + k] += a * t2[j];
+            }
         }
         iter += 1;                                                                              // :168
     }
     __syncthreads();
     double mx = 0.0;
-    for (int k = tid; k < m; k += 256) mx = nanmax(mx, fabs(cnew[k]));
-    red[tid] = mx;
+    for (int k = tid; k < m; k += kNRThreads) mx = nanmax(mx, fabs(cnew[k]));
+    scratch[tid] = mx;
     __syncthreads();
+    for (int o = kNRThreads / 2; o > 0; o >>= 1) {
+        if (tid < o) scratch[tid] = nanmax(scratch[tid], scratch[tid + o]);
+        __syncthreads();
+    }
     if (tid == 0) {
-        double c = 0.0;
-        for (int k = 0; k < 256; ++k) c = nanmax(c, red[k]);
+        const double c = scratch[0];
         int64_t st = 0;
         if (iter >= s.maxiter) { st = 1; s.istat[I_NR_FLAG] = 1; }      // :133 loop bound first: flag = (i == maxiter), :171-174
         else if (c < s.tol) { st = 1; s.istat[I_NR_FLAG] = 0; }         // :135
@@ -207,15 +371,81 @@ __global__ __launch_bounds__(256) void nr_small_kernel(NRSmall s, int init) {
         __hip_atomic_store(s.hstat + I_NR_FLAG, st ? s.istat[I_NR_FLAG] : (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(s.hstat + kNRRingOff + ((iter + 1) % kNRRing), st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(s.hstat + I_NR_STATUS, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        red[0] = (double)st;
+        scratch[0] = (double)st;
     }
     __syncthreads();
-    if (red[0] != 0.0) return;
-    for (int k = tid; k < m; k += 256) {                                                        // :140  delta = -D cval
-        double a = 0.0;
-        for (int j = 0; j < m; ++j) a += s.D[(size_t)j * m + k] * cnew[j];
-        s.delta[k] = -a;
+    const bool finished = scratch[0] != 0.0;
+    __syncthreads();
+    if (finished) return;
+    small_matvec(s.D, m, m, m, cnew, del, scratch);                                             // :140  delta = -D cval
+    if (tid < m) { del[tid] = -del[tid]; s.delta[tid] = del[tid]; }
+    __syncthreads();
+    if (s.W) {                                                                                  // t = W delta (one-stream step)
+        small_matvec(s.W, s.wm, s.wm, m, del, t2, scratch);
+        if (tid < s.wm) s.wdelta[tid] = t2[tid];
     }
+}
+
+// smallest instantiated (CPL, CW) tile covering ncN columns; 0 if none (then the two-stream kernel is used)
+static int nr_onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
+    if (ctx->tune_nr < 0 || ncN > kColChunk) return 0;
+    int cw = (ctx->tune_nr == 2 || ctx->tune_nr == 4 || ctx->tune_nr == 8) ? ctx->tune_nr : 4;
+    while (cw > 2 && ncN < cw) cw >>= 1;
+    if (ncN < cw) return 0;
+    // 32-bit lane offsets: column-within-group stride and the row byte offset must fit
+    if ((int64_t)(cw - 1) * ld * 8 + (int64_t)kPadRows * 8 >= ((int64_t)1 << 32) || (n + kPadRows) * 8 >= ((int64_t)1 << 32)) return 0;
+    return cw;
+}
+
+// out[0:ncT] = Jct[:, :ncT]' xnew, out[ncT] = ball partial, after xnew += [sx; sy] .* (Jct[:, :ncN] * t)  (all-reduced)
+static int run_nr_onepass(lfpsqp_ctx* ctx, int cw, const lfpsqp_mat* J, int ncN, int ncT, int64_t n, const double* t, const NRStepE& ep,
+                          double* out) {
+    const int64_t tiles = (n + kPadRows - 1) / kPadRows;
+    const int nout = ncT + 1;
+    const int part_ld = (int)round_up(nout, 32);
+    if (tiles > 0) {
+        LF_TRY(ensure_part(ctx, (size_t)tiles * part_ld + reduce_scratch(part_ld)));
+        const int cpl = (ncN + cw - 1) / cw;
+#define LF_NR1(CPL, CW)                                                                                                                  \
+    do {                                                                                                                                 \
+        if (ep.hs != 0)                                                                                                                  \
+            hipLaunchKernelGGL((nr_onepass_kernel<CPL, CW, true, true>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, J->p,   \
+                               J->ld, ncN, ncT, n, t, ep, ctx->part, part_ld);                                                           \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((nr_onepass_kernel<CPL, CW, true, false>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, J->p,  \
+                               J->ld, ncN, ncT, n, t, ep, ctx->part, part_ld);                                                           \
+    } while (0)
+        if (cw == 8) {
+            if (cpl <= 4) LF_NR1(4, 8);
+            else if (cpl <= 8) LF_NR1(8, 8);
+            else if (cpl <= 12) LF_NR1(12, 8);
+            else if (cpl <= 17) LF_NR1(17, 8);
+            else if (cpl <= 24) LF_NR1(24, 8);
+            else LF_NR1(32, 8);
+        } else if (cw == 4) {
+            if (cpl <= 4) LF_NR1(4, 4);
+            else if (cpl <= 8) LF_NR1(8, 4);
+            else if (cpl <= 16) LF_NR1(16, 4);
+            else if (cpl <= 24) LF_NR1(24, 4);
+            else if (cpl <= 33) LF_NR1(33, 4);
+            else if (cpl <= 48) LF_NR1(48, 4);
+            else LF_NR1(64, 4);
+        } else {
+            if (cpl <= 8) LF_NR1(8, 2);
+            else if (cpl <= 16) LF_NR1(16, 2);
+            else if (cpl <= 32) LF_NR1(32, 2);
+            else if (cpl <= 48) LF_NR1(48, 2);
+            else if (cpl <= 66) LF_NR1(66, 2);
+            else if (cpl <= 96) LF_NR1(96, 2);
+            else LF_NR1(128, 2);
+        }
+#undef LF_NR1
+        LF_LAUNCH_CHECK(ctx);
+        LF_TRY(launch_reduce(ctx, tiles, nout, part_ld, 0u, out, NoPost()));
+    } else {
+        LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
+    }
+    return allreduce_dev(ctx, out, nout);
 }
 
 int cons_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval) {
@@ -276,14 +506,21 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         const int ml = (int)cons->m_lin;
         const int64_t N = cons->Jct->n;
         const size_t mm = (size_t)m * m;
-        LF_TRY(ensure_small(ctx, 2 * mm + 8 * (size_t)m + 256));
+        // one-stream step: the caller vouches that U->Z == U->A * U->W and A is the matrix c! streams anyway
+        const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kNRMaxM) ? (int)U->A->m : 0;
+        const int cw = wm ? nr_onepass_cw(ctx, wm, cons->Jct->ld, N) : 0;
+        const size_t wsz = cw ? (((size_t)wm * m + (size_t)wm + 1) & ~(size_t)1) : 0;
+        LF_TRY(ensure_small(ctx, 2 * mm + wsz + 8 * (size_t)m + 256));
         double* dD = ctx->small;
         double* dVt = dD + mm;
-        double* dSig = dVt + mm;
+        double* dW = dVt + mm;
+        double* dwdelta = dW + (size_t)(cw ? wm : 0) * m;
+        double* dSig = dW + wsz;
         double* db = dSig + m;
         double* dcval = db + m;
         double* ddelta = dcval + m;
         double* draw = ddelta + m + (m & 1);          // keep the reduce output 16-byte aligned
+        if (cw) LF_HIP(ctx, hipMemcpyAsync(dW, U->W, sizeof(double) * (size_t)wm * m, hipMemcpyHostToDevice, ctx->stream));
         LF_HIP(ctx, hipMemcpyAsync(dVt, Vt, sizeof(double) * mm, hipMemcpyHostToDevice, ctx->stream));
         LF_HIP(ctx, hipMemcpyAsync(dSig, Sigma, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
         if (ml > 0) LF_HIP(ctx, hipMemcpyAsync(db, cons->b, sizeof(double) * ml, hipMemcpyHostToDevice, ctx->stream));
@@ -291,14 +528,14 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         volatile int64_t* hstat = ctx->h_istat;
         for (int k = 0; k < kNRRing; ++k) hstat[kNRRingOff + k] = 0;
         hstat[I_NR_STATUS] = 0;
-        const NRSmall sm{dD, dVt, dSig, db, dcval, ddelta, draw, ctx->istat, ctx->h_istat, m, ml, cons->has_ball ? 1 : 0,
-                         cons->R2, tol, maxiter};
+        const NRSmall sm{dD, dVt, dSig, db, dcval, ddelta, draw, cw ? dW : nullptr, dwdelta, ctx->istat, ctx->h_istat, m, ml,
+                         cons->has_ball ? 1 : 0, cw ? wm : 0, cons->R2, tol, maxiter};
         LF_TRY(lfpsqp_vec_copy(ctx, xnew, xtilde));                                             // :116
         if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew, x, idata));                                // :118-120
         if (ml > 0) LF_TRY(run_gemv_t(ctx, cons->Jct, ml, N, PlainVec{xnew->p}, draw));         // c!(cval, xnew), raw products
         if (cons->has_ball)
             LF_TRY((run_vec<BallF, 1, NoPost>(ctx, N, BallF{xnew->p, cons->n_x, cons->slack_row}, 0u, draw + ml, NoPost())));
-        hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(256), 0, ctx->stream, sm, 1);
+        hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sm, 1);
         LF_LAUNCH_CHECK(ctx);
         LF_HIP(ctx, hipEventRecord(ctx->ev_slot[0], ctx->stream));
         const NRStepE ep{xnew->p, x->p, ineq ? lfpsqp_half_stride(N) : 0, ineq ? U->sx->p : nullptr, ineq ? U->sy->p : nullptr,
@@ -308,9 +545,10 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         bool done = false;
         while (!done && it < maxiter) {
             // step `it`: xnew += U delta, y_retract!, raw c! products (one launch) ; Broyden + test + next delta (one workgroup)
-            if (cons->has_ball) LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
+            if (cw) LF_TRY(run_nr_onepass(ctx, cw, cons->Jct, wm, ml, N, dwdelta, ep, draw));
+            else if (cons->has_ball) LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
             else LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
-            hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(256), 0, ctx->stream, sm, 0);
+            hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sm, 0);
             LF_LAUNCH_CHECK(ctx);
             LF_HIP(ctx, hipEventRecord(ctx->ev_slot[(it + 1) & 3], ctx->stream));
             // rank-deterministic stop: status after `it` completed steps (published by the previous kernel generation)

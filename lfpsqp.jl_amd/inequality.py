@@ -82,8 +82,11 @@ class InequalityDecomp:
         self.Dx, self.Dy, self.S, self.sx, self.sy = (DeviceVector(ctx, N) for _ in range(5))
         self.Jct = Jct if Jct is not None else DeviceMatrix(ctx, N, M)
         self.rank = M
+        self.W = None                       # ksvd_'s small factor (Z == Jct @ W) when the driver keeps it
 
     def basis_c(self):
+        if self.W is not None:
+            return _capi.Basis(self.Z.h, self.rank, self.Dx.h, self.Dy.h, self.sx.h, self.sy.h, self.Jct.h, self.W.ctypes.data)
         return _capi.Basis(self.Z.h, self.rank, self.Dx.h, self.Dy.h, self.sx.h, self.sy.h)
 
 

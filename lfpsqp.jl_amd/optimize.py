@@ -162,6 +162,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     idecomp = InequalityDecomp(ctx, n, m, Jct)
     Z = idecomp.Z
     Sig, Vt = idecomp.Sigma, idecomp.Vt
+    Wgen = np.zeros((m, m), order='F') if m > 0 else None                  # ksvd_'s small factor: Z == Jct @ Wgen
     ineqproject = InequalityDecompProject(idecomp) if ineq else None
 
     diagonal_hessian = hasattr(hess_lag_vec_, "diag_")
@@ -213,7 +214,8 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
         rank = m
         if m > 0:
             jac_(Jct, cval, x)                                             # :283-284 (the device keeps only Jct)
-            S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank)   # :286-302
+            S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank, W=Wgen)   # :286-302
+            idecomp.W = Wgen
             Sig[:] = S_
             Vt[:, :] = Vt_
             if not ineq:                                                   # :305-308
@@ -283,7 +285,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
 
         if m > 0:                                                          # :396-412
             if rank == m and not param.do_project_retract:
-                nr.U = ineqproject if ineq else DeviceBasis(Z, rank)
+                nr.U = ineqproject if ineq else DeviceBasis(Z, rank, generator=(Jct, Wgen))
                 retract_method, mtype = nr, 0
             else:
                 retract_method, mtype = pp, 1

@@ -50,11 +50,15 @@ class DiagOperator:
 class DeviceBasis:
     """Orthonormal U = Z[:, :ncols] (``view(U, :, 1:rank)``, src/optimize.jl:370)."""
 
-    def __init__(self, Z: DeviceMatrix, ncols: int | None = None):
+    def __init__(self, Z: DeviceMatrix, ncols: int | None = None, generator=None):
         self.Z = Z
         self.ncols = Z.m if ncols is None else int(ncols)
+        self.generator = generator          # optional (A, W) with Z == A @ W (ksvd_'s W): lfpsqp_basis.A / .W
 
     def _c(self):
+        if self.generator is not None:
+            A, W = self.generator
+            return _capi.Basis(self.Z.h, self.ncols, None, None, None, None, A.h, W.ctypes.data)
         return _capi.Basis(self.Z.h, self.ncols, None, None, None, None)
 
     def mul_(self, dest, v, a=None, b=None):

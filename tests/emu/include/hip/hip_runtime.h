@@ -253,6 +253,14 @@ static inline void __syncthreads() { hipemu::syncthreads(); }
 template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return hipemu::shfl_generic(v, (threadIdx.x & 63) ^ (unsigned)mask); }
 template <class T> static inline T __shfl_down(T v, unsigned d, int = 64) { unsigned l = threadIdx.x & 63; return hipemu::shfl_generic(v, l + d < 64 ? l + d : l); }
 template <class T> static inline T __shfl(T v, int src, int = 64) { return hipemu::shfl_generic(v, (unsigned)src); }
+// buffer-descriptor loads (scalar base + 32-bit lane offset)
+struct __amdgpu_buffer_rsrc_t { const char* base; };
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return {static_cast<const char*>(p)}; }
+static inline unsigned long long __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int) {
+    unsigned long long v;
+    memcpy(&v, rs.base + voff + soff, 8);
+    return v;
+}
 static inline double __builtin_nontemporal_load(const double* p) { return *p; }
 static inline void __builtin_nontemporal_store(double v, double* p) { *p = v; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
