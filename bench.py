@@ -151,12 +151,14 @@ def main(argv=None, lib=None):
     # ---- per-kernel roofline numbers (HIP events on the library's stream) ---------------
     def avg(slot):
         return prof_ms[slot] / prof_cnt[slot] if prof_cnt[slot] else float("nan")
-    k1, k2, k3 = avg(0), avg(1), avg(2)
-    # algorithmic bytes per launch: K1 reads x,d,g,a writes x,d; K2 reads d,g,a + U;
-    # K3 reads d,g,a writes g + U
+    fused = prof_cnt[3] > 0                              # one pass over U per iteration (lfpsqp_projcg default)
+    k1, k2, k3, kf = avg(0), avg(1), avg(2), avg(3)
+    # algorithmic bytes per launch.  K1 reads x,d,g,a writes x,d.  Fused F: U once + reads g,d,a, writes g.
+    # Two-pass fallback: K2 reads d,g,a + U; K3 reads d,g,a writes g + U.
     bytes_k1 = 48.0 * n_loc
     bytes_k2 = 8.0 * n_loc * m + 24.0 * n_loc + 8.0 * m
     bytes_k3 = 8.0 * n_loc * m + 32.0 * n_loc + 8.0 * m
+    bytes_kf = 8.0 * n_loc * m + 32.0 * n_loc + 8.0 * m
     gbs = lambda by, ms: by / (ms * 1e-3) / 1e9
     # plain matvecs (the "achieved HBM GB/s on J matvec" half of the metric)
     v = ctx.vector(n_loc).hash_fill(5, r0)
@@ -192,15 +194,25 @@ def main(argv=None, lib=None):
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
                    "comm": comm_used, "device": ctx.device_name},
-        "roofline": {"bound": "hbm", "kernel": "gemv_t_kernel<PcgStepV> (K2: rp = g + alpha*A*d formed on the fly, fused with U'rp)",
-                     "achieved": gbs(bytes_k2, k2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gbs(bytes_k2, k2) / HBM_PEAK_GBS, "traffic": None,
-                     "avg_launch_ms": k2, "algorithmic_bytes": bytes_k2},
-        "kernels": {"K1_dir_dAd": {"ms": k1, "GBs": gbs(bytes_k1, k1)},
-                    "K2_step_UTrp": {"ms": k2, "GBs": gbs(bytes_k2, k2)},
-                    "K3_proj_dots": {"ms": k3, "GBs": gbs(bytes_k3, k3)},
-                    "iteration_algorithmic_GB": (bytes_k1 + bytes_k2 + bytes_k3) / 1e9,
-                    "iteration_GBs": (bytes_k1 + bytes_k2 + bytes_k3) * K / elapsed / 1e9},
+        "roofline": ({"bound": "hbm", "kernel": "onepass_kernel<PcgFuseE> (F: rp = g + alpha*A*d, gp = rp - U*Utr, g = gp, U'gp, U'(A gp): "
+                                                 "ONE pass over U per projected-CG iteration)",
+                      "achieved": gbs(bytes_kf, kf), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": gbs(bytes_kf, kf) / HBM_PEAK_GBS, "traffic": None,
+                      "avg_launch_ms": kf, "algorithmic_bytes": bytes_kf} if fused else
+                     {"bound": "hbm", "kernel": "gemv_t_kernel<PcgStepV> (K2: rp = g + alpha*A*d formed on the fly, fused with U'rp)",
+                      "achieved": gbs(bytes_k2, k2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": gbs(bytes_k2, k2) / HBM_PEAK_GBS, "traffic": None,
+                      "avg_launch_ms": k2, "algorithmic_bytes": bytes_k2}),
+        "kernels": ({"K1_dir_dAd": {"ms": k1, "GBs": gbs(bytes_k1, k1)},
+                     "F_fused_projection": {"ms": kf, "GBs": gbs(bytes_kf, kf)},
+                     "iteration_algorithmic_GB": (bytes_k1 + bytes_kf) / 1e9,
+                     "iteration_GBs": (bytes_k1 + bytes_kf) * K / elapsed / 1e9,
+                     "reference_formulation_GB": (16.0 * n_loc * m + 96.0 * n_loc) / 1e9} if fused else
+                    {"K1_dir_dAd": {"ms": k1, "GBs": gbs(bytes_k1, k1)},
+                     "K2_step_UTrp": {"ms": k2, "GBs": gbs(bytes_k2, k2)},
+                     "K3_proj_dots": {"ms": k3, "GBs": gbs(bytes_k3, k3)},
+                     "iteration_algorithmic_GB": (bytes_k1 + bytes_k2 + bytes_k3) / 1e9,
+                     "iteration_GBs": (bytes_k1 + bytes_k2 + bytes_k3) * K / elapsed / 1e9}),
         "matvec": {"gemv_t": {"ms": ms_t, "GBs": gbs(bytes_t, ms_t), "frac": gbs(bytes_t, ms_t) / HBM_PEAK_GBS},
                    "gemv_n": {"ms": ms_n, "GBs": gbs(bytes_n, ms_n), "frac": gbs(bytes_n, ms_n) / HBM_PEAK_GBS}},
     }
@@ -213,7 +225,7 @@ def main(argv=None, lib=None):
         if pmc and world == 1 and n == 10_000_000 and m == 128:
             summ = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
             for name, v in summ.items():
-                if "gemv_t_kernel<lfpsqp::PcgStepV" in name:
+                if ("onepass_kernel<lfpsqp::PcgFuseE" if fused else "gemv_t_kernel<lfpsqp::PcgStepV") in name:
                     out["roofline"]["traffic"] = v["traffic_GB"] * 1e9
                     out["roofline"]["traffic_source"] = f"profiles/{pmc[-1]} ({v['launches']} launches)"
     except (OSError, ValueError, KeyError):

@@ -146,7 +146,7 @@ int lfpsqp_ctx_create(int device, lfpsqp_ctx** out) {
     ok = ok && hipEventCreate(&ctx->ev_t0) == hipSuccess && hipEventCreate(&ctx->ev_t1) == hipSuccess;
     if (ok) ok = hipMemset(ctx->scal, 0, 64 * sizeof(double)) == hipSuccess && hipMemset(ctx->istat, 0, 16 * sizeof(int64_t)) == hipSuccess;
     if (!ok) { delete ctx; return set_err(nullptr, LFPSQP_ERR_HIP, "context resource allocation failed"); }
-    if (const char* e = getenv("LFPSQP_NR_ONEPASS")) ctx->tune_nr = atoi(e);
+    if (const char* e = getenv("LFPSQP_ONEPASS")) ctx->tune_onepass = atoi(e);
     *out = ctx;
     return 0;
 }

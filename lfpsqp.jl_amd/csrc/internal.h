@@ -72,9 +72,9 @@ struct lfpsqp_ctx {
     int tune_ks = 0;   // 0 = auto: 4 for >= 4M local rows (measured best at n = 1e7), else 2 (better at the 8-GPU shard size 1.25e6)
     bool tune_nt = true;
     int ks_for(int64_t n) const { return tune_ks ? tune_ks : (n >= 4000000 ? 4 : 2); }
-    // Newton-retraction one-stream step (retract.hip): 0 = auto, 2 / 4 = lane groups per row, -1 = always two streams.
-    // Development override: environment variable LFPSQP_NR_ONEPASS, read once at lfpsqp_ctx_create.
-    int tune_nr = 0;
+    // one-stream N->T kernels (Newton-retraction step, fused projected-CG iteration): 0 = on, -1 = always the two-pass kernels.
+    // Development override: environment variable LFPSQP_ONEPASS, read once at lfpsqp_ctx_create.
+    int tune_onepass = 0;
 
     // optional per-kernel-family profiling with HIP events on `stream`
     bool profiling = false;
@@ -244,6 +244,47 @@ int run_gemv_nt(lfpsqp_ctx* ctx, const lfpsqp_mat* M1, int n1, const double* t, 
     if (nout == 0) return 0;
     if (tiles > 0) LF_TRY(launch_reduce(ctx, tiles, nout, part_ld, 0u, out, NoPost()));
     else LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
+    return allreduce_dev(ctx, out, nout);
+}
+
+// One-stream N->T product over M (onepass_kernel): usable for this shape?  Returns the lane-group count CW (4) or 0.
+inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
+    const int cw = 4;
+    if (ctx->tune_onepass < 0 || ncN < cw || ncN > kColChunk) return 0;
+    // 32-bit lane offsets: column-within-group stride and the row byte offset must fit
+    if ((int64_t)(cw - 1) * ld * 8 + (int64_t)kPadRows * 8 >= ((int64_t)1 << 32) || (n + kPadRows) * 8 >= ((int64_t)1 << 32)) return 0;
+    return cw;
+}
+
+// out[k*ncT + j] = sum_rows M[row, j] * v_k[row] (k < NV, j < ncT), out[NV*ncT + r] = reduction r, with v produced by EP
+// from M[row, :ncN] . t -- all-reduced over ranks; one pass over M.
+template <class EP, int NV, int NRED>
+int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t n, const double* t, const EP& ep, double* out,
+                int prof_slot = -1) {
+    const int64_t tiles = (n + kPadRows - 1) / kPadRows;
+    const int nout = NV * ncT + NRED;
+    const int part_ld = (int)round_up(nout, 32);
+    if (tiles > 0) {
+        LF_TRY(ensure_part(ctx, (size_t)tiles * part_ld + reduce_scratch(part_ld)));
+        const int cpl = (ncN + 3) / 4;
+        if (prof_slot >= 0) prof_begin(ctx, prof_slot);
+#define LF_OP(CPL)                                                                                                                      \
+    hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, true>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, M->p, M->ld, \
+                       ncN, ncT, n, t, ep, ctx->part, part_ld)
+        if (cpl <= 4) LF_OP(4);
+        else if (cpl <= 8) LF_OP(8);
+        else if (cpl <= 16) LF_OP(16);
+        else if (cpl <= 24) LF_OP(24);
+        else if (cpl <= 33) LF_OP(33);
+        else if (cpl <= 48) LF_OP(48);
+        else LF_OP(64);
+#undef LF_OP
+        if (prof_slot >= 0) prof_end(ctx, prof_slot);
+        LF_LAUNCH_CHECK(ctx);
+        LF_TRY(launch_reduce(ctx, tiles, nout, part_ld, 0u, out, NoPost()));
+    } else {
+        LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
+    }
     return allreduce_dev(ctx, out, nout);
 }
 

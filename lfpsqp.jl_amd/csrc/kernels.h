@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace lfpsqp {
 
 // Tuning knobs are template parameters selected at run time per context (lfpsqp_ctx_set_tuning):
@@ -315,6 +317,154 @@ __global__ __launch_bounds__(kThreads) void gemv_nt_kernel(const double* __restr
         __syncthreads();
     }
     if (NRED > 0) block_reduce_store<(NRED > 0 ? NRED : 1)>(rsum, 0u, prow + n2);
+}
+
+// ---------------------------------------------------------------------------
+// One-stream GEMV-N -> GEMV-T over the SAME matrix (onepass_kernel).  For y[row] = M[row, :ncN] . t followed by
+// sums over rows of M[row, j] * v_k[row] (k < NV vectors produced from y by the row functor), a wave keeps a
+// 16-row x (4*CPL)-column tile of M in registers between the two products, so M is streamed from HBM once instead
+// of twice.  No LDS traffic and no barrier in the tile loop; the next tile's loads are issued while the current
+// tile's second product runs.  Loads go through a buffer descriptor (uniform column base + one 32-bit lane
+// offset), so the tile costs no address registers.
+//   Lane layout (lane bits 5..0 = R R H H r r): row = 4*RR + rr of the tile, column group H; register c of a lane is
+// column 4c + H.  One wave instruction reads, per column group, the 16 rows of one 128-byte line (measured: 128-byte
+// segments stream at the same rate as 512-byte ones, 64-byte ones at 70 %, tools/micro/segprobe.hip).
+//   The second product does NOT keep one accumulator per (lane, column): four columns at a time, the products are
+// summed over the row bits RR with two transposing lane swaps (v_permlane32_swap, v_permlane16_swap -- each swap
+// halves the number of live values), so a lane accumulates ceil(CPL/4) values per vector instead of CPL.  That is
+// what lets 2-3 waves per SIMD (enough loads in flight to saturate HBM) coexist with a register-resident tile.
+//   A workgroup owns kPadRows rows (tiles interleaved over its 4 waves) and emits ONE partial row, like the other
+// streaming kernels:  part[wg][k*ncT + j] (k < NV, j < ncT), then part[wg][NV*ncT + r] (r < NRED).
+// Users: the Newton-retraction step (retract.hip) and the fused projected-CG iteration (projcg.hip).
+//   EP::skip()                    uniform: launch is a no-op
+//   EP::Row, EP::fetch(o)         per-row inputs at byte offset o = row*8, fetched one tile ahead of their use
+//   EP::apply(row, o, acc, valid, owner, in, v[NV], red[NRED])   row update; `owner` lanes (one per row) store
+// Host guarantees ncN >= 4, 3*ld*8 + kPadRows*8 < 2^32 and (n + kPadRows)*8 < 2^32.
+// ---------------------------------------------------------------------------
+// (lanes l, l^BIT) hold (x0, x1) each: returns, in the lanes with BIT clear, x0(l) + x0(l^BIT); with BIT set, x1(l) + x1(l^BIT)
+template <int BIT>
+__device__ __forceinline__ double swap_add(double x0, double x1) {
+    const uint64_t u0 = __builtin_bit_cast(uint64_t, x0), u1 = __builtin_bit_cast(uint64_t, x1);
+    uint32_t a_lo, a_hi, b_lo, b_hi;
+    if (BIT == 32) {
+        const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)u0, (uint32_t)u1, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(u0 >> 32), (uint32_t)(u1 >> 32), false, false);
+        a_lo = lo[0]; b_lo = lo[1]; a_hi = hi[0]; b_hi = hi[1];
+    } else {
+        const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)u0, (uint32_t)u1, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(u0 >> 32), (uint32_t)(u1 >> 32), false, false);
+        a_lo = lo[0]; b_lo = lo[1]; a_hi = hi[0]; b_hi = hi[1];
+    }
+    return __builtin_bit_cast(double, ((uint64_t)a_hi << 32) | a_lo) + __builtin_bit_cast(double, ((uint64_t)b_hi << 32) | b_lo);
+}
+
+template <class EP, int NV, int NRED, int CPL, bool NT>
+__global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
+                                                            const double* __restrict__ t, EP ep, double* __restrict__ part, int part_ld) {
+    if (ep.skip()) return;
+    constexpr int CW = 4, RW = 16;                   // column groups per wave, rows per wave tile
+    constexpr int kStep = RW * kWaves;               // rows the workgroup advances per tile round
+    constexpr int kTiles = kPadRows / kStep;
+    constexpr int NC = CW * CPL;
+    constexpr int NQ = (CPL + 3) / 4;                // accumulators per lane and vector
+    static_assert(NC <= kColChunk, "column block must fit the LDS staging row");
+    __shared__ double ts[NC];
+    __shared__ double red[kWaves][NV][NC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = (lane & 3) | ((lane >> 4) << 2), h = (lane >> 2) & 3;
+    // Column groups: group g < glast holds columns g*CW .. g*CW+CW-1; the last group is shifted back to the columns
+    // ncN-CW .. ncN-1 (all valid; the ones it shares with group glast-1 get a zero coefficient), groups past it
+    // re-read it with zero coefficients.  Slot s = g*CW + h of ts[] / red[] therefore maps to one column.
+    const int glast = (ncN - 1) / CW;
+    const int lastc0 = ncN - CW;
+    for (int j = threadIdx.x; j < NC; j += kThreads) {
+        const int g = j / CW, hh = j - g * CW;
+        double v = 0.0;
+        if (g < glast) v = ld_scal(t + j);
+        else if (g == glast && lastc0 + hh >= glast * CW) v = ld_scal(t + lastc0 + hh);
+        ts[j] = v;
+    }
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * kPadRows;                        // uniform
+    const int lrow = wave * RW + r;                                              // row within the block, tile 0
+    const uint32_t vo = (uint32_t)(lrow * 8) + (uint32_t)((int64_t)h * ld * 8);  // lane offset: row, and column within the group
+    const char* Mb = reinterpret_cast<const char*>(M + row0);
+    const int64_t cs = (int64_t)CW * ld * 8;
+    const int64_t last_off = (int64_t)lastc0 * ld * 8;
+    auto load_tile = [&](double (&a)[CPL], int k) {
+        const char* sb = Mb + (int64_t)k * (kStep * 8);                                  // wave-uniform
+        const char* lastb = sb + last_off;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            a[c] = buf_load_f64<NT>((c < glast) ? sb : lastb, vo);
+            sb += cs;
+        }
+    };
+    double a[CPL], p[NV][NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) p[q][j] = 0.0;
+    load_tile(a, 0);
+    uint32_t ro = (uint32_t)((row0 + lrow) * 8);
+    typename EP::Row in = ep.fetch(ro);
+    double rsum[NRED > 0 ? NRED : 1];
+#pragma unroll
+    for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) rsum[q] = 0.0;
+    auto tile_step = [&](int k, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        compiler_fence();               // re-read ts[] from LDS every tile instead of pinning 2*CPL registers on it
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc = fma(a[c], ts[c * CW + h], acc);
+        acc += __shfl_xor(acc, 4);      // sum over the column groups H (commutative pairings: every lane of a row agrees)
+        acc += __shfl_xor(acc, 8);
+        const int64_t row = row0 + lrow + (int64_t)k * kStep;
+        typename EP::Row in_next = in;
+        if (MORE) in_next = ep.fetch(ro + kStep * 8);
+        double v[NV];
+        ep.apply(row, ro, acc, row < n, h == 0, in, v, rsum);
+        // second product: columns 4j .. 4j+3 of this lane's group, summed over the row bits RR by two transposing swaps;
+        // afterwards the lane holds the 4-row sum of column register 4j + 2*bit4 + bit5
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const double x0 = a[4 * j] * v[q];
+                const double x1 = (4 * j + 1 < CPL) ? a[(4 * j + 1 < CPL) ? 4 * j + 1 : 0] * v[q] : 0.0;
+                const double x2 = (4 * j + 2 < CPL) ? a[(4 * j + 2 < CPL) ? 4 * j + 2 : 0] * v[q] : 0.0;
+                const double x3 = (4 * j + 3 < CPL) ? a[(4 * j + 3 < CPL) ? 4 * j + 3 : 0] * v[q] : 0.0;
+                const double w01 = swap_add<32>(x0, x1);
+                const double w23 = swap_add<32>(x2, x3);
+                p[q][j] += swap_add<16>(w01, w23);
+            }
+        compiler_fence();               // the next tile's loads reuse a[]: keep them below its last use (no second buffer)
+        if (MORE) load_tile(a, k + 1);
+        in = in_next;
+        ro += kStep * 8;
+    };
+#pragma unroll 1
+    for (int k = 0; k < kTiles - 1; ++k) tile_step(k, std::true_type());
+    tile_step(kTiles - 1, std::false_type());
+    const int creg = 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);     // which of the 4 column registers this lane accumulated
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            double s = p[q][j];
+            s += __shfl_xor(s, 1);       // the remaining row bits rr
+            s += __shfl_xor(s, 2);
+            const int c = 4 * j + creg;
+            if ((lane & 3) == 0 && c < CPL) red[wave][q][c * CW + h] = s;
+        }
+    __syncthreads();
+    double* prow = part + (int64_t)blockIdx.x * part_ld;
+    for (int j = threadIdx.x; j < NV * ncT; j += kThreads) {
+        const int q = j / ncT, col = j - q * ncT;
+        const int sl = (col < glast * CW) ? col : (glast * CW + (col - lastc0));       // slot holding column `col`
+        prow[j] = (red[0][q][sl] + red[1][q][sl]) + (red[2][q][sl] + red[3][q][sl]);
+    }
+    if (NRED > 0) block_reduce_store<(NRED > 0 ? NRED : 1)>(rsum, 0u, prow + NV * ncT);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,5 +1,23 @@
 // Projected conjugate gradient on the device -- the reference's projcg!
-// (src/projcg.jl:40-121) as three fused streaming kernels per iteration:
+// (src/projcg.jl:40-121).
+//
+// DEFAULT: ONE pass over U per iteration (fused iteration, "F" below).  The projection of iteration k,
+//   gp = rp - U (U'rp)  (:95-97), needs U twice: U'rp (all rows) and then U*(U'rp).  But
+//   rp_{k+1} = g_{k+1} + alpha_{k+1} A d_{k+1},  d_{k+1} = -g_{k+1} + beta_{k+1} d_k   (:93, :99)  is LINEAR in vectors that are
+//   known row by row as soon as g_{k+1} = gp exists, so
+//       U'rp_{k+1} = t1 + alpha_{k+1} * t3_{k+1},   t1 = U'g_{k+1},  t2 = U'(A g_{k+1}),  t3_{k+1} = U'(A d_{k+1}) = -t2 + beta_{k+1} t3_k
+//   and t1, t2 are accumulated by the SAME kernel that forms g_{k+1}, over the row tile it still holds in registers
+//   (onepass_kernel, kernels.h).  Per iteration:
+//     K1  x += alpha_prev*d (deferred :92) ; d = beta*d - g ; partial d'(A d)   (vec_kernel)   :99, :74-75
+//         post: exits :77-87, alpha = rg/dAd :91 ;  Utr = t1 + alpha*t3  (m-vector kernel)
+//     F   rp = g + alpha A d (registers) ; gp = rp - U*Utr ; g = gp ; partials rp'gp, gp'gp, U'gp, U'(A gp)   :93-103
+//         post: beta :98, rg, nr, convergence / iteration limit :103-111
+//   = 8 n m + 80 n bytes instead of 16 n m + 104 n.  dAd, alpha, beta, rg, nr are computed exactly as in the reference;
+//   only U'rp is assembled from three exactly-computed pieces instead of one product, a difference of the same size as a
+//   change of summation order (t1 = U'g re-measures the basis component of g every iteration, so nothing accumulates).
+//   Used for a diagonal operator A and 4 <= m <= 256 columns; otherwise (and with LFPSQP_ONEPASS=-1):
+//
+// FALLBACK: three fused streaming kernels per iteration, two passes over U:
 //
 //   K1  x += alpha_prev*d (deferred :92) ; d = beta*d - g ; partial d'(A d)   (vec_kernel)     :99, :74-75
 //   K2  alpha = rg/dAd ; rp = g + alpha A d formed on the fly ; partial U' rp (gemv_t_kernel)  :91-96
@@ -35,6 +53,11 @@ struct AOpD {  // A = a0*I + diag(dg)
         }
         return make_double2(a0 * d.x, a0 * d.y);
     }
+};
+
+struct StackD {   // stacked (bound-constrained) basis Q = [[diag Dx; diag Dy], [sx.*Z; sy.*Z]]
+    int64_t hs;
+    const double *Dx, *Dy, *sx, *sy;
 };
 
 // ---- K1 -----------------------------------------------------------------------
@@ -153,9 +176,10 @@ struct PcgPost3 {  // beta, next rg, nr, convergence / iteration-limit exits (:9
     int64_t* istat;
     int init;
     HostMirror hm;
+    const double* src;   // [rp'gp, gp'gp] (scal + S_RPGP for the two-pass kernels, the tail of the fused kernel's output otherwise)
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ void run(double*) const {
-        const double rpgp = ld_scal(scal + S_RPGP), gpgp = ld_scal(scal + S_GPGP);
+        const double rpgp = ld_scal(src), gpgp = ld_scal(src + 1);
         if (init) {
             scal[S_RG] = gpgp;
             int64_t st0 = ST_RUNNING;
@@ -175,6 +199,99 @@ struct PcgPost3 {  // beta, next rg, nr, convergence / iteration-limit exits (:9
         hm.publish(st, it, nr);
     }
 };
+
+// ---- F: the fused iteration (one pass over U) -----------------------------------------------------------
+// Row functor of onepass_kernel: N-product acc = U[row, :] . Utr arrives, the row's residual is projected and stored,
+// and the two T-vectors (gp, A gp) go back into the same tile.  init = 1: the initial projection (:58-62): rp is the
+// stored residual and d = -g is written.  ST = stacked (bound) form, cf. PcgProjES.
+template <bool ST>
+struct PcgFuseE {
+    const double* rp;   // stored initial residual (init only)
+    double* g;
+    double* d;
+    AOpD A;
+    const double* scal;
+    const int64_t* istat;
+    int init;
+    StackD k;           // stacked only
+    struct Row { double alpha, gx, dx, ax, r0x, gy, dy, ay, r0y, Dx, Dy, sx, sy; };
+    static __device__ __forceinline__ double at(const double* base, uint32_t o) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
+    }
+    static __device__ __forceinline__ void put(double* base, uint32_t o, double v) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + o) = v;
+    }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        Row w;
+        w.alpha = init ? 0.0 : ld_scal(scal + S_ALPHA);
+        w.gx = init ? 0.0 : at(g, o);
+        w.dx = init ? 0.0 : at(d, o);
+        w.ax = A.a0 + (A.dg ? at(A.dg, o) : 0.0);
+        w.r0x = init ? at(rp, o) : 0.0;
+        if (ST) {
+            w.gy = init ? 0.0 : at(g + k.hs, o);
+            w.dy = init ? 0.0 : at(d + k.hs, o);
+            w.ay = A.a0 + (A.dg ? at(A.dg + k.hs, o) : 0.0);
+            w.r0y = init ? at(rp + k.hs, o) : 0.0;
+            w.Dx = at(k.Dx, o); w.Dy = at(k.Dy, o); w.sx = at(k.sx, o); w.sy = at(k.sy, o);
+        } else {
+            w.gy = w.dy = w.ay = w.r0y = w.Dx = w.Dy = w.sx = w.sy = 0.0;
+        }
+        return w;
+    }
+    __device__ __forceinline__ void apply(int64_t, uint32_t o, double acc, bool valid, bool owner, const Row& w, double (&v)[2],
+                                          double (&red)[2]) const {
+        const bool st = valid && owner;
+        if (!ST) {
+            const double rr = init ? w.r0x : fma(w.alpha, w.ax * w.dx, w.gx);        // :93 (same expression as PcgStepV::rp_at)
+            const double gp = rr - acc;                                              // :97
+            if (st) {
+                put(g, o, gp);
+                if (init) put(d, o, -gp);                                            // :62
+                red[0] += rr * gp;                                                   // :98
+                red[1] += gp * gp;                                                   // :84 / :103
+            }
+            v[0] = valid ? gp : 0.0;
+            v[1] = valid ? w.ax * gp : 0.0;
+        } else {
+            const double rx = init ? w.r0x : fma(w.alpha, w.ax * w.dx, w.gx);
+            const double ry = init ? w.r0y : fma(w.alpha, w.ay * w.dy, w.gy);
+            const double ww = w.Dx * rx + w.Dy * ry;                                 // diagonal block of Q'rp
+            const double gx = rx - fma(w.sx, acc, w.Dx * ww);
+            const double gy = ry - fma(w.sy, acc, w.Dy * ww);
+            if (st) {
+                put(g, o, gx); put(g + k.hs, o, gy);
+                if (init) { put(d, o, -gx); put(d + k.hs, o, -gy); }
+                red[0] += rx * gx + ry * gy;
+                red[1] += gx * gx + gy * gy;
+            }
+            v[0] = valid ? (w.sx * gx + w.sy * gy) : 0.0;                            // the Z-block of Q'g
+            v[1] = valid ? (w.sx * (w.ax * gx) + w.sy * (w.ay * gy)) : 0.0;          // ... of Q'(A g)
+        }
+    }
+};
+
+// Utr = t1 + alpha * t3,  t3 = -t2 + beta * t3  (first iteration: t3 = -t2, since d0 = -g0)
+struct PcgUtr {
+    const double* T;      // [t1 (m) ; t2 (m)] from the fused kernel
+    double* t3;
+    double* Utr;
+    const double* scal;
+    const int64_t* istat;
+    int m, first;
+};
+__global__ __launch_bounds__(256) void pcg_utr_kernel(PcgUtr u) {
+    if (ld_stat(u.istat + I_STATUS) != ST_RUNNING) return;
+    const double alpha = ld_scal(u.scal + S_ALPHA);
+    const double beta = u.first ? 0.0 : ld_scal(u.scal + S_BETA);
+    for (int j = threadIdx.x; j < u.m; j += 256) {
+        const double t1 = ld_scal(u.T + j), t2 = ld_scal(u.T + u.m + j);
+        const double t3 = u.first ? -t2 : fma(beta, u.t3[j], -t2);
+        u.t3[j] = t3;
+        u.Utr[j] = fma(alpha, t3, t1);
+    }
+}
 
 // ---- setup / teardown functors --------------------------------------------------
 struct ResidualV {  // v = sgn*(A x - b), optionally stored   (:56-57 with sgn=+1, :115-116 with sgn=-1)
@@ -252,10 +369,6 @@ struct NormalizeIntoF {  // x = d / sqrt(dd)    (:79)
 // ---- stacked (bound-constrained) variants: Q = [[diag Dx; diag Dy], [sx.*Z; sy.*Z]] -------
 // One workgroup row r of the N x M matrix Z serves BOTH halves of the 2N-vectors, so the
 // whole projection costs one pass over Z where the reference streams a 2N x M factor.
-struct StackD {
-    int64_t hs;
-    const double *Dx, *Dy, *sx, *sy;
-};
 struct PcgStepVS {
     PcgStepV p;
     StackD k;
@@ -372,9 +485,30 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     };
     auto launch_k3 = [&](int init) -> int {
         const PcgProjE pe{rp, g, d, istat, init, PcgStepV{d, g, Ad, scal, istat}};
-        const PcgPost3 post{scal, istat, init, hm};
+        const PcgPost3 post{scal, istat, init, hm, scal + S_RPGP};
         if (stacked) return run_gemv_n<PcgProjES, 2, PcgPost3>(ctx, Z, m, N, Utr, PcgProjES{pe, sk}, scal + S_RPGP, post, init ? -1 : 2);
         return run_gemv_n<PcgProjE, 2, PcgPost3>(ctx, Z, m, N, Utr, pe, scal + S_RPGP, post, init ? -1 : 2);
+    };
+
+    // fused iteration (one pass over U)?  Needs a tile shape for m columns and 32-bit lane offsets
+    const bool fused = m > 0 && onepass_cw(ctx, m, Z->ld, N) != 0;
+    double *T12 = nullptr, *t3 = nullptr;
+    if (fused) {
+        LF_TRY(ensure_mvec(ctx, (size_t)3 * m + 16));
+        T12 = ctx->d_m;                                  // [t1 (m); t2 (m); rp'gp; gp'gp]
+        t3 = ctx->d_m + round_up(2 * m + 2, 2);
+    }
+    auto launch_fused = [&](int init) -> int {
+        if (stacked) {
+            const PcgFuseE<true> fe{rp, g, d, Ad, scal, istat, init, sk};
+            LF_TRY((run_onepass<PcgFuseE<true>, 2, 2>(ctx, Z, m, m, N, Utr, fe, T12, init ? -1 : 3)));
+        } else {
+            const PcgFuseE<false> fe{rp, g, d, Ad, scal, istat, init, sk};
+            LF_TRY((run_onepass<PcgFuseE<false>, 2, 2>(ctx, Z, m, m, N, Utr, fe, T12, init ? -1 : 3)));
+        }
+        hipLaunchKernelGGL((post_kernel<PcgPost3>), dim3(1), dim3(1), 0, ctx->stream, scal, PcgPost3{scal, istat, init, hm, T12 + 2 * m});
+        LF_LAUNCH_CHECK(ctx);
+        return 0;
     };
 
     hipLaunchKernelGGL((post_kernel<InitState>), dim3(1), dim3(1), 0, ctx->stream, scal, InitState{scal, istat, tol, maxit_eff});
@@ -388,15 +522,22 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     }
     // r = A x - b (kept in rp), Utr = U' r, g = r - U Utr, d = -g, rg = g'g   (:56-62)
     LF_TRY(launch_residual(1.0, rp, Utr));
-    LF_TRY(launch_k3(1));
+    if (fused) LF_TRY(launch_fused(1));
+    else LF_TRY(launch_k3(1));
 
     int64_t it = 0;
     bool done = false;
     while (!done && it < maxit_eff) {
         LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, nv, PcgDirF{d, g, x->p, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
                                               PcgPost1{scal, istat, hm}, 0)));
-        LF_TRY(launch_k2());
-        LF_TRY(launch_k3(0));
+        if (fused) {
+            hipLaunchKernelGGL(pcg_utr_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgUtr{T12, t3, Utr, scal, istat, m, it == 0 ? 1 : 0});
+            LF_LAUNCH_CHECK(ctx);
+            LF_TRY(launch_fused(0));
+        } else {
+            LF_TRY(launch_k2());
+            LF_TRY(launch_k3(0));
+        }
         // throttle: stay at most two iterations ahead of the GPU; stop on the status of iteration it-2
         // (device iteration number it-1), which is final once its event has completed -- see HostMirror
         LF_HIP(ctx, hipEventRecord(ctx->ev_slot[it & 3], ctx->stream));

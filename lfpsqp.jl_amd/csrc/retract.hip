@@ -160,105 +160,21 @@ struct NRStepE {
     }
 };
 
-// ---------------------------------------------------------------------------
-// One-stream Newton step.  When the basis was formed as Z = Jct * W (lfpsqp_factorize), the step product is
-// U*delta = [sx; sy] .* (Jct * (W*delta)), so BOTH products of a Newton step (src/retractions.jl:141 and the c! of
-// :146/148) run over the same rows of the same matrix.  A wave keeps a (64/CW)-row x (CW*CPL)-column tile of Jct in
-// registers between the two products -- lane (r, h) holds row r, columns h, h+CW, h+2CW, ... -- so Jct is streamed
-// from HBM once per step instead of Z once plus Jct once.  No LDS traffic and no barrier in the tile loop; the
-// next tile's loads are issued while the current tile's second product runs.  Addresses are a uniform (scalar)
-// column base plus a 32-bit lane offset, so the tile costs no address registers.  A workgroup owns kPadRows rows
-// (tiles interleaved over its 4 waves) and emits one partial row, like the other streaming kernels.
-//   t = W*delta (ncN entries); part[wg][0:ncT) = sum_rows Jct[row, j] * xnew[row]; part[wg][ncT] = ball partial.
-// ST = stacked vectors (bounds).  Host guarantees (CW-1)*ld*8 + kPadRows*8 < 2^32 and (n + kPadRows)*8 < 2^32.
-// ---------------------------------------------------------------------------
-template <int CPL, int CW, bool NT, bool ST>
-__global__ __launch_bounds__(kThreads) void nr_onepass_kernel(const double* __restrict__ J, int64_t ld, int ncN, int ncT, int64_t n,
-                                                               const double* __restrict__ t, NRStepE ep, double* __restrict__ part,
-                                                               int part_ld) {
-    if (ep.skip()) return;
-    constexpr int RW = 64 / CW;                      // rows per wave tile
-    constexpr int kStep = RW * kWaves;               // rows the workgroup advances per tile round
-    constexpr int kTiles = kPadRows / kStep;
-    constexpr int NC = CW * CPL;
-    static_assert(NC <= kColChunk, "column block must fit the LDS staging row");
-    __shared__ double ts[NC];
-    __shared__ double red[kWaves][NC];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & (RW - 1), h = lane / RW;
-    // Column groups: group g < glast holds columns g*CW .. g*CW+CW-1; the last group is shifted back to the columns
-    // ncN-CW .. ncN-1 (all valid; the ones it shares with group glast-1 get a zero coefficient), groups past it
-    // re-read it with zero coefficients.  Slot s = g*CW + h of ts[] / red[] therefore maps to column col_of(s).
-    const int glast = (ncN - 1) / CW;                                            // host guarantees ncN >= CW
-    const int lastc0 = ncN - CW;
-    for (int j = threadIdx.x; j < NC; j += kThreads) {
-        const int g = j / CW, hh = j - g * CW;
-        double v = 0.0;
-        if (g < glast) v = t[j];
-        else if (g == glast && lastc0 + hh >= glast * CW) v = t[lastc0 + hh];
-        ts[j] = v;
+// One-stream Newton step (onepass_kernel, kernels.h).  When the basis was formed as Z = Jct * W (lfpsqp_factorize), the
+// step product is U*delta = [sx; sy] .* (Jct * (W*delta)), so BOTH products of a Newton step (src/retractions.jl:141 and
+// the c! of :146/148) run over the same rows of the same matrix: Jct is streamed once per step instead of Z plus Jct.
+//   t = W*delta; out[0:m_lin) = Jct[:, :m_lin]' xnew; out[m_lin] = ball partial.   ST = stacked vectors (bounds).
+template <bool ST>
+struct NRStepRow {
+    NRStepE e;
+    using Row = NRStepE::Row;
+    __device__ __forceinline__ bool skip() const { return e.skip(); }
+    __device__ __forceinline__ Row fetch(uint32_t o) const { return e.fetch1<ST>(o); }
+    __device__ __forceinline__ void apply(int64_t i, uint32_t o, double acc, bool valid, bool owner, const Row& w, double (&v)[1],
+                                          double (&red)[1]) const {
+        v[0] = e.apply1<ST>(i, o, acc, valid, owner, w, red[0]);
     }
-    __syncthreads();
-    const int64_t row0 = (int64_t)blockIdx.x * kPadRows;                        // uniform
-    const int lrow = wave * RW + r;                                              // row within the block, tile 0
-    const uint32_t vo = (uint32_t)(lrow * 8) + (uint32_t)((int64_t)h * ld * 8);  // lane offset: row, and column within the group
-    const char* Jb = reinterpret_cast<const char*>(J + row0);
-    const int64_t cs = (int64_t)CW * ld * 8;
-    const int64_t last_off = (int64_t)lastc0 * ld * 8;
-    auto load_tile = [&](double (&a)[CPL], int k) {
-        const char* sb = Jb + (int64_t)k * (kStep * 8);                                  // wave-uniform
-        const char* lastb = sb + last_off;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            a[c] = buf_load_f64<NT>((c < glast) ? sb : lastb, vo);
-            sb += cs;
-        }
-    };
-    double a[CPL], p[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) p[c] = 0.0;
-    load_tile(a, 0);
-    uint32_t ro = (uint32_t)((row0 + lrow) * 8);
-    NRStepE::Row in = ep.fetch1<ST>(ro);
-    double rsum = 0.0;
-    auto tile_step = [&](int k, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        compiler_fence();               // re-read ts[] from LDS every tile instead of pinning 2*CPL registers on it
-        double acc = 0.0;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) acc = fma(a[c], ts[c * CW + h], acc);
-#pragma unroll
-        for (int o = RW; o < 64; o <<= 1) acc += __shfl_xor(acc, o);          // commutative pairings: every lane of a row agrees
-        const int64_t row = row0 + lrow + (int64_t)k * kStep;
-        NRStepE::Row in_next = in;
-        if (MORE) in_next = ep.fetch1<ST>(ro + kStep * 8);
-        const double v = ep.apply1<ST>(row, ro, acc, row < n, h == 0, in, rsum);
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) p[c] = fma(a[c], v, p[c]);
-        compiler_fence();               // the next tile's loads reuse a[]: keep them below its last use (no second buffer)
-        if (MORE) load_tile(a, k + 1);
-        in = in_next;
-        ro += kStep * 8;
-    };
-#pragma unroll 1
-    for (int k = 0; k < kTiles - 1; ++k) tile_step(k, std::true_type());
-    tile_step(kTiles - 1, std::false_type());
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        double s = p[c];
-#pragma unroll
-        for (int o = RW / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (r == 0) red[wave][c * CW + h] = s;
-    }
-    __syncthreads();
-    double* prow = part + (int64_t)blockIdx.x * part_ld;
-    for (int j = threadIdx.x; j < ncT; j += kThreads) {
-        const int sl = (j < glast * CW) ? j : (glast * CW + (j - lastc0));       // slot holding column j
-        prow[j] = (red[0][sl] + red[1][sl]) + (red[2][sl] + red[3][sl]);
-    }
-    double rs[1] = {rsum};
-    block_reduce_store<1>(rs, 0u, prow + ncT);
-}
+};
 
 // The replicated m x m part of the Newton retraction on the device (src/retractions.jl:126-160): turns the raw
 // constraint products of the fused step into c(xnew), applies the good-Broyden update of the inverse Jacobian
@@ -386,68 +302,6 @@ __global__ __launch_bounds__(kNRThreads) void nr_small_kernel(NRSmall s, int ini
     }
 }
 
-// smallest instantiated (CPL, CW) tile covering ncN columns; 0 if none (then the two-stream kernel is used)
-static int nr_onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
-    if (ctx->tune_nr < 0 || ncN > kColChunk) return 0;
-    int cw = (ctx->tune_nr == 2 || ctx->tune_nr == 4 || ctx->tune_nr == 8) ? ctx->tune_nr : 4;
-    while (cw > 2 && ncN < cw) cw >>= 1;
-    if (ncN < cw) return 0;
-    // 32-bit lane offsets: column-within-group stride and the row byte offset must fit
-    if ((int64_t)(cw - 1) * ld * 8 + (int64_t)kPadRows * 8 >= ((int64_t)1 << 32) || (n + kPadRows) * 8 >= ((int64_t)1 << 32)) return 0;
-    return cw;
-}
-
-// out[0:ncT] = Jct[:, :ncT]' xnew, out[ncT] = ball partial, after xnew += [sx; sy] .* (Jct[:, :ncN] * t)  (all-reduced)
-static int run_nr_onepass(lfpsqp_ctx* ctx, int cw, const lfpsqp_mat* J, int ncN, int ncT, int64_t n, const double* t, const NRStepE& ep,
-                          double* out) {
-    const int64_t tiles = (n + kPadRows - 1) / kPadRows;
-    const int nout = ncT + 1;
-    const int part_ld = (int)round_up(nout, 32);
-    if (tiles > 0) {
-        LF_TRY(ensure_part(ctx, (size_t)tiles * part_ld + reduce_scratch(part_ld)));
-        const int cpl = (ncN + cw - 1) / cw;
-#define LF_NR1(CPL, CW)                                                                                                                  \
-    do {                                                                                                                                 \
-        if (ep.hs != 0)                                                                                                                  \
-            hipLaunchKernelGGL((nr_onepass_kernel<CPL, CW, true, true>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, J->p,   \
-                               J->ld, ncN, ncT, n, t, ep, ctx->part, part_ld);                                                           \
-        else                                                                                                                             \
-            hipLaunchKernelGGL((nr_onepass_kernel<CPL, CW, true, false>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, J->p,  \
-                               J->ld, ncN, ncT, n, t, ep, ctx->part, part_ld);                                                           \
-    } while (0)
-        if (cw == 8) {
-            if (cpl <= 4) LF_NR1(4, 8);
-            else if (cpl <= 8) LF_NR1(8, 8);
-            else if (cpl <= 12) LF_NR1(12, 8);
-            else if (cpl <= 17) LF_NR1(17, 8);
-            else if (cpl <= 24) LF_NR1(24, 8);
-            else LF_NR1(32, 8);
-        } else if (cw == 4) {
-            if (cpl <= 4) LF_NR1(4, 4);
-            else if (cpl <= 8) LF_NR1(8, 4);
-            else if (cpl <= 16) LF_NR1(16, 4);
-            else if (cpl <= 24) LF_NR1(24, 4);
-            else if (cpl <= 33) LF_NR1(33, 4);
-            else if (cpl <= 48) LF_NR1(48, 4);
-            else LF_NR1(64, 4);
-        } else {
-            if (cpl <= 8) LF_NR1(8, 2);
-            else if (cpl <= 16) LF_NR1(16, 2);
-            else if (cpl <= 32) LF_NR1(32, 2);
-            else if (cpl <= 48) LF_NR1(48, 2);
-            else if (cpl <= 66) LF_NR1(66, 2);
-            else if (cpl <= 96) LF_NR1(96, 2);
-            else LF_NR1(128, 2);
-        }
-#undef LF_NR1
-        LF_LAUNCH_CHECK(ctx);
-        LF_TRY(launch_reduce(ctx, tiles, nout, part_ld, 0u, out, NoPost()));
-    } else {
-        LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
-    }
-    return allreduce_dev(ctx, out, nout);
-}
-
 int cons_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval) {
     const lfpsqp_mat* J = cons->Jct;
     const int ml = (int)cons->m_lin;
@@ -508,7 +362,7 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         const size_t mm = (size_t)m * m;
         // one-stream step: the caller vouches that U->Z == U->A * U->W and A is the matrix c! streams anyway
         const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kNRMaxM) ? (int)U->A->m : 0;
-        const int cw = wm ? nr_onepass_cw(ctx, wm, cons->Jct->ld, N) : 0;
+        const int cw = wm ? onepass_cw(ctx, wm, cons->Jct->ld, N) : 0;
         const size_t wsz = cw ? (((size_t)wm * m + (size_t)wm + 1) & ~(size_t)1) : 0;
         LF_TRY(ensure_small(ctx, 2 * mm + wsz + 8 * (size_t)m + 256));
         double* dD = ctx->small;
@@ -545,7 +399,8 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         bool done = false;
         while (!done && it < maxiter) {
             // step `it`: xnew += U delta, y_retract!, raw c! products (one launch) ; Broyden + test + next delta (one workgroup)
-            if (cw) LF_TRY(run_nr_onepass(ctx, cw, cons->Jct, wm, ml, N, dwdelta, ep, draw));
+            if (cw && ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<true>{ep}, draw)));
+            else if (cw) LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<false>{ep}, draw)));
             else if (cons->has_ball) LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
             else LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
             hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sm, 0);

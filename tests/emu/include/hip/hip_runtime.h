@@ -253,6 +253,15 @@ static inline void __syncthreads() { hipemu::syncthreads(); }
 template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return hipemu::shfl_generic(v, (threadIdx.x & 63) ^ (unsigned)mask); }
 template <class T> static inline T __shfl_down(T v, unsigned d, int = 64) { unsigned l = threadIdx.x & 63; return hipemu::shfl_generic(v, l + d < 64 ? l + d : l); }
 template <class T> static inline T __shfl(T v, int src, int = 64) { return hipemu::shfl_generic(v, (unsigned)src); }
+// v_permlane32_swap / v_permlane16_swap (semantics probed on MI355X, tools/micro/permlane_probe.hip): lanes with the
+// bit clear get {own a, partner's a}, lanes with it set get {partner's b, own b}
+struct hipemu_u32x2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+static inline hipemu_u32x2 hipemu_permlane_swap(unsigned a, unsigned b, unsigned bit) {
+    const unsigned pa = __shfl_xor(a, (int)bit), pb = __shfl_xor(b, (int)bit);
+    return (threadIdx.x & bit) ? hipemu_u32x2{{pb, b}} : hipemu_u32x2{{a, pa}};
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) hipemu_permlane_swap((a), (b), 32u)
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) hipemu_permlane_swap((a), (b), 16u)
 // buffer-descriptor loads (scalar base + 32-bit lane offset)
 struct __amdgpu_buffer_rsrc_t { const char* base; };
 static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return {static_cast<const char*>(p)}; }
