@@ -224,6 +224,7 @@ def main(argv=None, lib=None):
         pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("pmc_summary.json"))
         if pmc and world == 1 and n == 10_000_000 and m == 128:
             summ = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
+            summ = summ.get("kernels", summ)
             for name, v in summ.items():
                 if ("onepass_kernel<lfpsqp::PcgFuseE" if fused else "gemv_t_kernel<lfpsqp::PcgStepV") in name:
                     out["roofline"]["traffic"] = v["traffic_GB"] * 1e9

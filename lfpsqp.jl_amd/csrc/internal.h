@@ -268,16 +268,18 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
         LF_TRY(ensure_part(ctx, (size_t)tiles * part_ld + reduce_scratch(part_ld)));
         const int cpl = (ncN + 3) / 4;
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);
-#define LF_OP(CPL)                                                                                                                      \
-    hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, true>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, M->p, M->ld, \
+#define LF_OP(CPL, EXACT)                                                                                                                 \
+    hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, M->p, M->ld, \
                        ncN, ncT, n, t, ep, ctx->part, part_ld)
-        if (cpl <= 4) LF_OP(4);
-        else if (cpl <= 8) LF_OP(8);
-        else if (cpl <= 16) LF_OP(16);
-        else if (cpl <= 24) LF_OP(24);
-        else if (cpl <= 33) LF_OP(33);
-        else if (cpl <= 48) LF_OP(48);
-        else LF_OP(64);
+        if (cpl <= 4) LF_OP(4, false);
+        else if (cpl <= 8) LF_OP(8, false);
+        else if (cpl <= 16) LF_OP(16, false);
+        else if (cpl <= 24) LF_OP(24, false);
+        else if (cpl == 32) LF_OP(32, true);
+        else if (cpl == 33) LF_OP(33, true);
+        else if (cpl <= 33) LF_OP(33, false);
+        else if (cpl <= 48) LF_OP(48, false);
+        else LF_OP(64, false);
 #undef LF_OP
         if (prof_slot >= 0) prof_end(ctx, prof_slot);
         LF_LAUNCH_CHECK(ctx);

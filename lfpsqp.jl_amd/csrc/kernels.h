@@ -358,7 +358,7 @@ __device__ __forceinline__ double swap_add(double x0, double x1) {
     return __builtin_bit_cast(double, ((uint64_t)a_hi << 32) | a_lo) + __builtin_bit_cast(double, ((uint64_t)b_hi << 32) | b_lo);
 }
 
-template <class EP, int NV, int NRED, int CPL, bool NT>
+template <class EP, int NV, int NRED, int CPL, bool EXACT>   // EXACT: ncN > 4*(CPL-1), i.e. the last column group is register CPL-1
 __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
                                                             const double* __restrict__ t, EP ep, double* __restrict__ part, int part_ld) {
     if (ep.skip()) return;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     // Column groups: group g < glast holds columns g*CW .. g*CW+CW-1; the last group is shifted back to the columns
     // ncN-CW .. ncN-1 (all valid; the ones it shares with group glast-1 get a zero coefficient), groups past it
     // re-read it with zero coefficients.  Slot s = g*CW + h of ts[] / red[] therefore maps to one column.
-    const int glast = (ncN - 1) / CW;
+    const int glast = EXACT ? (CPL - 1) : (ncN - 1) / CW;
     const int lastc0 = ncN - CW;
     for (int j = threadIdx.x; j < NC; j += kThreads) {
         const int g = j / CW, hh = j - g * CW;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
         const char* lastb = sb + last_off;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            a[c] = buf_load_f64<NT>((c < glast) ? sb : lastb, vo);
+            a[c] = buf_load_f64<true>((EXACT ? (c < CPL - 1) : (c < glast)) ? sb : lastb, vo);
             sb += cs;
         }
     };

@@ -110,6 +110,32 @@ def test_projcg_matches_oracle(dev_ctx, n, m):
                 assert np.linalg.norm(K) < max(tol, 1e-12)               # test_cg.jl:28
 
 
+@pytest.mark.parametrize("n,m", [(2100, 4), (2500, 33), (2100, 128), (4100, 129)])
+def test_projcg_fused_iteration_matches_two_pass_kernels(dev_ctx, monkeypatch, n, m):
+    """The default projcg iteration makes ONE pass over U (U'rp assembled from U'g and U'(A g), csrc/projcg.hip);
+    LFPSQP_ONEPASS=-1 selects the two-pass kernels.  Same counts, iterates equal to rounding, both equal to the oracle;
+    covers exact / shifted last column groups and the widest instantiated tile."""
+    Uh, a, bh = _cg_problem(n, m)
+    x0, l0 = np.zeros(n), np.zeros(m)
+    i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), Uh, bh, np.zeros(m), tol=1e-12)
+    res = {}
+    for mode in ("-1", "0"):
+        monkeypatch.setenv("LFPSQP_ONEPASS", mode)
+        ctx = L.Context(0, dev_ctx.L)
+        x, lam = ctx.vector(n), ctx.vector(m)
+        it, nr = L.projcg_(x, lam, L.DiagOperator(0.0, ctx.vector(n, a)), L.DeviceBasis(ctx.matrix(n, m, Uh)), ctx.vector(n, bh), None,
+                           tol=1e-12)
+        res[mode] = (it, nr, x.download(), lam.download()[:m])
+        ctx.close()
+    for mode in ("-1", "0"):
+        it, nr, xd, ld = res[mode]
+        assert it == i0 and nr == pytest.approx(nr0, rel=1e-5)
+        assert np.linalg.norm(xd - x0) <= 1e-11 * np.linalg.norm(x0)
+        assert np.abs(ld - l0).max() < 1e-11
+        assert np.linalg.norm(Uh.T @ xd) < 1e-13
+    assert not np.array_equal(res["-1"][2], res["0"][2])          # really two different code paths
+
+
 def test_projcg_negative_curvature(dev_ctx):
     """test_cg.jl:39-55: indefinite A => (i, Inf), lambda = NaN, x a unit direction with x'Ax <= 0."""
     ctx = dev_ctx

@@ -6,7 +6,9 @@ cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
+hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o /tmp/segprobe $R/tools/micro/segprobe.hip 2>/dev/null
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_calib -- /tmp/segprobe > $O/pmc_calib.log 2>&1
 cd $R
-python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_summary.json | head -8
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_summary.json $O/pmc_calib | head -12
 find $O -name "*kernel_trace.csv" -delete
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); head -8 "$f" | cut -c1-180

@@ -28,6 +28,46 @@ __global__ __launch_bounds__(256) void probe(const double* __restrict__ M, int64
     if (acc == 123.456) out[0] = acc;
 }
 
+// persistent variant: `grid` workgroups, each a contiguous, balanced span of 64-row tile rounds
+template <int CW, int UNR>
+__global__ __launch_bounds__(256) void probe_persist(const double* __restrict__ M, int64_t ld, int m, int64_t rounds, double* out) {
+    constexpr int RW = 64 / CW, kStep = RW * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & (RW - 1), h = lane / RW;
+    const int64_t q = rounds / gridDim.x, rem = rounds % gridDim.x;
+    const int64_t t0 = blockIdx.x * q + (blockIdx.x < rem ? blockIdx.x : rem), t1 = t0 + q + (blockIdx.x < rem ? 1 : 0);
+    const double* base = M + wave * RW + r + (int64_t)h * ld;
+    double acc = 0.0;
+    const int groups = m / CW;
+    for (int64_t k = t0; k < t1; ++k) {
+        const double* p = base + k * kStep;
+        for (int c = 0; c < groups; c += UNR) {
+            double v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) v[u] = __builtin_nontemporal_load(p + (int64_t)(c + u) * CW * ld);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) acc += v[u];
+        }
+    }
+    if (acc == 123.456) out[0] = acc;
+}
+template <int CW, int UNR>
+static void run_persist(const double* M, int64_t ld, int64_t n, int m, double* out, int wg_per_cu) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const unsigned grid = 256 * wg_per_cu;
+    const int64_t rounds = n / (64 / CW * 4);
+    probe_persist<CW, UNR><<<grid, 256>>>(M, ld, m, rounds, out);
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) probe_persist<CW, UNR><<<grid, 256>>>(M, ld, m, rounds, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= 5;
+    printf("persistent CW=%d unroll=%2d grid=256x%d : %.3f ms  %.0f GB/s\n", CW, UNR, wg_per_cu, ms, 8.0 * n * m / (ms * 1e-3) / 1e9);
+}
+
 template <int CW, int UNR>
 static void run(const double* M, int64_t ld, int64_t n, int m, double* out) {
     hipEvent_t e0, e1;
@@ -60,5 +100,8 @@ int main() {
     run<4, 32>(M, ld, n, m, out);
     run<4, 8>(M, ld, n, m, out);
     run<2, 8>(M, ld, n, m, out);
+    for (int w : {2, 3, 4, 6, 8}) run_persist<4, 16>(M, ld, n, m, out, w);
+    for (int w : {2, 4, 8}) run_persist<1, 16>(M, ld, n, m, out, w);
+    for (int w : {2, 3, 4}) run_persist<4, 32>(M, ld, n, m, out, w);
     return 0;
 }
