@@ -136,7 +136,10 @@ int lfpsqp_ctx_create(int device, lfpsqp_ctx** out) {
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return set_err(nullptr, LFPSQP_ERR_HIP, "hipSetDevice(%d) failed", device); }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+        ctx->num_cu = prop.multiProcessorCount;
+    }
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess;
     ok = ok && hipMalloc((void**)&ctx->scal, 64 * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc((void**)&ctx->istat, 16 * sizeof(int64_t)) == hipSuccess;

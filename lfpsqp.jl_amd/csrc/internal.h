@@ -42,6 +42,7 @@ struct Comm {
 
 struct lfpsqp_ctx {
     int device = 0;
+    int num_cu = 0;   // compute units (sizes the persistent grid of onepass_kernel)
     hipStream_t stream = nullptr;
     std::string err;
     std::string devname;
@@ -257,20 +258,39 @@ inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
 }
 
 // out[k*ncT + j] = sum_rows M[row, j] * v_k[row] (k < NV, j < ncT), out[NV*ncT + r] = reduction r, with v produced by EP
-// from M[row, :ncN] . t -- all-reduced over ranks; one pass over M.
+// from M[row, :ncN] . t -- all-reduced over ranks; one pass over M.  Persistent grid: as many workgroups as the device
+// keeps resident for this instantiation (occupancy query, cached), capped by the number of 64-row rounds.
+template <class EP, int NV, int NRED, int CPL, bool EXACT>
+inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {
+    static int per_cu = 0;                        // one per kernel instantiation
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, onepass_kernel<EP, NV, NRED, CPL, EXACT>, kThreads, 0) != hipSuccess || nb < 1)
+            nb = 1;
+        per_cu = nb;
+    }
+    int64_t g = (int64_t)per_cu * (ctx->num_cu > 0 ? ctx->num_cu : 1);
+    if (g > rounds) g = rounds;
+    return (int)(g < 1 ? 1 : g);
+}
+
 template <class EP, int NV, int NRED>
 int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t n, const double* t, const EP& ep, double* out,
                 int prof_slot = -1) {
-    const int64_t tiles = (n + kPadRows - 1) / kPadRows;
+    const int64_t rounds = (n + kOnepassRound - 1) / kOnepassRound;
     const int nout = NV * ncT + NRED;
     const int part_ld = (int)round_up(nout, 32);
-    if (tiles > 0) {
-        LF_TRY(ensure_part(ctx, (size_t)tiles * part_ld + reduce_scratch(part_ld)));
+    if (rounds > 0) {
         const int cpl = (ncN + 3) / 4;
-        if (prof_slot >= 0) prof_begin(ctx, prof_slot);
-#define LF_OP(CPL, EXACT)                                                                                                                 \
-    hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, M->p, M->ld, \
-                       ncN, ncT, n, t, ep, ctx->part, part_ld)
+        int grid = 0;
+#define LF_OP(CPL, EXACT)                                                                                                            \
+    do {                                                                                                                             \
+        grid = onepass_grid<EP, NV, NRED, CPL, EXACT>(ctx, rounds);                                                                  \
+        LF_TRY(ensure_part(ctx, (size_t)grid * part_ld + reduce_scratch(part_ld)));                                                  \
+        if (prof_slot >= 0) prof_begin(ctx, prof_slot);                                                                              \
+        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT>), dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, M->p,   \
+                           M->ld, ncN, ncT, n, rounds, t, ep, ctx->part, part_ld);                                                   \
+    } while (0)
         if (cpl <= 4) LF_OP(4, false);
         else if (cpl <= 8) LF_OP(8, false);
         else if (cpl <= 16) LF_OP(16, false);
@@ -283,7 +303,7 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
 #undef LF_OP
         if (prof_slot >= 0) prof_end(ctx, prof_slot);
         LF_LAUNCH_CHECK(ctx);
-        LF_TRY(launch_reduce(ctx, tiles, nout, part_ld, 0u, out, NoPost()));
+        LF_TRY(launch_reduce(ctx, grid, nout, part_ld, 0u, out, NoPost()));
     } else {
         LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
     }

@@ -36,6 +36,7 @@ constexpr int kPadRows = kSlabRows * kMaxKS;  // 2048: padding / shard-boundary 
 constexpr int kTC = LFPSQP_TCOLS;             // columns reduced together in gemv_t
 constexpr int kColChunk = 256;                // columns reduced per LDS flush
 constexpr int kMaxRed = 4;                    // scalar reductions per kernel
+constexpr int kOnepassRound = 64;             // rows per tile round of onepass_kernel (4 waves x 16 rows)
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 // matrix stream: every byte is read exactly once per pass, so it may bypass cache retention
@@ -333,13 +334,14 @@ __global__ __launch_bounds__(kThreads) void gemv_nt_kernel(const double* __restr
 // summed over the row bits RR with two transposing lane swaps (v_permlane32_swap, v_permlane16_swap -- each swap
 // halves the number of live values), so a lane accumulates ceil(CPL/4) values per vector instead of CPL.  That is
 // what lets 2-3 waves per SIMD (enough loads in flight to saturate HBM) coexist with a register-resident tile.
-//   A workgroup owns kPadRows rows (tiles interleaved over its 4 waves) and emits ONE partial row, like the other
-// streaming kernels:  part[wg][k*ncT + j] (k < NV, j < ncT), then part[wg][NV*ncT + r] (r < NRED).
+//   The grid is persistent: (resident workgroups per CU) x (CUs) workgroups, each a contiguous balanced span of 64-row
+// tile rounds (interleaved over its 4 waves), each emitting ONE partial row:
+//   part[wg][k*ncT + j] (k < NV, j < ncT), then part[wg][NV*ncT + r] (r < NRED).
 // Users: the Newton-retraction step (retract.hip) and the fused projected-CG iteration (projcg.hip).
 //   EP::skip()                    uniform: launch is a no-op
 //   EP::Row, EP::fetch(o)         per-row inputs at byte offset o = row*8, fetched one tile ahead of their use
 //   EP::apply(row, o, acc, valid, owner, in, v[NV], red[NRED])   row update; `owner` lanes (one per row) store
-// Host guarantees ncN >= 4, 3*ld*8 + kPadRows*8 < 2^32 and (n + kPadRows)*8 < 2^32.
+// Host guarantees ncN >= 4, 3*ld*8 + kPadRows*8 < 2^32, (n + kPadRows)*8 < 2^32 and 1 <= gridDim.x <= rounds = ceil(n/64).
 // ---------------------------------------------------------------------------
 // (lanes l, l^BIT) hold (x0, x1) each: returns, in the lanes with BIT clear, x0(l) + x0(l^BIT); with BIT set, x1(l) + x1(l^BIT)
 template <int BIT>
@@ -360,11 +362,11 @@ __device__ __forceinline__ double swap_add(double x0, double x1) {
 
 template <class EP, int NV, int NRED, int CPL, bool EXACT>   // EXACT: ncN > 4*(CPL-1), i.e. the last column group is register CPL-1
 __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
-                                                            const double* __restrict__ t, EP ep, double* __restrict__ part, int part_ld) {
+                                                            int64_t rounds, const double* __restrict__ t, EP ep,
+                                                            double* __restrict__ part, int part_ld) {
     if (ep.skip()) return;
     constexpr int CW = 4, RW = 16;                   // column groups per wave, rows per wave tile
-    constexpr int kStep = RW * kWaves;               // rows the workgroup advances per tile round
-    constexpr int kTiles = kPadRows / kStep;
+    constexpr int kStep = RW * kWaves;               // rows the workgroup advances per tile round (kOnepassRound)
     constexpr int NC = CW * CPL;
     constexpr int NQ = (CPL + 3) / 4;                // accumulators per lane and vector
     static_assert(NC <= kColChunk, "column block must fit the LDS staging row");
@@ -385,8 +387,14 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
         ts[j] = v;
     }
     __syncthreads();
-    const int64_t row0 = (int64_t)blockIdx.x * kPadRows;                        // uniform
-    const int lrow = wave * RW + r;                                              // row within the block, tile 0
+    // Persistent grid (one launch fills the machine once): workgroup b owns the contiguous span of `cnt` tile rounds
+    // (64 rows each) starting at round t0, balanced to +-1 round -- no tail of half-empty scheduling waves, and only
+    // gridDim.x partial rows for the second stage.  grid <= rounds, so cnt >= 1.
+    const int64_t q = rounds / gridDim.x, rem = rounds % gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * q + ((int64_t)blockIdx.x < rem ? (int64_t)blockIdx.x : rem);
+    const int cnt = (int)(q + ((int64_t)blockIdx.x < rem ? 1 : 0));
+    const int64_t row0 = t0 * kStep;                                             // uniform
+    const int lrow = wave * RW + r;                                              // row within the round
     const uint32_t vo = (uint32_t)(lrow * 8) + (uint32_t)((int64_t)h * ld * 8);  // lane offset: row, and column within the group
     const char* Mb = reinterpret_cast<const char*>(M + row0);
     const int64_t cs = (int64_t)CW * ld * 8;
@@ -444,8 +452,8 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
         ro += kStep * 8;
     };
 #pragma unroll 1
-    for (int k = 0; k < kTiles - 1; ++k) tile_step(k, std::true_type());
-    tile_step(kTiles - 1, std::false_type());
+    for (int k = 0; k < cnt - 1; ++k) tile_step(k, std::true_type());
+    tile_step(cnt - 1, std::false_type());
     const int creg = 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);     // which of the 4 column registers this lane accumulated
 #pragma unroll
     for (int j = 0; j < NQ; ++j)

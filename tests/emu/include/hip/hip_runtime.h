@@ -56,6 +56,7 @@ static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* nb, K, int, size_t) { *nb = 3; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     std::memset(p, 0, sizeof(*p)); std::strcpy(p->name, "cpu-emulator"); std::strcpy(p->gcnArchName, "emu");
     p->multiProcessorCount = 4; p->totalGlobalMem = size_t(8) << 30; return hipSuccess;
