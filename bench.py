@@ -273,6 +273,16 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         L.retract_(cval, xnew, cons, xt, xs, nr)                  # warm
         ctx.sync(); t0 = time.perf_counter(); flag, it, _ = L.retract_(cval, xnew, cons, xt, xs, nr); ctx.sync()
         nr_ms[label] = (time.perf_counter() - t0) * 1e3 / max(it, 1)
+    # pcg! of the default (ProjPenalty) retraction: 24 iterations of (J'J + mu I) x = b forced by tol = 0
+    from lfpsqp_jl_amd.projpenalty import _JacPlain
+    w = L.ProjPenaltyWork(ctx, m, n_loc, False)
+    xp, rp_ = ctx.vector(n_loc), ctx.vector(n_loc)
+    pcg_ms = None
+    for rep in range(2):
+        xp.fill(0.0); rp_.copy_from(xs)
+        ctx.sync(); t0 = time.perf_counter(); flag, pit = L.pcg_(1e-2, _JacPlain(J, w), L.no_precondition, xp, rp_, w.p, w.z, None, 0.0, 24); ctx.sync()
+        pcg_ms = (time.perf_counter() - t0) * 1e3 / max(pit, 1)
+    pcg_bytes = 8.0 * n_loc * m + 80.0 * n_loc               # one-pass iteration: J once + 10 n-vector passes
     nr1_bytes = 8.0 * n_loc * m + 24.0 * n_loc                # J pass + xnew read/write + v
     nr2_bytes = 16.0 * n_loc * m + 24.0 * n_loc               # Z pass + J pass + xnew read/write + v
     flop = 2.0 * n_loc * m * m
@@ -281,7 +291,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
             "nr_step_two_streams_ms": nr_ms["two_streams"], "nr_step_two_streams_GBs": gbs(nr2_bytes, nr_ms["two_streams"]),
-            "nr_iters_timed": int(it),
+            "nr_iters_timed": int(it), "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit),
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies"}
 
 

@@ -5,8 +5,19 @@
 //   P3  x += alpha*p ; r -= alpha*z ; partial r'r                     (vec_kernel)     :232-235
 //
 // z = M!(r) = r (no_precondition, the only preconditioner on the reference's live path, :374-375), so
-// rho = r'r is the previous iteration's residual norm squared and costs nothing.  Two passes over
-// Jct per iteration; scalars / status in device memory, published to the pinned host block.
+// rho = r'r is the previous iteration's residual norm squared and costs nothing.  Scalars / status in device
+// memory, published to the pinned host block.
+//
+// DEFAULT (4 <= m <= 256): ONE pass over Jct per iteration, same construction as the fused projcg iteration
+// (projcg.hip, onepass_kernel): with tmp = J p known, the kernel forms z = J'tmp + mu p row by row and, over the tile
+// it still holds, accumulates u = J z and s = J r.  The next iteration's J p follows from linearity,
+//     J p+ = J r+ + beta J p,   J r+ = J r - alpha J z = s - alpha u,
+// so the separate pass for J p (P1) disappears after the first iteration:
+//   F   p = r + beta*p (stored) ; z = J'tmp + mu*p (stored) ; partials p'z, J z, J r     (onepass_kernel)
+//   P3  x += alpha*p ; r -= alpha*z ; partial r'r                                        (vec_kernel)
+//   T   tmp = (s - alpha*u) + beta*tmp                                                   (m-vector kernel)
+// = 8 n m + 80 n bytes instead of 16 n m + 88 n.  alpha, beta, rho and the stopping test are computed exactly as in
+// the reference; s = J r is re-measured every iteration, so the recurrence for tmp does not drift.
 #include <math.h>
 
 #include "internal.h"
@@ -158,6 +169,90 @@ struct PPost3 {
         hm.publish(st, it);
     }
 };
+
+// ---- one-pass iteration ------------------------------------------------------------------------------------
+template <bool ST>
+struct PcgInnerE {
+    double* p;
+    const double* r;
+    double* z;
+    double mu;
+    const double* scal;
+    const int64_t* istat;
+    int first;          // first iteration: p (= r) was already formed by the P1 pass that computed tmp = J p
+    PStack k;
+    struct Row { double beta, px, rx, py, ry, Dx, Dy, sx, sy; };
+    static __device__ __forceinline__ double at(const double* base, uint32_t o) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
+    }
+    static __device__ __forceinline__ void put(double* base, uint32_t o, double v) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + o) = v;
+    }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        Row w;
+        w.beta = ld_scal(scal + P_BETA);
+        w.px = at(p, o); w.rx = at(r, o);
+        if (ST) {
+            w.py = at(p + k.hs, o); w.ry = at(r + k.hs, o);
+            w.Dx = at(k.Dx, o); w.Dy = at(k.Dy, o); w.sx = at(k.sx, o); w.sy = at(k.sy, o);
+        } else {
+            w.py = w.ry = w.Dx = w.Dy = w.sx = w.sy = 0.0;
+        }
+        return w;
+    }
+    __device__ __forceinline__ void apply(int64_t, uint32_t o, double acc, bool valid, bool owner, const Row& w, double (&v)[2],
+                                          double (&red)[1]) const {
+        const bool st = valid && owner;
+        if (!ST) {
+            const double pn = first ? w.px : (w.rx + w.beta * w.px);                 // :217
+            const double zz = fma(mu, pn, acc);                                      // :222
+            if (st) {
+                if (!first) put(p, o, pn);
+                put(z, o, zz);
+                red[0] += pn * zz;                                                   // :226
+            }
+            v[0] = valid ? zz : 0.0;
+            v[1] = valid ? w.rx : 0.0;
+        } else {
+            const double pnx = first ? w.px : (w.rx + w.beta * w.px);
+            const double pny = first ? w.py : (w.ry + w.beta * w.py);
+            const double ww = w.Dx * pnx + w.Dy * pny;                               // diagonal block of J p
+            const double zx = fma(mu, pnx, fma(w.sx, acc, w.Dx * ww));
+            const double zy = fma(mu, pny, fma(w.sy, acc, w.Dy * ww));
+            if (st) {
+                if (!first) { put(p, o, pnx); put(p + k.hs, o, pny); }
+                put(z, o, zx); put(z + k.hs, o, zy);
+                red[0] += pnx * zx + pny * zy;
+            }
+            v[0] = valid ? (w.sx * zx + w.sy * zy) : 0.0;                            // Z-block of J z
+            v[1] = valid ? (w.sx * w.rx + w.sy * w.ry) : 0.0;                        // ... of J r
+        }
+    }
+};
+struct PPost2F {   // alpha = rho / p'z, p'z at the tail of the fused kernel's output
+    double* scal;
+    const int64_t* istat;
+    const double* pz;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ void run(double*) const { scal[P_ALPHA] = ld_scal(scal + P_RHO) / ld_scal(pz); }   // :227
+};
+// tmp = (s - alpha*u) + beta*tmp  (J p of the next iteration), from the previous fused kernel's [u ; s]
+struct PcgTmp {
+    const double* US;
+    double* tmp;
+    const double* scal;
+    const int64_t* istat;
+    int m;
+};
+__global__ __launch_bounds__(256) void pcg_tmp_kernel(PcgTmp u) {
+    if (ld_stat(u.istat + IP_STATUS) != PST_RUNNING) return;
+    const double alpha = ld_scal(u.scal + P_ALPHA), beta = ld_scal(u.scal + P_BETA);
+    for (int j = threadIdx.x; j < u.m; j += 256) {
+        const double jr = fma(-alpha, ld_scal(u.US + j), ld_scal(u.US + u.m + j));
+        u.tmp[j] = fma(beta, u.tmp[j], jr);
+    }
+}
 struct RRF {
     const double* r;
     __device__ __forceinline__ bool skip() const { return false; }
@@ -202,15 +297,38 @@ extern "C" int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, l
 
     LF_TRY(lfpsqp_vec_fill(ctx, p, 0.0));                                                        // :204
     LF_TRY((run_vec<RRF, 1, PInit>(ctx, nv, RRF{r->p}, 0u, scal + P_RR, PInit{scal, istat, tol, maxiter, hm})));
+    const bool fused = m > 0 && onepass_cw(ctx, m, Z->ld, N) != 0;
+    double* US = nullptr;                            // [u = J z (m) ; s = J r (m) ; p'z]
+    if (fused) {
+        LF_TRY(ensure_mvec(ctx, (size_t)2 * m + 16));
+        US = ctx->d_m;
+    }
     int64_t it = 0;
     bool done = maxiter <= 0;
     while (!done && it < maxiter) {
-        const P1V p1{p->p, r->p, scal, istat};
-        if (stacked) LF_TRY(run_gemv_t(ctx, Z, m, N, P1VS{p1, sk}, tmp_m->p, 4));
-        else LF_TRY(run_gemv_t(ctx, Z, m, N, p1, tmp_m->p, 4));
-        const P2E p2{p->p, z->p, mu, istat};
-        if (stacked) LF_TRY((run_gemv_n<P2ES, 1, PPost2>(ctx, Z, m, N, tmp_m->p, P2ES{p2, sk}, scal + P_PZ, PPost2{scal, istat}, 5)));
-        else LF_TRY((run_gemv_n<P2E, 1, PPost2>(ctx, Z, m, N, tmp_m->p, p2, scal + P_PZ, PPost2{scal, istat}, 5)));
+        if (!fused || it == 0) {
+            const P1V p1{p->p, r->p, scal, istat};
+            if (stacked) LF_TRY(run_gemv_t(ctx, Z, m, N, P1VS{p1, sk}, tmp_m->p, 4));
+            else LF_TRY(run_gemv_t(ctx, Z, m, N, p1, tmp_m->p, 4));
+        } else {
+            hipLaunchKernelGGL(pcg_tmp_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgTmp{US, tmp_m->p, scal, istat, m});
+            LF_LAUNCH_CHECK(ctx);
+        }
+        if (fused) {
+            if (stacked) {
+                const PcgInnerE<true> fe{p->p, r->p, z->p, mu, scal, istat, it == 0 ? 1 : 0, sk};
+                LF_TRY((run_onepass<PcgInnerE<true>, 2, 1>(ctx, Z, m, m, N, tmp_m->p, fe, US, 5)));
+            } else {
+                const PcgInnerE<false> fe{p->p, r->p, z->p, mu, scal, istat, it == 0 ? 1 : 0, sk};
+                LF_TRY((run_onepass<PcgInnerE<false>, 2, 1>(ctx, Z, m, m, N, tmp_m->p, fe, US, 5)));
+            }
+            hipLaunchKernelGGL((post_kernel<PPost2F>), dim3(1), dim3(1), 0, ctx->stream, scal, PPost2F{scal, istat, US + 2 * m});
+            LF_LAUNCH_CHECK(ctx);
+        } else {
+            const P2E p2{p->p, z->p, mu, istat};
+            if (stacked) LF_TRY((run_gemv_n<P2ES, 1, PPost2>(ctx, Z, m, N, tmp_m->p, P2ES{p2, sk}, scal + P_PZ, PPost2{scal, istat}, 5)));
+            else LF_TRY((run_gemv_n<P2E, 1, PPost2>(ctx, Z, m, N, tmp_m->p, p2, scal + P_PZ, PPost2{scal, istat}, 5)));
+        }
         LF_TRY((run_vec<P3F, 1, PPost3>(ctx, nv, P3F{x->p, r->p, p->p, z->p, scal, istat}, 0u, scal + P_RR, PPost3{scal, istat, hm}, 6)));
         // rank-deterministic stop: the status of iteration it-2 (device iteration number it-1), after its event
         LF_HIP(ctx, hipEventRecord(ctx->ev_slot[it & 3], ctx->stream));

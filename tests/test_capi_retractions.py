@@ -458,3 +458,34 @@ def test_newton_retraction_one_stream_step(dev_ctx, monkeypatch, m_lin, has_ball
         assert np.max(np.abs(cv)) < 1e-9
     # the one-stream kernels are a different summation order than the two-stream one: they must not be the same code path
     assert not np.array_equal(results["-1"][2], results["0"][2]) or m < 4
+
+
+@pytest.mark.parametrize("m", [7, 32])
+def test_pcg_one_pass_iteration_matches_two_pass_kernels(dev_ctx, monkeypatch, m):
+    """lfpsqp_pcg's default iteration makes one pass over Jct (J p+ = (J r - alpha J z) + beta J p, csrc/pcg.hip);
+    LFPSQP_ONEPASS=-1 selects the two-pass kernels.  Same counts / flags, solutions equal to rounding, both equal to
+    the oracle's pcg! (src/retractions.jl:179-246)."""
+    from lfpsqp_jl_amd.projpenalty import _JacPlain
+    n = 2300
+    rng = np.random.default_rng(17 + m)
+    Jr = rng.standard_normal((m, n))
+    bh = rng.standard_normal(n)
+    for mu, tol, maxiter in ((1e-1, 1e-6, 100), (1e-4, 1e-9, 100), (1e-2, 1e-12, 6)):
+        x0h, r0 = np.zeros(n), bh.copy()
+        f0, i0 = R.pcg_(mu, Jr, R.no_precondition, x0h, r0, np.zeros(n), np.zeros(n), np.zeros(m), tol, maxiter)
+        res = {}
+        for mode in ("-1", "0"):
+            monkeypatch.setenv("LFPSQP_ONEPASS", mode)
+            ctx = L.Context(0, dev_ctx.L)
+            Jd = ctx.matrix(n, m, np.asfortranarray(Jr.T))
+            w = L.ProjPenaltyWork(ctx, m, n, False)
+            x, r = ctx.vector(n), ctx.vector(n, bh)
+            flag, i = L.pcg_(mu, _JacPlain(Jd, w), L.no_precondition, x, r, w.p, w.z, None, tol, maxiter)
+            res[mode] = (flag, i, x.download(), r.download())
+            ctx.close()
+        for mode in ("-1", "0"):
+            flag, i, xh, rh = res[mode]
+            assert (flag, i) == (f0, i0), (mode, mu)
+            np.testing.assert_allclose(xh, x0h, atol=1e-10 * max(1.0, np.abs(x0h).max()))
+            np.testing.assert_allclose(rh, r0, atol=1e-9 * max(1.0, np.abs(bh).max()))
+        assert not np.array_equal(res["-1"][2], res["0"][2])
