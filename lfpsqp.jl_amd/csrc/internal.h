@@ -251,7 +251,7 @@ int run_gemv_nt(lfpsqp_ctx* ctx, const lfpsqp_mat* M1, int n1, const double* t, 
 // One-stream N->T product over M (onepass_kernel): usable for this shape?  Returns the lane-group count CW (4) or 0.
 inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
     const int cw = 4;
-    if (ctx->tune_onepass < 0 || ncN < cw || ncN > kColChunk) return 0;
+    if (ctx->tune_onepass < 0 || ncN < cw || ncN > kOnepassMaxCols) return 0;
     // 32-bit lane offsets: column-within-group stride and the row byte offset must fit
     if ((int64_t)(cw - 1) * ld * 8 + (int64_t)kPadRows * 8 >= ((int64_t)1 << 32) || (n + kPadRows) * 8 >= ((int64_t)1 << 32)) return 0;
     return cw;
@@ -260,12 +260,13 @@ inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
 // out[k*ncT + j] = sum_rows M[row, j] * v_k[row] (k < NV, j < ncT), out[NV*ncT + r] = reduction r, with v produced by EP
 // from M[row, :ncN] . t -- all-reduced over ranks; one pass over M.  Persistent grid: as many workgroups as the device
 // keeps resident for this instantiation (occupancy query, cached), capped by the number of 64-row rounds.
-template <class EP, int NV, int NRED, int CPL, bool EXACT>
+template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE>
 inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {
     static int per_cu = 0;                        // one per kernel instantiation
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, onepass_kernel<EP, NV, NRED, CPL, EXACT>, kThreads, 0) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE>, kThreads, 0) != hipSuccess ||
+            nb < 1)
             nb = 1;
         per_cu = nb;
     }
@@ -277,29 +278,37 @@ inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {
 template <class EP, int NV, int NRED>
 int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t n, const double* t, const EP& ep, double* out,
                 int prof_slot = -1) {
-    const int64_t rounds = (n + kOnepassRound - 1) / kOnepassRound;
+    const int cpl = (ncN + 3) / 4;                // column groups
+    const bool wide = cpl > 64;                   // more than 256 columns: the four waves of a workgroup split the columns
+    const int round_rows = wide ? 16 : kOnepassRound;
+    const int64_t rounds = (n + round_rows - 1) / round_rows;
     const int nout = NV * ncT + NRED;
     const int part_ld = (int)round_up(nout, 32);
     if (rounds > 0) {
-        const int cpl = (ncN + 3) / 4;
         int grid = 0;
-#define LF_OP(CPL, EXACT)                                                                                                            \
+#define LF_OP(CPL, EXACT, WIDE)                                                                                                      \
     do {                                                                                                                             \
-        grid = onepass_grid<EP, NV, NRED, CPL, EXACT>(ctx, rounds);                                                                  \
+        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE>(ctx, rounds);                                                            \
         LF_TRY(ensure_part(ctx, (size_t)grid * part_ld + reduce_scratch(part_ld)));                                                  \
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);                                                                              \
-        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT>), dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, M->p,   \
-                           M->ld, ncN, ncT, n, rounds, t, ep, ctx->part, part_ld);                                                   \
+        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE>), dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream,   \
+                           M->p, M->ld, ncN, ncT, n, rounds, t, ep, ctx->part, part_ld);                                             \
     } while (0)
-        if (cpl <= 4) LF_OP(4, false);
-        else if (cpl <= 8) LF_OP(8, false);
-        else if (cpl <= 16) LF_OP(16, false);
-        else if (cpl <= 24) LF_OP(24, false);
-        else if (cpl == 32) LF_OP(32, true);
-        else if (cpl == 33) LF_OP(33, true);
-        else if (cpl <= 33) LF_OP(33, false);
-        else if (cpl <= 48) LF_OP(48, false);
-        else LF_OP(64, false);
+        if (wide) {
+            const int cplw = (cpl + kWaves - 1) / kWaves;     // column groups per wave
+            if (cplw <= 24) LF_OP(24, false, true);
+            else if (cplw <= 32) LF_OP(32, false, true);
+            else if (cplw <= 48) LF_OP(48, false, true);
+            else LF_OP(64, false, true);
+        } else if (cpl <= 4) LF_OP(4, false, false);
+        else if (cpl <= 8) LF_OP(8, false, false);
+        else if (cpl <= 16) LF_OP(16, false, false);
+        else if (cpl <= 24) LF_OP(24, false, false);
+        else if (cpl == 32) LF_OP(32, true, false);
+        else if (cpl == 33) LF_OP(33, true, false);
+        else if (cpl <= 33) LF_OP(33, false, false);
+        else if (cpl <= 48) LF_OP(48, false, false);
+        else LF_OP(64, false, false);
 #undef LF_OP
         if (prof_slot >= 0) prof_end(ctx, prof_slot);
         LF_LAUNCH_CHECK(ctx);

@@ -36,7 +36,8 @@ constexpr int kPadRows = kSlabRows * kMaxKS;  // 2048: padding / shard-boundary 
 constexpr int kTC = LFPSQP_TCOLS;             // columns reduced together in gemv_t
 constexpr int kColChunk = 256;                // columns reduced per LDS flush
 constexpr int kMaxRed = 4;                    // scalar reductions per kernel
-constexpr int kOnepassRound = 64;             // rows per tile round of onepass_kernel (4 waves x 16 rows)
+constexpr int kOnepassRound = 64;             // rows per tile round of onepass_kernel (4 waves x 16 rows); 16 in its wide form
+constexpr int kOnepassMaxCols = 1024;         // widest matrix of the one-pass kernels (wide form: 4 waves x 64 groups x 4)
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 // matrix stream: every byte is read exactly once per pass, so it may bypass cache retention
@@ -360,20 +361,27 @@ __device__ __forceinline__ double swap_add(double x0, double x1) {
     return __builtin_bit_cast(double, ((uint64_t)a_hi << 32) | a_lo) + __builtin_bit_cast(double, ((uint64_t)b_hi << 32) | b_lo);
 }
 
-template <class EP, int NV, int NRED, int CPL, bool EXACT>   // EXACT: ncN > 4*(CPL-1), i.e. the last column group is register CPL-1
+// EXACT: ncN > 4*(CPL-1), i.e. the last column group is register CPL-1 (no run-time column-group select).
+// WIDE (ncN up to 16*CPL columns): the four waves of a workgroup share ONE 16-row tile and split its columns (wave w owns
+// column groups [w*CPL, (w+1)*CPL)); the first product's per-wave partial sums meet in LDS (one barrier per tile round,
+// two buffers), the row update is computed redundantly by every wave (wave 0 stores), the second product stays per wave.
+template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE>
 __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
                                                             int64_t rounds, const double* __restrict__ t, EP ep,
                                                             double* __restrict__ part, int part_ld) {
     if (ep.skip()) return;
-    constexpr int CW = 4, RW = 16;                   // column groups per wave, rows per wave tile
-    constexpr int kStep = RW * kWaves;               // rows the workgroup advances per tile round (kOnepassRound)
-    constexpr int NC = CW * CPL;
+    constexpr int CW = 4, RW = 16;                   // column groups per wave instruction, rows per wave tile
+    constexpr int NW = WIDE ? kWaves : 1;            // waves sharing a row tile
+    constexpr int kStep = WIDE ? RW : RW * kWaves;   // rows the workgroup advances per tile round
+    constexpr int NC = CW * CPL * NW;
     constexpr int NQ = (CPL + 3) / 4;                // accumulators per lane and vector
-    static_assert(NC <= kColChunk, "column block must fit the LDS staging row");
+    static_assert(!(EXACT && WIDE), "the exact variant exists for the narrow kernel only");
     __shared__ double ts[NC];
-    __shared__ double red[kWaves][NV][NC];
+    __shared__ double red[WIDE ? 1 : kWaves][NV][NC];
+    __shared__ double accx[2][kWaves][RW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = (lane & 3) | ((lane >> 4) << 2), h = (lane >> 2) & 3;
+    const int g0 = WIDE ? wave * CPL : 0;            // first column group of this wave
     // Column groups: group g < glast holds columns g*CW .. g*CW+CW-1; the last group is shifted back to the columns
     // ncN-CW .. ncN-1 (all valid; the ones it shares with group glast-1 get a zero coefficient), groups past it
     // re-read it with zero coefficients.  Slot s = g*CW + h of ts[] / red[] therefore maps to one column.
@@ -388,23 +396,25 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     }
     __syncthreads();
     // Persistent grid (one launch fills the machine once): workgroup b owns the contiguous span of `cnt` tile rounds
-    // (64 rows each) starting at round t0, balanced to +-1 round -- no tail of half-empty scheduling waves, and only
+    // (kStep rows each) starting at round t0, balanced to +-1 round -- no tail of half-empty scheduling waves, and only
     // gridDim.x partial rows for the second stage.  grid <= rounds, so cnt >= 1.
     const int64_t q = rounds / gridDim.x, rem = rounds % gridDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * q + ((int64_t)blockIdx.x < rem ? (int64_t)blockIdx.x : rem);
     const int cnt = (int)(q + ((int64_t)blockIdx.x < rem ? 1 : 0));
     const int64_t row0 = t0 * kStep;                                             // uniform
-    const int lrow = wave * RW + r;                                              // row within the round
+    const int lrow = WIDE ? r : wave * RW + r;                                   // row within the round
     const uint32_t vo = (uint32_t)(lrow * 8) + (uint32_t)((int64_t)h * ld * 8);  // lane offset: row, and column within the group
-    const char* Mb = reinterpret_cast<const char*>(M + row0);
     const int64_t cs = (int64_t)CW * ld * 8;
+    const char* Mb = reinterpret_cast<const char*>(M + row0);
+    const int64_t first_off = (int64_t)g0 * cs;
     const int64_t last_off = (int64_t)lastc0 * ld * 8;
     auto load_tile = [&](double (&a)[CPL], int k) {
-        const char* sb = Mb + (int64_t)k * (kStep * 8);                                  // wave-uniform
-        const char* lastb = sb + last_off;
+        const char* tb = Mb + (int64_t)k * (kStep * 8);                                  // wave-uniform
+        const char* sb = tb + first_off;
+        const char* lastb = tb + last_off;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            a[c] = buf_load_f64<true>((EXACT ? (c < CPL - 1) : (c < glast)) ? sb : lastb, vo);
+            a[c] = buf_load_f64<true>((EXACT ? (c < CPL - 1) : (g0 + c < glast)) ? sb : lastb, vo);
             sb += cs;
         }
     };
@@ -412,39 +422,45 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
 #pragma unroll
-        for (int q = 0; q < NV; ++q) p[q][j] = 0.0;
+        for (int qq = 0; qq < NV; ++qq) p[qq][j] = 0.0;
     load_tile(a, 0);
     uint32_t ro = (uint32_t)((row0 + lrow) * 8);
     typename EP::Row in = ep.fetch(ro);
     double rsum[NRED > 0 ? NRED : 1];
 #pragma unroll
-    for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) rsum[q] = 0.0;
+    for (int qq = 0; qq < (NRED > 0 ? NRED : 1); ++qq) rsum[qq] = 0.0;
     auto tile_step = [&](int k, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
         compiler_fence();               // re-read ts[] from LDS every tile instead of pinning 2*CPL registers on it
         double acc = 0.0;
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) acc = fma(a[c], ts[c * CW + h], acc);
+        for (int c = 0; c < CPL; ++c) acc = fma(a[c], ts[(g0 + c) * CW + h], acc);
         acc += __shfl_xor(acc, 4);      // sum over the column groups H (commutative pairings: every lane of a row agrees)
         acc += __shfl_xor(acc, 8);
+        if (WIDE) {                     // ... and over the four waves' column ranges
+            const int b = k & 1;
+            if (h == 0) accx[b][wave][r] = acc;
+            __syncthreads();
+            acc = (accx[b][0][r] + accx[b][1][r]) + (accx[b][2][r] + accx[b][3][r]);
+        }
         const int64_t row = row0 + lrow + (int64_t)k * kStep;
         typename EP::Row in_next = in;
         if (MORE) in_next = ep.fetch(ro + kStep * 8);
         double v[NV];
-        ep.apply(row, ro, acc, row < n, h == 0, in, v, rsum);
+        ep.apply(row, ro, acc, row < n, h == 0 && (!WIDE || wave == 0), in, v, rsum);
         // second product: columns 4j .. 4j+3 of this lane's group, summed over the row bits RR by two transposing swaps;
         // afterwards the lane holds the 4-row sum of column register 4j + 2*bit4 + bit5
 #pragma unroll
         for (int j = 0; j < NQ; ++j)
 #pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                const double x0 = a[4 * j] * v[q];
-                const double x1 = (4 * j + 1 < CPL) ? a[(4 * j + 1 < CPL) ? 4 * j + 1 : 0] * v[q] : 0.0;
-                const double x2 = (4 * j + 2 < CPL) ? a[(4 * j + 2 < CPL) ? 4 * j + 2 : 0] * v[q] : 0.0;
-                const double x3 = (4 * j + 3 < CPL) ? a[(4 * j + 3 < CPL) ? 4 * j + 3 : 0] * v[q] : 0.0;
+            for (int qq = 0; qq < NV; ++qq) {
+                const double x0 = a[4 * j] * v[qq];
+                const double x1 = (4 * j + 1 < CPL) ? a[(4 * j + 1 < CPL) ? 4 * j + 1 : 0] * v[qq] : 0.0;
+                const double x2 = (4 * j + 2 < CPL) ? a[(4 * j + 2 < CPL) ? 4 * j + 2 : 0] * v[qq] : 0.0;
+                const double x3 = (4 * j + 3 < CPL) ? a[(4 * j + 3 < CPL) ? 4 * j + 3 : 0] * v[qq] : 0.0;
                 const double w01 = swap_add<32>(x0, x1);
                 const double w23 = swap_add<32>(x2, x3);
-                p[q][j] += swap_add<16>(w01, w23);
+                p[qq][j] += swap_add<16>(w01, w23);
             }
         compiler_fence();               // the next tile's loads reuse a[]: keep them below its last use (no second buffer)
         if (MORE) load_tile(a, k + 1);
@@ -458,19 +474,20 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            double s = p[q][j];
+        for (int qq = 0; qq < NV; ++qq) {
+            double s = p[qq][j];
             s += __shfl_xor(s, 1);       // the remaining row bits rr
             s += __shfl_xor(s, 2);
             const int c = 4 * j + creg;
-            if ((lane & 3) == 0 && c < CPL) red[wave][q][c * CW + h] = s;
+            if ((lane & 3) == 0 && c < CPL) red[WIDE ? 0 : wave][qq][(g0 + c) * CW + h] = s;
         }
     __syncthreads();
     double* prow = part + (int64_t)blockIdx.x * part_ld;
     for (int j = threadIdx.x; j < NV * ncT; j += kThreads) {
-        const int q = j / ncT, col = j - q * ncT;
+        const int qq = j / ncT, col = j - qq * ncT;
         const int sl = (col < glast * CW) ? col : (glast * CW + (col - lastc0));       // slot holding column `col`
-        prow[j] = (red[0][q][sl] + red[1][q][sl]) + (red[2][q][sl] + red[3][q][sl]);
+        constexpr int W1 = WIDE ? 0 : 1, W2 = WIDE ? 0 : 2, W3 = WIDE ? 0 : 3;   // (the wide form has a single row of slots)
+        prow[j] = WIDE ? red[0][qq][sl] : (red[0][qq][sl] + red[W1][qq][sl]) + (red[W2][qq][sl] + red[W3][qq][sl]);
     }
     if (NRED > 0) block_reduce_store<(NRED > 0 ? NRED : 1)>(rsum, 0u, prow + NV * ncT);
 }

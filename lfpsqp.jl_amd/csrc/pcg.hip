@@ -8,7 +8,7 @@
 // rho = r'r is the previous iteration's residual norm squared and costs nothing.  Scalars / status in device
 // memory, published to the pinned host block.
 //
-// DEFAULT (4 <= m <= 256): ONE pass over Jct per iteration, same construction as the fused projcg iteration
+// DEFAULT (4 <= m <= 1024): ONE pass over Jct per iteration, same construction as the fused projcg iteration
 // (projcg.hip, onepass_kernel): with tmp = J p known, the kernel forms z = J'tmp + mu p row by row and, over the tile
 // it still holds, accumulates u = J z and s = J r.  The next iteration's J p follows from linearity,
 //     J p+ = J r+ + beta J p,   J r+ = J r - alpha J z = s - alpha u,

@@ -15,7 +15,7 @@
 //   = 8 n m + 80 n bytes instead of 16 n m + 104 n.  dAd, alpha, beta, rg, nr are computed exactly as in the reference;
 //   only U'rp is assembled from three exactly-computed pieces instead of one product, a difference of the same size as a
 //   change of summation order (t1 = U'g re-measures the basis component of g every iteration, so nothing accumulates).
-//   Used for a diagonal operator A and 4 <= m <= 256 columns; otherwise (and with LFPSQP_ONEPASS=-1):
+//   Used for a diagonal operator A and 4 <= m <= 1024 columns; otherwise (and with LFPSQP_ONEPASS=-1):
 //
 // FALLBACK: three fused streaming kernels per iteration, two passes over U:
 //

@@ -110,11 +110,12 @@ def test_projcg_matches_oracle(dev_ctx, n, m):
                 assert np.linalg.norm(K) < max(tol, 1e-12)               # test_cg.jl:28
 
 
-@pytest.mark.parametrize("n,m", [(2100, 4), (2500, 33), (2100, 128), (4100, 129)])
+@pytest.mark.parametrize("n,m", [(2100, 4), (2500, 33), (2100, 128), (4100, 129), (1300, 300), (1100, 513)])
 def test_projcg_fused_iteration_matches_two_pass_kernels(dev_ctx, monkeypatch, n, m):
     """The default projcg iteration makes ONE pass over U (U'rp assembled from U'g and U'(A g), csrc/projcg.hip);
     LFPSQP_ONEPASS=-1 selects the two-pass kernels.  Same counts, iterates equal to rounding, both equal to the oracle;
-    covers exact / shifted last column groups and the widest instantiated tile."""
+    covers exact / shifted last column groups, the widest narrow tile and the wide form (m > 256: the four waves of a
+    workgroup split the columns)."""
     Uh, a, bh = _cg_problem(n, m)
     x0, l0 = np.zeros(n), np.zeros(m)
     i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), Uh, bh, np.zeros(m), tol=1e-12)
