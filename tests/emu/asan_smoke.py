@@ -6,7 +6,7 @@ from oracle import synth
 lib=L.load_library('tests/emu/_build_asan/liblfpsqp_emu.so')
 ctx=L.Context(0,lib)
 # odd sizes to stress padding / tails
-for n,m in ((1,1),(1023,3),(2049,5),(4097,130)):
+for n,m in ((1,1),(1023,3),(2049,5),(4097,130),(77,4),(1200,300)):   # incl. the one-pass kernels: narrow (m >= 4) and wide (m > 256)
     Mh=synth.hash_matrix(1,n,m); J=ctx.matrix(n,m,Mh); Z=ctx.matrix(n,m)
     S,Vt,r=L.ksvd_(J,Z)
     x,lam=ctx.vector(n),ctx.vector(m)
