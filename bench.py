@@ -153,9 +153,9 @@ def main(argv=None, lib=None):
         return prof_ms[slot] / prof_cnt[slot] if prof_cnt[slot] else float("nan")
     fused = prof_cnt[3] > 0                              # one pass over U per iteration (lfpsqp_projcg default)
     k1, k2, k3, kf = avg(0), avg(1), avg(2), avg(3)
-    # algorithmic bytes per launch.  K1 reads x,d,g,a writes x,d.  Fused F: U once + reads g,d,a, writes g.
+    # algorithmic bytes per launch.  K1 reads x,d,g(,a) writes x,d.  Fused F: U once + reads g,d,a, writes g.
     # Two-pass fallback: K2 reads d,g,a + U; K3 reads d,g,a writes g + U.
-    bytes_k1 = 48.0 * n_loc
+    bytes_k1 = (40.0 if fused else 48.0) * n_loc       # the fused flow's K1 needs no A (d'Ad comes out of F's sums)
     bytes_k2 = 8.0 * n_loc * m + 24.0 * n_loc + 8.0 * m
     bytes_k3 = 8.0 * n_loc * m + 32.0 * n_loc + 8.0 * m
     bytes_kf = 8.0 * n_loc * m + 32.0 * n_loc + 8.0 * m

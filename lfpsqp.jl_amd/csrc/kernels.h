@@ -35,7 +35,7 @@ constexpr int kMaxKS = 4;
 constexpr int kPadRows = kSlabRows * kMaxKS;  // 2048: padding / shard-boundary granularity
 constexpr int kTC = LFPSQP_TCOLS;             // columns reduced together in gemv_t
 constexpr int kColChunk = 256;                // columns reduced per LDS flush
-constexpr int kMaxRed = 4;                    // scalar reductions per kernel
+constexpr int kMaxRed = 8;                    // scalar reductions per kernel (row stride of the scalar partials)
 constexpr int kOnepassRound = 64;             // rows per tile round of onepass_kernel (4 waves x 16 rows); 16 in its wide form
 constexpr int kOnepassMaxCols = 1024;         // widest matrix of the one-pass kernels (wide form: 4 waves x 64 groups x 4)
 

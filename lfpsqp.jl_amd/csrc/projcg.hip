@@ -7,14 +7,17 @@
 //   known row by row as soon as g_{k+1} = gp exists, so
 //       U'rp_{k+1} = t1 + alpha_{k+1} * t3_{k+1},   t1 = U'g_{k+1},  t2 = U'(A g_{k+1}),  t3_{k+1} = U'(A d_{k+1}) = -t2 + beta_{k+1} t3_k
 //   and t1, t2 are accumulated by the SAME kernel that forms g_{k+1}, over the row tile it still holds in registers
-//   (onepass_kernel, kernels.h).  Per iteration:
-//     K1  x += alpha_prev*d (deferred :92) ; d = beta*d - g ; partial d'(A d)   (vec_kernel)   :99, :74-75
-//         post: exits :77-87, alpha = rg/dAd :91 ;  Utr = t1 + alpha*t3  (m-vector kernel)
-//     F   rp = g + alpha A d (registers) ; gp = rp - U*Utr ; g = gp ; partials rp'gp, gp'gp, U'gp, U'(A gp)   :93-103
-//         post: beta :98, rg, nr, convergence / iteration limit :103-111
-//   = 8 n m + 80 n bytes instead of 16 n m + 104 n.  dAd, alpha, beta, rg, nr are computed exactly as in the reference;
-//   only U'rp is assembled from three exactly-computed pieces instead of one product, a difference of the same size as a
-//   change of summation order (t1 = U'g re-measures the basis component of g every iteration, so nothing accumulates).
+//   (onepass_kernel, kernels.h).  In the same way the next d'Ad follows from three sums of row-local products,
+//       d+'A d+ = g+'A g+ - 2 beta+ g+'A d + beta+^2 d'A d        (d+ = beta+ d - g+),
+//   so an iteration needs ONE global reduction (one all-reduce of 2m+5 doubles across ranks).  Per iteration:
+//     K1  x += alpha_prev*d (deferred :92) ; d = beta*d - g                      (vec_kernel, no reduction)   :99
+//     F   rp = g + alpha A d (registers) ; gp = rp - U*Utr ; g = gp ;
+//         partials rp'gp, gp'gp, gp'A gp, gp'A d, d'A d, U'gp, U'(A gp)           (onepass_kernel)            :93-103
+//     post  beta :98, rg, nr, convergence / iteration limit :103-111 ; next d'Ad, exits :77-87, alpha :91 ; t3, Utr
+//   = 8 n m + 72 n bytes instead of 16 n m + 104 n.  beta, rg, nr and the exit tests are the reference's; U'rp and d'Ad
+//   are assembled from exactly computed pieces instead of one product each -- a difference of the same size as a change
+//   of summation order (t1 = U'g re-measures the basis component of g every iteration, nothing is a recurrence except
+//   t3, which t1 corrects).
 //   Used for a diagonal operator A and 4 <= m <= 1024 columns; otherwise (and with LFPSQP_ONEPASS=-1):
 //
 // FALLBACK: three fused streaming kernels per iteration, two passes over U:
@@ -39,7 +42,7 @@
 
 namespace lfpsqp {
 
-enum { S_DAD = 0, S_RG = 1, S_ALPHA = 2, S_RPGP = 3, S_GPGP = 4, S_BETA = 5, S_NR = 6, S_TOL = 7, S_DD = 8 };
+enum { S_DAD = 0, S_RG = 1, S_ALPHA = 2, S_RPGP = 3, S_GPGP = 4, S_BETA = 5, S_NR = 6, S_TOL = 7, S_DD = 8, S_ALPHA_PREV = 9 };
 enum { I_STATUS = 0, I_ITER = 1, I_MAXIT = 2 };
 enum { ST_RUNNING = 0, ST_CONVERGED = 1, ST_RG_BREAK = 2, ST_NEGCURV = 3, ST_MAXIT = 4 };
 
@@ -240,58 +243,141 @@ struct PcgFuseE {
         }
         return w;
     }
+    // reductions: rp'gp, gp'gp (:98, :84/:103) and the three sums from which the NEXT iteration's d'Ad follows without a
+    // second global reduction:  d+ = beta d - gp  =>  d+'A d+ = gp'A gp - 2 beta gp'A d + beta^2 d'A d   (all three direct)
     __device__ __forceinline__ void apply(int64_t, uint32_t o, double acc, bool valid, bool owner, const Row& w, double (&v)[2],
-                                          double (&red)[2]) const {
+                                          double (&red)[5]) const {
         const bool st = valid && owner;
         if (!ST) {
-            const double rr = init ? w.r0x : fma(w.alpha, w.ax * w.dx, w.gx);        // :93 (same expression as PcgStepV::rp_at)
+            const double ad = w.ax * w.dx;
+            const double rr = init ? w.r0x : fma(w.alpha, ad, w.gx);                 // :93 (same expression as PcgStepV::rp_at)
             const double gp = rr - acc;                                              // :97
+            const double ag = w.ax * gp;
             if (st) {
                 put(g, o, gp);
                 if (init) put(d, o, -gp);                                            // :62
                 red[0] += rr * gp;                                                   // :98
                 red[1] += gp * gp;                                                   // :84 / :103
+                red[2] += gp * ag;
+                red[3] += gp * ad;
+                red[4] += w.dx * ad;
             }
             v[0] = valid ? gp : 0.0;
-            v[1] = valid ? w.ax * gp : 0.0;
+            v[1] = valid ? ag : 0.0;
         } else {
-            const double rx = init ? w.r0x : fma(w.alpha, w.ax * w.dx, w.gx);
-            const double ry = init ? w.r0y : fma(w.alpha, w.ay * w.dy, w.gy);
+            const double adx = w.ax * w.dx, ady = w.ay * w.dy;
+            const double rx = init ? w.r0x : fma(w.alpha, adx, w.gx);
+            const double ry = init ? w.r0y : fma(w.alpha, ady, w.gy);
             const double ww = w.Dx * rx + w.Dy * ry;                                 // diagonal block of Q'rp
             const double gx = rx - fma(w.sx, acc, w.Dx * ww);
             const double gy = ry - fma(w.sy, acc, w.Dy * ww);
+            const double agx = w.ax * gx, agy = w.ay * gy;
             if (st) {
                 put(g, o, gx); put(g + k.hs, o, gy);
                 if (init) { put(d, o, -gx); put(d + k.hs, o, -gy); }
                 red[0] += rx * gx + ry * gy;
                 red[1] += gx * gx + gy * gy;
+                red[2] += gx * agx + gy * agy;
+                red[3] += gx * adx + gy * ady;
+                red[4] += w.dx * adx + w.dy * ady;
             }
             v[0] = valid ? (w.sx * gx + w.sy * gy) : 0.0;                            // the Z-block of Q'g
-            v[1] = valid ? (w.sx * (w.ax * gx) + w.sy * (w.ay * gy)) : 0.0;          // ... of Q'(A g)
+            v[1] = valid ? (w.sx * agx + w.sy * agy) : 0.0;                          // ... of Q'(A g)
         }
     }
 };
 
-// Utr = t1 + alpha * t3,  t3 = -t2 + beta * t3  (first iteration: t3 = -t2, since d0 = -g0)
-struct PcgUtr {
-    const double* T;      // [t1 (m) ; t2 (m)] from the fused kernel
+// The one post-op of the fused iteration, after the (all-reduced) sums T = [t1 (m); t2 (m); rp'gp; gp'gp; g'Ag; g'Ad; d'Ad]
+// of kernel F are final.  End of iteration it (:98-111): beta, rg, nr, convergence / iteration limit.  Start of iteration
+// it+1 (:72-91): d+'A d+ from the three direct sums, negative-curvature / rg exits, alpha.  Then (all threads)
+// Utr = U'rp+ = t1 + alpha * t3,  t3 = U'(A d+) = -t2 + beta * t3   (first iteration: d0 = -g0, so t3 = -t2).
+struct PcgPostF {
+    const double* T;
     double* t3;
     double* Utr;
-    const double* scal;
-    const int64_t* istat;
-    int m, first;
+    double* scal;
+    int64_t* istat;
+    int m, init;
+    HostMirror hm;
 };
-__global__ __launch_bounds__(256) void pcg_utr_kernel(PcgUtr u) {
+__global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
     if (ld_stat(u.istat + I_STATUS) != ST_RUNNING) return;
-    const double alpha = ld_scal(u.scal + S_ALPHA);
-    const double beta = u.first ? 0.0 : ld_scal(u.scal + S_BETA);
+    __shared__ double sh[2];
+    __shared__ int go;
+    if (threadIdx.x == 0) {
+        const double* S = u.T + 2 * u.m;
+        const double rpgp = ld_scal(S), gpgp = ld_scal(S + 1), gAg = ld_scal(S + 2), gAd = ld_scal(S + 3), dAd = ld_scal(S + 4);
+        double beta = 0.0, dAd_next = gAg;                              // d0 = -g0
+        int64_t it = 0;
+        int64_t st = ST_RUNNING;
+        double nr = INFINITY;                                           // src/projcg.jl:69
+        if (u.init) {
+            u.scal[S_RG] = gpgp;
+            if (ld_stat(u.istat + I_MAXIT) <= 0) st = ST_MAXIT;
+            u.hm.publish(st, 0, INFINITY);
+        } else {
+            beta = rpgp / ld_scal(u.scal + S_RG);                       // :98
+            u.scal[S_BETA] = beta;
+            u.scal[S_RG] = gpgp;
+            nr = sqrt(gpgp);                                            // :103
+            u.scal[S_NR] = nr;
+            it = ld_stat(u.istat + I_ITER);
+            if (nr < ld_scal(u.scal + S_TOL)) st = ST_CONVERGED;        // :107
+            else if (it >= ld_stat(u.istat + I_MAXIT)) st = ST_MAXIT;   // :71
+            u.hm.publish(st, it, nr);
+            dAd_next = fma(beta * beta, dAd, fma(-2.0 * beta, gAd, gAg));
+        }
+        if (st == ST_RUNNING) {                                         // iteration it+1 starts (:72-91)
+            u.istat[I_ITER] = it + 1;
+            u.scal[S_DAD] = dAd_next;
+            if (dAd_next <= 0.0) st = ST_NEGCURV;                       // :77
+            else if (gpgp <= 0.0) st = ST_RG_BREAK;                     // :84-87 (r == g)
+            else {
+                u.scal[S_ALPHA_PREV] = ld_scal(u.scal + S_ALPHA);       // still owed to x (deferred :92)
+                u.scal[S_ALPHA] = gpgp / dAd_next;                      // :91
+            }
+            if (st != ST_RUNNING) u.hm.publish(st, it + 1, nr);
+        }
+        if (st != ST_RUNNING) u.istat[I_STATUS] = st;
+        go = (st == ST_RUNNING);
+        sh[0] = gpgp / dAd_next;
+        sh[1] = beta;
+    }
+    __syncthreads();
+    if (!go) return;
+    const double alpha = sh[0], beta = sh[1];
     for (int j = threadIdx.x; j < u.m; j += 256) {
         const double t1 = ld_scal(u.T + j), t2 = ld_scal(u.T + u.m + j);
-        const double t3 = u.first ? -t2 : fma(beta, u.t3[j], -t2);
+        const double t3 = u.init ? -t2 : fma(beta, u.t3[j], -t2);
         u.t3[j] = t3;
         u.Utr[j] = fma(alpha, t3, t1);
     }
 }
+// the vector part of an iteration start in the fused flow: x += alpha_prev*d (deferred :92) ; d = beta*d - g (:99)
+struct PcgDirG {
+    double* d;
+    const double* g;
+    double* x;
+    const double* scal;
+    const int64_t* istat;
+    int force;            // run regardless of the status, d only (negative-curvature exit needs d+)
+    __device__ __forceinline__ bool skip() const { return !force && ld_stat(istat + I_STATUS) != ST_RUNNING; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        double2 dd = ld2(d + i);
+        if (!force) {
+            const double alpha = ld_scal(scal + S_ALPHA_PREV);
+            double2 xx = ld2(x + i);
+            xx = make_double2(fma(alpha, dd.x, xx.x), fma(alpha, dd.y, xx.y));
+            if (v1) st2(x + i, xx);
+            else if (v0) x[i] = xx.x;
+        }
+        const double beta = ld_scal(scal + S_BETA);
+        const double2 gg = ld2(g + i);
+        dd = make_double2(beta * dd.x - gg.x, beta * dd.y - gg.y);
+        if (v1) st2(d + i, dd);
+        else if (v0) d[i] = dd.x;
+    }
+};
 
 // ---- setup / teardown functors --------------------------------------------------
 struct ResidualV {  // v = sgn*(A x - b), optionally stored   (:56-57 with sgn=+1, :115-116 with sgn=-1)
@@ -494,19 +580,19 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     const bool fused = m > 0 && onepass_cw(ctx, m, Z->ld, N) != 0;
     double *T12 = nullptr, *t3 = nullptr;
     if (fused) {
-        LF_TRY(ensure_mvec(ctx, (size_t)3 * m + 16));
-        T12 = ctx->d_m;                                  // [t1 (m); t2 (m); rp'gp; gp'gp]
-        t3 = ctx->d_m + round_up(2 * m + 2, 2);
+        LF_TRY(ensure_mvec(ctx, (size_t)3 * m + 24));
+        T12 = ctx->d_m;                                  // [t1 (m); t2 (m); rp'gp; gp'gp; g'Ag; g'Ad; d'Ad]
+        t3 = ctx->d_m + round_up(2 * m + 5, 2);
     }
     auto launch_fused = [&](int init) -> int {
         if (stacked) {
             const PcgFuseE<true> fe{rp, g, d, Ad, scal, istat, init, sk};
-            LF_TRY((run_onepass<PcgFuseE<true>, 2, 2>(ctx, Z, m, m, N, Utr, fe, T12, init ? -1 : 3)));
+            LF_TRY((run_onepass<PcgFuseE<true>, 2, 5>(ctx, Z, m, m, N, Utr, fe, T12, init ? -1 : 3)));
         } else {
             const PcgFuseE<false> fe{rp, g, d, Ad, scal, istat, init, sk};
-            LF_TRY((run_onepass<PcgFuseE<false>, 2, 2>(ctx, Z, m, m, N, Utr, fe, T12, init ? -1 : 3)));
+            LF_TRY((run_onepass<PcgFuseE<false>, 2, 5>(ctx, Z, m, m, N, Utr, fe, T12, init ? -1 : 3)));
         }
-        hipLaunchKernelGGL((post_kernel<PcgPost3>), dim3(1), dim3(1), 0, ctx->stream, scal, PcgPost3{scal, istat, init, hm, T12 + 2 * m});
+        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, init, hm});
         LF_LAUNCH_CHECK(ctx);
         return 0;
     };
@@ -528,13 +614,13 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     int64_t it = 0;
     bool done = false;
     while (!done && it < maxit_eff) {
-        LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, nv, PcgDirF{d, g, x->p, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
-                                              PcgPost1{scal, istat, hm}, 0)));
         if (fused) {
-            hipLaunchKernelGGL(pcg_utr_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgUtr{T12, t3, Utr, scal, istat, m, it == 0 ? 1 : 0});
-            LF_LAUNCH_CHECK(ctx);
+            // one global reduction per iteration: the post-op of F has already done the exits and alpha of this iteration
+            if (it > 0) LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, g, x->p, scal, istat, 0}, 0u, nullptr, NoPost(), 0)));
             LF_TRY(launch_fused(0));
         } else {
+            LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, nv, PcgDirF{d, g, x->p, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
+                                                  PcgPost1{scal, istat, hm}, 0)));
             LF_TRY(launch_k2());
             LF_TRY(launch_k3(0));
         }
@@ -552,10 +638,13 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     *iters = hstat[1];
     *nr = *(volatile double*)ctx->h_scal;
 
-    // the x-update of the last COMPLETED iteration is still pending (K1 of the next one would have applied it)
-    if ((status == ST_CONVERGED || status == ST_MAXIT) && *iters > 0)
+    // the x-update of the last COMPLETED iteration is still pending (K1 of the next one would have applied it; in the fused
+    // flow the exits of an iteration start are taken before its K1, so they leave it pending too)
+    if ((status == ST_CONVERGED || status == ST_MAXIT || (fused && status == ST_RG_BREAK && *iters > 1)) && *iters > 0)
         LF_TRY((run_vec<FlushXF, 0, NoPost>(ctx, nv, FlushXF{x->p, d, scal}, 0u, nullptr, NoPost())));
     if (status == ST_NEGCURV) {   // :77-82
+        if (fused && *iters > 1)  // d+ = beta d - g of the iteration that found the negative curvature was not formed yet
+            LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, g, x->p, scal, istat, 1}, 0u, nullptr, NoPost())));
         LF_TRY((run_vec<SumSqF, 1, NoPost>(ctx, nv, SumSqF{d}, 0u, scal + S_DD, NoPost())));
         LF_TRY((run_vec<NormalizeIntoF, 0, NoPost>(ctx, nv, NormalizeIntoF{x->p, d, scal + S_DD}, 0u, nullptr, NoPost())));
         if (lambda) LF_TRY(lfpsqp_vec_fill(ctx, lambda, NAN));
