@@ -137,6 +137,31 @@ def test_projcg_fused_iteration_matches_two_pass_kernels(dev_ctx, monkeypatch, n
     assert not np.array_equal(res["-1"][2], res["0"][2])          # really two different code paths
 
 
+def test_projcg_fused_iteration_long_run_on_an_ill_conditioned_operator(dev_ctx, monkeypatch):
+    """Several hundred iterations with kappa(A) = 1e4: the pieces the fused iteration assembles (U'rp from U'g, U'(A g) and the
+    t3 recurrence; d'Ad from three sums) must not drift -- the solution stays in the null space of U' to rounding and meets
+    the KKT system as well as the two-pass kernels' does.  (Iterates of the two paths differ here like any two summation
+    orders do: CG on such an operator amplifies rounding.)"""
+    n, m = 1100, 8
+    Uh, _, bh = _cg_problem(n, m)
+    a = np.exp(np.log(1e4) * (synth.hash_vector(7, n) + 1.0) / 2.0)            # spectrum spread over [1, 1e4]
+    res = {}
+    for mode in ("-1", "0"):
+        monkeypatch.setenv("LFPSQP_ONEPASS", mode)
+        ctx = L.Context(0, dev_ctx.L)
+        x, lam = ctx.vector(n), ctx.vector(m)
+        it, nr = L.projcg_(x, lam, L.DiagOperator(0.0, ctx.vector(n, a)), L.DeviceBasis(ctx.matrix(n, m, Uh)), ctx.vector(n, bh), None,
+                           tol=1e-9, maxit=3000)
+        xd, ld = x.download(), lam.download()[:m]
+        res[mode] = (it, nr, np.linalg.norm(Uh.T @ xd), np.linalg.norm(a * xd + Uh @ ld - bh))
+        ctx.close()
+    for mode in ("-1", "0"):
+        it, nr, feas, kkt = res[mode]
+        assert 100 < it < 3000 and nr < 1e-9
+        assert feas < 1e-11 and kkt < 1e-7
+    assert abs(res["0"][0] - res["-1"][0]) <= max(3, res["-1"][0] // 50)
+
+
 def test_projcg_negative_curvature(dev_ctx):
     """test_cg.jl:39-55: indefinite A => (i, Inf), lambda = NaN, x a unit direction with x'Ax <= 0."""
     ctx = dev_ctx
