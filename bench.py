@@ -286,7 +286,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     nr1_bytes = 8.0 * n_loc * m + 24.0 * n_loc                # J pass + xnew read/write + v
     nr2_bytes = 16.0 * n_loc * m + 24.0 * n_loc               # Z pass + J pass + xnew read/write + v
     flop = 2.0 * n_loc * m * m
-    ceil = stream_ceilings(ctx, L)
+    ceil = stream_ceilings(ctx, L, nbig=int(max(1 << 20, min(400_000_000, 40 * n_loc))))
     return {"stream_ceilings": ceil, "factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs": flop / gram_ms / 1e9,
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),

@@ -138,13 +138,13 @@ def test_projcg_fused_iteration_matches_two_pass_kernels(dev_ctx, monkeypatch, n
 
 
 def test_projcg_fused_iteration_long_run_on_an_ill_conditioned_operator(dev_ctx, monkeypatch):
-    """Several hundred iterations with kappa(A) = 1e4: the pieces the fused iteration assembles (U'rp from U'g, U'(A g) and the
+    """A few hundred iterations with kappa(A) = 1e3: the pieces the fused iteration assembles (U'rp from U'g, U'(A g) and the
     t3 recurrence; d'Ad from three sums) must not drift -- the solution stays in the null space of U' to rounding and meets
     the KKT system as well as the two-pass kernels' does.  (Iterates of the two paths differ here like any two summation
     orders do: CG on such an operator amplifies rounding.)"""
     n, m = 1100, 8
     Uh, _, bh = _cg_problem(n, m)
-    a = np.exp(np.log(1e4) * (synth.hash_vector(7, n) + 1.0) / 2.0)            # spectrum spread over [1, 1e4]
+    a = np.exp(np.log(1e3) * (synth.hash_vector(7, n) + 1.0) / 2.0)            # spectrum spread over [1, 1e3]
     res = {}
     for mode in ("-1", "0"):
         monkeypatch.setenv("LFPSQP_ONEPASS", mode)
@@ -157,7 +157,7 @@ def test_projcg_fused_iteration_long_run_on_an_ill_conditioned_operator(dev_ctx,
         ctx.close()
     for mode in ("-1", "0"):
         it, nr, feas, kkt = res[mode]
-        assert 100 < it < n and nr < 1e-6          # (the loop bound is min(maxit, n + m), src/projcg.jl:71)
+        assert 60 < it < n and nr < 1e-6           # (the loop bound is min(maxit, n + m), src/projcg.jl:71)
         assert feas < 1e-11 and kkt < 1e-4
     assert abs(res["0"][0] - res["-1"][0]) <= max(3, res["-1"][0] // 50)
 
