@@ -1,18 +1,20 @@
 // Device-side building blocks of liblfpsqp_hip (gfx950 / CDNA4, wave64).
 //
-// Every big operation of the hot path is one of three streaming shapes over the
-// tall-skinny column-major layout (DESIGN.md §4):
+// Every big operation of the hot path is one of four streaming shapes over the
+// tall-skinny column-major layout (DESIGN.md §4, §5):
+//   onepass_kernel: y = M t, row-local update, then sums of M' v  -- ONE pass, tile held in registers
+//                   (the projected-CG iteration, the Newton-retraction step, the pcg! iteration)
 //   gemv_t_kernel : t = M' v      -- v produced on the fly by a functor (fused vector updates)
 //   gemv_n_kernel : y = M t       -- consumed on the fly by a functor (fused updates + dot partials)
-//   vec_kernel    : elementwise map + up to 4 sum/max reductions
+//   vec_kernel    : elementwise map + up to 8 sum/max reductions
 // plus reduce_rows_kernel, the fixed-order second stage of every reduction.
 //
-// A thread owns KS double2 row-pairs of a 512*KS-row tile and streams them over all
+// Two-pass kernels: a thread owns KS double2 row-pairs of a 512*KS-row tile and streams them over all
 // columns: lanes read consecutive 16-byte pieces (global_load_dwordx4, 1 KiB per wave
 // instruction), >= 8 loads are in flight per lane, nothing is staged through
 // LDS (each matrix byte is used exactly once -- guide: "GEMV / M<=16: load straight to
 // VGPRs, deep unroll").  All reductions are two-stage and atomics-free so results are
-// bit-reproducible for a given (n_loc, m).
+// bit-reproducible for a given (n_loc, m) on a given device.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
