@@ -56,9 +56,11 @@ int lfpsqp_device_name(const lfpsqp_ctx* ctx, char* buf, int64_t buflen);
  * >= 4M local rows, else 2), nt != 0 = non-temporal loads of the matrix stream.  Results are bit-identical
  * across nt, and differ only in summation order across ks.  Default (auto, 1), DESIGN.md §5. */
 int lfpsqp_ctx_set_tuning(lfpsqp_ctx* ctx, int ks, int nt);
-/* Development switch, read once by lfpsqp_ctx_create from the environment: LFPSQP_ONEPASS=-1 disables the one-pass
- * kernels (lfpsqp_projcg, lfpsqp_pcg and lfpsqp_retract_nr then run their two-pass forms, which are also the fallback for
- * fewer than 4 or more than 1024 columns); used by the tests to cross-check the two forms. */
+/* One-pass kernels (lfpsqp_projcg, lfpsqp_pcg, lfpsqp_retract_nr): 0 = on (default), -1 = off (their two-pass forms, which
+ * are also the fallback for fewer than 4 or more than 1024 columns). */
+int lfpsqp_ctx_set_onepass(lfpsqp_ctx* ctx, int mode);
+/* The same switch is read once by lfpsqp_ctx_create from the environment (LFPSQP_ONEPASS=-1); the tests use it to
+ * cross-check the two forms. */
 /* HIP-event timing on the context's stream: begin .. end -> milliseconds */
 int lfpsqp_timer_begin(lfpsqp_ctx* ctx);
 int lfpsqp_timer_end(lfpsqp_ctx* ctx, double* ms);

@@ -216,6 +216,13 @@ int lfpsqp_ctx_set_tuning(lfpsqp_ctx* ctx, int ks, int nt) {
     return 0;
 }
 
+int lfpsqp_ctx_set_onepass(lfpsqp_ctx* ctx, int mode) {
+    LF_ARG(ctx, ctx != nullptr && (mode == 0 || mode == -1));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tune_onepass = mode;
+    return 0;
+}
+
 int lfpsqp_ctx_set_profiling(lfpsqp_ctx* ctx, int on) {
     LF_ARG(ctx, ctx != nullptr);
     if (on && prof_lazy_init(ctx) != 0) return set_err(ctx, LFPSQP_ERR_HIP, "profiling event creation failed");

@@ -50,6 +50,9 @@ class Context:
         self.check(self.L.lfpsqp_timer_end(self.h, C.byref(ms)))
         return ms.value
 
+    def set_onepass(self, mode: int = 0):
+        self.check(self.L.lfpsqp_ctx_set_onepass(self.h, int(mode)))
+
     def set_tuning(self, ks: int = 0, nt: bool = True):
         self.check(self.L.lfpsqp_ctx_set_tuning(self.h, int(ks), 1 if nt else 0))
 
