@@ -263,8 +263,10 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
     if (W)
         for (size_t i = 0; i < (size_t)m * m; ++i) W[i] = 0.0;
     *rank_out = r;
-    hipLaunchKernelGGL(zero_cols_kernel, dim3(256, (unsigned)Z->m), dim3(kThreads), 0, ctx->stream, Z->p, Z->ld, Z->n, 0);
-    LF_LAUNCH_CHECK(ctx);
+    if (r < Z->m) {    // columns >= rank are zero (the rmul passes below overwrite columns < rank completely)
+        hipLaunchKernelGGL(zero_cols_kernel, dim3(256, (unsigned)(Z->m - r)), dim3(kThreads), 0, ctx->stream, Z->p, Z->ld, Z->n, r);
+        LF_LAUNCH_CHECK(ctx);
+    }
     if (r == 0) return 0;
     // 2. Q1 = A V_r S_r^-1
     std::vector<double> W1((size_t)m * r);
