@@ -232,7 +232,7 @@ def main(argv=None, lib=None):
     except (OSError, ValueError, KeyError):
         pass
 
-    if not args.no_extras:
+    if not args.no_extras and world == 1:                 # single-GPU diagnostics; the N > 1 runs measure the metric only
         out["extras"] = extras(ctx, L, n, m, n_loc, r0, Z, gbs)
     out["check"] = {"x_norm": L.nrm2(x), "nr": nr, "iters": iters}    # global ||x|| after the K timed iterations (sanity / N-rank agreement)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
