@@ -4,6 +4,7 @@
 // simple, accurate to high relative accuracy and needs no external LAPACK.
 #pragma once
 #include <math.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <numeric>
@@ -11,20 +12,42 @@
 
 namespace lfpsqp {
 
+// host threads for the small dense kernels: the CPUs this process may run on (cgroup / affinity aware), at most 8
+inline int small_threads() {
+    static int n = 0;
+    if (n == 0) {
+        cpu_set_t set;
+        int c = 1;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) c = CPU_COUNT(&set);
+        n = c < 1 ? 1 : (c > 8 ? 8 : c);
+    }
+    return n;
+}
+
 // A: rows x cols, column-major, leading dimension rows (rows >= 1, cols >= 0).
 // On exit U (rows x cols, orthonormal columns where S > 0), S (cols, descending, >= 0),
 // V (cols x cols, orthogonal), with A = U diag(S) V'.
+// One-sided (Hestenes) Jacobi in round-robin order: a sweep is cols-1 rounds of cols/2 DISJOINT column pairs, so the
+// pairs of a round rotate in parallel (OpenMP on the host; the result does not depend on the number of threads).
 inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::vector<double>& U, std::vector<double>& S,
                        std::vector<double>& V) {
     std::vector<double> A(Ain);
     V.assign((size_t)cols * cols, 0.0);
     for (int j = 0; j < cols; ++j) V[(size_t)j * cols + j] = 1.0;
     const double eps = 1e-16;
-    for (int sweep = 0; sweep < 80; ++sweep) {
+    const int np = cols + (cols & 1);                    // players of the tournament (one dummy if cols is odd)
+    std::vector<int> seat(np);
+    for (int k = 0; k < np; ++k) seat[k] = (k < cols) ? k : -1;
+    const int nthreads = (cols >= 192 && rows >= 192) ? small_threads() : 1;   // below that a round is too short to share
+    for (int sweep = 0; sweep < 80 && cols > 1; ++sweep) {
         double off = 0.0;
-        for (int p = 0; p < cols - 1; ++p) {
-            double* ap = &A[(size_t)p * rows];
-            for (int q = p + 1; q < cols; ++q) {
+        for (int round = 0; round < np - 1; ++round) {
+#pragma omp parallel for if (nthreads > 1) num_threads(nthreads) schedule(static) reduction(max : off)
+            for (int k = 0; k < np / 2; ++k) {
+                int p = seat[k], q = seat[np - 1 - k];
+                if (p < 0 || q < 0) continue;
+                if (p > q) std::swap(p, q);
+                double* ap = &A[(size_t)p * rows];
                 double* aq = &A[(size_t)q * rows];
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma omp simd reduction(+ : alpha, beta, gamma)
@@ -55,6 +78,10 @@ inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::
                     vq[i] = s * x + c * y;
                 }
             }
+            // next round: seat 0 stays, the others move one seat on
+            const int last = seat[np - 1];
+            for (int k = np - 1; k > 1; --k) seat[k] = seat[k - 1];
+            if (np > 1) seat[1] = last;
         }
         if (off <= 1e-15) break;
     }
