@@ -247,7 +247,8 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, const doub
     const int npan = (ncols + kPanel - 1) / kPanel;
     const int64_t pp = (int64_t)npan * npan * kPanel * kPanel;
     const int64_t nsteps = (M->n + kKStep - 1) / kKStep;
-    int groups = (int)(nsteps < 256 ? (nsteps < 1 ? 1 : nsteps) : 256);
+    const int64_t gmax = 2 * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 128);     // two workgroups per CU: one stages while the other multiplies
+    int groups = (int)(nsteps < gmax ? (nsteps < 1 ? 1 : nsteps) : gmax);
     LF_TRY(ensure_part(ctx, (size_t)groups * pp));
     LF_TRY(ensure_small(ctx, (size_t)pp));
     hipLaunchKernelGGL(gram_kernel, dim3(groups, npan * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2,
