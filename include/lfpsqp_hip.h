@@ -299,6 +299,16 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
                       const lfpsqp_vec* xtilde, const lfpsqp_vec* x, lfpsqp_vec* xnew, double tol, int64_t maxiter, double* cval,
                       int* flag, int64_t* iters);
 
+/* nb (2..4) Newton retractions at once: the trial points xtilde[b] of one linesearch (x + alpha d, x + alpha s d, ...;
+ * src/linesearch.jl:49-60) are independent, so they share every pass over Jct -- one launch advances all unfinished
+ * trials by one Newton step.  Per trial the arithmetic, the convergence test and the outputs are those of
+ * lfpsqp_retract_nr: xnew[b], cval[b*m .. b*m+m), flags[b], iters[b].  Needs the one-stream step (U->A / U->W known,
+ * device-resident constraints, 4..256 columns); returns LFPSQP_ERR_UNSUPPORTED otherwise (retract one by one then). */
+int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m,
+                            const lfpsqp_constraints* cons, const lfpsqp_ineq_data* idata, int nb, const lfpsqp_vec* const* xtilde,
+                            const lfpsqp_vec* x, lfpsqp_vec* const* xnew, double tol, int64_t maxiter, double* cval, int* flags,
+                            int64_t* iters);
+
 /* pcg!(mu, J, no_precondition, x, r, p, z, tmp_m, tol, maxiter) (src/retractions.jl:179-246): CG on
  * (J'J + mu I) x = b, the inner solve of the ProjPenalty retraction (:375), fused on the device
  * (3 kernels per iteration, scalars and exit status in device memory).  J' is given in the

@@ -102,6 +102,8 @@ _SIGS = {
     "lfpsqp_constraints_jac": [P, C.POINTER(Constraints), P, P, PD],
     "lfpsqp_retract_nr": [P, C.POINTER(Basis), P, P, c_i64, C.POINTER(Constraints), CFUN, P, C.POINTER(IneqData), P, P, P, c_dbl, c_i64,
                           PD, C.POINTER(C.c_int), C.POINTER(c_i64)],
+    "lfpsqp_retract_nr_batch": [P, C.POINTER(Basis), P, P, c_i64, C.POINTER(Constraints), C.POINTER(IneqData), C.c_int, C.POINTER(P), P,
+                                C.POINTER(P), c_dbl, c_i64, PD, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_pcg": [P, c_dbl, C.POINTER(Basis), P, P, P, P, P, P, c_dbl, c_i64, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_retract_pp": [P, C.POINTER(Constraints), CFUN, JACFUN, P, P, c_i64, C.POINTER(IneqData), P, P, P, P, P, P, c_dbl, c_dbl, c_i64,
                           c_i64, C.POINTER(PPWork), PD, C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)],

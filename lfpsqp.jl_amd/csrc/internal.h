@@ -63,7 +63,7 @@ struct lfpsqp_ctx {
     size_t m_cap = 0;
     // small device blocks: solver scalars / status, and their pinned host mirrors
     double* scal = nullptr;    // 64 doubles
-    int64_t* istat = nullptr;  // 16 int64
+    int64_t* istat = nullptr;  // 64 int64
     double* h_scal = nullptr;  // pinned: 4 slots x 64
     int64_t* h_istat = nullptr;  // pinned: 4 slots x 16
     hipEvent_t ev_slot[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -260,12 +260,12 @@ inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
 // out[k*ncT + j] = sum_rows M[row, j] * v_k[row] (k < NV, j < ncT), out[NV*ncT + r] = reduction r, with v produced by EP
 // from M[row, :ncN] . t -- all-reduced over ranks; one pass over M.  Persistent grid: as many workgroups as the device
 // keeps resident for this instantiation (occupancy query, cached), capped by the number of 64-row rounds.
-template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE>
+template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA>
 inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {
     static int per_cu = 0;                        // one per kernel instantiation
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE>, kThreads, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, NA>, kThreads, 0) != hipSuccess ||
             nb < 1)
             nb = 1;
         per_cu = nb;
@@ -275,11 +275,12 @@ inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {
     return (int)(g < 1 ? 1 : g);
 }
 
-template <class EP, int NV, int NRED>
+template <class EP, int NV, int NRED, int NA = 1>
 int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t n, const double* t, const EP& ep, double* out,
-                int prof_slot = -1) {
+                int prof_slot = -1, int t_stride = 0) {
     const int cpl = (ncN + 3) / 4;                // column groups
     const bool wide = cpl > 64;                   // more than 256 columns: the four waves of a workgroup split the columns
+    if (wide && NA > 1) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "batched one-pass product with more than 256 columns");
     const int round_rows = wide ? 16 : kOnepassRound;
     const int64_t rounds = (n + round_rows - 1) / round_rows;
     const int nout = NV * ncT + NRED;
@@ -288,18 +289,20 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
         int grid = 0;
 #define LF_OP(CPL, EXACT, WIDE)                                                                                                      \
     do {                                                                                                                             \
-        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE>(ctx, rounds);                                                            \
+        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA)>(ctx, rounds);                                           \
         LF_TRY(ensure_part(ctx, (size_t)grid * part_ld + reduce_scratch(part_ld)));                                                  \
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);                                                                              \
-        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE>), dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream,   \
-                           M->p, M->ld, ncN, ncT, n, rounds, t, ep, ctx->part, part_ld);                                             \
+        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA)>), dim3((unsigned)grid), dim3(kThreads), \
+                           0, ctx->stream, M->p, M->ld, ncN, ncT, n, rounds, t, t_stride, ep, ctx->part, part_ld);                    \
     } while (0)
         if (wide) {
-            const int cplw = (cpl + kWaves - 1) / kWaves;     // column groups per wave
-            if (cplw <= 24) LF_OP(24, false, true);
-            else if (cplw <= 32) LF_OP(32, false, true);
-            else if (cplw <= 48) LF_OP(48, false, true);
-            else LF_OP(64, false, true);
+            if constexpr (NA == 1) {
+                const int cplw = (cpl + kWaves - 1) / kWaves;     // column groups per wave
+                if (cplw <= 24) LF_OP(24, false, true);
+                else if (cplw <= 32) LF_OP(32, false, true);
+                else if (cplw <= 48) LF_OP(48, false, true);
+                else LF_OP(64, false, true);
+            }
         } else if (cpl <= 4) LF_OP(4, false, false);
         else if (cpl <= 8) LF_OP(8, false, false);
         else if (cpl <= 16) LF_OP(16, false, false);

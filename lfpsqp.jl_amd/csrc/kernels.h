@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kThreads) void gemv_nt_kernel(const double* __restr
 // Users: the Newton-retraction step (retract.hip) and the fused projected-CG iteration (projcg.hip).
 //   EP::skip()                    uniform: launch is a no-op
 //   EP::Row, EP::fetch(o)         per-row inputs at byte offset o = row*8, fetched one tile ahead of their use
-//   EP::apply(row, o, acc, valid, owner, in, v[NV], red[NRED])   row update; `owner` lanes (one per row) store
+//   EP::apply(row, o, acc[NA], valid, owner, in, v[NV], red[NRED])   row update; `owner` lanes (one per row) store
 // Host guarantees ncN >= 4, 3*ld*8 + kPadRows*8 < 2^32, (n + kPadRows)*8 < 2^32 and 1 <= gridDim.x <= rounds = ceil(n/64).
 // ---------------------------------------------------------------------------
 // (lanes l, l^BIT) hold (x0, x1) each: returns, in the lanes with BIT clear, x0(l) + x0(l^BIT); with BIT set, x1(l) + x1(l^BIT)
@@ -367,9 +367,10 @@ __device__ __forceinline__ double swap_add(double x0, double x1) {
 // WIDE (ncN up to 16*CPL columns): the four waves of a workgroup share ONE 16-row tile and split its columns (wave w owns
 // column groups [w*CPL, (w+1)*CPL)); the first product's per-wave partial sums meet in LDS (one barrier per tile round,
 // two buffers), the row update is computed redundantly by every wave (wave 0 stores), the second product stays per wave.
-template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE>
+// NA > 1: NA coefficient vectors t[b*t_stride ...] (batched first product: NA independent right-hand sides share the pass).
+template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA = 1>
 __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
-                                                            int64_t rounds, const double* __restrict__ t, EP ep,
+                                                            int64_t rounds, const double* __restrict__ t, int t_stride, EP ep,
                                                             double* __restrict__ part, int part_ld) {
     if (ep.skip()) return;
     constexpr int CW = 4, RW = 16;                   // column groups per wave instruction, rows per wave tile
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     constexpr int NC = CW * CPL * NW;
     constexpr int NQ = (CPL + 3) / 4;                // accumulators per lane and vector
     static_assert(!(EXACT && WIDE), "the exact variant exists for the narrow kernel only");
-    __shared__ double ts[NC];
+    static_assert(NA == 1 || !WIDE, "batched first products exist for the narrow kernel only");
+    __shared__ double ts[NA][NC];
     __shared__ double red[WIDE ? 1 : kWaves][NV][NC];
     __shared__ double accx[2][kWaves][RW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -391,10 +393,14 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     const int lastc0 = ncN - CW;
     for (int j = threadIdx.x; j < NC; j += kThreads) {
         const int g = j / CW, hh = j - g * CW;
-        double v = 0.0;
-        if (g < glast) v = ld_scal(t + j);
-        else if (g == glast && lastc0 + hh >= glast * CW) v = ld_scal(t + lastc0 + hh);
-        ts[j] = v;
+#pragma unroll
+        for (int b = 0; b < NA; ++b) {
+            const double* tb = t + (int64_t)b * t_stride;
+            double v = 0.0;
+            if (g < glast) v = ld_scal(tb + j);
+            else if (g == glast && lastc0 + hh >= glast * CW) v = ld_scal(tb + lastc0 + hh);
+            ts[b][j] = v;
+        }
     }
     __syncthreads();
     // Persistent grid (one launch fills the machine once): workgroup b owns the contiguous span of `cnt` tile rounds
@@ -434,16 +440,21 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     auto tile_step = [&](int k, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
         compiler_fence();               // re-read ts[] from LDS every tile instead of pinning 2*CPL registers on it
-        double acc = 0.0;
+        double acc[NA];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) acc = fma(a[c], ts[(g0 + c) * CW + h], acc);
-        acc += __shfl_xor(acc, 4);      // sum over the column groups H (commutative pairings: every lane of a row agrees)
-        acc += __shfl_xor(acc, 8);
-        if (WIDE) {                     // ... and over the four waves' column ranges
+        for (int b = 0; b < NA; ++b) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) s = fma(a[c], ts[b][(g0 + c) * CW + h], s);
+            s += __shfl_xor(s, 4);      // sum over the column groups H (commutative pairings: every lane of a row agrees)
+            s += __shfl_xor(s, 8);
+            acc[b] = s;
+        }
+        if (WIDE) {                     // ... and over the four waves' column ranges (NA == 1 in the wide form)
             const int b = k & 1;
-            if (h == 0) accx[b][wave][r] = acc;
+            if (h == 0) accx[b][wave][r] = acc[0];
             __syncthreads();
-            acc = (accx[b][0][r] + accx[b][1][r]) + (accx[b][2][r] + accx[b][3][r]);
+            acc[0] = (accx[b][0][r] + accx[b][1][r]) + (accx[b][2][r] + accx[b][3][r]);
         }
         const int64_t row = row0 + lrow + (int64_t)k * kStep;
         typename EP::Row in_next = in;

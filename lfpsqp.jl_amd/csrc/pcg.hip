@@ -201,8 +201,9 @@ struct PcgInnerE {
         }
         return w;
     }
-    __device__ __forceinline__ void apply(int64_t, uint32_t o, double acc, bool valid, bool owner, const Row& w, double (&v)[2],
-                                          double (&red)[1]) const {
+    __device__ __forceinline__ void apply(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, const Row& w,
+                                          double (&v)[2], double (&red)[1]) const {
+        const double acc = accv[0];
         const bool st = valid && owner;
         if (!ST) {
             const double pn = first ? w.px : (w.rx + w.beta * w.px);                 // :217

@@ -245,8 +245,9 @@ struct PcgFuseE {
     }
     // reductions: rp'gp, gp'gp (:98, :84/:103) and the three sums from which the NEXT iteration's d'Ad follows without a
     // second global reduction:  d+ = beta d - gp  =>  d+'A d+ = gp'A gp - 2 beta gp'A d + beta^2 d'A d   (all three direct)
-    __device__ __forceinline__ void apply(int64_t, uint32_t o, double acc, bool valid, bool owner, const Row& w, double (&v)[2],
-                                          double (&red)[5]) const {
+    __device__ __forceinline__ void apply(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, const Row& w,
+                                          double (&v)[2], double (&red)[5]) const {
+        const double acc = accv[0];
         const bool st = valid && owner;
         if (!ST) {
             const double ad = w.ax * w.dx;

@@ -170,9 +170,9 @@ struct NRStepRow {
     using Row = NRStepE::Row;
     __device__ __forceinline__ bool skip() const { return e.skip(); }
     __device__ __forceinline__ Row fetch(uint32_t o) const { return e.fetch1<ST>(o); }
-    __device__ __forceinline__ void apply(int64_t i, uint32_t o, double acc, bool valid, bool owner, const Row& w, double (&v)[1],
-                                          double (&red)[1]) const {
-        v[0] = e.apply1<ST>(i, o, acc, valid, owner, w, red[0]);
+    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[1], bool valid, bool owner, const Row& w,
+                                          double (&v)[1], double (&red)[1]) const {
+        v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0]);
     }
 };
 
@@ -189,11 +189,12 @@ struct NRSmall {
     const double* b;      // m_lin
     double* cval;         // m (current constraint values)
     double* delta;        // m (step coefficients, read by the fused step kernel)
-    const double* raw;    // m: [J'x (m_lin) ; ball partial]
+    const double* raw;    // m_lin: J'x
+    const double* raw_ball;   // 1: ball partial
     const double* W;      // wm x m generator factor (Z = A*W) or nullptr
     double* wdelta;       // wm: W * delta
-    int64_t* istat;
-    int64_t* hstat;       // pinned host block
+    int64_t* ist;         // this retraction's [status, iterations, flag] words (device)
+    int64_t* hstat;       // pinned host block (nullptr: the caller publishes)
     int m, m_lin, has_ball, wm;
     double R2, tol;
     int64_t maxiter;
@@ -219,15 +220,16 @@ __device__ __forceinline__ void small_matvec(const double* A, int lda, int rows,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kNRThreads) void nr_small_kernel(NRSmall s, int init) {
-    if (!init && ld_stat(s.istat + I_NR_STATUS) != 0) return;
+__device__ void nr_small_trial(const NRSmall& s, int init) {
+    if (!init && ld_stat(s.ist) != 0) return;
     __shared__ double cnew[kNRMaxM], del[kNRMaxM], t2[kNRMaxM], dcs[kNRMaxM], tv[kNRMaxM];
     __shared__ double scratch[kNRThreads];
     const int m = s.m, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    for (int k = tid; k < m; k += kNRThreads) cnew[k] = s.raw[k] - (k < s.m_lin ? s.b[k] : s.R2);
+    __syncthreads();                                    // (a previous trial of a batch may still be reading the arrays)
+    for (int k = tid; k < m; k += kNRThreads) cnew[k] = (k < s.m_lin) ? (s.raw[k] - s.b[k]) : (ld_scal(s.raw_ball) - s.R2);
     __syncthreads();
-    int64_t iter = init ? 0 : ld_stat(s.istat + I_NR_ITER);
+    int64_t iter = init ? 0 : ld_stat(s.ist + 1);
     if (init) {
         for (int k = tid; k < m; k += kNRThreads) s.cval[k] = cnew[k];
         for (size_t e = tid; e < (size_t)m * m; e += kNRThreads) s.D[e] = s.Vt[e] / s.Sigma[e % m];      // :126-130
@@ -278,15 +280,18 @@ __global__ __launch_bounds__(kNRThreads) void nr_small_kernel(NRSmall s, int ini
     }
     if (tid == 0) {
         const double c = scratch[0];
-        int64_t st = 0;
-        if (iter >= s.maxiter) { st = 1; s.istat[I_NR_FLAG] = 1; }      // :133 loop bound first: flag = (i == maxiter), :171-174
-        else if (c < s.tol) { st = 1; s.istat[I_NR_FLAG] = 0; }         // :135
-        s.istat[I_NR_ITER] = iter;
-        s.istat[I_NR_STATUS] = st;
-        __hip_atomic_store(s.hstat + I_NR_ITER, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(s.hstat + I_NR_FLAG, st ? s.istat[I_NR_FLAG] : (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(s.hstat + kNRRingOff + ((iter + 1) % kNRRing), st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(s.hstat + I_NR_STATUS, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        int64_t st = 0, fl = 0;
+        if (iter >= s.maxiter) { st = 1; fl = 1; }                       // :133 loop bound first: flag = (i == maxiter), :171-174
+        else if (c < s.tol) { st = 1; fl = 0; }                          // :135
+        if (st) s.ist[2] = fl;
+        s.ist[1] = iter;
+        s.ist[0] = st;
+        if (s.hstat) {
+            __hip_atomic_store(s.hstat + I_NR_ITER, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(s.hstat + I_NR_FLAG, fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(s.hstat + kNRRingOff + ((iter + 1) % kNRRing), st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(s.hstat + I_NR_STATUS, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         scratch[0] = (double)st;
     }
     __syncthreads();
@@ -301,6 +306,68 @@ __global__ __launch_bounds__(kNRThreads) void nr_small_kernel(NRSmall s, int ini
         if (tid < s.wm) s.wdelta[tid] = t2[tid];
     }
 }
+__global__ __launch_bounds__(kNRThreads) void nr_small_kernel(NRSmall s, int init) { nr_small_trial(s, init); }
+
+// ---- batched Newton retractions: NB independent trial points share every pass over Jct ---------------------------------
+// (the trial steps alpha, alpha*s, alpha*s^2, ... of an Armijo search whose retractions fail, src/linesearch.jl:57-60)
+constexpr int kNRBatchMax = 4;
+enum { I_NRB = 32, I_NRB_ALL = 48 };                      // istat: [status, iterations, flag, -] per trial, then the all-done word
+struct NRSmallB {
+    NRSmall t[kNRBatchMax];
+    int nb;
+    int64_t* all;         // device: 1 when every trial has finished
+    int64_t* hstat;
+};
+__global__ __launch_bounds__(kNRThreads) void nr_small_batch_kernel(NRSmallB s, int init, int64_t step) {
+    if (!init && ld_stat(s.all) != 0) return;
+    for (int b = 0; b < s.nb; ++b)
+        if (ld_stat(s.t[b].ist) == 0) nr_small_trial(s.t[b], init);      // (a padding trial is born finished)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t all = 1;
+        for (int b = 0; b < s.nb; ++b) all &= (ld_stat(s.t[b].ist) != 0);
+        *s.all = all;
+        __hip_atomic_store(s.hstat + kNRRingOff + ((step + 1) % kNRRing), all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(s.hstat + I_NR_STATUS, all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// row functor of the batched one-stream step: the shared row data once, xnew (and its y half) per trial
+template <bool ST, int NB>
+struct NRStepBatchRow {
+    NRStepE e;                    // shared fields; e.xnew is trial 0's iterate
+    double* xnew[NB];
+    const int64_t* ist[NB];       // per-trial status words
+    const int64_t* all;
+    struct Row { NRStepE::Row sh; double xn[NB], yn[NB]; unsigned active; };
+    __device__ __forceinline__ bool skip() const { return ld_stat(all) != 0; }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        Row w;
+        w.sh = e.fetch1<ST>(o);
+        w.active = 0u;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            w.xn[b] = NRStepE::at(xnew[b], o);
+            w.yn[b] = ST ? NRStepE::at(xnew[b] + e.hs, o) : 0.0;
+            if (ld_stat(ist[b]) == 0) w.active |= 1u << b;
+        }
+        return w;
+    }
+    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[NB], bool valid, bool owner, const Row& w,
+                                          double (&v)[NB], double (&red)[NB]) const {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            v[b] = 0.0;
+            if ((w.active >> b) & 1u) {               // a finished trial keeps its iterate and contributes nothing
+                NRStepE eb = e;
+                eb.xnew = xnew[b];
+                NRStepE::Row wb = w.sh;
+                wb.xn = w.xn[b];
+                wb.yn = w.yn[b];
+                v[b] = eb.apply1<ST>(i, o, acc[b], valid, owner, wb, red[b]);
+            }
+        }
+    }
+};
 
 int cons_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval) {
     const lfpsqp_mat* J = cons->Jct;
@@ -317,6 +384,16 @@ int cons_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec*
     for (int j = 0; j < ml; ++j) cval[j] = ctx->h_m[j] - cons->b[j];
     if (cons->has_ball) cval[ml] = ctx->h_m[ml] - cons->R2;
     return 0;
+}
+
+template <bool ST, int NB>
+int nr_batch_step(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, int wm, int ml, int64_t N, const double* dwdelta, int wstride,
+                         const NRStepE& ep0, lfpsqp_vec* const* xnew, double* draw) {
+    NRStepBatchRow<ST, NB> ep;
+    ep.e = ep0;
+    for (int b = 0; b < NB; ++b) { ep.xnew[b] = xnew[b]->p; ep.ist[b] = ctx->istat + I_NRB + 4 * b; }
+    ep.all = ctx->istat + I_NRB_ALL;
+    return run_onepass<NRStepBatchRow<ST, NB>, NB, NB, NB>(ctx, cons->Jct, wm, ml, N, dwdelta, ep, draw, -1, wstride);
 }
 
 }  // namespace lfpsqp
@@ -382,8 +459,8 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         volatile int64_t* hstat = ctx->h_istat;
         for (int k = 0; k < kNRRing; ++k) hstat[kNRRingOff + k] = 0;
         hstat[I_NR_STATUS] = 0;
-        const NRSmall sm{dD, dVt, dSig, db, dcval, ddelta, draw, cw ? dW : nullptr, dwdelta, ctx->istat, ctx->h_istat, m, ml,
-                         cons->has_ball ? 1 : 0, cw ? wm : 0, cons->R2, tol, maxiter};
+        const NRSmall sm{dD, dVt, dSig, db, dcval, ddelta, draw, draw + ml, cw ? dW : nullptr, dwdelta, ctx->istat + I_NR_STATUS,
+                         ctx->h_istat, m, ml, cons->has_ball ? 1 : 0, cw ? wm : 0, cons->R2, tol, maxiter};
         LF_TRY(lfpsqp_vec_copy(ctx, xnew, xtilde));                                             // :116
         if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew, x, idata));                                // :118-120
         if (ml > 0) LF_TRY(run_gemv_t(ctx, cons->Jct, ml, N, PlainVec{xnew->p}, draw));         // c!(cval, xnew), raw products
@@ -498,6 +575,114 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
     return 0;
 }
 
+
+// Batched form of lfpsqp_retract_nr: nb (2..4) independent retractions of the trial points xtilde[b] (all from the same x,
+// the same factors and constraints) advance together, one pass over Jct per Newton step for all of them.  Each trial
+// has its own Broyden state, convergence test and iteration count and stops on its own (a finished trial keeps its
+// iterate); the call returns when all have finished.  Requires the one-stream step (basis generator known,
+// device-resident constraints, 4 <= columns <= 256); otherwise LFPSQP_ERR_UNSUPPORTED and the caller retracts one by one.
+int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m64,
+                            const lfpsqp_constraints* cons, const lfpsqp_ineq_data* idata, int nb, const lfpsqp_vec* const* xtilde,
+                            const lfpsqp_vec* x, lfpsqp_vec* const* xnew, double tol, int64_t maxiter, double* cval, int* flags,
+                            int64_t* iters) {
+    LF_ARG(ctx, ctx && U && Sigma && Vt && xtilde && x && xnew && cval && flags && iters && m64 >= 1 && U->ncols == m64);
+    LF_ARG(ctx, cons_ok(cons) && nb >= 2 && nb <= kNRBatchMax);
+    const int m = (int)m64;
+    const bool ineq = idata != nullptr;
+    LF_ARG(ctx, ineq == (U->Dx != nullptr));
+    for (int b = 0; b < nb; ++b) {
+        LF_ARG(ctx, xtilde[b] && xnew[b] && xtilde[b]->n == x->n && xnew[b]->n == x->n && xnew[b]->p != x->p && xnew[b]->p != xtilde[b]->p);
+        for (int c = 0; c < b; ++c) LF_ARG(ctx, xnew[b]->p != xnew[c]->p);
+    }
+    const int ml = (int)cons->m_lin;
+    const int64_t N = cons->Jct->n;
+    const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kColChunk) ? (int)U->A->m : 0;
+    if (!wm || m > kNRMaxM || !onepass_cw(ctx, wm, cons->Jct->ld, N) || wm > kColChunk)
+        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "batched Newton retraction needs the one-stream step (generator known, 4..256 columns)");
+    const int NBk = nb <= 2 ? 2 : 4;                   // instantiated batch widths; a missing trial is born finished
+    const size_t mm = (size_t)m * m;
+    const int wstride = (int)round_up(wm, 2);
+    const int rawn = NBk * ml + NBk;
+    LF_TRY(ensure_small(ctx, (size_t)NBk * mm + mm + (size_t)wm * m + (size_t)NBk * wstride + 8 * (size_t)m * (NBk + 1) + rawn + 256));
+    double* dD = ctx->small;                           // NBk x (m x m)
+    double* dVt = dD + (size_t)NBk * mm;
+    double* dW = dVt + mm;
+    double* dwdelta = dW + (size_t)wm * m + ((wm * m) & 1);
+    double* dSig = dwdelta + (size_t)NBk * wstride;
+    double* db = dSig + m + (m & 1);
+    double* dcval = db + m + (m & 1);                  // NBk x m
+    double* ddelta = dcval + (size_t)NBk * m + ((NBk * m) & 1);
+    double* draw = ddelta + (size_t)NBk * m + ((NBk * m) & 1);   // [NBk x ml products ; NBk ball partials]
+    LF_HIP(ctx, hipMemcpyAsync(dVt, Vt, sizeof(double) * mm, hipMemcpyHostToDevice, ctx->stream));
+    LF_HIP(ctx, hipMemcpyAsync(dW, U->W, sizeof(double) * (size_t)wm * m, hipMemcpyHostToDevice, ctx->stream));
+    LF_HIP(ctx, hipMemcpyAsync(dSig, Sigma, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+    if (ml > 0) LF_HIP(ctx, hipMemcpyAsync(db, cons->b, sizeof(double) * ml, hipMemcpyHostToDevice, ctx->stream));
+    LF_HIP(ctx, hipMemsetAsync(draw, 0, sizeof(double) * rawn, ctx->stream));
+    LF_HIP(ctx, hipMemsetAsync(ctx->istat + I_NRB, 0, sizeof(int64_t) * (4 * kNRBatchMax + 1), ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));                     // caller-owned pageable sources
+    volatile int64_t* hstat = ctx->h_istat;
+    for (int k = 0; k < kNRRing; ++k) hstat[kNRRingOff + k] = 0;
+    hstat[I_NR_STATUS] = 0;
+
+    NRSmallB sb;
+    sb.nb = NBk;
+    sb.all = ctx->istat + I_NRB_ALL;
+    sb.hstat = ctx->h_istat;
+    lfpsqp_vec* xn[kNRBatchMax];
+    for (int b = 0; b < NBk; ++b) {
+        const int src = b < nb ? b : 0;               // padding trials alias trial 0 and never run
+        xn[b] = xnew[src];
+        sb.t[b] = NRSmall{dD + (size_t)b * mm, dVt, dSig, db, dcval + (size_t)b * m, ddelta + (size_t)b * m, draw + (size_t)b * ml,
+                          draw + (size_t)NBk * ml + b, dW, dwdelta + (size_t)b * wstride, ctx->istat + I_NRB + 4 * b, nullptr, m, ml,
+                          cons->has_ball ? 1 : 0, wm, cons->R2, tol, maxiter};
+    }
+    for (int b = 0; b < nb; ++b) {                                                                  // :116-124 per trial
+        LF_TRY(lfpsqp_vec_copy(ctx, xnew[b], xtilde[b]));
+        if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew[b], x, idata));
+        if (ml > 0) LF_TRY(run_gemv_t(ctx, cons->Jct, ml, N, PlainVec{xnew[b]->p}, draw + (size_t)b * ml));
+        if (cons->has_ball)
+            LF_TRY((run_vec<BallF, 1, NoPost>(ctx, N, BallF{xnew[b]->p, cons->n_x, cons->slack_row}, 0u, draw + (size_t)NBk * ml + b, NoPost())));
+    }
+    if (NBk > nb) {                                    // born finished: status 1, flag 1
+        const int64_t fin[3] = {1, 0, 1};
+        for (int b = nb; b < NBk; ++b)
+            LF_HIP(ctx, hipMemcpyAsync(ctx->istat + I_NRB + 4 * b, fin, sizeof(fin), hipMemcpyHostToDevice, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    hipLaunchKernelGGL(nr_small_batch_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sb, 1, (int64_t)-1);
+    LF_LAUNCH_CHECK(ctx);
+    LF_HIP(ctx, hipEventRecord(ctx->ev_slot[0], ctx->stream));
+    const NRStepE ep{xnew[0]->p, x->p, ineq ? lfpsqp_half_stride(N) : 0, ineq ? U->sx->p : nullptr, ineq ? U->sy->p : nullptr,
+                     ineq ? idata->q->p : nullptr, ineq ? idata->r->p : nullptr, ineq ? idata->s->p : nullptr,
+                     ineq ? idata->t->p : nullptr, cons->n_x, cons->slack_row, cons->has_ball ? 1 : 0, ctx->istat};
+    int64_t it = 0;
+    bool done = false;
+    while (!done && it < maxiter) {
+        if (NBk == 2) {
+            if (ineq) LF_TRY((nr_batch_step<true, 2>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, draw)));
+            else LF_TRY((nr_batch_step<false, 2>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, draw)));
+        } else {
+            if (ineq) LF_TRY((nr_batch_step<true, 4>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, draw)));
+            else LF_TRY((nr_batch_step<false, 4>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, draw)));
+        }
+        hipLaunchKernelGGL(nr_small_batch_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sb, 0, it);
+        LF_LAUNCH_CHECK(ctx);
+        LF_HIP(ctx, hipEventRecord(ctx->ev_slot[(it + 1) & 3], ctx->stream));
+        LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[it & 3]));            // all-done word after `it` completed steps
+        if (hstat[kNRRingOff + (it % kNRRing)] != 0) done = true;
+        ++it;
+    }
+    int64_t hist[4 * kNRBatchMax];
+    LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, dcval, sizeof(double) * (size_t)nb * m, hipMemcpyDeviceToHost, ctx->stream));
+    LF_HIP(ctx, hipMemcpyAsync(hist, ctx->istat + I_NRB, sizeof(hist), hipMemcpyDeviceToHost, ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < nb; ++b) {
+        for (int k = 0; k < m; ++k) cval[(size_t)b * m + k] = ctx->h_m[(size_t)b * m + k];
+        iters[b] = hist[4 * b + 1];
+        flags[b] = (int)hist[4 * b + 2];
+    }
+    return 0;
+}
 
 int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cfun cfun, lfpsqp_jacfun jacfun, void* user,
                       lfpsqp_mat* Jct, int64_t m64, const lfpsqp_ineq_data* idata, lfpsqp_vec* Dx, lfpsqp_vec* Dy, lfpsqp_vec* S,

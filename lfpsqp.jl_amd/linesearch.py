@@ -5,12 +5,19 @@ from __future__ import annotations
 import math
 
 from .device import DeviceVector, dot, nrm2, waxpby
-from .retractions import retract_
+from .retractions import retract_, retract_nr_batch_
 
 
 class ArmijoWork:  # src/linesearch.jl:1-5
     def __init__(self, like: DeviceVector):
-        self.xtilde = like.__class__(like.ctx, like.N) if hasattr(like, "N") else DeviceVector(like.ctx, like.n)
+        self._mk = (lambda: like.__class__(like.ctx, like.N)) if hasattr(like, "N") else (lambda: DeviceVector(like.ctx, like.n))
+        self.xtilde = self._mk()
+        self.batch = None          # lazily: (xtildes, xnews) for batched trial retractions
+
+    def batch_vectors(self, k):
+        if self.batch is None or len(self.batch[0]) < k:
+            self.batch = ([self._mk() for _ in range(k)], [self._mk() for _ in range(k)])
+        return self.batch
 
 
 class ExactLinesearchWork:  # :7-14
@@ -36,9 +43,42 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
     ar_dot = dot(d, g)
     xtilde = work.xtilde
     step = xtilde
+    # Trial retractions ahead of time: alpha -> (flag, iter1, iter2, xnew_b, cval_b).  Filled, after the first failure of
+    # this search, with the next param.ls_batch steps of the reference's own sequence alpha*s, alpha*s^2, ... -- the loop
+    # below consumes them exactly as it would have computed them one by one.
+    ahead = {}
+    nbatch = int(getattr(param, "ls_batch", 1))
+    failed_once = False
     while step_diff > param.eps_x:
-        waxpby(1.0, x, alpha, d, xtilde)                 # xtilde = x + alpha d
-        flag, iter1, iter2 = retract_(cval, xnew, c_, xtilde, x, retract_method)
+        if alpha in ahead:
+            flag, iter1, iter2, xb, cb = ahead.pop(alpha)
+            xnew.copy_from(xb)
+            cval[:] = cb
+        else:
+            got = None
+            if failed_once and nbatch > 1 and not param.disable_linesearch:
+                xts, xns = work.batch_vectors(nbatch)
+                alphas = [alpha]
+                for _ in range(nbatch - 1):
+                    alphas.append(alphas[-1] * param.s)
+                for a_, xt_ in zip(alphas, xts):
+                    waxpby(1.0, x, a_, d, xt_)
+                import numpy as _np
+                cvs = _np.zeros((nbatch, len(cval)))
+                got = retract_nr_batch_(cvs, xns, c_, xts, x, retract_method)
+                if got is not None:
+                    for a_, res, xb, cb in zip(alphas[1:], got[1:], xns[1:], cvs[1:]):
+                        ahead[a_] = (res[0], res[1], res[2], xb, cb.copy())
+                    flag, iter1, iter2 = got[0]
+                    xnew.copy_from(xns[0])
+                    cval[:] = cvs[0]
+                else:
+                    nbatch = 1                                 # this configuration cannot batch
+            if got is None:
+                waxpby(1.0, x, alpha, d, xtilde)             # xtilde = x + alpha d
+                flag, iter1, iter2 = retract_(cval, xnew, c_, xtilde, x, retract_method)
+        if flag > 0:
+            failed_once = True
         tot_iter1 += iter1
         tot_iter2 += iter2
         if flag > 0:

@@ -63,3 +63,8 @@ class LFPSQPParams:
     do_newton: bool = True
     tn_maxiter: int = 10000
     tn_kappa: float = 0.5
+    # not in the reference: after the first failed retraction of an Armijo search, the next `ls_batch` trial steps
+    # (alpha*s, alpha*s^2, ...) are retracted together (they share every pass over the constraint gradients); the search
+    # consumes them in the reference's order, so the accepted step and all counts are those of the one-by-one search.
+    # 1 = off.  Only the Newton retraction with device-resident constraints batches; everything else ignores it.
+    ls_batch: int = 4

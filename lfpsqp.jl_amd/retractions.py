@@ -94,6 +94,37 @@ def retract_(cval: np.ndarray, xnew: DeviceVector, c_, xtilde: DeviceVector, x: 
     raise TypeError(f"no retract_ method for {type(method)}")
 
 
+def retract_nr_batch_(cvals: np.ndarray, xnews, c_, xtildes, x, method: NR):
+    """Several Newton retractions of one linesearch at once (lfpsqp_retract_nr_batch): cvals is (nb, m), xnews / xtildes lists
+    of nb device vectors.  Returns a list of (flag, iter1, 0) per trial, or None when the device cannot batch this
+    configuration (the caller then retracts one by one)."""
+    if not isinstance(c_, DeviceConstraints) or not isinstance(method, NR):
+        return None
+    ctx = x.ctx
+    nb = len(xnews)
+    m = len(method.Sigma)
+    bc = method.U._c()
+    if not bc.A or not bc.W:
+        return None
+    Sig = np.ascontiguousarray(method.Sigma, dtype=np.float64)
+    Vt = np.asfortranarray(method.Vt, dtype=np.float64)
+    idc = method.idata._c() if method.ineq else None
+    cons = c_._c()
+    xt = (_capi.P * nb)(*[v.h for v in xtildes])
+    xn = (_capi.P * nb)(*[v.h for v in xnews])
+    flags = (C.c_int * nb)()
+    iters = (_capi.c_i64 * nb)()
+    out = np.zeros((nb, m))
+    rc = ctx.L.lfpsqp_retract_nr_batch(ctx.h, C.byref(bc), Sig.ctypes.data, Vt.ctypes.data, m, C.byref(cons),
+                                       C.byref(idc) if idc is not None else None, nb, xt, x.h, xn, float(method.tol),
+                                       int(method.maxiter), out.ctypes.data_as(_capi.PD), flags, iters)
+    if rc == -5:                                           # LFPSQP_ERR_UNSUPPORTED
+        return None
+    ctx.check(rc)
+    cvals[:nb, :] = out
+    return [(int(flags[b]), int(iters[b]), 0) for b in range(nb)]
+
+
 def _retract_nr(cval, xnew, c_, xtilde, x, method: NR):
     ctx = x.ctx
     m = len(method.Sigma)

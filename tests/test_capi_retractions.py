@@ -489,3 +489,86 @@ def test_pcg_one_pass_iteration_matches_two_pass_kernels(dev_ctx, monkeypatch, m
             np.testing.assert_allclose(xh, x0h, atol=1e-10 * max(1.0, np.abs(x0h).max()))
             np.testing.assert_allclose(rh, r0, atol=1e-9 * max(1.0, np.abs(bh).max()))
         assert not np.array_equal(res["-1"][2], res["0"][2])
+
+
+@pytest.mark.parametrize("nb,bounds", [(2, False), (3, True), (4, True)])
+def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds):
+    """lfpsqp_retract_nr_batch: nb trial points of one linesearch retracted together (one pass over Jct per Newton step for all of
+    them) give, trial by trial, what lfpsqp_retract_nr gives one by one -- including trials that converge at different
+    iterations and one that fails (maxiter)."""
+    ctx = dev_ctx
+    n, m = (1500, 7) if _is_emu(ctx) else (200_000, 31)
+    P0 = synth.BallBoxProblem(n, m)
+    N, M = n + 1, m + 1
+    Jct = ctx.matrix(N, M).hash_fill(1, 0, n, 1.0, n, m)
+    xl, xu = (P0.xl, P0.xu) if bounds else (np.full(n, -np.inf), np.full(n, np.inf))
+    P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=xl, xu=xu)
+    # one outer iteration's worth of state through the driver's own setup path: stop after the first tangent setup
+    x0 = 0.9 * synth.hash_vector(2, n) + 0.05
+    captured = {}
+    import lfpsqp_jl_amd.linesearch as LS
+    orig = LS.armijo_
+
+    def spy(xnew, x, nn, d, g, f, fval, retract_method, cval, c_, param, work):
+        captured.update(x=x, d=d, method=retract_method, c_=c_, m=len(cval), work=work, xnew=xnew)
+        raise StopIteration
+    LS.armijo_ = spy
+    import sys
+    OPT = sys.modules["lfpsqp_jl_amd.optimize"]            # (the package attribute `optimize` is the function, not the module)
+    OPT.armijo_ = spy
+    try:
+        with pytest.raises(StopIteration):
+            P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=3))
+    finally:
+        LS.armijo_ = orig
+        OPT.armijo_ = orig
+    x, d, method, c_, mm = captured["x"], captured["d"], captured["method"], captured["c_"], captured["m"]
+    assert isinstance(method, L.NR)
+    method.maxiter = 40                                    # so that the largest step fails while the small ones converge
+    alphas = [64.0, 0.02, 2e-3, 1e-4][:nb]
+    xts, xns = captured["work"].batch_vectors(nb)
+    for a, xt in zip(alphas, xts):
+        L.waxpby(1.0, x, a, d, xt)
+    cvs = np.zeros((nb, mm))
+    got = L.retract_nr_batch_(cvs, xns, c_, xts, x, method)
+    assert got is not None
+    one = captured["xnew"]
+    flags = []
+    for b in range(nb):
+        cv = np.zeros(mm)
+        fl, it, _ = L.retract_(cv, one, c_, xts[b], x, method)
+        flags.append(fl)
+        assert (got[b][0], got[b][1]) == (fl, it), (b, got[b], fl, it)
+        xa = xns[b].download2() if bounds else xns[b].download()
+        xb_ = one.download2() if bounds else one.download()
+        if fl == 0:
+            np.testing.assert_allclose(xa, xb_, rtol=0, atol=1e-12 * max(1.0, np.abs(xb_).max()))
+            np.testing.assert_allclose(cvs[b], cv, atol=1e-8)      # c(xnew) ~ 0: differences of rounding size in a sum over n terms
+    assert 0 in flags
+    if _is_emu(ctx):
+        assert len(set(g[1] for g in got)) > 1, got            # the trials really finished at different iterations
+
+
+def test_armijo_with_batched_trial_retractions_is_the_same_search(dev_ctx):
+    """LFPSQPParams.ls_batch: after the first failed retraction of an Armijo search the next trial steps are retracted
+    together; the search consumes them in the reference's order, so the accepted step, every count and the iterates are
+    those of the one-by-one search (src/linesearch.jl:32-89)."""
+    ctx = dev_ctx
+    emu = _is_emu(ctx)
+    n, m = (300, 5) if emu else (4000, 16)
+    P0 = synth.BallBoxProblem(n, m)                       # from P0.x0 the first linesearches fail repeatedly (config 4's regime)
+    res = {}
+    for k in (1, 4):
+        Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+        P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
+        tr = []
+        x, obj, lam, ti = P.optimize(P0.x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=3 if emu else 6,
+                                                           ls_batch=k), trace=tr)
+        res[k] = (tr, x, ti)
+    tr1, x1, ti1 = res[1]
+    tr4, x4, ti4 = res[4]
+    assert ti1.iter == ti4.iter and len(tr1) == len(tr4)
+    assert any((t.get('retract_iter1') or 0) >= 100 for t in tr1)          # the regime with failed retractions was reached
+    fork = _compare_traces(tr4, tr1, rtol=1e-11, failed_retractions_may_differ=not emu)
+    if fork is None:
+        assert np.linalg.norm(x4 - x1) <= 1e-10 * np.linalg.norm(x1)

@@ -1,10 +1,11 @@
-"""Run a BASELINE config end to end on the GPU at full size:  python tools/run_config.py {2|3|4} [n] [m] [--pp]"""
+"""Run a BASELINE config end to end on the GPU at full size:  python tools/run_config.py {2|3|4} [n] [m] [--pp] [--ls-batch=K]"""
 import sys, time; sys.path.insert(0, '.')
 import numpy as np
 import lfpsqp_jl_amd as L
 
 cfg = int(sys.argv[1]); args = [a for a in sys.argv[2:] if not a.startswith('--')]
 pp = '--pp' in sys.argv
+batch = int([a for a in sys.argv if a.startswith('--ls-batch=')][0].split('=')[1]) if any(a.startswith('--ls-batch=') for a in sys.argv) else 4
 ctx = L.Context(0)
 t0 = time.perf_counter()
 if cfg == 2:
@@ -26,6 +27,6 @@ else:
     P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download()[:m], R2=n / 2.0, xl=xl, xu=xu); x0 = 0.5 * np.ones(n)
 ctx.sync(); print(f"setup {time.perf_counter()-t0:.2f}s  device={ctx.device_name}", flush=True)
 t0 = time.perf_counter()
-x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=pp))
+x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=pp, ls_batch=batch))
 dt = time.perf_counter() - t0
 print(ti); print(f"optimize wall {dt:.2f}s  f={obj[-1]:.6e}  |lam|max={np.abs(lam).max():.3e}")
