@@ -378,6 +378,7 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     constexpr int kStep = WIDE ? RW : RW * kWaves;   // rows the workgroup advances per tile round
     constexpr int NC = CW * CPL * NW;
     constexpr int NQ = (CPL + 3) / 4;                // accumulators per lane and vector
+    constexpr bool kRowAhead = sizeof(typename EP::Row) <= 16 * sizeof(double);   // fetch the next tile's row inputs a tile ahead
     static_assert(!(EXACT && WIDE), "the exact variant exists for the narrow kernel only");
     static_assert(NA == 1 || !WIDE, "batched first products exist for the narrow kernel only");
     __shared__ double ts[NA][NC];
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
         }
         const int64_t row = row0 + lrow + (int64_t)k * kStep;
         typename EP::Row in_next = in;
-        if (MORE) in_next = ep.fetch(ro + kStep * 8);
+        if (MORE && kRowAhead) in_next = ep.fetch(ro + kStep * 8);
         double v[NV];
         ep.apply(row, ro, acc, row < n, h == 0 && (!WIDE || wave == 0), in, v, rsum);
         // second product: columns 4j .. 4j+3 of this lane's group, summed over the row bits RR by two transposing swaps;
@@ -477,8 +478,9 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
             }
         compiler_fence();               // the next tile's loads reuse a[]: keep them below its last use (no second buffer)
         if (MORE) load_tile(a, k + 1);
-        in = in_next;
         ro += kStep * 8;
+        if (kRowAhead) in = in_next;
+        else if (MORE) in = ep.fetch(ro);   // big row records (batched trials): fetched after this tile's use, no second copy live
     };
 #pragma unroll 1
     for (int k = 0; k < cnt - 1; ++k) tile_step(k, std::true_type());
