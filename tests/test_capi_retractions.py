@@ -555,20 +555,21 @@ def test_armijo_with_batched_trial_retractions_is_the_same_search(dev_ctx):
     those of the one-by-one search (src/linesearch.jl:32-89)."""
     ctx = dev_ctx
     emu = _is_emu(ctx)
-    n, m = (300, 5) if emu else (4000, 16)
+    n, m = (150, 4) if emu else (4000, 16)
+    mr = 30 if emu else 100                               # (shorter failed retractions keep the emulator run short)
     P0 = synth.BallBoxProblem(n, m)                       # from P0.x0 the first linesearches fail repeatedly (config 4's regime)
     res = {}
     for k in (1, 4):
         Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
         P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
         tr = []
-        x, obj, lam, ti = P.optimize(P0.x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=3 if emu else 6,
-                                                           ls_batch=k), trace=tr)
+        x, obj, lam, ti = P.optimize(P0.x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=2 if emu else 6,
+                                                           maxiter_retract=mr, ls_batch=k), trace=tr)
         res[k] = (tr, x, ti)
     tr1, x1, ti1 = res[1]
     tr4, x4, ti4 = res[4]
     assert ti1.iter == ti4.iter and len(tr1) == len(tr4)
-    assert any((t.get('retract_iter1') or 0) >= 100 for t in tr1)          # the regime with failed retractions was reached
+    assert any((t.get('retract_iter1') or 0) >= mr for t in tr1)           # the regime with failed retractions was reached
     fork = _compare_traces(tr4, tr1, rtol=1e-11, failed_retractions_may_differ=not emu)
     if fork is None:
         assert np.linalg.norm(x4 - x1) <= 1e-10 * np.linalg.norm(x1)
