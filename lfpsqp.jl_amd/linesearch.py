@@ -13,6 +13,7 @@ class ArmijoWork:  # src/linesearch.jl:1-5
         self._mk = (lambda: like.__class__(like.ctx, like.N)) if hasattr(like, "N") else (lambda: DeviceVector(like.ctx, like.n))
         self.xtilde = self._mk()
         self.batch = None          # lazily: (xtildes, xnews) for batched trial retractions
+        self.prev_failed = False   # did the previous search see a failed retraction? (then this one batches from its first trial)
 
     def batch_vectors(self, k):
         if self.batch is None or len(self.batch[0]) < k:
@@ -44,11 +45,12 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
     xtilde = work.xtilde
     step = xtilde
     # Trial retractions ahead of time: alpha -> (flag, iter1, iter2, xnew_b, cval_b).  Filled, after the first failure of
-    # this search, with the next param.ls_batch steps of the reference's own sequence alpha*s, alpha*s^2, ... -- the loop
+    # this search (or from its first trial when the previous search had failures), with the next param.ls_batch steps of the reference's own sequence alpha*s, alpha*s^2, ... -- the loop
     # below consumes them exactly as it would have computed them one by one.
     ahead = {}
     nbatch = int(getattr(param, "ls_batch", 1))
-    failed_once = False
+    failed_once = bool(getattr(work, "prev_failed", False))   # searches in a failing regime batch from their first trial
+    any_failed = False
     while step_diff > param.eps_x:
         if alpha in ahead:
             flag, iter1, iter2, xb, cb = ahead.pop(alpha)
@@ -78,7 +80,7 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
                 waxpby(1.0, x, alpha, d, xtilde)             # xtilde = x + alpha d
                 flag, iter1, iter2 = retract_(cval, xnew, c_, xtilde, x, retract_method)
         if flag > 0:
-            failed_once = True
+            failed_once = any_failed = True
         tot_iter1 += iter1
         tot_iter2 += iter2
         if flag > 0:
@@ -96,6 +98,7 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
         if alpha < 1e-100:
             flag = 99
             break
+    work.prev_failed = any_failed
     return flag, tot_iter1, tot_iter2, newf, f_diff, step_diff, alpha
 
 
