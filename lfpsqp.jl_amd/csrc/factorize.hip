@@ -241,9 +241,30 @@ __global__ __launch_bounds__(kThreads) void zero_cols_kernel(double* M, int64_t 
     }
 }
 
-static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, const double* w2, std::vector<double>& G) {
-    G.assign((size_t)ncols * ncols, 0.0);
-    if (ncols == 0) return 0;
+// GEMV-T producer for a border column of the Gram matrix: v = w2 .* M[:, col]
+struct ColTimesW {
+    const double* col;
+    const double* w2;   // may be null
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        double2 a = ld2(col + r);
+        if (w2) {
+            const double2 w = ld2(w2 + r);
+            a.x *= w.x;
+            a.y *= w.y;
+        }
+        return make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0);
+    }
+};
+
+static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const double* w2, std::vector<double>& G) {
+    G.assign((size_t)ncols_all * ncols_all, 0.0);
+    if (ncols_all == 0) return 0;
+    // A few columns beyond a multiple of the 128-column panel (m + 1 constraints with a slack/ball column, say) would cost
+    // a whole extra panel row and column of MFMA tiles; they are cheaper as GEMV-T passes: G[:, j] = M' (w2 .* M[:, j]).
+    const int rem = ncols_all % kPanel;
+    const int border = (ncols_all > kPanel && rem > 0 && rem <= 4) ? rem : 0;
+    const int ncols = ncols_all - border;
     const int npan = (ncols + kPanel - 1) / kPanel;
     const int64_t pp = (int64_t)npan * npan * kPanel * kPanel;
     const int64_t nsteps = (M->n + kKStep - 1) / kKStep;
@@ -271,15 +292,24 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, const doub
                 for (int i = 0; i < kPanel; ++i) {
                     const int gi = pi * kPanel + i;
                     if (gi >= ncols) break;
-                    G[(size_t)gj * ncols + gi] = blk[j * kPanel + i];
+                    G[(size_t)gj * ncols_all + gi] = blk[j * kPanel + i];
                 }
             }
         }
+    if (border > 0) {
+        LF_TRY(ensure_mvec(ctx, (size_t)ncols_all + 8));
+        for (int j = ncols; j < ncols_all; ++j) {
+            LF_TRY(run_gemv_t(ctx, M, ncols_all, M->n, ColTimesW{M->p + (int64_t)j * M->ld, w2}, ctx->d_m));
+            LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * ncols_all, hipMemcpyDeviceToHost, ctx->stream));
+            LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < ncols_all; ++i) G[(size_t)j * ncols_all + i] = G[(size_t)i * ncols_all + j] = ctx->h_m[i];
+        }
+    }
     // G is symmetric up to rounding of the two summation orders; symmetrise
-    for (int j = 0; j < ncols; ++j)
+    for (int j = 0; j < ncols_all; ++j)
         for (int i = 0; i < j; ++i) {
-            const double v = 0.5 * (G[(size_t)j * ncols + i] + G[(size_t)i * ncols + j]);
-            G[(size_t)j * ncols + i] = G[(size_t)i * ncols + j] = v;
+            const double v = 0.5 * (G[(size_t)j * ncols_all + i] + G[(size_t)i * ncols_all + j]);
+            G[(size_t)j * ncols_all + i] = G[(size_t)i * ncols_all + j] = v;
         }
     return 0;
 }

@@ -318,53 +318,66 @@ struct NRSmallB {
     int64_t* all;         // device: 1 when every trial has finished
     int64_t* hstat;
 };
-__global__ __launch_bounds__(kNRThreads) void nr_small_batch_kernel(NRSmallB s, int init, int64_t step) {
+// one workgroup per trial, then a one-thread kernel that forms and publishes the all-done word
+__global__ __launch_bounds__(kNRThreads) void nr_small_batch_kernel(NRSmallB s, int init) {
     if (!init && ld_stat(s.all) != 0) return;
-    for (int b = 0; b < s.nb; ++b)
-        if (ld_stat(s.t[b].ist) == 0) nr_small_trial(s.t[b], init);      // (a padding trial is born finished)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int64_t all = 1;
-        for (int b = 0; b < s.nb; ++b) all &= (ld_stat(s.t[b].ist) != 0);
-        *s.all = all;
-        __hip_atomic_store(s.hstat + kNRRingOff + ((step + 1) % kNRRing), all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(s.hstat + I_NR_STATUS, all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    const NRSmall& t = s.t[blockIdx.x];
+    if (ld_stat(t.ist) == 0) nr_small_trial(t, init);       // (a padding trial is born finished)
 }
-// row functor of the batched one-stream step: the shared row data once, xnew (and its y half) per trial
+__global__ void nr_batch_all_kernel(NRSmallB s, int init, int64_t step) {
+    if (!init && ld_stat(s.all) != 0) return;
+    int64_t all = 1;
+    for (int b = 0; b < s.nb; ++b) all &= (ld_stat(s.t[b].ist) != 0);
+    *s.all = all;
+    __hip_atomic_store(s.hstat + kNRRingOff + ((step + 1) % kNRRing), all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(s.hstat + I_NR_STATUS, all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// row functor of the batched one-stream step.  The four lane groups H of a row all see the same first-product results, so
+// they SPLIT the trials: group H does the row update (y_retract!: square roots and divisions, the expensive part) of trial
+// H mod NB only, stores it, and the groups then exchange their results for the second product.
 template <bool ST, int NB>
 struct NRStepBatchRow {
     NRStepE e;                    // shared fields; e.xnew is trial 0's iterate
     double* xnew[NB];
     const int64_t* ist[NB];       // per-trial status words
     const int64_t* all;
-    struct Row { NRStepE::Row sh; double xn[NB], yn[NB]; unsigned active; };
+    struct Row { NRStepE::Row sh; unsigned active; };       // sh.xn / sh.yn: this lane group's trial
     __device__ __forceinline__ bool skip() const { return ld_stat(all) != 0; }
+    static __device__ __forceinline__ int my_trial() { return (int)((threadIdx.x >> 2) & 3u) % NB; }   // lane bits 3..2 = H
+    __device__ __forceinline__ double* my_xnew(int tr) const {
+        double* p = xnew[0];
+#pragma unroll
+        for (int b = 1; b < NB; ++b) p = (tr == b) ? xnew[b] : p;
+        return p;
+    }
     __device__ __forceinline__ Row fetch(uint32_t o) const {
         Row w;
-        w.sh = e.fetch1<ST>(o);
+        NRStepE eb = e;
+        eb.xnew = my_xnew(my_trial());
+        w.sh = eb.fetch1<ST>(o);
         w.active = 0u;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            w.xn[b] = NRStepE::at(xnew[b], o);
-            w.yn[b] = ST ? NRStepE::at(xnew[b] + e.hs, o) : 0.0;
+        for (int b = 0; b < NB; ++b)
             if (ld_stat(ist[b]) == 0) w.active |= 1u << b;
-        }
         return w;
     }
-    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[NB], bool valid, bool owner, const Row& w,
+    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[NB], bool valid, bool, const Row& w,
                                           double (&v)[NB], double (&red)[NB]) const {
+        const int h = (int)((threadIdx.x >> 2) & 3u), tr = h % NB;
+        double acc_mine = acc[0];
+#pragma unroll
+        for (int b = 1; b < NB; ++b) acc_mine = (tr == b) ? acc[b] : acc_mine;
+        double mine = 0.0, ball = 0.0;
+        if ((w.active >> tr) & 1u) {                   // a finished trial keeps its iterate and contributes nothing
+            NRStepE eb = e;
+            eb.xnew = my_xnew(tr);
+            mine = eb.apply1<ST>(i, o, acc_mine, valid, h < NB, w.sh, ball);     // (h < NB: one storing lane per row and trial)
+        }
+        const int lane = (int)(threadIdx.x & 63u);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            v[b] = 0.0;
-            if ((w.active >> b) & 1u) {               // a finished trial keeps its iterate and contributes nothing
-                NRStepE eb = e;
-                eb.xnew = xnew[b];
-                NRStepE::Row wb = w.sh;
-                wb.xn = w.xn[b];
-                wb.yn = w.yn[b];
-                v[b] = eb.apply1<ST>(i, o, acc[b], valid, owner, wb, red[b]);
-            }
+            v[b] = __shfl(mine, (lane & ~12) | (b << 2));                        // trial b's value from lane group H = b
+            red[b] += (tr == b) ? ball : 0.0;
         }
     }
 };
@@ -649,7 +662,8 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
             LF_HIP(ctx, hipMemcpyAsync(ctx->istat + I_NRB + 4 * b, fin, sizeof(fin), hipMemcpyHostToDevice, ctx->stream));
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    hipLaunchKernelGGL(nr_small_batch_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sb, 1, (int64_t)-1);
+    hipLaunchKernelGGL(nr_small_batch_kernel, dim3(NBk), dim3(kNRThreads), 0, ctx->stream, sb, 1);
+    hipLaunchKernelGGL(nr_batch_all_kernel, dim3(1), dim3(1), 0, ctx->stream, sb, 1, (int64_t)-1);
     LF_LAUNCH_CHECK(ctx);
     LF_HIP(ctx, hipEventRecord(ctx->ev_slot[0], ctx->stream));
     const NRStepE ep{xnew[0]->p, x->p, ineq ? lfpsqp_half_stride(N) : 0, ineq ? U->sx->p : nullptr, ineq ? U->sy->p : nullptr,
@@ -665,7 +679,8 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
             if (ineq) LF_TRY((nr_batch_step<true, 4>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, draw)));
             else LF_TRY((nr_batch_step<false, 4>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, draw)));
         }
-        hipLaunchKernelGGL(nr_small_batch_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sb, 0, it);
+        hipLaunchKernelGGL(nr_small_batch_kernel, dim3(NBk), dim3(kNRThreads), 0, ctx->stream, sb, 0);
+        hipLaunchKernelGGL(nr_batch_all_kernel, dim3(1), dim3(1), 0, ctx->stream, sb, 0, it);
         LF_LAUNCH_CHECK(ctx);
         LF_HIP(ctx, hipEventRecord(ctx->ev_slot[(it + 1) & 3], ctx->stream));
         LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[it & 3]));            // all-done word after `it` completed steps

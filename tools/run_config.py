@@ -1,5 +1,5 @@
 """Run a BASELINE config end to end on the GPU at full size:  python tools/run_config.py {2|3|4} [n] [m] [--pp] [--ls-batch=K]"""
-import sys, time; sys.path.insert(0, '.')
+import sys, time; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 import lfpsqp_jl_amd as L
 
