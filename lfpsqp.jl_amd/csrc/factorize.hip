@@ -158,19 +158,22 @@ __global__ __launch_bounds__(kThreads) void rmul_kernel(const double* __restrict
         }
 }
 
-// Out[:, :rcols] = In[:, :kcols] * W for kcols, rcols <= 128 -- the shape of the tangent setup at m <= 128.  W (zero padded
-// to 128 x 128) stays in LDS for the workgroup's lifetime; the grid is persistent (one workgroup per CU, 144 KB of LDS),
+// Out[:, :rcols] = In[:, :kcols] * W for kcols <= 132, rcols <= 144 -- the shape of the tangent setup at m <= 132.  W (zero
+// padded) stays in LDS for the workgroup's lifetime; the grid is persistent (one workgroup per CU, 144 KB of LDS),
 // each workgroup a contiguous balanced span of 128-row tiles.  A wave owns 32 rows of every tile and all 128 output
 // columns (16 accumulators), and streams its rows of In straight from global memory in the MFMA B-operand layout
 // (16 consecutive rows x 4 columns per instruction: 128-byte segments), 16 k-groups ahead through a register ring that
 // runs on across tile boundaries: no staging of In through LDS and no barrier in the loop.
-constexpr int kRmulRing = 16;
+// NG k-groups of 4 (kcols <= 4*NG), NI output-column tiles of 16 (rcols <= 16*NI), RING | NG: <32, 8, 16> is the 128 x 128
+// case, <33, 9, 11> covers m = 129 .. 132 (one slack / ball column more than 128) with 152 KB of LDS.
+template <int NG, int NI, int RING>
 __global__ __launch_bounds__(kThreads) void rmul_resident_kernel(const double* __restrict__ In, int64_t ld_in, int64_t n, int kcols,
                                                                   const double* __restrict__ W, int ldw, int rcols,
                                                                   double* __restrict__ Out, int64_t ld_out, int64_t ntiles) {
-    __shared__ double Ws[kPanel][kLdsLd];    // Ws[k][c] = W[k, c]
-    for (int idx = threadIdx.x; idx < kPanel * kPanel; idx += kThreads) {
-        const int k = idx & (kPanel - 1), c = idx >> 7;
+    static_assert(NG % RING == 0, "the register ring must divide the k-groups of a tile");
+    __shared__ double Ws[4 * NG][kLdsLd];    // Ws[k][c] = W[k, c]
+    for (int idx = threadIdx.x; idx < 4 * NG * 16 * NI; idx += kThreads) {
+        const int k = idx % (4 * NG), c = idx / (4 * NG);
         Ws[k][c] = (k < kcols && c < rcols) ? W[(int64_t)c * ldw + k] : 0.0;
     }
     __syncthreads();
@@ -180,39 +183,38 @@ __global__ __launch_bounds__(kThreads) void rmul_resident_kernel(const double* _
     const int64_t t0 = (int64_t)blockIdx.x * q + ((int64_t)blockIdx.x < rem ? (int64_t)blockIdx.x : rem);
     const int64_t t1 = t0 + q + ((int64_t)blockIdx.x < rem ? 1 : 0);
     if (t0 >= t1) return;
-    constexpr int NG = kPanel / 4;           // k-groups of 4 per tile
     const int kmax = kcols - 1;
     // B operand of k-group g of tile t: In[row = t*128 + wave*32 + jj*16 + c, k = 4g + kq] (k clamped: W rows >= kcols are zero)
     auto in_ptr = [&](int64_t t, int g) -> const double* {
         const int k = (4 * g + kq < kmax) ? (4 * g + kq) : kmax;
         return In + (int64_t)k * ld_in + t * kPanel + wave * 32 + c;
     };
-    double b0[kRmulRing], b1[kRmulRing];
+    double b0[RING], b1[RING];
 #pragma unroll
-    for (int g = 0; g < kRmulRing; ++g) {
+    for (int g = 0; g < RING; ++g) {
         const double* p = in_ptr(t0, g);
         b0[g] = __builtin_nontemporal_load(p);
         b1[g] = __builtin_nontemporal_load(p + 16);
     }
     for (int64_t t = t0; t < t1; ++t) {
-        f64x4 acc[8][2];
+        f64x4 acc[NI][2];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) { acc[it][0] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[it][1] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+        for (int it = 0; it < NI; ++it) { acc[it][0] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[it][1] = f64x4{0.0, 0.0, 0.0, 0.0}; }
         const int64_t tn = (t + 1 < t1) ? (t + 1) : t;        // the ring reads on into the next tile (or re-reads this one at the end)
 #pragma unroll 1
-        for (int g8 = 0; g8 < NG; g8 += kRmulRing) {
-            const bool same = (g8 + kRmulRing < NG);                 // the refills of this round stay in tile t
+        for (int g8 = 0; g8 < NG; g8 += RING) {
+            const bool same = (g8 + RING < NG);                      // the refills of this round stay in tile t
             const int64_t tt = same ? t : tn;
-            const int gbase = same ? (g8 + kRmulRing) : 0;
+            const int gbase = same ? (g8 + RING) : 0;
 #pragma unroll
-            for (int slot = 0; slot < kRmulRing; ++slot) {
+            for (int slot = 0; slot < RING; ++slot) {
                 const double v0 = b0[slot], v1 = b1[slot];
-                const double* p = in_ptr(tt, gbase + slot);          // refill the slot with the group kRmulRing ahead
+                const double* p = in_ptr(tt, gbase + slot);          // refill the slot with the group RING ahead
                 b0[slot] = __builtin_nontemporal_load(p);
                 b1[slot] = __builtin_nontemporal_load(p + 16);
                 const int kr = 4 * (g8 + slot) + kq;
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
+                for (int it = 0; it < NI; ++it) {
                     const double a = Ws[kr][it * 16 + c];
                     acc[it][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, v0, acc[it][0], 0, 0, 0);
                     acc[it][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, v1, acc[it][1], 0, 0, 0);
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void rmul_resident_kernel(const double* _
         }
         const int64_t row = t * kPanel + wave * 32 + c;
 #pragma unroll
-        for (int it = 0; it < 8; ++it)
+        for (int it = 0; it < NI; ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int col = it * 16 + kq + 4 * r;
@@ -320,10 +322,14 @@ static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const dou
     LF_HIP(ctx, hipMemcpyAsync(ctx->small, W_host, sizeof(double) * (size_t)kcols * rcols, hipMemcpyHostToDevice, ctx->stream));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // W_host is caller-owned pageable memory
     const int64_t ntiles = (In->n + kPanel - 1) / kPanel;
+    const int64_t cus = ctx->num_cu > 0 ? ctx->num_cu : 1;
+    const dim3 pgrid((unsigned)(ntiles < cus ? ntiles : cus));
     if (kcols <= kPanel && rcols <= kPanel && ctx->tune_onepass >= 0) {      // W resident in LDS, persistent grid
-        const int64_t cus = ctx->num_cu > 0 ? ctx->num_cu : 1;
-        hipLaunchKernelGGL(rmul_resident_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(kThreads), 0, ctx->stream, In->p,
-                           In->ld, In->n, kcols, ctx->small, kcols, rcols, Out->p, Out->ld, ntiles);
+        hipLaunchKernelGGL((rmul_resident_kernel<32, 8, 16>), pgrid, dim3(kThreads), 0, ctx->stream, In->p, In->ld, In->n, kcols,
+                           ctx->small, kcols, rcols, Out->p, Out->ld, ntiles);
+    } else if (kcols <= 132 && rcols <= 144 && ctx->tune_onepass >= 0) {     // ... a few columns more (m = 128 + slack / ball)
+        hipLaunchKernelGGL((rmul_resident_kernel<33, 9, 11>), pgrid, dim3(kThreads), 0, ctx->stream, In->p, In->ld, In->n, kcols,
+                           ctx->small, kcols, rcols, Out->p, Out->ld, ntiles);
     } else {
         hipLaunchKernelGGL(rmul_kernel, dim3((unsigned)ntiles, (unsigned)((rcols + kPanel - 1) / kPanel)), dim3(kThreads), 0, ctx->stream,
                            In->p, In->ld, In->n, kcols, ctx->small, kcols, rcols, Out->p, Out->ld);
