@@ -239,3 +239,24 @@ export HipContext, DeviceVector, DeviceMatrix, DeviceBasis, DiagOperator, ProjCG
        upload!, download, projcg!, retract!, pcg!, ksvd!, comm_unique_id, comm_init!
 
 end # module
+
+# ---- optional: several trial points of one Armijo search retracted together --------------------------------------------
+# armijo! (src/linesearch.jl:32-89) tries x + α d, x + α s d, ... one after another; when retractions fail (100 Newton
+# iterations each) the trial points are independent and can share every pass over Jct.  A maintainer who wants this
+# adds a lookahead to armijo! (see lfpsqp.jl_amd/linesearch.py::armijo_ for the bookkeeping that keeps the accepted step
+# and all counts those of the one-by-one search) on top of this call.
+function retract_batch!(cvals::Matrix{Float64}, xnews::Vector{DeviceVector}, xtildes::Vector{DeviceVector}, x::DeviceVector, method::DeviceNR)
+    nb = length(xnews)
+    flags = zeros(Cint, nb); iters = zeros(Int64, nb)
+    xt = [v.h for v in xtildes]; xn = [v.h for v in xnews]
+    GC.@preserve method xt xn begin
+        u = Ref(CBasis(method.U.Z.h, method.U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, method.Jct.h, pointer(method.W)))
+        cons = Ref(CConstraints(method.Jct.h, method.m_lin, pointer(method.b), method.has_ball ? 1 : 0, method.R2, method.n_x, method.slack_row))
+        check(x.ctx, ccall((:lfpsqp_retract_nr_batch, lib), Cint,
+                           (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{CConstraints}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}},
+                            Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Float64, Int64, Ptr{Float64}, Ptr{Cint}, Ptr{Int64}),
+                           x.ctx.h, u, method.Σ, method.Vt, length(method.Σ), cons, C_NULL, nb, xt, x.h, xn, method.tol, method.maxiter,
+                           cvals, flags, iters))       # cvals is m × nb (column b = cval of trial b)
+    end
+    return [(Int(flags[b]), Int(iters[b]), 0) for b in 1:nb]
+end
