@@ -72,6 +72,13 @@ def main():
     P4 = L.QuadLinearBallBox(ctx, s1 - s0, m4, J4, b4.download()[:m4], R2=n4 / 2.0, xl=xl, xu=xu, n_global=n4, owns_slack=last)
     xo, obj, lamk, ti = P4.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=3))
     res.update(c4_x=xo, c4_obj=obj, c4_lam=lamk, c4_iter=ti.iter, s0=s0, s1=s1)
+    # the same problem from a start whose first linesearches FAIL repeatedly: the batched trial retractions (ls_batch) and
+    # their collectives run sharded
+    tr = []
+    xo, obj, lamk, ti = P4.optimize(0.5 * np.ones(s1 - s0), L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=2,
+                                                                           maxiter_retract=25), trace=tr)
+    res.update(c4b_x=xo, c4b_obj=obj, c4b_iter=ti.iter, c4b_r1=np.array([t.get("retract_iter1") or 0 for t in tr]),
+               c4b_alpha=np.array([t.get("alpha") or 0.0 for t in tr]))
     np.savez(out, **res)
     dist.barrier()
     ctx.close()

@@ -92,6 +92,29 @@ def test_sharded_config4_slack_on_last_rank(two_ranks):
     np.testing.assert_allclose(a["c4_lam"], lamr, rtol=1e-7, atol=1e-10)
 
 
+def test_sharded_config4_batched_failed_retractions(two_ranks):
+    """From x0 = 0.5 the first Armijo searches of config 4 see failed Newton retractions, so the trial steps are retracted in
+    batches (lfpsqp_retract_nr_batch): two ranks must agree with each other and with the single-process oracle on
+    every count, accepted step and iterate."""
+    a, b = two_ranks
+    n, m = 3000, 4
+    P0 = synth.BallBoxProblem(n, m)
+    tr0 = []
+    xr, objr, lamr, tir = R.optimize(P0.f, P0.c_, P0.d_, P0.x0, P0.xl, P0.xu, m, 1,
+                                     R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=2, maxiter_retract=25),
+                                     derivatives=P0.derivatives(), trace=tr0)
+    r1 = np.array([t.get("retract_iter1") or 0 for t in tr0])
+    al = np.array([t.get("alpha") or 0.0 for t in tr0])
+    assert r1.max() >= 25                                        # failed retractions did occur
+    for w in (a, b):
+        assert int(w["c4b_iter"]) == tir.iter
+        np.testing.assert_array_equal(w["c4b_r1"], r1)
+        np.testing.assert_array_equal(w["c4b_alpha"], al)
+    x = np.concatenate([a["c4b_x"], b["c4b_x"]])
+    assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
+    np.testing.assert_allclose(a["c4b_obj"], objr, rtol=1e-9)
+
+
 def test_rank_with_zero_rows(two_ranks):
     """n = 1500 < 2048 (the shard granule): rank 1 owns no rows, yet every collective must still be entered."""
     a, b = two_ranks
