@@ -49,6 +49,9 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
     # below consumes them exactly as it would have computed them one by one.
     ahead = {}
     nbatch = int(getattr(param, "ls_batch", 1))
+    from .retractions import NR as _NR, DeviceConstraints as _DC
+    if not (isinstance(retract_method, _NR) and isinstance(c_, _DC)):
+        nbatch = 1                                             # only Newton retractions on device-resident constraints batch
     failed_once = bool(getattr(work, "prev_failed", False))   # searches in a failing regime batch from their first trial
     any_failed = False
     while step_diff > param.eps_x:
