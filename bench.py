@@ -283,6 +283,21 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         ctx.sync(); t0 = time.perf_counter(); flag, pit = L.pcg_(1e-2, _JacPlain(J, w), L.no_precondition, xp, rp_, w.p, w.z, None, 0.0, 24); ctx.sync()
         pcg_ms = (time.perf_counter() - t0) * 1e3 / max(pit, 1)
     pcg_bytes = 8.0 * n_loc * m + 80.0 * n_loc               # one-pass iteration: J once + 10 n-vector passes
+    # four trial points of one linesearch retracted together (lfpsqp_retract_nr_batch): one pass over J per Newton step for all
+    nbt = 4
+    xts = [ctx.vector(n_loc) for _ in range(nbt)]
+    xns = [ctx.vector(n_loc) for _ in range(nbt)]
+    for j, xt_ in enumerate(xts):
+        L.waxpby(1.0, xs, 0.5 ** j, pert, xt_)
+    nrb = L.NR(L.DeviceBasis(Z2, generator=(J, Wg)), S, Vt, 0.0, 24, L.NRWork(m), False, None)
+    cvs = np.zeros((nbt, m))
+    nr_batch_ms = None
+    for rep in range(2):
+        ctx.sync(); t0 = time.perf_counter(); got = L.retract_nr_batch_(cvs, xns, cons, xts, xs, nrb); ctx.sync()
+        if got is not None:
+            nr_batch_ms = (time.perf_counter() - t0) * 1e3 / max(got[0][1], 1)
+    for v_ in xts + xns:
+        v_.free()
     nr1_bytes = 8.0 * n_loc * m + 24.0 * n_loc                # J pass + xnew read/write + v
     nr2_bytes = 16.0 * n_loc * m + 24.0 * n_loc               # Z pass + J pass + xnew read/write + v
     flop = 2.0 * n_loc * m * m
@@ -291,7 +306,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
             "nr_step_two_streams_ms": nr_ms["two_streams"], "nr_step_two_streams_GBs": gbs(nr2_bytes, nr_ms["two_streams"]),
-            "nr_iters_timed": int(it), "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit),
+            "nr_batch4_step_ms": nr_batch_ms, "nr_iters_timed": int(it), "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit),
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies"}
 
 
