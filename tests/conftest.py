@@ -27,6 +27,9 @@ def emu_lib():
 @pytest.fixture(scope="session")
 def gpu_lib():
     import lfpsqp_jl_amd as L
+    import __graft_entry__ as entry
+    if not os.path.exists(entry.LIB):      # a checkout without built artefacts: compile it here (hipcc is in the image)
+        entry.build()
     return L.load_library()   # raises loudly if the HIP extension is not built
 
 
