@@ -100,8 +100,9 @@ def main(argv=None, lib=None):
             ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev))
             comm_used = "torch-nccl-callback"
         else:
-            from lfpsqp_jl_amd.distributed import host_staged_allreduce_callback
-            ctx.comm_init_callback(rank, world, host_staged_allreduce_callback(dev))
+            from lfpsqp_jl_amd.distributed import host_staged_allreduce_callback, torch_allreduce_callback
+            emulated = "emulator" in ctx.device_name      # tests/test_bench_harness.py: the library's buffers are host memory
+            ctx.comm_init_callback(rank, world, torch_allreduce_callback(None) if emulated else host_staged_allreduce_callback(dev))
             comm_used = "host-gloo (functional test)"
     r0, r1 = ctx.shard_range(n, rank, world)
     n_loc = r1 - r0

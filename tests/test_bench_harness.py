@@ -20,3 +20,35 @@ def test_bench_json_contract(emu_lib, capsys):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert out["value"] > 0
+
+
+def test_bench_two_ranks_as_the_driver_launches_it(emu_lib):
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`: row-sharded workload, one
+    all-reduce per iteration (gloo here, RCCL on the GPUs), barrier-bracketed timing, rank 0 prints the one line;
+    the solve is the same as the single-rank one."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "liblfpsqp_emu.so")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--steps", "4", "--warmup", "1", "--rows", "9000", "--cols", "8", "--no-cpu-baseline", "--lib", EMU_LIB]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "host-gloo", "--device", "0", *common]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["config"]["parallelism"] == "row-sharded x2"
+    assert "extras" not in d2 and d2["value"] > 0
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-extras", *common], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["check"]["iters"] == d2["check"]["iters"] == 4
+    assert abs(d1["check"]["x_norm"] - d2["check"]["x_norm"]) <= 1e-10 * d1["check"]["x_norm"]
