@@ -99,3 +99,119 @@ def test_projcg_against_the_c_oracle_port_at_2e6():
     assert np.linalg.norm(xd - x0) <= 1e-10 * np.linalg.norm(x0)
     np.testing.assert_allclose(lam.download(), l0, atol=1e-9)
     ctx.close()
+
+
+@pytest.fixture(scope="module")
+def big_problem():
+    """Config 3's constraint block at full size: Jct = hash matrix (seed 1), tangent setup through lfpsqp_factorize."""
+    ctx = L.Context(0)
+    J = ctx.matrix(N, M).hash_fill(1, 0, N, 1.0)
+    Z = ctx.matrix(N, M)
+    W = np.zeros((M, M), order="F")
+    S, Vt, rank = L.ksvd_(J, Z, W=W)
+    yield ctx, J, Z, S, Vt, W, rank
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_full_size_tangent_setup_is_a_thin_svd(big_problem):
+    """ksvd! (src/la_helper.jl:8-34) at n = 1e7: Z'Z = I, Sigma descending and positive, Vt orthogonal,
+    Jct t = Z (Sigma .* (Vt t)) and Z t = Jct (W t) for a probe t."""
+    ctx, J, Z, S, Vt, W, rank = big_problem
+    assert rank == M and np.all(np.diff(S) <= 0) and S[-1] > 0
+    assert np.abs(L.gram(Z) - np.eye(M)).max() < 5e-13
+    assert np.abs(Vt @ Vt.T - np.eye(M)).max() < 1e-13
+    t = np.cos(np.arange(M) * 0.37) + 0.1
+    y1, y2 = ctx.vector(N), ctx.vector(N)
+    L.gemv_n(J, ctx.vector(M, t), y1)
+    L.gemv_n(Z, ctx.vector(M, S * (Vt @ t)), y2)
+    ref = L.nrm2(y1)
+    L.axpby(1.0, y1, -1.0, y2)
+    assert L.nrm2(y2) <= 1e-12 * ref
+    L.gemv_n(Z, ctx.vector(M, t), y1)
+    L.gemv_n(J, ctx.vector(M, W @ t), y2)
+    ref = L.nrm2(y1)
+    L.axpby(1.0, y1, -1.0, y2)
+    assert L.nrm2(y2) <= 1e-12 * ref
+
+
+@pytest.mark.gpu
+def test_full_size_newton_retraction(big_problem):
+    """retract!(..., ::NR) (src/retractions.jl:75-177) at n = 1e7: converges onto c(x) = J x - b = 0 moving only inside
+    range(U) (the properties of test_retractions.jl:94-101); the one-stream step, the two-stream step and the batched
+    form (three trial points sharing the passes) give the same points in the same number of iterations."""
+    ctx, J, Z, S, Vt, W, rank = big_problem
+    xs = ctx.vector(N).hash_fill(2)
+    bd = ctx.vector(M)
+    L.gemv_t(J, xs, bd)
+    cons = L.DeviceConstraints(J, M, bd.download())
+    noise = ctx.vector(N).hash_fill(4)
+    tol = 1e-7
+    nrm = L.NR(L.DeviceBasis(Z, generator=(J, W)), S, Vt, tol, 30, L.NRWork(M), False, None)
+    xts = [ctx.vector(N) for _ in range(3)]
+    for j, v in enumerate(xts):
+        L.waxpby(1.0, xs, 1e-2 * 0.5 ** j, noise, v)
+    out = {}
+    for mode in (0, -1):
+        ctx.set_onepass(mode)
+        xn, cv = ctx.vector(N), np.zeros(M)
+        flag, it, _ = L.retract_(cv, xn, cons, xts[0], xs, nrm)
+        out[mode] = (flag, it, xn, cv.copy())
+    ctx.set_onepass(0)
+    flag, it, xn, cv = out[0]
+    assert flag == 0 and 1 <= it <= 10 and np.abs(cv).max() < tol
+    c = ctx.vector(M)
+    L.gemv_t(J, xn, c)
+    assert np.abs(c.download() - bd.download()).max() < tol          # c(xnew) recomputed from scratch
+    step = ctx.vector(N)
+    L.waxpby(1.0, xn, -1.0, xts[0], step)                              # xnew - xtilde = U delta
+    size = L.nrm2(step)
+    L.gemv_t(Z, step, c)
+    L.gemv_n(Z, c, step, -1.0, 1.0)
+    assert size > 0 and L.nrm2(step) <= 1e-11 * size
+    assert (out[-1][0], out[-1][1]) == (flag, it)
+    L.waxpby(1.0, xn, -1.0, out[-1][2], step)
+    assert L.nrm2(step) <= 1e-12 * L.nrm2(xn)
+    # batched: three trial points, one pass per Newton iteration
+    xns = [ctx.vector(N) for _ in range(3)]
+    cvs = np.zeros((3, M))
+    got = L.retract_nr_batch_(cvs, xns, cons, xts, xs, nrm)
+    assert got is not None
+    one = ctx.vector(N)
+    for j in range(3):
+        c1 = np.zeros(M)
+        f1, i1, _ = L.retract_(c1, one, cons, xts[j], xs, nrm)
+        assert (got[j][0], got[j][1]) == (f1, i1)
+        L.axpby(1.0, xns[j], -1.0, one)
+        assert L.nrm2(one) <= 1e-12 * L.nrm2(xns[j])
+
+
+@pytest.mark.gpu
+def test_full_size_pcg_solves_the_penalty_system(big_problem):
+    """pcg! (src/retractions.jl:179-246) at n = 1e7: the returned x solves (J'J + mu I) x = b to the tolerance (true
+    residual recomputed with plain GEMVs; the property of test_retractions.jl:121-139), one-pass iteration == two-pass."""
+    from lfpsqp_jl_amd.projpenalty import _JacPlain
+    ctx, J, Z, S, Vt, W, rank = big_problem
+    mu = 1e-2 * float(S[0]) ** 2
+    b = ctx.vector(N).hash_fill(4)
+    tol = 1e-8 * float(S[0])
+    res = {}
+    for mode in (0, -1):
+        ctx.set_onepass(mode)
+        w = L.ProjPenaltyWork(ctx, M, N, False)
+        x, r = ctx.vector(N), ctx.vector(N)
+        r.copy_from(b)
+        flag, it = L.pcg_(mu, _JacPlain(J, w), L.no_precondition, x, r, w.p, w.z, None, tol, 60)
+        res[mode] = (flag, it, x)
+    ctx.set_onepass(0)
+    flag, it, x = res[0]
+    assert flag == 0 and 2 <= it < 60
+    t, y = ctx.vector(M), ctx.vector(N)
+    L.gemv_t(J, x, t)
+    L.gemv_n(J, t, y)                       # y = Jct (Jct' x)
+    L.axpby(mu, x, 1.0, y)                  # + mu x
+    L.axpby(1.0, b, -1.0, y)                # b - (J'J + mu I) x
+    assert L.nrm2(y) <= 2 * tol
+    assert (res[-1][0], res[-1][1]) == (flag, it)
+    L.waxpby(1.0, x, -1.0, res[-1][2], y)
+    assert L.nrm2(y) <= 1e-10 * L.nrm2(x)
