@@ -215,3 +215,59 @@ def test_full_size_pcg_solves_the_penalty_system(big_problem):
     assert (res[-1][0], res[-1][1]) == (flag, it)
     L.waxpby(1.0, x, -1.0, res[-1][2], y)
     assert L.nrm2(y) <= 1e-10 * L.nrm2(x)
+
+
+@pytest.mark.gpu
+def test_full_size_config3_reaches_the_minimum_norm_point():
+    """BASELINE config 3 end to end at n = 1e7, m = 128 (f = x'x s.t. J x = b, x0 = ones): terminates on kkt_tol at the
+    feasible point of least norm -- c(x) = 0 and x in range(J') (its component outside range(U) vanishes)."""
+    ctx = L.Context(0)
+    Jct = ctx.matrix(N, M).hash_fill(1)
+    xs = ctx.vector(N).hash_fill(2)
+    b = ctx.vector(M)
+    L.gemv_t(Jct, xs, b)
+    P = L.QuadLinearBallBox(ctx, N, M, Jct, b.download())
+    x, obj, lam, ti = P.optimize(np.ones(N), L.LFPSQPParams(disp=L.DisplayOption.off))
+    assert ti.condition.name == "kkt_tol" and ti.iter <= 5 and ti.kkt_diff < 1e-6
+    assert all(obj[k + 1] <= obj[k] for k in range(len(obj) - 1))
+    xd = ctx.vector(N, x)
+    c = ctx.vector(M)
+    L.gemv_t(Jct, xd, c)
+    assert np.abs(c.download() - b.download()).max() < 1e-6 * max(1.0, np.abs(b.download()).max())
+    Z = ctx.matrix(N, M)
+    L.ksvd_(Jct, Z)
+    size = L.nrm2(xd)
+    L.gemv_t(Z, xd, c)
+    L.gemv_n(Z, c, xd, -1.0, 1.0)                     # (I - ZZ') x
+    assert L.nrm2(xd) <= 1e-6 * size
+    assert obj[-1] == pytest.approx(size * size, rel=1e-12)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_full_size_config4_ball_and_box():
+    """BASELINE config 4 end to end at full size (N = 1e7 + 1, M = 129; ball + four-way bound pattern, Newton
+    retraction, batched trial retractions): the objective decreases monotonically, the run ends on kkt_tol, the point is
+    feasible for equalities, ball and box, and the objective is the one every earlier full-size run reached."""
+    n, m = N, M
+    ctx = L.Context(0)
+    Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+    xs = ctx.vector(n + 1).hash_fill(2, 0, 1.0, 0.0)
+    ctx.check(ctx.L.lfpsqp_vec_fill_range(ctx.h, xs.h, n, 1, 0.0))
+    b = ctx.vector(m + 1)
+    L.gemv_t(Jct, xs, b, ncols=m)
+    i = np.arange(n)
+    xl = np.where((i % 4 == 1) | (i % 4 == 3), -1.0, -np.inf)
+    xu = np.where((i % 4 == 2) | (i % 4 == 3), 1.0, np.inf)
+    bh = b.download()[:m]
+    P = L.QuadLinearBallBox(ctx, n, m, Jct, bh, R2=n / 2.0, xl=xl, xu=xu)
+    x, obj, lam, ti = P.optimize(0.5 * np.ones(n), L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off))
+    assert ti.condition.name == "kkt_tol" and 10 <= ti.iter <= 30
+    assert all(obj[k + 1] <= obj[k] for k in range(len(obj) - 1))
+    assert obj[-1] == pytest.approx(47.71209, rel=1e-5)
+    assert (x >= xl - 1e-9).all() and (x <= xu + 1e-9).all() and float(x @ x) <= n / 2.0 + 1e-6
+    J2 = ctx.matrix(n, m).hash_fill(1, 0, n, 1.0)
+    c = ctx.vector(m)
+    L.gemv_t(J2, ctx.vector(n, x), c)
+    assert np.abs(c.download() - bh).max() < 1e-6
+    ctx.close()
