@@ -1,4 +1,4 @@
-"""Run a BASELINE config end to end on the GPU at full size:  python tools/run_config.py {2|3|4} [n] [m] [--pp] [--ls-batch=K]"""
+"""Run a BASELINE config end to end on the GPU at full size:  python tools/run_config.py {2|3|4} [n] [m] [--pp] [--ls-batch=K] [--max-outer=K]"""
 import sys, time; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 import lfpsqp_jl_amd as L
@@ -27,6 +27,9 @@ else:
     P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download()[:m], R2=n / 2.0, xl=xl, xu=xu); x0 = 0.5 * np.ones(n)
 ctx.sync(); print(f"setup {time.perf_counter()-t0:.2f}s  device={ctx.device_name}", flush=True)
 t0 = time.perf_counter()
-x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=pp, ls_batch=batch))
+mo = [a for a in sys.argv if a.startswith('--max-outer=')]
+par = L.LFPSQPParams(do_project_retract=pp, ls_batch=batch)
+if mo: par.maxiter = int(mo[0].split('=')[1])
+x, obj, lam, ti = P.optimize(x0, par)
 dt = time.perf_counter() - t0
 print(ti); print(f"optimize wall {dt:.2f}s  f={obj[-1]:.6e}  |lam|max={np.abs(lam).max():.3e}")
