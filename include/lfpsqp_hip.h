@@ -346,9 +346,9 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
 
 /* per-kernel-family device time (ms) accumulated by the last lfpsqp_projcg call when
  * the context was created with profiling on (lfpsqp_ctx_set_profiling); used by
- * bench.py for the roofline object.  slots: 0 = K1 (direction update + d'Ad),
- * 1 = K2 (x/rp update fused with U' rp), 2 = K3 (gp = rp - U t fused with dots),
- * 3 = small reductions/posts, counts[] = launches per slot. */
+ * bench.py for the roofline object.  slots: 0 = K1 (direction update), 3 = F (the one-pass kernel:
+ * rp, gp = rp - U t, U'gp, U'(A gp) and the dots in ONE pass over U); on the two-pass fallback instead
+ * 1 = K2 (x/rp update fused with U' rp) and 2 = K3 (gp = rp - U t fused with dots).  counts[] = launches per slot. */
 int lfpsqp_ctx_set_profiling(lfpsqp_ctx* ctx, int on);
 int lfpsqp_profile_read(lfpsqp_ctx* ctx, double ms[8], int64_t counts[8]);
 
