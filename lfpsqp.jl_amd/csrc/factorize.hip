@@ -371,9 +371,17 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
     LF_TRY(gram_impl(ctx, Jct, m, w2p, G));
     for (double g : G)
         if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix");
-    jacobi_svd(m, m, G, Ug, lam, V);
-    std::vector<double> sig(m);
-    for (int j = 0; j < m; ++j) sig[j] = sqrt(lam[j] > 0 ? lam[j] : 0.0);
+    // G positive definite (the usual case): G = L L', and one-sided Jacobi on the columns of L turns them into sigma_j v_j --
+    // the singular values themselves (not their squares) and the eigenvectors, with no rotation accumulator.  A failed
+    // Cholesky (numerically singular G) takes the rank-revealing route on G itself.
+    std::vector<double> sig(m), Lc;
+    if (cholesky_lower(m, G, Lc)) {
+        std::vector<double> none;
+        jacobi_svd(m, m, Lc, V, sig, none, false);
+    } else {
+        jacobi_svd(m, m, G, Ug, lam, V);
+        for (int j = 0; j < m; ++j) sig[j] = sqrt(lam[j] > 0 ? lam[j] : 0.0);
+    }
     const double thr = fmax(eps_rank, 5e-7 * sig[0]);
     int r = 0;
     while (r < m && sig[r] >= thr && sig[r] > 0) ++r;

@@ -29,18 +29,30 @@ inline int small_threads() {
 // V (cols x cols, orthogonal), with A = U diag(S) V'.
 // One-sided (Hestenes) Jacobi in round-robin order: a sweep is cols-1 rounds of cols/2 DISJOINT column pairs, so the
 // pairs of a round rotate in parallel (OpenMP on the host; the result does not depend on the number of threads).
+// want_v = false: the rotations are not accumulated (V is returned empty) -- enough when only U and S are wanted.
 inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::vector<double>& U, std::vector<double>& S,
-                       std::vector<double>& V) {
+                       std::vector<double>& V, bool want_v = true) {
     std::vector<double> A(Ain);
-    V.assign((size_t)cols * cols, 0.0);
-    for (int j = 0; j < cols; ++j) V[(size_t)j * cols + j] = 1.0;
+    V.assign(want_v ? (size_t)cols * cols : 0, 0.0);
+    for (int j = 0; want_v && j < cols; ++j) V[(size_t)j * cols + j] = 1.0;
     const double eps = 1e-16;
     const int np = cols + (cols & 1);                    // players of the tournament (one dummy if cols is odd)
     std::vector<int> seat(np);
     for (int k = 0; k < np; ++k) seat[k] = (k < cols) ? k : -1;
     const int nthreads = (cols >= 192 && rows >= 192) ? small_threads() : 1;   // below that a round is too short to share
+    // Squared column norms are carried along (a rotation changes them by -+ t*gamma exactly) and recomputed at the start
+    // of every sweep, so a pair costs one dot product instead of three.
+    std::vector<double> sq(cols);
     for (int sweep = 0; sweep < 80 && cols > 1; ++sweep) {
         double off = 0.0;
+#pragma omp parallel for if (nthreads > 1) num_threads(nthreads) schedule(static)
+        for (int j = 0; j < cols; ++j) {
+            const double* aj = &A[(size_t)j * rows];
+            double s = 0.0;
+#pragma omp simd reduction(+ : s)
+            for (int i = 0; i < rows; ++i) s += aj[i] * aj[i];
+            sq[j] = s;
+        }
         for (int round = 0; round < np - 1; ++round) {
 #pragma omp parallel for if (nthreads > 1) num_threads(nthreads) schedule(static) reduction(max : off)
             for (int k = 0; k < np / 2; ++k) {
@@ -49,13 +61,10 @@ inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::
                 if (p > q) std::swap(p, q);
                 double* ap = &A[(size_t)p * rows];
                 double* aq = &A[(size_t)q * rows];
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-#pragma omp simd reduction(+ : alpha, beta, gamma)
-                for (int i = 0; i < rows; ++i) {
-                    alpha += ap[i] * ap[i];
-                    beta += aq[i] * aq[i];
-                    gamma += ap[i] * aq[i];
-                }
+                const double alpha = sq[p], beta = sq[q];
+                double gamma = 0.0;
+#pragma omp simd reduction(+ : gamma)
+                for (int i = 0; i < rows; ++i) gamma += ap[i] * aq[i];
                 if (gamma == 0.0) continue;
                 const double lim = sqrt(alpha * beta);
                 if (fabs(gamma) <= eps * lim) continue;
@@ -69,6 +78,9 @@ inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::
                     ap[i] = c * x - s * y;
                     aq[i] = s * x + c * y;
                 }
+                sq[p] = alpha - t * gamma;
+                sq[q] = beta + t * gamma;
+                if (!want_v) continue;
                 double* vp = &V[(size_t)p * cols];
                 double* vq = &V[(size_t)q * cols];
 #pragma omp simd
@@ -96,14 +108,41 @@ inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return nrm[a] > nrm[b]; });
     U.assign((size_t)rows * cols, 0.0);
     S.assign(cols, 0.0);
-    std::vector<double> Vs((size_t)cols * cols);
+    std::vector<double> Vs(want_v ? (size_t)cols * cols : 0);
     for (int jj = 0; jj < cols; ++jj) {
         const int j = idx[jj];
         S[jj] = nrm[j];
         for (int i = 0; i < rows; ++i) U[(size_t)jj * rows + i] = nrm[j] > 0 ? A[(size_t)j * rows + i] / nrm[j] : 0.0;
-        for (int i = 0; i < cols; ++i) Vs[(size_t)jj * cols + i] = V[(size_t)j * cols + i];
+        for (int i = 0; want_v && i < cols; ++i) Vs[(size_t)jj * cols + i] = V[(size_t)j * cols + i];
     }
     V.swap(Vs);
+}
+
+// Lower Cholesky factor of a symmetric positive definite matrix G (m x m, column-major): G = L L', L column-major with
+// zeros above the diagonal.  Returns false when a pivot is not safely positive (G numerically singular): the caller
+// then takes the rank-revealing route.  Left-looking by columns, so every inner loop runs down a contiguous column.
+inline bool cholesky_lower(int m, const std::vector<double>& G, std::vector<double>& L) {
+    L.assign((size_t)m * m, 0.0);
+    double dmax = 0.0;
+    for (int j = 0; j < m; ++j) dmax = std::max(dmax, G[(size_t)j * m + j]);
+    if (!(dmax > 0.0)) return false;
+    const double floor_piv = 1e-10 * dmax;                 // cond(G) <~ 1e10, i.e. cond(A) <~ 1e5: far inside what G can resolve
+    std::vector<double> col(m);
+    for (int j = 0; j < m; ++j) {
+        for (int i = j; i < m; ++i) col[i] = G[(size_t)j * m + i];
+        for (int k = 0; k < j; ++k) {
+            const double ljk = L[(size_t)k * m + j];
+            const double* lk = &L[(size_t)k * m];
+#pragma omp simd
+            for (int i = j; i < m; ++i) col[i] -= lk[i] * ljk;
+        }
+        if (!(col[j] > floor_piv)) return false;
+        const double d = sqrt(col[j]);
+        double* lj = &L[(size_t)j * m];
+        lj[j] = d;
+        for (int i = j + 1; i < m; ++i) lj[i] = col[i] / d;
+    }
+    return true;
 }
 
 // C (ra x cb) = A (ra x ca) * B (ca x cb), all column-major, tight leading dimensions
