@@ -139,6 +139,7 @@ int lfpsqp_ctx_create(int device, lfpsqp_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         ctx->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
         ctx->num_cu = prop.multiProcessorCount;
+        ctx->real_gpu = strncmp(prop.gcnArchName, "gfx", 3) == 0;
     }
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess;
     ok = ok && hipMalloc((void**)&ctx->scal, 64 * sizeof(double)) == hipSuccess;
@@ -166,6 +167,8 @@ int lfpsqp_ctx_destroy(lfpsqp_ctx* ctx) {
     for (int i = 0; i < 4; ++i) if (ctx->ev_slot[i]) (void)hipEventDestroy(ctx->ev_slot[i]);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
+    if (ctx->eig_handle && ctx->eig_destroy) (void)ctx->eig_destroy(ctx->eig_handle);
+    if (ctx->eig_buf) (void)hipFree(ctx->eig_buf);
     if (ctx->part) (void)hipFree(ctx->part);
     if (ctx->small) (void)hipFree(ctx->small);
     if (ctx->d_m) (void)hipFree(ctx->d_m);

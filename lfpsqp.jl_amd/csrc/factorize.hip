@@ -5,7 +5,9 @@
 // 128 x 128 output tile  C[i][j] += sum_k A[k][i] * B[k][j]  with a 16-deep K step staged through LDS
 // and v_mfma_f64_16x16x4_f64 (lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D row = (l>>4)+4*reg,
 // col = l&15).  Each of the 4 waves owns two 16-row i-tiles x all eight j-tiles = 16 accumulators.
+#include <dlfcn.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -338,6 +340,92 @@ static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const dou
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Eigen-decomposition of the replicated m x m Gram matrix on the device with the vendor's divide-and-conquer solver
+// (rocsolver_dsyevd; measured on MI355X incl. the two small copies: 2.3 ms at m = 128, 11 ms at m = 512 -- the host
+// Jacobi of smallla.h needs 3.5 ms and 105 ms).  The libraries are loaded with dlopen, as RCCL is, so the library keeps
+// no link-time dependency on them; anything missing or failing leaves the job to the host Jacobi.  With several ranks
+// rank 0's result is the one every rank uses (all-reduce with zeros elsewhere: exact), so the replicated factor is
+// bit-identical everywhere whatever the solver's internal ordering.
+// On success: lam[0..m) eigenvalues DEscending, V column j = eigenvector of lam[j].
+// ---------------------------------------------------------------------------
+constexpr int kVendorEigMinM = 96;      // below this the host Jacobi is faster than a device round trip
+
+static bool vendor_eig_ready(lfpsqp_ctx* ctx) {
+    if (ctx->eig_state != 0) return ctx->eig_state > 0;
+    ctx->eig_state = -1;
+    if (const char* e = getenv("LFPSQP_VENDOR_EIG"))
+        if (atoi(e) == 0) return false;
+    void* hb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    if (!hb) hb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    void* hs = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
+    if (!hs) hs = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!hb || !hs) return false;
+    auto create = reinterpret_cast<int (*)(void**)>(dlsym(hb, "rocblas_create_handle"));
+    auto set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(hb, "rocblas_set_stream"));
+    ctx->eig_destroy = reinterpret_cast<int (*)(void*)>(dlsym(hb, "rocblas_destroy_handle"));
+    ctx->eig_dsyevd = reinterpret_cast<int (*)(void*, int, int, int, double*, int, double*, double*, int*)>(dlsym(hs, "rocsolver_dsyevd"));
+    if (!create || !set_stream || !ctx->eig_destroy || !ctx->eig_dsyevd) return false;
+    if (create(&ctx->eig_handle) != 0 || !ctx->eig_handle) { ctx->eig_handle = nullptr; return false; }
+    if (set_stream(ctx->eig_handle, ctx->stream) != 0) return false;
+    ctx->eig_state = 1;
+    return true;
+}
+
+static bool vendor_syevd(lfpsqp_ctx* ctx, int m, const std::vector<double>& G, std::vector<double>& lam, std::vector<double>& V) {
+    if (m < kVendorEigMinM || !ctx->real_gpu) return false;       // the same decision on every rank
+    const size_t mm = (size_t)m * m, need = mm + 2 * (size_t)m + 8;
+    bool ok = vendor_eig_ready(ctx);
+    if (ok && need > ctx->eig_cap) {
+        if (ctx->eig_buf) (void)hipFree(ctx->eig_buf);
+        ctx->eig_buf = nullptr;
+        ctx->eig_cap = 0;
+        ok = hipMalloc((void**)&ctx->eig_buf, need * sizeof(double)) == hipSuccess;
+        if (ok) ctx->eig_cap = need;
+    }
+    double* dA = ctx->eig_buf;            // [A -> eigenvectors | D | E | info]: A and D contiguous for the broadcast below
+    double* dD = dA + mm;
+    double* dE = dD + m;
+    if (ok) {
+        int* dinfo = reinterpret_cast<int*>(dE + m);
+        constexpr int kEvectOriginal = 211, kFillLower = 122;     // rocblas_evect_original, rocblas_fill_lower
+        int info = -1;
+        ok = hipMemcpyAsync(dA, G.data(), mm * sizeof(double), hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+        ok = ok && ctx->eig_dsyevd(ctx->eig_handle, kEvectOriginal, kFillLower, m, dA, m, dD, dE, dinfo) == 0;
+        ok = ok && hipMemcpyAsync(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess && info == 0;
+    }
+    if (ctx->comm_active()) {
+        // every rank takes the same branch and uses the same factor: agree on success (ALL ranks get here), then take
+        // rank 0's numbers
+        if (ensure_mvec(ctx, 8) != 0) return false;
+        ctx->h_m[0] = ok ? 0.0 : 1.0;
+        if (hipMemcpyAsync(ctx->d_m, ctx->h_m, sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
+        if (allreduce_dev(ctx, ctx->d_m, 1, 1) != 0) return false;
+        if (hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+        ok = ctx->h_m[0] == 0.0;
+        if (ok) {
+            if (ctx->comm.rank != 0 && hipMemsetAsync(dA, 0, (mm + m) * sizeof(double), ctx->stream) != hipSuccess) return false;
+            if (allreduce_dev(ctx, dA, (int64_t)(mm + m)) != 0) return false;
+        }
+    }
+    if (!ok) return false;
+    std::vector<double> Va(mm), Da(m);
+    if (hipMemcpyAsync(Va.data(), dA, mm * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+    if (hipMemcpyAsync(Da.data(), dD, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+    lam.resize(m);
+    V.resize(mm);
+    for (int j = 0; j < m; ++j) {         // ascending -> descending
+        const int src = m - 1 - j;
+        lam[j] = Da[src];
+        if (!isfinite(lam[j])) return false;
+        for (int i = 0; i < m; ++i) V[(size_t)j * m + i] = Va[(size_t)src * m + i];
+    }
+    return true;
+}
+
 }  // namespace lfpsqp
 
 using namespace lfpsqp;
@@ -375,7 +463,9 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
     // the singular values themselves (not their squares) and the eigenvectors, with no rotation accumulator.  A failed
     // Cholesky (numerically singular G) takes the rank-revealing route on G itself.
     std::vector<double> sig(m), Lc;
-    if (cholesky_lower(m, G, Lc)) {
+    if (vendor_syevd(ctx, m, G, lam, V)) {
+        for (int j = 0; j < m; ++j) sig[j] = sqrt(lam[j] > 0 ? lam[j] : 0.0);
+    } else if (cholesky_lower(m, G, Lc)) {
         std::vector<double> none;
         jacobi_svd(m, m, Lc, V, sig, none, false);
     } else {

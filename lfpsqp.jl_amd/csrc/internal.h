@@ -77,6 +77,17 @@ struct lfpsqp_ctx {
     // Development override: environment variable LFPSQP_ONEPASS, read once at lfpsqp_ctx_create.
     int tune_onepass = 0;
 
+    // Vendor eigensolver for the replicated m x m Gram matrix of the tangent setup (rocsolver_dsyevd, loaded with dlopen
+    // like RCCL; factorize.hip).  Only on real hardware (gcnArchName "gfx..."); state: 0 untried, 1 ready, -1 unavailable
+    // (then the host Jacobi of smallla.h does the same job).  Development override: LFPSQP_VENDOR_EIG=0.
+    bool real_gpu = false;
+    int eig_state = 0;
+    void* eig_handle = nullptr;                        // rocblas_handle
+    int (*eig_destroy)(void*) = nullptr;
+    int (*eig_dsyevd)(void*, int, int, int, double*, int, double*, double*, int*) = nullptr;
+    double* eig_buf = nullptr;                         // device: m*m + 2m doubles + info
+    size_t eig_cap = 0;
+
     // optional per-kernel-family profiling with HIP events on `stream`
     bool profiling = false;
     hipEvent_t prof_ev[lfpsqp::kProfSlots][lfpsqp::kProfEvents][2];
