@@ -503,7 +503,7 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
     // 3. re-orthonormalise: G2 = Q1'Q1 = V2 L2 V2', W2 = G2^-1/2 (symmetric), B = G2^1/2 S_r V_r'
     std::vector<double> G2, U2, l2, V2;
     LF_TRY(gram_impl(ctx, Z, r, w2p, G2));
-    jacobi_svd(r, r, G2, U2, l2, V2);
+    jacobi_svd(r, r, G2, U2, l2, V2);      // G2 is I + rounding-level terms: Jacobi needs one or two sweeps, less than a device round trip
     if (!(l2[r - 1] > 0.25)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: basis lost orthogonality (min eig %g)", l2[r - 1]);
     std::vector<double> W2((size_t)r * r, 0.0), H2((size_t)r * r, 0.0);
     for (int k = 0; k < r; ++k) {
