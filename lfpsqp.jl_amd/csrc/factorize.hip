@@ -366,6 +366,7 @@ static bool vendor_eig_ready(lfpsqp_ctx* ctx) {
     ctx->eig_destroy = reinterpret_cast<int (*)(void*)>(dlsym(hb, "rocblas_destroy_handle"));
     ctx->eig_dsyevd = reinterpret_cast<int (*)(void*, int, int, int, double*, int, double*, double*, int*)>(dlsym(hs, "rocsolver_dsyevd"));
     if (!create || !set_stream || !ctx->eig_destroy || !ctx->eig_dsyevd) return false;
+    if (hipSetDevice(ctx->device) != hipSuccess) return false;             // the handle binds to the current device
     if (create(&ctx->eig_handle) != 0 || !ctx->eig_handle) { ctx->eig_handle = nullptr; return false; }
     if (set_stream(ctx->eig_handle, ctx->stream) != 0) return false;
     ctx->eig_state = 1;
