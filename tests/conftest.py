@@ -11,6 +11,37 @@ if ROOT not in sys.path:
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "liblfpsqp_emu.so")
 
 
+def _usable_cpus() -> int:
+    """CPUs this process may really use: affinity mask capped by the cgroup quota (a GPU box can show 256 hardware threads
+    to a container that is allowed 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError, IndexError):
+        pass
+    return n
+
+
+# The oracle is numpy on OpenBLAS, which sizes its thread pool by the hardware threads it sees: on a quota-limited box that
+# oversubscribes the allowed CPUs many times over and the (CPU-side) checker crawls.  Child processes inherit the variables;
+# the pool of this process, if numpy is loaded already, is limited in pytest_sessionstart.
+_NT = str(max(1, min(_usable_cpus(), 8)))
+for _var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_var, _NT)
+_BLAS_LIMIT = None
+
+
+def pytest_sessionstart(session):
+    global _BLAS_LIMIT
+    try:
+        from threadpoolctl import threadpool_limits
+        _BLAS_LIMIT = threadpool_limits(limits=int(_NT), user_api="blas")
+    except Exception:       # threadpoolctl missing: the environment variables above still cover a fresh numpy import
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
