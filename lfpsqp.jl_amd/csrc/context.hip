@@ -151,6 +151,7 @@ int lfpsqp_ctx_create(int device, lfpsqp_ctx** out) {
     if (ok) ok = hipMemset(ctx->scal, 0, 64 * sizeof(double)) == hipSuccess && hipMemset(ctx->istat, 0, 64 * sizeof(int64_t)) == hipSuccess;
     if (!ok) { delete ctx; return set_err(nullptr, LFPSQP_ERR_HIP, "context resource allocation failed"); }
     if (const char* e = getenv("LFPSQP_ONEPASS")) ctx->tune_onepass = atoi(e);
+    if (const char* e = getenv("LFPSQP_VENDOR_EIG")) ctx->eig_enabled = atoi(e) == 1;
     *out = ctx;
     return 0;
 }

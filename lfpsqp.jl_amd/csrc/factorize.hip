@@ -344,7 +344,10 @@ static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const dou
 // Eigen-decomposition of the replicated m x m Gram matrix on the device with the vendor's divide-and-conquer solver
 // (rocsolver_dsyevd; measured on MI355X incl. the two small copies: 2.3 ms at m = 128, 11 ms at m = 512 -- the host
 // Jacobi of smallla.h needs 3.5 ms and 105 ms).  The libraries are loaded with dlopen, as RCCL is, so the library keeps
-// no link-time dependency on them; anything missing or failing leaves the job to the host Jacobi.  With several ranks
+// no link-time dependency on them; anything missing or failing leaves the job to the host Jacobi.  OPT-IN
+// (LFPSQP_VENDOR_EIG=1 in the environment of every rank, read at lfpsqp_ctx_create): librocsolver.so is a 0.9 GB file, and
+// the first load on a freshly provisioned box took 4-10 minutes of paging (measured on three boxes; later loads: none).
+// With several ranks
 // rank 0's result is the one every rank uses (all-reduce with zeros elsewhere: exact), so the replicated factor is
 // bit-identical everywhere whatever the solver's internal ordering.
 // On success: lam[0..m) eigenvalues DEscending, V column j = eigenvector of lam[j].
@@ -354,8 +357,6 @@ constexpr int kVendorEigMinM = 96;      // below this the host Jacobi is faster 
 static bool vendor_eig_ready(lfpsqp_ctx* ctx) {
     if (ctx->eig_state != 0) return ctx->eig_state > 0;
     ctx->eig_state = -1;
-    if (const char* e = getenv("LFPSQP_VENDOR_EIG"))
-        if (atoi(e) == 0) return false;
     void* hb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
     if (!hb) hb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
     void* hs = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
@@ -374,7 +375,7 @@ static bool vendor_eig_ready(lfpsqp_ctx* ctx) {
 }
 
 static bool vendor_syevd(lfpsqp_ctx* ctx, int m, const std::vector<double>& G, std::vector<double>& lam, std::vector<double>& V) {
-    if (m < kVendorEigMinM || !ctx->real_gpu) return false;       // the same decision on every rank
+    if (m < kVendorEigMinM || !ctx->real_gpu || !ctx->eig_enabled) return false;   // the same decision on every rank
     const size_t mm = (size_t)m * m, need = mm + 2 * (size_t)m + 8;
     bool ok = vendor_eig_ready(ctx);
     if (ok && need > ctx->eig_cap) {

@@ -79,8 +79,9 @@ struct lfpsqp_ctx {
 
     // Vendor eigensolver for the replicated m x m Gram matrix of the tangent setup (rocsolver_dsyevd, loaded with dlopen
     // like RCCL; factorize.hip).  Only on real hardware (gcnArchName "gfx..."); state: 0 untried, 1 ready, -1 unavailable
-    // (then the host Jacobi of smallla.h does the same job).  Development override: LFPSQP_VENDOR_EIG=0.
+    // (then the host Jacobi of smallla.h does the same job).  Opt-in: LFPSQP_VENDOR_EIG=1, read at lfpsqp_ctx_create.
     bool real_gpu = false;
+    bool eig_enabled = false;
     int eig_state = 0;
     void* eig_handle = nullptr;                        // rocblas_handle
     int (*eig_destroy)(void*) = nullptr;
