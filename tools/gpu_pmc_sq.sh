@@ -7,7 +7,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTI
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq$i -- python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/pmc_sq$i.log 2>&1
 done
 cd $R
-python - <<'PY'
+python - <<'PY' | tee gpurun_out/sq_counters.txt
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_sq*/**/*counter_collection.csv", recursive=True):
