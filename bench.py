@@ -128,13 +128,19 @@ def main(argv=None, lib=None):
         if dist is not None:
             dist.barrier()
 
-    # ---- warmup ------------------------------------------------------------------------
+    # ---- warmup, then EXACTLY K timed steps of the running solve ------------------------------------
+    # The W warmup iterations run in one lfpsqp_projcg call (which also does the solve's set-up: two more passes over U);
+    # the timed region is a second call that RESUMES that solve for K iterations (LFPSQP_PROJCG_RESUME), so a "step" is
+    # one projected-CG iteration and nothing else.  With W = 0 there is nothing to resume: the timed call then contains
+    # the set-up as well (reported in config.timed_region).
+    resumed = W > 0
     if W > 0:
-        L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=W, work=work, n_global=n, want_lambda=False)
+        iw, _ = L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=W, work=work, n_global=n, want_lambda=False)
+        assert iw == W
     ctx.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    iters, nr = L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=K, work=work, n_global=n, want_lambda=False)
+    iters, nr = L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=K, work=work, n_global=n, want_lambda=False, resume=resumed)
     ctx.sync()
     if dist is not None:
         dist.barrier()
@@ -146,8 +152,20 @@ def main(argv=None, lib=None):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    assert iters == K, f"expected {K} iterations, got {iters} (nr={nr})"
+    assert iters == W + K, f"expected {W + K} iterations, got {iters} (nr={nr})"
     assert math.isfinite(nr)
+    x_norm = L.nrm2(x)
+    # the same K iterations as ONE fresh call (set-up inside the clock): what a caller of projcg! with maxit = K sees
+    barrier()
+    t0 = time.perf_counter()
+    L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=K, work=work, n_global=n, want_lambda=False)
+    ctx.sync()
+    single_call = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([single_call], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        single_call = float(t[0])
 
     # ---- per-kernel roofline numbers (HIP events on the library's stream) ---------------
     def avg(slot):
@@ -191,7 +209,9 @@ def main(argv=None, lib=None):
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"sustained projcg, dense basis n={n}, m={m}, A=diag(5+4u), tol=1e-300 (BASELINE configs[2] shape)",
+        "config": {"workload": f"sustained projcg, dense basis n={n}, m={m}, A=diag(5+4u), tol=1e-300 ({shape_name(n, m)})",
+                   "timed_region": (f"{K} iterations of a running solve (resumed after the {W} warmup iterations; set-up outside)"
+                                    if resumed else f"one projcg call: set-up (2 passes over U) + {K} iterations"),
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
                    "comm": comm_used, "device": ctx.device_name},
@@ -218,24 +238,33 @@ def main(argv=None, lib=None):
                    "gemv_n": {"ms": ms_n, "GBs": gbs(bytes_n, ms_n), "frac": gbs(bytes_n, ms_n) / HBM_PEAK_GBS}},
     }
 
-    # HBM traffic of the roofline kernel from the committed PMC passes of this same command
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; tools/pmc_summary.py applies the guide's
-    # gfx950 x2 correction to FETCH_SIZE).  PMC counters cannot be read from inside the timed run.
+    # HBM traffic of the roofline kernel: PMC counters cannot be read from inside the timed run, they come from separate
+    # rocprofv3 --pmc passes of this same command (tools/gpu_final.sh; tools/pmc_summary.py applies the guide's gfx950
+    # correction to FETCH_SIZE).  The committed summary counts as a measurement of THIS build only if it carries the
+    # checksum of the library loaded here; otherwise `traffic` stays null and the old figure is quoted under another key.
     try:
+        import hashlib
         pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("pmc_summary.json"))
         if pmc and world == 1 and n == 10_000_000 and m == 128:
-            summ = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
-            summ = summ.get("kernels", summ)
+            full = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
+            summ = full.get("kernels", full)
+            lib_sha = hashlib.sha256(open(ctx.L.path, "rb").read()).hexdigest()
             for name, v in summ.items():
-                if ("onepass_kernel<lfpsqp::PcgFuseE" if fused else "gemv_t_kernel<lfpsqp::PcgStepV") in name:
-                    out["roofline"]["traffic"] = v["traffic_GB"] * 1e9
-                    out["roofline"]["traffic_source"] = f"profiles/{pmc[-1]} ({v['launches']} launches)"
-    except (OSError, ValueError, KeyError):
+                if isinstance(v, dict) and ("onepass_kernel<lfpsqp::PcgFuseE" if fused else "gemv_t_kernel<lfpsqp::PcgStepV") in name:
+                    rec = {"bytes": v["traffic_GB"] * 1e9, "source": f"profiles/{pmc[-1]} ({v['launches']} launches)"}
+                    if full.get("lib_sha256") == lib_sha:
+                        out["roofline"]["traffic"] = rec["bytes"]
+                        out["roofline"]["traffic_source"] = rec["source"] + ", same library build (sha256 match)"
+                    else:
+                        out["roofline"]["traffic_from_committed_profile"] = dict(rec, note="PMC passes of another build of the library")
+    except (OSError, ValueError, KeyError, AttributeError):
         pass
 
     if not args.no_extras and world == 1:                 # single-GPU diagnostics; the N > 1 runs measure the metric only
         out["extras"] = extras(ctx, L, n, m, n_loc, r0, Z, gbs)
-    out["check"] = {"x_norm": L.nrm2(x), "nr": nr, "iters": iters}    # global ||x|| after the K timed iterations (sanity / N-rank agreement)
+    out["check"] = {"x_norm": x_norm, "nr": nr, "iters": iters}    # global ||x|| after the W + K iterations (sanity / N-rank agreement)
+    out["single_call"] = {"value": K / single_call, "ms_per_step": single_call / K * 1e3,
+                          "note": f"one lfpsqp_projcg call with maxit = {K}: set-up (x = 0, r = -b, U'r, first projection: 2 passes over U) + {K} iterations"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_n), m, n)
     if rank == 0:
@@ -244,6 +273,16 @@ def main(argv=None, lib=None):
     if dist is not None:
         dist.destroy_process_group()
     return out
+
+
+def shape_name(n, m):
+    if (n, m) == (10_000_000, 128):
+        return "BASELINE configs[2] shape"
+    if (n, m) == (5_000_000, 512):
+        return "per-GPU shard of BASELINE configs[4]: n=4e7, m=512 over 8 GPUs"
+    if (n, m) == (40_000_000, 512):
+        return "BASELINE configs[4] shape"
+    return "not a BASELINE shape"
 
 
 def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
@@ -302,8 +341,8 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     nr1_bytes = 8.0 * n_loc * m + 24.0 * n_loc                # J pass + xnew read/write + v
     nr2_bytes = 16.0 * n_loc * m + 24.0 * n_loc               # Z pass + J pass + xnew read/write + v
     flop = 2.0 * n_loc * m * m
-    ceil = stream_ceilings(ctx, L, nbig=int(max(1 << 20, min(400_000_000, 40 * n_loc))))
-    return {"stream_ceilings": ceil, "factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs": flop / gram_ms / 1e9,
+    rates = stream_rates(ctx, L, nbig=int(max(1 << 20, min(400_000_000, 40 * n_loc))))
+    return {"stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs": flop / gram_ms / 1e9,
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
             "nr_step_two_streams_ms": nr_ms["two_streams"], "nr_step_two_streams_GBs": gbs(nr2_bytes, nr_ms["two_streams"]),
@@ -311,18 +350,46 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies"}
 
 
-def stream_ceilings(ctx, L, nbig=400_000_000):
-    """What this box's HBM delivers to the library's own plain streaming kernels on 3.2 GB vectors (far beyond
-    the 256 MB infinity cache): read-only (nrm2, includes one host sync per call), copy (1 read + 1 write),
-    triad (waxpby: 2 reads + 1 write).  Context for the roofline fractions, which are quoted against 8 TB/s."""
+def placements(ctx, L, n, m, n_loc, r0, R=3, its=12):
+    """The fused kernel F on R further allocations of the basis, all alive at once in this process (its time
+    depends on where the 10 GB matrix landed and on the box): avg launch time of F over `its` iterations each."""
+    import statistics
+    keep, f_ms = [], []
+    A = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.0, 5.0))
+    b = ctx.vector(n_loc).hash_fill(4, r0)
+    x = ctx.vector(n_loc)
+    work = L.ProjCGWork(ctx, n_loc, m)
+    for r in range(R):
+        Zr = ctx.matrix(n_loc, m)
+        Zr.hash_fill(1, r0, n, 2.0 ** math.floor(math.log2(math.sqrt(3.0 / n))))
+        keep.append(Zr)
+        L.projcg_(x, None, A, L.DeviceBasis(Zr), b, None, tol=1e-300, maxit=2, work=work, n_global=n, want_lambda=False)
+        ctx.set_profiling(True)
+        L.projcg_(x, None, A, L.DeviceBasis(Zr), b, None, tol=1e-300, maxit=its, work=work, n_global=n, want_lambda=False)
+        ms, cnt = ctx.profile_read()
+        ctx.set_profiling(False)
+        f_ms.append(ms[3] / cnt[3] if cnt[3] else float("nan"))
+    for Zr in keep:
+        Zr.free()
+    return {"F_ms": f_ms, "min": min(f_ms), "median": statistics.median(f_ms), "max": max(f_ms), "allocations": R,
+            "note": "scaled-hash bases, fresh allocations held simultaneously; same process and box as the timed run"}
+
+
+def stream_rates(ctx, L, nbig=400_000_000):
+    """What this box's HBM delivers to the library's own plain streaming kernels on 3.2 GB vectors (far beyond the 256 MB
+    infinity cache): read-only (a one-column GEMV-T: two input streams, result stays on the device, no host sync), copy
+    (1 read + 1 write), triad (waxpby: 2 reads + 1 write).  Context for the roofline fractions, which are quoted against
+    8 TB/s; these are measurements of particular kernels, not ceilings."""
     a = ctx.vector(nbig).hash_fill(11)
     b = ctx.vector(nbig).hash_fill(12)
     c = ctx.vector(nbig)
+    col = ctx.matrix(nbig, 1).hash_fill(13, 0, nbig)
+    t1 = ctx.vector(1)
     reps = 5
-    L.nrm2(a); c.copy_from(a); L.waxpby(1.0, a, 2.0, b, c)
+    L.gemv_t(col, a, t1); c.copy_from(a); L.waxpby(1.0, a, 2.0, b, c)
     ctx.timer_begin()
     for _ in range(reps):
-        L.nrm2(a)
+        L.gemv_t(col, a, t1)
     ms_r = ctx.timer_end() / reps
     ctx.timer_begin()
     for _ in range(reps):
@@ -333,8 +400,10 @@ def stream_ceilings(ctx, L, nbig=400_000_000):
         L.waxpby(1.0, a, 2.0, b, c)
     ms_t = ctx.timer_end() / reps
     g = lambda nb, ms: nb * 8.0 * nbig / (ms * 1e-3) / 1e9
-    del a, b, c
-    return {"read_GBs": g(1, ms_r), "copy_GBs": g(2, ms_c), "triad_GBs": g(3, ms_t), "vector_GB": 8.0 * nbig / 1e9}
+    for v_ in (a, b, c, t1):
+        v_.free()
+    col.free()
+    return {"read_GBs": g(2, ms_r), "copy_GBs": g(2, ms_c), "triad_GBs": g(3, ms_t), "vector_GB": 8.0 * nbig / 1e9}
 
 
 def cpu_baseline(ns, m, n_full):
@@ -353,7 +422,7 @@ def cpu_baseline(ns, m, n_full):
     t0 = time.perf_counter()
     _, _, it, _ = port.projcg(a, U, b, None, 1e-300, k)
     dt = time.perf_counter() - t0
-    k = max(3, min(40, int(12.0 / (dt / k))))                  # ~12 s of CPU work
+    k = max(3, min(600, int(12.0 / (dt / k))))                 # ~12 s of CPU work
     t0 = time.perf_counter()
     _, _, it, _ = port.projcg(a, U, b, None, 1e-300, k)
     dt = time.perf_counter() - t0

@@ -245,6 +245,12 @@ typedef struct lfpsqp_projcg_work {
 } lfpsqp_projcg_work;
 
 #define LFPSQP_PROJCG_WANT_LAMBDA 1 /* compute lambda = U'(b - A x) (src/projcg.jl:115-118) */
+/* Carry on iterating where the previous lfpsqp_projcg call on this context stopped at its iteration limit: same x, A, U, b,
+ * work; `maxit` MORE iterations; *iters counts from the start of the solve.  The iterates are those of one call with the
+ * larger limit (the loop state -- d, g, the CG scalars -- lives in `work` and in the context).  Only after a call that
+ * ran the one-pass iteration and returned by the iteration limit, with no other library call in between; otherwise
+ * LFPSQP_ERR_UNSUPPORTED.  (bench.py times K iterations of a running solve with it; optimize never needs it.) */
+#define LFPSQP_PROJCG_RESUME 2
 
 /* projcg!(x, lambda, A, U, b, c; tol, maxit, work) -> (iters, nr).
  * c == NULL means c = 0 (always the case in optimize, src/optimize.jl:213,368,371).

@@ -45,6 +45,7 @@ int ensure_small(lfpsqp_ctx* ctx, size_t doubles) {
 }
 
 int ensure_mvec(lfpsqp_ctx* ctx, size_t doubles) {
+    ctx->pcg_resume.valid = false;        // whoever asks for the m-vector staging area is about to overwrite it
     if (doubles <= ctx->m_cap) return 0;
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_m) LF_HIP(ctx, hipFree(ctx->d_m));

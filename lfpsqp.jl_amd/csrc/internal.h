@@ -89,6 +89,15 @@ struct lfpsqp_ctx {
     double* eig_buf = nullptr;                         // device: m*m + 2m doubles + info
     size_t eig_cap = 0;
 
+    // state a projcg call that stopped at its iteration limit leaves behind for LFPSQP_PROJCG_RESUME (scalars, t3 and the last sums
+    // stay in scal / d_m; anything else that uses d_m invalidates it -- ensure_mvec)
+    struct ProjcgResume {
+        bool valid = false;
+        const double *x = nullptr, *g = nullptr, *d = nullptr, *Z = nullptr;
+        int m = 0;
+        int64_t nv = 0, iters = 0;
+    } pcg_resume;
+
     // optional per-kernel-family profiling with HIP events on `stream`
     bool profiling = false;
     hipEvent_t prof_ev[lfpsqp::kProfSlots][lfpsqp::kProfEvents][2];
@@ -272,12 +281,12 @@ inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
 // out[k*ncT + j] = sum_rows M[row, j] * v_k[row] (k < NV, j < ncT), out[NV*ncT + r] = reduction r, with v produced by EP
 // from M[row, :ncN] . t -- all-reduced over ranks; one pass over M.  Persistent grid: as many workgroups as the device
 // keeps resident for this instantiation (occupancy query, cached), capped by the number of 64-row rounds.
-template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA>
+template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA, bool LACC>
 inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {
     static int per_cu = 0;                        // one per kernel instantiation
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, NA>, kThreads, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, NA, LACC>, kThreads, 0) != hipSuccess ||
             nb < 1)
             nb = 1;
         per_cu = nb;
@@ -299,12 +308,16 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
     const int part_ld = (int)round_up(nout, 32);
     if (rounds > 0) {
         int grid = 0;
+// LACC (running sums of the second product in LDS): where the registers it frees buy a wave per SIMD and the LDS it takes
+// (NV * ceil(CPL/4) * 2 KB per workgroup) still leaves room for those workgroups -- the single-vector / two-vector kernels
+// with 17..33 column groups per wave (m = 65..132, and 260..528 in the wide form).
 #define LF_OP(CPL, EXACT, WIDE)                                                                                                      \
     do {                                                                                                                             \
-        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA)>(ctx, rounds);                                           \
+        constexpr bool kL = kOpLacc && NA == 1 && (CPL) > 16 && (CPL) <= 33;                                                        \
+        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL>(ctx, rounds);                                       \
         LF_TRY(ensure_part(ctx, (size_t)grid * part_ld + reduce_scratch(part_ld)));                                                  \
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);                                                                              \
-        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA)>), dim3((unsigned)grid), dim3(kThreads), \
+        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL>), dim3((unsigned)grid), dim3(kThreads), \
                            0, ctx->stream, M->p, M->ld, ncN, ncT, n, rounds, t, t_stride, ep, ctx->part, part_ld);                    \
     } while (0)
         if (wide) {

@@ -108,6 +108,26 @@ __device__ __forceinline__ void block_reduce_store(double (&red)[NRED], unsigned
     }
 }
 
+// The same for running sums SHARED by the four lane groups H = lane bits 3..2 (onepass_kernel, EP::kSplitRed): accumulator
+// s of a lane in group h is logical sum 4*s + h.  Sums over the lanes of a group in the order wave_sum uses (xor 32, 16, 2,
+// 1), then over the waves; dst[0 .. NLOG).
+template <int NRL, int NLOG>
+__device__ __forceinline__ void block_reduce_store_split(double (&red)[NRL], double* dst) {
+    __shared__ double sm[kWaves][4 * NRL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < NRL; ++s) {
+        double r = red[s];
+        r += __shfl_xor(r, 32);
+        r += __shfl_xor(r, 16);
+        r += __shfl_xor(r, 2);
+        r += __shfl_xor(r, 1);
+        if ((lane & 0x33) == 0) sm[wave][4 * s + (lane >> 2)] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < NLOG) dst[threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
 // ---------------------------------------------------------------------------
 // GEMV-T: part[tile][j] = sum over the tile's rows of M[row, j] * v[row]
 //   VP::load(row, valid0, valid1) returns (v[row], v[row+1]) and may store fused
@@ -341,9 +361,6 @@ __global__ __launch_bounds__(kThreads) void gemv_nt_kernel(const double* __restr
 // tile rounds (interleaved over its 4 waves), each emitting ONE partial row:
 //   part[wg][k*ncT + j] (k < NV, j < ncT), then part[wg][NV*ncT + r] (r < NRED).
 // Users: the Newton-retraction step (retract.hip) and the fused projected-CG iteration (projcg.hip).
-//   EP::skip()                    uniform: launch is a no-op
-//   EP::Row, EP::fetch(o)         per-row inputs at byte offset o = row*8, fetched one tile ahead of their use
-//   EP::apply(row, o, acc[NA], valid, owner, in, v[NV], red[NRED])   row update; `owner` lanes (one per row) store
 // Host guarantees ncN >= 4, 3*ld*8 + kPadRows*8 < 2^32, (n + kPadRows)*8 < 2^32 and 1 <= gridDim.x <= rounds = ceil(n/64).
 // ---------------------------------------------------------------------------
 // (lanes l, l^BIT) hold (x0, x1) each: returns, in the lanes with BIT clear, x0(l) + x0(l^BIT); with BIT set, x1(l) + x1(l^BIT)
@@ -368,7 +385,47 @@ __device__ __forceinline__ double swap_add(double x0, double x1) {
 // column groups [w*CPL, (w+1)*CPL)); the first product's per-wave partial sums meet in LDS (one barrier per tile round,
 // two buffers), the row update is computed redundantly by every wave (wave 0 stores), the second product stays per wave.
 // NA > 1: NA coefficient vectors t[b*t_stride ...] (batched first product: NA independent right-hand sides share the pass).
-template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA = 1>
+// LACC: the second product's running sums live in LDS (one private 8-byte slot per lane and sum, ds_add_f64, no
+// conflicts, no return value) instead of 2*NV*NQ registers -- at CPL = 32, NV = 2 that is the difference between 3 and 4
+// waves per SIMD.  The adds happen in the order the register version makes them: same bits.
+// PIPE: the next tile's loads of column registers 4j..4j+3 are issued right after their last use in the second product
+// (group by group) instead of after the whole tile -- the registers are dead from there on, so the single-buffered tile
+// gets up to a second product's worth of head start on its memory latency at no register cost.
+//
+// Row functor contract (all members required):
+//   EP::skip()                       uniform: launch is a no-op
+//   EP::Uni, EP::uniform()           wave-uniform inputs, read once per kernel (kept in scalar registers)
+//   EP::Row, EP::fetch(o)            per-row inputs at byte offset o = row*8, fetched one tile ahead of their use
+//   EP::kSplitRed                    the four lane groups H of a row (which all hold the same row values) SHARE the scalar
+//                                    reductions: group h accumulates logical sum 4*s + h in its accumulator s, so a lane keeps
+//                                    ceil(NRED/4) running sums instead of NRED
+//   EP::apply(row, o, acc[NA], valid, owner, lead, uni, in, v[NV], red[NRL])
+//       row update; `owner` lanes (one per row) store; `lead` = this wave's reductions count (wave 0 in the wide form)
+#ifndef LFPSQP_OP_LACC
+#define LFPSQP_OP_LACC 1
+#endif
+#ifndef LFPSQP_OP_PIPE
+#define LFPSQP_OP_PIPE 1
+#endif
+constexpr bool kOpLacc = LFPSQP_OP_LACC != 0, kOpPipe = LFPSQP_OP_PIPE != 0;
+
+struct NoUni {};
+// a wave-uniform double forced into scalar registers
+__device__ __forceinline__ double uniform_f64(double v) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// running sum in LDS: *p += v (no return value; p is private to the lane)
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+#ifdef LFPSQP_HIP_EMULATED
+    *p += v;
+#else
+    (void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
+#endif
+}
+
+template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA = 1, bool LACC = false>
 __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
                                                             int64_t rounds, const double* __restrict__ t, int t_stride, EP ep,
                                                             double* __restrict__ part, int part_ld) {
@@ -377,13 +434,21 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     constexpr int NW = WIDE ? kWaves : 1;            // waves sharing a row tile
     constexpr int kStep = WIDE ? RW : RW * kWaves;   // rows the workgroup advances per tile round
     constexpr int NC = CW * CPL * NW;
-    constexpr int NQ = (CPL + 3) / 4;                // accumulators per lane and vector
+    constexpr int NQ = (CPL + 3) / 4;                // running sums per lane and vector
+    constexpr bool kSplit = EP::kSplitRed;
+    constexpr int NRL = kSplit ? (NRED + 3) / 4 : NRED;   // scalar running sums per lane
     constexpr bool kRowAhead = sizeof(typename EP::Row) <= 16 * sizeof(double);   // fetch the next tile's row inputs a tile ahead
     static_assert(!(EXACT && WIDE), "the exact variant exists for the narrow kernel only");
     static_assert(NA == 1 || !WIDE, "batched first products exist for the narrow kernel only");
+    // LDS: ts (first-product coefficients), accx (wide form: per-wave partial sums of the first product), and ONE buffer
+    // that holds the running sums of the second product during the tile loop (LACC) and the per-wave column sums after it
+    constexpr int kRedD = (WIDE ? 1 : kWaves) * NV * NC;
+    constexpr int kAccD = LACC ? NV * NQ * kThreads : 0;
+    constexpr int kBufD = kRedD > kAccD ? kRedD : (kAccD > 0 ? kAccD : 1);
     __shared__ double ts[NA][NC];
-    __shared__ double red[WIDE ? 1 : kWaves][NV][NC];
+    __shared__ double buf[kBufD];
     __shared__ double accx[2][kWaves][RW];
+    auto red = [&](int w, int qq, int sl) -> double& { return buf[(w * NV + qq) * NC + sl]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = (lane & 3) | ((lane >> 4) << 2), h = (lane >> 2) & 3;
     const int g0 = WIDE ? wave * CPL : 0;            // first column group of this wave
@@ -403,11 +468,19 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
             ts[b][j] = v;
         }
     }
+    double* pl = buf + threadIdx.x;                  // LACC: this lane's running sum (qq, j) is pl[(qq*NQ + j) * kThreads]
+    if (LACC) {
+#pragma unroll
+        for (int s = 0; s < NV * NQ; ++s) pl[s * kThreads] = 0.0;
+    }
     __syncthreads();
+    const typename EP::Uni uni = ep.uniform();
     // Persistent grid (one launch fills the machine once): workgroup b owns the contiguous span of `cnt` tile rounds
     // (kStep rows each) starting at round t0, balanced to +-1 round -- no tail of half-empty scheduling waves, and only
     // gridDim.x partial rows for the second stage.  grid <= rounds, so cnt >= 1.
     const int64_t q = rounds / gridDim.x, rem = rounds % gridDim.x;
+    // (Dealing the rounds round-robin instead -- workgroup b takes rounds b, b + grid, ..., so that the whole grid works on one
+    // window of consecutive rows -- was measured 7 % SLOWER at n = 1e7, m = 128: 2.11 against 1.97 ms on the same box.)
     const int64_t t0 = (int64_t)blockIdx.x * q + ((int64_t)blockIdx.x < rem ? (int64_t)blockIdx.x : rem);
     const int cnt = (int)(q + ((int64_t)blockIdx.x < rem ? 1 : 0));
     const int64_t row0 = t0 * kStep;                                             // uniform
@@ -417,27 +490,27 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     const char* Mb = reinterpret_cast<const char*>(M + row0);
     const int64_t first_off = (int64_t)g0 * cs;
     const int64_t last_off = (int64_t)lastc0 * ld * 8;
-    auto load_tile = [&](double (&a)[CPL], int k) {
+    // column registers [c0, c1) of tile round k
+    auto load_cols = [&](double (&a)[CPL], int k, int c0, int c1) {
         const char* tb = Mb + (int64_t)k * (kStep * 8);                                  // wave-uniform
-        const char* sb = tb + first_off;
         const char* lastb = tb + last_off;
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            a[c] = buf_load_f64<true>((EXACT ? (c < CPL - 1) : (g0 + c < glast)) ? sb : lastb, vo);
-            sb += cs;
-        }
+        for (int c = c0; c < c1; ++c)
+            a[c] = buf_load_f64<true>((EXACT ? (c < CPL - 1) : (g0 + c < glast)) ? tb + first_off + (int64_t)c * cs : lastb, vo);
     };
-    double a[CPL], p[NV][NQ];
+    double a[CPL], p[LACC ? 1 : NV][LACC ? 1 : NQ];
+    if (!LACC) {
 #pragma unroll
-    for (int j = 0; j < NQ; ++j)
+        for (int j = 0; j < NQ; ++j)
 #pragma unroll
-        for (int qq = 0; qq < NV; ++qq) p[qq][j] = 0.0;
-    load_tile(a, 0);
+            for (int qq = 0; qq < NV; ++qq) p[LACC ? 0 : qq][LACC ? 0 : j] = 0.0;
+    }
+    load_cols(a, 0, 0, CPL);
     uint32_t ro = (uint32_t)((row0 + lrow) * 8);
     typename EP::Row in = ep.fetch(ro);
-    double rsum[NRED > 0 ? NRED : 1];
+    double rsum[NRL > 0 ? NRL : 1];
 #pragma unroll
-    for (int qq = 0; qq < (NRED > 0 ? NRED : 1); ++qq) rsum[qq] = 0.0;
+    for (int qq = 0; qq < (NRL > 0 ? NRL : 1); ++qq) rsum[qq] = 0.0;
     auto tile_step = [&](int k, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
         compiler_fence();               // re-read ts[] from LDS every tile instead of pinning 2*CPL registers on it
@@ -461,11 +534,12 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
         typename EP::Row in_next = in;
         if (MORE && kRowAhead) in_next = ep.fetch(ro + kStep * 8);
         double v[NV];
-        ep.apply(row, ro, acc, row < n, h == 0 && (!WIDE || wave == 0), in, v, rsum);
+        const bool lead = !WIDE || wave == 0;
+        ep.apply(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum);
         // second product: columns 4j .. 4j+3 of this lane's group, summed over the row bits RR by two transposing swaps;
         // afterwards the lane holds the 4-row sum of column register 4j + 2*bit4 + bit5
 #pragma unroll
-        for (int j = 0; j < NQ; ++j)
+        for (int j = 0; j < NQ; ++j) {
 #pragma unroll
             for (int qq = 0; qq < NV; ++qq) {
                 const double x0 = a[4 * j] * v[qq];
@@ -474,10 +548,19 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
                 const double x3 = (4 * j + 3 < CPL) ? a[(4 * j + 3 < CPL) ? 4 * j + 3 : 0] * v[qq] : 0.0;
                 const double w01 = swap_add<32>(x0, x1);
                 const double w23 = swap_add<32>(x2, x3);
-                p[qq][j] += swap_add<16>(w01, w23);
+                const double w = swap_add<16>(w01, w23);
+                if (LACC) lds_add_f64(pl + (qq * NQ + j) * kThreads, w);
+                else p[LACC ? 0 : qq][LACC ? 0 : j] += w;
             }
-        compiler_fence();               // the next tile's loads reuse a[]: keep them below its last use (no second buffer)
-        if (MORE) load_tile(a, k + 1);
+            if (kOpPipe && MORE) {      // these four column registers are dead now: start the next tile's loads of them
+                compiler_fence();
+                load_cols(a, k + 1, 4 * j, (4 * j + 4 < CPL) ? 4 * j + 4 : CPL);
+            }
+        }
+        if (!kOpPipe) {
+            compiler_fence();           // the next tile's loads reuse a[]: keep them below its last use (no second buffer)
+            if (MORE) load_cols(a, k + 1, 0, CPL);
+        }
         ro += kStep * 8;
         if (kRowAhead) in = in_next;
         else if (MORE) in = ep.fetch(ro);   // big row records (batched trials): fetched after this tile's use, no second copy live
@@ -486,15 +569,21 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     for (int k = 0; k < cnt - 1; ++k) tile_step(k, std::true_type());
     tile_step(cnt - 1, std::false_type());
     const int creg = 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);     // which of the 4 column registers this lane accumulated
+    double pfin[NV][NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int qq = 0; qq < NV; ++qq) pfin[qq][j] = LACC ? pl[(qq * NQ + j) * kThreads] : p[LACC ? 0 : qq][LACC ? 0 : j];
+    if (LACC) __syncthreads();           // buf changes its role: running sums -> per-wave column sums
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
 #pragma unroll
         for (int qq = 0; qq < NV; ++qq) {
-            double s = p[qq][j];
+            double s = pfin[qq][j];
             s += __shfl_xor(s, 1);       // the remaining row bits rr
             s += __shfl_xor(s, 2);
             const int c = 4 * j + creg;
-            if ((lane & 3) == 0 && c < CPL) red[WIDE ? 0 : wave][qq][(g0 + c) * CW + h] = s;
+            if ((lane & 3) == 0 && c < CPL) red(WIDE ? 0 : wave, qq, (g0 + c) * CW + h) = s;
         }
     __syncthreads();
     double* prow = part + (int64_t)blockIdx.x * part_ld;
@@ -502,9 +591,12 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
         const int qq = j / ncT, col = j - qq * ncT;
         const int sl = (col < glast * CW) ? col : (glast * CW + (col - lastc0));       // slot holding column `col`
         constexpr int W1 = WIDE ? 0 : 1, W2 = WIDE ? 0 : 2, W3 = WIDE ? 0 : 3;   // (the wide form has a single row of slots)
-        prow[j] = WIDE ? red[0][qq][sl] : (red[0][qq][sl] + red[W1][qq][sl]) + (red[W2][qq][sl] + red[W3][qq][sl]);
+        prow[j] = WIDE ? red(0, qq, sl) : (red(0, qq, sl) + red(W1, qq, sl)) + (red(W2, qq, sl) + red(W3, qq, sl));
     }
-    if (NRED > 0) block_reduce_store<(NRED > 0 ? NRED : 1)>(rsum, 0u, prow + NV * ncT);
+    if (NRED > 0) {
+        if (kSplit) block_reduce_store_split<NRL, NRED>(rsum, prow + NV * ncT);
+        else block_reduce_store<(NRL > 0 ? NRL : 1)>(rsum, 0u, prow + NV * ncT);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -181,7 +181,9 @@ struct PcgInnerE {
     const int64_t* istat;
     int first;          // first iteration: p (= r) was already formed by the P1 pass that computed tmp = J p
     PStack k;
-    struct Row { double beta, px, rx, py, ry, Dx, Dy, sx, sy; };
+    static constexpr bool kSplitRed = false;
+    struct Uni { double beta; };
+    struct Row { double px, rx, py, ry, Dx, Dy, sx, sy; };
     static __device__ __forceinline__ double at(const double* base, uint32_t o) {
         return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
     }
@@ -189,9 +191,9 @@ struct PcgInnerE {
         *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + o) = v;
     }
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ Uni uniform() const { return Uni{uniform_f64(ld_scal(scal + P_BETA))}; }
     __device__ __forceinline__ Row fetch(uint32_t o) const {
         Row w;
-        w.beta = ld_scal(scal + P_BETA);
         w.px = at(p, o); w.rx = at(r, o);
         if (ST) {
             w.py = at(p + k.hs, o); w.ry = at(r + k.hs, o);
@@ -201,12 +203,12 @@ struct PcgInnerE {
         }
         return w;
     }
-    __device__ __forceinline__ void apply(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, const Row& w,
-                                          double (&v)[2], double (&red)[1]) const {
+    __device__ __forceinline__ void apply(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool, const Uni& u,
+                                          const Row& w, double (&v)[2], double (&red)[1]) const {
         const double acc = accv[0];
         const bool st = valid && owner;
         if (!ST) {
-            const double pn = first ? w.px : (w.rx + w.beta * w.px);                 // :217
+            const double pn = first ? w.px : (w.rx + u.beta * w.px);                 // :217
             const double zz = fma(mu, pn, acc);                                      // :222
             if (st) {
                 if (!first) put(p, o, pn);
@@ -216,8 +218,8 @@ struct PcgInnerE {
             v[0] = valid ? zz : 0.0;
             v[1] = valid ? w.rx : 0.0;
         } else {
-            const double pnx = first ? w.px : (w.rx + w.beta * w.px);
-            const double pny = first ? w.py : (w.ry + w.beta * w.py);
+            const double pnx = first ? w.px : (w.rx + u.beta * w.px);
+            const double pny = first ? w.py : (w.ry + u.beta * w.py);
             const double ww = w.Dx * pnx + w.Dy * pny;                               // diagonal block of J p
             const double zx = fma(mu, pnx, fma(w.sx, acc, w.Dx * ww));
             const double zy = fma(mu, pny, fma(w.sy, acc, w.Dy * ww));

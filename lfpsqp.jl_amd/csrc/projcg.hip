@@ -205,19 +205,20 @@ struct PcgPost3 {  // beta, next rg, nr, convergence / iteration-limit exits (:9
 
 // ---- F: the fused iteration (one pass over U) -----------------------------------------------------------
 // Row functor of onepass_kernel: N-product acc = U[row, :] . Utr arrives, the row's residual is projected and stored,
-// and the two T-vectors (gp, A gp) go back into the same tile.  init = 1: the initial projection (:58-62): rp is the
+// and the two T-vectors (gp, A gp) go back into the same tile.  INIT: the initial projection (:58-62): rp is the
 // stored residual and d = -g is written.  ST = stacked (bound) form, cf. PcgProjES.
-template <bool ST>
+template <bool ST, bool INIT>
 struct PcgFuseE {
-    const double* rp;   // stored initial residual (init only)
+    const double* rp;   // stored initial residual (INIT only)
     double* g;
     double* d;
     AOpD A;
     const double* scal;
     const int64_t* istat;
-    int init;
     StackD k;           // stacked only
-    struct Row { double alpha, gx, dx, ax, r0x, gy, dy, ay, r0y, Dx, Dy, sx, sy; };
+    static constexpr bool kSplitRed = true;
+    struct Uni { double alpha; };
+    struct Row { double gx, dx, ax, gy, dy, ay, Dx, Dy, sx, sy; };   // INIT: gx / gy carry the stored residual, dx / dy are unused
     static __device__ __forceinline__ double at(const double* base, uint32_t o) {
         return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
     }
@@ -225,62 +226,65 @@ struct PcgFuseE {
         *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + o) = v;
     }
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
+    __device__ __forceinline__ Uni uniform() const { return Uni{INIT ? 0.0 : uniform_f64(ld_scal(scal + S_ALPHA))}; }
     __device__ __forceinline__ Row fetch(uint32_t o) const {
         Row w;
-        w.alpha = init ? 0.0 : ld_scal(scal + S_ALPHA);
-        w.gx = init ? 0.0 : at(g, o);
-        w.dx = init ? 0.0 : at(d, o);
+        w.gx = INIT ? at(rp, o) : at(g, o);
+        w.dx = INIT ? 0.0 : at(d, o);
         w.ax = A.a0 + (A.dg ? at(A.dg, o) : 0.0);
-        w.r0x = init ? at(rp, o) : 0.0;
         if (ST) {
-            w.gy = init ? 0.0 : at(g + k.hs, o);
-            w.dy = init ? 0.0 : at(d + k.hs, o);
+            w.gy = INIT ? at(rp + k.hs, o) : at(g + k.hs, o);
+            w.dy = INIT ? 0.0 : at(d + k.hs, o);
             w.ay = A.a0 + (A.dg ? at(A.dg + k.hs, o) : 0.0);
-            w.r0y = init ? at(rp + k.hs, o) : 0.0;
             w.Dx = at(k.Dx, o); w.Dy = at(k.Dy, o); w.sx = at(k.sx, o); w.sy = at(k.sy, o);
         } else {
-            w.gy = w.dy = w.ay = w.r0y = w.Dx = w.Dy = w.sx = w.sy = 0.0;
+            w.gy = w.dy = w.ay = w.Dx = w.Dy = w.sx = w.sy = 0.0;
         }
         return w;
     }
-    // reductions: rp'gp, gp'gp (:98, :84/:103) and the three sums from which the NEXT iteration's d'Ad follows without a
-    // second global reduction:  d+ = beta d - gp  =>  d+'A d+ = gp'A gp - 2 beta gp'A d + beta^2 d'A d   (all three direct)
-    __device__ __forceinline__ void apply(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, const Row& w,
-                                          double (&v)[2], double (&red)[5]) const {
+    // reductions (logical order in the kernel's output): rp'gp, gp'gp (:98, :84/:103) and the three sums from which the NEXT
+    // iteration's d'Ad follows without a second global reduction:
+    //     d+ = beta d - gp  =>  d+'A d+ = gp'A gp - 2 beta gp'A d + beta^2 d'A d   (all three direct).
+    // The first four are gp times {rp, gp, A gp, A d}: lane group h takes the h-th of them in running sum 0; d'A d is running sum 1
+    // of group 0 (kSplitRed: 2 running sums per lane instead of 5).
+    __device__ __forceinline__ void apply(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
+                                          const Row& w, double (&v)[2], double (&red)[2]) const {
         const double acc = accv[0];
-        const bool st = valid && owner;
+        const bool st = valid && owner, cnt = valid && lead;
+        const int h = (int)((threadIdx.x >> 2) & 3u);
         if (!ST) {
             const double ad = w.ax * w.dx;
-            const double rr = init ? w.r0x : fma(w.alpha, ad, w.gx);                 // :93 (same expression as PcgStepV::rp_at)
+            const double rr = INIT ? w.gx : fma(u.alpha, ad, w.gx);                  // :93 (same expression as PcgStepV::rp_at)
             const double gp = rr - acc;                                              // :97
             const double ag = w.ax * gp;
             if (st) {
                 put(g, o, gp);
-                if (init) put(d, o, -gp);                                            // :62
-                red[0] += rr * gp;                                                   // :98
-                red[1] += gp * gp;                                                   // :84 / :103
-                red[2] += gp * ag;
-                red[3] += gp * ad;
-                red[4] += w.dx * ad;
+                if (INIT) put(d, o, -gp);                                            // :62
+            }
+            const double f = (h == 0) ? rr : ((h == 1) ? gp : ((h == 2) ? ag : ad));
+            if (cnt) {
+                red[0] += gp * f;                                                    // :98, :84 / :103, g'Ag, g'Ad
+                if (h == 0) red[1] += w.dx * ad;                                     // d'Ad
             }
             v[0] = valid ? gp : 0.0;
             v[1] = valid ? ag : 0.0;
         } else {
             const double adx = w.ax * w.dx, ady = w.ay * w.dy;
-            const double rx = init ? w.r0x : fma(w.alpha, adx, w.gx);
-            const double ry = init ? w.r0y : fma(w.alpha, ady, w.gy);
+            const double rx = INIT ? w.gx : fma(u.alpha, adx, w.gx);
+            const double ry = INIT ? w.gy : fma(u.alpha, ady, w.gy);
             const double ww = w.Dx * rx + w.Dy * ry;                                 // diagonal block of Q'rp
             const double gx = rx - fma(w.sx, acc, w.Dx * ww);
             const double gy = ry - fma(w.sy, acc, w.Dy * ww);
             const double agx = w.ax * gx, agy = w.ay * gy;
             if (st) {
                 put(g, o, gx); put(g + k.hs, o, gy);
-                if (init) { put(d, o, -gx); put(d + k.hs, o, -gy); }
-                red[0] += rx * gx + ry * gy;
-                red[1] += gx * gx + gy * gy;
-                red[2] += gx * agx + gy * agy;
-                red[3] += gx * adx + gy * ady;
-                red[4] += w.dx * adx + w.dy * ady;
+                if (INIT) { put(d, o, -gx); put(d + k.hs, o, -gy); }
+            }
+            const double fx = (h == 0) ? rx : ((h == 1) ? gx : ((h == 2) ? agx : adx));
+            const double fy = (h == 0) ? ry : ((h == 1) ? gy : ((h == 2) ? agy : ady));
+            if (cnt) {
+                red[0] += fx * gx + fy * gy;
+                if (h == 0) red[1] += w.dx * adx + w.dy * ady;
             }
             v[0] = valid ? (w.sx * gx + w.sy * gy) : 0.0;                            // the Z-block of Q'g
             v[1] = valid ? (w.sx * agx + w.sy * agy) : 0.0;                          // ... of Q'(A g)
@@ -301,8 +305,13 @@ struct PcgPostF {
     int m, init;
     HostMirror hm;
 };
+// init = 2: RESUME after an iteration-limit exit (LFPSQP_PROJCG_RESUME): the end-of-iteration part already ran in the previous
+// call; the limit has been raised, so the start-of-next-iteration part runs now (x was flushed by that call: alpha_prev = 0).
 __global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
-    if (ld_stat(u.istat + I_STATUS) != ST_RUNNING) return;
+    if (u.init == 2) {
+        if (threadIdx.x == 0) u.istat[I_STATUS] = ST_RUNNING;
+        __syncthreads();
+    } else if (ld_stat(u.istat + I_STATUS) != ST_RUNNING) return;
     __shared__ double sh[2];
     __shared__ int go;
     if (threadIdx.x == 0) {
@@ -312,10 +321,17 @@ __global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
         int64_t it = 0;
         int64_t st = ST_RUNNING;
         double nr = INFINITY;                                           // src/projcg.jl:69
-        if (u.init) {
+        if (u.init == 1) {
             u.scal[S_RG] = gpgp;
             if (ld_stat(u.istat + I_MAXIT) <= 0) st = ST_MAXIT;
             u.hm.publish(st, 0, INFINITY);
+        } else if (u.init == 2) {
+            beta = ld_scal(u.scal + S_BETA);
+            nr = ld_scal(u.scal + S_NR);
+            it = ld_stat(u.istat + I_ITER);
+            if (it >= ld_stat(u.istat + I_MAXIT)) st = ST_MAXIT;
+            u.hm.publish(st, it, nr);
+            dAd_next = fma(beta * beta, dAd, fma(-2.0 * beta, gAd, gAg));
         } else {
             beta = rpgp / ld_scal(u.scal + S_RG);                       // :98
             u.scal[S_BETA] = beta;
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
             if (dAd_next <= 0.0) st = ST_NEGCURV;                       // :77
             else if (gpgp <= 0.0) st = ST_RG_BREAK;                     // :84-87 (r == g)
             else {
-                u.scal[S_ALPHA_PREV] = ld_scal(u.scal + S_ALPHA);       // still owed to x (deferred :92)
+                u.scal[S_ALPHA_PREV] = (u.init == 2) ? 0.0 : ld_scal(u.scal + S_ALPHA);   // still owed to x (deferred :92)
                 u.scal[S_ALPHA] = gpgp / dAd_next;                      // :91
             }
             if (st != ST_RUNNING) u.hm.publish(st, it + 1, nr);
@@ -349,7 +365,7 @@ __global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
     const double alpha = sh[0], beta = sh[1];
     for (int j = threadIdx.x; j < u.m; j += 256) {
         const double t1 = ld_scal(u.T + j), t2 = ld_scal(u.T + u.m + j);
-        const double t3 = u.init ? -t2 : fma(beta, u.t3[j], -t2);
+        const double t3 = (u.init == 1) ? -t2 : fma(beta, u.t3[j], -t2);
         u.t3[j] = t3;
         u.Utr[j] = fma(alpha, t3, t1);
     }
@@ -520,6 +536,7 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
                              const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
     LF_ARG(ctx, ctx && x && A && U && b && work && iters && nr);
     LF_ARG(ctx, work->g && work->d && work->rp && work->Utr);
+    const lfpsqp_ctx::ProjcgResume rs = ctx->pcg_resume;      // (taken before this call's own workspace requests invalidate it)
     const bool stacked = U->Dx != nullptr;
     const int64_t nv = b->n;                       // length of the n-vectors (hs + N when stacked)
     const int m = (int)U->ncols;
@@ -586,38 +603,56 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
         t3 = ctx->d_m + round_up(2 * m + 5, 2);
     }
     auto launch_fused = [&](int init) -> int {
-        if (stacked) {
-            const PcgFuseE<true> fe{rp, g, d, Ad, scal, istat, init, sk};
-            LF_TRY((run_onepass<PcgFuseE<true>, 2, 5>(ctx, Z, m, m, N, Utr, fe, T12, init ? -1 : 3)));
-        } else {
-            const PcgFuseE<false> fe{rp, g, d, Ad, scal, istat, init, sk};
-            LF_TRY((run_onepass<PcgFuseE<false>, 2, 5>(ctx, Z, m, m, N, Utr, fe, T12, init ? -1 : 3)));
-        }
+        const int slot = init ? -1 : 3;
+        if (stacked && init) LF_TRY((run_onepass<PcgFuseE<true, true>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<true, true>{rp, g, d, Ad, scal, istat, sk}, T12, slot)));
+        else if (stacked) LF_TRY((run_onepass<PcgFuseE<true, false>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<true, false>{rp, g, d, Ad, scal, istat, sk}, T12, slot)));
+        else if (init) LF_TRY((run_onepass<PcgFuseE<false, true>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<false, true>{rp, g, d, Ad, scal, istat, sk}, T12, slot)));
+        else LF_TRY((run_onepass<PcgFuseE<false, false>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<false, false>{rp, g, d, Ad, scal, istat, sk}, T12, slot)));
         hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, init, hm});
         LF_LAUNCH_CHECK(ctx);
         return 0;
     };
 
-    hipLaunchKernelGGL((post_kernel<InitState>), dim3(1), dim3(1), 0, ctx->stream, scal, InitState{scal, istat, tol, maxit_eff});
-    LF_LAUNCH_CHECK(ctx);
-
-    // x = U c (:55); c == NULL is the all-zero c of optimize
-    if (c && m > 0) {
-        LF_TRY(lfpsqp_gemv_n(ctx, Z, m, 1.0, c, 0.0, x));
-    } else {
-        LF_TRY(lfpsqp_vec_fill(ctx, x, 0.0));
+    // LFPSQP_PROJCG_RESUME: carry on from the state the previous call left when it stopped at its iteration limit
+    const bool resume = (flags & LFPSQP_PROJCG_RESUME) != 0;
+    int64_t it_base = 0;                              // device iteration number = it_base + host iteration + 1
+    if (resume) {
+        if (!fused || !rs.valid || rs.x != x->p || rs.g != g || rs.d != d || rs.Z != Z->p || rs.m != m || rs.nv != nv)
+            return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "LFPSQP_PROJCG_RESUME: no resumable projcg state for these arguments "
+                           "(needs the one-pass iteration, a previous call that stopped at its iteration limit, and no library call in between)");
+        it_base = rs.iters;
+        maxit_eff = (it_base + maxit < n_global + m_ref) ? it_base + maxit : n_global + m_ref;
+        hstat[1] = it_base;
+        const int64_t lim = maxit_eff;
+        LF_HIP(ctx, hipMemcpyAsync(istat + I_MAXIT, &lim, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));            // (source on the stack)
+        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, 2, hm});
+        LF_LAUNCH_CHECK(ctx);
     }
-    // r = A x - b (kept in rp), Utr = U' r, g = r - U Utr, d = -g, rg = g'g   (:56-62)
-    LF_TRY(launch_residual(1.0, rp, Utr));
-    if (fused) LF_TRY(launch_fused(1));
-    else LF_TRY(launch_k3(1));
+    ctx->pcg_resume.valid = false;
+    if (!resume) {
+        hipLaunchKernelGGL((post_kernel<InitState>), dim3(1), dim3(1), 0, ctx->stream, scal, InitState{scal, istat, tol, maxit_eff});
+        LF_LAUNCH_CHECK(ctx);
+
+        // x = U c (:55); c == NULL is the all-zero c of optimize
+        if (c && m > 0) {
+            LF_TRY(lfpsqp_gemv_n(ctx, Z, m, 1.0, c, 0.0, x));
+        } else {
+            LF_TRY(lfpsqp_vec_fill(ctx, x, 0.0));
+        }
+        // r = A x - b (kept in rp), Utr = U' r, g = r - U Utr, d = -g, rg = g'g   (:56-62)
+        LF_TRY(launch_residual(1.0, rp, Utr));
+        if (fused) LF_TRY(launch_fused(1));
+        else LF_TRY(launch_k3(1));
+    }
 
     int64_t it = 0;
     bool done = false;
-    while (!done && it < maxit_eff) {
+    const int64_t it_end = maxit_eff - it_base;
+    while (!done && it < it_end) {
         if (fused) {
             // one global reduction per iteration: the post-op of F has already done the exits and alpha of this iteration
-            if (it > 0) LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, g, x->p, scal, istat, 0}, 0u, nullptr, NoPost(), 0)));
+            if (it > 0 || resume) LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, g, x->p, scal, istat, 0}, 0u, nullptr, NoPost(), 0)));
             LF_TRY(launch_fused(0));
         } else {
             LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, nv, PcgDirF{d, g, x->p, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
@@ -630,7 +665,7 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
         LF_HIP(ctx, hipEventRecord(ctx->ev_slot[it & 3], ctx->stream));
         if (it >= 2) {
             LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[(it - 2) & 3]));
-            if (hstat[kRingOff + ((it - 1) % kRing)] != ST_RUNNING) done = true;
+            if (hstat[kRingOff + ((it_base + it - 1) % kRing)] != ST_RUNNING) done = true;
         }
         ++it;
     }
@@ -641,8 +676,10 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
 
     // the x-update of the last COMPLETED iteration is still pending (K1 of the next one would have applied it; in the fused
     // flow the exits of an iteration start are taken before its K1, so they leave it pending too)
-    if ((status == ST_CONVERGED || status == ST_MAXIT || (fused && status == ST_RG_BREAK && *iters > 1)) && *iters > 0)
+    if ((status == ST_CONVERGED || status == ST_MAXIT || (fused && status == ST_RG_BREAK && *iters > 1)) && *iters > it_base)
         LF_TRY((run_vec<FlushXF, 0, NoPost>(ctx, nv, FlushXF{x->p, d, scal}, 0u, nullptr, NoPost())));
+    if (fused && status == ST_MAXIT && *iters > 0)
+        ctx->pcg_resume = lfpsqp_ctx::ProjcgResume{true, x->p, g, d, Z->p, m, nv, *iters};
     if (status == ST_NEGCURV) {   // :77-82
         if (fused && *iters > 1)  // d+ = beta d - g of the iteration that found the negative curvature was not formed yet
             LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, g, x->p, scal, istat, 1}, 0u, nullptr, NoPost())));

@@ -168,10 +168,13 @@ template <bool ST>
 struct NRStepRow {
     NRStepE e;
     using Row = NRStepE::Row;
+    using Uni = NoUni;
+    static constexpr bool kSplitRed = false;
     __device__ __forceinline__ bool skip() const { return e.skip(); }
+    __device__ __forceinline__ Uni uniform() const { return Uni{}; }
     __device__ __forceinline__ Row fetch(uint32_t o) const { return e.fetch1<ST>(o); }
-    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[1], bool valid, bool owner, const Row& w,
-                                          double (&v)[1], double (&red)[1]) const {
+    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool, const Uni&,
+                                          const Row& w, double (&v)[1], double (&red)[1]) const {
         v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0]);
     }
 };
@@ -342,6 +345,9 @@ struct NRStepBatchRow {
     const int64_t* ist[NB];       // per-trial status words
     const int64_t* all;
     struct Row { NRStepE::Row sh; unsigned active; };       // sh.xn / sh.yn: this lane group's trial
+    using Uni = NoUni;
+    static constexpr bool kSplitRed = false;
+    __device__ __forceinline__ Uni uniform() const { return Uni{}; }
     __device__ __forceinline__ bool skip() const { return ld_stat(all) != 0; }
     static __device__ __forceinline__ int my_trial() { return (int)((threadIdx.x >> 2) & 3u) % NB; }   // lane bits 3..2 = H
     __device__ __forceinline__ double* my_xnew(int tr) const {
@@ -361,8 +367,8 @@ struct NRStepBatchRow {
             if (ld_stat(ist[b]) == 0) w.active |= 1u << b;
         return w;
     }
-    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[NB], bool valid, bool, const Row& w,
-                                          double (&v)[NB], double (&red)[NB]) const {
+    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[NB], bool valid, bool, bool, const Uni&,
+                                          const Row& w, double (&v)[NB], double (&red)[NB]) const {
         const int h = (int)((threadIdx.x >> 2) & 3u), tr = h % NB;
         double acc_mine = acc[0];
 #pragma unroll

@@ -19,6 +19,7 @@ from . import _capi
 from .device import (Context, DeviceMatrix, DeviceVector, axpby, dot, gemv_n, gemv_t, nrm2, vmul, waxpby)
 
 WANT_LAMBDA = 1
+RESUME = 2
 
 
 class DiagOperator:
@@ -105,7 +106,9 @@ class ProjCGWork:
 
 def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c: DeviceVector | None,
             tol: float = 1e-6, maxit: int | None = None, work: ProjCGWork | None = None, n_global: int | None = None,
-            want_lambda: bool = True):
+            want_lambda: bool = True, resume: bool = False):
+    """``resume=True`` (device path only): ``maxit`` MORE iterations of the solve the previous call left at its iteration
+    limit (LFPSQP_PROJCG_RESUME); the returned count runs from the start of the solve."""
     ctx = x.ctx
     n = b.n
     m = U.ncols if hasattr(U, "ncols") else (c.n if c is not None else 0)
@@ -123,11 +126,13 @@ def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c:
         iters = _capi.c_i64()
         nr = C.c_double()
         a_c, u_c, w_c = A._c(), U._c(), work._c()
-        flags = WANT_LAMBDA if (want_lambda and lam is not None) else 0
+        flags = (WANT_LAMBDA if (want_lambda and lam is not None) else 0) | (RESUME if resume else 0)
         ctx.check(ctx.L.lfpsqp_projcg(ctx.h, x.h, lam.h if lam is not None else None, C.byref(a_c), C.byref(u_c), b.h,
                                       c.h if c is not None else None, float(tol), int(maxit), int(n_global), flags,
                                       C.byref(w_c), C.byref(iters), C.byref(nr)))
         return iters.value, nr.value
+    if resume:
+        raise ValueError("resume is a feature of the device-resident projcg loop")
     return _projcg_generic(x, lam, A, U, b, c, tol, maxit, work, n_global, m)
 
 

@@ -279,4 +279,5 @@ static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __A
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
 template <class T, class V> static inline void __hip_atomic_store(T* p, V v, int, int) { *p = (T)v; }
+static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }   // only used on wave-uniform values
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }

@@ -20,6 +20,8 @@ def test_bench_json_contract(emu_lib, capsys):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert out["value"] > 0
+    assert d["check"]["iters"] == 4 and "resumed" in d["config"]["timed_region"] and d["single_call"]["value"] > 0
+    assert d["roofline"]["traffic"] is None            # no PMC passes of this build
 
 
 def test_bench_two_ranks_as_the_driver_launches_it(emu_lib):
@@ -50,5 +52,5 @@ def test_bench_two_ranks_as_the_driver_launches_it(emu_lib):
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
-    assert d1["check"]["iters"] == d2["check"]["iters"] == 4
+    assert d1["check"]["iters"] == d2["check"]["iters"] == 5        # 1 warmup + 4 timed iterations of one solve
     assert abs(d1["check"]["x_norm"] - d2["check"]["x_norm"]) <= 1e-10 * d1["check"]["x_norm"]

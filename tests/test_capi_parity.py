@@ -205,6 +205,34 @@ def test_projcg_iteration_limit_and_identity_operator(dev_ctx):
     assert np.linalg.norm(x.download() - x0) <= 1e-13 * np.linalg.norm(x0)
 
 
+@pytest.mark.parametrize("n,m,stack", [(2100, 16, False), (1300, 300, False)])
+def test_projcg_resume_continues_the_same_solve(dev_ctx, n, m, stack):
+    """LFPSQP_PROJCG_RESUME (bench.py's timed region): W iterations, then K more, give bit for bit the iterate, count and
+    residual of one call with the limit W + K -- also when the resumed part converges -- and the flag is refused when there
+    is nothing to resume."""
+    ctx = dev_ctx
+    Uh, a, bh = _cg_problem(n, m)
+    U = L.DeviceBasis(ctx.matrix(n, m, Uh))
+    A = L.DiagOperator(0.0, ctx.vector(n, a))
+    b = ctx.vector(n, bh)
+    work, work2 = L.ProjCGWork(ctx, n, m), L.ProjCGWork(ctx, n, m)
+    x1, x2 = ctx.vector(n), ctx.vector(n)
+    for W, K, tol in ((3, 4, 1e-300), (1, 1, 1e-300), (2, 500, 1e-9)):
+        i_ref, nr_ref = L.projcg_(x1, None, A, U, b, None, tol=tol, maxit=W + K, work=work, want_lambda=False)
+        iw, _ = L.projcg_(x2, None, A, U, b, None, tol=tol, maxit=W, work=work2, want_lambda=False)
+        assert iw == W
+        i2, nr2 = L.projcg_(x2, None, A, U, b, None, tol=tol, maxit=K, work=work2, want_lambda=False, resume=True)
+        assert (i2, nr2) == (i_ref, nr_ref)
+        assert np.array_equal(x1.download(), x2.download())
+    with pytest.raises(L.LfpsqpError):        # the converged solve above left nothing to resume
+        L.projcg_(x2, None, A, U, b, None, tol=1e-9, maxit=2, work=work2, want_lambda=False, resume=True)
+    L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=2, work=work2, want_lambda=False)
+    L.nrm2(x2); L.gemv_t(U.Z, x2, ctx.vector(m))      # harmless calls in between keep the state ...
+    L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=1, work=work2, want_lambda=False, resume=True)
+    with pytest.raises(L.LfpsqpError):        # ... other work vectors do not match it
+        L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=1, work=work, want_lambda=False, resume=True)
+
+
 def test_projcg_generic_operator_path(dev_ctx):
     """Duck-typed A (the LinearMap case, src/optimize.jl:228-230) goes through the unfused loop."""
     ctx = dev_ctx

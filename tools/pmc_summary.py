@@ -33,4 +33,8 @@ for k in sorted(F, key=lambda k: -sum(F[k])):
 for k, v in list(out.items())[:14]:
     print(f"{v['traffic_GB']:9.3f} GB  (fetch raw {v['fetch_raw_GB']:7.3f} x{v['fetch_factor']:.3f} = {v['fetch_GB']:7.3f}  write {v['write_GB']:6.3f})  n={v['launches']:3d}  {k[:100]}")
 if calib: print("calibration:", calib)
-json.dump(dict(kernels=out, calibration=calib), open(sys.argv[3], "w"), indent=1)
+# checksum of the library these passes profiled (bench.py quotes `traffic` as measured only for the same build)
+import hashlib, os
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lfpsqp.jl_amd", "lib", "liblfpsqp_hip.so")
+sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+json.dump(dict(kernels=out, calibration=calib, lib_sha256=sha), open(sys.argv[3], "w"), indent=1)
