@@ -271,3 +271,153 @@ def test_full_size_config4_ball_and_box():
     L.gemv_t(J2, ctx.vector(n, x), c)
     assert np.abs(c.download() - bh).max() < 1e-6
     ctx.close()
+
+
+# ---- BASELINE configs[4] at its per-GPU shape: n = 4e7, m = 512 over 8 GPUs = 5e6 rows x 512 columns per rank ------------
+N5, M5 = 5_000_000, 512
+
+
+@pytest.fixture(scope="module")
+def shard5():
+    ctx = L.Context(0)
+    J = ctx.matrix(N5, M5).hash_fill(1, 0, N5, 1.0)
+    Z = ctx.matrix(N5, M5)
+    W = np.zeros((M5, M5), order="F")
+    S, Vt, rank = L.ksvd_(J, Z, W=W)
+    yield ctx, J, Z, S, Vt, W, rank
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_config5_shard_tangent_setup_is_a_thin_svd(shard5):
+    """lfpsqp_factorize at 5e6 x 512 (four column panels in the Gram kernel, the tiled rmul): Z'Z = I, Sigma positive and
+    descending, Vt orthogonal, Jct t = Z (Sigma .* (Vt t)), Z t = Jct (W t)."""
+    ctx, J, Z, S, Vt, W, rank = shard5
+    assert rank == M5 and np.all(np.diff(S) <= 0) and S[-1] > 0
+    assert np.abs(L.gram(Z) - np.eye(M5)).max() < 2e-12
+    assert np.abs(Vt @ Vt.T - np.eye(M5)).max() < 1e-12
+    t = np.cos(np.arange(M5) * 0.37) + 0.1
+    y1, y2 = ctx.vector(N5), ctx.vector(N5)
+    L.gemv_n(J, ctx.vector(M5, t), y1)
+    L.gemv_n(Z, ctx.vector(M5, S * (Vt @ t)), y2)
+    ref = L.nrm2(y1)
+    L.axpby(1.0, y1, -1.0, y2)
+    assert L.nrm2(y2) <= 1e-11 * ref
+    L.gemv_n(Z, ctx.vector(M5, t), y1)
+    L.gemv_n(J, ctx.vector(M5, W @ t), y2)
+    ref = L.nrm2(y1)
+    L.axpby(1.0, y1, -1.0, y2)
+    assert L.nrm2(y2) <= 1e-11 * ref
+
+
+@pytest.mark.gpu
+def test_config5_shard_projcg_wide_onepass_against_two_pass_and_kkt(shard5):
+    """projcg! on the 512-column basis: the WIDE one-pass kernel (the four waves of a workgroup split the columns) and the
+    two-pass kernels run the same solve -- equal iteration counts, iterates within 1e-10 -- and the result satisfies the
+    KKT system of test_cg.jl:24-28 (U'x = 0, projected residual < tol, lambda = U'(b - A x))."""
+    ctx, J, Z, S, Vt, W, rank = shard5
+    a = ctx.vector(N5).hash_fill(3, 0, 4.0, 5.0)
+    b = ctx.vector(N5).hash_fill(4)
+    tol = 1e-8
+    res = {}
+    for mode in (0, -1):
+        ctx.set_onepass(mode)
+        x, lam = ctx.vector(N5), ctx.vector(M5)
+        it, nr = L.projcg_(x, lam, L.DiagOperator(0.0, a), L.DeviceBasis(Z), b, None, tol=tol, maxit=500)
+        res[mode] = (it, nr, x, lam)
+    ctx.set_onepass(0)
+    it, nr, x, lam = res[0]
+    assert nr < tol and 10 < it < 200
+    assert res[-1][0] == it and res[-1][1] == pytest.approx(nr, rel=1e-5)
+    d = ctx.vector(N5)
+    L.waxpby(1.0, x, -1.0, res[-1][2], d)
+    assert L.nrm2(d) <= 1e-10 * L.nrm2(x)
+    np.testing.assert_allclose(lam.download(), res[-1][3].download(), atol=1e-9)
+    t = ctx.vector(M5)
+    L.gemv_t(Z, x, t)
+    assert np.abs(t.download()).max() < 1e-11
+    r = ctx.vector(N5)
+    L.vmul(a, x, r)
+    L.axpby(1.0, b, -1.0, r)
+    L.gemv_t(Z, r, t)
+    np.testing.assert_allclose(t.download(), lam.download(), atol=1e-9)
+    L.gemv_n(Z, t, r, -1.0, 1.0)
+    assert L.nrm2(r) < 10 * tol
+
+
+@pytest.mark.gpu
+def test_config5_shard_newton_retraction_and_pcg(shard5):
+    """The retraction kernels at 512 columns (wide one-stream Newton step, wide one-pass pcg! iteration): the Newton
+    retraction lands on J x = b moving inside range(U), one-stream == two-stream; pcg! solves (J'J + mu I) x = b."""
+    from lfpsqp_jl_amd.projpenalty import _JacPlain
+    ctx, J, Z, S, Vt, W, rank = shard5
+    xs = ctx.vector(N5).hash_fill(2)
+    bd = ctx.vector(M5)
+    L.gemv_t(J, xs, bd)
+    cons = L.DeviceConstraints(J, M5, bd.download())
+    noise = ctx.vector(N5).hash_fill(4)
+    xt = ctx.vector(N5)
+    L.waxpby(1.0, xs, 1e-2, noise, xt)
+    tol = 1e-7
+    nrm = L.NR(L.DeviceBasis(Z, generator=(J, W)), S, Vt, tol, 30, L.NRWork(M5), False, None)
+    out = {}
+    for mode in (0, -1):
+        ctx.set_onepass(mode)
+        xn, cv = ctx.vector(N5), np.zeros(M5)
+        flag, it, _ = L.retract_(cv, xn, cons, xt, xs, nrm)
+        out[mode] = (flag, it, xn, cv.copy())
+    ctx.set_onepass(0)
+    flag, it, xn, cv = out[0]
+    assert flag == 0 and 1 <= it <= 10 and np.abs(cv).max() < tol
+    assert (out[-1][0], out[-1][1]) == (flag, it)
+    step = ctx.vector(N5)
+    L.waxpby(1.0, xn, -1.0, out[-1][2], step)
+    assert L.nrm2(step) <= 1e-12 * L.nrm2(xn)
+    c = ctx.vector(M5)
+    L.gemv_t(J, xn, c)
+    assert np.abs(c.download() - bd.download()).max() < tol
+    mu = 1e-2 * float(S[0]) ** 2
+    b = ctx.vector(N5).hash_fill(4)
+    ptol = 1e-8 * float(S[0])
+    w = L.ProjPenaltyWork(ctx, M5, N5, False)
+    x, r = ctx.vector(N5), ctx.vector(N5)
+    r.copy_from(b)
+    flag, it = L.pcg_(mu, _JacPlain(J, w), L.no_precondition, x, r, w.p, w.z, None, ptol, 60)
+    assert flag == 0 and 2 <= it < 60
+    t, y = ctx.vector(M5), ctx.vector(N5)
+    L.gemv_t(J, x, t)
+    L.gemv_n(J, t, y)
+    L.axpby(mu, x, 1.0, y)
+    L.axpby(1.0, b, -1.0, y)
+    assert L.nrm2(y) <= 2 * ptol
+
+
+@pytest.mark.gpu
+def test_config5_shape_two_ranks_share_the_gpu():
+    """The sharded path at 512 columns: bench.py --gpus 2 as the driver launches it (two processes, each 2.5e6 of the 5e6
+    rows, the library's collectives staged through host gloo because both ranks sit on the one GPU of this box) runs the
+    same solve as one rank: equal iteration count, ||x|| to 1e-10."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--steps", "6", "--warmup", "2", "--rows", str(N5), "--cols", str(M5), "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--comm", "host-gloo", "--device", "0",
+                          *common], cwd=root, capture_output=True, text=True, timeout=1200, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    d2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][0])
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", *common], cwd=root, capture_output=True, text=True,
+                         timeout=1200, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert d2["n_gpus"] == 2 and d2["config"]["rows_per_gpu"] * 2 >= N5 and "configs[4]" in d2["config"]["workload"]
+    assert d1["check"]["iters"] == d2["check"]["iters"] == 8
+    assert abs(d1["check"]["x_norm"] - d2["check"]["x_norm"]) <= 1e-10 * d1["check"]["x_norm"]
+    assert abs(d1["check"]["nr"] - d2["check"]["nr"]) <= 1e-8 * d1["check"]["nr"]
