@@ -172,8 +172,8 @@ int lfpsqp_y_retract(lfpsqp_ctx* ctx, lfpsqp_vec* xnewaug, const lfpsqp_vec* xau
  * outer iteration (src/la_helper.jl:8-34, called at src/optimize.jl:291/293, O(n m^2)) and
  * then only uses: the projector U_r U_r', lambda = V S^-1 U_r'd, and NR's D = S^-1 Vt.  On
  * the device this is a Gram-based factorisation (the "(JJ') normal-equation solve" of the
- * north star): G = A' diag(w2) A on the device, small eigen/SVD problems on the host,
- * Z = A * W on the device, one re-orthonormalisation pass.
+ * north star): G = A' diag(w2) A on the device (MFMA), the replicated m x m eigen/SVD problems by one-sided
+ * Jacobi, Z = A * W on the device (MFMA), refinement rounds when A is ill-conditioned.
  *
  * G_host (ncols x ncols, column-major) = M[:, :ncols]' diag(w2) M[:, :ncols], all-reduced.
  * w2 == NULL means unit weights. */
@@ -183,8 +183,13 @@ int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const doub
 /* Thin factorisation A = diag(sqrt(w2)) * Jct = U S Vt with U = diag(sqrt(w2)) * Z:
  *   Z (n x m, device, Z != Jct): Z' diag(w2) Z = I on the leading `rank` columns, the rest zero
  *   Sigma[m] (host, descending), Vt[m*m] (host, column-major; rows >= rank are zero),
- *   rank = #{Sigma_j >= max(eps_rank, 5e-7 * Sigma_1)}  (reference: Sigma_j >= eps_rank,
- *   src/optimize.jl:297-302; a Gram-based method cannot resolve below ~1e-8 * Sigma_1).
+ *   rank = #{Sigma_j >= eps_rank} -- the reference's ABSOLUTE rule on dgesvd's singular values (src/optimize.jl:297-302,
+ *   eps_rank = 1e-10), which decides between the Newton and the ProjPenalty retraction (:396-412).
+ * Well-conditioned blocks (cond^2 <= 10: the dense random blocks of the BASELINE configs) cost one Gram + one rmul
+ * pass.  Otherwise refinement rounds (one rmul + one Gram pass each, a one-sided Jacobi correction of the replicated
+ * m x m factor in between) resolve the singular values to dgesvd's own accuracy, eps * Sigma_1 absolute: a Gram matrix
+ * alone could not see below ~1e-8 * Sigma_1.  Z's columns are orthonormal to the rounding floor of the product
+ * Jct * w_j, eps * Sigma_1 / Sigma_j.
  * With w2 == NULL, Z is the U of ksvd! up to the sign/rotation freedom of the SVD, to which
  * every use in the reference is invariant.  With bounds, w2 = Dy.^2 and the reference's
  * 2N x M factor of PJct (src/optimize.jl:288-291) is [Dy.^2 .* Z ; -Dx.*Dy .* Z].

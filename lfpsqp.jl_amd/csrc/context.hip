@@ -152,7 +152,6 @@ int lfpsqp_ctx_create(int device, lfpsqp_ctx** out) {
     if (ok) ok = hipMemset(ctx->scal, 0, 64 * sizeof(double)) == hipSuccess && hipMemset(ctx->istat, 0, 64 * sizeof(int64_t)) == hipSuccess;
     if (!ok) { delete ctx; return set_err(nullptr, LFPSQP_ERR_HIP, "context resource allocation failed"); }
     if (const char* e = getenv("LFPSQP_ONEPASS")) ctx->tune_onepass = atoi(e);
-    if (const char* e = getenv("LFPSQP_VENDOR_EIG")) ctx->eig_enabled = atoi(e) == 1;
     *out = ctx;
     return 0;
 }
@@ -169,8 +168,6 @@ int lfpsqp_ctx_destroy(lfpsqp_ctx* ctx) {
     for (int i = 0; i < 4; ++i) if (ctx->ev_slot[i]) (void)hipEventDestroy(ctx->ev_slot[i]);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
-    if (ctx->eig_handle && ctx->eig_destroy) (void)ctx->eig_destroy(ctx->eig_handle);
-    if (ctx->eig_buf) (void)hipFree(ctx->eig_buf);
     if (ctx->part) (void)hipFree(ctx->part);
     if (ctx->small) (void)hipFree(ctx->small);
     if (ctx->d_m) (void)hipFree(ctx->d_m);

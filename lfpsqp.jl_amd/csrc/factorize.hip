@@ -5,10 +5,11 @@
 // 128 x 128 output tile  C[i][j] += sum_k A[k][i] * B[k][j]  with a 16-deep K step staged through LDS
 // and v_mfma_f64_16x16x4_f64 (lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D row = (l>>4)+4*reg,
 // col = l&15).  Each of the 4 waves owns two 16-row i-tiles x all eight j-tiles = 16 accumulators.
-#include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <numeric>
 #include <vector>
 
 #include "internal.h"
@@ -341,91 +342,101 @@ static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const dou
 }
 
 // ---------------------------------------------------------------------------
-// Eigen-decomposition of the replicated m x m Gram matrix on the device with the vendor's divide-and-conquer solver
-// (rocsolver_dsyevd; measured on MI355X incl. the two small copies: 2.3 ms at m = 128, 11 ms at m = 512 -- the host
-// Jacobi of smallla.h needs 3.5 ms and 105 ms).  The libraries are loaded with dlopen, as RCCL is, so the library keeps
-// no link-time dependency on them; anything missing or failing leaves the job to the host Jacobi.  OPT-IN
-// (LFPSQP_VENDOR_EIG=1 in the environment of every rank, read at lfpsqp_ctx_create): librocsolver.so is a 0.9 GB file, and
-// the first load on a freshly provisioned box took 4-10 minutes of paging (measured on three boxes; later loads: none).
-// With several ranks
-// rank 0's result is the one every rank uses (all-reduce with zeros elsewhere: exact), so the replicated factor is
-// bit-identical everywhere whatever the solver's internal ordering.
-// On success: lam[0..m) eigenvalues DEscending, V column j = eigenvector of lam[j].
+// Host side of the factorisation: the replicated m x m problems (smallla.h: one-sided Jacobi, Cholesky).
 // ---------------------------------------------------------------------------
-constexpr int kVendorEigMinM = 96;      // below this the host Jacobi is faster than a device round trip
-
-static bool vendor_eig_ready(lfpsqp_ctx* ctx) {
-    if (ctx->eig_state != 0) return ctx->eig_state > 0;
-    ctx->eig_state = -1;
-    void* hb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
-    if (!hb) hb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    void* hs = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
-    if (!hs) hs = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!hb || !hs) return false;
-    auto create = reinterpret_cast<int (*)(void**)>(dlsym(hb, "rocblas_create_handle"));
-    auto set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(hb, "rocblas_set_stream"));
-    ctx->eig_destroy = reinterpret_cast<int (*)(void*)>(dlsym(hb, "rocblas_destroy_handle"));
-    ctx->eig_dsyevd = reinterpret_cast<int (*)(void*, int, int, int, double*, int, double*, double*, int*)>(dlsym(hs, "rocsolver_dsyevd"));
-    if (!create || !set_stream || !ctx->eig_destroy || !ctx->eig_dsyevd) return false;
-    if (hipSetDevice(ctx->device) != hipSuccess) return false;             // the handle binds to the current device
-    if (create(&ctx->eig_handle) != 0 || !ctx->eig_handle) { ctx->eig_handle = nullptr; return false; }
-    if (set_stream(ctx->eig_handle, ctx->stream) != 0) return false;
-    ctx->eig_state = 1;
-    return true;
+// Eigen-decomposition of a Gram matrix G = V diag(sig^2) V' (sig descending).  G positive definite (the usual case):
+// G = L L', and one-sided Jacobi on the columns of L turns them into sig_j v_j -- the singular values themselves (not their
+// squares) and the eigenvectors, with no rotation accumulator.  A failed Cholesky (numerically singular G) takes Jacobi on G.
+static void gram_eig(int m, const std::vector<double>& G, std::vector<double>& sig, std::vector<double>& V) {
+    std::vector<double> Lc, Ug, lam;
+    sig.assign(m, 0.0);
+    if (cholesky_lower(m, G, Lc)) {
+        std::vector<double> none;
+        jacobi_svd(m, m, Lc, V, sig, none, false);
+    } else {
+        jacobi_svd(m, m, G, Ug, lam, V);
+        for (int j = 0; j < m; ++j) sig[j] = sqrt(lam[j] > 0 ? lam[j] : 0.0);
+    }
 }
 
-static bool vendor_syevd(lfpsqp_ctx* ctx, int m, const std::vector<double>& G, std::vector<double>& lam, std::vector<double>& V) {
-    if (m < kVendorEigMinM || !ctx->real_gpu || !ctx->eig_enabled) return false;   // the same decision on every rank
-    const size_t mm = (size_t)m * m, need = mm + 2 * (size_t)m + 8;
-    bool ok = vendor_eig_ready(ctx);
-    if (ok && need > ctx->eig_cap) {
-        if (ctx->eig_buf) (void)hipFree(ctx->eig_buf);
-        ctx->eig_buf = nullptr;
-        ctx->eig_cap = 0;
-        ok = hipMalloc((void**)&ctx->eig_buf, need * sizeof(double)) == hipSuccess;
-        if (ok) ctx->eig_cap = need;
+// One refinement round of the rank-revealing factorisation (lfpsqp_factorize, step 3).  In: the orthogonal V (m x m), the
+// scalings s (m) the trial basis Z = A V diag(1/s) was formed with, and its measured Gram matrix GZ = Z'Z.  The products
+// z_i'z_j are accurate RELATIVE to |z_i||z_j| however ill-conditioned A is, so the unit-diagonal matrix Gs = GZ ./ (dz dz'),
+// dz = sqrt(diag GZ), is known to absolute accuracy eps -- and the Gram matrix of B = A V, G' = D Gs D with D = diag(s.*dz) (the
+// TRUE column norms of B), is known in factored form.  Its eigen-decomposition to high RELATIVE accuracy (Demmel & Veselic):
+// Gs = Ls Ls' (well conditioned once the columns of B are roughly orthogonal), X = Ls' D, one-sided Jacobi on the columns of
+// X: X V2 = Ux diag(sig_new), so G' = X'X = V2 diag(sig_new^2) V2'.  Then V <- V V2 and sig <- sig_new.
+// Columns whose true norm is at the rounding level of the products (<= noise) are numerically zero: they keep their V column,
+// get sig = their measured norm and take no part.
+// Out: V, sig updated (sig descending); returns through `offmax` the largest |Gs_ij| (i != j) among active columns, through
+// `conv` whether every pair is orthogonal to max(tol, the rounding floor of the product A*w for that pair), through `devmax`
+// the largest |dz_j - 1| among active columns (how well s matched the true norms) and through `rotated` whether V changed.
+static void refine_round(int m, std::vector<double>& V, std::vector<double>& sig, const std::vector<double>& s, const std::vector<double>& GZ,
+                         double tol, double* offmax, bool* conv, double* devmax, bool* rotated) {
+    const double eps = 2.220446049250313e-16;
+    std::vector<double> dz(m), bt(m);
+    double btmax = 0.0;
+    for (int j = 0; j < m; ++j) {
+        const double g = GZ[(size_t)j * m + j];
+        dz[j] = (g > 0.0 && isfinite(g)) ? sqrt(g) : 0.0;
+        bt[j] = s[j] * dz[j];
+        btmax = std::max(btmax, bt[j]);
     }
-    double* dA = ctx->eig_buf;            // [A -> eigenvectors | D | E | info]: A and D contiguous for the broadcast below
-    double* dD = dA + mm;
-    double* dE = dD + m;
-    if (ok) {
-        int* dinfo = reinterpret_cast<int*>(dE + m);
-        constexpr int kEvectOriginal = 211, kFillLower = 122;     // rocblas_evect_original, rocblas_fill_lower
-        int info = -1;
-        ok = hipMemcpyAsync(dA, G.data(), mm * sizeof(double), hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
-        ok = ok && ctx->eig_dsyevd(ctx->eig_handle, kEvectOriginal, kFillLower, m, dA, m, dD, dE, dinfo) == 0;
-        ok = ok && hipMemcpyAsync(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-        ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess && info == 0;
-    }
-    if (ctx->comm_active()) {
-        // every rank takes the same branch and uses the same factor: agree on success (ALL ranks get here), then take
-        // rank 0's numbers
-        if (ensure_mvec(ctx, 8) != 0) return false;
-        ctx->h_m[0] = ok ? 0.0 : 1.0;
-        if (hipMemcpyAsync(ctx->d_m, ctx->h_m, sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
-        if (allreduce_dev(ctx, ctx->d_m, 1, 1) != 0) return false;
-        if (hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
-        ok = ctx->h_m[0] == 0.0;
-        if (ok) {
-            if (ctx->comm.rank != 0 && hipMemsetAsync(dA, 0, (mm + m) * sizeof(double), ctx->stream) != hipSuccess) return false;
-            if (allreduce_dev(ctx, dA, (int64_t)(mm + m)) != 0) return false;
+    const double noise = 64.0 * eps * sqrt((double)m) * btmax;
+    std::vector<int> act;
+    for (int j = 0; j < m; ++j)
+        if (bt[j] > noise) act.push_back(j);
+    const int ma = (int)act.size();
+    *offmax = 0.0; *devmax = 0.0; *conv = true; *rotated = false;
+    std::vector<double> Gs((size_t)ma * ma);
+    for (int b = 0; b < ma; ++b) {
+        *devmax = std::max(*devmax, fabs(dz[act[b]] - 1.0));
+        for (int a = 0; a < ma; ++a) {
+            const double v = GZ[(size_t)act[b] * m + act[a]] / (dz[act[a]] * dz[act[b]]);
+            Gs[(size_t)b * ma + a] = (a == b) ? 1.0 : v;
+            if (a != b) {
+                *offmax = std::max(*offmax, fabs(v));
+                const double floor_ab = 8.0 * sqrt((double)m) * eps * btmax / std::min(bt[act[a]], bt[act[b]]);
+                if (!(fabs(v) <= std::max(tol, floor_ab))) *conv = false;
+            }
         }
     }
-    if (!ok) return false;
-    std::vector<double> Va(mm), Da(m);
-    if (hipMemcpyAsync(Va.data(), dA, mm * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
-    if (hipMemcpyAsync(Da.data(), dD, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
-    lam.resize(m);
-    V.resize(mm);
-    for (int j = 0; j < m; ++j) {         // ascending -> descending
-        const int src = m - 1 - j;
-        lam[j] = Da[src];
-        if (!isfinite(lam[j])) return false;
-        for (int i = 0; i < m; ++i) V[(size_t)j * m + i] = Va[(size_t)src * m + i];
+    std::vector<double> signew(bt), Vnew(V);
+    if (!*conv && ma > 1) {
+        std::vector<double> Ls, X((size_t)ma * ma, 0.0), Ux, S2, V2;
+        if (cholesky_lower(ma, Gs, Ls, 1e-13)) {
+            for (int j = 0; j < ma; ++j)                       // X = Ls' D:  X[i, j] = Ls[j, i] * bt_j
+                for (int i = 0; i <= j; ++i) X[(size_t)j * ma + i] = Ls[(size_t)i * ma + j] * bt[act[j]];
+        } else {                                               // Gs = Ve diag(le) Ve':  X = diag(sqrt(le)) Ve' D
+            std::vector<double> Ue, le, Ve;
+            jacobi_svd(ma, ma, Gs, Ue, le, Ve);
+            for (int j = 0; j < ma; ++j)
+                for (int i = 0; i < ma; ++i) X[(size_t)j * ma + i] = sqrt(le[i] > 0 ? le[i] : 0.0) * Ve[(size_t)i * ma + j] * bt[act[j]];
+        }
+        jacobi_svd(ma, ma, X, Ux, S2, V2);
+        for (int b = 0; b < ma; ++b) {                         // V[:, act] <- V[:, act] * V2
+            double* dst = &Vnew[(size_t)act[b] * m];
+            for (int i = 0; i < m; ++i) dst[i] = 0.0;
+            for (int a = 0; a < ma; ++a) {
+                const double c = V2[(size_t)b * ma + a];
+                const double* src = &V[(size_t)act[a] * m];
+                for (int i = 0; i < m; ++i) dst[i] += src[i] * c;
+            }
+            signew[act[b]] = S2[b];
+        }
+        *rotated = true;
     }
-    return true;
+    // order by singular value, descending (numerically zero columns end up last)
+    std::vector<int> idx(m);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return signew[a] > signew[b]; });
+    bool moved = false;
+    for (int j = 0; j < m; ++j) {
+        moved = moved || idx[j] != j;
+        sig[j] = signew[idx[j]];
+        for (int i = 0; i < m; ++i) V[(size_t)j * m + i] = Vnew[(size_t)idx[j] * m + i];
+    }
+    if (moved) *rotated = true;
 }
 
 }  // namespace lfpsqp
@@ -456,85 +467,83 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
     *rank_out = 0;
     if (m == 0) return 0;
     const double* w2p = w2 ? w2->p : nullptr;
-    // 1. G = A'A, eigen-decomposition (SVD of a PSD matrix)
-    std::vector<double> G, Ug, lam, V;
-    LF_TRY(gram_impl(ctx, Jct, m, w2p, G));
-    for (double g : G)
-        if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix");
-    // G positive definite (the usual case): G = L L', and one-sided Jacobi on the columns of L turns them into sigma_j v_j --
-    // the singular values themselves (not their squares) and the eigenvectors, with no rotation accumulator.  A failed
-    // Cholesky (numerically singular G) takes the rank-revealing route on G itself.
-    std::vector<double> sig(m), Lc;
-    if (vendor_syevd(ctx, m, G, lam, V)) {
-        for (int j = 0; j < m; ++j) sig[j] = sqrt(lam[j] > 0 ? lam[j] : 0.0);
-    } else if (cholesky_lower(m, G, Lc)) {
-        std::vector<double> none;
-        jacobi_svd(m, m, Lc, V, sig, none, false);
-    } else {
-        jacobi_svd(m, m, G, Ug, lam, V);
-        for (int j = 0; j < m; ++j) sig[j] = sqrt(lam[j] > 0 ? lam[j] : 0.0);
-    }
-    const double thr = fmax(eps_rank, 5e-7 * sig[0]);
-    int r = 0;
-    while (r < m && sig[r] >= thr && sig[r] > 0) ++r;
-    for (int j = 0; j < m; ++j) Sigma[j] = sig[j];
     for (size_t i = 0; i < (size_t)m * m; ++i) Vt[i] = 0.0;
     if (W)
         for (size_t i = 0; i < (size_t)m * m; ++i) W[i] = 0.0;
-    *rank_out = r;
-    if (r < Z->m) {    // columns >= rank are zero (the rmul passes below overwrite columns < rank completely)
-        hipLaunchKernelGGL(zero_cols_kernel, dim3(256, (unsigned)(Z->m - r)), dim3(kThreads), 0, ctx->stream, Z->p, Z->ld, Z->n, r);
-        LF_LAUNCH_CHECK(ctx);
-    }
-    if (r == 0) return 0;
-    // 2. Q1 = A V_r S_r^-1
-    std::vector<double> W1((size_t)m * r);
-    for (int j = 0; j < r; ++j)
-        for (int i = 0; i < m; ++i) W1[(size_t)j * m + i] = V[(size_t)j * m + i] / sig[j];
-    LF_TRY(rmul_impl(ctx, Jct, m, W1.data(), r, Z));
-    // 2b. A well-conditioned full-rank factor needs no second pass: the loss of orthogonality of Q1 and the relative error of
-    //     the small singular values are eps * cond(A)^2, i.e. rounding level for cond(A)^2 <= 10 (the dense random
-    //     equality blocks of the BASELINE configs have cond ~ 1.1).  Then A = Q1 S V' is already the factorisation.
-    if (r == m && sig[0] * sig[0] <= 10.0 * sig[m - 1] * sig[m - 1]) {
-        if (W)
-            for (size_t i = 0; i < (size_t)m * m; ++i) W[i] = W1[i];
-        for (int k = 0; k < m; ++k)
-            for (int j = 0; j < m; ++j) Vt[(size_t)j * m + k] = V[(size_t)k * m + j];     // Vt[k, j] = V[j, k]
+    auto zero_from = [&](int r) -> int {       // columns >= r of Z are zero (the rmul passes overwrite columns < r completely)
+        if (r < Z->m) {
+            hipLaunchKernelGGL(zero_cols_kernel, dim3(256, (unsigned)(Z->m - r)), dim3(kThreads), 0, ctx->stream, Z->p, Z->ld, Z->n, r);
+            LF_LAUNCH_CHECK(ctx);
+        }
+        return 0;
+    };
+    auto finish = [&](const std::vector<double>& sig, const std::vector<double>& V, int r, const std::vector<double>* Wr) {
+        for (int j = 0; j < m; ++j) Sigma[j] = sig[j];
+        for (int k = 0; k < r; ++k)
+            for (int j = 0; j < m; ++j) Vt[(size_t)j * m + k] = V[(size_t)k * m + j];     // Vt[k, j] = V[j, k]; rows >= rank stay zero
+        if (W && Wr)
+            for (size_t i = 0; i < (size_t)m * r; ++i) W[i] = (*Wr)[i];                  // Z[:, :r] = Jct * W[:, :r]; columns >= r stay zero
+        *rank_out = r;
+    };
+    // 1. G = A'A (A = diag(sqrt(w2)) Jct), eigen-decomposition: estimates of the singular values and right singular vectors
+    std::vector<double> G, sig, V;
+    LF_TRY(gram_impl(ctx, Jct, m, w2p, G));
+    for (double g : G)
+        if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix");
+    gram_eig(m, G, sig, V);
+    if (!(sig[0] > 0.0)) {                     // A == 0
+        LF_TRY(zero_from(0));
+        finish(sig, V, 0, nullptr);
         return 0;
     }
-    // 3. re-orthonormalise: G2 = Q1'Q1 = V2 L2 V2', W2 = G2^-1/2 (symmetric), B = G2^1/2 S_r V_r'
-    std::vector<double> G2, U2, l2, V2;
-    LF_TRY(gram_impl(ctx, Z, r, w2p, G2));
-    jacobi_svd(r, r, G2, U2, l2, V2);      // G2 is I + rounding-level terms: Jacobi needs one or two sweeps, less than a device round trip
-    if (!(l2[r - 1] > 0.25)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: basis lost orthogonality (min eig %g)", l2[r - 1]);
-    std::vector<double> W2((size_t)r * r, 0.0), H2((size_t)r * r, 0.0);
-    for (int k = 0; k < r; ++k) {
-        const double is = 1.0 / sqrt(l2[k]), s = sqrt(l2[k]);
-        for (int j = 0; j < r; ++j) {
-            const double vjk = V2[(size_t)k * r + j];
-            for (int i = 0; i < r; ++i) {
-                const double vik = V2[(size_t)k * r + i];
-                W2[(size_t)j * r + i] += vik * is * vjk;
-                H2[(size_t)j * r + i] += vik * s * vjk;
-            }
-        }
+    // 2. A well-conditioned full-rank factor needs nothing more: the loss of orthogonality of A V S^-1 and the relative error of the
+    //    small singular values are eps * cond(A)^2, i.e. rounding level for cond(A)^2 <= 10 (the dense random equality blocks of
+    //    the BASELINE configs have cond ~ 1.1).  Then A = (A V S^-1) S V' is already the factorisation.
+    if (sig[m - 1] >= eps_rank && sig[0] * sig[0] <= 10.0 * sig[m - 1] * sig[m - 1]) {
+        std::vector<double> W1((size_t)m * m);
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < m; ++i) W1[(size_t)j * m + i] = V[(size_t)j * m + i] / sig[j];
+        LF_TRY(rmul_impl(ctx, Jct, m, W1.data(), m, Z));
+        LF_TRY(zero_from(m));
+        finish(sig, V, m, &W1);
+        return 0;
     }
-    // B' (m x r) = V_r S_r H2  ->  SVD  B' = Vb S Ub'
-    std::vector<double> VS((size_t)m * r), Bt, Vb, S, Ub;
+    // 3. Otherwise the eigenvalues of G below ~eps * sig_1^2 are noise (a Gram matrix squares the condition number), while the
+    //    reference's dgesvd is backward stable and its rank test is ABSOLUTE (sig_j >= eps_rank = 1e-10, src/optimize.jl:297-302).
+    //    Refinement rounds resolve what dgesvd resolves: form the trial basis Z = A V diag(1/s) with the current estimates,
+    //    measure its Gram matrix on the device, and correct V and the singular values from it on the host (refine_round: a
+    //    one-sided Jacobi step on a well-scaled m x m factor -- every round gains ~8 digits of relative range; converged when
+    //    the trial basis is orthogonal to the rounding floor of the products).  Cost per round: one rmul + one Gram pass.
+    const double tol = 4e-13;
+    constexpr int kMaxRounds = 6;
+    std::vector<double> s(m), Wk((size_t)m * m), GZ;
+    bool z_is_final = false;
+    for (int round = 1; round <= kMaxRounds; ++round) {
+        for (int j = 0; j < m; ++j) s[j] = std::max(sig[j], 1e-12 * sig[0]);
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < m; ++i) Wk[(size_t)j * m + i] = V[(size_t)j * m + i] / s[j];
+        LF_TRY(rmul_impl(ctx, Jct, m, Wk.data(), m, Z));
+        LF_TRY(gram_impl(ctx, Z, m, w2p, GZ));
+        for (double g : GZ)
+            if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix of the trial basis");
+        double offmax = 0.0, devmax = 0.0;
+        bool conv = false, rotated = false;
+        refine_round(m, V, sig, s, GZ, tol, &offmax, &conv, &devmax, &rotated);
+        if (conv && !rotated && devmax <= tol) {          // the basis on the device IS A V diag(1/sig) for every kept column
+            z_is_final = true;
+            break;
+        }
+        // quadratic convergence: a correction computed from an almost orthogonal trial basis (off-diagonals E) leaves E^2
+        if (conv || offmax <= 5e-7) break;
+    }
+    int r = 0;
+    while (r < m && sig[r] >= eps_rank && sig[r] > 0) ++r;                               // the reference's rule, src/optimize.jl:297-302
+    std::vector<double> Wr((size_t)m * std::max(r, 1));
     for (int j = 0; j < r; ++j)
-        for (int i = 0; i < m; ++i) VS[(size_t)j * m + i] = V[(size_t)j * m + i] * sig[j];
-    matmul(m, r, r, VS, H2, Bt);
-    jacobi_svd(m, r, Bt, Vb, S, Ub);
-    // 4. Z = A (W1 W2 Ub)
-    std::vector<double> T, Wtot;
-    matmul(r, r, r, W2, Ub, T);
-    matmul(m, r, r, W1, T, Wtot);
-    LF_TRY(rmul_impl(ctx, Jct, m, Wtot.data(), r, Z));
-    if (W)
-        for (size_t i = 0; i < (size_t)m * r; ++i) W[i] = Wtot[i];        // Z[:, :r] = Jct * W[:, :r]; columns >= r stay zero
-    for (int j = 0; j < r; ++j) Sigma[j] = S[j];
-    for (int k = 0; k < r; ++k)
-        for (int j = 0; j < m; ++j) Vt[(size_t)j * m + k] = Vb[(size_t)k * m + j];   // Vt[k, j] = Vb[j, k]
+        for (int i = 0; i < m; ++i) Wr[(size_t)j * m + i] = V[(size_t)j * m + i] / sig[j];
+    if (r > 0 && !z_is_final) LF_TRY(rmul_impl(ctx, Jct, m, Wr.data(), r, Z));
+    LF_TRY(zero_from(r));
+    finish(sig, V, r, &Wr);
     return 0;
 }
 

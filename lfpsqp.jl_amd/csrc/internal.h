@@ -77,17 +77,7 @@ struct lfpsqp_ctx {
     // Development override: environment variable LFPSQP_ONEPASS, read once at lfpsqp_ctx_create.
     int tune_onepass = 0;
 
-    // Vendor eigensolver for the replicated m x m Gram matrix of the tangent setup (rocsolver_dsyevd, loaded with dlopen
-    // like RCCL; factorize.hip).  Only on real hardware (gcnArchName "gfx..."); state: 0 untried, 1 ready, -1 unavailable
-    // (then the host Jacobi of smallla.h does the same job).  Opt-in: LFPSQP_VENDOR_EIG=1, read at lfpsqp_ctx_create.
-    bool real_gpu = false;
-    bool eig_enabled = false;
-    int eig_state = 0;
-    void* eig_handle = nullptr;                        // rocblas_handle
-    int (*eig_destroy)(void*) = nullptr;
-    int (*eig_dsyevd)(void*, int, int, int, double*, int, double*, double*, int*) = nullptr;
-    double* eig_buf = nullptr;                         // device: m*m + 2m doubles + info
-    size_t eig_cap = 0;
+    bool real_gpu = false;   // gcnArchName "gfx..." (false only in the CPU emulator build of the tests)
 
     // state a projcg call that stopped at its iteration limit leaves behind for LFPSQP_PROJCG_RESUME (scalars, t3 and the last sums
     // stay in scal / d_m; anything else that uses d_m invalidates it -- ensure_mvec)

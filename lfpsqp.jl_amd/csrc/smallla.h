@@ -121,12 +121,12 @@ inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::
 // Lower Cholesky factor of a symmetric positive definite matrix G (m x m, column-major): G = L L', L column-major with
 // zeros above the diagonal.  Returns false when a pivot is not safely positive (G numerically singular): the caller
 // then takes the rank-revealing route.  Left-looking by columns, so every inner loop runs down a contiguous column.
-inline bool cholesky_lower(int m, const std::vector<double>& G, std::vector<double>& L) {
+inline bool cholesky_lower(int m, const std::vector<double>& G, std::vector<double>& L, double rel_floor = 1e-10) {
     L.assign((size_t)m * m, 0.0);
     double dmax = 0.0;
     for (int j = 0; j < m; ++j) dmax = std::max(dmax, G[(size_t)j * m + j]);
     if (!(dmax > 0.0)) return false;
-    const double floor_piv = 1e-10 * dmax;                 // cond(G) <~ 1e10, i.e. cond(A) <~ 1e5: far inside what G can resolve
+    const double floor_piv = rel_floor * dmax;             // default: cond(G) <~ 1e10, i.e. cond(A) <~ 1e5: far inside what G can resolve
     std::vector<double> col(m);
     for (int j = 0; j < m; ++j) {
         for (int i = j; i < m; ++i) col[i] = G[(size_t)j * m + i];

@@ -15,8 +15,11 @@ outer iteration.  Callback contract (the device analogue of the reference's):
                               hess_lag_vec_(dest, src, x, lam) on device vectors (generic path)
 
 Deviations from the reference, all invisible in the iterates up to rounding: the thin SVD is the
-Gram-based factorisation of lfpsqp_factorize (basis rotation / sign freedom), ``Jct`` is not
-destroyed by it, and the 2N x M factor with bounds is never materialised."""
+Gram-based factorisation of lfpsqp_factorize (basis rotation / sign freedom; the rank is the reference's
+``sigma >= eps_rank`` on singular values of dgesvd's accuracy, so the Newton / ProjPenalty choice is the
+reference's also for ill-conditioned Jacobians), ``Jct`` is not destroyed by it, and the 2N x M factor with
+bounds is never materialised.  Where the reference itself fails -- a rank-deficient block without bounds ends
+in a DimensionMismatch at src/projcg.jl:118 -- this driver carries on with ProjPenalty."""
 from __future__ import annotations
 
 import math

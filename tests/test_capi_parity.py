@@ -385,24 +385,84 @@ def test_tuning_variants_agree(dev_ctx):
         ctx.set_tuning(3, True)
 
 
-def test_factorize_ill_conditioned(dev_ctx):
-    """Gram-based factorisation with the re-orthonormalisation pass on a matrix of condition number 1e5
-    (the reference's dgesvd is backward stable; SURVEY §7 'hard parts')."""
-    ctx = dev_ctx
-    n, m = 3000, 12
-    rng = np.random.default_rng(21)
+def _with_singular_values(n, sv, seed=21):
+    rng = np.random.default_rng(seed)
+    m = len(sv)
     Q1, _ = np.linalg.qr(rng.standard_normal((n, m)))
     Q2, _ = np.linalg.qr(rng.standard_normal((m, m)))
-    sv = np.logspace(0, -5, m)
-    Jh = np.asfortranarray((Q1 * sv) @ Q2.T)
+    return np.asfortranarray((Q1 * np.asarray(sv)) @ Q2.T), Q1
+
+
+@pytest.mark.parametrize("case", ["cond1e5", "cond1e7", "cond1e9", "cluster", "across_eps_rank", "big_sigma1", "duplicates", "zero_column", "m200"])
+def test_factorize_honours_the_reference_rank_rule(dev_ctx, case):
+    """The reference factors with backward-stable dgesvd and counts sigma_j >= eps_rank = 1e-10 ABSOLUTELY
+    (src/la_helper.jl:8-34, src/optimize.jl:297-302) -- a Jacobian of condition 1e9 whose singular values all exceed 1e-10 is
+    full rank there (Newton retraction, full tangent projection).  lfpsqp_factorize must make the same decision as the
+    oracle's dgesvd and return what dgesvd returns to ITS accuracy: singular values to eps*sigma_1 absolute, the rank, a basis
+    of range(A V_r) orthonormal to the rounding floor of the problem (eps * sigma_1 / sigma_j), the projector, A = Z S Vt."""
+    ctx = dev_ctx
+    n = 3000
+    dup = zero = False
+    if case == "cond1e5": sv = np.logspace(0, -5, 12)
+    elif case == "cond1e7": sv = np.logspace(0, -7, 12)
+    elif case == "cond1e9": sv = np.logspace(0, -9, 12)
+    elif case == "cluster": sv = np.array([1.0, 1.0, 0.5, 1e-8, 1e-9, 1.0001e-9, 3e-10, 2e-10])
+    elif case == "across_eps_rank": sv = np.array([2.0, 1.0, 1e-3, 1e-6, 1e-9, 1.5e-10, 0.5e-10, 1e-12])
+    elif case == "big_sigma1": sv = np.array([1e3, 10.0, 1.0, 1e-3, 1e-6, 1e-9])
+    elif case == "duplicates": sv, dup = np.logspace(0, -3, 12), True
+    elif case == "zero_column": sv, zero = np.logspace(0, -2, 9), True
+    else: sv = np.logspace(0, -8, 200)
+    Jh, _ = _with_singular_values(n, sv)
+    if dup:
+        Jh[:, -1] = Jh[:, 0]                     # exactly rank deficient
+        Jh[:, -2] = Jh[:, 1]
+    if zero:
+        Jh[:, 3] = 0.0
+    m = Jh.shape[1]
+    U0 = np.empty((n, m), order='F'); S0 = np.empty(m); Vt0 = np.empty((m, m), order='F')
+    R.ksvd_(Jh.copy(order='F'), U0, S0, Vt0)
+    rank0 = int(np.sum(S0 >= 1e-10))
     J, Z = ctx.matrix(n, m, Jh), ctx.matrix(n, m)
-    S, Vt, rank = L.ksvd_(J, Z)
+    W = np.zeros((m, m), order='F')
+    S, Vt, rank = L.ksvd_(J, Z, W=W)
     Zh = Z.download()
-    assert rank == m
-    np.testing.assert_allclose(S, sv, rtol=1e-5)                       # kappa^2 * eps relative accuracy on sigma
-    np.testing.assert_allclose(Zh.T @ Zh, np.eye(m), atol=1e-10)      # orthonormal after the second pass
-    np.testing.assert_allclose((Zh * S) @ Vt, Jh, atol=1e-12)
-    np.testing.assert_allclose(Zh @ (Zh.T @ np.ones(n)), Q1 @ (Q1.T @ np.ones(n)), atol=1e-6)
+    r = rank
+    assert rank == rank0, (rank, rank0, S, S0)                           # THE decision optimize takes (src/optimize.jl:396-412)
+    np.testing.assert_allclose(S, S0, rtol=0, atol=(50 + 2 * m) * np.finfo(float).eps * S0[0])   # dgesvd's own accuracy
+    np.testing.assert_allclose(S[:r], S0[:r], rtol=1e-6)                                      # (eps * cond relative at worst)
+    assert np.all(np.diff(S[:r]) <= 0) and np.all(Zh[:, r:] == 0.0) and np.all(Vt[r:, :] == 0.0)
+    # orthonormal to the floor the products A*w_j allow: eps * sigma_1 / min(sigma_i, sigma_j)
+    floor = 200 * np.sqrt(m) * np.finfo(float).eps * S0[0] / np.minimum.outer(S[:r], S[:r])
+    assert np.all(np.abs(Zh[:, :r].T @ Zh[:, :r] - np.eye(r)) <= np.maximum(5e-13, floor))
+    np.testing.assert_allclose(Vt[:r] @ Vt[:r].T, np.eye(r), atol=1e-13)
+    gen_err = np.abs(Zh[:, :r] - Jh @ W[:, :r]).max(axis=0)                                    # generator: Z = Jct W, to the
+    assert np.all(gen_err <= 100 * np.sqrt(m) * np.finfo(float).eps * S0[0] / S[:r])            # rounding of that product
+    np.testing.assert_allclose((Zh[:, :r] * S[:r]) @ Vt[:r], (U0[:, :r] * S0[:r]) @ Vt0[:r], atol=1e-12 * S0[0])
+    # projector onto the kept subspace vs dgesvd's; both carry the eps*cond uncertainty of the smallest kept direction
+    d = synth.hash_vector(9, n)
+    unc = 1e3 * np.finfo(float).eps * S0[0] / S0[r - 1]
+    assert np.linalg.norm(Zh[:, :r] @ (Zh[:, :r].T @ d) - U0[:, :r] @ (U0[:, :r].T @ d)) <= max(1e-12, unc) * np.linalg.norm(d)
+    np.testing.assert_array_equal(J.download(), Jh)
+
+
+def test_factorize_weighted_ill_conditioned(dev_ctx):
+    """The same with row weights (bounds present: w2 = Dy.^2, the reference factors the 2N x M matrix PJct)."""
+    ctx = dev_ctx
+    n, m = 2500, 10
+    rng = np.random.default_rng(8)
+    Jh, _ = _with_singular_values(n, np.logspace(0, -8, m), seed=3)
+    th = rng.uniform(0, 2 * np.pi, n)
+    Dx, Dy = np.cos(th), np.sin(th)
+    PJ = np.vstack([(1 - Dx * Dx)[:, None] * Jh, (-Dy * Dx)[:, None] * Jh])
+    S0 = np.linalg.svd(PJ, compute_uv=False)
+    J, Z = ctx.matrix(n, m, Jh), ctx.matrix(n, m)
+    S, Vt, rank = L.ksvd_(J, Z, w2=ctx.vector(n, Dy * Dy))
+    Zh = Z.download()
+    assert rank == int(np.sum(S0 >= 1e-10)) == m
+    np.testing.assert_allclose(S, S0, rtol=1e-6, atol=50 * np.finfo(float).eps * S0[0])
+    Ufull = np.vstack([(Dy * Dy)[:, None] * Zh, (-Dx * Dy)[:, None] * Zh])
+    np.testing.assert_allclose((Ufull * S) @ Vt, PJ, atol=1e-12)
+    assert np.abs(Ufull.T @ Ufull - np.eye(m)).max() < 1e-6
 
 
 @pytest.mark.parametrize("n,m", [(700, 300), (1500, 513)])

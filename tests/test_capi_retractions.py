@@ -217,6 +217,64 @@ def test_config3_dense_linear_equalities(dev_ctx, do_project_retract):
     np.testing.assert_allclose(lam, lamr, rtol=1e-8, atol=1e-12)
 
 
+@pytest.mark.parametrize("case", ["cond1e7", "cond1e9", "duplicates"])
+@pytest.mark.parametrize("bounds", [False, True])
+def test_ill_conditioned_jacobian_takes_the_references_retraction(dev_ctx, case, bounds):
+    """The rank scan of src/optimize.jl:297-302 is absolute (sigma >= eps_rank = 1e-10) on dgesvd's singular values, and
+    :396-412 picks the Newton retraction iff rank == m.  An equality block of condition 1e7 / 1e9 (all sigma >= 1e-10) is
+    therefore full rank in the reference -- NR, full tangent projection, all multipliers -- and one with exactly duplicated
+    rows is rank deficient -- ProjPenalty.  The device driver must take the same branch with the same rank, and the first
+    outer iterates must agree with the oracle's dgesvd path to the accuracy the data allow: the tangent projector of an
+    ill-conditioned block is only determined to eps * cond (for dgesvd as for any other backward-stable factorisation)."""
+    ctx = dev_ctx
+    n, m = (1500, 8) if not _is_emu(ctx) else (400, 5)
+    rng = np.random.default_rng(17)
+    Q1, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    if case == "duplicates":
+        sv, cond = np.logspace(0, -2, m), 1e2
+    else:
+        cond = 1e7 if case == "cond1e7" else 1e9
+        sv = np.logspace(0, -np.log10(cond), m)
+    Jct = np.asfortranarray((Q1 * sv) @ Q2.T)
+    if case == "duplicates":
+        Jct[:, m - 1] = Jct[:, 0]
+    xs = synth.hash_vector(2, n)
+    prob0 = synth.QuadLinearProblem(Jct, Jct.T @ xs)
+    x0 = xs.copy()
+    xl = xu = None
+    if bounds:
+        i = np.arange(n)
+        xl = np.where(i % 3 == 1, -2.0, -np.inf)
+        xu = np.where(i % 3 == 2, 2.0, np.inf)
+    maxiter = 3 if not (_is_emu(ctx) and case == "duplicates") else 1      # (ProjPenalty's inner pcg! is slow on the emulator)
+    tr0, tr = [], []
+    p0 = R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=maxiter)
+    P = L.QuadLinearBallBox(ctx, n, m, ctx.matrix(n, m, Jct), prob0.b, xl=xl, xu=xu)
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=maxiter), trace=tr)
+    want_rank = m - 1 if case == "duplicates" else m
+    if case == "duplicates" and not bounds:
+        # Without bounds the REFERENCE cannot run a rank-deficient block at all: projcg! ends with mul!(lambda, U', r) on a
+        # length-m lambda and the rank x n view U' (src/projcg.jl:118, src/optimize.jl:369,381) -- a DimensionMismatch in Julia,
+        # a shape error in the oracle.  The device driver never forms that unused lambda and carries on with ProjPenalty.
+        with pytest.raises(ValueError):
+            R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, xl, xu, m, p0, trace=tr0)
+        assert [t['rank'] for t in tr] == [want_rank] * len(tr) and tr[0].get('mtype') == 1
+        assert np.abs(Jct.T @ x - prob0.b).max() < 1e-5 and all(obj[k + 1] <= obj[k] for k in range(len(obj) - 1))
+        return
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, xl, xu, m, p0, trace=tr0)
+    assert [t['rank'] for t in tr0] == [want_rank] * len(tr0)                # what the reference's rule gives ...
+    assert [t['rank'] for t in tr] == [t['rank'] for t in tr0]               # ... and the device agrees
+    assert [t.get('mtype') for t in tr] == [t.get('mtype') for t in tr0]     # NR (0) iff rank == m, else ProjPenalty (1)
+    assert tr0[0].get('mtype') == (1 if case == "duplicates" else 0)
+    assert ti.iter == tir.iter and ti.condition.name == tir.condition.name
+    tol = max(1e-10, 1e3 * np.finfo(float).eps * cond)
+    for a, b in zip(tr, tr0):
+        assert np.linalg.norm(a['x'] - b['x']) <= tol * np.linalg.norm(b['x']), (a['iter'], np.linalg.norm(a['x'] - b['x']))
+        assert a.get('steptype') == b.get('steptype') and a.get('alpha') == b.get('alpha')
+    np.testing.assert_allclose(obj, objr, rtol=max(1e-12, tol))
+
+
 def test_config4_ball_box_newton_retraction(dev_ctx):
     """BASELINE configs[3]: equalities + ball (slack form) + four-way bounds, NR retraction, Armijo."""
     ctx = dev_ctx
