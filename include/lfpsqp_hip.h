@@ -246,7 +246,6 @@ typedef struct lfpsqp_projcg_work {
     lfpsqp_vec* d;
     lfpsqp_vec* rp;
     lfpsqp_vec* Utr;
-    lfpsqp_vec* w; /* unused (kept for layout stability): the diagonal block of Q'r is recomputed on the fly */
 } lfpsqp_projcg_work;
 
 #define LFPSQP_PROJCG_WANT_LAMBDA 1 /* compute lambda = U'(b - A x) (src/projcg.jl:115-118) */

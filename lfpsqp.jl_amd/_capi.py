@@ -42,7 +42,7 @@ class PPWork(C.Structure):  # lfpsqp_pp_work
 
 
 class ProjCGWorkC(C.Structure):  # lfpsqp_projcg_work
-    _fields_ = [("g", P), ("d", P), ("rp", P), ("Utr", P), ("w", P)]
+    _fields_ = [("g", P), ("d", P), ("rp", P), ("Utr", P)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, P, P, c_i64, C.c_int, P)

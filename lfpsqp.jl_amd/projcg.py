@@ -92,16 +92,14 @@ class ProjCGWork:
         if stacked_N is not None:
             from .inequality import StackedVector
             self.g, self.d, self.rp = (StackedVector(ctx, stacked_N) for _ in range(3))
-            self.w = DeviceVector(ctx, stacked_N)
         else:
             self.g, self.d, self.rp = (DeviceVector(ctx, n) for _ in range(3))
-            self.w = None
         self.Utr = DeviceVector(ctx, max(m, 1))
         # extra scratch for the generic (unfused) path, allocated on demand
         self._extra = None
 
     def _c(self):
-        return _capi.ProjCGWorkC(self.g.h, self.d.h, self.rp.h, self.Utr.h, self.w.h if self.w is not None else None)
+        return _capi.ProjCGWorkC(self.g.h, self.d.h, self.rp.h, self.Utr.h)
 
 
 def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c: DeviceVector | None,

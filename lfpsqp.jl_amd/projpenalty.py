@@ -186,30 +186,34 @@ def retract_pp(cval, xnew, c_, xtilde, x, method: ProjPenalty):
             v.ctx, v.n, v.h = ctx, length, C.c_void_p(handle)
             return v
 
+        # The vector handed to a callback belongs to the library: the wrapper must lose the handle on EVERY path (a
+        # DeviceVector that still holds it would free it when collected).
         def c_tramp(user, xh, cval_ptr):
+            v = borrow_vec(xh, x.n)
             try:
-                v = borrow_vec(xh, x.n)
                 out = np.ctypeslib.as_array(cval_ptr, shape=(m,))
                 if hasattr(c_, "c_"):
                     c_.c_(out, v)
                 else:
                     c_(out, v.download(n, 0))
-                v.h = None
                 return 0
             except Exception as e:   # never unwind through C
                 print("c! callback failed:", repr(e))
                 return 1
+            finally:
+                v.h = None
 
         def j_tramp(user, xh, jh, cval_ptr):
+            v = borrow_vec(xh, x.n)
             try:
-                v = borrow_vec(xh, x.n)
                 out = np.ctypeslib.as_array(cval_ptr, shape=(m,))
                 method.jac_(idecomp.Jct, out, v)        # the library passes back the same Jct it was given
-                v.h = None
                 return 0
             except Exception as e:
                 print("jac! callback failed:", repr(e))
                 return 1
+            finally:
+                v.h = None
         cfun, jacfun = _capi.CFUN(c_tramp), _capi.JACFUN(j_tramp)
         keep += [cfun, jacfun, c_tramp, j_tramp]
         cons_p = None
@@ -220,77 +224,3 @@ def retract_pp(cval, xnew, c_, xtilde, x, method: ProjPenalty):
                                       C.byref(flag), C.byref(iters), C.byref(pcg_iters)))
     del keep
     return flag.value, iters.value, pcg_iters.value
-
-
-def retract_pp_reference_loop(cval, xnew, c_, xtilde, x, method: ProjPenalty):
-    """The same retraction statement by statement in Python on the device primitives (kept as a readable
-    mirror of src/retractions.jl:265-441 and as a cross-check of the C implementation in the tests)."""
-    w = method.work
-    idecomp, idata = method.idecomp, method.idata
-    Jct = idecomp.Jct
-    r, p, z, dx, g = w.r, w.p, w.z, w.dx, w.g
-    ineq = method.ineq
-    n = idecomp.N
-    m = len(method.Sigma)
-    J = _JacStacked(idecomp, w) if ineq else _JacPlain(Jct, w)
-    mu0, tol, maxiter, maxiter_pcg = method.mu0, method.tol, method.maxiter, method.maxiter_pcg
-    flag = 0
-    xnew.copy_from(xtilde)                                   # :329
-    mu = mu0
-    i = 0
-    pcg_iter_count = 0
-    hh = 0.0
-    while i < maxiter:
-        method.jac_(Jct, cval, xnew)                         # :340 (device Jct == transpose!(idecomp.Jct, J), :347)
-        curtol = float(np.max(np.abs(cval), initial=0.0))
-        if ineq:                                             # :343-353
-            inequality_gradient_(idecomp, xnew, idata)
-            J.refresh()
-            hmax = calculate_h_(w.h, xnew, idata)
-            curtol = hmax if (math.isnan(hmax) or hmax > curtol) else curtol     # Julia max propagates NaN
-            hh = dot(w.h, w.h)
-        if curtol < tol:                                     # :359
-            break
-        waxpby(1.0, xnew, -1.0, xtilde, g)                   # :364
-        cc = float(np.dot(cval, cval))
-        prev_obj_val = (hh + cc) + mu * dot(g, g)            # :366
-        w.cval_dev.upload(cval)
-        J.apply_t(g, 1.0, mu, from_cval=True)                # :369  g = fulljac' cvalaug + mu g
-        dx.fill(0.0)
-        r.copy_from(g)
-        pcg_flag, pcg_i = pcg_(mu, J, no_precondition, dx, r, p, z, None, tol, maxiter_pcg)   # :375
-        pcg_iter_count += pcg_i
-        if pcg_flag > 0:                                     # :377-381
-            flag = 2
-            break
-        p.copy_from(xnew)                                    # :384
-        ar_dot = -dot(g, dx)                                 # :385
-        alpha = 1.0
-        axpby(-alpha, dx, 1.0, xnew)                         # :389
-        waxpby(1.0, xnew, -1.0, xtilde, g)
-        dist2 = dot(g, g)
-        _call_c(c_, cval, xnew, n)                           # :392
-        if ineq:
-            calculate_h_(w.h, xnew, idata, want_max=False)
-            hh = dot(w.h, w.h)
-        cc = float(np.dot(cval, cval))                       # :399 cvalaug[end-m+1:end] = cval
-        armijo_count = 0
-        while (hh + cc) + mu * dist2 > prev_obj_val + 1e-4 * alpha * ar_dot:   # :403
-            alpha /= 2
-            waxpby(1.0, p, -alpha, dx, xnew)
-            waxpby(1.0, xnew, -1.0, xtilde, g)
-            dist2 = dot(g, g)
-            # BUG-COMPAT :410-417: c! is evaluated into cvalaug and then overwritten by the stale
-            # full-step cval, so only the bound part h and dist2 change; the (discarded) c! call is skipped.
-            if ineq:
-                calculate_h_(w.h, xnew, idata, want_max=False)
-                hh = dot(w.h, w.h)
-            armijo_count += 1
-            if armijo_count == 100:                          # :422-425 (leaves only the inner loop)
-                flag = 3
-                break
-        i += 1
-        mu = min(mu * 0.1, math.sqrt(hh + cc))               # :431
-    if i == maxiter:                                         # :435-437
-        flag = 1
-    return flag, i, pcg_iter_count

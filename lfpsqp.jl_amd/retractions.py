@@ -125,6 +125,14 @@ def retract_nr_batch_(cvals: np.ndarray, xnews, c_, xtildes, x, method: NR):
     return [(int(flags[b]), int(iters[b]), 0) for b in range(nb)]
 
 
+def _download_borrowed(ctx, handle, count):
+    """The first `count` entries of a device vector the LIBRARY owns (the x handed to a user callback), through the raw
+    handle: wrapping it in a DeviceVector would free it on any exception path."""
+    out = np.empty(count)
+    ctx.check(ctx.L.lfpsqp_vec_download(ctx.h, C.c_void_p(handle), 0, out.ctypes.data_as(_capi.PD), count))
+    return out
+
+
 def _retract_nr(cval, xnew, c_, xtilde, x, method: NR):
     ctx = x.ctx
     m = len(method.Sigma)
@@ -144,10 +152,7 @@ def _retract_nr(cval, xnew, c_, xtilde, x, method: NR):
 
         def tramp(user, xvec_handle, cval_ptr):
             try:
-                tmpv = DeviceVector.__new__(DeviceVector)
-                tmpv.ctx, tmpv.n, tmpv.h = ctx, nrows, C.c_void_p(xvec_handle)
-                xh = tmpv.download(nrows, 0)
-                tmpv.h = None                     # borrowed handle: the library owns this vector
+                xh = _download_borrowed(ctx, xvec_handle, nrows)      # the library owns this vector: no owning wrapper
                 out = np.ctypeslib.as_array(cval_ptr, shape=(m,))
                 c_(out, xh)
                 return 0

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     CK(lfpsqp_factorize(ctx, J, NULL, Z, Sigma, Vt, NULL, &rank, 1e-10));
 
     lfpsqp_vec *a = NULL, *b = NULL, *x = NULL, *lam = NULL;
-    lfpsqp_projcg_work w = {NULL, NULL, NULL, NULL, NULL};
+    lfpsqp_projcg_work w = {NULL, NULL, NULL, NULL};
     CK(lfpsqp_vec_alloc(ctx, n, &a));
     CK(lfpsqp_vec_alloc(ctx, n, &b));
     CK(lfpsqp_vec_alloc(ctx, n, &x));

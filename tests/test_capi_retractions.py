@@ -449,7 +449,7 @@ def test_optimize_surface_with_host_callables_inequalities_and_bounds(dev_ctx):
 def test_retract_pp_c_matches_python_mirror(dev_ctx):
     """lfpsqp_retract_pp (C) against the statement-by-statement Python mirror of src/retractions.jl:265-441 on
     the device primitives, with bounds (stacked operator) and the device-resident ball/linear constraints."""
-    from lfpsqp_jl_amd.projpenalty import retract_pp_reference_loop
+    from .pp_mirror import retract_pp_reference_loop
     ctx = dev_ctx
     n, m = (1500, 5) if not _is_emu(ctx) else (150, 3)
     P0 = synth.BallBoxProblem(n, m)
