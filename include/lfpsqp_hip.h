@@ -199,6 +199,13 @@ int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const doub
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
                      double* W, int64_t* rank, double eps_rank);
 
+/* The replicated small step of lfpsqp_factorize on its own: thin SVD A = U diag(S) V' of a small host matrix (rows x cols,
+ * column-major, rows >= 1, rows + cols <= 1024 for the device path) by one-sided Jacobi -- on the device from 64 columns on
+ * (block Jacobi, csrc/jacobi.hip), on the host below that.  U: rows x cols (normalised columns), S: cols (descending),
+ * V: cols x cols (may be NULL).  High relative accuracy on column-scaled matrices, which is what the refinement rounds of
+ * lfpsqp_factorize rely on; the reference gets the same job done inside LAPACK's dgesvd (src/la_helper.jl:22). */
+int lfpsqp_small_svd(lfpsqp_ctx* ctx, int64_t rows, int64_t cols, const double* A, double* U, double* S, double* V);
+
 /* ---- projected CG (src/projcg.jl:40-121) --------------------------------- */
 /* The symmetric operator A of the QP ("B*p", the Lagrangian Hessian action that the
  * reference wraps in a LinearMap at src/optimize.jl:228-230).  Device-resident

@@ -6,7 +6,9 @@
 // and v_mfma_f64_16x16x4_f64 (lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D row = (l>>4)+4*reg,
 // col = l&15).  Each of the 4 waves owns two 16-row i-tiles x all eight j-tiles = 16 accumulators.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include <algorithm>
 #include <numeric>
@@ -347,14 +349,65 @@ static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const dou
 // Eigen-decomposition of a Gram matrix G = V diag(sig^2) V' (sig descending).  G positive definite (the usual case):
 // G = L L', and one-sided Jacobi on the columns of L turns them into sig_j v_j -- the singular values themselves (not their
 // squares) and the eigenvectors, with no rotation accumulator.  A failed Cholesky (numerically singular G) takes Jacobi on G.
-static void gram_eig(int m, const std::vector<double>& G, std::vector<double>& sig, std::vector<double>& V) {
+// A (rows x cols) = U diag(S) V' by one-sided Jacobi: on the device (jacobi.hip; with want_v the rotations are accumulated
+// by carrying an identity below A) from kDevJacobiMinCols columns on, else -- and for shapes the kernels do not cover -- by
+// the host routine of smallla.h.  Same contract as jacobi_svd: S descending, U = normalised columns, V orthogonal.
+constexpr int kDevJacobiMinCols = 64;
+static void small_svd(lfpsqp_ctx* ctx, int rows, int cols, const std::vector<double>& A, std::vector<double>& U, std::vector<double>& S,
+                      std::vector<double>& V, bool want_v = true) {
+    const int rows_all = want_v ? rows + cols : rows;
+    std::vector<double> X;
+    bool dev = ctx && cols >= kDevJacobiMinCols && rows_all <= 1024 && ctx->tune_onepass >= 0;
+    if (dev) {
+        X.assign((size_t)rows_all * cols, 0.0);
+        for (int j = 0; j < cols; ++j) {
+            for (int i = 0; i < rows; ++i) X[(size_t)j * rows_all + i] = A[(size_t)j * rows + i];
+            if (want_v) X[(size_t)j * rows_all + rows + j] = 1.0;
+        }
+        dev = device_jacobi(ctx, rows, rows_all, cols, X);
+    }
+    if (!dev) {
+        jacobi_svd(rows, cols, A, U, S, V, want_v);
+        return;
+    }
+    std::vector<double> nrm(cols);
+    for (int j = 0; j < cols; ++j) {
+        double sq = 0.0;
+        for (int i = 0; i < rows; ++i) sq += X[(size_t)j * rows_all + i] * X[(size_t)j * rows_all + i];
+        nrm[j] = sqrt(sq);
+    }
+    std::vector<int> idx(cols);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return nrm[a] > nrm[b]; });
+    U.assign((size_t)rows * cols, 0.0);
+    S.assign(cols, 0.0);
+    V.assign(want_v ? (size_t)cols * cols : 0, 0.0);
+    for (int jj = 0; jj < cols; ++jj) {
+        const int j = idx[jj];
+        S[jj] = nrm[j];
+        for (int i = 0; i < rows; ++i) U[(size_t)jj * rows + i] = nrm[j] > 0 ? X[(size_t)j * rows_all + i] / nrm[j] : 0.0;
+        for (int i = 0; want_v && i < cols; ++i) V[(size_t)jj * cols + i] = X[(size_t)j * rows_all + rows + i];
+    }
+}
+
+static double now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static const bool kTraceFactorize = getenv("LFPSQP_TRACE_FACTORIZE") != nullptr;     // development: phase times on stderr
+
+static void gram_eig(lfpsqp_ctx* ctx, int m, const std::vector<double>& G, std::vector<double>& sig, std::vector<double>& V) {
     std::vector<double> Lc, Ug, lam;
     sig.assign(m, 0.0);
-    if (cholesky_lower(m, G, Lc)) {
+    const double t0 = now_ms();
+    const bool pd = cholesky_lower(m, G, Lc);
+    if (kTraceFactorize) fprintf(stderr, "[factorize] cholesky %.3f ms (pd=%d)\n", now_ms() - t0, (int)pd);
+    if (pd) {
         std::vector<double> none;
-        jacobi_svd(m, m, Lc, V, sig, none, false);
+        small_svd(ctx, m, m, Lc, V, sig, none, false);
     } else {
-        jacobi_svd(m, m, G, Ug, lam, V);
+        small_svd(ctx, m, m, G, Ug, lam, V);
         for (int j = 0; j < m; ++j) sig[j] = sqrt(lam[j] > 0 ? lam[j] : 0.0);
     }
 }
@@ -371,7 +424,7 @@ static void gram_eig(int m, const std::vector<double>& G, std::vector<double>& s
 // Out: V, sig updated (sig descending); returns through `offmax` the largest |Gs_ij| (i != j) among active columns, through
 // `conv` whether every pair is orthogonal to max(tol, the rounding floor of the product A*w for that pair), through `devmax`
 // the largest |dz_j - 1| among active columns (how well s matched the true norms) and through `rotated` whether V changed.
-static void refine_round(int m, std::vector<double>& V, std::vector<double>& sig, const std::vector<double>& s, const std::vector<double>& GZ,
+static void refine_round(lfpsqp_ctx* ctx, int m, std::vector<double>& V, std::vector<double>& sig, const std::vector<double>& s, const std::vector<double>& GZ,
                          double tol, double* offmax, bool* conv, double* devmax, bool* rotated) {
     const double eps = 2.220446049250313e-16;
     std::vector<double> dz(m), bt(m);
@@ -409,11 +462,11 @@ static void refine_round(int m, std::vector<double>& V, std::vector<double>& sig
                 for (int i = 0; i <= j; ++i) X[(size_t)j * ma + i] = Ls[(size_t)i * ma + j] * bt[act[j]];
         } else {                                               // Gs = Ve diag(le) Ve':  X = diag(sqrt(le)) Ve' D
             std::vector<double> Ue, le, Ve;
-            jacobi_svd(ma, ma, Gs, Ue, le, Ve);
+            small_svd(ctx, ma, ma, Gs, Ue, le, Ve);
             for (int j = 0; j < ma; ++j)
                 for (int i = 0; i < ma; ++i) X[(size_t)j * ma + i] = sqrt(le[i] > 0 ? le[i] : 0.0) * Ve[(size_t)i * ma + j] * bt[act[j]];
         }
-        jacobi_svd(ma, ma, X, Ux, S2, V2);
+        small_svd(ctx, ma, ma, X, Ux, S2, V2);
         for (int b = 0; b < ma; ++b) {                         // V[:, act] <- V[:, act] * V2
             double* dst = &Vnew[(size_t)act[b] * m];
             for (int i = 0; i < m; ++i) dst[i] = 0.0;
@@ -459,6 +512,17 @@ int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const doub
     return rmul_impl(ctx, In, (int)kcols, W_host, (int)rcols, Out);
 }
 
+int lfpsqp_small_svd(lfpsqp_ctx* ctx, int64_t rows, int64_t cols, const double* A, double* U, double* S, double* V) {
+    LF_ARG(ctx, ctx && A && U && S && rows >= 1 && cols >= 0 && rows <= (1 << 20) && cols <= (1 << 14));
+    if (cols == 0) return 0;
+    std::vector<double> a(A, A + (size_t)rows * cols), u, sv, v;
+    small_svd(ctx, (int)rows, (int)cols, a, u, sv, v, V != nullptr);
+    for (size_t i = 0; i < u.size(); ++i) U[i] = u[i];
+    for (size_t i = 0; i < sv.size(); ++i) S[i] = sv[i];
+    for (size_t i = 0; V && i < v.size(); ++i) V[i] = v[i];
+    return 0;
+}
+
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
                      double* W, int64_t* rank_out, double eps_rank) {
     LF_ARG(ctx, ctx && Jct && Z && Sigma && Vt && rank_out && Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m &&
@@ -487,10 +551,13 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
     };
     // 1. G = A'A (A = diag(sqrt(w2)) Jct), eigen-decomposition: estimates of the singular values and right singular vectors
     std::vector<double> G, sig, V;
+    const double t_start = now_ms();
     LF_TRY(gram_impl(ctx, Jct, m, w2p, G));
     for (double g : G)
         if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix");
-    gram_eig(m, G, sig, V);
+    const double t_eig = now_ms();
+    gram_eig(ctx, m, G, sig, V);
+    if (kTraceFactorize) fprintf(stderr, "[factorize] gram %.3f ms, eig %.3f ms\n", t_eig - t_start, now_ms() - t_eig);
     if (!(sig[0] > 0.0)) {                     // A == 0
         LF_TRY(zero_from(0));
         finish(sig, V, 0, nullptr);
@@ -528,7 +595,7 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
             if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix of the trial basis");
         double offmax = 0.0, devmax = 0.0;
         bool conv = false, rotated = false;
-        refine_round(m, V, sig, s, GZ, tol, &offmax, &conv, &devmax, &rotated);
+        refine_round(ctx, m, V, sig, s, GZ, tol, &offmax, &conv, &devmax, &rotated);
         if (conv && !rotated && devmax <= tol) {          // the basis on the device IS A V diag(1/sig) for every kept column
             z_is_final = true;
             break;

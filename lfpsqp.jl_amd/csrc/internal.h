@@ -366,6 +366,9 @@ int run_vec(lfpsqp_ctx* ctx, int64_t n, F f, unsigned ismax, double* red_out, PO
     return 0;
 }
 
+// one-sided Jacobi on the columns of a small host matrix, run on the device (jacobi.hip); false = shape not covered
+bool device_jacobi(lfpsqp_ctx* ctx, int rows_dot, int rows_all, int cols, std::vector<double>& X, int* sweeps_out = nullptr);
+
 // read `count` doubles of device memory back after everything queued so far
 int read_back(lfpsqp_ctx* ctx, const double* dev, double* host, int64_t count);
 

