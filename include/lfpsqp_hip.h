@@ -275,6 +275,21 @@ int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfps
                   const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
                   int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr);
 
+/* The same solver for a GENERAL symmetric operator A -- the reference's LinearMap closure around hess_lag_vec! /
+ * augmented_hess_lag_vec! (src/optimize.jl:228-230, applied at src/projcg.jl:57,74,116): `A(user, src, dest)` must produce
+ * dest = A * src for device vectors of length(b) (stacked [x | gap | y] when U is a stacked basis), return 0, and leave
+ * src untouched.  It is called from the host once per iteration (plus once at the start and once for lambda); it may
+ * be synchronous, or queue its work on the context's stream (lfpsqp_ctx_stream; every lfpsqp_* primitive does) -- then
+ * nothing in the loop waits for the device: scalars, exits and d'(A d) stay on the device as in lfpsqp_projcg, and the two
+ * passes over U per iteration read the product from `Av` (caller-owned n-vector scratch, the reference's work.Ad).
+ * Everything else (arguments, exit semantics, outputs) as lfpsqp_projcg; LFPSQP_PROJCG_RESUME is not supported. */
+typedef int (*lfpsqp_opfun)(void* user, const lfpsqp_vec* src, lfpsqp_vec* dest);
+int lfpsqp_projcg_op(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, lfpsqp_opfun A, void* user, lfpsqp_vec* Av,
+                     const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
+                     int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr);
+/* the HIP stream (hipStream_t) all of the context's work is queued on, for callbacks that launch their own kernels */
+int lfpsqp_ctx_stream(lfpsqp_ctx* ctx, void** stream);
+
 /* ---- retractions (src/retractions.jl) ---------------------------------------------- */
 /* Device-resident equality constraints of the BASELINE configs:
  *     c(x) = [ J x - b ;  sum_{i < n_x} x_i^2 - R2 - x[slack_row] ]
@@ -361,7 +376,7 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
                       const lfpsqp_vec* xtilde, const lfpsqp_vec* x, lfpsqp_vec* xnew, double mu0, double tol, int64_t maxiter,
                       int64_t maxiter_pcg, const lfpsqp_pp_work* work, double* cval, int* flag, int64_t* iters, int64_t* pcg_iters);
 
-/* per-kernel-family device time (ms) accumulated by the last lfpsqp_projcg call when
+/* per-kernel-family device time (ms) of every 4th launch (sampled: event records between kernels are not free), accumulated by the last lfpsqp_projcg call when
  * the context was created with profiling on (lfpsqp_ctx_set_profiling); used by
  * bench.py for the roofline object.  slots: 0 = K1 (direction update), 3 = F (the one-pass kernel:
  * rp, gp = rp - U t, U'gp, U'(A gp) and the dots in ONE pass over U); on the two-pass fallback instead

@@ -46,6 +46,7 @@ class ProjCGWorkC(C.Structure):  # lfpsqp_projcg_work
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, P, P, c_i64, C.c_int, P)
+OPFUN = C.CFUNCTYPE(C.c_int, P, P, P)          # lfpsqp_opfun(user, src, dest)
 
 _SIGS = {
     "lfpsqp_ctx_create": [C.c_int, C.POINTER(P)],
@@ -113,6 +114,9 @@ _SIGS = {
     "lfpsqp_small_svd": [P, c_i64, c_i64, P, P, P, P],
     "lfpsqp_projcg": [P, P, P, C.POINTER(DiagOp), C.POINTER(Basis), P, P, c_dbl, c_i64, c_i64, C.c_int,
                       C.POINTER(ProjCGWorkC), C.POINTER(c_i64), PD],
+    "lfpsqp_projcg_op": [P, P, P, P, P, P, C.POINTER(Basis), P, P, c_dbl, c_i64, c_i64, C.c_int,
+                         C.POINTER(ProjCGWorkC), C.POINTER(c_i64), PD],
+    "lfpsqp_ctx_stream": [P, C.POINTER(P)],
     "lfpsqp_ctx_set_profiling": [P, C.c_int],
     "lfpsqp_profile_read": [P, PD, C.POINTER(c_i64)],
 }

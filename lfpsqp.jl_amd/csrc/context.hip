@@ -88,16 +88,19 @@ static int prof_lazy_init(lfpsqp_ctx* ctx) {
     return 0;
 }
 
+// Every kProfStride-th launch of a slot is bracketed (an event record between two kernels costs a few microseconds of
+// device time at the boundary -- per launch that was ~1 % of an iteration at n = 1e7 and ~6 % at the 8-GPU shard size).
+constexpr int kProfStride = 4;
 void prof_begin(lfpsqp_ctx* ctx, int s) {
     if (!ctx->profiling) return;
-    if (ctx->prof_used[s] < kProfEvents) (void)hipEventRecord(ctx->prof_ev[s][ctx->prof_used[s]][0], ctx->stream);
+    ctx->prof_live[s] = (ctx->prof_seq[s]++ % kProfStride == 0) && ctx->prof_used[s] < kProfEvents;
+    if (ctx->prof_live[s]) (void)hipEventRecord(ctx->prof_ev[s][ctx->prof_used[s]][0], ctx->stream);
 }
 void prof_end(lfpsqp_ctx* ctx, int s) {
-    if (!ctx->profiling) return;
-    if (ctx->prof_used[s] < kProfEvents) {
-        (void)hipEventRecord(ctx->prof_ev[s][ctx->prof_used[s]][1], ctx->stream);
-        ctx->prof_used[s]++;
-    }
+    if (!ctx->profiling || !ctx->prof_live[s]) return;
+    (void)hipEventRecord(ctx->prof_ev[s][ctx->prof_used[s]][1], ctx->stream);
+    ctx->prof_used[s]++;
+    ctx->prof_live[s] = false;
 }
 void prof_collect(lfpsqp_ctx* ctx) {
     if (!ctx->profiling) return;
@@ -229,7 +232,7 @@ int lfpsqp_ctx_set_profiling(lfpsqp_ctx* ctx, int on) {
     LF_ARG(ctx, ctx != nullptr);
     if (on && prof_lazy_init(ctx) != 0) return set_err(ctx, LFPSQP_ERR_HIP, "profiling event creation failed");
     ctx->profiling = on != 0;
-    for (int s = 0; s < kProfSlots; ++s) { ctx->prof_used[s] = 0; ctx->prof_count[s] = 0; ctx->prof_ms[s] = 0.0; }
+    for (int s = 0; s < kProfSlots; ++s) { ctx->prof_used[s] = 0; ctx->prof_count[s] = 0; ctx->prof_ms[s] = 0.0; ctx->prof_seq[s] = 0; ctx->prof_live[s] = false; }
     return 0;
 }
 int lfpsqp_profile_read(lfpsqp_ctx* ctx, double ms[8], int64_t counts[8]) {

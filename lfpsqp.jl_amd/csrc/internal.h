@@ -92,6 +92,8 @@ struct lfpsqp_ctx {
     bool profiling = false;
     hipEvent_t prof_ev[lfpsqp::kProfSlots][lfpsqp::kProfEvents][2];
     int prof_used[lfpsqp::kProfSlots] = {0};
+    int64_t prof_seq[lfpsqp::kProfSlots] = {0};     // launches seen per slot (every 4th is timed)
+    bool prof_live[lfpsqp::kProfSlots] = {false};
     int64_t prof_count[lfpsqp::kProfSlots] = {0};
     double prof_ms[lfpsqp::kProfSlots] = {0};
     bool prof_init = false;

@@ -58,6 +58,11 @@ struct AOpD {  // A = a0*I + diag(dg)
     }
 };
 
+struct AOpV {  // generic A behind a callback: the product A*v for the ONE vector v in question sits in a device vector
+    const double* Av;
+    __device__ __forceinline__ double2 apply(int64_t i, double2) const { return ld2(Av + i); }
+};
+
 struct StackD {   // stacked (bound-constrained) basis Q = [[diag Dx; diag Dy], [sx.*Z; sy.*Z]]
     int64_t hs;
     const double *Dx, *Dy, *sx, *sy;
@@ -92,6 +97,37 @@ struct PcgDirF {
         if (v0) s = dd.x * ad.x;
         if (v1) s = fma(dd.y, ad.y, s);
         red[0] += s;                                                      // :75
+    }
+};
+// generic-operator flow: x += alpha*d of the previous iteration (:92) ; d = beta*d - g (:99) -- A d comes from the callback afterwards
+struct PcgDirX {
+    double* d;
+    const double* g;
+    double* x;
+    const double* scal;
+    const int64_t* istat;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double alpha = ld_scal(scal + S_ALPHA), beta = ld_scal(scal + S_BETA);
+        double2 dd = ld2(d + i), xx = ld2(x + i);
+        const double2 gg = ld2(g + i);
+        xx = make_double2(fma(alpha, dd.x, xx.x), fma(alpha, dd.y, xx.y));
+        dd = make_double2(beta * dd.x - gg.x, beta * dd.y - gg.y);
+        if (v1) { st2(x + i, xx); st2(d + i, dd); }
+        else if (v0) { x[i] = xx.x; d[i] = dd.x; }
+    }
+};
+struct DotPairF {   // d'(A d) from the two vectors (:75)
+    const double* a;
+    const double* b;
+    const int64_t* istat;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double2 x = ld2(a + i), y = ld2(b + i);
+        double s = 0.0;
+        if (v0) s = x.x * y.x;
+        if (v1) s = fma(x.y, y.y, s);
+        red[0] += s;
     }
 };
 // The post-ops also publish (status, iteration, nr) into a pinned HOST block with system-scope
@@ -129,10 +165,11 @@ struct PcgPost1 {  // after d'Ad is final: iteration count, exits, alpha  (:72-9
 };
 
 // ---- K2 (producer of v = rp for U' rp; nothing is stored) -------------------------------
+template <class AOP>
 struct PcgStepV {
     const double* d;
     const double* g;
-    AOpD A;
+    AOP A;
     const double* scal;
     const int64_t* istat;
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
@@ -149,13 +186,14 @@ struct PcgStepV {
 };
 
 // ---- K3 (consumer of U*Utr) -------------------------------------------------------
+template <class AOP>
 struct PcgProjE {
     const double* rp;   // stored residual: only the initial projection (init = 1) reads it
     double* g;
     double* d;          // written (d = -g) only by the initial projection
     const int64_t* istat;
     int init;
-    PcgStepV sv;        // recomputes rp = g + alpha A d inside the loop
+    PcgStepV<AOP> sv;   // recomputes rp = g + alpha A d inside the loop
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
         const double2 rr = init ? ld2(rp + r) : sv.rp_at(r);
@@ -397,11 +435,12 @@ struct PcgDirG {
 };
 
 // ---- setup / teardown functors --------------------------------------------------
+template <class AOP>
 struct ResidualV {  // v = sgn*(A x - b), optionally stored   (:56-57 with sgn=+1, :115-116 with sgn=-1)
     const double* x;
     const double* b;
     double* out;  // may be null
-    AOpD A;
+    AOP A;
     double sgn;
     __device__ __forceinline__ bool skip() const { return false; }
     __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
@@ -472,8 +511,9 @@ struct NormalizeIntoF {  // x = d / sqrt(dd)    (:79)
 // ---- stacked (bound-constrained) variants: Q = [[diag Dx; diag Dy], [sx.*Z; sy.*Z]] -------
 // One workgroup row r of the N x M matrix Z serves BOTH halves of the 2N-vectors, so the
 // whole projection costs one pass over Z where the reference streams a 2N x M factor.
+template <class AOP>
 struct PcgStepVS {
-    PcgStepV p;
+    PcgStepV<AOP> p;
     StackD k;
     __device__ __forceinline__ bool skip() const { return p.skip(); }
     __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
@@ -483,8 +523,9 @@ struct PcgStepVS {
         return make_double2(ax.x * rx.x + ay.x * ry.x, ax.y * rx.y + ay.y * ry.y);
     }
 };
+template <class AOP>
 struct ResidualVS {
-    ResidualV p;
+    ResidualV<AOP> p;
     StackD k;
     double* wout;   // optional: the diagonal block Dx.*rx + Dy.*ry of Q'r (the first N entries of lambda)
     __device__ __forceinline__ bool skip() const { return false; }
@@ -501,8 +542,9 @@ struct ResidualVS {
         return make_double2(ax.x * rx.x + ay.x * ry.x, ax.y * rx.y + ay.y * ry.y);
     }
 };
+template <class AOP>
 struct PcgProjES {
-    PcgProjE p;
+    PcgProjE<AOP> p;
     StackD k;
     __device__ __forceinline__ bool skip() const { return p.skip(); }
     __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
@@ -531,10 +573,14 @@ struct PcgProjES {
 
 using namespace lfpsqp;
 
-extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, const lfpsqp_basis* U,
-                             const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit, int64_t n_global, int flags,
-                             const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
+// A is either the device-resident diagonal form (A) or a callback (opf, with the work vector Av its products land in)
+static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, lfpsqp_opfun opf, void* ouser,
+                       lfpsqp_vec* Av, const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
+                       int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
+    const lfpsqp_diag_op no_diag = {0.0, nullptr};
+    if (opf) A = &no_diag;
     LF_ARG(ctx, ctx && x && A && U && b && work && iters && nr);
+    LF_ARG(ctx, !opf || (Av && Av->n == b->n && !(flags & LFPSQP_PROJCG_RESUME)));
     LF_ARG(ctx, work->g && work->d && work->rp && work->Utr);
     const lfpsqp_ctx::ProjcgResume rs = ctx->pcg_resume;      // (taken before this call's own workspace requests invalidate it)
     const bool stacked = U->Dx != nullptr;
@@ -577,25 +623,42 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     hstat[0] = ST_RUNNING;
     hstat[1] = 0;
     for (int k = 0; k < kRing; ++k) hstat[kRingOff + k] = ST_RUNNING;
-    auto launch_residual = [&](double sgn, double* store, double* t_out) -> int {
-        const ResidualV rv{x->p, b->p, store, Ad, sgn};
-        if (stacked) return run_gemv_t(ctx, Z, m, N, ResidualVS{rv, sk, store ? nullptr : lambda->p}, t_out);
+    // the user's operator: Av = A * v, queued on the context's stream (or synchronous) by the callback
+    auto apply_op = [&](const lfpsqp_vec* v) -> int {
+        const int rc = opf(ouser, v, Av);
+        if (rc != 0) return set_err(ctx, LFPSQP_ERR_ARG, "operator callback returned %d", rc);
+        return 0;
+    };
+    const AOpV Aop{opf ? Av->p : nullptr};
+    auto residual_with = [&](auto aop, double sgn, double* store, double* t_out) -> int {
+        using AOP = decltype(aop);
+        const ResidualV<AOP> rv{x->p, b->p, store, aop, sgn};
+        if (stacked) return run_gemv_t(ctx, Z, m, N, ResidualVS<AOP>{rv, sk, store ? nullptr : lambda->p}, t_out);
         return run_gemv_t(ctx, Z, m, N, rv, t_out);
     };
-    auto launch_k2 = [&]() -> int {
-        const PcgStepV sv{d, g, Ad, scal, istat};
-        if (stacked) return run_gemv_t(ctx, Z, m, N, PcgStepVS{sv, sk}, Utr, 1);
+    auto launch_residual = [&](double sgn, double* store, double* t_out) -> int {
+        if (!opf) return residual_with(Ad, sgn, store, t_out);
+        LF_TRY(apply_op(x));                                                  // Av = A x
+        return residual_with(Aop, sgn, store, t_out);
+    };
+    auto k2_with = [&](auto aop) -> int {
+        using AOP = decltype(aop);
+        const PcgStepV<AOP> sv{d, g, aop, scal, istat};
+        if (stacked) return run_gemv_t(ctx, Z, m, N, PcgStepVS<AOP>{sv, sk}, Utr, 1);
         return run_gemv_t(ctx, Z, m, N, sv, Utr, 1);
     };
-    auto launch_k3 = [&](int init) -> int {
-        const PcgProjE pe{rp, g, d, istat, init, PcgStepV{d, g, Ad, scal, istat}};
+    auto launch_k2 = [&]() -> int { return opf ? k2_with(Aop) : k2_with(Ad); };
+    auto k3_with = [&](auto aop, int init) -> int {
+        using AOP = decltype(aop);
+        const PcgProjE<AOP> pe{rp, g, d, istat, init, PcgStepV<AOP>{d, g, aop, scal, istat}};
         const PcgPost3 post{scal, istat, init, hm, scal + S_RPGP};
-        if (stacked) return run_gemv_n<PcgProjES, 2, PcgPost3>(ctx, Z, m, N, Utr, PcgProjES{pe, sk}, scal + S_RPGP, post, init ? -1 : 2);
-        return run_gemv_n<PcgProjE, 2, PcgPost3>(ctx, Z, m, N, Utr, pe, scal + S_RPGP, post, init ? -1 : 2);
+        if (stacked) return run_gemv_n<PcgProjES<AOP>, 2, PcgPost3>(ctx, Z, m, N, Utr, PcgProjES<AOP>{pe, sk}, scal + S_RPGP, post, init ? -1 : 2);
+        return run_gemv_n<PcgProjE<AOP>, 2, PcgPost3>(ctx, Z, m, N, Utr, pe, scal + S_RPGP, post, init ? -1 : 2);
     };
+    auto launch_k3 = [&](int init) -> int { return opf ? k3_with(Aop, init) : k3_with(Ad, init); };
 
     // fused iteration (one pass over U)?  Needs a tile shape for m columns and 32-bit lane offsets
-    const bool fused = m > 0 && onepass_cw(ctx, m, Z->ld, N) != 0;
+    const bool fused = !opf && m > 0 && onepass_cw(ctx, m, Z->ld, N) != 0;
     double *T12 = nullptr, *t3 = nullptr;
     if (fused) {
         LF_TRY(ensure_mvec(ctx, (size_t)3 * m + 24));
@@ -654,6 +717,13 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
             // one global reduction per iteration: the post-op of F has already done the exits and alpha of this iteration
             if (it > 0 || resume) LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, g, x->p, scal, istat, 0}, 0u, nullptr, NoPost(), 0)));
             LF_TRY(launch_fused(0));
+        } else if (opf) {
+            // generic operator: the direction update, then the user's product A d, then d'(A d); the two passes over U read A d
+            if (it > 0) LF_TRY((run_vec<PcgDirX, 0, NoPost>(ctx, nv, PcgDirX{d, g, x->p, scal, istat}, 0u, nullptr, NoPost(), 0)));
+            LF_TRY(apply_op(work->d));
+            LF_TRY((run_vec<DotPairF, 1, PcgPost1>(ctx, nv, DotPairF{d, Av->p, istat}, 0u, scal + S_DAD, PcgPost1{scal, istat, hm})));
+            LF_TRY(launch_k2());
+            LF_TRY(launch_k3(0));
         } else {
             LF_TRY((run_vec<PcgDirF, 1, PcgPost1>(ctx, nv, PcgDirF{d, g, x->p, Ad, scal, istat, it == 0 ? 1 : 0}, 0u, scal + S_DAD,
                                                   PcgPost1{scal, istat, hm}, 0)));
@@ -695,5 +765,25 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         prof_collect(ctx);
     }
+    return 0;
+}
+
+extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, const lfpsqp_basis* U,
+                             const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit, int64_t n_global, int flags,
+                             const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
+    LF_ARG(ctx, ctx && A);
+    return projcg_impl(ctx, x, lambda, A, nullptr, nullptr, nullptr, U, b, c, tol, maxit, n_global, flags, work, iters, nr);
+}
+
+extern "C" int lfpsqp_projcg_op(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, lfpsqp_opfun A, void* user, lfpsqp_vec* Av,
+                                const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
+                                int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
+    LF_ARG(ctx, ctx && A && Av);
+    return projcg_impl(ctx, x, lambda, nullptr, A, user, Av, U, b, c, tol, maxit, n_global, flags, work, iters, nr);
+}
+
+extern "C" int lfpsqp_ctx_stream(lfpsqp_ctx* ctx, void** stream) {
+    LF_ARG(ctx, ctx && stream);
+    *stream = (void*)ctx->stream;
     return 0;
 }

@@ -95,7 +95,8 @@ class ProjCGWork:
         else:
             self.g, self.d, self.rp = (DeviceVector(ctx, n) for _ in range(3))
         self.Utr = DeviceVector(ctx, max(m, 1))
-        # extra scratch for the generic (unfused) path, allocated on demand
+        # extra scratch for a general operator A (lfpsqp_projcg_op's Av) and for the all-Python loop, allocated on demand
+        self.Av = None
         self._extra = None
 
     def _c(self):
@@ -131,6 +132,31 @@ def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c:
         return iters.value, nr.value
     if resume:
         raise ValueError("resume is a feature of the device-resident projcg loop")
+    if (isinstance(U, DeviceBasis) or stacked) and hasattr(A, "mul_"):
+        # general A (the LinearMap case, src/optimize.jl:228-230) on the C loop: lfpsqp_projcg_op calls back once per iteration
+        # for A*d; the products stay on the device and nothing in the loop waits for it (no per-dot host round trips)
+        if getattr(work, "Av", None) is None:
+            work.Av = work.g.__class__(ctx, work.g.N) if hasattr(work.g, "N") else DeviceVector(ctx, n)
+        Av = work.Av
+        known = {x.h.value: x, work.d.h.value: work.d}
+
+        def tramp(user, src_h, dst_h):
+            try:
+                A.mul_(Av, known[src_h])
+                return 0
+            except Exception as e:       # never unwind through C
+                print("operator callback failed:", repr(e))
+                return 1
+        cb = _capi.OPFUN(tramp)
+        iters = _capi.c_i64()
+        nr = C.c_double()
+        u_c, w_c = U._c(), work._c()
+        flags = WANT_LAMBDA if (want_lambda and lam is not None) else 0
+        ctx.check(ctx.L.lfpsqp_projcg_op(ctx.h, x.h, lam.h if lam is not None else None, cb, None, Av.h, C.byref(u_c), b.h,
+                                         c.h if c is not None else None, float(tol), int(maxit), int(n_global), flags,
+                                         C.byref(w_c), C.byref(iters), C.byref(nr)))
+        del cb
+        return iters.value, nr.value
     return _projcg_generic(x, lam, A, U, b, c, tol, maxit, work, n_global, m)
 
 

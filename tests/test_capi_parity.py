@@ -260,6 +260,145 @@ def test_projcg_generic_operator_path(dev_ctx):
     assert np.abs(lam.download() - l0).max() < 1e-11
 
 
+class _TriDevice:
+    """A = tridiag(e, a, e) on device vectors out of the library's own asynchronous primitives (vmul, ranged copies, axpby):
+    what a host's LinearMap looks like when its body runs on the device.  Works on plain n-vectors, and on the x-half of a
+    stacked vector with a diagonal (here: 2) on the y-half -- the shape of augmented_hess_lag_vec! (inequality_helper.jl:144-158)."""
+
+    def __init__(self, ctx, a, e, stacked_N=None):
+        n = len(a)
+        self.n, self.N = n, stacked_N
+        self.a = ctx.vector(n, a)
+        self.e_up = ctx.vector(n, np.concatenate([e, [0.0]]))          # e_up[i] = e[i]   multiplies v[i+1]
+        self.e_dn = ctx.vector(n, np.concatenate([[0.0], e]))          # e_dn[i] = e[i-1] multiplies v[i-1]
+        self.v, self.sh, self.t, self.out = (ctx.vector(n) for _ in range(4))
+        self.calls = 0
+
+    def _tri(self, dest, v):
+        n = self.n
+        L.vmul(self.a, v, dest)
+        self.sh.fill(0.0)
+        self.sh.copy_range_from(v, n - 1, 0, 1)                          # sh[i] = v[i+1]
+        L.vmul(self.e_up, self.sh, self.t)
+        L.axpby(1.0, self.t, 1.0, dest)
+        self.sh.fill(0.0)
+        self.sh.copy_range_from(v, n - 1, 1, 0)                          # sh[i] = v[i-1]
+        L.vmul(self.e_dn, self.sh, self.t)
+        L.axpby(1.0, self.t, 1.0, dest)
+
+    def mul_(self, dest, v, al=None, be=None):
+        assert al is None
+        self.calls += 1
+        if self.N is None:
+            self._tri(dest, v)
+        else:
+            hs = dest.hs
+            self.v.copy_range_from(v, self.n, 0, 0)
+            self._tri(self.out, self.v)
+            L.waxpby(2.0, v, 0.0, v, dest)                               # y-half: 2 * src_y (x-half overwritten next)
+            dest.copy_range_from(self.out, self.n, 0, 0)
+        return dest
+
+    def adjoint(self):
+        return self
+
+
+class _TriRef:
+    def __init__(self, a, e, stacked=False):
+        self.a, self.e, self.stacked = a, e, stacked
+
+    def _tri(self, v):
+        out = self.a * v
+        out[:-1] += self.e * v[1:]
+        out[1:] += self.e * v[:-1]
+        return out
+
+    def mul_(self, dest, v, al=None, be=None):
+        n = len(self.a)
+        t = np.concatenate([self._tri(v[:n]), 2.0 * v[n:]]) if self.stacked else self._tri(v)
+        dest[:] = t if al is None else al * t + be * dest
+        return dest
+
+    def adjoint(self):
+        return self
+
+
+@pytest.mark.parametrize("n,m", [(1500, 6), (2500, 130)])
+def test_projcg_op_with_a_tridiagonal_operator(dev_ctx, n, m):
+    """lfpsqp_projcg_op: the reference's A is a LinearMap closure (src/optimize.jl:228-230; applied at src/projcg.jl:57,74,116).
+    A tridiagonal A whose body consists of queued device primitives runs on the C loop -- counts, iterate and multipliers of
+    the oracle, the callback invoked once per iteration plus start and lambda."""
+    ctx = dev_ctx
+    Uh, a, bh = _cg_problem(n, m)
+    e = 0.8 * synth.hash_vector(15, n - 1)
+    A = _TriDevice(ctx, a, e)
+    for ch, tol in ((None, 1e-10), (np.linspace(-1, 1, m), 1e-12)):
+        x0, l0 = np.zeros(n), np.zeros(m)
+        i0, nr0 = R.projcg_(x0, l0, _TriRef(a, e), Uh, bh, np.zeros(m) if ch is None else ch, tol=tol)
+        x, lam = ctx.vector(n), ctx.vector(m)
+        A.calls = 0
+        i1, nr1 = L.projcg_(x, lam, A, L.DeviceBasis(ctx.matrix(n, m, Uh)), ctx.vector(n, bh), None if ch is None else ctx.vector(m, ch), tol=tol)
+        assert i1 == i0 and nr1 == pytest.approx(nr0, rel=1e-5)
+        assert np.linalg.norm(x.download() - x0) <= 1e-10 * np.linalg.norm(x0)
+        assert np.abs(lam.download() - l0).max() < 1e-10
+        assert i1 + 2 <= A.calls <= i1 + 5                     # (the host runs up to two iterations ahead of the exit it sees)
+    # negative curvature (src/projcg.jl:77-82) through the same loop
+    A2 = _TriDevice(ctx, -a, e)
+    x0, l0 = np.zeros(n), np.zeros(m)
+    i0, nr0 = R.projcg_(x0, l0, _TriRef(-a, e), Uh, bh, np.zeros(m), tol=1e-10)
+    x, lam = ctx.vector(n), ctx.vector(m)
+    i1, nr1 = L.projcg_(x, lam, A2, L.DeviceBasis(ctx.matrix(n, m, Uh)), ctx.vector(n, bh), None, tol=1e-10)
+    assert (i1, nr1) == (i0, nr0) and math.isinf(nr1)
+    assert np.linalg.norm(x.download() - x0) <= 1e-10 and np.all(np.isnan(lam.download()))
+
+
+def test_projcg_op_with_bounds_stacked_basis(dev_ctx):
+    """The same with the bound-projected basis Q (InequalityDecompProject, src/inequality_helper.jl:161-212) and an operator of
+    augmented_hess_lag_vec!'s shape ([H src_x + ...; diag src_y], :144-158): stacked vectors on the device, 2N-vectors in
+    the oracle."""
+    from lfpsqp_jl_amd.inequality import InequalityData, InequalityDecomp, InequalityDecompProject, StackedVector, generate_initial_y_, inequality_gradient_
+    ctx = dev_ctx
+    n, m = 900, 5
+    Jh = synth.hash_matrix(1, n, m)
+    i = np.arange(n)
+    xl = np.where((i % 4 == 1) | (i % 4 == 3), -1.0, -np.inf)
+    xu = np.where((i % 4 == 2) | (i % 4 == 3), 1.0, np.inf)
+    xh = 0.6 * synth.hash_vector(2, n)
+    a = 4.0 * synth.hash_vector(3, n) + 5.0
+    e = 0.8 * synth.hash_vector(15, n - 1)
+    bh = synth.hash_vector(4, 2 * n)
+    # oracle side
+    id0 = R.InequalityData(xl, xu)
+    xa0 = np.zeros(2 * n); xa0[:n] = xh
+    R.generate_initial_y_(xa0, id0)
+    dec0 = R.InequalityDecomp(np.empty((2 * n, m), order='F'), np.empty(m), np.empty((m, m), order='F'), np.empty(n), np.empty(n), np.empty(n),
+                              np.asfortranarray(Jh), m)
+    R.inequality_gradient_(dec0, xa0, id0)
+    PJ = np.vstack([(1 - dec0.Dx ** 2)[:, None] * Jh, (-dec0.Dy * dec0.Dx)[:, None] * Jh])
+    U0, S0, Vt0 = np.linalg.svd(PJ, full_matrices=False)
+    dec0.U[:, :] = U0
+    dec0.rank = m
+    Q0 = R.InequalityDecompProject(dec0)
+    x0, l0 = np.zeros(2 * n), np.zeros(n + m)
+    i0, nr0 = R.projcg_(x0, l0, _TriRef(a, e, stacked=True), Q0, bh, np.zeros(n + m), tol=1e-10)
+    # device side
+    idata = InequalityData(ctx, xl, xu)
+    xa = StackedVector(ctx, n)
+    xa.upload(xh, 0)
+    generate_initial_y_(xa, idata)
+    Jct = ctx.matrix(n, m, Jh)
+    dec = InequalityDecomp(ctx, n, m, Jct)
+    inequality_gradient_(dec, xa, idata)
+    S, Vt, rank = L.ksvd_(Jct, dec.Z, w2=dec.sx)
+    dec.rank = rank
+    Q = InequalityDecompProject(dec)
+    b = StackedVector(ctx, n).upload2(bh)
+    x = StackedVector(ctx, n)
+    it, nr = L.projcg_(x, None, _TriDevice(ctx, a, e, stacked_N=n), Q, b, None, tol=1e-10, want_lambda=False)
+    assert rank == m and it == i0 and nr == pytest.approx(nr0, rel=1e-5)
+    assert np.linalg.norm(x.download2() - x0) <= 1e-10 * np.linalg.norm(x0)
+
+
 def test_c_port_agrees_with_numpy_oracle():
     n, m = 4000, 9
     Uh, a, bh = _cg_problem(n, m)
