@@ -1,20 +1,26 @@
-# LFPSQPHip.jl -- the binding a maintainer of ksil/LFPSQP.jl adds to run the inner-loop hot path
-# (projcg!, retract!, the tangent setup, the bound operators) on an MI355X through liblfpsqp_hip.so.
+# LFPSQPHip.jl -- what a maintainer of ksil/LFPSQP.jl adds to run the package's inner loop (projcg!, retract!, the tangent
+# setup, the bound operators) AND the outer `optimize` driver on an MI355X through liblfpsqp_hip.so.
 #
-# NOT EXECUTED in this repository's CI: no `julia` binary exists in the build image (SURVEY.md §0),
-# so this file is syntax-reviewed only; every ccall below is exercised through the identical C ABI
-# by the Python ctypes mirror (lfpsqp.jl_amd/_capi.py) in tests/.  See INTEGRATION.md.
+# NOT EXECUTED in this repository: no `julia` binary exists in the build image (SURVEY.md §0).  What IS checked mechanically
+# (tests/test_julia_shim_signatures.py): every `ccall((:name, lib), ret, (types...), ...)` of this file against the prototype
+# of `name` in include/lfpsqp_hip.h, every `struct C...` against the C struct of the same role (field order and types), that
+# every function the header declares is bound here, and that definitions sit inside the module.  The same C ABI is
+# exercised call for call by the Python ctypes mirror (lfpsqp.jl_amd/_capi.py) in tests/.  See INTEGRATION.md.
+#
+# Layout:  1. raw bindings (one thin wrapper per C entry point)      2. device arrays and BLAS-1/2 dispatch (mul!, dot, norm)
+#          3. operators: DiagOperator, DeviceBasis, bound decomposition      4. projcg!, retract! (NR, ProjPenalty, ...), pcg!
+#          5. armijo! / exact_linesearch!      6. optimize: the six methods of src/optimize.jl:13-119 on device-resident state
 #
 # Usage inside LFPSQP.jl:   include("LFPSQPHip.jl"); using .LFPSQPHip
-#   ctx = HipContext(0)
-#   U   = DeviceBasis(upload(ctx, Umatrix))            # or factorize!(ctx, Jct_dev, Z_dev)
-#   A   = DiagOperator(2.0)                            # hess_lag_vec! = 2v  (a0*I + diag(dg))
-#   i, nr = projcg!(x_dev, λ_dev, A, U, b_dev, nothing; tol=tol, maxit=maxit, work=work)
-# i.e. the call sites of src/optimize.jl:381 / src/linesearch.jl:52 stay as they are; only the
-# array / operator types change and Julia's dispatch selects the methods defined here.
+#   ctx  = HipContext(0)
+#   prob = QuadLinearBallBox(ctx, n, m, Jct_dev, b; R2 = n / 2, xl = xl, xu = xu)       # device-resident f, c!, jac!, Hessian
+#   x, obj_values, λ_kkt, info = optimize(prob, x0, LFPSQPParams())
+# or, with arbitrary Julia callables (every user call costs one n-vector PCIe round trip):
+#   x, obj_values, λ_kkt, info = optimize(ctx, f, grad!, c!, jac!, hess_lag_vec!, x0, xl, xu, m, LFPSQPParams())
 module LFPSQPHip
 
 using LinearAlgebra
+using Printf
 import LinearAlgebra: mul!, dot, norm
 
 const lib = get(ENV, "LFPSQP_HIP_LIB", joinpath(@__DIR__, "..", "lfpsqp.jl_amd", "lib", "liblfpsqp_hip.so"))
@@ -24,43 +30,233 @@ struct HipError <: Exception
     msg::String
 end
 
+# =====================================================================================================================
+# 1. C structs of include/lfpsqp_hip.h (isbits mirrors, passed by reference) and raw bindings
+# =====================================================================================================================
+struct CDiagOp                 # lfpsqp_diag_op
+    a0::Float64
+    dg::Ptr{Cvoid}
+end
+struct CBasis                  # lfpsqp_basis
+    Z::Ptr{Cvoid}
+    ncols::Int64
+    Dx::Ptr{Cvoid}
+    Dy::Ptr{Cvoid}
+    sx::Ptr{Cvoid}
+    sy::Ptr{Cvoid}
+    A::Ptr{Cvoid}
+    W::Ptr{Float64}
+end
+struct CWork                   # lfpsqp_projcg_work
+    g::Ptr{Cvoid}
+    d::Ptr{Cvoid}
+    rp::Ptr{Cvoid}
+    Utr::Ptr{Cvoid}
+end
+struct CIneqData               # lfpsqp_ineq_data
+    q::Ptr{Cvoid}
+    r::Ptr{Cvoid}
+    s::Ptr{Cvoid}
+    t::Ptr{Cvoid}
+    n::Int64
+end
+struct CConstraints            # lfpsqp_constraints
+    Jct::Ptr{Cvoid}
+    m_lin::Int64
+    b::Ptr{Float64}
+    has_ball::Cint
+    R2::Float64
+    n_x::Int64
+    slack_row::Int64
+end
+struct CPPWork                 # lfpsqp_pp_work
+    r::Ptr{Cvoid}
+    p::Ptr{Cvoid}
+    z::Ptr{Cvoid}
+    dx::Ptr{Cvoid}
+    g::Ptr{Cvoid}
+    tmp_m::Ptr{Cvoid}
+    tmp_w::Ptr{Cvoid}
+    h::Ptr{Cvoid}
+    DxS::Ptr{Cvoid}
+    DyS::Ptr{Cvoid}
+    ones::Ptr{Cvoid}
+    zeros::Ptr{Cvoid}
+end
+
+const LFPSQP_PROJCG_WANT_LAMBDA = Cint(1)
+const LFPSQP_PROJCG_RESUME = Cint(2)
+const LFPSQP_ERR_UNSUPPORTED = Cint(-5)
+
+const H = Ptr{Cvoid}           # an opaque handle (lfpsqp_ctx*, lfpsqp_vec*, lfpsqp_mat*)
+
+# ---- context ---------------------------------------------------------------------------------------------------------
+c_ctx_create(device, out) = ccall((:lfpsqp_ctx_create, lib), Cint, (Cint, Ref{Ptr{Cvoid}}), device, out)
+c_ctx_destroy(ctx) = ccall((:lfpsqp_ctx_destroy, lib), Cint, (Ptr{Cvoid},), ctx)
+c_ctx_sync(ctx) = ccall((:lfpsqp_ctx_sync, lib), Cint, (Ptr{Cvoid},), ctx)
+c_last_error(ctx) = ccall((:lfpsqp_last_error, lib), Cstring, (Ptr{Cvoid},), ctx)
+c_device_name(ctx, buf, len) = ccall((:lfpsqp_device_name, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64), ctx, buf, len)
+c_ctx_set_tuning(ctx, ks, nt) = ccall((:lfpsqp_ctx_set_tuning, lib), Cint, (Ptr{Cvoid}, Cint, Cint), ctx, ks, nt)
+c_ctx_set_onepass(ctx, mode) = ccall((:lfpsqp_ctx_set_onepass, lib), Cint, (Ptr{Cvoid}, Cint), ctx, mode)
+c_ctx_stream(ctx, out) = ccall((:lfpsqp_ctx_stream, lib), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx, out)
+c_timer_begin(ctx) = ccall((:lfpsqp_timer_begin, lib), Cint, (Ptr{Cvoid},), ctx)
+c_timer_end(ctx, ms) = ccall((:lfpsqp_timer_end, lib), Cint, (Ptr{Cvoid}, Ref{Float64}), ctx, ms)
+c_ctx_set_profiling(ctx, on) = ccall((:lfpsqp_ctx_set_profiling, lib), Cint, (Ptr{Cvoid}, Cint), ctx, on)
+c_profile_read(ctx, ms, counts) = ccall((:lfpsqp_profile_read, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}), ctx, ms, counts)
+# ---- multi-GPU -----------------------------------------------------------------------------------------------------------
+c_shard_range(n, rank, nranks, r0, r1) = ccall((:lfpsqp_shard_range, lib), Cint, (Int64, Cint, Cint, Ref{Int64}, Ref{Int64}), n, rank, nranks, r0, r1)
+c_comm_unique_id(ctx, id) = ccall((:lfpsqp_comm_unique_id, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}), ctx, id)
+c_comm_init_rccl(ctx, rank, nranks, id) = ccall((:lfpsqp_comm_init_rccl, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx, rank, nranks, id)
+c_comm_init_callback(ctx, rank, nranks, fn, user) = ccall((:lfpsqp_comm_init_callback, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}), ctx, rank, nranks, fn, user)
+c_comm_info(ctx, rank, nranks) = ccall((:lfpsqp_comm_info, lib), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), ctx, rank, nranks)
+# ---- buffers -----------------------------------------------------------------------------------------------------------
+c_vec_alloc(ctx, n, out) = ccall((:lfpsqp_vec_alloc, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), ctx, n, out)
+c_vec_free(ctx, v) = ccall((:lfpsqp_vec_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx, v)
+c_vec_len(v) = ccall((:lfpsqp_vec_len, lib), Int64, (Ptr{Cvoid},), v)
+c_vec_upload(ctx, v, off, host, count) = ccall((:lfpsqp_vec_upload, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Int64), ctx, v, off, host, count)
+c_vec_download(ctx, v, off, host, count) = ccall((:lfpsqp_vec_download, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Int64), ctx, v, off, host, count)
+c_vec_fill(ctx, v, value) = ccall((:lfpsqp_vec_fill, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64), ctx, v, value)
+c_vec_copy(ctx, dst, src) = ccall((:lfpsqp_vec_copy, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, dst, src)
+c_vec_copy_range(ctx, dst, doff, src, soff, count) = ccall((:lfpsqp_vec_copy_range, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Int64), ctx, dst, doff, src, soff, count)
+c_vec_fill_range(ctx, v, off, count, value) = ccall((:lfpsqp_vec_fill_range, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Float64), ctx, v, off, count, value)
+c_vec_hash_fill(ctx, v, seed, off, scale, shift) = ccall((:lfpsqp_vec_hash_fill, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Int64, Float64, Float64), ctx, v, seed, off, scale, shift)
+c_mat_alloc(ctx, n, m, out) = ccall((:lfpsqp_mat_alloc, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), ctx, n, m, out)
+c_mat_free(ctx, M) = ccall((:lfpsqp_mat_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx, M)
+c_mat_shape(M, n, m) = ccall((:lfpsqp_mat_shape, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), M, n, m)
+c_mat_upload(ctx, M, col0, ncols, host, ldh) = ccall((:lfpsqp_mat_upload, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Int64), ctx, M, col0, ncols, host, ldh)
+c_mat_download(ctx, M, col0, ncols, host, ldh) = ccall((:lfpsqp_mat_download, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Int64), ctx, M, col0, ncols, host, ldh)
+c_mat_copy(ctx, dst, src) = ccall((:lfpsqp_mat_copy, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, dst, src)
+c_mat_hash_fill(ctx, M, seed, row0, nglob, scale, nrows, ncols) = ccall((:lfpsqp_mat_hash_fill, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Int64, Int64, Float64, Int64, Int64), ctx, M, seed, row0, nglob, scale, nrows, ncols)
+# ---- BLAS-1/2 ------------------------------------------------------------------------------------------------------------
+c_gemv_t(ctx, M, ncols, v, t) = ccall((:lfpsqp_gemv_t, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}), ctx, M, ncols, v, t)
+c_gemv_n(ctx, M, ncols, a, t, b, y) = ccall((:lfpsqp_gemv_n, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}), ctx, M, ncols, a, t, b, y)
+c_dot(ctx, x, y, out) = ccall((:lfpsqp_dot, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), ctx, x, y, out)
+c_dot_head(ctx, x, y, count, out) = ccall((:lfpsqp_dot_head, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{Float64}), ctx, x, y, count, out)
+c_nrm2(ctx, x, out) = ccall((:lfpsqp_nrm2, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), ctx, x, out)
+c_amax(ctx, x, out) = ccall((:lfpsqp_amax, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), ctx, x, out)
+c_axpby(ctx, a, x, b, y) = ccall((:lfpsqp_axpby, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}), ctx, a, x, b, y)
+c_waxpby(ctx, a, x, b, y, z) = ccall((:lfpsqp_waxpby, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Ptr{Cvoid}), ctx, a, x, b, y, z)
+c_vmul(ctx, d, x, y) = ccall((:lfpsqp_vmul, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, d, x, y)
+c_affine_head(ctx, a, x, c, count, y) = ccall((:lfpsqp_affine_head, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Int64, Ptr{Cvoid}), ctx, a, x, c, count, y)
+c_sumsq_shift(ctx, x, count, c, out) = ccall((:lfpsqp_sumsq_shift, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Ref{Float64}), ctx, x, count, c, out)
+c_allreduce(ctx, v, count) = ccall((:lfpsqp_allreduce, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), ctx, v, count)
+# ---- bound manifolds -------------------------------------------------------------------------------------------------------
+c_half_stride(N) = ccall((:lfpsqp_half_stride, lib), Int64, (Int64,), N)
+c_ineq_data_build(ctx, xl, xu, q, r, s, t) = ccall((:lfpsqp_ineq_data_build, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, xl, xu, q, r, s, t)
+c_generate_initial_y(ctx, xaug, id) = ccall((:lfpsqp_generate_initial_y, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{CIneqData}), ctx, xaug, id)
+c_calculate_h(ctx, h, xaug, id, hmax) = ccall((:lfpsqp_calculate_h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CIneqData}, Ptr{Float64}), ctx, h, xaug, id, hmax)
+c_inequality_gradient(ctx, xaug, id, Dx, Dy, S, sx, sy) = ccall((:lfpsqp_inequality_gradient, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{CIneqData}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, xaug, id, Dx, Dy, S, sx, sy)
+c_calculate_lambda_y(ctx, Jct, ncols, lam, Dx, S, w, lamy) = ccall((:lfpsqp_calculate_lambda_y, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, Jct, ncols, lam, Dx, S, w, lamy)
+c_augmented_diag(ctx, hx, lamy, id, a) = ccall((:lfpsqp_augmented_diag, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CIneqData}, Ptr{Cvoid}), ctx, hx, lamy, id, a)
+c_y_retract(ctx, xnew, x, id) = ccall((:lfpsqp_y_retract, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CIneqData}), ctx, xnew, x, id)
+# ---- tangent setup -----------------------------------------------------------------------------------------------------------
+c_gram(ctx, M, ncols, w2, G) = ccall((:lfpsqp_gram, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Float64}), ctx, M, ncols, w2, G)
+c_rmul(ctx, In, kcols, W, rcols, Out) = ccall((:lfpsqp_rmul, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Ptr{Cvoid}), ctx, In, kcols, W, rcols, Out)
+c_factorize(ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank) = ccall((:lfpsqp_factorize, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64), ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank)
+c_small_svd(ctx, rows, cols, A, U, S, V) = ccall((:lfpsqp_small_svd, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx, rows, cols, A, U, S, V)
+c_q_gemv_t(ctx, Q, v, w, t) = ccall((:lfpsqp_q_gemv_t, lib), Cint, (Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, Q, v, w, t)
+c_q_gemv_n(ctx, Q, a, w, t, b, y) = ccall((:lfpsqp_q_gemv_n, lib), Cint, (Ptr{Cvoid}, Ref{CBasis}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}), ctx, Q, a, w, t, b, y)
+# ---- solvers -------------------------------------------------------------------------------------------------------------------
+c_projcg(ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg, lib), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CDiagOp}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
+    ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
+c_projcg_op(ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg_op, lib), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
+    ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
+c_constraints_eval(ctx, cons, x, cval) = ccall((:lfpsqp_constraints_eval, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Float64}), ctx, cons, x, cval)
+c_constraints_jac(ctx, cons, x, Jct, cval) = ccall((:lfpsqp_constraints_jac, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), ctx, cons, x, Jct, cval)
+c_retract_nr(ctx, U, Sigma, Vt, m, cons, cfun, cuser, idata, xtilde, x, xnew, tol, maxiter, cval, flag, iters) = ccall((:lfpsqp_retract_nr, lib), Cint,
+    (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{CIneqData}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Ptr{Float64}, Ref{Cint}, Ref{Int64}),
+    ctx, U, Sigma, Vt, m, cons, cfun, cuser, idata, xtilde, x, xnew, tol, maxiter, cval, flag, iters)
+c_retract_nr_batch(ctx, U, Sigma, Vt, m, cons, idata, nb, xtilde, x, xnew, tol, maxiter, cval, flags, iters) = ccall((:lfpsqp_retract_nr_batch, lib), Cint,
+    (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{CConstraints}, Ptr{CIneqData}, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Float64, Int64, Ptr{Float64}, Ptr{Cint}, Ptr{Int64}),
+    ctx, U, Sigma, Vt, m, cons, idata, nb, xtilde, x, xnew, tol, maxiter, cval, flags, iters)
+c_pcg(ctx, mu, Jop, x, r, p, z, tmp_w, tmp_m, tol, maxiter, flag, iters) = ccall((:lfpsqp_pcg, lib), Cint,
+    (Ptr{Cvoid}, Float64, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Ref{Cint}, Ref{Int64}),
+    ctx, mu, Jop, x, r, p, z, tmp_w, tmp_m, tol, maxiter, flag, iters)
+c_retract_pp(ctx, cons, cfun, jacfun, user, Jct, m, idata, Dx, Dy, S, xtilde, x, xnew, mu0, tol, maxiter, maxiter_pcg, work, cval, flag, iters, pcg_iters) = ccall((:lfpsqp_retract_pp, lib), Cint,
+    (Ptr{Cvoid}, Ptr{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{CIneqData}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int64, Int64, Ref{CPPWork}, Ptr{Float64}, Ref{Cint}, Ref{Int64}, Ref{Int64}),
+    ctx, cons, cfun, jacfun, user, Jct, m, idata, Dx, Dy, S, xtilde, x, xnew, mu0, tol, maxiter, maxiter_pcg, work, cval, flag, iters, pcg_iters)
+
+# =====================================================================================================================
+# 2. Context, device arrays, BLAS-1/2 dispatch
+# =====================================================================================================================
 mutable struct HipContext
     h::Ptr{Cvoid}
+    rank::Int
+    nranks::Int
     function HipContext(device::Integer=0)
         r = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:lfpsqp_ctx_create, lib), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r)
+        rc = c_ctx_create(Cint(device), r)
         rc == 0 || throw(HipError(rc, "lfpsqp_ctx_create failed: no usable MI355X (there is no CPU fallback)"))
-        ctx = new(r[])
-        finalizer(c -> ccall((:lfpsqp_ctx_destroy, lib), Cint, (Ptr{Cvoid},), c.h), ctx)
+        ctx = new(r[], 0, 1)
+        finalizer(c -> c_ctx_destroy(c.h), ctx)
         return ctx
     end
 end
+check(ctx::HipContext, rc::Cint) = rc == 0 ? nothing : throw(HipError(rc, unsafe_string(c_last_error(ctx.h))))
+sync(ctx::HipContext) = check(ctx, c_ctx_sync(ctx.h))
 
-check(ctx::HipContext, rc::Cint) = rc == 0 ? nothing :
-    throw(HipError(rc, unsafe_string(ccall((:lfpsqp_last_error, lib), Cstring, (Ptr{Cvoid},), ctx.h))))
+# multi-GPU: one Julia process per GPU (e.g. under MPI.jl); rank 0 creates the id and broadcasts it
+function comm_unique_id(ctx::HipContext)
+    id = Vector{UInt8}(undef, 128)
+    check(ctx, c_comm_unique_id(ctx.h, id))
+    return id
+end
+function comm_init!(ctx::HipContext, rank::Integer, nranks::Integer, id::Vector{UInt8})
+    check(ctx, c_comm_init_rccl(ctx.h, Cint(rank), Cint(nranks), id))
+    ctx.rank, ctx.nranks = rank, nranks
+    return ctx
+end
+function shard_range(n::Integer, rank::Integer, nranks::Integer)
+    r0 = Ref{Int64}(0); r1 = Ref{Int64}(0)
+    c_shard_range(Int64(n), Cint(rank), Cint(nranks), r0, r1) == 0 || error("lfpsqp_shard_range: invalid arguments")
+    return Int(r0[]), Int(r1[])                 # 0-based half-open row range [r0, r1)
+end
 
-# ---- buffers --------------------------------------------------------------------------------
+# A device vector.  With bounds the reference doubles the variables (xaug = [x; y], length 2N); on the device such a STACKED
+# vector keeps the x-half at [0, N) and the y-half at [hs, hs + N) (hs = lfpsqp_half_stride(N)): N > 0 marks it.
 mutable struct DeviceVector <: AbstractVector{Float64}
     ctx::HipContext
     h::Ptr{Cvoid}
-    n::Int
+    n::Int                      # allocated logical length (hs + N when stacked)
+    N::Int                      # 0: plain vector; > 0: stacked [x | gap | y] of a 2N-vector
+    hs::Int
 end
 function DeviceVector(ctx::HipContext, n::Integer)
     r = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ctx, ccall((:lfpsqp_vec_alloc, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), ctx.h, n, r))
-    v = DeviceVector(ctx, r[], n)
-    finalizer(x -> ccall((:lfpsqp_vec_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.h, x.h), v)
+    check(ctx, c_vec_alloc(ctx.h, Int64(n), r))
+    v = DeviceVector(ctx, r[], n, 0, 0)
+    finalizer(x -> c_vec_free(x.ctx.h, x.h), v)
     return v
 end
-Base.size(v::DeviceVector) = (v.n,)
-Base.length(v::DeviceVector) = v.n
-upload!(v::DeviceVector, host::Vector{Float64}) =
-    (check(v.ctx, ccall((:lfpsqp_vec_upload, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Int64), v.ctx.h, v.h, 0, host, length(host))); v)
-function download(v::DeviceVector)
-    host = Vector{Float64}(undef, v.n)
-    check(v.ctx, ccall((:lfpsqp_vec_download, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Int64), v.ctx.h, v.h, 0, host, v.n))
+function StackedVector(ctx::HipContext, N::Integer)
+    hs = Int(c_half_stride(Int64(N)))
+    v = DeviceVector(ctx, hs + N)
+    v.N, v.hs = N, hs
+    return v
+end
+similar_device(v::DeviceVector) = v.N > 0 ? StackedVector(v.ctx, v.N) : DeviceVector(v.ctx, v.n)
+Base.size(v::DeviceVector) = (v.N > 0 ? 2 * v.N : v.n,)
+Base.length(v::DeviceVector) = v.N > 0 ? 2 * v.N : v.n
+function upload!(v::DeviceVector, host::AbstractVector{Float64}, offset::Integer=0)
+    hostc = Vector{Float64}(host)
+    check(v.ctx, c_vec_upload(v.ctx.h, v.h, Int64(offset), hostc, Int64(length(hostc))))
+    return v
+end
+function download(v::DeviceVector, count::Integer=v.n, offset::Integer=0)
+    host = Vector{Float64}(undef, count)
+    check(v.ctx, c_vec_download(v.ctx.h, v.h, Int64(offset), host, Int64(count)))
     return host
 end
+upload2!(v::DeviceVector, host::AbstractVector{Float64}) = (upload!(v, host[1:v.N], 0); upload!(v, host[v.N+1:2*v.N], v.hs); v)
+download2(v::DeviceVector) = vcat(download(v, v.N, 0), download(v, v.N, v.hs))
+Base.fill!(v::DeviceVector, value::Real) = (check(v.ctx, c_vec_fill(v.ctx.h, v.h, Float64(value))); v)
+Base.copyto!(dst::DeviceVector, src::DeviceVector) = (check(dst.ctx, c_vec_copy(dst.ctx.h, dst.h, src.h)); dst)
+copy_range!(dst::DeviceVector, doff::Integer, src::DeviceVector, soff::Integer, count::Integer) =
+    (check(dst.ctx, c_vec_copy_range(dst.ctx.h, dst.h, Int64(doff), src.h, Int64(soff), Int64(count))); dst)
+fill_range!(v::DeviceVector, off::Integer, count::Integer, value::Real) =
+    (check(v.ctx, c_vec_fill_range(v.ctx.h, v.h, Int64(off), Int64(count), Float64(value))); v)
 
 mutable struct DeviceMatrix <: AbstractMatrix{Float64}
     ctx::HipContext
@@ -70,193 +266,942 @@ mutable struct DeviceMatrix <: AbstractMatrix{Float64}
 end
 function DeviceMatrix(ctx::HipContext, n::Integer, m::Integer)
     r = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ctx, ccall((:lfpsqp_mat_alloc, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), ctx.h, n, m, r))
+    check(ctx, c_mat_alloc(ctx.h, Int64(n), Int64(m), r))
     M = DeviceMatrix(ctx, r[], n, m)
-    finalizer(x -> ccall((:lfpsqp_mat_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.h, x.h), M)
+    finalizer(x -> c_mat_free(x.ctx.h, x.h), M)
     return M
 end
 Base.size(M::DeviceMatrix) = (M.n, M.m)
-upload!(M::DeviceMatrix, host::Matrix{Float64}) =      # Julia matrices are column-major: zero-copy layout match
-    (check(M.ctx, ccall((:lfpsqp_mat_upload, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Int64),
-                        M.ctx.h, M.h, 0, size(host, 2), host, size(host, 1))); M)
+function upload!(M::DeviceMatrix, host::Matrix{Float64}, col0::Integer=0)      # Julia matrices are column-major: the layouts match
+    check(M.ctx, c_mat_upload(M.ctx.h, M.h, Int64(col0), Int64(size(host, 2)), host, Int64(max(size(host, 1), 1))))
+    return M
+end
+function download(M::DeviceMatrix)
+    host = Matrix{Float64}(undef, M.n, M.m)
+    check(M.ctx, c_mat_download(M.ctx.h, M.h, Int64(0), Int64(M.m), host, Int64(max(M.n, 1))))
+    return host
+end
 
-# ---- BLAS-1/2 on device arrays: the generic-dispatch surface projcg!/pcg! are written against --
-# replaces src/la_helper.jl:36-44 (kgemv!) and the mul!/dot/norm calls of src/projcg.jl, src/retractions.jl
-struct DeviceBasis            # view(U, :, 1:rank), src/optimize.jl:370
+# BLAS-1 on device vectors (reductions are global: all-reduced over the ranks and replicated)
+function dot(x::DeviceVector, y::DeviceVector)
+    r = Ref{Float64}(0.0)
+    check(x.ctx, c_dot(x.ctx.h, x.h, y.h, r))
+    return r[]
+end
+function norm(x::DeviceVector, p::Real=2)
+    r = Ref{Float64}(0.0)
+    check(x.ctx, p == Inf ? c_amax(x.ctx.h, x.h, r) : c_nrm2(x.ctx.h, x.h, r))
+    return r[]
+end
+function norm_head(x::DeviceVector, count::Integer)        # norm(view(step, 1:n)), src/linesearch.jl:66
+    r = Ref{Float64}(0.0)
+    check(x.ctx, c_dot_head(x.ctx.h, x.h, x.h, Int64(count), r))
+    return sqrt(r[])
+end
+axpby!(a::Real, x::DeviceVector, b::Real, y::DeviceVector) = (check(y.ctx, c_axpby(y.ctx.h, Float64(a), x.h, Float64(b), y.h)); y)
+waxpby!(z::DeviceVector, a::Real, x::DeviceVector, b::Real, y::DeviceVector) =
+    (check(z.ctx, c_waxpby(z.ctx.h, Float64(a), x.h, Float64(b), y.h, z.h)); z)            # z = a x + b y
+vmul!(y::DeviceVector, d::DeviceVector, x::DeviceVector) = (check(y.ctx, c_vmul(y.ctx.h, d.h, x.h, y.h)); y)
+
+# =====================================================================================================================
+# 3. Operators
+# =====================================================================================================================
+# view(U, :, 1:rank) (src/optimize.jl:370).  `generator` = (Jct, W) with Z == Jct*W (ksvd!'s W): the Newton retraction then
+# streams Jct once per step instead of Z and Jct.
+struct DeviceBasis
     Z::DeviceMatrix
     ncols::Int
+    generator::Union{Nothing,Tuple{DeviceMatrix,Matrix{Float64}}}
 end
-DeviceBasis(Z::DeviceMatrix) = DeviceBasis(Z, Z.m)
+DeviceBasis(Z::DeviceMatrix) = DeviceBasis(Z, Z.m, nothing)
+DeviceBasis(Z::DeviceMatrix, ncols::Integer) = DeviceBasis(Z, ncols, nothing)
 struct DeviceBasisAdjoint
     U::DeviceBasis
 end
 Base.adjoint(U::DeviceBasis) = DeviceBasisAdjoint(U)
 Base.adjoint(Ut::DeviceBasisAdjoint) = Ut.U
-
+# kgemv! (src/la_helper.jl:36-44) and the mul! calls of src/projcg.jl / src/retractions.jl
 mul!(y::DeviceVector, U::DeviceBasis, t::DeviceVector, a::Number=1.0, b::Number=0.0) =
-    (check(y.ctx, ccall((:lfpsqp_gemv_n, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}),
-                        y.ctx.h, U.Z.h, U.ncols, a, t.h, b, y.h)); y)
+    (check(y.ctx, c_gemv_n(y.ctx.h, U.Z.h, Int64(U.ncols), Float64(a), t.h, Float64(b), y.h)); y)
 mul!(t::DeviceVector, Ut::DeviceBasisAdjoint, v::DeviceVector) =
-    (check(t.ctx, ccall((:lfpsqp_gemv_t, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
-                        t.ctx.h, Ut.U.Z.h, Ut.U.ncols, v.h, t.h)); t)
-function dot(x::DeviceVector, y::DeviceVector)
-    r = Ref{Float64}(0.0)
-    check(x.ctx, ccall((:lfpsqp_dot, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), x.ctx.h, x.h, y.h, r))
-    return r[]
-end
-function norm(x::DeviceVector, p::Real=2)
-    r = Ref{Float64}(0.0)
-    if p == Inf
-        check(x.ctx, ccall((:lfpsqp_amax, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), x.ctx.h, x.h, r))
-    else
-        check(x.ctx, ccall((:lfpsqp_nrm2, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), x.ctx.h, x.h, r))
-    end
-    return r[]
-end
-axpby!(a::Number, x::DeviceVector, b::Number, y::DeviceVector) =
-    (check(y.ctx, ccall((:lfpsqp_axpby, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}), y.ctx.h, a, x.h, b, y.h)); y)
+    (check(t.ctx, c_gemv_t(t.ctx.h, Ut.U.Z.h, Int64(Ut.U.ncols), v.h, t.h)); t)
+cbasis(U::DeviceBasis) = U.generator === nothing ? CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL) :
+    CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, U.generator[1].h, pointer(U.generator[2]))
 
-# ---- tangent setup: replaces ksvd! (src/la_helper.jl:8-34), call sites src/optimize.jl:291/293 -----
-# W (optional m×m): the small factor with Z == Jct*W; a DeviceBasis that carries (Jct, W) lets the Newton retraction
-# stream Jct once per step instead of Z and Jct.
-function ksvd!(Jct::DeviceMatrix, Z::DeviceMatrix, Σ::Vector{Float64}, Vt::Matrix{Float64}; w2=nothing, ϵ_rank::Float64=1e-10,
-               W::Union{Nothing,Matrix{Float64}}=nothing)
-    rank = Ref{Int64}(0)
-    check(Jct.ctx, ccall((:lfpsqp_factorize, lib), Cint,
-                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64),
-                         Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, Z.h, Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
-    return Int(rank[])
-end
-
-# ---- projcg! (src/projcg.jl:40-121): fused device solve selected by dispatch on (A, U) ---------------
-struct DiagOperator            # A = a0*I + diag(dg): the LinearMap of src/optimize.jl:228-230 for diagonal Hessians
+# A = a0*I + diag(dg): the LinearMap of src/optimize.jl:228-230 for diagonal Lagrangian Hessians
+struct DiagOperator
     a0::Float64
     dg::Union{Nothing,DeviceVector}
 end
 DiagOperator(a0::Real) = DiagOperator(Float64(a0), nothing)
 
-struct CDiagOp;  a0::Float64; dg::Ptr{Cvoid}; end
-struct CBasis;   Z::Ptr{Cvoid}; ncols::Int64; Dx::Ptr{Cvoid}; Dy::Ptr{Cvoid}; sx::Ptr{Cvoid}; sy::Ptr{Cvoid}; A::Ptr{Cvoid}; W::Ptr{Float64}; end
-CBasis(Z, ncols, Dx, Dy, sx, sy) = CBasis(Z, ncols, Dx, Dy, sx, sy, C_NULL, C_NULL)      # generator unknown
-struct CWork;    g::Ptr{Cvoid}; d::Ptr{Cvoid}; rp::Ptr{Cvoid}; Utr::Ptr{Cvoid}; w::Ptr{Cvoid}; end
-
-struct ProjCGWork              # ProjCGWork(n, m), src/projcg.jl:1-11 (three n-vectors suffice on the device)
-    g::DeviceVector; d::DeviceVector; rp::DeviceVector; Utr::DeviceVector
+# InequalityData(xl, xu) (src/inequality_helper.jl:39-89), device-resident q, r, s, t
+struct InequalityData
+    q::DeviceVector
+    r::DeviceVector
+    s::DeviceVector
+    t::DeviceVector
+    n::Int
 end
-ProjCGWork(ctx::HipContext, n::Int, m::Int) =
-    ProjCGWork(DeviceVector(ctx, n), DeviceVector(ctx, n), DeviceVector(ctx, n), DeviceVector(ctx, max(m, 1)))
+function InequalityData(ctx::HipContext, xl::Vector{Float64}, xu::Vector{Float64})
+    length(xl) == length(xu) || error("xl and xu are of different lengths")
+    n = length(xl)
+    q, r, s, t = (DeviceVector(ctx, n) for _ in 1:4)
+    dxl = upload!(DeviceVector(ctx, n), xl); dxu = upload!(DeviceVector(ctx, n), xu)
+    check(ctx, c_ineq_data_build(ctx.h, dxl.h, dxu.h, q.h, r.h, s.h, t.h))
+    return InequalityData(q, r, s, t, n)
+end
+cineq(id::InequalityData) = CIneqData(id.q.h, id.r.h, id.s.h, id.t.h, id.n)
 
-function projcg!(x::DeviceVector, λ::Union{Nothing,DeviceVector}, A::DiagOperator, U::DeviceBasis, b::DeviceVector, c::Union{Nothing,DeviceVector};
-                 tol::Float64=1e-6, maxit::Int=length(b) + U.ncols, work::ProjCGWork=ProjCGWork(x.ctx, length(b), U.ncols),
-                 n_global::Int=length(b))
+# InequalityDecomp (src/inequality_helper.jl:10-19).  The reference's 2N x M factor U is held as the N x M matrix Z plus
+# the row scalings sx = Dy.^2, sy = -Dx.*Dy (U = [sx .* Z; sy .* Z]).
+mutable struct InequalityDecomp
+    ctx::HipContext
+    N::Int
+    M::Int
+    Z::DeviceMatrix
+    Σ::Vector{Float64}
+    Vt::Matrix{Float64}
+    Dx::DeviceVector
+    Dy::DeviceVector
+    S::DeviceVector
+    sx::DeviceVector
+    sy::DeviceVector
+    Jct::DeviceMatrix
+    rank::Int
+    W::Union{Nothing,Matrix{Float64}}
+end
+InequalityDecomp(ctx::HipContext, N::Integer, M::Integer, Jct::DeviceMatrix) =
+    InequalityDecomp(ctx, N, M, DeviceMatrix(ctx, N, M), zeros(M), zeros(M, M), (DeviceVector(ctx, N) for _ in 1:5)..., Jct, M, nothing)
+# Q = [[diag Dx; diag Dy], U[:, 1:rank]] (InequalityDecompProject, :25-27, :161-212): projcg!'s U with bounds
+struct InequalityDecompProject
+    idecomp::InequalityDecomp
+end
+cbasis(Q::InequalityDecompProject) = (d = Q.idecomp;
+    d.W === nothing ? CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, C_NULL, C_NULL) :
+                      CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, d.Jct.h, pointer(d.W)))
+const AnyBasis = Union{DeviceBasis,InequalityDecompProject}
+ncols(U::DeviceBasis) = U.ncols
+ncols(Q::InequalityDecompProject) = Q.idecomp.rank
+# [w; t] = Q'v and y = a Q [w; t] + b y  (:161-212); ONE pass over the N x M matrix Z each
+q_gemv_t!(w::DeviceVector, t::DeviceVector, Q::InequalityDecompProject, v::DeviceVector) =
+    (check(v.ctx, c_q_gemv_t(v.ctx.h, Ref(cbasis(Q)), v.h, w.h, t.h)); nothing)
+q_gemv_n!(y::DeviceVector, Q::InequalityDecompProject, w::Union{Nothing,DeviceVector}, t::DeviceVector, a::Real=1.0, b::Real=0.0) =
+    (check(y.ctx, c_q_gemv_n(y.ctx.h, Ref(cbasis(Q)), Float64(a), w === nothing ? C_NULL : w.h, t.h, Float64(b), y.h)); y)
+
+generate_initial_y!(xaug::DeviceVector, id::InequalityData) = (check(xaug.ctx, c_generate_initial_y(xaug.ctx.h, xaug.h, Ref(cineq(id)))); xaug)
+inequality_gradient!(d::InequalityDecomp, xaug::DeviceVector, id::InequalityData) =
+    (check(d.ctx, c_inequality_gradient(d.ctx.h, xaug.h, Ref(cineq(id)), d.Dx.h, d.Dy.h, d.S.h, d.sx.h, d.sy.h)); d)
+y_retract!(xnew::DeviceVector, x::DeviceVector, id::InequalityData) = (check(x.ctx, c_y_retract(x.ctx.h, xnew.h, x.h, Ref(cineq(id)))); xnew)
+
+# ksvd! (src/la_helper.jl:8-34, call sites src/optimize.jl:291/293): thin factorisation of diag(sqrt(w2)) Jct; Jct is NOT
+# destroyed.  Returns the rank by the reference's rule (Σ_j >= ϵ_rank, :297-302).  W (optional m x m): Z == Jct*W.
+function ksvd!(Jct::DeviceMatrix, Z::DeviceMatrix, Σ::Vector{Float64}, Vt::Matrix{Float64}; w2::Union{Nothing,DeviceVector}=nothing,
+               ϵ_rank::Float64=1e-10, W::Union{Nothing,Matrix{Float64}}=nothing)
+    rank = Ref{Int64}(0)
+    check(Jct.ctx, c_factorize(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, Z.h, Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
+    return Int(rank[])
+end
+
+# =====================================================================================================================
+# 4. projcg!, retractions, pcg!
+# =====================================================================================================================
+struct ProjCGWork              # ProjCGWork(n, m), src/projcg.jl:1-11 (three n-vectors suffice on the device; Av: general operators)
+    g::DeviceVector
+    d::DeviceVector
+    rp::DeviceVector
+    Utr::DeviceVector
+    Av::DeviceVector
+end
+ProjCGWork(like::DeviceVector, m::Integer) =
+    ProjCGWork(similar_device(like), similar_device(like), similar_device(like), DeviceVector(like.ctx, max(m, 1)), similar_device(like))
+cwork(w::ProjCGWork) = CWork(w.g.h, w.d.h, w.rp.h, w.Utr.h)
+
+# projcg!(x, λ, A, U, b, c; tol, maxit, work) -> (i, nr)  (src/projcg.jl:40-121), fused on the device for a diagonal A ...
+function projcg!(x::DeviceVector, λ::Union{Nothing,DeviceVector}, A::DiagOperator, U::AnyBasis, b::DeviceVector, c::Union{Nothing,DeviceVector};
+                 tol::Float64=1e-6, maxit::Int=length(b) + ncols(U), work::ProjCGWork=ProjCGWork(x, ncols(U)), n_global::Int=length(b))
     iters = Ref{Int64}(0); nr = Ref{Float64}(0.0)
-    a = Ref(CDiagOp(A.a0, A.dg === nothing ? C_NULL : A.dg.h))
-    u = Ref(CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL))
-    w = Ref(CWork(work.g.h, work.d.h, work.rp.h, work.Utr.h, C_NULL))
-    check(x.ctx, ccall((:lfpsqp_projcg, lib), Cint,
-                       (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CDiagOp}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint,
-                        Ref{CWork}, Ref{Int64}, Ref{Float64}),
-                       x.ctx.h, x.h, λ === nothing ? C_NULL : λ.h, a, u, b.h, c === nothing ? C_NULL : c.h, tol, maxit, n_global,
-                       λ === nothing ? 0 : 1, w, iters, nr))
+    GC.@preserve U begin
+        check(x.ctx, c_projcg(x.ctx.h, x.h, λ === nothing ? C_NULL : λ.h, Ref(CDiagOp(A.a0, A.dg === nothing ? C_NULL : A.dg.h)), Ref(cbasis(U)),
+                              b.h, c === nothing ? C_NULL : c.h, tol, Int64(maxit), Int64(n_global), λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA,
+                              Ref(cwork(work)), iters, nr))
+    end
     return Int(iters[]), nr[]          # (i, nr) exactly like the reference; nr == Inf and λ .== NaN on negative curvature
 end
-
-# ---- Newton retraction (src/retractions.jl:75-177) with device-resident linear + ball constraints ------
-struct CConstraints
-    Jct::Ptr{Cvoid}; m_lin::Int64; b::Ptr{Float64}; has_ball::Cint; R2::Float64; n_x::Int64; slack_row::Int64
+# ... and for a GENERAL operator A(dest, src) on device vectors (the LinearMap closure of src/optimize.jl:228-230): the same
+# device-resident loop, A called back once per iteration (lfpsqp_projcg_op); its body may queue device work and return.
+mutable struct OpBox           # what the C callback needs: the Julia closure and the vectors behind the handles it is given
+    apply::Function
+    known::Dict{Ptr{Cvoid},DeviceVector}
+    err::Any
 end
-struct DeviceNR                # NR(U, Σ, Vt, tol, maxiter, work, ineq, idata) of the reference
-    U::DeviceBasis; Σ::Vector{Float64}; Vt::Matrix{Float64}; tol::Float64; maxiter::Int
-    Jct::DeviceMatrix; m_lin::Int; b::Vector{Float64}; has_ball::Bool; R2::Float64; n_x::Int; slack_row::Int
-    W::Union{Nothing,Matrix{Float64}}      # ksvd!'s W (U.Z == Jct*W): one matrix stream per Newton step; nothing = two streams
-end
-function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceVector, x::DeviceVector, method::DeviceNR)
-    flag = Ref{Cint}(0); iters = Ref{Int64}(0)
-    GC.@preserve method begin
-        u = Ref(method.W === nothing ? CBasis(method.U.Z.h, method.U.ncols, C_NULL, C_NULL, C_NULL, C_NULL) :
-                CBasis(method.U.Z.h, method.U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, method.Jct.h, pointer(method.W)))
-        cons = Ref(CConstraints(method.Jct.h, method.m_lin, pointer(method.b), method.has_ball ? 1 : 0, method.R2, method.n_x, method.slack_row))
-        check(x.ctx, ccall((:lfpsqp_retract_nr, lib), Cint,
-                           (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-                            Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Ptr{Float64}, Ref{Cint}, Ref{Int64}),
-                           x.ctx.h, u, method.Σ, method.Vt, length(method.Σ), cons, C_NULL, C_NULL, C_NULL,
-                           xtilde.h, x.h, xnew.h, method.tol, method.maxiter, cval, flag, iters))
+function _op_trampoline(user::Ptr{Cvoid}, src::Ptr{Cvoid}, dest::Ptr{Cvoid})::Cint
+    box = unsafe_pointer_to_objref(user)::OpBox
+    try
+        box.apply(box.known[dest], box.known[src])
+        return Cint(0)
+    catch e                         # never unwind through C
+        box.err = e
+        return Cint(1)
     end
-    return Int(flag[]), Int(iters[]), 0      # (flag, iter1, iter2) as in the reference
 end
-
-# ---- ProjPenalty, the reference's DEFAULT retraction (src/retractions.jl:265-441) and its pcg! (:179-246) ------
-struct CPPWork
-    r::Ptr{Cvoid}; p::Ptr{Cvoid}; z::Ptr{Cvoid}; dx::Ptr{Cvoid}; g::Ptr{Cvoid}; tmp_m::Ptr{Cvoid}
-    tmp_w::Ptr{Cvoid}; h::Ptr{Cvoid}; DxS::Ptr{Cvoid}; DyS::Ptr{Cvoid}; ones::Ptr{Cvoid}; zeros::Ptr{Cvoid}
-end
-struct DevicePPWork            # ProjPenaltyWork(m, n, m_ineq, n_ineq) without bounds
-    r::DeviceVector; p::DeviceVector; z::DeviceVector; dx::DeviceVector; g::DeviceVector; tmp_m::DeviceVector
-end
-DevicePPWork(ctx::HipContext, n::Int, m::Int) =
-    DevicePPWork((DeviceVector(ctx, n) for _ in 1:5)..., DeviceVector(ctx, max(m, 1)))
-struct DevicePP                # ProjPenalty(jac!, U, Σ, Vt, rank, μ0, tol, maxiter, maxiter_pcg, work, ineq, idecomp, idata)
-    Jct::DeviceMatrix; m_lin::Int; b::Vector{Float64}; has_ball::Bool; R2::Float64; n_x::Int; slack_row::Int
-    μ0::Float64; tol::Float64; maxiter::Int; maxiter_pcg::Int; work::DevicePPWork
-end
-function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceVector, x::DeviceVector, pp::DevicePP)
-    flag = Ref{Cint}(0); iters = Ref{Int64}(0); pcg_iters = Ref{Int64}(0)
-    w = pp.work
-    wc = Ref(CPPWork(w.r.h, w.p.h, w.z.h, w.dx.h, w.g.h, w.tmp_m.h, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
-    GC.@preserve pp begin
-        cons = Ref(CConstraints(pp.Jct.h, pp.m_lin, pointer(pp.b), pp.has_ball ? 1 : 0, pp.R2, pp.n_x, pp.slack_row))
-        check(x.ctx, ccall((:lfpsqp_retract_pp, lib), Cint,
-                           (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid},
-                            Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int64, Int64,
-                            Ref{CPPWork}, Ptr{Float64}, Ref{Cint}, Ref{Int64}, Ref{Int64}),
-                           x.ctx.h, cons, C_NULL, C_NULL, C_NULL, pp.Jct.h, length(cval), C_NULL, C_NULL, C_NULL, C_NULL,
-                           xtilde.h, x.h, xnew.h, pp.μ0, pp.tol, pp.maxiter, pp.maxiter_pcg, wc, cval, flag, iters, pcg_iters))
+function projcg!(x::DeviceVector, λ::Union{Nothing,DeviceVector}, A::Function, U::AnyBasis, b::DeviceVector, c::Union{Nothing,DeviceVector};
+                 tol::Float64=1e-6, maxit::Int=length(b) + ncols(U), work::ProjCGWork=ProjCGWork(x, ncols(U)), n_global::Int=length(b))
+    iters = Ref{Int64}(0); nr = Ref{Float64}(0.0)
+    box = OpBox(A, Dict(x.h => x, work.d.h => work.d, work.Av.h => work.Av), nothing)
+    cb = @cfunction(_op_trampoline, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}))
+    GC.@preserve box U begin
+        rc = c_projcg_op(x.ctx.h, x.h, λ === nothing ? C_NULL : λ.h, cb, pointer_from_objref(box), work.Av.h, Ref(cbasis(U)), b.h,
+                         c === nothing ? C_NULL : c.h, tol, Int64(maxit), Int64(n_global), λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA,
+                         Ref(cwork(work)), iters, nr)
+        box.err === nothing || throw(box.err)
+        check(x.ctx, rc)
     end
-    return Int(flag[]), Int(iters[]), Int(pcg_iters[])      # (flag, iter1, iter2) as in the reference
+    return Int(iters[]), nr[]
 end
-# pcg!(μ, J, no_precondition, x, r, p, z, tmp_m, tol, maxiter) with J' = Jct given as a DeviceBasis
-function pcg!(μ::Float64, Jt::DeviceBasis, x::DeviceVector, r::DeviceVector, p::DeviceVector, z::DeviceVector,
-              tmp_m::DeviceVector, tol::Float64, maxiter::Int)
+
+# Device-resident equality constraints of the BASELINE configs: c(x) = [J x - b; sum_{i<=n_x} x_i^2 - R2 - x[slack]] (lfpsqp_constraints)
+struct DeviceConstraints
+    Jct::DeviceMatrix
+    m_lin::Int
+    b::Vector{Float64}
+    has_ball::Bool
+    R2::Float64
+    n_x::Int
+    slack_row::Int              # 0-based LOCAL row of the slack variable, -1 if another rank owns it
+end
+nconstraints(c::DeviceConstraints) = c.m_lin + (c.has_ball ? 1 : 0)
+ccons(c::DeviceConstraints) = CConstraints(c.Jct.h, c.m_lin, pointer(c.b), c.has_ball ? 1 : 0, c.R2, c.n_x, c.slack_row)
+function (c::DeviceConstraints)(cval::Vector{Float64}, x::DeviceVector)                       # c!(cval, x)
+    GC.@preserve c check(x.ctx, c_constraints_eval(x.ctx.h, Ref(ccons(c)), x.h, cval))
+    return cval
+end
+function jac!(c::DeviceConstraints, Jct::DeviceMatrix, cval::Vector{Float64}, x::DeviceVector)    # jac!(Jct, cval, x)
+    GC.@preserve c check(x.ctx, c_constraints_jac(x.ctx.h, Ref(ccons(c)), x.h, Jct.h, cval))
+    return cval
+end
+
+# A host c!(cval, x::Vector) behind the C callback of lfpsqp_retract_nr / lfpsqp_retract_pp: x is downloaded per evaluation
+mutable struct CfunBox
+    ctx::HipContext
+    c!::Function
+    nrows::Int
+    m::Int
+    err::Any
+end
+function _cfun_trampoline(user::Ptr{Cvoid}, xvec::Ptr{Cvoid}, cval::Ptr{Float64})::Cint
+    box = unsafe_pointer_to_objref(user)::CfunBox
+    try
+        xh = Vector{Float64}(undef, box.nrows)
+        c_vec_download(box.ctx.h, xvec, Int64(0), xh, Int64(box.nrows)) == 0 || error("download of the iterate failed")
+        box.c!(unsafe_wrap(Array, cval, box.m), xh)
+        return Cint(0)
+    catch e
+        box.err = e
+        return Cint(1)
+    end
+end
+
+abstract type RetractionMethod end
+struct Euclidean <: RetractionMethod end                                      # src/retractions.jl:51-52
+struct YRetract <: RetractionMethod                                           # :54-56
+    idata::InequalityData
+end
+mutable struct NR <: RetractionMethod                                         # :10-19
+    U::Union{Nothing,AnyBasis}
+    Σ::Vector{Float64}
+    Vt::Matrix{Float64}
+    tol::Float64
+    maxiter::Int
+    ineq::Bool
+    idata::Union{Nothing,InequalityData}
+end
+struct ProjPenaltyWork                                                        # :21-33 (J itself is the shared device Jct)
+    r::DeviceVector
+    p::DeviceVector
+    z::DeviceVector
+    dx::DeviceVector
+    g::DeviceVector
+    tmp_m::DeviceVector
+    tmp_w::Union{Nothing,DeviceVector}
+    h::Union{Nothing,DeviceVector}
+    DxS::Union{Nothing,DeviceVector}
+    DyS::Union{Nothing,DeviceVector}
+    ones::Union{Nothing,DeviceVector}
+    zeros::Union{Nothing,DeviceVector}
+end
+function ProjPenaltyWork(like::DeviceVector, m::Integer, N::Integer, ineq::Bool)
+    ctx = like.ctx
+    v5 = (similar_device(like) for _ in 1:5)
+    ineq || return ProjPenaltyWork(v5..., DeviceVector(ctx, max(m, 1)), nothing, nothing, nothing, nothing, nothing, nothing)
+    return ProjPenaltyWork(v5..., DeviceVector(ctx, max(m, 1)), DeviceVector(ctx, N), DeviceVector(ctx, N), DeviceVector(ctx, N), DeviceVector(ctx, N),
+                           fill!(DeviceVector(ctx, N), 1.0), DeviceVector(ctx, N))
+end
+_h(v) = v === nothing ? C_NULL : v.h
+cppwork(w::ProjPenaltyWork) = CPPWork(w.r.h, w.p.h, w.z.h, w.dx.h, w.g.h, w.tmp_m.h, _h(w.tmp_w), _h(w.h), _h(w.DxS), _h(w.DyS), _h(w.ones), _h(w.zeros))
+mutable struct ProjPenalty <: RetractionMethod                                # :35-49
+    jac!::Any                  # DeviceConstraints (device-resident jac!) or a host jac!(J, cval, x)
+    m::Int
+    rank::Int
+    μ0::Float64
+    tol::Float64
+    maxiter::Int
+    maxiter_pcg::Int
+    work::ProjPenaltyWork
+    ineq::Bool
+    idecomp::InequalityDecomp
+    idata::Union{Nothing,InequalityData}
+end
+
+# retract!(cval, xnew, c!, xtilde, x, method) -> (flag, iter1, iter2)
+function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceVector, x::DeviceVector, ::Euclidean)      # :61-65
+    copyto!(xnew, xtilde)
+    return 0, 0, 0
+end
+function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceVector, x::DeviceVector, method::YRetract)   # :67-72
+    copyto!(xnew, xtilde)
+    y_retract!(xnew, x, method.idata)
+    return 0, 0, 0
+end
+function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceVector, x::DeviceVector, method::NR)         # :75-177
     flag = Ref{Cint}(0); iters = Ref{Int64}(0)
-    u = Ref(CBasis(Jt.Z.h, Jt.ncols, C_NULL, C_NULL, C_NULL, C_NULL))
-    check(x.ctx, ccall((:lfpsqp_pcg, lib), Cint,
-                       (Ptr{Cvoid}, Float64, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-                        Float64, Int64, Ref{Cint}, Ref{Int64}),
-                       x.ctx.h, μ, u, x.h, r.h, p.h, z.h, C_NULL, tmp_m.h, tol, maxiter, flag, iters))
-    return Int(flag[]), Int(iters[])
+    m = length(method.Σ)
+    idref = method.ineq ? Ref(cineq(method.idata)) : nothing
+    idp = method.ineq ? Base.unsafe_convert(Ptr{CIneqData}, idref) : Ptr{CIneqData}(C_NULL)
+    if c! isa DeviceConstraints
+        consref = Ref(ccons(c!))
+        GC.@preserve method c! consref idref begin
+            check(x.ctx, c_retract_nr(x.ctx.h, Ref(cbasis(method.U)), method.Σ, method.Vt, Int64(m), Base.unsafe_convert(Ptr{CConstraints}, consref),
+                                      C_NULL, C_NULL, idp, xtilde.h, x.h, xnew.h, method.tol, Int64(method.maxiter), cval, flag, iters))
+        end
+    else
+        box = CfunBox(x.ctx, c!, method.ineq ? method.idata.n : x.n, m, nothing)
+        cb = @cfunction(_cfun_trampoline, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}))
+        GC.@preserve method box idref begin
+            rc = c_retract_nr(x.ctx.h, Ref(cbasis(method.U)), method.Σ, method.Vt, Int64(m), Ptr{CConstraints}(C_NULL), cb, pointer_from_objref(box), idp,
+                              xtilde.h, x.h, xnew.h, method.tol, Int64(method.maxiter), cval, flag, iters)
+            box.err === nothing || throw(box.err)
+            check(x.ctx, rc)
+        end
+    end
+    return Int(flag[]), Int(iters[]), 0
 end
-
-# ---- multi-GPU: one Julia process per GPU (e.g. under MPI.jl); rank 0 creates the id and broadcasts it --
-function comm_unique_id(ctx::HipContext)
-    id = Vector{UInt8}(undef, 128)
-    check(ctx, ccall((:lfpsqp_comm_unique_id, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}), ctx.h, id))
-    return id
-end
-comm_init!(ctx::HipContext, rank::Integer, nranks::Integer, id::Vector{UInt8}) =
-    check(ctx, ccall((:lfpsqp_comm_init_rccl, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx.h, rank, nranks, id))
-
-export HipContext, DeviceVector, DeviceMatrix, DeviceBasis, DiagOperator, ProjCGWork, DeviceNR, DevicePP, DevicePPWork,
-       upload!, download, projcg!, retract!, pcg!, ksvd!, comm_unique_id, comm_init!
-
-end # module
-
-# ---- optional: several trial points of one Armijo search retracted together --------------------------------------------
-# armijo! (src/linesearch.jl:32-89) tries x + α d, x + α s d, ... one after another; when retractions fail (100 Newton
-# iterations each) the trial points are independent and can share every pass over Jct.  A maintainer who wants this
-# adds a lookahead to armijo! (see lfpsqp.jl_amd/linesearch.py::armijo_ for the bookkeeping that keeps the accepted step
-# and all counts those of the one-by-one search) on top of this call.
-function retract_batch!(cvals::Matrix{Float64}, xnews::Vector{DeviceVector}, xtildes::Vector{DeviceVector}, x::DeviceVector, method::DeviceNR)
+# several trial points of one Armijo search retracted together (lfpsqp_retract_nr_batch); `nothing` when this configuration cannot
+function retract_nr_batch!(cvals::Matrix{Float64}, xnews::Vector{DeviceVector}, c!::DeviceConstraints, xtildes::Vector{DeviceVector}, x::DeviceVector, method::NR)
     nb = length(xnews)
     flags = zeros(Cint, nb); iters = zeros(Int64, nb)
     xt = [v.h for v in xtildes]; xn = [v.h for v in xnews]
-    GC.@preserve method xt xn begin
-        u = Ref(CBasis(method.U.Z.h, method.U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, method.Jct.h, pointer(method.W)))
-        cons = Ref(CConstraints(method.Jct.h, method.m_lin, pointer(method.b), method.has_ball ? 1 : 0, method.R2, method.n_x, method.slack_row))
-        check(x.ctx, ccall((:lfpsqp_retract_nr_batch, lib), Cint,
-                           (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{CConstraints}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}},
-                            Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Float64, Int64, Ptr{Float64}, Ptr{Cint}, Ptr{Int64}),
-                           x.ctx.h, u, method.Σ, method.Vt, length(method.Σ), cons, C_NULL, nb, xt, x.h, xn, method.tol, method.maxiter,
-                           cvals, flags, iters))       # cvals is m × nb (column b = cval of trial b)
+    idref = method.ineq ? Ref(cineq(method.idata)) : nothing
+    idp = method.ineq ? Base.unsafe_convert(Ptr{CIneqData}, idref) : Ptr{CIneqData}(C_NULL)
+    rc = Cint(0)
+    GC.@preserve method c! xt xn idref begin
+        rc = c_retract_nr_batch(x.ctx.h, Ref(cbasis(method.U)), method.Σ, method.Vt, Int64(length(method.Σ)), Ref(ccons(c!)), idp, Cint(nb), xt, x.h, xn,
+                                method.tol, Int64(method.maxiter), cvals, flags, iters)            # cvals is m x nb (column b = cval of trial b)
     end
+    rc == LFPSQP_ERR_UNSUPPORTED && return nothing
+    check(x.ctx, rc)
     return [(Int(flags[b]), Int(iters[b]), 0) for b in 1:nb]
 end
+# the reference's DEFAULT retraction (:265-441), ONE C call; c! / jac! device-resident or host callables
+mutable struct JacBox
+    ctx::HipContext
+    c!::Any
+    jac!::Any
+    Jct::DeviceMatrix
+    nrows::Int
+    m::Int
+    err::Any
+end
+function _pp_c_trampoline(user::Ptr{Cvoid}, xvec::Ptr{Cvoid}, cval::Ptr{Float64})::Cint
+    box = unsafe_pointer_to_objref(user)::JacBox
+    try
+        xh = Vector{Float64}(undef, box.nrows)
+        c_vec_download(box.ctx.h, xvec, Int64(0), xh, Int64(box.nrows)) == 0 || error("download of the iterate failed")
+        box.c!(unsafe_wrap(Array, cval, box.m), xh)
+        return Cint(0)
+    catch e
+        box.err = e
+        return Cint(1)
+    end
+end
+function _pp_jac_trampoline(user::Ptr{Cvoid}, xvec::Ptr{Cvoid}, Jct::Ptr{Cvoid}, cval::Ptr{Float64})::Cint
+    box = unsafe_pointer_to_objref(user)::JacBox
+    try
+        xh = Vector{Float64}(undef, box.nrows)
+        c_vec_download(box.ctx.h, xvec, Int64(0), xh, Int64(box.nrows)) == 0 || error("download of the iterate failed")
+        J = zeros(box.m, box.nrows)
+        box.jac!(J, unsafe_wrap(Array, cval, box.m), xh)
+        upload!(box.Jct, Matrix(J'))                   # the device keeps only Jct = J'
+        return Cint(0)
+    catch e
+        box.err = e
+        return Cint(1)
+    end
+end
+function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceVector, x::DeviceVector, pp::ProjPenalty)
+    flag = Ref{Cint}(0); iters = Ref{Int64}(0); pcg_iters = Ref{Int64}(0)
+    d = pp.idecomp
+    idref = pp.ineq ? Ref(cineq(pp.idata)) : nothing
+    idp = pp.ineq ? Base.unsafe_convert(Ptr{CIneqData}, idref) : Ptr{CIneqData}(C_NULL)
+    Dx, Dy, S = pp.ineq ? (d.Dx.h, d.Dy.h, d.S.h) : (C_NULL, C_NULL, C_NULL)
+    if c! isa DeviceConstraints
+        consref = Ref(ccons(c!))
+        GC.@preserve pp c! consref idref begin
+            check(x.ctx, c_retract_pp(x.ctx.h, Base.unsafe_convert(Ptr{CConstraints}, consref), C_NULL, C_NULL, C_NULL, d.Jct.h, Int64(pp.m), idp, Dx, Dy, S,
+                                      xtilde.h, x.h, xnew.h, pp.μ0, pp.tol, Int64(pp.maxiter), Int64(pp.maxiter_pcg), Ref(cppwork(pp.work)), cval,
+                                      flag, iters, pcg_iters))
+        end
+    else
+        box = JacBox(x.ctx, c!, pp.jac!, d.Jct, d.N, pp.m, nothing)
+        cbc = @cfunction(_pp_c_trampoline, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}))
+        cbj = @cfunction(_pp_jac_trampoline, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}))
+        GC.@preserve pp box idref begin
+            rc = c_retract_pp(x.ctx.h, Ptr{CConstraints}(C_NULL), cbc, cbj, pointer_from_objref(box), d.Jct.h, Int64(pp.m), idp, Dx, Dy, S,
+                              xtilde.h, x.h, xnew.h, pp.μ0, pp.tol, Int64(pp.maxiter), Int64(pp.maxiter_pcg), Ref(cppwork(pp.work)), cval,
+                              flag, iters, pcg_iters)
+            box.err === nothing || throw(box.err)
+            check(x.ctx, rc)
+        end
+    end
+    return Int(flag[]), Int(iters[]), Int(pcg_iters[])
+end
+# pcg!(μ, J, no_precondition, x, r, p, z, tmp_m, tol, maxiter) (:179-246) with J' given in the lfpsqp_basis form
+function pcg!(μ::Float64, Jt::CBasis, x::DeviceVector, r::DeviceVector, p::DeviceVector, z::DeviceVector, tmp_w::Union{Nothing,DeviceVector},
+              tmp_m::DeviceVector, tol::Float64, maxiter::Int)
+    flag = Ref{Cint}(0); iters = Ref{Int64}(0)
+    check(x.ctx, c_pcg(x.ctx.h, μ, Ref(Jt), x.h, r.h, p.h, z.h, _h(tmp_w), tmp_m.h, tol, Int64(maxiter), flag, iters))
+    return Int(flag[]), Int(iters[])
+end
+
+# =====================================================================================================================
+# 5. Parameters and linesearch (src/LFPSQP.jl:27-81, src/linesearch.jl) -- host control flow, device vectors
+# =====================================================================================================================
+@enum DisplayOption off iter
+@enum LinesearchOption armijo exact
+@enum TerminationCondition f_tol x_tol kkt_tol max_iter armijo_error
+struct TerminationInfo
+    condition::TerminationCondition
+    f_diff::Float64
+    step_diff::Float64
+    kkt_diff::Float64
+    iter::Int
+end
+Base.@kwdef mutable struct LFPSQPParams
+    α::Float64 = 1.0
+    β::Float64 = 0.0
+    t_β::Int = 0
+    s::Float64 = 0.5
+    σ::Float64 = 1e-4
+    ϵ_c::Float64 = 1e-6
+    ϵ_f::Float64 = 1e-6
+    ϵ_x::Float64 = 0.0
+    ϵ_kkt::Float64 = 1e-6
+    ϵ_rank::Float64 = 1e-10
+    maxiter::Int = 10000
+    maxiter_retract::Int = 100
+    maxiter_pcg::Int = 100
+    μ0::Float64 = 1e-2
+    disable_linesearch::Bool = false
+    do_project_retract::Bool = true
+    disp::DisplayOption = iter
+    callback::Union{Nothing,Function} = nothing
+    callback_period::Int = 100
+    linesearch::LinesearchOption = armijo
+    do_newton::Bool = true
+    tn_maxiter::Int = 10000
+    tn_κ::Float64 = 0.5
+    ls_batch::Int = 4           # not in the reference: trial retractions of a failing Armijo search share their passes (1 = off)
+end
+
+mutable struct ArmijoWork       # src/linesearch.jl:1-5
+    xtilde::DeviceVector
+    xts::Vector{DeviceVector}
+    xns::Vector{DeviceVector}
+    prev_failed::Bool
+end
+ArmijoWork(like::DeviceVector) = ArmijoWork(similar_device(like), DeviceVector[], DeviceVector[], false)
+struct ExactLinesearchWork      # :7-14
+    tmp_n1::DeviceVector
+    tmp_n2::DeviceVector
+    tmp_n3::DeviceVector
+    tmp_n4::DeviceVector
+end
+ExactLinesearchWork(like::DeviceVector) = ExactLinesearchWork((similar_device(like) for _ in 1:4)...)
+
+# armijo!(xnew, x, n, d, g, f, fval, retract_method, cval, c!, param, work) (src/linesearch.jl:32-89).  After the first failed
+# retraction of a search (or from its first trial when the previous search had failures) the next `ls_batch` trial steps of the
+# reference's own sequence α s, α s², ... are retracted together and consumed in the reference's order: same accepted step,
+# same counts.
+function armijo!(xnew::DeviceVector, x::DeviceVector, n::Int, d::DeviceVector, g::DeviceVector, f, fval::Float64, retract_method, cval::Vector{Float64}, c!,
+                 param::LFPSQPParams, work::ArmijoWork)
+    f_diff = Inf; step_diff = Inf
+    α = param.α
+    flag = 0; tot_iter1 = 0; tot_iter2 = 0; newf = 0.0
+    ar_dot = dot(d, g)
+    xtilde = work.xtilde
+    step = xtilde
+    ahead = Dict{Float64,Tuple{Int,Int,Int,DeviceVector,Vector{Float64}}}()
+    nbatch = (retract_method isa NR && c! isa DeviceConstraints) ? param.ls_batch : 1
+    failed_once = work.prev_failed
+    any_failed = false
+    while step_diff > param.ϵ_x
+        iter1 = 0; iter2 = 0
+        if haskey(ahead, α)
+            flag, iter1, iter2, xb, cb = pop!(ahead, α)
+            copyto!(xnew, xb); cval .= cb
+        else
+            got = nothing
+            if failed_once && nbatch > 1 && !param.disable_linesearch
+                while length(work.xts) < nbatch
+                    push!(work.xts, similar_device(x)); push!(work.xns, similar_device(x))
+                end
+                αs = [α * param.s^(k - 1) for k in 1:nbatch]
+                for k in 2:nbatch                       # the reference's own products α*s, (α*s)*s, ...
+                    αs[k] = αs[k-1] * param.s
+                end
+                for k in 1:nbatch
+                    waxpby!(work.xts[k], 1.0, x, αs[k], d)
+                end
+                cvs = zeros(length(cval), nbatch)
+                got = retract_nr_batch!(cvs, work.xns[1:nbatch], c!, work.xts[1:nbatch], x, retract_method)
+                if got !== nothing
+                    for k in 2:nbatch
+                        ahead[αs[k]] = (got[k][1], got[k][2], got[k][3], work.xns[k], cvs[:, k])
+                    end
+                    flag, iter1, iter2 = got[1]
+                    copyto!(xnew, work.xns[1]); cval .= cvs[:, 1]
+                else
+                    nbatch = 1
+                end
+            end
+            if got === nothing
+                waxpby!(xtilde, 1.0, x, α, d)                                       # xtilde = x + α d
+                flag, iter1, iter2 = retract!(cval, xnew, c!, xtilde, x, retract_method)
+            end
+        end
+        tot_iter1 += iter1; tot_iter2 += iter2
+        if flag > 0                                                               # :57-60
+            failed_once = true; any_failed = true
+            α *= param.s
+            continue
+        end
+        waxpby!(step, 1.0, xnew, -1.0, x)                                           # step = xnew - x
+        newf = f(xnew)
+        step_diff = norm_head(step, n)                                              # :66
+        f_diff = abs(newf - fval)
+        param.disable_linesearch && break
+        (newf - fval) <= param.σ * α * ar_dot && break                              # :75
+        α *= param.s
+        if α < 1e-100                                                             # :82
+            flag = 99
+            break
+        end
+    end
+    work.prev_failed = any_failed
+    return flag, tot_iter1, tot_iter2, newf, f_diff, step_diff, α
+end
+
+# exact_linesearch!(xnew, x, n, d, f, fval, retract_method, cval, c!, param, work) (src/linesearch.jl:107-339): bracketing,
+# shrinking and golden-section phases with the reference's rotation of its four work vectors
+function exact_linesearch!(xnew::DeviceVector, x::DeviceVector, n::Int, d::DeviceVector, f, fval::Float64, retract_method, cval::Vector{Float64}, c!,
+                           param::LFPSQPParams, work::ExactLinesearchWork)
+    φ1 = (3 - sqrt(5)) / 2; φ2 = (sqrt(5) - 1) / 2; φ3 = (sqrt(5) + 1) / 2
+    Δ = param.α
+    flag = 0; tot1 = 0; tot2 = 0
+    f_a = 0.0; f_b = 0.0; f_c = 0.0; f_d = 0.0
+    a_a = 0.0; a_b = 0.0; a_c = 0.0; a_d = 0.0
+    x_a, x_b, x_c, x_d = work.tmp_n1, work.tmp_n2, work.tmp_n3, work.tmp_n4
+    step = work.tmp_n1
+    do_shrinking = true
+    retract_pt! = function (pt::DeviceVector)
+        fl, i1, i2 = retract!(cval, xnew, c!, pt, x, retract_method)
+        tot1 += i1; tot2 += i2
+        copyto!(pt, xnew)
+        return fl
+    end
+    copyto!(x_d, x); f_d = fval
+    while true
+        x_b, x_c, x_d = x_c, x_d, x_b
+        f_b, f_c = f_c, f_d
+        a_b, a_c = a_c, a_d
+        waxpby!(x_d, 1.0, x, a_d + Δ, d)
+        flag = retract_pt!(x_d)
+        a_d += Δ
+        if flag > 0 || a_d > 1.0
+            f_d = Inf
+            break
+        end
+        f_d = f(x_d)
+        f_d > f_c && break
+        do_shrinking = false
+        Δ *= φ3
+    end
+    if do_shrinking
+        f_b = fval; a_b = 0.0
+        copyto!(x_b, x)
+        f_c = Inf; a_c = Δ
+        x_d, x_c = x_c, x_d
+        while true
+            x_d, x_c = x_c, x_d
+            f_d = f_c; a_d = a_c
+            waxpby!(x_c, 1.0, x, φ1 * a_c, d)
+            flag = retract_pt!(x_c)
+            a_c *= φ1
+            f_c = (flag > 0 || a_c > 1.0) ? Inf : f(x_c)
+            (f_c <= fval || a_c < 1e-100) && break
+        end
+    end
+    f_a, f_b = f_b, f_c
+    a_a, a_b = a_b, a_c
+    x_a, x_b, x_c = x_b, x_c, x_a
+    a_c = a_a + φ2 * (a_d - a_a)
+    waxpby!(x_c, 1.0, x, a_c, d)
+    flag = retract_pt!(x_c)
+    f_c = (flag > 0 || a_c > 1.0) ? Inf : f(x_c)
+    nd = norm(d)
+    while (a_c - a_b) > 1e-6 * nd
+        if f_b < f_c || isinf(f_c)
+            x_d, x_c, x_b = x_c, x_b, x_d
+            f_d, f_c = f_c, f_b
+            a_d, a_c = a_c, a_b
+            a_b = a_a + φ1 * (a_d - a_a)
+            waxpby!(x_b, 1.0, x, a_b, d)
+            flag = retract_pt!(x_b)
+            f_b = f(x_b)
+        else
+            x_a, x_b, x_c = x_b, x_c, x_a
+            f_a, f_b = f_b, f_c
+            a_a, a_b = a_b, a_c
+            a_c = a_a + φ2 * (a_d - a_a)
+            waxpby!(x_c, 1.0, x, a_c, d)
+            flag = retract_pt!(x_c)
+            f_c = (flag > 0 || a_c > 1.0) ? Inf : f(x_c)
+        end
+    end
+    newf = 0.0; α = 0.0
+    if f_b < f_c
+        copyto!(xnew, x_b); newf = f_b; α = a_b
+    else
+        copyto!(xnew, x_c); newf = f_c; α = a_c
+    end
+    waxpby!(step, 1.0, xnew, -1.0, x)
+    step_diff = norm_head(step, n)
+    f_diff = abs(newf - fval)
+    return flag, tot1, tot2, newf, f_diff, step_diff, α
+end
+
+# =====================================================================================================================
+# 6. optimize (src/optimize.jl:13-443) on device-resident state
+# =====================================================================================================================
+# Callback contract of the core method (the device analogue of the reference's explicit-derivative method, :119):
+#   f(x)                       -> Float64; x is the device iterate (stacked [x; y] with bounds; f looks at the first n entries)
+#   grad!(g, x)                writes the first n entries of the device vector g
+#   c!                         a DeviceConstraints, or a host c!(cval, x::Vector)
+#   jac!(Jct, cval, x)         refreshes the device n x m matrix Jct (= Jc' of the reference) and cval
+#   hess_lag_vec!              an object with hess_diag!(hx, x, λ) (diagonal Lagrangian Hessian: fused projcg path), or a
+#                              function hess_lag_vec!(dest, src, x, λ_dev) on device vectors (general path, lfpsqp_projcg_op)
+function print_iter_header()
+    println("   step |          f     ||c||      |Δf|    ||Δx||  |   S iter      res  |   M   iter  (pcg)  |        α  flag")
+    println("-"^110)
+end
+print_first_line(fval, normc) = @printf("      0 | %10.3e  %8.1e                      |                    |                    |               \n", fval, normc)
+print_iter(i, fval, normc, fstep, normx, steptype, tn_iter, tn_res, mtype, iter1, iter2, α, flag) =
+    @printf("%7d | %10.3e  %8.1e  %8.1e  %8.1e  |  %s %4d %8.1e  |  %s %6d %6d  | %8.1e  %4d\n", i, fval, normc, fstep, normx,
+            steptype == 0 ? "GD" : "TN", tn_iter, tn_res, mtype == 0 ? "NR" : "PP", iter1, iter2, α, flag)
+
+function hess_diag! end         # hess_diag!(problem, hx, x, λ): the diagonal of the Lagrangian Hessian, written into the device vector hx
+has_hess_diag(h) = hasmethod(hess_diag!, Tuple{typeof(h),DeviceVector,DeviceVector,Vector{Float64}})
+
+function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::Vector{Float64}, xl, xu, m::Int, param::LFPSQPParams=LFPSQPParams();
+                       n_global::Int=length(x0))
+    n = length(x0)
+    if xl !== nothing && xu !== nothing
+        length(xl) == length(xu) == n || error("xl, xu, and x0 must all be the same length")
+    end
+    ineq = !((xl === nothing && xu === nothing) || (all(xl .== -Inf) && all(xu .== Inf)))       # :146-170
+    idata = nothing
+    if ineq
+        any(xl .> xu) && error("Infeasible: lower bounds cannot be greater than upper bounds")
+        idata = InequalityData(ctx, Vector{Float64}(xl), Vector{Float64}(xu))
+    end
+    newvec() = ineq ? StackedVector(ctx, n) : DeviceVector(ctx, n)
+    x = newvec()
+    upload!(x, x0, 0)
+    ineq && generate_initial_y!(x, idata)                                                  # :179-182
+    obj_values = Float64[]
+    xnew, g, d, newton_d = newvec(), newvec(), newvec(), newvec()
+    Jct = c! isa DeviceConstraints ? c!.Jct : DeviceMatrix(ctx, n, m)      # device-resident classes own their (mostly constant) Jct
+    tmp_m = DeviceVector(ctx, max(m, 1))
+    tmp_w = ineq ? DeviceVector(ctx, n) : nothing
+    lamy_kkt = ineq ? DeviceVector(ctx, n) : nothing
+    hx = ineq ? DeviceVector(ctx, n) : nothing
+    cval = zeros(m)
+    λ_kkt = zeros(m)
+    λ_dev = DeviceVector(ctx, max(m, 1))
+    term_cond = f_tol
+    projcgwork = ProjCGWork(x, m)
+    prev_grad_norm = 0.0
+    idecomp = InequalityDecomp(ctx, n, m, Jct)
+    idecomp.W = m > 0 ? zeros(m, m) : nothing                 # ksvd!'s small factor: Z == Jct*W
+    Z, Σ, Vt = idecomp.Z, idecomp.Σ, idecomp.Vt
+    ineqproject = ineq ? InequalityDecompProject(idecomp) : nothing
+    diagonal_hessian = has_hess_diag(hess_lag_vec!)
+    a_diag = diagonal_hessian ? newvec() : nothing
+    # general Hessian with bounds: augmented_hess_lag_vec! (src/inequality_helper.jl:144-158) on the stacked vectors
+    aug_src = (!diagonal_hessian && ineq) ? DeviceVector(ctx, n) : nothing
+    aug_x = (!diagonal_hessian && ineq) ? DeviceVector(ctx, n) : nothing
+    aug_h = (!diagonal_hessian && ineq) ? DeviceVector(ctx, n) : nothing
+    aug_d = (!diagonal_hessian && ineq) ? StackedVector(ctx, n) : nothing
+    zero_hx = (!diagonal_hessian && ineq) ? DeviceVector(ctx, n) : nothing
+    function newton_apply!(dest::DeviceVector, src::DeviceVector)
+        if !ineq
+            hess_lag_vec!(dest, src, x, λ_dev)
+        else
+            check(ctx, c_augmented_diag(ctx.h, zero_hx.h, lamy_kkt.h, Ref(cineq(idata)), aug_d.h))   # [2 λy q ; 2 λy s]
+            copy_range!(aug_src, 0, src, 0, n); copy_range!(aug_x, 0, x, 0, n)
+            hess_lag_vec!(aug_h, aug_src, aug_x, λ_dev)                                                  # H src_x
+            vmul!(dest, aug_d, src)
+            check(ctx, c_vec_fill_range(ctx.h, aug_d.h, Int64(aug_d.hs), Int64(n), 0.0))             # reuse aug_d as [H src_x ; 0]
+            copy_range!(aug_d, 0, aug_h, 0, n)
+            axpby!(1.0, aug_d, 1.0, dest)
+        end
+        return dest
+    end
+    nr = NR(nothing, Σ, Vt, param.ϵ_c, param.maxiter_retract, ineq, idata)
+    pp = ProjPenalty(c! isa DeviceConstraints ? c! : jac!, m, m, param.μ0, param.ϵ_c, param.maxiter_retract, param.maxiter_pcg,
+                     ProjPenaltyWork(x, m, n, ineq), ineq, idecomp, idata)
+    armijo_work = ArmijoWork(x)
+    exact_work = (param.linesearch == exact && !param.disable_linesearch) ? ExactLinesearchWork(x) : nothing
+    i = 0
+    f_diff = Inf; step_diff = Inf; kkt_diff = Inf
+    fval = f(x)
+    push!(obj_values, fval)
+    if m > 0
+        c! isa DeviceConstraints ? c!(cval, x) : c!(cval, download(x, n, 0))
+    end
+    disp = param.disp == iter && ctx.rank == 0
+    if disp
+        print_iter_header()
+        print_first_line(fval, m > 0 ? maximum(abs, cval) : 0.0)
+    end
+    noise = nothing
+    while true
+        grad!(g, x)                                                                     # :259
+        waxpby!(d, -1.0, g, 0.0, g)                                                     # :262
+        if param.β > 0                                                                  # :264-273 (noise in the descent direction)
+            noise === nothing && (noise = newvec())
+            z = randn(ineq ? 2n : n)
+            ineq ? upload2!(noise, z) : upload!(noise, z)
+            axpby!(param.t_β > 0 ? param.β * max(1 - i / param.t_β, 0.0) : param.β, noise, 1.0, d)
+        end
+        ineq && inequality_gradient!(idecomp, x, idata)                                 # :277
+        rank = m
+        if m > 0
+            jac!(Jct, cval, x)                                                          # :283-284 (the device keeps only Jct)
+            rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W)     # :286-302
+            if !ineq                                                                    # :305-308
+                mul!(tmp_m, adjoint(DeviceBasis(Z, rank)), d)
+                mul!(d, DeviceBasis(Z, rank), tmp_m, -1.0, 1.0)
+            end
+        end
+        idecomp.rank = rank
+        if ineq                                                                         # :312-318
+            q_gemv_t!(tmp_w, tmp_m, ineqproject, d)
+            q_gemv_n!(d, ineqproject, tmp_w, tmp_m, -1.0, 1.0)
+        end
+        kkt_diff = norm(d, Inf)                                                         # :320
+        pp.rank = rank
+        steptype = 0; tn_iter = 0; tn_res = 0.0
+        if m > 0                                                                        # :331-343
+            th = download(tmp_m, m)
+            th[1:rank] ./= Σ[1:rank]
+            th[rank+1:m] .= 0.0
+            λ_kkt .= Vt' * th
+            upload!(λ_dev, λ_kkt)
+        end
+        if ineq                                                                         # calculate_λ_kkt!, inequality_helper.jl:286-308
+            check(ctx, c_calculate_lambda_y(ctx.h, Jct.h, Int64(m), λ_dev.h, idecomp.Dx.h, idecomp.S.h, tmp_w.h, lamy_kkt.h))
+        end
+        if f_diff <= param.ϵ_f                                                          # :347-359
+            term_cond = f_tol; break
+        elseif step_diff <= param.ϵ_x
+            term_cond = x_tol; break
+        elseif i >= param.maxiter
+            term_cond = max_iter; break
+        elseif kkt_diff <= param.ϵ_kkt
+            term_cond = kkt_tol; break
+        end
+        if param.do_newton                                                              # :364-390
+            Qview = ineq ? ineqproject : DeviceBasis(Z, rank)
+            grad_norm = norm(d)
+            tol = param.tn_κ * min(1, grad_norm / prev_grad_norm) * grad_norm           # :375-378 (prev = 0: ratio Inf => factor 1)
+            prev_grad_norm = grad_norm
+            nglob = ineq ? 2 * n_global : n_global
+            if diagonal_hessian
+                if ineq
+                    hess_diag!(hess_lag_vec!, hx, x, λ_kkt)
+                    check(ctx, c_augmented_diag(ctx.h, hx.h, lamy_kkt.h, Ref(cineq(idata)), a_diag.h))
+                else
+                    hess_diag!(hess_lag_vec!, a_diag, x, λ_kkt)
+                end
+                tn_iter, tn_res = projcg!(newton_d, nothing, DiagOperator(0.0, a_diag), Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
+                                          work=projcgwork, n_global=nglob)
+            else
+                tn_iter, tn_res = projcg!(newton_d, nothing, newton_apply!, Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
+                                          work=projcgwork, n_global=nglob)
+            end
+            if dot(newton_d, d) > 0.0                                                   # :386
+                copyto!(d, newton_d)
+                steptype = 1
+            end
+        end
+        retract_method = ineq ? YRetract(idata) : Euclidean()                           # :396-412
+        mtype = 0
+        if m > 0
+            if rank == m && !param.do_project_retract
+                nr.U = ineq ? ineqproject : DeviceBasis(Z, rank, (Jct, idecomp.W))
+                retract_method, mtype = nr, 0
+            else
+                retract_method, mtype = pp, 1
+            end
+        end
+        if param.linesearch == armijo || param.disable_linesearch
+            flag, iter1, iter2, newf, f_diff, step_diff, α = armijo!(xnew, x, n, d, g, f, fval, retract_method, cval, c!, param, armijo_work)
+        else
+            flag, iter1, iter2, newf, f_diff, step_diff, α = exact_linesearch!(xnew, x, n, d, f, fval, retract_method, cval, c!, param, exact_work)
+        end
+        copyto!(x, xnew)                                                                # :424-427
+        fval = newf
+        push!(obj_values, fval)
+        disp && print_iter(i + 1, fval, m > 0 ? maximum(abs, cval) : 0.0, f_diff, step_diff, steptype, tn_iter, tn_res, mtype, iter1, iter2, α, flag)
+        i += 1
+        (param.callback !== nothing && i % param.callback_period == 0) && param.callback(i, x)
+    end
+    (i == param.maxiter && disp) && println("Warning: Maximum # of outer iterations reached")
+    return download(x, n, 0), obj_values, λ_kkt, TerminationInfo(term_cond, f_diff, step_diff, kkt_diff, i)
+end
+
+# ---- device-resident problem class of BASELINE configs 2-5 --------------------------------------------------------------------
+# f = ||x - xc||², dense linear equalities J x = b, optional ball x'x <= R2 (an equality with a slack variable exactly as
+# src/optimize.jl:23-51 does it) and optional box bounds; f, grad!, c!, jac! and the (diagonal) Lagrangian Hessian run on the device.
+struct QuadLinearBallBox
+    ctx::HipContext
+    n::Int
+    m::Int
+    p::Int
+    ploc::Int                   # 1 on the rank that owns the slack variable
+    Jct::DeviceMatrix           # (n + ploc) x (m + p); the slack row and the ball column are managed here
+    cons::DeviceConstraints
+    R2::Float64
+    xl::Union{Nothing,Vector{Float64}}
+    xu::Union{Nothing,Vector{Float64}}
+    xc::Float64
+    n_global::Int
+end
+function QuadLinearBallBox(ctx::HipContext, n::Int, m::Int, Jct::DeviceMatrix, b::Vector{Float64}; R2=nothing, xl=nothing, xu=nothing, xc::Real=0.0,
+                           n_global::Int=n, owns_slack::Bool=true)
+    p = R2 === nothing ? 0 : 1
+    ploc = owns_slack ? p : 0
+    (Jct.n == n + ploc && Jct.m == m + p) || error("Jct must be (n + ploc) x (m + p)")
+    cons = DeviceConstraints(Jct, m, m > 0 ? copy(b) : zeros(1), p == 1, R2 === nothing ? 0.0 : Float64(R2), n, ploc == 1 ? n : -1)
+    return QuadLinearBallBox(ctx, n, m, p, ploc, Jct, cons, R2 === nothing ? 0.0 : Float64(R2), xl, xu, Float64(xc), n_global)
+end
+function objective(P::QuadLinearBallBox, x::DeviceVector)
+    out = Ref{Float64}(0.0)
+    check(P.ctx, c_sumsq_shift(P.ctx.h, x.h, Int64(P.n), P.xc, out))
+    return out[]
+end
+gradient!(P::QuadLinearBallBox, g::DeviceVector, x::DeviceVector) = (check(P.ctx, c_affine_head(P.ctx.h, 2.0, x.h, -2.0 * P.xc, Int64(P.n), g.h)); g)
+# diag of ∇²f + Σ λ_i ∇²c_i: 2 (+ 2 λ_ball) on the user's variables, 0 on the slack
+function hess_diag!(P::QuadLinearBallBox, hx::DeviceVector, x::DeviceVector, λ::Vector{Float64})
+    fill_range!(hx, 0, P.n, 2.0 + (P.p == 1 ? 2.0 * λ[P.m+1] : 0.0))
+    P.ploc == 1 && fill_range!(hx, P.n, 1, 0.0)
+    return hx
+end
+function optimize(P::QuadLinearBallBox, x0::Vector{Float64}, param::LFPSQPParams=LFPSQPParams())
+    x0a, xl, xu = x0, P.xl, P.xu
+    if P.p == 1                                                                   # the slack transformation of src/optimize.jl:23-36
+        tmp = upload!(DeviceVector(P.ctx, P.n), x0)
+        out = Ref{Float64}(0.0)
+        check(P.ctx, c_sumsq_shift(P.ctx.h, tmp.h, Int64(P.n), 0.0, out))          # global x0'x0 (all-reduced over the shards)
+        xl = P.xl === nothing ? fill(-Inf, P.n) : P.xl
+        xu = P.xu === nothing ? fill(Inf, P.n) : P.xu
+        if P.ploc == 1
+            x0a = vcat(x0, out[] - P.R2); xl = vcat(xl, -Inf); xu = vcat(xu, 0.0)
+        end
+    end
+    x, obj, λ, info = optimize_core(P.ctx, x -> objective(P, x), (g, x) -> gradient!(P, g, x), P.cons, (J, cv, x) -> jac!(P.cons, J, cv, x), P,
+                                    x0a, xl, xu, P.m + P.p, param; n_global=P.n_global + P.p)
+    return x[1:P.n], obj, λ, info
+end
+
+# ---- the reference's method table with arbitrary HOST callables (src/optimize.jl:13, 83, 88, 107, 112, 119) --------------------
+# Iterates are downloaded for every user call: plumbing / small problems (config 1), not the 1e7-variable configs.
+# The AD generators (src/autodiff_generators.jl) stay where they are: pass their outputs (grad!, jac!, hess_lag_vec!) here.
+function optimize(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::Vector{Float64}, xl, xu, m::Int, param::LFPSQPParams=LFPSQPParams())
+    n = length(x0)
+    f_dev(x) = Float64(f(download(x, n, 0)))
+    function grad_dev!(g, x)
+        gh = zeros(n)
+        grad!(gh, download(x, n, 0))
+        upload!(g, gh, 0)
+    end
+    function jac_dev!(Jct, cval, x)
+        J = zeros(m, n)
+        jac!(J, cval, download(x, n, 0))
+        upload!(Jct, Matrix(J'))
+    end
+    function hlv_dev!(dest, src, x, λ_dev)
+        out = zeros(n)
+        hess_lag_vec!(out, download(src, n, 0), download(x, n, 0), download(λ_dev, max(m, 1))[1:m])
+        upload!(dest, out, 0)
+    end
+    return optimize_core(ctx, f_dev, grad_dev!, c!, m > 0 ? jac_dev! : nothing, hlv_dev!, x0, xl, xu, m, param)
+end
+# unconstrained / equalities only / equalities + bounds: the derivatives come from the maintainer's AD generators
+optimize(ctx::HipContext, f, grad!, hess_lag_vec!, x0::Vector{Float64}, param::LFPSQPParams=LFPSQPParams()) =
+    optimize(ctx, f, grad!, nothing, nothing, hess_lag_vec!, x0, nothing, nothing, 0, param)                                   # src/optimize.jl:112
+optimize(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::Vector{Float64}, m::Int, param::LFPSQPParams=LFPSQPParams()) =
+    optimize(ctx, f, grad!, c!, jac!, hess_lag_vec!, x0, nothing, nothing, m, param)                                             # :107
+# general inequalities dl <= d(x) <= du through slack variables (:13-71): n -> n + p, m -> m + p, result truncated (:68)
+function optimize(ctx::HipContext, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, dl::Vector{Float64}, du::Vector{Float64}, x0::Vector{Float64},
+                  xl, xu, m::Int, p::Int, param::LFPSQPParams=LFPSQPParams())
+    (d! === nothing || p == 0) && return optimize(ctx, f, grad!, c!, jac_c!, hess_lag_vec!, x0, xl, xu, m, param)                  # :88
+    length(dl) == length(du) == p || error("Bound vectors dl and du must be of size p")
+    n = length(x0)
+    xl = xl === nothing ? fill(-Inf, n) : xl
+    xu = xu === nothing ? fill(Inf, n) : xu
+    x0_aux = vcat(x0, zeros(p))
+    d!(view(x0_aux, n+1:n+p), x0)
+    f_aux(x) = f(x[1:n])
+    function c_aux!(cval, x)
+        m > 0 && c!(view(cval, 1:m), x[1:n])
+        d!(view(cval, m+1:m+p), x[1:n])
+        cval[m+1:m+p] .-= x[n+1:n+p]
+        return cval
+    end
+    grad_aux!(g, x) = (grad!(view(g, 1:n), x[1:n]); g[n+1:end] .= 0.0; g)
+    function jac_aux!(J, cval, x)
+        J .= 0.0
+        m > 0 && jac_c!(view(J, 1:m, 1:n), view(cval, 1:m), x[1:n])
+        jac_d!(view(J, m+1:m+p, 1:n), view(cval, m+1:m+p), x[1:n])
+        cval[m+1:m+p] .-= x[n+1:n+p]
+        for k in 1:p
+            J[m+k, n+k] = -1.0
+        end
+    end
+    hlv_aux!(dest, src, x, λ) = (hess_lag_vec!(view(dest, 1:n), src[1:n], x[1:n], λ); dest[n+1:end] .= 0.0; dest)
+    x, obj, λ, info = optimize(ctx, f_aux, grad_aux!, c_aux!, jac_aux!, hlv_aux!, x0_aux, vcat(xl, dl), vcat(xu, du), m + p, param)
+    return x[1:n], obj, λ, info
+end
+# d(x) <= 0 (:83)
+optimize(ctx::HipContext, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, x0::Vector{Float64}, xl, xu, m::Int, p::Int, param::LFPSQPParams=LFPSQPParams()) =
+    optimize(ctx, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, fill(-Inf, p), zeros(p), x0, xl, xu, m, p, param)
+
+export HipContext, HipError, DeviceVector, StackedVector, DeviceMatrix, DeviceBasis, DiagOperator, InequalityData, InequalityDecomp,
+       InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
+       ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, upload!, download, upload2!, download2, projcg!, retract!,
+       retract_nr_batch!, pcg!, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!,
+       shard_range, sync
+
+end # module
