@@ -44,6 +44,7 @@ extern "C" {
 typedef struct lfpsqp_ctx lfpsqp_ctx; /* one GPU + stream + workspaces + communicator */
 typedef struct lfpsqp_vec lfpsqp_vec; /* device fp64 vector (sharded n-vector or replicated m-vector) */
 typedef struct lfpsqp_mat lfpsqp_mat; /* device fp64 column-major n_loc x m matrix */
+typedef struct lfpsqp_spmat lfpsqp_spmat; /* device fp64 sparse n_loc x m matrix with a few nonzeros per row */
 
 /* ---- context ------------------------------------------------------------ */
 int lfpsqp_ctx_create(int device, lfpsqp_ctx** out);
@@ -130,6 +131,23 @@ int lfpsqp_affine_head(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double c,
 int lfpsqp_sumsq_shift(lfpsqp_ctx* ctx, const lfpsqp_vec* x, int64_t count, double c, double* out);
 /* sum-all-reduce a replicated-partials device vector across ranks (no-op for 1 rank) */
 int lfpsqp_allreduce(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t count);
+
+/* ---- sparse constraint gradients (the reference's README.md:80 to-do) ---------------------- */
+/* Jct with a few nonzeros per ROW (every variable in a few constraints; e.g. the system of test/test_retractions.jl:34-54).
+ * Built from host triplets (0-based LOCAL row, column, value; duplicates add up; any order); at most 256 nonzeros per
+ * row.  Stored twice on the device: ELL by rows for Jct*t (row-local) and CSC cut into fixed chunks for Jct'*v
+ * (fixed-order sums, no atomics: bit-reproducible); both products move nnz*(8+4) bytes instead of 8*n*m.
+ * A handle in lfpsqp_constraints.Jsp / lfpsqp_basis.S makes lfpsqp_constraints_eval and lfpsqp_pcg use them. */
+int lfpsqp_spmat_create(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nnz, const int64_t* rows, const int64_t* cols,
+                        const double* vals, lfpsqp_spmat** out);
+int lfpsqp_spmat_free(lfpsqp_ctx* ctx, lfpsqp_spmat* S);
+int lfpsqp_spmat_info(const lfpsqp_spmat* S, int64_t* n, int64_t* m, int64_t* nnz, int64_t* ell_width);
+/* t[0:m) = S' * v  (all-reduced over ranks);  y = alpha * S * t + beta * y */
+int lfpsqp_spmv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_vec* v, lfpsqp_vec* t);
+int lfpsqp_spmv_n(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, double alpha, const lfpsqp_vec* t, double beta, lfpsqp_vec* y);
+/* M[:, 0:m) = S as a dense matrix (the tangent setup -- lfpsqp_factorize, whose basis Z is dense anyway -- and the Newton
+ * retraction keep using the dense kernels) */
+int lfpsqp_spmat_to_dense(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, lfpsqp_mat* M);
 
 /* ---- bound manifolds (src/inequality_helper.jl, src/retractions.jl:451-500) ------- */
 /* With bounds the reference doubles the variables: xaug = [x; y] (length 2N), each bounded
@@ -234,6 +252,9 @@ typedef struct lfpsqp_basis {
      * (lfpsqp_factorize's W).  NULL/NULL when unknown; only an optimisation hint, never required. */
     const lfpsqp_mat* A;
     const double* W;
+    /* optional sparse form of Z[:, 0:ncols] (same entries): lfpsqp_pcg then makes two sparse products per iteration
+     * instead of a dense pass.  NULL when Z is dense only. */
+    const lfpsqp_spmat* S;
 } lfpsqp_basis;
 
 /* mul!(dest, Q', v) (src/inequality_helper.jl:197-212): w[0:N) = Dx.*vx + Dy.*vy,
@@ -307,6 +328,8 @@ typedef struct lfpsqp_constraints {
     double R2;
     int64_t n_x;
     int64_t slack_row;
+    /* optional sparse form of Jct[:, 0:m_lin] (same entries): c! then streams its nonzeros instead of the dense block */
+    const lfpsqp_spmat* Jsp;
 } lfpsqp_constraints;
 /* c!(cval, x): cval (host, m_lin + has_ball).  x has >= rows(Jct) entries (the x-half of a
  * stacked vector is fine). */

@@ -46,6 +46,7 @@ struct CBasis                  # lfpsqp_basis
     sy::Ptr{Cvoid}
     A::Ptr{Cvoid}
     W::Ptr{Float64}
+    S::Ptr{Cvoid}               # optional sparse form of Z (lfpsqp_spmat), C_NULL otherwise
 end
 struct CWork                   # lfpsqp_projcg_work
     g::Ptr{Cvoid}
@@ -68,6 +69,7 @@ struct CConstraints            # lfpsqp_constraints
     R2::Float64
     n_x::Int64
     slack_row::Int64
+    Jsp::Ptr{Cvoid}             # optional sparse form of Jct[:, 1:m_lin] (lfpsqp_spmat), C_NULL otherwise
 end
 struct CPPWork                 # lfpsqp_pp_work
     r::Ptr{Cvoid}
@@ -140,6 +142,13 @@ c_vmul(ctx, d, x, y) = ccall((:lfpsqp_vmul, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid},
 c_affine_head(ctx, a, x, c, count, y) = ccall((:lfpsqp_affine_head, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Int64, Ptr{Cvoid}), ctx, a, x, c, count, y)
 c_sumsq_shift(ctx, x, count, c, out) = ccall((:lfpsqp_sumsq_shift, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Ref{Float64}), ctx, x, count, c, out)
 c_allreduce(ctx, v, count) = ccall((:lfpsqp_allreduce, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), ctx, v, count)
+# ---- sparse constraint gradients ---------------------------------------------------------------------------------------------
+c_spmat_create(ctx, n, m, nnz, rows, cols, vals, out) = ccall((:lfpsqp_spmat_create, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ref{Ptr{Cvoid}}), ctx, n, m, nnz, rows, cols, vals, out)
+c_spmat_free(ctx, S) = ccall((:lfpsqp_spmat_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx, S)
+c_spmat_info(S, n, m, nnz, k) = ccall((:lfpsqp_spmat_info, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ref{Int64}), S, n, m, nnz, k)
+c_spmv_t(ctx, S, v, t) = ccall((:lfpsqp_spmv_t, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, S, v, t)
+c_spmv_n(ctx, S, a, t, b, y) = ccall((:lfpsqp_spmv_n, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}), ctx, S, a, t, b, y)
+c_spmat_to_dense(ctx, S, M) = ccall((:lfpsqp_spmat_to_dense, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, S, M)
 # ---- bound manifolds -------------------------------------------------------------------------------------------------------
 c_half_stride(N) = ccall((:lfpsqp_half_stride, lib), Int64, (Int64,), N)
 c_ineq_data_build(ctx, xl, xu, q, r, s, t) = ccall((:lfpsqp_ineq_data_build, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, xl, xu, q, r, s, t)
@@ -282,6 +291,25 @@ function download(M::DeviceMatrix)
     return host
 end
 
+# sparse n_loc x m constraint gradients with a few nonzeros per row (lfpsqp_spmat), from 1-based Julia triplets / findnz(sparse(A))
+mutable struct SparseMatrix
+    ctx::HipContext
+    h::Ptr{Cvoid}
+    n::Int
+    m::Int
+end
+function SparseMatrix(ctx::HipContext, n::Integer, m::Integer, I::Vector{Int}, J::Vector{Int}, V::Vector{Float64})
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ctx, c_spmat_create(ctx.h, Int64(n), Int64(m), Int64(length(V)), Int64.(I .- 1), Int64.(J .- 1), V, r))
+    S = SparseMatrix(ctx, r[], n, m)
+    finalizer(x -> c_spmat_free(x.ctx.h, x.h), S)
+    return S
+end
+spmv_t!(t::DeviceVector, S::SparseMatrix, v::DeviceVector) = (check(t.ctx, c_spmv_t(t.ctx.h, S.h, v.h, t.h)); t)                 # t = S'v
+spmv_n!(y::DeviceVector, S::SparseMatrix, t::DeviceVector, a::Real=1.0, b::Real=0.0) =
+    (check(y.ctx, c_spmv_n(y.ctx.h, S.h, Float64(a), t.h, Float64(b), y.h)); y)                                                 # y = a S t + b y
+to_dense!(M::DeviceMatrix, S::SparseMatrix) = (check(M.ctx, c_spmat_to_dense(M.ctx.h, S.h, M.h)); M)
+
 # BLAS-1 on device vectors (reductions are global: all-reduced over the ranks and replicated)
 function dot(x::DeviceVector, y::DeviceVector)
     r = Ref{Float64}(0.0)
@@ -325,8 +353,8 @@ mul!(y::DeviceVector, U::DeviceBasis, t::DeviceVector, a::Number=1.0, b::Number=
     (check(y.ctx, c_gemv_n(y.ctx.h, U.Z.h, Int64(U.ncols), Float64(a), t.h, Float64(b), y.h)); y)
 mul!(t::DeviceVector, Ut::DeviceBasisAdjoint, v::DeviceVector) =
     (check(t.ctx, c_gemv_t(t.ctx.h, Ut.U.Z.h, Int64(Ut.U.ncols), v.h, t.h)); t)
-cbasis(U::DeviceBasis) = U.generator === nothing ? CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL) :
-    CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, U.generator[1].h, pointer(U.generator[2]))
+cbasis(U::DeviceBasis) = U.generator === nothing ? CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL) :
+    CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, U.generator[1].h, pointer(U.generator[2]), C_NULL)
 
 # A = a0*I + diag(dg): the LinearMap of src/optimize.jl:228-230 for diagonal Lagrangian Hessians
 struct DiagOperator
@@ -378,8 +406,8 @@ struct InequalityDecompProject
     idecomp::InequalityDecomp
 end
 cbasis(Q::InequalityDecompProject) = (d = Q.idecomp;
-    d.W === nothing ? CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, C_NULL, C_NULL) :
-                      CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, d.Jct.h, pointer(d.W)))
+    d.W === nothing ? CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, C_NULL, C_NULL, C_NULL) :
+                      CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, d.Jct.h, pointer(d.W), C_NULL))
 const AnyBasis = Union{DeviceBasis,InequalityDecompProject}
 ncols(U::DeviceBasis) = U.ncols
 ncols(Q::InequalityDecompProject) = Q.idecomp.rank
@@ -469,9 +497,11 @@ struct DeviceConstraints
     R2::Float64
     n_x::Int
     slack_row::Int              # 0-based LOCAL row of the slack variable, -1 if another rank owns it
+    Jsp::Ptr{Cvoid}             # optional SparseMatrix handle with the entries of Jct[:, 1:m_lin] (C_NULL: dense only)
 end
+DeviceConstraints(Jct, m_lin, b, has_ball, R2, n_x, slack_row) = DeviceConstraints(Jct, m_lin, b, has_ball, R2, n_x, slack_row, C_NULL)
 nconstraints(c::DeviceConstraints) = c.m_lin + (c.has_ball ? 1 : 0)
-ccons(c::DeviceConstraints) = CConstraints(c.Jct.h, c.m_lin, pointer(c.b), c.has_ball ? 1 : 0, c.R2, c.n_x, c.slack_row)
+ccons(c::DeviceConstraints) = CConstraints(c.Jct.h, c.m_lin, pointer(c.b), c.has_ball ? 1 : 0, c.R2, c.n_x, c.slack_row, c.Jsp)
 function (c::DeviceConstraints)(cval::Vector{Float64}, x::DeviceVector)                       # c!(cval, x)
     GC.@preserve c check(x.ctx, c_constraints_eval(x.ctx.h, Ref(ccons(c)), x.h, cval))
     return cval
@@ -1198,7 +1228,7 @@ end
 optimize(ctx::HipContext, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, x0::Vector{Float64}, xl, xu, m::Int, p::Int, param::LFPSQPParams=LFPSQPParams()) =
     optimize(ctx, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, fill(-Inf, p), zeros(p), x0, xl, xu, m, p, param)
 
-export HipContext, HipError, DeviceVector, StackedVector, DeviceMatrix, DeviceBasis, DiagOperator, InequalityData, InequalityDecomp,
+export HipContext, HipError, DeviceVector, StackedVector, DeviceMatrix, SparseMatrix, spmv_t!, spmv_n!, to_dense!, DeviceBasis, DiagOperator, InequalityData, InequalityDecomp,
        InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
        ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, upload!, download, upload2!, download2, projcg!, retract!,
        retract_nr_batch!, pcg!, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!,

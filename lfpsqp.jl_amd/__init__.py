@@ -4,8 +4,8 @@ Host-side mirror of the reference's operator interface over the C ABI of
 ``liblfpsqp_hip.so`` (include/lfpsqp_hip.h).  Import as ``lfpsqp_jl_amd``.
 """
 from ._capi import LfpsqpError, load_library, header_functions  # noqa: F401
-from .device import (Context, DeviceMatrix, DeviceVector, amax, axpby, dot, gemv_n, gemv_t, nrm2, vmul,  # noqa: F401
-                     waxpby)
+from .device import (Context, DeviceMatrix, DeviceVector, SparseMatrix, amax, axpby, dot, gemv_n, gemv_t, nrm2, spmv_n,  # noqa: F401
+                     spmv_t, vmul, waxpby)
 from .projcg import DeviceBasis, DiagOperator, ProjCGWork, projcg_  # noqa: F401
 from .factorize import gram, ksvd_, orthonormalize_, rmul, small_svd_  # noqa: F401
 from .inequality import (InequalityData, InequalityDecomp, InequalityDecompOp, InequalityDecompProject, StackedVector,  # noqa: F401

@@ -22,7 +22,7 @@ class DiagOp(C.Structure):  # lfpsqp_diag_op
 
 
 class Basis(C.Structure):  # lfpsqp_basis
-    _fields_ = [("Z", P), ("ncols", c_i64), ("Dx", P), ("Dy", P), ("sx", P), ("sy", P), ("A", P), ("W", P)]
+    _fields_ = [("Z", P), ("ncols", c_i64), ("Dx", P), ("Dy", P), ("sx", P), ("sy", P), ("A", P), ("W", P), ("S", P)]
 
 
 class IneqData(C.Structure):  # lfpsqp_ineq_data
@@ -30,7 +30,7 @@ class IneqData(C.Structure):  # lfpsqp_ineq_data
 
 
 class Constraints(C.Structure):  # lfpsqp_constraints
-    _fields_ = [("Jct", P), ("m_lin", c_i64), ("b", P), ("has_ball", C.c_int), ("R2", c_dbl), ("n_x", c_i64), ("slack_row", c_i64)]
+    _fields_ = [("Jct", P), ("m_lin", c_i64), ("b", P), ("has_ball", C.c_int), ("R2", c_dbl), ("n_x", c_i64), ("slack_row", c_i64), ("Jsp", P)]
 
 
 CFUN = C.CFUNCTYPE(C.c_int, P, P, PD)
@@ -108,6 +108,12 @@ _SIGS = {
     "lfpsqp_pcg": [P, c_dbl, C.POINTER(Basis), P, P, P, P, P, P, c_dbl, c_i64, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_retract_pp": [P, C.POINTER(Constraints), CFUN, JACFUN, P, P, c_i64, C.POINTER(IneqData), P, P, P, P, P, P, c_dbl, c_dbl, c_i64,
                           c_i64, C.POINTER(PPWork), PD, C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)],
+    "lfpsqp_spmat_create": [P, c_i64, c_i64, c_i64, P, P, P, C.POINTER(P)],
+    "lfpsqp_spmat_free": [P, P],
+    "lfpsqp_spmat_info": [P, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64)],
+    "lfpsqp_spmv_t": [P, P, P, P],
+    "lfpsqp_spmv_n": [P, P, c_dbl, P, c_dbl, P],
+    "lfpsqp_spmat_to_dense": [P, P, P],
     "lfpsqp_gram": [P, P, c_i64, P, P],
     "lfpsqp_rmul": [P, P, c_i64, P, c_i64, P],
     "lfpsqp_factorize": [P, P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],

@@ -21,6 +21,7 @@
 #include <math.h>
 
 #include "internal.h"
+#include "sparse.h"
 
 namespace lfpsqp {
 
@@ -256,6 +257,32 @@ __global__ __launch_bounds__(256) void pcg_tmp_kernel(PcgTmp u) {
         u.tmp[j] = fma(beta, u.tmp[j], jr);
     }
 }
+// ---- sparse operator (lfpsqp_basis.S): the two products of an iteration stream the nonzeros ----------------------------
+//   P1s  p = r + beta*p (stored) [stacked: w = Dx.*px + Dy.*py, v = sx.*px + sy.*py]     (vec_kernel)
+//        tmp = S'(p | v)                                                                   (spmv_t: chunked CSC, fixed order)
+//   P2s  z = S*tmp [+ the diagonal terms] + mu*p ; partial p'z                             (vec_kernel over the ELL rows)
+//   P3   as above
+template <class P1>
+struct P1SparseF {        // the producers of the dense kernels, run row by row; the vector handed to S' is stored for its gather
+    P1 e;
+    double* vz;           // stacked: where v goes (the x-half of z, free until P2s); plain: nullptr (p itself is gathered)
+    __device__ __forceinline__ bool skip() const { return e.skip(); }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 v = e.load(i, v0, v1);
+        if (vz) {
+            if (v1) st2(vz + i, v);
+            else if (v0) vz[i] = v.x;
+        }
+    }
+};
+template <class P2>
+struct P2SparseF {        // the consumers of the dense kernels fed from the ELL rows
+    P2 e;
+    EllRows E;
+    __device__ __forceinline__ bool skip() const { return e.skip(); }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const { e.apply(i, E.acc(i), v0, v1, red); }
+};
+
 struct RRF {
     const double* r;
     __device__ __forceinline__ bool skip() const { return false; }
@@ -300,7 +327,9 @@ extern "C" int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, l
 
     LF_TRY(lfpsqp_vec_fill(ctx, p, 0.0));                                                        // :204
     LF_TRY((run_vec<RRF, 1, PInit>(ctx, nv, RRF{r->p}, 0u, scal + P_RR, PInit{scal, istat, tol, maxiter, hm})));
-    const bool fused = m > 0 && onepass_cw(ctx, m, Z->ld, N) != 0;
+    const lfpsqp_spmat* S = Jop->S;
+    const bool sparse = S && m > 0 && S->m == m && S->n == N;
+    const bool fused = !sparse && m > 0 && onepass_cw(ctx, m, Z->ld, N) != 0;
     double* US = nullptr;                            // [u = J z (m) ; s = J r (m) ; p'z]
     if (fused) {
         LF_TRY(ensure_mvec(ctx, (size_t)2 * m + 16));
@@ -309,7 +338,20 @@ extern "C" int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, l
     int64_t it = 0;
     bool done = maxiter <= 0;
     while (!done && it < maxiter) {
-        if (!fused || it == 0) {
+        if (sparse) {
+            const P1V p1{p->p, r->p, scal, istat};
+            const P2E p2{p->p, z->p, mu, istat};
+            if (stacked) {
+                LF_TRY((run_vec<P1SparseF<P1VS>, 0, NoPost>(ctx, N, P1SparseF<P1VS>{P1VS{p1, sk}, z->p}, 0u, nullptr, NoPost(), 4)));
+                LF_TRY(spmv_t(ctx, S, z->p, tmp_m->p));
+                LF_TRY((run_vec<P2SparseF<P2ES>, 1, PPost2>(ctx, N, P2SparseF<P2ES>{P2ES{p2, sk}, ell_rows(S, tmp_m->p)}, 0u, scal + P_PZ,
+                                                            PPost2{scal, istat}, 5)));
+            } else {
+                LF_TRY((run_vec<P1SparseF<P1V>, 0, NoPost>(ctx, nv, P1SparseF<P1V>{p1, nullptr}, 0u, nullptr, NoPost(), 4)));
+                LF_TRY(spmv_t(ctx, S, p->p, tmp_m->p));
+                LF_TRY((run_vec<P2SparseF<P2E>, 1, PPost2>(ctx, nv, P2SparseF<P2E>{p2, ell_rows(S, tmp_m->p)}, 0u, scal + P_PZ, PPost2{scal, istat}, 5)));
+            }
+        } else if (!fused || it == 0) {
             const P1V p1{p->p, r->p, scal, istat};
             if (stacked) LF_TRY(run_gemv_t(ctx, Z, m, N, P1VS{p1, sk}, tmp_m->p, 4));
             else LF_TRY(run_gemv_t(ctx, Z, m, N, p1, tmp_m->p, 4));
@@ -317,7 +359,9 @@ extern "C" int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, l
             hipLaunchKernelGGL(pcg_tmp_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgTmp{US, tmp_m->p, scal, istat, m});
             LF_LAUNCH_CHECK(ctx);
         }
-        if (fused) {
+        if (sparse) {
+            // (both products done above)
+        } else if (fused) {
             if (stacked) {
                 const PcgInnerE<true> fe{p->p, r->p, z->p, mu, scal, istat, it == 0 ? 1 : 0, sk};
                 LF_TRY((run_onepass<PcgInnerE<true>, 2, 1>(ctx, Z, m, m, N, tmp_m->p, fe, US, 5)));

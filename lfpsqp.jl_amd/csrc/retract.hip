@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "internal.h"
+#include "sparse.h"
 
 namespace lfpsqp {
 
@@ -393,7 +394,8 @@ int cons_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec*
     const int ml = (int)cons->m_lin;
     const int mt = ml + (cons->has_ball ? 1 : 0);
     LF_TRY(ensure_mvec(ctx, (size_t)mt + 8));
-    if (ml > 0) LF_TRY(run_gemv_t(ctx, J, ml, J->n, PlainVec{x->p}, ctx->d_m));
+    if (ml > 0 && cons->Jsp) LF_TRY(spmv_t(ctx, cons->Jsp, x->p, ctx->d_m));              // c! streams the nonzeros
+    else if (ml > 0) LF_TRY(run_gemv_t(ctx, J, ml, J->n, PlainVec{x->p}, ctx->d_m));
     if (cons->has_ball)
         LF_TRY((run_vec<BallF, 1, NoPost>(ctx, J->n, BallF{x->p, cons->n_x, cons->slack_row}, 0u, ctx->d_m + ml, NoPost())));
     if (mt > 0) {
@@ -421,7 +423,8 @@ using namespace lfpsqp;
 
 static bool cons_ok(const lfpsqp_constraints* c) {
     return c && c->Jct && c->m_lin >= 0 && c->m_lin + (c->has_ball ? 1 : 0) <= c->Jct->m && (c->m_lin == 0 || c->b) &&
-           (!c->has_ball || (c->n_x >= 0 && c->n_x <= c->Jct->n && c->slack_row < c->Jct->n));
+           (!c->has_ball || (c->n_x >= 0 && c->n_x <= c->Jct->n && c->slack_row < c->Jct->n)) &&
+           (!c->Jsp || (c->Jsp->n == c->Jct->n && c->Jsp->m == c->m_lin));
 }
 
 extern "C" {
@@ -730,6 +733,9 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
     Jop.Dy = ineq ? w->DyS : nullptr;
     Jop.sx = ineq ? w->ones : nullptr;
     Jop.sy = ineq ? w->zeros : nullptr;
+    Jop.A = nullptr;
+    Jop.W = nullptr;
+    Jop.S = (cons && !cfun && cons->Jsp && cons->Jsp->m == m) ? cons->Jsp : nullptr;    // constant sparse equality block: sparse inner solves
 
     auto eval_c = [&](double* out) -> int {
         if (cfun) {

@@ -1,0 +1,201 @@
+// Sparse constraint gradients (the reference's README to-do "sparse Jacobians", README.md:80).
+//
+// Jct (n_loc x m, the transposed constraint Jacobian) with a few nonzeros per ROW -- every variable takes part in a few
+// constraints: banded / block-structured equality systems, the reference's own test system (test/test_retractions.jl:34-54:
+// two nonzeros per constraint).  Both products the retractions make with it stream nnz*(8+4) bytes instead of 8*n*m:
+//
+//   SpMV-N  y = alpha * Jct * t + beta * y     row-local: ELL by rows (K = max nonzeros of a row; val[k][row], col[k][row],
+//                                              coalesced over rows), t (m doubles) stays in cache
+//   SpMV-T  t = Jct' * v                       CSC (nonzeros of a column = of a constraint, rows ascending), cut into chunks
+//                                              of 2048 nonzeros: one workgroup per chunk, fixed-order sums -> a second kernel adds
+//                                              the chunks of each column in order.  No atomics: bit-reproducible.
+//
+// Users: lfpsqp_constraints_eval (c! of linear equalities), lfpsqp_pcg (the inner solve of the default ProjPenalty
+// retraction: per iteration two sparse products instead of a dense pass), lfpsqp_spmat_to_dense (the tangent setup keeps
+// using the dense MFMA path: its basis Z is dense anyway).
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "internal.h"
+#include "sparse.h"
+
+namespace lfpsqp {
+
+constexpr int kSpChunk = 2048;
+
+__global__ __launch_bounds__(kThreads) void spmv_t_chunk_kernel(const int64_t* __restrict__ chunk_beg, const int32_t* __restrict__ row,
+                                                                 const double* __restrict__ val, const double* __restrict__ v,
+                                                                 double* __restrict__ partial) {
+    const int64_t e0 = chunk_beg[blockIdx.x], e1 = chunk_beg[blockIdx.x + 1];
+    double acc = 0.0;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += kThreads) acc = fma(val[e], v[row[e]], acc);
+    double red[1] = {acc};
+    block_reduce_store<1>(red, 0u, partial + blockIdx.x);
+}
+__global__ void spmv_t_final_kernel(const int32_t* __restrict__ col_chunk, const double* __restrict__ partial, int m, double* __restrict__ t) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    double s = 0.0;
+    for (int c = col_chunk[j]; c < col_chunk[j + 1]; ++c) s += partial[c];
+    t[j] = s;
+}
+
+struct SpmvNF {   // y = alpha * (Jct t) + beta * y
+    EllRows E;
+    double* y;
+    double alpha, beta;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 a = E.acc(i);
+        double2 o;
+        if (beta == 0.0) {
+            o = make_double2(alpha * a.x, alpha * a.y);
+        } else {
+            const double2 yy = ld2(y + i);
+            o = make_double2(fma(alpha, a.x, beta * yy.x), fma(alpha, a.y, beta * yy.y));
+        }
+        if (v1) st2(y + i, o);
+        else if (v0) y[i] = o.x;
+    }
+};
+// dense[:, j] from the CSC arrays of column j (one entry per position: every element written once)
+__global__ void sp_scatter_kernel(const int64_t* __restrict__ colptr, const int32_t* __restrict__ row, const double* __restrict__ val,
+                                  double* __restrict__ dense, int64_t ld_dense) {
+    const int j = blockIdx.y;
+    for (int64_t e = colptr[j] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < colptr[j + 1]; e += (int64_t)gridDim.x * blockDim.x)
+        dense[(int64_t)j * ld_dense + row[e]] = val[e];
+}
+
+// t_out[0:m) = S' v (global: all-reduced).  v must hold at least S->n entries.
+int spmv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const double* v, double* t_out) {
+    if (S->m == 0) return 0;
+    if (S->nchunks > 0) {
+        LF_TRY(ensure_part(ctx, (size_t)S->nchunks + 8));
+        hipLaunchKernelGGL(spmv_t_chunk_kernel, dim3((unsigned)S->nchunks), dim3(kThreads), 0, ctx->stream, S->chunk_beg, S->csc_row, S->csc_val, v,
+                           ctx->part);
+        LF_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(spmv_t_final_kernel, dim3((unsigned)((S->m + 255) / 256)), dim3(256), 0, ctx->stream, S->col_chunk, ctx->part, (int)S->m, t_out);
+    LF_LAUNCH_CHECK(ctx);
+    return allreduce_dev(ctx, t_out, S->m);
+}
+
+
+}  // namespace lfpsqp
+
+using namespace lfpsqp;
+
+extern "C" {
+
+int lfpsqp_spmat_create(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nnz, const int64_t* rows, const int64_t* cols, const double* vals,
+                        lfpsqp_spmat** out) {
+    LF_ARG(ctx, ctx && out && n >= 0 && m >= 0 && nnz >= 0 && (nnz == 0 || (rows && cols && vals)) && m < (1 << 30) && n < ((int64_t)1 << 31));
+    *out = nullptr;
+    for (int64_t e = 0; e < nnz; ++e)
+        if (rows[e] < 0 || rows[e] >= n || cols[e] < 0 || cols[e] >= m) return set_err(ctx, LFPSQP_ERR_ARG, "spmat: entry %lld out of range", (long long)e);
+    // entries ordered by (column, row); duplicates (same row and column) are summed, so every format holds one entry per position
+    std::vector<int64_t> order((size_t)nnz);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return cols[a] != cols[b] ? cols[a] < cols[b] : rows[a] < rows[b]; });
+    std::vector<int32_t> hr;
+    std::vector<int32_t> hcol;
+    std::vector<double> hcv;
+    hr.reserve((size_t)nnz + 1); hcol.reserve((size_t)nnz + 1); hcv.reserve((size_t)nnz + 1);
+    for (int64_t k = 0; k < nnz; ++k) {
+        const int64_t e = order[(size_t)k];
+        if (!hr.empty() && hr.back() == (int32_t)rows[e] && hcol.back() == (int32_t)cols[e]) hcv.back() += vals[e];
+        else { hr.push_back((int32_t)rows[e]); hcol.push_back((int32_t)cols[e]); hcv.push_back(vals[e]); }
+    }
+    nnz = (int64_t)hr.size();
+    std::vector<int32_t> cnt((size_t)std::max<int64_t>(n, 1), 0);
+    for (int64_t k = 0; k < nnz; ++k) cnt[(size_t)hr[(size_t)k]]++;
+    int K = 0;
+    for (int64_t i = 0; i < n; ++i) K = std::max(K, (int)cnt[(size_t)i]);
+    if (K > 256) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "spmat: a row with %d nonzeros (> 256): keep such constraint gradients dense", K);
+    lfpsqp_spmat* S = new lfpsqp_spmat();
+    S->n = n; S->m = m; S->nnz = nnz; S->K = K;
+    S->ld = round_up(n > 0 ? n : 1, kPadRows);
+    const size_t ell = (size_t)std::max(K, 1) * (size_t)S->ld;
+    std::vector<double> hv(ell, 0.0);
+    std::vector<int32_t> hc(ell, 0);
+    std::fill(cnt.begin(), cnt.end(), 0);
+    std::vector<int64_t> colptr((size_t)m + 1, 0);
+    for (int64_t k = 0; k < nnz; ++k) {
+        colptr[(size_t)hcol[(size_t)k] + 1]++;
+        const int32_t r = hr[(size_t)k], slot = cnt[(size_t)r]++;   // ELL slots of a row in column order
+        hv[(size_t)slot * S->ld + r] = hcv[(size_t)k];
+        hc[(size_t)slot * S->ld + r] = hcol[(size_t)k];
+    }
+    for (int64_t j = 0; j < m; ++j) colptr[(size_t)j + 1] += colptr[(size_t)j];
+    std::vector<int64_t> cb2;
+    std::vector<int32_t> cchunk((size_t)m + 1, 0);
+    for (int64_t j = 0; j < m; ++j) {
+        cchunk[(size_t)j] = (int32_t)cb2.size();
+        for (int64_t e = colptr[(size_t)j]; e < colptr[(size_t)j + 1]; e += kSpChunk) cb2.push_back(e);
+    }
+    cchunk[(size_t)m] = (int32_t)cb2.size();
+    S->nchunks = (int64_t)cb2.size();
+    cb2.push_back(nnz);
+    if (hr.empty()) { hr.push_back(0); hcv.push_back(0.0); }
+    // the kernel reads [chunk_beg[c], chunk_beg[c+1]): consecutive chunks are contiguous in the CSC order, also across columns
+    bool ok = true;
+    auto dev_copy = [&](void** dst, const void* src, size_t bytes) {
+        if (!ok) return;
+        ok = hipMalloc(dst, bytes > 0 ? bytes : 8) == hipSuccess;
+        if (ok && bytes > 0) ok = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    };
+    dev_copy((void**)&S->ell_val, hv.data(), ell * sizeof(double));
+    dev_copy((void**)&S->ell_col, hc.data(), ell * sizeof(int32_t));
+    dev_copy((void**)&S->csc_row, hr.data(), hr.size() * sizeof(int32_t));
+    dev_copy((void**)&S->csc_val, hcv.data(), hcv.size() * sizeof(double));
+    dev_copy((void**)&S->colptr, colptr.data(), colptr.size() * sizeof(int64_t));
+    dev_copy((void**)&S->chunk_beg, cb2.data(), cb2.size() * sizeof(int64_t));
+    dev_copy((void**)&S->col_chunk, cchunk.data(), cchunk.size() * sizeof(int32_t));
+    if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (!ok) {
+        lfpsqp_spmat_free(ctx, S);
+        return set_err(ctx, LFPSQP_ERR_HIP, "spmat: device allocation / upload failed");
+    }
+    *out = S;
+    return 0;
+}
+
+int lfpsqp_spmat_free(lfpsqp_ctx* ctx, lfpsqp_spmat* S) {
+    if (!S) return 0;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : {(void*)S->ell_val, (void*)S->ell_col, (void*)S->csc_row, (void*)S->csc_val, (void*)S->colptr, (void*)S->chunk_beg, (void*)S->col_chunk})
+        if (p) (void)hipFree(p);
+    delete S;
+    return 0;
+}
+
+int lfpsqp_spmat_info(const lfpsqp_spmat* S, int64_t* n, int64_t* m, int64_t* nnz, int64_t* ell_width) {
+    if (!S) return LFPSQP_ERR_ARG;
+    if (n) *n = S->n;
+    if (m) *m = S->m;
+    if (nnz) *nnz = S->nnz;
+    if (ell_width) *ell_width = S->K;
+    return 0;
+}
+
+int lfpsqp_spmv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_vec* v, lfpsqp_vec* t) {
+    LF_ARG(ctx, ctx && S && v && t && v->n >= S->n && t->n >= S->m);
+    return spmv_t(ctx, S, v->p, t->p);
+}
+
+int lfpsqp_spmv_n(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, double alpha, const lfpsqp_vec* t, double beta, lfpsqp_vec* y) {
+    LF_ARG(ctx, ctx && S && t && y && y->n >= S->n && t->n >= S->m && t->p != y->p);
+    return run_vec<SpmvNF, 0, NoPost>(ctx, S->n, SpmvNF{ell_rows(S, t->p), y->p, alpha, beta}, 0u, nullptr, NoPost());
+}
+
+int lfpsqp_spmat_to_dense(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, lfpsqp_mat* M) {
+    LF_ARG(ctx, ctx && S && M && M->n == S->n && M->m >= S->m);
+    if (S->m == 0 || S->n == 0) return 0;
+    LF_HIP(ctx, hipMemsetAsync(M->p, 0, sizeof(double) * (size_t)M->ld * (size_t)S->m, ctx->stream));
+    hipLaunchKernelGGL(sp_scatter_kernel, dim3(64, (unsigned)S->m), dim3(256), 0, ctx->stream, S->colptr, S->csc_row, S->csc_val, M->p, M->ld);
+    LF_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+}  // extern "C"

@@ -265,3 +265,54 @@ def waxpby(a: float, x: DeviceVector, b: float, y: DeviceVector, z: DeviceVector
 def vmul(d: DeviceVector, x: DeviceVector, y: DeviceVector):
     x.ctx.check(x.ctx.L.lfpsqp_vmul(x.ctx.h, d.h, x.h, y.h))
     return y
+
+
+class SparseMatrix:
+    """Sparse n_loc x m constraint-gradient matrix with a few nonzeros per row (lfpsqp_spmat): built from triplets
+    (0-based local row, column, value) or from a scipy.sparse matrix of shape (n, m)."""
+
+    def __init__(self, ctx: Context, n: int, m: int, rows, cols, vals):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        assert rows.shape == cols.shape == vals.shape
+        self.ctx, self.n, self.m = ctx, int(n), int(m)
+        h = P()
+        ctx.check(ctx.L.lfpsqp_spmat_create(ctx.h, self.n, self.m, rows.size, rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, C.byref(h)))
+        self.h = h
+        nn, mm, nnz, k = _capi.c_i64(), _capi.c_i64(), _capi.c_i64(), _capi.c_i64()
+        ctx.L.lfpsqp_spmat_info(self.h, C.byref(nn), C.byref(mm), C.byref(nnz), C.byref(k))
+        self.nnz, self.ell_width = nnz.value, k.value
+
+    @classmethod
+    def from_scipy(cls, ctx: Context, A):
+        A = A.tocoo()
+        return cls(ctx, A.shape[0], A.shape[1], A.row, A.col, A.data)
+
+    def free(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.L.lfpsqp_spmat_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def to_dense(self, M: "DeviceMatrix | None" = None) -> "DeviceMatrix":
+        M = M if M is not None else DeviceMatrix(self.ctx, self.n, self.m)
+        self.ctx.check(self.ctx.L.lfpsqp_spmat_to_dense(self.ctx.h, self.h, M.h))
+        return M
+
+
+def spmv_t(S: SparseMatrix, v: DeviceVector, t: DeviceVector) -> DeviceVector:
+    """t = S' v (all-reduced)."""
+    S.ctx.check(S.ctx.L.lfpsqp_spmv_t(S.ctx.h, S.h, v.h, t.h))
+    return t
+
+
+def spmv_n(S: SparseMatrix, t: DeviceVector, y: DeviceVector, alpha: float = 1.0, beta: float = 0.0) -> DeviceVector:
+    """y = alpha S t + beta y."""
+    S.ctx.check(S.ctx.L.lfpsqp_spmv_n(S.ctx.h, S.h, float(alpha), t.h, float(beta), y.h))
+    return y

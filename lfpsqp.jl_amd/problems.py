@@ -24,7 +24,7 @@ from .retractions import DeviceConstraints
 
 class QuadLinearBallBox:
     def __init__(self, ctx: Context, n: int, m: int, Jct: DeviceMatrix, b, R2: Optional[float] = None, xl=None, xu=None,
-                 xc: float = 0.0, n_global: Optional[int] = None, owns_slack: bool = True):
+                 xc: float = 0.0, n_global: Optional[int] = None, owns_slack: bool = True, Jsp=None):
         """n = rows of this rank's shard.  Jct: device matrix with n + ploc rows and m + p columns
         (p = 1 iff R2 is given; ploc = 1 on the rank that owns the slack variable -- the last one --
         else 0) whose leading n x m block holds the constraint gradients; the slack row and the ball
@@ -36,7 +36,9 @@ class QuadLinearBallBox:
         assert Jct.n == self.N and Jct.m == self.M
         self.Jct = Jct
         self.R2 = 0.0 if R2 is None else float(R2)
-        self.cons = DeviceConstraints(Jct, m, b, has_ball=self.p == 1, R2=self.R2, n_x=n, slack_row=n if self.ploc else -1)
+        # Jsp: optional SparseMatrix (N x m) with the entries of the linear block Jct[:, :m]: c! and ProjPenalty's inner solves
+        # then stream its nonzeros (the tangent setup and the Newton retraction keep the dense block)
+        self.cons = DeviceConstraints(Jct, m, b, has_ball=self.p == 1, R2=self.R2, n_x=n, slack_row=n if self.ploc else -1, Jsp=Jsp)
         self.xl = None if xl is None else np.asarray(xl, dtype=np.float64)
         self.xu = None if xu is None else np.asarray(xu, dtype=np.float64)
         self.n_global = n if n_global is None else n_global

@@ -59,11 +59,11 @@ class ProjPenalty:  # src/retractions.jl:35-49
 class _JacPlain:
     """J = Jct' (m x n): tmp = J p ; z = J' tmp + mu z."""
 
-    def __init__(self, Jct: DeviceMatrix, work: ProjPenaltyWork):
-        self.Jct, self.w = Jct, work
+    def __init__(self, Jct: DeviceMatrix, work: ProjPenaltyWork, Jsp=None):
+        self.Jct, self.w, self.Jsp = Jct, work, Jsp      # Jsp: optional SparseMatrix with the same entries
 
     def _basis(self):
-        return _capi.Basis(self.Jct.h, self.Jct.m, None, None, None, None)
+        return _capi.Basis(self.Jct.h, self.Jct.m, None, None, None, None, None, None, self.Jsp.h if self.Jsp is not None else None)
 
     def apply(self, p):                       # mul!(tmp_m, J, p)       :221
         gemv_t(self.Jct, p, self.w.tmp_m)
@@ -76,12 +76,13 @@ class _JacStacked:
     """fulljac = idecomp' (InequalityDecompAdjoint): tmp = [S.*(Dx.*px + Dy.*py); Jct' px], in the
     lfpsqp_basis form with row scalings (1, 0) on the work struct's vectors."""
 
-    def __init__(self, idecomp: InequalityDecomp, work: ProjPenaltyWork):
-        self.idc, self.w = idecomp, work
+    def __init__(self, idecomp: InequalityDecomp, work: ProjPenaltyWork, Jsp=None):
+        self.idc, self.w, self.Jsp = idecomp, work, Jsp
 
     def _basis(self):
         w = self.w
-        return _capi.Basis(self.idc.Jct.h, self.idc.Jct.m, w.DxS.h, w.DyS.h, w.ones.h, w.zeros.h)
+        return _capi.Basis(self.idc.Jct.h, self.idc.Jct.m, w.DxS.h, w.DyS.h, w.ones.h, w.zeros.h, None, None,
+                           self.Jsp.h if self.Jsp is not None else None)
 
     def refresh(self):
         vmul(self.idc.Dx, self.idc.S, self.w.DxS)

@@ -21,8 +21,11 @@ class DeviceConstraints:
     (lfpsqp_constraints).  Callable as c!(cval, x) and jac!(Jct, cval, x)."""
 
     def __init__(self, Jct: DeviceMatrix, m_lin: int, b, has_ball: bool = False, R2: float = 0.0, n_x: int | None = None,
-                 slack_row: int = -1):
+                 slack_row: int = -1, Jsp=None):
+        """``Jsp`` (optional SparseMatrix with the entries of Jct[:, :m_lin]): c! and the inner solves of the ProjPenalty
+        retraction stream its nonzeros instead of the dense block."""
         self.Jct, self.m_lin = Jct, int(m_lin)
+        self.Jsp = Jsp
         self.b = np.ascontiguousarray(b, dtype=np.float64) if m_lin else np.zeros(1)
         self.has_ball, self.R2 = bool(has_ball), float(R2)
         self.n_x = Jct.n if n_x is None else int(n_x)
@@ -31,7 +34,7 @@ class DeviceConstraints:
 
     def _c(self):
         return _capi.Constraints(self.Jct.h, self.m_lin, self.b.ctypes.data, 1 if self.has_ball else 0, self.R2, self.n_x,
-                                 self.slack_row)
+                                 self.slack_row, self.Jsp.h if self.Jsp is not None else None)
 
     def c_(self, cval: np.ndarray, x: DeviceVector):
         ctx = x.ctx

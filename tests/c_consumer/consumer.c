@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
     CK(lfpsqp_vec_hash_fill(ctx, b, 4, 0, 1.0, 0.0));
 
     const lfpsqp_diag_op A = {0.0, a};
-    const lfpsqp_basis U = {Z, rank, NULL, NULL, NULL, NULL, NULL, NULL};
+    const lfpsqp_basis U = {Z, rank, NULL, NULL, NULL, NULL, NULL, NULL, NULL};
     int64_t iters = -1;
     double nr = -1.0, xn = 0.0, ln = 0.0;
     CK(lfpsqp_projcg(ctx, x, lam, &A, &U, b, NULL, tol, maxit, n, LFPSQP_PROJCG_WANT_LAMBDA, &w, &iters, &nr));

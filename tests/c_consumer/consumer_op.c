@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
     CK(lfpsqp_vec_copy_range(ctx, op.e_dn, 1, e, 0, n - 1));      /* e_dn[i] = e[i-1], e_dn[0] = 0 */
     CK(lfpsqp_vec_hash_fill(ctx, b, 4, 0, 1.0, 0.0));
 
-    const lfpsqp_basis U = {Z, rank, NULL, NULL, NULL, NULL, NULL, NULL};
+    const lfpsqp_basis U = {Z, rank, NULL, NULL, NULL, NULL, NULL, NULL, NULL};
     int64_t iters = -1;
     double nr = -1.0, xn = 0.0, ln = 0.0;
     CK(lfpsqp_projcg_op(ctx, x, lam, tri_apply, &op, Av, &U, b, NULL, tol, maxit, n, LFPSQP_PROJCG_WANT_LAMBDA, &w, &iters, &nr));

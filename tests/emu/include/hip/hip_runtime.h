@@ -46,6 +46,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct double2 { double x, y; };
+struct int2 { int x, y; };
 static inline double2 make_double2(double a, double b) { return double2{a, b}; }
 
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };

@@ -1,0 +1,189 @@
+"""Sparse constraint gradients (lfpsqp_spmat; SURVEY §8 f4, the reference's README.md:80 to-do): the two sparse products against
+numpy, the dense path they replace inside pcg! / ProjPenalty / c!, and an end-to-end optimize run -- same counts, same iterates."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import lfpsqp_jl_amd as L
+from lfpsqp_jl_amd.projpenalty import _JacPlain, _JacStacked
+from oracle import lfpsqp_ref as R
+from oracle import synth
+
+
+def _is_emu(ctx):
+    return "emulator" in ctx.device_name
+
+
+def banded(n, m, k=3, seed=5):
+    """n x m sparse Jct: row i touches k constraints around column i*m/n (a banded / block-structured equality system)."""
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n), k)
+    base = (np.arange(n) * m) // n
+    cols = (base[:, None] + np.arange(k)[None, :]) % m
+    vals = rng.standard_normal((n, k)) + 2.0 * (np.arange(k) == 0)
+    return rows, cols.ravel(), vals.ravel()
+
+
+@pytest.mark.parametrize("n,m,k", [(3000, 40, 3), (5000, 7, 2), (2500, 300, 5)])
+def test_sparse_products_match_numpy(dev_ctx, n, m, k):
+    ctx = dev_ctx
+    rows, cols, vals = banded(n, m, k)
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, m)).tocsr()
+    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+    assert S.nnz == A.nnz and S.ell_width == k
+    rng = np.random.default_rng(1)
+    vh, th, yh = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(n)
+    t = L.spmv_t(S, ctx.vector(n, vh), ctx.vector(m))
+    np.testing.assert_allclose(t.download(), A.T @ vh, rtol=0, atol=1e-12 * np.sqrt(n))
+    y = ctx.vector(n, yh)
+    L.spmv_n(S, ctx.vector(m, th), y, 1.5, -0.5)
+    np.testing.assert_allclose(y.download(), 1.5 * (A @ th) - 0.5 * yh, atol=1e-13)
+    L.spmv_n(S, ctx.vector(m, th), y, 1.0, 0.0)
+    np.testing.assert_allclose(y.download(), A @ th, atol=1e-13)
+    np.testing.assert_array_equal(S.to_dense().download(), A.toarray())
+    # the sparse products are the dense ones on the same entries
+    M = S.to_dense()
+    t2, y2 = ctx.vector(m), ctx.vector(n)
+    L.gemv_t(M, ctx.vector(n, vh), t2)
+    L.gemv_n(M, ctx.vector(m, th), y2)
+    np.testing.assert_allclose(t.download(), t2.download(), atol=1e-12 * np.sqrt(n))
+    np.testing.assert_allclose(y.download(), y2.download(), atol=1e-13)
+
+
+def test_sparse_edge_cases(dev_ctx):
+    """duplicates add up, empty columns / rows, unsorted input, nothing at all; a dense row is refused."""
+    ctx = dev_ctx
+    n, m = 1000, 6
+    rows = np.array([5, 5, 999, 0, 5, 700, 700])
+    cols = np.array([2, 2, 5, 0, 0, 2, 2])
+    vals = np.array([1.0, 2.5, -1.0, 4.0, 0.5, 1.0, -1.0])
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, m)).tocsr()          # scipy sums duplicates too
+    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+    assert S.nnz == 5                                                      # 7 triplets, two duplicated positions
+    v = np.cos(np.arange(n))
+    np.testing.assert_allclose(L.spmv_t(S, ctx.vector(n, v), ctx.vector(m)).download(), A.T @ v, atol=1e-14)
+    np.testing.assert_array_equal(S.to_dense().download(), A.toarray())
+    E = L.SparseMatrix(ctx, n, m, [], [], [])
+    assert E.nnz == 0
+    np.testing.assert_array_equal(L.spmv_t(E, ctx.vector(n, v), ctx.vector(m).fill(7.0)).download(), np.zeros(m))
+    y = ctx.vector(n, v)
+    L.spmv_n(E, ctx.vector(m).fill(1.0), y, 1.0, 2.0)
+    np.testing.assert_allclose(y.download(), 2.0 * v)
+    with pytest.raises(L.LfpsqpError):
+        L.SparseMatrix(ctx, 4, 300, np.zeros(300, dtype=int), np.arange(300), np.ones(300))       # one row with 300 nonzeros
+    with pytest.raises(L.LfpsqpError):
+        L.SparseMatrix(ctx, 4, 3, [4], [0], [1.0])                                                # row out of range
+
+
+@pytest.mark.parametrize("bounds", [False, True])
+def test_pcg_with_a_sparse_operator_is_the_dense_solve(dev_ctx, bounds):
+    """pcg! (src/retractions.jl:179-246) with lfpsqp_basis.S set: two sparse products per iteration instead of a dense pass --
+    the same iteration count and flag, iterates equal to rounding, the system solved."""
+    ctx = dev_ctx
+    n, m = (2400, 24) if _is_emu(ctx) else (20000, 64)
+    rows, cols, vals = banded(n, m, 3)
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, m)).tocsr()
+    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+    J = S.to_dense()
+    mu, tol = 0.05, 1e-9
+    rng = np.random.default_rng(2)
+    res = {}
+    for label, Jsp in (("dense", None), ("sparse", S)):
+        w = L.ProjPenaltyWork(ctx, m, n, bounds)
+        if bounds:
+            from lfpsqp_jl_amd.inequality import InequalityData, InequalityDecomp, StackedVector, generate_initial_y_, inequality_gradient_
+            i = np.arange(n)
+            xl = np.where(i % 3 == 1, -1.0, -np.inf)
+            xu = np.where(i % 3 == 2, 1.0, np.inf)
+            idata = InequalityData(ctx, xl, xu)
+            xa = StackedVector(ctx, n)
+            xa.upload(0.5 * synth.hash_vector(2, n), 0)
+            generate_initial_y_(xa, idata)
+            dec = InequalityDecomp(ctx, n, m, J)
+            inequality_gradient_(dec, xa, idata)
+            op = _JacStacked(dec, w, Jsp)
+            op.refresh()
+            x, r = StackedVector(ctx, n), StackedVector(ctx, n)
+            r.upload2(np.random.default_rng(3).standard_normal(2 * n))
+        else:
+            op = _JacPlain(J, w, Jsp)
+            x, r = ctx.vector(n), ctx.vector(n, np.random.default_rng(3).standard_normal(n))
+        flag, it = L.pcg_(mu, op, L.no_precondition, x, r, w.p, w.z, None, tol, 400)
+        res[label] = (flag, it, x.download2() if bounds else x.download())
+    # (the stopping test norm(r) > tol can flip by an iteration when the residual lands within rounding of tol: the two paths sum in
+    # different orders -- the same slack the dense-vs-oracle comparisons allow)
+    assert res["sparse"][0] == res["dense"][0] == 0 and res["dense"][1] > 3 and abs(res["sparse"][1] - res["dense"][1]) <= 2
+    exact = res["sparse"][1] == res["dense"][1]
+    np.testing.assert_allclose(res["sparse"][2], res["dense"][2], rtol=0, atol=(1e-11 if exact else 1e-7) * np.abs(res["dense"][2]).max())
+    if not bounds:       # (J'J + mu I) x = b
+        b = np.random.default_rng(3).standard_normal(n)
+        xs = res["sparse"][2]
+        assert np.linalg.norm(A @ (A.T @ xs) + mu * xs - b) <= 2 * tol
+
+
+@pytest.mark.parametrize("bounds", [False, True])
+def test_optimize_with_sparse_equalities_matches_the_dense_run_and_the_oracle(dev_ctx, bounds):
+    """End to end: f = ||x||^2 subject to banded sparse equalities (and bounds), the reference's DEFAULT retraction
+    (ProjPenalty: c!, jac!, pcg! all on the sparse block): the trajectory of the dense run and of the oracle."""
+    ctx = dev_ctx
+    n, m = (600, 8) if _is_emu(ctx) else (6000, 24)
+    rows, cols, vals = banded(n, m, 3, seed=9)
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, m)).toarray()
+    xs = synth.hash_vector(2, n)
+    prob0 = synth.QuadLinearProblem(np.asfortranarray(A), A.T @ xs)
+    x0 = xs + 0.05 * synth.hash_vector(6, n)
+    xl = xu = None
+    if bounds:
+        i = np.arange(n)
+        xl = np.where(i % 3 == 1, -2.0, -np.inf)
+        xu = np.where(i % 3 == 2, 2.0, np.inf)
+    maxiter = 3
+    tr0 = []
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, xl, xu, m,
+                                     R.LFPSQPParams(disp=R.DisplayOption.off, maxiter=maxiter), trace=tr0)
+    out = {}
+    for label in ("dense", "sparse"):
+        S = L.SparseMatrix(ctx, n, m, rows, cols, vals) if label == "sparse" else None
+        P = L.QuadLinearBallBox(ctx, n, m, ctx.matrix(n, m, np.asfortranarray(A)), prob0.b, xl=xl, xu=xu, Jsp=S)
+        tr = []
+        x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(disp=L.DisplayOption.off, maxiter=maxiter), trace=tr)
+        out[label] = (tr, x, obj, ti)
+    trd, xd, objd, tid = out["dense"]
+    trs, xsp, objs, tis = out["sparse"]
+    assert tis.iter == tid.iter == tir.iter
+    for a, b, c in zip(trs, trd, tr0):
+        for k in ("tn_iter", "steptype", "mtype", "retract_iter1", "alpha", "ls_flag", "rank"):
+            assert a.get(k) == b.get(k) == c.get(k), (a["iter"], k, a.get(k), b.get(k), c.get(k))
+        assert abs((a.get("retract_iter2") or 0) - (c.get("retract_iter2") or 0)) <= 2
+        assert np.linalg.norm(a["x"] - c["x"]) <= 1e-9 * np.linalg.norm(c["x"])
+        assert np.linalg.norm(a["x"] - b["x"]) <= 1e-10 * np.linalg.norm(b["x"])
+    np.testing.assert_allclose(objs, objr, rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_sparse_products_at_1e6_rows_against_the_dense_kernels():
+    """The §8 f4 bar: a banded Jct at n = 1e6, m = 128 (4 nonzeros per row): both sparse products agree with the dense GEMV
+    kernels on the same entries, and run at a multiple of their speed (48 MB of nonzeros against a 1 GB matrix)."""
+    ctx = L.Context(0)
+    n, m, k = 1_000_000, 128, 4
+    rows, cols, vals = banded(n, m, k)
+    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+    M = S.to_dense()
+    v, t = ctx.vector(n).hash_fill(5), ctx.vector(m).hash_fill(6)
+    ts, td, ys, yd = ctx.vector(m), ctx.vector(m), ctx.vector(n), ctx.vector(n)
+    L.spmv_t(S, v, ts); L.gemv_t(M, v, td)
+    L.spmv_n(S, t, ys); L.gemv_n(M, t, yd)
+    np.testing.assert_allclose(ts.download(), td.download(), rtol=0, atol=1e-12 * np.abs(td.download()).max())
+    L.axpby(1.0, ys, -1.0, yd)
+    assert L.nrm2(yd) <= 1e-13 * L.nrm2(ys)
+    ms = {}
+    for name, fn in (("spmv_t", lambda: L.spmv_t(S, v, ts)), ("gemv_t", lambda: L.gemv_t(M, v, td)), ("spmv_n", lambda: L.spmv_n(S, t, ys)),
+                     ("gemv_n", lambda: L.gemv_n(M, t, yd))):
+        fn()
+        ctx.timer_begin()
+        for _ in range(20):
+            fn()
+        ms[name] = ctx.timer_end() / 20
+    print("[sparse] ms per product:", {k_: round(v_, 4) for k_, v_ in ms.items()}, "nnz bytes", S.nnz * 12)
+    assert ms["spmv_t"] < ms["gemv_t"] and ms["spmv_n"] < ms["gemv_n"]
+    ctx.close()
