@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -182,6 +183,17 @@ inline void run_block(BlockState& b, unsigned nthreads, const std::function<void
         }
     }
 }
+inline std::mutex& pool_mutex() { static std::mutex m; return m; }
+inline std::vector<BlockState*>& pool() { static std::vector<BlockState*> p; return p; }
+inline BlockState* acquire_block_state() {
+    std::lock_guard<std::mutex> g(pool_mutex());
+    if (!pool().empty()) { BlockState* b = pool().back(); pool().pop_back(); return b; }
+    return new BlockState();
+}
+inline void release_block_state(BlockState* b) {
+    std::lock_guard<std::mutex> g(pool_mutex());
+    pool().push_back(b);
+}
 inline int num_workers() {
     const char* e = std::getenv("HIPEMU_THREADS");
     int n = e ? std::atoi(e) : 4;
@@ -195,7 +207,14 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
     std::function<void()> body = [=]() { kernel(args...); };
     std::atomic<unsigned> next{0};
     auto worker = [&]() {
-        static thread_local BlockState bs;
+        // fiber stacks are expensive to set up (256 KB each, up to 1024 per block) and every launch starts fresh OS threads:
+        // block states are pooled across launches instead of living (and leaking) in thread-local storage
+        struct Lease {
+            BlockState* b;
+            Lease() : b(acquire_block_state()) {}
+            ~Lease() { release_block_state(b); }
+        } lease;
+        BlockState& bs = *lease.b;
         g_bdim = Idx{block.x, block.y, block.z};
         g_gdim = Idx{grid.x, grid.y, grid.z};
         for (;;) {

@@ -576,6 +576,8 @@ def test_factorize_honours_the_reference_rank_rule(dev_ctx, case):
     oracle's dgesvd and return what dgesvd returns to ITS accuracy: singular values to eps*sigma_1 absolute, the rank, a basis
     of range(A V_r) orthonormal to the rounding floor of the problem (eps * sigma_1 / sigma_j), the projector, A = Z S Vt."""
     ctx = dev_ctx
+    if case == "m200" and _is_emu_ctx(ctx):
+        pytest.skip("kept small on the emulator (the 32-column block kernel is covered by test_small_svd_one_sided_jacobi)")
     n = 3000
     dup = zero = False
     if case == "cond1e5": sv = np.logspace(0, -5, 12)
