@@ -341,8 +341,35 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     nr1_bytes = 8.0 * n_loc * m + 24.0 * n_loc                # J pass + xnew read/write + v
     nr2_bytes = 16.0 * n_loc * m + 24.0 * n_loc               # Z pass + J pass + xnew read/write + v
     flop = 2.0 * n_loc * m * m
+    # sparse constraint gradients (lfpsqp_spmat): a banded Jct with 4 nonzeros per row at the bench's n x m; both products against
+    # their algorithmic bytes (12 per nonzero + the vectors; beyond the 256 MB infinity cache only from ~2e7 nonzeros on)
+    sparse = None
+    try:
+        k_sp = 4
+        ii = np.arange(n_loc, dtype=np.int64)
+        rows_sp = np.repeat(ii, k_sp)
+        cols_sp = (((ii * m) // max(n_loc, 1))[:, None] + np.arange(k_sp)[None, :]) % m
+        vals_sp = np.ones(n_loc * k_sp)
+        Ssp = L.SparseMatrix(ctx, n_loc, m, rows_sp, cols_sp.ravel(), vals_sp)
+        tsp, ysp = ctx.vector(m).hash_fill(6), ctx.vector(n_loc)
+        L.spmv_t(Ssp, xs, tsp); L.spmv_n(Ssp, tsp, ysp)
+        ctx.timer_begin()
+        for _ in range(10):
+            L.spmv_t(Ssp, xs, tsp)
+        ms_st = ctx.timer_end() / 10
+        ctx.timer_begin()
+        for _ in range(10):
+            L.spmv_n(Ssp, tsp, ysp)
+        ms_sn = ctx.timer_end() / 10
+        by_t = 12.0 * Ssp.nnz + 8.0 * n_loc
+        by_n = 12.0 * Ssp.nnz + 8.0 * n_loc
+        sparse = {"nnz": Ssp.nnz, "nnz_per_row": k_sp, "spmv_t_ms": ms_st, "spmv_t_GBs": gbs(by_t, ms_st), "spmv_n_ms": ms_sn,
+                  "spmv_n_GBs": gbs(by_n, ms_sn), "dense_matrix_GB": 8.0 * n_loc * m / 1e9, "algorithmic_GB": by_t / 1e9}
+        Ssp.free()
+    except Exception as e:      # diagnostics only
+        sparse = {"error": repr(e)}
     rates = stream_rates(ctx, L, nbig=int(max(1 << 20, min(400_000_000, 40 * n_loc))))
-    return {"stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs": flop / gram_ms / 1e9,
+    return {"stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs": flop / gram_ms / 1e9,
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
             "nr_step_two_streams_ms": nr_ms["two_streams"], "nr_step_two_streams_GBs": gbs(nr2_bytes, nr_ms["two_streams"]),
@@ -377,19 +404,21 @@ def placements(ctx, L, n, m, n_loc, r0, R=3, its=12):
 
 def stream_rates(ctx, L, nbig=400_000_000):
     """What this box's HBM delivers to the library's own plain streaming kernels on 3.2 GB vectors (far beyond the 256 MB
-    infinity cache): read-only (a one-column GEMV-T: two input streams, result stays on the device, no host sync), copy
+    infinity cache): read-only (an 8-column GEMV-T: nine input streams, result stays on the device, no host sync), copy
     (1 read + 1 write), triad (waxpby: 2 reads + 1 write).  Context for the roofline fractions, which are quoted against
     8 TB/s; these are measurements of particular kernels, not ceilings."""
     a = ctx.vector(nbig).hash_fill(11)
     b = ctx.vector(nbig).hash_fill(12)
     c = ctx.vector(nbig)
-    col = ctx.matrix(nbig, 1).hash_fill(13, 0, nbig)
-    t1 = ctx.vector(1)
+    nrow8 = nbig // 8
+    col = ctx.matrix(nrow8, 8).hash_fill(13, 0, nrow8)          # read probe: an 8-column GEMV-T (9 input streams of nrow8 doubles)
+    a8 = ctx.vector(nrow8).hash_fill(14)
+    t1 = ctx.vector(8)
     reps = 5
-    L.gemv_t(col, a, t1); c.copy_from(a); L.waxpby(1.0, a, 2.0, b, c)
+    L.gemv_t(col, a8, t1); c.copy_from(a); L.waxpby(1.0, a, 2.0, b, c)
     ctx.timer_begin()
     for _ in range(reps):
-        L.gemv_t(col, a, t1)
+        L.gemv_t(col, a8, t1)
     ms_r = ctx.timer_end() / reps
     ctx.timer_begin()
     for _ in range(reps):
@@ -400,10 +429,10 @@ def stream_rates(ctx, L, nbig=400_000_000):
         L.waxpby(1.0, a, 2.0, b, c)
     ms_t = ctx.timer_end() / reps
     g = lambda nb, ms: nb * 8.0 * nbig / (ms * 1e-3) / 1e9
-    for v_ in (a, b, c, t1):
+    for v_ in (a, b, c, t1, a8):
         v_.free()
     col.free()
-    return {"read_GBs": g(2, ms_r), "copy_GBs": g(2, ms_c), "triad_GBs": g(3, ms_t), "vector_GB": 8.0 * nbig / 1e9}
+    return {"read_GBs": 9.0 * 8.0 * nrow8 / (ms_r * 1e-3) / 1e9, "copy_GBs": g(2, ms_c), "triad_GBs": g(3, ms_t), "vector_GB": 8.0 * nbig / 1e9}
 
 
 def cpu_baseline(ns, m, n_full):

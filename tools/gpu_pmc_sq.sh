@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_sq*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        key = "F" if "PcgFuseE" in n else ("K1" if "PcgDirF" in n else None)
+        key = "F" if "PcgFuseE" in n else ("K1" if ("PcgDirG" in n or "PcgDirF" in n) else None)
         if key: acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)
