@@ -7,7 +7,7 @@
 //   SpMV-N  y = alpha * Jct * t + beta * y     row-local: ELL by rows (K = max nonzeros of a row; val[k][row], col[k][row],
 //                                              coalesced over rows), t (m doubles) stays in cache
 //   SpMV-T  t = Jct' * v                       CSC (nonzeros of a column = of a constraint, rows ascending), cut into chunks
-//                                              of 2048 nonzeros: one workgroup per chunk, fixed-order sums -> a second kernel adds
+//                                              of 8192 nonzeros: one workgroup per chunk, fixed-order sums -> a second kernel adds
 //                                              the chunks of each column in order.  No atomics: bit-reproducible.
 //
 // Users: lfpsqp_constraints_eval (c! of linear equalities), lfpsqp_pcg (the inner solve of the default ProjPenalty
@@ -22,15 +22,24 @@
 
 namespace lfpsqp {
 
-constexpr int kSpChunk = 2048;
+constexpr int kSpChunk = 8192;
 
 __global__ __launch_bounds__(kThreads) void spmv_t_chunk_kernel(const int64_t* __restrict__ chunk_beg, const int32_t* __restrict__ row,
                                                                  const double* __restrict__ val, const double* __restrict__ v,
                                                                  double* __restrict__ partial) {
     const int64_t e0 = chunk_beg[blockIdx.x], e1 = chunk_beg[blockIdx.x + 1];
-    double acc = 0.0;
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += kThreads) acc = fma(val[e], v[row[e]], acc);
-    double red[1] = {acc};
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;          // four gathers in flight per lane; fixed association
+    int64_t e = e0 + threadIdx.x;
+    for (; e + 3 * kThreads < e1; e += 4 * kThreads) {
+        const int32_t r0 = row[e], r1 = row[e + kThreads], r2 = row[e + 2 * kThreads], r3 = row[e + 3 * kThreads];
+        const double w0 = val[e], w1 = val[e + kThreads], w2 = val[e + 2 * kThreads], w3 = val[e + 3 * kThreads];
+        a0 = fma(w0, v[r0], a0);
+        a1 = fma(w1, v[r1], a1);
+        a2 = fma(w2, v[r2], a2);
+        a3 = fma(w3, v[r3], a3);
+    }
+    for (; e < e1; e += kThreads) a0 = fma(val[e], v[row[e]], a0);
+    double red[1] = {(a0 + a1) + (a2 + a3)};
     block_reduce_store<1>(red, 0u, partial + blockIdx.x);
 }
 __global__ void spmv_t_final_kernel(const int32_t* __restrict__ col_chunk, const double* __restrict__ partial, int m, double* __restrict__ t) {
