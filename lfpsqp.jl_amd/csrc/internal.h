@@ -86,6 +86,7 @@ struct lfpsqp_ctx {
         const double *x = nullptr, *g = nullptr, *d = nullptr, *Z = nullptr;
         int m = 0;
         int64_t nv = 0, iters = 0;
+        bool gcur_is_rp = false;     // which of the two alternating residual buffers holds g
     } pcg_resume;
 
     // optional per-kernel-family profiling with HIP events on `stream`

@@ -37,6 +37,7 @@
 // "already finished?" test, so the host may enqueue one iteration ahead of the
 // status it has seen (no pipeline bubble) and extra launches are no-ops.
 #include <math.h>
+#include <stdlib.h>
 
 #include "internal.h"
 
@@ -248,7 +249,8 @@ struct PcgPost3 {  // beta, next rg, nr, convergence / iteration-limit exits (:9
 template <bool ST, bool INIT>
 struct PcgFuseE {
     const double* rp;   // stored initial residual (INIT only)
-    double* g;
+    const double* g;    // the residual this iteration reads ...
+    double* gout;       // ... and where the projected one goes: the two alternate between iterations (see lfpsqp_projcg)
     double* d;
     AOpD A;
     const double* scal;
@@ -296,7 +298,7 @@ struct PcgFuseE {
             const double gp = rr - acc;                                              // :97
             const double ag = w.ax * gp;
             if (st) {
-                put(g, o, gp);
+                put(gout, o, gp);
                 if (INIT) put(d, o, -gp);                                            // :62
             }
             const double f = (h == 0) ? rr : ((h == 1) ? gp : ((h == 2) ? ag : ad));
@@ -315,7 +317,7 @@ struct PcgFuseE {
             const double gy = ry - fma(w.sy, acc, w.Dy * ww);
             const double agx = w.ax * gx, agy = w.ay * gy;
             if (st) {
-                put(g, o, gx); put(g + k.hs, o, gy);
+                put(gout, o, gx); put(gout + k.hs, o, gy);
                 if (INIT) { put(d, o, -gx); put(d + k.hs, o, -gy); }
             }
             const double fx = (h == 0) ? rx : ((h == 1) ? gx : ((h == 2) ? agx : adx));
@@ -665,12 +667,24 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         T12 = ctx->d_m;                                  // [t1 (m); t2 (m); rp'gp; gp'gp; g'Ag; g'Ad; d'Ad]
         t3 = ctx->d_m + round_up(2 * m + 5, 2);
     }
+    // The fused kernel reads the residual of a row a tile ahead and stores the projected one a tile later.  On a box in the slow
+    // state of DESIGN.md §6, removing EITHER that load or that store of the same line made the kernel 13 % faster (1.95 -> 1.70 ms),
+    // which suggested alternating two buffers between iterations (work->g and work->rp, free after the initial projection) so
+    // that the kernel never stores to lines it has just loaded.  Measured on a fast-state box that costs 4-5 % (1.76 against
+    // 1.70 ms: the store no longer hits a line the L2 already holds), so it is OFF by default; LFPSQP_GPING=1 turns it on
+    // (same bits either way).  gcur = the buffer holding the current g.
+    static const bool kPing = getenv("LFPSQP_GPING") && atoi(getenv("LFPSQP_GPING")) == 1;
+    double* gbuf[2] = {g, (fused && kPing) ? rp : g};
+    int gcur = 0;
     auto launch_fused = [&](int init) -> int {
         const int slot = init ? -1 : 3;
-        if (stacked && init) LF_TRY((run_onepass<PcgFuseE<true, true>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<true, true>{rp, g, d, Ad, scal, istat, sk}, T12, slot)));
-        else if (stacked) LF_TRY((run_onepass<PcgFuseE<true, false>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<true, false>{rp, g, d, Ad, scal, istat, sk}, T12, slot)));
-        else if (init) LF_TRY((run_onepass<PcgFuseE<false, true>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<false, true>{rp, g, d, Ad, scal, istat, sk}, T12, slot)));
-        else LF_TRY((run_onepass<PcgFuseE<false, false>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<false, false>{rp, g, d, Ad, scal, istat, sk}, T12, slot)));
+        const double* gin = gbuf[gcur];
+        double* gout = init ? gbuf[0] : gbuf[gcur ^ 1];
+        if (stacked && init) LF_TRY((run_onepass<PcgFuseE<true, true>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<true, true>{rp, gin, gout, d, Ad, scal, istat, sk}, T12, slot)));
+        else if (stacked) LF_TRY((run_onepass<PcgFuseE<true, false>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<true, false>{rp, gin, gout, d, Ad, scal, istat, sk}, T12, slot)));
+        else if (init) LF_TRY((run_onepass<PcgFuseE<false, true>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<false, true>{rp, gin, gout, d, Ad, scal, istat, sk}, T12, slot)));
+        else LF_TRY((run_onepass<PcgFuseE<false, false>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<false, false>{rp, gin, gout, d, Ad, scal, istat, sk}, T12, slot)));
+        if (!init) gcur ^= 1;
         hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, init, hm});
         LF_LAUNCH_CHECK(ctx);
         return 0;
@@ -684,6 +698,8 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
             return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "LFPSQP_PROJCG_RESUME: no resumable projcg state for these arguments "
                            "(needs the one-pass iteration, a previous call that stopped at its iteration limit, and no library call in between)");
         it_base = rs.iters;
+        gcur = (rs.gcur_is_rp && gbuf[1] == rp) ? 1 : 0;
+        if (rs.gcur_is_rp != (gcur == 1)) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "LFPSQP_PROJCG_RESUME: the buffer scheme changed between the calls");
         maxit_eff = (it_base + maxit < n_global + m_ref) ? it_base + maxit : n_global + m_ref;
         hstat[1] = it_base;
         const int64_t lim = maxit_eff;
@@ -711,11 +727,12 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
 
     int64_t it = 0;
     bool done = false;
+    const int gcur_start = gcur;
     const int64_t it_end = maxit_eff - it_base;
     while (!done && it < it_end) {
         if (fused) {
             // one global reduction per iteration: the post-op of F has already done the exits and alpha of this iteration
-            if (it > 0 || resume) LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, g, x->p, scal, istat, 0}, 0u, nullptr, NoPost(), 0)));
+            if (it > 0 || resume) LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, gbuf[gcur], x->p, scal, istat, 0}, 0u, nullptr, NoPost(), 0)));
             LF_TRY(launch_fused(0));
         } else if (opf) {
             // generic operator: the direction update, then the user's product A d, then d'(A d); the two passes over U read A d
@@ -743,16 +760,23 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     const int64_t status = hstat[0];
     *iters = hstat[1];
     *nr = *(volatile double*)ctx->h_scal;
+    if (fused) {
+        // which buffer holds g: the host toggled once per QUEUED iteration, the device once per EXECUTED one (launches behind the
+        // exit are no-ops).  An iteration-limit / convergence exit comes after the kernel of iteration *iters, the exits at an
+        // iteration start (negative curvature, rg <= 0) before it.
+        const int64_t executed = ((status == ST_CONVERGED || status == ST_MAXIT) ? *iters : *iters - 1) - it_base;
+        gcur = (gbuf[1] != gbuf[0]) ? (int)((gcur_start + (executed > 0 ? executed : 0)) & 1) : 0;
+    }
 
     // the x-update of the last COMPLETED iteration is still pending (K1 of the next one would have applied it; in the fused
     // flow the exits of an iteration start are taken before its K1, so they leave it pending too)
     if ((status == ST_CONVERGED || status == ST_MAXIT || (fused && status == ST_RG_BREAK && *iters > 1)) && *iters > it_base)
         LF_TRY((run_vec<FlushXF, 0, NoPost>(ctx, nv, FlushXF{x->p, d, scal}, 0u, nullptr, NoPost())));
     if (fused && status == ST_MAXIT && *iters > 0)
-        ctx->pcg_resume = lfpsqp_ctx::ProjcgResume{true, x->p, g, d, Z->p, m, nv, *iters};
+        ctx->pcg_resume = lfpsqp_ctx::ProjcgResume{true, x->p, g, d, Z->p, m, nv, *iters, gcur == 1};
     if (status == ST_NEGCURV) {   // :77-82
         if (fused && *iters > 1)  // d+ = beta d - g of the iteration that found the negative curvature was not formed yet
-            LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, g, x->p, scal, istat, 1}, 0u, nullptr, NoPost())));
+            LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, gbuf[gcur], x->p, scal, istat, 1}, 0u, nullptr, NoPost())));
         LF_TRY((run_vec<SumSqF, 1, NoPost>(ctx, nv, SumSqF{d}, 0u, scal + S_DD, NoPost())));
         LF_TRY((run_vec<NormalizeIntoF, 0, NoPost>(ctx, nv, NormalizeIntoF{x->p, d, scal + S_DD}, 0u, nullptr, NoPost())));
         if (lambda) LF_TRY(lfpsqp_vec_fill(ctx, lambda, NAN));
