@@ -755,8 +755,10 @@ struct ExactLinesearchWork      # :7-14
     tmp_n2::DeviceVector
     tmp_n3::DeviceVector
     tmp_n4::DeviceVector
+    xts::Vector{DeviceVector}   # look-ahead trial points of the shrinking phase (allocated on first use)
+    xns::Vector{DeviceVector}
 end
-ExactLinesearchWork(like::DeviceVector) = ExactLinesearchWork((similar_device(like) for _ in 1:4)...)
+ExactLinesearchWork(like::DeviceVector) = ExactLinesearchWork((similar_device(like) for _ in 1:4)..., DeviceVector[], DeviceVector[])
 
 # armijo!(xnew, x, n, d, g, f, fval, retract_method, cval, c!, param, work) (src/linesearch.jl:32-89).  After the first failed
 # retraction of a search (or from its first trial when the previous search had failures) the next `ls_batch` trial steps of the
@@ -849,6 +851,44 @@ function exact_linesearch!(xnew::DeviceVector, x::DeviceVector, n::Int, d::Devic
         copyto!(pt, xnew)
         return fl
     end
+    # Shrinking phase (:176-208): the trial steps a_c φ1, a_c φ1², ... are a fixed sequence from the same x, and where it runs most of
+    # them fail after the full iteration limit: the next `ls_batch` are retracted together and consumed in the reference's order.
+    nbatch = (retract_method isa NR && c! isa DeviceConstraints) ? param.ls_batch : 1
+    ahead = Dict{Float64,Tuple{Int,Int,Int,DeviceVector,Vector{Float64}}}()
+    retract_shrink! = function (pt::DeviceVector, a_next::Float64)
+        if haskey(ahead, a_next)
+            fl, i1, i2, xb, cb = pop!(ahead, a_next)
+            copyto!(xnew, xb); cval .= cb; copyto!(pt, xnew)
+            tot1 += i1; tot2 += i2
+            return fl
+        end
+        if nbatch > 1
+            while length(work.xts) < nbatch
+                push!(work.xts, similar_device(x)); push!(work.xns, similar_device(x))
+            end
+            αs = [a_next]
+            for k in 2:nbatch
+                push!(αs, αs[end] * φ1)                       # the reference's own products α_c *= ϕ1
+            end
+            copyto!(work.xts[1], pt)
+            for k in 2:nbatch
+                waxpby!(work.xts[k], 1.0, x, αs[k], d)
+            end
+            cvs = zeros(length(cval), nbatch)
+            got = retract_nr_batch!(cvs, work.xns[1:nbatch], c!, work.xts[1:nbatch], x, retract_method)
+            if got !== nothing
+                for k in 2:nbatch
+                    ahead[αs[k]] = (got[k][1], got[k][2], got[k][3], work.xns[k], cvs[:, k])
+                end
+                fl, i1, i2 = got[1]
+                copyto!(xnew, work.xns[1]); cval .= cvs[:, 1]; copyto!(pt, xnew)
+                tot1 += i1; tot2 += i2
+                return fl
+            end
+            nbatch = 1
+        end
+        return retract_pt!(pt)
+    end
     copyto!(x_d, x); f_d = fval
     while true
         x_b, x_c, x_d = x_c, x_d, x_b
@@ -875,7 +915,7 @@ function exact_linesearch!(xnew::DeviceVector, x::DeviceVector, n::Int, d::Devic
             x_d, x_c = x_c, x_d
             f_d = f_c; a_d = a_c
             waxpby!(x_c, 1.0, x, φ1 * a_c, d)
-            flag = retract_pt!(x_c)
+            flag = retract_shrink!(x_c, φ1 * a_c)
             a_c *= φ1
             f_c = (flag > 0 || a_c > 1.0) ? Inf : f(x_c)
             (f_c <= fval || a_c < 1e-100) && break

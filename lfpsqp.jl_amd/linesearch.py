@@ -24,7 +24,14 @@ class ArmijoWork:  # src/linesearch.jl:1-5
 class ExactLinesearchWork:  # :7-14
     def __init__(self, like: DeviceVector):
         mk = (lambda: like.__class__(like.ctx, like.N)) if hasattr(like, "N") else (lambda: DeviceVector(like.ctx, like.n))
+        self._mk = mk
         self.tmp_n1, self.tmp_n2, self.tmp_n3, self.tmp_n4 = mk(), mk(), mk(), mk()
+        self.batch = None          # lazily: (xtildes, xnews) for batched trial retractions of the shrinking phase
+
+    def batch_vectors(self, k):
+        if self.batch is None or len(self.batch[0]) < k:
+            self.batch = ([self._mk() for _ in range(k)], [self._mk() for _ in range(k)])
+        return self.batch
 
 
 def _step_norm(step, n_head):
@@ -126,6 +133,49 @@ def exact_linesearch_(xnew, x, n, d, f, fval, retract_method, cval, c_, param, w
         pt.copy_from(xnew)
         return fl
 
+    # Shrinking phase (:176-208): the trial steps a_c*phi1, a_c*phi1^2, ... are a fixed sequence, each retracted from the same x,
+    # and in the regime where it runs (the first trial of the search failed) most of them fail after the full iteration limit.
+    # The next `ls_batch` of them are retracted together (lfpsqp_retract_nr_batch: one pass over Jct per Newton step for all) and
+    # consumed in the reference's order -- same points, flags and counts as one by one; unconsumed look-ahead is not counted.
+    from .retractions import NR as _NR, DeviceConstraints as _DC
+    nbatch = int(getattr(param, "ls_batch", 1)) if (isinstance(retract_method, _NR) and isinstance(c_, _DC)) else 1
+    ahead = {}
+
+    def _retract_shrink(pt, a_next):
+        """retract x + a_next*d into pt (pt already holds xtilde), looking ahead along a_next*phi1^k"""
+        nonlocal nbatch
+        if a_next in ahead:
+            fl, i1, i2, xb, cb = ahead.pop(a_next)
+            xnew.copy_from(xb)
+            cval[:] = cb
+            pt.copy_from(xnew)
+            tot[0] += i1
+            tot[1] += i2
+            return fl
+        if nbatch > 1:
+            import numpy as _np
+            xts, xns = work.batch_vectors(nbatch)
+            alphas = [a_next]
+            for _ in range(nbatch - 1):
+                alphas.append(alphas[-1] * phi1)          # the reference's own products a_c *= phi1 (:196)
+            xts[0].copy_from(pt)
+            for a_, xt_ in zip(alphas[1:], xts[1:]):
+                waxpby(1.0, x, a_, d, xt_)
+            cvs = _np.zeros((nbatch, len(cval)))
+            got = retract_nr_batch_(cvs, xns, c_, xts, x, retract_method)
+            if got is not None:
+                for a_, res, xb, cb in zip(alphas[1:], got[1:], xns[1:], cvs[1:]):
+                    ahead[a_] = (res[0], res[1], res[2], xb, cb.copy())
+                fl, i1, i2 = got[0]
+                xnew.copy_from(xns[0])
+                cval[:] = cvs[0]
+                pt.copy_from(xnew)
+                tot[0] += i1
+                tot[1] += i2
+                return fl
+            nbatch = 1                                     # this configuration cannot batch
+        return _retract(pt)
+
     x_d.copy_from(x)
     f_d = fval
     while True:
@@ -155,7 +205,7 @@ def exact_linesearch_(xnew, x, n, d, f, fval, retract_method, cval, c_, param, w
             f_d = f_c
             a_d = a_c
             waxpby(1.0, x, phi1 * a_c, d, x_c)
-            flag = _retract(x_c)
+            flag = _retract_shrink(x_c, phi1 * a_c)
             a_c *= phi1
             f_c = math.inf if (flag > 0 or a_c > 1.0) else f(x_c)
             if f_c <= fval or a_c < 1e-100:

@@ -669,3 +669,36 @@ def test_armijo_with_batched_trial_retractions_is_the_same_search(dev_ctx):
     fork = _compare_traces(tr4, tr1, rtol=1e-11, failed_retractions_may_differ=not emu)
     if fork is None:
         assert np.linalg.norm(x4 - x1) <= 1e-10 * np.linalg.norm(x1)
+
+
+def test_exact_linesearch_with_batched_shrinking_is_the_same_search(dev_ctx):
+    """LFPSQPParams.ls_batch with linesearch = exact: the trial steps of the SHRINKING phase (src/linesearch.jl:176-208, a fixed
+    sequence a_c*phi1^k from the same x -- the phase that runs when the first trial retraction fails) are retracted together
+    and consumed in the reference's order: accepted step, counts and iterates of the one-by-one search, and of the oracle."""
+    ctx = dev_ctx
+    emu = _is_emu(ctx)
+    n, m = (150, 4) if emu else (4000, 16)
+    mr = 30 if emu else 100
+    maxiter = 2 if emu else 4
+    P0 = synth.BallBoxProblem(n, m)                       # from P0.x0 the first linesearches fail repeatedly (config 4's regime)
+    res = {}
+    for k in (1, 4):
+        Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+        P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
+        tr = []
+        x, obj, lam, ti = P.optimize(P0.x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=maxiter, maxiter_retract=mr,
+                                                           ls_batch=k, linesearch=L.LinesearchOption.exact), trace=tr)
+        res[k] = (tr, x, ti)
+    tr1, x1, ti1 = res[1]
+    tr4, x4, ti4 = res[4]
+    assert ti1.iter == ti4.iter and len(tr1) == len(tr4)
+    assert any((t.get('retract_iter1') or 0) >= mr for t in tr1)           # the regime with failed retractions was reached
+    fork = _compare_traces(tr4, tr1, rtol=1e-11, failed_retractions_may_differ=not emu)
+    if fork is None:
+        assert np.linalg.norm(x4 - x1) <= 1e-10 * np.linalg.norm(x1)
+    if emu:
+        tr0 = []
+        R.optimize(P0.f, P0.c_, P0.d_, P0.x0, P0.xl, P0.xu, P0.m, P0.p,
+                   R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=maxiter, maxiter_retract=mr,
+                                  linesearch=R.LinesearchOption.exact), derivatives=P0.derivatives(), trace=tr0)
+        assert _compare_traces(tr4, tr0, rtol=1e-9) is None
