@@ -129,6 +129,13 @@ int lfpsqp_vec_fill_range(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t offset, int64_
 int lfpsqp_affine_head(lfpsqp_ctx* ctx, double a, const lfpsqp_vec* x, double c, int64_t count, lfpsqp_vec* y);
 /* *out = sum_{i < count} (x[i] - c)^2   (all-reduced): quadratic objectives */
 int lfpsqp_sumsq_shift(lfpsqp_ctx* ctx, const lfpsqp_vec* x, int64_t count, double c, double* out);
+/* Separable objectives f(x) = sum_{i < count} phi(x_i - c_i; a_i) of device-resident problem classes (the analogue of the
+ * reference's user f / grad! / the diagonal of hess_lag_vec!, src/autodiff_generators.jl:72-107, for objectives that need no AD):
+ *   kind 0: a t^2      kind 1: a t^4 + t^2      kind 2: a (sqrt(1 + t^2) - 1)  (pseudo-Huber)
+ *   mode 0: *out_sum = f (all-reduced);  mode 1: out_vec[i] = phi'(x_i);  mode 2: out_vec[i] = phi''(x_i)  (entries >= count untouched)
+ * a / c: per-variable parameter vectors, or NULL for the constants a0 / c0. */
+int lfpsqp_separable(lfpsqp_ctx* ctx, int kind, int mode, const lfpsqp_vec* a, double a0, const lfpsqp_vec* c, double c0,
+                     const lfpsqp_vec* x, int64_t count, lfpsqp_vec* out_vec, double* out_sum);
 /* sum-all-reduce a replicated-partials device vector across ranks (no-op for 1 rank) */
 int lfpsqp_allreduce(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t count);
 

@@ -141,6 +141,7 @@ c_waxpby(ctx, a, x, b, y, z) = ccall((:lfpsqp_waxpby, lib), Cint, (Ptr{Cvoid}, F
 c_vmul(ctx, d, x, y) = ccall((:lfpsqp_vmul, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, d, x, y)
 c_affine_head(ctx, a, x, c, count, y) = ccall((:lfpsqp_affine_head, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Int64, Ptr{Cvoid}), ctx, a, x, c, count, y)
 c_sumsq_shift(ctx, x, count, c, out) = ccall((:lfpsqp_sumsq_shift, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Ref{Float64}), ctx, x, count, c, out)
+c_separable(ctx, kind, mode, a, a0, c, c0, x, count, outv, outs) = ccall((:lfpsqp_separable, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Float64}), ctx, kind, mode, a, a0, c, c0, x, count, outv, outs)
 c_allreduce(ctx, v, count) = ccall((:lfpsqp_allreduce, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), ctx, v, count)
 # ---- sparse constraint gradients ---------------------------------------------------------------------------------------------
 c_spmat_create(ctx, n, m, nnz, rows, cols, vals, out) = ccall((:lfpsqp_spmat_create, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ref{Ptr{Cvoid}}), ctx, n, m, nnz, rows, cols, vals, out)
@@ -1205,6 +1206,57 @@ function optimize(P::QuadLinearBallBox, x0::Vector{Float64}, param::LFPSQPParams
     return x[1:P.n], obj, λ, info
 end
 
+# ---- a second device-resident class: separable objective f(x) = Σ φ(x_i - c_i; a_i) (lfpsqp_separable) under the same constraints ----
+# kind 0: a t², 1: a t⁴ + t², 2: a (√(1 + t²) - 1); f, grad! and the diagonal Lagrangian Hessian φ''(x_i) + 2 λ_ball are elementwise kernels
+struct SeparableLinearBallBox
+    base::QuadLinearBallBox
+    kind::Int
+    a::DeviceVector
+    c::DeviceVector
+    lamvec::DeviceVector        # scratch: 2 λ_ball on the user's variables
+end
+function SeparableLinearBallBox(ctx::HipContext, n::Int, m::Int, Jct::DeviceMatrix, b::Vector{Float64}, kind::Int, a::Vector{Float64}, c::Vector{Float64}; kw...)
+    base = QuadLinearBallBox(ctx, n, m, Jct, b; kw...)
+    return SeparableLinearBallBox(base, kind, upload!(DeviceVector(ctx, n), a), upload!(DeviceVector(ctx, n), c), DeviceVector(ctx, n + base.ploc))
+end
+function objective(P::SeparableLinearBallBox, x::DeviceVector)
+    out = Ref{Float64}(0.0)
+    check(P.base.ctx, c_separable(P.base.ctx.h, Cint(P.kind), Cint(0), P.a.h, 0.0, P.c.h, 0.0, x.h, Int64(P.base.n), C_NULL, out))
+    return out[]
+end
+function gradient!(P::SeparableLinearBallBox, g::DeviceVector, x::DeviceVector)
+    check(P.base.ctx, c_separable(P.base.ctx.h, Cint(P.kind), Cint(1), P.a.h, 0.0, P.c.h, 0.0, x.h, Int64(P.base.n), g.h, Ptr{Float64}(C_NULL)))
+    P.base.ploc == 1 && fill_range!(g, P.base.n, 1, 0.0)
+    return g
+end
+function hess_diag!(P::SeparableLinearBallBox, hx::DeviceVector, x::DeviceVector, λ::Vector{Float64})
+    B = P.base
+    check(B.ctx, c_separable(B.ctx.h, Cint(P.kind), Cint(2), P.a.h, 0.0, P.c.h, 0.0, x.h, Int64(B.n), hx.h, Ptr{Float64}(C_NULL)))
+    if B.p == 1
+        fill_range!(P.lamvec, 0, B.n, 2.0 * λ[B.m+1])
+        check(B.ctx, c_axpby(B.ctx.h, 1.0, P.lamvec.h, 1.0, hx.h))
+    end
+    B.ploc == 1 && fill_range!(hx, B.n, 1, 0.0)
+    return hx
+end
+function optimize(P::SeparableLinearBallBox, x0::Vector{Float64}, param::LFPSQPParams=LFPSQPParams())
+    B = P.base
+    x0a, xl, xu = x0, B.xl, B.xu
+    if B.p == 1
+        tmp = upload!(DeviceVector(B.ctx, B.n), x0)
+        out = Ref{Float64}(0.0)
+        check(B.ctx, c_sumsq_shift(B.ctx.h, tmp.h, Int64(B.n), 0.0, out))
+        xl = B.xl === nothing ? fill(-Inf, B.n) : B.xl
+        xu = B.xu === nothing ? fill(Inf, B.n) : B.xu
+        if B.ploc == 1
+            x0a = vcat(x0, out[] - B.R2); xl = vcat(xl, -Inf); xu = vcat(xu, 0.0)
+        end
+    end
+    x, obj, λ, info = optimize_core(B.ctx, x -> objective(P, x), (g, x) -> gradient!(P, g, x), B.cons, (J, cv, x) -> jac!(B.cons, J, cv, x), P,
+                                    x0a, xl, xu, B.m + B.p, param; n_global=B.n_global + B.p)
+    return x[1:B.n], obj, λ, info
+end
+
 # ---- the reference's method table with arbitrary HOST callables (src/optimize.jl:13, 83, 88, 107, 112, 119) --------------------
 # Iterates are downloaded for every user call: plumbing / small problems (config 1), not the 1e7-variable configs.
 # The AD generators (src/autodiff_generators.jl) stay where they are: pass their outputs (grad!, jac!, hess_lag_vec!) here.
@@ -1270,7 +1322,7 @@ optimize(ctx::HipContext, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, x0::V
 
 export HipContext, HipError, DeviceVector, StackedVector, DeviceMatrix, SparseMatrix, spmv_t!, spmv_n!, to_dense!, DeviceBasis, DiagOperator, InequalityData, InequalityDecomp,
        InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
-       ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, upload!, download, upload2!, download2, projcg!, retract!,
+       ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, upload!, download, upload2!, download2, projcg!, retract!,
        retract_nr_batch!, pcg!, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!,
        shard_range, sync
 

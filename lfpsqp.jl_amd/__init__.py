@@ -16,4 +16,4 @@ from .retractions import NR, DeviceConstraints, Euclidean, NRWork, YRetract, ret
 from .projpenalty import ProjPenalty, ProjPenaltyWork, no_precondition, pcg_, proj_precondition_  # noqa: F401
 from .linesearch import ArmijoWork, ExactLinesearchWork, armijo_, exact_linesearch_  # noqa: F401
 from .optimize import optimize_core  # noqa: F401
-from .problems import Derivatives, QuadLinearBallBox, optimize  # noqa: F401
+from .problems import Derivatives, QuadLinearBallBox, SeparableLinearBallBox, optimize  # noqa: F401

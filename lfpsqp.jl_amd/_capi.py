@@ -108,6 +108,7 @@ _SIGS = {
     "lfpsqp_pcg": [P, c_dbl, C.POINTER(Basis), P, P, P, P, P, P, c_dbl, c_i64, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_retract_pp": [P, C.POINTER(Constraints), CFUN, JACFUN, P, P, c_i64, C.POINTER(IneqData), P, P, P, P, P, P, c_dbl, c_dbl, c_i64,
                           c_i64, C.POINTER(PPWork), PD, C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)],
+    "lfpsqp_separable": [P, C.c_int, C.c_int, P, c_dbl, P, c_dbl, P, c_i64, P, PD],
     "lfpsqp_spmat_create": [P, c_i64, c_i64, c_i64, P, P, P, C.POINTER(P)],
     "lfpsqp_spmat_free": [P, P],
     "lfpsqp_spmat_info": [P, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64)],

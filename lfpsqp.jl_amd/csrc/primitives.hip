@@ -156,6 +156,38 @@ __global__ __launch_bounds__(kThreads) void hash_mat_kernel(double* M, int64_t l
     }
 }
 
+// ---- separable objectives f(x) = sum_i phi(x_i; a_i, c_i) of the device-resident problem classes -----------
+//   kind 0: a (x-c)^2            kind 1: a (x-c)^4 + (x-c)^2            kind 2: a (sqrt(1 + (x-c)^2) - 1)   (pseudo-Huber)
+// mode 0: partial sums of phi; 1: out = phi'(x) ; 2: out = phi''(x) -- elementwise, no transcendental functions (the
+// same bits as a numpy evaluation up to the rounding of sqrt and the summation order).
+__device__ __forceinline__ double sep_eval(int kind, int mode, double a, double t) {   // t = x - c
+    if (kind == 0) return mode == 0 ? a * t * t : (mode == 1 ? 2.0 * a * t : 2.0 * a);
+    if (kind == 1) {
+        const double t2 = t * t;
+        return mode == 0 ? fma(a * t2, t2, t2) : (mode == 1 ? fma(4.0 * a * t2, t, 2.0 * t) : fma(12.0 * a, t2, 2.0));
+    }
+    const double s = sqrt(fma(t, t, 1.0));
+    return mode == 0 ? a * (s - 1.0) : (mode == 1 ? a * t / s : a / (s * s * s));
+}
+struct SepF {
+    int kind, mode;
+    const double *a, *c, *x;   // a, c: per-variable parameters (may be null: a = a0, c = c0)
+    double a0, c0;
+    double* out;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double2 xx = ld2(x + i);
+        const double2 aa = a ? ld2(a + i) : make_double2(a0, a0), cc = c ? ld2(c + i) : make_double2(c0, c0);
+        const double r0 = v0 ? sep_eval(kind, mode, aa.x, xx.x - cc.x) : 0.0, r1 = v1 ? sep_eval(kind, mode, aa.y, xx.y - cc.y) : 0.0;
+        if (mode == 0) {
+            red[0] += r0 + r1;
+        } else {
+            if (v1) st2(out + i, make_double2(r0, r1));
+            else if (v0) out[i] = r0;
+        }
+    }
+};
+
 }  // namespace lfpsqp
 
 using namespace lfpsqp;
@@ -272,6 +304,19 @@ int lfpsqp_sumsq_shift(lfpsqp_ctx* ctx, const lfpsqp_vec* x, int64_t count, doub
 int lfpsqp_allreduce(lfpsqp_ctx* ctx, lfpsqp_vec* v, int64_t count) {
     LF_ARG(ctx, ctx && v && count >= 0 && count <= v->n);
     return allreduce_dev(ctx, v->p, count, 0);
+}
+
+int lfpsqp_separable(lfpsqp_ctx* ctx, int kind, int mode, const lfpsqp_vec* a, double a0, const lfpsqp_vec* c, double c0, const lfpsqp_vec* x,
+                     int64_t count, lfpsqp_vec* out_vec, double* out_sum) {
+    LF_ARG(ctx, ctx && x && kind >= 0 && kind <= 2 && mode >= 0 && mode <= 2 && count >= 0 && count <= x->n && (!a || a->n >= count) &&
+                    (!c || c->n >= count) && (mode == 0 ? out_sum != nullptr : (out_vec && out_vec->n >= count)));
+    const SepF f{kind, mode, a ? a->p : nullptr, c ? c->p : nullptr, x->p, a0, c0, out_vec ? out_vec->p : nullptr};
+    if (mode == 0) {
+        LF_TRY((run_vec<SepF, 1, NoPost>(ctx, count, f, 0u, ctx->scal + 32, NoPost())));
+        return read_back(ctx, ctx->scal + 32, out_sum, 1);
+    }
+    if (count == 0) return 0;
+    return run_vec<SepF, 0, NoPost>(ctx, count, f, 0u, nullptr, NoPost());
 }
 
 }  // extern "C"

@@ -87,6 +87,66 @@ class QuadLinearBallBox:
         return x[:self.n], obj, lam, ti
 
 
+class SeparableLinearBallBox(QuadLinearBallBox):
+    """A second device-resident problem class: a SEPARABLE objective f(x) = sum_i phi(x_i - c_i; a_i) with per-variable
+    parameters -- ``kind`` 0: a t^2, 1: a t^4 + t^2, 2: a (sqrt(1 + t^2) - 1) (pseudo-Huber) -- under the same constraint set as
+    :class:`QuadLinearBallBox` (dense or sparse linear equalities, optional ball with slack, optional box).  f, grad! and the
+    diagonal of the Lagrangian Hessian phi''(x_i) + 2 lam_ball are elementwise kernels (lfpsqp_separable), so the whole
+    `optimize` run stays on the device and uses the fused projected-CG path; unlike the quadratic class the Hessian changes with x
+    and the truncated-Newton solves take several iterations."""
+
+    def __init__(self, ctx: Context, n: int, m: int, Jct: DeviceMatrix, b, kind: int, a, c=0.0, **kw):
+        super().__init__(ctx, n, m, Jct, b, **kw)
+        self.kind = int(kind)
+        self.a_dev = None if np.isscalar(a) else ctx.vector(n, np.asarray(a, dtype=np.float64))
+        self.c_dev = None if np.isscalar(c) else ctx.vector(n, np.asarray(c, dtype=np.float64))
+        self.a0 = float(a) if np.isscalar(a) else 0.0
+        self.c0 = float(c) if np.isscalar(c) else 0.0
+
+    def _sep(self, mode, x, out_vec=None):
+        out = C.c_double()
+        L = self.ctx.L
+        self.ctx.check(L.lfpsqp_separable(self.ctx.h, self.kind, mode, self.a_dev.h if self.a_dev is not None else None, self.a0,
+                                          self.c_dev.h if self.c_dev is not None else None, self.c0, x.h, self.n,
+                                          out_vec.h if out_vec is not None else None, C.byref(out)))
+        return out.value
+
+    def f(self, x: DeviceVector) -> float:
+        return self._sep(0, x)
+
+    def grad_(self, g: DeviceVector, x: DeviceVector):
+        self._sep(1, x, g)
+        if self.ploc:
+            self.ctx.check(self.ctx.L.lfpsqp_vec_fill_range(self.ctx.h, g.h, self.n, 1, 0.0))      # the slack variable is not in f
+
+    def diag_(self, hx: DeviceVector, x: DeviceVector, lam: np.ndarray):
+        self._sep(2, x, hx)
+        if self.p:                                                                                  # + 2 lam_ball on the user's variables
+            ones = getattr(self, "_lamvec", None)
+            if ones is None:
+                ones = self._lamvec = self.ctx.vector(hx.n)
+            L = self.ctx.L
+            self.ctx.check(L.lfpsqp_vec_fill_range(self.ctx.h, ones.h, 0, self.n, 2.0 * float(lam[self.m])))
+            from .device import axpby
+            axpby(1.0, ones, 1.0, hx)
+        if self.ploc:
+            self.ctx.check(self.ctx.L.lfpsqp_vec_fill_range(self.ctx.h, hx.h, self.n, 1, 0.0))
+
+    def aux_start(self, x0):
+        x0 = np.asarray(x0, dtype=np.float64)
+        if not self.p:
+            return x0, self.xl, self.xu
+        tmp = self.ctx.vector(self.n, x0)                       # global x0'x0 through the quadratic kernel
+        out = C.c_double()
+        self.ctx.check(self.ctx.L.lfpsqp_sumsq_shift(self.ctx.h, tmp.h, self.n, 0.0, C.byref(out)))
+        tmp.free()
+        xl = -np.inf * np.ones(self.n) if self.xl is None else self.xl
+        xu = np.inf * np.ones(self.n) if self.xu is None else self.xu
+        if not self.ploc:
+            return x0, xl, xu
+        return np.concatenate([x0, [out.value - self.R2]]), np.concatenate([xl, [-np.inf]]), np.concatenate([xu, [0.0]])
+
+
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class Derivatives:

@@ -702,3 +702,70 @@ def test_exact_linesearch_with_batched_shrinking_is_the_same_search(dev_ctx):
                    R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=maxiter, maxiter_retract=mr,
                                   linesearch=R.LinesearchOption.exact), derivatives=P0.derivatives(), trace=tr0)
         assert _compare_traces(tr4, tr0, rtol=1e-9) is None
+
+
+def _sep_host(kind, a, c):
+    """phi, phi', phi'' of lfpsqp_separable on the host (the oracle side of SeparableLinearBallBox)"""
+    def phi(x):
+        t = x - c
+        if kind == 0: return a * t * t
+        if kind == 1: return a * t ** 4 + t * t
+        return a * (np.sqrt(1.0 + t * t) - 1.0)
+
+    def d1(x):
+        t = x - c
+        if kind == 0: return 2.0 * a * t
+        if kind == 1: return 4.0 * a * t ** 3 + 2.0 * t
+        return a * t / np.sqrt(1.0 + t * t)
+
+    def d2(x):
+        t = x - c
+        if kind == 0: return 2.0 * a * np.ones_like(t)
+        if kind == 1: return 12.0 * a * t * t + 2.0
+        return a / np.sqrt(1.0 + t * t) ** 3
+    return phi, d1, d2
+
+
+@pytest.mark.parametrize("kind,with_ball_box", [(1, False), (2, True), (1, True)])
+def test_separable_objective_problem_class(dev_ctx, kind, with_ball_box):
+    """SeparableLinearBallBox (a second device-resident problem class): non-quadratic separable objectives with
+    per-variable parameters under dense equalities (+ ball in slack form + box).  f, grad! and the diagonal Lagrangian Hessian are
+    device kernels; the trajectory -- truncated-Newton iteration counts included, the Hessian now changes with x -- is the
+    oracle's with the same functions evaluated in numpy."""
+    ctx = dev_ctx
+    emu = _is_emu(ctx)
+    n, m = (240, 4) if emu else (6000, 16)
+    maxiter = 4 if emu else 12
+    a = 0.5 + synth.hash_vector(21, n) ** 2
+    c = 0.3 * synth.hash_vector(22, n)
+    phi, d1, d2 = _sep_host(kind, a, c)
+    P0 = synth.BallBoxProblem(n, m)
+    x0 = 0.9 * synth.hash_vector(2, n) + 0.1 * P0.x0 if with_ball_box else synth.hash_vector(2, n)
+    f = lambda x: float(np.sum(phi(x[:n])))
+
+    def grad_(g, x):
+        g[:n] = d1(x[:n])
+
+    tr0, tr = [], []
+    if with_ball_box:
+        dv0 = P0.derivatives()
+
+        def hlv_(dest, src, x, lam):
+            dest[:] = (d2(x) + 2.0 * lam[m]) * src
+        xr, objr, lamr, tir = R.optimize(f, P0.c_, P0.d_, x0, P0.xl, P0.xu, m, 1,
+                                         R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=maxiter, tn_kappa=1e-6),
+                                         derivatives=R.Derivatives(grad_=grad_, hess_lag_vec_=hlv_, jac_c_=dv0.jac_c_, jac_d_=dv0.jac_d_), trace=tr0)
+        Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+        P = L.SeparableLinearBallBox(ctx, n, m, Jct, P0.eq.b, kind, a, c, R2=P0.R2, xl=P0.xl, xu=P0.xu)
+    else:
+        def hlv_(dest, src, x, lam):
+            dest[:] = d2(x) * src
+        xr, objr, lamr, tir = R.optimize(f, grad_, P0.eq.c_, P0.eq.jac_, hlv_, x0, None, None, m,
+                                         R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=maxiter, tn_kappa=1e-6), trace=tr0)
+        P = L.SeparableLinearBallBox(ctx, n, m, ctx.matrix(n, m).hash_fill(1), P0.eq.b, kind, a, c)
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=maxiter, tn_kappa=1e-6), trace=tr)
+    assert ti.iter == tir.iter and ti.condition.name == tir.condition.name
+    assert any((t.get('tn_iter') or 0) > 1 for t in tr0)                       # the Newton systems are not solved in one iteration here
+    assert _compare_traces(tr, tr0, rtol=1e-9) is None
+    np.testing.assert_allclose(obj, objr, rtol=1e-11)
+    np.testing.assert_allclose(lam, lamr, rtol=1e-6, atol=1e-9)
