@@ -40,14 +40,17 @@ __device__ __forceinline__ void tile_mfma(const double (*As)[kLdsLd], const doub
     }
 }
 
-// Gram partials.  grid = (G row-step groups, npan*npan panel pairs).  Block (g, pp) sums the
+// Gram partials.  grid = (G row-step groups, npan*(npan+1)/2 panel pairs pi <= pj).  Block (g, pp) sums the
 // 16-row steps g, g+G, ... of panel pair (pi, pj) and writes its 128 x 128 partial to
 // part[g][pp*16384 + j*128 + i]  (i = row of G within panel pi, j = column within panel pj).
 __global__ __launch_bounds__(kThreads) void gram_kernel(const double* __restrict__ M, int64_t ld, int64_t n, int ncols, int npan,
                                                          const double* __restrict__ w2, double* __restrict__ part, int64_t part_ld) {
     __shared__ double As[kKStep][kLdsLd];
     __shared__ double Bs[kKStep][kLdsLd];
-    const int pi = blockIdx.y / npan, pj = blockIdx.y % npan;
+    // panel pair (pi <= pj): the Gram matrix is symmetric, only the upper block triangle is computed (10 of 16 pairs at m = 512)
+    int pi = 0, pj = (int)blockIdx.y;
+    while (pj >= npan - pi) { pj -= npan - pi; ++pi; }
+    pj += pi;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     f64x4 acc[2][8];
 #pragma unroll
@@ -273,13 +276,14 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     const int border = (ncols_all > kPanel && rem > 0 && rem <= 4) ? rem : 0;
     const int ncols = ncols_all - border;
     const int npan = (ncols + kPanel - 1) / kPanel;
-    const int64_t pp = (int64_t)npan * npan * kPanel * kPanel;
+    const int npair = npan * (npan + 1) / 2;
+    const int64_t pp = (int64_t)npair * kPanel * kPanel;
     const int64_t nsteps = (M->n + kKStep - 1) / kKStep;
     const int64_t gmax = 2 * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 128);     // two workgroups per CU: one stages while the other multiplies
     int groups = (int)(nsteps < gmax ? (nsteps < 1 ? 1 : nsteps) : gmax);
     LF_TRY(ensure_part(ctx, (size_t)groups * pp));
     LF_TRY(ensure_small(ctx, (size_t)pp));
-    hipLaunchKernelGGL(gram_kernel, dim3(groups, npan * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2,
+    hipLaunchKernelGGL(gram_kernel, dim3(groups, npair), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2,
                        ctx->part, pp);
     LF_LAUNCH_CHECK(ctx);
     // reduce the `groups` partials (pp columns: 32 per workgroup)
@@ -290,19 +294,23 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     std::vector<double> h((size_t)pp);
     LF_HIP(ctx, hipMemcpyAsync(h.data(), ctx->small, sizeof(double) * pp, hipMemcpyDeviceToHost, ctx->stream));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int pi = 0; pi < npan; ++pi)
-        for (int pj = 0; pj < npan; ++pj) {
-            const double* blk = h.data() + ((size_t)pi * npan + pj) * kPanel * kPanel;
-            for (int j = 0; j < kPanel; ++j) {
-                const int gj = pj * kPanel + j;
-                if (gj >= ncols) break;
-                for (int i = 0; i < kPanel; ++i) {
-                    const int gi = pi * kPanel + i;
-                    if (gi >= ncols) break;
-                    G[(size_t)gj * ncols_all + gi] = blk[j * kPanel + i];
+    {
+        size_t pidx = 0;
+        for (int pi = 0; pi < npan; ++pi)
+            for (int pj = pi; pj < npan; ++pj, ++pidx) {
+                const double* blk = h.data() + pidx * kPanel * kPanel;
+                for (int j = 0; j < kPanel; ++j) {
+                    const int gj = pj * kPanel + j;
+                    if (gj >= ncols) break;
+                    for (int i = 0; i < kPanel; ++i) {
+                        const int gi = pi * kPanel + i;
+                        if (gi >= ncols) break;
+                        G[(size_t)gj * ncols_all + gi] = blk[j * kPanel + i];
+                        if (pi != pj) G[(size_t)gi * ncols_all + gj] = blk[j * kPanel + i];      // the mirrored block
+                    }
                 }
             }
-        }
+    }
     if (border > 0) {
         LF_TRY(ensure_mvec(ctx, (size_t)ncols_all + 8));
         for (int j = ncols; j < ncols_all; ++j) {

@@ -7,8 +7,9 @@
 // into LDS, runs one complete cyclic sweep over those 2B columns there (2B-1 local rounds of B disjoint column pairs, a
 // group of 256/B lanes per pair: dot products over the lanes' rows, one rotation, a barrier) and writes the columns
 // back.  One launch = one round of the circle-method tournament over the blocks (nb/2 disjoint block pairs = nb/2
-// workgroups, no communication between them); nb-1 launches = one sweep in which every pair of columns has met at least
-// once.  Launch boundaries are the only grid-wide synchronisation, so the same code runs on the CPU emulator.
+// workgroups, no communication between them).  A sweep = an opening launch in which neighbouring blocks run a full cyclic sweep
+// over their union (all pairs inside a block meet there) + the nb-1 tournament rounds restricted to the CROSS pairs of a block
+// pair (B local rounds instead of 2B-1): every pair of columns meets at least once per sweep.  Launch boundaries are the only grid-wide synchronisation, so the same code runs on the CPU emulator.
 //   Rotations act on rows [0, rows_all), the dot products that define them use rows [0, rows_dot): with X stacked on an
 // identity, [X; I], the lower half accumulates the right singular vectors for free.
 //   Convergence: every rotated pair reports |p.q| / (|p||q|); the largest value of a sweep lands in off[sweep] (an
@@ -100,7 +101,12 @@ __global__ __launch_bounds__(B* LPP) void jacobi_round_kernel(double* __restrict
     __shared__ double cols[2 * B][LD];
     __shared__ double offw[THREADS / 64];
     const int tid = threadIdx.x;
-    const int bp = circle_player(blockIdx.x, round, nb), bq = circle_player(nb - 1 - blockIdx.x, round, nb);
+    // round < 0: the sweep's opening launch -- neighbouring blocks (2k, 2k+1), a FULL cyclic sweep over their 2B columns (this is where
+    // the pairs inside a block meet); round >= 0: round of the block tournament, CROSS pairs only (column i of one block with every
+    // column of the other: B local rounds instead of 2B-1)
+    const bool full = round < 0;
+    const int bp = full ? 2 * (int)blockIdx.x : circle_player(blockIdx.x, round, nb);
+    const int bq = full ? 2 * (int)blockIdx.x + 1 : circle_player(nb - 1 - blockIdx.x, round, nb);
     // load the two blocks: a wave takes whole columns, 16 bytes per lane, all loads of a column in flight together
     for (int c = tid >> 6; c < 2 * B; c += THREADS / 64) {
         const double* src = X + (size_t)((c < B ? bp * B + c : bq * B + (c - B))) * ld;
@@ -121,9 +127,11 @@ __global__ __launch_bounds__(B* LPP) void jacobi_round_kernel(double* __restrict
     __syncthreads();
     const int g = tid / LPP, l = tid % LPP;
     double offmax = 0.0;
+    const int nlr = full ? 2 * B - 1 : B;
 #pragma unroll 1
-    for (int lr = 0; lr < 2 * B - 1; ++lr) {
-        int i = circle_player(g, lr, 2 * B), j = circle_player(2 * B - 1 - g, lr, 2 * B);
+    for (int lr = 0; lr < nlr; ++lr) {
+        int i = full ? circle_player(g, lr, 2 * B) : g;
+        int j = full ? circle_player(2 * B - 1 - g, lr, 2 * B) : B + ((g + lr) % B);
         if (i > j) { const int t = i; i = j; j = t; }
         double* p = cols[i] + l;
         double* q = cols[j] + l;
@@ -211,7 +219,7 @@ bool device_jacobi(lfpsqp_ctx* ctx, int rows_dot, int rows_all, int cols, std::v
     int sweep = 0;
     bool done = false;
     for (; sweep < kMaxSweeps && !done; ++sweep) {
-        for (int round = 0; round < nb - 1; ++round) {
+        for (int round = -1; round < (nb > 2 ? nb - 1 : 0); ++round) {
 #define LF_JR(BB, MR, LP) hipLaunchKernelGGL((jacobi_round_kernel<BB, MR, LP>), dim3(nb / 2), dim3(BB * LP), 0, ctx->stream, dX, ldx, rows_dot, rows_all, nb, round, sweep, doff, tol)
             // lanes per pair as measured on MI355X (ms per problem at m = 128 / 256 / 512): 4 lanes 5.3 / - / -, 8 lanes 2.9 / 12.9 / -,
             // 16 lanes 2.6 / 9.0 / 32.2, 32 lanes - / - / 26.5
