@@ -33,6 +33,9 @@ def main(argv=None, lib=None):
     ap.add_argument("--rows", dest="n", type=float, default=1e7, help="global n (default: the metric's 1e7)")
     ap.add_argument("--cols", dest="m", type=int, default=128, help="m (default 128)")
     ap.add_argument("--basis", choices=["orthonormal", "scaled-hash"], default="orthonormal")
+    ap.add_argument("--prewarm-seconds", type=float, default=2.0,
+                    help="untimed device warm-up before the W warmup steps: the same iteration loop for this long, so that a GPU that "
+                         "was idle (low-power state) is timed in its steady state; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the tangent-setup / Newton-retraction timings (not part of `value`)")
     ap.add_argument("--cpu-sample-n", type=float, default=2e6)
@@ -133,6 +136,25 @@ def main(argv=None, lib=None):
     # the timed region is a second call that RESUMES that solve for K iterations (LFPSQP_PROJCG_RESUME), so a "step" is
     # one projected-CG iteration and nothing else.  With W = 0 there is nothing to resume: the timed call then contains
     # the set-up as well (reported in config.timed_region).
+    # untimed device warm-up: a GPU coming out of idle runs the same loop ~6 % slower for its first ~2 s (measured on fresh boxes:
+    # 543 / 546 it/s without, 577 / 581 with).  The number of calls is the SAME on every rank (each call contains collectives):
+    # one call is timed, the slowest rank's time sets the count.
+    prewarm_iters = 0
+    if args.prewarm_seconds > 0:
+        t_pw = time.perf_counter()
+        L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=50, work=work, n_global=n, want_lambda=False)
+        ctx.sync()
+        t_call = max(time.perf_counter() - t_pw, 1e-4)
+        if dist is not None:
+            import torch
+            tt_ = torch.tensor([t_call], dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            t_call = float(tt_[0])
+        ncalls = min(int(math.ceil(args.prewarm_seconds / t_call)), 2000)
+        for _ in range(ncalls - 1):
+            L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=50, work=work, n_global=n, want_lambda=False)
+        ctx.sync()
+        prewarm_iters = 50 * ncalls
     resumed = W > 0
     if W > 0:
         iw, _ = L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=W, work=work, n_global=n, want_lambda=False)
@@ -212,6 +234,7 @@ def main(argv=None, lib=None):
         "config": {"workload": f"sustained projcg, dense basis n={n}, m={m}, A=diag(5+4u), tol=1e-300 ({shape_name(n, m)})",
                    "timed_region": (f"{K} iterations of a running solve (resumed after the {W} warmup iterations; set-up outside)"
                                     if resumed else f"one projcg call: set-up (2 passes over U) + {K} iterations"),
+                   "prewarm": f"{prewarm_iters} untimed iterations ({args.prewarm_seconds:g} s) before the warmup steps",
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
                    "comm": comm_used, "device": ctx.device_name},
