@@ -59,9 +59,9 @@ def main(argv=None, lib=None):
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # control plane only (the data path is the library's own RCCL communicator); with --comm torch the
-        # callback needs an nccl group as well
-        dist.init_process_group(backend="gloo" if args.comm == "host-gloo" else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        # control plane only, on CPU tensors (gloo): barriers, the RCCL id, the max over ranks.  The data path is the library's own
+        # RCCL communicator; the torch-nccl callback (--comm torch, or the fallback) gets a separate nccl group when it is needed.
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     import lfpsqp_jl_amd as L
 
@@ -96,11 +96,13 @@ def main(argv=None, lib=None):
                 comm_used = "rccl"
             else:
                 from lfpsqp_jl_amd.distributed import torch_allreduce_callback
-                ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev))
+                torch.cuda.set_device(dev)
+                ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev, dist.new_group(backend="nccl")))
                 comm_used = "torch-nccl-callback (fallback)"
         elif args.comm == "torch":
             from lfpsqp_jl_amd.distributed import torch_allreduce_callback
-            ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev))
+            torch.cuda.set_device(dev)
+            ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev, dist.new_group(backend="nccl")))
             comm_used = "torch-nccl-callback"
         else:
             from lfpsqp_jl_amd.distributed import host_staged_allreduce_callback, torch_allreduce_callback

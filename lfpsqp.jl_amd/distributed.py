@@ -21,10 +21,10 @@ def init_rccl_from_torch(ctx, dist):
     ctx.comm_init_rccl(rank, world, box[0])
 
 
-def torch_allreduce_callback(device_index: int | None = None):
+def torch_allreduce_callback(device_index: int | None = None, group=None):
     """All-reduce callback for Context.comm_init_callback built on torch.distributed.
     device_index None => the buffer is HOST memory (emulator build, gloo); otherwise it is device
-    memory on cuda:<device_index> and is reduced through torch's nccl(=RCCL) group."""
+    memory on cuda:<device_index> and is reduced through torch's nccl(=RCCL) group ``group`` (default group if None)."""
     import torch
     import torch.distributed as dist
 
@@ -33,7 +33,7 @@ def torch_allreduce_callback(device_index: int | None = None):
         if device_index is None:
             arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(count,))
             t = torch.from_numpy(arr)
-            dist.all_reduce(t, op=rop)
+            dist.all_reduce(t, op=rop, group=group)
             return 0
 
         class _Holder:  # zero-copy view of the library's device buffer
@@ -41,7 +41,7 @@ def torch_allreduce_callback(device_index: int | None = None):
         t = torch.as_tensor(_Holder(), device=f"cuda:{device_index}")
         ext = torch.cuda.ExternalStream(stream, device=f"cuda:{device_index}") if stream else torch.cuda.current_stream()
         with torch.cuda.stream(ext):
-            dist.all_reduce(t, op=rop)
+            dist.all_reduce(t, op=rop, group=group)
         return 0
 
     return fn
