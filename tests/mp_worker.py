@@ -79,6 +79,58 @@ def main():
                                                                            maxiter_retract=25), trace=tr)
     res.update(c4b_x=xo, c4b_obj=obj, c4b_iter=ti.iter, c4b_r1=np.array([t.get("retract_iter1") or 0 for t in tr]),
                c4b_alpha=np.array([t.get("alpha") or 0.0 for t in tr]))
+    # ---- round-2 paths, sharded: refinement rounds of the factorisation (ill-conditioned block; the small Jacobi runs replicated),
+    #      a general operator behind the callback (lfpsqp_projcg_op), sparse equalities through the default retraction --------------
+    ni, mi = 4500, 6
+    rng = np.random.default_rng(31)
+    Q1, _ = np.linalg.qr(rng.standard_normal((ni, mi)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((mi, mi)))
+    Jill = np.asfortranarray((Q1 * np.logspace(0, -8, mi)) @ Q2.T)
+    i0, i1 = ctx.shard_range(ni)
+    Ji, Zi = ctx.matrix(i1 - i0, mi, Jill[i0:i1]), ctx.matrix(i1 - i0, mi)
+    Si, Vti, rki = L.ksvd_(Ji, Zi)
+    ai = ctx.vector(i1 - i0).hash_fill(3, i0, 4.0, 5.0)
+    ei_full = 0.8 * synth.hash_vector(15, ni)[:ni - 1]
+    # tridiagonal operator restricted to this rank's rows (couplings across the shard boundary dropped on both ranks: still symmetric)
+    e_loc = ei_full[i0:i1 - 1] if i1 - i0 > 0 else np.zeros(0)
+
+    class Tri:
+        def __init__(self):
+            nl_ = i1 - i0
+            self.up = ctx.vector(nl_, np.concatenate([e_loc, [0.0]]) if nl_ else None)
+            self.dn = ctx.vector(nl_, np.concatenate([[0.0], e_loc]) if nl_ else None)
+            self.sh, self.t = ctx.vector(nl_), ctx.vector(nl_)
+
+        def mul_(self, dest, v, al=None, be=None):
+            nl_ = i1 - i0
+            L.vmul(ai, v, dest)
+            if nl_ > 1:
+                self.sh.fill(0.0); self.sh.copy_range_from(v, nl_ - 1, 0, 1)
+                L.vmul(self.up, self.sh, self.t); L.axpby(1.0, self.t, 1.0, dest)
+                self.sh.fill(0.0); self.sh.copy_range_from(v, nl_ - 1, 1, 0)
+                L.vmul(self.dn, self.sh, self.t); L.axpby(1.0, self.t, 1.0, dest)
+            return dest
+
+        def adjoint(self):
+            return self
+    xi, lami = ctx.vector(i1 - i0), ctx.vector(mi)
+    iti, nri = L.projcg_(xi, lami, Tri(), L.DeviceBasis(Zi, rki), ctx.vector(i1 - i0).hash_fill(4, i0), None, tol=1e-10, maxit=400, n_global=ni)
+    res.update(i0=i0, i1=i1, ill_S=Si, ill_rank=rki, ill_Z=Zi.download(), op_x=xi.download(), op_it=iti, op_lam=lami.download())
+    nsp, msp, ksp = 5000, 8, 3
+    g0, g1 = ctx.shard_range(nsp)
+    rows = np.repeat(np.arange(nsp), ksp)
+    cols = (((np.arange(nsp) * msp) // nsp)[:, None] + np.arange(ksp)[None, :]) % msp
+    vals = (np.random.default_rng(9).standard_normal((nsp, ksp)) + 2.0 * (np.arange(ksp) == 0)).ravel()
+    sel = (rows >= g0) & (rows < g1)
+    Ssp = L.SparseMatrix(ctx, g1 - g0, msp, rows[sel] - g0, cols.ravel()[sel], vals[sel])
+    Jsp_dense = Ssp.to_dense()
+    xss = ctx.vector(g1 - g0).hash_fill(2, g0)
+    bsp = ctx.vector(msp)
+    L.spmv_t(Ssp, xss, bsp)
+    Psp = L.QuadLinearBallBox(ctx, g1 - g0, msp, Jsp_dense, bsp.download(), n_global=nsp, Jsp=Ssp)
+    x0sp = xss.download() + 0.05 * synth.hash_vector(6, nsp)[g0:g1]
+    xo, obj, lamk, ti = Psp.optimize(x0sp, L.LFPSQPParams(disp=L.DisplayOption.off, maxiter=3))
+    res.update(g0=g0, g1=g1, sp_x=xo, sp_obj=obj, sp_iter=ti.iter, sp_b=bsp.download())
     np.savez(out, **res)
     dist.barrier()
     ctx.close()

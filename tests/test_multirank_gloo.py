@@ -129,3 +129,65 @@ def test_rank_with_zero_rows(two_ranks):
     assert int(a["e_it"]) == int(b["e_it"]) == i0 and len(b["e_x"]) == 0
     assert np.linalg.norm(a["e_x"] - x0) <= 1e-10 * np.linalg.norm(x0)
     np.testing.assert_array_equal(a["e_lam"], b["e_lam"])
+
+
+def test_sharded_ill_conditioned_factorize_and_operator_callback(two_ranks):
+    """Round-2 paths on two ranks: the refinement rounds of lfpsqp_factorize on a block of condition 1e8 (rank and singular
+    values of dgesvd, replicated bit for bit; the device Jacobi of the small factor runs on every rank), and lfpsqp_projcg_op
+    with a (rank-local) tridiagonal operator against the single-process oracle."""
+    a, b = two_ranks
+    ni, mi = 4500, 6
+    rng = np.random.default_rng(31)
+    Q1, _ = np.linalg.qr(rng.standard_normal((ni, mi)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((mi, mi)))
+    Jill = (Q1 * np.logspace(0, -8, mi)) @ Q2.T
+    S0 = np.linalg.svd(Jill, compute_uv=False)
+    np.testing.assert_array_equal(a["ill_S"], b["ill_S"])
+    assert int(a["ill_rank"]) == int(b["ill_rank"]) == int(np.sum(S0 >= 1e-10)) == mi
+    np.testing.assert_allclose(a["ill_S"], S0, rtol=1e-6, atol=100 * np.finfo(float).eps)
+    Z = np.vstack([a["ill_Z"], b["ill_Z"]])
+    i0 = int(b["i0"])
+    av = 4.0 * synth.hash_vector(3, ni) + 5.0
+    e = 0.8 * synth.hash_vector(15, ni)[:ni - 1].copy()
+    e[i0 - 1] = 0.0                                           # the coupling across the shard boundary is dropped on both ranks
+    bv = synth.hash_vector(4, ni)
+
+    class Tri:
+        def mul_(self, dest, v, al=None, be=None):
+            t = av * v
+            t[:-1] += e * v[1:]
+            t[1:] += e * v[:-1]
+            dest[:] = t if al is None else al * t + be * dest
+            return dest
+
+        def adjoint(self):
+            return self
+    x0, l0 = np.zeros(ni), np.zeros(mi)
+    it0, _ = R.projcg_(x0, l0, Tri(), np.asfortranarray(Z), bv, np.zeros(mi), tol=1e-10, maxit=400)
+    x = np.concatenate([a["op_x"], b["op_x"]])
+    assert int(a["op_it"]) == int(b["op_it"]) == it0
+    assert np.linalg.norm(x - x0) <= 1e-9 * np.linalg.norm(x0)
+    np.testing.assert_array_equal(a["op_lam"], b["op_lam"])
+
+
+def test_sharded_sparse_equalities_through_the_default_retraction(two_ranks):
+    """Sparse constraint gradients sharded by rows (each rank holds the nonzeros of its rows): c!, jac! and ProjPenalty's pcg! on the
+    sparse products, their m-vectors all-reduced -- against the single-process oracle on the assembled dense matrix."""
+    a, b = two_ranks
+    nsp, msp, ksp = 5000, 8, 3
+    rows = np.repeat(np.arange(nsp), ksp)
+    cols = (((np.arange(nsp) * msp) // nsp)[:, None] + np.arange(ksp)[None, :]) % msp
+    vals = (np.random.default_rng(9).standard_normal((nsp, ksp)) + 2.0 * (np.arange(ksp) == 0)).ravel()
+    A = np.zeros((nsp, msp))
+    np.add.at(A, (rows, cols.ravel()), vals)
+    xs = synth.hash_vector(2, nsp)
+    np.testing.assert_allclose(a["sp_b"], A.T @ xs, atol=1e-11)
+    np.testing.assert_array_equal(a["sp_b"], b["sp_b"])
+    prob0 = synth.QuadLinearProblem(np.asfortranarray(A), A.T @ xs)
+    x0 = xs + 0.05 * synth.hash_vector(6, nsp)
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, None, None, msp,
+                                     R.LFPSQPParams(disp=R.DisplayOption.off, maxiter=3))
+    x = np.concatenate([a["sp_x"], b["sp_x"]])
+    assert int(a["sp_iter"]) == int(b["sp_iter"]) == tir.iter
+    assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
+    np.testing.assert_allclose(a["sp_obj"], objr, rtol=1e-10)
