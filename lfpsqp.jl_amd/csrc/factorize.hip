@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <type_traits>
 #include <vector>
 
 #include "internal.h"
@@ -40,71 +41,186 @@ __device__ __forceinline__ void tile_mfma(const double (*As)[kLdsLd], const doub
     }
 }
 
+// The Gram kernel stages its panels TRANSPOSED, T[column][k], with a row stride of 17 doubles (34 dwords).  The compiler pairs the
+// operand reads of two k-groups into ds_read2_b64, which the LDS serves in groups of 16 consecutive lanes on (address / 4) mod 32
+// banks: the 16 columns of a group start 2 banks apart and each read covers 2 -- conflict-free (a stride of 18 doubles, 16-byte
+// aligned for b128 stores, is 2-way conflicted on those reads).  The staging stores (two rows of
+// one column per lane, 8 lanes per column) are conflict-free by the same arithmetic.
+constexpr int kTLd = 17;
 // Gram partials.  grid = (G row-step groups, npan*(npan+1)/2 panel pairs pi <= pj).  Block (g, pp) sums the
 // 16-row steps g, g+G, ... of panel pair (pi, pj) and writes its 128 x 128 partial to
 // part[g][pp*16384 + j*128 + i]  (i = row of G within panel pi, j = column within panel pj).
-__global__ __launch_bounds__(kThreads) void gram_kernel(const double* __restrict__ M, int64_t ld, int64_t n, int ncols, int npan,
+// DIAG: blockIdx.y = pi of the diagonal pair (pi, pi); else blockIdx.y enumerates the pairs pi < pj.  (Two instantiations, so that
+// each gets its own register allocation: 9 accumulators leave room for more resident workgroups than 16.)
+template <bool DIAG, bool WEIGHTED>
+__global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restrict__ M, int64_t ld, int64_t n, int ncols, int npan,
                                                          const double* __restrict__ w2, double* __restrict__ part, int64_t part_ld) {
-    __shared__ double As[kKStep][kLdsLd];
-    __shared__ double Bs[kKStep][kLdsLd];
-    // panel pair (pi <= pj): the Gram matrix is symmetric, only the upper block triangle is computed (10 of 16 pairs at m = 512)
-    int pi = 0, pj = (int)blockIdx.y;
-    while (pj >= npan - pi) { pj -= npan - pi; ++pi; }
-    pj += pi;
+    constexpr bool needB = !DIAG || WEIGHTED;           // diagonal unweighted panel: B is A itself
+    // two LDS buffers per operand: step s+1 is written while step s is multiplied -- ONE barrier per step, and no phase in which
+    // the matrix cores wait for the staging (two workgroups that share a SIMD otherwise fall into step and stage at the same time)
+    __shared__ double As[2][kPanel][kTLd];
+    __shared__ double Bs[needB ? 2 : 1][needB ? kPanel : 1][kTLd];
+    // panel pair (pi <= pj): the Gram matrix is symmetric, only the upper block triangle is computed (10 of 16 pairs at m = 512),
+    // and of a diagonal block only its upper triangle of 16 x 16 tiles (36 of 64)
+    int pi = (int)blockIdx.y, pj = (int)blockIdx.y;
+    if (!DIAG) {
+        pi = 0;
+        while (pj >= npan - 1 - pi) { pj -= npan - 1 - pi; ++pi; }
+        pj += pi + 1;
+    }
+    const int pidx = pi * npan - pi * (pi - 1) / 2 + (pj - pi);     // position in the enumeration pi ascending, pj = pi .. npan-1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    f64x4 acc[2][8];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
     const int64_t nsteps = (n + kKStep - 1) / kKStep;
-    const bool needB = (pi != pj) || (w2 != nullptr);   // diagonal unweighted panel: B is A itself
-    // staging role: column c = tid / 2 of the panel, rows kh..kh+8 of the step
-    const int c = tid >> 1, kh = (tid & 1) * 8;
-    const int64_t colA = (int64_t)pi * kPanel + c, colB = (int64_t)pj * kPanel + c;
-    // software pipeline: the global loads of step s+1 are issued before the MFMAs of step s
-    double va[8], vb[8];
-    auto load_step = [&](int64_t step) {
-        const int64_t r0 = step * kKStep + kh;
+#ifndef LFPSQP_GRAM_ABL
+#define LFPSQP_GRAM_ABL 0     // development ablations: 1 = no global loads in the loop, 2 = no MFMAs, 3 = no loads and no LDS writes
+#endif
+#ifndef LFPSQP_GRAM_DEPTH
+#define LFPSQP_GRAM_DEPTH 1
+#endif
+    constexpr int DEPTH = 1;
+    // staging role: rows kh, kh + 1 of the step in the four columns c, c + 32, c + 64, c + 96 of the panel -- one load instruction of
+    // a wave covers whole 128-byte lines (8 lanes x 16 B per column, 8 columns)
+    const int kh = (tid & 7) * 2, c = tid >> 3;
+    // software pipeline: the global loads of step s+DEPTH are issued before the MFMAs of step s.  Row weights are applied when a
+    // buffer is staged, so that no arithmetic waits on the loads in flight.
+    double2 va[DEPTH][4], vb[needB ? DEPTH : 1][4], vw[WEIGHTED ? DEPTH : 1];
+    const double* pa = M + ((int64_t)pi * kPanel + c) * ld + kh;
+    const double* pb = M + ((int64_t)pj * kPanel + c) * ld + kh;
+    const int na = ncols - pi * kPanel - c, nb = ncols - pj * kPanel - c;      // column c + 32 q of the panel exists iff 32 q < na / nb
+    const int64_t cs = 32 * ld;
+    auto load_step = [&](int buf, int64_t step) {
+        const int64_t r = step * kKStep;
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-            const int64_t r = r0 + q;
-            double2 a = make_double2(0.0, 0.0), b = make_double2(0.0, 0.0);
-            if (colA < ncols) a = ld2(M + colA * ld + r);      // rows >= n are zero padding
-            if (needB && colB < ncols) b = ld2(M + colB * ld + r);
-            if (w2) {
-                const double2 w = ld2(w2 + r);
-                a.x *= (r < n) ? w.x : 0.0;
-                a.y *= (r + 1 < n) ? w.y : 0.0;
+        for (int q = 0; q < 4; ++q) {
+            va[buf][q] = make_double2(0.0, 0.0);
+            if (32 * q < na) va[buf][q] = ld2(pa + r + q * cs);          // rows >= n are zero padding
+            if constexpr (needB) {
+                vb[buf][q] = make_double2(0.0, 0.0);
+                if (32 * q < nb) vb[buf][q] = ld2(pb + r + q * cs);
             }
-            va[q] = a.x; va[q + 1] = a.y;
-            vb[q] = b.x; vb[q + 1] = b.y;
+        }
+        if constexpr (WEIGHTED) {
+            const double2 w = ld2(w2 + r + kh);
+            vw[buf] = make_double2((r + kh < n) ? w.x : 0.0, (r + kh + 1 < n) ? w.y : 0.0);
         }
     };
-    int64_t step = blockIdx.x;
-    if (step < nsteps) load_step(step);
-    for (; step < nsteps; step += gridDim.x) {
-        __syncthreads();
+    auto write_lds = [&](int p, int buf) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            As[kh + q][c] = va[q];
-            if (needB) Bs[kh + q][c] = vb[q];
-        }
-        __syncthreads();
-        if (step + gridDim.x < nsteps) load_step(step + gridDim.x);
-        tile_mfma(As, needB ? Bs : As, acc, wave, lane);
-    }
-    double* out = part + (int64_t)blockIdx.x * part_ld + (int64_t)blockIdx.y * (kPanel * kPanel);
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 8; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = (2 * wave + it) * 16 + (lane >> 4) + 4 * r;
-                const int j = jt * 16 + (lane & 15);
-                out[j * kPanel + i] = acc[it][jt][r];
+        for (int q = 0; q < 4; ++q) {
+            double2 a = va[buf][q];
+            if constexpr (WEIGHTED) { a.x *= vw[buf].x; a.y *= vw[buf].y; }
+            As[p][c + 32 * q][kh] = a.x;
+            As[p][c + 32 * q][kh + 1] = a.y;
+            if constexpr (needB) {
+                Bs[p][c + 32 * q][kh] = vb[buf][q].x;
+                Bs[p][c + 32 * q][kh + 1] = vb[buf][q].y;
             }
+        }
+    };
+    const int64_t G = gridDim.x;
+    int64_t step = blockIdx.x;
+    double* out = part + (int64_t)blockIdx.x * part_ld + (int64_t)pidx * (kPanel * kPanel);
+    // The MFMA operands of one k-group (4 of the 16 rows of a step): lane (kq = lane / 16, cc = lane % 16) holds row 4 kg + kq of
+    // column cc of each 16-column tile it needs.  DIAG (symmetric block, upper tile triangle only -- the host mirrors it, gram_impl):
+    // wave w owns tile rows w and 7 - w, (8 - w) + (w + 1) = 9 tiles for every wave, 9/16 of the MFMA work of the square;
+    // accumulator k belongs to tile (w, w + k) for k < 8 - w, else to tile (7 - w, k - 1).  Otherwise: tile rows 2w, 2w + 1, all 8 tile
+    // columns, accumulator it * 8 + jt.
+    // The whole pipeline is instantiated once per wave index for DIAG (WS = 0 .. 3; a switch on the wave picks its copy), so that the
+    // tile assignment of a wave is a compile-time fact: with a run-time index every MFMA of the triangle needed two v_cndmask to
+    // select its A operand, and those VALU instructions between the MFMAs cost 12 % of the kernel.
+    auto pipeline = [&](auto Wc) {
+        constexpr int WS = decltype(Wc)::value;
+        const int wv = WS >= 0 ? WS : wave;
+        constexpr int NB = DIAG ? 9 : 8, NACC = DIAG ? 9 : 16;
+        struct Ops { double a0, a1, b[NB]; };
+        const int cc = lane & 15, kq = lane >> 4;
+        auto read_ops = [&](Ops& o, int p, int kg) {
+            const double (*A)[kTLd] = As[p];
+            const double (*B)[kTLd] = needB ? Bs[needB ? p : 0] : As[p];
+            const int kr = 4 * kg + kq;
+            o.a0 = A[(DIAG ? wv : 2 * wv) * 16 + cc][kr];
+            o.a1 = A[(DIAG ? 7 - wv : 2 * wv + 1) * 16 + cc][kr];
+    #pragma unroll
+            for (int k = 0; k < NB; ++k) o.b[k] = B[(DIAG ? (k < 8 - wv ? wv + k : k - 1) : k) * 16 + cc][kr];
+        };
+        f64x4 acc[NACC];
+    #pragma unroll
+        for (int k = 0; k < NACC; ++k) acc[k] = f64x4{0.0, 0.0, 0.0, 0.0};
+        auto mfma_ops = [&](const Ops& o) {
+    #if LFPSQP_GRAM_ABL != 2
+    #pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if constexpr (DIAG) {
+                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k < 8 - wv ? o.a0 : o.a1, o.b[k], acc[k], 0, 0, 0);
+                } else {
+                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0, o.b[k], acc[k], 0, 0, 0);
+                    acc[8 + k] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1, o.b[k], acc[8 + k], 0, 0, 0);
+                }
+            }
+    #endif
+        };
+        // Pipeline.  LDS: two buffers per operand, step s+1 is written while step s is multiplied.  Registers: the global loads of step
+        // s+2 fly during step s; the LDS operand reads run one k-group ahead of the MFMAs (two operand sets), across the step boundary
+        // too -- which is why the one barrier of a step sits in its middle: by then every wave has written its share of the next buffer
+        // and has issued all its reads of this one (which the next step overwrites).
+        Ops o0, o1;
+        if (step < nsteps) {
+            load_step(0, step);
+            write_lds(0, 0);
+        }
+        if (step + G < nsteps) load_step(0, step + G);
+        __syncthreads();
+        if (step < nsteps) read_ops(o0, 0, 0);
+        while (step < nsteps) {
+    #pragma unroll
+            for (int i = 0; i < 2; ++i) {          // LDS buffer i holds this step
+                if (step >= nsteps) break;
+                const bool more = step + G < nsteps;
+                read_ops(o1, i, 1);
+                mfma_ops(o0);
+    #if LFPSQP_GRAM_ABL < 3
+                if (more) write_lds(i ^ 1, 0);
+    #endif
+    #if LFPSQP_GRAM_ABL == 0 || LFPSQP_GRAM_ABL == 2
+                if (step + 2 * G < nsteps) load_step(0, step + 2 * G);
+    #endif
+                read_ops(o0, i, 2);
+                mfma_ops(o1);
+                read_ops(o1, i, 3);                 // the last read of this buffer: issued before the barrier, after which it may be rewritten
+    #if LFPSQP_GRAM_ABL != 4 && LFPSQP_GRAM_ABL != 6
+                __syncthreads();
+    #endif
+                mfma_ops(o0);
+                if (more) read_ops(o0, i ^ 1, 0);
+                mfma_ops(o1);
+                step += G;
+            }
+        }
+    #pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            int it, jt;
+            if constexpr (DIAG) {
+                const bool first = k < 8 - wv;
+                it = first ? wv : 7 - wv;
+                jt = first ? wv + k : k - 1;
+            } else {
+                it = 2 * wv + k / 8;
+                jt = k % 8;
+            }
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) out[(jt * 16 + cc) * kPanel + it * 16 + kq + 4 * r] = acc[k][r];
+        }
+    };
+    if constexpr (DIAG) {
+        switch (wave) {
+            case 0: pipeline(std::integral_constant<int, 0>{}); break;
+            case 1: pipeline(std::integral_constant<int, 1>{}); break;
+            case 2: pipeline(std::integral_constant<int, 2>{}); break;
+            default: pipeline(std::integral_constant<int, 3>{}); break;
+        }
+    } else {
+        pipeline(std::integral_constant<int, -1>{});
+    }
 }
 
 // Out[row0 + r, c0 + c] = sum_k In[row0 + r, k] * W[k, c0 + c]; grid = (row tiles of 128, column panels).
@@ -279,12 +395,23 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     const int npair = npan * (npan + 1) / 2;
     const int64_t pp = (int64_t)npair * kPanel * kPanel;
     const int64_t nsteps = (M->n + kKStep - 1) / kKStep;
-    const int64_t gmax = 2 * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 128);     // two workgroups per CU: one stages while the other multiplies
+#ifndef LFPSQP_GRAM_WGS
+#define LFPSQP_GRAM_WGS 2
+#endif
+    const int64_t gmax = LFPSQP_GRAM_WGS * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 128);     // two workgroups per CU: one stages while the other multiplies
     int groups = (int)(nsteps < gmax ? (nsteps < 1 ? 1 : nsteps) : gmax);
     LF_TRY(ensure_part(ctx, (size_t)groups * pp));
     LF_TRY(ensure_small(ctx, (size_t)pp));
-    hipLaunchKernelGGL(gram_kernel, dim3(groups, npair), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2,
-                       ctx->part, pp);
+    const dim3 gd(groups, npan), go(groups, npair - npan);
+    if (w2) {
+        hipLaunchKernelGGL((gram_kernel<true, true>), gd, dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2, ctx->part, pp);
+        if (npair > npan)
+            hipLaunchKernelGGL((gram_kernel<false, true>), go, dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2, ctx->part, pp);
+    } else {
+        hipLaunchKernelGGL((gram_kernel<true, false>), gd, dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2, ctx->part, pp);
+        if (npair > npan)
+            hipLaunchKernelGGL((gram_kernel<false, false>), go, dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2, ctx->part, pp);
+    }
     LF_LAUNCH_CHECK(ctx);
     // reduce the `groups` partials (pp columns: 32 per workgroup)
     hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3((unsigned)((pp + 31) / 32), 1), dim3(1024), 0, ctx->stream, ctx->part,
@@ -305,8 +432,10 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
                     for (int i = 0; i < kPanel; ++i) {
                         const int gi = pi * kPanel + i;
                         if (gi >= ncols) break;
-                        G[(size_t)gj * ncols_all + gi] = blk[j * kPanel + i];
-                        if (pi != pj) G[(size_t)gi * ncols_all + gj] = blk[j * kPanel + i];      // the mirrored block
+                        // a diagonal block holds its tiles with (i / 16) <= (j / 16) only: the others are their mirror images
+                        const double v = (pi == pj && i / 16 > j / 16) ? blk[i * kPanel + j] : blk[j * kPanel + i];
+                        G[(size_t)gj * ncols_all + gi] = v;
+                        if (pi != pj) G[(size_t)gi * ncols_all + gj] = v;                        // the mirrored block
                     }
                 }
             }

@@ -1,8 +1,8 @@
 """Timings of the tangent setup at full size: python tools/time_factorize.py N M  (best of 5)"""
-import sys, time; sys.path.insert(0,'.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import lfpsqp_jl_amd as L
-ctx=L.Context(0)
+ctx=L.Context(0, L.load_library(os.environ['LFPSQP_LIB']) if 'LFPSQP_LIB' in os.environ else None)
 n,m=int(float(sys.argv[1])),int(sys.argv[2])
 J=ctx.matrix(n,m).hash_fill(1); Z=ctx.matrix(n,m)
 best=[1e9,1e9,1e9]
