@@ -290,13 +290,18 @@ __global__ __launch_bounds__(kThreads) void rmul_kernel(const double* __restrict
 // runs on across tile boundaries: no staging of In through LDS and no barrier in the loop.
 // NG k-groups of 4 (kcols <= 4*NG), NI output-column tiles of 16 (rcols <= 16*NI), RING | NG: <32, 8, 16> is the 128 x 128
 // case, <33, 9, 11> covers m = 129 .. 132 (one slack / ball column more than 128) with 152 KB of LDS.
-template <int NG, int NI, int RING>
-__global__ __launch_bounds__(kThreads) void rmul_resident_kernel(const double* __restrict__ In, int64_t ld_in, int64_t n, int kcols,
+#ifndef LFPSQP_RMUL_ABL
+#define LFPSQP_RMUL_ABL 0     // development ablations: bit 0 = no global loads in the loop, bit 1 = no stores
+#endif
+template <int NG, int NI, int RING, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rmul_resident_kernel(const double* __restrict__ In, int64_t ld_in, int64_t n, int kcols,
                                                                   const double* __restrict__ W, int ldw, int rcols,
                                                                   double* __restrict__ Out, int64_t ld_out, int64_t ntiles) {
     static_assert(NG % RING == 0, "the register ring must divide the k-groups of a tile");
+    static_assert(WAVES == 4 || WAVES == 8, "a wave owns 32 or 16 rows of the 128-row tile");
+    constexpr int HN = 8 / WAVES;            // 16-row halves per wave
     __shared__ double Ws[4 * NG][kLdsLd];    // Ws[k][c] = W[k, c]
-    for (int idx = threadIdx.x; idx < 4 * NG * 16 * NI; idx += kThreads) {
+    for (int idx = threadIdx.x; idx < 4 * NG * 16 * NI; idx += 64 * WAVES) {
         const int k = idx % (4 * NG), c = idx / (4 * NG);
         Ws[k][c] = (k < kcols && c < rcols) ? W[(int64_t)c * ldw + k] : 0.0;
     }
@@ -308,22 +313,28 @@ __global__ __launch_bounds__(kThreads) void rmul_resident_kernel(const double* _
     const int64_t t1 = t0 + q + ((int64_t)blockIdx.x < rem ? 1 : 0);
     if (t0 >= t1) return;
     const int kmax = kcols - 1;
-    // B operand of k-group g of tile t: In[row = t*128 + wave*32 + jj*16 + c, k = 4g + kq] (k clamped: W rows >= kcols are zero)
+    // B operand of k-group g of tile t: In[row = t*128 + wave*16*HN + h*16 + c, k = 4g + kq] (k clamped: W rows >= kcols are zero)
     auto in_ptr = [&](int64_t t, int g) -> const double* {
         const int k = (4 * g + kq < kmax) ? (4 * g + kq) : kmax;
-        return In + (int64_t)k * ld_in + t * kPanel + wave * 32 + c;
+        return In + (int64_t)k * ld_in + t * kPanel + wave * (16 * HN) + c;
     };
-    double b0[RING], b1[RING];
+    double bv[HN][RING];
 #pragma unroll
     for (int g = 0; g < RING; ++g) {
         const double* p = in_ptr(t0, g);
-        b0[g] = __builtin_nontemporal_load(p);
-        b1[g] = __builtin_nontemporal_load(p + 16);
-    }
-    for (int64_t t = t0; t < t1; ++t) {
-        f64x4 acc[NI][2];
 #pragma unroll
-        for (int it = 0; it < NI; ++it) { acc[it][0] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[it][1] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+        for (int h = 0; h < HN; ++h) bv[h][g] = __builtin_nontemporal_load(p + 16 * h);
+    }
+    // the A operands (W from LDS) run one k-group ahead of the MFMAs
+    double wa[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) wa[it] = Ws[kq][it * 16 + c];
+    for (int64_t t = t0; t < t1; ++t) {
+        f64x4 acc[NI][HN];
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+#pragma unroll
+            for (int h = 0; h < HN; ++h) acc[it][h] = f64x4{0.0, 0.0, 0.0, 0.0};
         const int64_t tn = (t + 1 < t1) ? (t + 1) : t;        // the ring reads on into the next tile (or re-reads this one at the end)
 #pragma unroll 1
         for (int g8 = 0; g8 < NG; g8 += RING) {
@@ -332,20 +343,27 @@ __global__ __launch_bounds__(kThreads) void rmul_resident_kernel(const double* _
             const int gbase = same ? (g8 + RING) : 0;
 #pragma unroll
             for (int slot = 0; slot < RING; ++slot) {
-                const double v0 = b0[slot], v1 = b1[slot];
-                const double* p = in_ptr(tt, gbase + slot);          // refill the slot with the group RING ahead
-                b0[slot] = __builtin_nontemporal_load(p);
-                b1[slot] = __builtin_nontemporal_load(p + 16);
-                const int kr = 4 * (g8 + slot) + kq;
+                double v[HN];
 #pragma unroll
-                for (int it = 0; it < NI; ++it) {
-                    const double a = Ws[kr][it * 16 + c];
-                    acc[it][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, v0, acc[it][0], 0, 0, 0);
-                    acc[it][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, v1, acc[it][1], 0, 0, 0);
-                }
+                for (int h = 0; h < HN; ++h) v[h] = bv[h][slot];
+#if !(LFPSQP_RMUL_ABL & 1)
+                const double* p = in_ptr(tt, gbase + slot);          // refill the slot with the group RING ahead
+#pragma unroll
+                for (int h = 0; h < HN; ++h) bv[h][slot] = __builtin_nontemporal_load(p + 16 * h);
+#endif
+                const int gn = (g8 + slot + 1 < NG) ? (g8 + slot + 1) : 0;      // the next k-group (of the next tile after the last)
+                double wn[NI];
+#pragma unroll
+                for (int it = 0; it < NI; ++it) wn[it] = Ws[4 * gn + kq][it * 16 + c];
+#pragma unroll
+                for (int it = 0; it < NI; ++it)
+#pragma unroll
+                    for (int h = 0; h < HN; ++h) acc[it][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[it], v[h], acc[it][h], 0, 0, 0);
+#pragma unroll
+                for (int it = 0; it < NI; ++it) wa[it] = wn[it];
             }
         }
-        const int64_t row = t * kPanel + wave * 32 + c;
+        const int64_t row = t * kPanel + wave * (16 * HN) + c;
 #pragma unroll
         for (int it = 0; it < NI; ++it)
 #pragma unroll
@@ -353,8 +371,14 @@ __global__ __launch_bounds__(kThreads) void rmul_resident_kernel(const double* _
                 const int col = it * 16 + kq + 4 * r;
                 if (col >= rcols) continue;
                 double* o = Out + (int64_t)col * ld_out + row;
-                if (row < n) o[0] = acc[it][0][r];
-                if (row + 16 < n) o[16] = acc[it][1][r];
+#pragma unroll
+                for (int h = 0; h < HN; ++h) {
+#if LFPSQP_RMUL_ABL & 2
+                    if (acc[it][h][r] == 1.2345) o[16 * h] = acc[it][h][r];
+#else
+                    if (row + 16 * h < n) o[16 * h] = acc[it][h][r];
+#endif
+                }
             }
     }
 }
@@ -466,11 +490,15 @@ static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const dou
     const int64_t ntiles = (In->n + kPanel - 1) / kPanel;
     const int64_t cus = ctx->num_cu > 0 ? ctx->num_cu : 1;
     const dim3 pgrid((unsigned)(ntiles < cus ? ntiles : cus));
+#ifndef LFPSQP_RMUL_WAVES
+#define LFPSQP_RMUL_WAVES 8
+#endif
+    constexpr int kRW = LFPSQP_RMUL_WAVES;    // waves of the W-resident kernel: 8 = two per SIMD, each covers the other's tile epilogue
     if (kcols <= kPanel && rcols <= kPanel && ctx->tune_onepass >= 0) {      // W resident in LDS, persistent grid
-        hipLaunchKernelGGL((rmul_resident_kernel<32, 8, 16>), pgrid, dim3(kThreads), 0, ctx->stream, In->p, In->ld, In->n, kcols,
+        hipLaunchKernelGGL((rmul_resident_kernel<32, 8, 16, kRW>), pgrid, dim3(64 * kRW), 0, ctx->stream, In->p, In->ld, In->n, kcols,
                            ctx->small, kcols, rcols, Out->p, Out->ld, ntiles);
     } else if (kcols <= 132 && rcols <= 144 && ctx->tune_onepass >= 0) {     // ... a few columns more (m = 128 + slack / ball)
-        hipLaunchKernelGGL((rmul_resident_kernel<33, 9, 11>), pgrid, dim3(kThreads), 0, ctx->stream, In->p, In->ld, In->n, kcols,
+        hipLaunchKernelGGL((rmul_resident_kernel<33, 9, 11, kRW>), pgrid, dim3(64 * kRW), 0, ctx->stream, In->p, In->ld, In->n, kcols,
                            ctx->small, kcols, rcols, Out->p, Out->ld, ntiles);
     } else {
         hipLaunchKernelGGL(rmul_kernel, dim3((unsigned)ntiles, (unsigned)((rcols + kPanel - 1) / kPanel)), dim3(kThreads), 0, ctx->stream,
