@@ -44,6 +44,9 @@ def main(argv=None, lib=None):
                          "host-gloo (functional test only: ranks may share one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device index (default: LOCAL_RANK)")
     ap.add_argument("--lib", default=None, help="(development) alternative build of liblfpsqp_hip.so to load")
+    ap.add_argument("--watchdog-seconds", type=float, default=1500.0,
+                    help="dump every thread's Python stack to stderr and exit non-zero if the run takes longer (0 = off): a stalled "
+                         "rendezvous or collective then fails with a diagnosis instead of hanging the caller")
     args = ap.parse_args(argv)
     n, m, K, W = int(args.n), args.m, args.steps, args.warmup
 
@@ -53,12 +56,24 @@ def main(argv=None, lib=None):
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    watchdog = False
+    if args.watchdog_seconds > 0:
+        import faulthandler
+        try:
+            faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True, file=sys.__stderr__)
+            watchdog = True
+        except (ValueError, OSError, AttributeError):       # no real stderr (in-process test harness): run without
+            pass
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # one node: keep gloo's pair connections on the loopback interface instead of whatever the host name resolves to
+            # (it may not resolve at all on these boxes, and a resolver time-out per connection stalls the rendezvous)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         # control plane only, on CPU tensors (gloo): barriers, the RCCL id, the max over ranks.  The data path is the library's own
         # RCCL communicator; the torch-nccl callback (--comm torch, or the fallback) gets a separate nccl group when it is needed.
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -297,6 +312,8 @@ def main(argv=None, lib=None):
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if watchdog:
+        faulthandler.cancel_dump_traceback_later()
     return out
 
 

@@ -47,36 +47,37 @@ __device__ __forceinline__ void tile_mfma(const double (*As)[kLdsLd], const doub
 // aligned for b128 stores, is 2-way conflicted on those reads).  The staging stores (two rows of
 // one column per lane, 8 lanes per column) are conflict-free by the same arithmetic.
 constexpr int kTLd = 17;
-// Gram partials.  grid = (G row-step groups, npan*(npan+1)/2 panel pairs pi <= pj).  Block (g, pp) sums the
-// 16-row steps g, g+G, ... of panel pair (pi, pj) and writes its 128 x 128 partial to
-// part[g][pp*16384 + j*128 + i]  (i = row of G within panel pi, j = column within panel pj).
-// DIAG: blockIdx.y = pi of the diagonal pair (pi, pi); else blockIdx.y enumerates the pairs pi < pj.  (Two instantiations, so that
-// each gets its own register allocation: 9 accumulators leave room for more resident workgroups than 16.)
+// Gram partials.  One launch per kind of panel pair (pi <= pj; the Gram matrix is symmetric, only the upper block triangle is
+// computed -- 10 of 16 pairs at m = 512): DIAG = the npan diagonal pairs (pi, pi), else the npan (npan - 1) / 2 pairs pi < pj; two
+// instantiations, so that each gets its own register allocation.  A launch runs `ngroups` row groups of every one of its pairs
+// CONCURRENTLY: workgroup (g, pair) sums the 16-row steps g, g + ngroups, ... of its pair and writes the 128 x 128 partial to
+// part[g][slot * 16384 + j * 128 + i] (i = row of G within panel pi, j = column within panel pj; slot = pi for a diagonal pair,
+// npan + position among the pairs pi < pj otherwise).  The pairs of one row group read the same rows of the matrix (every panel
+// is an operand of npan - 1 off-diagonal pairs), so they are placed on the SAME XCD, next to each other in dispatch order
+// (linear workgroup id L -> XCD L % 8): the panels then come from HBM once and from that XCD's L2 for the other pairs.  With
+// the pair as the slow grid dimension (one pair after the other) the m = 512 Gram read 61 GB for a 20 GB matrix.
 template <bool DIAG, bool WEIGHTED>
 __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restrict__ M, int64_t ld, int64_t n, int ncols, int npan,
-                                                         const double* __restrict__ w2, double* __restrict__ part, int64_t part_ld) {
+                                                         int ngroups, const double* __restrict__ w2, double* __restrict__ part,
+                                                         int64_t part_ld) {
     constexpr bool needB = !DIAG || WEIGHTED;           // diagonal unweighted panel: B is A itself
     // two LDS buffers per operand: step s+1 is written while step s is multiplied -- ONE barrier per step, and no phase in which
     // the matrix cores wait for the staging (two workgroups that share a SIMD otherwise fall into step and stage at the same time)
     __shared__ double As[2][kPanel][kTLd];
     __shared__ double Bs[needB ? 2 : 1][needB ? kPanel : 1][kTLd];
-    // panel pair (pi <= pj): the Gram matrix is symmetric, only the upper block triangle is computed (10 of 16 pairs at m = 512),
-    // and of a diagonal block only its upper triangle of 16 x 16 tiles (36 of 64)
-    int pi = (int)blockIdx.y, pj = (int)blockIdx.y;
+    // (row group g, pair pr) of this workgroup: ngroups is a multiple of 8; XCD x holds the row groups g = x (mod 8)
+    const int np = DIAG ? npan : npan * (npan - 1) / 2;
+    const int xslot = (int)blockIdx.x >> 3;
+    const int pr = xslot % np, g = (xslot / np) * 8 + ((int)blockIdx.x & 7);
+    int pi = pr, pj = pr;
     if (!DIAG) {
         pi = 0;
         while (pj >= npan - 1 - pi) { pj -= npan - 1 - pi; ++pi; }
         pj += pi + 1;
     }
-    const int pidx = pi * npan - pi * (pi - 1) / 2 + (pj - pi);     // position in the enumeration pi ascending, pj = pi .. npan-1
+    const int pidx = DIAG ? pr : npan + pr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t nsteps = (n + kKStep - 1) / kKStep;
-#ifndef LFPSQP_GRAM_ABL
-#define LFPSQP_GRAM_ABL 0     // development ablations: 1 = no global loads in the loop, 2 = no MFMAs, 3 = no loads and no LDS writes
-#endif
-#ifndef LFPSQP_GRAM_DEPTH
-#define LFPSQP_GRAM_DEPTH 1
-#endif
     constexpr int DEPTH = 1;
     // staging role: rows kh, kh + 1 of the step in the four columns c, c + 32, c + 64, c + 96 of the panel -- one load instruction of
     // a wave covers whole 128-byte lines (8 lanes x 16 B per column, 8 columns)
@@ -88,15 +89,24 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
     const double* pb = M + ((int64_t)pj * kPanel + c) * ld + kh;
     const int na = ncols - pi * kPanel - c, nb = ncols - pj * kPanel - c;      // column c + 32 q of the panel exists iff 32 q < na / nb
     const int64_t cs = 32 * ld;
-    auto load_step = [&](int buf, int64_t step) {
+    // FULL: both panels have all their 128 columns (the usual case: then the loads are unconditional -- the per-column test costs an
+    // exec-mask branch and a zero-fill per load in the loop)
+    const bool full = ncols - pi * kPanel >= kPanel && ncols - pj * kPanel >= kPanel;
+    auto load_step = [&](auto Fc, int buf, int64_t step) {
+        constexpr bool FULL = decltype(Fc)::value;
         const int64_t r = step * kKStep;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            va[buf][q] = make_double2(0.0, 0.0);
-            if (32 * q < na) va[buf][q] = ld2(pa + r + q * cs);          // rows >= n are zero padding
-            if constexpr (needB) {
-                vb[buf][q] = make_double2(0.0, 0.0);
-                if (32 * q < nb) vb[buf][q] = ld2(pb + r + q * cs);
+            if constexpr (FULL) {
+                va[buf][q] = ld2(pa + r + q * cs);                       // rows >= n are zero padding
+                if constexpr (needB) vb[buf][q] = ld2(pb + r + q * cs);
+            } else {
+                va[buf][q] = make_double2(0.0, 0.0);
+                if (32 * q < na) va[buf][q] = ld2(pa + r + q * cs);
+                if constexpr (needB) {
+                    vb[buf][q] = make_double2(0.0, 0.0);
+                    if (32 * q < nb) vb[buf][q] = ld2(pb + r + q * cs);
+                }
             }
         }
         if constexpr (WEIGHTED) {
@@ -117,9 +127,9 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
             }
         }
     };
-    const int64_t G = gridDim.x;
-    int64_t step = blockIdx.x;
-    double* out = part + (int64_t)blockIdx.x * part_ld + (int64_t)pidx * (kPanel * kPanel);
+    const int64_t G = ngroups;
+    int64_t step = g;
+    double* out = part + (int64_t)g * part_ld + (int64_t)pidx * (kPanel * kPanel);
     // The MFMA operands of one k-group (4 of the 16 rows of a step): lane (kq = lane / 16, cc = lane % 16) holds row 4 kg + kq of
     // column cc of each 16-column tile it needs.  DIAG (symmetric block, upper tile triangle only -- the host mirrors it, gram_impl):
     // wave w owns tile rows w and 7 - w, (8 - w) + (w + 1) = 9 tiles for every wave, 9/16 of the MFMA work of the square;
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
     // The whole pipeline is instantiated once per wave index for DIAG (WS = 0 .. 3; a switch on the wave picks its copy), so that the
     // tile assignment of a wave is a compile-time fact: with a run-time index every MFMA of the triangle needed two v_cndmask to
     // select its A operand, and those VALU instructions between the MFMAs cost 12 % of the kernel.
-    auto pipeline = [&](auto Wc) {
+    auto pipeline = [&](auto Wc, auto Fc) {
         constexpr int WS = decltype(Wc)::value;
         const int wv = WS >= 0 ? WS : wave;
         constexpr int NB = DIAG ? 9 : 8, NACC = DIAG ? 9 : 16;
@@ -140,15 +150,14 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
             const int kr = 4 * kg + kq;
             o.a0 = A[(DIAG ? wv : 2 * wv) * 16 + cc][kr];
             o.a1 = A[(DIAG ? 7 - wv : 2 * wv + 1) * 16 + cc][kr];
-    #pragma unroll
+#pragma unroll
             for (int k = 0; k < NB; ++k) o.b[k] = B[(DIAG ? (k < 8 - wv ? wv + k : k - 1) : k) * 16 + cc][kr];
         };
         f64x4 acc[NACC];
-    #pragma unroll
+#pragma unroll
         for (int k = 0; k < NACC; ++k) acc[k] = f64x4{0.0, 0.0, 0.0, 0.0};
         auto mfma_ops = [&](const Ops& o) {
-    #if LFPSQP_GRAM_ABL != 2
-    #pragma unroll
+#pragma unroll
             for (int k = 0; k < NB; ++k) {
                 if constexpr (DIAG) {
                     acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k < 8 - wv ? o.a0 : o.a1, o.b[k], acc[k], 0, 0, 0);
@@ -157,7 +166,6 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
                     acc[8 + k] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1, o.b[k], acc[8 + k], 0, 0, 0);
                 }
             }
-    #endif
         };
         // Pipeline.  LDS: two buffers per operand, step s+1 is written while step s is multiplied.  Registers: the global loads of step
         // s+2 fly during step s; the LDS operand reads run one k-group ahead of the MFMAs (two operand sets), across the step boundary
@@ -165,38 +173,32 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
         // and has issued all its reads of this one (which the next step overwrites).
         Ops o0, o1;
         if (step < nsteps) {
-            load_step(0, step);
+            load_step(Fc, 0, step);
             write_lds(0, 0);
         }
-        if (step + G < nsteps) load_step(0, step + G);
+        if (step + G < nsteps) load_step(Fc, 0, step + G);
         __syncthreads();
         if (step < nsteps) read_ops(o0, 0, 0);
         while (step < nsteps) {
-    #pragma unroll
+#pragma unroll
             for (int i = 0; i < 2; ++i) {          // LDS buffer i holds this step
                 if (step >= nsteps) break;
                 const bool more = step + G < nsteps;
                 read_ops(o1, i, 1);
                 mfma_ops(o0);
-    #if LFPSQP_GRAM_ABL < 3
                 if (more) write_lds(i ^ 1, 0);
-    #endif
-    #if LFPSQP_GRAM_ABL == 0 || LFPSQP_GRAM_ABL == 2
-                if (step + 2 * G < nsteps) load_step(0, step + 2 * G);
-    #endif
+                if (step + 2 * G < nsteps) load_step(Fc, 0, step + 2 * G);
                 read_ops(o0, i, 2);
                 mfma_ops(o1);
                 read_ops(o1, i, 3);                 // the last read of this buffer: issued before the barrier, after which it may be rewritten
-    #if LFPSQP_GRAM_ABL != 4 && LFPSQP_GRAM_ABL != 6
                 __syncthreads();
-    #endif
                 mfma_ops(o0);
                 if (more) read_ops(o0, i ^ 1, 0);
                 mfma_ops(o1);
                 step += G;
             }
         }
-    #pragma unroll
+#pragma unroll
         for (int k = 0; k < NACC; ++k) {
             int it, jt;
             if constexpr (DIAG) {
@@ -207,20 +209,24 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
                 it = 2 * wv + k / 8;
                 jt = k % 8;
             }
-    #pragma unroll
+#pragma unroll
             for (int r = 0; r < 4; ++r) out[(jt * 16 + cc) * kPanel + it * 16 + kq + 4 * r] = acc[k][r];
         }
     };
-    if constexpr (DIAG) {
-        switch (wave) {
-            case 0: pipeline(std::integral_constant<int, 0>{}); break;
-            case 1: pipeline(std::integral_constant<int, 1>{}); break;
-            case 2: pipeline(std::integral_constant<int, 2>{}); break;
-            default: pipeline(std::integral_constant<int, 3>{}); break;
+    auto run = [&](auto Fc) {
+        if constexpr (DIAG) {
+            switch (wave) {
+                case 0: pipeline(std::integral_constant<int, 0>{}, Fc); break;
+                case 1: pipeline(std::integral_constant<int, 1>{}, Fc); break;
+                case 2: pipeline(std::integral_constant<int, 2>{}, Fc); break;
+                default: pipeline(std::integral_constant<int, 3>{}, Fc); break;
+            }
+        } else {
+            pipeline(std::integral_constant<int, -1>{}, Fc);
         }
-    } else {
-        pipeline(std::integral_constant<int, -1>{});
-    }
+    };
+    if (full) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 // Out[row0 + r, c0 + c] = sum_k In[row0 + r, k] * W[k, c0 + c]; grid = (row tiles of 128, column panels).
@@ -290,9 +296,6 @@ __global__ __launch_bounds__(kThreads) void rmul_kernel(const double* __restrict
 // runs on across tile boundaries: no staging of In through LDS and no barrier in the loop.
 // NG k-groups of 4 (kcols <= 4*NG), NI output-column tiles of 16 (rcols <= 16*NI), RING | NG: <32, 8, 16> is the 128 x 128
 // case, <33, 9, 11> covers m = 129 .. 132 (one slack / ball column more than 128) with 152 KB of LDS.
-#ifndef LFPSQP_RMUL_ABL
-#define LFPSQP_RMUL_ABL 0     // development ablations: bit 0 = no global loads in the loop, bit 1 = no stores
-#endif
 template <int NG, int NI, int RING, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rmul_resident_kernel(const double* __restrict__ In, int64_t ld_in, int64_t n, int kcols,
                                                                   const double* __restrict__ W, int ldw, int rcols,
@@ -346,11 +349,9 @@ __global__ __launch_bounds__(64 * WAVES) void rmul_resident_kernel(const double*
                 double v[HN];
 #pragma unroll
                 for (int h = 0; h < HN; ++h) v[h] = bv[h][slot];
-#if !(LFPSQP_RMUL_ABL & 1)
                 const double* p = in_ptr(tt, gbase + slot);          // refill the slot with the group RING ahead
 #pragma unroll
                 for (int h = 0; h < HN; ++h) bv[h][slot] = __builtin_nontemporal_load(p + 16 * h);
-#endif
                 const int gn = (g8 + slot + 1 < NG) ? (g8 + slot + 1) : 0;      // the next k-group (of the next tile after the last)
                 double wn[NI];
 #pragma unroll
@@ -373,11 +374,7 @@ __global__ __launch_bounds__(64 * WAVES) void rmul_resident_kernel(const double*
                 double* o = Out + (int64_t)col * ld_out + row;
 #pragma unroll
                 for (int h = 0; h < HN; ++h) {
-#if LFPSQP_RMUL_ABL & 2
-                    if (acc[it][h][r] == 1.2345) o[16 * h] = acc[it][h][r];
-#else
                     if (row + 16 * h < n) o[16 * h] = acc[it][h][r];
-#endif
                 }
             }
     }
@@ -422,33 +419,49 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
 #ifndef LFPSQP_GRAM_WGS
 #define LFPSQP_GRAM_WGS 2
 #endif
-    const int64_t gmax = LFPSQP_GRAM_WGS * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 128);     // two workgroups per CU: one stages while the other multiplies
-    int groups = (int)(nsteps < gmax ? (nsteps < 1 ? 1 : nsteps) : gmax);
-    LF_TRY(ensure_part(ctx, (size_t)groups * pp));
+    // row groups per launch: as many as fill the device with all pairs of the launch resident at once (two workgroups per CU), a
+    // multiple of 8 (one XCD each, see gram_kernel)
+    const int64_t slots = LFPSQP_GRAM_WGS * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 128);
+    auto groups_for = [&](int np) -> int {
+        int64_t gcount = slots / np / 8 * 8;
+        const int64_t need = (nsteps + 7) / 8 * 8;
+        if (gcount > need) gcount = need;
+        return (int)(gcount < 8 ? 8 : gcount);
+    };
+    const int noff = npair - npan;
+    const int gd = groups_for(npan), go = noff > 0 ? groups_for(noff) : 0;
+    LF_TRY(ensure_part(ctx, (size_t)std::max(gd, go) * pp));
     LF_TRY(ensure_small(ctx, (size_t)pp));
-    const dim3 gd(groups, npan), go(groups, npair - npan);
+    const int64_t tile2 = (int64_t)kPanel * kPanel;
     if (w2) {
-        hipLaunchKernelGGL((gram_kernel<true, true>), gd, dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2, ctx->part, pp);
-        if (npair > npan)
-            hipLaunchKernelGGL((gram_kernel<false, true>), go, dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2, ctx->part, pp);
+        hipLaunchKernelGGL((gram_kernel<true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pp);
+        if (noff > 0)
+            hipLaunchKernelGGL((gram_kernel<false, true>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, w2, ctx->part, pp);
     } else {
-        hipLaunchKernelGGL((gram_kernel<true, false>), gd, dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2, ctx->part, pp);
-        if (npair > npan)
-            hipLaunchKernelGGL((gram_kernel<false, false>), go, dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, w2, ctx->part, pp);
+        hipLaunchKernelGGL((gram_kernel<true, false>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pp);
+        if (noff > 0)
+            hipLaunchKernelGGL((gram_kernel<false, false>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, w2, ctx->part, pp);
     }
     LF_LAUNCH_CHECK(ctx);
-    // reduce the `groups` partials (pp columns: 32 per workgroup)
-    hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3((unsigned)((pp + 31) / 32), 1), dim3(1024), 0, ctx->stream, ctx->part,
-                       (int64_t)groups, (int)pp, (int)pp, 0u, ctx->small, 0, (int64_t)groups, 5, NoPost());
+    // reduce the partials of each launch over its row groups (32 columns per workgroup)
+    hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3((unsigned)((npan * tile2 + 31) / 32), 1), dim3(1024), 0, ctx->stream, ctx->part,
+                       (int64_t)gd, (int)(npan * tile2), (int)pp, 0u, ctx->small, 0, (int64_t)gd, 5, NoPost());
     LF_LAUNCH_CHECK(ctx);
+    if (noff > 0) {
+        hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3((unsigned)((noff * tile2 + 31) / 32), 1), dim3(1024), 0, ctx->stream,
+                           ctx->part + npan * tile2, (int64_t)go, (int)(noff * tile2), (int)pp, 0u, ctx->small + npan * tile2, 0, (int64_t)go, 5,
+                           NoPost());
+        LF_LAUNCH_CHECK(ctx);
+    }
     LF_TRY(allreduce_dev(ctx, ctx->small, pp, 0));
     std::vector<double> h((size_t)pp);
     LF_HIP(ctx, hipMemcpyAsync(h.data(), ctx->small, sizeof(double) * pp, hipMemcpyDeviceToHost, ctx->stream));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     {
-        size_t pidx = 0;
+        size_t poff = npan;                     // slots of the pairs pi < pj follow the npan diagonal ones
         for (int pi = 0; pi < npan; ++pi)
-            for (int pj = pi; pj < npan; ++pj, ++pidx) {
+            for (int pj = pi; pj < npan; ++pj) {
+                const size_t pidx = (pi == pj) ? (size_t)pi : poff++;
                 const double* blk = h.data() + pidx * kPanel * kPanel;
                 for (int j = 0; j < kPanel; ++j) {
                     const int gj = pj * kPanel + j;

@@ -16,6 +16,7 @@ from oracle import synth  # noqa: E402
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: no host-name lookups for the pair connections
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     lib = L.load_library(os.path.join(ROOT, "tests", "emu", "_build", "liblfpsqp_emu.so"))
     ctx = L.Context(0, lib)

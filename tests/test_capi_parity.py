@@ -410,7 +410,7 @@ def test_c_port_agrees_with_numpy_oracle():
 
 
 # ----------------------------------------------------------------------------- tangent setup
-@pytest.mark.parametrize("n,m", [(700, 5), (2049, 16), (1500, 130)])
+@pytest.mark.parametrize("n,m", [(700, 5), (2049, 16), (1500, 130), (900, 260), (600, 300)])   # 1, 1 (+2 border), 2 (+4 border), 3 panels
 def test_gram_and_rmul(dev_ctx, n, m):
     ctx = dev_ctx
     rng = np.random.default_rng(11)

@@ -74,7 +74,7 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "host-gloo",
-                          "--device", "0"] + common, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                          "--device", "0", "--watchdog-seconds", "240"] + common, cwd=ROOT, capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert two.returncode == 0, (two.stdout[-1500:], two.stderr[-3000:])
     lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
