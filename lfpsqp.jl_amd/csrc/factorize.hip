@@ -25,22 +25,6 @@ constexpr int kKStep = 16;
 constexpr int kLdsLd = 144;   // row stride 288 dwords = 32 mod 64: the two k-rows a half-wave reads hit disjoint banks
 typedef double f64x4 __attribute__((vector_size(32)));
 
-__device__ __forceinline__ void tile_mfma(const double (*As)[kLdsLd], const double (*Bs)[kLdsLd], f64x4 (&acc)[2][8], int wave, int lane) {
-    const int c = lane & 15;
-#pragma unroll
-    for (int kk = 0; kk < kKStep; kk += 4) {
-        const int kr = kk + (lane >> 4);
-        const double a0 = As[kr][(2 * wave) * 16 + c];
-        const double a1 = As[kr][(2 * wave + 1) * 16 + c];
-#pragma unroll
-        for (int jt = 0; jt < 8; ++jt) {
-            const double b = Bs[kr][jt * 16 + c];
-            acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][jt], 0, 0, 0);
-            acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][jt], 0, 0, 0);
-        }
-    }
-}
-
 // The Gram kernel stages its panels TRANSPOSED, T[column][k], with a row stride of 17 doubles (34 dwords).  The compiler pairs the
 // operand reads of two k-groups into ds_read2_b64, which the LDS serves in groups of 16 consecutive lanes on (address / 4) mod 32
 // banks: the 16 columns of a group start 2 banks apart and each read covers 2 -- conflict-free (a stride of 18 doubles, 16-byte
@@ -229,60 +213,107 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
     else run(std::false_type{});
 }
 
-// Out[row0 + r, c0 + c] = sum_k In[row0 + r, k] * W[k, c0 + c]; grid = (row tiles of 128, column panels).
-// The contraction is computed transposed (i = output column c, j = matrix row r) so that each
-// accumulator register stores 16 consecutive matrix rows (128 contiguous bytes per column).
-__global__ __launch_bounds__(kThreads) void rmul_kernel(const double* __restrict__ In, int64_t ld_in, int64_t n, int kcols,
-                                                         const double* __restrict__ W, int ldw, int rcols, double* __restrict__ Out,
-                                                         int64_t ld_out) {
-    __shared__ double As[kKStep][kLdsLd];   // As[k][c] = W[k0+k, c0+c]
-    __shared__ double Bs[kKStep][kLdsLd];   // Bs[k][r] = In[row0+r, k0+k]
+// Out[row0 + r, c0 + c] = sum_k In[row0 + r, k] * W[k, c0 + c] for any shape: one workgroup per (128-row tile, 128-column panel).
+// The contraction is computed transposed (i = output column c, j = matrix row r) so that each accumulator register stores 16
+// consecutive matrix rows (128 contiguous bytes per column); wave w owns the column tiles 2w, 2w + 1 and all 8 row tiles.
+// Wd is W laid out for staging: row-major [kpad][rpad] (k padded to 16, columns to 128, zero filled) -- the loads of a step are
+// unconditional and fully coalesced, and both operands go to LDS with one 16-byte store per lane on consecutive addresses.
+// Same pipeline as gram_kernel: two LDS buffers per operand, the global loads of step s+2 in flight during step s, the operand
+// reads one k-group ahead of the MFMAs, one barrier per step (in its middle).
+// The column panels of one row tile are neighbours in dispatch order on one XCD (linear id L -> XCD L % 8), so the tile of In
+// comes from HBM once and from that XCD's L2 for the other panels (panel-major order read In once per panel: 4x at m = 512).
+__global__ __launch_bounds__(kThreads, 2) void rmul_kernel(const double* __restrict__ In, int64_t ld_in, int64_t n, int kcols,
+                                                            const double* __restrict__ Wd, int rpad, int rcols, double* __restrict__ Out,
+                                                            int64_t ld_out, int64_t ntiles, int ncp) {
+    __shared__ __attribute__((aligned(16))) double Ws[2][kKStep][kLdsLd];   // Ws[.][k][c] = W[k0+k, c0+c]
+    __shared__ __attribute__((aligned(16))) double Bs[2][kKStep][kLdsLd];   // Bs[.][k][r] = In[row0+r, k0+k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * kPanel;
-    const int c0 = blockIdx.y * kPanel;
+    const int cc = lane & 15, kq = lane >> 4;
+    const int xslot = (int)blockIdx.x >> 3;
+    const int cp = xslot % ncp;
+    const int64_t tile = (int64_t)(xslot / ncp) * 8 + ((int)blockIdx.x & 7);
+    if (tile >= ntiles) return;
+    const int64_t row0 = tile * kPanel;
+    const int c0 = cp * kPanel;
+    const int nk = (kcols + kKStep - 1) / kKStep;
+    // staging roles: W: rows wk + 4 j of the step, columns wc, wc + 1;  In: column bk of the step, rows br + 32 j, br + 32 j + 1
+    const int wk = tid >> 6, wc = (tid & 63) * 2;
+    const int bk = tid >> 4, br = (tid & 15) * 2;
+    double2 vw[4], vb[4];
+    auto load_step = [&](int s) {
+        const double* pw = Wd + (int64_t)(s * kKStep + wk) * rpad + c0 + wc;
+        const int kc = (s * kKStep + bk < kcols) ? (s * kKStep + bk) : (kcols - 1);     // clamped: rows >= kcols of Wd are zero
+        const double* pb = In + (int64_t)kc * ld_in + row0 + br;                         // rows >= n are zero padding
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            vw[j] = ld2(pw + (int64_t)(4 * j) * rpad);
+            vb[j] = ld2(pb + 32 * j);
+        }
+    };
+    auto write_lds = [&](int p) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<double2*>(&Ws[p][wk + 4 * j][wc]) = vw[j];
+            *reinterpret_cast<double2*>(&Bs[p][bk][br + 32 * j]) = vb[j];
+        }
+    };
+    struct Ops { double a0, a1, b[8]; };
+    auto read_ops = [&](Ops& o, int p, int kg) {
+        const int kr = 4 * kg + kq;
+        o.a0 = Ws[p][kr][(2 * wave) * 16 + cc];
+        o.a1 = Ws[p][kr][(2 * wave + 1) * 16 + cc];
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt) o.b[jt] = Bs[p][kr][jt * 16 + cc];
+    };
     f64x4 acc[2][8];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    // staging roles: In: k = tid / 16, rows (tid % 16)*8..+8 ; W: column tid / 2, k half (tid & 1)*8
-    const int kb = tid / 16, rb = (tid % 16) * 8;
-    const int ca = tid >> 1, ka = (tid & 1) * 8;
-    double va[8], vb[8];
-    auto load_step = [&](int k0) {
+    auto mfma_ops = [&](const Ops& o) {
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-            double2 b = make_double2(0.0, 0.0);
-            if (k0 + kb < kcols) b = ld2(In + (int64_t)(k0 + kb) * ld_in + row0 + rb + q);   // padded rows are zero
-            vb[q] = b.x; vb[q + 1] = b.y;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = k0 + ka + q;
-            va[q] = (k < kcols && c0 + ca < rcols) ? W[(int64_t)(c0 + ca) * ldw + k] : 0.0;
+        for (int jt = 0; jt < 8; ++jt) {
+            acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0, o.b[jt], acc[0][jt], 0, 0, 0);
+            acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1, o.b[jt], acc[1][jt], 0, 0, 0);
         }
     };
-    if (kcols > 0) load_step(0);
-    for (int k0 = 0; k0 < kcols; k0 += kKStep) {
-        __syncthreads();
+    Ops o0, o1;
+    if (nk > 0) {
+        load_step(0);
+        write_lds(0);
+    }
+    if (nk > 1) load_step(1);
+    __syncthreads();
+    if (nk > 0) read_ops(o0, 0, 0);
+    int s = 0;
+    while (s < nk) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            As[ka + q][ca] = va[q];
-            Bs[kb][rb + q] = vb[q];
+        for (int i = 0; i < 2; ++i) {          // LDS buffer i holds step s
+            if (s >= nk) break;
+            const bool more = s + 1 < nk;
+            read_ops(o1, i, 1);
+            mfma_ops(o0);
+            if (more) write_lds(i ^ 1);
+            if (s + 2 < nk) load_step(s + 2);
+            read_ops(o0, i, 2);
+            mfma_ops(o1);
+            read_ops(o1, i, 3);                 // the last read of this buffer, issued before the barrier (the next step rewrites it)
+            __syncthreads();
+            mfma_ops(o0);
+            if (more) read_ops(o0, i ^ 1, 0);
+            mfma_ops(o1);
+            ++s;
         }
-        __syncthreads();
-        if (k0 + kKStep < kcols) load_step(k0 + kKStep);   // next step's loads fly under this step's MFMAs
-        tile_mfma(As, Bs, acc, wave, lane);
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int col = c0 + (2 * wave + it) * 16 + (lane >> 4) + 4 * r;
+            const int col = c0 + (2 * wave + it) * 16 + kq + 4 * r;
             if (col >= rcols) continue;
 #pragma unroll
             for (int jt = 0; jt < 8; ++jt) {
-                const int64_t row = row0 + jt * 16 + (lane & 15);
+                const int64_t row = row0 + jt * 16 + cc;
                 if (row < n) Out[(int64_t)col * ld_out + row] = acc[it][jt][r];
             }
         }
@@ -497,7 +528,7 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
 
 static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const double* W_host, int rcols, lfpsqp_mat* Out) {
     if (rcols == 0 || In->n == 0) return 0;
-    LF_TRY(ensure_small(ctx, (size_t)kcols * rcols + 16));
+    LF_TRY(ensure_small(ctx, (size_t)kcols * rcols + 32 + ((size_t)kcols + kKStep) * ((size_t)rcols + kPanel)));
     LF_HIP(ctx, hipMemcpyAsync(ctx->small, W_host, sizeof(double) * (size_t)kcols * rcols, hipMemcpyHostToDevice, ctx->stream));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // W_host is caller-owned pageable memory
     const int64_t ntiles = (In->n + kPanel - 1) / kPanel;
@@ -514,8 +545,17 @@ static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const dou
         hipLaunchKernelGGL((rmul_resident_kernel<33, 9, 11, kRW>), pgrid, dim3(64 * kRW), 0, ctx->stream, In->p, In->ld, In->n, kcols,
                            ctx->small, kcols, rcols, Out->p, Out->ld, ntiles);
     } else {
-        hipLaunchKernelGGL(rmul_kernel, dim3((unsigned)ntiles, (unsigned)((rcols + kPanel - 1) / kPanel)), dim3(kThreads), 0, ctx->stream,
-                           In->p, In->ld, In->n, kcols, ctx->small, kcols, rcols, Out->p, Out->ld);
+        // W laid out for staging (rmul_kernel): row-major, k padded to the 16-deep step, columns to the 128-wide panel
+        const int ncp = (rcols + kPanel - 1) / kPanel, rpad = ncp * kPanel, kpad = (kcols + kKStep - 1) / kKStep * kKStep;
+        std::vector<double> Wd((size_t)kpad * rpad, 0.0);
+        for (int c = 0; c < rcols; ++c)
+            for (int k = 0; k < kcols; ++k) Wd[(size_t)k * rpad + c] = W_host[(size_t)c * kcols + k];
+        double* wdev = ctx->small + (((size_t)kcols * rcols + 15) & ~(size_t)15);
+        LF_HIP(ctx, hipMemcpyAsync(wdev, Wd.data(), sizeof(double) * Wd.size(), hipMemcpyHostToDevice, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int64_t tgroups = (ntiles + 7) / 8;
+        hipLaunchKernelGGL(rmul_kernel, dim3((unsigned)(tgroups * 8 * ncp)), dim3(kThreads), 0, ctx->stream, In->p, In->ld, In->n, kcols,
+                           wdev, rpad, rcols, Out->p, Out->ld, ntiles, ncp);
     }
     LF_LAUNCH_CHECK(ctx);
     return 0;
