@@ -20,3 +20,10 @@ d = json.loads([l for l in open("gpurun_out/final/bench_profiled.json") if l.sta
 print("profiled process: live F avg_launch_ms", d["roofline"]["avg_launch_ms"], "value", d["value"])
 PY
 bash tools/gpu_pmc_sq.sh > /dev/null 2>&1; cp gpurun_out/sq_counters.txt $O/sq_counters.txt; cat $O/sq_counters.txt
+# tangent setup: kernel statistics at the two headline shapes, SQ / LDS / MFMA counters and HBM traffic at (5e6, 512), the fp64 MFMA ceiling
+bash tools/gpu_factorize_prof.sh 1e7 128 > /dev/null 2>&1; bash tools/gpu_factorize_prof.sh 5e6 512 > /dev/null 2>&1
+cp gpurun_out/factorize_prof_1e7_128.txt gpurun_out/factorize_prof_5e6_512.txt $O/; cat $O/factorize_prof_5e6_512.txt | head -8
+bash tools/gpu_pmc_factorize.sh 5e6 512 > /dev/null 2>&1; cp gpurun_out/factorize_sq_counters.txt $O/
+bash tools/gpu_pmc_fetch_factorize.sh 5e6 512 > /dev/null 2>&1; cp gpurun_out/factorize_traffic.txt $O/; cat $O/factorize_traffic.txt
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_peak tools/micro/mfma_f64_peak.hip && /tmp/mfma_peak > $O/mfma_f64_peak.txt; tail -4 $O/mfma_f64_peak.txt
+rm -rf gpurun_out/fprof_*
