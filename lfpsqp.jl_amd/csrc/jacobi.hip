@@ -85,14 +85,21 @@ __device__ __forceinline__ double fast_rcp(double x) {
 #endif
 }
 
+constexpr double kJacQuadTol = 1e-7;    // relative off-diagonal level from which two more sweeps reach rounding (quadratic convergence)
+
 // B columns per block, 2B per workgroup; LPP lanes per column pair (B * LPP threads), each holding MAXROWS / LPP rows of both
 // columns in registers for the dot products and the rotation of a local round (one batch of LDS reads, one of writes per round).
 template <int B, int MAXROWS, int LPP>
 __global__ __launch_bounds__(B* LPP) void jacobi_round_kernel(double* __restrict__ X, int ld, int rows_dot, int rows_all, int nb, int round,
                                                                int sweep, unsigned long long* off, double tol) {
-    for (int k = 0; k < sweep; ++k) {                  // an earlier sweep found nothing left to rotate: done
+    // done already?  A sweep that found nothing left to rotate (off <= tol) ends the iteration; so does, one sweep later, a sweep
+    // that STARTED from off <= kJacQuadTol: its own rotations square that (cyclic Jacobi converges quadratically, also for
+    // clustered values), and the sweep after it -- which the host has queued by the time it sees the number -- squares it again.
+    for (int k = 0; k < sweep; ++k) {
         const unsigned long long u = (unsigned long long)ld_stat(reinterpret_cast<const int64_t*>(off) + k);
-        if (u != kJacUnset && __builtin_bit_cast(double, u) <= tol) return;
+        if (u == kJacUnset) continue;
+        const double o = __builtin_bit_cast(double, u);
+        if (o <= tol || (k + 2 <= sweep && o <= kJacQuadTol)) return;
     }
     constexpr int THREADS = B * LPP;
     constexpr int RPL = MAXROWS / LPP;                 // rows per lane
@@ -236,7 +243,8 @@ bool device_jacobi(lfpsqp_ctx* ctx, int rows_dot, int rows_all, int cols, std::v
         if (sweep >= 1) {                                // one sweep behind: the next one is queued while this result travels
             if (hipEventSynchronize(ctx->ev_slot[(sweep - 1) & 3]) != hipSuccess) return false;
             const unsigned long long u = hoff[sweep - 1];
-            if (u == kJacUnset || __builtin_bit_cast(double, u) <= tol) done = true;     // (unset: that sweep's launches were no-ops already)
+            // (unset: that sweep's launches were no-ops already; <= kJacQuadTol: sweep - 1 and the queued sweep finish the job)
+            if (u == kJacUnset || __builtin_bit_cast(double, u) <= kJacQuadTol) done = true;
         }
     }
     if (hipMemcpy2DAsync(X.data(), sizeof(double) * rows_all, dX, sizeof(double) * ldx, sizeof(double) * rows_all, (size_t)cols, hipMemcpyDeviceToHost,
@@ -244,7 +252,11 @@ bool device_jacobi(lfpsqp_ctx* ctx, int rows_dot, int rows_all, int cols, std::v
         return false;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
     if (sweeps_out) *sweeps_out = sweep;
-    if (getenv("LFPSQP_TRACE_FACTORIZE")) fprintf(stderr, "[jacobi] rows %d/%d cols %d B %d: %d sweeps queued\n", rows_dot, rows_all, cols, B, sweep);
+    if (getenv("LFPSQP_TRACE_FACTORIZE")) {
+        fprintf(stderr, "[jacobi] rows %d/%d cols %d B %d: %d sweeps queued, off per sweep:", rows_dot, rows_all, cols, B, sweep);
+        for (int k = 0; k < sweep; ++k) fprintf(stderr, " %.1e", hoff[k] == kJacUnset ? -1.0 : __builtin_bit_cast(double, (unsigned long long)hoff[k]));
+        fprintf(stderr, "\n");
+    }
     return true;
 }
 
