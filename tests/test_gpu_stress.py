@@ -17,3 +17,12 @@ def test_many_tiny_solves_in_a_fresh_process(proc):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "bad 0 of" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,args", [("fuzz_factorize.py", ["30", "7"]), ("fuzz_onepass.py", ["40", "5"])])
+def test_fuzz_random_shapes(script, args):
+    """tools/fuzz_*.py on the GPU: random (n, m) through the tangent-setup kernels (Gram plain / weighted / leading columns, all three rmul
+    kernels, lfpsqp_factorize against numpy: 5e-12) and through the one-pass kernels against the two-pass ones."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)] + args, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and " 0 mismatches" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])

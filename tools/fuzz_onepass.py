@@ -54,3 +54,5 @@ for case in range(cases):
     for o in (J, Z, a, b):
         o.free()
 print("fuzz: bad", bad, "of", cases)
+print(f"{cases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
