@@ -74,6 +74,7 @@ def main(argv=None, lib=None):
             # one node: keep gloo's pair connections on the loopback interface instead of whatever the host name resolves to
             # (it may not resolve at all on these boxes, and a resolver time-out per connection stalls the rendezvous)
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")        # RCCL's bootstrap sockets likewise (the data path is xGMI / P2P)
         # control plane only, on CPU tensors (gloo): barriers, the RCCL id, the max over ranks.  The data path is the library's own
         # RCCL communicator; the torch-nccl callback (--comm torch, or the fallback) gets a separate nccl group when it is needed.
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
