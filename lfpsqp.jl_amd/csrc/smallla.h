@@ -39,7 +39,7 @@ inline void jacobi_svd(int rows, int cols, const std::vector<double>& Ain, std::
     const int np = cols + (cols & 1);                    // players of the tournament (one dummy if cols is odd)
     std::vector<int> seat(np);
     for (int k = 0; k < np; ++k) seat[k] = (k < cols) ? k : -1;
-    const int nthreads = (cols >= 192 && rows >= 192) ? small_threads() : 1;   // below that a round is too short to share
+    [[maybe_unused]] const int nthreads = (cols >= 192 && rows >= 192) ? small_threads() : 1;   // below that a round is too short to share
     // Squared column norms are carried along (a rotation changes them by -+ t*gamma exactly) and recomputed at the start
     // of every sweep, so a pair costs one dot product instead of three.
     std::vector<double> sq(cols);
