@@ -182,9 +182,9 @@ def main(argv=None, lib=None):
     t0 = time.perf_counter()
     iters, nr = L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=K, work=work, n_global=n, want_lambda=False, resume=resumed)
     ctx.sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0          # this rank's K steps (they contain the collectives, so no rank finishes a step early);
+    if dist is not None:                        # the closing barrier of the bracket, then the MAX over ranks below -- the barrier's own
+        dist.barrier()                          # host-side (gloo) latency is not part of the K steps
     prof_ms, prof_cnt = ctx.profile_read()
     ctx.set_profiling(False)
     if dist is not None:
