@@ -409,6 +409,21 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         sparse = {"nnz": Ssp.nnz, "nnz_per_row": k_sp, "spmv_t_ms": ms_st, "spmv_t_GBs": gbs(by_t, ms_st), "spmv_n_ms": ms_sn,
                   "spmv_n_GBs": gbs(by_n, ms_sn), "dense_matrix_GB": 8.0 * n_loc * m / 1e9, "algorithmic_GB": by_t / 1e9}
         Ssp.free()
+        # tangent setup of a sparse block (lfpsqp_factorize_sp: Gram on the dense twin, basis-forming products from the nonzeros)
+        # against the dense factorisation of the same matrix; random values so that the block has full rank
+        vals_r = (np.random.default_rng(5).standard_normal((n_loc, k_sp)) + 2.0 * (np.arange(k_sp) == 0)).ravel()
+        Sr = L.SparseMatrix(ctx, n_loc, m, rows_sp, cols_sp.ravel(), vals_r)
+        Jd, Zs = Sr.to_dense(), ctx.matrix(n_loc, m)
+        tf = {}
+        for tag, kw in (("dense", dict()), ("from_nonzeros", dict(Jsp=Sr))):
+            L.ksvd_(Jd, Zs, **kw)
+            ctx.sync(); t0 = time.perf_counter()
+            for _ in range(3):
+                Sg, _, rk = L.ksvd_(Jd, Zs, **kw)
+            ctx.sync(); tf[tag] = (time.perf_counter() - t0) * 1e3 / 3
+        sparse.update({"factorize_dense_ms": tf["dense"], "factorize_from_nonzeros_ms": tf["from_nonzeros"], "factorize_rank": int(rk),
+                       "factorize_cond": float(Sg[0] / Sg[-1])})
+        Sr.free()
     except Exception as e:      # diagnostics only
         sparse = {"error": repr(e)}
     rates = stream_rates(ctx, L, nbig=int(max(1 << 20, min(400_000_000, 40 * n_loc))))

@@ -224,6 +224,13 @@ int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const doub
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
                      double* W, int64_t* rank, double eps_rank);
 
+/* The same factorisation when the constraint gradients are sparse: A = [S | Jct[:, S.m : Jct.m)], i.e. the sparse object holds the
+ * leading columns and the dense twin Jct (n x M, M - S.m <= 4: the ball / slack columns; NULL when there are none) the rest.  The
+ * basis-forming products Z = A * W stream the NONZEROS and write the dense basis (bound by that write: a third of the dense MFMA
+ * product at m = 128, K = 4); the Gram matrix comes from the dense twin when there is one, else S is expanded into Z first.  Results as
+ * lfpsqp_factorize(ctx, <dense A>, ...): identical Sigma / Vt / rank (same Gram matrix), Z equal up to the rounding of the product. */
+int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma,
+                        double* Vt, double* W, int64_t* rank_out, double eps_rank);
 /* The replicated small step of lfpsqp_factorize on its own: thin SVD A = U diag(S) V' of a small host matrix (rows x cols,
  * column-major, rows >= 1, rows + cols <= 1024 for the device path) by one-sided Jacobi -- on the device from 64 columns on
  * (block Jacobi, csrc/jacobi.hip), on the host below that.  U: rows x cols (normalised columns), S: cols (descending),

@@ -163,6 +163,7 @@ c_y_retract(ctx, xnew, x, id) = ccall((:lfpsqp_y_retract, lib), Cint, (Ptr{Cvoid
 c_gram(ctx, M, ncols, w2, G) = ccall((:lfpsqp_gram, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Float64}), ctx, M, ncols, w2, G)
 c_rmul(ctx, In, kcols, W, rcols, Out) = ccall((:lfpsqp_rmul, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Ptr{Cvoid}), ctx, In, kcols, W, rcols, Out)
 c_factorize(ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank) = ccall((:lfpsqp_factorize, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64), ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank)
+c_factorize_sp(ctx, S, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank) = ccall((:lfpsqp_factorize_sp, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64), ctx, S, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank)
 c_small_svd(ctx, rows, cols, A, U, S, V) = ccall((:lfpsqp_small_svd, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx, rows, cols, A, U, S, V)
 c_q_gemv_t(ctx, Q, v, w, t) = ccall((:lfpsqp_q_gemv_t, lib), Cint, (Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, Q, v, w, t)
 c_q_gemv_n(ctx, Q, a, w, t, b, y) = ccall((:lfpsqp_q_gemv_n, lib), Cint, (Ptr{Cvoid}, Ref{CBasis}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}), ctx, Q, a, w, t, b, y)
@@ -425,10 +426,15 @@ y_retract!(xnew::DeviceVector, x::DeviceVector, id::InequalityData) = (check(x.c
 
 # ksvd! (src/la_helper.jl:8-34, call sites src/optimize.jl:291/293): thin factorisation of diag(sqrt(w2)) Jct; Jct is NOT
 # destroyed.  Returns the rank by the reference's rule (Σ_j >= ϵ_rank, :297-302).  W (optional m x m): Z == Jct*W.
+# Jsp (optional SparseMatrix with the entries of the leading Jsp.m columns of Jct): the basis-forming products stream the nonzeros.
 function ksvd!(Jct::DeviceMatrix, Z::DeviceMatrix, Σ::Vector{Float64}, Vt::Matrix{Float64}; w2::Union{Nothing,DeviceVector}=nothing,
-               ϵ_rank::Float64=1e-10, W::Union{Nothing,Matrix{Float64}}=nothing)
+               ϵ_rank::Float64=1e-10, W::Union{Nothing,Matrix{Float64}}=nothing, Jsp=nothing)
     rank = Ref{Int64}(0)
-    check(Jct.ctx, c_factorize(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, Z.h, Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
+    if Jsp === nothing
+        check(Jct.ctx, c_factorize(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, Z.h, Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
+    else
+        check(Jct.ctx, c_factorize_sp(Jct.ctx.h, Jsp.h, Jct.h, w2 === nothing ? C_NULL : w2.h, Z.h, Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
+    end
     return Int(rank[])
 end
 
@@ -1069,7 +1075,8 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
         rank = m
         if m > 0
             jac!(Jct, cval, x)                                                          # :283-284 (the device keeps only Jct)
-            rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W)     # :286-302
+            jsp = (c! isa DeviceConstraints && c!.Jsp != C_NULL) ? (h = c!.Jsp,) : nothing     # sparse twin of the linear block, if any
+            rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp)     # :286-302
             if !ineq                                                                    # :305-308
                 mul!(tmp_m, adjoint(DeviceBasis(Z, rank)), d)
                 mul!(d, DeviceBasis(Z, rank), tmp_m, -1.0, 1.0)

@@ -15,8 +15,11 @@
 #include <type_traits>
 #include <vector>
 
+#include <functional>
+
 #include "internal.h"
 #include "smallla.h"
+#include "sparse.h"
 
 namespace lfpsqp {
 
@@ -710,6 +713,99 @@ static void refine_round(lfpsqp_ctx* ctx, int m, std::vector<double>& V, std::ve
     if (moved) *rotated = true;
 }
 
+// ---------------------------------------------------------------------------
+// The factorisation of an n x m matrix A that is only reachable through two operations: gramA(G) = A' diag(w2) A (m x m, host,
+// replicated) and rmulA(Wh, r) = "Z[:, :r] = A * Wh" (Wh: m x r, host, column-major).  lfpsqp_factorize supplies the dense MFMA
+// kernels, lfpsqp_factorize_sp the products of a sparse A.
+using GramFn = std::function<int(std::vector<double>&)>;
+using RmulFn = std::function<int(const double*, int)>;
+static int factorize_core(lfpsqp_ctx* ctx, int m, const GramFn& gramA, const RmulFn& rmulA, const double* w2p, lfpsqp_mat* Z, double* Sigma,
+                          double* Vt, double* W, int64_t* rank_out, double eps_rank) {
+    *rank_out = 0;
+    if (m == 0) return 0;
+    for (size_t i = 0; i < (size_t)m * m; ++i) Vt[i] = 0.0;
+    if (W)
+        for (size_t i = 0; i < (size_t)m * m; ++i) W[i] = 0.0;
+    auto zero_from = [&](int r) -> int {       // columns >= r of Z are zero (the rmul passes overwrite columns < r completely)
+        if (r < Z->m) {
+            hipLaunchKernelGGL(zero_cols_kernel, dim3(256, (unsigned)(Z->m - r)), dim3(kThreads), 0, ctx->stream, Z->p, Z->ld, Z->n, r);
+            LF_LAUNCH_CHECK(ctx);
+        }
+        return 0;
+    };
+    auto finish = [&](const std::vector<double>& sig, const std::vector<double>& V, int r, const std::vector<double>* Wr) {
+        for (int j = 0; j < m; ++j) Sigma[j] = sig[j];
+        for (int k = 0; k < r; ++k)
+            for (int j = 0; j < m; ++j) Vt[(size_t)j * m + k] = V[(size_t)k * m + j];     // Vt[k, j] = V[j, k]; rows >= rank stay zero
+        if (W && Wr)
+            for (size_t i = 0; i < (size_t)m * r; ++i) W[i] = (*Wr)[i];                  // Z[:, :r] = Jct * W[:, :r]; columns >= r stay zero
+        *rank_out = r;
+    };
+    // 1. G = A'A (A = diag(sqrt(w2)) Jct), eigen-decomposition: estimates of the singular values and right singular vectors
+    std::vector<double> G, sig, V;
+    const double t_start = now_ms();
+    LF_TRY(gramA(G));
+    for (double g : G)
+        if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix");
+    const double t_eig = now_ms();
+    gram_eig(ctx, m, G, sig, V);
+    if (kTraceFactorize) fprintf(stderr, "[factorize] gram %.3f ms, eig %.3f ms\n", t_eig - t_start, now_ms() - t_eig);
+    if (!(sig[0] > 0.0)) {                     // A == 0
+        LF_TRY(zero_from(0));
+        finish(sig, V, 0, nullptr);
+        return 0;
+    }
+    // 2. A well-conditioned full-rank factor needs nothing more: the loss of orthogonality of A V S^-1 and the relative error of the
+    //    small singular values are eps * cond(A)^2, i.e. rounding level for cond(A)^2 <= 10 (the dense random equality blocks of
+    //    the BASELINE configs have cond ~ 1.1).  Then A = (A V S^-1) S V' is already the factorisation.
+    if (sig[m - 1] >= eps_rank && sig[0] * sig[0] <= 10.0 * sig[m - 1] * sig[m - 1]) {
+        std::vector<double> W1((size_t)m * m);
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < m; ++i) W1[(size_t)j * m + i] = V[(size_t)j * m + i] / sig[j];
+        LF_TRY(rmulA(W1.data(), m));
+        LF_TRY(zero_from(m));
+        finish(sig, V, m, &W1);
+        return 0;
+    }
+    // 3. Otherwise the eigenvalues of G below ~eps * sig_1^2 are noise (a Gram matrix squares the condition number), while the
+    //    reference's dgesvd is backward stable and its rank test is ABSOLUTE (sig_j >= eps_rank = 1e-10, src/optimize.jl:297-302).
+    //    Refinement rounds resolve what dgesvd resolves: form the trial basis Z = A V diag(1/s) with the current estimates,
+    //    measure its Gram matrix on the device, and correct V and the singular values from it on the host (refine_round: a
+    //    one-sided Jacobi step on a well-scaled m x m factor -- every round gains ~8 digits of relative range; converged when
+    //    the trial basis is orthogonal to the rounding floor of the products).  Cost per round: one rmul + one Gram pass.
+    const double tol = 4e-13;
+    constexpr int kMaxRounds = 6;
+    std::vector<double> s(m), Wk((size_t)m * m), GZ;
+    bool z_is_final = false;
+    for (int round = 1; round <= kMaxRounds; ++round) {
+        for (int j = 0; j < m; ++j) s[j] = std::max(sig[j], 1e-12 * sig[0]);
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < m; ++i) Wk[(size_t)j * m + i] = V[(size_t)j * m + i] / s[j];
+        LF_TRY(rmulA(Wk.data(), m));
+        LF_TRY(gram_impl(ctx, Z, m, w2p, GZ));
+        for (double g : GZ)
+            if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix of the trial basis");
+        double offmax = 0.0, devmax = 0.0;
+        bool conv = false, rotated = false;
+        refine_round(ctx, m, V, sig, s, GZ, tol, &offmax, &conv, &devmax, &rotated);
+        if (conv && !rotated && devmax <= tol) {          // the basis on the device IS A V diag(1/sig) for every kept column
+            z_is_final = true;
+            break;
+        }
+        // quadratic convergence: a correction computed from an almost orthogonal trial basis (off-diagonals E) leaves E^2
+        if (conv || offmax <= 5e-7) break;
+    }
+    int r = 0;
+    while (r < m && sig[r] >= eps_rank && sig[r] > 0) ++r;                               // the reference's rule, src/optimize.jl:297-302
+    std::vector<double> Wr((size_t)m * std::max(r, 1));
+    for (int j = 0; j < r; ++j)
+        for (int i = 0; i < m; ++i) Wr[(size_t)j * m + i] = V[(size_t)j * m + i] / sig[j];
+    if (r > 0 && !z_is_final) LF_TRY(rmulA(Wr.data(), r));
+    LF_TRY(zero_from(r));
+    finish(sig, V, r, &Wr);
+    return 0;
+}
+
 }  // namespace lfpsqp
 
 using namespace lfpsqp;
@@ -746,90 +842,34 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
     LF_ARG(ctx, ctx && Jct && Z && Sigma && Vt && rank_out && Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m &&
                     (!w2 || w2->n == Jct->n));
     const int m = (int)Jct->m;
-    *rank_out = 0;
-    if (m == 0) return 0;
     const double* w2p = w2 ? w2->p : nullptr;
-    for (size_t i = 0; i < (size_t)m * m; ++i) Vt[i] = 0.0;
-    if (W)
-        for (size_t i = 0; i < (size_t)m * m; ++i) W[i] = 0.0;
-    auto zero_from = [&](int r) -> int {       // columns >= r of Z are zero (the rmul passes overwrite columns < r completely)
-        if (r < Z->m) {
-            hipLaunchKernelGGL(zero_cols_kernel, dim3(256, (unsigned)(Z->m - r)), dim3(kThreads), 0, ctx->stream, Z->p, Z->ld, Z->n, r);
-            LF_LAUNCH_CHECK(ctx);
-        }
-        return 0;
+    return factorize_core(
+        ctx, m, [&](std::vector<double>& G) { return gram_impl(ctx, Jct, m, w2p, G); },
+        [&](const double* Wh, int r) { return rmul_impl(ctx, Jct, m, Wh, r, Z); }, w2p, Z, Sigma, Vt, W, rank_out, eps_rank);
+}
+
+int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma,
+                        double* Vt, double* W, int64_t* rank_out, double eps_rank) {
+    LF_ARG(ctx, ctx && S && Z && Sigma && Vt && rank_out && S->n == Z->n && (!w2 || w2->n == S->n) &&
+                    (!Jct || (Jct->p != Z->p && Jct->n == S->n && Jct->m >= S->m && Jct->m - S->m <= 4)) && Z->m >= (Jct ? Jct->m : S->m));
+    const int ms = (int)S->m, m = Jct ? (int)Jct->m : ms;
+    const double* w2p = w2 ? w2->p : nullptr;
+    // Gram matrix: on the dense twin when there is one (it holds the extra columns too); else S is expanded into Z, which the first
+    // basis-forming product overwrites anyway.  (A Gram matrix from the nonzeros alone needs scattered accumulation -- LDS atomics, whose
+    // order is not reproducible -- and is not built: DESIGN.md 5.5.)
+    auto gramA = [&](std::vector<double>& G) -> int {
+        if (Jct) return gram_impl(ctx, Jct, m, w2p, G);
+        LF_TRY(lfpsqp_spmat_to_dense(ctx, S, Z));
+        return gram_impl(ctx, Z, m, w2p, G);
     };
-    auto finish = [&](const std::vector<double>& sig, const std::vector<double>& V, int r, const std::vector<double>* Wr) {
-        for (int j = 0; j < m; ++j) Sigma[j] = sig[j];
-        for (int k = 0; k < r; ++k)
-            for (int j = 0; j < m; ++j) Vt[(size_t)j * m + k] = V[(size_t)k * m + j];     // Vt[k, j] = V[j, k]; rows >= rank stay zero
-        if (W && Wr)
-            for (size_t i = 0; i < (size_t)m * r; ++i) W[i] = (*Wr)[i];                  // Z[:, :r] = Jct * W[:, :r]; columns >= r stay zero
-        *rank_out = r;
+    auto rmulA = [&](const double* Wh, int r) -> int {
+        if (r == 0) return 0;
+        LF_TRY(ensure_small(ctx, (size_t)m * r + 16));
+        LF_HIP(ctx, hipMemcpyAsync(ctx->small, Wh, sizeof(double) * (size_t)m * r, hipMemcpyHostToDevice, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));                      // Wh is pageable host memory
+        return spmm(ctx, S, Jct, ms, m - ms, ctx->small, m, r, Z);
     };
-    // 1. G = A'A (A = diag(sqrt(w2)) Jct), eigen-decomposition: estimates of the singular values and right singular vectors
-    std::vector<double> G, sig, V;
-    const double t_start = now_ms();
-    LF_TRY(gram_impl(ctx, Jct, m, w2p, G));
-    for (double g : G)
-        if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix");
-    const double t_eig = now_ms();
-    gram_eig(ctx, m, G, sig, V);
-    if (kTraceFactorize) fprintf(stderr, "[factorize] gram %.3f ms, eig %.3f ms\n", t_eig - t_start, now_ms() - t_eig);
-    if (!(sig[0] > 0.0)) {                     // A == 0
-        LF_TRY(zero_from(0));
-        finish(sig, V, 0, nullptr);
-        return 0;
-    }
-    // 2. A well-conditioned full-rank factor needs nothing more: the loss of orthogonality of A V S^-1 and the relative error of the
-    //    small singular values are eps * cond(A)^2, i.e. rounding level for cond(A)^2 <= 10 (the dense random equality blocks of
-    //    the BASELINE configs have cond ~ 1.1).  Then A = (A V S^-1) S V' is already the factorisation.
-    if (sig[m - 1] >= eps_rank && sig[0] * sig[0] <= 10.0 * sig[m - 1] * sig[m - 1]) {
-        std::vector<double> W1((size_t)m * m);
-        for (int j = 0; j < m; ++j)
-            for (int i = 0; i < m; ++i) W1[(size_t)j * m + i] = V[(size_t)j * m + i] / sig[j];
-        LF_TRY(rmul_impl(ctx, Jct, m, W1.data(), m, Z));
-        LF_TRY(zero_from(m));
-        finish(sig, V, m, &W1);
-        return 0;
-    }
-    // 3. Otherwise the eigenvalues of G below ~eps * sig_1^2 are noise (a Gram matrix squares the condition number), while the
-    //    reference's dgesvd is backward stable and its rank test is ABSOLUTE (sig_j >= eps_rank = 1e-10, src/optimize.jl:297-302).
-    //    Refinement rounds resolve what dgesvd resolves: form the trial basis Z = A V diag(1/s) with the current estimates,
-    //    measure its Gram matrix on the device, and correct V and the singular values from it on the host (refine_round: a
-    //    one-sided Jacobi step on a well-scaled m x m factor -- every round gains ~8 digits of relative range; converged when
-    //    the trial basis is orthogonal to the rounding floor of the products).  Cost per round: one rmul + one Gram pass.
-    const double tol = 4e-13;
-    constexpr int kMaxRounds = 6;
-    std::vector<double> s(m), Wk((size_t)m * m), GZ;
-    bool z_is_final = false;
-    for (int round = 1; round <= kMaxRounds; ++round) {
-        for (int j = 0; j < m; ++j) s[j] = std::max(sig[j], 1e-12 * sig[0]);
-        for (int j = 0; j < m; ++j)
-            for (int i = 0; i < m; ++i) Wk[(size_t)j * m + i] = V[(size_t)j * m + i] / s[j];
-        LF_TRY(rmul_impl(ctx, Jct, m, Wk.data(), m, Z));
-        LF_TRY(gram_impl(ctx, Z, m, w2p, GZ));
-        for (double g : GZ)
-            if (!isfinite(g)) return set_err(ctx, LFPSQP_ERR_NUMERIC, "factorize: non-finite Gram matrix of the trial basis");
-        double offmax = 0.0, devmax = 0.0;
-        bool conv = false, rotated = false;
-        refine_round(ctx, m, V, sig, s, GZ, tol, &offmax, &conv, &devmax, &rotated);
-        if (conv && !rotated && devmax <= tol) {          // the basis on the device IS A V diag(1/sig) for every kept column
-            z_is_final = true;
-            break;
-        }
-        // quadratic convergence: a correction computed from an almost orthogonal trial basis (off-diagonals E) leaves E^2
-        if (conv || offmax <= 5e-7) break;
-    }
-    int r = 0;
-    while (r < m && sig[r] >= eps_rank && sig[r] > 0) ++r;                               // the reference's rule, src/optimize.jl:297-302
-    std::vector<double> Wr((size_t)m * std::max(r, 1));
-    for (int j = 0; j < r; ++j)
-        for (int i = 0; i < m; ++i) Wr[(size_t)j * m + i] = V[(size_t)j * m + i] / sig[j];
-    if (r > 0 && !z_is_final) LF_TRY(rmul_impl(ctx, Jct, m, Wr.data(), r, Z));
-    LF_TRY(zero_from(r));
-    finish(sig, V, r, &Wr);
-    return 0;
+    return factorize_core(ctx, m, gramA, rmulA, w2p, Z, Sigma, Vt, W, rank_out, eps_rank);
 }
 
 }  // extern "C"

@@ -42,4 +42,8 @@ inline EllRows ell_rows(const lfpsqp_spmat* S, const double* t) { return EllRows
 // t_out[0:m) = S' v (global: all-reduced).  v must hold at least S->n entries.
 int spmv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const double* v, double* t_out);
 
+// Out[:, :r] = [S | X[:, x0 : x0+nx)] * W   (W on the device, (S->m + nx) x r column-major with leading dimension ldw; X dense, may be
+// null with nx = 0; nx <= 4).  Row-parallel, fixed summation order (ELL order, then the dense columns): bit-reproducible.
+int spmm(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0, int nx, const double* W_dev, int ldw, int r, lfpsqp_mat* Out);
+
 }  // namespace lfpsqp

@@ -68,6 +68,106 @@ struct SpmvNF {   // y = alpha * (Jct t) + beta * y
         else if (v0) y[i] = o.x;
     }
 };
+// Out = [S | X] * W, the basis-forming product of the tangent setup when the constraint gradients are sparse: n*m outputs but only
+// K (+nx) multiply-adds each, so the kernel is bound by WRITING the dense result.  A lane owns two consecutive rows (16-byte stores,
+// lanes along the rows: every store instruction writes 1 KB of one output column), keeps their ELL entries in registers (KR of them;
+// KR = 0: re-read per output column) and walks the columns of a panel of W that the workgroup holds in LDS (odd row stride: the
+// gathers W[col_k, c] of a wave spread over the banks; neighbouring rows of a banded matrix hit the same word and broadcast).
+constexpr int kSpmmThreads = 1024, kSpmmLds = 16384 + 1024;      // doubles of LDS for the panel of W
+template <int KR>
+__global__ __launch_bounds__(kSpmmThreads) void spmm_kernel(const double* __restrict__ val, const int32_t* __restrict__ col, int64_t ld, int K,
+                                                             const double* __restrict__ X, int64_t ldx, int nx, int ms,
+                                                             const double* __restrict__ W, int ldw, int r, int pw, double* __restrict__ Out,
+                                                             int64_t ld_out, int64_t n) {
+    __shared__ double Wl[kSpmmLds];
+    const int kw = ms + nx, pws = pw | 1;
+    const int c0 = (int)blockIdx.y * pw;
+    const int pc = (r - c0 < pw) ? (r - c0) : pw;
+    for (int idx = threadIdx.x; idx < kw * pc; idx += kSpmmThreads) {
+        const int k = idx % kw, c = idx / kw;
+        Wl[k * pws + c] = W[(int64_t)(c0 + c) * ldw + k];
+    }
+    __syncthreads();
+    const int64_t ntiles = (n + 2 * kSpmmThreads - 1) / (2 * kSpmmThreads);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t i = tile * (2 * kSpmmThreads) + 2 * (int64_t)threadIdx.x;
+        if (i >= n) continue;                                   // (no barrier below)
+        double2 v[KR > 0 ? KR : 1];
+        int2 ci[KR > 0 ? KR : 1];
+        if (KR > 0) {
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                v[k] = make_double2(0.0, 0.0);
+                ci[k] = make_int2(0, 0);
+                if (k < K) {                                    // (the ELL arrays are padded to whole tiles: row i + 1 exists, with value 0)
+                    v[k] = ld2(val + (int64_t)k * ld + i);
+                    ci[k] = *reinterpret_cast<const int2*>(col + (int64_t)k * ld + i);
+                }
+            }
+        }
+        double2 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j] = make_double2(0.0, 0.0);
+            if (j < nx) {
+                const double* px = X + (int64_t)j * ldx + i;
+                x[j] = make_double2(px[0], (i + 1 < n) ? px[1] : 0.0);
+            }
+        }
+        for (int c = 0; c < pc; ++c) {
+            double2 a = make_double2(0.0, 0.0);
+            if (KR > 0) {
+#pragma unroll
+                for (int k = 0; k < KR; ++k) {
+                    a.x = fma(v[k].x, Wl[ci[k].x * pws + c], a.x);
+                    a.y = fma(v[k].y, Wl[ci[k].y * pws + c], a.y);
+                }
+            } else {
+                for (int k = 0; k < K; ++k) {
+                    const double2 vv = ld2(val + (int64_t)k * ld + i);
+                    const int2 cc = *reinterpret_cast<const int2*>(col + (int64_t)k * ld + i);
+                    a.x = fma(vv.x, Wl[cc.x * pws + c], a.x);
+                    a.y = fma(vv.y, Wl[cc.y * pws + c], a.y);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nx) {
+                    const double w = Wl[(ms + j) * pws + c];
+                    a.x = fma(x[j].x, w, a.x);
+                    a.y = fma(x[j].y, w, a.y);
+                }
+            double* o = Out + (int64_t)(c0 + c) * ld_out + i;
+            if (i + 1 < n) st2(o, a);
+            else o[0] = a.x;
+        }
+    }
+}
+
+int spmm(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0, int nx, const double* W_dev, int ldw, int r, lfpsqp_mat* Out) {
+    if (r <= 0 || S->n == 0) return 0;
+    const int kw = (int)S->m + nx;
+    if (nx < 0 || nx > 4 || (nx > 0 && !X) || kw < 1 || kw > 16384 || Out->n != S->n || Out->m < r)
+        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "spmm: shape not covered (%d + %d rows of W, %d columns)", (int)S->m, nx, r);
+    int pw = 16384 / kw;
+    if (pw > r) pw = r;
+    const int npan = (r + pw - 1) / pw;
+    const int64_t ntiles = (S->n + 2 * kSpmmThreads - 1) / (2 * kSpmmThreads);
+    const int64_t cus = ctx->num_cu > 0 ? ctx->num_cu : 64;
+    const dim3 grid((unsigned)(ntiles < cus ? ntiles : cus), (unsigned)npan);
+    const double* xp = nx > 0 ? X->p + (int64_t)x0 * X->ld : nullptr;
+    const int64_t ldx = nx > 0 ? X->ld : 0;
+#define LF_SPMM(KR_)                                                                                                                          \
+    hipLaunchKernelGGL((spmm_kernel<KR_>), grid, dim3(kSpmmThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, xp, ldx, nx, (int)S->m, \
+                       W_dev, ldw, r, pw, Out->p, Out->ld, S->n)
+    if (S->K <= 4) LF_SPMM(4);
+    else if (S->K <= 8) LF_SPMM(8);
+    else LF_SPMM(0);
+#undef LF_SPMM
+    LF_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
 // dense[:, j] from the CSC arrays of column j (one entry per position: every element written once)
 __global__ void sp_scatter_kernel(const int64_t* __restrict__ colptr, const int32_t* __restrict__ row, const double* __restrict__ val,
                                   double* __restrict__ dense, int64_t ld_dense) {

@@ -25,20 +25,28 @@ def rmul(In: DeviceMatrix, W: np.ndarray, Out: DeviceMatrix) -> DeviceMatrix:
     return Out
 
 
-def ksvd_(Jct: DeviceMatrix, Z: DeviceMatrix, w2: DeviceVector | None = None, eps_rank: float = 1e-10,
-          W: np.ndarray | None = None):
+def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix, w2: DeviceVector | None = None, eps_rank: float = 1e-10,
+          W: np.ndarray | None = None, Jsp=None):
     """Thin factorisation diag(sqrt(w2)) Jct = U S Vt with U = diag(sqrt(w2)) Z.
     Returns (Sigma, Vt, rank); Z is overwritten (Jct is NOT destroyed, unlike dgesvd).
-    ``W`` (optional, m x m Fortran-ordered float64) receives the small factor with Z = Jct @ W."""
-    m = Jct.m
+    ``W`` (optional, m x m Fortran-ordered float64) receives the small factor with Z = Jct @ W.
+    ``Jsp`` (optional SparseMatrix with the entries of the leading ``Jsp.m`` columns of Jct; Jct may then be None when there are no
+    further columns): the basis-forming products stream the nonzeros (lfpsqp_factorize_sp)."""
+    m = Jct.m if Jct is not None else Jsp.m
+    ctx = Jct.ctx if Jct is not None else Jsp.ctx
     if W is not None:
         assert W.shape == (m, m) and W.flags.f_contiguous and W.dtype == np.float64
     S = np.zeros(m)
     Vt = np.zeros((m, m), order='F')
     rank = c_i64()
-    Jct.ctx.check(Jct.ctx.L.lfpsqp_factorize(Jct.ctx.h, Jct.h, w2.h if w2 is not None else None, Z.h, S.ctypes.data,
-                                             Vt.ctypes.data, W.ctypes.data if W is not None else None, C.byref(rank),
-                                             float(eps_rank)))
+    if Jsp is not None:
+        ctx.check(ctx.L.lfpsqp_factorize_sp(ctx.h, Jsp.h, Jct.h if Jct is not None else None, w2.h if w2 is not None else None, Z.h,
+                                            S.ctypes.data, Vt.ctypes.data, W.ctypes.data if W is not None else None, C.byref(rank),
+                                            float(eps_rank)))
+    else:
+        ctx.check(ctx.L.lfpsqp_factorize(ctx.h, Jct.h, w2.h if w2 is not None else None, Z.h, S.ctypes.data,
+                                         Vt.ctypes.data, W.ctypes.data if W is not None else None, C.byref(rank),
+                                         float(eps_rank)))
     return S, Vt, rank.value
 
 

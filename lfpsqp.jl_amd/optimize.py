@@ -217,7 +217,8 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
         rank = m
         if m > 0:
             jac_(Jct, cval, x)                                             # :283-284 (the device keeps only Jct)
-            S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank, W=Wgen)   # :286-302
+            S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank, W=Wgen,
+                                  Jsp=getattr(c_, "Jsp", None))                                                # :286-302
             idecomp.W = Wgen
             Sig[:] = S_
             Vt[:, :] = Vt_

@@ -48,6 +48,7 @@ struct dim3 {
 };
 struct double2 { double x, y; };
 struct int2 { int x, y; };
+static inline int2 make_int2(int x, int y) { int2 v; v.x = x; v.y = y; return v; }
 static inline double2 make_double2(double a, double b) { return double2{a, b}; }
 
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };

@@ -160,6 +160,47 @@ def test_optimize_with_sparse_equalities_matches_the_dense_run_and_the_oracle(de
     np.testing.assert_allclose(objs, objr, rtol=1e-10)
 
 
+@pytest.mark.parametrize("case", ["plain", "weighted", "ball_column", "no_dense_twin", "ill_conditioned", "wide_k", "m300"])
+def test_factorize_from_the_nonzeros_is_the_dense_factorisation(dev_ctx, case):
+    """lfpsqp_factorize_sp (Gram on the dense twin or on S expanded into Z, basis-forming products Z = [S | extra columns] * W from the
+    nonzeros) against lfpsqp_factorize on the dense matrix: the same Gram matrix, hence identical Sigma / Vt / rank / W, and the same
+    basis up to the rounding of the product; Z = A * W and Z' diag(w2) Z = I checked directly."""
+    ctx = dev_ctx
+    n, m, k = (2600, 300, 4) if case == "m300" else (3100, 12, 9 if case == "wide_k" else 3)
+    rows, cols, vals = banded(n, m, k, seed=8)
+    if case == "ill_conditioned":                    # refinement rounds: several basis-forming products from the nonzeros
+        vals = vals * np.logspace(0, -7, m)[cols]
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, m)).toarray()
+    extra = 1 if case == "ball_column" else 0
+    rng = np.random.default_rng(2)
+    Ad = np.asfortranarray(np.hstack([A, rng.standard_normal((n, extra))])) if extra else np.asfortranarray(A)
+    M = m + extra
+    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+    Jd = ctx.matrix(n, M, Ad)
+    w = ctx.vector(n, rng.random(n) + 0.2) if case == "weighted" else None
+    Z0, Z1 = ctx.matrix(n, M), ctx.matrix(n, M)
+    W0, W1 = np.zeros((M, M), order='F'), np.zeros((M, M), order='F')
+    S0, Vt0, r0 = L.ksvd_(Jd, Z0, w2=w, W=W0)
+    S1, Vt1, r1 = L.ksvd_(None if case == "no_dense_twin" else Jd, Z1, w2=w, W=W1, Jsp=S)
+    assert r1 == r0 == M
+    if case != "ill_conditioned":                    # same Gram matrix, same replicated small step: bit for bit
+        np.testing.assert_array_equal(S1, S0)
+        np.testing.assert_array_equal(Vt1, Vt0)
+        np.testing.assert_array_equal(W1, W0)
+    else:                                            # the refinement rounds measure the Gram matrix of a basis formed by a different product
+        np.testing.assert_allclose(S1, S0, rtol=1e-11)
+    Zh0, Zh1 = Z0.download(), Z1.download()
+    scale = np.abs(Zh0).max()
+    tol = 1e-9 if case == "ill_conditioned" else 2e-14
+    assert np.abs(Zh1 - Zh0).max() <= tol * scale * (M ** 0.5)
+    assert np.abs(Zh1 - Ad @ W1).max() <= tol * scale * (M ** 0.5)
+    wh = w.download() if w is not None else np.ones(n)
+    if case != "ill_conditioned":
+        assert np.abs(Zh1.T @ (wh[:, None] * Zh1) - np.eye(M)).max() <= 1e-12
+    np.testing.assert_allclose(S1, np.linalg.svd(np.sqrt(wh)[:, None] * Ad, compute_uv=False), rtol=1e-9 if case != "ill_conditioned" else 1e-6,
+                               atol=1e-13 * S1[0])
+
+
 @pytest.mark.gpu
 def test_sparse_products_at_1e6_rows_against_the_dense_kernels():
     """The §8 f4 bar: a banded Jct at n = 1e6, m = 128 (4 nonzeros per row): both sparse products agree with the dense GEMV
@@ -186,4 +227,44 @@ def test_sparse_products_at_1e6_rows_against_the_dense_kernels():
         ms[name] = ctx.timer_end() / 20
     print("[sparse] ms per product:", {k_: round(v_, 4) for k_, v_ in ms.items()}, "nnz bytes", S.nnz * 12)
     assert ms["spmv_t"] < ms["gemv_t"] and ms["spmv_n"] < ms["gemv_n"]
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ball", [False, True])
+def test_factorize_from_the_nonzeros_at_1e6_rows(ball):
+    """Tangent setup of a banded Jct at n = 1e6, m = 128 (4 nonzeros per row; with a dense ball column: M = 129): lfpsqp_factorize_sp
+    against lfpsqp_factorize on the dense twin -- identical Sigma / Vt (same Gram matrix, or rounding level when refinement rounds run),
+    the same basis to rounding, Z = A W and Z'Z = I by device products, and faster."""
+    import time
+    ctx = L.Context(0)
+    n, m, k = 1_000_000, 128, 4
+    rows, cols, vals = banded(n, m, k)
+    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+    M = m + (1 if ball else 0)
+    Jd = ctx.matrix(n, M)
+    S.to_dense(Jd)
+    if ball:
+        Jd.upload(synth.hash_vector(9, n)[:, None], col0=m)          # the dense extra column (2x of a ball constraint, say)
+    Z0, Z1 = ctx.matrix(n, M), ctx.matrix(n, M)
+    W1 = np.zeros((M, M), order='F')
+    S0, Vt0, r0 = L.ksvd_(Jd, Z0)
+    S1, Vt1, r1 = L.ksvd_(Jd, Z1, W=W1, Jsp=S)
+    assert r0 == r1 == M
+    np.testing.assert_allclose(S1, S0, rtol=1e-12)
+    G = L.gram(Z1)
+    assert np.abs(G - np.eye(M)).max() <= 1e-11
+    Zc = ctx.matrix(n, M)
+    L.rmul(Jd, W1, Zc)                                  # Z = A W with the dense MFMA product
+    for j in range(0, M, 37):
+        a, b = Z1.download(j, 1), Zc.download(j, 1)
+        assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max() * 10
+    t = {}
+    for tag, kw in (("dense", {}), ("from_nonzeros", {"Jsp": S})):
+        ctx.sync(); t0 = time.perf_counter()
+        for _ in range(5):
+            L.ksvd_(Jd, Z1, **kw)
+        ctx.sync(); t[tag] = (time.perf_counter() - t0) / 5 * 1e3
+    print("[sparse] factorize ms:", {k_: round(v_, 3) for k_, v_ in t.items()}, "cond", S1[0] / S1[-1])
+    assert t["from_nonzeros"] < t["dense"]
     ctx.close()
