@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the evidence bundle of tools/gpu_final.sh (gpurun_out/final) into profiles/<tag>_*:  bash tools/collect_profiles.sh r02b
-T=$1; O=gpurun_out/final; P=profiles
+T=$1; O=gpurun_out/final; P=profiles      # (delete gpurun_out/final before the gpurun call: merged results of earlier calls stay there otherwise)
 cp $O/bench.json $P/${T}_bench.json; cp $O/bench_profiled.json $P/${T}_bench_profiled.json; cp $O/boxinfo.txt $P/${T}_boxinfo.txt
 cp $O/pytest_gpu.txt $P/${T}_pytest_gpu.txt; cp $O/sq_counters.txt $P/${T}_sq_counters.txt; cp $O/pmc_summary.json $P/${T}_pmc_summary.json
 cp "$(find $O/stats -name '*kernel_stats.csv' | head -1)" $P/${T}_bench_kernel_stats.csv
