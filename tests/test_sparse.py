@@ -160,13 +160,13 @@ def test_optimize_with_sparse_equalities_matches_the_dense_run_and_the_oracle(de
     np.testing.assert_allclose(objs, objr, rtol=1e-10)
 
 
-@pytest.mark.parametrize("case", ["plain", "weighted", "ball_column", "no_dense_twin", "ill_conditioned", "wide_k", "m300"])
+@pytest.mark.parametrize("case", ["plain", "weighted", "ball_column", "no_dense_twin", "ill_conditioned", "wide_k", "two_panels"])
 def test_factorize_from_the_nonzeros_is_the_dense_factorisation(dev_ctx, case):
     """lfpsqp_factorize_sp (Gram on the dense twin or on S expanded into Z, basis-forming products Z = [S | extra columns] * W from the
     nonzeros) against lfpsqp_factorize on the dense matrix: the same Gram matrix, hence identical Sigma / Vt / rank / W, and the same
     basis up to the rounding of the product; Z = A * W and Z' diag(w2) Z = I checked directly."""
     ctx = dev_ctx
-    n, m, k = (1100 if _is_emu(ctx) else 26000, 300, 4) if case == "m300" else (3100, 12, 9 if case == "wide_k" else 3)
+    n, m, k = (1500 if _is_emu(ctx) else 26000, 200, 4) if case == "two_panels" else (3100, 12, 9 if case == "wide_k" else 3)
     rows, cols, vals = banded(n, m, k, seed=8)
     if case == "ill_conditioned":                    # refinement rounds: several basis-forming products from the nonzeros
         vals = vals * np.logspace(0, -7, m)[cols]
@@ -183,7 +183,8 @@ def test_factorize_from_the_nonzeros_is_the_dense_factorisation(dev_ctx, case):
     S0, Vt0, r0 = L.ksvd_(Jd, Z0, w2=w, W=W0)
     S1, Vt1, r1 = L.ksvd_(None if case == "no_dense_twin" else Jd, Z1, w2=w, W=W1, Jsp=S)
     assert r1 == r0 == M
-    if case != "ill_conditioned":                    # same Gram matrix, same replicated small step: bit for bit
+    fast = S0[0] ** 2 <= 10.0 * S0[-1] ** 2           # lfpsqp_factorize's one-Gram-one-product path
+    if fast:                                         # same Gram matrix, same replicated small step: bit for bit
         np.testing.assert_array_equal(S1, S0)
         np.testing.assert_array_equal(Vt1, Vt0)
         np.testing.assert_array_equal(W1, W0)
@@ -191,12 +192,12 @@ def test_factorize_from_the_nonzeros_is_the_dense_factorisation(dev_ctx, case):
         np.testing.assert_allclose(S1, S0, rtol=1e-11)
     Zh0, Zh1 = Z0.download(), Z1.download()
     scale = np.abs(Zh0).max()
-    tol = 1e-9 if case == "ill_conditioned" else 2e-14
+    tol = 1e-9 if case == "ill_conditioned" else (2e-14 if fast else 1e-12)
     assert np.abs(Zh1 - Zh0).max() <= tol * scale * (M ** 0.5)
     assert np.abs(Zh1 - Ad @ W1).max() <= tol * scale * (M ** 0.5)
     wh = w.download() if w is not None else np.ones(n)
     if case != "ill_conditioned":
-        assert np.abs(Zh1.T @ (wh[:, None] * Zh1) - np.eye(M)).max() <= 1e-12
+        assert np.abs(Zh1.T @ (wh[:, None] * Zh1) - np.eye(M)).max() <= (1e-12 if fast else 1e-10)
     np.testing.assert_allclose(S1, np.linalg.svd(np.sqrt(wh)[:, None] * Ad, compute_uv=False), rtol=1e-9 if case != "ill_conditioned" else 1e-6,
                                atol=1e-13 * S1[0])
 
