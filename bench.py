@@ -423,6 +423,18 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             ctx.sync(); tf[tag] = (time.perf_counter() - t0) * 1e3 / 3
         sparse.update({"factorize_dense_ms": tf["dense"], "factorize_from_nonzeros_ms": tf["from_nonzeros"], "factorize_rank": int(rk),
                        "factorize_cond": float(Sg[0] / Sg[-1])})
+        # Newton retraction on the same block (24 iterations forced by tol = 0): one dense pass per step vs the nonzeros alone
+        Wg2 = np.zeros((m, m), order='F')
+        Sg, Vtg, _ = L.ksvd_(Jd, Zs, W=Wg2, Jsp=Sr)
+        bsp = ctx.vector(m); L.spmv_t(Sr, xs, bsp)
+        tn = {}
+        for tag, jsp in (("dense", None), ("on_nonzeros", Sr)):
+            cons_s = L.DeviceConstraints(Jd, m, bsp.download(), Jsp=jsp)
+            nrs = L.NR(L.DeviceBasis(Zs, generator=(Jd, Wg2)), Sg, Vtg, 0.0, 24, L.NRWork(m), False, None)
+            L.retract_(cval, xnew, cons_s, xt, xs, nrs)
+            ctx.sync(); t0 = time.perf_counter(); _, itn, _ = L.retract_(cval, xnew, cons_s, xt, xs, nrs); ctx.sync()
+            tn[tag] = (time.perf_counter() - t0) * 1e3 / max(itn, 1)
+        sparse.update({"nr_step_dense_ms": tn["dense"], "nr_step_on_nonzeros_ms": tn["on_nonzeros"]})
         Sr.free()
     except Exception as e:      # diagnostics only
         sparse = {"error": repr(e)}

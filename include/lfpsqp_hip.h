@@ -361,7 +361,8 @@ typedef int (*lfpsqp_cfun)(void* user, const lfpsqp_vec* x, double* cval);
  * Per Newton step the device-resident path streams U (x += U*delta) and Jct (c!) in one launch; when U carries
  * its generator (U->A == cons->Jct, U->W from lfpsqp_factorize) the step is x += [sx;sy] .* (Jct*(W*delta)) and
  * Jct is streamed ONCE per step, each row tile held in registers between the two products (same iterates up
- * to rounding: Z*delta vs Jct*(W*delta)).
+ * to rounding: Z*delta vs Jct*(W*delta)).  With a sparse twin of the linear block besides (cons->Jsp, all but <= 4 of
+ * the generator's columns) no dense matrix is read at all: the step runs on the nonzeros (+ those few dense columns).
  * Outputs: xnew, cval[m] (== c!(xnew) on exit), *flag (0 ok, 1 = maxiter reached), *iters. */
 int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m,
                       const lfpsqp_constraints* cons, lfpsqp_cfun cfun, void* cuser, const lfpsqp_ineq_data* idata,
@@ -372,7 +373,7 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
  * src/linesearch.jl:49-60) are independent, so they share every pass over Jct -- one launch advances all unfinished
  * trials by one Newton step.  Per trial the arithmetic, the convergence test and the outputs are those of
  * lfpsqp_retract_nr: xnew[b], cval[b*m .. b*m+m), flags[b], iters[b].  Needs the one-stream step (U->A / U->W known,
- * device-resident constraints, 4..256 columns); returns LFPSQP_ERR_UNSUPPORTED otherwise (retract one by one then). */
+ * device-resident constraints without a sparse twin, 4..256 columns); returns LFPSQP_ERR_UNSUPPORTED otherwise (retract one by one then). */
 int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m,
                             const lfpsqp_constraints* cons, const lfpsqp_ineq_data* idata, int nb, const lfpsqp_vec* const* xtilde,
                             const lfpsqp_vec* x, lfpsqp_vec* const* xnew, double tol, int64_t maxiter, double* cval, int* flags,

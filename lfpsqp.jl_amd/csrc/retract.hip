@@ -33,6 +33,11 @@ struct BallF {  // partial of sum_{i<n_x} x_i^2 - x[slack_row]
     }
 };
 
+// Newton step when the constraint gradients have a sparse twin and the basis its generator (Z = Jct * W): U*ddelta = Jct*(W*ddelta), so the
+// step needs no pass over a dense matrix at all -- a row's entry of Jct*(W ddelta) from its ELL entries (+ the dense extra columns, e.g.
+// the ball column), the same row update as the dense kernels (NRStepE::apply), then c! = S'xnew by the sparse product.
+struct NRSparseStepF;   // (defined after NRStepE)
+
 struct BallColF {  // Jct[:, m_lin] = [2x (i < n_x); -1 at slack_row; 0 elsewhere]
     const double* x;
     double* col;
@@ -314,6 +319,26 @@ __global__ __launch_bounds__(kNRThreads) void nr_small_kernel(NRSmall s, int ini
 
 // ---- batched Newton retractions: NB independent trial points share every pass over Jct ---------------------------------
 // (the trial steps alpha, alpha*s, alpha*s^2, ... of an Armijo search whose retractions fail, src/linesearch.jl:57-60)
+struct NRSparseStepF {
+    NRStepE e;
+    EllRows E;                       // E.t = W * ddelta (first S.m entries)
+    const double* xcol;              // dense extra columns of Jct (column-major, leading dimension ldx), nx <= 4 of them
+    int64_t ldx;
+    const double* wx;                // their coefficients: (W * ddelta)[S.m ..]
+    int nx;
+    __device__ __forceinline__ bool skip() const { return e.skip(); }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        double2 acc = E.acc(i);
+        for (int j = 0; j < nx; ++j) {
+            const double w = ld_scal(wx + j);
+            const double2 c = ld2(xcol + (int64_t)j * ldx + i);
+            acc.x = fma(c.x, w, acc.x);
+            acc.y = fma(c.y, w, acc.y);
+        }
+        e.apply(i, acc, v0, v1, red);
+    }
+};
+
 constexpr int kNRBatchMax = 4;
 enum { I_NRB = 32, I_NRB_ALL = 48 };                      // istat: [status, iterations, flag, -] per trial, then the all-done word
 struct NRSmallB {
@@ -461,7 +486,10 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         const size_t mm = (size_t)m * m;
         // one-stream step: the caller vouches that U->Z == U->A * U->W and A is the matrix c! streams anyway
         const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kNRMaxM) ? (int)U->A->m : 0;
-        const int cw = wm ? onepass_cw(ctx, wm, cons->Jct->ld, N) : 0;
+        const int cwd = wm ? onepass_cw(ctx, wm, cons->Jct->ld, N) : 0;
+        // ... and with a sparse twin of the linear block (all but <= 4 of A's columns) the step runs on the nonzeros alone
+        const lfpsqp_spmat* Ssp = (wm && ml > 0 && cons->Jsp && cons->Jsp->n == N && cons->Jsp->m == ml && wm >= ml && wm - ml <= 4) ? cons->Jsp : nullptr;
+        const int cw = Ssp ? 1 : cwd;                 // (non-zero: the generator W and W*ddelta are kept on the device)
         const size_t wsz = cw ? (((size_t)wm * m + (size_t)wm + 1) & ~(size_t)1) : 0;
         LF_TRY(ensure_small(ctx, 2 * mm + wsz + 8 * (size_t)m + 256));
         double* dD = ctx->small;
@@ -485,7 +513,8 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
                          ctx->h_istat, m, ml, cons->has_ball ? 1 : 0, cw ? wm : 0, cons->R2, tol, maxiter};
         LF_TRY(lfpsqp_vec_copy(ctx, xnew, xtilde));                                             // :116
         if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew, x, idata));                                // :118-120
-        if (ml > 0) LF_TRY(run_gemv_t(ctx, cons->Jct, ml, N, PlainVec{xnew->p}, draw));         // c!(cval, xnew), raw products
+        if (Ssp) LF_TRY(spmv_t(ctx, Ssp, xnew->p, draw));                                        // c!(cval, xnew), raw products
+        else if (ml > 0) LF_TRY(run_gemv_t(ctx, cons->Jct, ml, N, PlainVec{xnew->p}, draw));
         if (cons->has_ball)
             LF_TRY((run_vec<BallF, 1, NoPost>(ctx, N, BallF{xnew->p, cons->n_x, cons->slack_row}, 0u, draw + ml, NoPost())));
         hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sm, 1);
@@ -498,7 +527,11 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         bool done = false;
         while (!done && it < maxiter) {
             // step `it`: xnew += U delta, y_retract!, raw c! products (one launch) ; Broyden + test + next delta (one workgroup)
-            if (cw && ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<true>{ep}, draw)));
+            if (Ssp) {
+                const NRSparseStepF sf{ep, ell_rows(Ssp, dwdelta), cons->Jct->p + (int64_t)ml * cons->Jct->ld, cons->Jct->ld, dwdelta + ml, wm - ml};
+                LF_TRY((run_vec<NRSparseStepF, 1, NoPost>(ctx, N, sf, 0u, draw + ml, NoPost())));
+                LF_TRY(spmv_t(ctx, Ssp, xnew->p, draw));
+            } else if (cw && ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<true>{ep}, draw)));
             else if (cw) LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<false>{ep}, draw)));
             else if (cons->has_ball) LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
             else LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
@@ -609,6 +642,7 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
                             int64_t* iters) {
     LF_ARG(ctx, ctx && U && Sigma && Vt && xtilde && x && xnew && cval && flags && iters && m64 >= 1 && U->ncols == m64);
     LF_ARG(ctx, cons_ok(cons) && nb >= 2 && nb <= kNRBatchMax);
+    if (cons->Jsp) return LFPSQP_ERR_UNSUPPORTED;     // sparse constraint gradients: single steps on the nonzeros beat a shared dense pass
     const int m = (int)m64;
     const bool ineq = idata != nullptr;
     LF_ARG(ctx, ineq == (U->Dx != nullptr));

@@ -121,10 +121,12 @@ def test_pcg_with_a_sparse_operator_is_the_dense_solve(dev_ctx, bounds):
         assert np.linalg.norm(A @ (A.T @ xs) + mu * xs - b) <= 2 * tol
 
 
+@pytest.mark.parametrize("newton", [False, True])
 @pytest.mark.parametrize("bounds", [False, True])
-def test_optimize_with_sparse_equalities_matches_the_dense_run_and_the_oracle(dev_ctx, bounds):
-    """End to end: f = ||x||^2 subject to banded sparse equalities (and bounds), the reference's DEFAULT retraction
-    (ProjPenalty: c!, jac!, pcg! all on the sparse block): the trajectory of the dense run and of the oracle."""
+def test_optimize_with_sparse_equalities_matches_the_dense_run_and_the_oracle(dev_ctx, bounds, newton):
+    """End to end: f = ||x||^2 subject to banded sparse equalities (and bounds): the reference's DEFAULT retraction (ProjPenalty: c!,
+    jac!, pcg! all on the sparse block) and the Newton retraction (do_project_retract = false: every step on the nonzeros, also on the
+    bound manifold) -- the trajectory of the dense run and of the oracle."""
     ctx = dev_ctx
     n, m = (600, 8) if _is_emu(ctx) else (6000, 24)
     rows, cols, vals = banded(n, m, 3, seed=9)
@@ -140,13 +142,13 @@ def test_optimize_with_sparse_equalities_matches_the_dense_run_and_the_oracle(de
     maxiter = 3
     tr0 = []
     xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, xl, xu, m,
-                                     R.LFPSQPParams(disp=R.DisplayOption.off, maxiter=maxiter), trace=tr0)
+                                     R.LFPSQPParams(disp=R.DisplayOption.off, maxiter=maxiter, do_project_retract=not newton), trace=tr0)
     out = {}
     for label in ("dense", "sparse"):
         S = L.SparseMatrix(ctx, n, m, rows, cols, vals) if label == "sparse" else None
         P = L.QuadLinearBallBox(ctx, n, m, ctx.matrix(n, m, np.asfortranarray(A)), prob0.b, xl=xl, xu=xu, Jsp=S)
         tr = []
-        x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(disp=L.DisplayOption.off, maxiter=maxiter), trace=tr)
+        x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(disp=L.DisplayOption.off, maxiter=maxiter, do_project_retract=not newton), trace=tr)
         out[label] = (tr, x, obj, ti)
     trd, xd, objd, tid = out["dense"]
     trs, xsp, objs, tis = out["sparse"]
@@ -269,3 +271,44 @@ def test_factorize_from_the_nonzeros_at_1e6_rows(ball):
     print("[sparse] factorize ms:", {k_: round(v_, 3) for k_, v_ in t.items()}, "cond", S1[0] / S1[-1])
     assert t["from_nonzeros"] < t["dense"]
     ctx.close()
+
+
+@pytest.mark.parametrize("has_ball", [False, True])
+def test_newton_retraction_on_the_nonzeros_is_the_dense_retraction(dev_ctx, has_ball):
+    """retract!(::NR) with a sparse twin of the linear block and the basis generator known: U*ddelta = Jct*(W*ddelta), so a Newton step is
+    one row pass over the ELL entries (+ the dense ball column), the same row update, and c! = S'x by the sparse product -- no dense
+    matrix is read.  Same (flag, iterations), iterate and cval as the dense one-stream step on the same data, plain and with a ball
+    constraint (one dense extra column); the bound manifold is covered through optimize above."""
+    ctx = dev_ctx
+    emu = _is_emu(ctx)
+    n, m_lin, k = (2400 if emu else 400_000), 10, 3
+    m = m_lin + (1 if has_ball else 0)
+    N = n + (1 if has_ball else 0)
+    rows, cols, vals = banded(n, m_lin, k, seed=21)
+    Jh = np.zeros((N, m), order='F')
+    np.add.at(Jh, (rows, cols), vals)
+    xs_h = np.concatenate([0.6 * synth.hash_vector(2, n), [0.0]])[:N]
+    if has_ball:
+        xs_h[n] = xs_h[:n] @ xs_h[:n] - 0.4 * n
+    b = Jh[:, :m_lin].T @ xs_h
+    pert = 5e-3 * np.random.default_rng(4).standard_normal(N)
+    out = {}
+    for mode in ("dense", "sparse"):
+        Jct = ctx.matrix(N, m, Jh)
+        Ssp = L.SparseMatrix(ctx, N, m_lin, rows, cols, vals) if mode == "sparse" else None
+        cons = L.DeviceConstraints(Jct, m_lin, b, has_ball, 0.4 * n, n, n if has_ball else -1, Jsp=Ssp)
+        xs_dev = ctx.vector(N, xs_h)
+        cv = np.zeros(m)
+        cons.jac_(Jct, cv, xs_dev)                            # (ball column of Jct at xs)
+        Z, W = ctx.matrix(N, m), np.zeros((m, m), order='F')
+        S, Vt, rank = L.ksvd_(Jct, Z, W=W, Jsp=Ssp)
+        assert rank == m
+        nr = L.NR(L.DeviceBasis(Z, generator=(Jct, W)), S, Vt, 1e-10, 60, L.NRWork(m), False, None)
+        xt, xnew = ctx.vector(N, xs_h + pert), ctx.vector(N)
+        cval = np.zeros(m)
+        flag, it, _ = L.retract_(cval, xnew, cons, xt, xs_dev, nr)
+        out[mode] = (flag, it, xnew.download(), cval.copy())
+    (f0, i0, x0, c0), (f1, i1, x1, c1) = out["dense"], out["sparse"]
+    assert (f1, i1) == (f0, i0) and f0 == 0 and i0 >= (2 if has_ball else 1)
+    assert np.abs(x1 - x0).max() <= 1e-12 * np.abs(x0).max()
+    assert np.abs(c1 - c0).max() <= 1e-11 and np.abs(c1).max() < 1e-9
