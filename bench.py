@@ -435,6 +435,18 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             ctx.sync(); t0 = time.perf_counter(); _, itn, _ = L.retract_(cval, xnew, cons_s, xt, xs, nrs); ctx.sync()
             tn[tag] = (time.perf_counter() - t0) * 1e3 / max(itn, 1)
         sparse.update({"nr_step_dense_ms": tn["dense"], "nr_step_on_nonzeros_ms": tn["on_nonzeros"]})
+        # the projected CG itself on that block: fused dense iteration (one pass over Z) vs the basis in factored form on the nonzeros
+        Asp = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.0, 5.0))
+        bsv, xsv, wsp = ctx.vector(n_loc).hash_fill(4, r0), ctx.vector(n_loc), L.ProjCGWork(ctx, n_loc, m)
+        tp = {}
+        for tag, basis in (("dense", L.DeviceBasis(Zs)), ("on_nonzeros", L.DeviceBasis(Zs, generator=(Jd, Wg2), sparse=Sr))):
+            L.projcg_(xsv, None, Asp, basis, bsv, None, tol=1e-300, maxit=5, work=wsp, n_global=n, want_lambda=False)
+            ctx.sync(); t0 = time.perf_counter()
+            itp, _ = L.projcg_(xsv, None, Asp, basis, bsv, None, tol=1e-300, maxit=30, work=wsp, n_global=n, want_lambda=False)
+            ctx.sync(); tp[tag] = (time.perf_counter() - t0) * 1e3 / max(itp, 1)
+            tp[tag + "_xnorm"] = L.nrm2(xsv)
+        sparse.update({"projcg_iter_dense_ms": tp["dense"], "projcg_iter_on_nonzeros_ms": tp["on_nonzeros"],
+                       "projcg_xnorm_rel_diff": abs(tp["dense_xnorm"] - tp["on_nonzeros_xnorm"]) / tp["dense_xnorm"]})
         Sr.free()
     except Exception as e:      # diagnostics only
         sparse = {"error": repr(e)}

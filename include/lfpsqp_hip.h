@@ -269,6 +269,10 @@ typedef struct lfpsqp_basis {
     /* optional sparse form of Z[:, 0:ncols] (same entries): lfpsqp_pcg then makes two sparse products per iteration
      * instead of a dense pass.  NULL when Z is dense only. */
     const lfpsqp_spmat* S;
+    /* optional sparse twin of the GENERATOR: the leading SA.m columns of A (at most 4 more dense columns behind them).  With A, W and
+     * SA set, lfpsqp_projcg applies the basis in factored form, U t = A (W t) and U'v = W'(A'v), on the nonzeros: no dense n x m matrix is
+     * read in the loop (plain basis only; same projector, iterates equal to the dense form up to rounding). */
+    const lfpsqp_spmat* SA;
 } lfpsqp_basis;
 
 /* mul!(dest, Q', v) (src/inequality_helper.jl:197-212): w[0:N) = Dx.*vx + Dy.*vy,

@@ -47,6 +47,7 @@ struct CBasis                  # lfpsqp_basis
     A::Ptr{Cvoid}
     W::Ptr{Float64}
     S::Ptr{Cvoid}               # optional sparse form of Z (lfpsqp_spmat), C_NULL otherwise
+    SA::Ptr{Cvoid}              # optional sparse twin of the generator A (projcg in factored form on the nonzeros), C_NULL otherwise
 end
 struct CWork                   # lfpsqp_projcg_work
     g::Ptr{Cvoid}
@@ -342,9 +343,11 @@ struct DeviceBasis
     Z::DeviceMatrix
     ncols::Int
     generator::Union{Nothing,Tuple{DeviceMatrix,Matrix{Float64}}}
+    sparse::Ptr{Cvoid}         # lfpsqp_spmat handle of the generator's sparse twin (projcg on the nonzeros), C_NULL otherwise
 end
-DeviceBasis(Z::DeviceMatrix) = DeviceBasis(Z, Z.m, nothing)
-DeviceBasis(Z::DeviceMatrix, ncols::Integer) = DeviceBasis(Z, ncols, nothing)
+DeviceBasis(Z::DeviceMatrix) = DeviceBasis(Z, Z.m, nothing, C_NULL)
+DeviceBasis(Z::DeviceMatrix, ncols::Integer) = DeviceBasis(Z, ncols, nothing, C_NULL)
+DeviceBasis(Z::DeviceMatrix, ncols::Integer, generator) = DeviceBasis(Z, ncols, generator, C_NULL)
 struct DeviceBasisAdjoint
     U::DeviceBasis
 end
@@ -355,8 +358,8 @@ mul!(y::DeviceVector, U::DeviceBasis, t::DeviceVector, a::Number=1.0, b::Number=
     (check(y.ctx, c_gemv_n(y.ctx.h, U.Z.h, Int64(U.ncols), Float64(a), t.h, Float64(b), y.h)); y)
 mul!(t::DeviceVector, Ut::DeviceBasisAdjoint, v::DeviceVector) =
     (check(t.ctx, c_gemv_t(t.ctx.h, Ut.U.Z.h, Int64(Ut.U.ncols), v.h, t.h)); t)
-cbasis(U::DeviceBasis) = U.generator === nothing ? CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL) :
-    CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, U.generator[1].h, pointer(U.generator[2]), C_NULL)
+cbasis(U::DeviceBasis) = U.generator === nothing ? CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL) :
+    CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, U.generator[1].h, pointer(U.generator[2]), C_NULL, U.sparse)
 
 # A = a0*I + diag(dg): the LinearMap of src/optimize.jl:228-230 for diagonal Lagrangian Hessians
 struct DiagOperator
@@ -408,8 +411,8 @@ struct InequalityDecompProject
     idecomp::InequalityDecomp
 end
 cbasis(Q::InequalityDecompProject) = (d = Q.idecomp;
-    d.W === nothing ? CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, C_NULL, C_NULL, C_NULL) :
-                      CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, d.Jct.h, pointer(d.W), C_NULL))
+    d.W === nothing ? CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, C_NULL, C_NULL, C_NULL, C_NULL) :
+                      CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, d.Jct.h, pointer(d.W), C_NULL, C_NULL))
 const AnyBasis = Union{DeviceBasis,InequalityDecompProject}
 ncols(U::DeviceBasis) = U.ncols
 ncols(Q::InequalityDecompProject) = Q.idecomp.rank
@@ -1002,6 +1005,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
         idata = InequalityData(ctx, Vector{Float64}(xl), Vector{Float64}(xu))
     end
     newvec() = ineq ? StackedVector(ctx, n) : DeviceVector(ctx, n)
+    jsp = (c! isa DeviceConstraints && c!.Jsp != C_NULL) ? (h = c!.Jsp,) : nothing     # sparse twin of the linear block, if any
     x = newvec()
     upload!(x, x0, 0)
     ineq && generate_initial_y!(x, idata)                                                  # :179-182
@@ -1075,7 +1079,6 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
         rank = m
         if m > 0
             jac!(Jct, cval, x)                                                          # :283-284 (the device keeps only Jct)
-            jsp = (c! isa DeviceConstraints && c!.Jsp != C_NULL) ? (h = c!.Jsp,) : nothing     # sparse twin of the linear block, if any
             rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp)     # :286-302
             if !ineq                                                                    # :305-308
                 mul!(tmp_m, adjoint(DeviceBasis(Z, rank)), d)
@@ -1110,7 +1113,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             term_cond = kkt_tol; break
         end
         if param.do_newton                                                              # :364-390
-            Qview = ineq ? ineqproject : DeviceBasis(Z, rank)
+            Qview = ineq ? ineqproject : (jsp === nothing ? DeviceBasis(Z, rank) : DeviceBasis(Z, rank, (Jct, idecomp.W), jsp.h))   # sparse twin: projcg! on the nonzeros
             grad_norm = norm(d)
             tol = param.tn_κ * min(1, grad_norm / prev_grad_norm) * grad_norm           # :375-378 (prev = 0: ratio Inf => factor 1)
             prev_grad_norm = grad_norm

@@ -22,7 +22,7 @@ class DiagOp(C.Structure):  # lfpsqp_diag_op
 
 
 class Basis(C.Structure):  # lfpsqp_basis
-    _fields_ = [("Z", P), ("ncols", c_i64), ("Dx", P), ("Dy", P), ("sx", P), ("sy", P), ("A", P), ("W", P), ("S", P)]
+    _fields_ = [("Z", P), ("ncols", c_i64), ("Dx", P), ("Dy", P), ("sx", P), ("sy", P), ("A", P), ("W", P), ("S", P), ("SA", P)]
 
 
 class IneqData(C.Structure):  # lfpsqp_ineq_data

@@ -40,6 +40,7 @@
 #include <stdlib.h>
 
 #include "internal.h"
+#include "sparse.h"
 
 namespace lfpsqp {
 
@@ -576,6 +577,69 @@ struct PcgProjES {
 using namespace lfpsqp;
 
 // A is either the device-resident diagonal form (A) or a callback (opf, with the work vector Av its products land in)
+// ---- the basis in factored form on the nonzeros: U = A W, A = [S | up to 4 dense columns] ---------------------------------------
+// U'v = W'(A'v): the producer's vector v is materialised (SpStoreV), A'v by the sparse product (+ a small dense GEMV-T for the extra
+// columns), W' by one workgroup (sp_basis_small_kernel).  U t = A (W t): u = W t by the same small kernel, then a row pass over the ELL
+// entries feeds the consumer functor what the dense GEMV-N would have fed it (SpConsumeE).
+struct SpPlainV {   // GEMV-T producer: the materialised vector itself
+    const double* v;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double2 a = ld2(v + r);
+        return make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0);
+    }
+};
+template <class V>
+struct SpStoreV {
+    V v;
+    double* tmp;
+    __device__ __forceinline__ bool skip() const { return v.skip(); }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 a = v.load(i, v0, v1);
+        if (v1) st2(tmp + i, a);
+        else if (v0) tmp[i] = a.x;
+    }
+};
+template <class E>
+struct SpConsumeE {
+    E e;
+    EllRows R;                      // R.t = u (first S.m entries)
+    const double* xcol;             // dense extra columns of A
+    int64_t ldx;
+    const double* ux;               // u[S.m ..]
+    int nx;
+    __device__ __forceinline__ bool skip() const { return e.skip(); }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        double2 acc = R.acc(i);
+        for (int j = 0; j < nx; ++j) {
+            const double w = ld_scal(ux + j);
+            const double2 c = ld2(xcol + (int64_t)j * ldx + i);
+            acc.x = fma(c.x, w, acc.x);
+            acc.y = fma(c.y, w, acc.y);
+        }
+        e.apply(i, acc, v0, v1, red);
+    }
+};
+// t = W' tA (m entries; W is wm x m, column-major), and optionally u = W t (wm entries).  One workgroup; tA / t are replicated.
+__global__ __launch_bounds__(256) void sp_basis_small_kernel(const double* __restrict__ W, int wm, int m, const double* tA, double* t_out,
+                                                              double* u_out) {
+    __shared__ double ts[kOnepassMaxCols];
+    for (int j = threadIdx.x; j < m; j += 256) {
+        const double* wj = W + (size_t)j * wm;
+        double s = 0.0;
+        for (int k = 0; k < wm; ++k) s = fma(wj[k], ld_scal(tA + k), s);
+        ts[j] = s;
+        t_out[j] = s;
+    }
+    __syncthreads();
+    if (u_out)
+        for (int k = threadIdx.x; k < wm; k += 256) {
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s = fma(W[(size_t)j * wm + k], ts[j], s);
+            u_out[k] = s;
+        }
+}
+
 static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, lfpsqp_opfun opf, void* ouser,
                        lfpsqp_vec* Av, const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
                        int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
@@ -620,6 +684,38 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     int64_t maxit_eff = maxit < n_global + m_ref ? maxit : n_global + m_ref;
     if (maxit_eff < 0) maxit_eff = 0;
 
+    // basis in factored form on the nonzeros (plain basis, generator and its sparse twin known)?
+    const lfpsqp_spmat* SA = nullptr;
+    int wm = 0;
+    double *dWs = nullptr, *tA = nullptr, *uA = nullptr;
+    if (!stacked && m > 0 && m <= kOnepassMaxCols && U->SA && U->A && U->W && U->SA->n == nv && U->A->n == nv && U->SA->m >= 1 && U->A->m >= U->SA->m &&
+        U->A->m - U->SA->m <= 4 && !(c && m > 0)) {
+        SA = U->SA;
+        wm = (int)U->A->m;
+        LF_TRY(ensure_small(ctx, (size_t)wm * m + 2 * (size_t)wm + 64));
+        dWs = ctx->small;
+        tA = dWs + (((size_t)wm * m + 1) & ~(size_t)1);
+        uA = tA + ((wm + 1) & ~1);
+        LF_HIP(ctx, hipMemcpyAsync(dWs, U->W, sizeof(double) * (size_t)wm * m, hipMemcpyHostToDevice, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // U->W is caller-owned pageable memory
+    }
+    const int nxs = SA ? wm - (int)SA->m : 0;
+    // t_out = U' v for the producer functor v (materialised in tmp): W' ([S | X]' v)
+    auto sp_gemv_t = [&](auto vf, double* tmp, double* t_out, double* u_out) -> int {
+        using V = decltype(vf);
+        LF_TRY((run_vec<SpStoreV<V>, 0, NoPost>(ctx, nv, SpStoreV<V>{vf, tmp}, 0u, nullptr, NoPost())));
+        LF_TRY(spmv_t(ctx, SA, tmp, tA));
+        if (nxs > 0) {
+            lfpsqp_mat view = *U->A;
+            view.p = U->A->p + (int64_t)SA->m * U->A->ld;
+            view.m = nxs;
+            LF_TRY(run_gemv_t(ctx, &view, nxs, nv, SpPlainV{tmp}, tA + SA->m));
+        }
+        hipLaunchKernelGGL(sp_basis_small_kernel, dim3(1), dim3(256), 0, ctx->stream, dWs, wm, m, tA, t_out, u_out);
+        LF_LAUNCH_CHECK(ctx);
+        return 0;
+    };
+
     const HostMirror hm{ctx->h_istat, ctx->h_scal};
     volatile int64_t* hstat = ctx->h_istat;
     hstat[0] = ST_RUNNING;
@@ -636,6 +732,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         using AOP = decltype(aop);
         const ResidualV<AOP> rv{x->p, b->p, store, aop, sgn};
         if (stacked) return run_gemv_t(ctx, Z, m, N, ResidualVS<AOP>{rv, sk, store ? nullptr : lambda->p}, t_out);
+        if (SA) return sp_gemv_t(rv, rp, t_out, store ? uA : nullptr);      // (rp doubles as the scratch vector: free outside the set-up)
         return run_gemv_t(ctx, Z, m, N, rv, t_out);
     };
     auto launch_residual = [&](double sgn, double* store, double* t_out) -> int {
@@ -647,6 +744,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         using AOP = decltype(aop);
         const PcgStepV<AOP> sv{d, g, aop, scal, istat};
         if (stacked) return run_gemv_t(ctx, Z, m, N, PcgStepVS<AOP>{sv, sk}, Utr, 1);
+        if (SA) return sp_gemv_t(sv, rp, Utr, uA);
         return run_gemv_t(ctx, Z, m, N, sv, Utr, 1);
     };
     auto launch_k2 = [&]() -> int { return opf ? k2_with(Aop) : k2_with(Ad); };
@@ -655,12 +753,17 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         const PcgProjE<AOP> pe{rp, g, d, istat, init, PcgStepV<AOP>{d, g, aop, scal, istat}};
         const PcgPost3 post{scal, istat, init, hm, scal + S_RPGP};
         if (stacked) return run_gemv_n<PcgProjES<AOP>, 2, PcgPost3>(ctx, Z, m, N, Utr, PcgProjES<AOP>{pe, sk}, scal + S_RPGP, post, init ? -1 : 2);
+        if (SA) {                                                         // u = W Utr was formed together with Utr (sp_gemv_t)
+            using E = PcgProjE<AOP>;
+            const SpConsumeE<E> ce{pe, ell_rows(SA, uA), U->A->p + (int64_t)SA->m * U->A->ld, U->A->ld, uA + SA->m, nxs};
+            return run_vec<SpConsumeE<E>, 2, PcgPost3>(ctx, nv, ce, 0u, scal + S_RPGP, post, init ? -1 : 2);
+        }
         return run_gemv_n<PcgProjE<AOP>, 2, PcgPost3>(ctx, Z, m, N, Utr, pe, scal + S_RPGP, post, init ? -1 : 2);
     };
     auto launch_k3 = [&](int init) -> int { return opf ? k3_with(Aop, init) : k3_with(Ad, init); };
 
     // fused iteration (one pass over U)?  Needs a tile shape for m columns and 32-bit lane offsets
-    const bool fused = !opf && m > 0 && onepass_cw(ctx, m, Z->ld, N) != 0;
+    const bool fused = !SA && !opf && m > 0 && onepass_cw(ctx, m, Z->ld, N) != 0;
     double *T12 = nullptr, *t3 = nullptr;
     if (fused) {
         LF_TRY(ensure_mvec(ctx, (size_t)3 * m + 24));

@@ -271,7 +271,8 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             if ineq:
                 Qview = ineqproject
             else:
-                Qview = DeviceBasis(Z, rank)
+                jsp_ = getattr(c_, "Jsp", None)                              # sparse twin: the projected CG runs on the nonzeros
+                Qview = DeviceBasis(Z, rank, generator=(Jct, Wgen), sparse=jsp_) if jsp_ is not None else DeviceBasis(Z, rank)
             grad_norm = nrm2(d)
             with np.errstate(divide='ignore', invalid='ignore'):
                 ratio = float(np.float64(grad_norm) / np.float64(prev_grad_norm))

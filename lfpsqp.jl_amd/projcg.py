@@ -51,15 +51,17 @@ class DiagOperator:
 class DeviceBasis:
     """Orthonormal U = Z[:, :ncols] (``view(U, :, 1:rank)``, src/optimize.jl:370)."""
 
-    def __init__(self, Z: DeviceMatrix, ncols: int | None = None, generator=None):
+    def __init__(self, Z: DeviceMatrix, ncols: int | None = None, generator=None, sparse=None):
         self.Z = Z
         self.ncols = Z.m if ncols is None else int(ncols)
         self.generator = generator          # optional (A, W) with Z == A @ W (ksvd_'s W): lfpsqp_basis.A / .W
+        self.sparse = sparse                # optional SparseMatrix twin of A's leading columns: projcg_ runs on the nonzeros (lfpsqp_basis.SA)
 
     def _c(self):
         if self.generator is not None:
             A, W = self.generator
-            return _capi.Basis(self.Z.h, self.ncols, None, None, None, None, A.h, W.ctypes.data)
+            return _capi.Basis(self.Z.h, self.ncols, None, None, None, None, A.h, W.ctypes.data, None,
+                               self.sparse.h if self.sparse is not None else None)
         return _capi.Basis(self.Z.h, self.ncols, None, None, None, None)
 
     def mul_(self, dest, v, a=None, b=None):

@@ -312,3 +312,72 @@ def test_newton_retraction_on_the_nonzeros_is_the_dense_retraction(dev_ctx, has_
     assert (f1, i1) == (f0, i0) and f0 == 0 and i0 >= (2 if has_ball else 1)
     assert np.abs(x1 - x0).max() <= 1e-12 * np.abs(x0).max()
     assert np.abs(c1 - c0).max() <= 1e-11 and np.abs(c1).max() < 1e-9
+
+
+@pytest.mark.parametrize("case", ["plain", "extra_column", "operator_callback"])
+def test_projected_cg_in_factored_form_on_the_nonzeros(dev_ctx, case):
+    """projcg! with the basis applied as U t = A (W t), U'v = W'(A'v) on the nonzeros of A (lfpsqp_basis.SA; A = [S | one dense column] in
+    the second case, a general operator behind the callback in the third) against the dense basis Z = A W and the oracle: same
+    iteration count, same iterate and multipliers."""
+    ctx = dev_ctx
+    emu = _is_emu(ctx)
+    n, m_lin, k = (2600 if emu else 300_000), 9, 3
+    extra = 1 if case == "extra_column" else 0
+    m = m_lin + extra
+    rows, cols, vals = banded(n, m_lin, k, seed=31)
+    Ah = np.zeros((n, m), order='F')
+    np.add.at(Ah, (rows, cols), vals)
+    if extra:
+        Ah[:, m_lin] = synth.hash_vector(12, n)
+    A = ctx.matrix(n, m, Ah)
+    S = L.SparseMatrix(ctx, n, m_lin, rows, cols, vals)
+    Z, W = ctx.matrix(n, m), np.zeros((m, m), order='F')
+    Sg, Vt, rank = L.ksvd_(A, Z, W=W, Jsp=S)
+    assert rank == m
+    a = 4.0 * synth.hash_vector(3, n) + 5.0
+    bh = synth.hash_vector(4, n)
+    Zh = Z.download()
+    if case == "operator_callback":
+        e = 0.7 * synth.hash_vector(15, n)[:n - 1]
+        av, up, dn = ctx.vector(n, a), ctx.vector(n, np.concatenate([e, [0.0]])), ctx.vector(n, np.concatenate([[0.0], e]))
+        sh, tt = ctx.vector(n), ctx.vector(n)
+
+        class Tri:
+            def mul_(self, dest, v, al=None, be=None):
+                L.vmul(av, v, dest)
+                sh.fill(0.0); sh.copy_range_from(v, n - 1, 0, 1)
+                L.vmul(up, sh, tt); L.axpby(1.0, tt, 1.0, dest)
+                sh.fill(0.0); sh.copy_range_from(v, n - 1, 1, 0)
+                L.vmul(dn, sh, tt); L.axpby(1.0, tt, 1.0, dest)
+                return dest
+
+            def adjoint(self):
+                return self
+
+        class TriRef:
+            def mul_(self, dest, v, al=None, be=None):
+                t = a * v
+                t[:-1] += e * v[1:]
+                t[1:] += e * v[:-1]
+                dest[:] = t if al is None else al * t + be * dest
+                return dest
+
+            def adjoint(self):
+                return self
+        Aop, Aref = Tri(), TriRef()
+    else:
+        from tests.helpers import DiagOpRef
+        Aop, Aref = L.DiagOperator(0.0, ctx.vector(n, a)), DiagOpRef(a)
+    x0, l0 = np.zeros(n), np.zeros(m)
+    it0, nr0 = R.projcg_(x0, l0, Aref, np.asfortranarray(Zh), bh, np.zeros(m), tol=1e-10, maxit=400)
+    res = {}
+    for label, basis in (("dense", L.DeviceBasis(Z)), ("nonzeros", L.DeviceBasis(Z, generator=(A, W), sparse=S))):
+        x, lam = ctx.vector(n), ctx.vector(m)
+        it, nr = L.projcg_(x, lam, Aop, basis, ctx.vector(n, bh), None, tol=1e-10, maxit=400)
+        res[label] = (it, nr, x.download(), lam.download())
+    for label in res:
+        it, nr, xh, lh = res[label]
+        assert it == it0, (label, it, it0)
+        assert np.linalg.norm(xh - x0) <= 1e-9 * np.linalg.norm(x0), label
+        assert np.abs(lh - l0).max() <= 1e-9 * max(np.abs(l0).max(), 1.0), label
+    assert np.abs(Zh.T @ res["nonzeros"][2]).max() <= 1e-10 * np.linalg.norm(res["nonzeros"][2])     # the iterate is in the null space of U'
