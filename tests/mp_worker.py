@@ -132,6 +132,9 @@ def main():
     x0sp = xss.download() + 0.05 * synth.hash_vector(6, nsp)[g0:g1]
     xo, obj, lamk, ti = Psp.optimize(x0sp, L.LFPSQPParams(disp=L.DisplayOption.off, maxiter=3))
     res.update(g0=g0, g1=g1, sp_x=xo, sp_obj=obj, sp_iter=ti.iter, sp_b=bsp.download())
+    # ... and with the Newton retraction: tangent setup, projected CG and every Newton step on the nonzeros of the shard
+    xo, obj, lamk, ti = Psp.optimize(x0sp, L.LFPSQPParams(disp=L.DisplayOption.off, maxiter=3, do_project_retract=False))
+    res.update(spn_x=xo, spn_obj=obj, spn_iter=ti.iter)
     np.savez(out, **res)
     dist.barrier()
     ctx.close()

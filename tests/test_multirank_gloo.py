@@ -191,3 +191,9 @@ def test_sharded_sparse_equalities_through_the_default_retraction(two_ranks):
     assert int(a["sp_iter"]) == int(b["sp_iter"]) == tir.iter
     assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
     np.testing.assert_allclose(a["sp_obj"], objr, rtol=1e-10)
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, None, None, msp,
+                                     R.LFPSQPParams(disp=R.DisplayOption.off, maxiter=3, do_project_retract=False))
+    x = np.concatenate([a["spn_x"], b["spn_x"]])
+    assert int(a["spn_iter"]) == int(b["spn_iter"]) == tir.iter
+    assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
+    np.testing.assert_allclose(a["spn_obj"], objr, rtol=1e-10)
