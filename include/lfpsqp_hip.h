@@ -277,7 +277,8 @@ typedef struct lfpsqp_basis {
 
 /* mul!(dest, Q', v) (src/inequality_helper.jl:197-212): w[0:N) = Dx.*vx + Dy.*vy,
  * t[0:ncols) = Z'(sx.*vx + sy.*vy)  -- ONE pass over the N x M matrix Z (the reference makes a
- * pass over a 2N x M matrix).  For a plain basis (Dx == NULL) this is lfpsqp_gemv_t and w is unused. */
+ * pass over a 2N x M matrix).  For a plain basis (Dx == NULL) this is lfpsqp_gemv_t and w is unused; a plain basis that carries
+ * A, W and SA is applied in factored form on the nonzeros, t = W'(A'v) (likewise lfpsqp_q_gemv_n: y = alpha A (W t) + beta y). */
 int lfpsqp_q_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, const lfpsqp_vec* v, lfpsqp_vec* w, lfpsqp_vec* t);
 /* mul!(y, Q, [w; t], alpha, beta) (:161-194): y = alpha * Q [w; t] + beta * y, y stacked; w may be
  * NULL (treated as zero, e.g. the Newton-retraction update xnew += U*delta, src/retractions.jl:141) */

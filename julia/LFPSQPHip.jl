@@ -354,10 +354,14 @@ end
 Base.adjoint(U::DeviceBasis) = DeviceBasisAdjoint(U)
 Base.adjoint(Ut::DeviceBasisAdjoint) = Ut.U
 # kgemv! (src/la_helper.jl:36-44) and the mul! calls of src/projcg.jl / src/retractions.jl
+# (a basis that carries its generator and the generator's sparse twin is applied in factored form on the nonzeros: lfpsqp_q_gemv_*)
+factored(U::DeviceBasis) = U.generator !== nothing && U.sparse != C_NULL
 mul!(y::DeviceVector, U::DeviceBasis, t::DeviceVector, a::Number=1.0, b::Number=0.0) =
-    (check(y.ctx, c_gemv_n(y.ctx.h, U.Z.h, Int64(U.ncols), Float64(a), t.h, Float64(b), y.h)); y)
+    (check(y.ctx, factored(U) ? c_q_gemv_n(y.ctx.h, Ref(cbasis(U)), Float64(a), C_NULL, t.h, Float64(b), y.h) :
+                                c_gemv_n(y.ctx.h, U.Z.h, Int64(U.ncols), Float64(a), t.h, Float64(b), y.h)); y)
 mul!(t::DeviceVector, Ut::DeviceBasisAdjoint, v::DeviceVector) =
-    (check(t.ctx, c_gemv_t(t.ctx.h, Ut.U.Z.h, Int64(Ut.U.ncols), v.h, t.h)); t)
+    (check(t.ctx, factored(Ut.U) ? c_q_gemv_t(t.ctx.h, Ref(cbasis(Ut.U)), v.h, C_NULL, t.h) :
+                                   c_gemv_t(t.ctx.h, Ut.U.Z.h, Int64(Ut.U.ncols), v.h, t.h)); t)
 cbasis(U::DeviceBasis) = U.generator === nothing ? CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL) :
     CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, U.generator[1].h, pointer(U.generator[2]), C_NULL, U.sparse)
 
@@ -1081,8 +1085,9 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             jac!(Jct, cval, x)                                                          # :283-284 (the device keeps only Jct)
             rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp)     # :286-302
             if !ineq                                                                    # :305-308
-                mul!(tmp_m, adjoint(DeviceBasis(Z, rank)), d)
-                mul!(d, DeviceBasis(Z, rank), tmp_m, -1.0, 1.0)
+                Ub = jsp === nothing ? DeviceBasis(Z, rank) : DeviceBasis(Z, rank, (Jct, idecomp.W), jsp.h)
+                mul!(tmp_m, adjoint(Ub), d)
+                mul!(d, Ub, tmp_m, -1.0, 1.0)
             end
         end
         idecomp.rank = rank

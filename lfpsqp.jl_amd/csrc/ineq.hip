@@ -5,6 +5,7 @@
 #include <math.h>
 
 #include "internal.h"
+#include "sparse.h"
 
 namespace lfpsqp {
 
@@ -290,10 +291,17 @@ int lfpsqp_y_retract(lfpsqp_ctx* ctx, lfpsqp_vec* xnewaug, const lfpsqp_vec* xau
     return run_vec<YRetractF, 0, NoPost>(ctx, id->n, YRetractF{xnewaug->p, xaug->p, hs, view(id)}, 0u, nullptr, NoPost());
 }
 
+// a plain basis with its generator and the generator's sparse twin: U = A W applied on the nonzeros (sparse.hip)
+static bool sp_factored_ok(const lfpsqp_basis* Q, int64_t n) {
+    return Q->ncols > 0 && Q->SA && Q->A && Q->W && Q->SA->n == n && Q->A->n == n && Q->SA->m >= 1 && Q->A->m >= Q->SA->m && Q->A->m - Q->SA->m <= 4 &&
+           Q->ncols <= 1024;
+}
+
 int lfpsqp_q_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, const lfpsqp_vec* v, lfpsqp_vec* w, lfpsqp_vec* t) {
     LF_ARG(ctx, ctx && Q && v && t && Q->ncols >= 0 && (Q->ncols == 0 || (Q->Z && Q->ncols <= Q->Z->m)) && t->n >= Q->ncols);
     if (!Q->Dx) {
         LF_ARG(ctx, Q->Z);
+        if (sp_factored_ok(Q, v->n)) return sp_factored_gemv_t(ctx, Q->SA, Q->A, Q->W, (int)Q->ncols, v->p, t->p);     // on the nonzeros
         return lfpsqp_gemv_t(ctx, Q->Z, Q->ncols, v, t);
     }
     LF_ARG(ctx, Q->Dy && Q->sx && Q->sy && w);
@@ -307,6 +315,7 @@ int lfpsqp_q_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, double alpha, const 
     LF_ARG(ctx, ctx && Q && y && Q->ncols >= 0 && (Q->ncols == 0 || (Q->Z && t && Q->ncols <= Q->Z->m && t->n >= Q->ncols)));
     if (!Q->Dx) {
         LF_ARG(ctx, Q->Z);
+        if (sp_factored_ok(Q, y->n)) return sp_factored_gemv_n(ctx, Q->SA, Q->A, Q->W, (int)Q->ncols, alpha, t->p, beta, y->p);
         return lfpsqp_gemv_n(ctx, Q->Z, Q->ncols, alpha, t, beta, y);
     }
     LF_ARG(ctx, Q->Dy && Q->sx && Q->sy);

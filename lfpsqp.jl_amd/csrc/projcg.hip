@@ -579,7 +579,7 @@ using namespace lfpsqp;
 // A is either the device-resident diagonal form (A) or a callback (opf, with the work vector Av its products land in)
 // ---- the basis in factored form on the nonzeros: U = A W, A = [S | up to 4 dense columns] ---------------------------------------
 // U'v = W'(A'v): the producer's vector v is materialised (SpStoreV), A'v by the sparse product (+ a small dense GEMV-T for the extra
-// columns), W' by one workgroup (sp_basis_small_kernel).  U t = A (W t): u = W t by the same small kernel, then a row pass over the ELL
+// columns), W' by one workgroup (sp_basis_small, sparse.hip).  U t = A (W t): u = W t by the same small kernel, then a row pass over the ELL
 // entries feeds the consumer functor what the dense GEMV-N would have fed it (SpConsumeE).
 struct SpPlainV {   // GEMV-T producer: the materialised vector itself
     const double* v;
@@ -620,26 +620,6 @@ struct SpConsumeE {
         e.apply(i, acc, v0, v1, red);
     }
 };
-// t = W' tA (m entries; W is wm x m, column-major), and optionally u = W t (wm entries).  One workgroup; tA / t are replicated.
-__global__ __launch_bounds__(256) void sp_basis_small_kernel(const double* __restrict__ W, int wm, int m, const double* tA, double* t_out,
-                                                              double* u_out) {
-    __shared__ double ts[kOnepassMaxCols];
-    for (int j = threadIdx.x; j < m; j += 256) {
-        const double* wj = W + (size_t)j * wm;
-        double s = 0.0;
-        for (int k = 0; k < wm; ++k) s = fma(wj[k], ld_scal(tA + k), s);
-        ts[j] = s;
-        t_out[j] = s;
-    }
-    __syncthreads();
-    if (u_out)
-        for (int k = threadIdx.x; k < wm; k += 256) {
-            double s = 0.0;
-            for (int j = 0; j < m; ++j) s = fma(W[(size_t)j * wm + k], ts[j], s);
-            u_out[k] = s;
-        }
-}
-
 static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, lfpsqp_opfun opf, void* ouser,
                        lfpsqp_vec* Av, const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
                        int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
@@ -711,9 +691,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
             view.m = nxs;
             LF_TRY(run_gemv_t(ctx, &view, nxs, nv, SpPlainV{tmp}, tA + SA->m));
         }
-        hipLaunchKernelGGL(sp_basis_small_kernel, dim3(1), dim3(256), 0, ctx->stream, dWs, wm, m, tA, t_out, u_out);
-        LF_LAUNCH_CHECK(ctx);
-        return 0;
+        return sp_basis_small(ctx, dWs, wm, m, tA, t_out, u_out);
     };
 
     const HostMirror hm{ctx->h_istat, ctx->h_scal};

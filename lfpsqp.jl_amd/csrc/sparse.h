@@ -44,6 +44,15 @@ int spmv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const double* v, double* t_ou
 
 // Out[:, :r] = [S | X[:, x0 : x0+nx)] * W   (W on the device, (S->m + nx) x r column-major with leading dimension ldw; X dense, may be
 // null with nx = 0; nx <= 4).  Row-parallel, fixed summation order (ELL order, then the dense columns): bit-reproducible.
+// t_out[0:m) = W' tA and optionally u_out[0:wm) = W t_out (W on the device, wm x m column-major): the replicated small step of a basis in
+// factored form U = A W
+int sp_basis_small(lfpsqp_ctx* ctx, const double* W_dev, int wm, int m, const double* tA, double* t_out, double* u_out);
+// the factored basis U = A W, A = [SA | A[:, SA.m:)] (at most 4 dense columns), W host (A.m x m), applied without a dense n x m matrix:
+// t_out = U'v   /   y = alpha U t + beta y   (v, t, y device pointers)
+int sp_factored_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, const double* v, double* t_out);
+int sp_factored_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, double alpha, const double* t,
+                       double beta, double* y);
+
 int spmm(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0, int nx, const double* W_dev, int ldw, int r, lfpsqp_mat* Out);
 
 }  // namespace lfpsqp

@@ -168,6 +168,112 @@ int spmm(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0, in
     return 0;
 }
 
+// t = W' tA (m entries; W is wm x m, column-major), and optionally u = W t (wm entries).  One workgroup; tA / t are replicated.
+__global__ __launch_bounds__(256) void sp_basis_small_kernel(const double* __restrict__ W, int wm, int m, const double* tA, double* t_out,
+                                                              double* u_out) {
+    __shared__ double ts[kOnepassMaxCols];
+    for (int j = threadIdx.x; j < m; j += 256) {
+        const double* wj = W + (size_t)j * wm;
+        double s = 0.0;
+        for (int k = 0; k < wm; ++k) s = fma(wj[k], ld_scal(tA + k), s);
+        ts[j] = s;
+        t_out[j] = s;
+    }
+    __syncthreads();
+    if (u_out)
+        for (int k = threadIdx.x; k < wm; k += 256) {
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s = fma(W[(size_t)j * wm + k], ts[j], s);
+            u_out[k] = s;
+        }
+}
+int sp_basis_small(lfpsqp_ctx* ctx, const double* W_dev, int wm, int m, const double* tA, double* t_out, double* u_out) {
+    hipLaunchKernelGGL(sp_basis_small_kernel, dim3(1), dim3(256), 0, ctx->stream, W_dev, wm, m, tA, t_out, u_out);
+    LF_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// The factored basis U = A W (A = [SA | X[:, SA.m:]], W host, wm x m) applied to a vector without a dense n x m matrix:
+// t = U'v = W'(A'v)   and   y = alpha U t + beta y = alpha A (W t) + beta y.
+struct SpPlainVecF {   // GEMV-T producer: the vector itself
+    const double* v;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double2 a = ld2(v + r);
+        return make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0);
+    }
+};
+struct SpFactoredNF {  // y = alpha * ([S | X] u) + beta * y
+    EllRows E;
+    const double* xcol;
+    int64_t ldx;
+    const double* ux;
+    int nx;
+    double* y;
+    double alpha, beta;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        double2 a = E.acc(i);
+        for (int j = 0; j < nx; ++j) {
+            const double w = ld_scal(ux + j);
+            const double2 c = ld2(xcol + (int64_t)j * ldx + i);
+            a.x = fma(c.x, w, a.x);
+            a.y = fma(c.y, w, a.y);
+        }
+        double2 o;
+        if (beta == 0.0) {
+            o = make_double2(alpha * a.x, alpha * a.y);
+        } else {
+            const double2 yy = ld2(y + i);
+            o = make_double2(fma(alpha, a.x, beta * yy.x), fma(alpha, a.y, beta * yy.y));
+        }
+        if (v1) st2(y + i, o);
+        else if (v0) y[i] = o.x;
+    }
+};
+static int factored_setup(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, double** dW, double** tA,
+                          double** uA) {
+    const int wm = (int)A->m;
+    LF_TRY(ensure_small(ctx, (size_t)wm * m + 2 * (size_t)wm + 64));
+    *dW = ctx->small;
+    *tA = *dW + (((size_t)wm * m + 1) & ~(size_t)1);
+    *uA = *tA + ((wm + 1) & ~1);
+    LF_HIP(ctx, hipMemcpyAsync(*dW, W_host, sizeof(double) * (size_t)wm * m, hipMemcpyHostToDevice, ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // W_host is caller-owned pageable memory
+    (void)SA;
+    return 0;
+}
+int sp_factored_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, const double* v, double* t_out) {
+    double *dW, *tA, *uA;
+    LF_TRY(factored_setup(ctx, SA, A, W_host, m, &dW, &tA, &uA));
+    const int wm = (int)A->m, nx = wm - (int)SA->m;
+    LF_TRY(spmv_t(ctx, SA, v, tA));
+    if (nx > 0) {
+        lfpsqp_mat view = *A;
+        view.p = A->p + (int64_t)SA->m * A->ld;
+        view.m = nx;
+        LF_TRY(run_gemv_t(ctx, &view, nx, A->n, SpPlainVecF{v}, tA + SA->m));
+    }
+    return sp_basis_small(ctx, dW, wm, m, tA, t_out, nullptr);
+}
+__global__ __launch_bounds__(256) void sp_w_times_t_kernel(const double* __restrict__ W, int wm, int m, const double* t, double* u_out) {
+    for (int k = threadIdx.x; k < wm; k += 256) {
+        double s = 0.0;
+        for (int j = 0; j < m; ++j) s = fma(W[(size_t)j * wm + k], ld_scal(t + j), s);
+        u_out[k] = s;
+    }
+}
+int sp_factored_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, double alpha, const double* t,
+                       double beta, double* y) {
+    double *dW, *tA, *uA;
+    LF_TRY(factored_setup(ctx, SA, A, W_host, m, &dW, &tA, &uA));
+    const int wm = (int)A->m, nx = wm - (int)SA->m;
+    hipLaunchKernelGGL(sp_w_times_t_kernel, dim3(1), dim3(256), 0, ctx->stream, dW, wm, m, t, uA);
+    LF_LAUNCH_CHECK(ctx);
+    const SpFactoredNF f{ell_rows(SA, uA), A->p + (int64_t)SA->m * A->ld, A->ld, uA + SA->m, nx, y, alpha, beta};
+    return run_vec<SpFactoredNF, 0, NoPost>(ctx, A->n, f, 0u, nullptr, NoPost());
+}
+
 // dense[:, j] from the CSC arrays of column j (one entry per position: every element written once)
 __global__ void sp_scatter_kernel(const int64_t* __restrict__ colptr, const int32_t* __restrict__ row, const double* __restrict__ val,
                                   double* __restrict__ dense, int64_t ld_dense) {

@@ -223,8 +223,14 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             Sig[:] = S_
             Vt[:, :] = Vt_
             if not ineq:                                                   # :305-308
-                gemv_t(Z, d, tmp_m, ncols=rank)
-                gemv_n(Z, tmp_m, d, -1.0, 1.0, ncols=rank)
+                jsp_ = getattr(c_, "Jsp", None)
+                if jsp_ is not None:                                       # sparse twin: the projection runs on the nonzeros too
+                    Ub = DeviceBasis(Z, rank, generator=(Jct, Wgen), sparse=jsp_)
+                    Ub.adjoint().mul_(tmp_m, d)
+                    Ub.mul_(d, tmp_m, -1.0, 1.0)
+                else:
+                    gemv_t(Z, d, tmp_m, ncols=rank)
+                    gemv_n(Z, tmp_m, d, -1.0, 1.0, ncols=rank)
         if ineq:                                                           # :312-318
             idecomp.rank = rank
             ineqproject.mul_t(tmp_w, tmp_m, d)

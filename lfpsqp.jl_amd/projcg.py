@@ -64,9 +64,17 @@ class DeviceBasis:
                                self.sparse.h if self.sparse is not None else None)
         return _capi.Basis(self.Z.h, self.ncols, None, None, None, None)
 
+    def _factored(self):
+        return self.sparse is not None and self.generator is not None
+
     def mul_(self, dest, v, a=None, b=None):
         if a is None:
             a, b = 1.0, 0.0
+        if self._factored():                # U t = A (W t) on the nonzeros (lfpsqp_q_gemv_n with lfpsqp_basis.SA)
+            c = self.Z.ctx
+            bs = self._c()
+            c.check(c.L.lfpsqp_q_gemv_n(c.h, C.byref(bs), float(a), None, v.h, float(b), dest.h))
+            return dest
         return gemv_n(self.Z, v, dest, a, b, self.ncols)
 
     def adjoint(self):
@@ -79,6 +87,11 @@ class _BasisAdjoint:
 
     def mul_(self, dest, v, a=None, b=None):
         assert a is None
+        if self.basis._factored():          # U'v = W'(A'v) on the nonzeros
+            c = self.basis.Z.ctx
+            bs = self.basis._c()
+            c.check(c.L.lfpsqp_q_gemv_t(c.h, C.byref(bs), v.h, None, dest.h))
+            return dest
         return gemv_t(self.basis.Z, v, dest, self.basis.ncols)
 
     def adjoint(self):

@@ -381,3 +381,30 @@ def test_projected_cg_in_factored_form_on_the_nonzeros(dev_ctx, case):
         assert np.linalg.norm(xh - x0) <= 1e-9 * np.linalg.norm(x0), label
         assert np.abs(lh - l0).max() <= 1e-9 * max(np.abs(l0).max(), 1.0), label
     assert np.abs(Zh.T @ res["nonzeros"][2]).max() <= 1e-10 * np.linalg.norm(res["nonzeros"][2])     # the iterate is in the null space of U'
+
+
+@pytest.mark.parametrize("extra", [0, 1])
+def test_factored_basis_products_are_the_dense_ones(dev_ctx, extra):
+    """mul!(t, U', v) and mul!(y, U, t, alpha, beta) with U = A W applied on the nonzeros of A (lfpsqp_q_gemv_t / _n with lfpsqp_basis.SA:
+    the tangent projection of optimize for sparse constraint gradients) against the products with the dense basis Z."""
+    ctx = dev_ctx
+    n, m_lin, k = (2200 if _is_emu(ctx) else 200_000), 11, 3
+    m = m_lin + extra
+    rows, cols, vals = banded(n, m_lin, k, seed=41)
+    Ah = np.zeros((n, m), order='F')
+    np.add.at(Ah, (rows, cols), vals)
+    if extra:
+        Ah[:, m_lin] = synth.hash_vector(13, n)
+    A = ctx.matrix(n, m, Ah)
+    S = L.SparseMatrix(ctx, n, m_lin, rows, cols, vals)
+    Z, W = ctx.matrix(n, m), np.zeros((m, m), order='F')
+    _, _, rank = L.ksvd_(A, Z, W=W, Jsp=S)
+    assert rank == m
+    Ud, Uf = L.DeviceBasis(Z), L.DeviceBasis(Z, generator=(A, W), sparse=S)
+    v = ctx.vector(n).hash_fill(7)
+    td, tf = ctx.vector(m), ctx.vector(m)
+    Ud.adjoint().mul_(td, v); Uf.adjoint().mul_(tf, v)
+    np.testing.assert_allclose(tf.download(), td.download(), rtol=0, atol=1e-12 * np.abs(td.download()).max())
+    yd, yf = ctx.vector(n).hash_fill(8), ctx.vector(n).hash_fill(8)
+    Ud.mul_(yd, td, -1.5, 0.5); Uf.mul_(yf, td, -1.5, 0.5)
+    assert np.abs(yf.download() - yd.download()).max() <= 1e-13 * np.abs(yd.download()).max() * 10
