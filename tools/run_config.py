@@ -1,4 +1,4 @@
-"""Run a BASELINE config end to end on the GPU at full size:  python tools/run_config.py {2|3|4} [n] [m] [--pp] [--exact] [--ls-batch=K] [--max-outer=K]"""
+"""Run a BASELINE config end to end on the GPU at full size:  python tools/run_config.py {2|3|4} [n] [m] [--pp] [--exact] [--ls-batch=K] [--max-outer=K] [--banded | --banded-dense]"""
 import sys, time; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 import lfpsqp_jl_amd as L
@@ -12,6 +12,16 @@ if cfg == 2:
     n = int(float(args[0])) if args else 1_000_000
     J = ctx.matrix(n, 1); col = np.zeros((n, 1), order='F'); col[0, 0] = 1.0; J.upload(col)
     P = L.QuadLinearBallBox(ctx, n, 1, J, np.array([0.75])); x0 = np.ones(n)
+elif cfg == 3 and ('--banded' in sys.argv or '--banded-dense' in sys.argv):
+    # config 3's shape with BANDED equalities (4 nonzeros per row): --banded hands the solver the sparse twin, --banded-dense only the dense matrix
+    n = int(float(args[0])) if args else 10_000_000; m = int(args[1]) if len(args) > 1 else 128
+    ii = np.arange(n, dtype=np.int64); k = 4
+    rows = np.repeat(ii, k); cols = ((((ii * m) // n)[:, None] + np.arange(k)[None, :]) % m).ravel()
+    vals = (np.random.default_rng(5).standard_normal((n, k)) + 2.0 * (np.arange(k) == 0)).ravel()
+    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+    Jct = S.to_dense()
+    xs = ctx.vector(n).hash_fill(2); b = ctx.vector(m); L.spmv_t(S, xs, b)
+    P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download(), Jsp=S if '--banded' in sys.argv else None); x0 = np.ones(n)
 elif cfg == 3:
     n = int(float(args[0])) if args else 10_000_000; m = int(args[1]) if len(args) > 1 else 128
     Jct = ctx.matrix(n, m).hash_fill(1)
