@@ -23,7 +23,7 @@ def main():
     ctx.comm_init_callback(rank, world, torch_allreduce_callback(None))
     res = {}
     # ---- sharded projcg on the bench workload -------------------------------------------------
-    n, m = 5000, 6
+    n, m = 3200, 6
     r0, r1 = ctx.shard_range(n)
     nl = r1 - r0
     J = ctx.matrix(nl, m).hash_fill(1, r0, n)
@@ -45,7 +45,7 @@ def main():
                          ctx.vector(e1 - e0).hash_fill(4, e0), None, tol=1e-10, maxit=300, n_global=ne)
     res.update(e0=e0, e1=e1, e_x=xe.download(), e_it=ite, e_S=Se, e_lam=lame.download())
     # ---- sharded config 3 through the outer driver (NR and ProjPenalty) ----------------------
-    n3, m3 = 4000, 5
+    n3, m3 = 2800, 5
     q0, q1 = ctx.shard_range(n3)
     Jct = ctx.matrix(q1 - q0, m3).hash_fill(1, q0, n3)
     xs = ctx.vector(q1 - q0).hash_fill(2, q0)
@@ -56,7 +56,7 @@ def main():
         xo, obj, lamk, ti = P.optimize(np.ones(q1 - q0), L.LFPSQPParams(do_project_retract=dpr, disp=L.DisplayOption.off))
         res.update({f"c3{tag}_x": xo, f"c3{tag}_obj": obj, f"c3{tag}_lam": lamk, f"c3{tag}_iter": ti.iter, "q0": q0, "q1": q1})
     # ---- sharded config 4: the slack variable lives on the LAST rank --------------------------
-    n4, m4 = 3000, 4
+    n4, m4 = 2600, 4
     s0, s1 = ctx.shard_range(n4)
     last = rank == world - 1
     p_loc = 1 if last else 0
@@ -82,7 +82,7 @@ def main():
                c4b_alpha=np.array([t.get("alpha") or 0.0 for t in tr]))
     # ---- round-2 paths, sharded: refinement rounds of the factorisation (ill-conditioned block; the small Jacobi runs replicated),
     #      a general operator behind the callback (lfpsqp_projcg_op), sparse equalities through the default retraction --------------
-    ni, mi = 4500, 6
+    ni, mi = 3000, 6
     rng = np.random.default_rng(31)
     Q1, _ = np.linalg.qr(rng.standard_normal((ni, mi)))
     Q2, _ = np.linalg.qr(rng.standard_normal((mi, mi)))
@@ -117,7 +117,7 @@ def main():
     xi, lami = ctx.vector(i1 - i0), ctx.vector(mi)
     iti, nri = L.projcg_(xi, lami, Tri(), L.DeviceBasis(Zi, rki), ctx.vector(i1 - i0).hash_fill(4, i0), None, tol=1e-10, maxit=400, n_global=ni)
     res.update(i0=i0, i1=i1, ill_S=Si, ill_rank=rki, ill_Z=Zi.download(), op_x=xi.download(), op_it=iti, op_lam=lami.download())
-    nsp, msp, ksp = 5000, 8, 3
+    nsp, msp, ksp = 3000, 8, 3
     g0, g1 = ctx.shard_range(nsp)
     rows = np.repeat(np.arange(nsp), ksp)
     cols = (((np.arange(nsp) * msp) // nsp)[:, None] + np.arange(ksp)[None, :]) % msp

@@ -39,12 +39,12 @@ def two_ranks(emu_lib, tmp_path_factory):
 
 def test_shards_partition_the_rows(two_ranks):
     a, b = two_ranks
-    assert a["r0"] == 0 and a["r1"] == b["r0"] and b["r1"] == 5000 and a["r1"] % 2048 == 0
+    assert a["r0"] == 0 and a["r1"] == b["r0"] and b["r1"] == 3200 and a["r1"] % 2048 == 0
 
 
 def test_sharded_factorize_and_projcg_match_single_process_oracle(two_ranks):
     a, b = two_ranks
-    n, m = 5000, 6
+    n, m = 3200, 6
     Jh = synth.hash_matrix(1, n, m)
     Z = np.vstack([a["Z"], b["Z"]])
     np.testing.assert_array_equal(a["S"], b["S"])                        # replicated factors agree bit for bit
@@ -65,7 +65,7 @@ def test_sharded_factorize_and_projcg_match_single_process_oracle(two_ranks):
 @pytest.mark.parametrize("tag,dpr", [("nr", False), ("pp", True)])
 def test_sharded_config3_driver(two_ranks, tag, dpr):
     a, b = two_ranks
-    n, m = 4000, 5
+    n, m = 2800, 5
     prob0, x0 = synth.config3(n, m)
     xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, None, None, m,
                                      R.LFPSQPParams(do_project_retract=dpr, disp=R.DisplayOption.off))
@@ -79,7 +79,7 @@ def test_sharded_config3_driver(two_ranks, tag, dpr):
 
 def test_sharded_config4_slack_on_last_rank(two_ranks):
     a, b = two_ranks
-    n, m = 3000, 4
+    n, m = 2600, 4
     P0 = synth.BallBoxProblem(n, m)
     x0 = 0.97 * synth.hash_vector(2, n) + 0.03 * 0.5
     xr, objr, lamr, tir = R.optimize(P0.f, P0.c_, P0.d_, x0, P0.xl, P0.xu, m, 1,
@@ -97,7 +97,7 @@ def test_sharded_config4_batched_failed_retractions(two_ranks):
     batches (lfpsqp_retract_nr_batch): two ranks must agree with each other and with the single-process oracle on
     every count, accepted step and iterate."""
     a, b = two_ranks
-    n, m = 3000, 4
+    n, m = 2600, 4
     P0 = synth.BallBoxProblem(n, m)
     tr0 = []
     xr, objr, lamr, tir = R.optimize(P0.f, P0.c_, P0.d_, P0.x0, P0.xl, P0.xu, m, 1,
@@ -136,7 +136,7 @@ def test_sharded_ill_conditioned_factorize_and_operator_callback(two_ranks):
     values of dgesvd, replicated bit for bit; the device Jacobi of the small factor runs on every rank), and lfpsqp_projcg_op
     with a (rank-local) tridiagonal operator against the single-process oracle."""
     a, b = two_ranks
-    ni, mi = 4500, 6
+    ni, mi = 3000, 6
     rng = np.random.default_rng(31)
     Q1, _ = np.linalg.qr(rng.standard_normal((ni, mi)))
     Q2, _ = np.linalg.qr(rng.standard_normal((mi, mi)))
@@ -174,7 +174,7 @@ def test_sharded_sparse_equalities_through_the_default_retraction(two_ranks):
     """Sparse constraint gradients sharded by rows (each rank holds the nonzeros of its rows): c!, jac! and ProjPenalty's pcg! on the
     sparse products, their m-vectors all-reduced -- against the single-process oracle on the assembled dense matrix."""
     a, b = two_ranks
-    nsp, msp, ksp = 5000, 8, 3
+    nsp, msp, ksp = 3000, 8, 3
     rows = np.repeat(np.arange(nsp), ksp)
     cols = (((np.arange(nsp) * msp) // nsp)[:, None] + np.arange(ksp)[None, :]) % msp
     vals = (np.random.default_rng(9).standard_normal((nsp, ksp)) + 2.0 * (np.arange(ksp) == 0)).ravel()
