@@ -271,7 +271,7 @@ typedef struct lfpsqp_basis {
     const lfpsqp_spmat* S;
     /* optional sparse twin of the GENERATOR: the leading SA.m columns of A (at most 4 more dense columns behind them).  With A, W and
      * SA set, lfpsqp_projcg applies the basis in factored form, U t = A (W t) and U'v = W'(A'v), on the nonzeros: no dense n x m matrix is
-     * read in the loop (plain basis only; same projector, iterates equal to the dense form up to rounding). */
+     * read in the loop (plain and bound-stacked bases; same projector, iterates equal to the dense form up to rounding). */
     const lfpsqp_spmat* SA;
 } lfpsqp_basis;
 

@@ -407,16 +407,17 @@ mutable struct InequalityDecomp
     Jct::DeviceMatrix
     rank::Int
     W::Union{Nothing,Matrix{Float64}}
+    Jsp::Ptr{Cvoid}            # sparse twin of Jct's leading columns (lfpsqp_spmat handle): projcg! on the nonzeros; C_NULL otherwise
 end
 InequalityDecomp(ctx::HipContext, N::Integer, M::Integer, Jct::DeviceMatrix) =
-    InequalityDecomp(ctx, N, M, DeviceMatrix(ctx, N, M), zeros(M), zeros(M, M), (DeviceVector(ctx, N) for _ in 1:5)..., Jct, M, nothing)
+    InequalityDecomp(ctx, N, M, DeviceMatrix(ctx, N, M), zeros(M), zeros(M, M), (DeviceVector(ctx, N) for _ in 1:5)..., Jct, M, nothing, C_NULL)
 # Q = [[diag Dx; diag Dy], U[:, 1:rank]] (InequalityDecompProject, :25-27, :161-212): projcg!'s U with bounds
 struct InequalityDecompProject
     idecomp::InequalityDecomp
 end
 cbasis(Q::InequalityDecompProject) = (d = Q.idecomp;
     d.W === nothing ? CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, C_NULL, C_NULL, C_NULL, C_NULL) :
-                      CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, d.Jct.h, pointer(d.W), C_NULL, C_NULL))
+                      CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, d.Jct.h, pointer(d.W), C_NULL, d.Jsp))
 const AnyBasis = Union{DeviceBasis,InequalityDecompProject}
 ncols(U::DeviceBasis) = U.ncols
 ncols(Q::InequalityDecompProject) = Q.idecomp.rank
@@ -1028,6 +1029,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     prev_grad_norm = 0.0
     idecomp = InequalityDecomp(ctx, n, m, Jct)
     idecomp.W = m > 0 ? zeros(m, m) : nothing                 # ksvd!'s small factor: Z == Jct*W
+    jsp === nothing || (idecomp.Jsp = jsp.h)                  # sparse twin: the stacked basis is applied on the nonzeros too
     Z, Σ, Vt = idecomp.Z, idecomp.Σ, idecomp.Vt
     ineqproject = ineq ? InequalityDecompProject(idecomp) : nothing
     diagonal_hessian = has_hess_diag(hess_lag_vec!)

@@ -668,14 +668,16 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     const lfpsqp_spmat* SA = nullptr;
     int wm = 0;
     double *dWs = nullptr, *tA = nullptr, *uA = nullptr;
-    if (!stacked && m > 0 && m <= kOnepassMaxCols && U->SA && U->A && U->W && U->SA->n == nv && U->A->n == nv && U->SA->m >= 1 && U->A->m >= U->SA->m &&
+    double* tmpN = rp;                             // scratch for the materialised producer vector: rp, or (stacked: rp holds both halves) a buffer
+    if (m > 0 && m <= kOnepassMaxCols && U->SA && U->A && U->W && U->SA->n == N && U->A->n == N && U->SA->m >= 1 && U->A->m >= U->SA->m &&
         U->A->m - U->SA->m <= 4 && !(c && m > 0)) {
         SA = U->SA;
         wm = (int)U->A->m;
-        LF_TRY(ensure_small(ctx, (size_t)wm * m + 2 * (size_t)wm + 64));
+        LF_TRY(ensure_small(ctx, (size_t)wm * m + 2 * (size_t)wm + 64 + (stacked ? (size_t)N + 2 : 0)));
         dWs = ctx->small;
         tA = dWs + (((size_t)wm * m + 1) & ~(size_t)1);
         uA = tA + ((wm + 1) & ~1);
+        if (stacked) tmpN = uA + ((wm + 1) & ~1);
         LF_HIP(ctx, hipMemcpyAsync(dWs, U->W, sizeof(double) * (size_t)wm * m, hipMemcpyHostToDevice, ctx->stream));
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // U->W is caller-owned pageable memory
     }
@@ -683,13 +685,13 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     // t_out = U' v for the producer functor v (materialised in tmp): W' ([S | X]' v)
     auto sp_gemv_t = [&](auto vf, double* tmp, double* t_out, double* u_out) -> int {
         using V = decltype(vf);
-        LF_TRY((run_vec<SpStoreV<V>, 0, NoPost>(ctx, nv, SpStoreV<V>{vf, tmp}, 0u, nullptr, NoPost())));
+        LF_TRY((run_vec<SpStoreV<V>, 0, NoPost>(ctx, N, SpStoreV<V>{vf, tmp}, 0u, nullptr, NoPost())));
         LF_TRY(spmv_t(ctx, SA, tmp, tA));
         if (nxs > 0) {
             lfpsqp_mat view = *U->A;
             view.p = U->A->p + (int64_t)SA->m * U->A->ld;
             view.m = nxs;
-            LF_TRY(run_gemv_t(ctx, &view, nxs, nv, SpPlainV{tmp}, tA + SA->m));
+            LF_TRY(run_gemv_t(ctx, &view, nxs, N, SpPlainV{tmp}, tA + SA->m));
         }
         return sp_basis_small(ctx, dWs, wm, m, tA, t_out, u_out);
     };
@@ -709,8 +711,9 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     auto residual_with = [&](auto aop, double sgn, double* store, double* t_out) -> int {
         using AOP = decltype(aop);
         const ResidualV<AOP> rv{x->p, b->p, store, aop, sgn};
+        if (SA && stacked) return sp_gemv_t(ResidualVS<AOP>{rv, sk, store ? nullptr : lambda->p}, tmpN, t_out, store ? uA : nullptr);
         if (stacked) return run_gemv_t(ctx, Z, m, N, ResidualVS<AOP>{rv, sk, store ? nullptr : lambda->p}, t_out);
-        if (SA) return sp_gemv_t(rv, rp, t_out, store ? uA : nullptr);      // (rp doubles as the scratch vector: free outside the set-up)
+        if (SA) return sp_gemv_t(rv, tmpN, t_out, store ? uA : nullptr);    // (plain basis: rp doubles as the scratch vector)
         return run_gemv_t(ctx, Z, m, N, rv, t_out);
     };
     auto launch_residual = [&](double sgn, double* store, double* t_out) -> int {
@@ -721,8 +724,9 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     auto k2_with = [&](auto aop) -> int {
         using AOP = decltype(aop);
         const PcgStepV<AOP> sv{d, g, aop, scal, istat};
+        if (SA && stacked) return sp_gemv_t(PcgStepVS<AOP>{sv, sk}, tmpN, Utr, uA);
         if (stacked) return run_gemv_t(ctx, Z, m, N, PcgStepVS<AOP>{sv, sk}, Utr, 1);
-        if (SA) return sp_gemv_t(sv, rp, Utr, uA);
+        if (SA) return sp_gemv_t(sv, tmpN, Utr, uA);
         return run_gemv_t(ctx, Z, m, N, sv, Utr, 1);
     };
     auto launch_k2 = [&]() -> int { return opf ? k2_with(Aop) : k2_with(Ad); };
@@ -730,8 +734,13 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         using AOP = decltype(aop);
         const PcgProjE<AOP> pe{rp, g, d, istat, init, PcgStepV<AOP>{d, g, aop, scal, istat}};
         const PcgPost3 post{scal, istat, init, hm, scal + S_RPGP};
+        if (SA && stacked) {                                              // u = W Utr was formed together with Utr (sp_gemv_t)
+            using E = PcgProjES<AOP>;
+            const SpConsumeE<E> ce{E{pe, sk}, ell_rows(SA, uA), U->A->p + (int64_t)SA->m * U->A->ld, U->A->ld, uA + SA->m, nxs};
+            return run_vec<SpConsumeE<E>, 2, PcgPost3>(ctx, N, ce, 0u, scal + S_RPGP, post, init ? -1 : 2);
+        }
         if (stacked) return run_gemv_n<PcgProjES<AOP>, 2, PcgPost3>(ctx, Z, m, N, Utr, PcgProjES<AOP>{pe, sk}, scal + S_RPGP, post, init ? -1 : 2);
-        if (SA) {                                                         // u = W Utr was formed together with Utr (sp_gemv_t)
+        if (SA) {
             using E = PcgProjE<AOP>;
             const SpConsumeE<E> ce{pe, ell_rows(SA, uA), U->A->p + (int64_t)SA->m * U->A->ld, U->A->ld, uA + SA->m, nxs};
             return run_vec<SpConsumeE<E>, 2, PcgPost3>(ctx, nv, ce, 0u, scal + S_RPGP, post, init ? -1 : 2);

@@ -83,10 +83,12 @@ class InequalityDecomp:
         self.Jct = Jct if Jct is not None else DeviceMatrix(ctx, N, M)
         self.rank = M
         self.W = None                       # ksvd_'s small factor (Z == Jct @ W) when the driver keeps it
+        self.Jsp = None                     # sparse twin of Jct's leading columns: projcg_ then runs on the nonzeros (lfpsqp_basis.SA)
 
     def basis_c(self):
         if self.W is not None:
-            return _capi.Basis(self.Z.h, self.rank, self.Dx.h, self.Dy.h, self.sx.h, self.sy.h, self.Jct.h, self.W.ctypes.data)
+            return _capi.Basis(self.Z.h, self.rank, self.Dx.h, self.Dy.h, self.sx.h, self.sy.h, self.Jct.h, self.W.ctypes.data, None,
+                               self.Jsp.h if self.Jsp is not None else None)
         return _capi.Basis(self.Z.h, self.rank, self.Dx.h, self.Dy.h, self.sx.h, self.sy.h)
 
 

@@ -220,6 +220,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank, W=Wgen,
                                   Jsp=getattr(c_, "Jsp", None))                                                # :286-302
             idecomp.W = Wgen
+            idecomp.Jsp = getattr(c_, "Jsp", None)
             Sig[:] = S_
             Vt[:, :] = Vt_
             if not ineq:                                                   # :305-308

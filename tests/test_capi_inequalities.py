@@ -110,14 +110,25 @@ def test_projection_operator_and_y_retraction(dev_ctx, n, m):
     np.testing.assert_array_equal(X.download2(), xaug)
 
 
+@pytest.mark.parametrize("sparse", [False, True])
 @pytest.mark.parametrize("n,m", [(64, 5), (1500, 12)])
-def test_projcg_with_bounds_matches_oracle(dev_ctx, n, m):
+def test_projcg_with_bounds_matches_oracle(dev_ctx, n, m, sparse):
     """projcg! with U = InequalityDecompProject (src/optimize.jl:366-381) and the augmented diagonal
-    Hessian (augmented_hess_lag_vec!, src/inequality_helper.jl:144-158): fused stacked kernels vs oracle."""
+    Hessian (augmented_hess_lag_vec!, src/inequality_helper.jl:144-158): fused stacked kernels vs oracle.
+    sparse: banded constraint gradients with a sparse twin -- the stacked basis applied in factored form on the nonzeros
+    (lfpsqp_basis.SA: U t = [sx; sy] .* (Jct (W t)), same diagonal blocks)."""
     from tests.helpers import DiagOpRef
     ctx = dev_ctx
     rng, xl, xu, xaug, idata0, idata, X = _setup(ctx, n, m)
     Jh = synth.hash_matrix(1, n, m)
+    Ssp = None
+    if sparse:
+        rows = np.repeat(np.arange(n), 3)
+        cols = ((((np.arange(n) * m) // n)[:, None] + np.arange(3)[None, :]) % m).ravel()
+        vals = (np.random.default_rng(17).standard_normal((n, 3)) + 2.0 * (np.arange(3) == 0)).ravel()
+        Jh = np.zeros((n, m), order='F')
+        np.add.at(Jh, (rows, cols), vals)
+        Ssp = L.SparseMatrix(ctx, n, m, rows, cols, vals)
     idc0 = R.InequalityDecomp(np.empty((2 * n, m), order='F'), np.empty(m), np.empty((m, m), order='F'),
                               np.empty(n), np.empty(n), np.empty(n), Jh, m)
     R.inequality_gradient_(idc0, xaug, idata0)
@@ -126,7 +137,10 @@ def test_projcg_with_bounds_matches_oracle(dev_ctx, n, m):
     P0 = R.InequalityDecompProject(idc0)
     idc = L.InequalityDecomp(ctx, n, m, ctx.matrix(n, m, Jh))
     L.inequality_gradient_(idc, X, idata)
-    idc.Sigma, idc.Vt, idc.rank = L.ksvd_(idc.Jct, idc.Z, w2=ctx.vector(n, idc0.Dy ** 2))
+    Wg = np.zeros((m, m), order='F')
+    idc.Sigma, idc.Vt, idc.rank = L.ksvd_(idc.Jct, idc.Z, w2=ctx.vector(n, idc0.Dy ** 2), W=Wg, Jsp=Ssp)
+    if sparse:
+        idc.W, idc.Jsp = Wg, Ssp
     P = L.InequalityDecompProject(idc)
     # A = diag: 2 + 2*lamy*q on the x-half, 2*lamy*s (+3 to keep it SPD) on the y-half
     lamy = 0.3 * rng.random(n)
