@@ -27,6 +27,19 @@ elif cfg == 3:
     Jct = ctx.matrix(n, m).hash_fill(1)
     xs = ctx.vector(n).hash_fill(2); b = ctx.vector(m); L.gemv_t(Jct, xs, b)
     P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download()); x0 = np.ones(n)
+elif '--banded' in sys.argv or '--banded-dense' in sys.argv:
+    # config 4's shape (ball + four-way bounds, slack row) with BANDED equalities
+    n = int(float(args[0])) if args else 10_000_000; m = int(args[1]) if len(args) > 1 else 128
+    ii = np.arange(n, dtype=np.int64); k = 4
+    rows = np.repeat(ii, k); cols = ((((ii * m) // n)[:, None] + np.arange(k)[None, :]) % m).ravel()
+    vals = (np.random.default_rng(5).standard_normal((n, k)) + 2.0 * (np.arange(k) == 0)).ravel()
+    S = L.SparseMatrix(ctx, n + 1, m, rows, cols, vals)
+    Jct = ctx.matrix(n + 1, m + 1); S.to_dense(Jct)
+    xs = ctx.vector(n + 1).hash_fill(2, 0, 1.0, 0.0); ctx.check(ctx.L.lfpsqp_vec_fill_range(ctx.h, xs.h, n, 1, 0.0))
+    b = ctx.vector(m + 1); L.spmv_t(S, xs, b)
+    i = np.arange(n)
+    xl = np.where((i % 4 == 1) | (i % 4 == 3), -1.0, -np.inf); xu = np.where((i % 4 == 2) | (i % 4 == 3), 1.0, np.inf)
+    P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download()[:m], R2=n / 2.0, xl=xl, xu=xu, Jsp=S if '--banded' in sys.argv else None); x0 = 0.5 * np.ones(n)
 else:
     n = int(float(args[0])) if args else 10_000_000; m = int(args[1]) if len(args) > 1 else 128
     Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
