@@ -44,6 +44,10 @@ def main(argv=None, lib=None):
                          "host-gloo (functional test only: ranks may share one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device index (default: LOCAL_RANK)")
     ap.add_argument("--lib", default=None, help="(development) alternative build of liblfpsqp_hip.so to load")
+    ap.add_argument("--work-candidates", type=int, default=4,
+                    help="allocate this many candidate sets of the solver's work vectors (x, g, d, rp), time the fused kernel briefly on each "
+                         "(untimed, before the warm-up) and keep the fastest: where a set of n-vectors lands in physical memory decides between "
+                         "1.63 and 1.93 ms for that kernel (tools/work_placement_probe.py).  1 = take the first allocation")
     ap.add_argument("--watchdog-seconds", type=float, default=1500.0,
                     help="dump every thread's Python stack to stderr and exit non-zero if the run takes longer (0 = off): a stalled "
                          "rendezvous or collective then fails with a diagnosis instead of hanging the caller")
@@ -141,8 +145,27 @@ def main(argv=None, lib=None):
     U = L.DeviceBasis(Z)
     A = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.0, 5.0))
     b = ctx.vector(n_loc).hash_fill(4, r0)
-    x = ctx.vector(n_loc)
-    work = L.ProjCGWork(ctx, n_loc, m)
+    # candidate placements of the work vectors: the same number of (collective-carrying) trial calls on every rank, the choice is local
+    ncand = max(1, int(args.work_candidates))
+    cands, pads, trial_ms = [], [], []
+    for k in range(ncand):
+        cands.append((ctx.vector(n_loc), L.ProjCGWork(ctx, n_loc, m)))
+        if k + 1 < ncand:
+            pads.append(ctx.vector(1_000_003 * (k + 1)))                 # shifts where the next set lands
+    if ncand > 1:
+        for xk, wk in cands:
+            L.projcg_(xk, None, A, U, b, None, tol=1e-300, maxit=2, work=wk, n_global=n, want_lambda=False)     # touch
+        for xk, wk in cands:
+            ctx.set_profiling(True)
+            L.projcg_(xk, None, A, U, b, None, tol=1e-300, maxit=12, work=wk, n_global=n, want_lambda=False)
+            pms, pcnt = ctx.profile_read()
+            ctx.set_profiling(False)
+            slot = 3 if pcnt[3] > 0 else 2                                   # fused kernel F, else the second pass of the two-pass iteration
+            trial_ms.append(pms[slot] / pcnt[slot] if pcnt[slot] else float("inf"))
+    chosen = int(min(range(ncand), key=lambda k: trial_ms[k])) if trial_ms else 0
+    x, work = cands[chosen]
+    del pads
+    cands = [cands[chosen]]
 
     def barrier():
         ctx.sync()
@@ -253,6 +276,9 @@ def main(argv=None, lib=None):
                    "timed_region": (f"{K} iterations of a running solve (resumed after the {W} warmup iterations; set-up outside)"
                                     if resumed else f"one projcg call: set-up (2 passes over U) + {K} iterations"),
                    "prewarm": f"{prewarm_iters} untimed iterations ({args.prewarm_seconds:g} s) before the warmup steps",
+                   "work_placement": ({"candidates": ncand, "trial_F_ms": [round(t, 4) for t in trial_ms], "chosen": chosen,
+                                       "note": "candidate allocations of the solver's work vectors, fused kernel timed on each before the warm-up, fastest kept"}
+                                      if ncand > 1 else {"candidates": 1}),
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
                    "comm": comm_used, "device": ctx.device_name},
