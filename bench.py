@@ -48,6 +48,8 @@ def main(argv=None, lib=None):
                     help="allocate this many candidate sets of the solver's work vectors (x, g, d, rp), time the fused kernel briefly on each "
                          "(untimed, before the warm-up) and keep the fastest: where a set of n-vectors lands in physical memory decides between "
                          "1.63 and 1.93 ms for that kernel (tools/work_placement_probe.py).  1 = take the first allocation")
+    ap.add_argument("--basis-candidates", type=int, default=3,
+                    help="likewise for the basis matrix: this many allocations of it, the fused kernel timed on each, the fastest kept (1 = first)")
     ap.add_argument("--watchdog-seconds", type=float, default=1500.0,
                     help="dump every thread's Python stack to stderr and exit non-zero if the run takes longer (0 = off): a stalled "
                          "rendezvous or collective then fails with a diagnosis instead of hanging the caller")
@@ -133,35 +135,52 @@ def main(argv=None, lib=None):
     n_loc = r1 - r0
 
     # ---- workload, generated on the device -------------------------------
-    Z = ctx.matrix(n_loc, m)
-    if args.basis == "orthonormal" and hasattr(L, "orthonormalize_"):
-        Z.hash_fill(1, r0, n, 1.0)
-        L.orthonormalize_(Z, n_global=n)
-        basis_desc = "orthonormalised hash matrix (CholeskyQR2 on device)"
-    else:
-        scale = 2.0 ** math.floor(math.log2(math.sqrt(3.0 / n)))
-        Z.hash_fill(1, r0, n, scale)
-        basis_desc = "scaled hash matrix (columns orthonormal to O(sqrt(m/n)))"
-    U = L.DeviceBasis(Z)
+    def make_basis():
+        Zc = ctx.matrix(n_loc, m)
+        if args.basis == "orthonormal" and hasattr(L, "orthonormalize_"):
+            Zc.hash_fill(1, r0, n, 1.0)
+            L.orthonormalize_(Zc, n_global=n)
+            return Zc, "orthonormalised hash matrix (CholeskyQR2 on device)"
+        Zc.hash_fill(1, r0, n, 2.0 ** math.floor(math.log2(math.sqrt(3.0 / n))))
+        return Zc, "scaled hash matrix (columns orthonormal to O(sqrt(m/n)))"
+
     A = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.0, 5.0))
     b = ctx.vector(n_loc).hash_fill(4, r0)
-    # candidate placements of the work vectors: the same number of (collective-carrying) trial calls on every rank, the choice is local
+    # Placement candidates.  Where the basis and the work vectors land in memory decides between 1.63 and 1.93 ms for the fused kernel
+    # (three allocations of the basis in one process measured 1.92 / 1.92 / 1.68 ms with every work set; another day six work
+    # sets under one basis 1.93 x 4 / 1.63 x 2).  So: a few allocations of each, the fused kernel timed briefly on them (untimed, before
+    # the warm-up), the fastest kept.  Every rank makes the same number of (collective-carrying) trial calls; the choice is local.
+    def trial(Uk, xk, wk):
+        L.projcg_(xk, None, A, Uk, b, None, tol=1e-300, maxit=2, work=wk, n_global=n, want_lambda=False)     # touch
+        ctx.set_profiling(True)
+        L.projcg_(xk, None, A, Uk, b, None, tol=1e-300, maxit=12, work=wk, n_global=n, want_lambda=False)
+        pms, pcnt = ctx.profile_read()
+        ctx.set_profiling(False)
+        slot = 3 if pcnt[3] > 0 else 2                                        # fused kernel F, else the second pass of the two-pass iteration
+        return pms[slot] / pcnt[slot] if pcnt[slot] else float("inf")
+
     ncand = max(1, int(args.work_candidates))
-    cands, pads, trial_ms = [], [], []
+    nbas = max(1, int(args.basis_candidates))
+    cands, pads = [], []
     for k in range(ncand):
         cands.append((ctx.vector(n_loc), L.ProjCGWork(ctx, n_loc, m)))
         if k + 1 < ncand:
-            pads.append(ctx.vector(1_000_003 * (k + 1)))                 # shifts where the next set lands
-    if ncand > 1:
-        for xk, wk in cands:
-            L.projcg_(xk, None, A, U, b, None, tol=1e-300, maxit=2, work=wk, n_global=n, want_lambda=False)     # touch
-        for xk, wk in cands:
-            ctx.set_profiling(True)
-            L.projcg_(xk, None, A, U, b, None, tol=1e-300, maxit=12, work=wk, n_global=n, want_lambda=False)
-            pms, pcnt = ctx.profile_read()
-            ctx.set_profiling(False)
-            slot = 3 if pcnt[3] > 0 else 2                                   # fused kernel F, else the second pass of the two-pass iteration
-            trial_ms.append(pms[slot] / pcnt[slot] if pcnt[slot] else float("inf"))
+            pads.append(ctx.vector(1_000_003 * (k + 1)))                     # shifts where the next set lands
+    bases, basis_ms = [], []
+    for k in range(nbas):
+        bases.append(make_basis())
+        if k + 1 < nbas:
+            pads.append(ctx.vector(3_000_017 * (k + 1)))
+    if nbas > 1:
+        basis_ms = [trial(L.DeviceBasis(Zk), *cands[0]) for Zk, _ in bases]
+    bchosen = int(min(range(nbas), key=lambda k: basis_ms[k])) if basis_ms else 0
+    Z, basis_desc = bases[bchosen]
+    for k, (Zk, _) in enumerate(bases):
+        if k != bchosen:
+            Zk.free()
+    bases = None
+    U = L.DeviceBasis(Z)
+    trial_ms = [trial(U, xk, wk) for xk, wk in cands] if ncand > 1 else []
     chosen = int(min(range(ncand), key=lambda k: trial_ms[k])) if trial_ms else 0
     x, work = cands[chosen]
     del pads
@@ -279,6 +298,9 @@ def main(argv=None, lib=None):
                    "work_placement": ({"candidates": ncand, "trial_F_ms": [round(t, 4) for t in trial_ms], "chosen": chosen,
                                        "note": "candidate allocations of the solver's work vectors, fused kernel timed on each before the warm-up, fastest kept"}
                                       if ncand > 1 else {"candidates": 1}),
+                   "basis_placement": ({"candidates": nbas, "trial_F_ms": [round(t, 4) for t in basis_ms], "chosen": bchosen,
+                                        "note": "candidate allocations of the basis matrix (same contents), timed with the first work set; fastest kept"}
+                                       if nbas > 1 else {"candidates": 1}),
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
                    "comm": comm_used, "device": ctx.device_name},
