@@ -30,4 +30,15 @@ for rnd in range(2):
             L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=16, work=w, n_global=n, want_lambda=False)
             ms, cnt = ctx.profile_read(); ctx.set_profiling(False)
             row.append(ms[3] / max(cnt[3], 1))
-        print(f"round {rnd} Z{iz}: F ms over the work sets: " + "  ".join(f"{v:.3f}" for v in row), flush=True)
+        # does the plain GEMV-N (a store stream inside the matrix stream as well) rank the allocations of the matrix like F does?
+        tt, yy = ctx.vector(m).hash_fill(6), sets[0][1].rp
+        L.gemv_n(Z, tt, yy, 1.0, 1.0)
+        ctx.timer_begin()
+        for _ in range(4):
+            L.gemv_n(Z, tt, yy, 1.0, 1.0)
+        gn = ctx.timer_end() / 4
+        ctx.timer_begin()
+        for _ in range(4):
+            L.gemv_t(Z, yy, tt)
+        gt = ctx.timer_end() / 4
+        print(f"round {rnd} Z{iz}: F ms over the work sets: " + "  ".join(f"{v:.3f}" for v in row) + f"   gemv_n {gn:.3f}  gemv_t {gt:.3f}", flush=True)
