@@ -38,7 +38,7 @@ def test_bench_two_ranks_as_the_driver_launches_it(emu_lib):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    common = ["--steps", "4", "--warmup", "1", "--rows", "9000", "--cols", "8", "--no-cpu-baseline", "--prewarm-seconds", "0.2", "--work-candidates", "2", "--basis-candidates", "2", "--lib", EMU_LIB]
+    common = ["--steps", "4", "--warmup", "1", "--rows", "9000", "--cols", "8", "--no-cpu-baseline", "--prewarm-seconds", "0.2", "--work-candidates", "1", "--basis-candidates", "2", "--lib", EMU_LIB]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "host-gloo", "--device", "0", *common]
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)

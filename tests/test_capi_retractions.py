@@ -501,7 +501,7 @@ def test_newton_retraction_one_stream_step(dev_ctx, monkeypatch, m_lin, has_ball
     emu = _is_emu(ctx0)
     n = 2500 if emu else 300_000
     if emu and m_lin > 64:
-        n = 2100 if m_lin < 256 else 1200
+        n = 2100 if m_lin < 256 else 800
     m = m_lin + (1 if has_ball else 0)
     N = n + (1 if has_ball else 0)
     rng = np.random.default_rng(5 + m)
