@@ -171,17 +171,17 @@ def main(argv=None, lib=None):
         bases.append(make_basis())
         if k + 1 < nbas:
             pads.append(ctx.vector(3_000_017 * (k + 1)))
-    if nbas > 1:
-        basis_ms = [trial(L.DeviceBasis(Zk), *cands[0]) for Zk, _ in bases]
-    bchosen = int(min(range(nbas), key=lambda k: basis_ms[k])) if basis_ms else 0
+    # the full grid (basis allocation x work set): which allocation of the one is fast can depend on the other
+    grid = [[trial(L.DeviceBasis(Zk), xk, wk) for xk, wk in cands] for Zk, _ in bases] if nbas * ncand > 1 else [[0.0]]
+    bchosen, chosen = min(((i, j) for i in range(nbas) for j in range(ncand)), key=lambda ij: grid[ij[0]][ij[1]])
+    basis_ms = [min(row) for row in grid] if nbas > 1 else []
+    trial_ms = list(grid[bchosen]) if ncand > 1 else []
     Z, basis_desc = bases[bchosen]
     for k, (Zk, _) in enumerate(bases):
         if k != bchosen:
             Zk.free()
     bases = None
     U = L.DeviceBasis(Z)
-    trial_ms = [trial(U, xk, wk) for xk, wk in cands] if ncand > 1 else []
-    chosen = int(min(range(ncand), key=lambda k: trial_ms[k])) if trial_ms else 0
     x, work = cands[chosen]
     del pads
     cands = [cands[chosen]]
@@ -299,7 +299,9 @@ def main(argv=None, lib=None):
                                        "note": "candidate allocations of the solver's work vectors, fused kernel timed on each before the warm-up, fastest kept"}
                                       if ncand > 1 else {"candidates": 1}),
                    "basis_placement": ({"candidates": nbas, "trial_F_ms": [round(t, 4) for t in basis_ms], "chosen": bchosen,
-                                        "note": "candidate allocations of the basis matrix (same contents), timed with the first work set; fastest kept"}
+                                        "trial_grid_F_ms": [[round(t, 4) for t in row] for row in grid],
+                                        "note": "candidate allocations of the basis matrix (same contents) x the work-vector candidates: the fused kernel timed on every pair, "
+                                                "the fastest pair kept (trial_F_ms = the best of each basis allocation)"}
                                        if nbas > 1 else {"candidates": 1}),
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
