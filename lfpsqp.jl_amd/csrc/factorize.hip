@@ -1,10 +1,11 @@
 // Tangent setup on the device: weighted Gram matrix, right-multiplication by a small matrix, and
 // the thin factorisation built from them (replaces the reference's per-outer-iteration LAPACK dgesvd,
 // src/la_helper.jl:8-34).  These are the only genuinely contraction-shaped (compute-bound) operations
-// of the hot path (AI = m/4 flop/B), so they run on the matrix cores: both kernels are the same
-// 128 x 128 output tile  C[i][j] += sum_k A[k][i] * B[k][j]  with a 16-deep K step staged through LDS
-// and v_mfma_f64_16x16x4_f64 (lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D row = (l>>4)+4*reg,
-// col = l&15).  Each of the 4 waves owns two 16-row i-tiles x all eight j-tiles = 16 accumulators.
+// of the hot path (AI = m/4 flop/B), so they run on the matrix cores: v_mfma_f64_16x16x4_f64 (lane l holds
+// A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D row = (l>>4)+4*reg, col = l&15) on 128 x 128 output tiles.
+// gram_kernel and rmul_kernel stage 16-deep K steps through double-buffered LDS with the operand reads one k-group
+// ahead of the MFMAs and one barrier per step; rmul_resident_kernel keeps the small factor in LDS for the workgroup's
+// lifetime and streams the matrix straight into the B operand.  What bounds each: DESIGN.md 5.3.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
                                                          int64_t part_ld) {
     constexpr bool needB = !DIAG || WEIGHTED;           // diagonal unweighted panel: B is A itself
     // two LDS buffers per operand: step s+1 is written while step s is multiplied -- ONE barrier per step, and no phase in which
-    // the matrix cores wait for the staging (two workgroups that share a SIMD otherwise fall into step and stage at the same time)
+    // the matrix cores wait for the staging
     __shared__ double As[2][kPanel][kTLd];
     __shared__ double Bs[needB ? 2 : 1][needB ? kPanel : 1][kTLd];
     // (row group g, pair pr) of this workgroup: ngroups is a multiple of 8; XCD x holds the row groups g = x (mod 8)

@@ -14,7 +14,8 @@
 // identity, [X; I], the lower half accumulates the right singular vectors for free.
 //   Convergence: every rotated pair reports |p.q| / (|p||q|); the largest value of a sweep lands in off[sweep] (an
 // atomic max on the bit pattern of a non-negative double: order-independent, so bit-reproducible and identical on every
-// rank).  A launch whose predecessors include a converged sweep is a no-op; the host looks at off[] one sweep behind.
+// rank).  A launch whose predecessors include a converged sweep is a no-op; the host looks at off[] one sweep behind, and stops
+// two sweeps after the level enters the quadratic regime (kJacQuadTol) rather than after a sweep that measures rounding level.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>

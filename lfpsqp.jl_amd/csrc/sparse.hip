@@ -10,9 +10,13 @@
 //                                              of 8192 nonzeros: one workgroup per chunk, fixed-order sums -> a second kernel adds
 //                                              the chunks of each column in order.  No atomics: bit-reproducible.
 //
-// Users: lfpsqp_constraints_eval (c! of linear equalities), lfpsqp_pcg (the inner solve of the default ProjPenalty
-// retraction: per iteration two sparse products instead of a dense pass), lfpsqp_spmat_to_dense (the tangent setup keeps
-// using the dense MFMA path: its basis Z is dense anyway).
+//   SpMM    Z = [Jct | dense extra columns] * W  the basis-forming product of the tangent setup (lfpsqp_factorize_sp): bound by writing the
+//                                              dense basis, a third of the MFMA product's time
+//
+// Users: lfpsqp_constraints_eval (c! of linear equalities), lfpsqp_pcg (the inner solve of the default ProjPenalty retraction: per
+// iteration two sparse products instead of a dense pass), lfpsqp_factorize_sp, and -- through the basis in factored form U = Jct W
+// (sp_basis_small, sp_factored_gemv_t/_n below; projcg.hip, retract.hip, ineq.hip) -- the projected CG, the Newton step and the
+// tangent projection, none of which then reads a dense n x m matrix.
 #include <algorithm>
 #include <numeric>
 #include <vector>
