@@ -148,43 +148,17 @@ def main(argv=None, lib=None):
     b = ctx.vector(n_loc).hash_fill(4, r0)
     # Placement candidates.  Where the basis and the work vectors land in memory decides between 1.63 and 1.93 ms for the fused kernel
     # (three allocations of the basis in one process measured 1.92 / 1.92 / 1.68 ms with every work set; another day six work
-    # sets under one basis 1.93 x 4 / 1.63 x 2).  So: a few allocations of each, the fused kernel timed briefly on them (untimed, before
-    # the warm-up), the fastest kept.  Every rank makes the same number of (collective-carrying) trial calls; the choice is local.
-    def trial(Uk, xk, wk):
-        L.projcg_(xk, None, A, Uk, b, None, tol=1e-300, maxit=2, work=wk, n_global=n, want_lambda=False)     # touch
-        ctx.set_profiling(True)
-        L.projcg_(xk, None, A, Uk, b, None, tol=1e-300, maxit=12, work=wk, n_global=n, want_lambda=False)
-        pms, pcnt = ctx.profile_read()
-        ctx.set_profiling(False)
-        slot = 3 if pcnt[3] > 0 else 2                                        # fused kernel F, else the second pass of the two-pass iteration
-        return pms[slot] / pcnt[slot] if pcnt[slot] else float("inf")
-
+    # sets under one basis 1.93 x 4 / 1.63 x 2; and which allocation of the one is fast can depend on the other).  So: a few allocations of
+    # each, the fused kernel timed briefly on every pair (untimed, before the warm-up), the fastest pair kept (lfpsqp_jl_amd.placement).
+    # Every rank makes the same number of (collective-carrying) trial calls; the choice is local.
+    from lfpsqp_jl_amd.placement import best_projcg_buffers
     ncand = max(1, int(args.work_candidates))
     nbas = max(1, int(args.basis_candidates))
-    cands, pads = [], []
-    for k in range(ncand):
-        cands.append((ctx.vector(n_loc), L.ProjCGWork(ctx, n_loc, m)))
-        if k + 1 < ncand:
-            pads.append(ctx.vector(1_000_003 * (k + 1)))                     # shifts where the next set lands
-    bases, basis_ms = [], []
-    for k in range(nbas):
-        bases.append(make_basis())
-        if k + 1 < nbas:
-            pads.append(ctx.vector(3_000_017 * (k + 1)))
-    # the full grid (basis allocation x work set): which allocation of the one is fast can depend on the other
-    grid = [[trial(L.DeviceBasis(Zk), xk, wk) for xk, wk in cands] for Zk, _ in bases] if nbas * ncand > 1 else [[0.0]]
-    bchosen, chosen = min(((i, j) for i in range(nbas) for j in range(ncand)), key=lambda ij: grid[ij[0]][ij[1]])
+    Z, basis_desc, x, work, pinfo = best_projcg_buffers(ctx, make_basis, n_loc, m, A, b, n_global=n, nbasis=nbas, nwork=ncand)
+    grid, bchosen, chosen = pinfo["grid"], pinfo["basis"], pinfo["work"]
     basis_ms = [min(row) for row in grid] if nbas > 1 else []
     trial_ms = list(grid[bchosen]) if ncand > 1 else []
-    Z, basis_desc = bases[bchosen]
-    for k, (Zk, _) in enumerate(bases):
-        if k != bchosen:
-            Zk.free()
-    bases = None
     U = L.DeviceBasis(Z)
-    x, work = cands[chosen]
-    del pads
-    cands = [cands[chosen]]
 
     def barrier():
         ctx.sync()

@@ -1,0 +1,48 @@
+"""Placement trials for the buffers of the projected-CG loop.
+
+On MI355X the kernels that run a store stream inside a matrix read stream (the fused projected-CG iteration, GEMV-N, the Newton step)
+are 10-15 % faster or slower depending on where the matrix and the n-vectors were allocated -- a property of the PAIR of allocations,
+reproducible inside a process, different from one hour to the next.  ``best_projcg_buffers`` allocates a few candidates
+of each, times the fused kernel on every pair for a dozen iterations and keeps the fastest pair.  Results do not depend on the choice."""
+from __future__ import annotations
+
+from .device import Context
+from .projcg import DeviceBasis, ProjCGWork, projcg_
+
+
+def best_projcg_buffers(ctx: Context, make_basis, n_loc: int, m: int, A, b, *, n_global: int | None = None, nbasis: int = 3, nwork: int = 4,
+                        iters: int = 12):
+    """``make_basis()`` -> (DeviceMatrix, description): called ``nbasis`` times (same contents, new allocation each time).
+    Returns (Z, description, x, work, info) with info = {"grid": F ms per (basis, work set), "basis": i, "work": j}.
+    Every rank makes the same (collective-carrying) calls; the choice itself is local."""
+    n_global = n_loc if n_global is None else n_global
+    nbasis, nwork = max(1, int(nbasis)), max(1, int(nwork))
+
+    def trial(Uk, xk, wk):
+        projcg_(xk, None, A, Uk, b, None, tol=1e-300, maxit=2, work=wk, n_global=n_global, want_lambda=False)      # touch
+        ctx.set_profiling(True)
+        projcg_(xk, None, A, Uk, b, None, tol=1e-300, maxit=iters, work=wk, n_global=n_global, want_lambda=False)
+        pms, pcnt = ctx.profile_read()
+        ctx.set_profiling(False)
+        slot = 3 if pcnt[3] > 0 else 2                  # fused kernel F, else the second pass of the two-pass iteration
+        return pms[slot] / pcnt[slot] if pcnt[slot] else float("inf")
+
+    cands, pads = [], []
+    for k in range(nwork):
+        cands.append((ctx.vector(n_loc), ProjCGWork(ctx, n_loc, m)))
+        if k + 1 < nwork:
+            pads.append(ctx.vector(1_000_003 * (k + 1)))                   # shifts where the next set lands
+    bases = []
+    for k in range(nbasis):
+        bases.append(make_basis())
+        if k + 1 < nbasis:
+            pads.append(ctx.vector(3_000_017 * (k + 1)))
+    grid = [[trial(DeviceBasis(Zk), xk, wk) for xk, wk in cands] for Zk, _ in bases] if nbasis * nwork > 1 else [[0.0]]
+    bi, wi = min(((i, j) for i in range(nbasis) for j in range(nwork)), key=lambda ij: grid[ij[0]][ij[1]])
+    Z, desc = bases[bi]
+    for k, (Zk, _) in enumerate(bases):
+        if k != bi:
+            Zk.free()
+    x, work = cands[wi]
+    del pads
+    return Z, desc, x, work, {"grid": grid, "basis": bi, "work": wi}
