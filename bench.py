@@ -154,7 +154,8 @@ def main(argv=None, lib=None):
     from lfpsqp_jl_amd.placement import best_projcg_buffers
     ncand = max(1, int(args.work_candidates))
     nbas = max(1, int(args.basis_candidates))
-    Z, basis_desc, x, work, pinfo = best_projcg_buffers(ctx, make_basis, n_loc, m, A, b, n_global=n, nbasis=nbas, nwork=ncand)
+    Z, basis_desc, x, work, pinfo = best_projcg_buffers(ctx, make_basis, n_loc, m, A, b, n_global=n, nbasis=nbas, nwork=ncand,
+                                                        try_alternating=(world == 1))
     grid, bchosen, chosen = pinfo["grid"], pinfo["basis"], pinfo["work"]
     basis_ms = [min(row) for row in grid] if nbas > 1 else []
     trial_ms = list(grid[bchosen]) if ncand > 1 else []
@@ -274,6 +275,8 @@ def main(argv=None, lib=None):
                                       if ncand > 1 else {"candidates": 1}),
                    "basis_placement": ({"candidates": nbas, "trial_F_ms": [round(t, 4) for t in basis_ms], "chosen": bchosen,
                                         "trial_grid_F_ms": [[round(t, 4) for t in row] for row in grid],
+                                        "residual_buffers": ("alternating" if pinfo.get("residual_buffers") else "in place"),
+                                        "call_ms_per_iteration": pinfo.get("call_ms_per_iteration"),
                                         "note": "candidate allocations of the basis matrix (same contents) x the work-vector candidates: the fused kernel timed on every pair, "
                                                 "the fastest pair kept (trial_F_ms = the best of each basis allocation)"}
                                        if nbas > 1 else {"candidates": 1}),

@@ -60,6 +60,10 @@ int lfpsqp_ctx_set_tuning(lfpsqp_ctx* ctx, int ks, int nt);
 /* One-pass kernels (lfpsqp_projcg, lfpsqp_pcg, lfpsqp_retract_nr): 0 = on (default), -1 = off (their two-pass forms, which
  * are also the fallback for fewer than 4 or more than 1024 columns). */
 int lfpsqp_ctx_set_onepass(lfpsqp_ctx* ctx, int mode);
+/* Residual buffers of the fused projected-CG iteration: 0 = updated in place (default), 1 = two buffers alternating between iterations
+ * (the kernel then never stores to lines it has just loaded).  Same iterates bit for bit; which is faster depends on where the buffers
+ * landed in memory: in-place wins by 2-4 % on well-placed buffers, the alternating scheme by ~12 % on badly placed ones. */
+int lfpsqp_ctx_set_residual_buffers(lfpsqp_ctx* ctx, int mode);
 /* The same switch is read once by lfpsqp_ctx_create from the environment (LFPSQP_ONEPASS=-1); the tests use it to
  * cross-check the two forms. */
 /* HIP-event timing on the context's stream: begin .. end -> milliseconds */

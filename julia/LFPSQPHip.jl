@@ -101,6 +101,7 @@ c_last_error(ctx) = ccall((:lfpsqp_last_error, lib), Cstring, (Ptr{Cvoid},), ctx
 c_device_name(ctx, buf, len) = ccall((:lfpsqp_device_name, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64), ctx, buf, len)
 c_ctx_set_tuning(ctx, ks, nt) = ccall((:lfpsqp_ctx_set_tuning, lib), Cint, (Ptr{Cvoid}, Cint, Cint), ctx, ks, nt)
 c_ctx_set_onepass(ctx, mode) = ccall((:lfpsqp_ctx_set_onepass, lib), Cint, (Ptr{Cvoid}, Cint), ctx, mode)
+c_ctx_set_residual_buffers(ctx, mode) = ccall((:lfpsqp_ctx_set_residual_buffers, lib), Cint, (Ptr{Cvoid}, Cint), ctx, mode)
 c_ctx_stream(ctx, out) = ccall((:lfpsqp_ctx_stream, lib), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx, out)
 c_timer_begin(ctx) = ccall((:lfpsqp_timer_begin, lib), Cint, (Ptr{Cvoid},), ctx)
 c_timer_end(ctx, ms) = ccall((:lfpsqp_timer_end, lib), Cint, (Ptr{Cvoid}, Ref{Float64}), ctx, ms)

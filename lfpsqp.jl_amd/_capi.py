@@ -54,6 +54,7 @@ _SIGS = {
     "lfpsqp_ctx_sync": [P],
     "lfpsqp_ctx_set_tuning": [P, C.c_int, C.c_int],
     "lfpsqp_ctx_set_onepass": [P, C.c_int],
+    "lfpsqp_ctx_set_residual_buffers": [P, C.c_int],
     "lfpsqp_device_name": [P, C.c_char_p, c_i64],
     "lfpsqp_timer_begin": [P],
     "lfpsqp_timer_end": [P, PD],

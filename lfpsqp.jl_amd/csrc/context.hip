@@ -155,6 +155,7 @@ int lfpsqp_ctx_create(int device, lfpsqp_ctx** out) {
     if (ok) ok = hipMemset(ctx->scal, 0, 64 * sizeof(double)) == hipSuccess && hipMemset(ctx->istat, 0, 64 * sizeof(int64_t)) == hipSuccess;
     if (!ok) { delete ctx; return set_err(nullptr, LFPSQP_ERR_HIP, "context resource allocation failed"); }
     if (const char* e = getenv("LFPSQP_ONEPASS")) ctx->tune_onepass = atoi(e);
+    if (const char* e = getenv("LFPSQP_GPING")) ctx->tune_gping = atoi(e) == 1 ? 1 : 0;
     *out = ctx;
     return 0;
 }
@@ -225,6 +226,14 @@ int lfpsqp_ctx_set_onepass(lfpsqp_ctx* ctx, int mode) {
     LF_ARG(ctx, ctx != nullptr && (mode == 0 || mode == -1));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tune_onepass = mode;
+    return 0;
+}
+
+int lfpsqp_ctx_set_residual_buffers(lfpsqp_ctx* ctx, int mode) {
+    LF_ARG(ctx, ctx != nullptr && (mode == 0 || mode == 1));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tune_gping = mode;
+    ctx->pcg_resume.valid = false;          // a resumable solve is tied to the scheme it ran with
     return 0;
 }
 

@@ -761,9 +761,9 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     // state of DESIGN.md §6, removing EITHER that load or that store of the same line made the kernel 13 % faster (1.95 -> 1.70 ms),
     // which suggested alternating two buffers between iterations (work->g and work->rp, free after the initial projection) so
     // that the kernel never stores to lines it has just loaded.  Measured on a fast-state box that costs 4-5 % (1.76 against
-    // 1.70 ms: the store no longer hits a line the L2 already holds), so it is OFF by default; LFPSQP_GPING=1 turns it on
-    // (same bits either way).  gcur = the buffer holding the current g.
-    static const bool kPing = getenv("LFPSQP_GPING") && atoi(getenv("LFPSQP_GPING")) == 1;
+    // 1.70 ms: the store no longer hits a line the L2 already holds), so it is OFF by default; lfpsqp_ctx_set_residual_buffers(ctx, 1)
+    // (or LFPSQP_GPING=1) turns it on (same bits either way).  gcur = the buffer holding the current g.
+    const bool kPing = ctx->tune_gping == 1;
     double* gbuf[2] = {g, (fused && kPing) ? rp : g};
     int gcur = 0;
     auto launch_fused = [&](int init) -> int {

@@ -53,6 +53,10 @@ class Context:
     def set_onepass(self, mode: int = 0):
         self.check(self.L.lfpsqp_ctx_set_onepass(self.h, int(mode)))
 
+    def set_residual_buffers(self, mode: int = 0):
+        """0 = the fused projected-CG iteration updates its residual in place (default), 1 = two buffers alternating."""
+        self.check(self.L.lfpsqp_ctx_set_residual_buffers(self.h, int(mode)))
+
     def set_tuning(self, ks: int = 0, nt: bool = True):
         self.check(self.L.lfpsqp_ctx_set_tuning(self.h, int(ks), 1 if nt else 0))
 

@@ -11,9 +11,11 @@ from .projcg import DeviceBasis, ProjCGWork, projcg_
 
 
 def best_projcg_buffers(ctx: Context, make_basis, n_loc: int, m: int, A, b, *, n_global: int | None = None, nbasis: int = 3, nwork: int = 4,
-                        iters: int = 12):
+                        iters: int = 12, try_alternating: bool = False):
     """``make_basis()`` -> (DeviceMatrix, description): called ``nbasis`` times (same contents, new allocation each time).
-    Returns (Z, description, x, work, info) with info = {"grid": F ms per (basis, work set), "basis": i, "work": j}.
+    Returns (Z, description, x, work, info) with info = {"grid": F ms per (basis, work set), "basis": i, "work": j, "residual_buffers": 0 | 1}.
+    ``try_alternating``: also time the alternating residual buffers on the chosen pair and leave the context in the faster scheme
+    (single-rank use: the decision is taken from local wall times).
     Every rank makes the same (collective-carrying) calls; the choice itself is local."""
     n_global = n_loc if n_global is None else n_global
     nbasis, nwork = max(1, int(nbasis)), max(1, int(nwork))
@@ -45,4 +47,25 @@ def best_projcg_buffers(ctx: Context, make_basis, n_loc: int, m: int, A, b, *, n
             Zk.free()
     x, work = cands[wi]
     del pads
-    return Z, desc, x, work, {"grid": grid, "basis": bi, "work": wi}
+    info = {"grid": grid, "basis": bi, "work": wi, "residual_buffers": 0}
+    if try_alternating and nbasis * nwork > 1:
+        # the alternating residual buffers (lfpsqp_ctx_set_residual_buffers) on the chosen pair: ~12 % faster when even the best pair is a
+        # slow one, 2-4 % slower otherwise.  Compared by the wall time of whole calls (the sampled kernel time would alias with the
+        # period-2 alternation).
+        import time
+        U = DeviceBasis(Z)
+
+        def wall(mode):
+            ctx.set_residual_buffers(mode)
+            projcg_(x, None, A, U, b, None, tol=1e-300, maxit=2, work=work, n_global=n_global, want_lambda=False)
+            best = float("inf")
+            for _ in range(2):
+                ctx.sync(); t0 = time.perf_counter()
+                projcg_(x, None, A, U, b, None, tol=1e-300, maxit=iters + 4, work=work, n_global=n_global, want_lambda=False)
+                ctx.sync(); best = min(best, time.perf_counter() - t0)
+            return best * 1e3 / (iters + 4)
+        w0, w1 = wall(0), wall(1)
+        info["call_ms_per_iteration"] = {"in_place": w0, "alternating": w1}
+        info["residual_buffers"] = 1 if w1 < 0.98 * w0 else 0
+        ctx.set_residual_buffers(info["residual_buffers"])
+    return Z, desc, x, work, info

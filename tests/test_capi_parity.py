@@ -233,6 +233,40 @@ def test_projcg_resume_continues_the_same_solve(dev_ctx, n, m, stack):
         L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=1, work=work, want_lambda=False, resume=True)
 
 
+@pytest.mark.parametrize("n,m", [(2100, 16), (1300, 300)])
+def test_projcg_residual_buffer_schemes_agree(dev_ctx, n, m):
+    """lfpsqp_ctx_set_residual_buffers: the alternating scheme moves where the residual lives between iterations, never
+    the arithmetic -- iterates, counts and residual norms are bit for bit those of the in-place scheme, with and without
+    a resumed second call; switching the scheme drops the state a resume would continue from."""
+    ctx = dev_ctx
+    Uh, a, bh = _cg_problem(n, m)
+    U = L.DeviceBasis(ctx.matrix(n, m, Uh))
+    A = L.DiagOperator(0.0, ctx.vector(n, a))
+    b = ctx.vector(n, bh)
+    work = L.ProjCGWork(ctx, n, m)
+    out = {}
+    try:
+        for mode in (0, 1):
+            ctx.set_residual_buffers(mode)
+            x, lam = ctx.vector(n), ctx.vector(m)
+            res = [L.projcg_(x, lam, A, U, b, None, tol=1e-300, maxit=7, work=work)]
+            res.append(L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=3, work=work, want_lambda=False))
+            res.append(L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=4, work=work, want_lambda=False, resume=True))
+            res.append(L.projcg_(x, lam, A, U, b, None, tol=1e-9, maxit=500, work=work))
+            out[mode] = (res, x.download(), lam.download())
+        assert out[0][0] == out[1][0]
+        assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+        x = ctx.vector(n)
+        L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=2, work=work, want_lambda=False)
+        ctx.set_residual_buffers(0)
+        with pytest.raises(L.LfpsqpError):
+            L.projcg_(x, None, A, U, b, None, tol=1e-300, maxit=1, work=work, want_lambda=False, resume=True)
+        with pytest.raises(L.LfpsqpError):
+            ctx.set_residual_buffers(2)
+    finally:
+        ctx.set_residual_buffers(0)
+
+
 def test_projcg_generic_operator_path(dev_ctx):
     """Duck-typed A (the LinearMap case, src/optimize.jl:228-230) goes through the unfused loop."""
     ctx = dev_ctx
