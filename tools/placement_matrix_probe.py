@@ -5,7 +5,7 @@ import math
 import lfpsqp_jl_amd as L
 KZ = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 KW = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-ctx = L.Context(0)
+ctx = L.Context(0, L.load_library(os.environ['LFPSQP_LIB']) if 'LFPSQP_LIB' in os.environ else None)      # (a variant build)
 n, m = 10_000_000, 128
 scale = 2.0 ** math.floor(math.log2(math.sqrt(3.0 / n)))
 Zs, pads = [], []
