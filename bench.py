@@ -436,7 +436,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         sparse = {"nnz": Ssp.nnz, "nnz_per_row": k_sp, "spmv_t_ms": ms_st, "spmv_t_GBs": gbs(by_t, ms_st), "spmv_n_ms": ms_sn,
                   "spmv_n_GBs": gbs(by_n, ms_sn), "dense_matrix_GB": 8.0 * n_loc * m / 1e9, "algorithmic_GB": by_t / 1e9}
         Ssp.free()
-        # tangent setup of a sparse block (lfpsqp_factorize_sp: Gram on the dense twin, basis-forming products from the nonzeros)
+        # tangent setup of a sparse block (lfpsqp_factorize_sp: Gram matrix and basis-forming products from the nonzeros)
         # against the dense factorisation of the same matrix; random values so that the block has full rank
         vals_r = (np.random.default_rng(5).standard_normal((n_loc, k_sp)) + 2.0 * (np.arange(k_sp) == 0)).ravel()
         Sr = L.SparseMatrix(ctx, n_loc, m, rows_sp, cols_sp.ravel(), vals_r)
@@ -448,8 +448,19 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             for _ in range(3):
                 Sg, _, rk = L.ksvd_(Jd, Zs, **kw)
             ctx.sync(); tf[tag] = (time.perf_counter() - t0) * 1e3 / 3
+        Sr.gram()
+        ctx.sync(); t0 = time.perf_counter()
+        for _ in range(3):
+            Gs = Sr.gram()
+        ctx.sync(); tg_sp = (time.perf_counter() - t0) * 1e3 / 3
+        L.gram(Jd)
+        ctx.sync(); t0 = time.perf_counter()
+        for _ in range(3):
+            Gd = L.gram(Jd)
+        ctx.sync(); tg_d = (time.perf_counter() - t0) * 1e3 / 3
         sparse.update({"factorize_dense_ms": tf["dense"], "factorize_from_nonzeros_ms": tf["from_nonzeros"], "factorize_rank": int(rk),
-                       "factorize_cond": float(Sg[0] / Sg[-1])})
+                       "factorize_cond": float(Sg[0] / Sg[-1]), "gram_dense_ms": tg_d, "gram_from_nonzeros_ms": tg_sp,
+                       "gram_max_rel_diff": float(np.abs(Gs - Gd).max() / np.abs(Gd).max())})
         # Newton retraction on the same block (24 iterations forced by tol = 0): one dense pass per step vs the nonzeros alone
         Wg2 = np.zeros((m, m), order='F')
         Sg, Vtg, _ = L.ksvd_(Jd, Zs, W=Wg2, Jsp=Sr)

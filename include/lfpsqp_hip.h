@@ -159,6 +159,11 @@ int lfpsqp_spmv_n(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, double alpha, const lf
 /* M[:, 0:m) = S as a dense matrix (the tangent setup -- lfpsqp_factorize, whose basis Z is dense anyway -- and the Newton
  * retraction keep using the dense kernels) */
 int lfpsqp_spmat_to_dense(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, lfpsqp_mat* M);
+/* G (host, M x M column-major) = A' diag(w2) A for A = [S | Jct[:, S.m : Jct.m)] (Jct NULL: A = S, M = S.m; w2 NULL: no weights), summed
+ * over the ranks: the Gram matrix of the tangent setup from the NONZEROS.  The scattered accumulation is exact (every term cut into two
+ * fixed-point limbs, 64-bit integer sums), so the result does not depend on the order in which rows are visited -- bit-reproducible, and
+ * identical for any permutation of the rows.  LFPSQP_ERR_UNSUPPORTED for rows wider than 32 nonzeros or non-finite / extreme values. */
+int lfpsqp_spmat_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, double* G);
 
 /* ---- bound manifolds (src/inequality_helper.jl, src/retractions.jl:451-500) ------- */
 /* With bounds the reference doubles the variables: xaug = [x; y] (length 2N), each bounded
@@ -231,8 +236,8 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
 /* The same factorisation when the constraint gradients are sparse: A = [S | Jct[:, S.m : Jct.m)], i.e. the sparse object holds the
  * leading columns and the dense twin Jct (n x M, M - S.m <= 4: the ball / slack columns; NULL when there are none) the rest.  The
  * basis-forming products Z = A * W stream the NONZEROS and write the dense basis (bound by that write: a third of the dense MFMA
- * product at m = 128, K = 4); the Gram matrix comes from the dense twin when there is one, else S is expanded into Z first.  Results as
- * lfpsqp_factorize(ctx, <dense A>, ...): identical Sigma / Vt / rank (same Gram matrix), Z equal up to the rounding of the product. */
+ * product at m = 128, K = 4); the Gram matrix comes from the nonzeros as well (lfpsqp_spmat_gram; for rows wider than 8 nonzeros, or
+ * where that is refused, from the dense twin, or from S expanded into Z).  Results as lfpsqp_factorize(ctx, <dense A>, ...) up to the rounding of the Gram matrix and of the product. */
 int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma,
                         double* Vt, double* W, int64_t* rank_out, double eps_rank);
 /* The replicated small step of lfpsqp_factorize on its own: thin SVD A = U diag(S) V' of a small host matrix (rows x cols,

@@ -152,6 +152,7 @@ c_spmat_info(S, n, m, nnz, k) = ccall((:lfpsqp_spmat_info, lib), Cint, (Ptr{Cvoi
 c_spmv_t(ctx, S, v, t) = ccall((:lfpsqp_spmv_t, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, S, v, t)
 c_spmv_n(ctx, S, a, t, b, y) = ccall((:lfpsqp_spmv_n, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}), ctx, S, a, t, b, y)
 c_spmat_to_dense(ctx, S, M) = ccall((:lfpsqp_spmat_to_dense, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, S, M)
+c_spmat_gram(ctx, S, Jct, w2, G) = ccall((:lfpsqp_spmat_gram, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}), ctx, S, Jct, w2, G)
 # ---- bound manifolds -------------------------------------------------------------------------------------------------------
 c_half_stride(N) = ccall((:lfpsqp_half_stride, lib), Int64, (Int64,), N)
 c_ineq_data_build(ctx, xl, xu, q, r, s, t) = ccall((:lfpsqp_ineq_data_build, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, xl, xu, q, r, s, t)
@@ -313,6 +314,13 @@ spmv_t!(t::DeviceVector, S::SparseMatrix, v::DeviceVector) = (check(t.ctx, c_spm
 spmv_n!(y::DeviceVector, S::SparseMatrix, t::DeviceVector, a::Real=1.0, b::Real=0.0) =
     (check(y.ctx, c_spmv_n(y.ctx.h, S.h, Float64(a), t.h, Float64(b), y.h)); y)                                                 # y = a S t + b y
 to_dense!(M::DeviceMatrix, S::SparseMatrix) = (check(M.ctx, c_spmat_to_dense(M.ctx.h, S.h, M.h)); M)
+# [S | Jct[:, m+1:end]]' * Diagonal(w2) * [S | ...] from the nonzeros, exactly accumulated (order-independent)
+function gram(S::SparseMatrix; Jct::Union{DeviceMatrix,Nothing}=nothing, w2::Union{DeviceVector,Nothing}=nothing)
+    M = Jct === nothing ? S.m : Jct.m
+    G = zeros(Float64, M, M)
+    check(S.ctx, c_spmat_gram(S.ctx.h, S.h, Jct === nothing ? C_NULL : Jct.h, w2 === nothing ? C_NULL : w2.h, G))
+    return G
+end
 
 # BLAS-1 on device vectors (reductions are global: all-reduced over the ranks and replicated)
 function dot(x::DeviceVector, y::DeviceVector)

@@ -119,6 +119,7 @@ _SIGS = {
     "lfpsqp_gram": [P, P, c_i64, P, P],
     "lfpsqp_rmul": [P, P, c_i64, P, c_i64, P],
     "lfpsqp_factorize": [P, P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],
+    "lfpsqp_spmat_gram": [P, P, P, P, P],
     "lfpsqp_factorize_sp": [P, P, P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],
     "lfpsqp_small_svd": [P, c_i64, c_i64, P, P, P, P],
     "lfpsqp_projcg": [P, P, P, C.POINTER(DiagOp), C.POINTER(Basis), P, P, c_dbl, c_i64, c_i64, C.c_int,

@@ -855,10 +855,13 @@ int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat
                     (!Jct || (Jct->p != Z->p && Jct->n == S->n && Jct->m >= S->m && Jct->m - S->m <= 4)) && Z->m >= (Jct ? Jct->m : S->m));
     const int ms = (int)S->m, m = Jct ? (int)Jct->m : ms;
     const double* w2p = w2 ? w2->p : nullptr;
-    // Gram matrix: on the dense twin when there is one (it holds the extra columns too); else S is expanded into Z, which the first
-    // basis-forming product overwrites anyway.  (A Gram matrix from the nonzeros alone needs scattered accumulation -- LDS atomics, whose
-    // order is not reproducible -- and is not built: DESIGN.md 5.5.)
+    // Gram matrix from the nonzeros (sp_gram: exact fixed-point accumulation, so reproducible; the extra dense columns through SpMV-T and
+    // dot products; Z's first column is its scratch vector -- the basis-forming product overwrites Z afterwards).  Where that is refused
+    // (rows wider than 8 nonzeros, extreme values): on the dense twin, or on S expanded into Z.
     auto gramA = [&](std::vector<double>& G) -> int {
+        G.assign((size_t)m * m, 0.0);
+        const int rc = ctx->tune_spgram >= 0 ? sp_gram(ctx, S, Jct, ms, m - ms, w2, Z->p, G.data(), 8) : LFPSQP_ERR_UNSUPPORTED;
+        if (rc != LFPSQP_ERR_UNSUPPORTED) return rc;
         if (Jct) return gram_impl(ctx, Jct, m, w2p, G);
         LF_TRY(lfpsqp_spmat_to_dense(ctx, S, Z));
         return gram_impl(ctx, Z, m, w2p, G);

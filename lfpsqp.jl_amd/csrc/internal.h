@@ -76,6 +76,7 @@ struct lfpsqp_ctx {
     // one-stream N->T kernels (Newton-retraction step, fused projected-CG iteration): 0 = on, -1 = always the two-pass kernels.
     // Development override: environment variable LFPSQP_ONEPASS, read once at lfpsqp_ctx_create.
     int tune_onepass = 0;
+    int tune_spgram = 0;    // lfpsqp_factorize_sp: 0 = Gram matrix from the nonzeros (sp_gram), -1 = on a dense copy (env LFPSQP_SPGRAM=-1; A/B timing)
     int tune_gping = 0;     // fused projected-CG iteration: 0 = the residual updated in place, 1 = two buffers alternating (lfpsqp_ctx_set_residual_buffers)
 
     bool real_gpu = false;   // gcnArchName "gfx..." (false only in the CPU emulator build of the tests)

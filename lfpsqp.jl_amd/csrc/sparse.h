@@ -6,6 +6,7 @@
 struct lfpsqp_spmat {
     int64_t n = 0, m = 0, nnz = 0;
     int K = 0;              // ELL width
+    double amax = 0.0;      // largest |value| (NaN when an entry is not finite)
     int64_t ld = 0;         // rows rounded up to whole tiles
     double* ell_val = nullptr;    // [K][ld]
     int32_t* ell_col = nullptr;   // [K][ld]
@@ -52,6 +53,9 @@ int sp_basis_small(lfpsqp_ctx* ctx, const double* W_dev, int wm, int m, const do
 int sp_factored_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, const double* v, double* t_out);
 int sp_factored_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, double alpha, const double* t,
                        double beta, double* y);
+
+// G = [S | X]' diag(w2) [S | X] from the nonzeros, exactly accumulated (sparse.hip); LFPSQP_ERR_UNSUPPORTED: form it on a dense copy
+int sp_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0, int nx, const lfpsqp_vec* w2, double* scratch, double* G, int kmax);
 
 int spmm(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0, int nx, const double* W_dev, int ldw, int r, lfpsqp_mat* Out);
 

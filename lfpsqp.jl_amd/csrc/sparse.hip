@@ -10,6 +10,8 @@
 //                                              of 8192 nonzeros: one workgroup per chunk, fixed-order sums -> a second kernel adds
 //                                              the chunks of each column in order.  No atomics: bit-reproducible.
 //
+//   Gram    G = Jct' diag(w2) Jct              exact fixed-point accumulation of the K (K + 1) / 2 products of a row (sp_gram below): atomics whose
+//                                              order cannot matter -- bit-reproducible, 13 x faster than the MFMA Gram of a dense copy
 //   SpMM    Z = [Jct | dense extra columns] * W  the basis-forming product of the tangent setup (lfpsqp_factorize_sp): bound by writing the
 //                                              dense basis, a third of the MFMA product's time
 //
@@ -301,6 +303,226 @@ int spmv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const double* v, double* t_ou
 }
 
 
+
+// ---- Gram matrix from the nonzeros -----------------------------------------------------------------------------------------------------
+// G = S' diag(w2) S: row i adds w2_i v_a v_b to G[c_a, c_b] for every pair of its nonzeros -- a scattered accumulation.  Floating-point
+// atomics would make the result depend on the order of arrival.  Here the accumulation is EXACT, so the order cannot matter and the result is
+// bit-reproducible: with |term| < 2^E (E from max|v|^2 max w2) and at most n terms per entry (one per row: duplicates are merged at creation),
+// every term x is cut into two fixed-point limbs of b = min(62 - ceil(log2(n + 1)), 40) bits,
+//     q1 = rint(x 2^(b-E)),      q2 = rint((x - q1 2^(E-b)) 2^(2b-E))        (power-of-two scalings and an exact remainder),
+// which are summed as 64-bit integers -- LDS atomics inside a workgroup, plain integer sums over the workgroups -- without overflow or
+// rounding; what is dropped is below 2^(E-2b-1) per term (b = 38 at n = 1e7: 2^-77 of the largest term).  One rounding at the end.
+// A workgroup owns the rows of a slice and one 128 x 64 tile of G (two limbs = 128 KB of LDS); tiles below the diagonal are skipped, the
+// mirror image is written by the reduction.
+constexpr int kSgJ = 128, kSgK = 64, kSgTile = kSgJ * kSgK, kSgThreads = 1024, kSgRun = 4096, kSgLimbMax = 40;
+// KR > 0 (rows of at most KR nonzeros): a lane walks the rows tid, tid + T, ... of its workgroup's contiguous slice and keeps the limb sums of
+// the KR (KR + 1) / 2 pairs in REGISTERS while the column set of its rows stays the same (integer-valued doubles: exact up to 2^53, hence
+// limbs of at most 40 bits and runs of at most 4096 rows); the LDS atomics happen when the column set changes.  In a banded or
+// block-structured system thousands of consecutive rows share their columns, and the atomics -- 64 lanes on one address cost ~160 cycles
+// of the CU's one LDS per instruction: 0.8 ms of the first version's 0.96 at n = 1e7, K = 4 -- all but vanish.  Scattered column sets
+// degrade to one flush per row, the generic path (KR = 0: no registers, atomics per term).
+template <int KR, int T>
+__global__ __launch_bounds__(T) void sp_gram_kernel(const double* __restrict__ val, const int32_t* __restrict__ col, int64_t ld, int K, int64_t n,
+                                                   const double* __restrict__ w2, double s1, double r1, double s2, int nkb,
+                                                   int64_t rows_per_wg, unsigned long long* __restrict__ partial) {
+    __shared__ unsigned long long acc[2 * kSgTile];
+    const int j0 = ((int)blockIdx.y / nkb) * kSgJ, k0 = ((int)blockIdx.y % nkb) * kSgK;
+    if (k0 + kSgK - 1 < j0) return;                          // a tile wholly below the diagonal (uniform over the workgroup)
+    for (int idx = threadIdx.x; idx < 2 * kSgTile; idx += T) acc[idx] = 0ull;
+    __syncthreads();
+    const int64_t rbeg = (int64_t)blockIdx.x * rows_per_wg, rend = (rbeg + rows_per_wg < n) ? rbeg + rows_per_wg : n;
+    if constexpr (KR > 0) {
+        constexpr int NP = KR * (KR + 1) / 2;
+        double a1[NP], a2[NP];
+        int cur[KR];
+#pragma unroll
+        for (int a = 0; a < KR; ++a) cur[a] = -1;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a1[p] = a2[p] = 0.0;
+        int run = 0;
+        auto flush = [&]() {
+            int p = 0;
+#pragma unroll
+            for (int a = 0; a < KR; ++a) {
+                const int ca = cur[a] - j0;
+#pragma unroll
+                for (int b = a; b < KR; ++b, ++p) {
+                    const int cb = cur[b] - k0;
+                    if ((a1[p] != 0.0 || a2[p] != 0.0) && ca >= 0 && ca < kSgJ && cb >= 0 && cb < kSgK) {
+                        const int idx = ca * kSgK + cb;
+                        atomicAdd(&acc[idx], (unsigned long long)(long long)a1[p]);
+                        atomicAdd(&acc[kSgTile + idx], (unsigned long long)(long long)a2[p]);
+                    }
+                    a1[p] = a2[p] = 0.0;
+                }
+            }
+        };
+        for (int64_t i = rbeg + threadIdx.x; i < rend; i += T) {
+            double v[KR];
+            int c[KR];
+            bool same = run < kSgRun;
+#pragma unroll
+            for (int a = 0; a < KR; ++a) {
+                v[a] = a < K ? val[(int64_t)a * ld + i] : 0.0;
+                c[a] = a < K ? col[(int64_t)a * ld + i] : 0;
+                same = same && c[a] == cur[a];
+            }
+            if (!same) {
+                flush();
+                run = 0;
+#pragma unroll
+                for (int a = 0; a < KR; ++a) cur[a] = c[a];
+            }
+            ++run;
+            const double w = w2 ? w2[i] : 1.0;
+            int p = 0;
+#pragma unroll
+            for (int a = 0; a < KR; ++a) {                   // the slots of a row are in ascending column order: c_a < c_b for a < b
+                const double wa = w * v[a];
+#pragma unroll
+                for (int b = a; b < KR; ++b, ++p) {
+                    const double x = wa * v[b];
+                    const double q1 = rint(x * s1);
+                    a1[p] += q1;
+                    a2[p] += rint(fma(-q1, r1, x) * s2);
+                }
+            }
+        }
+        flush();
+    } else {
+        for (int64_t i = rbeg + threadIdx.x; i < rend; i += T) {
+            const double w = w2 ? w2[i] : 1.0;
+            for (int a = 0; a < K; ++a) {
+                const double va = val[(int64_t)a * ld + i];
+                const int ca = col[(int64_t)a * ld + i] - j0;
+                if (va == 0.0 || ca < 0 || ca >= kSgJ) continue;
+                const double wa = w * va;
+                for (int b = a; b < K; ++b) {
+                    const double vb = val[(int64_t)b * ld + i];
+                    const int cb = col[(int64_t)b * ld + i] - k0;
+                    if (vb == 0.0 || cb < 0 || cb >= kSgK) continue;
+                    const double x = wa * vb;
+                    const double q1 = rint(x * s1);
+                    const double q2 = rint(fma(-q1, r1, x) * s2);
+                    const int idx = ca * kSgK + cb;
+                    atomicAdd(&acc[idx], (unsigned long long)(long long)q1);
+                    atomicAdd(&acc[kSgTile + idx], (unsigned long long)(long long)q2);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * kSgTile);
+    for (int idx = threadIdx.x; idx < 2 * kSgTile; idx += T) out[idx] = acc[idx];
+}
+// sums the workgroups' limbs of each entry, rounds once, writes G[j, k] and its mirror image (G: m x m, column-major, leading dimension ldg)
+__global__ __launch_bounds__(256) void sp_gram_reduce_kernel(const unsigned long long* __restrict__ partial, int nblk, int nkb, int m, double r1,
+                                                             double r2, double* __restrict__ G, int ldg) {
+    const int j0 = ((int)blockIdx.y / nkb) * kSgJ, k0 = ((int)blockIdx.y % nkb) * kSgK;
+    if (k0 + kSgK - 1 < j0) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int j = j0 + idx / kSgK, k = k0 + idx % kSgK;
+    if (j > k || k >= m) return;
+    const unsigned long long* p = partial + (int64_t)blockIdx.y * nblk * (2 * kSgTile) + idx;
+    long long a1 = 0, a2 = 0;
+    for (int b = 0; b < nblk; ++b) {
+        a1 += (long long)p[(int64_t)b * (2 * kSgTile)];
+        a2 += (long long)p[(int64_t)b * (2 * kSgTile) + kSgTile];
+    }
+    const double hi = (double)a1;                             // |a1| <= 2^62: the conversion rounds, its error is an exact integer
+    const double lo = (double)(a1 - (long long)hi);
+    const double g = hi * r1 + (lo * r1 + (double)a2 * r2);
+    G[(int64_t)k * ldg + j] = g;
+    G[(int64_t)j * ldg + k] = g;
+}
+__global__ void sp_mul_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+
+// G (host, mt x mt column-major, mt = S->m + nx) = A' diag(w2) A for A = [S | X[:, x0 : x0+nx)], all-reduced over the ranks.  scratch: an
+// n-vector (used when there are extra columns and weights).  LFPSQP_ERR_UNSUPPORTED when the nonzeros do not allow the exact accumulation
+// (rows wider than kmax nonzeros -- the register-resident kernels cover 8, beyond that the per-term LDS atomics are slower than the MFMA Gram
+// of a dense copy at K = 12 already (10.4 vs 2.8 ms at n = 1e7, m = 128) --, non-finite or extreme values): the caller then forms the Gram
+// matrix on a dense copy.
+int sp_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0, int nx, const lfpsqp_vec* w2, double* scratch, double* G, int kmax) {
+    const int ms = (int)S->m, mt = ms + nx;
+    for (size_t e = 0; e < (size_t)mt * mt; ++e) G[e] = 0.0;
+    if (mt == 0) return 0;
+    if (S->K > kmax) return LFPSQP_ERR_UNSUPPORTED;
+    double wmax = 1.0;
+    if (w2) LF_TRY(lfpsqp_amax(ctx, w2, &wmax));             // (global maximum: every rank uses the same grid)
+    const double B = S->amax * S->amax * wmax;
+    if (!(B == B) || B > 1e200 || (B != 0.0 && B < 1e-200)) return LFPSQP_ERR_UNSUPPORTED;
+    LF_TRY(ensure_small(ctx, (size_t)ms * ms + 16));
+    LF_HIP(ctx, hipMemsetAsync(ctx->small, 0, sizeof(double) * (size_t)ms * ms, ctx->stream));
+    if (ms > 0 && B != 0.0 && S->n > 0) {
+        int E = 0;
+        (void)frexp(B, &E);                                   // B < 2^E
+        E += 1;                                               // (one binade of slack for the rounding of the three-factor product)
+        int hb = 0;
+        while (((int64_t)1 << hb) < S->n + 1) ++hb;
+        const int b = std::min(62 - hb, kSgLimbMax);
+        const double s1 = ldexp(1.0, b - E), r1 = ldexp(1.0, E - b), s2 = ldexp(1.0, 2 * b - E), r2 = ldexp(1.0, E - 2 * b);
+        const int njb = (ms + kSgJ - 1) / kSgJ, nkb = (ms + kSgK - 1) / kSgK;
+        int active = 0;
+        for (int t = 0; t < njb * nkb; ++t) active += ((t % nkb) * kSgK + kSgK - 1 >= (t / nkb) * kSgJ);
+        const int64_t cus = ctx->num_cu > 0 ? ctx->num_cu : 64;
+        int64_t nblk = std::max<int64_t>(cus / active, 8);     // one workgroup per CU (LDS); at least eight slices of the rows
+        nblk = std::min<int64_t>(nblk, std::max<int64_t>((S->n + kSgThreads - 1) / kSgThreads, 1));
+        LF_TRY(ensure_part(ctx, (size_t)njb * nkb * nblk * 2 * kSgTile + 8));
+        unsigned long long* part = reinterpret_cast<unsigned long long*>(ctx->part);
+        const int64_t rows_per_wg = (S->n + nblk - 1) / nblk;
+        const dim3 grid((unsigned)nblk, (unsigned)(njb * nkb));
+        const double* w2p = w2 ? w2->p : nullptr;
+        if (S->K <= 4)
+            hipLaunchKernelGGL((sp_gram_kernel<4, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p, s1,
+                               r1, s2, nkb, rows_per_wg, part);
+        else if (S->K <= 8)                                  // 72 limb sums per lane: two waves per SIMD
+            hipLaunchKernelGGL((sp_gram_kernel<8, 512>), grid, dim3(512), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p, s1, r1, s2,
+                               nkb, rows_per_wg, part);
+        else
+            hipLaunchKernelGGL((sp_gram_kernel<0, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p, s1,
+                               r1, s2, nkb, rows_per_wg, part);
+        hipLaunchKernelGGL(sp_gram_reduce_kernel, dim3(kSgTile / 256, (unsigned)(njb * nkb)), dim3(256), 0, ctx->stream, part, (int)nblk, nkb, ms, r1, r2,
+                           ctx->small, ms);
+        LF_LAUNCH_CHECK(ctx);
+        LF_TRY(allreduce_dev(ctx, ctx->small, (int64_t)ms * ms, 0));
+    }
+    std::vector<double> h((size_t)ms * ms + 1);
+    if (ms > 0) {
+        LF_HIP(ctx, hipMemcpyAsync(h.data(), ctx->small, sizeof(double) * (size_t)ms * ms, hipMemcpyDeviceToHost, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < ms; ++k)
+            for (int j = 0; j < ms; ++j) G[(size_t)k * mt + j] = h[(size_t)k * ms + j];
+    }
+    // the dense extra columns: G[0:ms, ms + c] = S' (w2 .* x_c) streams the nonzeros, the corner is a handful of dot products
+    if (nx > 0) LF_TRY(ensure_mvec(ctx, (size_t)mt + 8));
+    for (int c = 0; c < nx; ++c) {
+        const double* xc = X->p + (int64_t)(x0 + c) * X->ld;
+        const double* wx = xc;
+        if (w2) {
+            hipLaunchKernelGGL(sp_mul_kernel, dim3(2048), dim3(256), 0, ctx->stream, w2->p, xc, scratch, S->n);
+            LF_LAUNCH_CHECK(ctx);
+            wx = scratch;
+        }
+        if (ms > 0) {
+            LF_TRY(spmv_t(ctx, S, wx, ctx->d_m));
+            LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * ms, hipMemcpyDeviceToHost, ctx->stream));
+            LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int j = 0; j < ms; ++j) G[(size_t)(ms + c) * mt + j] = G[(size_t)j * mt + ms + c] = ctx->h_m[j];
+        }
+        lfpsqp_vec va, vb;
+        va.p = const_cast<double*>(wx); va.n = va.cap = S->n;
+        for (int d = c; d < nx; ++d) {
+            vb.p = X->p + (int64_t)(x0 + d) * X->ld; vb.n = vb.cap = S->n;
+            double dv = 0.0;
+            LF_TRY(lfpsqp_dot(ctx, &va, &vb, &dv));
+            G[(size_t)(ms + d) * mt + ms + c] = G[(size_t)(ms + c) * mt + ms + d] = dv;
+        }
+    }
+    return 0;
+}
+
 }  // namespace lfpsqp
 
 using namespace lfpsqp;
@@ -327,6 +549,9 @@ int lfpsqp_spmat_create(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nnz, cons
         else { hr.push_back((int32_t)rows[e]); hcol.push_back((int32_t)cols[e]); hcv.push_back(vals[e]); }
     }
     nnz = (int64_t)hr.size();
+    double amax = 0.0;
+    for (double v : hcv) amax = std::max(amax, fabs(v));          // (a NaN entry: the comparison keeps amax, sp_gram's own test of the
+    for (double v : hcv) if (!(v == v) || fabs(v) > 1e300) amax = NAN;    //  bound then refuses the exact accumulation)
     std::vector<int32_t> cnt((size_t)std::max<int64_t>(n, 1), 0);
     for (int64_t k = 0; k < nnz; ++k) cnt[(size_t)hr[(size_t)k]]++;
     int K = 0;
@@ -334,6 +559,7 @@ int lfpsqp_spmat_create(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nnz, cons
     if (K > 256) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "spmat: a row with %d nonzeros (> 256): keep such constraint gradients dense", K);
     lfpsqp_spmat* S = new lfpsqp_spmat();
     S->n = n; S->m = m; S->nnz = nnz; S->K = K;
+    S->amax = amax;
     S->ld = round_up(n > 0 ? n : 1, kPadRows);
     const size_t ell = (size_t)std::max(K, 1) * (size_t)S->ld;
     std::vector<double> hv(ell, 0.0);
@@ -406,6 +632,17 @@ int lfpsqp_spmv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_vec* v, l
 int lfpsqp_spmv_n(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, double alpha, const lfpsqp_vec* t, double beta, lfpsqp_vec* y) {
     LF_ARG(ctx, ctx && S && t && y && y->n >= S->n && t->n >= S->m && t->p != y->p);
     return run_vec<SpmvNF, 0, NoPost>(ctx, S->n, SpmvNF{ell_rows(S, t->p), y->p, alpha, beta}, 0u, nullptr, NoPost());
+}
+
+int lfpsqp_spmat_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, double* G) {
+    LF_ARG(ctx, ctx && S && G && (!w2 || w2->n == S->n) && (!Jct || (Jct->n == S->n && Jct->m >= S->m && Jct->m - S->m <= 4)));
+    const int nx = Jct ? (int)(Jct->m - S->m) : 0;
+    double* scratch = nullptr;
+    if (nx > 0 && w2) LF_HIP(ctx, hipMalloc((void**)&scratch, sizeof(double) * (size_t)(S->n > 0 ? S->n : 1)));
+    const int rc = sp_gram(ctx, S, Jct, (int)S->m, nx, w2, scratch, G, 32);
+    if (scratch) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(scratch); }
+    if (rc == LFPSQP_ERR_UNSUPPORTED) return set_err(ctx, rc, "spmat_gram: rows wider than 32 nonzeros or values outside the exactly accumulable range");
+    return rc;
 }
 
 int lfpsqp_spmat_to_dense(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, lfpsqp_mat* M) {

@@ -309,6 +309,14 @@ class SparseMatrix:
         self.ctx.check(self.ctx.L.lfpsqp_spmat_to_dense(self.ctx.h, self.h, M.h))
         return M
 
+    def gram(self, Jct: "DeviceMatrix | None" = None, w2: "DeviceVector | None" = None) -> np.ndarray:
+        """[S | Jct[:, m:]]' diag(w2) [S | Jct[:, m:]] from the nonzeros, exactly accumulated (lfpsqp_spmat_gram)."""
+        M = Jct.m if Jct is not None else self.m
+        G = np.zeros((M, M), order="F")
+        self.ctx.check(self.ctx.L.lfpsqp_spmat_gram(self.ctx.h, self.h, Jct.h if Jct is not None else None, w2.h if w2 is not None else None,
+                                                    G.ctypes.data))
+        return G
+
 
 def spmv_t(S: SparseMatrix, v: DeviceVector, t: DeviceVector) -> DeviceVector:
     """t = S' v (all-reduced)."""

@@ -162,13 +162,100 @@ def test_optimize_with_sparse_equalities_matches_the_dense_run_and_the_oracle(de
     np.testing.assert_allclose(objs, objr, rtol=1e-10)
 
 
-@pytest.mark.parametrize("case", ["plain", "weighted", "ball_column", "no_dense_twin", "ill_conditioned", "wide_k", "two_panels"])
-def test_factorize_from_the_nonzeros_is_the_dense_factorisation(dev_ctx, case):
-    """lfpsqp_factorize_sp (Gram on the dense twin or on S expanded into Z, basis-forming products Z = [S | extra columns] * W from the
-    nonzeros) against lfpsqp_factorize on the dense matrix: the same Gram matrix, hence identical Sigma / Vt / rank / W, and the same
-    basis up to the rounding of the product; Z = A * W and Z' diag(w2) Z = I checked directly."""
+def _exact_gram(A, w=None):
+    """A' diag(w) A with every product and sum exact (Python fractions), rounded once."""
+    from fractions import Fraction
+    n, m = A.shape
+    G = np.zeros((m, m))
+    nz = [[(j, Fraction(float(A[i, j]))) for j in range(m) if A[i, j] != 0.0] for i in range(n)]
+    acc = {}
+    for i in range(n):
+        wi = Fraction(float(w[i])) if w is not None else Fraction(1)
+        for a, (ja, va) in enumerate(nz[i]):
+            for jb, vb in nz[i][a:]:
+                acc[(ja, jb)] = acc.get((ja, jb), Fraction(0)) + wi * va * vb
+    for (ja, jb), v in acc.items():
+        G[ja, jb] = G[jb, ja] = float(v)
+    return G
+
+
+@pytest.mark.parametrize("case", ["plain", "weighted", "ball_weighted", "two_tiles", "wide_range", "k6", "k11", "scattered"])
+def test_gram_from_the_nonzeros_is_exact_and_order_independent(dev_ctx, case):
+    """lfpsqp_spmat_gram: the scattered accumulation in two fixed-point limbs.  The device forms each term w_i v_a v_b in floating point (two
+    roundings) and then sums EXACTLY: against exact rational arithmetic on the same rounded terms the result is the correctly rounded sum up
+    to the dropped third limb; a permutation of the rows changes nothing, bit for bit; the dense extra columns (SpMV-T, dot products) and
+    the weights agree with numpy."""
+    from fractions import Fraction
     ctx = dev_ctx
-    n, m, k = (1500 if _is_emu(ctx) else 26000, 200, 4) if case == "two_panels" else (3100, 12, 9 if case == "wide_k" else 3)
+    n, m, k = (900, 150, 3) if case == "two_tiles" else (1300, 14, {"k6": 6, "k11": 11}.get(case, 3))
+    rows, cols, vals = banded(n, m, k, seed=4)
+    if case == "scattered":                          # no two consecutive rows with the same columns, rows of 1..3 nonzeros
+        rng0 = np.random.default_rng(11)
+        cols = np.stack([rng0.permutation(m)[:k] for _ in range(n)]).ravel()
+        keep = rng0.random(cols.size) < 0.8
+        rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    if case == "wide_range":
+        vals = vals * np.logspace(0, -9, m)[cols] * np.where(np.arange(vals.size) % 7 == 0, 1e3, 1.0)
+    rng = np.random.default_rng(3)
+    w = rng.random(n) + 0.2 if case in ("weighted", "ball_weighted") else None
+    extra = 2 if case == "ball_weighted" else 0
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, m)).toarray()
+    X = rng.standard_normal((n, extra))
+    Ad = np.asfortranarray(np.hstack([A, X]))
+    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+    Jd = ctx.matrix(n, m + extra, Ad) if extra else None
+    wv = ctx.vector(n, w) if w is not None else None
+    G = S.gram(Jd, wv)
+    # the terms as the device forms them: (w_i * v_a) * v_b in floating point, then exact sums
+    acc = {}
+    A0 = sp.coo_matrix((vals, (rows, cols)), shape=(n, m)).tocsr()
+    for i in range(n):
+        lo, hi = A0.indptr[i], A0.indptr[i + 1]
+        cs, vs = A0.indices[lo:hi], A0.data[lo:hi]
+        order = np.argsort(cs)
+        cs, vs = cs[order], vs[order]
+        wi = w[i] if w is not None else 1.0
+        for a in range(len(cs)):
+            wa = wi * vs[a]
+            for b in range(a, len(cs)):
+                acc[(cs[a], cs[b])] = acc.get((cs[a], cs[b]), Fraction(0)) + Fraction(float(wa * vs[b]))
+    Gx = np.zeros((m, m))
+    for (ja, jb), v in acc.items():
+        Gx[ja, jb] = Gx[jb, ja] = float(v)
+    Gs = G[:m, :m]
+    tmax = (np.abs(vals).max() ** 2) * (w.max() if w is not None else 1.0)
+    assert np.abs(Gs - Gx).max() <= 2.0 ** -52 * np.abs(Gx).max() * 0.51 + tmax * 2.0 ** -70 * n     # one rounding + the dropped limb
+    if case != "wide_range":
+        np.testing.assert_array_equal(Gs, Gx)
+    np.testing.assert_array_equal(Gs, Gs.T)
+    Gn = Ad.T @ ((w[:, None] if w is not None else 1.0) * Ad)
+    np.testing.assert_allclose(G, Gn, rtol=0, atol=1e-13 * np.abs(Gn).max())
+    np.testing.assert_array_equal(G, G.T)
+    # the rows in another order: the same matrix, bit for bit
+    perm = rng.permutation(n)
+    inv = np.empty(n, dtype=np.int64); inv[perm] = np.arange(n)
+    S2 = L.SparseMatrix(ctx, n, m, inv[rows], cols, vals)
+    Jd2 = ctx.matrix(n, m + extra, np.asfortranarray(Ad[perm])) if extra else None
+    wv2 = ctx.vector(n, w[perm]) if w is not None else None
+    G2 = S2.gram(Jd2, wv2)
+    np.testing.assert_array_equal(G2[:m, :m], Gs)
+    np.testing.assert_allclose(G2, G, rtol=0, atol=1e-13 * np.abs(Gn).max())
+    # refused, not approximated: rows wider than 32 nonzeros
+    r3, c3, v3 = banded(200, 40, 33, seed=1)
+    with pytest.raises(L.LfpsqpError):
+        L.SparseMatrix(ctx, 200, 40, r3, c3, v3).gram()
+
+
+@pytest.mark.parametrize("case", ["plain", "weighted", "ball_column", "no_dense_twin", "ill_conditioned", "wide_k", "two_panels", "very_wide_k"])
+def test_factorize_from_the_nonzeros_is_the_dense_factorisation(dev_ctx, case):
+    """lfpsqp_factorize_sp (Gram matrix from the nonzeros, exactly accumulated; basis-forming products Z = [S | extra columns] * W from the
+    nonzeros) against lfpsqp_factorize on the dense matrix: the same factorisation up to the rounding of the Gram matrix and of the product;
+    Z = A * W and Z' diag(w2) Z = I checked directly.  With the Gram matrix taken from a dense copy (context setting LFPSQP_SPGRAM=-1, and
+    always when a row has more than 8 nonzeros: wide_k, very_wide_k) Sigma / Vt / W are those of the dense factorisation bit for bit."""
+    import os
+    ctx = dev_ctx
+    n, m, k = (1500 if _is_emu(ctx) else 26000, 200, 4) if case == "two_panels" else (3100, 12 if case != "very_wide_k" else 40,
+                                                                                     {"wide_k": 9, "very_wide_k": 34}.get(case, 3))
     rows, cols, vals = banded(n, m, k, seed=8)
     if case == "ill_conditioned":                    # refinement rounds: several basis-forming products from the nonzeros
         vals = vals * np.logspace(0, -7, m)[cols]
@@ -177,31 +264,43 @@ def test_factorize_from_the_nonzeros_is_the_dense_factorisation(dev_ctx, case):
     rng = np.random.default_rng(2)
     Ad = np.asfortranarray(np.hstack([A, rng.standard_normal((n, extra))])) if extra else np.asfortranarray(A)
     M = m + extra
-    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
-    Jd = ctx.matrix(n, M, Ad)
-    w = ctx.vector(n, rng.random(n) + 0.2) if case == "weighted" else None
-    Z0, Z1 = ctx.matrix(n, M), ctx.matrix(n, M)
-    W0, W1 = np.zeros((M, M), order='F'), np.zeros((M, M), order='F')
-    S0, Vt0, r0 = L.ksvd_(Jd, Z0, w2=w, W=W0)
-    S1, Vt1, r1 = L.ksvd_(None if case == "no_dense_twin" else Jd, Z1, w2=w, W=W1, Jsp=S)
-    assert r1 == r0 == M
-    fast = S0[0] ** 2 <= 10.0 * S0[-1] ** 2           # lfpsqp_factorize's one-Gram-one-product path
-    if fast:                                         # same Gram matrix, same replicated small step: bit for bit
-        np.testing.assert_array_equal(S1, S0)
-        np.testing.assert_array_equal(Vt1, Vt0)
-        np.testing.assert_array_equal(W1, W0)
-    else:                                            # the refinement rounds measure the Gram matrix of a basis formed by a different product
-        np.testing.assert_allclose(S1, S0, rtol=1e-11)
-    Zh0, Zh1 = Z0.download(), Z1.download()
-    scale = np.abs(Zh0).max()
-    tol = 1e-9 if case == "ill_conditioned" else (2e-14 if fast else 1e-12)
-    assert np.abs(Zh1 - Zh0).max() <= tol * scale * (M ** 0.5)
-    assert np.abs(Zh1 - Ad @ W1).max() <= tol * scale * (M ** 0.5)
-    wh = w.download() if w is not None else np.ones(n)
-    if case != "ill_conditioned":
-        assert np.abs(Zh1.T @ (wh[:, None] * Zh1) - np.eye(M)).max() <= (1e-12 if fast else 1e-10)
-    np.testing.assert_allclose(S1, np.linalg.svd(np.sqrt(wh)[:, None] * Ad, compute_uv=False), rtol=1e-9 if case != "ill_conditioned" else 1e-6,
-                               atol=1e-13 * S1[0])
+    wh = rng.random(n) + 0.2 if case == "weighted" else None
+    res = {}
+    for label in ("exact", "dense_copy"):
+        if label == "dense_copy":
+            os.environ["LFPSQP_SPGRAM"] = "-1"
+        try:
+            c = ctx if label == "exact" else L.Context(0, ctx.L)
+        finally:
+            os.environ.pop("LFPSQP_SPGRAM", None)
+        S = L.SparseMatrix(c, n, m, rows, cols, vals)
+        Jd = c.matrix(n, M, Ad)
+        w = c.vector(n, wh) if wh is not None else None
+        Z0, Z1 = c.matrix(n, M), c.matrix(n, M)
+        W0, W1 = np.zeros((M, M), order='F'), np.zeros((M, M), order='F')
+        S0, Vt0, r0 = L.ksvd_(Jd, Z0, w2=w, W=W0)
+        S1, Vt1, r1 = L.ksvd_(None if case == "no_dense_twin" else Jd, Z1, w2=w, W=W1, Jsp=S)
+        res[label] = (S0, Vt0, W0, r0, Z0.download(), S1, Vt1, W1, r1, Z1.download())
+        if c is not ctx:
+            c.close()
+    for label, (S0, Vt0, W0, r0, Zh0, S1, Vt1, W1, r1, Zh1) in res.items():
+        assert r1 == r0 == M
+        fast = S0[0] ** 2 <= 10.0 * S0[-1] ** 2           # lfpsqp_factorize's one-Gram-one-product path
+        if fast and (label == "dense_copy" or k > 8):     # same Gram matrix, same replicated small step: bit for bit
+            np.testing.assert_array_equal(S1, S0)
+            np.testing.assert_array_equal(Vt1, Vt0)
+            np.testing.assert_array_equal(W1, W0)
+        else:                                            # Gram matrices that differ in their last bits / refinement rounds on another product
+            np.testing.assert_allclose(S1, S0, rtol=1e-11 if not fast else 1e-13)
+        scale = np.abs(Zh0).max()
+        tol = 1e-9 if case == "ill_conditioned" else 1e-11        # (eigenvectors of a matrix perturbed in its last bits: rounding / gap)
+        assert np.abs(Zh1 - Zh0).max() <= tol * scale * (M ** 0.5)
+        assert np.abs(Zh1 - Ad @ W1).max() <= (1e-9 if case == "ill_conditioned" else 2e-14 if fast else 1e-12) * scale * (M ** 0.5)
+        wv = wh if wh is not None else np.ones(n)
+        if case != "ill_conditioned":
+            assert np.abs(Zh1.T @ (wv[:, None] * Zh1) - np.eye(M)).max() <= (1e-12 if fast else 1e-10)
+        np.testing.assert_allclose(S1, np.linalg.svd(np.sqrt(wv)[:, None] * Ad, compute_uv=False), rtol=1e-9 if case != "ill_conditioned" else 1e-6,
+                                   atol=1e-13 * S1[0])
 
 
 @pytest.mark.gpu
