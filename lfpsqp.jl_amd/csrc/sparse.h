@@ -7,6 +7,7 @@ struct lfpsqp_spmat {
     int64_t n = 0, m = 0, nnz = 0;
     int K = 0;              // ELL width
     double amax = 0.0;      // largest |value| (NaN when an entry is not finite)
+    double* col_scale = nullptr;   // [2 m] (device): 2^-e_j with |value| 2^-e_j < 1 for every entry of column j, then 2^e_j (sp_gram)
     int64_t ld = 0;         // rows rounded up to whole tiles
     double* ell_val = nullptr;    // [K][ld]
     int32_t* ell_col = nullptr;   // [K][ld]

@@ -307,7 +307,9 @@ int spmv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const double* v, double* t_ou
 // ---- Gram matrix from the nonzeros -----------------------------------------------------------------------------------------------------
 // G = S' diag(w2) S: row i adds w2_i v_a v_b to G[c_a, c_b] for every pair of its nonzeros -- a scattered accumulation.  Floating-point
 // atomics would make the result depend on the order of arrival.  Here the accumulation is EXACT, so the order cannot matter and the result is
-// bit-reproducible: with |term| < 2^E (E from max|v|^2 max w2) and at most n terms per entry (one per row: duplicates are merged at creation),
+// bit-reproducible: with the values scaled by a power of two per column (|v'| < 1: entrywise accuracy relative to the columns' own magnitudes,
+// as a floating-point Gram matrix has it), |term| < 2^E (E from the measured max_i w2_i max_a v'_ia^2) and at most n terms per entry (one per row:
+// duplicates are merged at creation),
 // every term x is cut into two fixed-point limbs of b = min(62 - ceil(log2(n + 1)), 40) bits,
 //     q1 = rint(x 2^(b-E)),      q2 = rint((x - q1 2^(E-b)) 2^(2b-E))        (power-of-two scalings and an exact remainder),
 // which are summed as 64-bit integers -- LDS atomics inside a workgroup, plain integer sums over the workgroups -- without overflow or
@@ -323,8 +325,8 @@ constexpr int kSgJ = 128, kSgK = 64, kSgTile = kSgJ * kSgK, kSgThreads = 1024, k
 // degrade to one flush per row, the generic path (KR = 0: no registers, atomics per term).
 template <int KR, int T>
 __global__ __launch_bounds__(T) void sp_gram_kernel(const double* __restrict__ val, const int32_t* __restrict__ col, int64_t ld, int K, int64_t n,
-                                                   const double* __restrict__ w2, double s1, double r1, double s2, int nkb,
-                                                   int64_t rows_per_wg, unsigned long long* __restrict__ partial) {
+                                                   const double* __restrict__ w2, const double* __restrict__ cs, double s1, double r1,
+                                                   double s2, int nkb, int64_t rows_per_wg, unsigned long long* __restrict__ partial) {
     __shared__ unsigned long long acc[2 * kSgTile];
     const int j0 = ((int)blockIdx.y / nkb) * kSgJ, k0 = ((int)blockIdx.y % nkb) * kSgK;
     if (k0 + kSgK - 1 < j0) return;                          // a tile wholly below the diagonal (uniform over the workgroup)
@@ -335,8 +337,9 @@ __global__ __launch_bounds__(T) void sp_gram_kernel(const double* __restrict__ v
         constexpr int NP = KR * (KR + 1) / 2;
         double a1[NP], a2[NP];
         int cur[KR];
+        double csr[KR];                                      // the scales of the run's columns: looked up when the column set changes
 #pragma unroll
-        for (int a = 0; a < KR; ++a) cur[a] = -1;
+        for (int a = 0; a < KR; ++a) { cur[a] = -1; csr[a] = 0.0; }
 #pragma unroll
         for (int p = 0; p < NP; ++p) a1[p] = a2[p] = 0.0;
         int run = 0;
@@ -363,17 +366,19 @@ __global__ __launch_bounds__(T) void sp_gram_kernel(const double* __restrict__ v
             bool same = run < kSgRun;
 #pragma unroll
             for (int a = 0; a < KR; ++a) {
-                v[a] = a < K ? val[(int64_t)a * ld + i] : 0.0;
                 c[a] = a < K ? col[(int64_t)a * ld + i] : 0;
+                v[a] = a < K ? val[(int64_t)a * ld + i] : 0.0;
                 same = same && c[a] == cur[a];
             }
             if (!same) {
                 flush();
                 run = 0;
 #pragma unroll
-                for (int a = 0; a < KR; ++a) cur[a] = c[a];
+                for (int a = 0; a < KR; ++a) { cur[a] = c[a]; csr[a] = cs[c[a]]; }
             }
             ++run;
+#pragma unroll
+            for (int a = 0; a < KR; ++a) v[a] *= csr[a];     // (column scaling: an exact power of two)
             const double w = w2 ? w2[i] : 1.0;
             int p = 0;
 #pragma unroll
@@ -393,13 +398,13 @@ __global__ __launch_bounds__(T) void sp_gram_kernel(const double* __restrict__ v
         for (int64_t i = rbeg + threadIdx.x; i < rend; i += T) {
             const double w = w2 ? w2[i] : 1.0;
             for (int a = 0; a < K; ++a) {
-                const double va = val[(int64_t)a * ld + i];
-                const int ca = col[(int64_t)a * ld + i] - j0;
+                const int ca0 = col[(int64_t)a * ld + i], ca = ca0 - j0;
+                const double va = val[(int64_t)a * ld + i] * cs[ca0];
                 if (va == 0.0 || ca < 0 || ca >= kSgJ) continue;
                 const double wa = w * va;
                 for (int b = a; b < K; ++b) {
-                    const double vb = val[(int64_t)b * ld + i];
-                    const int cb = col[(int64_t)b * ld + i] - k0;
+                    const int cb0 = col[(int64_t)b * ld + i], cb = cb0 - k0;
+                    const double vb = val[(int64_t)b * ld + i] * cs[cb0];
                     if (vb == 0.0 || cb < 0 || cb >= kSgK) continue;
                     const double x = wa * vb;
                     const double q1 = rint(x * s1);
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(T) void sp_gram_kernel(const double* __restrict__ v
 }
 // sums the workgroups' limbs of each entry, rounds once, writes G[j, k] and its mirror image (G: m x m, column-major, leading dimension ldg)
 __global__ __launch_bounds__(256) void sp_gram_reduce_kernel(const unsigned long long* __restrict__ partial, int nblk, int nkb, int m, double r1,
-                                                             double r2, double* __restrict__ G, int ldg) {
+                                                             double r2, const double* __restrict__ csinv, double* __restrict__ G, int ldg) {
     const int j0 = ((int)blockIdx.y / nkb) * kSgJ, k0 = ((int)blockIdx.y % nkb) * kSgK;
     if (k0 + kSgK - 1 < j0) return;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -431,9 +436,39 @@ __global__ __launch_bounds__(256) void sp_gram_reduce_kernel(const unsigned long
     }
     const double hi = (double)a1;                             // |a1| <= 2^62: the conversion rounds, its error is an exact integer
     const double lo = (double)(a1 - (long long)hi);
-    const double g = hi * r1 + (lo * r1 + (double)a2 * r2);
+    const double g = (hi * r1 + (lo * r1 + (double)a2 * r2)) * csinv[j] * csinv[k];      // (undoing the column scaling: exact)
     G[(int64_t)k * ldg + j] = g;
     G[(int64_t)j * ldg + k] = g;
+}
+// max over the rows of w2_i (max_a |v'_ia|)^2, v' the column-scaled values: the bound on the terms.  (The largest weight alone will not do: a row
+// without nonzeros -- the slack row of a ball constraint -- may carry a weight 2^23 times the others, and every bit of slack in the bound is a
+// bit lost at the bottom of the second limb.)
+__global__ __launch_bounds__(1024) void sp_gram_bound_kernel(const double* __restrict__ val, const int32_t* __restrict__ col, int64_t ld, int K,
+                                                             int64_t n, const double* __restrict__ w2, const double* __restrict__ cs,
+                                                             unsigned long long* __restrict__ out) {
+    __shared__ double red[1024];
+    double mx = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
+        double r = 0.0;
+        for (int a = 0; a < K; ++a) r = fmax(r, fabs(val[(int64_t)a * ld + i] * cs[col[(int64_t)a * ld + i]]));
+        const double t = fabs(w2[i]) * r * r;
+        mx = (t > mx || t != t) ? t : mx;                     // (a NaN sticks)
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int h = 512; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            const double o = red[threadIdx.x + h];
+            if (o > red[threadIdx.x] || o != o) red[threadIdx.x] = o;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        unsigned long long bits;
+        const double r0 = red[0];
+        memcpy(&bits, &r0, sizeof(bits));
+        atomicMax(out, bits);
+    }     // non-negative doubles (and NaN above them) order like integers
 }
 __global__ void sp_mul_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
@@ -449,10 +484,18 @@ int sp_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0,
     for (size_t e = 0; e < (size_t)mt * mt; ++e) G[e] = 0.0;
     if (mt == 0) return 0;
     if (S->K > kmax) return LFPSQP_ERR_UNSUPPORTED;
-    double wmax = 1.0;
-    if (w2) LF_TRY(lfpsqp_amax(ctx, w2, &wmax));             // (global maximum: every rank uses the same grid)
-    const double B = S->amax * S->amax * wmax;
-    if (!(B == B) || B > 1e200 || (B != 0.0 && B < 1e-200)) return LFPSQP_ERR_UNSUPPORTED;
+    // |column-scaled value| < 1, so without weights every term is below 1; with weights the bound is measured (sp_gram_bound_kernel)
+    double B = 1.0;
+    if (w2 && ms > 0 && S->n > 0) {
+        unsigned long long* slot = reinterpret_cast<unsigned long long*>(ctx->scal + 40);
+        LF_HIP(ctx, hipMemsetAsync(slot, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(sp_gram_bound_kernel, dim3((unsigned)std::min<int64_t>((S->n + 1023) / 1024, 1024)), dim3(1024), 0, ctx->stream, S->ell_val,
+                           S->ell_col, S->ld, S->K, S->n, w2->p, S->col_scale, slot);
+        LF_LAUNCH_CHECK(ctx);
+        LF_TRY(allreduce_dev(ctx, ctx->scal + 40, 1, 1));      // (every rank on the same grid)
+        LF_TRY(read_back(ctx, ctx->scal + 40, &B, 1));
+    }
+    if (!(S->amax == S->amax) || !(B == B) || B > 1e200 || (B != 0.0 && B < 1e-200)) return LFPSQP_ERR_UNSUPPORTED;
     LF_TRY(ensure_small(ctx, (size_t)ms * ms + 16));
     LF_HIP(ctx, hipMemsetAsync(ctx->small, 0, sizeof(double) * (size_t)ms * ms, ctx->stream));
     if (ms > 0 && B != 0.0 && S->n > 0) {
@@ -475,16 +518,16 @@ int sp_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0,
         const dim3 grid((unsigned)nblk, (unsigned)(njb * nkb));
         const double* w2p = w2 ? w2->p : nullptr;
         if (S->K <= 4)
-            hipLaunchKernelGGL((sp_gram_kernel<4, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p, s1,
-                               r1, s2, nkb, rows_per_wg, part);
+            hipLaunchKernelGGL((sp_gram_kernel<4, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p,
+                               S->col_scale, s1, r1, s2, nkb, rows_per_wg, part);
         else if (S->K <= 8)                                  // 72 limb sums per lane: two waves per SIMD
-            hipLaunchKernelGGL((sp_gram_kernel<8, 512>), grid, dim3(512), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p, s1, r1, s2,
-                               nkb, rows_per_wg, part);
+            hipLaunchKernelGGL((sp_gram_kernel<8, 512>), grid, dim3(512), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p, S->col_scale, s1, r1,
+                               s2, nkb, rows_per_wg, part);
         else
-            hipLaunchKernelGGL((sp_gram_kernel<0, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p, s1,
-                               r1, s2, nkb, rows_per_wg, part);
+            hipLaunchKernelGGL((sp_gram_kernel<0, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p,
+                               S->col_scale, s1, r1, s2, nkb, rows_per_wg, part);
         hipLaunchKernelGGL(sp_gram_reduce_kernel, dim3(kSgTile / 256, (unsigned)(njb * nkb)), dim3(256), 0, ctx->stream, part, (int)nblk, nkb, ms, r1, r2,
-                           ctx->small, ms);
+                           S->col_scale + S->m, ctx->small, ms);
         LF_LAUNCH_CHECK(ctx);
         LF_TRY(allreduce_dev(ctx, ctx->small, (int64_t)ms * ms, 0));
     }
@@ -559,7 +602,6 @@ int lfpsqp_spmat_create(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nnz, cons
     if (K > 256) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "spmat: a row with %d nonzeros (> 256): keep such constraint gradients dense", K);
     lfpsqp_spmat* S = new lfpsqp_spmat();
     S->n = n; S->m = m; S->nnz = nnz; S->K = K;
-    S->amax = amax;
     S->ld = round_up(n > 0 ? n : 1, kPadRows);
     const size_t ell = (size_t)std::max(K, 1) * (size_t)S->ld;
     std::vector<double> hv(ell, 0.0);
@@ -597,6 +639,23 @@ int lfpsqp_spmat_create(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nnz, cons
     dev_copy((void**)&S->colptr, colptr.data(), colptr.size() * sizeof(int64_t));
     dev_copy((void**)&S->chunk_beg, cb2.data(), cb2.size() * sizeof(int64_t));
     dev_copy((void**)&S->col_chunk, cchunk.data(), cchunk.size() * sizeof(int32_t));
+    // power-of-two column scales for the exact Gram accumulation: entrywise accuracy relative to the columns' own magnitudes, whatever their scaling
+    std::vector<double> cscale(2 * (size_t)std::max<int64_t>(m, 1), 1.0);
+    {
+        std::vector<double> cmax((size_t)std::max<int64_t>(m, 1), 0.0);
+        for (size_t k = 0; k < hcv.size() && k < hcol.size(); ++k)
+            if (fabs(hcv[k]) > cmax[(size_t)hcol[k]]) cmax[(size_t)hcol[k]] = fabs(hcv[k]);
+        for (int64_t j = 0; j < m; ++j) {
+            int e = 0;
+            if (cmax[(size_t)j] > 0.0 && cmax[(size_t)j] < 1e300) (void)frexp(cmax[(size_t)j], &e);      // cmax = f 2^e, f in [0.5, 1)
+            if (e > 400 || e < -400) amax = NAN;                // (sp_gram refuses; the scalings below stay finite)
+            e = std::max(-400, std::min(400, e));
+            cscale[(size_t)j] = ldexp(1.0, -e);
+            cscale[(size_t)m + (size_t)j] = ldexp(1.0, e);
+        }
+    }
+    dev_copy((void**)&S->col_scale, cscale.data(), cscale.size() * sizeof(double));
+    S->amax = amax;
     if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
     if (!ok) {
         lfpsqp_spmat_free(ctx, S);
@@ -609,7 +668,7 @@ int lfpsqp_spmat_create(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nnz, cons
 int lfpsqp_spmat_free(lfpsqp_ctx* ctx, lfpsqp_spmat* S) {
     if (!S) return 0;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    for (void* p : {(void*)S->ell_val, (void*)S->ell_col, (void*)S->csc_row, (void*)S->csc_val, (void*)S->colptr, (void*)S->chunk_beg, (void*)S->col_chunk})
+    for (void* p : {(void*)S->ell_val, (void*)S->ell_col, (void*)S->csc_row, (void*)S->csc_val, (void*)S->colptr, (void*)S->chunk_beg, (void*)S->col_chunk, (void*)S->col_scale})
         if (p) (void)hipFree(p);
     delete S;
     return 0;

@@ -179,7 +179,7 @@ def _exact_gram(A, w=None):
     return G
 
 
-@pytest.mark.parametrize("case", ["plain", "weighted", "ball_weighted", "two_tiles", "wide_range", "k6", "k11", "scattered"])
+@pytest.mark.parametrize("case", ["plain", "weighted", "ball_weighted", "two_tiles", "wide_range", "k6", "k11", "scattered", "slack_weight"])
 def test_gram_from_the_nonzeros_is_exact_and_order_independent(dev_ctx, case):
     """lfpsqp_spmat_gram: the scattered accumulation in two fixed-point limbs.  The device forms each term w_i v_a v_b in floating point (two
     roundings) and then sums EXACTLY: against exact rational arithmetic on the same rounded terms the result is the correctly rounded sum up
@@ -197,7 +197,11 @@ def test_gram_from_the_nonzeros_is_exact_and_order_independent(dev_ctx, case):
     if case == "wide_range":
         vals = vals * np.logspace(0, -9, m)[cols] * np.where(np.arange(vals.size) % 7 == 0, 1e3, 1.0)
     rng = np.random.default_rng(3)
-    w = rng.random(n) + 0.2 if case in ("weighted", "ball_weighted") else None
+    w = rng.random(n) + 0.2 if case in ("weighted", "ball_weighted", "slack_weight") else None
+    if case == "slack_weight":                       # a row without nonzeros (the slack row of a ball constraint) with a weight 2^40 times the others:
+        keep = rows != n - 1                         # the bound on the terms is measured over the rows that have nonzeros, so nothing is lost
+        rows, cols, vals = rows[keep], cols[keep], vals[keep]
+        w[n - 1] = 2.0 ** 40
     extra = 2 if case == "ball_weighted" else 0
     A = sp.coo_matrix((vals, (rows, cols)), shape=(n, m)).toarray()
     X = rng.standard_normal((n, extra))
@@ -223,8 +227,10 @@ def test_gram_from_the_nonzeros_is_exact_and_order_independent(dev_ctx, case):
     for (ja, jb), v in acc.items():
         Gx[ja, jb] = Gx[jb, ja] = float(v)
     Gs = G[:m, :m]
-    tmax = (np.abs(vals).max() ** 2) * (w.max() if w is not None else 1.0)
-    assert np.abs(Gs - Gx).max() <= 2.0 ** -52 * np.abs(Gx).max() * 0.51 + tmax * 2.0 ** -70 * n     # one rounding + the dropped limb
+    # one rounding + the dropped third limb, ENTRYWISE relative to the magnitudes of the two columns (power-of-two column scaling)
+    cmax = np.array([np.abs(vals[cols == j]).max() if np.any(cols == j) else 0.0 for j in range(m)])
+    wmax = w[:n - 1].max() if case == "slack_weight" else (w.max() if w is not None else 1.0)
+    assert np.all(np.abs(Gs - Gx) <= 2.0 ** -52 * np.abs(Gx) * 0.51 + 4.0 * wmax * np.outer(cmax, cmax) * 2.0 ** -70 * n)
     if case != "wide_range":
         np.testing.assert_array_equal(Gs, Gx)
     np.testing.assert_array_equal(Gs, Gs.T)
