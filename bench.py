@@ -489,12 +489,23 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     except Exception as e:      # diagnostics only
         sparse = {"error": repr(e)}
     rates = stream_rates(ctx, L, nbig=int(max(1 << 20, min(400_000_000, 40 * n_loc))))
-    return {"stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs": flop / gram_ms / 1e9,
+    return {"stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs_of_the_full_product": flop / gram_ms / 1e9,
+            "gram_TFLOPs_executed": flop * gram_tile_share(m) / gram_ms / 1e9,
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
             "nr_step_two_streams_ms": nr_ms["two_streams"], "nr_step_two_streams_GBs": gbs(nr2_bytes, nr_ms["two_streams"]),
             "nr_batch4_step_ms": nr_batch_ms, "nr_iters_timed": int(it), "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit),
-            "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies"}
+            "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies; the Gram kernel computes the upper "
+                    "triangle only (16 x 16 tiles on and above the diagonal): gram_TFLOPs_executed counts that work, ..._of_the_full_product 2 n m^2"}
+
+
+def gram_tile_share(m):
+    """Share of the 16 x 16 output tiles of an m x m product that the Gram kernel computes (the upper block triangle of 128-column panels,
+    inside a diagonal block its upper tile triangle)."""
+    npan = (m + 127) // 128
+    diag = npan * 36                 # 8 * 9 / 2 tiles of the 64 of a diagonal block
+    off = npan * (npan - 1) // 2 * 64
+    return (diag + off) / (npan * npan * 64.0)
 
 
 def placements(ctx, L, n, m, n_loc, r0, R=3, its=12):
