@@ -135,6 +135,10 @@ def main():
     # ... and with the Newton retraction: tangent setup, projected CG and every Newton step on the nonzeros of the shard
     xo, obj, lamk, ti = Psp.optimize(x0sp, L.LFPSQPParams(disp=L.DisplayOption.off, maxiter=3, do_project_retract=False))
     res.update(spn_x=xo, spn_obj=obj, spn_iter=ti.iter)
+    # the Gram matrix of the sharded sparse block from its nonzeros, weighted (the bound on the terms is a max-all-reduce, the sum of the
+    # ranks' exactly accumulated partial matrices a floating-point all-reduce)
+    wsp = ctx.vector(g1 - g0).hash_fill(7, g0, 0.4, 0.6)
+    res.update(sp_gram=Ssp.gram(w2=wsp), sp_gram_plain=Ssp.gram())
     np.savez(out, **res)
     dist.barrier()
     ctx.close()

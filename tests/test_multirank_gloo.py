@@ -196,4 +196,10 @@ def test_sharded_sparse_equalities_through_the_default_retraction(two_ranks):
     x = np.concatenate([a["spn_x"], b["spn_x"]])
     assert int(a["spn_iter"]) == int(b["spn_iter"]) == tir.iter
     assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
+    # lfpsqp_spmat_gram on the shards: replicated bit for bit, equal to the Gram matrix of the assembled block
+    w = 0.4 * synth.hash_vector(7, nsp) + 0.6
+    np.testing.assert_array_equal(a["sp_gram"], b["sp_gram"])
+    np.testing.assert_array_equal(a["sp_gram_plain"], b["sp_gram_plain"])
+    np.testing.assert_allclose(a["sp_gram"], A.T @ (w[:, None] * A), rtol=0, atol=1e-13 * np.abs(A.T @ A).max())
+    np.testing.assert_allclose(a["sp_gram_plain"], A.T @ A, rtol=0, atol=1e-13 * np.abs(A.T @ A).max())
     np.testing.assert_allclose(a["spn_obj"], objr, rtol=1e-10)
