@@ -339,6 +339,41 @@ def test_sparse_products_at_1e6_rows_against_the_dense_kernels():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [4, 7])
+def test_gram_from_the_nonzeros_at_1e6_rows(k):
+    """lfpsqp_spmat_gram at n = 1e6, m = 128 (both register-resident kernels: rows of 4 and of 7 nonzeros), weighted: equal to the MFMA Gram of
+    the dense copy to rounding, bit-identical under a permutation of the rows (which changes every run of equal column sets, every
+    workgroup's slice and the order of all atomics), and faster than the dense kernel."""
+    ctx = L.Context(0)
+    n, m = 1_000_000, 128
+    rows, cols, vals = banded(n, m, k)
+    rng = np.random.default_rng(12)
+    wh = rng.random(n) + 0.25
+    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+    w = ctx.vector(n, wh)
+    G = S.gram(w2=w)
+    Gd = L.gram(S.to_dense(), w2=w)
+    np.testing.assert_allclose(G, Gd, rtol=0, atol=1e-13 * np.abs(Gd).max())
+    np.testing.assert_array_equal(G, G.T)
+    perm = rng.permutation(n)
+    inv = np.empty(n, dtype=np.int64); inv[perm] = np.arange(n)
+    S2 = L.SparseMatrix(ctx, n, m, inv[rows], cols, vals)
+    G2 = S2.gram(w2=ctx.vector(n, wh[perm]))
+    np.testing.assert_array_equal(G2, G)
+    ms = {}
+    Jd = S.to_dense()
+    for name, fn in (("from_nonzeros", lambda: S.gram(w2=w)), ("scattered_rows", lambda: S2.gram(w2=w)), ("dense", lambda: L.gram(Jd, w2=w))):
+        fn()
+        ctx.timer_begin()
+        for _ in range(5):
+            fn()
+        ms[name] = ctx.timer_end() / 5
+    print("[sparse gram] ms:", {a: round(b, 4) for a, b in ms.items()})
+    assert ms["from_nonzeros"] < ms["dense"]
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ball", [False, True])
 def test_factorize_from_the_nonzeros_at_1e6_rows(ball):
     """Tangent setup of a banded Jct at n = 1e6, m = 128 (4 nonzeros per row; with a dense ball column: M = 129): lfpsqp_factorize_sp
