@@ -582,7 +582,7 @@ def cpu_baseline(ns, m, n_full):
     t0 = time.perf_counter()
     _, _, it, _ = port.projcg(a, U, b, None, 1e-300, k)
     dt = time.perf_counter() - t0
-    k = max(3, min(600, int(12.0 / (dt / k))))                 # ~12 s of CPU work
+    k = max(3, min(900, int(18.0 / (dt / k))))                 # 10-12 s of CPU work (the three calibration iterations run cold, ~1.6 x slower)
     t0 = time.perf_counter()
     _, _, it, _ = port.projcg(a, U, b, None, 1e-300, k)
     dt = time.perf_counter() - t0
