@@ -461,12 +461,26 @@ int lfpsqp_vec_download(lfpsqp_ctx* ctx, const lfpsqp_vec* v, int64_t offset, do
     return 0;
 }
 
+// Rows added to the leading dimension of every matrix (env LFPSQP_LD_SKEW, even, 0 .. 2046).  Rounded to whole 2048-row tiles alone, every column
+// would start on the same 16 KB phase, and the one-pass kernels -- whose wave instructions read 16 rows of FOUR neighbouring columns -- would
+// send the four 128-byte pieces of an instruction to addresses that agree in their low 14 bits.
+static int64_t mat_ld_skew() {
+    static const int64_t v = [] {
+        const char* e = getenv("LFPSQP_LD_SKEW");
+        int64_t s = e ? atoll(e) : kLdSkewDefault;
+        if (s < 0 || s > 2046) s = kLdSkewDefault;
+        return s & ~(int64_t)1;
+    }();
+    return v;
+}
+
 int lfpsqp_mat_alloc(lfpsqp_ctx* ctx, int64_t n, int64_t m, lfpsqp_mat** out) {
     LF_ARG(ctx, ctx != nullptr && out != nullptr && n >= 0 && m >= 0);
     lfpsqp_mat* M = new lfpsqp_mat();
     M->n = n;
     M->m = m;
     M->ld = round_up(n > 0 ? n : 1, kPadRows);
+    M->ld += mat_ld_skew();
     const size_t bytes = sizeof(double) * (size_t)M->ld * (size_t)(m > 0 ? m : 1);
     hipError_t e = dev_alloc((void**)&M->p, bytes);
     if (e != hipSuccess) { delete M; return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%lld x %lld matrix) failed: %s", (long long)n, (long long)m, hipGetErrorString(e)); }

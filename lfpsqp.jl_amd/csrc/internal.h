@@ -15,6 +15,8 @@ struct lfpsqp_vec {
     int64_t cap = 0;  // allocated doubles: n rounded up to whole tiles, padding kept finite
 };
 
+constexpr int64_t kLdSkewDefault = 16;  // rows (128 bytes); see mat_ld_skew (context.hip)
+
 struct lfpsqp_mat {
     double* p = nullptr;
     int64_t n = 0, m = 0;
