@@ -19,4 +19,4 @@ except Exception as e:
 PY
     echo "        factorize: $(LFPSQP_LD_SKEW=$sk python tools/time_factorize.py 1e7 128 2>&1 | tail -2 | head -1)"
   done
-done | tee gpurun_out/ldskew_ab.txt
+done | tee -a gpurun_out/ldskew_ab.txt
