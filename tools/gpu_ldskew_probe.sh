@@ -4,7 +4,7 @@
 #   gpurun -- bash tools/gpu_ldskew_probe.sh
 
 for rep in 1 2; do
-  for sk in 0 16 32 96 544 2080; do
+  for sk in 0 16 32 96 544 1040; do
     echo "== rep $rep: leading dimension + $sk rows"; LFPSQP_LD_SKEW=$sk timeout 150 python tools/placement_matrix_probe.py 3 4 2>&1 | grep "^round 1"
   done
 done | tee gpurun_out/ldskew_probe.txt
