@@ -10,8 +10,8 @@ lib = L.load_library(os.environ["LFPSQP_LIB"])
 lib.lib.lfpsqp_x_vec_skew.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
 ctx = L.Context(0, lib)
 n, m = 10_000_000, 128
-MB = 1 << 17                       # doubles per MB
-SLACK = 160 * MB
+MB = int(os.environ.get('SKEW_UNIT_DOUBLES', 1 << 17))      # doubles per step: 1 MB by default; 16 = one 128-byte line
+SLACK = 160 * (1 << 17)
 scale = 2.0 ** math.floor(math.log2(math.sqrt(3.0 / n)))
 Z = ctx.matrix(n, m).hash_fill(1, 0, n, scale)
 U = L.DeviceBasis(Z)
