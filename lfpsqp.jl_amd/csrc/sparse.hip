@@ -483,22 +483,34 @@ int sp_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0,
     const int ms = (int)S->m, mt = ms + nx;
     for (size_t e = 0; e < (size_t)mt * mt; ++e) G[e] = 0.0;
     if (mt == 0) return 0;
-    if (S->K > kmax) return LFPSQP_ERR_UNSUPPORTED;
+    // whether the exact accumulation is possible is a LOCAL property (row width, finite values) -- the ranks must agree on it before the first
+    // collective, or one would enter the dense Gram's all-reduce while the others enter this one's
+    double cannot = (S->K > kmax || !(S->amax == S->amax)) ? 1.0 : 0.0;
+    if (ctx->comm_active()) {
+        LF_HIP(ctx, hipMemcpyAsync(ctx->scal + 41, &cannot, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));       // (a stack variable)
+        LF_TRY(allreduce_dev(ctx, ctx->scal + 41, 1, 1));
+        LF_TRY(read_back(ctx, ctx->scal + 41, &cannot, 1));
+    }
+    if (cannot != 0.0) return LFPSQP_ERR_UNSUPPORTED;
     // |column-scaled value| < 1, so without weights every term is below 1; with weights the bound is measured (sp_gram_bound_kernel)
     double B = 1.0;
-    if (w2 && ms > 0 && S->n > 0) {
+    // (collectives are entered by every rank, also by one that holds no rows: only the kernel launches depend on the local row count)
+    if (w2 && ms > 0) {
         unsigned long long* slot = reinterpret_cast<unsigned long long*>(ctx->scal + 40);
         LF_HIP(ctx, hipMemsetAsync(slot, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(sp_gram_bound_kernel, dim3((unsigned)std::min<int64_t>((S->n + 1023) / 1024, 1024)), dim3(1024), 0, ctx->stream, S->ell_val,
-                           S->ell_col, S->ld, S->K, S->n, w2->p, S->col_scale, slot);
-        LF_LAUNCH_CHECK(ctx);
+        if (S->n > 0) {
+            hipLaunchKernelGGL(sp_gram_bound_kernel, dim3((unsigned)std::min<int64_t>((S->n + 1023) / 1024, 1024)), dim3(1024), 0, ctx->stream,
+                               S->ell_val, S->ell_col, S->ld, S->K, S->n, w2->p, S->col_scale, slot);
+            LF_LAUNCH_CHECK(ctx);
+        }
         LF_TRY(allreduce_dev(ctx, ctx->scal + 40, 1, 1));      // (every rank on the same grid)
         LF_TRY(read_back(ctx, ctx->scal + 40, &B, 1));
     }
-    if (!(S->amax == S->amax) || !(B == B) || B > 1e200 || (B != 0.0 && B < 1e-200)) return LFPSQP_ERR_UNSUPPORTED;
+    if (!(B == B) || B > 1e200 || (B != 0.0 && B < 1e-200)) return LFPSQP_ERR_UNSUPPORTED;      // (B is global: every rank decides alike)
     LF_TRY(ensure_small(ctx, (size_t)ms * ms + 16));
     LF_HIP(ctx, hipMemsetAsync(ctx->small, 0, sizeof(double) * (size_t)ms * ms, ctx->stream));
-    if (ms > 0 && B != 0.0 && S->n > 0) {
+    if (ms > 0 && B != 0.0) {
         int E = 0;
         (void)frexp(B, &E);                                   // B < 2^E
         E += 1;                                               // (one binade of slack for the rounding of the three-factor product)
@@ -514,21 +526,23 @@ int sp_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0,
         nblk = std::min<int64_t>(nblk, std::max<int64_t>((S->n + kSgThreads - 1) / kSgThreads, 1));
         LF_TRY(ensure_part(ctx, (size_t)njb * nkb * nblk * 2 * kSgTile + 8));
         unsigned long long* part = reinterpret_cast<unsigned long long*>(ctx->part);
-        const int64_t rows_per_wg = (S->n + nblk - 1) / nblk;
-        const dim3 grid((unsigned)nblk, (unsigned)(njb * nkb));
-        const double* w2p = w2 ? w2->p : nullptr;
-        if (S->K <= 4)
-            hipLaunchKernelGGL((sp_gram_kernel<4, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p,
-                               S->col_scale, s1, r1, s2, nkb, rows_per_wg, part);
-        else if (S->K <= 8)                                  // 72 limb sums per lane: two waves per SIMD
-            hipLaunchKernelGGL((sp_gram_kernel<8, 512>), grid, dim3(512), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p, S->col_scale, s1, r1,
-                               s2, nkb, rows_per_wg, part);
-        else
-            hipLaunchKernelGGL((sp_gram_kernel<0, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p,
-                               S->col_scale, s1, r1, s2, nkb, rows_per_wg, part);
-        hipLaunchKernelGGL(sp_gram_reduce_kernel, dim3(kSgTile / 256, (unsigned)(njb * nkb)), dim3(256), 0, ctx->stream, part, (int)nblk, nkb, ms, r1, r2,
-                           S->col_scale + S->m, ctx->small, ms);
-        LF_LAUNCH_CHECK(ctx);
+        if (S->n > 0) {
+            const int64_t rows_per_wg = (S->n + nblk - 1) / nblk;
+            const dim3 grid((unsigned)nblk, (unsigned)(njb * nkb));
+            const double* w2p = w2 ? w2->p : nullptr;
+            if (S->K <= 4)
+                hipLaunchKernelGGL((sp_gram_kernel<4, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p,
+                                   S->col_scale, s1, r1, s2, nkb, rows_per_wg, part);
+            else if (S->K <= 8)                                  // 72 limb sums per lane: two waves per SIMD
+                hipLaunchKernelGGL((sp_gram_kernel<8, 512>), grid, dim3(512), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p, S->col_scale, s1, r1,
+                                   s2, nkb, rows_per_wg, part);
+            else
+                hipLaunchKernelGGL((sp_gram_kernel<0, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p,
+                                   S->col_scale, s1, r1, s2, nkb, rows_per_wg, part);
+            hipLaunchKernelGGL(sp_gram_reduce_kernel, dim3(kSgTile / 256, (unsigned)(njb * nkb)), dim3(256), 0, ctx->stream, part, (int)nblk, nkb, ms, r1, r2,
+                               S->col_scale + S->m, ctx->small, ms);
+            LF_LAUNCH_CHECK(ctx);
+        }
         LF_TRY(allreduce_dev(ctx, ctx->small, (int64_t)ms * ms, 0));
     }
     std::vector<double> h((size_t)ms * ms + 1);

@@ -44,6 +44,15 @@ def main():
     ite, nre = L.projcg_(xe, lame, L.DiagOperator(0.0, ctx.vector(e1 - e0).hash_fill(3, e0, 4.0, 5.0)), L.DeviceBasis(Ze),
                          ctx.vector(e1 - e0).hash_fill(4, e0), None, tol=1e-10, maxit=300, n_global=ne)
     res.update(e0=e0, e1=e1, e_x=xe.download(), e_it=ite, e_S=Se, e_lam=lame.download())
+    # ... and a sparse block on the same sharding: the exact Gram accumulation's collectives (agreement, bound, sum) with an empty shard
+    ke = 2
+    rows_e = np.repeat(np.arange(ne), ke)
+    cols_e = (((np.arange(ne) * me) // ne)[:, None] + np.arange(ke)[None, :]) % me
+    vals_e = (np.random.default_rng(4).standard_normal((ne, ke)) + 2.0 * (np.arange(ke) == 0)).ravel()
+    sel_e = (rows_e >= e0) & (rows_e < e1)
+    Se_sp = L.SparseMatrix(ctx, e1 - e0, me, rows_e[sel_e] - e0, cols_e.ravel()[sel_e], vals_e[sel_e])
+    we = ctx.vector(e1 - e0).hash_fill(7, e0, 0.4, 0.6)
+    res.update(e_gram=Se_sp.gram(w2=we), e_gram_plain=Se_sp.gram())
     # ---- sharded config 3 through the outer driver (NR and ProjPenalty) ----------------------
     n3, m3 = 2800, 5
     q0, q1 = ctx.shard_range(n3)

@@ -129,6 +129,16 @@ def test_rank_with_zero_rows(two_ranks):
     assert int(a["e_it"]) == int(b["e_it"]) == i0 and len(b["e_x"]) == 0
     assert np.linalg.norm(a["e_x"] - x0) <= 1e-10 * np.linalg.norm(x0)
     np.testing.assert_array_equal(a["e_lam"], b["e_lam"])
+    # the sparse Gram matrix with an empty shard on rank 1
+    ke = 2
+    rows_e = np.repeat(np.arange(n), ke)
+    cols_e = (((np.arange(n) * m) // n)[:, None] + np.arange(ke)[None, :]) % m
+    vals_e = (np.random.default_rng(4).standard_normal((n, ke)) + 2.0 * (np.arange(ke) == 0)).ravel()
+    Ae = np.zeros((n, m)); np.add.at(Ae, (rows_e, cols_e.ravel()), vals_e)
+    we = 0.4 * synth.hash_vector(7, n) + 0.6
+    np.testing.assert_array_equal(a["e_gram"], b["e_gram"])
+    np.testing.assert_allclose(a["e_gram"], Ae.T @ (we[:, None] * Ae), rtol=0, atol=1e-13 * np.abs(Ae.T @ Ae).max())
+    np.testing.assert_allclose(a["e_gram_plain"], Ae.T @ Ae, rtol=0, atol=1e-13 * np.abs(Ae.T @ Ae).max())
 
 
 def test_sharded_ill_conditioned_factorize_and_operator_callback(two_ranks):
