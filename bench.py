@@ -154,8 +154,11 @@ def main(argv=None, lib=None):
     from lfpsqp_jl_amd.placement import best_projcg_buffers
     ncand = max(1, int(args.work_candidates))
     nbas = max(1, int(args.basis_candidates))
+    # one rank: while no pair reaches 0.81 of the HBM peak, up to three more allocations of the basis are tried (the count depends on local times)
+    f_target_ms = (8.0 * n_loc * m + 32.0 * n_loc + 8.0 * m) / (0.81 * 8.0e12) * 1e3
     Z, basis_desc, x, work, pinfo = best_projcg_buffers(ctx, make_basis, n_loc, m, A, b, n_global=n, nbasis=nbas, nwork=ncand,
-                                                        try_alternating=(world == 1))
+                                                        try_alternating=(world == 1),
+                                                        extend=(f_target_ms, 3) if (world == 1 and nbas > 1 and "emulator" not in ctx.device_name) else None)
     grid, bchosen, chosen = pinfo["grid"], pinfo["basis"], pinfo["work"]
     basis_ms = [min(row) for row in grid] if nbas > 1 else []
     trial_ms = list(grid[bchosen]) if ncand > 1 else []
@@ -275,6 +278,7 @@ def main(argv=None, lib=None):
                                       if ncand > 1 else {"candidates": 1}),
                    "basis_placement": ({"candidates": nbas, "trial_F_ms": [round(t, 4) for t in basis_ms], "chosen": bchosen,
                                         "trial_grid_F_ms": [[round(t, 4) for t in row] for row in grid],
+                                        "extra_basis_trials": pinfo.get("extra_basis_trials", 0), "extra_trials_while_F_above_ms": round(f_target_ms, 4),
                                         "residual_buffers": ("alternating" if pinfo.get("residual_buffers") else "in place"),
                                         "call_ms_per_iteration": pinfo.get("call_ms_per_iteration"),
                                         "note": "candidate allocations of the basis matrix (same contents) x the work-vector candidates: the fused kernel timed on every pair, "

@@ -11,12 +11,15 @@ from .projcg import DeviceBasis, ProjCGWork, projcg_
 
 
 def best_projcg_buffers(ctx: Context, make_basis, n_loc: int, m: int, A, b, *, n_global: int | None = None, nbasis: int = 3, nwork: int = 4,
-                        iters: int = 12, try_alternating: bool = False):
+                        iters: int = 12, try_alternating: bool = False, extend: tuple | None = None):
     """``make_basis()`` -> (DeviceMatrix, description): called ``nbasis`` times (same contents, new allocation each time).
     Returns (Z, description, x, work, info) with info = {"grid": F ms per (basis, work set), "basis": i, "work": j, "residual_buffers": 0 | 1}.
     ``try_alternating``: also time the alternating residual buffers on the chosen pair and leave the context in the faster scheme
     (single-rank use: the decision is taken from local wall times).
-    Every rank makes the same (collective-carrying) calls; the choice itself is local."""
+    ``extend = (target_ms, max_extra)``: while the best pair's F is above ``target_ms``, up to ``max_extra`` further basis allocations are tried
+    against every work set, one at a time (the loser of each comparison is freed at once).  Single-rank use as well: how many extra trials run
+    is decided from local times.
+    Every rank makes the same (collective-carrying) calls when neither option is used; the choice itself is local."""
     n_global = n_loc if n_global is None else n_global
     nbasis, nwork = max(1, int(nbasis)), max(1, int(nwork))
 
@@ -45,9 +48,27 @@ def best_projcg_buffers(ctx: Context, make_basis, n_loc: int, m: int, A, b, *, n
     for k, (Zk, _) in enumerate(bases):
         if k != bi:
             Zk.free()
+    info = {"grid": grid, "basis": bi, "work": wi, "residual_buffers": 0}
+    if extend is not None and nbasis * nwork > 1:
+        target_ms, max_extra = float(extend[0]), int(extend[1])
+        best = grid[bi][wi]
+        extra = 0
+        while best > target_ms and extra < max_extra:
+            pads.append(ctx.vector(3_000_017 * (nbasis + extra)))
+            Zn, descn = make_basis()
+            row = [trial(DeviceBasis(Zn), xk, wk) for xk, wk in cands]
+            grid.append(row)
+            extra += 1
+            j = min(range(nwork), key=lambda jj: row[jj])
+            if row[j] < best:
+                Z.free()
+                Z, desc, best, wi = Zn, descn, row[j], j
+                info.update(basis=nbasis + extra - 1, work=j)
+            else:
+                Zn.free()
+        info["extra_basis_trials"] = extra
     x, work = cands[wi]
     del pads
-    info = {"grid": grid, "basis": bi, "work": wi, "residual_buffers": 0}
     if try_alternating and nbasis * nwork > 1:
         # the alternating residual buffers (lfpsqp_ctx_set_residual_buffers) on the chosen pair: ~12 % faster when even the best pair is a
         # slow one, 2-4 % slower otherwise.  Compared by the wall time of whole calls (the sampled kernel time would alias with the
