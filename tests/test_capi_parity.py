@@ -233,7 +233,7 @@ def test_projcg_resume_continues_the_same_solve(dev_ctx, n, m, stack):
         L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=1, work=work, want_lambda=False, resume=True)
 
 
-@pytest.mark.parametrize("n,m", [(2100, 16), (1300, 300)])
+@pytest.mark.parametrize("n,m", [(2100, 16), (800, 260)])
 def test_projcg_residual_buffer_schemes_agree(dev_ctx, n, m):
     """lfpsqp_ctx_set_residual_buffers: the alternating scheme moves where the residual lives between iterations, never
     the arithmetic -- iterates, counts and residual norms are bit for bit those of the in-place scheme, with and without

@@ -260,7 +260,7 @@ def test_factorize_from_the_nonzeros_is_the_dense_factorisation(dev_ctx, case):
     always when a row has more than 8 nonzeros: wide_k, very_wide_k) Sigma / Vt / W are those of the dense factorisation bit for bit."""
     import os
     ctx = dev_ctx
-    n, m, k = (1500 if _is_emu(ctx) else 26000, 200, 4) if case == "two_panels" else (3100, 12 if case != "very_wide_k" else 40,
+    n, m, k = (1000 if _is_emu(ctx) else 26000, 200, 4) if case == "two_panels" else (3100, 12 if case != "very_wide_k" else 40,
                                                                                      {"wide_k": 9, "very_wide_k": 34}.get(case, 3))
     rows, cols, vals = banded(n, m, k, seed=8)
     if case == "ill_conditioned":                    # refinement rounds: several basis-forming products from the nonzeros
