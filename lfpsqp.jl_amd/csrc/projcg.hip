@@ -673,7 +673,8 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         U->A->m - U->SA->m <= 4 && !(c && m > 0)) {
         SA = U->SA;
         wm = (int)U->A->m;
-        LF_TRY(ensure_small(ctx, (size_t)wm * m + 2 * (size_t)wm + 64 + (stacked ? (size_t)N + 2 : 0)));
+        // (the scratch n-vector is read by whole tiles, like every n-vector of the library: padded to kPadRows, SpPlainV::load)
+        LF_TRY(ensure_small(ctx, (size_t)wm * m + 2 * (size_t)wm + 64 + (stacked ? (size_t)round_up(N, kPadRows) + 2 : 0)));
         dWs = ctx->small;
         tA = dWs + (((size_t)wm * m + 1) & ~(size_t)1);
         uA = tA + ((wm + 1) & ~1);

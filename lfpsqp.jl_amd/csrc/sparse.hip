@@ -569,9 +569,9 @@ int sp_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0,
             for (int j = 0; j < ms; ++j) G[(size_t)(ms + c) * mt + j] = G[(size_t)j * mt + ms + c] = ctx->h_m[j];
         }
         lfpsqp_vec va, vb;
-        va.p = const_cast<double*>(wx); va.n = va.cap = S->n;
+        va.p = const_cast<double*>(wx); va.n = S->n; va.cap = round_up(S->n, kPadRows);     // (scratch and matrix columns are both padded to whole tiles)
         for (int d = c; d < nx; ++d) {
-            vb.p = X->p + (int64_t)(x0 + d) * X->ld; vb.n = vb.cap = S->n;
+            vb.p = X->p + (int64_t)(x0 + d) * X->ld; vb.n = S->n; vb.cap = round_up(S->n, kPadRows);
             double dv = 0.0;
             LF_TRY(lfpsqp_dot(ctx, &va, &vb, &dv));
             G[(size_t)(ms + d) * mt + ms + c] = G[(size_t)(ms + c) * mt + ms + d] = dv;
@@ -711,7 +711,11 @@ int lfpsqp_spmat_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* 
     LF_ARG(ctx, ctx && S && G && (!w2 || w2->n == S->n) && (!Jct || (Jct->n == S->n && Jct->m >= S->m && Jct->m - S->m <= 4)));
     const int nx = Jct ? (int)(Jct->m - S->m) : 0;
     double* scratch = nullptr;
-    if (nx > 0 && w2) LF_HIP(ctx, hipMalloc((void**)&scratch, sizeof(double) * (size_t)(S->n > 0 ? S->n : 1)));
+    if (nx > 0 && w2) {     // an n-vector like any other: whole tiles (the vector kernels load row pairs up to the end of the last tile)
+        const size_t cap = (size_t)round_up(S->n > 0 ? S->n : 1, kPadRows);
+        LF_HIP(ctx, hipMalloc((void**)&scratch, sizeof(double) * cap));
+        LF_HIP(ctx, hipMemsetAsync(scratch, 0, sizeof(double) * cap, ctx->stream));
+    }
     const int rc = sp_gram(ctx, S, Jct, (int)S->m, nx, w2, scratch, G, 32);
     if (scratch) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(scratch); }
     if (rc == LFPSQP_ERR_UNSUPPORTED) return set_err(ctx, rc, "spmat_gram: rows wider than 32 nonzeros or values outside the exactly accumulable range");
