@@ -156,6 +156,11 @@ int lfpsqp_spmat_info(const lfpsqp_spmat* S, int64_t* n, int64_t* m, int64_t* nn
 /* t[0:m) = S' * v  (all-reduced over ranks);  y = alpha * S * t + beta * y */
 int lfpsqp_spmv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_vec* v, lfpsqp_vec* t);
 int lfpsqp_spmv_n(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, double alpha, const lfpsqp_vec* t, double beta, lfpsqp_vec* y);
+/* A second object with the STRUCTURE of S (same rows / columns, shared on the device) and its own copy of the values: the
+ * x-dependent constraint gradients diag(phi'(x)) A of lfpsqp_elementwise, rescaled in place by lfpsqp_spmat_rowscale. */
+int lfpsqp_spmat_clone(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, lfpsqp_spmat** out);
+/* dst.values = diag(v) * src.values (v: n-vector); dst is src itself or a clone of it */
+int lfpsqp_spmat_rowscale(lfpsqp_ctx* ctx, lfpsqp_spmat* dst, const lfpsqp_spmat* src, const lfpsqp_vec* v);
 /* M[:, 0:m) = S as a dense matrix (the tangent setup -- lfpsqp_factorize, whose basis Z is dense anyway -- and the Newton
  * retraction keep using the dense kernels) */
 int lfpsqp_spmat_to_dense(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, lfpsqp_mat* M);
@@ -358,7 +363,45 @@ typedef struct lfpsqp_constraints {
     int64_t slack_row;
     /* optional sparse form of Jct[:, 0:m_lin] (same entries): c! then streams its nonzeros instead of the dense block */
     const lfpsqp_spmat* Jsp;
+    /* optional: the first m_lin constraints are NONLINEAR (elementwise-transformed linear, below); NULL = linear */
+    const struct lfpsqp_elementwise* ew;
 } lfpsqp_constraints;
+
+/* Device-resident NONLINEAR equality constraints (problem classes beyond linear / ball / box) -- the contract
+ * of the reference's user callbacks c!(cval, x), jac!(J, cval, x) and of the constraint part of hess_lag_vec!
+ * (src/autodiff_generators.jl:72-107, entry src/optimize.jl:119) for constraints of the form
+ *
+ *     c(x) = A' phi(x) + qw * sum_{i < n_x} x_i^2 - b,        phi(x)_i = phi_{kind_i}(x_i),
+ *
+ * kind_i in {0: t, 1: sin t, 2: t^2} per VARIABLE (stored as doubles; NULL = all 0).  The reference's own nonlinear test
+ * systems are of this form: the sin system c_i = x_{2i} - sin x_{2i-1} (test/test_retractions.jl:34-54: A sparse with
+ * entries +-1, kind = sin on the odd variables) and the sphere system c_i = |x - center_i|^2 - R_i^2
+ * (test/test_retractions.jl:1-31: A = -2 [center_1 ... center_m], kind = NULL, qw = 1, b_i = R_i^2 - |center_i|^2).
+ * The constraint gradients are a ROW-SCALED copy of the constant A plus a rank-one term,
+ *     Jct(x) = diag(phi'(x)) A + 2 [x_i (i < n_x)] qw',
+ * refreshed in place by lfpsqp_constraints_jac (the reference's jac! fills J the same way every outer iteration); the
+ * constraint part of the Lagrangian Hessian is DIAGONAL, diag(phi''(x) .* (A lam)) + 2 (qw'lam) I_{i < n_x}
+ * (lfpsqp_constraints_hess_diag), so projcg! keeps its fused diagonal-operator path.  Every solver that takes an
+ * lfpsqp_constraints (lfpsqp_constraints_eval / _jac, lfpsqp_retract_nr, lfpsqp_retract_pp) honours `ew`; c! streams A
+ * (or its nonzeros) once with phi applied on the fly -- nothing n-sized crosses PCIe.
+ *   A    : constant n x m_lin coefficients (may be NULL when Asp is given).  lfpsqp_constraints.Jct is a DIFFERENT matrix
+ *          (>= m_lin columns).
+ *   Asp  : optional sparse form of A (same entries).  lfpsqp_constraints.Jsp must then be a structural clone
+ *          (lfpsqp_spmat_clone): lfpsqp_constraints_jac rescales its values and expands it into Jct[:, 0:m_lin).
+ *          With Asp, qw must be NULL (the rank-one term would make the gradients dense) and `work` is required.
+ *   qw   : host, m_lin weights of the common quadratic term, or NULL.  Not together with has_ball.
+ *   work : n-vector scratch (phi(x) for the sparse product). */
+typedef struct lfpsqp_elementwise {
+    const lfpsqp_mat* A;
+    const lfpsqp_spmat* Asp;
+    const lfpsqp_vec* kind;
+    const double* qw;
+    lfpsqp_vec* work;
+} lfpsqp_elementwise;
+/* hx[i] += phi''(x_i) (A lam)_i + 2 (qw'lam + [has_ball] lam[m_lin]) [i < n_x]   -- the diagonal of sum_j lam_j grad^2 c_j(x) added to
+ * the caller's diagonal of grad^2 f (hess_lag_vec!, src/autodiff_generators.jl:80-104, for this constraint class; for a linear
+ * class only the ball term remains).  lam: host, m_lin + has_ball.  Entries of hx beyond rows(Jct) are untouched. */
+int lfpsqp_constraints_hess_diag(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, const double* lam, lfpsqp_vec* hx);
 /* c!(cval, x): cval (host, m_lin + has_ball).  x has >= rows(Jct) entries (the x-half of a
  * stacked vector is fine). */
 int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval);

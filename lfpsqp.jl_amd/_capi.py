@@ -29,8 +29,13 @@ class IneqData(C.Structure):  # lfpsqp_ineq_data
     _fields_ = [("q", P), ("r", P), ("s", P), ("t", P), ("n", c_i64)]
 
 
+class Elementwise(C.Structure):  # lfpsqp_elementwise
+    _fields_ = [("A", P), ("Asp", P), ("kind", P), ("qw", P), ("work", P)]
+
+
 class Constraints(C.Structure):  # lfpsqp_constraints
-    _fields_ = [("Jct", P), ("m_lin", c_i64), ("b", P), ("has_ball", C.c_int), ("R2", c_dbl), ("n_x", c_i64), ("slack_row", c_i64), ("Jsp", P)]
+    _fields_ = [("Jct", P), ("m_lin", c_i64), ("b", P), ("has_ball", C.c_int), ("R2", c_dbl), ("n_x", c_i64), ("slack_row", c_i64), ("Jsp", P),
+                ("ew", C.POINTER(Elementwise))]
 
 
 CFUN = C.CFUNCTYPE(C.c_int, P, P, PD)
@@ -102,6 +107,9 @@ _SIGS = {
     "lfpsqp_q_gemv_n": [P, C.POINTER(Basis), c_dbl, P, P, c_dbl, P],
     "lfpsqp_constraints_eval": [P, C.POINTER(Constraints), P, PD],
     "lfpsqp_constraints_jac": [P, C.POINTER(Constraints), P, P, PD],
+    "lfpsqp_constraints_hess_diag": [P, C.POINTER(Constraints), P, PD, P],
+    "lfpsqp_spmat_clone": [P, P, C.POINTER(P)],
+    "lfpsqp_spmat_rowscale": [P, P, P, P],
     "lfpsqp_retract_nr": [P, C.POINTER(Basis), P, P, c_i64, C.POINTER(Constraints), CFUN, P, C.POINTER(IneqData), P, P, P, c_dbl, c_i64,
                           PD, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_retract_nr_batch": [P, C.POINTER(Basis), P, P, c_i64, C.POINTER(Constraints), C.POINTER(IneqData), C.c_int, C.POINTER(P), P,

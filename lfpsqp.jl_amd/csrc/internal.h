@@ -63,6 +63,9 @@ struct lfpsqp_ctx {
     double* d_m = nullptr;
     double* h_m = nullptr;
     size_t m_cap = 0;
+    // the weights of lfpsqp_elementwise's quadratic term (device, m_lin)
+    double* d_qw = nullptr;
+    size_t qw_cap = 0;
     // small device blocks: solver scalars / status, and their pinned host mirrors
     double* scal = nullptr;    // 64 doubles
     int64_t* istat = nullptr;  // 64 int64

@@ -407,7 +407,14 @@ __device__ __forceinline__ double swap_add(double x0, double x1) {
 #ifndef LFPSQP_OP_PIPE
 #define LFPSQP_OP_PIPE 1
 #endif
-constexpr bool kOpLacc = LFPSQP_OP_LACC != 0, kOpPipe = LFPSQP_OP_PIPE != 0;
+// ROWLATE: the next tile's row inputs (g, d, a ... of the row functor) are requested AFTER the next tile's matrix loads instead of before
+// them.  The vector cache returns a CU's loads in order (profiles/r03b_*: on slow allocation pairs TCP_LFIFO_STALL_CYCLES is +57 % at equal
+// traffic -- head-of-line blocking), so a slow row-input request ahead of 32 matrix loads holds all of them back; behind them it holds
+// nothing, and it is not needed before the first product (which waits for the matrix anyway) is done.
+#ifndef LFPSQP_OP_ROWLATE
+#define LFPSQP_OP_ROWLATE 0
+#endif
+constexpr bool kOpLacc = LFPSQP_OP_LACC != 0, kOpPipe = LFPSQP_OP_PIPE != 0, kOpRowLate = LFPSQP_OP_ROWLATE != 0;
 
 struct NoUni {};
 // a wave-uniform double forced into scalar registers
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
         }
         const int64_t row = row0 + lrow + (int64_t)k * kStep;
         typename EP::Row in_next = in;
-        if (MORE && kRowAhead) in_next = ep.fetch(ro + kStep * 8);
+        if (MORE && kRowAhead && !kOpRowLate) in_next = ep.fetch(ro + kStep * 8);
         double v[NV];
         const bool lead = !WIDE || wave == 0;
         ep.apply(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum);
@@ -562,7 +569,8 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
             if (MORE) load_cols(a, k + 1, 0, CPL);
         }
         ro += kStep * 8;
-        if (kRowAhead) in = in_next;
+        if (kRowAhead && kOpRowLate) { if (MORE) in = ep.fetch(ro); }
+        else if (kRowAhead) in = in_next;
         else if (MORE) in = ep.fetch(ro);   // big row records (batched trials): fetched after this tile's use, no second copy live
     };
 #pragma unroll 1

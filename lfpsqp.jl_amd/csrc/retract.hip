@@ -88,6 +88,11 @@ __device__ __forceinline__ void y_retract_one_nr(double& xn, double& yn, double 
     }
 }
 
+// Elementwise transforms of the nonlinear constraint class lfpsqp_elementwise (kind as a double code: 0: t, 1: sin t, 2: t^2)
+__device__ __forceinline__ double ew_phi(double k, double t) { return k == 0.0 ? t : (k == 1.0 ? sin(t) : t * t); }
+__device__ __forceinline__ double ew_phi1(double k, double t) { return k == 0.0 ? 1.0 : (k == 1.0 ? cos(t) : 2.0 * t); }
+__device__ __forceinline__ double ew_phi2(double k, double t) { return k == 0.0 ? 0.0 : (k == 1.0 ? -sin(t) : 2.0); }
+
 // Fused Newton-retraction step (src/retractions.jl:141-149): xnew += U*delta (stacked when bounds exist),
 // y_retract!, and the value handed to the c! product; one reduction term = the ball partial.
 struct NRStepE {
@@ -97,8 +102,10 @@ struct NRStepE {
     const double *sx, *sy;           // row scalings of the stacked basis
     const double *q, *r, *s, *t;     // InequalityData
     int64_t n_x, slack_row;          // ball term: sum_{i<n_x} x_i^2 - x[slack_row]  (slack_row < 0: none here)
-    int has_ball;
+    int has_ball;                    // (also set for the common quadratic term of lfpsqp_elementwise: the same partial sum)
     const int64_t* istat;            // NR status word: a finished retraction turns further launches into no-ops
+    const double* kind = nullptr;    // lfpsqp_elementwise: the c! product takes phi(xnew) instead of xnew  (two-stream / sparse step only)
+    double* phi_out = nullptr;       // ... stored here when the product is a separate (sparse) launch
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_NR_STATUS) != 0; }
     __device__ __forceinline__ double ball(int64_t i, double xi) const {
         return !has_ball ? 0.0 : (i < n_x ? xi * xi : (i == slack_row ? -xi : 0.0));
@@ -125,6 +132,15 @@ struct NRStepE {
         if (v0) b += ball(i, xn.x);
         if (v1) b += ball(i + 1, xn.y);
         red[0] += b;
+        if (kind) {
+            const double2 kk = ld2(kind + i);
+            xn.x = ew_phi(kk.x, xn.x);
+            xn.y = ew_phi(kk.y, xn.y);
+            if (phi_out) {
+                if (v1) st2(phi_out + i, xn);
+                else if (v0) phi_out[i] = xn.x;
+            }
+        }
         return make_double2(v0 ? xn.x : 0.0, v1 ? xn.y : 0.0);
     }
     // one-row form for the one-stream step kernel: the inputs of a row are fetched a tile ahead of their use.
@@ -207,6 +223,7 @@ struct NRSmall {
     int m, m_lin, has_ball, wm;
     double R2, tol;
     int64_t maxiter;
+    const double* qw = nullptr;   // m_lin weights of the common quadratic term (lfpsqp_elementwise) or nullptr
 };
 constexpr int kNRThreads = 1024;
 
@@ -236,7 +253,10 @@ __device__ void nr_small_trial(const NRSmall& s, int init) {
     const int m = s.m, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     __syncthreads();                                    // (a previous trial of a batch may still be reading the arrays)
-    for (int k = tid; k < m; k += kNRThreads) cnew[k] = (k < s.m_lin) ? (s.raw[k] - s.b[k]) : (ld_scal(s.raw_ball) - s.R2);
+    for (int k = tid; k < m; k += kNRThreads) {
+        if (k < s.m_lin) cnew[k] = s.qw ? fma(s.qw[k], ld_scal(s.raw_ball), s.raw[k]) - s.b[k] : (s.raw[k] - s.b[k]);   // (explicit fma: the host's cons_eval rounds alike)
+        else cnew[k] = ld_scal(s.raw_ball) - s.R2;
+    }
     __syncthreads();
     int64_t iter = init ? 0 : ld_stat(s.ist + 1);
     if (init) {
@@ -414,20 +434,153 @@ struct NRStepBatchRow {
     }
 };
 
-int cons_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval) {
+// ---- lfpsqp_elementwise: c(x) = A' phi(x) + qw * sum_{i<n_x} x_i^2 - b --------------------------------------------------------------
+// c! as the SAME launch shape as the two-stream Newton step (gemv_nt_kernel with an empty first product): the raw products and the
+// quadratic partial are then summed in the same order in both, so the cval a retraction returns is bit for bit c!(xnew)
+// (test/test_retractions.jl:97 asserts exactly that of the reference).
+struct EwEvalE {
+    const double* x;
+    const double* kind;              // nullptr: phi = identity
+    double* phi_out;                 // optional: phi(x) stored (the sparse product is a separate launch)
+    int64_t n_x, slack_row;
+    int has_ball;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double ball(int64_t i, double xi) const {
+        return !has_ball ? 0.0 : (i < n_x ? xi * xi : (i == slack_row ? -xi : 0.0));
+    }
+    __device__ __forceinline__ double2 apply(int64_t i, double2, bool v0, bool v1, double* red) const {
+        double2 a = ld2(x + i);
+        double b = 0.0;
+        if (v0) b += ball(i, a.x);
+        if (v1) b += ball(i + 1, a.y);
+        red[0] += b;
+        if (kind) {
+            const double2 kk = ld2(kind + i);
+            a.x = ew_phi(kk.x, a.x);
+            a.y = ew_phi(kk.y, a.y);
+        }
+        if (phi_out) {
+            if (v1) st2(phi_out + i, a);
+            else if (v0) phi_out[i] = a.x;
+        }
+        return make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0);
+    }
+};
+struct EwEvalVecF {   // the same as a plain row pass (sparse A: phi(x) -> work, quadratic partial)
+    EwEvalE e;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const { (void)e.apply(i, make_double2(0.0, 0.0), v0, v1, red); }
+};
+struct EwDerivF {     // out = phi'(x)  (row scales of the sparse constraint gradients)
+    const double *x, *kind;
+    double* out;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 a = ld2(x + i);
+        const double2 kk = kind ? ld2(kind + i) : make_double2(0.0, 0.0);
+        const double2 d = make_double2(ew_phi1(kk.x, a.x), ew_phi1(kk.y, a.y));
+        if (v1) st2(out + i, d);
+        else if (v0) out[i] = d.x;
+    }
+};
+// Jct[:, j] = phi'(x) .* A[:, j] + 2 qw_j x [i < n_x]   (jac! of the dense class: one read of A, one write of Jct)
+constexpr int kEwJacCols = 16;
+__global__ __launch_bounds__(kThreads) void ew_jac_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ J, int64_t ldj, int64_t n, int m,
+                                                          const double* __restrict__ x, const double* __restrict__ kind, const double* __restrict__ qw,
+                                                          int64_t n_x) {
+    const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 2;
+    if (i >= n) return;
+    const double2 a = ld2(x + i);
+    const double2 kk = kind ? ld2(kind + i) : make_double2(0.0, 0.0);
+    const double2 d = make_double2(ew_phi1(kk.x, a.x), ew_phi1(kk.y, a.y));
+    const double2 xq = make_double2(i < n_x ? 2.0 * a.x : 0.0, i + 1 < n_x ? 2.0 * a.y : 0.0);
+    const bool v1 = i + 1 < n;
+    const int j0 = blockIdx.y * kEwJacCols, j1 = (j0 + kEwJacCols < m) ? j0 + kEwJacCols : m;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const double2 c = ld2(A + (int64_t)j * lda + i);
+        const double w = qw ? qw[j] : 0.0;
+        const double2 o = make_double2(fma(d.x, c.x, w * xq.x), fma(d.y, c.y, w * xq.y));
+        if (v1) st2(J + (int64_t)j * ldj + i, o);
+        else J[(int64_t)j * ldj + i] = o.x;
+    }
+}
+struct EwHessE {      // hx[i] += phi''(x_i) * (A lam)_i + cq [i < n_x]       (GEMV-N consumer)
+    const double *x, *kind;
+    double* hx;
+    double cq;
+    int64_t n_x;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, double2 acc, bool v0, bool v1, double*) const {
+        const double2 a = ld2(x + i);
+        const double2 kk = kind ? ld2(kind + i) : make_double2(0.0, 0.0);
+        double2 h = ld2(hx + i);
+        h.x += ew_phi2(kk.x, a.x) * acc.x + (i < n_x ? cq : 0.0);
+        h.y += ew_phi2(kk.y, a.y) * acc.y + (i + 1 < n_x ? cq : 0.0);
+        if (v1) st2(hx + i, h);
+        else if (v0) hx[i] = h.x;
+    }
+};
+struct EwHessVecF {   // the same with (A lam) from the ELL entries, or without a product at all (R.t == nullptr: phi'' = 0 everywhere)
+    EwHessE e;
+    EllRows R;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        e.apply(i, R.t ? R.acc(i) : make_double2(0.0, 0.0), v0, v1, red);
+    }
+};
+
+// the m_lin weights of the quadratic term on the device (a buffer of its own: d_m / small are carved up by the callers)
+static int stage_qw(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const double** out) {
+    *out = nullptr;
+    if (!cons->ew || !cons->ew->qw || cons->m_lin == 0) return 0;
+    if ((size_t)cons->m_lin > ctx->qw_cap) {
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_qw) LF_HIP(ctx, hipFree(ctx->d_qw));
+        ctx->d_qw = nullptr; ctx->qw_cap = 0;
+        LF_HIP(ctx, hipMalloc((void**)&ctx->d_qw, sizeof(double) * (size_t)round_up(cons->m_lin, 64)));
+        ctx->qw_cap = (size_t)round_up(cons->m_lin, 64);
+    }
+    LF_HIP(ctx, hipMemcpyAsync(ctx->d_qw, cons->ew->qw, sizeof(double) * (size_t)cons->m_lin, hipMemcpyHostToDevice, ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));            // caller-owned pageable source
+    *out = ctx->d_qw;
+    return 0;
+}
+
+// raw[0:m_lin) = the constraint products (J x, or A' phi(x)), raw[m_lin] = sum_{i<n_x} x_i^2 - x[slack_row] (when the class has a ball or a
+// common quadratic term) -- device buffer, all-reduced, stream-ordered.  `x` has >= rows(Jct) entries.
+static int cons_raw(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const double* x, double* raw) {
     const lfpsqp_mat* J = cons->Jct;
     const int ml = (int)cons->m_lin;
+    const int64_t N = J->n;
+    const lfpsqp_elementwise* ew = cons->ew;
+    const bool quad = cons->has_ball || (ew && ew->qw);
+    if (ew) {
+        const EwEvalE ee{x, ew->kind ? ew->kind->p : nullptr, ew->Asp ? ew->work->p : nullptr, cons->n_x, cons->slack_row, quad ? 1 : 0};
+        if (ew->Asp) {
+            LF_TRY((run_vec<EwEvalVecF, 1, NoPost>(ctx, N, EwEvalVecF{ee}, 0u, raw + ml, NoPost())));
+            return spmv_t(ctx, ew->Asp, ew->work->p, raw);
+        }
+        return run_gemv_nt<EwEvalE, 1>(ctx, nullptr, 0, nullptr, ew->A, ml, N, ee, raw);
+    }
+    if (ml > 0 && cons->Jsp) LF_TRY(spmv_t(ctx, cons->Jsp, x, raw));                       // c! streams the nonzeros
+    else if (ml > 0) LF_TRY(run_gemv_t(ctx, J, ml, N, PlainVec{x}, raw));
+    if (cons->has_ball) LF_TRY((run_vec<BallF, 1, NoPost>(ctx, N, BallF{x, cons->n_x, cons->slack_row}, 0u, raw + ml, NoPost())));
+    return 0;
+}
+
+int cons_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval) {
+    const int ml = (int)cons->m_lin;
     const int mt = ml + (cons->has_ball ? 1 : 0);
-    LF_TRY(ensure_mvec(ctx, (size_t)mt + 8));
-    if (ml > 0 && cons->Jsp) LF_TRY(spmv_t(ctx, cons->Jsp, x->p, ctx->d_m));              // c! streams the nonzeros
-    else if (ml > 0) LF_TRY(run_gemv_t(ctx, J, ml, J->n, PlainVec{x->p}, ctx->d_m));
-    if (cons->has_ball)
-        LF_TRY((run_vec<BallF, 1, NoPost>(ctx, J->n, BallF{x->p, cons->n_x, cons->slack_row}, 0u, ctx->d_m + ml, NoPost())));
-    if (mt > 0) {
-        LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * mt, hipMemcpyDeviceToHost, ctx->stream));
+    const double* qw = cons->ew ? cons->ew->qw : nullptr;
+    LF_TRY(ensure_mvec(ctx, (size_t)ml + 9));
+    LF_TRY(cons_raw(ctx, cons, x->p, ctx->d_m));
+    if (ml + 1 > 0) {
+        LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * (ml + 1), hipMemcpyDeviceToHost, ctx->stream));
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    for (int j = 0; j < ml; ++j) cval[j] = ctx->h_m[j] - cons->b[j];
+    (void)mt;
+    for (int j = 0; j < ml; ++j) cval[j] = qw ? fma(qw[j], ctx->h_m[ml], ctx->h_m[j]) - cons->b[j] : (ctx->h_m[j] - cons->b[j]);
     if (cons->has_ball) cval[ml] = ctx->h_m[ml] - cons->R2;
     return 0;
 }
@@ -447,9 +600,18 @@ int nr_batch_step(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, int wm, int m
 using namespace lfpsqp;
 
 static bool cons_ok(const lfpsqp_constraints* c) {
-    return c && c->Jct && c->m_lin >= 0 && c->m_lin + (c->has_ball ? 1 : 0) <= c->Jct->m && (c->m_lin == 0 || c->b) &&
-           (!c->has_ball || (c->n_x >= 0 && c->n_x <= c->Jct->n && c->slack_row < c->Jct->n)) &&
-           (!c->Jsp || (c->Jsp->n == c->Jct->n && c->Jsp->m == c->m_lin));
+    if (!(c && c->Jct && c->m_lin >= 0 && c->m_lin + (c->has_ball ? 1 : 0) <= c->Jct->m && (c->m_lin == 0 || c->b) &&
+          (!c->has_ball || (c->n_x >= 0 && c->n_x <= c->Jct->n && c->slack_row < c->Jct->n)) &&
+          (!c->Jsp || (c->Jsp->n == c->Jct->n && c->Jsp->m == c->m_lin))))
+        return false;
+    const lfpsqp_elementwise* e = c->ew;
+    if (!e) return true;
+    return c->m_lin >= 1 && (e->Asp || e->A) && (!e->A || (e->A->p != c->Jct->p && e->A->n == c->Jct->n && e->A->m >= c->m_lin)) &&
+           (!e->kind || e->kind->n >= c->Jct->n) &&
+           (!e->qw || (!c->has_ball && !e->Asp && c->n_x >= 0 && c->n_x <= c->Jct->n)) &&
+           (!e->Asp || (c->Jsp && c->Jsp != e->Asp && e->Asp->n == c->Jct->n && e->Asp->m == c->m_lin && c->Jsp->ell_col == e->Asp->ell_col &&
+                        c->Jsp->csc_row == e->Asp->csc_row && e->work && e->work->n >= c->Jct->n)) &&
+           (e->Asp || !c->Jsp);
 }
 
 extern "C" {
@@ -461,10 +623,47 @@ int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, con
 
 int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval) {
     LF_ARG(ctx, ctx && cons_ok(cons) && x && Jct && cval && x->n >= cons->Jct->n && Jct->p == cons->Jct->p);
+    if (const lfpsqp_elementwise* ew = cons->ew) {             // Jct[:, :m_lin] = diag(phi'(x)) A + 2 x qw'
+        const int64_t N = Jct->n;
+        const int ml = (int)cons->m_lin;
+        if (ew->Asp) {
+            LF_TRY((run_vec<EwDerivF, 0, NoPost>(ctx, N, EwDerivF{x->p, ew->kind ? ew->kind->p : nullptr, ew->work->p}, 0u, nullptr, NoPost())));
+            LF_TRY(lfpsqp_spmat_rowscale(ctx, const_cast<lfpsqp_spmat*>(cons->Jsp), ew->Asp, ew->work));
+            LF_TRY(lfpsqp_spmat_to_dense(ctx, cons->Jsp, Jct));
+        } else if (N > 0) {
+            const double* dqw = nullptr;
+            LF_TRY(stage_qw(ctx, cons, &dqw));
+            hipLaunchKernelGGL(ew_jac_kernel, dim3((unsigned)((N + 2 * kThreads - 1) / (2 * kThreads)), (unsigned)((ml + kEwJacCols - 1) / kEwJacCols)),
+                               dim3(kThreads), 0, ctx->stream, ew->A->p, ew->A->ld, Jct->p, Jct->ld, N, ml, x->p, ew->kind ? ew->kind->p : nullptr, dqw,
+                               cons->n_x);
+            LF_LAUNCH_CHECK(ctx);
+        }
+    }
     if (cons->has_ball)
         LF_TRY((run_vec<BallColF, 0, NoPost>(ctx, Jct->n, BallColF{x->p, Jct->p + cons->m_lin * Jct->ld, cons->n_x, cons->slack_row}, 0u,
                                              nullptr, NoPost())));
     return cons_eval(ctx, cons, x, cval);
+}
+
+int lfpsqp_constraints_hess_diag(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, const double* lam, lfpsqp_vec* hx) {
+    LF_ARG(ctx, ctx && cons_ok(cons) && x && lam && hx && x->n >= cons->Jct->n && hx->n >= cons->Jct->n && hx->p != x->p);
+    const int64_t N = cons->Jct->n;
+    const int ml = (int)cons->m_lin;
+    const lfpsqp_elementwise* ew = cons->ew;
+    double cq = cons->has_ball ? 2.0 * lam[ml] : 0.0;
+    if (ew && ew->qw)
+        for (int j = 0; j < ml; ++j) cq += 2.0 * ew->qw[j] * lam[j];
+    const double* kind = (ew && ew->kind) ? ew->kind->p : nullptr;
+    const EwHessE he{x->p, kind, hx->p, cq, cons->n_x};
+    if (!kind) {                                               // phi'' = 0: only the constant of the quadratic terms
+        if (cq == 0.0) return 0;
+        return run_vec<EwHessVecF, 0, NoPost>(ctx, N, EwHessVecF{he, EllRows{nullptr, nullptr, 0, 0, nullptr}}, 0u, nullptr, NoPost());
+    }
+    LF_TRY(ensure_mvec(ctx, (size_t)ml + 8));
+    for (int j = 0; j < ml; ++j) ctx->h_m[j] = lam[j];
+    LF_HIP(ctx, hipMemcpyAsync(ctx->d_m, ctx->h_m, sizeof(double) * ml, hipMemcpyHostToDevice, ctx->stream));
+    if (ew->Asp) return run_vec<EwHessVecF, 0, NoPost>(ctx, N, EwHessVecF{he, ell_rows(ew->Asp, ctx->d_m)}, 0u, nullptr, NoPost());
+    return run_gemv_n<EwHessE, 0, NoPost>(ctx, ew->A, ml, N, ctx->d_m, he, nullptr, NoPost());
 }
 
 int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m64,
@@ -485,8 +684,10 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         const int64_t N = cons->Jct->n;
         const size_t mm = (size_t)m * m;
         // one-stream step: the caller vouches that U->Z == U->A * U->W and A is the matrix c! streams anyway
+        const lfpsqp_elementwise* ew = cons->ew;                  // nonlinear class: c! streams the constant A with phi(xnew), not Jct
+        const bool quad = cons->has_ball || (ew && ew->qw);
         const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kNRMaxM) ? (int)U->A->m : 0;
-        const int cwd = wm ? onepass_cw(ctx, wm, cons->Jct->ld, N) : 0;
+        const int cwd = (wm && !ew) ? onepass_cw(ctx, wm, cons->Jct->ld, N) : 0;
         // ... and with a sparse twin of the linear block (all but <= 4 of A's columns) the step runs on the nonzeros alone
         const lfpsqp_spmat* Ssp = (wm && ml > 0 && cons->Jsp && cons->Jsp->n == N && cons->Jsp->m == ml && wm >= ml && wm - ml <= 4) ? cons->Jsp : nullptr;
         const int cw = Ssp ? 1 : cwd;                 // (non-zero: the generator W and W*ddelta are kept on the device)
@@ -509,20 +710,25 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         volatile int64_t* hstat = ctx->h_istat;
         for (int k = 0; k < kNRRing; ++k) hstat[kNRRingOff + k] = 0;
         hstat[I_NR_STATUS] = 0;
-        const NRSmall sm{dD, dVt, dSig, db, dcval, ddelta, draw, draw + ml, cw ? dW : nullptr, dwdelta, ctx->istat + I_NR_STATUS,
-                         ctx->h_istat, m, ml, cons->has_ball ? 1 : 0, cw ? wm : 0, cons->R2, tol, maxiter};
+        NRSmall sm{dD, dVt, dSig, db, dcval, ddelta, draw, draw + ml, cw ? dW : nullptr, dwdelta, ctx->istat + I_NR_STATUS,
+                   ctx->h_istat, m, ml, cons->has_ball ? 1 : 0, cw ? wm : 0, cons->R2, tol, maxiter};
+        LF_TRY(stage_qw(ctx, cons, &sm.qw));
         LF_TRY(lfpsqp_vec_copy(ctx, xnew, xtilde));                                             // :116
         if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew, x, idata));                                // :118-120
-        if (Ssp) LF_TRY(spmv_t(ctx, Ssp, xnew->p, draw));                                        // c!(cval, xnew), raw products
-        else if (ml > 0) LF_TRY(run_gemv_t(ctx, cons->Jct, ml, N, PlainVec{xnew->p}, draw));
-        if (cons->has_ball)
-            LF_TRY((run_vec<BallF, 1, NoPost>(ctx, N, BallF{xnew->p, cons->n_x, cons->slack_row}, 0u, draw + ml, NoPost())));
+        LF_TRY(cons_raw(ctx, cons, xnew->p, draw));                                             // c!(cval, xnew), raw products
         hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sm, 1);
         LF_LAUNCH_CHECK(ctx);
         LF_HIP(ctx, hipEventRecord(ctx->ev_slot[0], ctx->stream));
-        const NRStepE ep{xnew->p, x->p, ineq ? lfpsqp_half_stride(N) : 0, ineq ? U->sx->p : nullptr, ineq ? U->sy->p : nullptr,
-                         ineq ? idata->q->p : nullptr, ineq ? idata->r->p : nullptr, ineq ? idata->s->p : nullptr,
-                         ineq ? idata->t->p : nullptr, cons->n_x, cons->slack_row, cons->has_ball ? 1 : 0, ctx->istat};
+        NRStepE ep{xnew->p, x->p, ineq ? lfpsqp_half_stride(N) : 0, ineq ? U->sx->p : nullptr, ineq ? U->sy->p : nullptr,
+                   ineq ? idata->q->p : nullptr, ineq ? idata->r->p : nullptr, ineq ? idata->s->p : nullptr,
+                   ineq ? idata->t->p : nullptr, cons->n_x, cons->slack_row, quad ? 1 : 0, ctx->istat};
+        if (ew) {
+            ep.kind = ew->kind ? ew->kind->p : nullptr;
+            ep.phi_out = ew->Asp ? ew->work->p : nullptr;      // (identity phi with a sparse A: the product reads xnew itself)
+            if (ew->Asp && !ep.kind) ep.phi_out = nullptr;
+        }
+        const lfpsqp_mat* cmat = ew ? ew->A : cons->Jct;          // the matrix of the c! product
+        const lfpsqp_spmat* csp = ew ? ew->Asp : Ssp;
         int64_t it = 0;
         bool done = false;
         while (!done && it < maxiter) {
@@ -530,11 +736,15 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
             if (Ssp) {
                 const NRSparseStepF sf{ep, ell_rows(Ssp, dwdelta), cons->Jct->p + (int64_t)ml * cons->Jct->ld, cons->Jct->ld, dwdelta + ml, wm - ml};
                 LF_TRY((run_vec<NRSparseStepF, 1, NoPost>(ctx, N, sf, 0u, draw + ml, NoPost())));
-                LF_TRY(spmv_t(ctx, Ssp, xnew->p, draw));
+                LF_TRY(spmv_t(ctx, csp, ep.phi_out ? ep.phi_out : xnew->p, draw));
             } else if (cw && ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<true>{ep}, draw)));
             else if (cw) LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<false>{ep}, draw)));
-            else if (cons->has_ball) LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
-            else LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, U->Z, m, ddelta, cons->Jct, ml, N, ep, draw)));
+            else if (ew && ew->Asp) {                             // sparse A without the generator hint: dense step over Z, sparse c!
+                LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, U->Z, m, ddelta, nullptr, 0, N, ep, draw + ml)));
+                if (quad) LF_TRY((run_vec<BallF, 1, NoPost>(ctx, N, BallF{xnew->p, cons->n_x, cons->slack_row}, 0u, draw + ml, NoPost())));   // (summed as c! sums it)
+                LF_TRY(spmv_t(ctx, csp, ep.phi_out ? ep.phi_out : xnew->p, draw));
+            } else if (quad || ew) LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, U->Z, m, ddelta, cmat, ml, N, ep, draw)));
+            else LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, U->Z, m, ddelta, cmat, ml, N, ep, draw)));
             hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sm, 0);
             LF_LAUNCH_CHECK(ctx);
             LF_HIP(ctx, hipEventRecord(ctx->ev_slot[(it + 1) & 3], ctx->stream));
@@ -588,7 +798,7 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
             h_delta[k] = -s;
         }
         LF_HIP(ctx, hipMemcpyAsync(tv.p, h_delta, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
-        if (!cfun) {
+        if (!cfun && !cons->ew) {
             // fused step: xnew += U tmp (:141), y_retract! (:145), and the c! products (:146/148) in one launch
             const int ml = (int)cons->m_lin;
             const int64_t N = cons->Jct->n;
@@ -642,7 +852,7 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
                             int64_t* iters) {
     LF_ARG(ctx, ctx && U && Sigma && Vt && xtilde && x && xnew && cval && flags && iters && m64 >= 1 && U->ncols == m64);
     LF_ARG(ctx, cons_ok(cons) && nb >= 2 && nb <= kNRBatchMax);
-    if (cons->Jsp) return LFPSQP_ERR_UNSUPPORTED;     // sparse constraint gradients: single steps on the nonzeros beat a shared dense pass
+    if (cons->Jsp || cons->ew) return LFPSQP_ERR_UNSUPPORTED;     // sparse constraint gradients: single steps on the nonzeros beat a shared dense pass; nonlinear class: one by one
     const int m = (int)m64;
     const bool ineq = idata != nullptr;
     LF_ARG(ctx, ineq == (U->Dx != nullptr));

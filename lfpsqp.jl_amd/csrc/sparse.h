@@ -17,6 +17,7 @@ struct lfpsqp_spmat {
     int64_t* colptr = nullptr;      // [m + 1] (device): nonzero range of a column
     int64_t* chunk_beg = nullptr;   // [nchunks + 1] (device): nonzero range of a chunk
     int32_t* col_chunk = nullptr;   // [m + 1] (device): chunk range of a column
+    bool owns_structure = true;     // false for lfpsqp_spmat_clone's objects: the index arrays belong to the original
 };
 
 namespace lfpsqp {

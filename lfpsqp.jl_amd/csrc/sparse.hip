@@ -682,9 +682,102 @@ int lfpsqp_spmat_create(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nnz, cons
 int lfpsqp_spmat_free(lfpsqp_ctx* ctx, lfpsqp_spmat* S) {
     if (!S) return 0;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    for (void* p : {(void*)S->ell_val, (void*)S->ell_col, (void*)S->csc_row, (void*)S->csc_val, (void*)S->colptr, (void*)S->chunk_beg, (void*)S->col_chunk, (void*)S->col_scale})
+    for (void* p : {(void*)S->ell_val, (void*)S->csc_val, (void*)S->col_scale})
         if (p) (void)hipFree(p);
+    if (S->owns_structure)
+        for (void* p : {(void*)S->ell_col, (void*)S->csc_row, (void*)S->colptr, (void*)S->chunk_beg, (void*)S->col_chunk})
+            if (p) (void)hipFree(p);
     delete S;
+    return 0;
+}
+
+// ---- x-dependent values on a fixed structure (lfpsqp_elementwise: Jct(x) = diag(phi'(x)) A) ------------------------------------------
+int lfpsqp_spmat_clone(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, lfpsqp_spmat** out) {
+    LF_ARG(ctx, ctx && S && out);
+    *out = nullptr;
+    lfpsqp_spmat* C = new lfpsqp_spmat(*S);
+    C->owns_structure = false;
+    C->ell_val = nullptr; C->csc_val = nullptr; C->col_scale = nullptr;
+    const size_t ell = (size_t)std::max(S->K, 1) * (size_t)S->ld, nz = (size_t)std::max<int64_t>(S->nnz, 1), cs = 2 * (size_t)std::max<int64_t>(S->m, 1);
+    bool ok = hipMalloc((void**)&C->ell_val, ell * sizeof(double)) == hipSuccess && hipMalloc((void**)&C->csc_val, nz * sizeof(double)) == hipSuccess &&
+              hipMalloc((void**)&C->col_scale, cs * sizeof(double)) == hipSuccess;
+    ok = ok && hipMemcpyAsync(C->ell_val, S->ell_val, ell * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+         hipMemcpyAsync(C->csc_val, S->csc_val, nz * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+         hipMemcpyAsync(C->col_scale, S->col_scale, cs * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+         hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (!ok) {
+        lfpsqp_spmat_free(ctx, C);
+        return set_err(ctx, LFPSQP_ERR_HIP, "spmat_clone: device allocation / copy failed");
+    }
+    *out = C;
+    return 0;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void sp_rowscale_ell_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t ld, int K, int64_t n,
+                                                              const double* __restrict__ v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double s = v[i];
+        for (int k = 0; k < K; ++k) dst[(int64_t)k * ld + i] = src[(int64_t)k * ld + i] * s;
+    }
+}
+// one workgroup per column: the CSC values of the column, its largest magnitude -> the power-of-two scales of sp_gram, and the global
+// maximum (bit pattern of a non-negative double, NaN above everything) for the finiteness test
+__global__ __launch_bounds__(256) void sp_rowscale_csc_kernel(const int64_t* __restrict__ colptr, const int32_t* __restrict__ row,
+                                                              const double* __restrict__ src, double* __restrict__ dst, const double* __restrict__ v,
+                                                              int m, double* __restrict__ cscale, unsigned long long* __restrict__ amax_bits) {
+    __shared__ double red[256];
+    const int j = blockIdx.x;
+    double mx = 0.0;
+    for (int64_t e = colptr[j] + threadIdx.x; e < colptr[j + 1]; e += 256) {
+        const double a = src[e] * v[row[e]];
+        dst[e] = a;
+        const double f = fabs(a);
+        mx = (f > mx || f != f) ? f : mx;
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            const double o = red[threadIdx.x + h];
+            if (o > red[threadIdx.x] || o != o) red[threadIdx.x] = o;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double c = red[0];
+        if (!(c == c) || c > 1e300) c = NAN;
+        int e = 0;
+        if (c == c && c > 0.0) (void)frexp(c, &e);
+        if (e > 400 || e < -400) c = NAN;
+        e = e > 400 ? 400 : (e < -400 ? -400 : e);
+        cscale[j] = ldexp(1.0, -e);
+        cscale[m + j] = ldexp(1.0, e);
+        unsigned long long bits;
+        memcpy(&bits, &c, sizeof(bits));
+        atomicMax(amax_bits, bits);
+    }
+}
+}  // namespace
+
+int lfpsqp_spmat_rowscale(lfpsqp_ctx* ctx, lfpsqp_spmat* dst, const lfpsqp_spmat* src, const lfpsqp_vec* v) {
+    LF_ARG(ctx, ctx && dst && src && v && v->n >= src->n && dst->n == src->n && dst->m == src->m && dst->nnz == src->nnz && dst->K == src->K &&
+                    dst->ell_col == src->ell_col && dst->csc_row == src->csc_row);
+    if (src->n > 0 && src->K > 0) {
+        hipLaunchKernelGGL(sp_rowscale_ell_kernel, dim3((unsigned)std::min<int64_t>((src->n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, src->ell_val,
+                           dst->ell_val, src->ld, src->K, src->n, v->p);
+        LF_LAUNCH_CHECK(ctx);
+    }
+    double amax = 0.0;
+    if (src->m > 0) {
+        unsigned long long* slot = reinterpret_cast<unsigned long long*>(ctx->scal + 42);
+        LF_HIP(ctx, hipMemsetAsync(slot, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(sp_rowscale_csc_kernel, dim3((unsigned)src->m), dim3(256), 0, ctx->stream, src->colptr, src->csc_row, src->csc_val, dst->csc_val,
+                           v->p, (int)src->m, dst->col_scale, slot);
+        LF_LAUNCH_CHECK(ctx);
+        LF_TRY(read_back(ctx, ctx->scal + 42, &amax, 1));
+    }
+    dst->amax = amax;
     return 0;
 }
 

@@ -304,6 +304,22 @@ class SparseMatrix:
         except Exception:
             pass
 
+    def clone(self) -> "SparseMatrix":
+        """A second object with this one's STRUCTURE (shared on the device: keep the original alive) and its own values
+        (lfpsqp_spmat_clone) -- the x-dependent constraint gradients of ElementwiseConstraints."""
+        c = object.__new__(SparseMatrix)
+        c.ctx, c.n, c.m, c.nnz, c.ell_width = self.ctx, self.n, self.m, self.nnz, self.ell_width
+        c._structure_of = self
+        h = P()
+        self.ctx.check(self.ctx.L.lfpsqp_spmat_clone(self.ctx.h, self.h, C.byref(h)))
+        c.h = h
+        return c
+
+    def rowscale_from(self, src: "SparseMatrix", v: "DeviceVector"):
+        """values = diag(v) * src.values (lfpsqp_spmat_rowscale)."""
+        self.ctx.check(self.ctx.L.lfpsqp_spmat_rowscale(self.ctx.h, self.h, src.h, v.h))
+        return self
+
     def to_dense(self, M: "DeviceMatrix | None" = None) -> "DeviceMatrix":
         M = M if M is not None else DeviceMatrix(self.ctx, self.n, self.m)
         self.ctx.check(self.ctx.L.lfpsqp_spmat_to_dense(self.ctx.h, self.h, M.h))

@@ -147,6 +147,35 @@ class SeparableLinearBallBox(QuadLinearBallBox):
         return np.concatenate([x0, [out.value - self.R2]]), np.concatenate([xl, [-np.inf]]), np.concatenate([xu, [0.0]])
 
 
+class SeparableElementwiseBox(SeparableLinearBallBox):
+    """The device-resident problem class with NONLINEAR equality constraints: a separable objective
+    (``kind`` / ``a`` / ``c`` as in :class:`SeparableLinearBallBox`) under ``cons``, an :class:`ElementwiseConstraints`
+    (c(x) = A' phi(x) + qw x'x - b: the reference's sin and sphere test systems and their relatives), with optional box
+    bounds.  f, grad!, c!, jac! and the diagonal Lagrangian Hessian phi_f''(x) + phi''(x) .* (A lam) + 2 qw'lam all run on the
+    device, so `optimize` keeps the fused projected-CG path and nothing n-sized crosses PCIe in the loop."""
+
+    def __init__(self, ctx: Context, cons, kind: int, a, c=0.0, xl=None, xu=None, n_global: Optional[int] = None):
+        n, m = cons.Jct.n, cons.m_lin
+        assert not cons.has_ball and cons.Jct.m == m
+        self.ctx, self.n, self.m, self.xc = ctx, n, m, 0.0
+        self.p = self.ploc = 0
+        self.N, self.M = n, m
+        self.Jct, self.R2, self.cons = cons.Jct, 0.0, cons
+        self.xl = None if xl is None else np.asarray(xl, dtype=np.float64)
+        self.xu = None if xu is None else np.asarray(xu, dtype=np.float64)
+        self.n_global = n if n_global is None else n_global
+        self.is_diagonal = True
+        self.kind = int(kind)
+        self.a_dev = None if np.isscalar(a) else ctx.vector(n, np.asarray(a, dtype=np.float64))
+        self.c_dev = None if np.isscalar(c) else ctx.vector(n, np.asarray(c, dtype=np.float64))
+        self.a0 = float(a) if np.isscalar(a) else 0.0
+        self.c0 = float(c) if np.isscalar(c) else 0.0
+
+    def diag_(self, hx: DeviceVector, x: DeviceVector, lam: np.ndarray):
+        self._sep(2, x, hx)
+        self.cons.hess_diag_(hx, x, lam)
+
+
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class Derivatives:

@@ -34,7 +34,10 @@ class DeviceConstraints:
 
     def _c(self):
         return _capi.Constraints(self.Jct.h, self.m_lin, self.b.ctypes.data, 1 if self.has_ball else 0, self.R2, self.n_x,
-                                 self.slack_row, self.Jsp.h if self.Jsp is not None else None)
+                                 self.slack_row, self.Jsp.h if self.Jsp is not None else None, self._ew_ptr())
+
+    def _ew_ptr(self):
+        return None
 
     def c_(self, cval: np.ndarray, x: DeviceVector):
         ctx = x.ctx
@@ -49,6 +52,77 @@ class DeviceConstraints:
         cc = self._c()
         ctx.check(ctx.L.lfpsqp_constraints_jac(ctx.h, C.byref(cc), x.h, Jct.h, cval.ctypes.data_as(_capi.PD)))
         return cval
+
+
+    def hess_diag_(self, hx: DeviceVector, x: DeviceVector, lam: np.ndarray):
+        """hx += the diagonal of sum_j lam_j grad^2 c_j(x) (lfpsqp_constraints_hess_diag): the ball term for this class,
+        phi'' .* (A lam) and the quadratic term for ElementwiseConstraints."""
+        ctx = x.ctx
+        cc = self._c()
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        assert lam.size >= self.m
+        ctx.check(ctx.L.lfpsqp_constraints_hess_diag(ctx.h, C.byref(cc), x.h, lam.ctypes.data_as(_capi.PD), hx.h))
+        return hx
+
+
+KIND_ID, KIND_SIN, KIND_SQUARE = 0, 1, 2
+
+
+class ElementwiseConstraints(DeviceConstraints):
+    """The device-resident NONLINEAR constraint class (lfpsqp_elementwise):
+
+        c(x) = A' phi(x) + qw * sum_{i < n_x} x_i^2 - b,      phi_i in {t, sin t, t^2} per variable (``kind``),
+
+    with constraint gradients Jct(x) = diag(phi'(x)) A + 2 x qw' refreshed in place by ``jac_`` (the reference's jac!,
+    src/autodiff_generators.jl:60-66) and a DIAGONAL Lagrangian-Hessian term (``hess_diag_``; hess_lag_vec!, :80-104).
+    Covers the reference's own nonlinear test systems (test/test_retractions.jl:1-54, see :func:`sin_system_constraints` /
+    :func:`sphere_system_constraints`).  ``A``: DeviceMatrix (n x m), or a SparseMatrix -- then c!, jac!, the tangent setup, the
+    Newton steps and the inner solves of ProjPenalty all stream the nonzeros.  ``Jct`` (n x (m + ball)) is the working matrix."""
+
+    def __init__(self, ctx, A, b, kind=None, qw=None, Jct: DeviceMatrix | None = None, has_ball: bool = False, R2: float = 0.0,
+                 n_x: int | None = None, slack_row: int = -1):
+        from .device import SparseMatrix
+        sparse = isinstance(A, SparseMatrix)
+        n, m = A.n, A.m
+        if Jct is None:
+            Jct = DeviceMatrix(ctx, n, m + (1 if has_ball else 0))
+        Jsp = A.clone() if sparse else None
+        super().__init__(Jct, m, b, has_ball=has_ball, R2=R2, n_x=(n if n_x is None else n_x), slack_row=slack_row, Jsp=Jsp)
+        self.A = None if sparse else A
+        self.Asp = A if sparse else None
+        if kind is None or isinstance(kind, DeviceVector):
+            self.kind = kind
+        else:
+            self.kind = ctx.vector(n, np.asarray(kind, dtype=np.float64))
+        self.qw = None if qw is None else np.ascontiguousarray(qw, dtype=np.float64)
+        assert self.qw is None or self.qw.size == m
+        self.work = ctx.vector(n) if sparse else None
+        self._ew = _capi.Elementwise(self.A.h if self.A is not None else None, self.Asp.h if self.Asp is not None else None,
+                                     self.kind.h if self.kind is not None else None,
+                                     self.qw.ctypes.data if self.qw is not None else None, self.work.h if self.work is not None else None)
+
+    def _ew_ptr(self):
+        return C.pointer(self._ew)
+
+
+def sin_system_constraints(ctx, n: int, m: int):
+    """generate_sin_system(n, m) of the reference's tests (test/test_retractions.jl:34-54) as a device-resident class:
+    c_i = x[2i+1] - sin(x[2i]) (0-based): two nonzeros per constraint, kind = sin on the even variables below 2m."""
+    from .device import SparseMatrix
+    i = np.arange(m)
+    A = SparseMatrix(ctx, n, m, np.concatenate([2 * i + 1, 2 * i]), np.concatenate([i, i]), np.concatenate([np.ones(m), -np.ones(m)]))
+    kind = np.zeros(n)
+    kind[0:2 * m:2] = KIND_SIN
+    return ElementwiseConstraints(ctx, A, np.zeros(m), kind=kind)
+
+
+def sphere_system_constraints(ctx, centers: np.ndarray, Rs: np.ndarray):
+    """generate_sphere_system of the reference's tests (test/test_retractions.jl:1-31): c_i = |x - center_i|^2 - R_i^2
+    = x'x - 2 center_i'x + |center_i|^2 - R_i^2  ->  A = -2 centers (n x m, dense), phi = identity, qw = 1."""
+    n, m = centers.shape
+    A = ctx.matrix(n, m, np.asfortranarray(-2.0 * centers))
+    b = Rs ** 2 - np.einsum("ij,ij->j", centers, centers)
+    return ElementwiseConstraints(ctx, A, b, qw=np.ones(m))
 
 
 class NRWork:

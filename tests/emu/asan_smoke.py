@@ -21,3 +21,19 @@ for dpr in (False,True):
     out=P.optimize(0.97*synth.hash_vector(2,n)+0.015,L.LFPSQPParams(do_project_retract=dpr,disp=L.DisplayOption.off,maxiter=2))
     print('opt',dpr,out[3].iter)
 print("ASAN RUN DONE")
+# bounds + ball + sparse twin (Jsp): the factored stacked basis with a dense extra column (round-2 advisor finding: its scratch n-vector)
+import scipy.sparse as sp
+Jh=Jct.download()[:n+1,:m]
+Jsp=L.SparseMatrix.from_scipy(ctx,sp.csr_matrix(Jh))
+P=L.QuadLinearBallBox(ctx,n,m,Jct,P0.eq.b,R2=P0.R2,xl=P0.xl,xu=P0.xu,Jsp=Jsp)
+for dpr in (False,True):
+    out=P.optimize(0.97*synth.hash_vector(2,n)+0.015,L.LFPSQPParams(do_project_retract=dpr,disp=L.DisplayOption.off,maxiter=2))
+    print('opt sparse twin',dpr,out[3].iter)
+G=Jsp.gram(Jct,ctx.vector(n+1).hash_fill(9,0,0.5,1.0))           # weighted Gram with a dense extra column (its scratch vector)
+# the nonlinear (elementwise) constraint class: sin system on the nonzeros, sphere system dense, through optimize
+for cons in (L.sin_system_constraints(ctx,301,7),):
+    prob=L.SeparableElementwiseBox(ctx,cons,0,1.0,0.3*synth.hash_vector(5,301),xl=-np.ones(301),xu=np.ones(301))
+    for dpr in (False,True):
+        out=prob.optimize(np.zeros(301),L.LFPSQPParams(do_project_retract=dpr,disp=L.DisplayOption.off,maxiter=2))
+        print('opt elementwise',dpr,out[3].iter)
+print("ASAN RUN 2 DONE")
