@@ -345,28 +345,6 @@ int lfpsqp_projcg_op(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, lfpsqp_
 int lfpsqp_ctx_stream(lfpsqp_ctx* ctx, void** stream);
 
 /* ---- retractions (src/retractions.jl) ---------------------------------------------- */
-/* Device-resident equality constraints of the BASELINE configs (SURVEY §8d):
- *     c(x) = [ J x - b ;  sum_{i < n_x} x_i^2 - R2 - x[slack_row] ]
- * Jct is the N x M constraint-gradient matrix (the reference's Jct, src/optimize.jl:190,284);
- * its first m_lin columns are the constant gradients of the linear equalities; when has_ball,
- * column m_lin is the ball gradient [2x; -1] (refreshed by lfpsqp_constraints_jac) and the
- * inequality x'x <= R2 has been turned into an equality with a slack variable
- * (src/optimize.jl:23-51).  n_x / slack_row are LOCAL row indices on this rank
- * (slack_row = -1 if another rank owns the slack variable). */
-typedef struct lfpsqp_constraints {
-    const lfpsqp_mat* Jct;
-    int64_t m_lin;
-    const double* b; /* host, m_lin */
-    int has_ball;
-    double R2;
-    int64_t n_x;
-    int64_t slack_row;
-    /* optional sparse form of Jct[:, 0:m_lin] (same entries): c! then streams its nonzeros instead of the dense block */
-    const lfpsqp_spmat* Jsp;
-    /* optional: the first m_lin constraints are NONLINEAR (elementwise-transformed linear, below); NULL = linear */
-    const struct lfpsqp_elementwise* ew;
-} lfpsqp_constraints;
-
 /* Device-resident NONLINEAR equality constraints (problem classes beyond linear / ball / box) -- the contract
  * of the reference's user callbacks c!(cval, x), jac!(J, cval, x) and of the constraint part of hess_lag_vec!
  * (src/autodiff_generators.jl:72-107, entry src/optimize.jl:119) for constraints of the form
@@ -398,6 +376,28 @@ typedef struct lfpsqp_elementwise {
     const double* qw;
     lfpsqp_vec* work;
 } lfpsqp_elementwise;
+/* Device-resident equality constraints of the BASELINE configs (SURVEY §8d):
+ *     c(x) = [ J x - b ;  sum_{i < n_x} x_i^2 - R2 - x[slack_row] ]
+ * Jct is the N x M constraint-gradient matrix (the reference's Jct, src/optimize.jl:190,284);
+ * its first m_lin columns are the constant gradients of the linear equalities; when has_ball,
+ * column m_lin is the ball gradient [2x; -1] (refreshed by lfpsqp_constraints_jac) and the
+ * inequality x'x <= R2 has been turned into an equality with a slack variable
+ * (src/optimize.jl:23-51).  n_x / slack_row are LOCAL row indices on this rank
+ * (slack_row = -1 if another rank owns the slack variable). */
+typedef struct lfpsqp_constraints {
+    const lfpsqp_mat* Jct;
+    int64_t m_lin;
+    const double* b; /* host, m_lin */
+    int has_ball;
+    double R2;
+    int64_t n_x;
+    int64_t slack_row;
+    /* optional sparse form of Jct[:, 0:m_lin] (same entries): c! then streams its nonzeros instead of the dense block */
+    const lfpsqp_spmat* Jsp;
+    /* optional: the first m_lin constraints are NONLINEAR (elementwise-transformed linear, above); NULL = linear */
+    const lfpsqp_elementwise* ew;
+} lfpsqp_constraints;
+
 /* hx[i] += phi''(x_i) (A lam)_i + 2 (qw'lam + [has_ball] lam[m_lin]) [i < n_x]   -- the diagonal of sum_j lam_j grad^2 c_j(x) added to
  * the caller's diagonal of grad^2 f (hess_lag_vec!, src/autodiff_generators.jl:80-104, for this constraint class; for a linear
  * class only the ball term remains).  lam: host, m_lin + has_ball.  Entries of hx beyond rows(Jct) are untouched. */

@@ -62,6 +62,13 @@ struct CIneqData               # lfpsqp_ineq_data
     t::Ptr{Cvoid}
     n::Int64
 end
+struct CElementwise            # lfpsqp_elementwise
+    A::Ptr{Cvoid}
+    Asp::Ptr{Cvoid}
+    kind::Ptr{Cvoid}
+    qw::Ptr{Float64}
+    work::Ptr{Cvoid}
+end
 struct CConstraints            # lfpsqp_constraints
     Jct::Ptr{Cvoid}
     m_lin::Int64
@@ -71,6 +78,7 @@ struct CConstraints            # lfpsqp_constraints
     n_x::Int64
     slack_row::Int64
     Jsp::Ptr{Cvoid}             # optional sparse form of Jct[:, 1:m_lin] (lfpsqp_spmat), C_NULL otherwise
+    ew::Ptr{CElementwise}       # optional: the first m_lin constraints are elementwise-transformed linear (nonlinear class), C_NULL otherwise
 end
 struct CPPWork                 # lfpsqp_pp_work
     r::Ptr{Cvoid}
@@ -152,6 +160,8 @@ c_spmat_info(S, n, m, nnz, k) = ccall((:lfpsqp_spmat_info, lib), Cint, (Ptr{Cvoi
 c_spmv_t(ctx, S, v, t) = ccall((:lfpsqp_spmv_t, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, S, v, t)
 c_spmv_n(ctx, S, a, t, b, y) = ccall((:lfpsqp_spmv_n, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}), ctx, S, a, t, b, y)
 c_spmat_to_dense(ctx, S, M) = ccall((:lfpsqp_spmat_to_dense, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, S, M)
+c_spmat_clone(ctx, S, out) = ccall((:lfpsqp_spmat_clone, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx, S, out)
+c_spmat_rowscale(ctx, dst, src, v) = ccall((:lfpsqp_spmat_rowscale, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, dst, src, v)
 c_spmat_gram(ctx, S, Jct, w2, G) = ccall((:lfpsqp_spmat_gram, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}), ctx, S, Jct, w2, G)
 # ---- bound manifolds -------------------------------------------------------------------------------------------------------
 c_half_stride(N) = ccall((:lfpsqp_half_stride, lib), Int64, (Int64,), N)
@@ -179,6 +189,7 @@ c_projcg_op(ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, i
     ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
 c_constraints_eval(ctx, cons, x, cval) = ccall((:lfpsqp_constraints_eval, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Float64}), ctx, cons, x, cval)
 c_constraints_jac(ctx, cons, x, Jct, cval) = ccall((:lfpsqp_constraints_jac, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), ctx, cons, x, Jct, cval)
+c_constraints_hess_diag(ctx, cons, x, lam, hx) = ccall((:lfpsqp_constraints_hess_diag, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), ctx, cons, x, lam, hx)
 c_retract_nr(ctx, U, Sigma, Vt, m, cons, cfun, cuser, idata, xtilde, x, xnew, tol, maxiter, cval, flag, iters) = ccall((:lfpsqp_retract_nr, lib), Cint,
     (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{CIneqData}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Ptr{Float64}, Ref{Cint}, Ref{Int64}),
     ctx, U, Sigma, Vt, m, cons, cfun, cuser, idata, xtilde, x, xnew, tol, maxiter, cval, flag, iters)
@@ -314,6 +325,16 @@ spmv_t!(t::DeviceVector, S::SparseMatrix, v::DeviceVector) = (check(t.ctx, c_spm
 spmv_n!(y::DeviceVector, S::SparseMatrix, t::DeviceVector, a::Real=1.0, b::Real=0.0) =
     (check(y.ctx, c_spmv_n(y.ctx.h, S.h, Float64(a), t.h, Float64(b), y.h)); y)                                                 # y = a S t + b y
 to_dense!(M::DeviceMatrix, S::SparseMatrix) = (check(M.ctx, c_spmat_to_dense(M.ctx.h, S.h, M.h)); M)
+# a second object with S's STRUCTURE (shared on the device: keep S alive) and its own values -- the x-dependent constraint gradients
+# diag(phi'(x)) A of ElementwiseConstraints, rescaled in place by rowscale!
+function clone(S::SparseMatrix)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(S.ctx, c_spmat_clone(S.ctx.h, S.h, r))
+    C = SparseMatrix(S.ctx, r[], S.n, S.m)
+    finalizer(x -> c_spmat_free(x.ctx.h, x.h), C)
+    return C
+end
+rowscale!(dst::SparseMatrix, src::SparseMatrix, v::DeviceVector) = (check(dst.ctx, c_spmat_rowscale(dst.ctx.h, dst.h, src.h, v.h)); dst)   # dst.values = Diagonal(v) * src.values
 # [S | Jct[:, m+1:end]]' * Diagonal(w2) * [S | ...] from the nonzeros, exactly accumulated (order-independent)
 function gram(S::SparseMatrix; Jct::Union{DeviceMatrix,Nothing}=nothing, w2::Union{DeviceVector,Nothing}=nothing)
     M = Jct === nothing ? S.m : Jct.m
@@ -522,10 +543,59 @@ struct DeviceConstraints
     n_x::Int
     slack_row::Int              # 0-based LOCAL row of the slack variable, -1 if another rank owns it
     Jsp::Ptr{Cvoid}             # optional SparseMatrix handle with the entries of Jct[:, 1:m_lin] (C_NULL: dense only)
+    ew::Any                     # nothing, or the Elementwise description that makes the first m_lin constraints nonlinear (below)
 end
-DeviceConstraints(Jct, m_lin, b, has_ball, R2, n_x, slack_row) = DeviceConstraints(Jct, m_lin, b, has_ball, R2, n_x, slack_row, C_NULL)
+DeviceConstraints(Jct, m_lin, b, has_ball, R2, n_x, slack_row) = DeviceConstraints(Jct, m_lin, b, has_ball, R2, n_x, slack_row, C_NULL, nothing)
+DeviceConstraints(Jct, m_lin, b, has_ball, R2, n_x, slack_row, Jsp::Ptr{Cvoid}) = DeviceConstraints(Jct, m_lin, b, has_ball, R2, n_x, slack_row, Jsp, nothing)
 nconstraints(c::DeviceConstraints) = c.m_lin + (c.has_ball ? 1 : 0)
-ccons(c::DeviceConstraints) = CConstraints(c.Jct.h, c.m_lin, pointer(c.b), c.has_ball ? 1 : 0, c.R2, c.n_x, c.slack_row, c.Jsp)
+ccons(c::DeviceConstraints) = CConstraints(c.Jct.h, c.m_lin, pointer(c.b), c.has_ball ? 1 : 0, c.R2, c.n_x, c.slack_row, c.Jsp,
+                                           c.ew === nothing ? Ptr{CElementwise}(C_NULL) : Base.unsafe_convert(Ptr{CElementwise}, c.ew.cref))
+
+# ---- the device-resident NONLINEAR constraint class (lfpsqp_elementwise): c(x) = A' phi(x) + qw * sum_{i<=n_x} x_i^2 - b -------------
+# phi elementwise per variable: kind 0: t, 1: sin t, 2: t^2.  Jct(x) = Diagonal(phi'(x)) A + 2 x qw' is refreshed in place by jac!, the
+# constraint part of the Lagrangian Hessian is diagonal (hess_diag!), c! streams A (or its nonzeros) once -- the contract of the reference's
+# c! / jac! / hess_lag_vec! (src/autodiff_generators.jl:72-107) without AD.  Covers the reference's own nonlinear test systems
+# (test/test_retractions.jl:1-54): sin_system_constraints, sphere_system_constraints.
+mutable struct Elementwise
+    A::Union{Nothing,DeviceMatrix}
+    Asp::Union{Nothing,SparseMatrix}
+    Jsp::Union{Nothing,SparseMatrix}       # clone of Asp holding the current gradients
+    kind::Union{Nothing,DeviceVector}
+    qw::Union{Nothing,Vector{Float64}}
+    work::Union{Nothing,DeviceVector}
+    cref::Base.RefValue{CElementwise}
+end
+function ElementwiseConstraints(ctx::HipContext, A::Union{DeviceMatrix,SparseMatrix}, b::Vector{Float64};
+                                kind::Union{Nothing,Vector{Float64}}=nothing, qw::Union{Nothing,Vector{Float64}}=nothing)
+    n, m = A.n, A.m
+    sparse = A isa SparseMatrix
+    Jct = DeviceMatrix(ctx, n, m)
+    Jsp = sparse ? clone(A) : nothing
+    kd = kind === nothing ? nothing : upload!(DeviceVector(ctx, n), kind)
+    work = sparse ? DeviceVector(ctx, n) : nothing
+    qwc = qw === nothing ? nothing : copy(qw)
+    cref = Ref(CElementwise(sparse ? C_NULL : A.h, sparse ? A.h : C_NULL, kd === nothing ? C_NULL : kd.h,
+                            qwc === nothing ? Ptr{Float64}(C_NULL) : pointer(qwc), work === nothing ? C_NULL : work.h))
+    ew = Elementwise(sparse ? nothing : A, sparse ? A : nothing, Jsp, kd, qwc, work, cref)
+    return DeviceConstraints(Jct, m, copy(b), false, 0.0, n, -1, sparse ? Jsp.h : C_NULL, ew)
+end
+# generate_sin_system(n, m) (test/test_retractions.jl:34-54): c_i = x[2i] - sin(x[2i-1])
+function sin_system_constraints(ctx::HipContext, n::Int, m::Int)
+    I = vcat(2 .* (1:m), 2 .* (1:m) .- 1); J = vcat(1:m, 1:m); V = vcat(ones(m), -ones(m))
+    kind = zeros(n); kind[1:2:2m] .= 1.0
+    return ElementwiseConstraints(ctx, SparseMatrix(ctx, n, m, collect(I), collect(J), V), zeros(m); kind=kind)
+end
+# generate_sphere_system (test/test_retractions.jl:1-31): c_i = |x - center_i|^2 - R_i^2 = x'x - 2 center_i'x + |center_i|^2 - R_i^2
+function sphere_system_constraints(ctx::HipContext, centers::Matrix{Float64}, Rs::Vector{Float64})
+    n, m = size(centers)
+    A = upload!(DeviceMatrix(ctx, n, m), -2.0 .* centers)
+    return ElementwiseConstraints(ctx, A, Rs .^ 2 .- vec(sum(abs2, centers; dims=1)); qw=ones(m))
+end
+# hx .+= diag of sum_j lam_j grad^2 c_j(x): phi''(x) .* (A lam) + 2 qw'lam (+ 2 lam_ball) on the user's variables
+function hess_diag!(c::DeviceConstraints, hx::DeviceVector, x::DeviceVector, λ::Vector{Float64})
+    GC.@preserve c check(x.ctx, c_constraints_hess_diag(x.ctx.h, Ref(ccons(c)), x.h, λ, hx.h))
+    return hx
+end
 function (c::DeviceConstraints)(cval::Vector{Float64}, x::DeviceVector)                       # c!(cval, x)
     GC.@preserve c check(x.ctx, c_constraints_eval(x.ctx.h, Ref(ccons(c)), x.h, cval))
     return cval
@@ -1283,6 +1353,36 @@ function optimize(P::SeparableLinearBallBox, x0::Vector{Float64}, param::LFPSQPP
     return x[1:B.n], obj, λ, info
 end
 
+# ---- device-resident class with NONLINEAR equalities: separable objective under ElementwiseConstraints, optional box bounds ----------
+struct SeparableElementwiseBox
+    ctx::HipContext
+    cons::DeviceConstraints     # from ElementwiseConstraints
+    kind::Int
+    a::DeviceVector
+    c::DeviceVector
+    xl::Union{Nothing,Vector{Float64}}
+    xu::Union{Nothing,Vector{Float64}}
+    n_global::Int
+end
+SeparableElementwiseBox(ctx::HipContext, cons::DeviceConstraints, kind::Int, a::Vector{Float64}, c::Vector{Float64}; xl=nothing, xu=nothing,
+                        n_global::Int=cons.Jct.n) =
+    SeparableElementwiseBox(ctx, cons, kind, upload!(DeviceVector(ctx, cons.Jct.n), a), upload!(DeviceVector(ctx, cons.Jct.n), c), xl, xu, n_global)
+function objective(P::SeparableElementwiseBox, x::DeviceVector)
+    out = Ref{Float64}(0.0)
+    check(P.ctx, c_separable(P.ctx.h, Cint(P.kind), Cint(0), P.a.h, 0.0, P.c.h, 0.0, x.h, Int64(P.cons.Jct.n), C_NULL, out))
+    return out[]
+end
+gradient!(P::SeparableElementwiseBox, g::DeviceVector, x::DeviceVector) =
+    (check(P.ctx, c_separable(P.ctx.h, Cint(P.kind), Cint(1), P.a.h, 0.0, P.c.h, 0.0, x.h, Int64(P.cons.Jct.n), g.h, Ptr{Float64}(C_NULL))); g)
+function hess_diag!(P::SeparableElementwiseBox, hx::DeviceVector, x::DeviceVector, λ::Vector{Float64})
+    check(P.ctx, c_separable(P.ctx.h, Cint(P.kind), Cint(2), P.a.h, 0.0, P.c.h, 0.0, x.h, Int64(P.cons.Jct.n), hx.h, Ptr{Float64}(C_NULL)))
+    return hess_diag!(P.cons, hx, x, λ)
+end
+function optimize(P::SeparableElementwiseBox, x0::Vector{Float64}, param::LFPSQPParams=LFPSQPParams())
+    return optimize_core(P.ctx, x -> objective(P, x), (g, x) -> gradient!(P, g, x), P.cons, (J, cv, x) -> jac!(P.cons, J, cv, x), P,
+                         x0, P.xl, P.xu, P.cons.m_lin, param; n_global=P.n_global)
+end
+
 # ---- the reference's method table with arbitrary HOST callables (src/optimize.jl:13, 83, 88, 107, 112, 119) --------------------
 # Iterates are downloaded for every user call: plumbing / small problems (config 1), not the 1e7-variable configs.
 # The AD generators (src/autodiff_generators.jl) stay where they are: pass their outputs (grad!, jac!, hess_lag_vec!) here.
@@ -1348,7 +1448,8 @@ optimize(ctx::HipContext, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, x0::V
 
 export HipContext, HipError, DeviceVector, StackedVector, DeviceMatrix, SparseMatrix, spmv_t!, spmv_n!, to_dense!, DeviceBasis, DiagOperator, InequalityData, InequalityDecomp,
        InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
-       ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, upload!, download, upload2!, download2, projcg!, retract!,
+       ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, SeparableElementwiseBox, ElementwiseConstraints,
+       sin_system_constraints, sphere_system_constraints, clone, rowscale!, upload!, download, upload2!, download2, projcg!, retract!,
        retract_nr_batch!, pcg!, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!,
        shard_range, sync
 

@@ -421,3 +421,85 @@ def test_config5_shape_two_ranks_share_the_gpu():
     assert d1["check"]["iters"] == d2["check"]["iters"] == 8
     assert abs(d1["check"]["x_norm"] - d2["check"]["x_norm"]) <= 1e-10 * d1["check"]["x_norm"]
     assert abs(d1["check"]["nr"] - d2["check"]["nr"]) <= 1e-8 * d1["check"]["nr"]
+
+
+# ---- the nonlinear (elementwise) constraint class at full size: size-independent properties ------------------------------
+def _ew_big(ctx, sparse):
+    n, m = N, M
+    kind = (np.arange(n) % 3).astype(np.float64)                     # t, sin t, t^2 in turn
+    if sparse:                                                        # four nonzeros per row, banded over the constraints
+        rows = np.repeat(np.arange(n, dtype=np.int64), 4)
+        cols = (np.repeat((np.arange(n, dtype=np.int64) * m) // n, 4) + np.tile(np.arange(4, dtype=np.int64), n)) % m
+        vals = np.cos(0.37 * np.arange(4 * n)) + 1.5
+        A = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+        cons = L.ElementwiseConstraints(ctx, A, np.zeros(m), kind=kind)
+    else:
+        A = ctx.matrix(n, m).hash_fill(21, 0, n, 2.0 ** -11)
+        cons = L.ElementwiseConstraints(ctx, A, np.zeros(m), kind=kind, qw=1e-7 * np.cos(np.arange(m)))
+    return cons, n, m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sparse", [False, True])
+def test_full_size_elementwise_constraints(sparse):
+    """c!, jac!, the Hessian diagonal and the Newton retraction of the nonlinear class at n = 1e7, m = 128: jac! is the derivative of c!
+    (central differences along a random direction), hess_diag! the derivative of jac!'lam, the retraction lands on c = 0 inside
+    range(U), and its cval is bit for bit c!(xnew) (test/test_retractions.jl:94-101 at full size)."""
+    ctx = L.Context(0)
+    cons, n, m = _ew_big(ctx, sparse)
+    x = ctx.vector(n).hash_fill(31, 0, 0.5, 0.0)
+    v = ctx.vector(n).hash_fill(32)
+    c0, cp, cm = np.zeros(m), np.zeros(m), np.zeros(m)
+    cons.jac_(cons.Jct, c0, x)
+    t = ctx.vector(m)
+    L.gemv_t(cons.Jct, v, t)
+    jv = t.download()
+    eps = 1e-5
+    xp, xm = ctx.vector(n), ctx.vector(n)
+    L.waxpby(1.0, x, eps, v, xp)
+    L.waxpby(1.0, x, -eps, v, xm)
+    cons.c_(cp, xp)
+    cons.c_(cm, xm)
+    np.testing.assert_allclose((cp - cm) / (2 * eps), jv, rtol=1e-6, atol=1e-6 * np.abs(jv).max())
+    # Hessian diagonal: d/deps [Jct(x + eps v) lam] = hdiag .* v
+    lam = np.cos(1.0 + np.arange(m))
+    lam_d = ctx.vector(m, lam)
+    gp, gm, hx, hv = ctx.vector(n), ctx.vector(n), ctx.vector(n), ctx.vector(n)
+    ctmp = np.zeros(m)
+    cons.jac_(cons.Jct, ctmp, xp)
+    L.gemv_n(cons.Jct, lam_d, gp)
+    cons.jac_(cons.Jct, ctmp, xm)
+    L.gemv_n(cons.Jct, lam_d, gm)
+    L.waxpby(1.0 / (2 * eps), gp, -1.0 / (2 * eps), gm, gp)                     # finite-difference Hessian-vector product
+    cons.hess_diag_(hx, x, lam)
+    L.vmul(hx, v, hv)
+    L.axpby(-1.0, hv, 1.0, gp)
+    assert L.nrm2(gp) <= 1e-6 * max(L.nrm2(hv), 1.0)
+    # Newton retraction from a tangent step
+    cons.jac_(cons.Jct, c0, x)
+    cons.b = cons.b + c0                                                         # make x feasible
+    Z = ctx.matrix(n, m)
+    W = np.zeros((m, m), order='F')
+    S, Vt, rank = L.ksvd_(cons.Jct, Z, W=W, Jsp=cons.Jsp)
+    assert rank == m
+    step = ctx.vector(n).hash_fill(33)
+    L.gemv_t(Z, step, t)
+    L.gemv_n(Z, t, step, -1.0, 1.0)
+    xt, xnew = ctx.vector(n), ctx.vector(n)
+    L.waxpby(1.0, x, 30.0 / L.nrm2(step), step, xt)                             # (a step long enough to leave the manifold by >> tol)
+    nr = L.NR(L.DeviceBasis(Z, generator=(cons.Jct, W)), S, Vt, 1e-9, 100, L.NRWork(m), False, None)
+    cval, cval2 = np.zeros(m), np.zeros(m)
+    ctx.sync()
+    import time
+    t0 = time.perf_counter()
+    flag, it, _ = L.retract_(cval, xnew, cons, xt, x, nr)
+    dt = time.perf_counter() - t0
+    cons.c_(cval2, xnew)
+    assert flag == 0 and 0 < it < 30 and np.abs(cval).max() < 1e-9
+    np.testing.assert_array_equal(cval, cval2)
+    L.waxpby(1.0, xnew, -1.0, xt, gp)                                            # the correction lies in range(U)
+    L.gemv_t(Z, gp, t)
+    L.gemv_n(Z, t, gp, -1.0, 1.0)
+    assert L.nrm2(gp) < 1e-9
+    print(f"[elementwise n=1e7 m=128 {'sparse' if sparse else 'dense'}] Newton retraction: {it} iterations, {dt * 1e3 / max(it, 1):.2f} ms per iteration")
+    ctx.close()

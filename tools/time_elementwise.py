@@ -1,0 +1,50 @@
+"""Seconds per call / per outer iteration of the device-resident nonlinear constraint class at full size (n = 1e7, m = 128, one MI355X):
+c!, jac!, hess_diag!, tangent setup, and an `optimize` run (f = |x - target|^2) with the Newton and the ProjPenalty retraction.
+    python tools/time_elementwise.py [dense|sparse] > gpurun_out/elementwise_<kind>.json"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import lfpsqp_jl_amd as L
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from tests.test_gpu_fullsize import _ew_big
+
+sparse = len(sys.argv) > 1 and sys.argv[1] == "sparse"
+ctx = L.Context(0)
+cons, n, m = _ew_big(ctx, sparse)
+x = ctx.vector(n).hash_fill(31, 0, 0.5, 0.0)
+cv = np.zeros(m)
+
+
+def timed(fn, reps=5):
+    fn(); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+out = {"n": n, "m": m, "A": "sparse, 4 nonzeros per row" if sparse else "dense", "device": ctx.device_name}
+out["c_ms"] = timed(lambda: cons.c_(cv, x))
+out["jac_ms"] = timed(lambda: cons.jac_(cons.Jct, cv, x))
+hx = ctx.vector(n)
+lam = np.cos(1.0 + np.arange(m))
+out["hess_diag_ms"] = timed(lambda: cons.hess_diag_(hx, x, lam))
+Z = ctx.matrix(n, m); W = np.zeros((m, m), order='F')
+out["tangent_setup_ms"] = timed(lambda: L.ksvd_(cons.Jct, Z, W=W, Jsp=cons.Jsp), 3)
+Z.free()
+cons.jac_(cons.Jct, cv, x)
+cons.b = cons.b + cv                       # x feasible; the optimum of |x - target|^2 on the manifold lies nearby
+target = ctx.vector(n).hash_fill(41, 0, 0.5, 0.0)
+L.axpby(0.98, x, 0.02, target)
+for name, dpr in (("newton", False), ("projpenalty", True)):
+    prob = L.SeparableElementwiseBox(ctx, cons, 0, 1.0, target.download())
+    tr = []
+    t0 = time.perf_counter()
+    xs, obj, lamk, ti = prob.optimize(x.download(), L.LFPSQPParams(do_project_retract=dpr, maxiter=8, disp=L.DisplayOption.off), trace=tr)
+    dt = time.perf_counter() - t0
+    out["optimize_" + name] = {"outer_iterations": ti.iter, "condition": ti.condition.name, "seconds": dt,
+                               "seconds_per_outer_iteration": dt / max(ti.iter, 1), "objective": [float(v) for v in obj],
+                               "retraction_iterations": [d.get("retract_iter1") for d in tr], "tn_iterations": [d.get("tn_iter") for d in tr],
+                               "cmax_final": float(np.abs(tr[-1]["cval"]).max())}
+print(json.dumps(out, indent=1))
