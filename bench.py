@@ -44,12 +44,14 @@ def main(argv=None, lib=None):
                          "host-gloo (functional test only: ranks may share one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device index (default: LOCAL_RANK)")
     ap.add_argument("--lib", default=None, help="(development) alternative build of liblfpsqp_hip.so to load")
-    ap.add_argument("--work-candidates", type=int, default=4,
-                    help="allocate this many candidate sets of the solver's work vectors (x, g, d, rp), time the fused kernel briefly on each "
-                         "(untimed, before the warm-up) and keep the fastest: where a set of n-vectors lands in physical memory decides between "
-                         "1.63 and 1.93 ms for that kernel (tools/work_placement_probe.py).  1 = take the first allocation")
-    ap.add_argument("--basis-candidates", type=int, default=3,
-                    help="likewise for the basis matrix: this many allocations of it, the fused kernel timed on each, the fastest kept (1 = first)")
+    ap.add_argument("--placement", choices=["library", "first", "grid"], default="library",
+                    help="where the basis and the solver's n-vectors are allocated decides between two speeds of the fused kernel (DESIGN.md 6). "
+                         "library (default): the library's own policy -- lfpsqp_mat_alloc_placed / lfpsqp_vecs_alloc_placed, what optimize() uses; "
+                         "first: plain first allocations (policy off); grid: the round-2 harness (every pair of --basis-candidates x "
+                         "--work-candidates allocations timed from Python, the fastest kept) for comparison")
+    ap.add_argument("--placement-tries", type=int, default=3, help="candidate allocations per placed buffer (lfpsqp_ctx_set_placement)")
+    ap.add_argument("--work-candidates", type=int, default=4, help="--placement grid: candidate sets of the work vectors")
+    ap.add_argument("--basis-candidates", type=int, default=3, help="--placement grid: candidate allocations of the basis")
     ap.add_argument("--watchdog-seconds", type=float, default=1500.0,
                     help="dump every thread's Python stack to stderr and exit non-zero if the run takes longer (0 = off): a stalled "
                          "rendezvous or collective then fails with a diagnosis instead of hanging the caller")
@@ -135,8 +137,8 @@ def main(argv=None, lib=None):
     n_loc = r1 - r0
 
     # ---- workload, generated on the device -------------------------------
-    def make_basis():
-        Zc = ctx.matrix(n_loc, m)
+    def make_basis(placed=False, Zc=None):
+        Zc = Zc if Zc is not None else ctx.matrix(n_loc, m, placed=placed)
         if args.basis == "orthonormal" and hasattr(L, "orthonormalize_"):
             Zc.hash_fill(1, r0, n, 1.0)
             L.orthonormalize_(Zc, n_global=n)
@@ -144,24 +146,53 @@ def main(argv=None, lib=None):
         Zc.hash_fill(1, r0, n, 2.0 ** math.floor(math.log2(math.sqrt(3.0 / n))))
         return Zc, "scaled hash matrix (columns orthonormal to O(sqrt(m/n)))"
 
-    A = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.0, 5.0))
     b = ctx.vector(n_loc).hash_fill(4, r0)
-    # Placement candidates.  Where the basis and the work vectors land in memory decides between 1.63 and 1.93 ms for the fused kernel
-    # (three allocations of the basis in one process measured 1.92 / 1.92 / 1.68 ms with every work set; another day six work
-    # sets under one basis 1.93 x 4 / 1.63 x 2; and which allocation of the one is fast can depend on the other).  So: a few allocations of
-    # each, the fused kernel timed briefly on every pair (untimed, before the warm-up), the fastest pair kept (lfpsqp_jl_amd.placement).
-    # Every rank makes the same number of (collective-carrying) trial calls; the choice is local.
-    from lfpsqp_jl_amd.placement import best_projcg_buffers
-    ncand = max(1, int(args.work_candidates))
-    nbas = max(1, int(args.basis_candidates))
-    # one rank: while no pair reaches 0.81 of the HBM peak, up to three more allocations of the basis are tried (the count depends on local times)
-    f_target_ms = (8.0 * n_loc * m + 32.0 * n_loc + 8.0 * m) / (0.81 * 8.0e12) * 1e3
-    Z, basis_desc, x, work, pinfo = best_projcg_buffers(ctx, make_basis, n_loc, m, A, b, n_global=n, nbasis=nbas, nwork=ncand,
-                                                        try_alternating=(world == 1),
-                                                        extend=(f_target_ms, 3) if (world == 1 and nbas > 1 and "emulator" not in ctx.device_name) else None)
-    grid, bchosen, chosen = pinfo["grid"], pinfo["basis"], pinfo["work"]
-    basis_ms = [min(row) for row in grid] if nbas > 1 else []
-    trial_ms = list(grid[bchosen]) if ncand > 1 else []
+    # Placement.  Where the basis and the work vectors land in memory decides between two speeds of the fused kernel, 10-15 % apart (DESIGN.md 6;
+    # a property of the PAIR of allocations).  Default: the library's own policy, the one optimize() uses -- the basis from
+    # lfpsqp_mat_alloc_placed, ProjCGWork and the operator diagonal from lfpsqp_vecs_alloc_placed (candidate allocations, the fused kernel
+    # timed on each, the fastest kept; every rank makes the same calls, the choice is local).
+    emulated = "emulator" in ctx.device_name
+
+    def f_ms_on(Uk, Ak, xk, wk, iters=12, warm=400):
+        # (a GPU coming out of idle runs its first ~second several per cent slower: `warm` untimed iterations first)
+        L.projcg_(xk, None, Ak, Uk, b, None, tol=1e-300, maxit=max(2, warm), work=wk, n_global=n, want_lambda=False)
+        ctx.set_profiling(True)
+        L.projcg_(xk, None, Ak, Uk, b, None, tol=1e-300, maxit=iters, work=wk, n_global=n, want_lambda=False)
+        pms, pcnt = ctx.profile_read()
+        ctx.set_profiling(False)
+        slot = 3 if pcnt[3] > 0 else 2
+        return pms[slot] / pcnt[slot] if pcnt[slot] else float("nan")
+
+    placement = {"policy": args.placement}
+    first_probe = None          # (trial time of the FIRST allocations, trial time of the kept ones): what the policy changed
+    if args.placement == "grid":
+        from lfpsqp_jl_amd.placement import best_projcg_buffers
+        ctx.set_placement(1)
+        A = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.0, 5.0))
+        ncand, nbas = max(1, int(args.work_candidates)), max(1, int(args.basis_candidates))
+        Z, basis_desc, x, work, pinfo = best_projcg_buffers(ctx, make_basis, n_loc, m, A, b, n_global=n, nbasis=nbas, nwork=ncand,
+                                                            try_alternating=(world == 1))
+        flat = sorted(t for row in pinfo["grid"] for t in row)
+        first_probe = (pinfo["grid"][0][0], pinfo["grid"][pinfo["basis"]][pinfo["work"]]) if len(flat) > 1 else None
+        placement.update({"basis_candidates": nbas, "work_candidates": ncand, "chosen": [pinfo["basis"], pinfo["work"]],
+                          "trial_grid_F_ms": [[round(t, 4) for t in row] for row in pinfo["grid"]],
+                          "grid_min_median_max_F_ms": [round(flat[0], 4), round(flat[len(flat) // 2], 4), round(flat[-1], 4)],
+                          "residual_buffers": ("alternating" if pinfo.get("residual_buffers") else "in place"),
+                          "note": "round-2 harness: every (basis, work set) pair timed from Python, the fastest kept"})
+    else:
+        tries = 1 if args.placement == "first" else max(1, args.placement_tries)
+        ctx.set_placement(tries)
+        work = L.ProjCGWork(ctx, n_loc, m, against=("new", n_loc, m), extra=1)       # the basis and its work vectors, allocated together
+        pt = ctx.placement_info()
+        Z, basis_desc = make_basis(Zc=work.basis)
+        A = L.DiagOperator(0.0, work.placed_extra[0].hash_fill(3, r0, 4.0, 5.0))
+        x = ctx.vector(n_loc)
+        flat = sorted(pt[2])
+        first_probe = (pt[2][0], pt[2][pt[1]]) if len(pt[2]) > 1 else None
+        placement.update({"tries_per_buffer": tries, "pairs_tried": pt[0], "kept_pair": pt[1], "probe_F_ms": [round(t, 4) for t in pt[2]],
+                          "probe_min_median_max_F_ms": ([round(flat[0], 4), round(flat[len(flat) // 2], 4), round(flat[-1], 4)] if flat else None),
+                          "note": "lfpsqp_basis_work_alloc_placed: every (basis candidate, work-vector-set candidate) pair tried with the fused kernel "
+                                  "itself (on zeros, two rounds), the fastest pair kept -- the same call optimize() makes for Z and ProjCGWork"})
     U = L.DeviceBasis(Z)
 
     def barrier():
@@ -273,17 +304,7 @@ def main(argv=None, lib=None):
                    "timed_region": (f"{K} iterations of a running solve (resumed after the {W} warmup iterations; set-up outside)"
                                     if resumed else f"one projcg call: set-up (2 passes over U) + {K} iterations"),
                    "prewarm": f"{prewarm_iters} untimed iterations ({args.prewarm_seconds:g} s) before the warmup steps",
-                   "work_placement": ({"candidates": ncand, "trial_F_ms": [round(t, 4) for t in trial_ms], "chosen": chosen,
-                                       "note": "candidate allocations of the solver's work vectors, fused kernel timed on each before the warm-up, fastest kept"}
-                                      if ncand > 1 else {"candidates": 1}),
-                   "basis_placement": ({"candidates": nbas, "trial_F_ms": [round(t, 4) for t in basis_ms], "chosen": bchosen,
-                                        "trial_grid_F_ms": [[round(t, 4) for t in row] for row in grid],
-                                        "extra_basis_trials": pinfo.get("extra_basis_trials", 0), "extra_trials_while_F_above_ms": round(f_target_ms, 4),
-                                        "residual_buffers": ("alternating" if pinfo.get("residual_buffers") else "in place"),
-                                        "call_ms_per_iteration": pinfo.get("call_ms_per_iteration"),
-                                        "note": "candidate allocations of the basis matrix (same contents) x the work-vector candidates: the fused kernel timed on every pair, "
-                                                "the fastest pair kept (trial_F_ms = the best of each basis allocation)"}
-                                       if nbas > 1 else {"candidates": 1}),
+                   "placement": placement,
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
                    "comm": comm_used, "device": ctx.device_name},
@@ -334,6 +355,17 @@ def main(argv=None, lib=None):
 
     if not args.no_extras and world == 1:                 # single-GPU diagnostics; the N > 1 runs measure the metric only
         out["extras"] = extras(ctx, L, n, m, n_loc, r0, Z, gbs)
+    if fused:
+        # what a caller WITHOUT the policy gets: the pair of FIRST allocations of this process is trial (0, 0); its trial time, scaled by
+        # (F in the timed run) / (trial time of the kept pair) -- the trial runs on zeros, 2-5 % faster than on data -- estimates its F
+        f0 = kf if first_probe is None else first_probe[0] * kf / first_probe[1]
+        other = elapsed / K * 1e3 - kf                                      # everything of a step that is not the fused kernel
+        out["first_allocation"] = {"F_ms": f0, "frac": gbs(bytes_kf, f0) / HBM_PEAK_GBS, "iters_per_s": 1e3 / (f0 + other),
+                                   "estimated": first_probe is not None,
+                                   "note": ("the timed run itself: placement policy off" if first_probe is None else
+                                            "fused kernel on the FIRST allocations of the basis and the work vectors in this process (trial pair 0 of "
+                                            "the policy, scaled from the trial's zeros to data by the kept pair's timed / trial ratio), and the "
+                                            "iteration rate that implies with this run's other per-step costs: what a caller without the policy gets")}
     out["check"] = {"x_norm": x_norm, "nr": nr, "iters": iters}    # global ||x|| after the W + K iterations (sanity / N-rank agreement)
     out["single_call"] = {"value": K / single_call, "ms_per_step": single_call / K * 1e3,
                           "note": f"one lfpsqp_projcg call with maxit = {K}: set-up (x = 0, r = -b, U'r, first projection: 2 passes over U) + {K} iterations"}

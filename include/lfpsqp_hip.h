@@ -101,6 +101,32 @@ int lfpsqp_mat_shape(const lfpsqp_mat* M, int64_t* n, int64_t* m);
 int lfpsqp_mat_upload(lfpsqp_ctx* ctx, lfpsqp_mat* M, int64_t col0, int64_t ncols, const double* host, int64_t ldh);
 int lfpsqp_mat_download(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t col0, int64_t ncols, double* host, int64_t ldh);
 int lfpsqp_mat_copy(lfpsqp_ctx* ctx, lfpsqp_mat* dst, const lfpsqp_mat* src);
+/* ---- placement-tuned allocation ---------------------------------------------------------------------------------------
+ * On MI355X the kernels that run a small store stream inside a matrix read stream -- the fused projected-CG iteration (src/projcg.jl:93-97),
+ * the Newton step, pcg! -- run 10-15 % faster or slower depending on WHERE the matrix and the n-vectors they touch were allocated: a
+ * property of the pair of allocations, reproducible within a process.  These two calls allocate by trial: `tries` candidate allocations
+ * (lfpsqp_ctx_set_placement, default 3, 1 = off), a few launches of the fused kernel itself on each (on zeros), the fastest kept, the rest
+ * freed.  Matrices below 1 GiB, shapes without a one-pass kernel (fewer than 4 or more than 1024 columns) and candidates that would not
+ * fit side by side are allocated plainly.  Results never depend on the choice.
+ *   lfpsqp_mat_alloc_placed: as lfpsqp_mat_alloc; the candidates are tried with a scratch vector set.  For a long-lived matrix whose
+ *     vectors come and go (Jct, src/optimize.jl:190).
+ *   lfpsqp_vecs_alloc_placed: `count` (>= 3) zero-filled n-vectors carved from ONE allocation (they share its speed), tried against the
+ *     matrix M (leading ncols columns) they will be streamed with; out[0..2] play the residual / direction / operator-diagonal roles in the
+ *     trial (hand them to lfpsqp_projcg_work.g, .d and lfpsqp_diag_op.dg).  M == NULL: one plain allocation.  Each vector is released with
+ *     lfpsqp_vec_free as usual; the allocation goes with the last of them.
+ *   lfpsqp_basis_work_alloc_placed: the basis (n x m) AND `count` vectors of nvec >= n doubles together -- which allocation of the one is
+ *     fast depends on the other, so every (matrix candidate, vector-set candidate) pair is tried (tries^2 trials of ~4 launches, two
+ *     rounds so that a GPU coming out of idle does not handicap the first candidates) and the fastest PAIR kept.  What `optimize` wants for
+ *     the basis Z and ProjCGWork (src/projcg.jl:1-11), both allocated once at src/optimize.jl:191,214. */
+int lfpsqp_ctx_set_placement(lfpsqp_ctx* ctx, int tries);
+int lfpsqp_mat_alloc_placed(lfpsqp_ctx* ctx, int64_t n, int64_t m, lfpsqp_mat** out);
+int lfpsqp_vecs_alloc_placed(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, int64_t n, int count, lfpsqp_vec** out);
+int lfpsqp_basis_work_alloc_placed(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nvec, int count, lfpsqp_mat** M_out, lfpsqp_vec** out);
+/* what the last placed allocation measured: trials made (0: none were; for the joint call tries_m * tries_v, row = matrix candidate), the one
+ * kept, fused-kernel ms per trial (ms: ms_cap doubles, may be NULL) */
+int lfpsqp_placement_info(const lfpsqp_ctx* ctx, int* tries, int* picked, double* ms, int ms_cap);
+/* one trial on its own: average ms of `reps` launches of the fused kernel over M[:, :ncols] with the ZERO-filled n-vectors g, d, a (-1: no one-pass kernel for the shape) */
+int lfpsqp_placement_probe(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, lfpsqp_vec* g, lfpsqp_vec* d, lfpsqp_vec* a, int reps, double* ms);
 /* synthetic inputs of SURVEY §8(d): v[i] = u(seed, offset+i);
  * M[i,j] = scale * u(seed, j*n_global + row0 + i)  (splitmix64-finaliser hash in [-1,1));
  * a power-of-two scale keeps the values bit-identical to the numpy generator */

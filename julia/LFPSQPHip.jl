@@ -133,6 +133,13 @@ c_vec_copy_range(ctx, dst, doff, src, soff, count) = ccall((:lfpsqp_vec_copy_ran
 c_vec_fill_range(ctx, v, off, count, value) = ccall((:lfpsqp_vec_fill_range, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Float64), ctx, v, off, count, value)
 c_vec_hash_fill(ctx, v, seed, off, scale, shift) = ccall((:lfpsqp_vec_hash_fill, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Int64, Float64, Float64), ctx, v, seed, off, scale, shift)
 c_mat_alloc(ctx, n, m, out) = ccall((:lfpsqp_mat_alloc, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), ctx, n, m, out)
+# placement-tuned allocation (DESIGN.md 6): candidate allocations tried with the fused projected-CG kernel, the fastest kept
+c_ctx_set_placement(ctx, tries) = ccall((:lfpsqp_ctx_set_placement, lib), Cint, (Ptr{Cvoid}, Cint), ctx, tries)
+c_mat_alloc_placed(ctx, n, m, out) = ccall((:lfpsqp_mat_alloc_placed, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), ctx, n, m, out)
+c_vecs_alloc_placed(ctx, M, ncols, n, count, out) = ccall((:lfpsqp_vecs_alloc_placed, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Ptr{Ptr{Cvoid}}), ctx, M, ncols, n, count, out)
+c_basis_work_alloc_placed(ctx, n, m, nvec, count, M, out) = ccall((:lfpsqp_basis_work_alloc_placed, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ref{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), ctx, n, m, nvec, count, M, out)
+c_placement_info(ctx, tries, picked, ms, cap) = ccall((:lfpsqp_placement_info, lib), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ptr{Float64}, Cint), ctx, tries, picked, ms, cap)
+c_placement_probe(ctx, M, ncols, g, d, a, reps, ms) = ccall((:lfpsqp_placement_probe, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ref{Float64}), ctx, M, ncols, g, d, a, reps, ms)
 c_mat_free(ctx, M) = ccall((:lfpsqp_mat_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx, M)
 c_mat_shape(M, n, m) = ccall((:lfpsqp_mat_shape, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), M, n, m)
 c_mat_upload(ctx, M, col0, ncols, host, ldh) = ccall((:lfpsqp_mat_upload, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Int64), ctx, M, col0, ncols, host, ldh)
@@ -289,14 +296,40 @@ mutable struct DeviceMatrix <: AbstractMatrix{Float64}
     n::Int
     m::Int
 end
-function DeviceMatrix(ctx::HipContext, n::Integer, m::Integer)
+function DeviceMatrix(ctx::HipContext, n::Integer, m::Integer; placed::Bool=false)      # placed: allocate by trial (lfpsqp_mat_alloc_placed)
     r = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ctx, c_mat_alloc(ctx.h, Int64(n), Int64(m), r))
+    check(ctx, placed ? c_mat_alloc_placed(ctx.h, Int64(n), Int64(m), r) : c_mat_alloc(ctx.h, Int64(n), Int64(m), r))
     M = DeviceMatrix(ctx, r[], n, m)
     finalizer(x -> c_mat_free(x.ctx.h, x.h), M)
     return M
 end
 Base.size(M::DeviceMatrix) = (M.n, M.m)
+set_placement!(ctx::HipContext, tries::Integer) = (check(ctx, c_ctx_set_placement(ctx.h, Cint(tries))); ctx)      # 1 = off, default 3
+# The basis (n x m) and `count` n-vectors streamed with it (stacked [x | gap | y] vectors of 2N entries when N > 0), allocated TOGETHER by
+# trial over every pair of candidate allocations -- the speed of the fused projected-CG kernel is a property of the PAIR
+# (lfpsqp_basis_work_alloc_placed).  Returns (DeviceMatrix, Vector{DeviceVector}); the vectors share one allocation.
+function basis_and_vectors_placed(ctx::HipContext, n::Integer, m::Integer, count::Integer; N::Integer=0)
+    hs = N > 0 ? Int(c_half_stride(Int64(N))) : 0
+    nv = N > 0 ? hs + N : n
+    hh = fill(Ptr{Cvoid}(C_NULL), count)
+    mr = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ctx, c_basis_work_alloc_placed(ctx.h, Int64(n), Int64(m), Int64(nv), Cint(count), mr, hh))
+    M = DeviceMatrix(ctx, mr[], n, m)
+    finalizer(x -> c_mat_free(x.ctx.h, x.h), M)
+    vs = DeviceVector[]
+    for h in hh
+        v = DeviceVector(ctx, h, nv, N, hs)
+        finalizer(x -> c_vec_free(x.ctx.h, x.h), v)
+        push!(vs, v)
+    end
+    return M, vs
+end
+function placement_info(ctx::HipContext)                    # (trials made, index kept, fused-kernel ms per trial) of the last placed allocation
+    tries, picked = Ref{Cint}(0), Ref{Cint}(0)
+    ms = zeros(64)
+    check(ctx, c_placement_info(ctx.h, tries, picked, ms, Cint(64)))
+    return Int(tries[]), Int(picked[]), ms[1:tries[]]
+end
 function upload!(M::DeviceMatrix, host::Matrix{Float64}, col0::Integer=0)      # Julia matrices are column-major: the layouts match
     check(M.ctx, c_mat_upload(M.ctx.h, M.h, Int64(col0), Int64(size(host, 2)), host, Int64(max(size(host, 1), 1))))
     return M
@@ -439,8 +472,8 @@ mutable struct InequalityDecomp
     W::Union{Nothing,Matrix{Float64}}
     Jsp::Ptr{Cvoid}            # sparse twin of Jct's leading columns (lfpsqp_spmat handle): projcg! on the nonzeros; C_NULL otherwise
 end
-InequalityDecomp(ctx::HipContext, N::Integer, M::Integer, Jct::DeviceMatrix) =
-    InequalityDecomp(ctx, N, M, DeviceMatrix(ctx, N, M), zeros(M), zeros(M, M), (DeviceVector(ctx, N) for _ in 1:5)..., Jct, M, nothing, C_NULL)
+InequalityDecomp(ctx::HipContext, N::Integer, M::Integer, Jct::DeviceMatrix, Z::DeviceMatrix=DeviceMatrix(ctx, N, M)) =
+    InequalityDecomp(ctx, N, M, Z, zeros(M), zeros(M, M), (DeviceVector(ctx, N) for _ in 1:5)..., Jct, M, nothing, C_NULL)
 # Q = [[diag Dx; diag Dy], U[:, 1:rank]] (InequalityDecompProject, :25-27, :161-212): projcg!'s U with bounds
 struct InequalityDecompProject
     idecomp::InequalityDecomp
@@ -1104,15 +1137,25 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     λ_kkt = zeros(m)
     λ_dev = DeviceVector(ctx, max(m, 1))
     term_cond = f_tol
-    projcgwork = ProjCGWork(x, m)
     prev_grad_norm = 0.0
-    idecomp = InequalityDecomp(ctx, n, m, Jct)
+    diagonal_hessian = has_hess_diag(hess_lag_vec!)
+    # The basis Z (src/optimize.jl:191), ProjCGWork (:214) and the operator diagonal the fused iteration reads beside them: allocated TOGETHER,
+    # by trial over pairs of candidate allocations (DESIGN.md 6)
+    if m > 0
+        Zp, vs = basis_and_vectors_placed(ctx, n, m, 5; N=ineq ? n : 0)
+        projcgwork = ProjCGWork(vs[1], vs[2], vs[4], DeviceVector(ctx, max(m, 1)), vs[5])
+        a_placed = vs[3]
+        idecomp = InequalityDecomp(ctx, n, m, Jct, Zp)
+    else
+        projcgwork = ProjCGWork(x, m)
+        a_placed = nothing
+        idecomp = InequalityDecomp(ctx, n, m, Jct)
+    end
     idecomp.W = m > 0 ? zeros(m, m) : nothing                 # ksvd!'s small factor: Z == Jct*W
     jsp === nothing || (idecomp.Jsp = jsp.h)                  # sparse twin: the stacked basis is applied on the nonzeros too
     Z, Σ, Vt = idecomp.Z, idecomp.Σ, idecomp.Vt
     ineqproject = ineq ? InequalityDecompProject(idecomp) : nothing
-    diagonal_hessian = has_hess_diag(hess_lag_vec!)
-    a_diag = diagonal_hessian ? newvec() : nothing
+    a_diag = diagonal_hessian ? (a_placed === nothing ? newvec() : a_placed) : nothing
     # general Hessian with bounds: augmented_hess_lag_vec! (src/inequality_helper.jl:144-158) on the stacked vectors
     aug_src = (!diagonal_hessian && ineq) ? DeviceVector(ctx, n) : nothing
     aug_x = (!diagonal_hessian && ineq) ? DeviceVector(ctx, n) : nothing
@@ -1449,7 +1492,7 @@ optimize(ctx::HipContext, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, x0::V
 export HipContext, HipError, DeviceVector, StackedVector, DeviceMatrix, SparseMatrix, spmv_t!, spmv_n!, to_dense!, DeviceBasis, DiagOperator, InequalityData, InequalityDecomp,
        InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
        ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, SeparableElementwiseBox, ElementwiseConstraints,
-       sin_system_constraints, sphere_system_constraints, clone, rowscale!, upload!, download, upload2!, download2, projcg!, retract!,
+       sin_system_constraints, sphere_system_constraints, clone, rowscale!, set_placement!, basis_and_vectors_placed, placement_info, upload!, download, upload2!, download2, projcg!, retract!,
        retract_nr_batch!, pcg!, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!,
        shard_range, sync
 

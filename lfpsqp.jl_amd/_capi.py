@@ -77,6 +77,12 @@ _SIGS = {
     "lfpsqp_vec_copy_range": [P, P, c_i64, P, c_i64, c_i64],
     "lfpsqp_mat_alloc": [P, c_i64, c_i64, C.POINTER(P)],
     "lfpsqp_mat_free": [P, P],
+    "lfpsqp_ctx_set_placement": [P, C.c_int],
+    "lfpsqp_mat_alloc_placed": [P, c_i64, c_i64, C.POINTER(P)],
+    "lfpsqp_vecs_alloc_placed": [P, P, c_i64, c_i64, C.c_int, C.POINTER(P)],
+    "lfpsqp_basis_work_alloc_placed": [P, c_i64, c_i64, c_i64, C.c_int, C.POINTER(P), C.POINTER(P)],
+    "lfpsqp_placement_info": [P, C.POINTER(C.c_int), C.POINTER(C.c_int), PD, C.c_int],
+    "lfpsqp_placement_probe": [P, P, c_i64, P, P, P, C.c_int, PD],
     "lfpsqp_mat_shape": [P, C.POINTER(c_i64), C.POINTER(c_i64)],
     "lfpsqp_mat_upload": [P, P, c_i64, c_i64, P, c_i64],
     "lfpsqp_mat_download": [P, P, c_i64, c_i64, P, c_i64],

@@ -439,9 +439,194 @@ int lfpsqp_vec_alloc(lfpsqp_ctx* ctx, int64_t n, lfpsqp_vec** out) {
 int lfpsqp_vec_free(lfpsqp_ctx* ctx, lfpsqp_vec* v) {
     if (!v) return 0;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    if (v->p) dev_free(v->p);
+    if (v->slab) {                                   // a member of a placement-tuned set: the set's allocation goes with its last member
+        if (--v->slab->refs == 0) { dev_free(v->slab->p); delete v->slab; }
+    } else if (v->p) dev_free(v->p);
     delete v;
     return 0;
+}
+
+// ---- placement policy ------------------------------------------------------------------------------------------------
+// On MI355X the kernels that run a small store stream inside a matrix read stream (the fused projected-CG iteration, the Newton step, pcg!)
+// run at one of two speeds -- 10-15 % apart -- depending on WHERE the matrix and the n-vectors they touch were allocated: a property of the
+// pair of allocations, reproducible within a process (profiles/r03b_*: same traffic and cache hits, fewer requests in flight and +57 %
+// latency-FIFO stall cycles in the vector caches on a slow pair).  The library therefore allocates such buffers by trial: a few candidate
+// allocations, a few launches of the fused kernel itself on each (on zeros), the fastest kept, the others freed.
+int lfpsqp_ctx_set_placement(lfpsqp_ctx* ctx, int tries) {
+    LF_ARG(ctx, ctx && tries >= 1 && tries <= 8);
+    ctx->place_tries = tries;
+    return 0;
+}
+
+int lfpsqp_placement_info(const lfpsqp_ctx* ctx, int* tries, int* picked, double* ms, int ms_cap) {
+    if (!ctx) return LFPSQP_ERR_ARG;
+    if (tries) *tries = ctx->place_last_n;
+    if (picked) *picked = ctx->place_last_pick;
+    if (ms) for (int k = 0; k < ms_cap; ++k) ms[k] = k < ctx->place_last_n ? ctx->place_last_ms[k] : 0.0;
+    return 0;
+}
+
+// the trial on its own (diagnostics, tools/placement_probe_check.py): g, d, a must be zero-filled n-vectors
+int lfpsqp_placement_probe(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, lfpsqp_vec* g, lfpsqp_vec* d, lfpsqp_vec* a, int reps, double* ms) {
+    LF_ARG(ctx, ctx && M && g && d && a && ms && reps >= 1 && g->n >= M->n && d->n >= M->n && a->n >= M->n);
+    return lfpsqp::placement_probe(ctx, M, (int)ncols, g->p, d->p, a->p, reps, ms);
+}
+
+static int64_t mat_ld_skew();
+static bool worth_placing(const lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols) {
+    return ctx->place_tries > 1 && ctx->real_gpu && M && M->n > 0 && ncols >= 4 && ncols <= M->m &&
+           (int64_t)sizeof(double) * M->ld * ncols >= ctx->place_min_bytes && getenv("LFPSQP_PLACEMENT_OFF") == nullptr;
+}
+
+// `count` vectors of n doubles each as views of one slab
+static void slab_views(void* base, int64_t n, int64_t cap, int count, lfpsqp_vec** out) {
+    lfpsqp_slab* slab = new lfpsqp_slab();
+    slab->p = base;
+    slab->refs = count;
+    for (int k = 0; k < count; ++k) {
+        lfpsqp_vec* v = new lfpsqp_vec();
+        v->p = (double*)base + (size_t)k * cap;
+        v->n = n;
+        v->cap = cap;
+        v->slab = slab;
+        out[k] = v;
+    }
+}
+
+// The trial itself: every (matrix candidate, vector-slab candidate) pair, two rounds over all pairs (a GPU coming out of idle runs its first
+// launches several per cent slower: the first round doubles as the warm-up, a pair's time is the smaller of its two), the fastest pair kept.
+// mats[0..nm), slabs[0..nv): live candidates.  Returns the chosen indices; ms_out (nm * nv, row = matrix) for lfpsqp_placement_info.
+static int place_grid(lfpsqp_ctx* ctx, lfpsqp_mat* const* mats, int nm, int ncols, void* const* slabs, int nv, int64_t cap, int* bm, int* bv,
+                      double* ms_out) {
+    *bm = 0; *bv = 0;
+    double best = 1e300;
+    for (int k = 0; k < nm * nv; ++k) ms_out[k] = 1e300;
+    if (nm * nv <= 1) { ms_out[0] = 0.0; return 0; }
+    for (int round = 0; round < 2; ++round)
+        for (int i = 0; i < nm; ++i)
+            for (int j = 0; j < nv; ++j) {
+                double* base = (double*)slabs[j];
+                double t = -1.0;
+                LF_TRY(lfpsqp::placement_probe(ctx, mats[i], ncols, base, base + cap, base + 2 * cap, round == 0 ? 2 : 3, &t));
+                if (t < 0.0) { ms_out[0] = 0.0; return 0; }            // no one-pass kernel for this shape: nothing to choose
+                if (t < ms_out[i * nv + j]) ms_out[i * nv + j] = t;
+            }
+    for (int i = 0; i < nm; ++i)
+        for (int j = 0; j < nv; ++j)
+            if (ms_out[i * nv + j] < best) { best = ms_out[i * nv + j]; *bm = i; *bv = j; }
+    return 0;
+}
+
+static void place_record(lfpsqp_ctx* ctx, int n, int pick, const double* ms) {
+    ctx->place_last_n = n > 64 ? 64 : n;
+    ctx->place_last_pick = pick;
+    for (int k = 0; k < 64; ++k) ctx->place_last_ms[k] = k < n ? ms[k] : 0.0;
+}
+
+int lfpsqp_vecs_alloc_placed(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, int64_t n, int count, lfpsqp_vec** out) {
+    LF_ARG(ctx, ctx && out && n >= 0 && count >= 1 && count <= 64);
+    for (int k = 0; k < count; ++k) out[k] = nullptr;
+    const int64_t cap = round_up(n > 0 ? n : 1, kPadRows);
+    const size_t bytes = sizeof(double) * (size_t)cap * count;
+    const int tries = (worth_placing(ctx, M, ncols) && count >= 3 && n >= M->n) ? ctx->place_tries : 1;
+    void* cand[8] = {nullptr};
+    int got = 0;
+    for (int k = 0; k < tries; ++k) {
+        if (dev_alloc(&cand[k], bytes) != hipSuccess) { cand[k] = nullptr; (void)hipGetLastError(); break; }
+        ++got;
+        if (hipMemsetAsync(cand[k], 0, bytes, ctx->stream) != hipSuccess) break;
+    }
+    if (got == 0) return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%d vectors of %lld doubles) failed", count, (long long)n);
+    int bm = 0, bv = 0;
+    double ms[8];
+    lfpsqp_mat* mats[1] = {const_cast<lfpsqp_mat*>(M)};
+    const int rc = got > 1 ? place_grid(ctx, mats, 1, (int)ncols, cand, got, cap, &bm, &bv, ms) : 0;
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < got; ++k)
+        if (k != bv) dev_free(cand[k]);
+    place_record(ctx, got > 1 ? got : 0, bv, ms);
+    slab_views(cand[bv], n, cap, count, out);
+    return rc;
+}
+
+// candidate matrices (as many of `tries` as fit side by side in three quarters of the free memory)
+static int mat_candidates(lfpsqp_ctx* ctx, int64_t n, int64_t m, int tries, lfpsqp_mat** cand) {
+    lfpsqp_mat shape;
+    shape.n = n; shape.m = m;
+    shape.ld = round_up(n > 0 ? n : 1, kPadRows) + mat_ld_skew();
+    const size_t bytes = sizeof(double) * (size_t)shape.ld * (size_t)(m > 0 ? m : 1);
+    if (!worth_placing(ctx, &shape, m)) tries = 1;
+    size_t free_b = 0, total_b = 0;
+    if (tries > 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t room = free_b - free_b / 4;
+        while (tries > 1 && (size_t)tries * bytes > room) --tries;
+    }
+    int got = 0;
+    for (int k = 0; k < tries; ++k) {
+        if (lfpsqp_mat_alloc(ctx, n, m, &cand[k]) != 0) { cand[k] = nullptr; (void)hipGetLastError(); break; }
+        ++got;
+    }
+    return got;
+}
+
+int lfpsqp_mat_alloc_placed(lfpsqp_ctx* ctx, int64_t n, int64_t m, lfpsqp_mat** out) {
+    LF_ARG(ctx, ctx != nullptr && out != nullptr && n >= 0 && m >= 0);
+    lfpsqp_mat* cand[8] = {nullptr};
+    const int got = mat_candidates(ctx, n, m, ctx->place_tries, cand);
+    if (got == 0) return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%lld x %lld matrix) failed", (long long)n, (long long)m);
+    int bm = 0, bv = 0, rc = 0;
+    double ms[8] = {0};
+    if (got > 1) {
+        const int64_t cap = round_up(n > 0 ? n : 1, kPadRows);
+        void* scratch = nullptr;
+        if (dev_alloc(&scratch, sizeof(double) * (size_t)cap * 3) == hipSuccess &&
+            hipMemsetAsync(scratch, 0, sizeof(double) * (size_t)cap * 3, ctx->stream) == hipSuccess)
+            rc = place_grid(ctx, cand, got, (int)m, &scratch, 1, cap, &bm, &bv, ms);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (scratch) dev_free(scratch);
+    }
+    for (int k = 0; k < got; ++k)
+        if (k != bm) lfpsqp_mat_free(ctx, cand[k]);
+    place_record(ctx, got > 1 ? got : 0, bm, ms);
+    *out = cand[bm];
+    return rc;
+}
+
+// The basis and the n-vectors streamed with it, allocated TOGETHER: which allocation of the one is fast depends on the other (a property of
+// the pair), so every (matrix candidate, vector-set candidate) pair is tried and the fastest pair kept.
+int lfpsqp_basis_work_alloc_placed(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nvec, int count, lfpsqp_mat** M_out, lfpsqp_vec** out) {
+    LF_ARG(ctx, ctx && M_out && out && n >= 0 && m >= 0 && nvec >= n && count >= 3 && count <= 64);
+    *M_out = nullptr;
+    for (int k = 0; k < count; ++k) out[k] = nullptr;
+    lfpsqp_mat* cand[8] = {nullptr};
+    const int gm = mat_candidates(ctx, n, m, ctx->place_tries, cand);
+    if (gm == 0) return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%lld x %lld matrix) failed", (long long)n, (long long)m);
+    const int64_t cap = round_up(nvec > 0 ? nvec : 1, kPadRows);
+    const size_t bytes = sizeof(double) * (size_t)cap * count;
+    const int tv = worth_placing(ctx, cand[0], m) ? ctx->place_tries : 1;
+    void* slabs[8] = {nullptr};
+    int gv = 0;
+    for (int k = 0; k < tv; ++k) {
+        if (dev_alloc(&slabs[k], bytes) != hipSuccess) { slabs[k] = nullptr; (void)hipGetLastError(); break; }
+        ++gv;
+        if (hipMemsetAsync(slabs[k], 0, bytes, ctx->stream) != hipSuccess) break;
+    }
+    if (gv == 0) {
+        for (int k = 0; k < gm; ++k) lfpsqp_mat_free(ctx, cand[k]);
+        return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%d vectors of %lld doubles) failed", count, (long long)nvec);
+    }
+    int bm = 0, bv = 0;
+    double ms[64];
+    const int rc = (gm * gv > 1) ? place_grid(ctx, cand, gm, (int)m, slabs, gv, cap, &bm, &bv, ms) : 0;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < gm; ++k)
+        if (k != bm) lfpsqp_mat_free(ctx, cand[k]);
+    for (int k = 0; k < gv; ++k)
+        if (k != bv) dev_free(slabs[k]);
+    place_record(ctx, gm * gv > 1 ? gm * gv : 0, bm * gv + bv, ms);
+    *M_out = cand[bm];
+    slab_views(slabs[bv], nvec, cap, count, out);
+    return rc;
 }
 
 int64_t lfpsqp_vec_len(const lfpsqp_vec* v) { return v ? v->n : -1; }

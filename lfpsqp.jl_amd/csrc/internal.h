@@ -9,10 +9,15 @@
 #include "../../include/lfpsqp_hip.h"
 #include "kernels.h"
 
+struct lfpsqp_slab {   // one device allocation shared by the vectors of a placement-tuned set (lfpsqp_vecs_alloc_placed)
+    void* p = nullptr;
+    int refs = 0;
+};
 struct lfpsqp_vec {
     double* p = nullptr;
     int64_t n = 0;    // logical length (local part of a sharded vector)
     int64_t cap = 0;  // allocated doubles: n rounded up to whole tiles, padding kept finite
+    lfpsqp_slab* slab = nullptr;   // non-null: p points into this shared allocation
 };
 
 constexpr int64_t kLdSkewDefault = 16;  // rows (128 bytes); see mat_ld_skew (context.hip)
@@ -85,6 +90,11 @@ struct lfpsqp_ctx {
     int tune_gping = 0;     // fused projected-CG iteration: 0 = the residual updated in place, 1 = two buffers alternating (lfpsqp_ctx_set_residual_buffers)
 
     bool real_gpu = false;   // gcnArchName "gfx..." (false only in the CPU emulator build of the tests)
+    // placement policy (lfpsqp_ctx_set_placement): candidate allocations tried by lfpsqp_mat_alloc_placed / lfpsqp_vecs_alloc_placed
+    int place_tries = 3;
+    int64_t place_min_bytes = (int64_t)1 << 30;     // matrices below this size are not worth a probe
+    double place_last_ms[64] = {0};                  // probe times of the last placed allocation (diagnostics)
+    int place_last_n = 0, place_last_pick = 0;
 
     // state a projcg call that stopped at its iteration limit leaves behind for LFPSQP_PROJCG_RESUME (scalars, t3 and the last sums
     // stay in scal / d_m; anything else that uses d_m invalidates it -- ensure_mvec)
@@ -378,6 +388,11 @@ int run_vec(lfpsqp_ctx* ctx, int64_t n, F f, unsigned ismax, double* red_out, PO
 
 // one-sided Jacobi on the columns of a small host matrix, run on the device (jacobi.hip); false = shape not covered
 bool device_jacobi(lfpsqp_ctx* ctx, int rows_dot, int rows_all, int cols, std::vector<double>& X, int* sweeps_out = nullptr);
+
+// average time (ms) of `reps` launches of the fused projected-CG kernel over M[:, :ncols] with (g, d, a) as its residual (loaded and stored in
+// place), direction and operator-diagonal vectors -- all three must be ZERO-filled (the kernel then leaves them zero); *ms < 0: shape without a
+// one-pass kernel.  The placement probe of lfpsqp_mat_alloc_placed / lfpsqp_vecs_alloc_placed (projcg.hip).
+int placement_probe(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, double* g, double* d, double* a, int reps, double* ms);
 
 // read `count` doubles of device memory back after everything queued so far
 int read_back(lfpsqp_ctx* ctx, const double* dev, double* host, int64_t count);

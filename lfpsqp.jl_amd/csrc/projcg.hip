@@ -883,6 +883,31 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     return 0;
 }
 
+// The placement probe: the fused kernel F itself, on zero vectors (alpha = 0, g = d = 0: every store writes the zero it loaded), so what is
+// timed is exactly the access pattern whose speed depends on where the matrix and the vectors were allocated.
+int lfpsqp::placement_probe(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, double* g, double* d, double* a, int reps, double* ms) {
+    *ms = -1.0;
+    if (!M || M->n <= 0 || ncols < 4 || ncols > M->m || onepass_cw(ctx, ncols, M->ld, M->n) == 0) return 0;
+    LF_TRY(ensure_mvec(ctx, (size_t)3 * ncols + 24));               // (also invalidates any resumable projcg state: scal is rewritten below)
+    double* T12 = ctx->d_m;
+    double* Utr = ctx->d_m + round_up(2 * ncols + 5, 2);           // zeros: the first product vanishes
+    LF_HIP(ctx, hipMemsetAsync(ctx->d_m, 0, sizeof(double) * ((size_t)3 * ncols + 24), ctx->stream));
+    hipLaunchKernelGGL((post_kernel<InitState>), dim3(1), dim3(1), 0, ctx->stream, ctx->scal, InitState{ctx->scal, ctx->istat, 0.0, (int64_t)1 << 40});
+    LF_LAUNCH_CHECK(ctx);
+    const StackD sk{0, nullptr, nullptr, nullptr, nullptr};
+    const PcgFuseE<false, false> f{g, g, g, d, AOpD{0.0, a}, ctx->scal, ctx->istat, sk};
+    for (int k = 0; k < reps + 1; ++k) {
+        if (k == 1) LF_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+        LF_TRY((run_onepass<PcgFuseE<false, false>, 2, 5>(ctx, M, ncols, ncols, M->n, Utr, f, T12, -1)));
+    }
+    LF_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+    LF_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
+    float t = 0.f;
+    LF_HIP(ctx, hipEventElapsedTime(&t, ctx->ev_t0, ctx->ev_t1));
+    *ms = (double)t / reps;
+    return 0;
+}
+
 extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, const lfpsqp_basis* U,
                              const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit, int64_t n_global, int flags,
                              const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {

@@ -57,6 +57,68 @@ class Context:
         """0 = the fused projected-CG iteration updates its residual in place (default), 1 = two buffers alternating."""
         self.check(self.L.lfpsqp_ctx_set_residual_buffers(self.h, int(mode)))
 
+    def set_placement(self, tries: int = 3):
+        """Candidate allocations tried by the placement-tuned allocators (lfpsqp_ctx_set_placement; 1 = off)."""
+        self.check(self.L.lfpsqp_ctx_set_placement(self.h, int(tries)))
+
+    def free_memory(self):
+        """Free device memory in bytes (None when unknown): sizes the candidate count of placed allocations in bench.py."""
+        try:
+            import ctypes.util
+            hip = C.CDLL("libamdhip64.so")
+            f, t = C.c_size_t(), C.c_size_t()
+            if hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0:
+                return int(f.value)
+        except OSError:
+            pass
+        return None
+
+    def placement_info(self):
+        """(candidates tried, index kept, fused-kernel ms per candidate) of the last placed allocation."""
+        tries, pick = C.c_int(), C.c_int()
+        ms = (C.c_double * 64)()
+        self.check(self.L.lfpsqp_placement_info(self.h, C.byref(tries), C.byref(pick), ms, 64))
+        return tries.value, pick.value, list(ms)[:tries.value]
+
+    def _wrap_vecs(self, hh, n, count, stacked_N, hs):
+        out = []
+        for k in range(count):
+            if stacked_N is not None:
+                from .inequality import StackedVector
+                v = StackedVector.__new__(StackedVector)
+                v.N, v.hs = int(stacked_N), hs
+            else:
+                v = DeviceVector.__new__(DeviceVector)
+            v.ctx, v.n, v.h = self, int(n), P(hh[k])
+            out.append(v)
+        return out
+
+    def basis_and_vectors_placed(self, n: int, m: int, count: int, stacked_N: int | None = None):
+        """The basis matrix (n x m) and ``count`` vectors streamed with it, allocated together by trial over every pair of candidate
+        allocations (lfpsqp_basis_work_alloc_placed).  Returns (DeviceMatrix, [vectors])."""
+        hs, nv = None, int(n)
+        if stacked_N is not None:
+            hs = int(self.L.lfpsqp_half_stride(int(stacked_N)))
+            nv = hs + int(stacked_N)
+        hh = (P * count)()
+        mh = P()
+        self.check(self.L.lfpsqp_basis_work_alloc_placed(self.h, int(n), int(m), nv, int(count), C.byref(mh), hh))
+        M = DeviceMatrix.__new__(DeviceMatrix)
+        M.ctx, M.n, M.m, M.h = self, int(n), int(m), mh
+        return M, self._wrap_vecs(hh, nv, count, stacked_N, hs)
+
+    def vectors_placed(self, M: "DeviceMatrix | None", n: int, count: int, ncols: int | None = None, stacked_N: int | None = None):
+        """``count`` zero-filled n-vectors from ONE allocation, placement-tuned against the matrix M they will be streamed with
+        (lfpsqp_vecs_alloc_placed).  ``stacked_N``: StackedVector objects of N + N entries (n is then ignored)."""
+        hs = None
+        if stacked_N is not None:
+            hs = int(self.L.lfpsqp_half_stride(int(stacked_N)))
+            n = hs + int(stacked_N)
+        hh = (P * count)()
+        self.check(self.L.lfpsqp_vecs_alloc_placed(self.h, M.h if M is not None else None, (M.m if ncols is None else ncols) if M is not None else 0,
+                                                   int(n), int(count), hh))
+        return self._wrap_vecs(hh, n, count, stacked_N, hs)
+
     def set_tuning(self, ks: int = 0, nt: bool = True):
         self.check(self.L.lfpsqp_ctx_set_tuning(self.h, int(ks), 1 if nt else 0))
 
@@ -108,8 +170,8 @@ class Context:
             v.upload(data)
         return v
 
-    def matrix(self, n: int, m: int, data=None) -> "DeviceMatrix":
-        M = DeviceMatrix(self, n, m)
+    def matrix(self, n: int, m: int, data=None, placed: bool = False) -> "DeviceMatrix":
+        M = DeviceMatrix(self, n, m, placed=placed)
         if data is not None:
             M.upload(data)
         return M
@@ -167,10 +229,11 @@ class DeviceVector:
 class DeviceMatrix:
     """Column-major n_loc x m matrix, every column contiguous (SURVEY §7 layout)."""
 
-    def __init__(self, ctx: Context, n: int, m: int):
+    def __init__(self, ctx: Context, n: int, m: int, placed: bool = False):
+        """``placed``: allocate by trial (lfpsqp_mat_alloc_placed) -- for the long-lived matrices the hot loops stream."""
         self.ctx, self.n, self.m = ctx, int(n), int(m)
         h = P()
-        ctx.check(ctx.L.lfpsqp_mat_alloc(ctx.h, self.n, self.m, C.byref(h)))
+        ctx.check((ctx.L.lfpsqp_mat_alloc_placed if placed else ctx.L.lfpsqp_mat_alloc)(ctx.h, self.n, self.m, C.byref(h)))
         self.h = h
 
     @property

@@ -74,9 +74,9 @@ class InequalityDecomp:
     """InequalityDecomp (src/inequality_helper.jl:10-19).  ``U`` of the reference (2N x M) is held
     as the N x M matrix ``Z`` plus the row scalings sx = Dy^2, sy = -Dx*Dy."""
 
-    def __init__(self, ctx: Context, N: int, M: int, Jct: DeviceMatrix | None = None):
+    def __init__(self, ctx: Context, N: int, M: int, Jct: DeviceMatrix | None = None, Z: DeviceMatrix | None = None):
         self.ctx, self.N, self.M = ctx, N, M
-        self.Z = DeviceMatrix(ctx, N, M)
+        self.Z = Z if Z is not None else DeviceMatrix(ctx, N, M)      # (the driver hands in a basis allocated jointly with ProjCGWork, DESIGN.md 6)
         self.Sigma = np.zeros(M)
         self.Vt = np.zeros((M, M), order='F')
         self.Dx, self.Dy, self.S, self.sx, self.sy = (DeviceVector(ctx, N) for _ in range(5))

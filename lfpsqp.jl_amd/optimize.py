@@ -150,7 +150,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     obj_values = []
     xnew, g, d, newton_d = newvec(), newvec(), newvec(), newvec()
     # device-resident constraint classes own their (mostly constant) Jct; otherwise the driver allocates it
-    Jct = getattr(c_, "Jct", None) or DeviceMatrix(ctx, n, m)
+    Jct = getattr(c_, "Jct", None) or DeviceMatrix(ctx, n, m, placed=True)
     assert Jct.n == n and Jct.m == m
     tmp_m = DeviceVector(ctx, max(m, 1))
     tmp_w = DeviceVector(ctx, n) if ineq else None
@@ -158,19 +158,22 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     lam_kkt = np.zeros(m)
     lam_dev = DeviceVector(ctx, max(m, 1))
     term_cond = TerminationCondition.f_tol
-    projcgwork = ProjCGWork(ctx, n, m, n if ineq else None)
     prev_grad_norm = 0.0
     noise = None
 
-    idecomp = InequalityDecomp(ctx, n, m, Jct)
+    # The basis Z (src/optimize.jl:191), ProjCGWork (:214) and the operator diagonal the fused iteration reads beside them: allocated TOGETHER,
+    # by trial over pairs of candidate allocations (lfpsqp_basis_work_alloc_placed, DESIGN.md 6: the speed of the fused kernel is a property of
+    # the pair of allocations)
+    diagonal_hessian = hasattr(hess_lag_vec_, "diag_")
+    projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=(("new", n, m) if m > 0 else None), extra=1 if diagonal_hessian else 0)
+    idecomp = InequalityDecomp(ctx, n, m, Jct, Z=projcgwork.basis)
     Z = idecomp.Z
     Sig, Vt = idecomp.Sigma, idecomp.Vt
     Wgen = np.zeros((m, m), order='F') if m > 0 else None                  # ksvd_'s small factor: Z == Jct @ Wgen
     ineqproject = InequalityDecompProject(idecomp) if ineq else None
 
-    diagonal_hessian = hasattr(hess_lag_vec_, "diag_")
     if diagonal_hessian:
-        a_diag = newvec()
+        a_diag = projcgwork.placed_extra[0] if projcgwork.placed_extra else newvec()
         newton_map = DiagOperator(0.0, a_diag)
     elif ineq:
         newton_map = _GenericAugHessian(hess_lag_vec_, x, lam_dev, lamy_kkt, ineqdata, n)

@@ -101,10 +101,28 @@ class _BasisAdjoint:
 class ProjCGWork:
     """ProjCGWork(n, m) (src/projcg.jl:1-11); only g, d, rp, Utr exist on the device."""
 
-    def __init__(self, ctx: Context, n: int, m: int, stacked_N: int | None = None):
+    def __init__(self, ctx: Context, n: int, m: int, stacked_N: int | None = None, against=None, extra: int = 0):
         """n = length of the n-vectors on this rank; with bounds pass stacked_N = N and the
-        vectors get the stacked [x | gap | y] layout (length hs + N)."""
-        if stacked_N is not None:
+        vectors get the stacked [x | gap | y] layout (length hs + N).
+        ``against`` (DeviceMatrix): the basis these vectors will be streamed with -- they then come from one placement-tuned
+        allocation (lfpsqp_vecs_alloc_placed), together with ``extra`` more vectors of the same kind left in
+        ``self.placed_extra`` (in the trial, the first of them plays the operator diagonal: use it for DiagOperator).
+        ``against = ("new", rows, m)``: the basis matrix is allocated here as well, jointly with the vectors (every pair of candidate
+        allocations tried, lfpsqp_basis_work_alloc_placed), and left in ``self.basis``."""
+        self.placed_extra = []
+        self.basis = None
+        if isinstance(against, tuple):              # ("new", rows, m): allocate the basis too, jointly (lfpsqp_basis_work_alloc_placed) -> self.basis
+            self.basis, vs = ctx.basis_and_vectors_placed(against[1], against[2], 3 + extra, stacked_N=stacked_N)
+            against = None
+            self.g, self.d = vs[0], vs[1]
+            self.placed_extra = vs[2:2 + extra]
+            self.rp = vs[2 + extra]
+        elif against is not None:
+            vs = ctx.vectors_placed(against, n, 3 + extra, stacked_N=stacked_N)
+            self.g, self.d = vs[0], vs[1]
+            self.placed_extra = vs[2:2 + extra]
+            self.rp = vs[2 + extra]
+        elif stacked_N is not None:
             from .inequality import StackedVector
             self.g, self.d, self.rp = (StackedVector(ctx, stacked_N) for _ in range(3))
         else:

@@ -85,7 +85,7 @@ class ElementwiseConstraints(DeviceConstraints):
         sparse = isinstance(A, SparseMatrix)
         n, m = A.n, A.m
         if Jct is None:
-            Jct = DeviceMatrix(ctx, n, m + (1 if has_ball else 0))
+            Jct = DeviceMatrix(ctx, n, m + (1 if has_ball else 0), placed=True)
         Jsp = A.clone() if sparse else None
         super().__init__(Jct, m, b, has_ball=has_ball, R2=R2, n_x=(n if n_x is None else n_x), slack_row=slack_row, Jsp=Jsp)
         self.A = None if sparse else A

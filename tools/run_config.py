@@ -24,7 +24,7 @@ elif cfg == 3 and ('--banded' in sys.argv or '--banded-dense' in sys.argv):
     P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download(), Jsp=S if '--banded' in sys.argv else None); x0 = np.ones(n)
 elif cfg == 3:
     n = int(float(args[0])) if args else 10_000_000; m = int(args[1]) if len(args) > 1 else 128
-    Jct = ctx.matrix(n, m).hash_fill(1)
+    Jct = ctx.matrix(n, m, placed=True).hash_fill(1)
     xs = ctx.vector(n).hash_fill(2); b = ctx.vector(m); L.gemv_t(Jct, xs, b)
     P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download()); x0 = np.ones(n)
 elif '--banded' in sys.argv or '--banded-dense' in sys.argv:
@@ -34,7 +34,7 @@ elif '--banded' in sys.argv or '--banded-dense' in sys.argv:
     rows = np.repeat(ii, k); cols = ((((ii * m) // n)[:, None] + np.arange(k)[None, :]) % m).ravel()
     vals = (np.random.default_rng(5).standard_normal((n, k)) + 2.0 * (np.arange(k) == 0)).ravel()
     S = L.SparseMatrix(ctx, n + 1, m, rows, cols, vals)
-    Jct = ctx.matrix(n + 1, m + 1); S.to_dense(Jct)
+    Jct = ctx.matrix(n + 1, m + 1, placed=True); S.to_dense(Jct)
     xs = ctx.vector(n + 1).hash_fill(2, 0, 1.0, 0.0); ctx.check(ctx.L.lfpsqp_vec_fill_range(ctx.h, xs.h, n, 1, 0.0))
     b = ctx.vector(m + 1); L.spmv_t(S, xs, b)
     i = np.arange(n)
@@ -42,7 +42,7 @@ elif '--banded' in sys.argv or '--banded-dense' in sys.argv:
     P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download()[:m], R2=n / 2.0, xl=xl, xu=xu, Jsp=S if '--banded' in sys.argv else None); x0 = 0.5 * np.ones(n)
 else:
     n = int(float(args[0])) if args else 10_000_000; m = int(args[1]) if len(args) > 1 else 128
-    Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+    Jct = ctx.matrix(n + 1, m + 1, placed=True).hash_fill(1, 0, n, 1.0, n, m)
     xs = ctx.vector(n + 1).hash_fill(2, 0, 1.0, 0.0); ctx.check(ctx.L.lfpsqp_vec_fill_range(ctx.h, xs.h, n, 1, 0.0))
     b = ctx.vector(m + 1); L.gemv_t(Jct, xs, b, ncols=m)
     i = np.arange(n)
@@ -57,3 +57,6 @@ if mo: par.maxiter = int(mo[0].split('=')[1])
 x, obj, lam, ti = P.optimize(x0, par)
 dt = time.perf_counter() - t0
 print(ti); print(f"optimize wall {dt:.2f}s  f={obj[-1]:.6e}  |lam|max={np.abs(lam).max():.3e}")
+pt = ctx.placement_info()
+if pt[0]:
+    print(f"placement (last placed allocation: basis + ProjCGWork pairs): {pt[0]} trials, kept {pt[1]}, fused-kernel trial ms min {min(pt[2]):.4f} / first {pt[2][0]:.4f} / max {max(pt[2]):.4f}")
