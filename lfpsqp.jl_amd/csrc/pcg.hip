@@ -18,6 +18,11 @@
 //   T   tmp = (s - alpha*u) + beta*tmp                                                   (m-vector kernel)
 // = 8 n m + 80 n bytes instead of 16 n m + 88 n.  alpha, beta, rho and the stopping test are computed exactly as in
 // the reference; s = J r is re-measured every iteration, so the recurrence for tmp does not drift.
+// Stores inside the matrix stream are the expensive part of F (160 MB of writes cost as much as 1.4 GB of reads), so F
+// stores ONE vector, z; the direction p = r + beta*p, which it forms in registers, is formed again -- by the same fma -- and stored by P3,
+// a plain vector kernel that reads p and r anyway:
+//   F   z = J'tmp + mu*(r + beta*p) (stored) ; partials p'z, J z, J r
+//   P3  p = r + beta*p (stored) ; x += alpha*p ; r -= alpha*z ; partial r'r
 #include <math.h>
 
 #include "internal.h"
@@ -128,18 +133,26 @@ struct PPost2 {
     __device__ __forceinline__ void run(double*) const { scal[P_ALPHA] = ld_scal(scal + P_RHO) / ld_scal(scal + P_PZ); }   // :227
 };
 
-struct P3F {  // x += alpha p ; r -= alpha z ; r'r
+struct P3F {  // [p = r + beta p ;] x += alpha p ; r -= alpha z ; r'r
     double* x;
     double* r;
-    const double* p;
+    double* p;
     const double* z;
     const double* scal;
     const int64_t* istat;
+    int pupd;             // the one-pass iteration left the direction update to this kernel (:217, the expression of PcgInnerE)
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
     __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
         const double alpha = ld_scal(scal + P_ALPHA);
-        const double2 pp = ld2(p + i), zz = ld2(z + i);
+        double2 pp = ld2(p + i);
+        const double2 zz = ld2(z + i);
         double2 xx = ld2(x + i), rr = ld2(r + i);
+        if (pupd) {
+            const double beta = ld_scal(scal + P_BETA);
+            pp = make_double2(fma(beta, pp.x, rr.x), fma(beta, pp.y, rr.y));
+            if (v1) st2(p + i, pp);
+            else if (v0) p[i] = pp.x;
+        }
         xx = make_double2(fma(alpha, pp.x, xx.x), fma(alpha, pp.y, xx.y));     // :232
         rr = make_double2(fma(-alpha, zz.x, rr.x), fma(-alpha, zz.y, rr.y));   // :233
         if (v1) { st2(x + i, xx); st2(r + i, rr); }
@@ -174,7 +187,7 @@ struct PPost3 {
 // ---- one-pass iteration ------------------------------------------------------------------------------------
 template <bool ST>
 struct PcgInnerE {
-    double* p;
+    const double* p;
     const double* r;
     double* z;
     double mu;
@@ -209,23 +222,21 @@ struct PcgInnerE {
         const double acc = accv[0];
         const bool st = valid && owner;
         if (!ST) {
-            const double pn = first ? w.px : (w.rx + u.beta * w.px);                 // :217
+            const double pn = first ? w.px : fma(u.beta, w.px, w.rx);                // :217 (stored by P3: same fma)
             const double zz = fma(mu, pn, acc);                                      // :222
             if (st) {
-                if (!first) put(p, o, pn);
                 put(z, o, zz);
                 red[0] += pn * zz;                                                   // :226
             }
             v[0] = valid ? zz : 0.0;
             v[1] = valid ? w.rx : 0.0;
         } else {
-            const double pnx = first ? w.px : (w.rx + u.beta * w.px);
-            const double pny = first ? w.py : (w.ry + u.beta * w.py);
+            const double pnx = first ? w.px : fma(u.beta, w.px, w.rx);
+            const double pny = first ? w.py : fma(u.beta, w.py, w.ry);
             const double ww = w.Dx * pnx + w.Dy * pny;                               // diagonal block of J p
             const double zx = fma(mu, pnx, fma(w.sx, acc, w.Dx * ww));
             const double zy = fma(mu, pny, fma(w.sy, acc, w.Dy * ww));
             if (st) {
-                if (!first) { put(p, o, pnx); put(p + k.hs, o, pny); }
                 put(z, o, zx); put(z + k.hs, o, zy);
                 red[0] += pnx * zx + pny * zy;
             }
@@ -376,7 +387,8 @@ extern "C" int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, l
             if (stacked) LF_TRY((run_gemv_n<P2ES, 1, PPost2>(ctx, Z, m, N, tmp_m->p, P2ES{p2, sk}, scal + P_PZ, PPost2{scal, istat}, 5)));
             else LF_TRY((run_gemv_n<P2E, 1, PPost2>(ctx, Z, m, N, tmp_m->p, p2, scal + P_PZ, PPost2{scal, istat}, 5)));
         }
-        LF_TRY((run_vec<P3F, 1, PPost3>(ctx, nv, P3F{x->p, r->p, p->p, z->p, scal, istat}, 0u, scal + P_RR, PPost3{scal, istat, hm}, 6)));
+        LF_TRY((run_vec<P3F, 1, PPost3>(ctx, nv, P3F{x->p, r->p, p->p, z->p, scal, istat, (fused && it > 0) ? 1 : 0}, 0u, scal + P_RR,
+                                         PPost3{scal, istat, hm}, 6)));
         // rank-deterministic stop: the status of iteration it-2 (device iteration number it-1), after its event
         LF_HIP(ctx, hipEventRecord(ctx->ev_slot[it & 3], ctx->stream));
         if (it >= 2) {
