@@ -213,15 +213,23 @@ c_retract_pp(ctx, cons, cfun, jacfun, user, Jct, m, idata, Dx, Dy, S, xtilde, x,
 # =====================================================================================================================
 # 2. Context, device arrays, BLAS-1/2 dispatch
 # =====================================================================================================================
+# Options of the DEVICE implementation with no counterpart in the reference -- kept out of LFPSQPParams, which mirrors src/LFPSQP.jl:57-81
+# field for field.  ls_batch: trial retractions of a failing linesearch that share their passes over Jct (1 = off);
+# placement_tries: candidate allocations per placement-tuned buffer (set_placement!).
+mutable struct DeviceOptions
+    ls_batch::Int
+    placement_tries::Int
+end
 mutable struct HipContext
     h::Ptr{Cvoid}
     rank::Int
     nranks::Int
+    options::DeviceOptions
     function HipContext(device::Integer=0)
         r = Ref{Ptr{Cvoid}}(C_NULL)
         rc = c_ctx_create(Cint(device), r)
         rc == 0 || throw(HipError(rc, "lfpsqp_ctx_create failed: no usable MI355X (there is no CPU fallback)"))
-        ctx = new(r[], 0, 1)
+        ctx = new(r[], 0, 1, DeviceOptions(4, 3))
         finalizer(c -> c_ctx_destroy(c.h), ctx)
         return ctx
     end
@@ -304,7 +312,7 @@ function DeviceMatrix(ctx::HipContext, n::Integer, m::Integer; placed::Bool=fals
     return M
 end
 Base.size(M::DeviceMatrix) = (M.n, M.m)
-set_placement!(ctx::HipContext, tries::Integer) = (check(ctx, c_ctx_set_placement(ctx.h, Cint(tries))); ctx)      # 1 = off, default 3
+set_placement!(ctx::HipContext, tries::Integer) = (check(ctx, c_ctx_set_placement(ctx.h, Cint(tries))); ctx.options.placement_tries = tries; ctx)      # 1 = off, default 3
 # The basis (n x m) and `count` n-vectors streamed with it (stacked [x | gap | y] vectors of 2N entries when N > 0), allocated TOGETHER by
 # trial over every pair of candidate allocations -- the speed of the fused projected-CG kernel is a property of the PAIR
 # (lfpsqp_basis_work_alloc_placed).  Returns (DeviceMatrix, Vector{DeviceVector}); the vectors share one allocation.
@@ -867,7 +875,6 @@ Base.@kwdef mutable struct LFPSQPParams
     do_newton::Bool = true
     tn_maxiter::Int = 10000
     tn_κ::Float64 = 0.5
-    ls_batch::Int = 4           # not in the reference: trial retractions of a failing Armijo search share their passes (1 = off)
 end
 
 mutable struct ArmijoWork       # src/linesearch.jl:1-5
@@ -900,7 +907,7 @@ function armijo!(xnew::DeviceVector, x::DeviceVector, n::Int, d::DeviceVector, g
     xtilde = work.xtilde
     step = xtilde
     ahead = Dict{Float64,Tuple{Int,Int,Int,DeviceVector,Vector{Float64}}}()
-    nbatch = (retract_method isa NR && c! isa DeviceConstraints) ? param.ls_batch : 1
+    nbatch = (retract_method isa NR && c! isa DeviceConstraints) ? x.ctx.options.ls_batch : 1
     failed_once = work.prev_failed
     any_failed = false
     while step_diff > param.ϵ_x
@@ -980,7 +987,7 @@ function exact_linesearch!(xnew::DeviceVector, x::DeviceVector, n::Int, d::Devic
     end
     # Shrinking phase (:176-208): the trial steps a_c φ1, a_c φ1², ... are a fixed sequence from the same x, and where it runs most of
     # them fail after the full iteration limit: the next `ls_batch` are retracted together and consumed in the reference's order.
-    nbatch = (retract_method isa NR && c! isa DeviceConstraints) ? param.ls_batch : 1
+    nbatch = (retract_method isa NR && c! isa DeviceConstraints) ? x.ctx.options.ls_batch : 1
     ahead = Dict{Float64,Tuple{Int,Int,Int,DeviceVector,Vector{Float64}}}()
     retract_shrink! = function (pt::DeviceVector, a_next::Float64)
         if haskey(ahead, a_next)
@@ -1489,7 +1496,7 @@ end
 optimize(ctx::HipContext, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, x0::Vector{Float64}, xl, xu, m::Int, p::Int, param::LFPSQPParams=LFPSQPParams()) =
     optimize(ctx, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, fill(-Inf, p), zeros(p), x0, xl, xu, m, p, param)
 
-export HipContext, HipError, DeviceVector, StackedVector, DeviceMatrix, SparseMatrix, spmv_t!, spmv_n!, to_dense!, DeviceBasis, DiagOperator, InequalityData, InequalityDecomp,
+export HipContext, HipError, DeviceOptions, DeviceVector, StackedVector, DeviceMatrix, SparseMatrix, spmv_t!, spmv_n!, to_dense!, DeviceBasis, DiagOperator, InequalityData, InequalityDecomp,
        InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
        ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, SeparableElementwiseBox, ElementwiseConstraints,
        sin_system_constraints, sphere_system_constraints, clone, rowscale!, set_placement!, basis_and_vectors_placed, placement_info, upload!, download, upload2!, download2, projcg!, retract!,

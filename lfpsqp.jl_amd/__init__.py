@@ -11,7 +11,7 @@ from .factorize import gram, ksvd_, orthonormalize_, rmul, small_svd_  # noqa: F
 from .inequality import (InequalityData, InequalityDecomp, InequalityDecompOp, InequalityDecompProject, StackedVector,  # noqa: F401
                          augmented_hess_diag_, calculate_h_, calculate_lambda_kkt_, generate_initial_y_, half_stride,
                          inequality_gradient_, y_retract_)
-from .params import DisplayOption, LFPSQPParams, LinesearchOption, TerminationCondition, TerminationInfo  # noqa: F401
+from .params import DeviceOptions, DisplayOption, LFPSQPParams, LinesearchOption, TerminationCondition, TerminationInfo  # noqa: F401
 from .retractions import (NR, DeviceConstraints, ElementwiseConstraints, Euclidean, NRWork, YRetract, retract_, retract_nr_batch_,  # noqa: F401
                           sin_system_constraints, sphere_system_constraints)
 from .projpenalty import ProjPenalty, ProjPenaltyWork, no_precondition, pcg_, proj_precondition_  # noqa: F401

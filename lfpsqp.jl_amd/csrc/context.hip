@@ -44,6 +44,32 @@ int ensure_small(lfpsqp_ctx* ctx, size_t doubles) {
     return 0;
 }
 
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("LFPSQP_ROCTX");
+        if (e && atoi(e) == 0) return;
+        void* h = nullptr;
+        for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"})   // (rocprofv3 --marker-trace reads the SDK's)
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr;
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+TraceRange::TraceRange(const char* name) : on(false) {
+    Roctx& r = roctx();
+    if (r.push) { r.push(name); on = true; }
+}
+TraceRange::~TraceRange() {
+    if (on) roctx().pop();
+}
+
 int ensure_mvec(lfpsqp_ctx* ctx, size_t doubles) {
     ctx->pcg_resume.valid = false;        // whoever asks for the m-vector staging area is about to overwrite it
     if (doubles <= ctx->m_cap) return 0;

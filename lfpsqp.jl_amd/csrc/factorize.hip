@@ -814,6 +814,7 @@ using namespace lfpsqp;
 extern "C" {
 
 int lfpsqp_gram(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* w2, double* G_host) {
+    LF_RANGE("lfpsqp_gram");
     LF_ARG(ctx, ctx && M && G_host && ncols >= 0 && ncols <= M->m && (!w2 || w2->n == M->n));
     std::vector<double> G;
     LF_TRY(gram_impl(ctx, M, (int)ncols, w2 ? w2->p : nullptr, G));
@@ -822,6 +823,7 @@ int lfpsqp_gram(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsq
 }
 
 int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const double* W_host, int64_t rcols, lfpsqp_mat* Out) {
+    LF_RANGE("lfpsqp_rmul");
     LF_ARG(ctx, ctx && In && Out && W_host && In->p != Out->p && kcols >= 0 && kcols <= In->m && rcols >= 0 && rcols <= Out->m &&
                     In->n == Out->n);
     return rmul_impl(ctx, In, (int)kcols, W_host, (int)rcols, Out);
@@ -840,6 +842,7 @@ int lfpsqp_small_svd(lfpsqp_ctx* ctx, int64_t rows, int64_t cols, const double* 
 
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
                      double* W, int64_t* rank_out, double eps_rank) {
+    LF_RANGE("lfpsqp_factorize");
     LF_ARG(ctx, ctx && Jct && Z && Sigma && Vt && rank_out && Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m &&
                     (!w2 || w2->n == Jct->n));
     const int m = (int)Jct->m;
@@ -851,6 +854,7 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
 
 int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma,
                         double* Vt, double* W, int64_t* rank_out, double eps_rank) {
+    LF_RANGE("lfpsqp_factorize_sp");
     LF_ARG(ctx, ctx && S && Z && Sigma && Vt && rank_out && S->n == Z->n && (!w2 || w2->n == S->n) &&
                     (!Jct || (Jct->p != Z->p && Jct->n == S->n && Jct->m >= S->m && Jct->m - S->m <= 4)) && Z->m >= (Jct ? Jct->m : S->m));
     const int ms = (int)S->m, m = Jct ? (int)Jct->m : ms;

@@ -298,6 +298,7 @@ static bool sp_factored_ok(const lfpsqp_basis* Q, int64_t n) {
 }
 
 int lfpsqp_q_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, const lfpsqp_vec* v, lfpsqp_vec* w, lfpsqp_vec* t) {
+    LF_RANGE("lfpsqp_q_gemv_t");
     LF_ARG(ctx, ctx && Q && v && t && Q->ncols >= 0 && (Q->ncols == 0 || (Q->Z && Q->ncols <= Q->Z->m)) && t->n >= Q->ncols);
     if (!Q->Dx) {
         LF_ARG(ctx, Q->Z);
@@ -312,6 +313,7 @@ int lfpsqp_q_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, const lfpsqp_vec* v,
 
 int lfpsqp_q_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, double alpha, const lfpsqp_vec* w, const lfpsqp_vec* t, double beta,
                     lfpsqp_vec* y) {
+    LF_RANGE("lfpsqp_q_gemv_n");
     LF_ARG(ctx, ctx && Q && y && Q->ncols >= 0 && (Q->ncols == 0 || (Q->Z && t && Q->ncols <= Q->Z->m && t->n >= Q->ncols)));
     if (!Q->Dx) {
         LF_ARG(ctx, Q->Z);

@@ -104,7 +104,12 @@ struct lfpsqp_ctx {
         int m = 0;
         int64_t nv = 0, iters = 0;
         bool gcur_is_rp = false;     // which of the two alternating residual buffers holds g
+        const double *dg = nullptr, *b = nullptr;    // the operator diagonal and right-hand side the solve was started with
+        double a0 = 0.0;
+        int64_t n_global = 0;
+        uint64_t epoch = 0;          // launch_epoch when the call returned: ANY kernel the library queued since then voids the state
     } pcg_resume;
+    uint64_t launch_epoch = 0;       // bumped by every launch helper (run_vec / run_gemv_* / run_onepass / launch_reduce)
 
     // optional per-kernel-family profiling with HIP events on `stream`
     bool profiling = false;
@@ -165,6 +170,7 @@ constexpr int kReduceRowBlocks = 16;
 inline size_t reduce_scratch(int part_ld) { return (size_t)kReduceRowBlocks * part_ld; }
 template <class POST>
 int launch_reduce(lfpsqp_ctx* ctx, int64_t nrows, int ncols, int part_ld, unsigned ismax, double* out, POST post) {
+    ++ctx->launch_epoch;
     int cw_log2 = 0;
     while ((1 << cw_log2) < ncols && cw_log2 < 5) ++cw_log2;
     const int cw = 1 << cw_log2;
@@ -191,6 +197,7 @@ int launch_reduce(lfpsqp_ctx* ctx, int64_t nrows, int ncols, int part_ld, unsign
 // empty basis (reference: projcg! with an n x 0 U).
 template <class VP>
 int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp, double* t_out, int prof_slot = -1) {
+    ++ctx->launch_epoch;
     const int ks = ctx->ks_for(n);
     const int64_t tiles = ntiles_of(n, ks);
     const int part_ld = (int)round_up(ncols > 0 ? ncols : 1, 32);
@@ -219,6 +226,7 @@ int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp
 template <class EP, int NRED, class POST>
 int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const double* t, EP ep, double* red_out, POST post,
                int prof_slot = -1) {
+    ++ctx->launch_epoch;
     const int ks = ctx->ks_for(n);
     const int64_t tiles = ntiles_of(n, ks);
     if (tiles > 0) {
@@ -257,6 +265,7 @@ int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const
 template <class EP, int NRED>
 int run_gemv_nt(lfpsqp_ctx* ctx, const lfpsqp_mat* M1, int n1, const double* t, const lfpsqp_mat* M2, int n2, int64_t n, EP ep,
                 double* out) {
+    ++ctx->launch_epoch;
     const int ks = ctx->ks_for(n);
     const int64_t tiles = ntiles_of(n, ks);
     const int nout = n2 + NRED;
@@ -309,6 +318,7 @@ inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {
 template <class EP, int NV, int NRED, int NA = 1>
 int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t n, const double* t, const EP& ep, double* out,
                 int prof_slot = -1, int t_stride = 0) {
+    ++ctx->launch_epoch;
     const int cpl = (ncN + 3) / 4;                // column groups
     const bool wide = cpl > 64;                   // more than 256 columns: the four waves of a workgroup split the columns
     if (wide && NA > 1) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "batched one-pass product with more than 256 columns");
@@ -365,6 +375,7 @@ inline int vec_grid(int64_t n) {
 // elementwise map with NRED reductions (sum, or max where ismax bit set) -> red_out (global)
 template <class F, int NRED, class POST>
 int run_vec(lfpsqp_ctx* ctx, int64_t n, F f, unsigned ismax, double* red_out, POST post, int prof_slot = -1) {
+    ++ctx->launch_epoch;
     const int grid = vec_grid(n);
     if (NRED > 0) LF_TRY(ensure_part(ctx, (size_t)grid * kMaxRed));
     if (prof_slot >= 0) prof_begin(ctx, prof_slot);
@@ -393,6 +404,15 @@ bool device_jacobi(lfpsqp_ctx* ctx, int rows_dot, int rows_all, int cols, std::v
 // place), direction and operator-diagonal vectors -- all three must be ZERO-filled (the kernel then leaves them zero); *ms < 0: shape without a
 // one-pass kernel.  The placement probe of lfpsqp_mat_alloc_placed / lfpsqp_vecs_alloc_placed (projcg.hip).
 int placement_probe(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, double* g, double* d, double* a, int reps, double* ms);
+
+// roctx range around a solver call (SURVEY 5 "tracing"): rocprofv3 --marker-trace / the kernel trace then shows which lfpsqp_* call a kernel
+// belongs to.  libroctx64 is loaded on first use (dlopen, like RCCL); without it, or with LFPSQP_ROCTX=0, the ranges are no-ops.
+struct TraceRange {
+    explicit TraceRange(const char* name);
+    ~TraceRange();
+    bool on;
+};
+#define LF_RANGE(name) lfpsqp::TraceRange lf_range__(name)
 
 // read `count` doubles of device memory back after everything queued so far
 int read_back(lfpsqp_ctx* ctx, const double* dev, double* host, int64_t count);

@@ -312,6 +312,7 @@ using namespace lfpsqp;
 
 extern "C" int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, lfpsqp_vec* x, lfpsqp_vec* r, lfpsqp_vec* p, lfpsqp_vec* z,
                           lfpsqp_vec* tmp_w, lfpsqp_vec* tmp_m, double tol, int64_t maxiter, int* flag, int64_t* iters) {
+    LF_RANGE("lfpsqp_pcg");
     LF_ARG(ctx, ctx && Jop && x && r && p && z && tmp_m && flag && iters);
     const bool stacked = Jop->Dx != nullptr;
     const int m = (int)Jop->ncols;

@@ -232,11 +232,13 @@ int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t 
 }
 
 int lfpsqp_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* v, lfpsqp_vec* t) {
+    LF_RANGE("lfpsqp_gemv_t");
     LF_ARG(ctx, ctx && M && v && t && ncols >= 0 && ncols <= M->m && v->n == M->n && t->n >= ncols);
     return run_gemv_t(ctx, M, (int)ncols, M->n, PlainV{v->p}, t->p);
 }
 
 int lfpsqp_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, double alpha, const lfpsqp_vec* t, double beta, lfpsqp_vec* y) {
+    LF_RANGE("lfpsqp_gemv_n");
     LF_ARG(ctx, ctx && M && y && ncols >= 0 && ncols <= M->m && y->n == M->n && (ncols == 0 || (t && t->n >= ncols)));
     return run_gemv_n<AxpbyEpi, 0, NoPost>(ctx, M, (int)ncols, M->n, t ? t->p : nullptr, AxpbyEpi{y->p, alpha, beta}, nullptr, NoPost());
 }

@@ -785,9 +785,10 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     const bool resume = (flags & LFPSQP_PROJCG_RESUME) != 0;
     int64_t it_base = 0;                              // device iteration number = it_base + host iteration + 1
     if (resume) {
-        if (!fused || !rs.valid || rs.x != x->p || rs.g != g || rs.d != d || rs.Z != Z->p || rs.m != m || rs.nv != nv)
+        if (!fused || !rs.valid || rs.x != x->p || rs.g != g || rs.d != d || rs.Z != Z->p || rs.m != m || rs.nv != nv || rs.dg != Ad.dg ||
+            rs.a0 != Ad.a0 || rs.b != b->p || rs.n_global != n_global || rs.epoch != ctx->launch_epoch)
             return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "LFPSQP_PROJCG_RESUME: no resumable projcg state for these arguments "
-                           "(needs the one-pass iteration, a previous call that stopped at its iteration limit, and no library call in between)");
+                           "(needs the one-pass iteration, a previous call with the same x, A, U, b, work that stopped at its iteration limit, and no library call that queued device work in between)");
         it_base = rs.iters;
         gcur = (rs.gcur_is_rp && gbuf[1] == rp) ? 1 : 0;
         if (rs.gcur_is_rp != (gcur == 1)) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "LFPSQP_PROJCG_RESUME: the buffer scheme changed between the calls");
@@ -864,7 +865,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     if ((status == ST_CONVERGED || status == ST_MAXIT || (fused && status == ST_RG_BREAK && *iters > 1)) && *iters > it_base)
         LF_TRY((run_vec<FlushXF, 0, NoPost>(ctx, nv, FlushXF{x->p, d, scal}, 0u, nullptr, NoPost())));
     if (fused && status == ST_MAXIT && *iters > 0)
-        ctx->pcg_resume = lfpsqp_ctx::ProjcgResume{true, x->p, g, d, Z->p, m, nv, *iters, gcur == 1};
+        ctx->pcg_resume = lfpsqp_ctx::ProjcgResume{true, x->p, g, d, Z->p, m, nv, *iters, gcur == 1, Ad.dg, b->p, Ad.a0, n_global, ctx->launch_epoch};
     if (status == ST_NEGCURV) {   // :77-82
         if (fused && *iters > 1)  // d+ = beta d - g of the iteration that found the negative curvature was not formed yet
             LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, gbuf[gcur], x->p, scal, istat, 1}, 0u, nullptr, NoPost())));
@@ -911,6 +912,7 @@ int lfpsqp::placement_probe(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, dou
 extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, const lfpsqp_basis* U,
                              const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit, int64_t n_global, int flags,
                              const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
+    LF_RANGE("lfpsqp_projcg");
     LF_ARG(ctx, ctx && A);
     return projcg_impl(ctx, x, lambda, A, nullptr, nullptr, nullptr, U, b, c, tol, maxit, n_global, flags, work, iters, nr);
 }
@@ -918,6 +920,7 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
 extern "C" int lfpsqp_projcg_op(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, lfpsqp_opfun A, void* user, lfpsqp_vec* Av,
                                 const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
                                 int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
+    LF_RANGE("lfpsqp_projcg_op");
     LF_ARG(ctx, ctx && A && Av);
     return projcg_impl(ctx, x, lambda, nullptr, A, user, Av, U, b, c, tol, maxit, n_global, flags, work, iters, nr);
 }

@@ -617,11 +617,13 @@ static bool cons_ok(const lfpsqp_constraints* c) {
 extern "C" {
 
 int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval) {
+    LF_RANGE("lfpsqp_constraints_eval");
     LF_ARG(ctx, ctx && cons_ok(cons) && x && cval && x->n >= cons->Jct->n);
     return cons_eval(ctx, cons, x, cval);
 }
 
 int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval) {
+    LF_RANGE("lfpsqp_constraints_jac");
     LF_ARG(ctx, ctx && cons_ok(cons) && x && Jct && cval && x->n >= cons->Jct->n && Jct->p == cons->Jct->p);
     if (const lfpsqp_elementwise* ew = cons->ew) {             // Jct[:, :m_lin] = diag(phi'(x)) A + 2 x qw'
         const int64_t N = Jct->n;
@@ -646,6 +648,7 @@ int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, cons
 }
 
 int lfpsqp_constraints_hess_diag(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, const double* lam, lfpsqp_vec* hx) {
+    LF_RANGE("lfpsqp_constraints_hess_diag");
     LF_ARG(ctx, ctx && cons_ok(cons) && x && lam && hx && x->n >= cons->Jct->n && hx->n >= cons->Jct->n && hx->p != x->p);
     const int64_t N = cons->Jct->n;
     const int ml = (int)cons->m_lin;
@@ -670,6 +673,7 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
                       const lfpsqp_constraints* cons, lfpsqp_cfun cfun, void* cuser, const lfpsqp_ineq_data* idata,
                       const lfpsqp_vec* xtilde, const lfpsqp_vec* x, lfpsqp_vec* xnew, double tol, int64_t maxiter, double* cval,
                       int* flag, int64_t* iters) {
+    LF_RANGE("lfpsqp_retract_nr");
     LF_ARG(ctx, ctx && U && Sigma && Vt && xtilde && x && xnew && cval && flag && iters && m64 >= 1 && U->ncols == m64);
     LF_ARG(ctx, cfun || cons_ok(cons));
     LF_ARG(ctx, xtilde->n == x->n && xnew->n == x->n && xnew->p != x->p && xnew->p != xtilde->p);
@@ -850,6 +854,7 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
                             const lfpsqp_constraints* cons, const lfpsqp_ineq_data* idata, int nb, const lfpsqp_vec* const* xtilde,
                             const lfpsqp_vec* x, lfpsqp_vec* const* xnew, double tol, int64_t maxiter, double* cval, int* flags,
                             int64_t* iters) {
+    LF_RANGE("lfpsqp_retract_nr_batch");
     LF_ARG(ctx, ctx && U && Sigma && Vt && xtilde && x && xnew && cval && flags && iters && m64 >= 1 && U->ncols == m64);
     LF_ARG(ctx, cons_ok(cons) && nb >= 2 && nb <= kNRBatchMax);
     if (cons->Jsp || cons->ew) return LFPSQP_ERR_UNSUPPORTED;     // sparse constraint gradients: single steps on the nonzeros beat a shared dense pass; nonlinear class: one by one
@@ -956,6 +961,7 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
                       lfpsqp_mat* Jct, int64_t m64, const lfpsqp_ineq_data* idata, lfpsqp_vec* Dx, lfpsqp_vec* Dy, lfpsqp_vec* S,
                       const lfpsqp_vec* xtilde, const lfpsqp_vec* x, lfpsqp_vec* xnew, double mu0, double tol, int64_t maxiter,
                       int64_t maxiter_pcg, const lfpsqp_pp_work* w, double* cval, int* flag_out, int64_t* iters, int64_t* pcg_iters) {
+    LF_RANGE("lfpsqp_retract_pp");
     LF_ARG(ctx, ctx && Jct && xtilde && x && xnew && w && cval && flag_out && iters && pcg_iters && m64 >= 1 && m64 <= Jct->m);
     LF_ARG(ctx, (cfun && jacfun) || cons_ok(cons));
     LF_ARG(ctx, w->r && w->p && w->z && w->dx && w->g && w->tmp_m && w->tmp_m->n >= m64);

@@ -22,6 +22,8 @@ class Context:
         self.h = h
         self.rank, self.nranks = 0, 1
         self._cb_keep = None
+        from .params import DeviceOptions
+        self.options = DeviceOptions()          # device-only options (ls_batch, placement_tries): not part of LFPSQPParams
 
     # -- plumbing
     def check(self, rc: int):
@@ -60,6 +62,7 @@ class Context:
     def set_placement(self, tries: int = 3):
         """Candidate allocations tried by the placement-tuned allocators (lfpsqp_ctx_set_placement; 1 = off)."""
         self.check(self.L.lfpsqp_ctx_set_placement(self.h, int(tries)))
+        self.options.placement_tries = int(tries)
 
     def free_memory(self):
         """Free device memory in bytes (None when unknown): sizes the candidate count of placed allocations in bench.py."""

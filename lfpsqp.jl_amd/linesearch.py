@@ -13,6 +13,7 @@ class ArmijoWork:  # src/linesearch.jl:1-5
         self._mk = (lambda: like.__class__(like.ctx, like.N)) if hasattr(like, "N") else (lambda: DeviceVector(like.ctx, like.n))
         self.xtilde = self._mk()
         self.batch = None          # lazily: (xtildes, xnews) for batched trial retractions
+        self.ls_batch = int(like.ctx.options.ls_batch)      # DeviceOptions: trial retractions per pass
         self.prev_failed = False   # did the previous search see a failed retraction? (then this one batches from its first trial)
 
     def batch_vectors(self, k):
@@ -27,6 +28,7 @@ class ExactLinesearchWork:  # :7-14
         self._mk = mk
         self.tmp_n1, self.tmp_n2, self.tmp_n3, self.tmp_n4 = mk(), mk(), mk(), mk()
         self.batch = None          # lazily: (xtildes, xnews) for batched trial retractions of the shrinking phase
+        self.ls_batch = int(like.ctx.options.ls_batch)
 
     def batch_vectors(self, k):
         if self.batch is None or len(self.batch[0]) < k:
@@ -52,10 +54,10 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
     xtilde = work.xtilde
     step = xtilde
     # Trial retractions ahead of time: alpha -> (flag, iter1, iter2, xnew_b, cval_b).  Filled, after the first failure of
-    # this search (or from its first trial when the previous search had failures), with the next param.ls_batch steps of the reference's own sequence alpha*s, alpha*s^2, ... -- the loop
+    # this search (or from its first trial when the previous search had failures), with the next `ls_batch` (ctx.options.ls_batch, a device option: not in LFPSQPParams) steps of the reference's own sequence alpha*s, alpha*s^2, ... -- the loop
     # below consumes them exactly as it would have computed them one by one.
     ahead = {}
-    nbatch = int(getattr(param, "ls_batch", 1))
+    nbatch = int(getattr(work, "ls_batch", 1))
     from .retractions import NR as _NR, DeviceConstraints as _DC
     if not (isinstance(retract_method, _NR) and isinstance(c_, _DC)):
         nbatch = 1                                             # only Newton retractions on device-resident constraints batch
@@ -138,7 +140,7 @@ def exact_linesearch_(xnew, x, n, d, f, fval, retract_method, cval, c_, param, w
     # The next `ls_batch` of them are retracted together (lfpsqp_retract_nr_batch: one pass over Jct per Newton step for all) and
     # consumed in the reference's order -- same points, flags and counts as one by one; unconsumed look-ahead is not counted.
     from .retractions import NR as _NR, DeviceConstraints as _DC
-    nbatch = int(getattr(param, "ls_batch", 1)) if (isinstance(retract_method, _NR) and isinstance(c_, _DC)) else 1
+    nbatch = int(getattr(work, "ls_batch", 1)) if (isinstance(retract_method, _NR) and isinstance(c_, _DC)) else 1
     ahead = {}
 
     def _retract_shrink(pt, a_next):

@@ -63,8 +63,16 @@ class LFPSQPParams:
     do_newton: bool = True
     tn_maxiter: int = 10000
     tn_kappa: float = 0.5
-    # not in the reference: after the first failed retraction of an Armijo search, the next `ls_batch` trial steps
-    # (alpha*s, alpha*s^2, ...) are retracted together (they share every pass over the constraint gradients); the search
-    # consumes them in the reference's order, so the accepted step and all counts are those of the one-by-one search.
-    # 1 = off.  Only the Newton retraction with device-resident constraints batches; everything else ignores it.
+
+
+@dataclass
+class DeviceOptions:
+    """Options of the DEVICE implementation that have no counterpart in the reference -- kept out of LFPSQPParams, which mirrors
+    src/LFPSQP.jl:57-81 field for field.  One instance per Context (``ctx.options``)."""
+    # After the first failed retraction of an Armijo search (or in the shrinking phase of the exact search), the next `ls_batch` trial steps
+    # (alpha*s, alpha*s^2, ...) are retracted together: they share every pass over the constraint gradients (lfpsqp_retract_nr_batch); the
+    # search consumes them in the reference's order, so the accepted step and all counts are those of the one-by-one search.  1 = off.
+    # Only the Newton retraction with device-resident constraints batches; everything else ignores it.
     ls_batch: int = 4
+    # candidate allocations per placement-tuned buffer (lfpsqp_ctx_set_placement; 1 = off)
+    placement_tries: int = 3

@@ -1,4 +1,6 @@
-"""Placement trials for the buffers of the projected-CG loop.
+"""Placement trials for the buffers of the projected-CG loop -- the round-2 HARNESS, kept for comparison (bench.py --placement grid).
+The product's policy lives in the library: lfpsqp_basis_work_alloc_placed / lfpsqp_mat_alloc_placed / lfpsqp_vecs_alloc_placed
+(csrc/context.hip), used by optimize_core and by bench.py's default.
 
 On MI355X the kernels that run a store stream inside a matrix read stream (the fused projected-CG iteration, GEMV-N, the Newton step)
 are 10-15 % faster or slower depending on where the matrix and the n-vectors were allocated -- a property of the PAIR of allocations,
@@ -22,6 +24,11 @@ def best_projcg_buffers(ctx: Context, make_basis, n_loc: int, m: int, A, b, *, n
     Every rank makes the same (collective-carrying) calls when neither option is used; the choice itself is local."""
     n_global = n_loc if n_global is None else n_global
     nbasis, nwork = max(1, int(nbasis)), max(1, int(nwork))
+    # the candidates of the basis live side by side (plus one scratch copy while make_basis orthonormalises): no more of them than fit in
+    # three quarters of the free device memory (round-2 advisor finding: 3 x 164 GB at n = 4e7, m = 512 would not)
+    free_b = ctx.free_memory()
+    if free_b is not None and n_loc * m > 0:
+        nbasis = max(1, min(nbasis, int(0.75 * free_b / (8.0 * n_loc * m)) - 1))
 
     def trial(Uk, xk, wk):
         projcg_(xk, None, A, Uk, b, None, tol=1e-300, maxit=2, work=wk, n_global=n_global, want_lambda=False)      # touch
@@ -68,6 +75,12 @@ def best_projcg_buffers(ctx: Context, make_basis, n_loc: int, m: int, A, b, *, n
                 Zn.free()
         info["extra_basis_trials"] = extra
     x, work = cands[wi]
+    for k, (xk, wk) in enumerate(cands):            # the losing work sets are released now, not whenever the garbage collector gets to them
+        if k != wi:
+            for v_ in (xk, wk.g, wk.d, wk.rp, wk.Utr):
+                v_.free()
+    for v_ in pads:
+        v_.free()
     del pads
     if try_alternating and nbasis * nwork > 1:
         # the alternating residual buffers (lfpsqp_ctx_set_residual_buffers) on the chosen pair: ~12 % faster when even the best pair is a

@@ -227,10 +227,19 @@ def test_projcg_resume_continues_the_same_solve(dev_ctx, n, m, stack):
     with pytest.raises(L.LfpsqpError):        # the converged solve above left nothing to resume
         L.projcg_(x2, None, A, U, b, None, tol=1e-9, maxit=2, work=work2, want_lambda=False, resume=True)
     L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=2, work=work2, want_lambda=False)
-    L.nrm2(x2); L.gemv_t(U.Z, x2, ctx.vector(m))      # harmless calls in between keep the state ...
+    ctx.sync(); x2.download()                           # calls that queue no device work keep the state ...
     L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=1, work=work2, want_lambda=False, resume=True)
     with pytest.raises(L.LfpsqpError):        # ... other work vectors do not match it
         L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=1, work=work, want_lambda=False, resume=True)
+    # ANY library call that queued kernels in between voids it (it may have rewritten the CG scalars or the vectors: round-2 advisor finding),
+    # and so does another operator or right-hand side
+    L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=2, work=work2, want_lambda=False)
+    L.nrm2(x2)
+    with pytest.raises(L.LfpsqpError):
+        L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=1, work=work2, want_lambda=False, resume=True)
+    L.projcg_(x2, None, A, U, b, None, tol=1e-300, maxit=2, work=work2, want_lambda=False)
+    with pytest.raises(L.LfpsqpError):
+        L.projcg_(x2, None, L.DiagOperator(1.0, A.dg), U, b, None, tol=1e-300, maxit=1, work=work2, want_lambda=False, resume=True)
 
 
 @pytest.mark.parametrize("n,m", [(2100, 16), (800, 260)])

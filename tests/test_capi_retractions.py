@@ -646,7 +646,7 @@ def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds):
 
 
 def test_armijo_with_batched_trial_retractions_is_the_same_search(dev_ctx):
-    """LFPSQPParams.ls_batch: after the first failed retraction of an Armijo search the next trial steps are retracted
+    """DeviceOptions.ls_batch (ctx.options): after the first failed retraction of an Armijo search the next trial steps are retracted
     together; the search consumes them in the reference's order, so the accepted step, every count and the iterates are
     those of the one-by-one search (src/linesearch.jl:32-89)."""
     ctx = dev_ctx
@@ -659,8 +659,9 @@ def test_armijo_with_batched_trial_retractions_is_the_same_search(dev_ctx):
         Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
         P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
         tr = []
+        ctx.options.ls_batch = k
         x, obj, lam, ti = P.optimize(P0.x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=2 if emu else 6,
-                                                           maxiter_retract=mr, ls_batch=k), trace=tr)
+                                                           maxiter_retract=mr), trace=tr)
         res[k] = (tr, x, ti)
     tr1, x1, ti1 = res[1]
     tr4, x4, ti4 = res[4]
@@ -672,7 +673,7 @@ def test_armijo_with_batched_trial_retractions_is_the_same_search(dev_ctx):
 
 
 def test_exact_linesearch_with_batched_shrinking_is_the_same_search(dev_ctx):
-    """LFPSQPParams.ls_batch with linesearch = exact: the trial steps of the SHRINKING phase (src/linesearch.jl:176-208, a fixed
+    """DeviceOptions.ls_batch with linesearch = exact: the trial steps of the SHRINKING phase (src/linesearch.jl:176-208, a fixed
     sequence a_c*phi1^k from the same x -- the phase that runs when the first trial retraction fails) are retracted together
     and consumed in the reference's order: accepted step, counts and iterates of the one-by-one search, and of the oracle."""
     ctx = dev_ctx
@@ -686,8 +687,9 @@ def test_exact_linesearch_with_batched_shrinking_is_the_same_search(dev_ctx):
         Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
         P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
         tr = []
+        ctx.options.ls_batch = k
         x, obj, lam, ti = P.optimize(P0.x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=maxiter, maxiter_retract=mr,
-                                                           ls_batch=k, linesearch=L.LinesearchOption.exact), trace=tr)
+                                                           linesearch=L.LinesearchOption.exact), trace=tr)
         res[k] = (tr, x, ti)
     tr1, x1, ti1 = res[1]
     tr4, x4, ti4 = res[4]

@@ -51,7 +51,8 @@ else:
 ctx.sync(); print(f"setup {time.perf_counter()-t0:.2f}s  device={ctx.device_name}", flush=True)
 t0 = time.perf_counter()
 mo = [a for a in sys.argv if a.startswith('--max-outer=')]
-par = L.LFPSQPParams(do_project_retract=pp, ls_batch=batch)
+ctx.options.ls_batch = batch
+par = L.LFPSQPParams(do_project_retract=pp)
 if '--exact' in sys.argv: par.linesearch = L.LinesearchOption.exact
 if mo: par.maxiter = int(mo[0].split('=')[1])
 x, obj, lam, ti = P.optimize(x0, par)
