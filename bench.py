@@ -400,6 +400,9 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     Wg = np.zeros((m, m), order='F')
     L.ksvd_(J, Z2, W=Wg)                                      # warm
     ctx.sync(); t0 = time.perf_counter(); S, Vt, rank = L.ksvd_(J, Z2, W=Wg); ctx.sync(); fact_ms = (time.perf_counter() - t0) * 1e3
+    # the same factorisation with the basis left in factored form U = J W (no basis-forming product: what optimize() runs per outer iteration)
+    L.ksvd_(J, None, W=Wg)
+    ctx.sync(); t0 = time.perf_counter(); L.ksvd_(J, None, W=Wg); ctx.sync(); fact_factored_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter(); L.gram(J); gram_ms = (time.perf_counter() - t0) * 1e3
     W = np.eye(m)
     t0 = time.perf_counter(); L.rmul(J, W, Z2); ctx.sync(); rmul_ms = (time.perf_counter() - t0) * 1e3
@@ -443,6 +446,18 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         if got is not None:
             nr_batch_ms = (time.perf_counter() - t0) * 1e3 / max(got[0][1], 1)
     for v_ in xts + xns:
+        v_.free()
+    # the fused projected-CG iteration on the basis in factored form (streams J, applies W in the post-kernel) against the materialised Z2
+    Af = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.0, 5.0))
+    bf, xf, wf = ctx.vector(n_loc).hash_fill(4, r0), ctx.vector(n_loc), L.ProjCGWork(ctx, n_loc, m)
+    pf = {}
+    for tag, basis in (("materialised", L.DeviceBasis(Z2)), ("factored", L.DeviceBasis(None, m, generator=(J, Wg)))):
+        L.projcg_(xf, None, Af, basis, bf, None, tol=1e-300, maxit=5, work=wf, n_global=n, want_lambda=False)
+        ctx.sync(); t0 = time.perf_counter()
+        itf, _ = L.projcg_(xf, None, Af, basis, bf, None, tol=1e-300, maxit=30, work=wf, n_global=n, want_lambda=False)
+        ctx.sync(); pf[tag] = (time.perf_counter() - t0) * 1e3 / max(itf, 1)
+        pf[tag + "_xnorm"] = L.nrm2(xf)
+    for v_ in (bf, xf, wf.g, wf.d, wf.rp, Af.dg):
         v_.free()
     nr1_bytes = 8.0 * n_loc * m + 24.0 * n_loc                # J pass + xnew read/write + v
     nr2_bytes = 16.0 * n_loc * m + 24.0 * n_loc               # Z pass + J pass + xnew read/write + v
@@ -525,12 +540,13 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     except Exception as e:      # diagnostics only
         sparse = {"error": repr(e)}
     rates = stream_rates(ctx, L, nbig=int(max(1 << 20, min(400_000_000, 40 * n_loc))))
-    return {"stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs_of_the_full_product": flop / gram_ms / 1e9,
+    return {"stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "factorize_factored_basis_ms": fact_factored_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs_of_the_full_product": flop / gram_ms / 1e9,
             "gram_TFLOPs_executed": flop * gram_tile_share(m) / gram_ms / 1e9,
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
             "nr_step_two_streams_ms": nr_ms["two_streams"], "nr_step_two_streams_GBs": gbs(nr2_bytes, nr_ms["two_streams"]),
-            "nr_batch4_step_ms": nr_batch_ms, "nr_iters_timed": int(it), "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit),
+            "nr_batch4_step_ms": nr_batch_ms, "projcg_call_iter_materialised_ms": pf["materialised"], "projcg_call_iter_factored_ms": pf["factored"],
+            "projcg_factored_xnorm_rel_diff": abs(pf["factored_xnorm"] - pf["materialised_xnorm"]) / pf["materialised_xnorm"], "nr_iters_timed": int(it), "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit),
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies; the Gram kernel computes the upper "
                     "triangle only (16 x 16 tiles on and above the diagonal): gram_TFLOPs_executed counts that work, ..._of_the_full_product 2 n m^2"}
 

@@ -720,15 +720,18 @@ static void refine_round(lfpsqp_ctx* ctx, int m, std::vector<double>& V, std::ve
 // kernels, lfpsqp_factorize_sp the products of a sparse A.
 using GramFn = std::function<int(std::vector<double>&)>;
 using RmulFn = std::function<int(const double*, int)>;
-static int factorize_core(lfpsqp_ctx* ctx, int m, const GramFn& gramA, const RmulFn& rmulA, const double* w2p, lfpsqp_mat* Z, double* Sigma,
-                          double* Vt, double* W, int64_t* rank_out, double eps_rank) {
+// Z == nullptr: the caller wants the factors only (Sigma, Vt, W with the basis = A W left in factored form): on the fast path no
+// basis-forming product runs at all; the refinement rounds of an ill-conditioned block still need their trial basis -- needZ() provides one.
+static int factorize_core(lfpsqp_ctx* ctx, int m, const GramFn& gramA, const RmulFn& rmulA, const double* w2p, lfpsqp_mat*& Z,
+                          const std::function<int()>& needZ, double* Sigma, double* Vt, double* W, int64_t* rank_out, double eps_rank) {
+    const bool want_basis = Z != nullptr;
     *rank_out = 0;
     if (m == 0) return 0;
     for (size_t i = 0; i < (size_t)m * m; ++i) Vt[i] = 0.0;
     if (W)
         for (size_t i = 0; i < (size_t)m * m; ++i) W[i] = 0.0;
     auto zero_from = [&](int r) -> int {       // columns >= r of Z are zero (the rmul passes overwrite columns < r completely)
-        if (r < Z->m) {
+        if (Z && r < Z->m) {
             hipLaunchKernelGGL(zero_cols_kernel, dim3(256, (unsigned)(Z->m - r)), dim3(kThreads), 0, ctx->stream, Z->p, Z->ld, Z->n, r);
             LF_LAUNCH_CHECK(ctx);
         }
@@ -763,7 +766,7 @@ static int factorize_core(lfpsqp_ctx* ctx, int m, const GramFn& gramA, const Rmu
         std::vector<double> W1((size_t)m * m);
         for (int j = 0; j < m; ++j)
             for (int i = 0; i < m; ++i) W1[(size_t)j * m + i] = V[(size_t)j * m + i] / sig[j];
-        LF_TRY(rmulA(W1.data(), m));
+        if (want_basis) LF_TRY(rmulA(W1.data(), m));
         LF_TRY(zero_from(m));
         finish(sig, V, m, &W1);
         return 0;
@@ -774,6 +777,7 @@ static int factorize_core(lfpsqp_ctx* ctx, int m, const GramFn& gramA, const Rmu
     //    measure its Gram matrix on the device, and correct V and the singular values from it on the host (refine_round: a
     //    one-sided Jacobi step on a well-scaled m x m factor -- every round gains ~8 digits of relative range; converged when
     //    the trial basis is orthogonal to the rounding floor of the products).  Cost per round: one rmul + one Gram pass.
+    if (!Z) LF_TRY(needZ());
     const double tol = 4e-13;
     constexpr int kMaxRounds = 6;
     std::vector<double> s(m), Wk((size_t)m * m), GZ;
@@ -801,7 +805,7 @@ static int factorize_core(lfpsqp_ctx* ctx, int m, const GramFn& gramA, const Rmu
     std::vector<double> Wr((size_t)m * std::max(r, 1));
     for (int j = 0; j < r; ++j)
         for (int i = 0; i < m; ++i) Wr[(size_t)j * m + i] = V[(size_t)j * m + i] / sig[j];
-    if (r > 0 && !z_is_final) LF_TRY(rmulA(Wr.data(), r));
+    if (r > 0 && !z_is_final && want_basis) LF_TRY(rmulA(Wr.data(), r));
     LF_TRY(zero_from(r));
     finish(sig, V, r, &Wr);
     return 0;
@@ -843,13 +847,18 @@ int lfpsqp_small_svd(lfpsqp_ctx* ctx, int64_t rows, int64_t cols, const double* 
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
                      double* W, int64_t* rank_out, double eps_rank) {
     LF_RANGE("lfpsqp_factorize");
-    LF_ARG(ctx, ctx && Jct && Z && Sigma && Vt && rank_out && Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m &&
+    LF_ARG(ctx, ctx && Jct && Sigma && Vt && rank_out && (Z ? (Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m) : W != nullptr) &&
                     (!w2 || w2->n == Jct->n));
     const int m = (int)Jct->m;
     const double* w2p = w2 ? w2->p : nullptr;
-    return factorize_core(
+    lfpsqp_mat* Zu = Z;
+    lfpsqp_mat* Ztmp = nullptr;
+    const int rc = factorize_core(
         ctx, m, [&](std::vector<double>& G) { return gram_impl(ctx, Jct, m, w2p, G); },
-        [&](const double* Wh, int r) { return rmul_impl(ctx, Jct, m, Wh, r, Z); }, w2p, Z, Sigma, Vt, W, rank_out, eps_rank);
+        [&](const double* Wh, int r) { return rmul_impl(ctx, Jct, m, Wh, r, Zu); }, w2p, Zu,
+        [&]() -> int { LF_TRY(lfpsqp_mat_alloc(ctx, Jct->n, m, &Ztmp)); Zu = Ztmp; return 0; }, Sigma, Vt, W, rank_out, eps_rank);
+    if (Ztmp) lfpsqp_mat_free(ctx, Ztmp);
+    return rc;
 }
 
 int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma,
@@ -877,7 +886,7 @@ int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));                      // Wh is pageable host memory
         return spmm(ctx, S, Jct, ms, m - ms, ctx->small, m, r, Z);
     };
-    return factorize_core(ctx, m, gramA, rmulA, w2p, Z, Sigma, Vt, W, rank_out, eps_rank);
+    return factorize_core(ctx, m, gramA, rmulA, w2p, Z, []() -> int { return LFPSQP_ERR_ARG; }, Sigma, Vt, W, rank_out, eps_rank);
 }
 
 }  // extern "C"

@@ -297,9 +297,52 @@ static bool sp_factored_ok(const lfpsqp_basis* Q, int64_t n) {
            Q->ncols <= 1024;
 }
 
+// the basis in factored form with a DENSE generator (lfpsqp_basis.Z == NULL, A and W given): U = [sx; sy] .* (A W) is never materialised,
+// U't = W'(A'v) and U t = A (W t) stream A, the m x m factor is applied by a one-workgroup kernel
+static bool dense_factored(const lfpsqp_basis* Q) { return !Q->Z && Q->A && Q->W && Q->ncols > 0 && Q->ncols <= Q->A->m && Q->A->m <= kOnepassMaxCols; }
+struct QPlainV {
+    const double* v;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double2 a = ld2(v + r);
+        return make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0);
+    }
+};
+struct QAxpbyE {       // y = alpha * acc + beta * y
+    double* y;
+    double alpha, beta;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, double2 acc, bool v0, bool v1, double*) const {
+        double2 o;
+        if (beta == 0.0) o = make_double2(alpha * acc.x, alpha * acc.y);
+        else {
+            const double2 yy = ld2(y + i);
+            o = make_double2(fma(alpha, acc.x, beta * yy.x), fma(alpha, acc.y, beta * yy.y));
+        }
+        if (v1) st2(y + i, o);
+        else if (v0) y[i] = o.x;
+    }
+};
+
 int lfpsqp_q_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, const lfpsqp_vec* v, lfpsqp_vec* w, lfpsqp_vec* t) {
     LF_RANGE("lfpsqp_q_gemv_t");
-    LF_ARG(ctx, ctx && Q && v && t && Q->ncols >= 0 && (Q->ncols == 0 || (Q->Z && Q->ncols <= Q->Z->m)) && t->n >= Q->ncols);
+    LF_ARG(ctx, ctx && Q && v && t && Q->ncols >= 0 && (Q->ncols == 0 || dense_factored(Q) || (Q->Z && Q->ncols <= Q->Z->m)) && t->n >= Q->ncols);
+    if (dense_factored(Q)) {
+        const int m = (int)Q->ncols, wm = (int)Q->A->m;
+        const int64_t N = Q->A->n;
+        double *dW, *tA, *uA;
+        LF_TRY(factored_setup(ctx, Q->A, Q->W, m, &dW, &tA, &uA));
+        if (!Q->Dx) {
+            LF_ARG(ctx, v->n >= N);
+            LF_TRY(run_gemv_t(ctx, Q->A, wm, N, QPlainV{v->p}, tA));
+        } else {
+            LF_ARG(ctx, Q->Dy && Q->sx && Q->sy && w);
+            const int64_t hs = lfpsqp_half_stride(N);
+            LF_ARG(ctx, Q->Dx->n == N && v->n == hs + N && w->n == N && Q->Dy->n == N && Q->sx->n == N && Q->sy->n == N);
+            LF_TRY(run_gemv_t(ctx, Q->A, wm, N, QtV{v->p, hs, Q->Dx->p, Q->Dy->p, Q->sx->p, Q->sy->p, w->p}, tA));
+        }
+        return sp_basis_small(ctx, dW, wm, m, tA, t->p, nullptr);
+    }
     if (!Q->Dx) {
         LF_ARG(ctx, Q->Z);
         if (sp_factored_ok(Q, v->n)) return sp_factored_gemv_t(ctx, Q->SA, Q->A, Q->W, (int)Q->ncols, v->p, t->p);     // on the nonzeros
@@ -314,7 +357,23 @@ int lfpsqp_q_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, const lfpsqp_vec* v,
 int lfpsqp_q_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, double alpha, const lfpsqp_vec* w, const lfpsqp_vec* t, double beta,
                     lfpsqp_vec* y) {
     LF_RANGE("lfpsqp_q_gemv_n");
-    LF_ARG(ctx, ctx && Q && y && Q->ncols >= 0 && (Q->ncols == 0 || (Q->Z && t && Q->ncols <= Q->Z->m && t->n >= Q->ncols)));
+    LF_ARG(ctx, ctx && Q && y && Q->ncols >= 0 && (Q->ncols == 0 || ((dense_factored(Q) || (Q->Z && Q->ncols <= Q->Z->m)) && t && t->n >= Q->ncols)));
+    if (dense_factored(Q)) {
+        const int m = (int)Q->ncols, wm = (int)Q->A->m;
+        const int64_t N = Q->A->n;
+        double *dW, *tA, *uA;
+        LF_TRY(factored_setup(ctx, Q->A, Q->W, m, &dW, &tA, &uA));
+        LF_TRY(factored_w_times_t(ctx, dW, wm, m, t->p, uA));
+        if (!Q->Dx) {
+            LF_ARG(ctx, y->n >= N);
+            return run_gemv_n<QAxpbyE, 0, NoPost>(ctx, Q->A, wm, N, uA, QAxpbyE{y->p, alpha, beta}, nullptr, NoPost());
+        }
+        LF_ARG(ctx, Q->Dy && Q->sx && Q->sy);
+        const int64_t hs = lfpsqp_half_stride(N);
+        LF_ARG(ctx, Q->Dx->n == N && y->n == hs + N && (!w || w->n == N));
+        return run_gemv_n<QApplyE, 0, NoPost>(ctx, Q->A, wm, N, uA, QApplyE{y->p, hs, Q->Dx->p, Q->Dy->p, Q->sx->p, Q->sy->p, w ? w->p : nullptr, alpha, beta},
+                                              nullptr, NoPost());
+    }
     if (!Q->Dx) {
         LF_ARG(ctx, Q->Z);
         if (sp_factored_ok(Q, y->n)) return sp_factored_gemv_n(ctx, Q->SA, Q->A, Q->W, (int)Q->ncols, alpha, t->p, beta, y->p);

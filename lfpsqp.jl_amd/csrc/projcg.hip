@@ -345,6 +345,14 @@ struct PcgPostF {
     int64_t* istat;
     int m, init;
     HostMirror hm;
+    // basis in factored form with a dense generator, U = A W (lfpsqp_basis.Z == NULL): kernel F streamed A and left the RAW sums
+    // Traw = [A'gp (wm); A'(A_op gp) (wm); 5 scalars]; this kernel applies the small factor -- T = [W'raw1; W'raw2; scalars] first, and
+    // uA = W Utr (the coefficients of F's next first product) last.  W == nullptr: materialised basis, nothing of this runs.
+    const double* W = nullptr;    // wm x m, column-major (device)
+    const double* Traw = nullptr;
+    double* Tw = nullptr;         // == T, writable
+    double* uA = nullptr;
+    int wm = 0;
 };
 // init = 2: RESUME after an iteration-limit exit (LFPSQP_PROJCG_RESUME): the end-of-iteration part already ran in the previous
 // call; the limit has been raised, so the start-of-next-iteration part runs now (x was flushed by that call: alpha_prev = 0).
@@ -355,6 +363,22 @@ __global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
     } else if (ld_stat(u.istat + I_STATUS) != ST_RUNNING) return;
     __shared__ double sh[2];
     __shared__ int go;
+    __shared__ double s_utr[kOnepassMaxCols];
+    if (u.W && u.init != 2) {                                          // (a resumed solve finds T as the previous call converted it)
+        for (int j = threadIdx.x; j < u.m; j += 256) {
+            const double* wj = u.W + (size_t)j * u.wm;
+            double a1 = 0.0, a2 = 0.0;
+            for (int k = 0; k < u.wm; ++k) {
+                a1 = fma(wj[k], ld_scal(u.Traw + k), a1);
+                a2 = fma(wj[k], ld_scal(u.Traw + u.wm + k), a2);
+            }
+            u.Tw[j] = a1;
+            u.Tw[u.m + j] = a2;
+        }
+        if (threadIdx.x < 5) u.Tw[2 * u.m + threadIdx.x] = ld_scal(u.Traw + 2 * u.wm + threadIdx.x);
+        __threadfence();
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         const double* S = u.T + 2 * u.m;
         const double rpgp = ld_scal(S), gpgp = ld_scal(S + 1), gAg = ld_scal(S + 2), gAd = ld_scal(S + 3), dAd = ld_scal(S + 4);
@@ -408,7 +432,17 @@ __global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
         const double t1 = ld_scal(u.T + j), t2 = ld_scal(u.T + u.m + j);
         const double t3 = (u.init == 1) ? -t2 : fma(beta, u.t3[j], -t2);
         u.t3[j] = t3;
-        u.Utr[j] = fma(alpha, t3, t1);
+        const double ut = fma(alpha, t3, t1);
+        u.Utr[j] = ut;
+        if (u.W) s_utr[j] = ut;
+    }
+    if (u.W) {                                                          // uA = W Utr
+        __syncthreads();
+        for (int k = threadIdx.x; k < u.wm; k += 256) {
+            double a = 0.0;
+            for (int j = 0; j < u.m; ++j) a = fma(u.W[(size_t)j * u.wm + k], s_utr[j], a);
+            u.uA[k] = a;
+        }
     }
 }
 // the vector part of an iteration start in the fused flow: x += alpha_prev*d (deferred :92) ; d = beta*d - g (:99)
@@ -633,7 +667,9 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     const int64_t nv = b->n;                       // length of the n-vectors (hs + N when stacked)
     const int m = (int)U->ncols;
     LF_ARG(ctx, x->n == nv && work->g->n == nv && work->d->n == nv && work->rp->n == nv);
-    LF_ARG(ctx, m >= 0 && (m == 0 || (U->Z && m <= U->Z->m && work->Utr->n >= m)));
+    // basis in factored form with a DENSE generator (U->Z == NULL, U = [sx; sy] .* (A W)): the fused iteration streams A
+    const bool DF = m > 0 && !U->Z && U->A && U->W && !U->SA && m <= U->A->m && U->A->m <= kOnepassMaxCols;
+    LF_ARG(ctx, m >= 0 && (m == 0 || ((DF || (U->Z && m <= U->Z->m)) && work->Utr->n >= m)));
     LF_ARG(ctx, !A->dg || A->dg->n == nv);
     LF_ARG(ctx, n_global >= (stacked ? 0 : nv));
     int64_t N = nv, hs = 0;                        // rows of Z
@@ -641,11 +677,11 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         LF_ARG(ctx, U->Dy && U->sx && U->sy);
         N = U->Dx->n;
         hs = lfpsqp_half_stride(N);
-        LF_ARG(ctx, nv == hs + N && U->Dy->n == N && U->sx->n == N && U->sy->n == N && (m == 0 || U->Z->n == N));
+        LF_ARG(ctx, nv == hs + N && U->Dy->n == N && U->sx->n == N && U->sy->n == N && (m == 0 || (DF ? U->A->n : U->Z->n) == N));
         if (c) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "stacked basis with c != 0 (never used by optimize, src/optimize.jl:368)");
         LF_ARG(ctx, !(flags & LFPSQP_PROJCG_WANT_LAMBDA) || (lambda && lambda->n >= N + m));
     } else {
-        LF_ARG(ctx, m == 0 || U->Z->n == nv);
+        LF_ARG(ctx, m == 0 || (DF ? U->A->n : U->Z->n) == nv);
         LF_ARG(ctx, !c || c->n >= m);
         LF_ARG(ctx, !(flags & LFPSQP_PROJCG_WANT_LAMBDA) || (lambda && lambda->n >= m));
     }
@@ -657,7 +693,8 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     double* d = work->d->p;
     double* rp = work->rp->p;
     double* Utr = work->Utr->p;
-    const lfpsqp_mat* Z = m > 0 ? U->Z : nullptr;
+    const lfpsqp_mat* Z = m > 0 ? (DF ? U->A : U->Z) : nullptr;      // the matrix the kernels stream
+    const int mc = DF ? (int)U->A->m : m;                            // ... and how many of its columns
     const StackD sk = stacked ? StackD{hs, U->Dx->p, U->Dy->p, U->sx->p, U->sy->p} : StackD{0, nullptr, nullptr, nullptr, nullptr};
     // loop bound min(maxit, n + m) with the reference's n = length(b), m = length(c)   (src/projcg.jl:43-44,71)
     const int64_t m_ref = stacked ? n_global / 2 + m : m;
@@ -697,6 +734,31 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         return sp_basis_small(ctx, dWs, wm, m, tA, t_out, u_out);
     };
 
+    // fused iteration (one pass over U)?  Needs a tile shape for m columns and 32-bit lane offsets
+    const bool fused = !SA && !opf && m > 0 && onepass_cw(ctx, mc, Z->ld, N) != 0;
+    if (DF && !fused)
+        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "basis in factored form (Z == NULL) needs the fused iteration: diagonal operator, 4 .. 1024 generator "
+                                                    "columns; materialise Z = A W for this shape");
+    if (DF && c) LF_TRY(lfpsqp_q_gemv_n(ctx, U, 1.0, nullptr, c, 0.0, x));       // x = U c (:55), before the small factor settles in ctx->small
+    double *T12 = nullptr, *t3 = nullptr, *Traw = nullptr, *uDF = nullptr, *dWf = nullptr;
+    if (fused) {
+        LF_TRY(ensure_mvec(ctx, (size_t)3 * m + (DF ? 3 * (size_t)mc + 16 : 0) + 24));
+        T12 = ctx->d_m;                                  // [t1 (m); t2 (m); rp'gp; gp'gp; g'Ag; g'Ad; d'Ad]
+        t3 = ctx->d_m + round_up(2 * m + 5, 2);
+        if (DF) {
+            Traw = t3 + round_up(m, 2);                  // the kernel's raw sums over the generator's columns
+            uDF = Traw + round_up(2 * mc + 5, 2);        // W Utr: the coefficients of the first product
+            LF_TRY(ensure_small(ctx, (size_t)mc * m + 64));
+            dWf = ctx->small;
+            LF_HIP(ctx, hipMemcpyAsync(dWf, U->W, sizeof(double) * (size_t)mc * m, hipMemcpyHostToDevice, ctx->stream));
+            LF_HIP(ctx, hipStreamSynchronize(ctx->stream));             // U->W is caller-owned pageable memory
+        }
+    }
+    // t_out = U'v for the producer v: W'(A'v) (raw products parked in Traw); u_out (optional) = W t_out
+    auto df_gemv_t = [&](auto vf, double* t_out, double* u_out) -> int {
+        LF_TRY(run_gemv_t(ctx, Z, mc, N, vf, Traw));
+        return sp_basis_small(ctx, dWf, mc, m, Traw, t_out, u_out);
+    };
     const HostMirror hm{ctx->h_istat, ctx->h_scal};
     volatile int64_t* hstat = ctx->h_istat;
     hstat[0] = ST_RUNNING;
@@ -713,6 +775,8 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         using AOP = decltype(aop);
         const ResidualV<AOP> rv{x->p, b->p, store, aop, sgn};
         if (SA && stacked) return sp_gemv_t(ResidualVS<AOP>{rv, sk, store ? nullptr : lambda->p}, tmpN, t_out, store ? uA : nullptr);
+        if (DF && stacked) return df_gemv_t(ResidualVS<AOP>{rv, sk, store ? nullptr : lambda->p}, t_out, store ? uDF : nullptr);
+        if (DF) return df_gemv_t(rv, t_out, store ? uDF : nullptr);
         if (stacked) return run_gemv_t(ctx, Z, m, N, ResidualVS<AOP>{rv, sk, store ? nullptr : lambda->p}, t_out);
         if (SA) return sp_gemv_t(rv, tmpN, t_out, store ? uA : nullptr);    // (plain basis: rp doubles as the scratch vector)
         return run_gemv_t(ctx, Z, m, N, rv, t_out);
@@ -750,14 +814,6 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     };
     auto launch_k3 = [&](int init) -> int { return opf ? k3_with(Aop, init) : k3_with(Ad, init); };
 
-    // fused iteration (one pass over U)?  Needs a tile shape for m columns and 32-bit lane offsets
-    const bool fused = !SA && !opf && m > 0 && onepass_cw(ctx, m, Z->ld, N) != 0;
-    double *T12 = nullptr, *t3 = nullptr;
-    if (fused) {
-        LF_TRY(ensure_mvec(ctx, (size_t)3 * m + 24));
-        T12 = ctx->d_m;                                  // [t1 (m); t2 (m); rp'gp; gp'gp; g'Ag; g'Ad; d'Ad]
-        t3 = ctx->d_m + round_up(2 * m + 5, 2);
-    }
     // The fused kernel reads the residual of a row a tile ahead and stores the projected one a tile later.  On a box in the slow
     // state of DESIGN.md §6, removing EITHER that load or that store of the same line made the kernel 13 % faster (1.95 -> 1.70 ms),
     // which suggested alternating two buffers between iterations (work->g and work->rp, free after the initial projection) so
@@ -771,12 +827,14 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         const int slot = init ? -1 : 3;
         const double* gin = gbuf[gcur];
         double* gout = init ? gbuf[0] : gbuf[gcur ^ 1];
-        if (stacked && init) LF_TRY((run_onepass<PcgFuseE<true, true>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<true, true>{rp, gin, gout, d, Ad, scal, istat, sk}, T12, slot)));
-        else if (stacked) LF_TRY((run_onepass<PcgFuseE<true, false>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<true, false>{rp, gin, gout, d, Ad, scal, istat, sk}, T12, slot)));
-        else if (init) LF_TRY((run_onepass<PcgFuseE<false, true>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<false, true>{rp, gin, gout, d, Ad, scal, istat, sk}, T12, slot)));
-        else LF_TRY((run_onepass<PcgFuseE<false, false>, 2, 5>(ctx, Z, m, m, N, Utr, PcgFuseE<false, false>{rp, gin, gout, d, Ad, scal, istat, sk}, T12, slot)));
+        const double* tin = DF ? uDF : Utr;               // coefficients of the first product over the streamed matrix's mc columns
+        double* Tout = DF ? Traw : T12;
+        if (stacked && init) LF_TRY((run_onepass<PcgFuseE<true, true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<true, true>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
+        else if (stacked) LF_TRY((run_onepass<PcgFuseE<true, false>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<true, false>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
+        else if (init) LF_TRY((run_onepass<PcgFuseE<false, true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<false, true>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
+        else LF_TRY((run_onepass<PcgFuseE<false, false>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<false, false>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
         if (!init) gcur ^= 1;
-        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, init, hm});
+        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, init, hm, dWf, Traw, T12, uDF, DF ? mc : 0});
         LF_LAUNCH_CHECK(ctx);
         return 0;
     };
@@ -797,7 +855,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         const int64_t lim = maxit_eff;
         LF_HIP(ctx, hipMemcpyAsync(istat + I_MAXIT, &lim, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));            // (source on the stack)
-        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, 2, hm});
+        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, 2, hm, dWf, Traw, T12, uDF, DF ? mc : 0});
         LF_LAUNCH_CHECK(ctx);
     }
     ctx->pcg_resume.valid = false;
@@ -807,7 +865,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
 
         // x = U c (:55); c == NULL is the all-zero c of optimize
         if (c && m > 0) {
-            LF_TRY(lfpsqp_gemv_n(ctx, Z, m, 1.0, c, 0.0, x));
+            if (!DF) LF_TRY(lfpsqp_gemv_n(ctx, Z, m, 1.0, c, 0.0, x));      // (factored basis: done above)
         } else {
             LF_TRY(lfpsqp_vec_fill(ctx, x, 0.0));
         }

@@ -694,7 +694,10 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         const int cwd = (wm && !ew) ? onepass_cw(ctx, wm, cons->Jct->ld, N) : 0;
         // ... and with a sparse twin of the linear block (all but <= 4 of A's columns) the step runs on the nonzeros alone
         const lfpsqp_spmat* Ssp = (wm && ml > 0 && cons->Jsp && cons->Jsp->n == N && cons->Jsp->m == ml && wm >= ml && wm - ml <= 4) ? cons->Jsp : nullptr;
-        const int cw = Ssp ? 1 : cwd;                 // (non-zero: the generator W and W*ddelta are kept on the device)
+        // (non-zero: the generator W and W*ddelta are kept on the device) -- also when only the two-stream kernel applies (nonlinear class, shapes
+        // without a one-pass kernel): it then streams Jct with W*ddelta instead of Z with ddelta, so a basis in factored form (U->Z == NULL) works
+        const int cw = (Ssp || wm) ? 1 : cwd;
+        LF_ARG(ctx, U->Z || wm);
         const size_t wsz = cw ? (((size_t)wm * m + (size_t)wm + 1) & ~(size_t)1) : 0;
         LF_TRY(ensure_small(ctx, 2 * mm + wsz + 8 * (size_t)m + 256));
         double* dD = ctx->small;
@@ -732,6 +735,10 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
             if (ew->Asp && !ep.kind) ep.phi_out = nullptr;
         }
         const lfpsqp_mat* cmat = ew ? ew->A : cons->Jct;          // the matrix of the c! product
+        // first product of a two-stream step: U delta = Z delta, or Jct (W delta) when the generator is known
+        const lfpsqp_mat* s1 = wm ? cons->Jct : U->Z;
+        const int n1 = wm ? wm : m;
+        const double* t1 = wm ? dwdelta : ddelta;
         const lfpsqp_spmat* csp = ew ? ew->Asp : Ssp;
         int64_t it = 0;
         bool done = false;
@@ -741,14 +748,14 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
                 const NRSparseStepF sf{ep, ell_rows(Ssp, dwdelta), cons->Jct->p + (int64_t)ml * cons->Jct->ld, cons->Jct->ld, dwdelta + ml, wm - ml};
                 LF_TRY((run_vec<NRSparseStepF, 1, NoPost>(ctx, N, sf, 0u, draw + ml, NoPost())));
                 LF_TRY(spmv_t(ctx, csp, ep.phi_out ? ep.phi_out : xnew->p, draw));
-            } else if (cw && ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<true>{ep}, draw)));
-            else if (cw) LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<false>{ep}, draw)));
+            } else if (cwd && ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<true>{ep}, draw)));
+            else if (cwd) LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<false>{ep}, draw)));
             else if (ew && ew->Asp) {                             // sparse A without the generator hint: dense step over Z, sparse c!
-                LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, U->Z, m, ddelta, nullptr, 0, N, ep, draw + ml)));
+                LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, s1, n1, t1, nullptr, 0, N, ep, draw + ml)));
                 if (quad) LF_TRY((run_vec<BallF, 1, NoPost>(ctx, N, BallF{xnew->p, cons->n_x, cons->slack_row}, 0u, draw + ml, NoPost())));   // (summed as c! sums it)
                 LF_TRY(spmv_t(ctx, csp, ep.phi_out ? ep.phi_out : xnew->p, draw));
-            } else if (quad || ew) LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, U->Z, m, ddelta, cmat, ml, N, ep, draw)));
-            else LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, U->Z, m, ddelta, cmat, ml, N, ep, draw)));
+            } else if (quad || ew) LF_TRY((run_gemv_nt<NRStepE, 1>(ctx, s1, n1, t1, cmat, ml, N, ep, draw)));
+            else LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, s1, n1, t1, cmat, ml, N, ep, draw)));
             hipLaunchKernelGGL(nr_small_kernel, dim3(1), dim3(kNRThreads), 0, ctx->stream, sm, 0);
             LF_LAUNCH_CHECK(ctx);
             LF_HIP(ctx, hipEventRecord(ctx->ev_slot[(it + 1) & 3], ctx->stream));
@@ -802,7 +809,7 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
             h_delta[k] = -s;
         }
         LF_HIP(ctx, hipMemcpyAsync(tv.p, h_delta, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
-        if (!cfun && !cons->ew) {
+        if (!cfun && !cons->ew && U->Z) {
             // fused step: xnew += U tmp (:141), y_retract! (:145), and the c! products (:146/148) in one launch
             const int ml = (int)cons->m_lin;
             const int64_t N = cons->Jct->n;

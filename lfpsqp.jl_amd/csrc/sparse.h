@@ -50,6 +50,11 @@ int spmv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const double* v, double* t_ou
 // t_out[0:m) = W' tA and optionally u_out[0:wm) = W t_out (W on the device, wm x m column-major): the replicated small step of a basis in
 // factored form U = A W
 int sp_basis_small(lfpsqp_ctx* ctx, const double* W_dev, int wm, int m, const double* tA, double* t_out, double* u_out);
+// W (host, wm x m) onto the device (ctx->small) with two wm-vectors of scratch behind it: the replicated part of a basis in factored form
+// U = A W, with or without a sparse twin of A (dense generator: lfpsqp_basis.Z == NULL)
+int factored_setup(lfpsqp_ctx* ctx, const lfpsqp_mat* A, const double* W_host, int m, double** dW, double** tA, double** uA);
+// u_out[0:wm) = W t (t: m entries on the device)
+int factored_w_times_t(lfpsqp_ctx* ctx, const double* W_dev, int wm, int m, const double* t, double* u_out);
 // the factored basis U = A W, A = [SA | A[:, SA.m:)] (at most 4 dense columns), W host (A.m x m), applied without a dense n x m matrix:
 // t_out = U'v   /   y = alpha U t + beta y   (v, t, y device pointers)
 int sp_factored_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, const double* v, double* t_out);

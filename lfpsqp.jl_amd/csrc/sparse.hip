@@ -237,8 +237,7 @@ struct SpFactoredNF {  // y = alpha * ([S | X] u) + beta * y
         else if (v0) y[i] = o.x;
     }
 };
-static int factored_setup(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, double** dW, double** tA,
-                          double** uA) {
+int factored_setup(lfpsqp_ctx* ctx, const lfpsqp_mat* A, const double* W_host, int m, double** dW, double** tA, double** uA) {
     const int wm = (int)A->m;
     LF_TRY(ensure_small(ctx, (size_t)wm * m + 2 * (size_t)wm + 64));
     *dW = ctx->small;
@@ -246,12 +245,11 @@ static int factored_setup(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_
     *uA = *tA + ((wm + 1) & ~1);
     LF_HIP(ctx, hipMemcpyAsync(*dW, W_host, sizeof(double) * (size_t)wm * m, hipMemcpyHostToDevice, ctx->stream));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // W_host is caller-owned pageable memory
-    (void)SA;
     return 0;
 }
 int sp_factored_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, const double* v, double* t_out) {
     double *dW, *tA, *uA;
-    LF_TRY(factored_setup(ctx, SA, A, W_host, m, &dW, &tA, &uA));
+    LF_TRY(factored_setup(ctx, A, W_host, m, &dW, &tA, &uA));
     const int wm = (int)A->m, nx = wm - (int)SA->m;
     LF_TRY(spmv_t(ctx, SA, v, tA));
     if (nx > 0) {
@@ -269,10 +267,15 @@ __global__ __launch_bounds__(256) void sp_w_times_t_kernel(const double* __restr
         u_out[k] = s;
     }
 }
+int factored_w_times_t(lfpsqp_ctx* ctx, const double* W_dev, int wm, int m, const double* t, double* u_out) {
+    hipLaunchKernelGGL(sp_w_times_t_kernel, dim3(1), dim3(256), 0, ctx->stream, W_dev, wm, m, t, u_out);
+    LF_LAUNCH_CHECK(ctx);
+    return 0;
+}
 int sp_factored_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_spmat* SA, const lfpsqp_mat* A, const double* W_host, int m, double alpha, const double* t,
                        double beta, double* y) {
     double *dW, *tA, *uA;
-    LF_TRY(factored_setup(ctx, SA, A, W_host, m, &dW, &tA, &uA));
+    LF_TRY(factored_setup(ctx, A, W_host, m, &dW, &tA, &uA));
     const int wm = (int)A->m, nx = wm - (int)SA->m;
     hipLaunchKernelGGL(sp_w_times_t_kernel, dim3(1), dim3(256), 0, ctx->stream, dW, wm, m, t, uA);
     LF_LAUNCH_CHECK(ctx);

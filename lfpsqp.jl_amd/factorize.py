@@ -25,10 +25,11 @@ def rmul(In: DeviceMatrix, W: np.ndarray, Out: DeviceMatrix) -> DeviceMatrix:
     return Out
 
 
-def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix, w2: DeviceVector | None = None, eps_rank: float = 1e-10,
+def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix | None, w2: DeviceVector | None = None, eps_rank: float = 1e-10,
           W: np.ndarray | None = None, Jsp=None):
     """Thin factorisation diag(sqrt(w2)) Jct = U S Vt with U = diag(sqrt(w2)) Z.
-    Returns (Sigma, Vt, rank); Z is overwritten (Jct is NOT destroyed, unlike dgesvd).
+    Returns (Sigma, Vt, rank); Z is overwritten (Jct is NOT destroyed, unlike dgesvd).  ``Z = None`` (dense Jct, ``W`` required): the
+    basis Z = Jct @ W is not formed -- the caller keeps it in factored form (DeviceBasis(None, rank, generator=(Jct, W))).
     ``W`` (optional, m x m Fortran-ordered float64) receives the small factor with Z = Jct @ W.
     ``Jsp`` (optional SparseMatrix with the entries of the leading ``Jsp.m`` columns of Jct; Jct may then be None when there are no
     further columns): the basis-forming products stream the nonzeros (lfpsqp_factorize_sp)."""
@@ -44,7 +45,7 @@ def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix, w2: DeviceVector | None = N
                                             S.ctypes.data, Vt.ctypes.data, W.ctypes.data if W is not None else None, C.byref(rank),
                                             float(eps_rank)))
     else:
-        ctx.check(ctx.L.lfpsqp_factorize(ctx.h, Jct.h, w2.h if w2 is not None else None, Z.h, S.ctypes.data,
+        ctx.check(ctx.L.lfpsqp_factorize(ctx.h, Jct.h, w2.h if w2 is not None else None, Z.h if Z is not None else None, S.ctypes.data,
                                          Vt.ctypes.data, W.ctypes.data if W is not None else None, C.byref(rank),
                                          float(eps_rank)))
     return S, Vt, rank.value

@@ -74,9 +74,10 @@ class InequalityDecomp:
     """InequalityDecomp (src/inequality_helper.jl:10-19).  ``U`` of the reference (2N x M) is held
     as the N x M matrix ``Z`` plus the row scalings sx = Dy^2, sy = -Dx*Dy."""
 
-    def __init__(self, ctx: Context, N: int, M: int, Jct: DeviceMatrix | None = None, Z: DeviceMatrix | None = None):
+    def __init__(self, ctx: Context, N: int, M: int, Jct: DeviceMatrix | None = None, Z: DeviceMatrix | None = None, factored: bool = False):
         self.ctx, self.N, self.M = ctx, N, M
-        self.Z = Z if Z is not None else DeviceMatrix(ctx, N, M)      # (the driver hands in a basis allocated jointly with ProjCGWork, DESIGN.md 6)
+        # (the driver hands in a basis allocated jointly with ProjCGWork, DESIGN.md 6 -- or none at all: factored form, 5.3)
+        self.Z = Z if (Z is not None or factored) else DeviceMatrix(ctx, N, M)
         self.Sigma = np.zeros(M)
         self.Vt = np.zeros((M, M), order='F')
         self.Dx, self.Dy, self.S, self.sx, self.sy = (DeviceVector(ctx, N) for _ in range(5))
@@ -86,10 +87,11 @@ class InequalityDecomp:
         self.Jsp = None                     # sparse twin of Jct's leading columns: projcg_ then runs on the nonzeros (lfpsqp_basis.SA)
 
     def basis_c(self):
+        zh = self.Z.h if self.Z is not None else None        # None: the basis stays in factored form U = [sx; sy] .* (Jct W)
         if self.W is not None:
-            return _capi.Basis(self.Z.h, self.rank, self.Dx.h, self.Dy.h, self.sx.h, self.sy.h, self.Jct.h, self.W.ctypes.data, None,
+            return _capi.Basis(zh, self.rank, self.Dx.h, self.Dy.h, self.sx.h, self.sy.h, self.Jct.h, self.W.ctypes.data, None,
                                self.Jsp.h if self.Jsp is not None else None)
-        return _capi.Basis(self.Z.h, self.rank, self.Dx.h, self.Dy.h, self.sx.h, self.sy.h)
+        return _capi.Basis(zh, self.rank, self.Dx.h, self.Dy.h, self.sx.h, self.sy.h)
 
 
 def inequality_gradient_(idecomp: InequalityDecomp, xaug: StackedVector, idata: InequalityData):

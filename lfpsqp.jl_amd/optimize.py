@@ -165,8 +165,16 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     # by trial over pairs of candidate allocations (lfpsqp_basis_work_alloc_placed, DESIGN.md 6: the speed of the fused kernel is a property of
     # the pair of allocations)
     diagonal_hessian = hasattr(hess_lag_vec_, "diag_")
-    projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=(("new", n, m) if m > 0 else None), extra=1 if diagonal_hessian else 0)
-    idecomp = InequalityDecomp(ctx, n, m, Jct, Z=projcgwork.basis)
+    # ... unless the basis can stay in FACTORED form U = Jct W: then there is no Z at all -- the fused projected-CG iteration, the
+    # Newton step and the projections stream Jct and apply the m x m factor W on the side, the tangent setup skips its basis-forming product,
+    # and the work vectors are placed against Jct.
+    factored = bool(ctx.options.factored_basis) and diagonal_hessian and 4 <= m <= 1024 and getattr(c_, "Jsp", None) is None
+    if factored:
+        projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=Jct, extra=1)
+        idecomp = InequalityDecomp(ctx, n, m, Jct, factored=True)
+    else:
+        projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=(("new", n, m) if m > 0 else None), extra=1 if diagonal_hessian else 0)
+        idecomp = InequalityDecomp(ctx, n, m, Jct, Z=projcgwork.basis)
     Z = idecomp.Z
     Sig, Vt = idecomp.Sigma, idecomp.Vt
     Wgen = np.zeros((m, m), order='F') if m > 0 else None                  # ksvd_'s small factor: Z == Jct @ Wgen
@@ -228,7 +236,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             Vt[:, :] = Vt_
             if not ineq:                                                   # :305-308
                 jsp_ = getattr(c_, "Jsp", None)
-                if jsp_ is not None:                                       # sparse twin: the projection runs on the nonzeros too
+                if jsp_ is not None or Z is None:                          # sparse twin / factored basis: U = Jct W applied without Z
                     Ub = DeviceBasis(Z, rank, generator=(Jct, Wgen), sparse=jsp_)
                     Ub.adjoint().mul_(tmp_m, d)
                     Ub.mul_(d, tmp_m, -1.0, 1.0)
@@ -282,7 +290,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
                 Qview = ineqproject
             else:
                 jsp_ = getattr(c_, "Jsp", None)                              # sparse twin: the projected CG runs on the nonzeros
-                Qview = DeviceBasis(Z, rank, generator=(Jct, Wgen), sparse=jsp_) if jsp_ is not None else DeviceBasis(Z, rank)
+                Qview = DeviceBasis(Z, rank, generator=(Jct, Wgen), sparse=jsp_) if (jsp_ is not None or Z is None) else DeviceBasis(Z, rank)
             grad_norm = nrm2(d)
             with np.errstate(divide='ignore', invalid='ignore'):
                 ratio = float(np.float64(grad_norm) / np.float64(prev_grad_norm))

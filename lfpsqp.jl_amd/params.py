@@ -76,3 +76,7 @@ class DeviceOptions:
     ls_batch: int = 4
     # candidate allocations per placement-tuned buffer (lfpsqp_ctx_set_placement; 1 = off)
     placement_tries: int = 3
+    # the tangent basis stays in factored form U = Jct W (no n x m basis matrix, no basis-forming product in the tangent setup) whenever the
+    # fused projected-CG iteration applies (diagonal Lagrangian Hessian, 4 .. 1024 constraints, dense constraint gradients); False: always
+    # materialise Z = Jct W as rounds 1-2 did
+    factored_basis: bool = True

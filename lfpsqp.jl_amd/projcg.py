@@ -49,29 +49,37 @@ class DiagOperator:
 
 
 class DeviceBasis:
-    """Orthonormal U = Z[:, :ncols] (``view(U, :, 1:rank)``, src/optimize.jl:370)."""
+    """Orthonormal U = Z[:, :ncols] (``view(U, :, 1:rank)``, src/optimize.jl:370).
+    ``Z = None`` with ``generator = (A, W)``: the basis in FACTORED form U = A W -- never materialised; projcg_, the Newton retraction and
+    the projections stream A and apply the small factor W on the side (lfpsqp_basis.Z == NULL)."""
 
-    def __init__(self, Z: DeviceMatrix, ncols: int | None = None, generator=None, sparse=None):
+    def __init__(self, Z: DeviceMatrix | None, ncols: int | None = None, generator=None, sparse=None):
         self.Z = Z
-        self.ncols = Z.m if ncols is None else int(ncols)
+        assert Z is not None or generator is not None
+        self.ncols = (Z.m if Z is not None else generator[1].shape[1]) if ncols is None else int(ncols)
         self.generator = generator          # optional (A, W) with Z == A @ W (ksvd_'s W): lfpsqp_basis.A / .W
         self.sparse = sparse                # optional SparseMatrix twin of A's leading columns: projcg_ runs on the nonzeros (lfpsqp_basis.SA)
 
+    @property
+    def ctx(self):
+        return self.Z.ctx if self.Z is not None else self.generator[0].ctx
+
     def _c(self):
+        zh = self.Z.h if self.Z is not None else None
         if self.generator is not None:
             A, W = self.generator
-            return _capi.Basis(self.Z.h, self.ncols, None, None, None, None, A.h, W.ctypes.data, None,
+            return _capi.Basis(zh, self.ncols, None, None, None, None, A.h, W.ctypes.data, None,
                                self.sparse.h if self.sparse is not None else None)
-        return _capi.Basis(self.Z.h, self.ncols, None, None, None, None)
+        return _capi.Basis(zh, self.ncols, None, None, None, None)
 
     def _factored(self):
-        return self.sparse is not None and self.generator is not None
+        return self.generator is not None and (self.sparse is not None or self.Z is None)
 
     def mul_(self, dest, v, a=None, b=None):
         if a is None:
             a, b = 1.0, 0.0
-        if self._factored():                # U t = A (W t) on the nonzeros (lfpsqp_q_gemv_n with lfpsqp_basis.SA)
-            c = self.Z.ctx
+        if self._factored():                # U t = A (W t): on the nonzeros (lfpsqp_basis.SA) or over the dense generator (Z == NULL)
+            c = self.ctx
             bs = self._c()
             c.check(c.L.lfpsqp_q_gemv_n(c.h, C.byref(bs), float(a), None, v.h, float(b), dest.h))
             return dest
@@ -87,8 +95,8 @@ class _BasisAdjoint:
 
     def mul_(self, dest, v, a=None, b=None):
         assert a is None
-        if self.basis._factored():          # U'v = W'(A'v) on the nonzeros
-            c = self.basis.Z.ctx
+        if self.basis._factored():          # U'v = W'(A'v)
+            c = self.basis.ctx
             bs = self.basis._c()
             c.check(c.L.lfpsqp_q_gemv_t(c.h, C.byref(bs), v.h, None, dest.h))
             return dest
