@@ -219,6 +219,7 @@ c_retract_pp(ctx, cons, cfun, jacfun, user, Jct, m, idata, Dx, Dy, S, xtilde, x,
 mutable struct DeviceOptions
     ls_batch::Int
     placement_tries::Int
+    factored_basis::Bool        # keep the tangent basis in factored form U = Jct W whenever the fused projected-CG iteration applies
 end
 mutable struct HipContext
     h::Ptr{Cvoid}
@@ -229,7 +230,7 @@ mutable struct HipContext
         r = Ref{Ptr{Cvoid}}(C_NULL)
         rc = c_ctx_create(Cint(device), r)
         rc == 0 || throw(HipError(rc, "lfpsqp_ctx_create failed: no usable MI355X (there is no CPU fallback)"))
-        ctx = new(r[], 0, 1, DeviceOptions(4, 3))
+        ctx = new(r[], 0, 1, DeviceOptions(4, 3, true))
         finalizer(c -> c_ctx_destroy(c.h), ctx)
         return ctx
     end
@@ -332,6 +333,20 @@ function basis_and_vectors_placed(ctx::HipContext, n::Integer, m::Integer, count
     end
     return M, vs
 end
+# `count` n-vectors (stacked when N > 0) from ONE allocation, placement-tuned against the matrix M they are streamed with (lfpsqp_vecs_alloc_placed)
+function vectors_placed(ctx::HipContext, M::DeviceMatrix, n::Integer, count::Integer; N::Integer=0)
+    hs = N > 0 ? Int(c_half_stride(Int64(N))) : 0
+    nv = N > 0 ? hs + N : n
+    hh = fill(Ptr{Cvoid}(C_NULL), count)
+    check(ctx, c_vecs_alloc_placed(ctx.h, M.h, Int64(M.m), Int64(nv), Cint(count), hh))
+    vs = DeviceVector[]
+    for h in hh
+        v = DeviceVector(ctx, h, nv, N, hs)
+        finalizer(x -> c_vec_free(x.ctx.h, x.h), v)
+        push!(vs, v)
+    end
+    return vs
+end
 function placement_info(ctx::HipContext)                    # (trials made, index kept, fused-kernel ms per trial) of the last placed allocation
     tries, picked = Ref{Cint}(0), Ref{Cint}(0)
     ms = zeros(64)
@@ -410,15 +425,18 @@ vmul!(y::DeviceVector, d::DeviceVector, x::DeviceVector) = (check(y.ctx, c_vmul(
 # =====================================================================================================================
 # view(U, :, 1:rank) (src/optimize.jl:370).  `generator` = (Jct, W) with Z == Jct*W (ksvd!'s W): the Newton retraction then
 # streams Jct once per step instead of Z and Jct.
+# Z === nothing with generator = (A, W): the basis in FACTORED form U = A W, never materialised -- projcg!, the projections and the Newton
+# retraction stream A and apply the small factor W on the side (lfpsqp_basis.Z == NULL, DESIGN.md 5.3).
 struct DeviceBasis
-    Z::DeviceMatrix
+    Z::Union{Nothing,DeviceMatrix}
     ncols::Int
     generator::Union{Nothing,Tuple{DeviceMatrix,Matrix{Float64}}}
     sparse::Ptr{Cvoid}         # lfpsqp_spmat handle of the generator's sparse twin (projcg on the nonzeros), C_NULL otherwise
 end
 DeviceBasis(Z::DeviceMatrix) = DeviceBasis(Z, Z.m, nothing, C_NULL)
 DeviceBasis(Z::DeviceMatrix, ncols::Integer) = DeviceBasis(Z, ncols, nothing, C_NULL)
-DeviceBasis(Z::DeviceMatrix, ncols::Integer, generator) = DeviceBasis(Z, ncols, generator, C_NULL)
+DeviceBasis(Z::Union{Nothing,DeviceMatrix}, ncols::Integer, generator) = DeviceBasis(Z, ncols, generator, C_NULL)
+zhandle(Z) = Z === nothing ? Ptr{Cvoid}(C_NULL) : Z.h
 struct DeviceBasisAdjoint
     U::DeviceBasis
 end
@@ -426,7 +444,7 @@ Base.adjoint(U::DeviceBasis) = DeviceBasisAdjoint(U)
 Base.adjoint(Ut::DeviceBasisAdjoint) = Ut.U
 # kgemv! (src/la_helper.jl:36-44) and the mul! calls of src/projcg.jl / src/retractions.jl
 # (a basis that carries its generator and the generator's sparse twin is applied in factored form on the nonzeros: lfpsqp_q_gemv_*)
-factored(U::DeviceBasis) = U.generator !== nothing && U.sparse != C_NULL
+factored(U::DeviceBasis) = U.generator !== nothing && (U.sparse != C_NULL || U.Z === nothing)
 mul!(y::DeviceVector, U::DeviceBasis, t::DeviceVector, a::Number=1.0, b::Number=0.0) =
     (check(y.ctx, factored(U) ? c_q_gemv_n(y.ctx.h, Ref(cbasis(U)), Float64(a), C_NULL, t.h, Float64(b), y.h) :
                                 c_gemv_n(y.ctx.h, U.Z.h, Int64(U.ncols), Float64(a), t.h, Float64(b), y.h)); y)
@@ -434,7 +452,7 @@ mul!(t::DeviceVector, Ut::DeviceBasisAdjoint, v::DeviceVector) =
     (check(t.ctx, factored(Ut.U) ? c_q_gemv_t(t.ctx.h, Ref(cbasis(Ut.U)), v.h, C_NULL, t.h) :
                                    c_gemv_t(t.ctx.h, Ut.U.Z.h, Int64(Ut.U.ncols), v.h, t.h)); t)
 cbasis(U::DeviceBasis) = U.generator === nothing ? CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL) :
-    CBasis(U.Z.h, U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, U.generator[1].h, pointer(U.generator[2]), C_NULL, U.sparse)
+    CBasis(zhandle(U.Z), U.ncols, C_NULL, C_NULL, C_NULL, C_NULL, U.generator[1].h, pointer(U.generator[2]), C_NULL, U.sparse)
 
 # A = a0*I + diag(dg): the LinearMap of src/optimize.jl:228-230 for diagonal Lagrangian Hessians
 struct DiagOperator
@@ -467,7 +485,7 @@ mutable struct InequalityDecomp
     ctx::HipContext
     N::Int
     M::Int
-    Z::DeviceMatrix
+    Z::Union{Nothing,DeviceMatrix}      # nothing: the basis stays in factored form U = [sx; sy] .* (Jct W)
     Σ::Vector{Float64}
     Vt::Matrix{Float64}
     Dx::DeviceVector
@@ -480,7 +498,7 @@ mutable struct InequalityDecomp
     W::Union{Nothing,Matrix{Float64}}
     Jsp::Ptr{Cvoid}            # sparse twin of Jct's leading columns (lfpsqp_spmat handle): projcg! on the nonzeros; C_NULL otherwise
 end
-InequalityDecomp(ctx::HipContext, N::Integer, M::Integer, Jct::DeviceMatrix, Z::DeviceMatrix=DeviceMatrix(ctx, N, M)) =
+InequalityDecomp(ctx::HipContext, N::Integer, M::Integer, Jct::DeviceMatrix, Z::Union{Nothing,DeviceMatrix}=DeviceMatrix(ctx, N, M)) =
     InequalityDecomp(ctx, N, M, Z, zeros(M), zeros(M, M), (DeviceVector(ctx, N) for _ in 1:5)..., Jct, M, nothing, C_NULL)
 # Q = [[diag Dx; diag Dy], U[:, 1:rank]] (InequalityDecompProject, :25-27, :161-212): projcg!'s U with bounds
 struct InequalityDecompProject
@@ -488,7 +506,7 @@ struct InequalityDecompProject
 end
 cbasis(Q::InequalityDecompProject) = (d = Q.idecomp;
     d.W === nothing ? CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, C_NULL, C_NULL, C_NULL, C_NULL) :
-                      CBasis(d.Z.h, d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, d.Jct.h, pointer(d.W), C_NULL, d.Jsp))
+                      CBasis(zhandle(d.Z), d.rank, d.Dx.h, d.Dy.h, d.sx.h, d.sy.h, d.Jct.h, pointer(d.W), C_NULL, d.Jsp))
 const AnyBasis = Union{DeviceBasis,InequalityDecompProject}
 ncols(U::DeviceBasis) = U.ncols
 ncols(Q::InequalityDecompProject) = Q.idecomp.rank
@@ -506,11 +524,12 @@ y_retract!(xnew::DeviceVector, x::DeviceVector, id::InequalityData) = (check(x.c
 # ksvd! (src/la_helper.jl:8-34, call sites src/optimize.jl:291/293): thin factorisation of diag(sqrt(w2)) Jct; Jct is NOT
 # destroyed.  Returns the rank by the reference's rule (Σ_j >= ϵ_rank, :297-302).  W (optional m x m): Z == Jct*W.
 # Jsp (optional SparseMatrix with the entries of the leading Jsp.m columns of Jct): the basis-forming products stream the nonzeros.
-function ksvd!(Jct::DeviceMatrix, Z::DeviceMatrix, Σ::Vector{Float64}, Vt::Matrix{Float64}; w2::Union{Nothing,DeviceVector}=nothing,
+# Z === nothing (dense Jct, W required): the basis Z = Jct*W is not formed -- the caller keeps it in factored form, DeviceBasis(nothing, rank, (Jct, W))
+function ksvd!(Jct::DeviceMatrix, Z::Union{Nothing,DeviceMatrix}, Σ::Vector{Float64}, Vt::Matrix{Float64}; w2::Union{Nothing,DeviceVector}=nothing,
                ϵ_rank::Float64=1e-10, W::Union{Nothing,Matrix{Float64}}=nothing, Jsp=nothing)
     rank = Ref{Int64}(0)
     if Jsp === nothing
-        check(Jct.ctx, c_factorize(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, Z.h, Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
+        check(Jct.ctx, c_factorize(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, zhandle(Z), Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
     else
         check(Jct.ctx, c_factorize_sp(Jct.ctx.h, Jsp.h, Jct.h, w2 === nothing ? C_NULL : w2.h, Z.h, Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
     end
@@ -1148,7 +1167,15 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     diagonal_hessian = has_hess_diag(hess_lag_vec!)
     # The basis Z (src/optimize.jl:191), ProjCGWork (:214) and the operator diagonal the fused iteration reads beside them: allocated TOGETHER,
     # by trial over pairs of candidate allocations (DESIGN.md 6)
-    if m > 0
+    # ... unless the basis can stay in FACTORED form U = Jct W (DESIGN.md 5.3): no Z at all, the tangent setup skips its basis-forming product,
+    # and the work vectors are placed against Jct
+    factored_basis = ctx.options.factored_basis && diagonal_hessian && 4 <= m <= 1024 && jsp === nothing
+    if factored_basis
+        vs = vectors_placed(ctx, Jct, ineq ? 0 : n, 5; N=ineq ? n : 0)
+        projcgwork = ProjCGWork(vs[1], vs[2], vs[4], DeviceVector(ctx, max(m, 1)), vs[5])
+        a_placed = vs[3]
+        idecomp = InequalityDecomp(ctx, n, m, Jct, nothing)
+    elseif m > 0
         Zp, vs = basis_and_vectors_placed(ctx, n, m, 5; N=ineq ? n : 0)
         projcgwork = ProjCGWork(vs[1], vs[2], vs[4], DeviceVector(ctx, max(m, 1)), vs[5])
         a_placed = vs[3]
@@ -1216,7 +1243,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             jac!(Jct, cval, x)                                                          # :283-284 (the device keeps only Jct)
             rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp)     # :286-302
             if !ineq                                                                    # :305-308
-                Ub = jsp === nothing ? DeviceBasis(Z, rank) : DeviceBasis(Z, rank, (Jct, idecomp.W), jsp.h)
+                Ub = jsp === nothing ? (Z === nothing ? DeviceBasis(nothing, rank, (Jct, idecomp.W)) : DeviceBasis(Z, rank)) : DeviceBasis(Z, rank, (Jct, idecomp.W), jsp.h)
                 mul!(tmp_m, adjoint(Ub), d)
                 mul!(d, Ub, tmp_m, -1.0, 1.0)
             end
@@ -1249,7 +1276,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             term_cond = kkt_tol; break
         end
         if param.do_newton                                                              # :364-390
-            Qview = ineq ? ineqproject : (jsp === nothing ? DeviceBasis(Z, rank) : DeviceBasis(Z, rank, (Jct, idecomp.W), jsp.h))   # sparse twin: projcg! on the nonzeros
+            Qview = ineq ? ineqproject : (jsp === nothing ? (Z === nothing ? DeviceBasis(nothing, rank, (Jct, idecomp.W)) : DeviceBasis(Z, rank)) : DeviceBasis(Z, rank, (Jct, idecomp.W), jsp.h))   # sparse twin: projcg! on the nonzeros
             grad_norm = norm(d)
             tol = param.tn_κ * min(1, grad_norm / prev_grad_norm) * grad_norm           # :375-378 (prev = 0: ratio Inf => factor 1)
             prev_grad_norm = grad_norm
@@ -1499,7 +1526,7 @@ optimize(ctx::HipContext, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, x0::V
 export HipContext, HipError, DeviceOptions, DeviceVector, StackedVector, DeviceMatrix, SparseMatrix, spmv_t!, spmv_n!, to_dense!, DeviceBasis, DiagOperator, InequalityData, InequalityDecomp,
        InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
        ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, SeparableElementwiseBox, ElementwiseConstraints,
-       sin_system_constraints, sphere_system_constraints, clone, rowscale!, set_placement!, basis_and_vectors_placed, placement_info, upload!, download, upload2!, download2, projcg!, retract!,
+       sin_system_constraints, sphere_system_constraints, clone, rowscale!, set_placement!, basis_and_vectors_placed, vectors_placed, placement_info, upload!, download, upload2!, download2, projcg!, retract!,
        retract_nr_batch!, pcg!, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!,
        shard_range, sync
 

@@ -356,7 +356,38 @@ struct PcgPostF {
 };
 // init = 2: RESUME after an iteration-limit exit (LFPSQP_PROJCG_RESUME): the end-of-iteration part already ran in the previous
 // call; the limit has been raised, so the start-of-next-iteration part runs now (x was flushed by that call: alpha_prev = 0).
-__global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
+// y[j] = sum_k W[j*ld + k*sk] x[k], j < rows, k < cols, by the whole workgroup: `groups` threads share an output (the k-range dealt round
+// robin), partial sums meet in LDS in a fixed order.  x read by ld_scal (written by an earlier kernel) or from LDS (xs != nullptr).
+template <int NY>
+__device__ __forceinline__ void small_wdot(const double* W, size_t ld, size_t sk, int rows, int cols, const double* const (&x)[NY], const double* xs,
+                                           double (&y)[NY], double* scratch /* NY * blockDim.x */) {
+    int rp = 32;
+    while (rp < rows) rp <<= 1;
+    const int groups = (int)blockDim.x / rp > 0 ? (int)blockDim.x / rp : 1;
+    const int j = threadIdx.x % rp, g = threadIdx.x / rp;
+    double acc[NY];
+#pragma unroll
+    for (int q = 0; q < NY; ++q) acc[q] = 0.0;
+    if (j < rows && g < groups)
+        for (int k = g; k < cols; k += groups) {
+            const double w = W[(size_t)j * ld + (size_t)k * sk];
+#pragma unroll
+            for (int q = 0; q < NY; ++q) acc[q] = fma(w, xs ? xs[k] : ld_scal(x[q] + k), acc[q]);
+        }
+#pragma unroll
+    for (int q = 0; q < NY; ++q) scratch[q * blockDim.x + threadIdx.x] = acc[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NY; ++q) {
+        double sum = 0.0;
+        if (g == 0 && j < rows)
+            for (int gg = 0; gg < groups; ++gg) sum += scratch[q * blockDim.x + gg * rp + j];
+        y[q] = sum;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void pcg_post_kernel(PcgPostF u) {
     if (u.init == 2) {
         if (threadIdx.x == 0) u.istat[I_STATUS] = ST_RUNNING;
         __syncthreads();
@@ -364,16 +395,16 @@ __global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
     __shared__ double sh[2];
     __shared__ int go;
     __shared__ double s_utr[kOnepassMaxCols];
+    __shared__ double s_part[2 * 1024];
     if (u.W && u.init != 2) {                                          // (a resumed solve finds T as the previous call converted it)
-        for (int j = threadIdx.x; j < u.m; j += 256) {
-            const double* wj = u.W + (size_t)j * u.wm;
-            double a1 = 0.0, a2 = 0.0;
-            for (int k = 0; k < u.wm; ++k) {
-                a1 = fma(wj[k], ld_scal(u.Traw + k), a1);
-                a2 = fma(wj[k], ld_scal(u.Traw + u.wm + k), a2);
-            }
-            u.Tw[j] = a1;
-            u.Tw[u.m + j] = a2;
+        // [t1; t2] = W' [raw1; raw2]: output j = column j of W (contiguous) against the raw sums.  m <= 1024 = blockDim: one output per thread slot
+        const double* const xin[2] = {u.Traw, u.Traw + u.wm};
+        double yo[2];
+        small_wdot<2>(u.W, (size_t)u.wm, 1, u.m, u.wm, xin, nullptr, yo, s_part);
+        if ((int)threadIdx.x < u.m) {
+            int rp = 32;
+            while (rp < u.m) rp <<= 1;
+            if ((int)threadIdx.x / rp == 0) { u.Tw[threadIdx.x] = yo[0]; u.Tw[u.m + threadIdx.x] = yo[1]; }
         }
         if (threadIdx.x < 5) u.Tw[2 * u.m + threadIdx.x] = ld_scal(u.Traw + 2 * u.wm + threadIdx.x);
         __threadfence();
@@ -428,7 +459,7 @@ __global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
     __syncthreads();
     if (!go) return;
     const double alpha = sh[0], beta = sh[1];
-    for (int j = threadIdx.x; j < u.m; j += 256) {
+    for (int j = threadIdx.x; j < u.m; j += blockDim.x) {
         const double t1 = ld_scal(u.T + j), t2 = ld_scal(u.T + u.m + j);
         const double t3 = (u.init == 1) ? -t2 : fma(beta, u.t3[j], -t2);
         u.t3[j] = t3;
@@ -436,13 +467,14 @@ __global__ __launch_bounds__(256) void pcg_post_kernel(PcgPostF u) {
         u.Utr[j] = ut;
         if (u.W) s_utr[j] = ut;
     }
-    if (u.W) {                                                          // uA = W Utr
+    if (u.W) {                                                          // uA = W Utr: output k = row k of W (stride wm between its entries)
         __syncthreads();
-        for (int k = threadIdx.x; k < u.wm; k += 256) {
-            double a = 0.0;
-            for (int j = 0; j < u.m; ++j) a = fma(u.W[(size_t)j * u.wm + k], s_utr[j], a);
-            u.uA[k] = a;
-        }
+        const double* const xin[1] = {nullptr};
+        double yo[1];
+        small_wdot<1>(u.W, 1, (size_t)u.wm, u.wm, u.m, xin, s_utr, yo, s_part);
+        int rp = 32;
+        while (rp < u.wm) rp <<= 1;
+        if ((int)threadIdx.x < u.wm && (int)threadIdx.x / rp == 0) u.uA[threadIdx.x] = yo[0];
     }
 }
 // the vector part of an iteration start in the fused flow: x += alpha_prev*d (deferred :92) ; d = beta*d - g (:99)
@@ -834,7 +866,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         else if (init) LF_TRY((run_onepass<PcgFuseE<false, true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<false, true>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
         else LF_TRY((run_onepass<PcgFuseE<false, false>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<false, false>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
         if (!init) gcur ^= 1;
-        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, init, hm, dWf, Traw, T12, uDF, DF ? mc : 0});
+        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(DF ? 1024 : 256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, init, hm, dWf, Traw, T12, uDF, DF ? mc : 0});
         LF_LAUNCH_CHECK(ctx);
         return 0;
     };
@@ -855,7 +887,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         const int64_t lim = maxit_eff;
         LF_HIP(ctx, hipMemcpyAsync(istat + I_MAXIT, &lim, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));            // (source on the stack)
-        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, 2, hm, dWf, Traw, T12, uDF, DF ? mc : 0});
+        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(DF ? 1024 : 256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, 2, hm, dWf, Traw, T12, uDF, DF ? mc : 0});
         LF_LAUNCH_CHECK(ctx);
     }
     ctx->pcg_resume.valid = false;
