@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "internal.h"
 
 namespace lfpsqp {
@@ -86,9 +88,90 @@ int ensure_mvec(lfpsqp_ctx* ctx, size_t doubles) {
     return 0;
 }
 
+// ---- P2P: a one-shot all-reduce for small payloads over peer-mapped memory (SURVEY 5 "distributed communication backend") -------------
+// Every collective of the hot loops is latency-bound (2m + 5 doubles per projected-CG iteration, m + 1 per Newton step): a ring costs
+// 2 (N - 1) hops, a one-shot exchange one.  Each rank owns a MAILBOX in its device memory -- two slots (sequence parity) of kP2PSlot
+// doubles + a sequence flag each -- that every other rank maps through hipIpc.  One workgroup per collective: copy the payload into my
+// slot, publish the sequence number with a system-scope release store; then, rank by rank in FIXED order (so every rank adds in the same
+// order: bit-identical results everywhere), wait for that rank's flag and accumulate its payload with system-scope loads.  Stream-ordered,
+// no host involvement.  A slot is rewritten two collectives later: a rank posts sequence s + 1 only after it has finished reading every
+// slot of sequence s, and I start s + 2 only after I have seen everybody's s + 1.
+constexpr int kP2PSlot = 4096;                 // doubles per slot (32 KB); larger payloads go in pieces
+constexpr int kP2PMaxRanks = 16;
+struct P2PSlot { double data[kP2PSlot]; unsigned long long flag; unsigned long long pad[15]; };
+struct P2PBox { P2PSlot slot[2]; };
+struct P2PArgs {
+    P2PBox* box[kP2PMaxRanks];
+    int rank, nranks;
+    double* buf;
+    int count, op;
+    unsigned long long seq;                    // >= 1
+    int* err;
+    long long timeout_ticks;                   // wall_clock64 ticks (100 MHz)
+};
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
+    P2PSlot* mine = &a.box[a.rank]->slot[a.seq & 1];
+    for (int i = threadIdx.x; i < a.count; i += 256)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine->data) + i, __builtin_bit_cast(unsigned long long, a.buf[i]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&mine->flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __shared__ int ok;
+    double acc[kP2PSlot / 256];
+    for (int r = 0; r < a.nranks; ++r) {
+        P2PSlot* s = &a.box[r]->slot[a.seq & 1];
+        if (threadIdx.x == 0) {
+            ok = 1;
+            if (r != a.rank) {
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(&s->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+                    if (wall_clock64() - t0 > a.timeout_ticks) { ok = 0; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+        __syncthreads();
+        if (!ok) {                              // a peer never arrived: poison the result, tell the host, do not hang the device
+            if (threadIdx.x == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int i = threadIdx.x; i < a.count; i += 256) a.buf[i] = NAN;
+            return;
+        }
+        for (int i = threadIdx.x, k = 0; i < a.count; i += 256, ++k) {
+            const double v = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<unsigned long long*>(s->data) + i, __ATOMIC_RELAXED,
+                                                                          __HIP_MEMORY_SCOPE_SYSTEM));
+            acc[k] = (r == 0) ? v : (a.op == 1 ? nanmax(acc[k], v) : acc[k] + v);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x, k = 0; i < a.count; i += 256, ++k) a.buf[i] = acc[k];
+}
+
+static int p2p_allreduce(lfpsqp_ctx* ctx, double* buf, int64_t count, int op) {
+    Comm& c = ctx->comm;
+    for (int64_t off = 0; off < count; off += kP2PSlot) {
+        P2PArgs a;
+        for (int r = 0; r < kP2PMaxRanks; ++r) a.box[r] = static_cast<P2PBox*>(c.p2p_peer[r]);
+        a.rank = c.rank; a.nranks = c.nranks;
+        a.buf = buf + off;
+        a.count = (int)std::min<int64_t>(kP2PSlot, count - off);
+        a.op = op;
+        a.seq = ++c.p2p_seq;
+        a.err = c.p2p_err;
+        a.timeout_ticks = 20LL * 100000000LL;   // 20 s
+        hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
+        LF_LAUNCH_CHECK(ctx);
+    }
+    return 0;
+}
+
 int allreduce_dev(lfpsqp_ctx* ctx, double* buf, int64_t count, int op) {
     Comm& c = ctx->comm;
     if (c.kind == Comm::NONE || count == 0) return 0;
+    if (c.kind == Comm::P2P) {
+        if (c.p2p_err && *(volatile int*)c.p2p_err) return set_err(ctx, LFPSQP_ERR_COMM, "P2P all-reduce: a peer did not arrive within the time limit");
+        return p2p_allreduce(ctx, buf, count, op);
+    }
     if (c.kind == Comm::RCCL) {
         const int ncclFloat64 = 8, ncclSum = 0, ncclMax = 2;  // rccl.h enums
         int rc = c.ncclAllReduce(buf, buf, (size_t)count, ncclFloat64, op == 1 ? ncclMax : ncclSum, c.nccl_comm, ctx->stream);
@@ -436,6 +519,39 @@ int lfpsqp_comm_init_callback(lfpsqp_ctx* ctx, int rank, int nranks, lfpsqp_allr
     ctx->comm.cb_user = user;
     ctx->comm.rank = rank;
     ctx->comm.nranks = nranks;
+    return 0;
+}
+
+// P2P transport.  lfpsqp_comm_p2p_export: allocate this rank's mailbox, return its 64-byte IPC handle; ship the handles of all ranks to
+// every rank by any control plane; lfpsqp_comm_init_p2p maps them.  Works across the GPUs of one node (xGMI / PCIe peer access) and for
+// several ranks sharing one GPU (the functional test on a 1-GPU box).
+int lfpsqp_comm_p2p_export(lfpsqp_ctx* ctx, void* handle64) {
+    LF_ARG(ctx, ctx && handle64);
+    Comm& c = ctx->comm;
+    if (!c.p2p_mine) {
+        LF_HIP(ctx, hipExtMallocWithFlags(&c.p2p_mine, sizeof(P2PBox), hipDeviceMallocUncached));
+        LF_HIP(ctx, hipMemset(c.p2p_mine, 0, sizeof(P2PBox)));
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the header promises a 64-byte handle");
+    hipIpcMemHandle_t h;
+    LF_HIP(ctx, hipIpcGetMemHandle(&h, c.p2p_mine));
+    memcpy(handle64, &h, 64);
+    return 0;
+}
+int lfpsqp_comm_init_p2p(lfpsqp_ctx* ctx, int rank, int nranks, const void* handles) {
+    LF_ARG(ctx, ctx && handles && nranks >= 1 && nranks <= kP2PMaxRanks && rank >= 0 && rank < nranks && ctx->comm.p2p_mine);
+    Comm& c = ctx->comm;
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) { c.p2p_peer[r] = c.p2p_mine; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, static_cast<const char*>(handles) + 64 * (size_t)r, 64);
+        LF_HIP(ctx, hipIpcOpenMemHandle(&c.p2p_peer[r], h, hipIpcMemLazyEnablePeerAccess));
+    }
+    if (!c.p2p_err) {
+        LF_HIP(ctx, hipHostMalloc((void**)&c.p2p_err, sizeof(int)));
+        *c.p2p_err = 0;
+    }
+    c.rank = rank; c.nranks = nranks; c.kind = Comm::P2P; c.p2p_seq = 0;
     return 0;
 }
 

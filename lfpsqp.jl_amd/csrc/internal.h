@@ -35,7 +35,12 @@ constexpr int kProfEvents = 128;  // event pairs kept per slot
 
 struct Comm {
     int rank = 0, nranks = 1;
-    enum Kind { NONE, RCCL, CALLBACK } kind = NONE;
+    enum Kind { NONE, RCCL, CALLBACK, P2P } kind = NONE;
+    // P2P: one-shot all-reduce over peer-mapped mailboxes (hipIpc), for the library's latency-bound payloads (context.hip)
+    void* p2p_mine = nullptr;            // this rank's mailbox (device memory, exported with hipIpcGetMemHandle)
+    void* p2p_peer[16] = {nullptr};      // every rank's mailbox as mapped here (p2p_peer[rank] == p2p_mine)
+    uint64_t p2p_seq = 0;                // collectives issued so far (the same on every rank by construction)
+    int* p2p_err = nullptr;              // pinned host word: set by a kernel whose wait for a peer timed out
     void* rccl_lib = nullptr;
     void* nccl_comm = nullptr;
     int (*ncclAllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, void*, hipStream_t) = nullptr;

@@ -66,7 +66,69 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
 }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
-static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+// ---- inter-process "device" memory for the P2P transport test: hipExtMallocWithFlags(hipDeviceMallocUncached) is backed by POSIX shared
+// memory, its IPC handle is the object's name (two emulator processes then really share the mailbox)
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <map>
+#include <string>
+#define hipDeviceMallocUncached 0x3
+#define hipIpcMemLazyEnablePeerAccess 0x1
+struct hipIpcMemHandle_t { char reserved[64]; };
+struct HipemuShm { std::string name; size_t bytes; bool owner; };
+static inline std::map<void*, HipemuShm>& hipemu_shm() { static std::map<void*, HipemuShm> m; return m; }
+static inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) {
+    static int counter = 0;
+    char name[64];
+    std::snprintf(name, sizeof name, "/lfpsqp_emu_%d_%d", (int)getpid(), counter++);
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)n) != 0) return hipErrorInvalidValue;
+    void* q = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (q == MAP_FAILED) return hipErrorInvalidValue;
+    hipemu_shm()[q] = HipemuShm{name, n, true};
+    *p = q;
+    return hipSuccess;
+}
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
+    auto it = hipemu_shm().find(p);
+    if (it == hipemu_shm().end()) return hipErrorInvalidValue;
+    std::memset(h, 0, sizeof *h);
+    std::snprintf(h->reserved, 48, "%s", it->second.name.c_str());
+    std::memcpy(h->reserved + 48, &it->second.bytes, sizeof(size_t));
+    return hipSuccess;
+}
+static inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
+    size_t n = 0;
+    std::memcpy(&n, h.reserved + 48, sizeof(size_t));
+    const int fd = shm_open(h.reserved, O_RDWR, 0600);
+    if (fd < 0) return hipErrorInvalidValue;
+    void* q = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (q == MAP_FAILED) return hipErrorInvalidValue;
+    hipemu_shm()[q] = HipemuShm{h.reserved, n, false};
+    *p = q;
+    return hipSuccess;
+}
+static inline hipError_t hipIpcCloseMemHandle(void* p) {
+    auto it = hipemu_shm().find(p);
+    if (it == hipemu_shm().end()) return hipErrorInvalidValue;
+    munmap(p, it->second.bytes);
+    hipemu_shm().erase(it);
+    return hipSuccess;
+}
+static inline hipError_t hipFree(void* p) {
+    auto it = hipemu_shm().find(p);
+    if (it != hipemu_shm().end()) {
+        munmap(p, it->second.bytes);
+        if (it->second.owner) shm_unlink(it->second.name.c_str());
+        hipemu_shm().erase(it);
+        return hipSuccess;
+    }
+    std::free(p);
+    return hipSuccess;
+}
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
 static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
@@ -308,7 +370,12 @@ static inline unsigned long long atomicMax(unsigned long long* p, unsigned long 
 }
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
-template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
-template <class T, class V> static inline void __hip_atomic_store(T* p, V v, int, int) { *p = (T)v; }
+template <class T> static inline T __hip_atomic_load(const T* p, int, int) { T v; __atomic_load(const_cast<T*>(p), &v, __ATOMIC_SEQ_CST); return v; }   // (really atomic: two emulator processes may share the word)
+template <class T, class V> static inline void __hip_atomic_store(T* p, V v, int, int) { T w = (T)v; __atomic_store(p, &w, __ATOMIC_SEQ_CST); }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }   // only used on wave-uniform values
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+#include <sched.h>
+#include <time.h>
+static inline long long wall_clock64() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 100000000LL + ts.tv_nsec / 10; }   // 100 MHz
+#define __builtin_amdgcn_s_sleep(x) sched_yield()
