@@ -39,8 +39,9 @@ def main(argv=None, lib=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the tangent-setup / Newton-retraction timings (not part of `value`)")
     ap.add_argument("--cpu-sample-n", type=float, default=2e6)
-    ap.add_argument("--comm", choices=["rccl", "torch", "host-gloo"], default="rccl",
-                    help="all-reduce transport for N > 1: rccl (library-native, default), torch (torch.distributed nccl callback), "
+    ap.add_argument("--comm", choices=["rccl", "p2p", "torch", "host-gloo"], default="rccl",
+                    help="all-reduce transport for N > 1: rccl (library-native, default), p2p (the library's one-shot all-reduce over peer-mapped "
+                         "mailboxes, hipIpc: one exchange instead of a ring; ranks may share one GPU), torch (torch.distributed nccl callback), "
                          "host-gloo (functional test only: ranks may share one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device index (default: LOCAL_RANK)")
     ap.add_argument("--lib", default=None, help="(development) alternative build of liblfpsqp_hip.so to load")
@@ -123,6 +124,11 @@ def main(argv=None, lib=None):
                 torch.cuda.set_device(dev)
                 ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev, dist.new_group(backend="nccl")))
                 comm_used = "torch-nccl-callback (fallback)"
+        elif args.comm == "p2p":
+            box = [None] * world
+            dist.all_gather_object(box, ctx.comm_p2p_export())
+            ctx.comm_init_p2p(rank, world, box)
+            comm_used = "p2p (one-shot all-reduce over hipIpc-mapped mailboxes)"
         elif args.comm == "torch":
             from lfpsqp_jl_amd.distributed import torch_allreduce_callback
             torch.cuda.set_device(dev)

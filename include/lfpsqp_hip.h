@@ -82,6 +82,15 @@ int lfpsqp_comm_init_rccl(lfpsqp_ctx* ctx, int rank, int nranks, const void* id1
  * ordered on `stream` (a hipStream_t). */
 typedef int (*lfpsqp_allreduce_fn)(void* user, double* buf, int64_t count, int op, void* stream);
 int lfpsqp_comm_init_callback(lfpsqp_ctx* ctx, int rank, int nranks, lfpsqp_allreduce_fn fn, void* user);
+/* Third transport: a ONE-SHOT all-reduce over peer-mapped memory for the latency-bound payloads of the hot loops (2m + 5 doubles per
+ * projected-CG iteration, src/projcg.jl:75,84,96,98,103; m + 1 per Newton step) -- a ring pays 2 (N - 1) hops, this one exchange.  Every
+ * rank owns a mailbox in its device memory that the others map through hipIpc; a collective is one single-workgroup kernel on the
+ * context's stream: publish my payload + sequence flag (system-scope release), then rank by rank in FIXED order wait for the flag and
+ * accumulate (bit-identical results on every rank).  Payloads beyond 4096 doubles go in pieces.  lfpsqp_comm_p2p_export: create this rank's
+ * mailbox and return its 64-byte IPC handle; ship all handles to all ranks by any control plane; lfpsqp_comm_init_p2p(handles: nranks x 64
+ * bytes, in rank order) maps them.  One node (xGMI / PCIe peers), at most 16 ranks; ranks may also share a GPU (the 1-GPU test). */
+int lfpsqp_comm_p2p_export(lfpsqp_ctx* ctx, void* handle64);
+int lfpsqp_comm_init_p2p(lfpsqp_ctx* ctx, int rank, int nranks, const void* handles);
 int lfpsqp_comm_info(const lfpsqp_ctx* ctx, int* rank, int* nranks);
 
 /* ---- buffers ------------------------------------------------------------- */

@@ -121,6 +121,8 @@ c_comm_unique_id(ctx, id) = ccall((:lfpsqp_comm_unique_id, lib), Cint, (Ptr{Cvoi
 c_comm_init_rccl(ctx, rank, nranks, id) = ccall((:lfpsqp_comm_init_rccl, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx, rank, nranks, id)
 c_comm_init_callback(ctx, rank, nranks, fn, user) = ccall((:lfpsqp_comm_init_callback, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}), ctx, rank, nranks, fn, user)
 c_comm_info(ctx, rank, nranks) = ccall((:lfpsqp_comm_info, lib), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), ctx, rank, nranks)
+c_comm_p2p_export(ctx, handle) = ccall((:lfpsqp_comm_p2p_export, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}), ctx, handle)
+c_comm_init_p2p(ctx, rank, nranks, handles) = ccall((:lfpsqp_comm_init_p2p, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx, rank, nranks, handles)
 # ---- buffers -----------------------------------------------------------------------------------------------------------
 c_vec_alloc(ctx, n, out) = ccall((:lfpsqp_vec_alloc, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), ctx, n, out)
 c_vec_free(ctx, v) = ccall((:lfpsqp_vec_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx, v)
@@ -243,6 +245,19 @@ function comm_unique_id(ctx::HipContext)
     id = Vector{UInt8}(undef, 128)
     check(ctx, c_comm_unique_id(ctx.h, id))
     return id
+end
+# the one-shot peer-to-peer all-reduce (one node): every rank exports its mailbox handle (64 bytes), all handles go to all ranks
+# (e.g. MPI.Allgather), comm_init_p2p! maps them -- instead of comm_unique_id / comm_init!
+function comm_p2p_export(ctx::HipContext)
+    h = Vector{UInt8}(undef, 64)
+    check(ctx, c_comm_p2p_export(ctx.h, h))
+    return h
+end
+function comm_init_p2p!(ctx::HipContext, rank::Integer, nranks::Integer, handles::Vector{UInt8})
+    length(handles) == 64 * nranks || error("handles must hold 64 bytes per rank, in rank order")
+    check(ctx, c_comm_init_p2p(ctx.h, Cint(rank), Cint(nranks), handles))
+    ctx.rank, ctx.nranks = rank, nranks
+    return ctx
 end
 function comm_init!(ctx::HipContext, rank::Integer, nranks::Integer, id::Vector{UInt8})
     check(ctx, c_comm_init_rccl(ctx.h, Cint(rank), Cint(nranks), id))
@@ -1527,7 +1542,7 @@ export HipContext, HipError, DeviceOptions, DeviceVector, StackedVector, DeviceM
        InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
        ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, SeparableElementwiseBox, ElementwiseConstraints,
        sin_system_constraints, sphere_system_constraints, clone, rowscale!, set_placement!, basis_and_vectors_placed, vectors_placed, placement_info, upload!, download, upload2!, download2, projcg!, retract!,
-       retract_nr_batch!, pcg!, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!,
+       retract_nr_batch!, pcg!, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!, comm_p2p_export, comm_init_p2p!,
        shard_range, sync
 
 end # module

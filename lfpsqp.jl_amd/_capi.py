@@ -67,6 +67,8 @@ _SIGS = {
     "lfpsqp_comm_unique_id": [P, P],
     "lfpsqp_comm_init_rccl": [P, C.c_int, C.c_int, P],
     "lfpsqp_comm_init_callback": [P, C.c_int, C.c_int, ALLREDUCE_FN, P],
+    "lfpsqp_comm_p2p_export": [P, P],
+    "lfpsqp_comm_init_p2p": [P, C.c_int, C.c_int, P],
     "lfpsqp_comm_info": [P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "lfpsqp_vec_alloc": [P, c_i64, C.POINTER(P)],
     "lfpsqp_vec_free": [P, P],

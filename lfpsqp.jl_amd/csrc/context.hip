@@ -528,12 +528,19 @@ int lfpsqp_comm_init_callback(lfpsqp_ctx* ctx, int rank, int nranks, lfpsqp_allr
 int lfpsqp_comm_p2p_export(lfpsqp_ctx* ctx, void* handle64) {
     LF_ARG(ctx, ctx && handle64);
     Comm& c = ctx->comm;
-    if (!c.p2p_mine) {
-        LF_HIP(ctx, hipExtMallocWithFlags(&c.p2p_mine, sizeof(P2PBox), hipDeviceMallocUncached));
-        LF_HIP(ctx, hipMemset(c.p2p_mine, 0, sizeof(P2PBox)));
-    }
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the header promises a 64-byte handle");
     hipIpcMemHandle_t h;
+    if (!c.p2p_mine) {
+        // fine-grained (uncached) device memory first; if the runtime will not export that kind, ordinary device memory: every access of the
+        // protocol is a system-scope atomic either way
+        if (hipExtMallocWithFlags(&c.p2p_mine, sizeof(P2PBox), hipDeviceMallocUncached) != hipSuccess || hipIpcGetMemHandle(&h, c.p2p_mine) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c.p2p_mine) (void)hipFree(c.p2p_mine);
+            c.p2p_mine = nullptr;
+            LF_HIP(ctx, hipMalloc(&c.p2p_mine, sizeof(P2PBox)));
+        }
+        LF_HIP(ctx, hipMemset(c.p2p_mine, 0, sizeof(P2PBox)));
+    }
     LF_HIP(ctx, hipIpcGetMemHandle(&h, c.p2p_mine));
     memcpy(handle64, &h, 64);
     return 0;

@@ -153,6 +153,19 @@ class Context:
         self.check(self.L.lfpsqp_comm_init_rccl(self.h, rank, nranks, buf))
         self.rank, self.nranks = rank, nranks
 
+    def comm_p2p_export(self) -> bytes:
+        """This rank's mailbox for the one-shot peer-to-peer all-reduce: its 64-byte IPC handle (lfpsqp_comm_p2p_export)."""
+        buf = C.create_string_buffer(64)
+        self.check(self.L.lfpsqp_comm_p2p_export(self.h, buf))
+        return buf.raw
+
+    def comm_init_p2p(self, rank: int, nranks: int, handles):
+        """``handles``: the 64-byte handles of all ranks, in rank order (lfpsqp_comm_init_p2p)."""
+        blob = b"".join(handles)
+        assert len(blob) == 64 * nranks
+        self.check(self.L.lfpsqp_comm_init_p2p(self.h, rank, nranks, blob))
+        self.rank, self.nranks = rank, nranks
+
     def comm_init_callback(self, rank: int, nranks: int, fn):
         """fn(ptr:int, count:int, op:int, stream:int) -> int; all-reduce `count` doubles at device pointer `ptr`."""
         def tramp(user, buf, count, op, stream):

@@ -1,0 +1,86 @@
+"""The one-shot peer-to-peer all-reduce (lfpsqp_comm_init_p2p, SURVEY §5 "distributed communication backend"; reduction points
+src/projcg.jl:75,84,96,98,103): two processes whose mailboxes are mapped into each other -- on the CPU two emulator processes over POSIX
+shared memory, on the GPU two processes sharing the one device through hipIpc -- run plain collectives, the sharded tangent setup and the
+sharded projected CG, and must agree BIT FOR BIT with the same run over the gloo (host-staged) transport and across ranks."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu", "_build", "liblfpsqp_emu.so")
+
+
+def _run(d, transport, lib, n, m, timeout):
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), str(r), "2", str(d), transport, lib, str(n), str(m)],
+                              cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=timeout)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [np.load(os.path.join(d, f"out_{transport}_{r}.npz")) for r in range(2)]
+
+
+def _check(p2p, gloo, n, m):
+    for key in ("sum9000", "dot", "amax", "S", "it", "nr", "lam"):
+        np.testing.assert_array_equal(p2p[0][key], p2p[1][key], err_msg=key)          # replicated results agree across the ranks
+        np.testing.assert_array_equal(p2p[0][key], gloo[0][key], err_msg=key)         # ... and with the other transport, bit for bit
+    for r in range(2):
+        np.testing.assert_array_equal(p2p[r]["x"], gloo[r]["x"])
+    x = np.concatenate([p2p[0]["x"], p2p[1]["x"]])
+    assert x.size == n and int(p2p[0]["it"]) > 3 and float(p2p[0]["nr"]) < 1e-10
+    print(f"[p2p] {float(p2p[0]['us_per_allreduce']):.1f} us per 261-double all-reduce (gloo / host-staged: {float(gloo[0]['us_per_allreduce']):.1f}); "
+          f"sharded projcg {int(p2p[0]['it'])} iterations in {float(p2p[0]['projcg_s']) * 1e3:.1f} ms ({float(gloo[0]['projcg_s']) * 1e3:.1f})")
+
+
+def test_two_emulator_processes_over_shared_memory(emu_lib, tmp_path):
+    n, m = 6000, 12
+    p2p = _run(tmp_path, "p2p", EMU, n, m, 600)
+    gloo = _run(tmp_path, "gloo", EMU, n, m, 600)
+    _check(p2p, gloo, n, m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(2_000_000, 128)])
+def test_two_processes_sharing_the_gpu(gpu_lib, tmp_path, n, m):
+    p2p = _run(tmp_path, "p2p", "default", n, m, 300)
+    gloo = _run(tmp_path, "gloo", "default", n, m, 300)
+    _check(p2p, gloo, n, m)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_p2p_at_the_headline_shape():
+    """bench.py --gpus 2 --comm p2p exactly as the driver launches it (torch.distributed.run, two ranks -- here sharing the one GPU), n = 1e7,
+    m = 128 row-sharded: the same solve as one rank (equal count, ||x|| to 1e-10), bit-identical to the host-staged transport."""
+    import json
+    import socket
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extras", "--prewarm-seconds", "0.3"]
+    out = {}
+    for comm in ("p2p", "host-gloo"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", comm, "--device", "0", *common],
+                             cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert two.returncode == 0, two.stderr[-3000:]
+        out[comm] = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][0])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], cwd=ROOT, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    p, g = out["p2p"], out["host-gloo"]
+    assert p["n_gpus"] == 2 and "p2p" in p["config"]["comm"]
+    assert p["check"]["iters"] == g["check"]["iters"] == d1["check"]["iters"] == 13
+    assert p["check"]["x_norm"] == g["check"]["x_norm"] and p["check"]["nr"] == g["check"]["nr"]          # fixed rank order: bit for bit
+    assert abs(d1["check"]["x_norm"] - p["check"]["x_norm"]) <= 1e-10 * d1["check"]["x_norm"]
+    print(f"[bench --gpus 2 on ONE GPU] p2p {p['value']:.1f} it/s, host-staged gloo {g['value']:.1f} it/s, one rank {d1['value']:.1f} it/s")
