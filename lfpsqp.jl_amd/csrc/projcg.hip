@@ -987,10 +987,17 @@ int lfpsqp::placement_probe(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, dou
     LF_LAUNCH_CHECK(ctx);
     const StackD sk{0, nullptr, nullptr, nullptr, nullptr};
     const PcgFuseE<false, false> f{g, g, g, d, AOpD{0.0, a}, ctx->scal, ctx->istat, sk};
-    for (int k = 0; k < reps + 1; ++k) {
-        if (k == 1) LF_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
-        LF_TRY((run_onepass<PcgFuseE<false, false>, 2, 5>(ctx, M, ncols, ncols, M->n, Utr, f, T12, -1)));
+    // The trial is LOCAL: no collective inside it.  How many candidates a rank tries depends on its own shard size and free memory, so a
+    // trial that all-reduced its (meaningless) sums would leave the ranks with different numbers of collectives in flight.
+    const Comm::Kind saved = ctx->comm.kind;
+    ctx->comm.kind = Comm::NONE;
+    int rc = 0;
+    for (int k = 0; k < reps + 1 && rc == 0; ++k) {
+        if (k == 1) rc = hipEventRecord(ctx->ev_t0, ctx->stream) == hipSuccess ? 0 : LFPSQP_ERR_HIP;
+        if (rc == 0) rc = run_onepass<PcgFuseE<false, false>, 2, 5>(ctx, M, ncols, ncols, M->n, Utr, f, T12, -1);
     }
+    ctx->comm.kind = saved;
+    LF_TRY(rc);
     LF_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
     LF_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
     float t = 0.f;

@@ -34,18 +34,27 @@ __global__ __launch_bounds__(kThreads) void spmv_t_chunk_kernel(const int64_t* _
                                                                  const double* __restrict__ val, const double* __restrict__ v,
                                                                  double* __restrict__ partial) {
     const int64_t e0 = chunk_beg[blockIdx.x], e1 = chunk_beg[blockIdx.x + 1];
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;          // four gathers in flight per lane; fixed association
+    // Eight gathers (row index, then v[row]) in flight per lane, fixed association.  (Round 3 measured four against eight in flight: 0.130 ms
+    // either way at n = 1e7, K = 4 -- the kernel is not latency-bound.  Rows ascend inside a column, so the gathers of a wave are coalesced and
+    // every v[i] is read once per nonzero of its row: 12 + 8 bytes per nonzero = 800 MB in 0.125 ms, 6.4 TB/s through L2 -- the "0.53 of peak"
+    // of the algorithmic-bytes accounting (12 nnz + 8 n) is the price of reading v K times, not idle bandwidth.)
+    constexpr int U = 8;
+    double a[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) a[k] = 0.0;
     int64_t e = e0 + threadIdx.x;
-    for (; e + 3 * kThreads < e1; e += 4 * kThreads) {
-        const int32_t r0 = row[e], r1 = row[e + kThreads], r2 = row[e + 2 * kThreads], r3 = row[e + 3 * kThreads];
-        const double w0 = val[e], w1 = val[e + kThreads], w2 = val[e + 2 * kThreads], w3 = val[e + 3 * kThreads];
-        a0 = fma(w0, v[r0], a0);
-        a1 = fma(w1, v[r1], a1);
-        a2 = fma(w2, v[r2], a2);
-        a3 = fma(w3, v[r3], a3);
+    for (; e + (U - 1) * kThreads < e1; e += U * kThreads) {
+        int32_t r[U];
+        double w[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) r[k] = __builtin_nontemporal_load(row + e + k * kThreads);
+#pragma unroll
+        for (int k = 0; k < U; ++k) w[k] = __builtin_nontemporal_load(val + e + k * kThreads);
+#pragma unroll
+        for (int k = 0; k < U; ++k) a[k] = fma(w[k], v[r[k]], a[k]);
     }
-    for (; e < e1; e += kThreads) a0 = fma(val[e], v[row[e]], a0);
-    double red[1] = {(a0 + a1) + (a2 + a3)};
+    for (; e < e1; e += kThreads) a[0] = fma(val[e], v[row[e]], a[0]);
+    double red[1] = {((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))};
     block_reduce_store<1>(red, 0u, partial + blockIdx.x);
 }
 __global__ void spmv_t_final_kernel(const int32_t* __restrict__ col_chunk, const double* __restrict__ partial, int m, double* __restrict__ t) {
