@@ -47,9 +47,9 @@ __global__ __launch_bounds__(kThreads) void spmv_t_chunk_kernel(const int64_t* _
         int32_t r[U];
         double w[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) r[k] = __builtin_nontemporal_load(row + e + k * kThreads);
+        for (int k = 0; k < U; ++k) r[k] = row[e + k * kThreads];
 #pragma unroll
-        for (int k = 0; k < U; ++k) w[k] = __builtin_nontemporal_load(val + e + k * kThreads);
+        for (int k = 0; k < U; ++k) w[k] = val[e + k * kThreads];
 #pragma unroll
         for (int k = 0; k < U; ++k) a[k] = fma(w[k], v[r[k]], a[k]);
     }
