@@ -362,6 +362,10 @@ int lfpsqp_ctx_destroy(lfpsqp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm.kind == Comm::RCCL && ctx->comm.nccl_comm && ctx->comm.ncclCommDestroy) ctx->comm.ncclCommDestroy(ctx->comm.nccl_comm);
+    for (int r = 0; r < kP2PMaxRanks; ++r)                     // the P2P transport's mappings and this rank's mailbox
+        if (ctx->comm.p2p_peer[r] && ctx->comm.p2p_peer[r] != ctx->comm.p2p_mine) (void)hipIpcCloseMemHandle(ctx->comm.p2p_peer[r]);
+    if (ctx->comm.p2p_mine) (void)hipFree(ctx->comm.p2p_mine);
+    if (ctx->comm.p2p_err) (void)hipHostFree(ctx->comm.p2p_err);
     if (ctx->prof_init)
         for (int s = 0; s < kProfSlots; ++s)
             for (int e = 0; e < kProfEvents; ++e)

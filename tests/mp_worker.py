@@ -148,6 +148,29 @@ def main():
     # ranks' exactly accumulated partial matrices a floating-point all-reduce)
     wsp = ctx.vector(g1 - g0).hash_fill(7, g0, 0.4, 0.6)
     res.update(sp_gram=Ssp.gram(w2=wsp), sp_gram_plain=Ssp.gram())
+    # ---- round 3, sharded: the nonlinear (elementwise) constraint class -- dense A with mixed kinds + the common quadratic term (its sum
+    #      of squares is a collective), Newton retraction and `optimize`; and the sin system on the nonzeros of the shard ------------------
+    from tests.test_elementwise import ew_test_data
+    ne_, me_ = 2600, 6
+    h0, h1 = ctx.shard_range(ne_)
+    Ar, kr, qr, br, target, x0e = ew_test_data(ne_, me_)
+    cons = L.ElementwiseConstraints(ctx, ctx.matrix(h1 - h0, me_, np.asfortranarray(Ar[h0:h1])), br, kind=kr[h0:h1], qw=qr)
+    prob = L.SeparableElementwiseBox(ctx, cons, 0, 1.0, target[h0:h1], n_global=ne_)
+    tr = []
+    xo, obj, lamk, ti = prob.optimize(x0e[h0:h1], L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=5), trace=tr)
+    res.update(h0=h0, h1=h1, ew_x=xo, ew_obj=obj, ew_iter=ti.iter, ew_lam=lamk, ew_r1=np.array([t.get("retract_iter1") or 0 for t in tr]))
+    ns_, ms_ = 2600, 40
+    k0, k1 = ctx.shard_range(ns_)
+    i_ = np.arange(ms_)
+    rows_s = np.concatenate([2 * i_ + 1, 2 * i_]); cols_s = np.concatenate([i_, i_]); vals_s = np.concatenate([np.ones(ms_), -np.ones(ms_)])
+    sel = (rows_s >= k0) & (rows_s < k1)
+    As = L.SparseMatrix(ctx, k1 - k0, ms_, rows_s[sel] - k0, cols_s[sel], vals_s[sel])
+    kind_s = np.zeros(ns_); kind_s[0:2 * ms_:2] = 1
+    cons_s = L.ElementwiseConstraints(ctx, As, np.zeros(ms_), kind=kind_s[k0:k1])
+    targ_s = 0.5 * synth.hash_vector(21, ns_)
+    prob_s = L.SeparableElementwiseBox(ctx, cons_s, 0, 1.0, targ_s[k0:k1], n_global=ns_)
+    xo, obj, lamk, ti = prob_s.optimize(np.zeros(k1 - k0), L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=5))
+    res.update(k0=k0, k1=k1, sin_x=xo, sin_obj=obj, sin_iter=ti.iter)
     np.savez(out, **res)
     dist.barrier()
     ctx.close()

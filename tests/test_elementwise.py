@@ -45,6 +45,17 @@ def ew_callables(A, kind, qw, b):
     return c_, jac_, hdiag
 
 
+def ew_test_data(n, m, seed=17):
+    """A dense mixed-kind system with the common quadratic term, an objective target and a start -- shared with the 2-rank worker
+    (tests/mp_worker.py), which takes the row shards of the same arrays."""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, m)) / np.sqrt(n)
+    kind = rng.integers(0, 3, n).astype(np.float64)
+    qw = rng.standard_normal(m) * 0.01
+    b = rng.standard_normal(m) * 0.1
+    return A, kind, qw, b, 0.5 * rng.standard_normal(n), 0.2 * rng.standard_normal(n)
+
+
 def sphere_system(n, m, rng):
     """generate_sphere_system (test/test_retractions.jl:1-31), seeded."""
     Rs = rng.random(m) + 1.0

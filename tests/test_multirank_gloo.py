@@ -213,3 +213,51 @@ def test_sharded_sparse_equalities_through_the_default_retraction(two_ranks):
     np.testing.assert_allclose(a["sp_gram"], A.T @ (w[:, None] * A), rtol=0, atol=1e-13 * np.abs(A.T @ A).max())
     np.testing.assert_allclose(a["sp_gram_plain"], A.T @ A, rtol=0, atol=1e-13 * np.abs(A.T @ A).max())
     np.testing.assert_allclose(a["spn_obj"], objr, rtol=1e-10)
+
+
+def test_sharded_nonlinear_constraint_class(two_ranks):
+    """Round 3: the device-resident nonlinear class (lfpsqp_elementwise) row-sharded over two ranks -- dense A with mixed kinds and the
+    common quadratic term (whose sum of squares is a collective), and the reference's sin system on the nonzeros of each shard -- through
+    `optimize` with the Newton retraction: counts, objective and iterates of the single-process oracle with host callables."""
+    from .test_elementwise import ew_callables, ew_test_data
+    a, b = two_ranks
+    n, m = 2600, 6
+    A, kind, qw, bb, target, x0 = ew_test_data(n, m)
+    c_, jac_, hdiag = ew_callables(A, kind, qw, bb)
+    f = lambda xx: float(np.sum((xx[:n] - target) ** 2))
+
+    def grad_(g, xx):
+        g[:n] = 2.0 * (xx[:n] - target)
+
+    def hlv_(dest, src, xx, lam_):
+        dest[:n] = (2.0 + hdiag(xx, lam_)) * src[:n]
+    tr0 = []
+    xr, objr, lamr, tir = R.optimize_core(f, grad_, c_, jac_, hlv_, x0, None, None, m,
+                                          R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=5), trace=tr0)
+    x = np.concatenate([a["ew_x"], b["ew_x"]])
+    assert int(a["ew_iter"]) == int(b["ew_iter"]) == tir.iter
+    np.testing.assert_array_equal(a["ew_r1"], np.array([t.get("retract_iter1") or 0 for t in tr0]))
+    np.testing.assert_array_equal(a["ew_lam"], b["ew_lam"])
+    assert np.linalg.norm(x - xr) <= 1e-10 * max(1.0, np.linalg.norm(xr))
+    np.testing.assert_allclose(a["ew_obj"], objr, rtol=1e-11)
+    # the sin system (test/test_retractions.jl:34-54), sparse, sharded
+    from .test_oracle_reference_properties import sin_system
+    ns, ms = 2600, 40
+    _, cs_, js_ = sin_system(ns, ms)
+    As = np.zeros((ns, ms)); i_ = np.arange(ms); As[2 * i_ + 1, i_], As[2 * i_, i_] = 1.0, -1.0
+    ks = np.zeros(ns); ks[0:2 * ms:2] = 1
+    _, _, hd_s = ew_callables(As, ks, None, np.zeros(ms))
+    targ = 0.5 * synth.hash_vector(21, ns)
+    fs = lambda xx: float(np.sum((xx[:ns] - targ) ** 2))
+
+    def gs_(g, xx):
+        g[:ns] = 2.0 * (xx[:ns] - targ)
+
+    def hs_(dest, src, xx, lam_):
+        dest[:ns] = (2.0 + hd_s(xx, lam_)) * src[:ns]
+    xr, objr, lamr, tir = R.optimize_core(fs, gs_, cs_, js_, hs_, np.zeros(ns), None, None, ms,
+                                          R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=5))
+    xs = np.concatenate([a["sin_x"], b["sin_x"]])
+    assert int(a["sin_iter"]) == int(b["sin_iter"]) == tir.iter
+    assert np.linalg.norm(xs - xr) <= 1e-10 * max(1.0, np.linalg.norm(xr))
+    np.testing.assert_allclose(a["sin_obj"], objr, rtol=1e-11)

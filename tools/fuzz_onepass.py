@@ -48,6 +48,19 @@ for case in range(cases):
         for j in range(3):
             c1 = np.zeros(m); f1, i1, _ = L.retract_(c1, one, cons, xts[j], xs, nrm)
             ok = ok and got is not None and (got[j][0], got[j][1]) == (f1, i1) and rel(xns[j].download(), one.download()) < 1e-11
+    # the basis in factored form (Z == NULL: projcg, projection and Newton retraction stream J) against the materialised basis
+    if 4 <= m <= 1024:
+        Uf = L.DeviceBasis(None, m, generator=(J, W))
+        xf, lf = ctx.vector(n), ctx.vector(m)
+        itf, nrf = L.projcg_(xf, lf, L.DiagOperator(0.0, a), Uf, b, None, tol=1e-11, maxit=25)
+        tf, tm = ctx.vector(m), ctx.vector(m)
+        Uf.adjoint().mul_(tf, b); L.gemv_t(Z, b, tm)
+        cf = np.zeros(m); nff, nif, _ = L.retract_(cf, xn, cons, xt, xs, L.NR(Uf, S, Vt, 1e-9, 20, L.NRWork(m), False, None))
+        okf = (itf == B[0] and rel(xf.download(), B[2]) < 1e-10 and np.abs(tf.download() - tm.download()).max() < 1e-11 * max(1.0, np.abs(tm.download()).max())
+               and (nff, nif) == (B[6], B[7]) and rel(xn.download(), B[8]) < 1e-11)
+        if not okf:
+            print("FACTORED MISMATCH", case, n, m, itf, B[0], rel(xf.download(), B[2]), (nff, nif), (B[6], B[7]))
+        ok = ok and okf
     if not ok:
         bad += 1
         print("MISMATCH", case, n, m, A[0], B[0], rel(B[2], A[2]), (A[3], A[4]), (B[3], B[4]), rel(B[5], A[5]), (A[6], A[7]), (B[6], B[7]), rel(B[8], A[8]))
