@@ -510,11 +510,12 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         Sr = L.SparseMatrix(ctx, n_loc, m, rows_sp, cols_sp.ravel(), vals_r)
         Jd, Zs = Sr.to_dense(), ctx.matrix(n_loc, m)
         tf = {}
-        for tag, kw in (("dense", dict()), ("from_nonzeros", dict(Jsp=Sr))):
-            L.ksvd_(Jd, Zs, **kw)
+        Wn = np.zeros((m, m), order='F')
+        for tag, Zarg, kw in (("dense", Zs, dict()), ("from_nonzeros", Zs, dict(Jsp=Sr)), ("from_nonzeros_factored", None, dict(Jsp=Sr, W=Wn))):
+            L.ksvd_(Jd, Zarg, **kw)
             ctx.sync(); t0 = time.perf_counter()
             for _ in range(3):
-                Sg, _, rk = L.ksvd_(Jd, Zs, **kw)
+                Sg, _, rk = L.ksvd_(Jd, Zarg, **kw)
             ctx.sync(); tf[tag] = (time.perf_counter() - t0) * 1e3 / 3
         Sr.gram()
         ctx.sync(); t0 = time.perf_counter()
@@ -526,7 +527,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         for _ in range(3):
             Gd = L.gram(Jd)
         ctx.sync(); tg_d = (time.perf_counter() - t0) * 1e3 / 3
-        sparse.update({"factorize_dense_ms": tf["dense"], "factorize_from_nonzeros_ms": tf["from_nonzeros"], "factorize_rank": int(rk),
+        sparse.update({"factorize_dense_ms": tf["dense"], "factorize_from_nonzeros_ms": tf["from_nonzeros"], "factorize_from_nonzeros_factored_basis_ms": tf["from_nonzeros_factored"], "factorize_rank": int(rk),
                        "factorize_cond": float(Sg[0] / Sg[-1]), "gram_dense_ms": tg_d, "gram_from_nonzeros_ms": tg_sp,
                        "gram_max_rel_diff": float(np.abs(Gs - Gd).max() / np.abs(Gd).max())})
         # Newton retraction on the same block (24 iterations forced by tol = 0): one dense pass per step vs the nonzeros alone

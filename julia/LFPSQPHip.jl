@@ -546,7 +546,7 @@ function ksvd!(Jct::DeviceMatrix, Z::Union{Nothing,DeviceMatrix}, Σ::Vector{Flo
     if Jsp === nothing
         check(Jct.ctx, c_factorize(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, zhandle(Z), Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
     else
-        check(Jct.ctx, c_factorize_sp(Jct.ctx.h, Jsp.h, Jct.h, w2 === nothing ? C_NULL : w2.h, Z.h, Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
+        check(Jct.ctx, c_factorize_sp(Jct.ctx.h, Jsp.h, Jct.h, w2 === nothing ? C_NULL : w2.h, zhandle(Z), Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
     end
     return Int(rank[])
 end
@@ -1184,7 +1184,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     # by trial over pairs of candidate allocations (DESIGN.md 6)
     # ... unless the basis can stay in FACTORED form U = Jct W (DESIGN.md 5.3): no Z at all, the tangent setup skips its basis-forming product,
     # and the work vectors are placed against Jct
-    factored_basis = ctx.options.factored_basis && diagonal_hessian && 4 <= m <= 1024 && jsp === nothing
+    factored_basis = ctx.options.factored_basis && diagonal_hessian && 4 <= m <= 1024      # (with a sparse twin: on the nonzeros, no Z either)
     if factored_basis
         vs = vectors_placed(ctx, Jct, ineq ? 0 : n, 5; N=ineq ? n : 0)
         projcgwork = ProjCGWork(vs[1], vs[2], vs[4], DeviceVector(ctx, max(m, 1)), vs[5])

@@ -864,29 +864,52 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
 int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma,
                         double* Vt, double* W, int64_t* rank_out, double eps_rank) {
     LF_RANGE("lfpsqp_factorize_sp");
-    LF_ARG(ctx, ctx && S && Z && Sigma && Vt && rank_out && S->n == Z->n && (!w2 || w2->n == S->n) &&
-                    (!Jct || (Jct->p != Z->p && Jct->n == S->n && Jct->m >= S->m && Jct->m - S->m <= 4)) && Z->m >= (Jct ? Jct->m : S->m));
+    LF_ARG(ctx, ctx && S && Sigma && Vt && rank_out && (!w2 || w2->n == S->n) && (Z ? S->n == Z->n : W != nullptr) &&
+                    (!Jct || ((!Z || Jct->p != Z->p) && Jct->n == S->n && Jct->m >= S->m && Jct->m - S->m <= 4)) &&
+                    (!Z || Z->m >= (Jct ? Jct->m : S->m)));
     const int ms = (int)S->m, m = Jct ? (int)Jct->m : ms;
     const double* w2p = w2 ? w2->p : nullptr;
+    // Z == NULL: factors only, the basis stays in factored form U = [S | X] W (as lfpsqp_factorize): no basis-forming product on the fast
+    // path; a temporary trial basis for the refinement rounds (or for a dense Gram matrix of S alone) is allocated on demand and freed.
+    lfpsqp_mat* Zu = Z;
+    lfpsqp_mat* Ztmp = nullptr;
+    lfpsqp_vec* stmp = nullptr;
+    auto needZ = [&]() -> int {
+        if (Zu) return 0;
+        LF_TRY(lfpsqp_mat_alloc(ctx, S->n, m, &Ztmp));
+        Zu = Ztmp;
+        return 0;
+    };
     // Gram matrix from the nonzeros (sp_gram: exact fixed-point accumulation, so reproducible; the extra dense columns through SpMV-T and
     // dot products; Z's first column is its scratch vector -- the basis-forming product overwrites Z afterwards).  Where that is refused
     // (rows wider than 8 nonzeros, extreme values): on the dense twin, or on S expanded into Z.
     auto gramA = [&](std::vector<double>& G) -> int {
         G.assign((size_t)m * m, 0.0);
-        const int rc = ctx->tune_spgram >= 0 ? sp_gram(ctx, S, Jct, ms, m - ms, w2, Z->p, G.data(), 8) : LFPSQP_ERR_UNSUPPORTED;
+        double* scratch = Zu ? Zu->p : nullptr;
+        if (!scratch && m > ms && w2) {                         // (the weighted extra columns need an n-vector of scratch)
+            LF_TRY(lfpsqp_vec_alloc(ctx, S->n, &stmp));
+            scratch = stmp->p;
+        }
+        const int rc = ctx->tune_spgram >= 0 ? sp_gram(ctx, S, Jct, ms, m - ms, w2, scratch, G.data(), 8) : LFPSQP_ERR_UNSUPPORTED;
         if (rc != LFPSQP_ERR_UNSUPPORTED) return rc;
         if (Jct) return gram_impl(ctx, Jct, m, w2p, G);
-        LF_TRY(lfpsqp_spmat_to_dense(ctx, S, Z));
-        return gram_impl(ctx, Z, m, w2p, G);
+        LF_TRY(needZ());
+        LF_TRY(lfpsqp_spmat_to_dense(ctx, S, Zu));
+        return gram_impl(ctx, Zu, m, w2p, G);
     };
     auto rmulA = [&](const double* Wh, int r) -> int {
         if (r == 0) return 0;
         LF_TRY(ensure_small(ctx, (size_t)m * r + 16));
         LF_HIP(ctx, hipMemcpyAsync(ctx->small, Wh, sizeof(double) * (size_t)m * r, hipMemcpyHostToDevice, ctx->stream));
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));                      // Wh is pageable host memory
-        return spmm(ctx, S, Jct, ms, m - ms, ctx->small, m, r, Z);
+        return spmm(ctx, S, Jct, ms, m - ms, ctx->small, m, r, Zu);
     };
-    return factorize_core(ctx, m, gramA, rmulA, w2p, Z, []() -> int { return LFPSQP_ERR_ARG; }, Sigma, Vt, W, rank_out, eps_rank);
+    lfpsqp_mat* Zcore = Z;           // what factorize_core sees: the caller's basis, or none (it asks needZ for a trial basis when it must)
+    const int rc = factorize_core(ctx, m, gramA, rmulA, w2p, Zcore, [&]() -> int { LF_TRY(needZ()); Zcore = Zu; return 0; }, Sigma, Vt, W, rank_out,
+                                  eps_rank);
+    if (Ztmp) lfpsqp_mat_free(ctx, Ztmp);
+    if (stmp) lfpsqp_vec_free(ctx, stmp);
+    return rc;
 }
 
 }  // extern "C"

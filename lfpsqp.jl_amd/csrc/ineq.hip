@@ -299,7 +299,11 @@ static bool sp_factored_ok(const lfpsqp_basis* Q, int64_t n) {
 
 // the basis in factored form with a DENSE generator (lfpsqp_basis.Z == NULL, A and W given): U = [sx; sy] .* (A W) is never materialised,
 // U't = W'(A'v) and U t = A (W t) stream A, the m x m factor is applied by a one-workgroup kernel
-static bool dense_factored(const lfpsqp_basis* Q) { return !Q->Z && Q->A && Q->W && Q->ncols > 0 && Q->ncols <= Q->A->m && Q->A->m <= kOnepassMaxCols; }
+static bool sp_factored_ok(const lfpsqp_basis* Q, int64_t n);
+// (a PLAIN basis with a sparse twin of its generator goes through the nonzeros instead, sp_factored_*; a bound-stacked one streams the dense twin)
+static bool dense_factored(const lfpsqp_basis* Q) {
+    return !Q->Z && Q->A && Q->W && Q->ncols > 0 && Q->ncols <= Q->A->m && Q->A->m <= kOnepassMaxCols && !(!Q->Dx && sp_factored_ok(Q, Q->A->n));
+}
 struct QPlainV {
     const double* v;
     __device__ __forceinline__ bool skip() const { return false; }
@@ -326,7 +330,7 @@ struct QAxpbyE {       // y = alpha * acc + beta * y
 
 int lfpsqp_q_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, const lfpsqp_vec* v, lfpsqp_vec* w, lfpsqp_vec* t) {
     LF_RANGE("lfpsqp_q_gemv_t");
-    LF_ARG(ctx, ctx && Q && v && t && Q->ncols >= 0 && (Q->ncols == 0 || dense_factored(Q) || (Q->Z && Q->ncols <= Q->Z->m)) && t->n >= Q->ncols);
+    LF_ARG(ctx, ctx && Q && v && t && Q->ncols >= 0 && (Q->ncols == 0 || dense_factored(Q) || (!Q->Dx && sp_factored_ok(Q, v->n)) || (Q->Z && Q->ncols <= Q->Z->m)) && t->n >= Q->ncols);
     if (dense_factored(Q)) {
         const int m = (int)Q->ncols, wm = (int)Q->A->m;
         const int64_t N = Q->A->n;
@@ -344,8 +348,8 @@ int lfpsqp_q_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, const lfpsqp_vec* v,
         return sp_basis_small(ctx, dW, wm, m, tA, t->p, nullptr);
     }
     if (!Q->Dx) {
-        LF_ARG(ctx, Q->Z);
         if (sp_factored_ok(Q, v->n)) return sp_factored_gemv_t(ctx, Q->SA, Q->A, Q->W, (int)Q->ncols, v->p, t->p);     // on the nonzeros
+        LF_ARG(ctx, Q->Z);
         return lfpsqp_gemv_t(ctx, Q->Z, Q->ncols, v, t);
     }
     LF_ARG(ctx, Q->Dy && Q->sx && Q->sy && w);
@@ -357,7 +361,7 @@ int lfpsqp_q_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, const lfpsqp_vec* v,
 int lfpsqp_q_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, double alpha, const lfpsqp_vec* w, const lfpsqp_vec* t, double beta,
                     lfpsqp_vec* y) {
     LF_RANGE("lfpsqp_q_gemv_n");
-    LF_ARG(ctx, ctx && Q && y && Q->ncols >= 0 && (Q->ncols == 0 || ((dense_factored(Q) || (Q->Z && Q->ncols <= Q->Z->m)) && t && t->n >= Q->ncols)));
+    LF_ARG(ctx, ctx && Q && y && Q->ncols >= 0 && (Q->ncols == 0 || ((dense_factored(Q) || (!Q->Dx && sp_factored_ok(Q, y->n)) || (Q->Z && Q->ncols <= Q->Z->m)) && t && t->n >= Q->ncols)));
     if (dense_factored(Q)) {
         const int m = (int)Q->ncols, wm = (int)Q->A->m;
         const int64_t N = Q->A->n;
@@ -375,8 +379,8 @@ int lfpsqp_q_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_basis* Q, double alpha, const 
                                               nullptr, NoPost());
     }
     if (!Q->Dx) {
-        LF_ARG(ctx, Q->Z);
         if (sp_factored_ok(Q, y->n)) return sp_factored_gemv_n(ctx, Q->SA, Q->A, Q->W, (int)Q->ncols, alpha, t->p, beta, y->p);
+        LF_ARG(ctx, Q->Z);
         return lfpsqp_gemv_n(ctx, Q->Z, Q->ncols, alpha, t, beta, y);
     }
     LF_ARG(ctx, Q->Dy && Q->sx && Q->sy);

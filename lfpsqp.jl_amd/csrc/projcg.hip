@@ -701,7 +701,8 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     LF_ARG(ctx, x->n == nv && work->g->n == nv && work->d->n == nv && work->rp->n == nv);
     // basis in factored form with a DENSE generator (U->Z == NULL, U = [sx; sy] .* (A W)): the fused iteration streams A
     const bool DF = m > 0 && !U->Z && U->A && U->W && !U->SA && m <= U->A->m && U->A->m <= kOnepassMaxCols;
-    LF_ARG(ctx, m >= 0 && (m == 0 || ((DF || (U->Z && m <= U->Z->m)) && work->Utr->n >= m)));
+    const bool SF = m > 0 && !U->Z && U->A && U->W && U->SA;       // ... or on the nonzeros of its sparse twin: no Z either
+    LF_ARG(ctx, m >= 0 && (m == 0 || ((DF || SF || (U->Z && m <= U->Z->m)) && work->Utr->n >= m)));
     LF_ARG(ctx, !A->dg || A->dg->n == nv);
     LF_ARG(ctx, n_global >= (stacked ? 0 : nv));
     int64_t N = nv, hs = 0;                        // rows of Z
@@ -709,11 +710,11 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         LF_ARG(ctx, U->Dy && U->sx && U->sy);
         N = U->Dx->n;
         hs = lfpsqp_half_stride(N);
-        LF_ARG(ctx, nv == hs + N && U->Dy->n == N && U->sx->n == N && U->sy->n == N && (m == 0 || (DF ? U->A->n : U->Z->n) == N));
+        LF_ARG(ctx, nv == hs + N && U->Dy->n == N && U->sx->n == N && U->sy->n == N && (m == 0 || ((DF || SF) ? U->A->n : U->Z->n) == N));
         if (c) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "stacked basis with c != 0 (never used by optimize, src/optimize.jl:368)");
         LF_ARG(ctx, !(flags & LFPSQP_PROJCG_WANT_LAMBDA) || (lambda && lambda->n >= N + m));
     } else {
-        LF_ARG(ctx, m == 0 || (DF ? U->A->n : U->Z->n) == nv);
+        LF_ARG(ctx, m == 0 || ((DF || SF) ? U->A->n : U->Z->n) == nv);
         LF_ARG(ctx, !c || c->n >= m);
         LF_ARG(ctx, !(flags & LFPSQP_PROJCG_WANT_LAMBDA) || (lambda && lambda->n >= m));
     }
@@ -751,6 +752,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         LF_HIP(ctx, hipMemcpyAsync(dWs, U->W, sizeof(double) * (size_t)wm * m, hipMemcpyHostToDevice, ctx->stream));
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // U->W is caller-owned pageable memory
     }
+    if (SF && !SA) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "basis in factored form on the nonzeros (Z == NULL, SA given): shape not covered; materialise Z");
     const int nxs = SA ? wm - (int)SA->m : 0;
     // t_out = U' v for the producer functor v (materialised in tmp): W' ([S | X]' v)
     auto sp_gemv_t = [&](auto vf, double* tmp, double* t_out, double* u_out) -> int {

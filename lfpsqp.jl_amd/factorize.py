@@ -41,7 +41,8 @@ def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix | None, w2: DeviceVector | N
     Vt = np.zeros((m, m), order='F')
     rank = c_i64()
     if Jsp is not None:
-        ctx.check(ctx.L.lfpsqp_factorize_sp(ctx.h, Jsp.h, Jct.h if Jct is not None else None, w2.h if w2 is not None else None, Z.h,
+        ctx.check(ctx.L.lfpsqp_factorize_sp(ctx.h, Jsp.h, Jct.h if Jct is not None else None, w2.h if w2 is not None else None,
+                                            Z.h if Z is not None else None,
                                             S.ctypes.data, Vt.ctypes.data, W.ctypes.data if W is not None else None, C.byref(rank),
                                             float(eps_rank)))
     else:

@@ -168,7 +168,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     # ... unless the basis can stay in FACTORED form U = Jct W: then there is no Z at all -- the fused projected-CG iteration, the
     # Newton step and the projections stream Jct and apply the m x m factor W on the side, the tangent setup skips its basis-forming product,
     # and the work vectors are placed against Jct.
-    factored = bool(ctx.options.factored_basis) and diagonal_hessian and 4 <= m <= 1024 and getattr(c_, "Jsp", None) is None
+    factored = bool(ctx.options.factored_basis) and diagonal_hessian and 4 <= m <= 1024     # (with a sparse twin: on the nonzeros, no Z either)
     if factored:
         projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=Jct, extra=1)
         idecomp = InequalityDecomp(ctx, n, m, Jct, factored=True)

@@ -146,3 +146,56 @@ def test_optimize_is_the_same_with_and_without_the_materialised_basis(dev_ctx, b
         for key in ("steptype", "mtype", "alpha", "ls_flag", "tn_iter", "rank"):
             assert a.get(key) == b_.get(key), (key, a.get(key), b_.get(key))
     np.testing.assert_allclose(o1, o0, rtol=1e-12)
+
+
+@pytest.mark.parametrize("bounds", [False, True])
+def test_sparse_twin_without_the_basis(dev_ctx, bounds):
+    """Sparse constraint gradients (lfpsqp_spmat twin) with the basis in factored form: lfpsqp_factorize_sp(Z = NULL) returns the factors of the
+    run that forms Z (no basis-forming product, no n x m basis in memory), and `optimize` on banded equalities -- projected CG, projection and
+    Newton steps on the nonzeros -- follows the same trajectory with DeviceOptions.factored_basis on and off."""
+    import scipy.sparse as sp
+    ctx = dev_ctx
+    n, m, k = (600, 8, 3) if _is_emu(ctx) else (30000, 32, 4)
+    ii = np.arange(n)
+    rows = np.repeat(ii, k)
+    cols = ((((ii * m) // n)[:, None] + np.arange(k)[None, :]) % m).ravel()
+    vals = (np.random.default_rng(5).standard_normal((n, k)) + 2.0 * (np.arange(k) == 0)).ravel()
+    p = 1 if bounds else 0
+    S = L.SparseMatrix(ctx, n + p, m, rows, cols, vals)
+    Jct = ctx.matrix(n + p, m + p)
+    S.to_dense(Jct)
+    if not bounds:
+        Z = ctx.matrix(n, m)
+        W1, W2 = np.zeros((m, m), order='F'), np.zeros((m, m), order='F')
+        S1, Vt1, r1 = L.ksvd_(Jct, Z, W=W1, Jsp=S)
+        S2, Vt2, r2 = L.ksvd_(Jct, None, W=W2, Jsp=S)
+        assert r1 == r2 == m
+        np.testing.assert_array_equal(S1, S2)
+        np.testing.assert_array_equal(W1, W2)
+    xs = ctx.vector(n + p).hash_fill(2, 0, 1.0, 0.0)
+    if bounds:
+        ctx.check(ctx.L.lfpsqp_vec_fill_range(ctx.h, xs.h, n, 1, 0.0))
+    b = ctx.vector(m + p)
+    L.spmv_t(S, xs, b)
+    res = {}
+    for factored in (True, False):
+        ctx.options.factored_basis = factored
+        if bounds:
+            xl = np.where((ii % 4 == 1) | (ii % 4 == 3), -1.0, -np.inf)
+            xu = np.where((ii % 4 == 2) | (ii % 4 == 3), 1.0, np.inf)
+            P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download()[:m], R2=n / 2.0, xl=xl, xu=xu, Jsp=S)
+            x0 = 0.5 * np.ones(n)
+        else:
+            P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download(), Jsp=S)
+            x0 = xs.download() + 0.05 * synth.hash_vector(6, n)
+        tr = []
+        x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=4), trace=tr)
+        res[factored] = (tr, obj, ti)
+    ctx.options.factored_basis = True
+    (tr1, o1, t1), (tr0, o0, t0) = res[True], res[False]
+    assert t1.iter == t0.iter
+    for a, b_ in zip(tr1, tr0):
+        assert np.linalg.norm(a["x"] - b_["x"]) <= 1e-10 * max(1.0, np.linalg.norm(b_["x"]))
+        for key in ("steptype", "mtype", "alpha", "ls_flag", "tn_iter", "rank", "retract_iter1"):
+            assert a.get(key) == b_.get(key), (key, a.get(key), b_.get(key))
+    np.testing.assert_allclose(o1, o0, rtol=1e-12)
