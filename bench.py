@@ -90,6 +90,7 @@ def main(argv=None, lib=None):
 
     import lfpsqp_jl_amd as L
 
+    dev_uuid = gpu_uuid() if (rank == 0 and lib is None) else None      # (asked before this process touches the GPU)
     if args.lib:
         lib = L.load_library(args.lib)
     dev = local_rank if args.device is None else args.device
@@ -322,7 +323,7 @@ def main(argv=None, lib=None):
                    "placement": placement,
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
-                   "comm": comm_used, "device": ctx.device_name},
+                   "comm": comm_used, "device": ctx.device_name, "device_uuid": dev_uuid},
         "roofline": ({"bound": "hbm", "kernel": "onepass_kernel<PcgFuseE> (F: rp = g + alpha*A*d, gp = rp - U*Utr, g = gp, U'gp, U'(A gp): "
                                                  "ONE pass over U per projected-CG iteration)",
                       "achieved": gbs(bytes_kf, kf), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -396,6 +397,20 @@ def main(argv=None, lib=None):
     if watchdog:
         faulthandler.cancel_dump_traceback_later()
     return out
+
+
+def gpu_uuid():
+    """Uuid of the first GPU agent (rocminfo): boxes differ (on some GPUs every allocation pair runs the fused kernel at the slow
+    speed), so a bench line says which device it was measured on."""
+    try:
+        import subprocess
+        out = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=20).stdout
+        for line in out.splitlines():
+            if "Uuid:" in line and "GPU-" in line:
+                return line.split()[-1]
+    except Exception:
+        pass
+    return None
 
 
 def shape_name(n, m):
