@@ -432,8 +432,14 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 #endif
 }
 
-template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA = 1, bool LACC = false>
-__global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
+// STG > 0 (functors with a staged output, EP::apply_staged / EP::stage_out): the row update's output vector is not stored tile by
+// tile; up to STG rounds of it (STG * 512 bytes) wait in LDS and the whole workgroup stores them in one burst, in equal bursts
+// over its span.  Why: on MI355X a thin store stream inside the matrix read stream costs far more than its bytes (an 80 MB
+// stream inside 10.2 GB of reads: +0.11 ... +0.25 ms on 1.53, depending on where the buffers landed); the same stores issued
+// in a few device-wide phases (the workgroups of the persistent grid advance in step) cost half of that or less
+// (tools/micro/layoutprobe.hip, profiles/r03e_layoutprobe_store_modes.txt).  The staging area shares `buf`, so STG excludes LACC.
+template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA = 1, bool LACC = false, int STG = 0>
+__global__ __launch_bounds__(kThreads, (STG > 102 ? 2 : (STG > 0 ? 3 : 1))) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
                                                             int64_t rounds, const double* __restrict__ t, int t_stride, EP ep,
                                                             double* __restrict__ part, int part_ld) {
     if (ep.skip()) return;
@@ -451,10 +457,13 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     // that holds the running sums of the second product during the tile loop (LACC) and the per-wave column sums after it
     constexpr int kRedD = (WIDE ? 1 : kWaves) * NV * NC;
     constexpr int kAccD = LACC ? NV * NQ * kThreads : 0;
-    constexpr int kBufD = kRedD > kAccD ? kRedD : (kAccD > 0 ? kAccD : 1);
+    constexpr int kStgD = STG * kStep;
+    static_assert(STG == 0 || (!LACC && !WIDE && NA == 1), "staged stores: narrow kernel, register sums");
+    constexpr int kBufD0 = kRedD > kAccD ? kRedD : (kAccD > 0 ? kAccD : 1);
+    constexpr int kBufD = kBufD0 > kStgD ? kBufD0 : kStgD;
     __shared__ double ts[NA][NC];
     __shared__ double buf[kBufD];
-    __shared__ double accx[2][kWaves][RW];
+    __shared__ double accx[WIDE ? 2 : 1][WIDE ? kWaves : 1][WIDE ? RW : 1];
     auto red = [&](int w, int qq, int sl) -> double& { return buf[(w * NV + qq) * NC + sl]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = (lane & 3) | ((lane >> 4) << 2), h = (lane >> 2) & 3;
@@ -518,6 +527,10 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     double rsum[NRL > 0 ? NRL : 1];
 #pragma unroll
     for (int qq = 0; qq < (NRL > 0 ? NRL : 1); ++qq) rsum[qq] = 0.0;
+    // staged stores: `cnt` rounds in ceil(cnt / STG) bursts of equal length (the last one may be shorter)
+    const int nburst = STG > 0 ? (cnt + STG - 1) / STG : 1;
+    const int blen = (cnt + nburst - 1) / nburst;
+    int sk = 0;                                      // rounds waiting in the staging area
     auto tile_step = [&](int k, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
         compiler_fence();               // re-read ts[] from LDS every tile instead of pinning 2*CPL registers on it
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
             s += __shfl_xor(s, 8);
             acc[b] = s;
         }
-        if (WIDE) {                     // ... and over the four waves' column ranges (NA == 1 in the wide form)
+        if constexpr (WIDE) {           // ... and over the four waves' column ranges (NA == 1 in the wide form)
             const int b = k & 1;
             if (h == 0) accx[b][wave][r] = acc[0];
             __syncthreads();
@@ -542,7 +555,8 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
         if (MORE && kRowAhead && !kOpRowLate) in_next = ep.fetch(ro + kStep * 8);
         double v[NV];
         const bool lead = !WIDE || wave == 0;
-        ep.apply(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum);
+        if constexpr (STG > 0) ep.apply_staged(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum, buf + sk * kStep + lrow);
+        else ep.apply(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum);
         // second product: columns 4j .. 4j+3 of this lane's group, summed over the row bits RR by two transposing swaps;
         // afterwards the lane holds the 4-row sum of column register 4j + 2*bit4 + bit5
 #pragma unroll
@@ -572,6 +586,17 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
         if (kRowAhead && kOpRowLate) { if (MORE) in = ep.fetch(ro); }
         else if (kRowAhead) in = in_next;
         else if (MORE) in = ep.fetch(ro);   // big row records (batched trials): fetched after this tile's use, no second copy live
+        if constexpr (STG > 0) {
+            if (++sk == blen || !MORE) {    // uniform: the workgroup stores the staged rounds (the next tile's loads are in flight meanwhile)
+                __syncthreads();
+                const int64_t rb = row0 + (int64_t)(k + 1 - sk) * kStep;
+                double* outv = ep.stage_out();
+                for (int e = threadIdx.x; e < sk * kStep; e += kThreads)
+                    if (rb + e < n) outv[rb + e] = buf[e];
+                __syncthreads();            // before the next round overwrites the area
+                sk = 0;
+            }
+        }
     };
 #pragma unroll 1
     for (int k = 0; k < cnt - 1; ++k) tile_step(k, std::true_type());
@@ -582,7 +607,7 @@ __global__ __launch_bounds__(kThreads) void onepass_kernel(const double* __restr
     for (int j = 0; j < NQ; ++j)
 #pragma unroll
         for (int qq = 0; qq < NV; ++qq) pfin[qq][j] = LACC ? pl[(qq * NQ + j) * kThreads] : p[LACC ? 0 : qq][LACC ? 0 : j];
-    if (LACC) __syncthreads();           // buf changes its role: running sums -> per-wave column sums
+    if (LACC) __syncthreads();           // buf changes its role: running sums -> per-wave column sums (STG: the last burst ended with a barrier)
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
 #pragma unroll

@@ -217,15 +217,23 @@ struct PcgInnerE {
         }
         return w;
     }
-    __device__ __forceinline__ void apply(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool, const Uni& u,
+    // staged form (onepass_kernel STG): z of the plain iteration waits in LDS and is stored in bursts
+    static constexpr bool kStaged = !ST;
+    __device__ __forceinline__ double* stage_out() const { return z; }
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
                                           const Row& w, double (&v)[2], double (&red)[1]) const {
+        apply_staged(row, o, accv, valid, owner, lead, u, w, v, red, nullptr);
+    }
+    __device__ __forceinline__ void apply_staged(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool, const Uni& u,
+                                                 const Row& w, double (&v)[2], double (&red)[1], double* slot) const {
         const double acc = accv[0];
         const bool st = valid && owner;
         if (!ST) {
             const double pn = first ? w.px : fma(u.beta, w.px, w.rx);                // :217 (stored by P3: same fma)
             const double zz = fma(mu, pn, acc);                                      // :222
             if (st) {
-                put(z, o, zz);
+                if (slot) *slot = zz;
+                else put(z, o, zz);
                 red[0] += pn * zz;                                                   // :226
             }
             v[0] = valid ? zz : 0.0;

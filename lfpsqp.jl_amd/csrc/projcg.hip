@@ -288,8 +288,16 @@ struct PcgFuseE {
     //     d+ = beta d - gp  =>  d+'A d+ = gp'A gp - 2 beta gp'A d + beta^2 d'A d   (all three direct).
     // The first four are gp times {rp, gp, A gp, A d}: lane group h takes the h-th of them in running sum 0; d'A d is running sum 1
     // of group 0 (kSplitRed: 2 running sums per lane instead of 5).
-    __device__ __forceinline__ void apply(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
+    // staged form (onepass_kernel STG): the projected residual of the plain iteration goes to the workgroup's LDS slot of the row
+    // instead of memory; the kernel stores whole bursts of them through stage_out()
+    static constexpr bool kStaged = !ST && !INIT;
+    __device__ __forceinline__ double* stage_out() const { return gout; }
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
                                           const Row& w, double (&v)[2], double (&red)[2]) const {
+        apply_staged(row, o, accv, valid, owner, lead, u, w, v, red, nullptr);
+    }
+    __device__ __forceinline__ void apply_staged(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
+                                                 const Row& w, double (&v)[2], double (&red)[2], double* slot) const {
         const double acc = accv[0];
         const bool st = valid && owner, cnt = valid && lead;
         const int h = (int)((threadIdx.x >> 2) & 3u);
@@ -299,7 +307,8 @@ struct PcgFuseE {
             const double gp = rr - acc;                                              // :97
             const double ag = w.ax * gp;
             if (st) {
-                put(gout, o, gp);
+                if (slot) *slot = gp;
+                else put(gout, o, gp);
                 if (INIT) put(d, o, -gp);                                            // :62
             }
             const double f = (h == 0) ? rr : ((h == 1) ? gp : ((h == 2) ? ag : ad));

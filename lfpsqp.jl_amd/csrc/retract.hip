@@ -165,11 +165,15 @@ struct NRStepE {
         return w;
     }
     template <bool ST>
-    __device__ __forceinline__ double apply1(int64_t i, uint32_t o, double acc, bool valid, bool owner, const Row& w, double& red) const {
+    __device__ __forceinline__ double apply1(int64_t i, uint32_t o, double acc, bool valid, bool owner, const Row& w, double& red,
+                                             double* slot = nullptr) const {
         double xn = w.xn;
         if (!ST) {
             xn += acc;
-            if (valid && owner) put(xnew, o, xn);
+            if (valid && owner) {
+                if (slot) *slot = xn;      // staged stores (onepass_kernel STG)
+                else put(xnew, o, xn);
+            }
         } else {
             double yn = w.yn;
             xn += w.ax * acc;
@@ -198,6 +202,13 @@ struct NRStepRow {
     __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool, const Uni&,
                                           const Row& w, double (&v)[1], double (&red)[1]) const {
         v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0]);
+    }
+    // staged form: the new point of the plain (unstacked) step waits in LDS and is stored in bursts
+    static constexpr bool kStaged = !ST;
+    __device__ __forceinline__ double* stage_out() const { return e.xnew; }
+    __device__ __forceinline__ void apply_staged(int64_t i, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool, const Uni&,
+                                                 const Row& w, double (&v)[1], double (&red)[1], double* slot) const {
+        v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0], slot);
     }
 };
 

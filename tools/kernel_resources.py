@@ -3,7 +3,7 @@ usage: python tools/kernel_resources.py lfpsqp.jl_amd/csrc/retract.hip [name-fil
 import re, subprocess, sys, os
 src = sys.argv[1]; filt = sys.argv[2] if len(sys.argv) > 2 else ""
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{root}/include", "-c", src, "--cuda-device-only",
+out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *os.environ.get("KR_FLAGS", "").split(), f"-I{root}/include", "-c", src, "--cuda-device-only",
                       "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null"], capture_output=True, text=True).stderr
 cur = None; rows = []
 for line in out.splitlines():

@@ -15,7 +15,7 @@
 
 constexpr int M_COLS = 128, CPL = 32;      // 32 column registers per lane x 4 lane groups
 
-template <bool PANEL>
+template <bool PANEL, bool LOADV = true, bool STOREV = true>
 __global__ __launch_bounds__(256) void tile_kernel(const double* __restrict__ M, int64_t ld, int64_t rounds, const double* __restrict__ g_in,
                                                    double* __restrict__ g_out, const double* __restrict__ d, const double* __restrict__ a,
                                                    double* __restrict__ part) {
@@ -36,19 +36,90 @@ __global__ __launch_bounds__(256) void tile_kernel(const double* __restrict__ M,
             av[c] = __builtin_nontemporal_load(p);
         }
         const int64_t row = row0 + r;
-        const double gg = g_in[row], dd = d[row], aa = a[row];
+        const double gg = LOADV ? g_in[row] : 1.0, dd = LOADV ? d[row] : 2.0, aa = LOADV ? a[row] : 3.0;
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) s = fma(av[c], 1e-3 * (c + 1), s);       // first product
         s += __shfl_xor(s, 4);
         s += __shfl_xor(s, 8);
         const double gp = fma(1e-9, aa * dd, gg) - 1e-12 * s;                  // row update
-        if (h == 0) g_out[row] = gp;
+        if (STOREV && h == 0) g_out[row] = gp;
         s_red += gp * gp;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) acc2[c & 3] = fma(av[c], gp, acc2[c & 3]);   // second product (no cross-lane reduction: traffic only)
     }
     const double tot = (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]) + s_red;
+    if (tot == 123.456) part[blockIdx.x] = tot;
+}
+
+// ---- how the 80 MB store stream is issued (column-major walk, vector loads on) ----------------------------------------------------------
+//   SMODE 0: one 128-byte store per tile by the 16 owner lanes (what the library's kernels do)
+//   SMODE 1: lane group h keeps the value of tile k = h (mod 4); every fourth tile all 64 lanes store: one instruction, four 128-byte pieces
+//   SMODE 2: the four waves of a workgroup meet in LDS once per 64-row round (one barrier); wave (k & 3) stores the round's 512 contiguous bytes
+//   SMODE 3: every wave walks its OWN contiguous quarter of the workgroup's span, 512 contiguous bytes stored every fourth tile
+//   SMODE 4: stores go to a 64 KB window (cache-resident): what the kernel costs when the store stream never reaches memory
+//   SMODE 8 / 32 / 128: that many rounds staged in LDS, then stored in one burst by the whole workgroup (workgroups run in near lockstep: bursts align)
+template <int SMODE>
+__global__ __launch_bounds__(256) void store_kernel(const double* __restrict__ M, int64_t ld, int64_t rounds, const double* __restrict__ g_in,
+                                                    double* __restrict__ g_out, const double* __restrict__ d, const double* __restrict__ a,
+                                                    double* __restrict__ part) {
+    constexpr int BURST = SMODE >= 5 ? SMODE : 2;      // SMODE >= 5: rounds staged in LDS before one burst of stores
+    __shared__ double stage[BURST][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = (lane & 3) | ((lane >> 4) << 2), h = (lane >> 2) & 3;
+    const int64_t q = rounds / gridDim.x, rem = rounds % gridDim.x;
+    const int64_t t0 = blockIdx.x * q + (blockIdx.x < rem ? blockIdx.x : rem);
+    const int cnt = (int)(q + (blockIdx.x < rem ? 1 : 0));
+    double acc2[4] = {0.0, 0.0, 0.0, 0.0};
+    double s_red = 0.0, keep = 0.0;
+    // SMODE 3: this wave's tiles are the 16-row tiles [wt0, wt0 + wcnt) of the span (4 * cnt tiles in all)
+    const int64_t tiles = (int64_t)cnt * 4, wq = tiles / 4;
+    const int64_t wt0 = t0 * 4 + wave * wq;
+    const int wcnt = (int)(wave == 3 ? tiles - 3 * wq : wq);
+    const int iters = SMODE == 3 ? wcnt : cnt;
+    for (int k = 0; k < iters; ++k) {
+        const int64_t row0 = SMODE == 3 ? (wt0 + k) * 16 : (t0 + k) * 64 + wave * 16;
+        double av[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) av[c] = __builtin_nontemporal_load(M + row0 + r + (int64_t)(4 * c + h) * ld);
+        const int64_t row = row0 + r;
+        const double gg = g_in[row], dd = d[row], aa = a[row];
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) s = fma(av[c], 1e-3 * (c + 1), s);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        const double gp = fma(1e-9, aa * dd, gg) - 1e-12 * s;
+        if (SMODE == 0) { if (h == 0) g_out[row] = gp; }
+        if (SMODE == 4) { if (h == 0) g_out[row & 8191] = gp; }
+        if (SMODE == 1) {
+            if ((k & 3) == h) keep = gp;
+            if ((k & 3) == 3) g_out[(t0 + (k - 3 + h)) * 64 + wave * 16 + r] = keep;          // tile k-3+h of this wave
+        }
+        if (SMODE == 3) {
+            if ((k & 3) == h) keep = gp;
+            if ((k & 3) == 3) g_out[(wt0 + (k - 3 + h)) * 16 + r] = keep;                      // 64 contiguous rows
+        }
+        if (SMODE >= 5) {                              // stage BURST rounds (BURST * 512 bytes) in LDS, then the whole workgroup stores them at once
+            if (h == 0) stage[k % BURST][wave * 16 + r] = gp;
+            if (k % BURST == BURST - 1 || k == iters - 1) {
+                const int nr = k % BURST + 1;                                    // rounds staged (the last burst of a span may be short)
+                __syncthreads();
+                for (int e = threadIdx.x; e < nr * 64; e += 256) g_out[(t0 + k - (nr - 1)) * 64 + e] = stage[e / 64][e % 64];
+                __syncthreads();
+            }
+        }
+        if (SMODE == 2) {
+            if (h == 0) stage[k & 1][wave * 16 + r] = gp;
+            __syncthreads();
+            if (wave == (k & 3)) g_out[(t0 + k) * 64 + lane] = stage[k & 1][lane];
+        }
+        s_red += gp * gp;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc2[c & 3] = fma(av[c], gp, acc2[c & 3]);
+    }
+    // (the last < 4 tiles of SMODE 1 / 3 are not flushed: a timing probe)
+    const double tot = (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]) + s_red + keep;
     if (tot == 123.456) part[blockIdx.x] = tot;
 }
 
@@ -92,5 +163,67 @@ int main(int argc, char** argv) {
                 }
                 printf("round %d Z%d W%d: colmajor %.4f ms   panel %.4f ms\n", rnd, iz, iw, ms[0], ms[1]);
             }
+    // which component of the kernel makes a slow pair slow?  column-major walk; all four combinations of {vector loads, vector store}
+    printf("\ncomponents (column-major): full | loads only (no store) | store only (no vector loads) | matrix stream alone\n");
+    for (int iz = 0; iz < KZ; ++iz)
+        for (int iw = 0; iw < KW; ++iw) {
+            float ms[4];
+            for (int v = 0; v < 4; ++v) {
+                for (int rep = 0; rep < 5; ++rep) {
+                    if (rep == 1) hipEventRecord(e0);
+                    if (v == 0) tile_kernel<false, true, true><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 1) tile_kernel<false, true, false><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 2) tile_kernel<false, false, true><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 3) tile_kernel<false, false, false><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                }
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms[v], e0, e1);
+                ms[v] /= 4;
+            }
+            printf("Z%d W%d: %.4f | %.4f | %.4f | %.4f ms\n", iz, iw, ms[0], ms[1], ms[2], ms[3]);
+        }
+    printf("\nstore modes (column-major): per tile 128 B | every 4th tile 4 x 128 B | LDS + barrier, 512 B per round | own quarter span, 512 B | stores to a 64 KB window\n");
+    for (int iz = 0; iz < KZ; ++iz)
+        for (int iw = 0; iw < KW; iw += (KW > 1 ? KW - 1 : 1)) {
+            float ms[10];
+            for (int v = 0; v < 10; ++v) {
+                for (int rep = 0; rep < 5; ++rep) {
+                    if (rep == 1) hipEventRecord(e0);
+                    if (v == 0) store_kernel<0><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 1) store_kernel<1><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 2) store_kernel<2><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 3) store_kernel<3><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 4) store_kernel<4><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 5) store_kernel<32><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 6) store_kernel<64><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 7) store_kernel<128><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    // what the fused kernel could afford: 3 workgroups per CU (register sums, no LDS sums), 52 KB of staging each, 2 bursts per span
+                    if (v == 8) store_kernel<102><<<768, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 9) store_kernel<0><<<768, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                }
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms[v], e0, e1);
+                ms[v] /= 4;
+            }
+            printf("Z%d W%d: %.4f | %.4f | %.4f | %.4f | %.4f | bursts of 32 / 64 / 128 (= the whole span) rounds: %.4f %.4f %.4f ms\n", iz, iw, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], ms[7]);
+            printf("        768 workgroups: 2 bursts of 102 rounds %.4f | per tile %.4f ms\n", ms[8], ms[9]);
+        }
+    // ... and does it follow the STORED vector alone?  g from set iw, d and a from set (iw + 1) % KW
+    printf("\nresidual (loaded + stored) from set W, direction / diagonal from the NEXT set:\n");
+    for (int iz = 0; iz < KZ; ++iz)
+        for (int iw = 0; iw < KW; ++iw) {
+            const int jw = (iw + 1) % KW;
+            float t;
+            for (int rep = 0; rep < 5; ++rep) {
+                if (rep == 1) hipEventRecord(e0);
+                tile_kernel<false, true, true><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[jw], A[jw], part);
+            }
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&t, e0, e1);
+            printf("Z%d g:W%d d,a:W%d: %.4f ms\n", iz, iw, jw, t / 4);
+        }
     return 0;
 }
