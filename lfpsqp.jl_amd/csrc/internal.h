@@ -114,6 +114,7 @@ struct lfpsqp_ctx {
         int64_t n_global = 0;
         uint64_t epoch = 0;          // launch_epoch when the call returned: ANY kernel the library queued since then voids the state
     } pcg_resume;
+    int stage_cap = 0;               // test hook (env LFPSQP_STAGE_ROUNDS at context creation): cap on the rounds per burst of staged stores
     uint64_t launch_epoch = 0;       // bumped by every launch helper (run_vec / run_gemv_* / run_onepass / launch_reduce)
 
     // optional per-kernel-family profiling with HIP events on `stream`
@@ -362,7 +363,7 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
         LF_TRY(ensure_part(ctx, (size_t)grid * part_ld + reduce_scratch(part_ld)));                                                  \
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);                                                                              \
         hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL, kG>), dim3((unsigned)grid), dim3(kThreads), \
-                           0, ctx->stream, M->p, M->ld, ncN, ncT, n, rounds, t, t_stride, ep, ctx->part, part_ld);                    \
+                           0, ctx->stream, M->p, M->ld, ncN, ncT, n, rounds, t, t_stride, ep, ctx->part, part_ld, ctx->stage_cap);    \
     } while (0)
         if (wide) {
             if constexpr (NA == 1) {

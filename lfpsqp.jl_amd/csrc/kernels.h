@@ -441,7 +441,7 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA = 1, bool LACC = false, int STG = 0>
 __global__ __launch_bounds__(kThreads, (STG > 102 ? 2 : (STG > 0 ? 3 : 1))) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
                                                             int64_t rounds, const double* __restrict__ t, int t_stride, EP ep,
-                                                            double* __restrict__ part, int part_ld) {
+                                                            double* __restrict__ part, int part_ld, int stage_cap) {
     if (ep.skip()) return;
     constexpr int CW = 4, RW = 16;                   // column groups per wave instruction, rows per wave tile
     constexpr int NW = WIDE ? kWaves : 1;            // waves sharing a row tile
@@ -528,7 +528,8 @@ __global__ __launch_bounds__(kThreads, (STG > 102 ? 2 : (STG > 0 ? 3 : 1))) void
 #pragma unroll
     for (int qq = 0; qq < (NRL > 0 ? NRL : 1); ++qq) rsum[qq] = 0.0;
     // staged stores: `cnt` rounds in ceil(cnt / STG) bursts of equal length (the last one may be shorter)
-    const int nburst = STG > 0 ? (cnt + STG - 1) / STG : 1;
+    const int bmax = (stage_cap > 0 && stage_cap < STG) ? stage_cap : STG;       // (stage_cap: test hook, 0 in production)
+    const int nburst = STG > 0 ? (cnt + bmax - 1) / bmax : 1;
     const int blen = (cnt + nburst - 1) / nburst;
     int sk = 0;                                      // rounds waiting in the staging area
     auto tile_step = [&](int k, auto more_tag) {
