@@ -123,6 +123,53 @@ __global__ __launch_bounds__(256) void store_kernel(const double* __restrict__ M
     if (tot == 123.456) part[blockIdx.x] = tot;
 }
 
+// A fifth wave does ALL the stores: the four tile waves hand their values over through an LDS ring (two batches of R rounds, one
+// barrier per batch) and never issue a store themselves.  If what hurts is a store sitting in a tile wave's in-order memory queue
+// (loads issued behind it cannot be waited for without waiting for the store's acknowledgement as well), this is free.
+template <int R>
+__global__ __launch_bounds__(320) void writer_kernel(const double* __restrict__ M, int64_t ld, int64_t rounds, const double* __restrict__ g_in,
+                                                     double* __restrict__ g_out, const double* __restrict__ d, const double* __restrict__ a,
+                                                     double* __restrict__ part) {
+    __shared__ double ring[2][R][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = (lane & 3) | ((lane >> 4) << 2), h = (lane >> 2) & 3;
+    const int64_t q = rounds / gridDim.x, rem = rounds % gridDim.x;
+    const int64_t t0 = blockIdx.x * q + (blockIdx.x < rem ? blockIdx.x : rem);
+    const int cnt = (int)(q + (blockIdx.x < rem ? 1 : 0));
+    const int nb = (cnt + R - 1) / R;
+    if (wave == 4) {
+        for (int b = 0; b < nb; ++b) {
+            __syncthreads();                                   // batch b is complete
+            const int nr = (cnt - b * R) < R ? (cnt - b * R) : R;
+            for (int e = lane; e < nr * 64; e += 64) g_out[(t0 + (int64_t)b * R) * 64 + e] = ring[b & 1][e / 64][e % 64];
+        }
+        return;
+    }
+    double acc2[4] = {0.0, 0.0, 0.0, 0.0};
+    double s_red = 0.0;
+    for (int k = 0; k < cnt; ++k) {
+        const int64_t row0 = (t0 + k) * 64 + wave * 16;
+        double av[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) av[c] = __builtin_nontemporal_load(M + row0 + r + (int64_t)(4 * c + h) * ld);
+        const int64_t row = row0 + r;
+        const double gg = g_in[row], dd = d[row], aa = a[row];
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) s = fma(av[c], 1e-3 * (c + 1), s);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        const double gp = fma(1e-9, aa * dd, gg) - 1e-12 * s;
+        if (h == 0) ring[(k / R) & 1][k % R][wave * 16 + r] = gp;
+        if (k % R == R - 1 || k == cnt - 1) __syncthreads();   // hand the batch to the writer wave
+        s_red += gp * gp;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc2[c & 3] = fma(av[c], gp, acc2[c & 3]);
+    }
+    const double tot = (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]) + s_red;
+    if (tot == 123.456) part[blockIdx.x] = tot;
+}
+
 int main(int argc, char** argv) {
     const int KZ = argc > 1 ? atoi(argv[1]) : 3, KW = argc > 2 ? atoi(argv[2]) : 3;
     const int64_t n = 10000000, nround = (n + 63) / 64, npad = nround * 64, ld = npad + 16;
@@ -186,8 +233,8 @@ int main(int argc, char** argv) {
     printf("\nstore modes (column-major): per tile 128 B | every 4th tile 4 x 128 B | LDS + barrier, 512 B per round | own quarter span, 512 B | stores to a 64 KB window\n");
     for (int iz = 0; iz < KZ; ++iz)
         for (int iw = 0; iw < KW; iw += (KW > 1 ? KW - 1 : 1)) {
-            float ms[10];
-            for (int v = 0; v < 10; ++v) {
+            float ms[13];
+            for (int v = 0; v < 13; ++v) {
                 for (int rep = 0; rep < 5; ++rep) {
                     if (rep == 1) hipEventRecord(e0);
                     if (v == 0) store_kernel<0><<<grid, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
@@ -201,6 +248,9 @@ int main(int argc, char** argv) {
                     // what the fused kernel could afford: 3 workgroups per CU (register sums, no LDS sums), 52 KB of staging each, 2 bursts per span
                     if (v == 8) store_kernel<102><<<768, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
                     if (v == 9) store_kernel<0><<<768, 256>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 10) writer_kernel<4><<<grid, 320>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 11) writer_kernel<16><<<grid, 320>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
+                    if (v == 12) writer_kernel<16><<<768, 320>>>(Z[iz], ld, nround, G[iw], G[iw], D[iw], A[iw], part);
                 }
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
@@ -209,6 +259,7 @@ int main(int argc, char** argv) {
             }
             printf("Z%d W%d: %.4f | %.4f | %.4f | %.4f | %.4f | bursts of 32 / 64 / 128 (= the whole span) rounds: %.4f %.4f %.4f ms\n", iz, iw, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], ms[7]);
             printf("        768 workgroups: 2 bursts of 102 rounds %.4f | per tile %.4f ms\n", ms[8], ms[9]);
+            printf("        a fifth wave stores (tile waves never do): batches of 4 rounds %.4f | 16 rounds %.4f | 16 rounds, 768 workgroups %.4f ms\n", ms[10], ms[11], ms[12]);
         }
     // ... and does it follow the STORED vector alone?  g from set iw, d and a from set (iw + 1) % KW
     printf("\nresidual (loaded + stored) from set W, direction / diagonal from the NEXT set:\n");
