@@ -306,30 +306,38 @@ inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
 // out[k*ncT + j] = sum_rows M[row, j] * v_k[row] (k < NV, j < ncT), out[NV*ncT + r] = reduction r, with v produced by EP
 // from M[row, :ncN] . t -- all-reduced over ranks; one pass over M.  Persistent grid: as many workgroups as the device
 // keeps resident for this instantiation (occupancy query, cached), capped by the number of 64-row rounds.
-// Rounds of staged stores (onepass_kernel STG) of functor EP at CPL column groups per wave, for functors that offer a staged form
-// (EP::kStaged).  The CU's 160 KB of LDS hold 320 rounds however they are split: two workgroups of 153 rounds (2 waves per SIMD, the
-// register budget the 25..33-group tiles need without LDS sums) or three of 102 (3 waves per SIMD, the smaller tiles).
+// Staged stores (onepass_kernel STG) of functor EP at CPL column groups per wave, for functors that offer a staged form (EP::kStaged):
+// rounds per burst and the waves per SIMD the instantiation is compiled for.  The CU's 160 KB of LDS hold 320 rounds of the narrow form
+// (512 bytes each) however they are split: three workgroups of 102 rounds (3 waves per SIMD: tiles of up to 24 column groups) or two
+// of 153 (2 waves per SIMD, the register budget the larger tiles need with their running sums in registers).  A round of the wide
+// form is 16 rows (128 bytes): 256 rounds (160 at three workgroups per CU) fit beside its LDS running sums.
 #ifndef LFPSQP_OP_STAGE
 #define LFPSQP_OP_STAGE 1
 #endif
 #ifndef LFPSQP_OP_STAGE_MINCPL
 #define LFPSQP_OP_STAGE_MINCPL 8
 #endif
+#ifndef LFPSQP_OP_STAGE_WIDE
+#define LFPSQP_OP_STAGE_WIDE 1
+#endif
+struct StageCfg { int rounds, waves; };
 template <class EP, class = void>
 struct onepass_staged : std::false_type {};
 template <class EP>
 struct onepass_staged<EP, std::enable_if_t<EP::kStaged>> : std::true_type {};
 template <class EP>
-constexpr int onepass_stage(int cpl, bool wide, int na) {
-    if (!LFPSQP_OP_STAGE || !onepass_staged<EP>::value || wide || na != 1 || cpl < LFPSQP_OP_STAGE_MINCPL || cpl > 33) return 0;
-    return cpl >= 32 ? 153 : 102;
+constexpr StageCfg onepass_stage(int cpl, bool wide, int na) {
+    // (tiles of more than 33 column groups per wave run at one wave per SIMD with part of the tile in accumulation registers: no staging)
+    if (!LFPSQP_OP_STAGE || !onepass_staged<EP>::value || na != 1 || cpl < LFPSQP_OP_STAGE_MINCPL || cpl > 33) return StageCfg{0, 1};
+    if (wide) return !LFPSQP_OP_STAGE_WIDE ? StageCfg{0, 1} : (cpl <= 24 ? StageCfg{160, 3} : StageCfg{256, 2});
+    return cpl <= 24 ? StageCfg{102, 3} : StageCfg{153, 2};
 }
-template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA, bool LACC, int STG = 0>
+template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA, bool LACC, int STG = 0, int SW = 1>
 inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {
     static int per_cu = 0;                        // one per kernel instantiation
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, NA, LACC, STG>, kThreads, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, NA, LACC, STG, SW>, kThreads, 0) != hipSuccess ||
             nb < 1)
             nb = 1;
         per_cu = nb;
@@ -357,12 +365,13 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
 // with 17..33 column groups per wave (m = 65..132, and 260..528 in the wide form).
 #define LF_OP(CPL, EXACT, WIDE)                                                                                                      \
     do {                                                                                                                             \
-        constexpr int kG = onepass_stage<EP>(CPL, WIDE, NA);                                                                         \
-        constexpr bool kL = kG == 0 && kOpLacc && NA == 1 && (CPL) > 16 && (CPL) <= 33;                                             \
-        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL, kG>(ctx, rounds);                                   \
+        constexpr StageCfg kC = onepass_stage<EP>(CPL, WIDE, NA);                                                                    \
+        constexpr int kG = kC.rounds, kW = kC.waves;                                                                                 \
+        constexpr bool kL = (kG == 0 || (WIDE)) && kOpLacc && NA == 1 && (CPL) > 16 && (CPL) <= 33;                                 \
+        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL, kG, kW>(ctx, rounds);                               \
         LF_TRY(ensure_part(ctx, (size_t)grid * part_ld + reduce_scratch(part_ld)));                                                  \
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);                                                                              \
-        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL, kG>), dim3((unsigned)grid), dim3(kThreads), \
+        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL, kG, kW>), dim3((unsigned)grid), dim3(kThreads), \
                            0, ctx->stream, M->p, M->ld, ncN, ncT, n, rounds, t, t_stride, ep, ctx->part, part_ld, ctx->stage_cap);    \
     } while (0)
         if (wide) {

@@ -437,9 +437,10 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 // over its span.  Why: on MI355X a thin store stream inside the matrix read stream costs far more than its bytes (an 80 MB
 // stream inside 10.2 GB of reads: +0.11 ... +0.25 ms on 1.53, depending on where the buffers landed); the same stores issued
 // in a few device-wide phases (the workgroups of the persistent grid advance in step) cost half of that or less
-// (tools/micro/layoutprobe.hip, profiles/r03e_layoutprobe_store_modes.txt).  The staging area shares `buf`, so STG excludes LACC.
-template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA = 1, bool LACC = false, int STG = 0>
-__global__ __launch_bounds__(kThreads, (STG > 102 ? 2 : (STG > 0 ? 3 : 1))) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
+// (tools/micro/layoutprobe.hip, profiles/r03e_layoutprobe_store_modes.txt).  The staging area shares `buf` (next to LDS running sums, LACC, it is an array of its own).
+// SW: waves per SIMD the kernel is compiled for (the register budget follows from it; 1 = the compiler's choice).
+template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA = 1, bool LACC = false, int STG = 0, int SW = 1>
+__global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
                                                             int64_t rounds, const double* __restrict__ t, int t_stride, EP ep,
                                                             double* __restrict__ part, int part_ld, int stage_cap) {
     if (ep.skip()) return;
@@ -458,11 +459,14 @@ __global__ __launch_bounds__(kThreads, (STG > 102 ? 2 : (STG > 0 ? 3 : 1))) void
     constexpr int kRedD = (WIDE ? 1 : kWaves) * NV * NC;
     constexpr int kAccD = LACC ? NV * NQ * kThreads : 0;
     constexpr int kStgD = STG * kStep;
-    static_assert(STG == 0 || (!LACC && !WIDE && NA == 1), "staged stores: narrow kernel, register sums");
+    static_assert(STG == 0 || NA == 1, "staged stores: one first product");
+    // the staging area shares `buf` with the final column sums; next to LDS running sums (LACC) it is an array of its own
     constexpr int kBufD0 = kRedD > kAccD ? kRedD : (kAccD > 0 ? kAccD : 1);
-    constexpr int kBufD = kBufD0 > kStgD ? kBufD0 : kStgD;
+    constexpr int kBufD = (!LACC && kStgD > kBufD0) ? kStgD : kBufD0;
     __shared__ double ts[NA][NC];
     __shared__ double buf[kBufD];
+    __shared__ double stg_own[(LACC && STG > 0) ? kStgD : 1];
+    double* const stg = (LACC && STG > 0) ? stg_own : buf;
     __shared__ double accx[WIDE ? 2 : 1][WIDE ? kWaves : 1][WIDE ? RW : 1];
     auto red = [&](int w, int qq, int sl) -> double& { return buf[(w * NV + qq) * NC + sl]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(kThreads, (STG > 102 ? 2 : (STG > 0 ? 3 : 1))) void
         if (MORE && kRowAhead && !kOpRowLate) in_next = ep.fetch(ro + kStep * 8);
         double v[NV];
         const bool lead = !WIDE || wave == 0;
-        if constexpr (STG > 0) ep.apply_staged(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum, buf + sk * kStep + lrow);
+        if constexpr (STG > 0) ep.apply_staged(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum, stg + sk * kStep + lrow);
         else ep.apply(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum);
         // second product: columns 4j .. 4j+3 of this lane's group, summed over the row bits RR by two transposing swaps;
         // afterwards the lane holds the 4-row sum of column register 4j + 2*bit4 + bit5
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(kThreads, (STG > 102 ? 2 : (STG > 0 ? 3 : 1))) void
                 const int64_t rb = row0 + (int64_t)(k + 1 - sk) * kStep;
                 double* outv = ep.stage_out();
                 for (int e = threadIdx.x; e < sk * kStep; e += kThreads)
-                    if (rb + e < n) outv[rb + e] = buf[e];
+                    if (rb + e < n) outv[rb + e] = stg[e];
                 __syncthreads();            // before the next round overwrites the area
                 sk = 0;
             }

@@ -2,7 +2,7 @@
 workgroup stores it in a few bursts over its span.  WHEN a value is stored must not change WHAT is stored: with the rounds per burst
 capped at 1, 2 or 3 (test hook LFPSQP_STAGE_ROUNDS, read when a context is created) every workgroup goes through many bursts and a
 ragged last one, and the iterates have to be bit-identical to the uncapped run (one or two bursts per span), which the parity tests
-compare with the oracle.  Covers every staged tile width (8 / 16 / 24 / 32 / 33 column groups per wave) of the three staged kernels:
+compare with the oracle.  Covers every staged tile width (8 / 16 / 24 / 32 / 33 column groups per wave, and the wide form at 24 / 32) of the staged kernels:
 the fused projected-CG iteration (src/projcg.jl:84-103), the pcg! iteration (src/retractions.jl:215-229) and the one-stream Newton
 step (src/retractions.jl:141-148)."""
 import numpy as np
@@ -30,7 +30,7 @@ def _with_caps(ctx0, monkeypatch, run, caps=("", "1", "3")):
     return out
 
 
-@pytest.mark.parametrize("m", [20, 40, 90, 128, 130])
+@pytest.mark.parametrize("m", [20, 40, 90, 128, 130, 300, 500])
 def test_projcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m):
     emu = _is_emu(dev_ctx)
     n = 5003 if emu else 400_003          # not a multiple of the 64-row round: the last round of the last workgroup is ragged
@@ -52,7 +52,7 @@ def test_projcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch,
         np.testing.assert_array_equal(x, x0)
 
 
-@pytest.mark.parametrize("m", [24, 100])
+@pytest.mark.parametrize("m", [24, 100, 320])
 def test_pcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m):
     from lfpsqp_jl_amd.projpenalty import _JacPlain
     emu = _is_emu(dev_ctx)
@@ -76,7 +76,7 @@ def test_pcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m)
         np.testing.assert_array_equal(r, res[0][3])
 
 
-@pytest.mark.parametrize("m_lin", [12, 60, 128])
+@pytest.mark.parametrize("m_lin", [12, 60, 128, 300])
 def test_newton_step_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m_lin):
     emu = _is_emu(dev_ctx)
     n = 3001 if emu else 300_001

@@ -3,11 +3,10 @@
 #   gpurun -- bash tools/gpu_stage_ab.sh
 mkdir -p gpurun_out
 {
-python tools/ab_same_buffers.py base main 3 2
-AB_COLS=120 python tools/ab_same_buffers.py base main 2 2
-AB_COLS=96 python tools/ab_same_buffers.py base c8 2 2
-AB_COLS=64 python tools/ab_same_buffers.py base c8 2 2
-AB_COLS=32 python tools/ab_same_buffers.py base c8 2 2
+AB_ROWS=5e6 AB_COLS=512 python tools/ab_same_buffers.py nowide main 3 2
+AB_ROWS=5e6 AB_COLS=384 python tools/ab_same_buffers.py nowide main 2 2
+AB_ROWS=1e7 AB_COLS=256 python tools/ab_same_buffers.py nowide main 2 2
 timeout 900 python tools/fuzz_onepass.py 2>&1 | tail -2
-} > gpurun_out/stage_ab.txt 2>&1
-tail -50 gpurun_out/stage_ab.txt
+python -m pytest tests/test_staged_stores.py -m gpu -x -q 2>&1 | tail -2
+} > gpurun_out/stage_ab_wide.txt 2>&1
+tail -50 gpurun_out/stage_ab_wide.txt
