@@ -17,10 +17,15 @@ struct lfpsqp_spmat {
     int64_t* colptr = nullptr;      // [m + 1] (device): nonzero range of a column
     int64_t* chunk_beg = nullptr;   // [nchunks + 1] (device): nonzero range of a chunk
     int32_t* col_chunk = nullptr;   // [m + 1] (device): chunk range of a column
+    int32_t* box_lo = nullptr;      // [ceil(n / kSpBox)] (device): smallest / largest column index among the nonzeros of a block of kSpBox rows
+    int32_t* box_hi = nullptr;      //   (an empty block: lo > hi) -- the Gram kernels skip the blocks that cannot touch their tile
+    double run_frac = 0.0;          // share of the rows whose column set is that of the row 128 places earlier (structured systems: ~1)
     bool owns_structure = true;     // false for lfpsqp_spmat_clone's objects: the index arrays belong to the original
 };
 
 namespace lfpsqp {
+
+constexpr int kSpBox = 4096;      // rows per column bounding box of lfpsqp_spmat
 
 // acc(i), acc(i+1) = (Jct t)[i], [i+1] from the ELL arrays
 struct EllRows {

@@ -335,10 +335,22 @@ constexpr int kSgJ = 128, kSgK = 64, kSgTile = kSgJ * kSgK, kSgThreads = 1024, k
 // block-structured system thousands of consecutive rows share their columns, and the atomics -- 64 lanes on one address cost ~160 cycles
 // of the CU's one LDS per instruction: 0.8 ms of the first version's 0.96 at n = 1e7, K = 4 -- all but vanish.  Scattered column sets
 // degrade to one flush per row, the generic path (KR = 0: no registers, atomics per term).
+// Can a block of kSpBox rows whose nonzeros lie in the columns [lo, hi] touch the tile (rows j0 .. j0+kSgJ-1) x (columns k0 .. k0+kSgK-1) of G?
+// (rows_per_wg is a multiple of kSpBox, so a workgroup's slice is whole blocks; uniform over the workgroup)
+__device__ __forceinline__ bool sg_box_hits(const int32_t* lo, const int32_t* hi, int64_t b0, int j0, int k0) {
+    const int l = lo[b0 / kSpBox], h = hi[b0 / kSpBox];
+    return l < j0 + kSgJ && h >= j0 && l < k0 + kSgK && h >= k0;
+}
+// rint(y) for |y| < 2^51 in two full-rate additions (round-to-nearest-even, like rint): the limbs are at most 40 bits wide
+constexpr double kSgMagic = 6755399441055744.0;              // 1.5 * 2^52
+__device__ __forceinline__ double sg_rint_scaled(double x, double s) {      // rint(x * s), s a power of two (x * s exact)
+    return fma(x, s, kSgMagic) - kSgMagic;
+}
 template <int KR, int T>
 __global__ __launch_bounds__(T) void sp_gram_kernel(const double* __restrict__ val, const int32_t* __restrict__ col, int64_t ld, int K, int64_t n,
                                                    const double* __restrict__ w2, const double* __restrict__ cs, double s1, double r1,
-                                                   double s2, int nkb, int64_t rows_per_wg, unsigned long long* __restrict__ partial) {
+                                                   double s2, int nkb, int64_t rows_per_wg, const int32_t* __restrict__ box_lo,
+                                                   const int32_t* __restrict__ box_hi, unsigned long long* __restrict__ partial) {
     __shared__ unsigned long long acc[2 * kSgTile];
     const int j0 = ((int)blockIdx.y / nkb) * kSgJ, k0 = ((int)blockIdx.y % nkb) * kSgK;
     if (k0 + kSgK - 1 < j0) return;                          // a tile wholly below the diagonal (uniform over the workgroup)
@@ -372,7 +384,10 @@ __global__ __launch_bounds__(T) void sp_gram_kernel(const double* __restrict__ v
                 }
             }
         };
-        for (int64_t i = rbeg + threadIdx.x; i < rend; i += T) {
+        for (int64_t b0 = rbeg; b0 < rend; b0 += kSpBox) {
+        if (!sg_box_hits(box_lo, box_hi, b0, j0, k0)) continue;
+        const int64_t bend = (b0 + kSpBox < rend) ? b0 + kSpBox : rend;
+        for (int64_t i = b0 + threadIdx.x; i < bend; i += T) {
             double v[KR];
             int c[KR];
             bool same = run < kSgRun;
@@ -399,15 +414,19 @@ __global__ __launch_bounds__(T) void sp_gram_kernel(const double* __restrict__ v
 #pragma unroll
                 for (int b = a; b < KR; ++b, ++p) {
                     const double x = wa * v[b];
-                    const double q1 = rint(x * s1);
+                    const double q1 = sg_rint_scaled(x, s1);
                     a1[p] += q1;
-                    a2[p] += rint(fma(-q1, r1, x) * s2);
+                    a2[p] += sg_rint_scaled(fma(-q1, r1, x), s2);
                 }
             }
         }
+        }
         flush();
     } else {
-        for (int64_t i = rbeg + threadIdx.x; i < rend; i += T) {
+        for (int64_t b0 = rbeg; b0 < rend; b0 += kSpBox) {
+        if (!sg_box_hits(box_lo, box_hi, b0, j0, k0)) continue;
+        const int64_t bend = (b0 + kSpBox < rend) ? b0 + kSpBox : rend;
+        for (int64_t i = b0 + threadIdx.x; i < bend; i += T) {
             const double w = w2 ? w2[i] : 1.0;
             for (int a = 0; a < K; ++a) {
                 const int ca0 = col[(int64_t)a * ld + i], ca = ca0 - j0;
@@ -419,21 +438,118 @@ __global__ __launch_bounds__(T) void sp_gram_kernel(const double* __restrict__ v
                     const double vb = val[(int64_t)b * ld + i] * cs[cb0];
                     if (vb == 0.0 || cb < 0 || cb >= kSgK) continue;
                     const double x = wa * vb;
-                    const double q1 = rint(x * s1);
-                    const double q2 = rint(fma(-q1, r1, x) * s2);
+                    const double q1 = sg_rint_scaled(x, s1);
+                    const double q2 = sg_rint_scaled(fma(-q1, r1, x), s2);
                     const int idx = ca * kSgK + cb;
                     atomicAdd(&acc[idx], (unsigned long long)(long long)q1);
                     atomicAdd(&acc[kSgTile + idx], (unsigned long long)(long long)q2);
                 }
             }
         }
+        }
     }
     __syncthreads();
     unsigned long long* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * kSgTile);
     for (int idx = threadIdx.x; idx < 2 * kSgTile; idx += T) out[idx] = acc[idx];
 }
+// Rows of 9 .. 16 nonzeros: KR (KR + 1) / 2 pairs are too many limb sums for one lane, so PS lanes share a row stream -- lane q of the
+// group keeps the pairs (a, b) with b = j PS + q (j < KR / PS; static register indices on both sides: every lane holds all KR values of
+// the row for the a side and its own KR / PS of them for the b side), i.e. about KR^2 / (2 PS) pairs of two limbs each.  The lanes of a
+// group load the same addresses (one request), the pair products cost what they cost in the one-lane form, and the LDS atomics again
+// happen only when the column set of the stream changes.
+template <int KR, int PS, int T>
+__global__ __launch_bounds__(T) void sp_gram_split_kernel(const double* __restrict__ val, const int32_t* __restrict__ col, int64_t ld, int K, int64_t n,
+                                                         const double* __restrict__ w2, const double* __restrict__ cs, double s1, double r1,
+                                                         double s2, int nkb, int64_t rows_per_wg, const int32_t* __restrict__ box_lo,
+                                                         const int32_t* __restrict__ box_hi, unsigned long long* __restrict__ partial) {
+    static_assert(KR % PS == 0 && T % PS == 0, "whole b-slots per lane, whole groups per workgroup");
+    __shared__ unsigned long long acc[2 * kSgTile];
+    const int j0 = ((int)blockIdx.y / nkb) * kSgJ, k0 = ((int)blockIdx.y % nkb) * kSgK;
+    if (k0 + kSgK - 1 < j0) return;
+    for (int idx = threadIdx.x; idx < 2 * kSgTile; idx += T) acc[idx] = 0ull;
+    __syncthreads();
+    const int64_t rbeg = (int64_t)blockIdx.x * rows_per_wg, rend = (rbeg + rows_per_wg < n) ? rbeg + rows_per_wg : n;
+    constexpr int NB = KR / PS, G = T / PS;
+    const int q = (int)threadIdx.x % PS, g = (int)threadIdx.x / PS;
+    double a1[NB][KR], a2[NB][KR];                           // (j, a): used for a < (j + 1) PS only -- the rest is never touched
+    int cur[KR], curb[NB];
+    double csr[KR];
+#pragma unroll
+    for (int a = 0; a < KR; ++a) { cur[a] = -1; csr[a] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        curb[j] = -1;
+#pragma unroll
+        for (int a = 0; a < (j + 1) * PS; ++a) a1[j][a] = a2[j][a] = 0.0;
+    }
+    int run = 0;
+    auto flush = [&]() {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int cb = curb[j] - k0;
+#pragma unroll
+            for (int a = 0; a < (j + 1) * PS; ++a) {
+                const int ca = cur[a] - j0;
+                if ((a1[j][a] != 0.0 || a2[j][a] != 0.0) && ca >= 0 && ca < kSgJ && cb >= 0 && cb < kSgK) {
+                    const int idx = ca * kSgK + cb;
+                    atomicAdd(&acc[idx], (unsigned long long)(long long)a1[j][a]);
+                    atomicAdd(&acc[kSgTile + idx], (unsigned long long)(long long)a2[j][a]);
+                }
+                a1[j][a] = a2[j][a] = 0.0;
+            }
+        }
+    };
+    for (int64_t b0 = rbeg; b0 < rend; b0 += kSpBox) {
+    if (!sg_box_hits(box_lo, box_hi, b0, j0, k0)) continue;
+    const int64_t bend = (b0 + kSpBox < rend) ? b0 + kSpBox : rend;
+    for (int64_t i = b0 + g; i < bend; i += G) {
+        double v[KR];
+        int c[KR];
+        bool same = run < kSgRun;
+#pragma unroll
+        for (int a = 0; a < KR; ++a) {
+            c[a] = a < K ? col[(int64_t)a * ld + i] : 0;
+            v[a] = a < K ? val[(int64_t)a * ld + i] : 0.0;
+            same = same && c[a] == cur[a];
+        }
+        if (!same) {
+            flush();
+            run = 0;
+#pragma unroll
+            for (int a = 0; a < KR; ++a) { cur[a] = c[a]; csr[a] = cs[c[a]]; }
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int sl = 0; sl < PS; ++sl)
+                    if (q == sl) curb[j] = c[j * PS + sl];
+        }
+        ++run;
+        const double w = w2 ? w2[i] : 1.0;
+#pragma unroll
+        for (int a = 0; a < KR; ++a) v[a] *= csr[a];         // (column scaling: an exact power of two)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double vb = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < PS; ++sl)
+                if (q == sl) vb = v[j * PS + sl];
+#pragma unroll
+            for (int a = 0; a < (j + 1) * PS; ++a) {         // a <= b = j PS + q: the slots of a row are in ascending column order
+                const double x = (a < j * PS || a - j * PS <= q) ? (w * v[a]) * vb : 0.0;
+                const double q1 = sg_rint_scaled(x, s1);
+                a1[j][a] += q1;
+                a2[j][a] += sg_rint_scaled(fma(-q1, r1, x), s2);
+            }
+        }
+    }
+    }
+    flush();
+    __syncthreads();
+    unsigned long long* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * kSgTile);
+    for (int idx = threadIdx.x; idx < 2 * kSgTile; idx += T) out[idx] = acc[idx];
+}
 // sums the workgroups' limbs of each entry, rounds once, writes G[j, k] and its mirror image (G: m x m, column-major, leading dimension ldg)
-__global__ __launch_bounds__(256) void sp_gram_reduce_kernel(const unsigned long long* __restrict__ partial, int nblk, int nkb, int m, double r1,
+__global__ __launch_bounds__(256) void sp_gram_reduce_kernel(const unsigned long long* __restrict__ partial, int nblk, int nsum, int nkb, int m, double r1,
                                                              double r2, const double* __restrict__ csinv, double* __restrict__ G, int ldg) {
     const int j0 = ((int)blockIdx.y / nkb) * kSgJ, k0 = ((int)blockIdx.y % nkb) * kSgK;
     if (k0 + kSgK - 1 < j0) return;
@@ -442,7 +558,7 @@ __global__ __launch_bounds__(256) void sp_gram_reduce_kernel(const unsigned long
     if (j > k || k >= m) return;
     const unsigned long long* p = partial + (int64_t)blockIdx.y * nblk * (2 * kSgTile) + idx;
     long long a1 = 0, a2 = 0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = 0; b < nsum; ++b) {                          // (nsum = nblk, or the folded slots of sp_gram_fold_kernel)
         a1 += (long long)p[(int64_t)b * (2 * kSgTile)];
         a2 += (long long)p[(int64_t)b * (2 * kSgTile) + kSgTile];
     }
@@ -451,6 +567,17 @@ __global__ __launch_bounds__(256) void sp_gram_reduce_kernel(const unsigned long
     const double g = (hi * r1 + (lo * r1 + (double)a2 * r2)) * csinv[j] * csinv[k];      // (undoing the column scaling: exact)
     G[(int64_t)k * ldg + j] = g;
     G[(int64_t)j * ldg + k] = g;
+}
+// many slices: slot z of a tile's partials takes the sum of the slots z, z + nfold, z + 2 nfold, ... (integers: any order gives the same
+// bits), so that the reduction above reads nfold slots per entry and this one runs on (entries x nfold) threads
+__global__ __launch_bounds__(256) void sp_gram_fold_kernel(unsigned long long* __restrict__ partial, int nblk, int nfold, int nkb) {
+    const int j0 = ((int)blockIdx.y / nkb) * kSgJ, k0 = ((int)blockIdx.y % nkb) * kSgK;
+    if (k0 + kSgK - 1 < j0) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;              // < 2 * kSgTile: both limbs
+    unsigned long long* p = partial + (int64_t)blockIdx.y * nblk * (2 * kSgTile) + idx;
+    unsigned long long a = 0ull;
+    for (int b = (int)blockIdx.z; b < nblk; b += nfold) a += p[(int64_t)b * (2 * kSgTile)];
+    p[(int64_t)blockIdx.z * (2 * kSgTile)] = a;
 }
 // max over the rows of w2_i (max_a |v'_ia|)^2, v' the column-scaled values: the bound on the terms.  (The largest weight alone will not do: a row
 // without nonzeros -- the slack row of a ball constraint -- may carry a weight 2^23 times the others, and every bit of slack in the bound is a
@@ -534,24 +661,41 @@ int sp_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* X, int x0,
         int active = 0;
         for (int t = 0; t < njb * nkb; ++t) active += ((t % nkb) * kSgK + kSgK - 1 >= (t / nkb) * kSgJ);
         const int64_t cus = ctx->num_cu > 0 ? ctx->num_cu : 64;
-        int64_t nblk = std::max<int64_t>(cus / active, 8);     // one workgroup per CU (LDS); at least eight slices of the rows
-        nblk = std::min<int64_t>(nblk, std::max<int64_t>((S->n + kSgThreads - 1) / kSgThreads, 1));
+        // one workgroup per CU (LDS); at least eight slices of the rows.  The wide-row kernels are arithmetic-bound and skip the row blocks whose
+        // columns cannot touch their tile (sg_box_hits): eight times as many, shorter slices, so that the workgroups with nothing to do make room
+        // for the others (a banded system: every slice matters to one or two tiles only)
+        const char* slices_env = getenv("LFPSQP_SPGRAM_SLICES");      // (tuning experiments and tests: slices per CU and active tile)
+        const int slices_x = slices_env ? atoi(slices_env) : 0;
+        int64_t nblk = std::max<int64_t>((slices_x > 0 ? slices_x : (S->K > 8 ? 8 : 1)) * cus / active, 8);
+        nblk = std::min<int64_t>(nblk, std::max<int64_t>((S->n + kSpBox - 1) / kSpBox, 1));
         LF_TRY(ensure_part(ctx, (size_t)njb * nkb * nblk * 2 * kSgTile + 8));
         unsigned long long* part = reinterpret_cast<unsigned long long*>(ctx->part);
         if (S->n > 0) {
-            const int64_t rows_per_wg = (S->n + nblk - 1) / nblk;
+            const int64_t rows_per_wg = round_up((S->n + nblk - 1) / nblk, kSpBox);      // whole column boxes per workgroup
             const dim3 grid((unsigned)nblk, (unsigned)(njb * nkb));
             const double* w2p = w2 ? w2->p : nullptr;
             if (S->K <= 4)
                 hipLaunchKernelGGL((sp_gram_kernel<4, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p,
-                                   S->col_scale, s1, r1, s2, nkb, rows_per_wg, part);
+                                   S->col_scale, s1, r1, s2, nkb, rows_per_wg, S->box_lo, S->box_hi, part);
             else if (S->K <= 8)                                  // 72 limb sums per lane: two waves per SIMD
                 hipLaunchKernelGGL((sp_gram_kernel<8, 512>), grid, dim3(512), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p, S->col_scale, s1, r1,
-                                   s2, nkb, rows_per_wg, part);
+                                   s2, nkb, rows_per_wg, S->box_lo, S->box_hi, part);
+            else if (S->K <= 12 && ctx->tune_spgram >= 0)
+                hipLaunchKernelGGL((sp_gram_split_kernel<12, 4, 512>), grid, dim3(512), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p,
+                                   S->col_scale, s1, r1, s2, nkb, rows_per_wg, S->box_lo, S->box_hi, part);
+            else if (S->K <= 16 && ctx->tune_spgram >= 0)
+                hipLaunchKernelGGL((sp_gram_split_kernel<16, 8, 512>), grid, dim3(512), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p,
+                                   S->col_scale, s1, r1, s2, nkb, rows_per_wg, S->box_lo, S->box_hi, part);
             else
                 hipLaunchKernelGGL((sp_gram_kernel<0, kSgThreads>), grid, dim3(kSgThreads), 0, ctx->stream, S->ell_val, S->ell_col, S->ld, S->K, S->n, w2p,
-                                   S->col_scale, s1, r1, s2, nkb, rows_per_wg, part);
-            hipLaunchKernelGGL(sp_gram_reduce_kernel, dim3(kSgTile / 256, (unsigned)(njb * nkb)), dim3(256), 0, ctx->stream, part, (int)nblk, nkb, ms, r1, r2,
+                                   S->col_scale, s1, r1, s2, nkb, rows_per_wg, S->box_lo, S->box_hi, part);
+            constexpr int kFold = 32;
+            if (nblk > 2 * kFold)
+                hipLaunchKernelGGL(sp_gram_fold_kernel, dim3(2 * kSgTile / 256, (unsigned)(njb * nkb), kFold), dim3(256), 0, ctx->stream, part, (int)nblk,
+                                   kFold, nkb);
+            // (the reduction's stride between slots stays nblk; it reads the first kFold of them after a fold)
+            hipLaunchKernelGGL(sp_gram_reduce_kernel, dim3(kSgTile / 256, (unsigned)(njb * nkb)), dim3(256), 0, ctx->stream, part, (int)nblk,
+                               (int)(nblk > 2 * kFold ? kFold : nblk), nkb, ms, r1, r2,
                                S->col_scale + S->m, ctx->small, ms);
             LF_LAUNCH_CHECK(ctx);
         }
@@ -665,6 +809,24 @@ int lfpsqp_spmat_create(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_t nnz, cons
     dev_copy((void**)&S->colptr, colptr.data(), colptr.size() * sizeof(int64_t));
     dev_copy((void**)&S->chunk_beg, cb2.data(), cb2.size() * sizeof(int64_t));
     dev_copy((void**)&S->col_chunk, cchunk.data(), cchunk.size() * sizeof(int32_t));
+    {   // column bounding boxes of row blocks, and how often a row repeats the column set of the row 128 places before it
+        const int64_t nbox = (std::max<int64_t>(n, 1) + kSpBox - 1) / kSpBox;
+        std::vector<int32_t> lo((size_t)nbox, INT32_MAX), hi((size_t)nbox, -1);
+        int64_t same = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const size_t b = (size_t)(i / kSpBox);
+            bool eq = i >= 128 && cnt[(size_t)i] == cnt[(size_t)(i - 128)];
+            for (int a = 0; a < cnt[(size_t)i]; ++a) {
+                const int32_t c = hc[(size_t)a * S->ld + i];
+                lo[b] = std::min(lo[b], c); hi[b] = std::max(hi[b], c);
+                eq = eq && c == hc[(size_t)a * S->ld + i - 128];
+            }
+            same += eq ? 1 : 0;
+        }
+        S->run_frac = n > 128 ? (double)same / (double)(n - 128) : 0.0;
+        dev_copy((void**)&S->box_lo, lo.data(), lo.size() * sizeof(int32_t));
+        dev_copy((void**)&S->box_hi, hi.data(), hi.size() * sizeof(int32_t));
+    }
     // power-of-two column scales for the exact Gram accumulation: entrywise accuracy relative to the columns' own magnitudes, whatever their scaling
     std::vector<double> cscale(2 * (size_t)std::max<int64_t>(m, 1), 1.0);
     {
@@ -697,7 +859,7 @@ int lfpsqp_spmat_free(lfpsqp_ctx* ctx, lfpsqp_spmat* S) {
     for (void* p : {(void*)S->ell_val, (void*)S->csc_val, (void*)S->col_scale})
         if (p) (void)hipFree(p);
     if (S->owns_structure)
-        for (void* p : {(void*)S->ell_col, (void*)S->csc_row, (void*)S->colptr, (void*)S->chunk_beg, (void*)S->col_chunk})
+        for (void* p : {(void*)S->ell_col, (void*)S->csc_row, (void*)S->colptr, (void*)S->chunk_beg, (void*)S->col_chunk, (void*)S->box_lo, (void*)S->box_hi})
             if (p) (void)hipFree(p);
     delete S;
     return 0;

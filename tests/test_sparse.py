@@ -179,7 +179,8 @@ def _exact_gram(A, w=None):
     return G
 
 
-@pytest.mark.parametrize("case", ["plain", "weighted", "ball_weighted", "two_tiles", "wide_range", "k6", "k11", "scattered", "slack_weight"])
+@pytest.mark.parametrize("case", ["plain", "weighted", "ball_weighted", "two_tiles", "wide_range", "k6", "k11", "scattered", "slack_weight",
+                                  "k12", "k16", "k16_weighted", "k13_scattered", "k20", "k12_boxes", "k5_boxes"])
 def test_gram_from_the_nonzeros_is_exact_and_order_independent(dev_ctx, case):
     """lfpsqp_spmat_gram: the scattered accumulation in two fixed-point limbs.  The device forms each term w_i v_a v_b in floating point (two
     roundings) and then sums EXACTLY: against exact rational arithmetic on the same rounded terms the result is the correctly rounded sum up
@@ -188,8 +189,12 @@ def test_gram_from_the_nonzeros_is_exact_and_order_independent(dev_ctx, case):
     from fractions import Fraction
     ctx = dev_ctx
     n, m, k = (900, 150, 3) if case == "two_tiles" else (1300, 14, {"k6": 6, "k11": 11}.get(case, 3))
+    if case in ("k12", "k16", "k16_weighted", "k13_scattered", "k20"):       # 9..16 nonzeros: a group of lanes shares a row (sp_gram_split_kernel); 20: per term
+        n, m, k = 1100, 70, {"k12": 12, "k13_scattered": 13, "k20": 20}.get(case, 16)
+    if case in ("k12_boxes", "k5_boxes"):            # several column boxes of 4096 rows, three tiles of G: most (box, tile) pairs are skipped
+        n, m, k = 9000, 150, 12 if case == "k12_boxes" else 5
     rows, cols, vals = banded(n, m, k, seed=4)
-    if case == "scattered":                          # no two consecutive rows with the same columns, rows of 1..3 nonzeros
+    if case in ("scattered", "k13_scattered"):                          # no two consecutive rows with the same columns, rows of 1..3 nonzeros
         rng0 = np.random.default_rng(11)
         cols = np.stack([rng0.permutation(m)[:k] for _ in range(n)]).ravel()
         keep = rng0.random(cols.size) < 0.8
@@ -197,7 +202,7 @@ def test_gram_from_the_nonzeros_is_exact_and_order_independent(dev_ctx, case):
     if case == "wide_range":
         vals = vals * np.logspace(0, -9, m)[cols] * np.where(np.arange(vals.size) % 7 == 0, 1e3, 1.0)
     rng = np.random.default_rng(3)
-    w = rng.random(n) + 0.2 if case in ("weighted", "ball_weighted", "slack_weight") else None
+    w = rng.random(n) + 0.2 if case in ("weighted", "ball_weighted", "slack_weight", "k16_weighted") else None
     if case == "slack_weight":                       # a row without nonzeros (the slack row of a ball constraint) with a weight 2^40 times the others:
         keep = rows != n - 1                         # the bound on the terms is measured over the rows that have nonzeros, so nothing is lost
         rows, cols, vals = rows[keep], cols[keep], vals[keep]
@@ -252,17 +257,38 @@ def test_gram_from_the_nonzeros_is_exact_and_order_independent(dev_ctx, case):
         L.SparseMatrix(ctx, 200, 40, r3, c3, v3).gram()
 
 
-@pytest.mark.parametrize("case", ["plain", "weighted", "ball_column", "no_dense_twin", "ill_conditioned", "wide_k", "two_panels", "very_wide_k"])
+def test_gram_from_the_nonzeros_with_many_row_slices(dev_ctx, monkeypatch):
+    """More than 64 slices of the rows per tile of G: their integer partial sums are folded before the final reduction
+    (sp_gram_fold_kernel) -- same matrix as with few slices, bit for bit, and equal to numpy's to rounding."""
+    ctx = dev_ctx
+    n, m, k = 4096 * 70 + 17, 40, 9
+    rows, cols, vals = banded(n, m, k, seed=6)
+    S = L.SparseMatrix(ctx, n, m, rows, cols, vals)
+    G1 = S.gram()
+    monkeypatch.setenv("LFPSQP_SPGRAM_SLICES", "64")
+    G2 = S.gram()
+    monkeypatch.delenv("LFPSQP_SPGRAM_SLICES")
+    np.testing.assert_array_equal(G1, G2)
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, m)).tocsr()
+    Gn = (A.T @ A).toarray()
+    np.testing.assert_allclose(G1, Gn, rtol=0, atol=1e-12 * np.abs(Gn).max())
+
+
+@pytest.mark.parametrize("case", ["plain", "weighted", "ball_column", "no_dense_twin", "ill_conditioned", "wide_k", "two_panels", "very_wide_k",
+                                  "wide_k_scattered"])
 def test_factorize_from_the_nonzeros_is_the_dense_factorisation(dev_ctx, case):
     """lfpsqp_factorize_sp (Gram matrix from the nonzeros, exactly accumulated; basis-forming products Z = [S | extra columns] * W from the
     nonzeros) against lfpsqp_factorize on the dense matrix: the same factorisation up to the rounding of the Gram matrix and of the product;
     Z = A * W and Z' diag(w2) Z = I checked directly.  With the Gram matrix taken from a dense copy (context setting LFPSQP_SPGRAM=-1, and
-    always when a row has more than 8 nonzeros: wide_k, very_wide_k) Sigma / Vt / W are those of the dense factorisation bit for bit."""
+    always when a row has more than 16 nonzeros: very_wide_k; wide_k = 9 nonzeros per row goes through the lane-group kernel) Sigma / Vt / W are
+    those of the dense factorisation bit for bit; likewise with 9 .. 16 nonzeros per row in scattered columns (wide_k_scattered)."""
     import os
     ctx = dev_ctx
     n, m, k = (1000 if _is_emu(ctx) else 26000, 200, 4) if case == "two_panels" else (3100, 12 if case != "very_wide_k" else 40,
-                                                                                     {"wide_k": 9, "very_wide_k": 34}.get(case, 3))
+                                                                                     {"wide_k": 9, "very_wide_k": 34, "wide_k_scattered": 9}.get(case, 3))
     rows, cols, vals = banded(n, m, k, seed=8)
+    if case == "wide_k_scattered":                   # 9 nonzeros per row in columns that change from row to row: the dense twin's Gram matrix
+        cols = np.stack([np.random.default_rng(100 + i).permutation(m)[:k] for i in range(n)]).ravel()
     if case == "ill_conditioned":                    # refinement rounds: several basis-forming products from the nonzeros
         vals = vals * np.logspace(0, -7, m)[cols]
     A = sp.coo_matrix((vals, (rows, cols)), shape=(n, m)).toarray()
@@ -292,7 +318,7 @@ def test_factorize_from_the_nonzeros_is_the_dense_factorisation(dev_ctx, case):
     for label, (S0, Vt0, W0, r0, Zh0, S1, Vt1, W1, r1, Zh1) in res.items():
         assert r1 == r0 == M
         fast = S0[0] ** 2 <= 10.0 * S0[-1] ** 2           # lfpsqp_factorize's one-Gram-one-product path
-        if fast and (label == "dense_copy" or k > 8):     # same Gram matrix, same replicated small step: bit for bit
+        if fast and (label == "dense_copy" or k > 16 or case == "wide_k_scattered"):    # same Gram matrix, same replicated small step: bit for bit
             np.testing.assert_array_equal(S1, S0)
             np.testing.assert_array_equal(Vt1, Vt0)
             np.testing.assert_array_equal(W1, W0)
