@@ -22,8 +22,12 @@ import math
 from dataclasses import dataclass, field
 from typing import Callable, Optional
 
+import os
+
 import numpy as np
 from scipy.linalg import lapack as _lapack
+
+_POISON = os.environ.get("ORACLE_POISON_UNINIT", "") not in ("", "0")
 
 # --------------------------------------------------------------------------
 # enums / params / termination info               (src/LFPSQP.jl:27-81)
@@ -102,14 +106,14 @@ class LinearMap:
     def __init__(self, f_, n):
         self.f_ = f_
         self.n = n
-        self._tmp = np.empty(n)
+        self._tmp = _uninit(n)
 
     def mul_(self, dest, v, a=None, b=None):
         if a is None:
             self.f_(dest, v)
         else:
             self.f_(self._tmp, v)
-            dest[:] = a * self._tmp + b * dest
+            dest[:] = a * self._tmp + _scaled(b, dest)
         return dest
 
     def adjoint(self):
@@ -128,6 +132,22 @@ def adj(Op):
     return Op.adjoint()
 
 
+def _uninit(shape, order='C'):
+    """Work arrays the reference allocates uninitialised.  ORACLE_POISON_UNINIT=1 fills them with NaN, so that a read before the first
+    write shows up in any test (a long-lived test process recycles memory: what np.empty returns there is garbage, not zeros)."""
+    a = np.empty(shape, order=order)
+    if _POISON:
+        a.fill(np.nan)
+    return a
+
+
+def _scaled(beta, y):
+    """beta * y as BLAS gemv and Julia's mul!(y, A, x, alpha, beta) understand it: with beta == 0 the destination is NOT read (its contents
+    may be uninitialised memory -- the reference's work arrays are `similar(...)` / `Vector{Float64}(undef, n)`, here np.empty -- and
+    0 * NaN would turn garbage into NaN)."""
+    return 0.0 if beta == 0 else beta * y
+
+
 def mul_(dest, Op, v, a=None, b=None):
     """LinearAlgebra.mul!(dest, Op, v[, a, b])."""
     if isinstance(Op, np.ndarray):
@@ -135,12 +155,12 @@ def mul_(dest, Op, v, a=None, b=None):
             if a is None:
                 dest[:] = 0.0
             else:
-                dest[:] = b * dest
+                dest[:] = _scaled(b, dest)
             return dest
         if a is None:
             dest[:] = Op @ v
         else:
-            dest[:] = a * (Op @ v) + b * dest
+            dest[:] = a * (Op @ v) + _scaled(b, dest)
         return dest
     return Op.mul_(dest, v, a, b)
 
@@ -166,9 +186,9 @@ def kgemv_(tA, rank, alpha, A, x, beta, y):
     """src/la_helper.jl:36-44: dgemv on the leading ``rank`` columns of A."""
     Ar = A[:, :rank]
     if tA == 'N':
-        y[:] = alpha * (Ar @ x[:rank]) + beta * y
+        y[:] = alpha * (Ar @ x[:rank]) + _scaled(beta, y)
     else:
-        y[:rank] = alpha * (Ar.T @ x) + beta * y[:rank]
+        y[:rank] = alpha * (Ar.T @ x) + _scaled(beta, y[:rank])
     return y
 
 
@@ -179,8 +199,8 @@ def kgemv_(tA, rank, alpha, A, x, beta, y):
 
 class ProjCGWork:  # src/projcg.jl:1-11
     def __init__(self, n, m):
-        self.r, self.g, self.d, self.rp, self.gp, self.Ad = (np.empty(n) for _ in range(6))
-        self.Utr = np.empty(m)
+        self.r, self.g, self.d, self.rp, self.gp, self.Ad = (_uninit(n) for _ in range(6))
+        self.Utr = _uninit(m)
 
 
 def projcg_(x, lam, A, U, b, c, tol=1e-6, maxit=None, work=None):
@@ -315,9 +335,9 @@ class InequalityDecompAdjoint:  # :21-23, :254-271
             # generic 5-arg fallback (the reference reaches this only through
             # mul!(z, J', tmp, 1.0, mu) in pcg!, where J' is the non-adjoint
             # InequalityDecomp; kept for completeness)
-            tmp = np.empty(n + m)
+            tmp = _uninit(n + m)
             self.mul_(tmp, v)
-            dest[:n + m] = a * tmp + b * dest[:n + m]
+            dest[:n + m] = a * tmp + _scaled(b, dest[:n + m])
         return dest
 
     def adjoint(self):
@@ -465,10 +485,10 @@ def y_retract_(xnewaug, xaug, idata):  # src/retractions.jl:451-500
 
 class NRWork:  # src/retractions.jl:1-8
     def __init__(self, m):
-        self.D = np.empty((m, m), order='F')
-        self.tmp_m = np.empty(m)
-        self.tmp_m2 = np.empty(m)
-        self.dc = np.empty(m)
+        self.D = _uninit((m, m), order='F')
+        self.tmp_m = _uninit(m)
+        self.tmp_m2 = _uninit(m)
+        self.dc = _uninit(m)
 
 
 @dataclass
@@ -485,10 +505,14 @@ class NR:  # :10-19
 
 class ProjPenaltyWork:  # :21-33
     def __init__(self, m, n, m_ineq, n_ineq):
-        self.J = np.empty((m, n), order='F')
-        self.tmp_m = np.empty(m_ineq)
-        self.r, self.p, self.z, self.dx, self.g = (np.empty(n_ineq) for _ in range(5))
-        self.cvalaug = np.empty(m_ineq)
+        self.J = _uninit((m, n), order='F')
+        self.tmp_m = _uninit(m_ineq)
+        self.r, self.p, self.z, self.dx, self.g = (_uninit(n_ineq) for _ in range(5))
+        # The reference allocates cvalaug undef as well (src/retractions.jl:31-32) and READS its last m entries before their first write:
+        # norm(cvalaug, Inf) at :352 covers the whole vector, the tail is filled at :356 -- on the first call that is uninitialised memory
+        # (later calls see the previous call's values).  Zeros here, as the device's zero-filled allocation has it: the one place where
+        # the reference's behaviour is undefined and the restatement has to choose.
+        self.cvalaug = np.zeros(m_ineq)
 
 
 @dataclass
@@ -682,12 +706,12 @@ def retract_(cval, xnew, c_, xtilde, x, method):
 
 class ArmijoWork:  # :1-5
     def __init__(self, n):
-        self.xtilde = np.empty(n)
+        self.xtilde = _uninit(n)
 
 
 class ExactLinesearchWork:  # :7-14
     def __init__(self, n):
-        self.tmp_n1, self.tmp_n2, self.tmp_n3, self.tmp_n4 = (np.empty(n) for _ in range(4))
+        self.tmp_n1, self.tmp_n2, self.tmp_n3, self.tmp_n4 = (_uninit(n) for _ in range(4))
 
 
 def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
@@ -881,43 +905,43 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m, param, trace
         if np.any(xl > xu):
             raise ValueError("Infeasible: lower bounds cannot be greater than upper bounds")
         f_aug = lambda xx: f(xx[:n])
-        PJct = np.empty((2 * n, m), order='F')
+        PJct = _uninit((2 * n, m), order='F')
         lamy_kkt = np.zeros(n)
         ineqdata = InequalityData(xl, xu)
 
     n_ineq = 2 * n if ineq else n
     m_ineq = m + n if ineq else m
 
-    x = np.empty(n_ineq)
+    x = _uninit(n_ineq)
     x[:n] = x0
     if ineq:
         generate_initial_y_(x, ineqdata)
     obj_values = []
 
-    xnew = np.empty(n_ineq)
-    Jc = np.empty((m, n), order='F')
-    Jct = np.empty((n, m), order='F')
+    xnew = _uninit(n_ineq)
+    Jc = _uninit((m, n), order='F')
+    Jct = _uninit((n, m), order='F')
     g = np.zeros(n_ineq)
-    d = np.empty(n_ineq)
-    tmp_n = np.empty(n_ineq)
-    tmp_m = np.empty(m_ineq)
+    d = _uninit(n_ineq)
+    tmp_n = _uninit(n_ineq)
+    tmp_m = _uninit(m_ineq)
     cval = np.zeros(m)
     lam_kkt = np.zeros(m)
     term_cond = TerminationCondition.f_tol
 
-    U = np.empty((n_ineq, m), order='F')
-    Sig = np.empty(m)
-    Vt = np.empty((m, m), order='F')
+    U = _uninit((n_ineq, m), order='F')
+    Sig = _uninit(m)
+    Vt = _uninit((m, m), order='F')
 
-    newton_d = np.empty(n_ineq)
-    newton_dlam = np.empty(m_ineq)
+    newton_d = _uninit(n_ineq)
+    newton_dlam = _uninit(m_ineq)
     newton_b2 = np.zeros(m_ineq)
     projcgwork = ProjCGWork(n_ineq, m_ineq)
     prev_grad_norm = 0.0
     grad_norm = math.inf
 
     if ineq:
-        ineqdecomp = InequalityDecomp(U, Sig, Vt, np.empty(n), np.empty(n), np.empty(n), Jct, m)
+        ineqdecomp = InequalityDecomp(U, Sig, Vt, _uninit(n), _uninit(n), _uninit(n), Jct, m)
     else:
         ineqdecomp = InequalityDecomp(U, Sig, Vt, np.zeros(0), np.zeros(0), np.zeros(0), Jct, m)
     ineqproject = InequalityDecompProject(ineqdecomp)
@@ -1132,7 +1156,7 @@ def _optimize_slack(f, c_, d_, dl, du, x0, xl, xu, m, p, param, dv, trace):
         xl = -np.inf * np.ones(n)
     if xu is None:
         xu = np.inf * np.ones(n)
-    x0_aux = np.empty(n + p)
+    x0_aux = _uninit(n + p)
     x0_aux[:n] = x0
     d_(x0_aux[n:], x0)
     xl_aux = np.concatenate([xl, dl])

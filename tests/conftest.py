@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "liblfpsqp_emu.so")
 
+# The oracle allocates its work arrays uninitialised where the reference does (`Array{Float64}(undef, ...)`).  In a long test process
+# np.empty hands back recycled memory, so a read before the first write would make a test depend on what ran before it (one such read --
+# beta * y with beta = 0 on an uninitialised y -- once sent the oracle into an endless Armijo loop in the middle of a suite run).  Under
+# the tests those arrays are NaN-filled instead, which turns any such read into a deterministic failure (oracle/lfpsqp_ref.py::_uninit).
+os.environ.setdefault("ORACLE_POISON_UNINIT", "1")
+
 
 def _usable_cpus() -> int:
     """CPUs this process may really use: affinity mask capped by the cgroup quota (a GPU box can show 256 hardware threads
