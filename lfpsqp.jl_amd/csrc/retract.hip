@@ -434,7 +434,11 @@ struct NRStepBatchRow {
         if ((w.active >> tr) & 1u) {                   // a finished trial keeps its iterate and contributes nothing
             NRStepE eb = e;
             eb.xnew = my_xnew(tr);
+#ifdef LFPSQP_ABLATE_NRB_STORE                               /* timing experiment: the batched step without its stores (results are wrong) */
+            mine = eb.apply1<ST>(i, o, acc_mine, valid, false, w.sh, ball);
+#else
             mine = eb.apply1<ST>(i, o, acc_mine, valid, h < NB, w.sh, ball);     // (h < NB: one storing lane per row and trial)
+#endif
         }
         const int lane = (int)(threadIdx.x & 63u);
 #pragma unroll
