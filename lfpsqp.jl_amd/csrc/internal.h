@@ -306,7 +306,7 @@ inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
 // out[k*ncT + j] = sum_rows M[row, j] * v_k[row] (k < NV, j < ncT), out[NV*ncT + r] = reduction r, with v produced by EP
 // from M[row, :ncN] . t -- all-reduced over ranks; one pass over M.  Persistent grid: as many workgroups as the device
 // keeps resident for this instantiation (occupancy query, cached), capped by the number of 64-row rounds.
-// Staged stores (onepass_kernel STG) of functor EP at CPL column groups per wave, for functors that offer a staged form (EP::kStaged):
+// Staged stores (onepass_kernel STG) of functor EP at CPL column groups per wave, for functors that offer a staged form (EP::kStageStreams):
 // rounds per burst and the waves per SIMD the instantiation is compiled for.  The CU's 160 KB of LDS hold 320 rounds of the narrow form
 // (512 bytes each) however they are split: three workgroups of 102 rounds (3 waves per SIMD: tiles of up to 24 column groups) or two
 // of 153 (2 waves per SIMD, the register budget the larger tiles need with their running sums in registers).  A round of the wide
@@ -321,16 +321,14 @@ inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
 #define LFPSQP_OP_STAGE_WIDE 1
 #endif
 struct StageCfg { int rounds, waves; };
-template <class EP, class = void>
-struct onepass_staged : std::false_type {};
-template <class EP>
-struct onepass_staged<EP, std::enable_if_t<EP::kStaged>> : std::true_type {};
 template <class EP>
 constexpr StageCfg onepass_stage(int cpl, bool wide, int na) {
     // (tiles of more than 33 column groups per wave run at one wave per SIMD with part of the tile in accumulation registers: no staging)
-    if (!LFPSQP_OP_STAGE || !onepass_staged<EP>::value || na != 1 || cpl < LFPSQP_OP_STAGE_MINCPL || cpl > 33) return StageCfg{0, 1};
-    if (wide) return !LFPSQP_OP_STAGE_WIDE ? StageCfg{0, 1} : (cpl <= 24 ? StageCfg{160, 3} : StageCfg{256, 2});
-    return cpl <= 24 ? StageCfg{102, 3} : StageCfg{153, 2};
+    constexpr int ns = stage_streams<EP>::value;      // two staged vectors (stacked forms): half the rounds per burst
+    if (!LFPSQP_OP_STAGE || ns == 0 || na != 1 || cpl < LFPSQP_OP_STAGE_MINCPL || cpl > 33) return StageCfg{0, 1};
+    if (wide) return !LFPSQP_OP_STAGE_WIDE ? StageCfg{0, 1} : (cpl <= 24 ? StageCfg{160 / ns, 3} : StageCfg{256 / ns, 2});
+    // (the stacked forms at 17..24 column groups need a few registers more than three waves per SIMD leave them)
+    return (cpl <= 16 || (cpl <= 24 && ns == 1)) ? StageCfg{102 / ns, 3} : StageCfg{153 / ns, 2};
 }
 template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA, bool LACC, int STG = 0, int SW = 1>
 inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {

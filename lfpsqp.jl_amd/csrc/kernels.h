@@ -432,6 +432,12 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 #endif
 }
 
+// number of staged output vectors a row functor offers (EP::kStageStreams; absent = 0)
+template <class EP, class = void>
+struct stage_streams : std::integral_constant<int, 0> {};
+template <class EP>
+struct stage_streams<EP, std::void_t<decltype(EP::kStageStreams)>> : std::integral_constant<int, EP::kStageStreams> {};
+
 // STG > 0 (functors with a staged output, EP::apply_staged / EP::stage_out): the row update's output vector is not stored tile by
 // tile; up to STG rounds of it (STG * 512 bytes) wait in LDS and the whole workgroup stores them in one burst, in equal bursts
 // over its span.  Why: on MI355X a thin store stream inside the matrix read stream costs far more than its bytes (an 80 MB
@@ -458,7 +464,8 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
     // that holds the running sums of the second product during the tile loop (LACC) and the per-wave column sums after it
     constexpr int kRedD = (WIDE ? 1 : kWaves) * NV * NC;
     constexpr int kAccD = LACC ? NV * NQ * kThreads : 0;
-    constexpr int kStgD = STG * kStep;
+    constexpr int NS = stage_streams<EP>::value > 0 ? stage_streams<EP>::value : 1;   // staged output vectors (the stacked forms: two)
+    constexpr int kStgD = NS * STG * kStep;
     static_assert(STG == 0 || NA == 1, "staged stores: one first product");
     // the staging area shares `buf` with the final column sums; next to LDS running sums (LACC) it is an array of its own
     constexpr int kBufD0 = kRedD > kAccD ? kRedD : (kAccD > 0 ? kAccD : 1);
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
         if (MORE && kRowAhead && !kOpRowLate) in_next = ep.fetch(ro + kStep * 8);
         double v[NV];
         const bool lead = !WIDE || wave == 0;
-        if constexpr (STG > 0) ep.apply_staged(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum, stg + sk * kStep + lrow);
+        if constexpr (STG > 0) ep.apply_staged(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum, stg + sk * kStep + lrow, STG * kStep);
         else ep.apply(row, ro, acc, row < n, h == 0 && lead, lead, uni, in, v, rsum);
         // second product: columns 4j .. 4j+3 of this lane's group, summed over the row bits RR by two transposing swaps;
         // afterwards the lane holds the 4-row sum of column register 4j + 2*bit4 + bit5
@@ -595,9 +602,12 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
             if (++sk == blen || !MORE) {    // uniform: the workgroup stores the staged rounds (the next tile's loads are in flight meanwhile)
                 __syncthreads();
                 const int64_t rb = row0 + (int64_t)(k + 1 - sk) * kStep;
-                double* outv = ep.stage_out();
-                for (int e = threadIdx.x; e < sk * kStep; e += kThreads)
-                    if (rb + e < n) outv[rb + e] = stg[e];
+#pragma unroll
+                for (int sv = 0; sv < NS; ++sv) {
+                    double* outv = ep.stage_out(sv);
+                    for (int e = threadIdx.x; e < sk * kStep; e += kThreads)
+                        if (rb + e < n) outv[rb + e] = stg[sv * (STG * kStep) + e];
+                }
                 __syncthreads();            // before the next round overwrites the area
                 sk = 0;
             }

@@ -217,15 +217,15 @@ struct PcgInnerE {
         }
         return w;
     }
-    // staged form (onepass_kernel STG): z of the plain iteration waits in LDS and is stored in bursts
-    static constexpr bool kStaged = !ST;
-    __device__ __forceinline__ double* stage_out() const { return z; }
+    // staged form (onepass_kernel STG): z (stacked: its two halves) waits in LDS and is stored in bursts
+    static constexpr int kStageStreams = ST ? 2 : 1;
+    __device__ __forceinline__ double* stage_out(int sv) const { return sv == 0 ? z : z + k.hs; }
     __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
                                           const Row& w, double (&v)[2], double (&red)[1]) const {
-        apply_staged(row, o, accv, valid, owner, lead, u, w, v, red, nullptr);
+        apply_staged(row, o, accv, valid, owner, lead, u, w, v, red, nullptr, 0);
     }
     __device__ __forceinline__ void apply_staged(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool, const Uni& u,
-                                                 const Row& w, double (&v)[2], double (&red)[1], double* slot) const {
+                                                 const Row& w, double (&v)[2], double (&red)[1], double* slot, int sstride) const {
         const double acc = accv[0];
         const bool st = valid && owner;
         if (!ST) {
@@ -245,7 +245,8 @@ struct PcgInnerE {
             const double zx = fma(mu, pnx, fma(w.sx, acc, w.Dx * ww));
             const double zy = fma(mu, pny, fma(w.sy, acc, w.Dy * ww));
             if (st) {
-                put(z, o, zx); put(z + k.hs, o, zy);
+                if (slot) { slot[0] = zx; slot[sstride] = zy; }
+                else { put(z, o, zx); put(z + k.hs, o, zy); }
                 red[0] += pnx * zx + pny * zy;
             }
             v[0] = valid ? (w.sx * zx + w.sy * zy) : 0.0;                            // Z-block of J z

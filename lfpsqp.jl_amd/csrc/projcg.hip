@@ -290,14 +290,14 @@ struct PcgFuseE {
     // of group 0 (kSplitRed: 2 running sums per lane instead of 5).
     // staged form (onepass_kernel STG): the projected residual of the plain iteration goes to the workgroup's LDS slot of the row
     // instead of memory; the kernel stores whole bursts of them through stage_out()
-    static constexpr bool kStaged = !ST && !INIT;
-    __device__ __forceinline__ double* stage_out() const { return gout; }
+    static constexpr int kStageStreams = INIT ? 0 : (ST ? 2 : 1);          // (stacked: the x and the y half of the residual)
+    __device__ __forceinline__ double* stage_out(int sv) const { return sv == 0 ? gout : gout + k.hs; }
     __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
                                           const Row& w, double (&v)[2], double (&red)[2]) const {
-        apply_staged(row, o, accv, valid, owner, lead, u, w, v, red, nullptr);
+        apply_staged(row, o, accv, valid, owner, lead, u, w, v, red, nullptr, 0);
     }
     __device__ __forceinline__ void apply_staged(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
-                                                 const Row& w, double (&v)[2], double (&red)[2], double* slot) const {
+                                                 const Row& w, double (&v)[2], double (&red)[2], double* slot, int sstride) const {
         const double acc = accv[0];
         const bool st = valid && owner, cnt = valid && lead;
         const int h = (int)((threadIdx.x >> 2) & 3u);
@@ -327,7 +327,8 @@ struct PcgFuseE {
             const double gy = ry - fma(w.sy, acc, w.Dy * ww);
             const double agx = w.ax * gx, agy = w.ay * gy;
             if (st) {
-                put(gout, o, gx); put(gout + k.hs, o, gy);
+                if (slot) { slot[0] = gx; slot[sstride] = gy; }
+                else { put(gout, o, gx); put(gout + k.hs, o, gy); }
                 if (INIT) { put(d, o, -gx); put(d + k.hs, o, -gy); }
             }
             const double fx = (h == 0) ? rx : ((h == 1) ? gx : ((h == 2) ? agx : adx));

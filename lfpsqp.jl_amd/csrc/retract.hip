@@ -166,7 +166,7 @@ struct NRStepE {
     }
     template <bool ST>
     __device__ __forceinline__ double apply1(int64_t i, uint32_t o, double acc, bool valid, bool owner, const Row& w, double& red,
-                                             double* slot = nullptr) const {
+                                             double* slot = nullptr, int sstride = 0) const {
         double xn = w.xn;
         if (!ST) {
             xn += acc;
@@ -179,7 +179,10 @@ struct NRStepE {
             xn += w.ax * acc;
             yn += w.ay * acc;
             if (valid) y_retract_one_nr(xn, yn, w.xo, w.yo, w.q, w.r, w.s, w.t);
-            if (valid && owner) { put(xnew, o, xn); put(xnew + hs, o, yn); }
+            if (valid && owner) {
+                if (slot) { slot[0] = xn; slot[sstride] = yn; }
+                else { put(xnew, o, xn); put(xnew + hs, o, yn); }
+            }
         }
         if (valid && owner) red += ball(i, xn);
         return valid ? xn : 0.0;
@@ -203,12 +206,12 @@ struct NRStepRow {
                                           const Row& w, double (&v)[1], double (&red)[1]) const {
         v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0]);
     }
-    // staged form: the new point of the plain (unstacked) step waits in LDS and is stored in bursts
-    static constexpr bool kStaged = !ST;
-    __device__ __forceinline__ double* stage_out() const { return e.xnew; }
+    // staged form: the new point (stacked: its x and y halves) waits in LDS and is stored in bursts
+    static constexpr int kStageStreams = ST ? 2 : 1;
+    __device__ __forceinline__ double* stage_out(int sv) const { return sv == 0 ? e.xnew : e.xnew + e.hs; }
     __device__ __forceinline__ void apply_staged(int64_t i, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool, const Uni&,
-                                                 const Row& w, double (&v)[1], double (&red)[1], double* slot) const {
-        v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0], slot);
+                                                 const Row& w, double (&v)[1], double (&red)[1], double* slot, int sstride) const {
+        v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0], slot, sstride);
     }
 };
 

@@ -105,3 +105,42 @@ def test_newton_step_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeyp
         assert (flag, it) == res[0][:2]
         np.testing.assert_array_equal(x, res[0][2])
         np.testing.assert_array_equal(cv, res[0][3])
+
+
+@pytest.mark.parametrize("m", [12, 60, 128])
+def test_stacked_projcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m):
+    """The stacked (bound-projected) forms stage TWO vectors, the x and the y half of the residual, in bursts half as long."""
+    from lfpsqp_jl_amd.inequality import (InequalityData, InequalityDecomp, InequalityDecompProject, StackedVector, generate_initial_y_,
+                                           inequality_gradient_)
+    emu = _is_emu(dev_ctx)
+    n = 3001 if emu else 200_001
+    i = np.arange(n)
+    xl = np.where((i % 4 == 1) | (i % 4 == 3), -1.0, -np.inf)
+    xu = np.where((i % 4 == 2) | (i % 4 == 3), 1.0, np.inf)
+    xh = 0.6 * synth.hash_vector(2, n)
+    a = 4.0 * synth.hash_vector(3, 2 * n) + 5.0
+    bh = synth.hash_vector(4, 2 * n)
+
+    def run(ctx):
+        idata = InequalityData(ctx, xl, xu)
+        xa = StackedVector(ctx, n)
+        xa.upload(xh, 0)
+        generate_initial_y_(xa, idata)
+        Jct = ctx.matrix(n, m).hash_fill(1, 0, n, 1.0)
+        dec = InequalityDecomp(ctx, n, m, Jct)
+        inequality_gradient_(dec, xa, idata)
+        S, Vt, rank = L.ksvd_(Jct, dec.Z, w2=dec.sx)
+        assert rank == m
+        dec.rank = rank
+        Q = InequalityDecompProject(dec)
+        A = L.DiagOperator(0.0, StackedVector(ctx, n).upload2(a))
+        b = StackedVector(ctx, n).upload2(bh)
+        x = StackedVector(ctx, n)
+        it, nr = L.projcg_(x, None, A, Q, b, None, tol=1e-300, maxit=7, work=L.ProjCGWork(ctx, 0, m, stacked_N=n), want_lambda=False)
+        return it, nr, x.download2()
+
+    res = _with_caps(dev_ctx, monkeypatch, run)
+    assert res[0][0] == 7 and np.isfinite(res[0][1]) and np.linalg.norm(res[0][2]) > 0
+    for it, nr, x in res[1:]:
+        assert (it, nr) == res[0][:2]
+        np.testing.assert_array_equal(x, res[0][2])
