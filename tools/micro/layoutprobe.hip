@@ -170,6 +170,84 @@ __global__ __launch_bounds__(320) void writer_kernel(const double* __restrict__ 
     if (tot == 123.456) part[blockIdx.x] = tot;
 }
 
+// The four waves of a workgroup all load the SAME 16-row tile (each would then do the row update and the second product of a different trial
+// point of a batched Newton step): does the matrix still come from memory once?  SYNC: a barrier every 8 tiles keeps the waves together.
+template <bool SYNC>
+__global__ __launch_bounds__(256) void redundant_kernel(const double* __restrict__ M, int64_t ld, int64_t rounds16, const double* __restrict__ g_in,
+                                                        const double* __restrict__ d, const double* __restrict__ a, double* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = (lane & 3) | ((lane >> 4) << 2), h = (lane >> 2) & 3;
+    const int64_t q = rounds16 / gridDim.x, rem = rounds16 % gridDim.x;
+    const int64_t t0 = blockIdx.x * q + (blockIdx.x < rem ? blockIdx.x : rem);
+    const int cnt = (int)(q + (blockIdx.x < rem ? 1 : 0));
+    double acc2[4] = {0.0, 0.0, 0.0, 0.0};
+    double s_red = 0.0;
+    for (int k = 0; k < cnt; ++k) {
+        const int64_t row0 = (t0 + k) * 16;
+        double av[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) av[c] = __builtin_nontemporal_load(M + row0 + r + (int64_t)(4 * c + h) * ld);
+        const int64_t row = row0 + r;
+        const double gg = g_in[row], dd = d[row], aa = a[row];
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) s = fma(av[c], 1e-3 * (c + 1 + wave), s);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        const double gp = fma(1e-9, aa * dd, gg) - 1e-12 * s;
+        s_red += gp * gp;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc2[c & 3] = fma(av[c], gp, acc2[c & 3]);
+        if (SYNC && (k & 7) == 7) __syncthreads();
+    }
+    const double tot = (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]) + s_red;
+    if (tot == 123.456) part[blockIdx.x * 4 + wave] = tot;
+}
+
+// ... or through LDS: each wave loads a QUARTER of the 16-row tile (8 of the 32 column registers), the four quarters meet in LDS (two
+// buffers, one barrier per tile), and every wave reads the whole tile back into registers for its own trial point.
+__global__ __launch_bounds__(256) void shared_tile_kernel(const double* __restrict__ M, int64_t ld, int64_t rounds16, const double* __restrict__ g_in,
+                                                          const double* __restrict__ d, const double* __restrict__ a, double* __restrict__ part) {
+    __shared__ double tile[2][CPL][64];                       // [buffer][column register c][lane slot (r, h)]: 16 KB each
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = (lane & 3) | ((lane >> 4) << 2), h = (lane >> 2) & 3;
+    const int64_t q = rounds16 / gridDim.x, rem = rounds16 % gridDim.x;
+    const int64_t t0 = blockIdx.x * q + (blockIdx.x < rem ? blockIdx.x : rem);
+    const int cnt = (int)(q + (blockIdx.x < rem ? 1 : 0));
+    constexpr int CQ = CPL / 4;                               // column registers a wave fetches
+    double acc2[4] = {0.0, 0.0, 0.0, 0.0};
+    double s_red = 0.0;
+    double nx[CQ];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) nx[c] = __builtin_nontemporal_load(M + t0 * 16 + r + (int64_t)(4 * (wave * CQ + c) + h) * ld);
+    for (int k = 0; k < cnt; ++k) {
+        const int b = k & 1;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) tile[b][wave * CQ + c][lane] = nx[c];
+        if (k + 1 < cnt) {
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) nx[c] = __builtin_nontemporal_load(M + (t0 + k + 1) * 16 + r + (int64_t)(4 * (wave * CQ + c) + h) * ld);
+        }
+        __syncthreads();
+        double av[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) av[c] = tile[b][c][lane];
+        const int64_t row = (t0 + k) * 16 + r;
+        const double gg = g_in[row], dd = d[row], aa = a[row];
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) s = fma(av[c], 1e-3 * (c + 1 + wave), s);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        const double gp = fma(1e-9, aa * dd, gg) - 1e-12 * s;
+        s_red += gp * gp;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc2[c & 3] = fma(av[c], gp, acc2[c & 3]);
+    }
+    const double tot = (acc2[0] + acc2[1]) + (acc2[2] + acc2[3]) + s_red;
+    if (tot == 123.456) part[blockIdx.x * 4 + wave] = tot;
+}
+
 int main(int argc, char** argv) {
     const int KZ = argc > 1 ? atoi(argv[1]) : 3, KW = argc > 2 ? atoi(argv[2]) : 3;
     const int64_t n = 10000000, nround = (n + 63) / 64, npad = nround * 64, ld = npad + 16;
@@ -183,7 +261,7 @@ int main(int argc, char** argv) {
         G[k] = slab; D[k] = slab + npad; A[k] = slab + 2 * npad;
     }
     double* part;
-    hipMalloc((void**)&part, 8 * 4096);
+    hipMalloc((void**)&part, 8 * 16384);
     int nb = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tile_kernel<false>, 256, 0);
     const unsigned grid = 256u * (unsigned)(nb > 0 ? nb : 1);
@@ -261,6 +339,24 @@ int main(int argc, char** argv) {
             printf("        768 workgroups: 2 bursts of 102 rounds %.4f | per tile %.4f ms\n", ms[8], ms[9]);
             printf("        a fifth wave stores (tile waves never do): batches of 4 rounds %.4f | 16 rounds %.4f | 16 rounds, 768 workgroups %.4f ms\n", ms[10], ms[11], ms[12]);
         }
+    printf("\nfour waves of a workgroup load the SAME tile (a trial point each): free-running | a barrier every 8 tiles | four different tiles (no store)\n");
+    for (int iz = 0; iz < KZ; ++iz) {
+        float ms[4];
+        for (int v = 0; v < 4; ++v) {
+            for (int rep = 0; rep < 5; ++rep) {
+                if (rep == 1) hipEventRecord(e0);
+                if (v == 0) redundant_kernel<false><<<grid, 256>>>(Z[iz], ld, nround * 4, G[0], D[0], A[0], part);
+                if (v == 1) redundant_kernel<true><<<grid, 256>>>(Z[iz], ld, nround * 4, G[0], D[0], A[0], part);
+                if (v == 2) tile_kernel<false, true, false><<<grid, 256>>>(Z[iz], ld, nround, G[0], G[0], D[0], A[0], part);
+                if (v == 3) shared_tile_kernel<<<grid, 256>>>(Z[iz], ld, nround * 4, G[0], D[0], A[0], part);
+            }
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms[v], e0, e1);
+            ms[v] /= 4;
+        }
+        printf("Z%d: %.4f | %.4f | %.4f ms   | the tile shared through LDS (a quarter loaded per wave): %.4f ms\n", iz, ms[0], ms[1], ms[2], ms[3]);
+    }
     // ... and does it follow the STORED vector alone?  g from set iw, d and a from set (iw + 1) % KW
     printf("\nresidual (loaded + stored) from set W, direction / diagonal from the NEXT set:\n");
     for (int iz = 0; iz < KZ; ++iz)
