@@ -37,3 +37,33 @@ for cons in (L.sin_system_constraints(ctx,301,7),):
         out=prob.optimize(np.zeros(301),L.LFPSQPParams(do_project_retract=dpr,disp=L.DisplayOption.off,maxiter=2))
         print('opt elementwise',dpr,out[3].iter)
 print("ASAN RUN 2 DONE")
+# round 3: staged stores with many short bursts and a ragged last round (narrow, wide and stacked forms), the sparse Gram kernels for rows
+# of 9 .. 16 nonzeros over several column boxes, and the integer fold of many row slices
+os.environ["LFPSQP_STAGE_ROUNDS"]="2"
+ctx2=L.Context(0,lib)
+for n,m in ((5003,20),(4999,130),(3001,300)):
+    Z=ctx2.matrix(n,m).hash_fill(1,0,n,0.02)
+    x=ctx2.vector(n)
+    it,nr=L.projcg_(x,None,L.DiagOperator(0.0,ctx2.vector(n).hash_fill(3,0,4.0,5.0)),L.DeviceBasis(Z),ctx2.vector(n).hash_fill(4),None,tol=1e-300,maxit=5,want_lambda=False)
+    print('staged',n,m,it,nr)
+n,m=1201,6
+P0=synth.BallBoxProblem(n,m)
+Jct=ctx2.matrix(n+1,m+1).hash_fill(1,0,n,1.0,n,m)
+P=L.QuadLinearBallBox(ctx2,n,m,Jct,P0.eq.b,R2=P0.R2,xl=P0.xl,xu=P0.xu)
+for dpr in (False,True):
+    out=P.optimize(0.97*synth.hash_vector(2,n)+0.015,L.LFPSQPParams(do_project_retract=dpr,disp=L.DisplayOption.off,maxiter=2))
+    print('staged stacked opt',dpr,out[3].iter)
+del os.environ["LFPSQP_STAGE_ROUNDS"]
+for n,m,k in ((9001,70,12),(8200,150,16),(5000,40,9)):
+    rows=np.repeat(np.arange(n),k); cols=((((np.arange(n)*m)//n)[:,None]+np.arange(k)[None,:])%m).ravel()
+    vals=np.random.default_rng(k).standard_normal(n*k)
+    S=L.SparseMatrix(ctx,n,m,rows,cols,vals)
+    G=S.gram(None,ctx.vector(n).hash_fill(9,0,0.5,1.0))
+    print('sparse gram',n,m,k,float(np.abs(G).max()))
+os.environ["LFPSQP_SPGRAM_SLICES"]="64"
+n,m,k=4096*66+5,24,10
+rows=np.repeat(np.arange(n),k); cols=((((np.arange(n)*m)//n)[:,None]+np.arange(k)[None,:])%m).ravel()
+S=L.SparseMatrix(ctx,n,m,rows,cols,np.random.default_rng(1).standard_normal(n*k))
+print('sparse gram fold',float(np.abs(S.gram()).max()))
+del os.environ["LFPSQP_SPGRAM_SLICES"]
+print("ASAN RUN 3 DONE")
