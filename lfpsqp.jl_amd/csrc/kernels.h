@@ -69,6 +69,15 @@ __device__ __forceinline__ double buf_load_f64(const void* uniform_base, uint32_
 // compiler-only ordering point for memory operations (no instruction is emitted)
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
+// streaming store: the line is not kept dirty in the L2 for a later write-back (which would then fall into the NEXT kernel's read stream)
+__device__ __forceinline__ void st2_stream(double* p, double2 v) {
+#ifdef LFPSQP_HIP_EMULATED
+    st2(p, v);
+#else
+    __builtin_nontemporal_store(v.x, p);
+    __builtin_nontemporal_store(v.y, p + 1);
+#endif
+}
 
 // max that PROPAGATES NaN like Julia's max / norm(v, Inf) (fmax would drop it): a NaN constraint
 // value must read as "not converged" (reference src/retractions.jl:135, src/optimize.jl:320).

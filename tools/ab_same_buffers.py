@@ -44,7 +44,7 @@ def run(ctx, Z, x, w, maxit):
 for ctx in (ctxA, ctxB):
     for _ in range(6):
         run(ctx, Zs[0], sets[0][0], sets[0][1], 50)
-res = {}
+res, k1 = {}, {}
 for rnd in range(3):
     for iz, Z in enumerate(Zs):
         for iw, (x, w) in enumerate(sets):
@@ -54,6 +54,7 @@ for rnd in range(3):
                 run(ctx, Z, x, w, 16)
                 ms, cnt = ctx.profile_read(); ctx.set_profiling(False)
                 res.setdefault((iz, iw), {}).setdefault(tag, []).append(ms[3] / max(cnt[3], 1))
+                k1.setdefault(tag, []).append(ms[0] / max(cnt[0], 1))
 print(f"F ms per (basis, work set) allocation pair, n={n} m={m}: {tagA} | {tagB}   (min of 3 rounds)")
 tot = {tagA: 0.0, tagB: 0.0}
 for (iz, iw), r in sorted(res.items()):
@@ -61,3 +62,4 @@ for (iz, iw), r in sorted(res.items()):
     tot[tagA] += a; tot[tagB] += bb
     print(f"  Z{iz} W{iw}: {a:.4f} | {bb:.4f}   ({(bb / a - 1) * 100:+.1f} %)")
 print(f"  mean: {tot[tagA] / len(res):.4f} | {tot[tagB] / len(res):.4f}")
+print(f"  K1 (x += alpha d; d = beta d - g) mean ms: {sum(k1[tagA]) / len(k1[tagA]):.4f} | {sum(k1[tagB]) / len(k1[tagB]):.4f}")
