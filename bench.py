@@ -359,7 +359,7 @@ def main(argv=None, lib=None):
             summ = full.get("kernels", full)
             lib_sha = hashlib.sha256(open(ctx.L.path, "rb").read()).hexdigest()
             for name, v in summ.items():
-                if isinstance(v, dict) and ("onepass_kernel<lfpsqp::PcgFuseE" if fused else "gemv_t_kernel<lfpsqp::PcgStepV") in name:
+                if isinstance(v, dict) and ("onepass_kernel<lfpsqp::PcgFuseE<false, false>" if fused else "gemv_t_kernel<lfpsqp::PcgStepV") in name:
                     rec = {"bytes": v["traffic_GB"] * 1e9, "source": f"profiles/{pmc[-1]} ({v['launches']} launches)"}
                     if full.get("lib_sha256") == lib_sha:
                         out["roofline"]["traffic"] = rec["bytes"]
