@@ -18,6 +18,9 @@ KZ = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 KW = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 n = int(float(os.environ.get("AB_ROWS", "1e7"))); m = int(os.environ.get("AB_COLS", "128"))
 ctxA, ctxB = L.Context(0, lib_of(tagA)), L.Context(0, lib_of(tagB))
+if os.environ.get("AB_PING_B"):           # build B with the alternating residual buffers (lfpsqp_ctx_set_residual_buffers)
+    ctxB.set_residual_buffers(1)
+    tagB = tagB + "+alternating"
 scale = 2.0 ** math.floor(math.log2(math.sqrt(3.0 / n)))
 Zs, pads = [], []
 for k in range(KZ):
