@@ -40,7 +40,7 @@ def test_factorisation_without_the_basis_returns_the_same_factors(dev_ctx, n, m,
     np.testing.assert_allclose(Z.download(), Jh @ W, atol=1e-13 * max(1.0, cond))      # Z = Jct W is what the factored form applies
 
 
-@pytest.mark.parametrize("n,m", [(2100, 4), (2500, 33), (2100, 128), (1300, 300)])
+@pytest.mark.parametrize("n,m", [(2100, 4), (2500, 33), (1500, 128), (700, 300)])
 def test_projcg_on_the_factored_basis_matches_the_materialised_one_and_the_oracle(dev_ctx, n, m):
     """projcg! (src/projcg.jl:40-121) with U = Jct W applied in factored form: counts, iterate and multipliers of the run on the
     materialised Z and of the oracle on Z's host copy -- zero and non-zero c, loose and tight tolerances."""

@@ -33,7 +33,7 @@ def _with_caps(ctx0, monkeypatch, run, caps=("", "1", "3")):
 @pytest.mark.parametrize("m", [20, 40, 90, 128, 130, 300, 500])
 def test_projcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m):
     emu = _is_emu(dev_ctx)
-    n = 5003 if emu else 400_003          # not a multiple of the 64-row round: the last round of the last workgroup is ragged
+    n = (5003 if m < 200 else 1603) if emu else 400_003     # not a multiple of the 64-row round: the last round of the last workgroup is ragged
 
     def run(ctx):
         scale = 2.0 ** np.floor(np.log2(np.sqrt(3.0 / n)))
@@ -56,7 +56,7 @@ def test_projcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch,
 def test_pcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m):
     from lfpsqp_jl_amd.projpenalty import _JacPlain
     emu = _is_emu(dev_ctx)
-    n = 4001 if emu else 300_001
+    n = (4001 if m < 200 else 1501) if emu else 300_001
     rng = np.random.default_rng(3 + m)
     Jt = np.asfortranarray(rng.standard_normal((n, m)))
     bh = rng.standard_normal(n)
@@ -79,7 +79,7 @@ def test_pcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m)
 @pytest.mark.parametrize("m_lin", [12, 60, 128, 300])
 def test_newton_step_iterates_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m_lin):
     emu = _is_emu(dev_ctx)
-    n = 3001 if emu else 300_001
+    n = (3001 if m_lin < 200 else 901) if emu else 300_001
     m = m_lin
     pert = 1e-2 * np.random.default_rng(5 + m).standard_normal(n)
 
