@@ -176,7 +176,7 @@ def test_projcg_with_bounds_matches_oracle(dev_ctx, n, m, sparse):
     assert np.linalg.norm(x.download2() - x0) < 1e-10
 
 
-@pytest.mark.parametrize("n,m", [(16, 5), (2100, 7)])
+@pytest.mark.parametrize("n,m", [(16, 5), (1100, 7)])
 def test_full_jacobian_operator_multipliers_and_hessian_diag(dev_ctx, n, m):
     """test_inequalities.jl:111-120 (InequalityDecomp mul! x3), :143-155 (calculate_lambda_kkt! == bigA \\ d)
     and :157-177 (augmented Hessian action, diagonal case) on the device."""

@@ -205,7 +205,7 @@ def test_projcg_iteration_limit_and_identity_operator(dev_ctx):
     assert np.linalg.norm(x.download() - x0) <= 1e-13 * np.linalg.norm(x0)
 
 
-@pytest.mark.parametrize("n,m,stack", [(2100, 16, False), (1300, 300, False)])
+@pytest.mark.parametrize("n,m,stack", [(2100, 16, False), (700, 300, False)])
 def test_projcg_resume_continues_the_same_solve(dev_ctx, n, m, stack):
     """LFPSQP_PROJCG_RESUME (bench.py's timed region): W iterations, then K more, give bit for bit the iterate, count and
     residual of one call with the limit W + K -- also when the resumed part converges -- and the flag is refused when there
