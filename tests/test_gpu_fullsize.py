@@ -78,6 +78,33 @@ def test_full_size_projcg_invariants(big):
 
 
 @pytest.mark.gpu
+def test_full_size_staged_stores_do_not_change_the_iterates(big, monkeypatch):
+    """At n = 1e7 a workgroup of the fused kernel stores its span of the residual in two bursts (onepass_kernel STG).  With the bursts capped
+    at 40 rounds (8 per span) the 12th iterate is the same, bit for bit: when a value is stored does not change what is stored."""
+    ctx, Z = big
+    res = []
+    for cap in ("", "40"):
+        if cap:
+            monkeypatch.setenv("LFPSQP_STAGE_ROUNDS", cap)
+        c = L.Context(0, ctx.L) if cap else ctx
+        a = c.vector(N).hash_fill(3, 0, 4.0, 5.0)
+        b = c.vector(N).hash_fill(4)
+        x = c.vector(N)
+        Zc = Z
+        if c is not ctx:                     # (plain device buffers of the same process: the other context's kernels may read them)
+            ctx.sync()
+            Zc = c.matrix(N, M)
+            Zc.copy_from(Z)
+        it, nr = L.projcg_(x, None, L.DiagOperator(0.0, a), L.DeviceBasis(Zc), b, None, tol=1e-300, maxit=12, want_lambda=False)
+        res.append((it, nr, x.download()))
+        if c is not ctx:
+            c.close()
+    monkeypatch.delenv("LFPSQP_STAGE_ROUNDS", raising=False)
+    assert res[0][0] == res[1][0] == 12 and res[0][1] == res[1][1]
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.gpu
 def test_projcg_against_the_c_oracle_port_at_2e6():
     """The largest size the C/OpenMP oracle port (oracle/projcg_port.c) finishes in seconds on the box's host
     cores: n = 2e6, m = 64 -- iterates within 1e-10 relative, equal iteration count, lambda to 1e-9."""
