@@ -378,6 +378,7 @@ int lfpsqp_ctx_destroy(lfpsqp_ctx* ctx) {
     if (ctx->small) (void)hipFree(ctx->small);
     if (ctx->d_m) (void)hipFree(ctx->d_m);
     if (ctx->d_qw) (void)hipFree(ctx->d_qw);
+    if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->h_m) (void)hipHostFree(ctx->h_m);
     if (ctx->scal) (void)hipFree(ctx->scal);
     if (ctx->istat) (void)hipFree(ctx->istat);

@@ -74,6 +74,7 @@ struct lfpsqp_ctx {
     double* h_m = nullptr;
     size_t m_cap = 0;
     // the weights of lfpsqp_elementwise's quadratic term (device, m_lin)
+    double* d_zeros = nullptr;       // kOnepassMaxCols zeros (the first-product coefficients of a one-pass launch that only evaluates)
     double* d_qw = nullptr;
     size_t qw_cap = 0;
     // small device blocks: solver scalars / status, and their pinned host mirrors

@@ -613,9 +613,10 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
                 const int64_t rb = row0 + (int64_t)(k + 1 - sk) * kStep;
 #pragma unroll
                 for (int sv = 0; sv < NS; ++sv) {
-                    double* outv = ep.stage_out(sv);
-                    for (int e = threadIdx.x; e < sk * kStep; e += kThreads)
-                        if (rb + e < n) outv[rb + e] = stg[sv * (STG * kStep) + e];
+                    double* outv = ep.stage_out(sv);            // (nullptr: a launch that stores nothing, e.g. an evaluation-only pass)
+                    if (outv != nullptr)
+                        for (int e = threadIdx.x; e < sk * kStep; e += kThreads)
+                            if (rb + e < n) outv[rb + e] = stg[sv * (STG * kStep) + e];
                 }
                 __syncthreads();            // before the next round overwrites the area
                 sk = 0;

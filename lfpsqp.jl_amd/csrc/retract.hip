@@ -106,7 +106,13 @@ struct NRStepE {
     const int64_t* istat;            // NR status word: a finished retraction turns further launches into no-ops
     const double* kind = nullptr;    // lfpsqp_elementwise: the c! product takes phi(xnew) instead of xnew  (two-stream / sparse step only)
     double* phi_out = nullptr;       // ... stored here when the product is a separate (sparse) launch
-    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_NR_STATUS) != 0; }
+    // One-stream step of the nonlinear class with a dense A (onepass_kernel over A itself): the step product over Jct(x) = diag(phi'(x)) A +
+    // 2 x qw' is rebuilt from the kernel's first product over A -- (Jct u)_i = phi'(xold_i) (A u)_i + 2 xold_i (qw . u) [i < n_x] -- and the
+    // second product takes phi(xnew).  sq = qw . u, a device scalar written by the small kernel (nullptr: no quadratic term).
+    int ew_one = 0;
+    const double* sq = nullptr;
+    int eval_only = 0;               // the same launch as c!: no update, no store, products of phi(x) (so cval is bit for bit c!(xnew))
+    __device__ __forceinline__ bool skip() const { return !eval_only && ld_stat(istat + I_NR_STATUS) != 0; }
     __device__ __forceinline__ double ball(int64_t i, double xi) const {
         return !has_ball ? 0.0 : (i < n_x ? xi * xi : (i == slack_row ? -xi : 0.0));
     }
@@ -145,7 +151,7 @@ struct NRStepE {
     }
     // one-row form for the one-stream step kernel: the inputs of a row are fetched a tile ahead of their use.
     // `o` is the row's BYTE offset (uniform base + 32-bit lane offset: the scalar-base addressing mode).
-    struct Row { double xn, yn, xo, yo, ax, ay, q, r, s, t; };
+    struct Row { double xn, yn, xo, yo, ax, ay, q, r, s, t, kk; };
     static __device__ __forceinline__ double at(const double* base, uint32_t o) {
         return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
     }
@@ -162,13 +168,21 @@ struct NRStepE {
         } else {
             w.yn = w.xo = w.yo = w.ax = w.ay = w.q = w.r = w.s = w.t = 0.0;
         }
+        w.kk = 0.0;
+        if (ew_one) {
+            if (!ST && !eval_only) w.xo = at(xold, o);
+            if (kind) w.kk = at(kind, o);
+        }
         return w;
     }
     template <bool ST>
     __device__ __forceinline__ double apply1(int64_t i, uint32_t o, double acc, bool valid, bool owner, const Row& w, double& red,
-                                             double* slot = nullptr, int sstride = 0) const {
+                                             double* slot = nullptr, int sstride = 0, double sqv = 0.0) const {
         double xn = w.xn;
-        if (!ST) {
+        if (ew_one && !eval_only) acc = fma(ew_phi1(w.kk, w.xo), acc, (i < n_x) ? 2.0 * w.xo * sqv : 0.0);      // (Jct(xold) u)_i from (A u)_i
+        if (eval_only) {
+            // c! alone: xn is the point itself
+        } else if (!ST) {
             xn += acc;
             if (valid && owner) {
                 if (slot) *slot = xn;      // staged stores (onepass_kernel STG)
@@ -185,6 +199,7 @@ struct NRStepE {
             }
         }
         if (valid && owner) red += ball(i, xn);
+        if (ew_one) xn = ew_phi(w.kk, xn);
         return valid ? xn : 0.0;
     }
 };
@@ -197,21 +212,21 @@ template <bool ST>
 struct NRStepRow {
     NRStepE e;
     using Row = NRStepE::Row;
-    using Uni = NoUni;
+    struct Uni { double sq; };
     static constexpr bool kSplitRed = false;
     __device__ __forceinline__ bool skip() const { return e.skip(); }
-    __device__ __forceinline__ Uni uniform() const { return Uni{}; }
+    __device__ __forceinline__ Uni uniform() const { return Uni{(e.ew_one && e.sq && !e.eval_only) ? uniform_f64(ld_scal(e.sq)) : 0.0}; }
     __device__ __forceinline__ Row fetch(uint32_t o) const { return e.fetch1<ST>(o); }
-    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool, const Uni&,
+    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool, const Uni& u,
                                           const Row& w, double (&v)[1], double (&red)[1]) const {
-        v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0]);
+        v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0], nullptr, 0, u.sq);
     }
     // staged form: the new point (stacked: its x and y halves) waits in LDS and is stored in bursts
     static constexpr int kStageStreams = ST ? 2 : 1;
-    __device__ __forceinline__ double* stage_out(int sv) const { return sv == 0 ? e.xnew : e.xnew + e.hs; }
-    __device__ __forceinline__ void apply_staged(int64_t i, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool, const Uni&,
+    __device__ __forceinline__ double* stage_out(int sv) const { return e.eval_only ? nullptr : (sv == 0 ? e.xnew : e.xnew + e.hs); }
+    __device__ __forceinline__ void apply_staged(int64_t i, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool, const Uni& u,
                                                  const Row& w, double (&v)[1], double (&red)[1], double* slot, int sstride) const {
-        v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0], slot, sstride);
+        v[0] = e.apply1<ST>(i, o, acc[0], valid, owner, w, red[0], slot, sstride, u.sq);
     }
 };
 
@@ -347,6 +362,11 @@ __device__ void nr_small_trial(const NRSmall& s, int init) {
     if (s.W) {                                                                                  // t = W delta (one-stream step)
         small_matvec(s.W, s.wm, s.wm, m, del, t2, scratch);
         if (tid < s.wm) s.wdelta[tid] = t2[tid];
+        if (s.qw && tid == 0) {                                                                 // qw . t behind it (one-stream step of the nonlinear class)
+            double sq = 0.0;
+            for (int j = 0; j < s.m_lin && j < s.wm; ++j) sq = fma(s.qw[j], t2[j], sq);
+            s.wdelta[s.wm] = sq;
+        }
     }
 }
 __global__ __launch_bounds__(kNRThreads) void nr_small_kernel(NRSmall s, int init) { nr_small_trial(s, init); }
@@ -565,6 +585,12 @@ static int stage_qw(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const doubl
     return 0;
 }
 
+// nonlinear class with a dense A of a shape the one-pass kernel covers: c! and the Newton step stream A through onepass_kernel
+static bool ew_onepass_ok(const lfpsqp_ctx* ctx, const lfpsqp_constraints* cons) {
+    const lfpsqp_elementwise* ew = cons->ew;
+    return ew && !ew->Asp && ew->A && !cons->has_ball && cons->m_lin >= 4 && onepass_cw(ctx, (int)cons->m_lin, ew->A->ld, cons->Jct->n) != 0;
+}
+
 // raw[0:m_lin) = the constraint products (J x, or A' phi(x)), raw[m_lin] = sum_{i<n_x} x_i^2 - x[slack_row] (when the class has a ball or a
 // common quadratic term) -- device buffer, all-reduced, stream-ordered.  `x` has >= rows(Jct) entries.
 static int cons_raw(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const double* x, double* raw) {
@@ -578,6 +604,20 @@ static int cons_raw(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const doubl
         if (ew->Asp) {
             LF_TRY((run_vec<EwEvalVecF, 1, NoPost>(ctx, N, EwEvalVecF{ee}, 0u, raw + ml, NoPost())));
             return spmv_t(ctx, ew->Asp, ew->work->p, raw);
+        }
+        if (ew_onepass_ok(ctx, cons)) {
+            // c! in the launch shape of the one-stream Newton step (first-product coefficients zero, nothing updated or stored): the sums of a
+            // step's second product and of this evaluation are then taken in the same order -- cval of a retraction == c!(xnew), bit for bit
+            if (!ctx->d_zeros) {
+                LF_HIP(ctx, hipMalloc((void**)&ctx->d_zeros, sizeof(double) * (kOnepassMaxCols + 8)));
+                LF_HIP(ctx, hipMemsetAsync(ctx->d_zeros, 0, sizeof(double) * (kOnepassMaxCols + 8), ctx->stream));
+            }
+            NRStepE e0{const_cast<double*>(x), nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cons->n_x, cons->slack_row, quad ? 1 : 0,
+                       ctx->istat};
+            e0.kind = ew->kind ? ew->kind->p : nullptr;
+            e0.ew_one = 1;
+            e0.eval_only = 1;
+            return run_onepass<NRStepRow<false>, 1, 1>(ctx, ew->A, ml, ml, N, ctx->d_zeros, NRStepRow<false>{e0}, raw);
         }
         return run_gemv_nt<EwEvalE, 1>(ctx, nullptr, 0, nullptr, ew->A, ml, N, ee, raw);
     }
@@ -716,7 +756,7 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         // without a one-pass kernel): it then streams Jct with W*ddelta instead of Z with ddelta, so a basis in factored form (U->Z == NULL) works
         const int cw = (Ssp || wm) ? 1 : cwd;
         LF_ARG(ctx, U->Z || wm);
-        const size_t wsz = cw ? (((size_t)wm * m + (size_t)wm + 1) & ~(size_t)1) : 0;
+        const size_t wsz = cw ? (((size_t)wm * m + (size_t)wm + 3) & ~(size_t)1) : 0;     // W, W*delta and one scalar (qw . W*delta) behind it
         LF_TRY(ensure_small(ctx, 2 * mm + wsz + 8 * (size_t)m + 256));
         double* dD = ctx->small;
         double* dVt = dD + mm;
@@ -758,6 +798,7 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
         const int n1 = wm ? wm : m;
         const double* t1 = wm ? dwdelta : ddelta;
         const lfpsqp_spmat* csp = ew ? ew->Asp : Ssp;
+        const bool ewo = ew_onepass_ok(ctx, cons);
         int64_t it = 0;
         bool done = false;
         while (!done && it < maxiter) {
@@ -766,6 +807,17 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
                 const NRSparseStepF sf{ep, ell_rows(Ssp, dwdelta), cons->Jct->p + (int64_t)ml * cons->Jct->ld, cons->Jct->ld, dwdelta + ml, wm - ml};
                 LF_TRY((run_vec<NRSparseStepF, 1, NoPost>(ctx, N, sf, 0u, draw + ml, NoPost())));
                 LF_TRY(spmv_t(ctx, csp, ep.phi_out ? ep.phi_out : xnew->p, draw));
+            } else if (ewo && wm == ml) {                          // nonlinear class, dense A, generator known: ONE pass over A per step
+                NRStepE e1 = ep;
+                e1.ew_one = 1;
+                e1.sq = ew->qw ? dwdelta + wm : nullptr;
+                if (ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, ew->A, ml, ml, N, dwdelta, NRStepRow<true>{e1}, draw)));
+                else LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, ew->A, ml, ml, N, dwdelta, NRStepRow<false>{e1}, draw)));
+            } else if (ewo) {                                      // ... without the generator: the update over Z, then c! in its own (one-pass) launch
+                NRStepE e1 = ep;
+                e1.kind = nullptr;                                 // (the update alone: nothing is handed to a second product)
+                LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, s1, n1, t1, nullptr, 0, N, e1, draw + ml)));
+                LF_TRY(cons_raw(ctx, cons, xnew->p, draw));
             } else if (cwd && ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<true>{ep}, draw)));
             else if (cwd) LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<false>{ep}, draw)));
             else if (ew && ew->Asp) {                             // sparse A without the generator hint: dense step over Z, sparse c!

@@ -204,7 +204,7 @@ def _trace_compare(tr, tr0, tol=1e-10):
 
 
 @pytest.mark.parametrize("system,bounds,project", [("sin-sparse", False, False), ("sin-sparse", True, False), ("sphere", False, False),
-                                                   ("mixed-dense", False, False), ("sin-dense", False, True)])
+                                                   ("mixed-dense", False, False), ("sin-dense", False, True), ("sin-dense", True, False)])
 def test_optimize_end_to_end_against_the_oracle(dev_ctx, system, bounds, project):
     """optimize(f, grad!, c!, jac!, hess_lag_vec!, x0, xl, xu, m) (src/optimize.jl:119) with everything resident on the device against
     the oracle's run with host callables of the same functions: equal counts, step types, retraction iterations, accepted steps;

@@ -32,6 +32,19 @@ lam = np.cos(1.0 + np.arange(m))
 out["hess_diag_ms"] = timed(lambda: cons.hess_diag_(hx, x, lam))
 Z = ctx.matrix(n, m); W = np.zeros((m, m), order='F')
 out["tangent_setup_ms"] = timed(lambda: L.ksvd_(cons.Jct, Z, W=W, Jsp=cons.Jsp), 3)
+# Newton retraction, 12 iterations forced by tol = 0 (flag 1): ms per iteration with and without the generator hint (Z = Jct W)
+Sg, Vtg, rank = L.ksvd_(cons.Jct, Z, W=W, Jsp=cons.Jsp)
+xt, xnew = ctx.vector(n), ctx.vector(n)
+pert = ctx.vector(n).hash_fill(51, 0, 1e-3, 0.0)
+for tag, U in (("with_generator", L.DeviceBasis(Z, generator=(cons.Jct, W))), ("basis_only", L.DeviceBasis(Z))):
+    nr = L.NR(U, Sg, Vtg, 0.0, 12, L.NRWork(m), False, None)
+    best = 1e9
+    for rep in range(3):
+        xt.copy_from(x); L.axpby(1.0, pert, 1.0, xt)
+        ctx.sync(); t0 = time.perf_counter()
+        flag, it, _ = L.retract_(cv, xnew, cons, xt, x, nr)
+        ctx.sync(); best = min(best, (time.perf_counter() - t0) * 1e3 / max(it, 1))
+    out["nr_iteration_ms_" + tag] = best
 Z.free()
 cons.jac_(cons.Jct, cv, x)
 cons.b = cons.b + cv                       # x feasible; the optimum of |x - target|^2 on the manifold lies nearby
