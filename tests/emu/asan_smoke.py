@@ -67,3 +67,15 @@ S=L.SparseMatrix(ctx,n,m,rows,cols,np.random.default_rng(1).standard_normal(n*k)
 print('sparse gram fold',float(np.abs(S.gram()).max()))
 del os.environ["LFPSQP_SPGRAM_SLICES"]
 print("ASAN RUN 3 DONE")
+# the nonlinear class with a DENSE A: one-pass Newton step (generator known) and c! as the same launch, with and without bounds, with the common quadratic term
+rng=np.random.default_rng(4)
+n,m=1203,9
+Ad=np.asfortranarray(rng.standard_normal((n,m))/np.sqrt(n))
+kd=rng.integers(0,3,n).astype(np.float64)
+consd=L.ElementwiseConstraints(ctx,ctx.matrix(n,m,Ad),0.1*rng.standard_normal(m),kind=kd,qw=0.01*rng.standard_normal(m))
+for bounds in (False,True):
+    kw=dict(xl=-2*np.ones(n),xu=2*np.ones(n)) if bounds else {}
+    prob=L.SeparableElementwiseBox(ctx,consd,0,1.0,0.3*synth.hash_vector(5,n),**kw)
+    out=prob.optimize(0.1*synth.hash_vector(6,n),L.LFPSQPParams(do_project_retract=False,disp=L.DisplayOption.off,maxiter=2))
+    print('opt elementwise dense',bounds,out[3].iter)
+print("ASAN RUN 4 DONE")
