@@ -332,7 +332,7 @@ constexpr StageCfg onepass_stage(int cpl, bool wide, int na) {
     return (cpl <= 16 || (cpl <= 24 && ns == 1)) ? StageCfg{102 / ns, 3} : StageCfg{153 / ns, 2};
 }
 template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA, bool LACC, int STG = 0, int SW = 1>
-inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {
+inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds, int wg_per_cu_cap = 0) {
     static int per_cu = 0;                        // one per kernel instantiation
     if (per_cu == 0) {
         int nb = 0;
@@ -341,14 +341,16 @@ inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds) {
             nb = 1;
         per_cu = nb;
     }
-    int64_t g = (int64_t)per_cu * (ctx->num_cu > 0 ? ctx->num_cu : 1);
+    // (wg_per_cu_cap: launches of DIFFERENT instantiations that must sum their partials in the same order ask for the same grid)
+    const int pc = (wg_per_cu_cap > 0 && wg_per_cu_cap < per_cu) ? wg_per_cu_cap : per_cu;
+    int64_t g = (int64_t)pc * (ctx->num_cu > 0 ? ctx->num_cu : 1);
     if (g > rounds) g = rounds;
     return (int)(g < 1 ? 1 : g);
 }
 
 template <class EP, int NV, int NRED, int NA = 1>
 int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t n, const double* t, const EP& ep, double* out,
-                int prof_slot = -1, int t_stride = 0) {
+                int prof_slot = -1, int t_stride = 0, int wg_per_cu_cap = 0) {
     ++ctx->launch_epoch;
     const int cpl = (ncN + 3) / 4;                // column groups
     const bool wide = cpl > 64;                   // more than 256 columns: the four waves of a workgroup split the columns
@@ -367,7 +369,7 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
         constexpr StageCfg kC = onepass_stage<EP>(CPL, WIDE, NA);                                                                    \
         constexpr int kG = kC.rounds, kW = kC.waves;                                                                                 \
         constexpr bool kL = (kG == 0 || (WIDE)) && kOpLacc && NA == 1 && (CPL) > 16 && (CPL) <= 33;                                 \
-        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL, kG, kW>(ctx, rounds);                               \
+        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL, kG, kW>(ctx, rounds, wg_per_cu_cap);                \
         LF_TRY(ensure_part(ctx, (size_t)grid * part_ld + reduce_scratch(part_ld)));                                                  \
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);                                                                              \
         hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL, kG, kW>), dim3((unsigned)grid), dim3(kThreads), \

@@ -585,6 +585,10 @@ static int stage_qw(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const doubl
     return 0;
 }
 
+// The stacked step, the plain step and the c! evaluation are different instantiations of the one-pass kernel; with the same number of
+// workgroups (two per CU: what each of them keeps resident at least) they cut the rows alike and sum their partials in the same order,
+// so the cval a retraction returns is c!(xnew) bit for bit with bounds as well.
+constexpr int kEwWgPerCu = 2;
 // nonlinear class with a dense A of a shape the one-pass kernel covers: c! and the Newton step stream A through onepass_kernel
 static bool ew_onepass_ok(const lfpsqp_ctx* ctx, const lfpsqp_constraints* cons) {
     const lfpsqp_elementwise* ew = cons->ew;
@@ -617,7 +621,7 @@ static int cons_raw(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const doubl
             e0.kind = ew->kind ? ew->kind->p : nullptr;
             e0.ew_one = 1;
             e0.eval_only = 1;
-            return run_onepass<NRStepRow<false>, 1, 1>(ctx, ew->A, ml, ml, N, ctx->d_zeros, NRStepRow<false>{e0}, raw);
+            return run_onepass<NRStepRow<false>, 1, 1>(ctx, ew->A, ml, ml, N, ctx->d_zeros, NRStepRow<false>{e0}, raw, -1, 0, kEwWgPerCu);
         }
         return run_gemv_nt<EwEvalE, 1>(ctx, nullptr, 0, nullptr, ew->A, ml, N, ee, raw);
     }
@@ -811,8 +815,8 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
                 NRStepE e1 = ep;
                 e1.ew_one = 1;
                 e1.sq = ew->qw ? dwdelta + wm : nullptr;
-                if (ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, ew->A, ml, ml, N, dwdelta, NRStepRow<true>{e1}, draw)));
-                else LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, ew->A, ml, ml, N, dwdelta, NRStepRow<false>{e1}, draw)));
+                if (ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, ew->A, ml, ml, N, dwdelta, NRStepRow<true>{e1}, draw, -1, 0, kEwWgPerCu)));
+                else LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, ew->A, ml, ml, N, dwdelta, NRStepRow<false>{e1}, draw, -1, 0, kEwWgPerCu)));
             } else if (ewo) {                                      // ... without the generator: the update over Z, then c! in its own (one-pass) launch
                 NRStepE e1 = ep;
                 e1.kind = nullptr;                                 // (the update alone: nothing is handed to a second product)

@@ -205,7 +205,7 @@ def _trace_compare(tr, tr0, tol=1e-10):
 
 @pytest.mark.parametrize("system,bounds,project", [("sin-sparse", False, False), ("sin-sparse", True, False), ("sphere", False, False),
                                                    ("mixed-dense", False, False), ("sin-dense", False, True), ("sin-dense", True, False)])
-def test_optimize_end_to_end_against_the_oracle(dev_ctx, system, bounds, project):
+def test_optimize_end_to_end_against_the_oracle(dev_ctx, monkeypatch, system, bounds, project):
     """optimize(f, grad!, c!, jac!, hess_lag_vec!, x0, xl, xu, m) (src/optimize.jl:119) with everything resident on the device against
     the oracle's run with host callables of the same functions: equal counts, step types, retraction iterations, accepted steps;
     iterates within 1e-10 after every outer iteration."""
@@ -230,7 +230,26 @@ def test_optimize_end_to_end_against_the_oracle(dev_ctx, system, bounds, project
     prob = L.SeparableElementwiseBox(ctx, cons, 0, 1.0, target, xl=xl, xu=xu)          # f = sum (x - target)^2
     p = L.LFPSQPParams(do_project_retract=project, maxiter=12, disp=L.DisplayOption.off)
     tr = []
+    # every successful retraction of the run returns c!(xnew) bit for bit (test/test_retractions.jl:97) -- with bounds too, where the step is the
+    # stacked instantiation of the one-pass kernel and c! the plain one
+    import lfpsqp_jl_amd.linesearch as LS
+    checked = []
+    real_retract = LS.retract_
+
+    def checking_retract(cval, xnew, c_dev, xtilde, x, method):
+        out = real_retract(cval, xnew, c_dev, xtilde, x, method)
+        if out[0] == 0 and isinstance(method, L.NR):
+            cv2 = np.zeros_like(cval)
+            c_dev.c_(cv2, xnew)
+            np.testing.assert_array_equal(cval, cv2)
+            checked.append(1)
+        return out
+    monkeypatch.setattr(LS, "retract_", checking_retract)
+    ctx.options.ls_batch = 1                    # (one by one: every retraction goes through the wrapper)
     xd, obj, lam, ti = prob.optimize(x0, p, trace=tr)
+    ctx.options.ls_batch = 4
+    monkeypatch.setattr(LS, "retract_", real_retract)
+    assert project or len(checked) > 0
 
     f = lambda xx: float(np.sum((xx[:n] - target) ** 2))
 
