@@ -729,9 +729,12 @@ struct ProjPenaltyWork                                                        # 
     ones::Union{Nothing,DeviceVector}
     zeros::Union{Nothing,DeviceVector}
 end
-function ProjPenaltyWork(like::DeviceVector, m::Integer, N::Integer, ineq::Bool)
+# `against`: the constraint-gradient matrix the pcg! iteration streams -- the five n-vectors then come from one allocation chosen by the
+# library's placement policy against it (lfpsqp_vecs_alloc_placed), as ProjCGWork's do
+function ProjPenaltyWork(like::DeviceVector, m::Integer, N::Integer, ineq::Bool; against::Union{Nothing,DeviceMatrix}=nothing)
     ctx = like.ctx
-    v5 = (similar_device(like) for _ in 1:5)
+    v5 = (against !== nothing && ctx.options.placement_tries > 1) ? vectors_placed(ctx, against, N, 5; N=(ineq ? N : 0)) :
+         [similar_device(like) for _ in 1:5]
     ineq || return ProjPenaltyWork(v5..., DeviceVector(ctx, max(m, 1)), nothing, nothing, nothing, nothing, nothing, nothing)
     return ProjPenaltyWork(v5..., DeviceVector(ctx, max(m, 1)), DeviceVector(ctx, N), DeviceVector(ctx, N), DeviceVector(ctx, N), DeviceVector(ctx, N),
                            fill!(DeviceVector(ctx, N), 1.0), DeviceVector(ctx, N))
@@ -1227,7 +1230,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     end
     nr = NR(nothing, Σ, Vt, param.ϵ_c, param.maxiter_retract, ineq, idata)
     pp = ProjPenalty(c! isa DeviceConstraints ? c! : jac!, m, m, param.μ0, param.ϵ_c, param.maxiter_retract, param.maxiter_pcg,
-                     ProjPenaltyWork(x, m, n, ineq), ineq, idecomp, idata)
+                     ProjPenaltyWork(x, m, n, ineq; against=(m > 0 ? Jct : nothing)), ineq, idecomp, idata)
     armijo_work = ArmijoWork(x)
     exact_work = (param.linesearch == exact && !param.disable_linesearch) ? ExactLinesearchWork(x) : nothing
     i = 0

@@ -190,7 +190,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
 
     nr = NR(None, Sig, Vt, param.eps_c, param.maxiter_retract, NRWork(m), ineq, ineqdata)
     pp = ProjPenalty(jac_, None, Sig, Vt, m, param.mu0, param.eps_c, param.maxiter_retract, param.maxiter_pcg,
-                     ProjPenaltyWork(ctx, m, n, ineq), ineq, idecomp, ineqdata)
+                     ProjPenaltyWork(ctx, m, n, ineq, against=Jct if m > 0 else None), ineq, idecomp, ineqdata)
     euc = Euclidean()
     yr = YRetract(ineqdata) if ineq else None
     armijo_work = ArmijoWork(x)

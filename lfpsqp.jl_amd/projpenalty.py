@@ -20,9 +20,14 @@ from .inequality import InequalityData, InequalityDecomp, StackedVector, calcula
 
 
 class ProjPenaltyWork:  # src/retractions.jl:21-33 (J itself is the shared device Jct)
-    def __init__(self, ctx: Context, m: int, n: int, ineq: bool):
+    def __init__(self, ctx: Context, m: int, n: int, ineq: bool, against=None):
+        """``against``: the constraint-gradient matrix the pcg! iteration streams -- its five n-vectors then come from ONE allocation
+        chosen by the library's placement policy against that matrix (lfpsqp_vecs_alloc_placed), as ProjCGWork's do."""
         mk = (lambda: StackedVector(ctx, n)) if ineq else (lambda: DeviceVector(ctx, n))
-        self.r, self.p, self.z, self.dx, self.g = mk(), mk(), mk(), mk(), mk()
+        if against is not None and ctx.options.placement_tries > 1:
+            self.r, self.p, self.z, self.dx, self.g = ctx.vectors_placed(against, n, 5, stacked_N=n if ineq else None)
+        else:
+            self.r, self.p, self.z, self.dx, self.g = mk(), mk(), mk(), mk(), mk()
         self.tmp_m = DeviceVector(ctx, max(m, 1))
         self.cval_dev = DeviceVector(ctx, max(m, 1))
         self.ineq = ineq
