@@ -350,7 +350,7 @@ inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds, int wg_per_cu_cap = 0) 
 
 template <class EP, int NV, int NRED, int NA = 1>
 int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t n, const double* t, const EP& ep, double* out,
-                int prof_slot = -1, int t_stride = 0, int wg_per_cu_cap = 0) {
+                int prof_slot = -1, int t_stride = 0, int wg_per_cu_cap = 0, bool discard_sums = false) {
     ++ctx->launch_epoch;
     const int cpl = (ncN + 3) / 4;                // column groups
     const bool wide = cpl > 64;                   // more than 256 columns: the four waves of a workgroup split the columns
@@ -395,8 +395,10 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
 #undef LF_OP
         if (prof_slot >= 0) prof_end(ctx, prof_slot);
         LF_LAUNCH_CHECK(ctx);
+        if (discard_sums) return 0;          // (a launch used for its row update alone, e.g. GEMV-N: no second stage, no collective)
         LF_TRY(launch_reduce(ctx, grid, nout, part_ld, 0u, out, NoPost()));
     } else {
+        if (discard_sums) return 0;
         LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
     }
     return allreduce_dev(ctx, out, nout);

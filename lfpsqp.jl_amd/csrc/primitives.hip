@@ -16,6 +16,9 @@ struct PlainV {  // v straight from memory
     }
 };
 
+#ifndef LFPSQP_GEMVN_ONEPASS
+#define LFPSQP_GEMVN_ONEPASS 1
+#endif
 struct AxpbyEpi {  // y = alpha*acc + beta*y   (beta == 0 never reads y: BLAS semantics)
     double* y;
     double alpha, beta;
@@ -30,6 +33,37 @@ struct AxpbyEpi {  // y = alpha*acc + beta*y   (beta == 0 never reads y: BLAS se
         }
         if (v1) st2(y + r, o);
         else if (v0) y[r] = o.x;
+    }
+};
+
+// The same update as a row functor of the one-pass kernel (kernels.h): the persistent grid stores y in a few device-wide bursts instead of a
+// continuous trickle inside the matrix read stream (DESIGN.md 6 "The thin store stream"); the kernel's second product is fed zeros and its
+// sums are discarded.
+struct GemvNRow {
+    double* y;
+    double alpha, beta;
+    using Uni = NoUni;
+    struct Row { double yy; };
+    static constexpr bool kSplitRed = false;
+    static constexpr int kStageStreams = 1;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ Uni uniform() const { return Uni{}; }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        return Row{beta == 0.0 ? 0.0 : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(y) + o)};
+    }
+    __device__ __forceinline__ double* stage_out(int) const { return y; }
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool lead, const Uni& u, const Row& w,
+                                          double (&v)[1], double (&red)[1]) const {
+        apply_staged(row, o, acc, valid, owner, lead, u, w, v, red, nullptr, 0);
+    }
+    __device__ __forceinline__ void apply_staged(int64_t, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool, const Uni&, const Row& w,
+                                                 double (&v)[1], double (&)[1], double* slot, int) const {
+        const double out = beta == 0.0 ? alpha * acc[0] : fma(alpha, acc[0], beta * w.yy);       // (the expressions of AxpbyEpi)
+        if (valid && owner) {
+            if (slot) *slot = out;
+            else *reinterpret_cast<double*>(reinterpret_cast<char*>(y) + o) = out;
+        }
+        v[0] = 0.0;
     }
 };
 
@@ -240,6 +274,11 @@ int lfpsqp_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfp
 int lfpsqp_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, double alpha, const lfpsqp_vec* t, double beta, lfpsqp_vec* y) {
     LF_RANGE("lfpsqp_gemv_n");
     LF_ARG(ctx, ctx && M && y && ncols >= 0 && ncols <= M->m && y->n == M->n && (ncols == 0 || (t && t->n >= ncols)));
+    // 97 .. 132 columns: through the one-pass kernel's persistent grid and staged stores (GemvNRow) -- same buffers, both forms
+    // (tools/gpu_gemvn_ab.sh, n = 1e7): m = 128 1.590 / 1.604 ms (min / mean over 12 placements) against 1.617 / 1.658; at m = 32, 64 and
+    // 512 the two-pass form is the faster one by 1-6 % (the one-pass kernel's idle second product costs more than its store pattern saves)
+    if (LFPSQP_GEMVN_ONEPASS && ncols >= 97 && ncols <= 132 && onepass_cw(ctx, (int)ncols, M->ld, M->n) != 0)
+        return run_onepass<GemvNRow, 1, 1>(ctx, M, (int)ncols, 0, M->n, t->p, GemvNRow{y->p, alpha, beta}, nullptr, -1, 0, 0, true);
     return run_gemv_n<AxpbyEpi, 0, NoPost>(ctx, M, (int)ncols, M->n, t ? t->p : nullptr, AxpbyEpi{y->p, alpha, beta}, nullptr, NoPost());
 }
 
