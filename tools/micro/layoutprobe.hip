@@ -248,6 +248,15 @@ __global__ __launch_bounds__(256) void shared_tile_kernel(const double* __restri
     if (tot == 123.456) part[blockIdx.x * 4 + wave] = tot;
 }
 
+// pseudo-random doubles in [0.5, 1.5) (every bit pattern different from its neighbours'), or zeros
+__global__ void fill_kernel(double* p, int64_t n, unsigned long long seed, int zero) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long x = (unsigned long long)i * 0x9E3779B97F4A7C15ull + seed;
+        x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
+        p[i] = zero ? 0.0 : 0.5 + (double)(x >> 11) * (1.0 / 9007199254740992.0);
+    }
+}
+
 int main(int argc, char** argv) {
     const int KZ = argc > 1 ? atoi(argv[1]) : 3, KW = argc > 2 ? atoi(argv[2]) : 3;
     const int64_t n = 10000000, nround = (n + 63) / 64, npad = nround * 64, ld = npad + 16;
@@ -356,6 +365,34 @@ int main(int argc, char** argv) {
             ms[v] /= 4;
         }
         printf("Z%d: %.4f | %.4f | %.4f ms   | the tile shared through LDS (a quarter loaded per wave): %.4f ms\n", iz, ms[0], ms[1], ms[2], ms[3]);
+    }
+    // Does the CONTENT of the vectors matter (the library's placement trials run on zeros and come out faster than the real kernel on slow
+    // pairs)?  Same kernels, the three vectors zero or pseudo-random: g alone (what is loaded AND what is stored changes), d and a alone (the
+    // stored values become non-zero, the loaded g stays zero), all three.
+    printf("\nvector contents (Z0 W0): per-tile store | two bursts, 768 workgroups | loads only\n");
+    {
+        const char* names[4] = {"all zero", "g random", "d, a random (stores non-zero)", "g, d, a random"};
+        for (int c = 0; c < 4; ++c) {
+            fill_kernel<<<1024, 256>>>(G[0], npad, 1, !(c == 1 || c == 3));
+            fill_kernel<<<1024, 256>>>(D[0], npad, 2, !(c >= 2));
+            fill_kernel<<<1024, 256>>>(A[0], npad, 3, !(c >= 2));
+            float ms[3];
+            for (int v = 0; v < 3; ++v) {
+                for (int rep = 0; rep < 5; ++rep) {
+                    if (rep == 1) hipEventRecord(e0);
+                    if (c == 1 || c == 3) { if (rep == 0) {} }
+                    if (v == 0) store_kernel<0><<<grid, 256>>>(Z[0], ld, nround, G[0], G[0], D[0], A[0], part);
+                    if (v == 1) store_kernel<102><<<768, 256>>>(Z[0], ld, nround, G[0], G[0], D[0], A[0], part);
+                    if (v == 2) tile_kernel<false, true, false><<<grid, 256>>>(Z[0], ld, nround, G[0], G[0], D[0], A[0], part);
+                }
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms[v], e0, e1);
+                ms[v] /= 4;
+            }
+            printf("%-32s %.4f | %.4f | %.4f ms\n", names[c], ms[0], ms[1], ms[2]);
+        }
+        fill_kernel<<<1024, 256>>>(G[0], npad, 1, 1); fill_kernel<<<1024, 256>>>(D[0], npad, 2, 1); fill_kernel<<<1024, 256>>>(A[0], npad, 3, 1);
     }
     // ... and does it follow the STORED vector alone?  g from set iw, d and a from set (iw + 1) % KW
     printf("\nresidual (loaded + stored) from set W, direction / diagonal from the NEXT set:\n");
