@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kThreads) void gemv_nt_kernel(const double* __restr
 // One-stream GEMV-N -> GEMV-T over the SAME matrix (onepass_kernel).  For y[row] = M[row, :ncN] . t followed by
 // sums over rows of M[row, j] * v_k[row] (k < NV vectors produced from y by the row functor), a wave keeps a
 // 16-row x (4*CPL)-column tile of M in registers between the two products, so M is streamed from HBM once instead
-// of twice.  No LDS traffic and no barrier in the tile loop; the next tile's loads are issued while the current
+// of twice.  No barrier per tile (two per burst of staged stores, STG below); the next tile's loads are issued while the current
 // tile's second product runs.  Loads go through a buffer descriptor (uniform column base + one 32-bit lane
 // offset), so the tile costs no address registers.
 //   Lane layout (lane bits 5..0 = R R H H r r): row = 4*RR + rr of the tile, column group H; register c of a lane is
