@@ -672,6 +672,16 @@ static int place_grid(lfpsqp_ctx* ctx, lfpsqp_mat* const* mats, int nm, int ncol
     return 0;
 }
 
+// Did no candidate stand out (all trials within 1.5 % of the fastest)?  Pairs come in two kinds about 3.5 % apart (a matrix and a vector
+// slab "collide" or they do not, tools/placement_pairs_probe.py: consecutive slabs tend to be of one kind against a given matrix), so a
+// uniform table may be all collisions -- the callers then try as many vector slabs again, once: a slab is small next to the matrix.
+static bool place_uniform(const double* ms, int n) {
+    if (const char* e = getenv("LFPSQP_PLACEMENT_EXTEND")) return atoi(e) != 0 && n > 1;      // (tests: force / forbid the second batch)
+    double lo = 1e300, hi = 0.0;
+    for (int k = 0; k < n; ++k) { lo = ms[k] < lo ? ms[k] : lo; hi = ms[k] > hi ? ms[k] : hi; }
+    return n > 1 && lo > 0.0 && hi <= 1.015 * lo;
+}
+
 static void place_record(lfpsqp_ctx* ctx, int n, int pick, const double* ms) {
     ctx->place_last_n = n > 64 ? 64 : n;
     ctx->place_last_pick = pick;
@@ -695,7 +705,22 @@ int lfpsqp_vecs_alloc_placed(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols
     int bm = 0, bv = 0;
     double ms[8];
     lfpsqp_mat* mats[1] = {const_cast<lfpsqp_mat*>(M)};
-    const int rc = got > 1 ? place_grid(ctx, mats, 1, (int)ncols, cand, got, cap, &bm, &bv, ms) : 0;
+    int rc = got > 1 ? place_grid(ctx, mats, 1, (int)ncols, cand, got, cap, &bm, &bv, ms) : 0;
+    if (rc == 0 && got == tries && tries > 1 && 2 * tries <= 8 && place_uniform(ms, got)) {      // nobody stood out: as many slabs again
+        int more = 0;
+        for (int k = got; k < 2 * tries; ++k) {
+            if (dev_alloc(&cand[k], bytes) != hipSuccess) { cand[k] = nullptr; (void)hipGetLastError(); break; }
+            ++more;
+            if (hipMemsetAsync(cand[k], 0, bytes, ctx->stream) != hipSuccess) break;
+        }
+        if (more > 0) {
+            int bm2 = 0, bv2 = 0;
+            rc = place_grid(ctx, mats, 1, (int)ncols, cand + got, more, cap, &bm2, &bv2, ms + got);
+            if (more == 1) ms[got] = ms[bv];                      // (a single extra candidate is not timed by place_grid: leave the choice alone)
+            else if (rc == 0 && ms[got + bv2] < ms[bv]) bv = got + bv2;
+            got += more;
+        }
+    }
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < got; ++k)
         if (k != bv) dev_free(cand[k]);
@@ -772,7 +797,31 @@ int lfpsqp_basis_work_alloc_placed(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_
     }
     int bm = 0, bv = 0;
     double ms[64];
-    const int rc = (gm * gv > 1) ? place_grid(ctx, cand, gm, (int)m, slabs, gv, cap, &bm, &bv, ms) : 0;
+    int rc = (gm * gv > 1) ? place_grid(ctx, cand, gm, (int)m, slabs, gv, cap, &bm, &bv, ms) : 0;
+    if (rc == 0 && gm * gv > 1 && gv == tv && tv > 1 && 2 * tv <= 8 && place_uniform(ms, gm * gv)) {   // nobody stood out: as many slabs again
+        int more = 0;
+        for (int k = gv; k < 2 * tv; ++k) {
+            if (dev_alloc(&slabs[k], bytes) != hipSuccess) { slabs[k] = nullptr; (void)hipGetLastError(); break; }
+            ++more;
+            if (hipMemsetAsync(slabs[k], 0, bytes, ctx->stream) != hipSuccess) break;
+        }
+        if (more > 0 && gm * more > 1) {
+            double ms2[64];
+            int bm2 = 0, bv2 = 0;
+            rc = place_grid(ctx, cand, gm, (int)m, slabs + gv, more, cap, &bm2, &bv2, ms2);
+            double all[64];
+            const int nv2 = gv + more;
+            for (int i = 0; i < gm; ++i) {
+                for (int j = 0; j < gv; ++j) all[i * nv2 + j] = ms[i * gv + j];
+                for (int j = 0; j < more; ++j) all[i * nv2 + gv + j] = ms2[i * more + j];
+            }
+            if (rc == 0 && ms2[bm2 * more + bv2] < ms[bm * gv + bv]) { bm = bm2; bv = gv + bv2; }
+            for (int k = 0; k < gm * nv2; ++k) ms[k] = all[k];
+            gv = nv2;
+        } else {
+            for (int k = gv; k < gv + more; ++k) { dev_free(slabs[k]); slabs[k] = nullptr; }
+        }
+    }
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < gm; ++k)
         if (k != bm) lfpsqp_mat_free(ctx, cand[k]);
