@@ -39,20 +39,22 @@ def main(argv=None, lib=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the tangent-setup / Newton-retraction timings (not part of `value`)")
     ap.add_argument("--cpu-sample-n", type=float, default=2e6)
-    ap.add_argument("--comm", choices=["rccl", "p2p", "torch", "host-gloo"], default="rccl",
-                    help="all-reduce transport for N > 1: rccl (library-native, default), p2p (the library's one-shot all-reduce over peer-mapped "
-                         "mailboxes, hipIpc: one exchange instead of a ring; ranks may share one GPU), torch (torch.distributed nccl callback), "
-                         "host-gloo (functional test only: ranks may share one GPU)")
+    ap.add_argument("--comm", choices=["auto", "rccl", "p2p", "torch", "host-gloo"], default="auto",
+                    help="all-reduce transport for N > 1.  auto (default): bring up the library's one-shot peer-to-peer all-reduce (mailboxes mapped "
+                         "through hipIpc: one exchange instead of a ring) AND the library-native RCCL communicator, check each with a known sum, time "
+                         "200 all-reduces of the iteration's payload on each, keep the faster one that works (all ranks agree through the gloo control "
+                         "plane; both latencies are reported in config.comm_probe); rccl / p2p: that transport or fail loudly -- no fallback; torch: "
+                         "torch.distributed nccl callback; host-gloo: functional test only (host-staged; ranks may share one GPU)")
+    ap.add_argument("--p2p-allow-coarse", action="store_true",
+                    help="allow ordinary (coarse-grained) device memory for the p2p mailboxes when fine-grained memory cannot be exported "
+                         "(lfpsqp_comm_p2p_allow_coarse); the kind that was allocated is reported in config.comm either way")
     ap.add_argument("--device", type=int, default=None, help="HIP device index (default: LOCAL_RANK)")
     ap.add_argument("--lib", default=None, help="(development) alternative build of liblfpsqp_hip.so to load")
-    ap.add_argument("--placement", choices=["library", "first", "grid"], default="library",
+    ap.add_argument("--placement", choices=["library", "first"], default="library",
                     help="where the basis and the solver's n-vectors are allocated decides between two speeds of the fused kernel (DESIGN.md 6). "
-                         "library (default): the library's own policy -- lfpsqp_mat_alloc_placed / lfpsqp_vecs_alloc_placed, what optimize() uses; "
-                         "first: plain first allocations (policy off); grid: the round-2 harness (every pair of --basis-candidates x "
-                         "--work-candidates allocations timed from Python, the fastest kept) for comparison")
+                         "library (default): the library's own policy -- lfpsqp_basis_work_alloc_placed, what optimize() uses; "
+                         "first: plain first allocations (policy off)")
     ap.add_argument("--placement-tries", type=int, default=3, help="candidate allocations per placed buffer (lfpsqp_ctx_set_placement)")
-    ap.add_argument("--work-candidates", type=int, default=4, help="--placement grid: candidate sets of the work vectors")
-    ap.add_argument("--basis-candidates", type=int, default=3, help="--placement grid: candidate allocations of the basis")
     ap.add_argument("--watchdog-seconds", type=float, default=1500.0,
                     help="dump every thread's Python stack to stderr and exit non-zero if the run takes longer (0 = off): a stalled "
                          "rendezvous or collective then fails with a diagnosis instead of hanging the caller")
@@ -62,9 +64,15 @@ def main(argv=None, lib=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (no launcher): this process has not touched the GPU (nothing but argparse ran), so it
+        # starts the ranks itself -- one `torch.distributed.run` child, one process per GPU -- relays rank 0's line and exits
+        # with the child's code.  A child process, never an exec: the ranks initialise the GPU, the parent never does.
+        return self_launch(args, argv if argv is not None else sys.argv[1:])
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one process per GPU: "
+                 f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ..., or call "
+                 f"`python bench.py --gpus {args.gpus}` without a launcher and let it start its ranks)")
     watchdog = False
     if args.watchdog_seconds > 0:
         import faulthandler
@@ -90,56 +98,15 @@ def main(argv=None, lib=None):
 
     import lfpsqp_jl_amd as L
 
-    dev_uuid = gpu_uuid() if (rank == 0 and lib is None) else None      # (asked before this process touches the GPU)
     if args.lib:
         lib = L.load_library(args.lib)
     dev = local_rank if args.device is None else args.device
-    ctx = L.Context(dev, lib)
-    comm_used = "none"
+    comm_used, comm_probe = "none", None
     if world > 1:
-        import torch
-        if args.comm == "rccl":
-            # library-native RCCL communicator; the id travels over the gloo control plane.  If ANY rank fails
-            # to bring it up, all ranks agree (gloo) to fall back to the torch.distributed(nccl) callback.
-            ok = 1
-            try:
-                box = [ctx.comm_unique_id() if rank == 0 else None]
-            except L.LfpsqpError as e:
-                box, ok = [None], 0
-                print(f"[bench] rank {rank}: RCCL unique id failed: {e}", file=sys.stderr)
-            dist.broadcast_object_list(box, src=0)
-            if ok and box[0] is not None:
-                try:
-                    ctx.comm_init_rccl(rank, world, box[0])
-                except L.LfpsqpError as e:
-                    ok = 0
-                    print(f"[bench] rank {rank}: native RCCL init failed: {e}", file=sys.stderr)
-            else:
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag[0]) == 1:
-                comm_used = "rccl"
-            else:
-                from lfpsqp_jl_amd.distributed import torch_allreduce_callback
-                torch.cuda.set_device(dev)
-                ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev, dist.new_group(backend="nccl")))
-                comm_used = "torch-nccl-callback (fallback)"
-        elif args.comm == "p2p":
-            box = [None] * world
-            dist.all_gather_object(box, ctx.comm_p2p_export())
-            ctx.comm_init_p2p(rank, world, box)
-            comm_used = "p2p (one-shot all-reduce over hipIpc-mapped mailboxes)"
-        elif args.comm == "torch":
-            from lfpsqp_jl_amd.distributed import torch_allreduce_callback
-            torch.cuda.set_device(dev)
-            ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev, dist.new_group(backend="nccl")))
-            comm_used = "torch-nccl-callback"
-        else:
-            from lfpsqp_jl_amd.distributed import host_staged_allreduce_callback, torch_allreduce_callback
-            emulated = "emulator" in ctx.device_name      # tests/test_bench_harness.py: the library's buffers are host memory
-            ctx.comm_init_callback(rank, world, torch_allreduce_callback(None) if emulated else host_staged_allreduce_callback(dev))
-            comm_used = "host-gloo (functional test)"
+        ctx, comm_used, comm_probe = bring_up_comm(args, L, dist, dev, rank, world, lib)
+    else:
+        ctx = L.Context(dev, lib)
+    dev_uuid = ctx.device_uuid() if rank == 0 else None       # of the device this rank computes on
     r0, r1 = ctx.shard_range(n, rank, world)
     n_loc = r1 - r0
 
@@ -160,46 +127,21 @@ def main(argv=None, lib=None):
     # timed on each, the fastest kept; every rank makes the same calls, the choice is local).
     emulated = "emulator" in ctx.device_name
 
-    def f_ms_on(Uk, Ak, xk, wk, iters=12, warm=400):
-        # (a GPU coming out of idle runs its first ~second several per cent slower: `warm` untimed iterations first)
-        L.projcg_(xk, None, Ak, Uk, b, None, tol=1e-300, maxit=max(2, warm), work=wk, n_global=n, want_lambda=False)
-        ctx.set_profiling(True)
-        L.projcg_(xk, None, Ak, Uk, b, None, tol=1e-300, maxit=iters, work=wk, n_global=n, want_lambda=False)
-        pms, pcnt = ctx.profile_read()
-        ctx.set_profiling(False)
-        slot = 3 if pcnt[3] > 0 else 2
-        return pms[slot] / pcnt[slot] if pcnt[slot] else float("nan")
-
     placement = {"policy": args.placement}
     first_probe = None          # (trial time of the FIRST allocations, trial time of the kept ones): what the policy changed
-    if args.placement == "grid":
-        from lfpsqp_jl_amd.placement import best_projcg_buffers
-        ctx.set_placement(1)
-        A = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.0, 5.0))
-        ncand, nbas = max(1, int(args.work_candidates)), max(1, int(args.basis_candidates))
-        Z, basis_desc, x, work, pinfo = best_projcg_buffers(ctx, make_basis, n_loc, m, A, b, n_global=n, nbasis=nbas, nwork=ncand,
-                                                            try_alternating=(world == 1))
-        flat = sorted(t for row in pinfo["grid"] for t in row)
-        first_probe = (pinfo["grid"][0][0], pinfo["grid"][pinfo["basis"]][pinfo["work"]]) if len(flat) > 1 else None
-        placement.update({"basis_candidates": nbas, "work_candidates": ncand, "chosen": [pinfo["basis"], pinfo["work"]],
-                          "trial_grid_F_ms": [[round(t, 4) for t in row] for row in pinfo["grid"]],
-                          "grid_min_median_max_F_ms": [round(flat[0], 4), round(flat[len(flat) // 2], 4), round(flat[-1], 4)],
-                          "residual_buffers": ("alternating" if pinfo.get("residual_buffers") else "in place"),
-                          "note": "round-2 harness: every (basis, work set) pair timed from Python, the fastest kept"})
-    else:
-        tries = 1 if args.placement == "first" else max(1, args.placement_tries)
-        ctx.set_placement(tries)
-        work = L.ProjCGWork(ctx, n_loc, m, against=("new", n_loc, m), extra=1)       # the basis and its work vectors, allocated together
-        pt = ctx.placement_info()
-        Z, basis_desc = make_basis(Zc=work.basis)
-        A = L.DiagOperator(0.0, work.placed_extra[0].hash_fill(3, r0, 4.0, 5.0))
-        x = ctx.vector(n_loc)
-        flat = sorted(pt[2])
-        first_probe = (pt[2][0], pt[2][pt[1]]) if len(pt[2]) > 1 else None
-        placement.update({"tries_per_buffer": tries, "pairs_tried": pt[0], "kept_pair": pt[1], "probe_F_ms": [round(t, 4) for t in pt[2]],
-                          "probe_min_median_max_F_ms": ([round(flat[0], 4), round(flat[len(flat) // 2], 4), round(flat[-1], 4)] if flat else None),
-                          "note": "lfpsqp_basis_work_alloc_placed: every (basis candidate, work-vector-set candidate) pair tried with the fused kernel "
-                                  "itself (on zeros, two rounds), the fastest pair kept -- the same call optimize() makes for Z and ProjCGWork"})
+    tries = 1 if args.placement == "first" else max(1, args.placement_tries)
+    ctx.set_placement(tries)
+    work = L.ProjCGWork(ctx, n_loc, m, against=("new", n_loc, m), extra=1)       # the basis and its work vectors, allocated together
+    pt = ctx.placement_info()
+    Z, basis_desc = make_basis(Zc=work.basis)
+    A = L.DiagOperator(0.0, work.placed_extra[0].hash_fill(3, r0, 4.0, 5.0))
+    x = ctx.vector(n_loc)
+    flat = sorted(pt[2])
+    first_probe = (pt[2][0], pt[2][pt[1]]) if len(pt[2]) > 1 else None
+    placement.update({"tries_per_buffer": tries, "pairs_tried": pt[0], "kept_pair": pt[1], "probe_F_ms": [round(t, 4) for t in pt[2]],
+                      "probe_min_median_max_F_ms": ([round(flat[0], 4), round(flat[len(flat) // 2], 4), round(flat[-1], 4)] if flat else None),
+                      "note": "lfpsqp_basis_work_alloc_placed: every (basis candidate, work-vector-set candidate) pair tried with the fused kernel "
+                              "itself (on zeros, two rounds), the fastest pair kept -- the same call optimize() makes for Z and ProjCGWork"})
     U = L.DeviceBasis(Z)
 
     def barrier():
@@ -323,7 +265,7 @@ def main(argv=None, lib=None):
                    "placement": placement,
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
-                   "comm": comm_used, "device": ctx.device_name, "device_uuid": dev_uuid},
+                   "comm": comm_used, "comm_probe": comm_probe, "device": ctx.device_name, "device_uuid": dev_uuid},
         "roofline": ({"bound": "hbm", "kernel": "onepass_kernel<PcgFuseE> (F: rp = g + alpha*A*d, gp = rp - U*Utr, g = gp, U'gp, U'(A gp): "
                                                  "ONE pass over U per projected-CG iteration)",
                       "achieved": gbs(bytes_kf, kf), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -399,18 +341,180 @@ def main(argv=None, lib=None):
     return out
 
 
-def gpu_uuid():
-    """Uuid of the first GPU agent (rocminfo): boxes differ (on some GPUs every allocation pair runs the fused kernel at the slow
-    speed), so a bench line says which device it was measured on."""
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: run the N ranks as ONE child (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>`), pass its stdout (rank 0's JSON
+    line) and stderr through, return its exit code.  Nothing here initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL / hipIpc between the ranks)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print("[bench] --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    import signal
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)      # its own process group: a timeout ends the launcher AND its ranks
     try:
-        import subprocess
-        out = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=20).stdout
-        for line in out.splitlines():
-            if "Uuid:" in line and "GPU-" in line:
-                return line.split()[-1]
-    except Exception:
-        pass
+        # the ranks' own watchdogs end a stalled run with a diagnosis; this limit only backs them up
+        rc = child.wait(timeout=(args.watchdog_seconds + 120.0) if args.watchdog_seconds > 0 else None)
+    except subprocess.TimeoutExpired:
+        print("[bench] the ranks did not finish in time", file=sys.stderr)
+        os.killpg(child.pid, signal.SIGKILL)
+        child.wait()
+        rc = 124
+    except KeyboardInterrupt:
+        os.killpg(child.pid, signal.SIGTERM)
+        child.wait()
+        raise
+    if rc != 0:
+        sys.exit(rc)
     return None
+
+
+def bring_up_comm(args, L, dist, dev, rank, world, lib):
+    """The all-reduce transport of an N-rank run -> (context, description, probe record).  Every decision is taken from values all ranks
+    share (gloo all-reduces on the control plane), so the ranks cannot disagree about the transport; a transport that was ASKED for by
+    name fails loudly instead of falling back."""
+    import torch
+    m_pay = 2 * args.m + 5                                     # the projected-CG iteration's payload (doubles)
+
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag[0]) == 1
+
+    def check_and_time(ctx, reps=200):
+        """a known sum (rank r contributes r + 1 + j/1024 in slot j) -> (correct on every rank, microseconds per all-reduce, max over ranks)"""
+        import numpy as np
+        ok, us = True, float("inf")
+        try:
+            v = ctx.vector(m_pay, (rank + 1.0) + np.arange(m_pay) / 1024.0)
+            ctx.check(ctx.L.lfpsqp_allreduce(ctx.h, v.h, m_pay))
+            want = world * (world + 1) / 2.0 + world * np.arange(m_pay) / 1024.0
+            ok = bool(np.array_equal(v.download(), want))             # (exact: small dyadic rationals)
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.check(ctx.L.lfpsqp_allreduce(ctx.h, v.h, m_pay))
+            ctx.sync()
+            us = (time.perf_counter() - t0) / reps * 1e6
+            v.free()
+        except L.LfpsqpError as e:
+            print(f"[bench] rank {rank}: all-reduce check failed: {e}", file=sys.stderr)
+            ok = False
+        t = torch.tensor([us], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return agree(ok), float(t[0])
+
+    def try_p2p():
+        ctx = L.Context(dev, lib)
+        ok, kind = True, "none"
+        try:
+            if args.p2p_allow_coarse:
+                ctx.comm_p2p_allow_coarse(True)
+            handle = ctx.comm_p2p_export()
+        except L.LfpsqpError as e:
+            print(f"[bench] rank {rank}: p2p mailbox export failed: {e}", file=sys.stderr)
+            ok, handle = False, b"\0" * 64
+        box = [None] * world
+        dist.all_gather_object(box, handle)
+        if agree(ok):
+            try:
+                ctx.comm_init_p2p(rank, world, box)
+                kind = ctx.comm_p2p_info()[0]
+            except L.LfpsqpError as e:
+                print(f"[bench] rank {rank}: p2p init failed: {e}", file=sys.stderr)
+                ok = False
+            ok = agree(ok)
+        else:
+            ok = False
+        kinds = [None] * world
+        dist.all_gather_object(kinds, kind)
+        return ctx, ok, "/".join(sorted(set(kinds)))
+
+    def try_rccl():
+        ctx = L.Context(dev, lib)
+        ok = True
+        try:
+            box = [ctx.comm_unique_id() if rank == 0 else None]
+        except L.LfpsqpError as e:
+            box, ok = [None], False
+            print(f"[bench] rank {rank}: RCCL unique id failed: {e}", file=sys.stderr)
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            ok = False
+        if agree(ok):
+            try:
+                ctx.comm_init_rccl(rank, world, box[0])
+            except L.LfpsqpError as e:
+                ok = False
+                print(f"[bench] rank {rank}: native RCCL init failed: {e}", file=sys.stderr)
+            ok = agree(ok)
+        else:
+            ok = False
+        return ctx, ok
+
+    if args.comm == "host-gloo":
+        from lfpsqp_jl_amd.distributed import host_staged_allreduce_callback, torch_allreduce_callback
+        ctx = L.Context(dev, lib)
+        emulated = "emulator" in ctx.device_name      # tests/test_bench_harness.py: the library's buffers are host memory
+        ctx.comm_init_callback(rank, world, torch_allreduce_callback(None) if emulated else host_staged_allreduce_callback(dev))
+        return ctx, "host-gloo (functional test)", None
+    if args.comm == "torch":
+        from lfpsqp_jl_amd.distributed import torch_allreduce_callback
+        ctx = L.Context(dev, lib)
+        torch.cuda.set_device(dev)
+        ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev, dist.new_group(backend="nccl")))
+        return ctx, "torch-nccl-callback", None
+    devs = [None] * world
+    dist.all_gather_object(devs, dev)
+    shared = len(set(devs)) < world                  # ranks sharing a GPU (the 1-GPU functional runs): RCCL refuses duplicate devices
+    probe = {"payload_doubles": m_pay, "ranks_share_a_gpu": shared}
+    cands = []
+    if args.comm in ("auto", "p2p"):
+        ctx, ok, kind = try_p2p()
+        us = None
+        if ok:
+            ok, us = check_and_time(ctx)
+        probe["p2p"] = {"ok": ok, "mailbox_memory": kind, "us_per_allreduce": us}
+        if ok:
+            cands.append((us, "p2p", ctx, f"p2p (one-shot all-reduce over hipIpc-mapped mailboxes, {kind} memory)"))
+        else:
+            ctx.close()
+            if args.comm == "p2p":
+                sys.exit("bench.py --comm p2p: the peer-to-peer transport did not come up on every rank (see stderr); no fallback for a transport asked for by name")
+    if args.comm == "rccl" or (args.comm == "auto" and not shared):
+        ctx, ok = try_rccl()
+        us = None
+        if ok:
+            ok, us = check_and_time(ctx)
+        probe["rccl"] = {"ok": ok, "us_per_allreduce": us}
+        if ok:
+            cands.append((us, "rccl", ctx, "rccl (library-native communicator)"))
+        else:
+            ctx.close()
+            if args.comm == "rccl":
+                sys.exit("bench.py --comm rccl: the RCCL communicator did not come up on every rank (see stderr); no fallback for a transport asked for by name")
+    elif args.comm == "auto":
+        probe["rccl"] = {"ok": False, "skipped": "ranks share a GPU"}
+    if cands:
+        cands.sort(key=lambda c: c[0])               # (times are max-over-ranks values: identical on every rank)
+        for c in cands[1:]:
+            c[2].close()
+        probe["chosen"] = cands[0][1]
+        return cands[0][2], cands[0][3] + (" [auto: faster of the transports that passed their check]" if args.comm == "auto" else ""), probe
+    # auto, and neither library transport works: LOUDLY down to the torch callback
+    print("[bench] WARNING: neither the p2p nor the RCCL transport of the library came up; falling back to the torch.distributed(nccl) callback",
+          file=sys.stderr, flush=True)
+    from lfpsqp_jl_amd.distributed import torch_allreduce_callback
+    ctx = L.Context(dev, lib)
+    torch.cuda.set_device(dev)
+    ctx.comm_init_callback(rank, world, torch_allreduce_callback(dev, dist.new_group(backend="nccl")))
+    probe["chosen"] = "torch"
+    return ctx, "torch-nccl-callback (FALLBACK: library transports failed)", probe
 
 
 def shape_name(n, m):

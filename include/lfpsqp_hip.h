@@ -53,6 +53,8 @@ int lfpsqp_ctx_sync(lfpsqp_ctx* ctx); /* wait for the context's stream */
 const char* lfpsqp_last_error(const lfpsqp_ctx* ctx);
 /* name of the device the context runs on ("cpu-emulator" only in the test build) */
 int lfpsqp_device_name(const lfpsqp_ctx* ctx, char* buf, int64_t buflen);
+/* "GPU-<16 hex digits>" (as rocminfo prints it) of the device this context computes on; buflen >= 40 */
+int lfpsqp_device_uuid(const lfpsqp_ctx* ctx, char* buf, int64_t buflen);
 /* streaming-kernel variant: ks = 16-byte row pairs per lane (2 or 4; tile = 512*ks rows; 0 = auto: 4 for
  * >= 4M local rows, else 2), nt != 0 = non-temporal loads of the matrix stream.  Results are bit-identical
  * across nt, and differ only in summation order across ks.  Default (auto, 1), DESIGN.md §5. */
@@ -91,6 +93,16 @@ int lfpsqp_comm_init_callback(lfpsqp_ctx* ctx, int rank, int nranks, lfpsqp_allr
  * bytes, in rank order) maps them.  One node (xGMI / PCIe peers), at most 16 ranks; ranks may also share a GPU (the 1-GPU test). */
 int lfpsqp_comm_p2p_export(lfpsqp_ctx* ctx, void* handle64);
 int lfpsqp_comm_init_p2p(lfpsqp_ctx* ctx, int rank, int nranks, const void* handles);
+/* Required order: export (zero-fills the mailbox; complete before it returns) -> handles to all ranks -> init_p2p -> collectives; no barrier
+ * is needed before the first collective (a peer writes only its own mailbox).  A context takes ONE communicator: a second init is an error.
+ * The mailbox is FINE-GRAINED (uncached) device memory; if the runtime cannot allocate or export that kind, export fails with
+ * LFPSQP_ERR_COMM unless coarse-grained memory was allowed beforehand (allow_coarse(ctx, 1), or LFPSQP_P2P_ALLOW_COARSE=1 in the
+ * environment) -- never silently.  p2p_info: *mem_kind = LFPSQP_P2P_MEM_* of this rank's mailbox, *collectives = all-reduce launches so far. */
+#define LFPSQP_P2P_MEM_NONE 0
+#define LFPSQP_P2P_MEM_FINE 1   /* hipExtMallocWithFlags(hipDeviceMallocUncached) */
+#define LFPSQP_P2P_MEM_COARSE 2 /* hipMalloc (explicitly allowed fallback) */
+int lfpsqp_comm_p2p_allow_coarse(lfpsqp_ctx* ctx, int allow);
+int lfpsqp_comm_p2p_info(const lfpsqp_ctx* ctx, int* mem_kind, unsigned long long* collectives);
 int lfpsqp_comm_info(const lfpsqp_ctx* ctx, int* rank, int* nranks);
 
 /* ---- buffers ------------------------------------------------------------- */
@@ -351,6 +363,13 @@ typedef struct lfpsqp_projcg_work {
  * ran the one-pass iteration and returned by the iteration limit, with no other library call in between; otherwise
  * LFPSQP_ERR_UNSUPPORTED.  (bench.py times K iterations of a running solve with it; optimize never needs it.) */
 #define LFPSQP_PROJCG_RESUME 2
+
+/* Can lfpsqp_projcg run on a basis kept in FACTORED form (lfpsqp_basis.Z == NULL, generator A (N rows) and W given; SA = the sparse twin of
+ * A's leading columns, or NULL) with a diagonal operator on THIS context?  *yes = 1 / 0.  The factored form needs the fused one-pass
+ * iteration over A (4 .. 1024 columns, leading dimension inside the 32-bit lane offsets, one-pass kernels not switched off by
+ * lfpsqp_ctx_set_onepass / LFPSQP_ONEPASS=-1) or, with SA, a twin whose shape the nonzero path covers.  Callers (optimize) ask BEFORE they
+ * decide not to allocate Z; a "no" means: materialise Z = A W (lfpsqp_factorize with Z != NULL), every path then has its two-pass form. */
+int lfpsqp_factored_basis_supported(const lfpsqp_ctx* ctx, const lfpsqp_mat* A, const lfpsqp_spmat* SA, int* yes);
 
 /* projcg!(x, lambda, A, U, b, c; tol, maxit, work) -> (iters, nr).
  * c == NULL means c = 0 (always the case in optimize, src/optimize.jl:213,368,371).

@@ -107,6 +107,7 @@ c_ctx_destroy(ctx) = ccall((:lfpsqp_ctx_destroy, lib), Cint, (Ptr{Cvoid},), ctx)
 c_ctx_sync(ctx) = ccall((:lfpsqp_ctx_sync, lib), Cint, (Ptr{Cvoid},), ctx)
 c_last_error(ctx) = ccall((:lfpsqp_last_error, lib), Cstring, (Ptr{Cvoid},), ctx)
 c_device_name(ctx, buf, len) = ccall((:lfpsqp_device_name, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64), ctx, buf, len)
+c_device_uuid(ctx, buf, len) = ccall((:lfpsqp_device_uuid, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64), ctx, buf, len)
 c_ctx_set_tuning(ctx, ks, nt) = ccall((:lfpsqp_ctx_set_tuning, lib), Cint, (Ptr{Cvoid}, Cint, Cint), ctx, ks, nt)
 c_ctx_set_onepass(ctx, mode) = ccall((:lfpsqp_ctx_set_onepass, lib), Cint, (Ptr{Cvoid}, Cint), ctx, mode)
 c_ctx_set_residual_buffers(ctx, mode) = ccall((:lfpsqp_ctx_set_residual_buffers, lib), Cint, (Ptr{Cvoid}, Cint), ctx, mode)
@@ -123,6 +124,8 @@ c_comm_init_callback(ctx, rank, nranks, fn, user) = ccall((:lfpsqp_comm_init_cal
 c_comm_info(ctx, rank, nranks) = ccall((:lfpsqp_comm_info, lib), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), ctx, rank, nranks)
 c_comm_p2p_export(ctx, handle) = ccall((:lfpsqp_comm_p2p_export, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}), ctx, handle)
 c_comm_init_p2p(ctx, rank, nranks, handles) = ccall((:lfpsqp_comm_init_p2p, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx, rank, nranks, handles)
+c_comm_p2p_allow_coarse(ctx, allow) = ccall((:lfpsqp_comm_p2p_allow_coarse, lib), Cint, (Ptr{Cvoid}, Cint), ctx, allow)
+c_comm_p2p_info(ctx, kind, count) = ccall((:lfpsqp_comm_p2p_info, lib), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Culonglong}), ctx, kind, count)
 # ---- buffers -----------------------------------------------------------------------------------------------------------
 c_vec_alloc(ctx, n, out) = ccall((:lfpsqp_vec_alloc, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), ctx, n, out)
 c_vec_free(ctx, v) = ccall((:lfpsqp_vec_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx, v)
@@ -190,6 +193,7 @@ c_small_svd(ctx, rows, cols, A, U, S, V) = ccall((:lfpsqp_small_svd, lib), Cint,
 c_q_gemv_t(ctx, Q, v, w, t) = ccall((:lfpsqp_q_gemv_t, lib), Cint, (Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, Q, v, w, t)
 c_q_gemv_n(ctx, Q, a, w, t, b, y) = ccall((:lfpsqp_q_gemv_n, lib), Cint, (Ptr{Cvoid}, Ref{CBasis}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}), ctx, Q, a, w, t, b, y)
 # ---- solvers -------------------------------------------------------------------------------------------------------------------
+c_factored_basis_supported(ctx, A, SA, yes) = ccall((:lfpsqp_factored_basis_supported, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cint}), ctx, A, SA, yes)
 c_projcg(ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg, lib), Cint,
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CDiagOp}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
     ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
@@ -252,6 +256,13 @@ function comm_p2p_export(ctx::HipContext)
     h = Vector{UInt8}(undef, 64)
     check(ctx, c_comm_p2p_export(ctx.h, h))
     return h
+end
+comm_p2p_allow_coarse!(ctx::HipContext, allow::Bool=true) = (check(ctx, c_comm_p2p_allow_coarse(ctx.h, Cint(allow))); ctx)
+# (memory kind of this rank's mailbox -- :fine, :coarse or :none --, all-reduce launches so far)
+function comm_p2p_info(ctx::HipContext)
+    k = Ref{Cint}(0); cnt = Ref{Culonglong}(0)
+    check(ctx, c_comm_p2p_info(ctx.h, k, cnt))
+    return ((:none, :fine, :coarse)[k[] + 1], cnt[])
 end
 function comm_init_p2p!(ctx::HipContext, rank::Integer, nranks::Integer, handles::Vector{UInt8})
     length(handles) == 64 * nranks || error("handles must hold 64 bytes per rank, in rank order")
@@ -458,6 +469,12 @@ end
 Base.adjoint(U::DeviceBasis) = DeviceBasisAdjoint(U)
 Base.adjoint(Ut::DeviceBasisAdjoint) = Ut.U
 # kgemv! (src/la_helper.jl:36-44) and the mul! calls of src/projcg.jl / src/retractions.jl
+# can projcg! run on a basis kept in factored form U = A W (no Z) on this context?  (lfpsqp_factored_basis_supported)
+function factored_basis_supported(ctx::HipContext, A::DeviceMatrix, SA::Ptr{Cvoid}=C_NULL)
+    yes = Ref{Cint}(0)
+    check(ctx, c_factored_basis_supported(ctx.h, A.h, SA, yes))
+    return yes[] != 0
+end
 # (a basis that carries its generator and the generator's sparse twin is applied in factored form on the nonzeros: lfpsqp_q_gemv_*)
 factored(U::DeviceBasis) = U.generator !== nothing && (U.sparse != C_NULL || U.Z === nothing)
 mul!(y::DeviceVector, U::DeviceBasis, t::DeviceVector, a::Number=1.0, b::Number=0.0) =
@@ -1187,7 +1204,9 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     # by trial over pairs of candidate allocations (DESIGN.md 6)
     # ... unless the basis can stay in FACTORED form U = Jct W (DESIGN.md 5.3): no Z at all, the tangent setup skips its basis-forming product,
     # and the work vectors are placed against Jct
-    factored_basis = ctx.options.factored_basis && diagonal_hessian && 4 <= m <= 1024      # (with a sparse twin: on the nonzeros, no Z either)
+    # (the library says whether this context can run projcg! without Z for this Jct: one-pass kernels on, shape inside their limits, or a
+    # sparse twin the nonzero path covers; otherwise Z is materialised and every path has its two-pass form)
+    factored_basis = ctx.options.factored_basis && diagonal_hessian && 4 <= m <= 1024 && factored_basis_supported(ctx, Jct, jsp === nothing ? C_NULL : jsp.h)
     if factored_basis
         vs = vectors_placed(ctx, Jct, ineq ? 0 : n, 5; N=ineq ? n : 0)
         projcgwork = ProjCGWork(vs[1], vs[2], vs[4], DeviceVector(ctx, max(m, 1)), vs[5])

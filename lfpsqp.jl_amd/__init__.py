@@ -18,4 +18,3 @@ from .projpenalty import ProjPenalty, ProjPenaltyWork, no_precondition, pcg_, pr
 from .linesearch import ArmijoWork, ExactLinesearchWork, armijo_, exact_linesearch_  # noqa: F401
 from .optimize import optimize_core  # noqa: F401
 from .problems import Derivatives, QuadLinearBallBox, SeparableElementwiseBox, SeparableLinearBallBox, optimize  # noqa: F401
-from .placement import best_projcg_buffers  # noqa: F401

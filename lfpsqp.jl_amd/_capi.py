@@ -59,8 +59,10 @@ _SIGS = {
     "lfpsqp_ctx_sync": [P],
     "lfpsqp_ctx_set_tuning": [P, C.c_int, C.c_int],
     "lfpsqp_ctx_set_onepass": [P, C.c_int],
+    "lfpsqp_factored_basis_supported": [P, P, P, C.POINTER(C.c_int)],
     "lfpsqp_ctx_set_residual_buffers": [P, C.c_int],
     "lfpsqp_device_name": [P, C.c_char_p, c_i64],
+    "lfpsqp_device_uuid": [P, C.c_char_p, c_i64],
     "lfpsqp_timer_begin": [P],
     "lfpsqp_timer_end": [P, PD],
     "lfpsqp_shard_range": [c_i64, C.c_int, C.c_int, C.POINTER(c_i64), C.POINTER(c_i64)],
@@ -69,6 +71,8 @@ _SIGS = {
     "lfpsqp_comm_init_callback": [P, C.c_int, C.c_int, ALLREDUCE_FN, P],
     "lfpsqp_comm_p2p_export": [P, P],
     "lfpsqp_comm_init_p2p": [P, C.c_int, C.c_int, P],
+    "lfpsqp_comm_p2p_allow_coarse": [P, C.c_int],
+    "lfpsqp_comm_p2p_info": [P, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)],
     "lfpsqp_comm_info": [P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "lfpsqp_vec_alloc": [P, c_i64, C.POINTER(P)],
     "lfpsqp_vec_free": [P, P],

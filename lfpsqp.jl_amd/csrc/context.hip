@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <ctype.h>
 #include <string.h>
 
 #include <algorithm>
@@ -115,36 +116,42 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine->data) + i, __builtin_bit_cast(unsigned long long, a.buf[i]), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();
+    __shared__ volatile int ok;             // cleared by any lane whose peer did not arrive (the only writers after the barrier all write 0)
+    if (threadIdx.x == 0) ok = 1;
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&mine->flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    __shared__ int ok;
-    double acc[kP2PSlot / 256];
-    for (int r = 0; r < a.nranks; ++r) {
-        P2PSlot* s = &a.box[r]->slot[a.seq & 1];
-        if (threadIdx.x == 0) {
-            ok = 1;
-            if (r != a.rank) {
-                const long long t0 = wall_clock64();
-                while (__hip_atomic_load(&s->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
-                    if (wall_clock64() - t0 > a.timeout_ticks) { ok = 0; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
+    // every peer's flag is awaited by a lane of its own, all at once: the wait costs the slowest peer's arrival plus ONE round trip over the
+    // links, not one round trip per peer
+    if ((int)threadIdx.x < a.nranks && (int)threadIdx.x != a.rank) {
+        const unsigned long long* f = &a.box[threadIdx.x]->slot[a.seq & 1].flag;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+            if (wall_clock64() - t0 > a.timeout_ticks) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
         }
-        __syncthreads();
-        if (!ok) {                              // a peer never arrived: poison the result, tell the host, do not hang the device
-            if (threadIdx.x == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            for (int i = threadIdx.x; i < a.count; i += 256) a.buf[i] = NAN;
-            return;
-        }
-        for (int i = threadIdx.x, k = 0; i < a.count; i += 256, ++k) {
-            const double v = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<unsigned long long*>(s->data) + i, __ATOMIC_RELAXED,
-                                                                          __HIP_MEMORY_SCOPE_SYSTEM));
-            acc[k] = (r == 0) ? v : (a.op == 1 ? nanmax(acc[k], v) : acc[k] + v);
-        }
-        __syncthreads();
     }
-    for (int i = threadIdx.x, k = 0; i < a.count; i += 256, ++k) a.buf[i] = acc[k];
+    __threadfence_system();
+    __syncthreads();
+    if (!ok) {   // a peer never arrived: poison the result, tell the host, do not hang the device
+        if (threadIdx.x == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int i = threadIdx.x; i < a.count; i += 256) a.buf[i] = NAN;
+        return;
+    }
+    // the payloads of all ranks are requested together (independent loads, one round trip) and added in FIXED rank order 0, 1, 2, ...:
+    // the same bits on every rank, and the same bits as any other transport that adds in that order
+    for (int i = threadIdx.x; i < a.count; i += 256) {
+        double v[kP2PMaxRanks];
+#pragma unroll
+        for (int r = 0; r < kP2PMaxRanks; ++r)
+            if (r < a.nranks)
+                v[r] = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<unsigned long long*>(a.box[r]->slot[a.seq & 1].data) + i,
+                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        double acc = v[0];
+#pragma unroll
+        for (int r = 1; r < kP2PMaxRanks; ++r)
+            if (r < a.nranks) acc = (a.op == 1) ? nanmax(acc, v[r]) : acc + v[r];
+        a.buf[i] = acc;
+    }
 }
 
 static int p2p_allreduce(lfpsqp_ctx* ctx, double* buf, int64_t count, int op) {
@@ -403,6 +410,26 @@ int lfpsqp_device_name(const lfpsqp_ctx* ctx, char* buf, int64_t buflen) {
     return 0;
 }
 
+// "GPU-<16 hex digits>" as rocminfo / rocm-smi print it, of the device THIS context computes on (hipDeviceGetUuid: the 16 bytes are the
+// hex digits themselves on AMD devices; anything else is hex-encoded)
+int lfpsqp_device_uuid(const lfpsqp_ctx* ctx, char* buf, int64_t buflen) {
+    if (!ctx || !buf || buflen < 40) return LFPSQP_ERR_ARG;
+    hipUUID id;
+    memset(&id, 0, sizeof(id));
+    hipDevice_t d;
+    if (hipDeviceGet(&d, ctx->device) != hipSuccess || hipDeviceGetUuid(&id, d) != hipSuccess) {
+        (void)hipGetLastError();
+        snprintf(buf, (size_t)buflen, "unknown");
+        return 0;
+    }
+    bool hexchars = true;
+    for (int i = 0; i < 16; ++i) hexchars = hexchars && isxdigit((unsigned char)id.bytes[i]);
+    int o = snprintf(buf, (size_t)buflen, "GPU-");
+    for (int i = 0; i < 16; ++i)
+        o += hexchars ? snprintf(buf + o, (size_t)buflen - o, "%c", id.bytes[i]) : snprintf(buf + o, (size_t)buflen - o, "%02x", (unsigned char)id.bytes[i]);
+    return 0;
+}
+
 int lfpsqp_timer_begin(lfpsqp_ctx* ctx) {
     LF_ARG(ctx, ctx != nullptr);
     LF_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
@@ -537,23 +564,54 @@ int lfpsqp_comm_p2p_export(lfpsqp_ctx* ctx, void* handle64) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the header promises a 64-byte handle");
     hipIpcMemHandle_t h;
     if (!c.p2p_mine) {
-        // fine-grained (uncached) device memory first; if the runtime will not export that kind, ordinary device memory: every access of the
-        // protocol is a system-scope atomic either way
-        if (hipExtMallocWithFlags(&c.p2p_mine, sizeof(P2PBox), hipDeviceMallocUncached) != hipSuccess || hipIpcGetMemHandle(&h, c.p2p_mine) != hipSuccess) {
+        // Fine-grained (uncached) device memory: no cache between a peer and the mailbox.  If the runtime cannot allocate or export that
+        // kind, the call FAILS -- unless ordinary (coarse-grained) device memory was explicitly allowed (lfpsqp_comm_p2p_allow_coarse /
+        // LFPSQP_P2P_ALLOW_COARSE=1): every access of the protocol is a system-scope atomic either way, and ranks sharing ONE GPU work with
+        // it, but across xGMI that kind is untested, so it is never chosen silently.  lfpsqp_comm_p2p_info reports what was allocated.
+        hipError_t e = hipExtMallocWithFlags(&c.p2p_mine, sizeof(P2PBox), hipDeviceMallocUncached);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&h, c.p2p_mine);
+        c.p2p_memkind = LFPSQP_P2P_MEM_FINE;
+        if (e != hipSuccess) {
             (void)hipGetLastError();
             if (c.p2p_mine) (void)hipFree(c.p2p_mine);
             c.p2p_mine = nullptr;
+            c.p2p_memkind = LFPSQP_P2P_MEM_NONE;
+            const char* env = getenv("LFPSQP_P2P_ALLOW_COARSE");
+            if (!(c.p2p_allow_coarse || (env && atoi(env) > 0)))
+                return set_err(ctx, LFPSQP_ERR_COMM, "P2P mailbox: fine-grained (uncached) device memory cannot be allocated / exported through hipIpc (%s); "
+                               "coarse-grained memory was not allowed (lfpsqp_comm_p2p_allow_coarse, LFPSQP_P2P_ALLOW_COARSE=1)", hipGetErrorString(e));
             LF_HIP(ctx, hipMalloc(&c.p2p_mine, sizeof(P2PBox)));
+            c.p2p_memkind = LFPSQP_P2P_MEM_COARSE;
         }
         LF_HIP(ctx, hipMemset(c.p2p_mine, 0, sizeof(P2PBox)));
+        LF_HIP(ctx, hipDeviceSynchronize());      // the zeros are in memory before the handle leaves this process
     }
     LF_HIP(ctx, hipIpcGetMemHandle(&h, c.p2p_mine));
     memcpy(handle64, &h, 64);
     return 0;
 }
+int lfpsqp_comm_p2p_allow_coarse(lfpsqp_ctx* ctx, int allow) {
+    if (!ctx) return LFPSQP_ERR_ARG;
+    ctx->comm.p2p_allow_coarse = allow != 0;
+    return 0;
+}
+int lfpsqp_comm_p2p_info(const lfpsqp_ctx* ctx, int* mem_kind, unsigned long long* collectives) {
+    if (!ctx) return LFPSQP_ERR_ARG;
+    if (mem_kind) *mem_kind = ctx->comm.p2p_memkind;
+    if (collectives) *collectives = ctx->comm.p2p_seq;
+    return 0;
+}
+// Ordering the transport relies on (documented in the header): export zero-fills the mailbox and completes before the handle is returned; a
+// peer can touch my mailbox only after it received that handle; its first collective WRITES only its own mailbox and READS mine.  So no
+// barrier is needed between init and the first collective.  A context is initialised ONCE: a second init (a re-rendezvous after a timeout)
+// would restart the sequence numbers over mailboxes that still hold flags of the first life, and waits would pass on stale slots --
+// rejected; create a new context instead.
 int lfpsqp_comm_init_p2p(lfpsqp_ctx* ctx, int rank, int nranks, const void* handles) {
     LF_ARG(ctx, ctx && handles && nranks >= 1 && nranks <= kP2PMaxRanks && rank >= 0 && rank < nranks && ctx->comm.p2p_mine);
     Comm& c = ctx->comm;
+    if (c.kind != Comm::NONE)
+        return set_err(ctx, LFPSQP_ERR_ARG, "lfpsqp_comm_init_p2p: this context already has a communicator (a P2P communicator cannot be "
+                       "re-initialised: its mailboxes keep the sequence flags of their first life); create a new context");
     for (int r = 0; r < nranks; ++r) {
         if (r == rank) { c.p2p_peer[r] = c.p2p_mine; continue; }
         hipIpcMemHandle_t h;
@@ -682,6 +740,21 @@ static bool place_uniform(const double* ms, int n) {
     return n > 1 && lo > 0.0 && hi <= 1.015 * lo;
 }
 
+// one zero-filled candidate slab; a candidate that could not be allocated OR zeroed does not exist (nothing is left behind)
+static bool slab_alloc_zeroed(lfpsqp_ctx* ctx, void** p, size_t bytes) {
+    *p = nullptr;
+    if (dev_alloc(p, bytes) != hipSuccess) { *p = nullptr; (void)hipGetLastError(); return false; }
+    if (hipMemsetAsync(*p, 0, bytes, ctx->stream) != hipSuccess) { (void)hipGetLastError(); dev_free(*p); *p = nullptr; return false; }
+    return true;
+}
+// A trial that FAILED (a launch or an event error inside place_grid) is "no preference": the first candidates are kept and the allocation
+// succeeds -- the policy is an optimisation, its failure must neither fail nor leak the allocation it serves.
+static void place_no_preference(lfpsqp_ctx* ctx, int* bm, int* bv) {
+    (void)hipGetLastError();
+    *bm = 0; *bv = 0;
+    ctx->place_last_n = 0;
+}
+
 static void place_record(lfpsqp_ctx* ctx, int n, int pick, const double* ms) {
     ctx->place_last_n = n > 64 ? 64 : n;
     ctx->place_last_pick = pick;
@@ -697,36 +770,36 @@ int lfpsqp_vecs_alloc_placed(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols
     void* cand[8] = {nullptr};
     int got = 0;
     for (int k = 0; k < tries; ++k) {
-        if (dev_alloc(&cand[k], bytes) != hipSuccess) { cand[k] = nullptr; (void)hipGetLastError(); break; }
+        if (!slab_alloc_zeroed(ctx, &cand[got], bytes)) break;
         ++got;
-        if (hipMemsetAsync(cand[k], 0, bytes, ctx->stream) != hipSuccess) break;
     }
     if (got == 0) return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%d vectors of %lld doubles) failed", count, (long long)n);
     int bm = 0, bv = 0;
-    double ms[8];
+    double ms[8] = {0};
     lfpsqp_mat* mats[1] = {const_cast<lfpsqp_mat*>(M)};
-    int rc = got > 1 ? place_grid(ctx, mats, 1, (int)ncols, cand, got, cap, &bm, &bv, ms) : 0;
-    if (rc == 0 && got == tries && tries > 1 && 2 * tries <= 8 && place_uniform(ms, got)) {      // nobody stood out: as many slabs again
+    bool trial_ok = got <= 1 || place_grid(ctx, mats, 1, (int)ncols, cand, got, cap, &bm, &bv, ms) == 0;
+    if (trial_ok && got == tries && tries > 1 && 2 * tries <= 8 && place_uniform(ms, got)) {      // nobody stood out: as many slabs again
         int more = 0;
         for (int k = got; k < 2 * tries; ++k) {
-            if (dev_alloc(&cand[k], bytes) != hipSuccess) { cand[k] = nullptr; (void)hipGetLastError(); break; }
+            if (!slab_alloc_zeroed(ctx, &cand[got + more], bytes)) break;
             ++more;
-            if (hipMemsetAsync(cand[k], 0, bytes, ctx->stream) != hipSuccess) break;
         }
         if (more > 0) {
             int bm2 = 0, bv2 = 0;
-            rc = place_grid(ctx, mats, 1, (int)ncols, cand + got, more, cap, &bm2, &bv2, ms + got);
+            trial_ok = place_grid(ctx, mats, 1, (int)ncols, cand + got, more, cap, &bm2, &bv2, ms + got) == 0;
             if (more == 1) ms[got] = ms[bv];                      // (a single extra candidate is not timed by place_grid: leave the choice alone)
-            else if (rc == 0 && ms[got + bv2] < ms[bv]) bv = got + bv2;
+            else if (trial_ok && ms[got + bv2] < ms[bv]) bv = got + bv2;
             got += more;
         }
     }
-    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!trial_ok) place_no_preference(ctx, &bm, &bv);
+    const hipError_t es = hipStreamSynchronize(ctx->stream);      // the zero fills (and the trials) are done before anything is freed or handed out
     for (int k = 0; k < got; ++k)
-        if (k != bv) dev_free(cand[k]);
-    place_record(ctx, got > 1 ? got : 0, bv, ms);
+        if (k != bv || es != hipSuccess) dev_free(cand[k]);
+    if (es != hipSuccess) return set_err(ctx, LFPSQP_ERR_HIP, "hipStreamSynchronize failed while allocating %d vectors: %s", count, hipGetErrorString(es));
+    if (trial_ok) place_record(ctx, got > 1 ? got : 0, bv, ms);
     slab_views(cand[bv], n, cap, count, out);
-    return rc;
+    return 0;
 }
 
 // candidate matrices (as many of `tries` as fit side by side in three quarters of the free memory)
@@ -754,22 +827,25 @@ int lfpsqp_mat_alloc_placed(lfpsqp_ctx* ctx, int64_t n, int64_t m, lfpsqp_mat** 
     lfpsqp_mat* cand[8] = {nullptr};
     const int got = mat_candidates(ctx, n, m, ctx->place_tries, cand);
     if (got == 0) return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%lld x %lld matrix) failed", (long long)n, (long long)m);
-    int bm = 0, bv = 0, rc = 0;
+    int bm = 0, bv = 0;
+    bool trial_ok = true;
     double ms[8] = {0};
     if (got > 1) {
         const int64_t cap = round_up(n > 0 ? n : 1, kPadRows);
         void* scratch = nullptr;
-        if (dev_alloc(&scratch, sizeof(double) * (size_t)cap * 3) == hipSuccess &&
-            hipMemsetAsync(scratch, 0, sizeof(double) * (size_t)cap * 3, ctx->stream) == hipSuccess)
-            rc = place_grid(ctx, cand, got, (int)m, &scratch, 1, cap, &bm, &bv, ms);
+        if (slab_alloc_zeroed(ctx, &scratch, sizeof(double) * (size_t)cap * 3))
+            trial_ok = place_grid(ctx, cand, got, (int)m, &scratch, 1, cap, &bm, &bv, ms) == 0;
+        else
+            trial_ok = false;
         (void)hipStreamSynchronize(ctx->stream);
         if (scratch) dev_free(scratch);
     }
+    if (!trial_ok) place_no_preference(ctx, &bm, &bv);
     for (int k = 0; k < got; ++k)
         if (k != bm) lfpsqp_mat_free(ctx, cand[k]);
-    place_record(ctx, got > 1 ? got : 0, bm, ms);
+    if (trial_ok) place_record(ctx, got > 1 ? got : 0, bm, ms);
     *out = cand[bm];
-    return rc;
+    return 0;
 }
 
 // The basis and the n-vectors streamed with it, allocated TOGETHER: which allocation of the one is fast depends on the other (a property of
@@ -787,50 +863,53 @@ int lfpsqp_basis_work_alloc_placed(lfpsqp_ctx* ctx, int64_t n, int64_t m, int64_
     void* slabs[8] = {nullptr};
     int gv = 0;
     for (int k = 0; k < tv; ++k) {
-        if (dev_alloc(&slabs[k], bytes) != hipSuccess) { slabs[k] = nullptr; (void)hipGetLastError(); break; }
+        if (!slab_alloc_zeroed(ctx, &slabs[gv], bytes)) break;
         ++gv;
-        if (hipMemsetAsync(slabs[k], 0, bytes, ctx->stream) != hipSuccess) break;
     }
     if (gv == 0) {
         for (int k = 0; k < gm; ++k) lfpsqp_mat_free(ctx, cand[k]);
         return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%d vectors of %lld doubles) failed", count, (long long)nvec);
     }
     int bm = 0, bv = 0;
-    double ms[64];
-    int rc = (gm * gv > 1) ? place_grid(ctx, cand, gm, (int)m, slabs, gv, cap, &bm, &bv, ms) : 0;
-    if (rc == 0 && gm * gv > 1 && gv == tv && tv > 1 && 2 * tv <= 8 && place_uniform(ms, gm * gv)) {   // nobody stood out: as many slabs again
+    double ms[64] = {0};
+    bool trial_ok = gm * gv <= 1 || place_grid(ctx, cand, gm, (int)m, slabs, gv, cap, &bm, &bv, ms) == 0;
+    if (trial_ok && gm * gv > 1 && gv == tv && tv > 1 && 2 * tv <= 8 && place_uniform(ms, gm * gv)) {   // nobody stood out: as many slabs again
         int more = 0;
         for (int k = gv; k < 2 * tv; ++k) {
-            if (dev_alloc(&slabs[k], bytes) != hipSuccess) { slabs[k] = nullptr; (void)hipGetLastError(); break; }
+            if (!slab_alloc_zeroed(ctx, &slabs[gv + more], bytes)) break;
             ++more;
-            if (hipMemsetAsync(slabs[k], 0, bytes, ctx->stream) != hipSuccess) break;
         }
         if (more > 0 && gm * more > 1) {
             double ms2[64];
             int bm2 = 0, bv2 = 0;
-            rc = place_grid(ctx, cand, gm, (int)m, slabs + gv, more, cap, &bm2, &bv2, ms2);
-            double all[64];
-            const int nv2 = gv + more;
-            for (int i = 0; i < gm; ++i) {
-                for (int j = 0; j < gv; ++j) all[i * nv2 + j] = ms[i * gv + j];
-                for (int j = 0; j < more; ++j) all[i * nv2 + gv + j] = ms2[i * more + j];
+            trial_ok = place_grid(ctx, cand, gm, (int)m, slabs + gv, more, cap, &bm2, &bv2, ms2) == 0;
+            if (trial_ok) {
+                double all[64];
+                const int nv2 = gv + more;
+                for (int i = 0; i < gm; ++i) {
+                    for (int j = 0; j < gv; ++j) all[i * nv2 + j] = ms[i * gv + j];
+                    for (int j = 0; j < more; ++j) all[i * nv2 + gv + j] = ms2[i * more + j];
+                }
+                if (ms2[bm2 * more + bv2] < ms[bm * gv + bv]) { bm = bm2; bv = gv + bv2; }
+                for (int k = 0; k < gm * nv2; ++k) ms[k] = all[k];
             }
-            if (rc == 0 && ms2[bm2 * more + bv2] < ms[bm * gv + bv]) { bm = bm2; bv = gv + bv2; }
-            for (int k = 0; k < gm * nv2; ++k) ms[k] = all[k];
-            gv = nv2;
+            gv += more;
         } else {
+            (void)hipStreamSynchronize(ctx->stream);
             for (int k = gv; k < gv + more; ++k) { dev_free(slabs[k]); slabs[k] = nullptr; }
         }
     }
-    (void)hipStreamSynchronize(ctx->stream);
+    if (!trial_ok) place_no_preference(ctx, &bm, &bv);
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < gm; ++k)
-        if (k != bm) lfpsqp_mat_free(ctx, cand[k]);
+        if (k != bm || es != hipSuccess) lfpsqp_mat_free(ctx, cand[k]);
     for (int k = 0; k < gv; ++k)
-        if (k != bv) dev_free(slabs[k]);
-    place_record(ctx, gm * gv > 1 ? gm * gv : 0, bm * gv + bv, ms);
+        if (k != bv || es != hipSuccess) dev_free(slabs[k]);
+    if (es != hipSuccess) return set_err(ctx, LFPSQP_ERR_HIP, "hipStreamSynchronize failed while allocating the basis and its vectors: %s", hipGetErrorString(es));
+    if (trial_ok) place_record(ctx, gm * gv > 1 ? gm * gv : 0, bm * gv + bv, ms);
     *M_out = cand[bm];
     slab_views(slabs[bv], nvec, cap, count, out);
-    return rc;
+    return 0;
 }
 
 int64_t lfpsqp_vec_len(const lfpsqp_vec* v) { return v ? v->n : -1; }

@@ -41,6 +41,8 @@ struct Comm {
     void* p2p_peer[16] = {nullptr};      // every rank's mailbox as mapped here (p2p_peer[rank] == p2p_mine)
     uint64_t p2p_seq = 0;                // collectives issued so far (the same on every rank by construction)
     int* p2p_err = nullptr;              // pinned host word: set by a kernel whose wait for a peer timed out
+    int p2p_memkind = 0;                 // LFPSQP_P2P_MEM_*: what kind of memory the mailbox is (lfpsqp_comm_p2p_info)
+    bool p2p_allow_coarse = false;       // lfpsqp_comm_p2p_allow_coarse
     void* rccl_lib = nullptr;
     void* nccl_comm = nullptr;
     int (*ncclAllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, void*, hipStream_t) = nullptr;

@@ -702,6 +702,16 @@ struct SpConsumeE {
         e.apply(i, acc, v0, v1, red);
     }
 };
+// the conditions projcg_impl puts on a basis without Z (DF: dense generator, fused iteration; SF: on the nonzeros of the sparse twin)
+int lfpsqp_factored_basis_supported(const lfpsqp_ctx* ctx, const lfpsqp_mat* A, const lfpsqp_spmat* SA, int* yes) {
+    if (!ctx || !A || !yes) return LFPSQP_ERR_ARG;
+    if (SA)
+        *yes = (A->m >= 1 && A->m <= kOnepassMaxCols && SA->n == A->n && SA->m >= 1 && A->m >= SA->m && A->m - SA->m <= 4) ? 1 : 0;
+    else
+        *yes = (A->m <= kOnepassMaxCols && onepass_cw(ctx, (int)A->m, A->ld, A->n) != 0) ? 1 : 0;
+    return 0;
+}
+
 static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, lfpsqp_opfun opf, void* ouser,
                        lfpsqp_vec* Av, const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
                        int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {

@@ -727,6 +727,8 @@ int lfpsqp_constraints_hess_diag(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons
     LF_TRY(ensure_mvec(ctx, (size_t)ml + 8));
     for (int j = 0; j < ml; ++j) ctx->h_m[j] = lam[j];
     LF_HIP(ctx, hipMemcpyAsync(ctx->d_m, ctx->h_m, sizeof(double) * ml, hipMemcpyHostToDevice, ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));            // h_m is the context's SHARED pinned staging block: the copy must have read it
+                                                               // before this call returns and another call writes it (as stage_qw does)
     if (ew->Asp) return run_vec<EwHessVecF, 0, NoPost>(ctx, N, EwHessVecF{he, ell_rows(ew->Asp, ctx->d_m)}, 0u, nullptr, NoPost());
     return run_gemv_n<EwHessE, 0, NoPost>(ctx, ew->A, ml, N, ctx->d_m, he, nullptr, NoPost());
 }

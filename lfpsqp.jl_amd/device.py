@@ -44,6 +44,12 @@ class Context:
         self.check(self.L.lfpsqp_device_name(self.h, buf, 256))
         return buf.value.decode()
 
+    def device_uuid(self) -> str:
+        """"GPU-<16 hex digits>" of the device this context computes on (what rocminfo / rocm-smi print)."""
+        buf = C.create_string_buffer(64)
+        self.check(self.L.lfpsqp_device_uuid(self.h, buf, 64))
+        return buf.value.decode()
+
     def timer_begin(self):
         self.check(self.L.lfpsqp_timer_begin(self.h))
 
@@ -51,6 +57,12 @@ class Context:
         ms = C.c_double()
         self.check(self.L.lfpsqp_timer_end(self.h, C.byref(ms)))
         return ms.value
+
+    def factored_basis_supported(self, A, SA=None) -> bool:
+        """Can projcg_ run on a basis kept in factored form U = A W (no Z) on this context?  (lfpsqp_factored_basis_supported)"""
+        yes = C.c_int(0)
+        self.check(self.L.lfpsqp_factored_basis_supported(self.h, A.h, SA.h if SA is not None else None, C.byref(yes)))
+        return bool(yes.value)
 
     def set_onepass(self, mode: int = 0):
         self.check(self.L.lfpsqp_ctx_set_onepass(self.h, int(mode)))
@@ -158,6 +170,16 @@ class Context:
         buf = C.create_string_buffer(64)
         self.check(self.L.lfpsqp_comm_p2p_export(self.h, buf))
         return buf.raw
+
+    def comm_p2p_allow_coarse(self, allow: bool = True):
+        """Allow ordinary (coarse-grained) device memory for the mailbox when fine-grained memory cannot be exported (never silent)."""
+        self.check(self.L.lfpsqp_comm_p2p_allow_coarse(self.h, 1 if allow else 0))
+
+    def comm_p2p_info(self):
+        """(memory kind of this rank's mailbox: 'fine-grained' | 'coarse-grained' | 'none', all-reduce launches so far)."""
+        k, cnt = C.c_int(0), C.c_ulonglong(0)
+        self.check(self.L.lfpsqp_comm_p2p_info(self.h, C.byref(k), C.byref(cnt)))
+        return {0: "none", 1: "fine-grained", 2: "coarse-grained"}[k.value], cnt.value
 
     def comm_init_p2p(self, rank: int, nranks: int, handles):
         """``handles``: the 64-byte handles of all ranks, in rank order (lfpsqp_comm_init_p2p)."""

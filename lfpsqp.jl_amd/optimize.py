@@ -168,7 +168,11 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     # ... unless the basis can stay in FACTORED form U = Jct W: then there is no Z at all -- the fused projected-CG iteration, the
     # Newton step and the projections stream Jct and apply the m x m factor W on the side, the tangent setup skips its basis-forming product,
     # and the work vectors are placed against Jct.
-    factored = bool(ctx.options.factored_basis) and diagonal_hessian and 4 <= m <= 1024     # (with a sparse twin: on the nonzeros, no Z either)
+    # The LIBRARY says whether this context can run projcg without Z for this Jct (one-pass kernels on, shape and leading dimension inside
+    # their limits, or a sparse twin the nonzero path covers); where it cannot (LFPSQP_ONEPASS=-1, ld beyond the 32-bit lane offsets ...)
+    # Z is materialised and every path has its two-pass form.
+    factored = (bool(ctx.options.factored_basis) and diagonal_hessian and 4 <= m <= 1024
+                and ctx.factored_basis_supported(Jct, getattr(c_, "Jsp", None)))
     if factored:
         projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=Jct, extra=1)
         idecomp = InequalityDecomp(ctx, n, m, Jct, factored=True)

@@ -60,6 +60,10 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* nb, K, int, size_t) { *nb = 3; return hipSuccess; }
+struct hipUUID { char bytes[16]; };
+typedef int hipDevice_t;
+static inline hipError_t hipDeviceGet(hipDevice_t* d, int i) { *d = i; return hipSuccess; }
+static inline hipError_t hipDeviceGetUuid(hipUUID* u, hipDevice_t) { std::memcpy(u->bytes, "00000000000e0000", 16); return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     std::memset(p, 0, sizeof(*p)); std::strcpy(p->name, "cpu-emulator"); std::strcpy(p->gcnArchName, "emu");
     p->multiProcessorCount = 4; p->totalGlobalMem = size_t(8) << 30; return hipSuccess;

@@ -734,35 +734,3 @@ def test_argument_errors_are_status_codes_not_crashes(dev_ctx):
     x, lam = ctx.vector(600), ctx.vector(3)
     it, nr = L.projcg_(x, lam, L.DiagOperator(2.0), L.DeviceBasis(ctx.matrix(600, 3, Uh)), ctx.vector(600, bh), None, tol=1e-8, maxit=5)
     assert it == 5 and math.isnan(nr)
-
-
-def test_placement_helper_keeps_a_valid_pair_and_frees_the_rest(dev_ctx):
-    """lfpsqp_jl_amd.placement.best_projcg_buffers (what bench.py calls before its warm-up): the grid over candidate allocations, the
-    residual-buffer trial and the extra basis trials (forced here with an unreachable target) hand back one basis, one work set and a
-    context on which the solve is the oracle's; the basis contents do not depend on which candidate won."""
-    ctx = dev_ctx
-    n, m = 2100, 16
-    Uh, a, bh = _cg_problem(n, m)
-    made = []
-
-    def make_basis():
-        Z = ctx.matrix(n, m, Uh)
-        made.append(Z)
-        return Z, f"candidate {len(made)}"
-    A = L.DiagOperator(0.0, ctx.vector(n, a))
-    b = ctx.vector(n, bh)
-    try:
-        Z, desc, x, work, info = L.best_projcg_buffers(ctx, make_basis, n, m, A, b, nbasis=2, nwork=2, iters=4, try_alternating=True,
-                                                        extend=(0.0, 2))
-        assert info["extra_basis_trials"] == 2 and len(made) == 4 and len(info["grid"]) == 4 and all(len(r) == 2 for r in info["grid"])
-        assert sum(1 for Zk in made if Zk.h is not None) == 1 and Z.h is not None          # the losers were freed
-        assert desc == f"candidate {info['basis'] + 1}" and info["residual_buffers"] in (0, 1)
-        np.testing.assert_array_equal(Z.download(), Uh)
-        lam = ctx.vector(m)
-        it, nr = L.projcg_(x, lam, A, L.DeviceBasis(Z), b, None, tol=1e-10, maxit=300, work=work)
-        x0, l0 = np.zeros(n), np.zeros(m)
-        i0, nr0 = R.projcg_(x0, l0, DiagOpRef(a), Uh, bh, np.zeros(m), tol=1e-10, maxit=300)
-        assert it == i0
-        assert np.linalg.norm(x.download() - x0) <= 1e-10 * np.linalg.norm(x0)
-    finally:
-        ctx.set_residual_buffers(0)

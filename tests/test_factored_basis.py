@@ -199,3 +199,46 @@ def test_sparse_twin_without_the_basis(dev_ctx, bounds):
         for key in ("steptype", "mtype", "alpha", "ls_flag", "tn_iter", "rank", "retract_iter1"):
             assert a.get(key) == b_.get(key), (key, a.get(key), b_.get(key))
     np.testing.assert_allclose(o1, o0, rtol=1e-12)
+
+
+@pytest.mark.parametrize("lib_kind", ["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("bounds", [False, True])
+def test_optimize_with_the_one_pass_kernels_switched_off(request, lib_kind, bounds):
+    """LFPSQP_ONEPASS=-1 (the documented cross-check path: every one-pass kernel replaced by its two-pass form) with the DEFAULT options:
+    the factored basis needs the fused iteration, so the driver must ask the library (lfpsqp_factored_basis_supported), materialise Z and
+    reach the same trajectory as with the one-pass kernels -- not fail with LFPSQP_ERR_UNSUPPORTED.  (src/optimize.jl:119, :291-307)"""
+    lib = request.getfixturevalue("emu_lib" if lib_kind == "emu" else "gpu_lib")
+    n, m = (2600, 6) if lib_kind == "emu" else (20000, 32)
+    res = {}
+    for onepass in (0, -1):
+        ctx = L.Context(0, lib)
+        try:
+            ctx.set_onepass(onepass)
+            assert ctx.options.factored_basis                     # the default
+            Jprobe = ctx.matrix(n, m)
+            assert ctx.factored_basis_supported(Jprobe) == (onepass == 0)
+            Jprobe.free()
+            if bounds:
+                P0 = synth.BallBoxProblem(n, m)
+                Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+                P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
+                x0 = 0.97 * synth.hash_vector(2, n) + 0.015
+            else:
+                Jct = ctx.matrix(n, m).hash_fill(1)
+                xs = ctx.vector(n).hash_fill(2)
+                b = ctx.vector(m)
+                L.gemv_t(Jct, xs, b)
+                P = L.QuadLinearBallBox(ctx, n, m, Jct, b.download())
+                x0 = np.ones(n)
+            tr = []
+            x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=5), trace=tr)
+            res[onepass] = (tr, x, obj, ti)
+        finally:
+            ctx.close()
+    (tr1, x1, o1, t1), (tr0, x0_, o0, t0) = res[0], res[-1]
+    assert t1.iter == t0.iter and len(tr1) == len(tr0)
+    for a, b_ in zip(tr1, tr0):
+        assert np.linalg.norm(a["x"] - b_["x"]) <= 1e-10 * max(1.0, np.linalg.norm(b_["x"]))
+        for key in ("steptype", "mtype", "alpha", "ls_flag", "tn_iter", "rank"):
+            assert a.get(key) == b_.get(key), (key, a.get(key), b_.get(key))
+    np.testing.assert_allclose(o1, o0, rtol=1e-12)

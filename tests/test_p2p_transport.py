@@ -84,3 +84,28 @@ def test_bench_two_ranks_over_p2p_at_the_headline_shape():
     assert p["check"]["x_norm"] == g["check"]["x_norm"] and p["check"]["nr"] == g["check"]["nr"]          # fixed rank order: bit for bit
     assert abs(d1["check"]["x_norm"] - p["check"]["x_norm"]) <= 1e-10 * d1["check"]["x_norm"]
     print(f"[bench --gpus 2 on ONE GPU] p2p {p['value']:.1f} it/s, host-staged gloo {g['value']:.1f} it/s, one rank {d1['value']:.1f} it/s")
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_without_a_launcher():
+    """`python3 bench.py --gpus 2 --comm p2p --device 0` -- NO torch.distributed.run around it: bench.py starts its ranks itself (a child
+    process, before anything touches the GPU) and prints the one line; --comm auto picks the same transport on a box whose ranks share the
+    GPU (RCCL refuses duplicate devices and is not probed).  The mailbox must be fine-grained memory."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extras", "--prewarm-seconds", "0.3", "--rows", "2e6"]
+    out = {}
+    for comm in ("p2p", "auto"):
+        two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", comm, "--device", "0", *common],
+                             cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert two.returncode == 0, two.stderr[-3000:]
+        lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        out[comm] = json.loads(lines[0])
+        d = out[comm]
+        assert d["n_gpus"] == 2 and d["check"]["iters"] == 13 and "p2p" in d["config"]["comm"]
+        pr = d["config"]["comm_probe"]
+        assert pr["chosen"] == "p2p" and pr["p2p"]["mailbox_memory"] == "fine-grained", pr
+        print(f"[bench --gpus 2, no launcher, --comm {comm}] {d['value']:.1f} it/s; {d['config']['comm']}; probe {pr}")
+    assert out["p2p"]["check"] == out["auto"]["check"]
