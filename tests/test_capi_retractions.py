@@ -151,6 +151,10 @@ def _compare_traces(tr, tr0, rtol=1e-10, pcg_slack=0, failed_retractions_may_dif
     passes Armijo) the trajectories have legitimately forked: returns the fork index instead of asserting."""
     if not failed_retractions_may_differ:
         assert len(tr) == len(tr0)
+    worst = max((np.linalg.norm(a['x'] - b['x']) / max(np.linalg.norm(b['x']), 1e-300) for a, b in zip(tr, tr0)), default=0.0)
+    if rtol > 1e-10:        # a site looser than north_star's 1e-10 says what it measured (the reason for its tolerance is stated at the call)
+        import inspect
+        _note(f"{inspect.stack()[1].function}: max relative deviation of an iterate {worst:.2e} (tolerance {rtol:g})")
     for a, b in zip(tr, tr0):
         chaotic = failed_retractions_may_differ and (b.get('retract_iter1') or 0) >= 100
         if chaotic and a.get('retract_iter1') != b.get('retract_iter1'):

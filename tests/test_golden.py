@@ -21,6 +21,13 @@ OFF0 = dict(disp=R.DisplayOption.off)
 def _check(out, tr, gold, rel=1e-10, pcg_slack=0):
     x, obj, lam, ti = out
     assert ti.iter == gold["iters"] and ti.condition.name == gold["condition"]
+    if rel > 1e-10:        # a check looser than north_star's 1e-10 says what it measured
+        import warnings
+        wn = max((abs(np.linalg.norm(t["x"]) - g["x_norm"]) / g["x_norm"] for t, g in zip(tr, gold["trace"])), default=0.0)
+        wo = float(np.max(np.abs(np.asarray(obj) - np.asarray(gold["obj_values"])) / np.maximum(np.abs(gold["obj_values"]), 1e-300)))
+        msg = f"[golden parity] worst relative deviation: |x_k| {wn:.2e}, f_k {wo:.2e} (tolerance {rel:g})"
+        print(msg)
+        warnings.warn(msg)
     np.testing.assert_allclose(obj, gold["obj_values"], rtol=rel, atol=1e-13)
     np.testing.assert_allclose(lam, gold["lam"], rtol=1e-7, atol=1e-10)
     assert np.linalg.norm(x) == pytest.approx(gold["x_norm"], rel=rel)

@@ -1,0 +1,65 @@
+"""The n = 1e6 point of the parity protocol (trajectories at n in {1e3, 1e4, 1e6}; callback period 1,
+src/optimize.jl:432-434): `optimize` on the GPU against the numpy oracle's run of the same problem -- x after every outer iteration within
+1e-10 relative, equal iteration counts, flags, step types, accepted steps, retraction iterations.  Config 3 at the headline m = 128 with
+both retractions; config 4 (ball in slack form + four-way bounds, Newton retraction) in the strict regime (no failed trial retraction) at
+m = 16.  The oracle needs 20 ... 50 s per case on the box's host cores, which is why these cases exist on the GPU only."""
+import numpy as np
+import pytest
+
+import lfpsqp_jl_amd as L
+from oracle import lfpsqp_ref as R
+from oracle import synth
+
+from .test_capi_retractions import _compare_traces
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_lib):
+    c = L.Context(0, gpu_lib)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("do_project_retract", [False, True])
+def test_config3_trajectory_at_1e6_by_128(ctx, do_project_retract):
+    """BASELINE configs[2]'s constraint block at n = 1e6, m = 128: Newton retraction (src/retractions.jl:75-177) and the reference's default
+    ProjPenalty + pcg! (:179-246, :265-441)."""
+    n, m = 1_000_000, 128
+    prob0, x0 = synth.config3(n, m)
+    tr0, tr = [], []
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, None, None, m,
+                                     R.LFPSQPParams(do_project_retract=do_project_retract, disp=R.DisplayOption.off), trace=tr0)
+    P = L.QuadLinearBallBox(ctx, n, m, ctx.matrix(n, m).hash_fill(1), prob0.b)
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=do_project_retract, disp=L.DisplayOption.off), trace=tr)
+    assert ti.condition.name == tir.condition.name and ti.iter == tir.iter
+    _compare_traces(tr, tr0, rtol=1e-10, pcg_slack=2 if do_project_retract else 0)
+    dev = np.linalg.norm(x - xr) / np.linalg.norm(xr)
+    print(f"[parity n=1e6 m=128 {'PP' if do_project_retract else 'NR'}] {ti.iter} outer iteration(s), |x - x_oracle| / |x_oracle| = {dev:.2e}")
+    assert dev <= 1e-10
+    np.testing.assert_allclose(obj, objr, rtol=1e-12)
+    np.testing.assert_allclose(lam, lamr, rtol=1e-8, atol=1e-12)
+
+
+def test_config4_strict_trajectory_at_1e6_by_16(ctx):
+    """BASELINE configs[3]'s shape at n = 1e6, m = 16 from a start near the feasible set (no trial retraction reaches the reference's
+    100-iteration limit -- asserted on the oracle's trace -- so there is no chaotic regime and the comparison is strict): eight outer
+    iterations, every count and accepted step equal, iterates within 1e-10 after every one of them."""
+    n, m, maxiter = 1_000_000, 16, 8
+    P0 = synth.BallBoxProblem(n, m)
+    x0 = 0.9 * synth.hash_vector(2, n) + 0.1 * P0.x0
+    tr0, tr = [], []
+    xr, objr, lamr, tir = R.optimize(P0.f, P0.c_, P0.d_, x0, P0.xl, P0.xu, P0.m, P0.p,
+                                     R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=maxiter),
+                                     derivatives=P0.derivatives(), trace=tr0)
+    assert all((t.get('retract_iter1') or 0) < 100 for t in tr0) and len(tr0) == maxiter + 1      # the premise of strictness
+    Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+    P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=maxiter), trace=tr)
+    assert ti.iter == tir.iter and ti.condition.name == tir.condition.name
+    assert _compare_traces(tr, tr0, rtol=1e-10) is None
+    worst = max(np.linalg.norm(a['x'] - b['x']) / np.linalg.norm(b['x']) for a, b in zip(tr, tr0))
+    print(f"[parity n=1e6 m=16 config 4] {ti.iter} outer iterations, worst iterate deviation {worst:.2e}")
+    np.testing.assert_allclose(obj, objr, rtol=1e-11)
+    np.testing.assert_allclose(lam, lamr, rtol=1e-7, atol=1e-10)
