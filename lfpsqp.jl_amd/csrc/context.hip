@@ -359,6 +359,7 @@ int lfpsqp_ctx_create(int device, lfpsqp_ctx** out) {
     if (!ok) { delete ctx; return set_err(nullptr, LFPSQP_ERR_HIP, "context resource allocation failed"); }
     if (const char* e = getenv("LFPSQP_ONEPASS")) ctx->tune_onepass = atoi(e);
     if (const char* e = getenv("LFPSQP_SPGRAM")) ctx->tune_spgram = atoi(e) < 0 ? -1 : 0;
+    if (const char* e = getenv("LFPSQP_VEC_BLOCKS")) ctx->tune_vec_blocks = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("LFPSQP_GPING")) ctx->tune_gping = atoi(e) == 1 ? 1 : 0;
     if (const char* e = getenv("LFPSQP_STAGE_ROUNDS")) ctx->stage_cap = atoi(e) > 0 ? atoi(e) : 0;
     *out = ctx;

@@ -95,6 +95,7 @@ struct lfpsqp_ctx {
     // Development override: environment variable LFPSQP_ONEPASS, read once at lfpsqp_ctx_create.
     int tune_onepass = 0;
     int tune_spgram = 0;    // lfpsqp_factorize_sp: 0 = Gram matrix from the nonzeros (sp_gram), -1 = on a dense copy (env LFPSQP_SPGRAM=-1; A/B timing)
+    int tune_vec_blocks = 0;   // vec_kernel: 0 = one tile per block (4096 blocks at most with reductions); > 0 = at most this many blocks (env LFPSQP_VEC_BLOCKS)
     int tune_gping = 0;     // fused projected-CG iteration: 0 = the residual updated in place, 1 = two buffers alternating (lfpsqp_ctx_set_residual_buffers)
 
     bool real_gpu = false;   // gcnArchName "gfx..." (false only in the CPU emulator build of the tests)
@@ -406,19 +407,29 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
     return allreduce_dev(ctx, out, nout);
 }
 
-inline int vec_grid(int64_t n) {
+// grid of vec_kernel: one 512-row tile per block without reductions; with reductions at most kVecRedBlocks blocks of consecutive tiles
+// (their partial rows are read back by the second stage).  ctx->tune_vec_blocks > 0 caps the grid of BOTH kinds (env LFPSQP_VEC_BLOCKS:
+// A/B against the earlier persistent grid of 2048 blocks).
+constexpr int kVecRedBlocks = 4096;
+inline void vec_grid(const lfpsqp_ctx* ctx, int64_t n, bool reduces, int* grid, int* tpb) {
     int64_t t = (n + kSlabRows - 1) / kSlabRows;
-    return (int)(t < 2048 ? (t < 1 ? 1 : t) : 2048);
+    if (t < 1) t = 1;
+    int64_t cap = reduces ? kVecRedBlocks : t;
+    if (ctx->tune_vec_blocks > 0 && ctx->tune_vec_blocks < cap) cap = ctx->tune_vec_blocks;
+    const int64_t per = (t + cap - 1) / cap;
+    *tpb = (int)per;
+    *grid = (int)((t + per - 1) / per);
 }
 
 // elementwise map with NRED reductions (sum, or max where ismax bit set) -> red_out (global)
 template <class F, int NRED, class POST>
 int run_vec(lfpsqp_ctx* ctx, int64_t n, F f, unsigned ismax, double* red_out, POST post, int prof_slot = -1) {
     ++ctx->launch_epoch;
-    const int grid = vec_grid(n);
+    int grid = 1, tpb = 1;
+    vec_grid(ctx, n, NRED > 0, &grid, &tpb);
     if (NRED > 0) LF_TRY(ensure_part(ctx, (size_t)grid * kMaxRed));
     if (prof_slot >= 0) prof_begin(ctx, prof_slot);
-    hipLaunchKernelGGL((vec_kernel<F, NRED>), dim3(grid), dim3(kThreads), 0, ctx->stream, f, n, ismax, ctx->part);
+    hipLaunchKernelGGL((vec_kernel<F, NRED>), dim3(grid), dim3(kThreads), 0, ctx->stream, f, n, ismax, ctx->part, tpb);
     if (prof_slot >= 0) prof_end(ctx, prof_slot);
     LF_LAUNCH_CHECK(ctx);
     if (NRED > 0) {

@@ -659,17 +659,24 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
 
 // ---------------------------------------------------------------------------
 // Elementwise map + reductions.  F::apply(i, valid0, valid1, red) handles the
-// row pair (i, i+1).  Static tile -> block assignment (tile = block + k*grid) and
-// a fixed in-block order keep the sums reproducible.  part[block][k].
+// row pair (i, i+1).  Block b handles the `tpb` consecutive 512-row tiles [b*tpb, (b+1)*tpb) in order: a static assignment
+// and a fixed in-block order keep the sums reproducible.  part[block][k].
+//   Why short-lived blocks (tools/micro/vecprobe.hip, profiles/r04a_vecprobe.txt): on MI355X a plain fp64 copy / triad over 3.2 GB
+// vectors streams at 6.24 / 6.03 TB/s with ONE tile per block (781 250 blocks dispatched in order), 5.8 / 5.6 with two, 5.3 / 5.3
+// with eight or more, and 4.7 / 4.9 TB/s with a persistent grid of 2048 blocks striding over the tiles -- whatever the number of
+// 16-byte pieces a lane keeps in flight (1, 2, 4, 8: no difference) and whatever the temporal hints.  So kernels without
+// reductions get one tile per block; kernels with reductions keep the number of partial rows bounded (the second stage reads them).
 // ---------------------------------------------------------------------------
 template <class F, int NRED>
-__global__ __launch_bounds__(kThreads) void vec_kernel(F f, int64_t n, unsigned ismax, double* __restrict__ part) {
+__global__ __launch_bounds__(kThreads) void vec_kernel(F f, int64_t n, unsigned ismax, double* __restrict__ part, int tpb) {
     if (f.skip()) return;
     double red[NRED > 0 ? NRED : 1];
 #pragma unroll
     for (int k = 0; k < (NRED > 0 ? NRED : 1); ++k) red[k] = 0.0;
     const int64_t ntiles = (n + kSlabRows - 1) / kSlabRows;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t tile = (int64_t)blockIdx.x * tpb;
+    const int64_t tend = (tile + tpb < ntiles) ? tile + tpb : ntiles;
+    for (; tile < tend; ++tile) {
         const int64_t i = tile * kSlabRows + (int64_t)threadIdx.x * 2;
         f.apply(i, i < n, i + 1 < n, red);
     }

@@ -88,6 +88,16 @@ struct AmaxF {
         if (v1) red[0] = nanmax(red[0], fabs(a.y));
     }
 };
+struct CopyF {  // y = x
+    const double* x;
+    double* y;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 xx = ld2(x + i);
+        if (v1) st2(y + i, xx);
+        else if (v0) y[i] = xx.x;
+    }
+};
 struct WaxpbyF {  // z = a*x + b*y
     double a, b;
     const double *x, *y;
@@ -237,8 +247,9 @@ int lfpsqp_vec_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, double value) {
 int lfpsqp_vec_copy(lfpsqp_ctx* ctx, lfpsqp_vec* dst, const lfpsqp_vec* src) {
     LF_ARG(ctx, ctx && dst && src && dst->n == src->n);
     if (src->n == 0 || dst->p == src->p) return 0;
-    LF_HIP(ctx, hipMemcpyAsync(dst->p, src->p, sizeof(double) * src->n, hipMemcpyDeviceToDevice, ctx->stream));
-    return 0;
+    // (the runtime's device-to-device copy streams at 4.97 TB/s on MI355X, one tile per block of the library's own kernel at 6.24:
+    // tools/micro/vecprobe.hip)
+    return run_vec<CopyF, 0, NoPost>(ctx, src->n, CopyF{src->p, dst->p}, 0u, nullptr, NoPost());
 }
 
 int lfpsqp_vec_copy_range(lfpsqp_ctx* ctx, lfpsqp_vec* dst, int64_t dst_off, const lfpsqp_vec* src, int64_t src_off, int64_t count) {

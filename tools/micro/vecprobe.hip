@@ -69,6 +69,40 @@ __global__ __launch_bounds__(256) void vk_span(const double* __restrict__ x, con
     }
 }
 
+// block b handles the C consecutive tiles [b*C, (b+1)*C): grid = ceil(ntiles / C) >> resident slots, dispatched in order
+template <int OP, int C, bool UNR, int BT>
+__global__ __launch_bounds__(BT) void vk_chunk(const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ z, int64_t n2, double a, double b) {
+    // n2 = number of 16-byte pieces; a tile = BT pieces
+    const int64_t p0 = (int64_t)blockIdx.x * C * BT + threadIdx.x;
+    if (UNR) {
+        double2 xx[C], yy[C];
+#pragma unroll
+        for (int u = 0; u < C; ++u) {
+            const int64_t p = p0 + (int64_t)u * BT;
+            if (p < n2) { xx[u] = ldv<false>(x + 2 * p); if (OP == 1) yy[u] = ldv<false>(y + 2 * p); }
+        }
+#pragma unroll
+        for (int u = 0; u < C; ++u) {
+            const int64_t p = p0 + (int64_t)u * BT;
+            if (p < n2) {
+                double2 o = xx[u];
+                if (OP == 1) o = make_double2(fma(a, xx[u].x, b * yy[u].x), fma(a, xx[u].y, b * yy[u].y));
+                stv<false>(z + 2 * p, o);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int u = 0; u < C; ++u) {
+            const int64_t p = p0 + (int64_t)u * BT;
+            if (p < n2) {
+                double2 o = ldv<false>(x + 2 * p);
+                if (OP == 1) { const double2 yv = ldv<false>(y + 2 * p); o = make_double2(fma(a, o.x, b * yv.x), fma(a, o.y, b * yv.y)); }
+                stv<false>(z + 2 * p, o);
+            }
+        }
+    }
+}
+
 template <class K>
 static double time_ms(K launch, int reps = 5) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -95,17 +129,30 @@ int main() {
 #define RUNS(OP, U, NTL, NTS, GRID)                                                                                             \
     { char nm[128]; snprintf(nm, sizeof nm, "%s U=%d ntl=%d nts=%d grid=%d SPAN", OP ? "triad" : "copy ", U, NTL, NTS, GRID);  \
       rep(nm, OP ? 3 : 2, time_ms([&] { hipLaunchKernelGGL((vk_span<OP, U, NTL, NTS>), dim3(GRID), dim3(256), 0, 0, x, y, z, ntiles, 1.0, 2.0); })); }
+#define RUNC(OP, C, UNR, BT, N)                                                                                                 \
+    { char nm[128]; snprintf(nm, sizeof nm, "%s chunk C=%d unrolled=%d block=%d n=%lld", OP ? "triad" : "copy ", C, UNR, BT, (long long)(N)); \
+      const int64_t n2 = (N) / 2; const int64_t g = (n2 + (int64_t)C * BT - 1) / ((int64_t)C * BT);                              \
+      const double ms = time_ms([&] { hipLaunchKernelGGL((vk_chunk<OP, C, UNR, BT>), dim3((unsigned)g), dim3(BT), 0, 0, x, y, z, n2, 1.0, 2.0); }, 10); \
+      printf("%-64s %8.4f ms  %7.1f GB/s\n", nm, ms, (OP ? 3 : 2) * 8.0 * (N) / ms / 1e6); fflush(stdout); }
     for (int pass = 0; pass < 2; ++pass) {
         printf("---- pass %d\n", pass);
-        RUN(0, 1, false, false, 2048) RUN(0, 2, false, false, 2048) RUN(0, 4, false, false, 2048) RUN(0, 8, false, false, 2048)
-        RUN(0, 4, true, false, 2048) RUN(0, 4, false, true, 2048) RUN(0, 4, true, true, 2048)
-        RUN(0, 4, false, false, 1024) RUN(0, 4, false, false, 4096) RUN(0, 8, false, false, 1024) RUN(0, 2, false, false, 4096) RUN(0, 1, false, false, 8192)
-        RUN(0, 1, false, false, 781250)
-        RUNS(0, 4, false, false, 2048) RUNS(0, 4, true, true, 2048) RUNS(0, 8, false, false, 2048) RUNS(0, 4, false, false, 1024)
-        RUN(1, 1, false, false, 2048) RUN(1, 2, false, false, 2048) RUN(1, 4, false, false, 2048) RUN(1, 8, false, false, 2048)
-        RUN(1, 4, true, false, 2048) RUN(1, 4, false, true, 2048) RUN(1, 4, true, true, 2048)
-        RUN(1, 4, false, false, 1024) RUN(1, 2, false, false, 4096) RUN(1, 1, false, false, 781250)
-        RUNS(1, 4, false, false, 2048) RUNS(1, 4, true, true, 2048) RUNS(1, 2, false, false, 2048)
+        RUN(0, 1, false, false, 2048) RUN(0, 1, false, false, 781250) RUN(0, 1, false, false, 32768) RUN(0, 1, false, false, 131072)
+        RUN(1, 1, false, false, 2048) RUN(1, 1, false, false, 781250) RUN(1, 1, false, false, 32768) RUN(1, 1, false, false, 131072)
+        RUNC(0, 1, false, 256, n) RUNC(0, 2, false, 256, n) RUNC(0, 4, false, 256, n) RUNC(0, 8, false, 256, n) RUNC(0, 16, false, 256, n) RUNC(0, 64, false, 256, n)
+        RUNC(0, 2, true, 256, n) RUNC(0, 4, true, 256, n) RUNC(0, 8, true, 256, n)
+        RUNC(0, 1, false, 512, n) RUNC(0, 1, false, 1024, n) RUNC(0, 2, true, 1024, n) RUNC(0, 1, false, 64, n) RUNC(0, 1, false, 128, n)
+        RUNC(1, 1, false, 256, n) RUNC(1, 2, false, 256, n) RUNC(1, 4, false, 256, n) RUNC(1, 8, false, 256, n) RUNC(1, 16, false, 256, n) RUNC(1, 64, false, 256, n)
+        RUNC(1, 2, true, 256, n) RUNC(1, 4, true, 256, n) RUNC(1, 8, true, 256, n)
+        RUNC(1, 1, false, 512, n) RUNC(1, 1, false, 1024, n) RUNC(1, 1, false, 128, n)
+        // the solver's size: n = 1e7 (80 MB per vector: partly served by the 256 MB infinity cache)
+        const int64_t ns = 10000000;
+        RUNC(0, 1, false, 256, ns) RUNC(0, 4, false, 256, ns) RUNC(0, 8, false, 256, ns) RUNC(0, 4, true, 256, ns)
+        RUNC(1, 1, false, 256, ns) RUNC(1, 4, false, 256, ns) RUNC(1, 8, false, 256, ns) RUNC(1, 4, true, 256, ns)
+        { const int64_t nt = ns / 512; char nm[64];
+          snprintf(nm, sizeof nm, "copy  grid-stride 2048 n=1e7"); const double m0 = time_ms([&] { hipLaunchKernelGGL((vk<0, 1, false, false>), dim3(2048), dim3(256), 0, 0, x, y, z, nt, 1.0, 2.0); }, 10);
+          printf("%-64s %8.4f ms  %7.1f GB/s\n", nm, m0, 2 * 8.0 * ns / m0 / 1e6);
+          snprintf(nm, sizeof nm, "triad grid-stride 2048 n=1e7"); const double m1 = time_ms([&] { hipLaunchKernelGGL((vk<1, 1, false, false>), dim3(2048), dim3(256), 0, 0, x, y, z, nt, 1.0, 2.0); }, 10);
+          printf("%-64s %8.4f ms  %7.1f GB/s\n", nm, m1, 3 * 8.0 * ns / m1 / 1e6); }
     }
     return 0;
 }
