@@ -552,21 +552,33 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     pert = ctx.vector(n_loc).hash_fill(7, r0, 1e-3, 0.0)
     xt = ctx.vector(n_loc); L.waxpby(1.0, xs, 1.0, pert, xt)
     xnew, cval = ctx.vector(n_loc), np.zeros(m)
-    nr_ms = {}
+    # Timed the way `value` is: MANY iterations of one running solve (tol = 0 forces exactly `its`), so that the call's set-up (the first
+    # c! pass, the H2D copies of the small factors) weighs < 1 %; beside the wall time per iteration the KERNEL CHAIN of an iteration from
+    # the library's own HIP events (every 4th launch of a kernel family is bracketed): what is left between the two is launch gaps.
+    its_long = 200
+    nr_ms, nr_chain = {}, {}
     for label, basis in (("one_stream", L.DeviceBasis(Z2, generator=(J, Wg))), ("two_streams", L.DeviceBasis(Z2))):
-        nr = L.NR(basis, S, Vt, 0.0, 24, L.NRWork(m), False, None)
+        nits = its_long if label == "one_stream" else 24
+        nr = L.NR(basis, S, Vt, 0.0, nits, L.NRWork(m), False, None)
         L.retract_(cval, xnew, cons, xt, xs, nr)                  # warm
+        ctx.set_profiling(True)
         ctx.sync(); t0 = time.perf_counter(); flag, it, _ = L.retract_(cval, xnew, cons, xt, xs, nr); ctx.sync()
         nr_ms[label] = (time.perf_counter() - t0) * 1e3 / max(it, 1)
-    # pcg! of the default (ProjPenalty) retraction: 24 iterations of (J'J + mu I) x = b forced by tol = 0
+        pms, pcnt = ctx.profile_read(); ctx.set_profiling(False)
+        nr_chain[label] = (pms[4] / pcnt[4]) if pcnt[4] else None          # the one-pass step kernel (slot 4)
+    # pcg! of the default (ProjPenalty) retraction: iterations of (J'J + mu I) x = b forced by tol = 0
     from lfpsqp_jl_amd.projpenalty import _JacPlain
     w = L.ProjPenaltyWork(ctx, m, n_loc, False)
     xp, rp_ = ctx.vector(n_loc), ctx.vector(n_loc)
-    pcg_ms = None
+    pcg_ms = pcg_chain = None
     for rep in range(2):
         xp.fill(0.0); rp_.copy_from(xs)
-        ctx.sync(); t0 = time.perf_counter(); flag, pit = L.pcg_(1e-2, _JacPlain(J, w), L.no_precondition, xp, rp_, w.p, w.z, None, 0.0, 24); ctx.sync()
+        ctx.set_profiling(True)
+        ctx.sync(); t0 = time.perf_counter(); flag, pit = L.pcg_(1e-2, _JacPlain(J, w), L.no_precondition, xp, rp_, w.p, w.z, None, 0.0, its_long); ctx.sync()
         pcg_ms = (time.perf_counter() - t0) * 1e3 / max(pit, 1)
+        pms, pcnt = ctx.profile_read(); ctx.set_profiling(False)
+        if pcnt[5] and pcnt[6]:
+            pcg_chain = {"fused_kernel_ms": pms[5] / pcnt[5], "P3_vector_kernel_ms": pms[6] / pcnt[6]}
     pcg_bytes = 8.0 * n_loc * m + 80.0 * n_loc               # one-pass iteration: J once + 10 n-vector passes
     # four trial points of one linesearch retracted together (lfpsqp_retract_nr_batch): one pass over J per Newton step for all
     nbt = 4
@@ -574,13 +586,16 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     xns = [ctx.vector(n_loc) for _ in range(nbt)]
     for j, xt_ in enumerate(xts):
         L.waxpby(1.0, xs, 0.5 ** j, pert, xt_)
-    nrb = L.NR(L.DeviceBasis(Z2, generator=(J, Wg)), S, Vt, 0.0, 24, L.NRWork(m), False, None)
+    nrb = L.NR(L.DeviceBasis(Z2, generator=(J, Wg)), S, Vt, 0.0, 100, L.NRWork(m), False, None)
     cvs = np.zeros((nbt, m))
-    nr_batch_ms = None
+    nr_batch_ms = nr_batch_kernel_ms = None
     for rep in range(2):
+        ctx.set_profiling(True)
         ctx.sync(); t0 = time.perf_counter(); got = L.retract_nr_batch_(cvs, xns, cons, xts, xs, nrb); ctx.sync()
         if got is not None:
             nr_batch_ms = (time.perf_counter() - t0) * 1e3 / max(got[0][1], 1)
+        pms, pcnt = ctx.profile_read(); ctx.set_profiling(False)
+        nr_batch_kernel_ms = (pms[7] / pcnt[7]) if pcnt[7] else None
     for v_ in xts + xns:
         v_.free()
     # the fused projected-CG iteration on the basis in factored form (streams J, applies W in the post-kernel) against the materialised Z2
@@ -682,8 +697,9 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
             "nr_step_two_streams_ms": nr_ms["two_streams"], "nr_step_two_streams_GBs": gbs(nr2_bytes, nr_ms["two_streams"]),
-            "nr_batch4_step_ms": nr_batch_ms, "projcg_call_iter_materialised_ms": pf["materialised"], "projcg_call_iter_factored_ms": pf["factored"],
-            "projcg_factored_xnorm_rel_diff": abs(pf["factored_xnorm"] - pf["materialised_xnorm"]) / pf["materialised_xnorm"], "nr_iters_timed": int(it), "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit),
+            "nr_step_kernel_ms": nr_chain["one_stream"], "nr_step_gap_note": "nr_step_ms = wall per iteration of a 200-iteration call; nr_step_kernel_ms = the one-pass step kernel alone (HIP events); the rest is the m x m Broyden kernel (~25 us) and the second-stage reduction",
+            "nr_batch4_step_ms": nr_batch_ms, "nr_batch4_step_kernel_ms": nr_batch_kernel_ms, "projcg_call_iter_materialised_ms": pf["materialised"], "projcg_call_iter_factored_ms": pf["factored"],
+            "projcg_factored_xnorm_rel_diff": abs(pf["factored_xnorm"] - pf["materialised_xnorm"]) / pf["materialised_xnorm"], "nr_iters_timed": its_long, "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit), "pcg_iter_kernel_chain": pcg_chain,
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies; the Gram kernel computes the upper "
                     "triangle only (16 x 16 tiles on and above the diagonal): gram_TFLOPs_executed counts that work, ..._of_the_full_product 2 n m^2"}
 
@@ -756,28 +772,96 @@ def stream_rates(ctx, L, nbig=400_000_000):
 
 
 def cpu_baseline(ns, m, n_full):
-    """The oracle's C/OpenMP restatement of the reference's (unfused) projcg! call sequence,
-    timed on this box's host cores on a bounded sample: n_s rows instead of n, same m, same
-    generator; iterations/s is rescaled by n_s/n (the loop is linear in n)."""
+    """The reference's CPU path as the oracle's C/OpenMP restatement (oracle/projcg_port.c), timed on this box's host cores
+    (BASELINE.md 3): the (unfused) projcg! call sequence of src/projcg.jl:71-112, the two matvecs on their own (kgemv!, src/la_helper.jl:36-44),
+    one Newton-retraction iteration (src/retractions.jl:133-165: a GEMV-N over U, c! = a GEMV-T over Jct, the m x m Broyden algebra) and a
+    host triad.  At the FULL n when the host has the memory for it (the matrix alone is 8 n m bytes), else on a sample of ns rows with the
+    rates rescaled by ns/n (every leg is linear in n); `n_measured` says which.  About 25 s of CPU work."""
+    import numpy as np
     from oracle import port
     threads = port.usable_cpus()
     port.lib().port_set_num_threads(threads)
-    scale = 2.0 ** math.floor(math.log2(math.sqrt(3.0 / ns)))
-    U = port.hash_matrix(1, ns, m, scale=scale)
-    a = port.hash_vector(3, ns, 0, 4.0, 5.0)
-    b = port.hash_vector(4, ns)
+    avail = 0
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+    except (OSError, ValueError):
+        pass
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):      # a container's limit, if lower
+        try:
+            txt = open(path).read().strip()
+            if txt != "max":
+                used = 0
+                try:
+                    used = int(open(path.replace("memory.max", "memory.current").replace("limit_in_bytes", "usage_in_bytes")).read())
+                except (OSError, ValueError):
+                    pass
+                avail = min(avail, max(0, int(txt) - used)) if avail else max(0, int(txt) - used)
+        except (OSError, ValueError):
+            pass
+    need_full = 8.0 * n_full * m + 8.0 * n_full * 12 + (2 << 30)
+    nm = n_full if (ns >= n_full or avail >= 1.5 * need_full) else ns        # measured size: full when it fits comfortably
+    scale = 2.0 ** math.floor(math.log2(math.sqrt(3.0 / nm)))
+    U = port.hash_matrix(1, nm, m, scale=scale)
+    a = port.hash_vector(3, nm, 0, 4.0, 5.0)
+    b = port.hash_vector(4, nm)
     port.projcg(a, U, b, None, 1e-300, 1)                     # touch everything once
-    k = 3
+    k = 2
     t0 = time.perf_counter()
     _, _, it, _ = port.projcg(a, U, b, None, 1e-300, k)
     dt = time.perf_counter() - t0
-    k = max(3, min(900, int(18.0 / (dt / k))))                 # 10-12 s of CPU work (the three calibration iterations run cold, ~1.6 x slower)
+    k = max(3, min(900, int(12.0 / (dt / k))))                 # ~10 s of CPU work (the calibration iterations run cold, ~1.6 x slower)
     t0 = time.perf_counter()
     _, _, it, _ = port.projcg(a, U, b, None, 1e-300, k)
     dt = time.perf_counter() - t0
-    return {"value": (it / dt) * (ns / n_full), "unit": "iters/s", "cores": threads, "kind": "port",
-            "sample": f"{it} iterations at n={ns}, m={m} (same generator), rate scaled by {ns}/{n_full}; "
-                      f"measured {it / dt:.3f} it/s on the sample; unfused reference call sequence, OpenMP on all loops"}
+    fac = nm / n_full
+    gb = lambda by, sec: by / sec / 1e9
+
+    def timed(fn, budget=2.5):
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        one = max(time.perf_counter() - t0, 1e-6)
+        reps = max(2, min(200, int(budget / one)))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+    # the J matvecs on their own
+    v, y, tm = port.hash_vector(5, nm), np.zeros(nm), port.hash_vector(6, m)
+    s_t = timed(lambda: port.gemv_t(U, v))
+    s_n = timed(lambda: port.gemv_n(U, tm, y, 1.0, 1.0))
+    # one Newton-retraction iteration without bounds (retractions.jl:140-160): delta = -D c; xnew += U delta; c! = Jct' xnew - b; good Broyden.
+    # U and Jct are two n x m matrices in the reference; the same array stands in for both here (identical traffic, half the host memory).
+    D = np.asfortranarray(np.eye(m)); cval = port.hash_vector(8, m); bb = np.zeros(m)
+
+    def nr_iter():
+        dl = -(D @ cval)
+        port.gemv_n(U, dl, y, 1.0, 1.0)
+        c2 = port.gemv_t(U, y) - bb
+        dc = c2 - cval
+        t2 = D.T @ dl
+        tv = dl - D @ dc
+        den = float(t2 @ dc)
+        if den != 0.0:
+            D[:, :] += np.outer(tv, t2) / den
+    s_nr = timed(nr_iter)
+    # host triad on three vectors of min(n, 1e8) doubles
+    nt = int(min(nm, 100_000_000))
+    z = np.zeros(nt)
+    s_tr = timed(lambda: port.triad(2.0, v[:nt], y[:nt], z), budget=1.0)
+    by_t = 8.0 * nm * m + 8.0 * nm + 8.0 * m
+    by_n = 8.0 * nm * m + 16.0 * nm + 8.0 * m
+    return {"value": (it / dt) * fac, "unit": "iters/s", "cores": threads, "kind": "port", "n_measured": nm,
+            "sample": (f"{it} iterations at n={nm}, m={m} (same generator)" +
+                       (f", rate scaled by {nm}/{n_full}; measured {it / dt:.3f} it/s on the sample" if nm != n_full else " = the full size") +
+                       "; unfused reference call sequence (src/projcg.jl:71-112), OpenMP on all loops"),
+            "gemv_t": {"ms": s_t * 1e3 / fac, "GBs": gb(by_t, s_t), "note": "t = U'v (kgemv! 'T')" + ("" if nm == n_full else "; ms scaled to the full n")},
+            "gemv_n": {"ms": s_n * 1e3 / fac, "GBs": gb(by_n, s_n), "note": "y = U t + y (kgemv! 'N')" + ("" if nm == n_full else "; ms scaled to the full n")},
+            "nr_iteration": {"ms": s_nr * 1e3 / fac, "note": "one Newton-retraction iteration without bounds: GEMV-N over U, c! = GEMV-T over Jct, "
+                                                             "m x m good-Broyden algebra (src/retractions.jl:140-160)" + ("" if nm == n_full else "; ms scaled to the full n")},
+            "host_triad_GBs": gb(24.0 * nt, s_tr), "host_mem_available_GB": avail / 1e9}
 
 
 if __name__ == "__main__":

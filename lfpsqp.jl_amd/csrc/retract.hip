@@ -654,7 +654,7 @@ int nr_batch_step(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, int wm, int m
     ep.e = ep0;
     for (int b = 0; b < NB; ++b) { ep.xnew[b] = xnew[b]->p; ep.ist[b] = ctx->istat + I_NRB + 4 * b; }
     ep.all = ctx->istat + I_NRB_ALL;
-    return run_onepass<NRStepBatchRow<ST, NB>, NB, NB, NB>(ctx, cons->Jct, wm, ml, N, dwdelta, ep, draw, -1, wstride);
+    return run_onepass<NRStepBatchRow<ST, NB>, NB, NB, NB>(ctx, cons->Jct, wm, ml, N, dwdelta, ep, draw, 7, wstride);     // (profiling slot 7)
 }
 
 }  // namespace lfpsqp
@@ -824,8 +824,8 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
                 e1.kind = nullptr;                                 // (the update alone: nothing is handed to a second product)
                 LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, s1, n1, t1, nullptr, 0, N, e1, draw + ml)));
                 LF_TRY(cons_raw(ctx, cons, xnew->p, draw));
-            } else if (cwd && ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<true>{ep}, draw)));
-            else if (cwd) LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<false>{ep}, draw)));
+            } else if (cwd && ineq) LF_TRY((run_onepass<NRStepRow<true>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<true>{ep}, draw, 4)));      // (profiling slot 4)
+            else if (cwd) LF_TRY((run_onepass<NRStepRow<false>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<false>{ep}, draw, 4)));
             else if (ew && ew->Asp) {                             // sparse A without the generator hint: dense step over Z, sparse c!
                 LF_TRY((run_gemv_nt<NRStepE, 0>(ctx, s1, n1, t1, nullptr, 0, N, ep, draw + ml)));
                 if (quad) LF_TRY((run_vec<BallF, 1, NoPost>(ctx, N, BallF{xnew->p, cons->n_x, cons->slack_row}, 0u, draw + ml, NoPost())));   // (summed as c! sums it)

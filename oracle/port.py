@@ -48,6 +48,7 @@ def lib():
         L.port_gemv_t.argtypes = [i64, i64, P, i64, P, P]
         L.port_gemv_n.argtypes = [i64, i64, dbl, P, i64, P, dbl, P]
         L.port_dot.argtypes = [i64, P, P]
+        L.port_triad.argtypes = [i64, dbl, P, P, P]
         L.port_dot.restype = dbl
         L.port_projcg.argtypes = [i64, i64, P, P, i64, P, P, dbl, i64, P, P, P, C.POINTER(dbl)]
         L.port_projcg.restype = i64
@@ -82,6 +83,11 @@ def gemv_n(M, t, y, alpha=1.0, beta=0.0):
     n, m = M.shape
     lib().port_gemv_n(n, m, alpha, _p(M), n, _p(t), beta, _p(y))
     return y
+
+
+def triad(a, x, y, z):
+    lib().port_triad(x.size, a, _p(x), _p(y), _p(z))
+    return z
 
 
 def projcg(adiag, U, b, c, tol, maxit):

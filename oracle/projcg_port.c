@@ -107,6 +107,12 @@ void port_gemv_n(int64_t n, int64_t m, double alpha, const double* M, int64_t ld
     }
 }
 
+/* STREAM-like triad z = a x + y on the host cores: what this box's DRAM gives the CPU baseline (bench.py cpu_baseline.host_triad_GBs) */
+void port_triad(int64_t n, double a, const double* x, const double* y, double* z) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) z[i] = a * x[i] + y[i];
+}
+
 double port_dot(int64_t n, const double* x, const double* y) {
     double s = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : s)

@@ -355,7 +355,7 @@ def test_config4_default_projection_penalty_with_bounds(dev_ctx):
     P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
     x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(disp=L.DisplayOption.off, maxiter=maxiter), trace=tr)
     assert ti.iter == tir.iter
-    _compare_traces(tr, tr0, rtol=1e-9, pcg_slack=2)
+    _compare_traces(tr, tr0, pcg_slack=2)        # (1e-10; measured on the GPU: 3.9e-12, emulator 2.2e-13)
 
 
 def test_pcg_with_exact_preconditioners(sin_setup):
@@ -445,7 +445,7 @@ def test_optimize_surface_with_host_callables_inequalities_and_bounds(dev_ctx):
                                  derivatives=L.Derivatives(grad_=grad_, hess_lag_vec_=hlv_, jac_c_=dv0.jac_c_, jac_d_=dv0.jac_d_),
                                  ctx=ctx, trace=tr)
     assert ti.iter == tir.iter and ti.condition.name == tir.condition.name and len(x) == n
-    _compare_traces(tr, tr0, rtol=1e-9)
+    _compare_traces(tr, tr0)                      # (1e-10; measured on the GPU: 6.9e-16)
     np.testing.assert_allclose(obj, objr, rtol=1e-10)
     np.testing.assert_allclose(lam, lamr, rtol=1e-6, atol=1e-9)
 
@@ -707,7 +707,7 @@ def test_exact_linesearch_with_batched_shrinking_is_the_same_search(dev_ctx):
         R.optimize(P0.f, P0.c_, P0.d_, P0.x0, P0.xl, P0.xu, P0.m, P0.p,
                    R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, maxiter=maxiter, maxiter_retract=mr,
                                   linesearch=R.LinesearchOption.exact), derivatives=P0.derivatives(), trace=tr0)
-        assert _compare_traces(tr4, tr0, rtol=1e-9) is None
+        assert _compare_traces(tr4, tr0) is None      # (1e-10; measured: 8.8e-14)
 
 
 def _sep_host(kind, a, c):
@@ -772,6 +772,6 @@ def test_separable_objective_problem_class(dev_ctx, kind, with_ball_box):
     x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=maxiter, tn_kappa=1e-6), trace=tr)
     assert ti.iter == tir.iter and ti.condition.name == tir.condition.name
     assert any((t.get('tn_iter') or 0) > 1 for t in tr0)                       # the Newton systems are not solved in one iteration here
-    assert _compare_traces(tr, tr0, rtol=1e-9) is None
+    assert _compare_traces(tr, tr0) is None               # (1e-10; measured on the GPU: 4.1e-16)
     np.testing.assert_allclose(obj, objr, rtol=1e-11)
     np.testing.assert_allclose(lam, lamr, rtol=1e-6, atol=1e-9)

@@ -108,5 +108,5 @@ def test_device_config4_matches_golden():
     tr = []
     out = L.QuadLinearBallBox(ctx, n, m, Jct, bvec.download()[:m], R2=n / 2.0, xl=xl, xu=xu).optimize(
         0.5 * np.ones(n), L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off), trace=tr)
-    _check(out, tr, G["config4_n400_m6_nr"], rel=1e-9)
+    _check(out, tr, G["config4_n400_m6_nr"])         # (1e-10; measured on the GPU: |x_k| 7.1e-13, f_k 2.6e-11)
     ctx.close()
