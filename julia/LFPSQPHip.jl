@@ -206,6 +206,7 @@ c_constraints_hess_diag(ctx, cons, x, lam, hx) = ccall((:lfpsqp_constraints_hess
 c_retract_nr(ctx, U, Sigma, Vt, m, cons, cfun, cuser, idata, xtilde, x, xnew, tol, maxiter, cval, flag, iters) = ccall((:lfpsqp_retract_nr, lib), Cint,
     (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{CIneqData}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Ptr{Float64}, Ref{Cint}, Ref{Int64}),
     ctx, U, Sigma, Vt, m, cons, cfun, cuser, idata, xtilde, x, xnew, tol, maxiter, cval, flag, iters)
+c_retract_nr_batch_width(ctx, U, cons, width) = ccall((:lfpsqp_retract_nr_batch_width, lib), Cint, (Ptr{Cvoid}, Ref{CBasis}, Ref{CConstraints}, Ref{Cint}), ctx, U, cons, width)
 c_retract_nr_batch(ctx, U, Sigma, Vt, m, cons, idata, nb, xtilde, x, xnew, tol, maxiter, cval, flags, iters) = ccall((:lfpsqp_retract_nr_batch, lib), Cint,
     (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{CConstraints}, Ptr{CIneqData}, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Float64, Int64, Ptr{Float64}, Ptr{Cint}, Ptr{Int64}),
     ctx, U, Sigma, Vt, m, cons, idata, nb, xtilde, x, xnew, tol, maxiter, cval, flags, iters)
@@ -220,7 +221,8 @@ c_retract_pp(ctx, cons, cfun, jacfun, user, Jct, m, idata, Dx, Dy, S, xtilde, x,
 # 2. Context, device arrays, BLAS-1/2 dispatch
 # =====================================================================================================================
 # Options of the DEVICE implementation with no counterpart in the reference -- kept out of LFPSQPParams, which mirrors src/LFPSQP.jl:57-81
-# field for field.  ls_batch: trial retractions of a failing linesearch that share their passes over Jct (1 = off);
+# field for field.  ls_batch: trial retractions of a failing linesearch that share their passes over Jct (1 = off; 0 = automatic: what the
+# previous search's failures suggest, at least 4, up to what a pass takes for the shape -- 16 on the matrix cores; k > 1 = at most k);
 # placement_tries: candidate allocations per placement-tuned buffer (set_placement!).
 mutable struct DeviceOptions
     ls_batch::Int
@@ -236,7 +238,7 @@ mutable struct HipContext
         r = Ref{Ptr{Cvoid}}(C_NULL)
         rc = c_ctx_create(Cint(device), r)
         rc == 0 || throw(HipError(rc, "lfpsqp_ctx_create failed: no usable MI355X (there is no CPU fallback)"))
-        ctx = new(r[], 0, 1, DeviceOptions(4, 3, true))
+        ctx = new(r[], 0, 1, DeviceOptions(0, 3, true))
         finalizer(c -> c_ctx_destroy(c.h), ctx)
         return ctx
     end
@@ -805,6 +807,18 @@ function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceV
     end
     return Int(flag[]), Int(iters[]), 0
 end
+# trial retractions per pass for a search: DeviceOptions.ls_batch, never more than the library takes for this shape
+# (lfpsqp_retract_nr_batch_width: 16 on the matrix cores, 4, or 0 = cannot batch)
+function batch_width(ctx::HipContext, retract_method, c!, prev_failures::Int)
+    (retract_method isa NR && c! isa DeviceConstraints) || return 1
+    opt = ctx.options.ls_batch
+    opt == 1 && return 1
+    w = Ref{Cint}(0)
+    GC.@preserve retract_method c! check(ctx, c_retract_nr_batch_width(ctx.h, Ref(cbasis(retract_method.U)), Ref(ccons(c!)), w))
+    width = Int(w[])
+    width < 2 && return 1
+    return opt > 1 ? min(opt, width) : min(width, max(4, prev_failures + 2))
+end
 # several trial points of one Armijo search retracted together (lfpsqp_retract_nr_batch); `nothing` when this configuration cannot
 function retract_nr_batch!(cvals::Matrix{Float64}, xnews::Vector{DeviceVector}, c!::DeviceConstraints, xtildes::Vector{DeviceVector}, x::DeviceVector, method::NR)
     nb = length(xnews)
@@ -936,8 +950,9 @@ mutable struct ArmijoWork       # src/linesearch.jl:1-5
     xts::Vector{DeviceVector}
     xns::Vector{DeviceVector}
     prev_failed::Bool
+    prev_failures::Int
 end
-ArmijoWork(like::DeviceVector) = ArmijoWork(similar_device(like), DeviceVector[], DeviceVector[], false)
+ArmijoWork(like::DeviceVector) = ArmijoWork(similar_device(like), DeviceVector[], DeviceVector[], false, 0)
 struct ExactLinesearchWork      # :7-14
     tmp_n1::DeviceVector
     tmp_n2::DeviceVector
@@ -961,9 +976,10 @@ function armijo!(xnew::DeviceVector, x::DeviceVector, n::Int, d::DeviceVector, g
     xtilde = work.xtilde
     step = xtilde
     ahead = Dict{Float64,Tuple{Int,Int,Int,DeviceVector,Vector{Float64}}}()
-    nbatch = (retract_method isa NR && c! isa DeviceConstraints) ? x.ctx.options.ls_batch : 1
+    nbatch = batch_width(x.ctx, retract_method, c!, work.prev_failures)
     failed_once = work.prev_failed
     any_failed = false
+    n_failed = 0
     while step_diff > param.ϵ_x
         iter1 = 0; iter2 = 0
         if haskey(ahead, α)
@@ -1001,7 +1017,7 @@ function armijo!(xnew::DeviceVector, x::DeviceVector, n::Int, d::DeviceVector, g
         end
         tot_iter1 += iter1; tot_iter2 += iter2
         if flag > 0                                                               # :57-60
-            failed_once = true; any_failed = true
+            failed_once = true; any_failed = true; n_failed += 1
             α *= param.s
             continue
         end
@@ -1018,6 +1034,7 @@ function armijo!(xnew::DeviceVector, x::DeviceVector, n::Int, d::DeviceVector, g
         end
     end
     work.prev_failed = any_failed
+    work.prev_failures = n_failed
     return flag, tot_iter1, tot_iter2, newf, f_diff, step_diff, α
 end
 
@@ -1041,7 +1058,7 @@ function exact_linesearch!(xnew::DeviceVector, x::DeviceVector, n::Int, d::Devic
     end
     # Shrinking phase (:176-208): the trial steps a_c φ1, a_c φ1², ... are a fixed sequence from the same x, and where it runs most of
     # them fail after the full iteration limit: the next `ls_batch` are retracted together and consumed in the reference's order.
-    nbatch = (retract_method isa NR && c! isa DeviceConstraints) ? x.ctx.options.ls_batch : 1
+    nbatch = batch_width(x.ctx, retract_method, c!, 2)
     ahead = Dict{Float64,Tuple{Int,Int,Int,DeviceVector,Vector{Float64}}}()
     retract_shrink! = function (pt::DeviceVector, a_next::Float64)
         if haskey(ahead, a_next)

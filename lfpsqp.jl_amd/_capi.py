@@ -124,6 +124,7 @@ _SIGS = {
     "lfpsqp_spmat_rowscale": [P, P, P, P],
     "lfpsqp_retract_nr": [P, C.POINTER(Basis), P, P, c_i64, C.POINTER(Constraints), CFUN, P, C.POINTER(IneqData), P, P, P, c_dbl, c_i64,
                           PD, C.POINTER(C.c_int), C.POINTER(c_i64)],
+    "lfpsqp_retract_nr_batch_width": [P, C.POINTER(Basis), C.POINTER(Constraints), C.POINTER(C.c_int)],
     "lfpsqp_retract_nr_batch": [P, C.POINTER(Basis), P, P, c_i64, C.POINTER(Constraints), C.POINTER(IneqData), C.c_int, C.POINTER(P), P,
                                 C.POINTER(P), c_dbl, c_i64, PD, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_pcg": [P, c_dbl, C.POINTER(Basis), P, P, P, P, P, P, c_dbl, c_i64, C.POINTER(C.c_int), C.POINTER(c_i64)],

@@ -350,16 +350,17 @@ int lfpsqp_ctx_create(int device, lfpsqp_ctx** out) {
     }
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess;
     ok = ok && hipMalloc((void**)&ctx->scal, 64 * sizeof(double)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&ctx->istat, 64 * sizeof(int64_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&ctx->istat, 128 * sizeof(int64_t)) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&ctx->h_scal, 4 * 64 * sizeof(double)) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&ctx->h_istat, 4 * 16 * sizeof(int64_t)) == hipSuccess;
     for (int i = 0; ok && i < 4; ++i) ok = hipEventCreate(&ctx->ev_slot[i]) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->ev_t0) == hipSuccess && hipEventCreate(&ctx->ev_t1) == hipSuccess;
-    if (ok) ok = hipMemset(ctx->scal, 0, 64 * sizeof(double)) == hipSuccess && hipMemset(ctx->istat, 0, 64 * sizeof(int64_t)) == hipSuccess;
+    if (ok) ok = hipMemset(ctx->scal, 0, 64 * sizeof(double)) == hipSuccess && hipMemset(ctx->istat, 0, 128 * sizeof(int64_t)) == hipSuccess;
     if (!ok) { delete ctx; return set_err(nullptr, LFPSQP_ERR_HIP, "context resource allocation failed"); }
     if (const char* e = getenv("LFPSQP_ONEPASS")) ctx->tune_onepass = atoi(e);
     if (const char* e = getenv("LFPSQP_SPGRAM")) ctx->tune_spgram = atoi(e) < 0 ? -1 : 0;
     if (const char* e = getenv("LFPSQP_VEC_BLOCKS")) ctx->tune_vec_blocks = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("LFPSQP_NRB_MFMA")) ctx->tune_nrb_mfma = atoi(e) > 0 ? 1 : (atoi(e) < 0 ? -1 : 0);
     if (const char* e = getenv("LFPSQP_GPING")) ctx->tune_gping = atoi(e) == 1 ? 1 : 0;
     if (const char* e = getenv("LFPSQP_STAGE_ROUNDS")) ctx->stage_cap = atoi(e) > 0 ? atoi(e) : 0;
     *out = ctx;

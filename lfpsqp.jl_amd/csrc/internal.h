@@ -96,6 +96,7 @@ struct lfpsqp_ctx {
     int tune_onepass = 0;
     int tune_spgram = 0;    // lfpsqp_factorize_sp: 0 = Gram matrix from the nonzeros (sp_gram), -1 = on a dense copy (env LFPSQP_SPGRAM=-1; A/B timing)
     int tune_vec_blocks = 0;   // vec_kernel: 0 = one tile per block (4096 blocks at most with reductions); > 0 = at most this many blocks (env LFPSQP_VEC_BLOCKS)
+    int tune_nrb_mfma = 0;     // batched Newton step: 0 = matrix cores for more than 4 trials, 1 = for every batch, -1 = never (env LFPSQP_NRB_MFMA)
     int tune_gping = 0;     // fused projected-CG iteration: 0 = the residual updated in place, 1 = two buffers alternating (lfpsqp_ctx_set_residual_buffers)
 
     bool real_gpu = false;   // gcnArchName "gfx..." (false only in the CPU emulator build of the tests)

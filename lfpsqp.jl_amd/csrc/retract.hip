@@ -393,8 +393,8 @@ struct NRSparseStepF {
     }
 };
 
-constexpr int kNRBatchMax = 4;
-enum { I_NRB = 32, I_NRB_ALL = 48 };                      // istat: [status, iterations, flag, -] per trial, then the all-done word
+constexpr int kNRBatchMax = 16;                           // (2 or 4 trials: the VALU form of the one-pass kernel; 5..16: the matrix cores, nrbatch.h)
+enum { I_NRB = 32, I_NRB_ALL = I_NRB + 4 * kNRBatchMax };   // istat: [status, iterations, flag, -] per trial, then the all-done word
 struct NRSmallB {
     NRSmall t[kNRBatchMax];
     int nb;
@@ -655,6 +655,61 @@ int nr_batch_step(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, int wm, int m
     for (int b = 0; b < NB; ++b) { ep.xnew[b] = xnew[b]->p; ep.ist[b] = ctx->istat + I_NRB + 4 * b; }
     ep.all = ctx->istat + I_NRB_ALL;
     return run_onepass<NRStepBatchRow<ST, NB>, NB, NB, NB>(ctx, cons->Jct, wm, ml, N, dwdelta, ep, draw, 7, wstride);     // (profiling slot 7)
+}
+
+}  // namespace lfpsqp
+
+#include "nrbatch.h"
+
+namespace lfpsqp {
+
+// shape covered by the matrix-core form of the batched step?  (first product over wm <= 132 columns, second over ml <= 128)
+static bool nrb_mfma_shape(int wm, int ml) { return wm >= 4 && wm <= 132 && ml >= 1 && ml <= 128 && ml <= wm; }
+
+template <bool ST, int CPL, int NBLK>
+static int nrb_mfma_launch(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int wm, int ml, int64_t N, const double* dwdelta, int wstride, const NRBatchArgs& ep,
+                           double* out) {
+    ++ctx->launch_epoch;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nrb_mfma_kernel<ST, CPL, NBLK>, kThreads, 0) != hipSuccess || nb < 1) nb = 1;
+        per_cu = nb;
+    }
+    const int64_t rounds = (N + kOnepassRound - 1) / kOnepassRound;
+    const int nout = kNRBW * ml + kNRBW;
+    const int part_ld = (int)round_up(nout, 32);
+    if (rounds <= 0) {
+        LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
+        return allreduce_dev(ctx, out, nout);
+    }
+    int64_t g = (int64_t)per_cu * (ctx->num_cu > 0 ? ctx->num_cu : 1);
+    if (g > rounds) g = rounds;
+    const int grid = (int)(g < 1 ? 1 : g);
+    LF_TRY(ensure_part(ctx, (size_t)grid * kWaves * part_ld + reduce_scratch(part_ld)));
+    prof_begin(ctx, 7);
+    hipLaunchKernelGGL((nrb_mfma_kernel<ST, CPL, NBLK>), dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, M->p, M->ld, wm, ml, N, rounds, dwdelta,
+                       wstride, ep, ctx->part, part_ld);
+    prof_end(ctx, 7);
+    LF_LAUNCH_CHECK(ctx);
+    LF_TRY(launch_reduce(ctx, (int64_t)grid * kWaves, nout, part_ld, 0u, out, NoPost()));
+    return allreduce_dev(ctx, out, nout);
+}
+
+template <bool ST>
+static int nrb_mfma_step(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, int wm, int ml, int64_t N, const double* dwdelta, int wstride,
+                         const NRStepE& ep0, lfpsqp_vec* const* xnew, int nb, double* draw) {
+    NRBatchArgs ep;
+    ep.e = ep0;
+    for (int b = 0; b < kNRBW; ++b) ep.xnew[b] = xnew[b < nb ? b : 0]->p;
+    ep.ist = ctx->istat + I_NRB;
+    ep.all = ctx->istat + I_NRB_ALL;
+    ep.nb = nb;
+    const int cpl = (wm + 3) / 4, nblk = (ml + 15) / 16;
+    if (cpl <= 9 && nblk <= 3) return nrb_mfma_launch<ST, 9, 3>(ctx, cons->Jct, wm, ml, N, dwdelta, wstride, ep, draw);
+    if (cpl <= 17 && nblk <= 5) return nrb_mfma_launch<ST, 17, 5>(ctx, cons->Jct, wm, ml, N, dwdelta, wstride, ep, draw);
+    if (cpl <= 32) return nrb_mfma_launch<ST, 32, 8>(ctx, cons->Jct, wm, ml, N, dwdelta, wstride, ep, draw);
+    return nrb_mfma_launch<ST, 33, 8>(ctx, cons->Jct, wm, ml, N, dwdelta, wstride, ep, draw);
 }
 
 }  // namespace lfpsqp
@@ -928,7 +983,21 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
 }
 
 
-// Batched form of lfpsqp_retract_nr: nb (2..4) independent retractions of the trial points xtilde[b] (all from the same x,
+// How many trial points lfpsqp_retract_nr_batch takes per pass for this basis and these constraints: 16 (the step on the matrix cores: up
+// to 132 generator columns / 128 linear constraints), 4 (the VALU form: up to 256 columns) or 0 (cannot batch: no generator, sparse
+// constraint gradients, the nonlinear class, a shape without the one-stream step).
+int lfpsqp_retract_nr_batch_width(const lfpsqp_ctx* ctx, const lfpsqp_basis* U, const lfpsqp_constraints* cons, int* width) {
+    if (!ctx || !U || !cons || !width || !cons->Jct) return LFPSQP_ERR_ARG;
+    *width = 0;
+    if (cons->Jsp || cons->ew) return 0;
+    const int ml = (int)cons->m_lin;
+    const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kColChunk) ? (int)U->A->m : 0;
+    if (!wm || U->ncols > kNRMaxM || !onepass_cw(ctx, wm, cons->Jct->ld, cons->Jct->n)) return 0;
+    *width = (nrb_mfma_shape(wm, ml) && ctx->tune_nrb_mfma >= 0) ? kNRBatchMax : 4;
+    return 0;
+}
+
+// Batched form of lfpsqp_retract_nr: nb (2..16) independent retractions of the trial points xtilde[b] (all from the same x,
 // the same factors and constraints) advance together, one pass over Jct per Newton step for all of them.  Each trial
 // has its own Broyden state, convergence test and iteration count and stops on its own (a finished trial keeps its
 // iterate); the call returns when all have finished.  Requires the one-stream step (basis generator known,
@@ -940,7 +1009,12 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
     LF_RANGE("lfpsqp_retract_nr_batch");
     LF_ARG(ctx, ctx && U && Sigma && Vt && xtilde && x && xnew && cval && flags && iters && m64 >= 1 && U->ncols == m64);
     LF_ARG(ctx, cons_ok(cons) && nb >= 2 && nb <= kNRBatchMax);
-    if (cons->Jsp || cons->ew) return LFPSQP_ERR_UNSUPPORTED;     // sparse constraint gradients: single steps on the nonzeros beat a shared dense pass; nonlinear class: one by one
+    {
+        int width = 0;
+        LF_TRY(lfpsqp_retract_nr_batch_width(ctx, U, cons, &width));
+        if (width == 0) return LFPSQP_ERR_UNSUPPORTED;            // (sparse constraint gradients, the nonlinear class, shapes without the one-stream step)
+        if (nb > width) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "batched Newton retraction: %d trials, this shape takes at most %d per pass", nb, width);
+    }
     const int m = (int)m64;
     const bool ineq = idata != nullptr;
     LF_ARG(ctx, ineq == (U->Dx != nullptr));
@@ -953,7 +1027,11 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
     const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kColChunk) ? (int)U->A->m : 0;
     if (!wm || m > kNRMaxM || !onepass_cw(ctx, wm, cons->Jct->ld, N) || wm > kColChunk)
         return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "batched Newton retraction needs the one-stream step (generator known, 4..256 columns)");
-    const int NBk = nb <= 2 ? 2 : 4;                   // instantiated batch widths; a missing trial is born finished
+    LF_TRY(ensure_mvec(ctx, (size_t)kNRBatchMax * m + 8));            // h_m: the trials' constraint values on their way back
+    // instantiated batch widths (a missing trial is born finished): 2 and 4 on the VALU form of the one-pass kernel, 16 on the matrix
+    // cores (ctx->tune_nrb_mfma: 1 = the matrix-core form for every batch its shape covers, -1 = never)
+    const bool mfma = nrb_mfma_shape(wm, ml) && ctx->tune_nrb_mfma >= 0 && (nb > 4 || ctx->tune_nrb_mfma > 0);
+    const int NBk = mfma ? kNRBatchMax : (nb <= 2 ? 2 : 4);
     const size_t mm = (size_t)m * m;
     const int wstride = (int)round_up(wm, 2);
     const int rawn = NBk * ml + NBk;
@@ -1013,7 +1091,10 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
     int64_t it = 0;
     bool done = false;
     while (!done && it < maxiter) {
-        if (NBk == 2) {
+        if (mfma) {
+            if (ineq) LF_TRY((nrb_mfma_step<true>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, nb, draw)));
+            else LF_TRY((nrb_mfma_step<false>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, nb, draw)));
+        } else if (NBk == 2) {
             if (ineq) LF_TRY((nr_batch_step<true, 2>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, draw)));
             else LF_TRY((nr_batch_step<false, 2>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, draw)));
         } else {

@@ -5,7 +5,7 @@ from __future__ import annotations
 import math
 
 from .device import DeviceVector, dot, nrm2, waxpby
-from .retractions import retract_, retract_nr_batch_
+from .retractions import retract_, retract_nr_batch_, retract_nr_batch_width_
 
 
 class ArmijoWork:  # src/linesearch.jl:1-5
@@ -15,6 +15,7 @@ class ArmijoWork:  # src/linesearch.jl:1-5
         self.batch = None          # lazily: (xtildes, xnews) for batched trial retractions
         self.ls_batch = int(like.ctx.options.ls_batch)      # DeviceOptions: trial retractions per pass
         self.prev_failed = False   # did the previous search see a failed retraction? (then this one batches from its first trial)
+        self.prev_failures = 0     # ... and how many: the automatic batch width follows it
 
     def batch_vectors(self, k):
         if self.batch is None or len(self.batch[0]) < k:
@@ -29,11 +30,26 @@ class ExactLinesearchWork:  # :7-14
         self.tmp_n1, self.tmp_n2, self.tmp_n3, self.tmp_n4 = mk(), mk(), mk(), mk()
         self.batch = None          # lazily: (xtildes, xnews) for batched trial retractions of the shrinking phase
         self.ls_batch = int(like.ctx.options.ls_batch)
+        self.prev_failures = 0
 
     def batch_vectors(self, k):
         if self.batch is None or len(self.batch[0]) < k:
             self.batch = ([self._mk() for _ in range(k)], [self._mk() for _ in range(k)])
         return self.batch
+
+
+def _batch_width(work, retract_method, c_):
+    """Trial retractions per pass for this search: DeviceOptions.ls_batch (1 = off, k > 1 = at most k, 0 = automatic: what the
+    previous search's failures suggest, at least 4), never more than the library takes for this shape."""
+    opt = int(getattr(work, "ls_batch", 1))
+    if opt == 1:
+        return 1
+    width = retract_nr_batch_width_(c_, retract_method)
+    if width < 2:
+        return 1
+    if opt > 1:
+        return min(opt, width)
+    return min(width, max(4, int(getattr(work, "prev_failures", 0)) + 2))
 
 
 def _step_norm(step, n_head):
@@ -57,12 +73,10 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
     # this search (or from its first trial when the previous search had failures), with the next `ls_batch` (ctx.options.ls_batch, a device option: not in LFPSQPParams) steps of the reference's own sequence alpha*s, alpha*s^2, ... -- the loop
     # below consumes them exactly as it would have computed them one by one.
     ahead = {}
-    nbatch = int(getattr(work, "ls_batch", 1))
-    from .retractions import NR as _NR, DeviceConstraints as _DC
-    if not (isinstance(retract_method, _NR) and isinstance(c_, _DC)):
-        nbatch = 1                                             # only Newton retractions on device-resident constraints batch
+    nbatch = _batch_width(work, retract_method, c_)          # (only Newton retractions on device-resident constraints batch)
     failed_once = bool(getattr(work, "prev_failed", False))   # searches in a failing regime batch from their first trial
     any_failed = False
+    n_failed = 0
     while step_diff > param.eps_x:
         if alpha in ahead:
             flag, iter1, iter2, xb, cb = ahead.pop(alpha)
@@ -93,6 +107,7 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
                 flag, iter1, iter2 = retract_(cval, xnew, c_, xtilde, x, retract_method)
         if flag > 0:
             failed_once = any_failed = True
+            n_failed += 1
         tot_iter1 += iter1
         tot_iter2 += iter2
         if flag > 0:
@@ -111,6 +126,7 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
             flag = 99
             break
     work.prev_failed = any_failed
+    work.prev_failures = n_failed
     return flag, tot_iter1, tot_iter2, newf, f_diff, step_diff, alpha
 
 
@@ -139,9 +155,9 @@ def exact_linesearch_(xnew, x, n, d, f, fval, retract_method, cval, c_, param, w
     # and in the regime where it runs (the first trial of the search failed) most of them fail after the full iteration limit.
     # The next `ls_batch` of them are retracted together (lfpsqp_retract_nr_batch: one pass over Jct per Newton step for all) and
     # consumed in the reference's order -- same points, flags and counts as one by one; unconsumed look-ahead is not counted.
-    from .retractions import NR as _NR, DeviceConstraints as _DC
-    nbatch = int(getattr(work, "ls_batch", 1)) if (isinstance(retract_method, _NR) and isinstance(c_, _DC)) else 1
+    nbatch = _batch_width(work, retract_method, c_)
     ahead = {}
+    n_shrink_failed = [0]
 
     def _retract_shrink(pt, a_next):
         """retract x + a_next*d into pt (pt already holds xtilde), looking ahead along a_next*phi1^k"""
@@ -208,6 +224,7 @@ def exact_linesearch_(xnew, x, n, d, f, fval, retract_method, cval, c_, param, w
             a_d = a_c
             waxpby(1.0, x, phi1 * a_c, d, x_c)
             flag = _retract_shrink(x_c, phi1 * a_c)
+            n_shrink_failed[0] += 1 if flag > 0 else 0
             a_c *= phi1
             f_c = math.inf if (flag > 0 or a_c > 1.0) else f(x_c)
             if f_c <= fval or a_c < 1e-100:
@@ -246,4 +263,5 @@ def exact_linesearch_(xnew, x, n, d, f, fval, retract_method, cval, c_, param, w
     waxpby(1.0, xnew, -1.0, x, step)
     step_diff = _step_norm(step, n)
     f_diff = abs(newf - fval)
+    work.prev_failures = n_shrink_failed[0]
     return flag, tot[0], tot[1], newf, f_diff, step_diff, alpha

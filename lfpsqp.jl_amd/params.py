@@ -73,7 +73,9 @@ class DeviceOptions:
     # (alpha*s, alpha*s^2, ...) are retracted together: they share every pass over the constraint gradients (lfpsqp_retract_nr_batch); the
     # search consumes them in the reference's order, so the accepted step and all counts are those of the one-by-one search.  1 = off.
     # Only the Newton retraction with device-resident constraints batches; everything else ignores it.
-    ls_batch: int = 4
+    # 0 (default) = automatic: as many as the previous search's failed retractions suggest (at least 4), up to what one pass takes for
+    # the problem's shape (lfpsqp_retract_nr_batch_width: 16 on the matrix cores, 4 otherwise); k > 1 = at most k.
+    ls_batch: int = 0
     # candidate allocations per placement-tuned buffer (lfpsqp_ctx_set_placement; 1 = off)
     placement_tries: int = 3
     # the tangent basis stays in factored form U = Jct W (no n x m basis matrix, no basis-forming product in the tangent setup) whenever the

@@ -171,6 +171,21 @@ def retract_(cval: np.ndarray, xnew: DeviceVector, c_, xtilde: DeviceVector, x: 
     raise TypeError(f"no retract_ method for {type(method)}")
 
 
+def retract_nr_batch_width_(c_, method) -> int:
+    """How many trial points retract_nr_batch_ takes per pass for this retraction method and these constraints
+    (lfpsqp_retract_nr_batch_width): 16 (matrix cores), 4, or 0 (cannot batch)."""
+    if not isinstance(c_, DeviceConstraints) or not isinstance(method, NR):
+        return 0
+    bc = method.U._c()
+    if not bc.A or not bc.W:
+        return 0
+    ctx = c_.Jct.ctx
+    cons = c_._c()
+    w = C.c_int(0)
+    ctx.check(ctx.L.lfpsqp_retract_nr_batch_width(ctx.h, C.byref(bc), C.byref(cons), C.byref(w)))
+    return int(w.value)
+
+
 def retract_nr_batch_(cvals: np.ndarray, xnews, c_, xtildes, x, method: NR):
     """Several Newton retractions of one linesearch at once (lfpsqp_retract_nr_batch): cvals is (nb, m), xnews / xtildes lists
     of nb device vectors.  Returns a list of (flag, iter1, 0) per trial, or None when the device cannot batch this

@@ -591,11 +591,12 @@ def test_pcg_one_pass_iteration_matches_two_pass_kernels(dev_ctx, monkeypatch, m
         assert not np.array_equal(res["-1"][2], res["0"][2])
 
 
-@pytest.mark.parametrize("nb,bounds", [(2, False), (3, True), (4, True)])
+@pytest.mark.parametrize("nb,bounds", [(2, False), (3, True), (4, True), (4, False), (5, False), (8, True), (8, False), (13, True), (16, True), (16, False)])
 def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds):
     """lfpsqp_retract_nr_batch: nb trial points of one linesearch retracted together (one pass over Jct per Newton step for all of
     them) give, trial by trial, what lfpsqp_retract_nr gives one by one -- including trials that converge at different
-    iterations and one that fails (maxiter)."""
+    iterations and one that fails (maxiter).  Up to 4 trials: the VALU form of the one-pass kernel; 5 ... 16: the step on the matrix
+    cores (nrbatch.h: both products of src/retractions.jl:141 / :146 as v_mfma_f64_16x16x4_f64 contractions over the stacked trials)."""
     ctx = dev_ctx
     n, m = (1500, 7) if _is_emu(ctx) else (200_000, 31)
     P0 = synth.BallBoxProblem(n, m)
@@ -625,7 +626,8 @@ def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds):
     x, d, method, c_, mm = captured["x"], captured["d"], captured["method"], captured["c_"], captured["m"]
     assert isinstance(method, L.NR)
     method.maxiter = 40                                    # so that the largest step fails while the small ones converge
-    alphas = [64.0, 0.02, 2e-3, 1e-4][:nb]
+    alphas = ([64.0, 0.02, 2e-3, 1e-4] + [0.05 * 0.5 ** k for k in range(12)])[:nb]
+    assert L.retract_nr_batch_width_(c_, method) == 16
     xts, xns = captured["work"].batch_vectors(nb)
     for a, xt in zip(alphas, xts):
         L.waxpby(1.0, x, a, d, xt)
@@ -642,8 +644,16 @@ def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds):
         xa = xns[b].download2() if bounds else xns[b].download()
         xb_ = one.download2() if bounds else one.download()
         if fl == 0:
-            np.testing.assert_allclose(xa, xb_, rtol=0, atol=1e-12 * max(1.0, np.abs(xb_).max()))
-            np.testing.assert_allclose(cvs[b], cv, atol=1e-8)      # c(xnew) ~ 0: differences of rounding size in a sum over n terms
+            # The matrix-core form (nb > 4) sums in another order than the single-trial kernel.  A trial that starts far away (alpha = 64:
+            # iterates of size 1e3, constraint values of size 1e9 in its first steps) and needs dozens of Broyden steps amplifies that
+            # rounding along its path -- it still lands on c = 0 after the same number of steps, at a point 1e-9 (relative) along the manifold
+            # from the other kernel's; trials that converge from nearby agree to 1e-12.
+            rel = 1e-12 if (nb <= 4 or it <= 20) else 1e-8
+            np.testing.assert_allclose(xa, xb_, rtol=0, atol=rel * max(1.0, np.abs(xb_).max()))
+            if rel == 1e-12:
+                np.testing.assert_allclose(cvs[b], cv, atol=1e-8)      # c(xnew) ~ 0: differences of rounding size in a sum over n terms
+            else:
+                assert np.abs(cvs[b]).max() < method.tol and np.abs(cv).max() < method.tol      # both converged; see above
     assert 0 in flags
     if _is_emu(ctx):
         assert len(set(g[1] for g in got)) > 1, got            # the trials really finished at different iterations

@@ -1,13 +1,14 @@
-# kernel timeline of the BATCHED Newton-retraction loop (lfpsqp_retract_nr_batch inside bench.py's extras): durations and gaps
+# kernel timeline of the BATCHED Newton-retraction loop (tools/time_nrbatch.py, 16 trials on the matrix cores): durations and gaps
+#   bash tools/gpu_nrb_trace.sh [bounds 0|1] [nb]
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_nrb -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --prewarm-seconds 0 > $R/gpurun_out/trace_nrb.log 2>&1
-cd $R; python - <<'PY' | tee gpurun_out/nrb_trace.txt
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; B=${1:-1}; NB=${2:-16}
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_nrb -- python3 $R/tools/time_nrbatch.py 1e7 128 --bounds $B --nbs $NB --iters 30 > $R/gpurun_out/trace_nrb.log 2>&1
+cd $R; tail -2 gpurun_out/trace_nrb.log; python - <<'PY' | tee gpurun_out/nrb_trace.txt
 import csv, glob, collections
 f = sorted(glob.glob("gpurun_out/trace_nrb/**/*kernel_trace.csv", recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "NRStepBatchRow" in r["Kernel_Name"]]
-seq = rows[idx[2]:idx[-2] + 1]          # steady state of the batched loop
+idx = [i for i, r in enumerate(rows) if "nrb_mfma_kernel" in r["Kernel_Name"] or "NRStepBatchRow" in r["Kernel_Name"]]
+seq = rows[idx[35]:idx[85] + 1]          # steady state of the batched loop (second timed repetition)
 def short(n):
     n = n.replace("void lfpsqp::", "").replace("lfpsqp::", "")
     return n[:60]
@@ -15,7 +16,7 @@ dur = collections.defaultdict(list); gaps = []
 for a, b in zip(seq, seq[1:]):
     dur[short(a["Kernel_Name"])].append(int(a["End_Timestamp"]) - int(a["Start_Timestamp"]))
     gaps.append(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]))
-steps = len(idx) - 4
+steps = 50
 span = (int(seq[-1]["Start_Timestamp"]) - int(seq[0]["Start_Timestamp"])) / 1e3
 print(f"{steps} batched steps, {span/steps:.1f} us per step; kernels per step: {len(seq)/steps:.1f}; gaps per step {sum(gaps)/steps/1e3:.1f} us")
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
