@@ -580,24 +580,26 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         if pcnt[5] and pcnt[6]:
             pcg_chain = {"fused_kernel_ms": pms[5] / pcnt[5], "P3_vector_kernel_ms": pms[6] / pcnt[6]}
     pcg_bytes = 8.0 * n_loc * m + 80.0 * n_loc               # one-pass iteration: J once + 10 n-vector passes
-    # four trial points of one linesearch retracted together (lfpsqp_retract_nr_batch): one pass over J per Newton step for all
-    nbt = 4
-    xts = [ctx.vector(n_loc) for _ in range(nbt)]
-    xns = [ctx.vector(n_loc) for _ in range(nbt)]
-    for j, xt_ in enumerate(xts):
-        L.waxpby(1.0, xs, 0.5 ** j, pert, xt_)
-    nrb = L.NR(L.DeviceBasis(Z2, generator=(J, Wg)), S, Vt, 0.0, 100, L.NRWork(m), False, None)
-    cvs = np.zeros((nbt, m))
-    nr_batch_ms = nr_batch_kernel_ms = None
-    for rep in range(2):
-        ctx.set_profiling(True)
-        ctx.sync(); t0 = time.perf_counter(); got = L.retract_nr_batch_(cvs, xns, cons, xts, xs, nrb); ctx.sync()
-        if got is not None:
-            nr_batch_ms = (time.perf_counter() - t0) * 1e3 / max(got[0][1], 1)
-        pms, pcnt = ctx.profile_read(); ctx.set_profiling(False)
-        nr_batch_kernel_ms = (pms[7] / pcnt[7]) if pcnt[7] else None
-    for v_ in xts + xns:
-        v_.free()
+    # several trial points of one linesearch retracted together (lfpsqp_retract_nr_batch): one pass over J per Newton step for all of them --
+    # 4 on the VALU form of the one-pass kernel, 8 and 16 on the matrix cores (100 steps forced by tol = 0)
+    nrb_ms, nrb_kernel_ms = {}, {}
+    for nbt in (4, 8, 16):
+        xts = [ctx.vector(n_loc) for _ in range(nbt)]
+        xns = [ctx.vector(n_loc) for _ in range(nbt)]
+        for j, xt_ in enumerate(xts):
+            L.waxpby(1.0, xs, 0.5 ** j, pert, xt_)
+        nrb = L.NR(L.DeviceBasis(Z2, generator=(J, Wg)), S, Vt, 0.0, 100, L.NRWork(m), False, None)
+        cvs = np.zeros((nbt, m))
+        for rep in range(2):
+            ctx.set_profiling(True)
+            ctx.sync(); t0 = time.perf_counter(); got = L.retract_nr_batch_(cvs, xns, cons, xts, xs, nrb); ctx.sync()
+            if got is not None:
+                nrb_ms[nbt] = (time.perf_counter() - t0) * 1e3 / max(got[0][1], 1)
+            pms, pcnt = ctx.profile_read(); ctx.set_profiling(False)
+            nrb_kernel_ms[nbt] = (pms[7] / pcnt[7]) if pcnt[7] else None
+        for v_ in xts + xns:
+            v_.free()
+    nr_batch_ms, nr_batch_kernel_ms = nrb_ms.get(4), nrb_kernel_ms.get(4)
     # the fused projected-CG iteration on the basis in factored form (streams J, applies W in the post-kernel) against the materialised Z2
     Af = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.0, 5.0))
     bf, xf, wf = ctx.vector(n_loc).hash_fill(4, r0), ctx.vector(n_loc), L.ProjCGWork(ctx, n_loc, m)
@@ -698,7 +700,9 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
             "nr_step_two_streams_ms": nr_ms["two_streams"], "nr_step_two_streams_GBs": gbs(nr2_bytes, nr_ms["two_streams"]),
             "nr_step_kernel_ms": nr_chain["one_stream"], "nr_step_gap_note": "nr_step_ms = wall per iteration of a 200-iteration call; nr_step_kernel_ms = the one-pass step kernel alone (HIP events); the rest is the m x m Broyden kernel (~25 us) and the second-stage reduction",
-            "nr_batch4_step_ms": nr_batch_ms, "nr_batch4_step_kernel_ms": nr_batch_kernel_ms, "projcg_call_iter_materialised_ms": pf["materialised"], "projcg_call_iter_factored_ms": pf["factored"],
+            "nr_batch4_step_ms": nr_batch_ms, "nr_batch4_step_kernel_ms": nr_batch_kernel_ms,
+            "nr_batch8_step_ms": nrb_ms.get(8), "nr_batch8_step_kernel_ms": nrb_kernel_ms.get(8), "nr_batch16_step_ms": nrb_ms.get(16), "nr_batch16_step_kernel_ms": nrb_kernel_ms.get(16),
+            "nr_batch_note": "ms per Newton step of a 100-step call for 4 / 8 / 16 trial points without bounds (4: VALU form of the one-pass kernel; 8, 16: v_mfma_f64_16x16x4_f64, csrc/nrbatch.h); wall includes the per-trial start (copy, first c! pass) and the trials' m x m Broyden kernels", "projcg_call_iter_materialised_ms": pf["materialised"], "projcg_call_iter_factored_ms": pf["factored"],
             "projcg_factored_xnorm_rel_diff": abs(pf["factored_xnorm"] - pf["materialised_xnorm"]) / pf["materialised_xnorm"], "nr_iters_timed": its_long, "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit), "pcg_iter_kernel_chain": pcg_chain,
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies; the Gram kernel computes the upper "
                     "triangle only (16 x 16 tiles on and above the diagonal): gram_TFLOPs_executed counts that work, ..._of_the_full_product 2 n m^2"}

@@ -58,8 +58,12 @@ struct NRBatchArgs {
     int nb;
 };
 
-// swizzle of the transposed-tile staging area: element (row, col) of a 16 x 64 chunk lives at word row * 64 + (col ^ swz(row))
-__device__ __forceinline__ int nrb_swz(int row) { return ((row & 1) << 4) | ((row >> 3 & 1) << 3) | ((row >> 2 & 1) << 2) | ((row >> 1 & 1) << 1); }
+// Transposed-tile staging area: element (row, col) of a 16 x 64 chunk lives at word row * 66 + col.  The odd-ish row stride makes the
+// column-wise writes conflict-free (word = (66 r16 + kq) + 4c: lanes differ by 2 r16 + kq mod 32) and leaves the row-wise reads
+// ((66 kq + r16) + 66 * 4ks + 16 cb) with 2-way conflicts -- but BOTH address one lane-dependent register plus an immediate offset.  An
+// XOR swizzle is conflict-free on both sides and costs a register per (k-step, block) address: 25 registers this kernel does not have
+// (the bound-constrained form spilled 30, and a spilled load forces a full vmcnt(0) drain where it is reloaded).
+constexpr int kNRBLdr = kNRBChunk + 2;
 
 // CPL: column groups (of 4) of the first product held per lane, ncN <= 4 * CPL; NBLK: 16-column blocks of the second product, ncT <= 16 * NBLK.
 // part: one row PER WAVE: [trial * ncT + col] (16 x ncT), then the 16 ball partials.
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
     constexpr int NCH = (NBLK * 16 + kNRBChunk - 1) / kNRBChunk;
     constexpr int kStep = 16 * kWaves;
     __shared__ double ts[CPL * 4][kNRBW];
-    __shared__ double tj[kWaves][16 * kNRBChunk];
+    __shared__ double tj[kWaves][16 * kNRBLdr];
     __shared__ double vs[kWaves][16 * 17];
     __shared__ double* xp[kNRBW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
     double ball[4] = {0.0, 0.0, 0.0, 0.0};
     double* tjw = tj[wave];
     double* vsw = vs[wave];
-    const int swz_w = nrb_swz(r16);                           // my row's swizzle when I write column-wise
+    double* const tjwr = tjw + r16 * kNRBLdr + kq;            // my write position (column-wise: + 4 per register)
+    const double* const tjrd = tjw + kq * kNRBLdr + r16;      // my read position (row-wise: + 4 ks rows, + 16 per block)
     // Copy of the last group's register, taken after the first product: every chunk's staging write needs that group, but its reload for the
     // next tile must not wait for the last chunk -- without a separate store counter on this architecture the compiler drains ALL outstanding
     // memory operations (s_waitcnt vmcnt(0)) before the next first product, so a load issued right before it costs a full memory latency.
@@ -152,9 +157,9 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
     auto tj_write = [&](int h) {
 #pragma unroll
         for (int c = 16 * h; c < 16 * h + 16 && c < CPL; ++c)
-            if (c < glast) tjw[r16 * kNRBChunk + ((4 * (c - 16 * h) + kq) ^ swz_w)] = a[c];
+            if (c < glast) tjwr[4 * (c - 16 * h)] = a[c];
         const int lc = lastc0 + kq - kNRBChunk * h;          // the last group (register CPL - 1 always holds it; `alast` = its copy, below)
-        if (lc >= 0 && lc < kNRBChunk) tjw[r16 * kNRBChunk + (lc ^ swz_w)] = alast;
+        if (lc >= 0 && lc < kNRBChunk) tjw[r16 * kNRBLdr + lc] = alast;
     };
     // first product: Y'[trial, row] over all columns -- two accumulator chains, the coefficient operands read from LDS two MFMAs ahead
     // of their use (left to itself the compiler emits read -> wait -> MFMA, the LDS latency exposed 33 times per tile)
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
                 w.xn = in.xn[v]; w.yn = in.yn[v];
                 double so[2] = {0.0, 0.0};                  // the new iterate (x and y halves), stored below through the GLOBAL pointer
                 vv[v] = e.apply1<ST>(row, 0u, y[v], valid, true, w, ball[v], so, 1);
-                if (valid) {
+                if (valid && !e.eval_only) {                 // (eval_only: the launch that evaluates c! at the trial points: nothing is updated)
                     xpv[v][row] = so[0];
                     if (ST) xpv[v][e.hs + row] = so[1];
                 }
@@ -224,10 +229,7 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
             wave_lds_fence();
             constexpr int kBlkMax = 4;
             const int nsteps = 4 * ((NBLK - 4 * h) < kBlkMax ? (NBLK - 4 * h) : kBlkMax);
-            auto rd = [&](int i) {
-                const int rw = 4 * (i & 3) + kq;
-                return tjw[rw * kNRBChunk + ((16 * (i >> 2) + r16) ^ nrb_swz(rw))];
-            };
+            auto rd = [&](int i) { return tjrd[4 * (i & 3) * kNRBLdr + 16 * (i >> 2)]; };     // row 4ks + kq, column 16cb + r16
             double p0 = rd(0), p1 = rd(1);
 #pragma unroll
             for (int i = 0; i < 4 * kBlkMax; ++i) {
@@ -271,5 +273,6 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
         if (r16 == 0) prow[kNRBW * ncT + kq + 4 * v] = s;
     }
 }
+
 
 }  // namespace lfpsqp

@@ -1068,12 +1068,30 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
                           draw + (size_t)NBk * ml + b, dW, dwdelta + (size_t)b * wstride, ctx->istat + I_NRB + 4 * b, nullptr, m, ml,
                           cons->has_ball ? 1 : 0, wm, cons->R2, tol, maxiter};
     }
+    const NRStepE ep{xnew[0]->p, x->p, ineq ? lfpsqp_half_stride(N) : 0, ineq ? U->sx->p : nullptr, ineq ? U->sy->p : nullptr,
+                     ineq ? idata->q->p : nullptr, ineq ? idata->r->p : nullptr, ineq ? idata->s->p : nullptr,
+                     ineq ? idata->t->p : nullptr, cons->n_x, cons->slack_row, cons->has_ball ? 1 : 0, ctx->istat};
     for (int b = 0; b < nb; ++b) {                                                                  // :116-124 per trial
         LF_TRY(lfpsqp_vec_copy(ctx, xnew[b], xtilde[b]));
         if (ineq) LF_TRY(lfpsqp_y_retract(ctx, xnew[b], x, idata));
+        if (mfma) continue;                       // c! of all trial points in ONE pass over Jct, below
         if (ml > 0) LF_TRY(run_gemv_t(ctx, cons->Jct, ml, N, PlainVec{xnew[b]->p}, draw + (size_t)b * ml));
         if (cons->has_ball)
             LF_TRY((run_vec<BallF, 1, NoPost>(ctx, N, BallF{xnew[b]->p, cons->n_x, cons->slack_row}, 0u, draw + (size_t)NBk * ml + b, NoPost())));
+    }
+    if (mfma) {
+        // the step kernel with zero coefficients and nothing updated or stored (eval_only): its second product and ball partials ARE c! at the
+        // sixteen points -- one pass instead of a GEMV-T per trial
+        NRStepE e0 = ep;
+        e0.eval_only = 1;
+        if (!ctx->d_zeros) {
+            LF_HIP(ctx, hipMalloc((void**)&ctx->d_zeros, sizeof(double) * (kOnepassMaxCols + 8)));
+            LF_HIP(ctx, hipMemsetAsync(ctx->d_zeros, 0, sizeof(double) * (kOnepassMaxCols + 8), ctx->stream));
+        }
+        lfpsqp_vec* xe[kNRBatchMax];
+        for (int b = 0; b < kNRBatchMax; ++b) xe[b] = xnew[b < nb ? b : 0];
+        if (ineq) LF_TRY((nrb_mfma_step<true>(ctx, cons, wm, ml, N, ctx->d_zeros, 0, e0, xe, nb, draw)));
+        else LF_TRY((nrb_mfma_step<false>(ctx, cons, wm, ml, N, ctx->d_zeros, 0, e0, xe, nb, draw)));
     }
     if (NBk > nb) {                                    // born finished: status 1, flag 1
         const int64_t fin[3] = {1, 0, 1};
@@ -1085,9 +1103,6 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
     hipLaunchKernelGGL(nr_batch_all_kernel, dim3(1), dim3(1), 0, ctx->stream, sb, 1, (int64_t)-1);
     LF_LAUNCH_CHECK(ctx);
     LF_HIP(ctx, hipEventRecord(ctx->ev_slot[0], ctx->stream));
-    const NRStepE ep{xnew[0]->p, x->p, ineq ? lfpsqp_half_stride(N) : 0, ineq ? U->sx->p : nullptr, ineq ? U->sy->p : nullptr,
-                     ineq ? idata->q->p : nullptr, ineq ? idata->r->p : nullptr, ineq ? idata->s->p : nullptr,
-                     ineq ? idata->t->p : nullptr, cons->n_x, cons->slack_row, cons->has_ball ? 1 : 0, ctx->istat};
     int64_t it = 0;
     bool done = false;
     while (!done && it < maxiter) {

@@ -85,7 +85,7 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
         else:
             got = None
             if failed_once and nbatch > 1 and not param.disable_linesearch:
-                xts, xns = work.batch_vectors(nbatch)
+                xts, xns = (vs_[:nbatch] for vs_ in work.batch_vectors(nbatch))      # (the cache may hold more from an earlier, wider batch)
                 alphas = [alpha]
                 for _ in range(nbatch - 1):
                     alphas.append(alphas[-1] * param.s)
@@ -172,7 +172,7 @@ def exact_linesearch_(xnew, x, n, d, f, fval, retract_method, cval, c_, param, w
             return fl
         if nbatch > 1:
             import numpy as _np
-            xts, xns = work.batch_vectors(nbatch)
+            xts, xns = (vs_[:nbatch] for vs_ in work.batch_vectors(nbatch))      # (the cache may hold more from an earlier, wider batch)
             alphas = [a_next]
             for _ in range(nbatch - 1):
                 alphas.append(alphas[-1] * phi1)          # the reference's own products a_c *= phi1 (:196)

@@ -591,14 +591,20 @@ def test_pcg_one_pass_iteration_matches_two_pass_kernels(dev_ctx, monkeypatch, m
         assert not np.array_equal(res["-1"][2], res["0"][2])
 
 
-@pytest.mark.parametrize("nb,bounds", [(2, False), (3, True), (4, True), (4, False), (5, False), (8, True), (8, False), (13, True), (16, True), (16, False)])
-def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds):
+@pytest.mark.parametrize("nb,bounds,mcols", [(2, False, 0), (3, True, 0), (4, True, 0), (4, False, 0), (5, False, 0), (8, True, 0), (8, False, 0),
+                                             (13, True, 0), (16, True, 0), (16, False, 0),
+                                             # 65 .. 132 generator columns: the LDS-DMA form of the matrix-core step (nrb2_kernel); m = 128 with
+                                             # the ball column (129 columns: 17 DMA pieces) is config 4's shape, m = 127 + ball fills 128 exactly
+                                             (16, True, 128), (7, False, 128), (16, False, 127), (5, True, 69), (12, True, 100)])
+def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds, mcols):
     """lfpsqp_retract_nr_batch: nb trial points of one linesearch retracted together (one pass over Jct per Newton step for all of
     them) give, trial by trial, what lfpsqp_retract_nr gives one by one -- including trials that converge at different
     iterations and one that fails (maxiter).  Up to 4 trials: the VALU form of the one-pass kernel; 5 ... 16: the step on the matrix
     cores (nrbatch.h: both products of src/retractions.jl:141 / :146 as v_mfma_f64_16x16x4_f64 contractions over the stacked trials)."""
     ctx = dev_ctx
     n, m = (1500, 7) if _is_emu(ctx) else (200_000, 31)
+    if mcols:
+        n, m = (1100 if _is_emu(ctx) else 150_000), mcols
     P0 = synth.BallBoxProblem(n, m)
     N, M = n + 1, m + 1
     Jct = ctx.matrix(N, M).hash_fill(1, 0, n, 1.0, n, m)

@@ -5,7 +5,7 @@ import lfpsqp_jl_amd as L
 
 cfg = int(sys.argv[1]); args = [a for a in sys.argv[2:] if not a.startswith('--')]
 pp = '--pp' in sys.argv
-batch = int([a for a in sys.argv if a.startswith('--ls-batch=')][0].split('=')[1]) if any(a.startswith('--ls-batch=') for a in sys.argv) else 4
+batch = int([a for a in sys.argv if a.startswith('--ls-batch=')][0].split('=')[1]) if any(a.startswith('--ls-batch=') for a in sys.argv) else 0      # (0 = automatic: DeviceOptions.ls_batch)
 ctx = L.Context(0)
 t0 = time.perf_counter()
 if cfg == 2:
