@@ -506,6 +506,24 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
 int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, lfpsqp_vec* x, lfpsqp_vec* r, lfpsqp_vec* p, lfpsqp_vec* z,
                lfpsqp_vec* tmp_w, lfpsqp_vec* tmp_m, double tol, int64_t maxiter, int* flag, int64_t* iters);
 
+/* pcg! with an EXACT preconditioner M! (src/retractions.jl:209): the operator is A_f = D0 + E E' with E = [Jct; 0] and D0 = mu I (plain) or
+ * mu I plus the 2 x 2 blocks of the inequality rows (stacked), so M^-1 = D0^-1 - D0^-1 E K E' D0^-1 with the m x m matrix
+ * K = (I + E' D0^-1 E)^-1.  For the plain operator and K = mu W diag(s^2 / (mu + s^2)) W' (U = Jct W, Sigma = s) this is the reference's
+ * proj_precondition!(z, r, mu, U, Sigma, rank, tmp_m) (src/retractions.jl:248-257, the call commented out at :374); with K from the CURRENT
+ * Jct the solve converges in one iteration (test/test_retractions.jl:126-139).  Two passes over Jct per iteration (lfpsqp_pcg: one; its
+ * iteration counts on ill-conditioned bound problems run into the thousands).
+ *   K   host, m x m column-major (symmetric)
+ *   i11, i12, i22   stacked operator only: the rows of D0^-1 = [i11 i12; i12 i22] (N-vectors); NULL for the plain operator (D0^-1 = 1/mu)
+ *   q   work n-vector (A_f p)
+ * Same outputs and exit semantics as lfpsqp_pcg.  LFPSQP_ERR_UNSUPPORTED without the one-pass kernels (sparse twin, m < 4 or > 1024). */
+typedef struct lfpsqp_pcg_precond {
+    const double* K;
+    const lfpsqp_vec *i11, *i12, *i22;
+    lfpsqp_vec* q;
+} lfpsqp_pcg_precond;
+int lfpsqp_pcg_pre(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, const lfpsqp_pcg_precond* P, lfpsqp_vec* x, lfpsqp_vec* r,
+                   lfpsqp_vec* p, lfpsqp_vec* z, double tol, int64_t maxiter, int* flag, int64_t* iters);
+
 /* A user jac!: refresh the DEVICE matrix Jct (rows(Jct) x m, the reference's Jct = Jc') and cval at x. */
 typedef int (*lfpsqp_jacfun)(void* user, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval);
 
@@ -514,6 +532,12 @@ typedef int (*lfpsqp_jacfun)(void* user, const lfpsqp_vec* x, lfpsqp_mat* Jct, d
 typedef struct lfpsqp_pp_work {
     lfpsqp_vec *r, *p, *z, *dx, *g, *tmp_m;
     lfpsqp_vec *tmp_w, *h, *DxS, *DyS, *ones, *zeros;
+    /* OPTIONAL (all NULL / 0 = the reference's live path, no_precondition): q != NULL and precondition != 0 make every inner solve a
+     * lfpsqp_pcg_pre with the exact preconditioner of ITS operator -- K = (I + Jct' D0^-1 Jct)^-1 from a Gram pass over the current Jct
+     * (weighted by i11 with bounds), rebuilt whenever mu or the point changes; q: n-vector work (stacked with bounds); i11, i12, i22:
+     * N-vector work, bounds only.  The inner solves then take one or two iterations instead of hundreds to thousands. */
+    lfpsqp_vec *q, *i11, *i12, *i22;
+    int precondition;
 } lfpsqp_pp_work;
 
 /* retract!(cval, xnew, c!, xtilde, x, method::ProjPenalty) (src/retractions.jl:265-441), the reference's

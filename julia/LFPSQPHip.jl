@@ -93,6 +93,18 @@ struct CPPWork                 # lfpsqp_pp_work
     DyS::Ptr{Cvoid}
     ones::Ptr{Cvoid}
     zeros::Ptr{Cvoid}
+    q::Ptr{Cvoid}              # optional (exact preconditioner of the inner solves, DeviceOptions.pp_precondition): work n-vector
+    i11::Ptr{Cvoid}            # ... and, with bounds, the rows of D0^-1 (N-vectors)
+    i12::Ptr{Cvoid}
+    i22::Ptr{Cvoid}
+    precondition::Cint
+end
+struct CPcgPrecond             # lfpsqp_pcg_precond
+    K::Ptr{Float64}
+    i11::Ptr{Cvoid}
+    i12::Ptr{Cvoid}
+    i22::Ptr{Cvoid}
+    q::Ptr{Cvoid}
 end
 
 const LFPSQP_PROJCG_WANT_LAMBDA = Cint(1)
@@ -210,6 +222,9 @@ c_retract_nr_batch_width(ctx, U, cons, width) = ccall((:lfpsqp_retract_nr_batch_
 c_retract_nr_batch(ctx, U, Sigma, Vt, m, cons, idata, nb, xtilde, x, xnew, tol, maxiter, cval, flags, iters) = ccall((:lfpsqp_retract_nr_batch, lib), Cint,
     (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{CConstraints}, Ptr{CIneqData}, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Float64, Int64, Ptr{Float64}, Ptr{Cint}, Ptr{Int64}),
     ctx, U, Sigma, Vt, m, cons, idata, nb, xtilde, x, xnew, tol, maxiter, cval, flags, iters)
+c_pcg_pre(ctx, mu, J, P, x, r, p, z, tol, maxiter, flag, iters) = ccall((:lfpsqp_pcg_pre, lib), Cint,
+    (Ptr{Cvoid}, Float64, Ref{CBasis}, Ref{CPcgPrecond}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Ref{Cint}, Ref{Int64}),
+    ctx, mu, J, P, x, r, p, z, tol, maxiter, flag, iters)
 c_pcg(ctx, mu, Jop, x, r, p, z, tmp_w, tmp_m, tol, maxiter, flag, iters) = ccall((:lfpsqp_pcg, lib), Cint,
     (Ptr{Cvoid}, Float64, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Ref{Cint}, Ref{Int64}),
     ctx, mu, Jop, x, r, p, z, tmp_w, tmp_m, tol, maxiter, flag, iters)
@@ -228,6 +243,7 @@ mutable struct DeviceOptions
     ls_batch::Int
     placement_tries::Int
     factored_basis::Bool        # keep the tangent basis in factored form U = Jct W whenever the fused projected-CG iteration applies
+    pp_precondition::Bool       # ProjPenalty's inner solves with the exact preconditioner of their operator (lfpsqp_pcg_pre); false = the reference's live path
 end
 mutable struct HipContext
     h::Ptr{Cvoid}
@@ -238,7 +254,7 @@ mutable struct HipContext
         r = Ref{Ptr{Cvoid}}(C_NULL)
         rc = c_ctx_create(Cint(device), r)
         rc == 0 || throw(HipError(rc, "lfpsqp_ctx_create failed: no usable MI355X (there is no CPU fallback)"))
-        ctx = new(r[], 0, 1, DeviceOptions(0, 3, true))
+        ctx = new(r[], 0, 1, DeviceOptions(0, 3, true, false))
         finalizer(c -> c_ctx_destroy(c.h), ctx)
         return ctx
     end
@@ -747,6 +763,10 @@ struct ProjPenaltyWork                                                        # 
     DyS::Union{Nothing,DeviceVector}
     ones::Union{Nothing,DeviceVector}
     zeros::Union{Nothing,DeviceVector}
+    q::Union{Nothing,DeviceVector}          # DeviceOptions.pp_precondition: the inner solves run lfpsqp_pcg_pre
+    i11::Union{Nothing,DeviceVector}
+    i12::Union{Nothing,DeviceVector}
+    i22::Union{Nothing,DeviceVector}
 end
 # `against`: the constraint-gradient matrix the pcg! iteration streams -- the five n-vectors then come from one allocation chosen by the
 # library's placement policy against it (lfpsqp_vecs_alloc_placed), as ProjCGWork's do
@@ -754,12 +774,16 @@ function ProjPenaltyWork(like::DeviceVector, m::Integer, N::Integer, ineq::Bool;
     ctx = like.ctx
     v5 = (against !== nothing && ctx.options.placement_tries > 1) ? vectors_placed(ctx, against, N, 5; N=(ineq ? N : 0)) :
          [similar_device(like) for _ in 1:5]
-    ineq || return ProjPenaltyWork(v5..., DeviceVector(ctx, max(m, 1)), nothing, nothing, nothing, nothing, nothing, nothing)
+    pre = ctx.options.pp_precondition
+    q = pre ? similar_device(like) : nothing
+    ineq || return ProjPenaltyWork(v5..., DeviceVector(ctx, max(m, 1)), nothing, nothing, nothing, nothing, nothing, nothing, q, nothing, nothing, nothing)
     return ProjPenaltyWork(v5..., DeviceVector(ctx, max(m, 1)), DeviceVector(ctx, N), DeviceVector(ctx, N), DeviceVector(ctx, N), DeviceVector(ctx, N),
-                           fill!(DeviceVector(ctx, N), 1.0), DeviceVector(ctx, N))
+                           fill!(DeviceVector(ctx, N), 1.0), DeviceVector(ctx, N), q, pre ? DeviceVector(ctx, N) : nothing,
+                           pre ? DeviceVector(ctx, N) : nothing, pre ? DeviceVector(ctx, N) : nothing)
 end
 _h(v) = v === nothing ? C_NULL : v.h
-cppwork(w::ProjPenaltyWork) = CPPWork(w.r.h, w.p.h, w.z.h, w.dx.h, w.g.h, w.tmp_m.h, _h(w.tmp_w), _h(w.h), _h(w.DxS), _h(w.DyS), _h(w.ones), _h(w.zeros))
+cppwork(w::ProjPenaltyWork) = CPPWork(w.r.h, w.p.h, w.z.h, w.dx.h, w.g.h, w.tmp_m.h, _h(w.tmp_w), _h(w.h), _h(w.DxS), _h(w.DyS), _h(w.ones), _h(w.zeros),
+                                      _h(w.q), _h(w.i11), _h(w.i12), _h(w.i22), Cint(w.q === nothing ? 0 : 1))
 mutable struct ProjPenalty <: RetractionMethod                                # :35-49
     jac!::Any                  # DeviceConstraints (device-resident jac!) or a host jac!(J, cval, x)
     m::Int

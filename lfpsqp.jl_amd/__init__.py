@@ -14,7 +14,7 @@ from .inequality import (InequalityData, InequalityDecomp, InequalityDecompOp, I
 from .params import DeviceOptions, DisplayOption, LFPSQPParams, LinesearchOption, TerminationCondition, TerminationInfo  # noqa: F401
 from .retractions import (NR, DeviceConstraints, ElementwiseConstraints, Euclidean, NRWork, YRetract, retract_, retract_nr_batch_, retract_nr_batch_width_,  # noqa: F401
                           sin_system_constraints, sphere_system_constraints)
-from .projpenalty import ProjPenalty, ProjPenaltyWork, no_precondition, pcg_, proj_precondition_  # noqa: F401
+from .projpenalty import ProjPenalty, ProjPenaltyWork, ProjPrecondition, no_precondition, pcg_, proj_precondition_  # noqa: F401
 from .linesearch import ArmijoWork, ExactLinesearchWork, armijo_, exact_linesearch_  # noqa: F401
 from .optimize import optimize_core  # noqa: F401
 from .problems import Derivatives, QuadLinearBallBox, SeparableElementwiseBox, SeparableLinearBallBox, optimize  # noqa: F401

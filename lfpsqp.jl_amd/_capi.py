@@ -43,7 +43,12 @@ JACFUN = C.CFUNCTYPE(C.c_int, P, P, P, PD)
 
 
 class PPWork(C.Structure):  # lfpsqp_pp_work
-    _fields_ = [(k, P) for k in ("r", "p", "z", "dx", "g", "tmp_m", "tmp_w", "h", "DxS", "DyS", "ones", "zeros")]
+    _fields_ = [(k, P) for k in ("r", "p", "z", "dx", "g", "tmp_m", "tmp_w", "h", "DxS", "DyS", "ones", "zeros", "q", "i11", "i12", "i22")] + \
+               [("precondition", C.c_int)]
+
+
+class PcgPrecond(C.Structure):  # lfpsqp_pcg_precond
+    _fields_ = [("K", P), ("i11", P), ("i12", P), ("i22", P), ("q", P)]
 
 
 class ProjCGWorkC(C.Structure):  # lfpsqp_projcg_work
@@ -127,6 +132,7 @@ _SIGS = {
     "lfpsqp_retract_nr_batch_width": [P, C.POINTER(Basis), C.POINTER(Constraints), C.POINTER(C.c_int)],
     "lfpsqp_retract_nr_batch": [P, C.POINTER(Basis), P, P, c_i64, C.POINTER(Constraints), C.POINTER(IneqData), C.c_int, C.POINTER(P), P,
                                 C.POINTER(P), c_dbl, c_i64, PD, C.POINTER(C.c_int), C.POINTER(c_i64)],
+    "lfpsqp_pcg_pre": [P, c_dbl, C.POINTER(Basis), C.POINTER(PcgPrecond), P, P, P, P, c_dbl, c_i64, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_pcg": [P, c_dbl, C.POINTER(Basis), P, P, P, P, P, P, c_dbl, c_i64, C.POINTER(C.c_int), C.POINTER(c_i64)],
     "lfpsqp_retract_pp": [P, C.POINTER(Constraints), CFUN, JACFUN, P, P, c_i64, C.POINTER(IneqData), P, P, P, P, P, P, c_dbl, c_dbl, c_i64,
                           c_i64, C.POINTER(PPWork), PD, C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)],

@@ -315,9 +315,335 @@ struct RRF {
     }
 };
 
+// ---- pcg! with an EXACT preconditioner (lfpsqp_pcg_pre) -------------------------------------------------------------------------
+// The operator of the inner solve is  A_f = D0 + E E'  with E = [Jct; 0] and D0 = mu I (plain) or, with bounds, mu I plus the 2 x 2
+// blocks [a^2, ab; ab, b^2] of the inequality rows (a = Dx.*S, b = Dy.*S: src/inequality_helper.jl:215-271).  Its inverse is
+//     M^-1 = D0^-1 - D0^-1 E K E' D0^-1,     K = (I + E' D0^-1 E)^-1  (m x m),
+// and for the plain operator that IS the reference's proj_precondition! (src/retractions.jl:248-257: z = (r - U diag(s^2/(mu+s^2)) U'r)/mu
+// with U = Jct W, i.e. K = mu W diag(s^2/(mu+s^2)) W').  The caller hands over K and the rows of D0^-1; an iteration of
+// src/retractions.jl:207-238 is then three passes over Jct and one vector kernel -- and one iteration is what an exact M takes:
+//   S   sP = Jct'(D0^-1 r)_x, measured DIRECTLY (gemv_t_kernel).  (A recurrence sP+ = sP - alpha Jct'(D0^-1 q)_x would save this pass, but r
+//       shrinks by ten orders of magnitude in one iteration of an exact preconditioner and the recurrence cancels catastrophically: the
+//       second iteration then gains one digit instead of ten -- measured: 6e-11 -> 5e-12 against the oracle's 5e-11 -> 9e-22.)
+//   Z   z = M^-1 r:  first product Jct c1 with c1 = K sP; second product Jct' z_x (-> J z); partial z'r            :209-213   (onepass_kernel)
+//   Q   q = A_f p for p = z + beta p:  first product Jct (J p) with J p = J z + beta J p; partial p'q               :216-227   (onepass_kernel)
+//   P3  p = z + beta p (stored) ; x += alpha p ; r -= alpha q ; partial r'r                                          :217, :232-235
+struct PrecScale {
+    const double *i11, *i12, *i22;   // rows of D0^-1 = [i11 i12; i12 i22] (stacked operator); nullptr: plain operator, D0^-1 = inv_mu
+    double inv_mu;
+};
+enum { PM_OUT1 = 0 };
+template <bool ST>
+struct PrecZE {
+    const double* r;
+    double* z;
+    PrecScale ps;
+    int64_t hs;
+    const int64_t* istat;
+    static constexpr bool kSplitRed = false;
+    using Uni = NoUni;
+    struct Row { double rx, ry, a11, a12, a22; };
+    static __device__ __forceinline__ double at(const double* base, uint32_t o) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
+    }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ Uni uniform() const { return Uni{}; }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        Row w;
+        w.rx = at(r, o);
+        if (ST) { w.ry = at(r + hs, o); w.a11 = at(ps.i11, o); w.a12 = at(ps.i12, o); w.a22 = at(ps.i22, o); }
+        else { w.ry = w.a12 = w.a22 = 0.0; w.a11 = ps.inv_mu; }
+        return w;
+    }
+    static constexpr int kStageStreams = ST ? 2 : 1;
+    __device__ __forceinline__ double* stage_out(int sv) const { return sv == 0 ? z : z + hs; }
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
+                                          const Row& w, double (&v)[1], double (&red)[1]) const {
+        apply_staged(row, o, accv, valid, owner, lead, u, w, v, red, nullptr, 0);
+    }
+    __device__ __forceinline__ void apply_staged(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool, const Uni&,
+                                                 const Row& w, double (&v)[1], double (&red)[1], double* slot, int sstride) const {
+        const double acc = accv[0];
+        const bool st = valid && owner;
+        const double ux = ST ? fma(w.a12, w.ry, w.a11 * w.rx) : w.a11 * w.rx;           // (D0^-1 r)_x
+        const double zx = fma(-w.a11, acc, ux);                                          // z = D0^-1 r - D0^-1 E c1
+        double zy = 0.0;
+        if (ST) zy = fma(-w.a12, acc, fma(w.a22, w.ry, w.a12 * w.rx));
+        if (st) {
+            if (slot) { slot[0] = zx; if (ST) slot[sstride] = zy; }
+            else { *reinterpret_cast<double*>(reinterpret_cast<char*>(z) + o) = zx; if (ST) *reinterpret_cast<double*>(reinterpret_cast<char*>(z + hs) + o) = zy; }
+            red[0] += ST ? fma(zy, w.ry, zx * w.rx) : zx * w.rx;                         // rho = z'r   :213
+        }
+        v[0] = valid ? zx : 0.0;                                                         // -> J z  (fulljac's column block sees the x half)
+    }
+};
+template <bool ST>
+struct PrecQE {
+    const double* z;
+    const double* p;
+    double* q;
+    double mu;
+    PrecScale ps;
+    PStack k;            // fulljac's diagonal block (Dx.*S, Dy.*S); hs
+    const double* scal;
+    const int64_t* istat;
+    static constexpr bool kSplitRed = false;
+    struct Uni { double beta; };
+    struct Row { double zx, zy, px, py, a, b, a11, a12; };
+    static __device__ __forceinline__ double at(const double* base, uint32_t o) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
+    }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ Uni uniform() const { return Uni{uniform_f64(ld_scal(scal + P_BETA))}; }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        Row w;
+        w.zx = at(z, o); w.px = at(p, o);
+        if (ST) {
+            w.zy = at(z + k.hs, o); w.py = at(p + k.hs, o); w.a = at(k.Dx, o); w.b = at(k.Dy, o); w.a11 = at(ps.i11, o); w.a12 = at(ps.i12, o);
+        } else {
+            w.zy = w.py = w.a = w.b = w.a12 = 0.0; w.a11 = ps.inv_mu;
+        }
+        return w;
+    }
+    static constexpr int kStageStreams = ST ? 2 : 1;
+    __device__ __forceinline__ double* stage_out(int sv) const { return sv == 0 ? q : q + k.hs; }
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
+                                          const Row& w, double (&v)[1], double (&red)[1]) const {
+        apply_staged(row, o, accv, valid, owner, lead, u, w, v, red, nullptr, 0);
+    }
+    __device__ __forceinline__ void apply_staged(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool, const Uni& u,
+                                                 const Row& w, double (&v)[1], double (&red)[1], double* slot, int sstride) const {
+        const double acc = accv[0];
+        const bool st = valid && owner;
+        const double pnx = fma(u.beta, w.px, w.zx);                                      // :217 (stored by P3: the same fma)
+        double qx, qy = 0.0, pny = 0.0;
+        if (!ST) {
+            qx = fma(mu, pnx, acc);                                                      // :222
+        } else {
+            pny = fma(u.beta, w.py, w.zy);
+            const double ww = w.a * pnx + w.b * pny;                                     // diagonal block of J p
+            qx = fma(mu, pnx, fma(w.a, ww, acc));
+            qy = fma(mu, pny, w.b * ww);
+        }
+        if (st) {
+            if (slot) { slot[0] = qx; if (ST) slot[sstride] = qy; }
+            else { *reinterpret_cast<double*>(reinterpret_cast<char*>(q) + o) = qx; if (ST) *reinterpret_cast<double*>(reinterpret_cast<char*>(q + k.hs) + o) = qy; }
+            red[0] += ST ? fma(pny, qy, pnx * qx) : pnx * qx;                            // p'q   :226
+        }
+        v[0] = 0.0;                                                                      // (no second product needed: sP is measured directly)
+    }
+};
+struct PrecP3F {  // p = z + beta p (stored) ; x += alpha p ; r -= alpha q ; r'r
+    double* x;
+    double* r;
+    double* p;
+    const double* z;
+    const double* q;
+    const double* scal;
+    const int64_t* istat;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double alpha = ld_scal(scal + P_ALPHA), beta = ld_scal(scal + P_BETA);
+        double2 pp = ld2(p + i);
+        const double2 zz = ld2(z + i), qq = ld2(q + i);
+        double2 xx = ld2(x + i), rr = ld2(r + i);
+        pp = make_double2(fma(beta, pp.x, zz.x), fma(beta, pp.y, zz.y));                 // :217
+        xx = make_double2(fma(alpha, pp.x, xx.x), fma(alpha, pp.y, xx.y));               // :232
+        rr = make_double2(fma(-alpha, qq.x, rr.x), fma(-alpha, qq.y, rr.y));             // :233
+        if (v1) { st2(p + i, pp); st2(x + i, xx); st2(r + i, rr); }
+        else if (v0) { p[i] = pp.x; x[i] = xx.x; r[i] = rr.x; }
+        double s = 0.0;
+        if (v0) s = rr.x * rr.x;
+        if (v1) s = fma(rr.y, rr.y, s);
+        red[0] += s;
+    }
+};
+struct PrecInit {       // rho_prev = 1 (:203), status
+    double* scal;
+    int64_t* istat;
+    double tol;
+    int64_t maxit;
+    PcgHostMirror hm;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void run(double*) const {
+        scal[P_RHO] = 1.0;
+        scal[P_NRES] = INFINITY;
+        scal[P_TOL] = tol;
+        istat[IP_ITER] = 0;
+        istat[IP_MAXIT] = maxit;
+        const int64_t st = (maxit > 0) ? PST_RUNNING : PST_DONE;
+        istat[IP_STATUS] = st;
+        hm.publish(st, 0);
+    }
+};
+struct PrecPost3 {
+    double* scal;
+    int64_t* istat;
+    PcgHostMirror hm;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ void run(double*) const {
+        const double nres = sqrt(ld_scal(scal + P_RR));     // :235
+        scal[P_NRES] = nres;
+        const int64_t it = ld_stat(istat + IP_ITER) + 1;    // :237
+        istat[IP_ITER] = it;
+        int64_t st = PST_RUNNING;
+        if (!(nres > ld_scal(scal + P_TOL)) || it >= ld_stat(istat + IP_MAXIT)) st = PST_DONE;   // :207
+        if (st != PST_RUNNING) istat[IP_STATUS] = st;
+        hm.publish(st, it);
+    }
+};
+// the replicated m-vector steps between the passes (one workgroup):
+//   mode 1 (after Z): rho = z'r, beta = rho / rho_prev (:212-216), J p = J z + beta J p
+//   mode 2 (after Q): alpha = rho / p'q (:227)
+//   mode 0 / 3 (after S): c1 = K sP  (3: only while the solve is running)
+struct PrecSmall {
+    const double* out1;   // [J z (m) ; z'r]
+    const double* out2;   // [- (m) ; p'q]
+    double* tp;           // J p
+    double* sP;
+    double* c1;
+    const double* K;      // m x m, column-major (symmetric)
+    double* scal;
+    const int64_t* istat;
+    int m;
+};
+__global__ __launch_bounds__(1024) void prec_small_kernel(PrecSmall s, int mode) {
+    if (mode != 0 && ld_stat(s.istat + IP_STATUS) != PST_RUNNING) return;
+    __shared__ double sp[kOnepassMaxCols];
+    const int m = s.m, tid = threadIdx.x;
+    if (mode == 1) {
+        const double rho = ld_scal(s.out1 + m), rho_prev = ld_scal(s.scal + P_RHO);
+        const double beta = rho / rho_prev;
+        for (int j = tid; j < m; j += 1024) s.tp[j] = fma(beta, s.tp[j], ld_scal(s.out1 + j));
+        __syncthreads();
+        if (tid == 0) { s.scal[P_RHO] = rho; s.scal[P_BETA] = beta; }
+        return;
+    }
+    if (mode == 2) {
+        if (tid == 0) s.scal[P_ALPHA] = ld_scal(s.scal + P_RHO) / ld_scal(s.out2 + m);
+        return;
+    }
+    for (int j = tid; j < m; j += 1024) sp[j] = ld_scal(s.sP + j);
+    __syncthreads();
+    // c1 = K sP: a group of 16 lanes per row (K symmetric: row j = column j, read along the column)
+    const int g = tid >> 4, l = tid & 15;
+    for (int j = g; j < m; j += 64) {
+        double a = 0.0;
+        for (int k = l; k < m; k += 16) a = fma(s.K[(size_t)j * m + k], sp[k], a);
+        a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+        if (l == 0) s.c1[j] = a;
+    }
+}
+template <bool ST>
+struct PrecS0V {     // producer of sP = Jct'(D0^-1 r)_x
+    const double* r;
+    PrecScale ps;
+    int64_t hs;
+    const int64_t* istat;     // nullptr: always (the start of a solve); else only while the solve is running
+    __device__ __forceinline__ bool skip() const { return istat != nullptr && ld_stat(istat + IP_STATUS) != PST_RUNNING; }
+    __device__ __forceinline__ double2 load(int64_t i, bool v0, bool v1) const {
+        const double2 rx = ld2(r + i);
+        double2 u;
+        if (ST) {
+            const double2 ry = ld2(r + hs + i), a11 = ld2(ps.i11 + i), a12 = ld2(ps.i12 + i);
+            u = make_double2(fma(a12.x, ry.x, a11.x * rx.x), fma(a12.y, ry.y, a11.y * rx.y));
+        } else {
+            u = make_double2(ps.inv_mu * rx.x, ps.inv_mu * rx.y);
+        }
+        return make_double2(v0 ? u.x : 0.0, v1 ? u.y : 0.0);
+    }
+};
+
 }  // namespace lfpsqp
 
 using namespace lfpsqp;
+
+template <bool ST>
+static int pcg_pre_impl(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, const lfpsqp_pcg_precond* P, lfpsqp_vec* x, lfpsqp_vec* r, lfpsqp_vec* p,
+                        lfpsqp_vec* z, double tol, int64_t maxiter, int* flag, int64_t* iters) {
+    const int m = (int)Jop->ncols;
+    const int64_t nv = r->n;
+    const int64_t N = ST ? Jop->Dx->n : nv, hs = ST ? lfpsqp_half_stride(N) : 0;
+    const lfpsqp_mat* A = Jop->Z;
+    double* scal = ctx->scal;
+    int64_t* istat = ctx->istat;
+    const PcgHostMirror hm{ctx->h_istat};
+    volatile int64_t* hstat = ctx->h_istat;
+    hstat[IP_STATUS] = PST_RUNNING;
+    hstat[IP_ITER] = 0;
+    for (int k = 0; k < kPRing; ++k) hstat[kPRingOff + k] = PST_RUNNING;
+    const size_t mm = (size_t)m * m;
+    LF_TRY(ensure_small(ctx, mm + 8));
+    LF_TRY(ensure_mvec(ctx, (size_t)6 * m + 64));
+    double* dK = ctx->small;
+    double* out1 = ctx->d_m;                                   // m + 1
+    double* out2 = out1 + round_up(2 * m + 1, 2) + 2;          // m + 1
+    double* tp = out2 + round_up(m + 1, 2) + 2;
+    double* sP = tp + round_up(m, 2);
+    double* c1 = sP + round_up(m, 2);
+    LF_HIP(ctx, hipMemcpyAsync(dK, P->K, sizeof(double) * mm, hipMemcpyHostToDevice, ctx->stream));
+    LF_HIP(ctx, hipMemsetAsync(tp, 0, sizeof(double) * m, ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));            // P->K is caller-owned pageable memory
+    const PrecScale ps{ST ? P->i11->p : nullptr, ST ? P->i12->p : nullptr, ST ? P->i22->p : nullptr, 1.0 / mu};
+    const PStack sk = ST ? PStack{hs, Jop->Dx->p, Jop->Dy->p, Jop->sx->p, Jop->sy->p, nullptr} : PStack{0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const PrecSmall sm{out1, out2, tp, sP, c1, dK, scal, istat, m};
+    LF_TRY(lfpsqp_vec_fill(ctx, p, 0.0));                                                        // :204
+    hipLaunchKernelGGL((post_kernel<PrecInit>), dim3(1), dim3(1), 0, ctx->stream, scal, PrecInit{scal, istat, tol, maxiter, hm});
+    LF_LAUNCH_CHECK(ctx);
+    LF_TRY(run_gemv_t(ctx, A, m, N, PrecS0V<ST>{r->p, ps, hs, nullptr}, sP));                    // sP = Jct'(D0^-1 r)_x
+    hipLaunchKernelGGL(prec_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, sm, 0);          // c1 = K sP
+    LF_LAUNCH_CHECK(ctx);
+    int64_t it = 0;
+    bool done = maxiter <= 0;
+    while (!done && it < maxiter) {
+        if (it > 0) {                                          // sP of the updated residual, measured directly (a no-op once the solve has stopped)
+            LF_TRY(run_gemv_t(ctx, A, m, N, PrecS0V<ST>{r->p, ps, hs, istat}, sP, 4));
+            hipLaunchKernelGGL(prec_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, sm, 3);
+            LF_LAUNCH_CHECK(ctx);
+        }
+        LF_TRY((run_onepass<PrecZE<ST>, 1, 1>(ctx, A, m, m, N, c1, PrecZE<ST>{r->p, z->p, ps, hs, istat}, out1, 5)));
+        hipLaunchKernelGGL(prec_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, sm, 1);
+        LF_LAUNCH_CHECK(ctx);
+        LF_TRY((run_onepass<PrecQE<ST>, 1, 1>(ctx, A, m, m, N, tp, PrecQE<ST>{z->p, p->p, P->q->p, mu, ps, sk, scal, istat}, out2, 5)));
+        hipLaunchKernelGGL(prec_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, sm, 2);
+        LF_LAUNCH_CHECK(ctx);
+        LF_TRY((run_vec<PrecP3F, 1, PrecPost3>(ctx, nv, PrecP3F{x->p, r->p, p->p, z->p, P->q->p, scal, istat}, 0u, scal + P_RR,
+                                               PrecPost3{scal, istat, hm}, 6)));
+        LF_HIP(ctx, hipEventRecord(ctx->ev_slot[it & 3], ctx->stream));
+        if (it >= 2) {
+            LF_HIP(ctx, hipEventSynchronize(ctx->ev_slot[(it - 2) & 3]));
+            if (hstat[kPRingOff + ((it - 1) % kPRing)] != PST_RUNNING) done = true;
+        }
+        ++it;
+    }
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *iters = hstat[IP_ITER];
+    *flag = (*iters == maxiter) ? 1 : 0;                                                         // :240-243
+    if (ctx->profiling) prof_collect(ctx);
+    return 0;
+}
+
+extern "C" int lfpsqp_pcg_pre(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, const lfpsqp_pcg_precond* P, lfpsqp_vec* x, lfpsqp_vec* r,
+                              lfpsqp_vec* p, lfpsqp_vec* z, double tol, int64_t maxiter, int* flag, int64_t* iters) {
+    LF_RANGE("lfpsqp_pcg_pre");
+    LF_ARG(ctx, ctx && Jop && P && P->K && P->q && x && r && p && z && flag && iters && mu > 0.0);
+    const bool stacked = Jop->Dx != nullptr;
+    const int m = (int)Jop->ncols;
+    const int64_t nv = r->n;
+    LF_ARG(ctx, x->n == nv && p->n == nv && z->n == nv && P->q->n == nv && m >= 1 && Jop->Z && m <= Jop->Z->m);
+    int64_t N = nv;
+    if (stacked) {
+        LF_ARG(ctx, Jop->Dy && Jop->sx && Jop->sy && P->i11 && P->i12 && P->i22);
+        N = Jop->Dx->n;
+        LF_ARG(ctx, nv == lfpsqp_half_stride(N) + N && Jop->Dy->n == N && Jop->Z->n == N && P->i11->n == N && P->i12->n == N && P->i22->n == N);
+    } else {
+        LF_ARG(ctx, Jop->Z->n == nv);
+    }
+    if (Jop->S || !onepass_cw(ctx, m, Jop->Z->ld, N))
+        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "preconditioned pcg! needs the one-pass kernels over a dense Jct (4 .. 1024 columns); use lfpsqp_pcg");
+    return stacked ? pcg_pre_impl<true>(ctx, mu, Jop, P, x, r, p, z, tol, maxiter, flag, iters)
+                   : pcg_pre_impl<false>(ctx, mu, Jop, P, x, r, p, z, tol, maxiter, flag, iters);
+}
 
 extern "C" int lfpsqp_pcg(lfpsqp_ctx* ctx, double mu, const lfpsqp_basis* Jop, lfpsqp_vec* x, lfpsqp_vec* r, lfpsqp_vec* p, lfpsqp_vec* z,
                           lfpsqp_vec* tmp_w, lfpsqp_vec* tmp_m, double tol, int64_t maxiter, int* flag, int64_t* iters) {

@@ -13,12 +13,31 @@
 
 #include "internal.h"
 #include "sparse.h"
+#include "smallla.h"
 
 namespace lfpsqp {
 
 enum { I_NR_STATUS = 8, I_NR_ITER = 9, I_NR_FLAG = 10 };   // istat slots of the Newton retraction
 constexpr int kNRRing = 8, kNRRingOff = 24;                 // per-iteration host status ring (see projcg.hip HostMirror)
 constexpr int kNRMaxM = 1024;                               // m x m Broyden state handled by one workgroup
+
+// rows of D0^-1 for the stacked operator of ProjPenalty's inner solve: D0 = mu I + [a; b][a b] per variable (a = Dx.*S, b = Dy.*S), so
+// det = mu (a^2 + b^2 + mu) and D0^-1 = [b^2 + mu, -ab; -ab, a^2 + mu] / det
+struct D0InvF {
+    const double *a, *b;
+    double *i11, *i12, *i22;
+    double mu;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 aa = ld2(a + i), bb = ld2(b + i);
+        const double dx = mu * (aa.x * aa.x + bb.x * bb.x + mu), dy = mu * (aa.y * aa.y + bb.y * bb.y + mu);
+        const double2 o11 = make_double2((bb.x * bb.x + mu) / dx, (bb.y * bb.y + mu) / dy);
+        const double2 o12 = make_double2(-(aa.x * bb.x) / dx, -(aa.y * bb.y) / dy);
+        const double2 o22 = make_double2((aa.x * aa.x + mu) / dx, (aa.y * aa.y + mu) / dy);
+        if (v1) { st2(i11 + i, o11); st2(i12 + i, o12); st2(i22 + i, o22); }
+        else if (v0) { i11[i] = o11.x; i12[i] = o12.x; i22[i] = o22.x; }
+    }
+};
 
 struct BallF {  // partial of sum_{i<n_x} x_i^2 - x[slack_row]
     const double* x;
@@ -1216,7 +1235,43 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
         LF_TRY(lfpsqp_vec_copy(ctx, w->r, w->g));
         int pcg_flag = 0;
         int64_t pcg_i = 0;
-        LF_TRY(lfpsqp_pcg(ctx, mu, &Jop, w->dx, w->r, w->p, w->z, w->tmp_w, w->tmp_m, tol, maxiter_pcg, &pcg_flag, &pcg_i));   // :375
+        bool pre_done = false;
+        if (w->precondition && w->q && !Jop.S && (!ineq || (w->i11 && w->i12 && w->i22)) && onepass_cw(ctx, m, Jct->ld, N) != 0) {
+            // exact preconditioner of this Gauss-Newton step's operator (DeviceOptions.pp_precondition; lfpsqp_pcg_pre): K = (I + G)^-1 with
+            // G = Jct' D0^-1 Jct from one Gram pass over the CURRENT Jct
+            if (ineq) LF_TRY((run_vec<D0InvF, 0, NoPost>(ctx, N, D0InvF{w->DxS->p, w->DyS->p, w->i11->p, w->i12->p, w->i22->p, mu}, 0u, nullptr, NoPost())));
+            std::vector<double> G((size_t)m * m), Lc, Kh((size_t)m * m);
+            LF_TRY(lfpsqp_gram(ctx, Jct, m, ineq ? w->i11 : nullptr, G.data()));
+            for (int j = 0; j < m; ++j)
+                for (int k = 0; k < m; ++k) {
+                    double v = ineq ? G[(size_t)j * m + k] : G[(size_t)j * m + k] / mu;
+                    if (j == k) v += 1.0;
+                    G[(size_t)j * m + k] = v;
+                }
+            bool finite = true;
+            for (double v : G) finite = finite && (v == v) && fabs(v) < 1e300;
+            if (finite && cholesky_lower(m, G, Lc, 0.0)) {
+                // K = L^-T L^-1: solve L Y = I (forward), then L' K = Y (backward), column by column
+                for (int c = 0; c < m; ++c) {
+                    std::vector<double> y(m, 0.0);
+                    for (int i2 = c; i2 < m; ++i2) {
+                        double acc = (i2 == c) ? 1.0 : 0.0;
+                        for (int k = c; k < i2; ++k) acc -= Lc[(size_t)k * m + i2] * y[k];
+                        y[i2] = acc / Lc[(size_t)i2 * m + i2];
+                    }
+                    for (int i2 = m - 1; i2 >= 0; --i2) {
+                        double acc = y[i2];
+                        for (int k = i2 + 1; k < m; ++k) acc -= Lc[(size_t)i2 * m + k] * Kh[(size_t)c * m + k];
+                        Kh[(size_t)c * m + i2] = acc / Lc[(size_t)i2 * m + i2];
+                    }
+                }
+                lfpsqp_pcg_precond pc{Kh.data(), ineq ? w->i11 : nullptr, ineq ? w->i12 : nullptr, ineq ? w->i22 : nullptr, w->q};
+                LF_TRY(lfpsqp_pcg_pre(ctx, mu, &Jop, &pc, w->dx, w->r, w->p, w->z, tol, maxiter_pcg, &pcg_flag, &pcg_i));
+                pre_done = true;
+            }
+        }
+        if (!pre_done)
+            LF_TRY(lfpsqp_pcg(ctx, mu, &Jop, w->dx, w->r, w->p, w->z, w->tmp_w, w->tmp_m, tol, maxiter_pcg, &pcg_flag, &pcg_i));   // :375
         pcg_total += pcg_i;
         if (pcg_flag > 0) { flag = 2; break; }                                    // :377-381
         LF_TRY(lfpsqp_vec_copy(ctx, w->p, xnew));                                 // :384

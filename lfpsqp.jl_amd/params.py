@@ -76,6 +76,11 @@ class DeviceOptions:
     # 0 (default) = automatic: as many as the previous search's failed retractions suggest (at least 4), up to what one pass takes for
     # the problem's shape (lfpsqp_retract_nr_batch_width: 16 on the matrix cores, 4 otherwise); k > 1 = at most k.
     ls_batch: int = 0
+    # ProjPenalty's inner pcg! solves with the EXACT preconditioner of their operator (lfpsqp_pcg_pre; the reference's proj_precondition!,
+    # src/retractions.jl:248-257 -- its call is commented out at :374 -- generalised to the bound operator): one or two inner iterations
+    # per Gauss-Newton step instead of hundreds to thousands, at one Gram pass per step.  False (default) = the reference's live path
+    # (no_precondition): same iterates as the reference, iteration for iteration.
+    pp_precondition: bool = False
     # candidate allocations per placement-tuned buffer (lfpsqp_ctx_set_placement; 1 = off)
     placement_tries: int = 3
     # the tangent basis stays in factored form U = Jct W (no n x m basis matrix, no basis-forming product in the tangent setup) whenever the

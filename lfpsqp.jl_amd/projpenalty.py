@@ -37,11 +37,17 @@ class ProjPenaltyWork:  # src/retractions.jl:21-33 (J itself is the shared devic
             self.DxS, self.DyS = DeviceVector(ctx, n), DeviceVector(ctx, n)
             self.ones = DeviceVector(ctx, n).fill(1.0)
             self.zeros = DeviceVector(ctx, n)
+        # DeviceOptions.pp_precondition: the inner solves run lfpsqp_pcg_pre (one more n-vector; with bounds the rows of D0^-1)
+        self.precondition = bool(getattr(ctx.options, "pp_precondition", False))
+        if self.precondition:
+            self.q = mk()
+            if ineq:
+                self.i11, self.i12, self.i22 = DeviceVector(ctx, n), DeviceVector(ctx, n), DeviceVector(ctx, n)
 
     def _c(self):
         g = lambda name: getattr(self, name).h if hasattr(self, name) else None
         return _capi.PPWork(self.r.h, self.p.h, self.z.h, self.dx.h, self.g.h, self.tmp_m.h, g("tmp_w"), g("h"), g("DxS"), g("DyS"),
-                            g("ones"), g("zeros"))
+                            g("ones"), g("zeros"), g("q"), g("i11"), g("i12"), g("i22"), 1 if self.precondition else 0)
 
 
 @dataclass
@@ -125,6 +131,29 @@ def proj_precondition_(z, r, mu, U, Sigma, rank, tmp_m):
     return z
 
 
+class ProjPrecondition:
+    """M! = (z, r) -> proj_precondition!(z, r, mu, U, Sigma, rank, tmp_m) (the line commented out at src/retractions.jl:374) as an
+    object, for a basis known through its generator: U = Jct W (ksvd_'s W).  pcg_ recognises it and runs the whole solve fused on the
+    device (lfpsqp_pcg_pre with K = mu W diag(s^2 / (mu + s^2)) W'); called as a function it is the statement-by-statement form."""
+
+    def __init__(self, Jct: DeviceMatrix, W: np.ndarray, Sigma, rank: int, q: DeviceVector, Z: DeviceMatrix | None = None):
+        self.Jct, self.W, self.Sigma, self.rank, self.q, self.Z = Jct, np.asarray(W), np.asarray(Sigma, dtype=np.float64), int(rank), q, Z
+        self.mu = None
+        self._tmp = None
+
+    def K(self, mu: float) -> np.ndarray:
+        s2 = self.Sigma[:self.rank] ** 2
+        Wr = self.W[:, :self.rank]
+        return np.asfortranarray(mu * (Wr * (s2 / (mu + s2))) @ Wr.T)
+
+    def __call__(self, z, r):
+        if self.Z is None:
+            raise ValueError("the statement-by-statement form needs the materialised basis Z")
+        if self._tmp is None:
+            self._tmp = DeviceVector(z.ctx, max(self.rank, 1))
+        return proj_precondition_(z, r, self.mu, self.Z, self.Sigma, self.rank, self._tmp)
+
+
 def pcg_(mu, J, M_, x, r, p, z, tmp_m, tol, maxiter):
     """pcg!(mu, J, M!, x, r, p, z, tmp_m, tol, maxiter) (src/retractions.jl:179-246) -> (flag, i).
     J is one of the operator adapters above (tmp_m lives inside it).  With the reference's live
@@ -139,6 +168,20 @@ def pcg_(mu, J, M_, x, r, p, z, tmp_m, tol, maxiter):
         ctx.check(ctx.L.lfpsqp_pcg(ctx.h, float(mu), C.byref(b), x.h, r.h, p.h, z.h, w.tmp_w.h if hasattr(w, "tmp_w") else None,
                                    w.tmp_m.h, float(tol), int(maxiter), C.byref(flag), C.byref(iters)))
         return flag.value, iters.value
+    if isinstance(M_, ProjPrecondition) and isinstance(J, _JacPlain) and J.Jsp is None:
+        ctx = x.ctx
+        flag = C.c_int()
+        iters = _capi.c_i64()
+        b = J._basis()
+        K = M_.K(float(mu))
+        pc = _capi.PcgPrecond(K.ctypes.data, None, None, None, M_.q.h)
+        rc = ctx.L.lfpsqp_pcg_pre(ctx.h, float(mu), C.byref(b), C.byref(pc), x.h, r.h, p.h, z.h, float(tol), int(maxiter), C.byref(flag),
+                                  C.byref(iters))
+        if rc != -5:                               # (LFPSQP_ERR_UNSUPPORTED: no one-pass kernel for this shape -> the loop below)
+            ctx.check(rc)
+            return flag.value, iters.value
+    if isinstance(M_, ProjPrecondition):
+        M_.mu = float(mu)
     norm_res = math.inf
     rho = 1.0
     p.fill(0.0)

@@ -589,6 +589,40 @@ def proj_precondition_(z, r, mu, U, Sig, rank, tmp_m):  # :248-257 (dead on the 
     return z
 
 
+# Switches for restatements of DEVICE options that have no counterpart on the reference's live path (all off = the reference).
+EXTENSIONS = {"pp_precondition": False}
+
+
+def exact_precondition(mu, J, idecomp=None):
+    """EXTENSION (no counterpart on the reference's live path): M!(z, r) = (D0 + E E')^-1 r for the operator of ProjPenalty's inner solve,
+    E = [J'; 0], D0 = mu I (plain) or mu I + [a; b][a b] per variable with a = Dx.*S, b = Dy.*S (bounds; src/inequality_helper.jl:215-271),
+    by the Woodbury identity: D0^-1 - D0^-1 E (I + E' D0^-1 E)^-1 E' D0^-1.  Plain operator: the same map as proj_precondition!
+    (src/retractions.jl:248-257) with U, Sigma from J itself."""
+    Jct = np.asarray(J).T if idecomp is None else idecomp.Jct
+    N, m = Jct.shape
+    if idecomp is None:
+        i11 = np.full(N, 1.0 / mu)
+        i12 = i22 = None
+    else:
+        a, b = idecomp.Dx * idecomp.S, idecomp.Dy * idecomp.S
+        det = mu * (a * a + b * b + mu)
+        i11, i12, i22 = (b * b + mu) / det, -(a * b) / det, (a * a + mu) / det
+    K = np.linalg.inv(np.eye(m) + Jct.T @ (i11[:, None] * Jct))
+
+    def M_(z, r):
+        if idecomp is None:
+            ux = i11 * r
+            z[:] = ux - i11 * (Jct @ (K @ (Jct.T @ ux)))
+        else:
+            rx, ry = r[:N], r[N:]
+            ux, uy = i11 * rx + i12 * ry, i12 * rx + i22 * ry
+            v = Jct @ (K @ (Jct.T @ ux))
+            z[:N] = ux - i11 * v
+            z[N:] = uy - i12 * v
+        return z
+    return M_
+
+
 def pcg_(mu, J, M_, x, r, p, z, tmp_m, tol, maxiter):
     """src/retractions.jl:179-246.  Returns (flag, i)."""
     norm_res = math.inf
@@ -646,7 +680,13 @@ def _retract_pp(cval, xnew, c_, xtilde, x, method):
         mul_(g, fulljac_t, cvalaug, 1.0, mu)                 # :369
         dx[:] = 0.0
         r[:] = g
-        pcg_flag, pcg_i = pcg_(mu, fulljac, no_precondition, dx, r, p, z, tmp_m, tol, maxiter_pcg)  # :375
+        M_ = no_precondition
+        if getattr(method, "precondition", False):
+            # NOT on the reference's live path (its M! is no_precondition, :375): the exact preconditioner the device offers as an option
+            # (DeviceOptions.pp_precondition, lfpsqp_pcg_pre), restated here so that the option has a checker.  For the plain operator it is
+            # proj_precondition! (:248-257, the call commented out at :374) with the factors of the CURRENT J.
+            M_ = exact_precondition(mu, J, idecomp if method.ineq else None)
+        pcg_flag, pcg_i = pcg_(mu, fulljac, M_, dx, r, p, z, tmp_m, tol, maxiter_pcg)  # :375
         pcg_iter_count += pcg_i
         if pcg_flag > 0:                                     # :377-381
             flag = 2
@@ -955,6 +995,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m, param, trace
     nr = NR(U, Sig, Vt, param.eps_c, param.maxiter_retract, NRWork(m), ineq, ineqdata)
     pp = ProjPenalty(jac_, U, Sig, Vt, m, param.mu0, param.eps_c, param.maxiter_retract, param.maxiter_pcg,
                      ProjPenaltyWork(m, n, m_ineq, n_ineq), ineq, ineqdecomp, ineqdata)
+    pp.precondition = bool(EXTENSIONS["pp_precondition"])      # (False: the reference's live path)
     euc = Euclidean()
     yr = YRetract(ineqdata)
     armijo_work = ArmijoWork(n_ineq)
