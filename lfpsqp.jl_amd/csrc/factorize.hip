@@ -489,9 +489,12 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
         LF_LAUNCH_CHECK(ctx);
     }
     LF_TRY(allreduce_dev(ctx, ctx->small, pp, 0));
-    std::vector<double> h((size_t)pp);
-    LF_HIP(ctx, hipMemcpyAsync(h.data(), ctx->small, sizeof(double) * pp, hipMemcpyDeviceToHost, ctx->stream));
+    // (into the context's PINNED staging block: a copy to pageable memory goes through the runtime's own staging and costs 0.1 ms more)
+    LF_TRY(ensure_mvec(ctx, (size_t)pp + 8));
+    LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->small, sizeof(double) * pp, hipMemcpyDeviceToHost, ctx->stream));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double* const hpin = ctx->h_m;
+    struct { const double* p; const double* data() const { return p; } } h{hpin};
     {
         size_t poff = npan;                     // slots of the pairs pi < pj follow the npan diagonal ones
         for (int pi = 0; pi < npan; ++pi)

@@ -87,6 +87,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
 }
 
 constexpr double kJacQuadTol = 1e-7;    // relative off-diagonal level from which two more sweeps reach rounding (quadratic convergence)
+constexpr double kJacQuadTol1 = 1e-8;   // ... and from which ONE does: the sweep that measured it leaves (1e-8)^2 = 1e-16 behind.  (At m = 128 the
+                                        // clustered Gram spectra of the configs enter at 2e-9: the ninth sweep only re-measured rounding, 0.28 ms.)
 
 // B columns per block, 2B per workgroup; LPP lanes per column pair (B * LPP threads), each holding MAXROWS / LPP rows of both
 // columns in registers for the dot products and the rotation of a local round (one batch of LDS reads, one of writes per round).
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(B* LPP) void jacobi_round_kernel(double* __restrict
         const unsigned long long u = (unsigned long long)ld_stat(reinterpret_cast<const int64_t*>(off) + k);
         if (u == kJacUnset) continue;
         const double o = __builtin_bit_cast(double, u);
-        if (o <= tol || (k + 2 <= sweep && o <= kJacQuadTol)) return;
+        if (o <= tol || (k + 1 <= sweep && o <= kJacQuadTol1) || (k + 2 <= sweep && o <= kJacQuadTol)) return;
     }
     constexpr int THREADS = B * LPP;
     constexpr int RPL = MAXROWS / LPP;                 // rows per lane
@@ -162,17 +164,23 @@ __global__ __launch_bounds__(B* LPP) void jacobi_round_kernel(double* __restrict
         const double rel = fabs(gamma) * rlim;                                   // |cos| of the angle between the columns
         if (rel > 1e-16) {
             offmax = fmax(offmax, rel);
-            const double zeta = (beta - alpha) * 0.5 * fast_rcp(gamma);
-            const double az = fabs(zeta);
-            double t;
-            if (az < 1e100) {
-                const double w = fma(zeta, zeta, 1.0);
-                t = fast_rcp(az + w * fast_rsqrt(w));          // 1 / (|zeta| + sqrt(1 + zeta^2))
-            } else {
-                t = 0.5 * fast_rcp(az);
+            // the smaller-angle rotation that makes the pair orthogonal: tan(2 theta) = 2 gamma / (beta - alpha).  With d = beta - alpha and
+            // r = sqrt(d^2 + 4 gamma^2): cos^2 = (1 + |d| / r) / 2 and sin = sign(d) gamma / (r cos) -- TWO reciprocal square roots instead of
+            // the classical zeta / t sequence's two reciprocals and two reciprocal square roots (every lane of a pair runs them redundantly:
+            // a tenth of the round's instructions).
+            const double d = beta - alpha;
+            const double dn = d * rlim, gn = gamma * rlim;     // scaled by 1 / (|p||q|), which the convergence measure needs anyway: |gn| <= 1
+            double c, s;
+            if (fabs(dn) < 1e100) {
+                const double rinv = fast_rsqrt(fma(dn, dn, 4.0 * gn * gn));
+                const double h = fma(0.5 * fabs(dn), rinv, 0.5);   // cos^2 in [1/2, 1]
+                const double cinv = fast_rsqrt(h);
+                c = h * cinv;
+                s = (d >= 0 ? gn : -gn) * rinv * cinv;
+            } else {                                           // columns of wildly different size: the rotation is the identity to rounding
+                c = 1.0;
+                s = gn * fast_rcp(dn);
             }
-            t = zeta >= 0 ? t : -t;
-            const double c = fast_rsqrt(fma(t, t, 1.0)), s = c * t;
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
                 p[k * LPP] = c * x[k] - s * y[k];

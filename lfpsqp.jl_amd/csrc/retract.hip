@@ -1167,7 +1167,13 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
     const int m = (int)m64;
     const int64_t N = Jct->n;
     if (ineq) LF_ARG(ctx, Dx && Dy && S && w->tmp_w && w->h && w->DxS && w->DyS && w->ones && w->zeros && idata->n == N);
-    LF_TRY(ensure_mvec(ctx, (size_t)2 * m + 16));
+    {
+        // everything this call will ask of the m-vector staging area, reserved NOW: the pointers taken from it below must survive the Gram
+        // passes and the preconditioned solves of the loop (ensure_mvec reallocates when it has to grow)
+        const size_t np = ((size_t)m + 127) / 128;
+        const size_t gram_doubles = w->precondition ? np * (np + 1) / 2 * 16384 + 64 : 0;
+        LF_TRY(ensure_mvec(ctx, std::max((size_t)8 * m + 128, gram_doubles)));
+    }
     lfpsqp_vec cdev;                       // replicated device copy of cval (rhs of J' c)
     cdev.p = ctx->d_m + round_up(m + 8, 2);
     cdev.n = m;
