@@ -73,6 +73,10 @@ def main():
     res["us_per_allreduce"] = (time.perf_counter() - t0) / K * 1e6
     np.savez(os.path.join(d, f"out_{transport}_{rank}.npz"), **res)
     ctx.close()
+    if transport != "p2p":          # leave the group in order: a process that exits with gloo's threads alive can abort in their destructors
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
