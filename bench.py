@@ -51,7 +51,7 @@ def main(argv=None, lib=None):
     ap.add_argument("--device", type=int, default=None, help="HIP device index (default: LOCAL_RANK)")
     ap.add_argument("--lib", default=None, help="(development) alternative build of liblfpsqp_hip.so to load")
     ap.add_argument("--placement", choices=["library", "first"], default="library",
-                    help="where the basis and the solver's n-vectors are allocated decides between two speeds of the fused kernel (DESIGN.md 6). "
+                    help="where the basis and the solver's n-vectors are allocated decides between two speeds of the fused kernel (FINDINGS.md 6). "
                          "library (default): the library's own policy -- lfpsqp_basis_work_alloc_placed, what optimize() uses; "
                          "first: plain first allocations (policy off)")
     ap.add_argument("--placement-tries", type=int, default=3, help="candidate allocations per placed buffer (lfpsqp_ctx_set_placement)")
@@ -121,7 +121,7 @@ def main(argv=None, lib=None):
         return Zc, "scaled hash matrix (columns orthonormal to O(sqrt(m/n)))"
 
     b = ctx.vector(n_loc).hash_fill(4, r0)
-    # Placement.  Where the basis and the work vectors land in memory decides between two speeds of the fused kernel, 10-15 % apart (DESIGN.md 6;
+    # Placement.  Where the basis and the work vectors land in memory decides between two speeds of the fused kernel, 10-15 % apart (FINDINGS.md 6;
     # a property of the PAIR of allocations).  Default: the library's own policy, the one optimize() uses -- the basis from
     # lfpsqp_mat_alloc_placed, ProjCGWork and the operator diagonal from lfpsqp_vecs_alloc_placed (candidate allocations, the fused kernel
     # timed on each, the fastest kept; every rank makes the same calls, the choice is local).
@@ -221,7 +221,7 @@ def main(argv=None, lib=None):
         return prof_ms[slot] / prof_cnt[slot] if prof_cnt[slot] else float("nan")
     fused = prof_cnt[3] > 0                              # one pass over U per iteration (lfpsqp_projcg default)
     k1, k2, k3, kf = avg(0), avg(1), avg(2), avg(3)
-    # algorithmic bytes per launch.  K1 reads x,d,g(,a) writes x,d.  Fused F: U once + reads g,d,a, writes g.
+    # algorithmic bytes per launch (FINDINGS.md §5).  K1 reads x,d,g(,a) writes x,d.  Fused F: U once + reads g,d,a, writes g.
     # Two-pass fallback: K2 reads d,g,a + U; K3 reads d,g,a writes g + U.
     bytes_k1 = (40.0 if fused else 48.0) * n_loc       # the fused flow's K1 needs no A (d'Ad comes out of F's sums)
     bytes_k2 = 8.0 * n_loc * m + 24.0 * n_loc + 8.0 * m
@@ -718,7 +718,7 @@ def gram_tile_share(m):
 
 
 def placements(ctx, L, n, m, n_loc, r0, R=3, its=12):
-    """The fused kernel F on R further allocations of the basis, all alive at once in this process (its time
+    """The fused kernel F on R further allocations of the basis, all alive at once in this process (FINDINGS.md §6: its time
     depends on where the 10 GB matrix landed and on the box): avg launch time of F over `its` iterations each."""
     import statistics
     keep, f_ms = [], []
@@ -851,10 +851,10 @@ def cpu_baseline(ns, m, n_full):
         if den != 0.0:
             D[:, :] += np.outer(tv, t2) / den
     s_nr = timed(nr_iter)
-    # host triad on three vectors of min(n, 1e8) doubles
-    nt = int(min(nm, 100_000_000))
-    z = np.zeros(nt)
-    s_tr = timed(lambda: port.triad(2.0, v[:nt], y[:nt], z), budget=1.0)
+    # host triad on three vectors of 2e8 doubles (4.8 GB: beyond every cache level of the host; smaller when memory is short)
+    nt = 200_000_000 if avail >= 20e9 else int(min(nm, 50_000_000))
+    ta, tb, z = np.ones(nt), np.ones(nt), np.zeros(nt)
+    s_tr = timed(lambda: port.triad(2.0, ta, tb, z), budget=1.0)
     by_t = 8.0 * nm * m + 8.0 * nm + 8.0 * m
     by_n = 8.0 * nm * m + 16.0 * nm + 8.0 * m
     return {"value": (it / dt) * fac, "unit": "iters/s", "cores": threads, "kind": "port", "n_measured": nm,
@@ -865,7 +865,7 @@ def cpu_baseline(ns, m, n_full):
             "gemv_n": {"ms": s_n * 1e3 / fac, "GBs": gb(by_n, s_n), "note": "y = U t + y (kgemv! 'N')" + ("" if nm == n_full else "; ms scaled to the full n")},
             "nr_iteration": {"ms": s_nr * 1e3 / fac, "note": "one Newton-retraction iteration without bounds: GEMV-N over U, c! = GEMV-T over Jct, "
                                                              "m x m good-Broyden algebra (src/retractions.jl:140-160)" + ("" if nm == n_full else "; ms scaled to the full n")},
-            "host_triad_GBs": gb(24.0 * nt, s_tr), "host_mem_available_GB": avail / 1e9}
+            "host_triad_GBs": gb(24.0 * nt, s_tr), "host_triad_doubles_per_vector": nt, "host_mem_available_GB": avail / 1e9}
 
 
 if __name__ == "__main__":

@@ -57,14 +57,14 @@ int lfpsqp_device_name(const lfpsqp_ctx* ctx, char* buf, int64_t buflen);
 int lfpsqp_device_uuid(const lfpsqp_ctx* ctx, char* buf, int64_t buflen);
 /* streaming-kernel variant: ks = 16-byte row pairs per lane (2 or 4; tile = 512*ks rows; 0 = auto: 4 for
  * >= 4M local rows, else 2), nt != 0 = non-temporal loads of the matrix stream.  Results are bit-identical
- * across nt, and differ only in summation order across ks.  Default (auto, 1), DESIGN.md §5. */
+ * across nt, and differ only in summation order across ks.  Default (auto, 1), FINDINGS.md §5. */
 int lfpsqp_ctx_set_tuning(lfpsqp_ctx* ctx, int ks, int nt);
 /* One-pass kernels (lfpsqp_projcg, lfpsqp_pcg, lfpsqp_retract_nr): 0 = on (default), -1 = off (their two-pass forms, which
  * are also the fallback for fewer than 4 or more than 1024 columns). */
 int lfpsqp_ctx_set_onepass(lfpsqp_ctx* ctx, int mode);
 /* Residual buffers of the fused projected-CG iteration: 0 = updated in place (default), 1 = two buffers alternating between iterations
  * (the kernel then never stores to lines it has just loaded).  Same iterates bit for bit; which is faster depends on where the buffers
- * landed in memory: in-place wins by 2-4 % on well-placed buffers, the alternating scheme by ~12 % on badly placed ones. */
+ * landed in memory (FINDINGS.md 6): in-place wins by 2-4 % on well-placed buffers, the alternating scheme by ~12 % on badly placed ones. */
 int lfpsqp_ctx_set_residual_buffers(lfpsqp_ctx* ctx, int mode);
 /* The same switch is read once by lfpsqp_ctx_create from the environment (LFPSQP_ONEPASS=-1); the tests use it to
  * cross-check the two forms. */
@@ -122,7 +122,7 @@ int lfpsqp_mat_shape(const lfpsqp_mat* M, int64_t* n, int64_t* m);
 int lfpsqp_mat_upload(lfpsqp_ctx* ctx, lfpsqp_mat* M, int64_t col0, int64_t ncols, const double* host, int64_t ldh);
 int lfpsqp_mat_download(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t col0, int64_t ncols, double* host, int64_t ldh);
 int lfpsqp_mat_copy(lfpsqp_ctx* ctx, lfpsqp_mat* dst, const lfpsqp_mat* src);
-/* ---- placement-tuned allocation ---------------------------------------------------------------------------------------
+/* ---- placement-tuned allocation (FINDINGS.md 6) ---------------------------------------------------------------------------------------
  * On MI355X the kernels that run a small store stream inside a matrix read stream -- the fused projected-CG iteration (src/projcg.jl:93-97),
  * the Newton step, pcg! -- run 10-15 % faster or slower depending on WHERE the matrix and the n-vectors they touch were allocated: a
  * property of the pair of allocations, reproducible within a process.  These two calls allocate by trial: `tries` candidate allocations
@@ -259,7 +259,7 @@ int lfpsqp_y_retract(lfpsqp_ctx* ctx, lfpsqp_vec* xnewaug, const lfpsqp_vec* xau
  * then only uses: the projector U_r U_r', lambda = V S^-1 U_r'd, and NR's D = S^-1 Vt.  On
  * the device this is a Gram-based factorisation (the "(JJ') normal-equation solve" of the
  * north star): G = A' diag(w2) A on the device (MFMA), the replicated m x m eigen/SVD problems by one-sided
- * Jacobi, Z = A * W on the device (MFMA), refinement rounds when A is ill-conditioned.
+ * Jacobi, Z = A * W on the device (MFMA), refinement rounds when A is ill-conditioned (FINDINGS.md §5.3).
  *
  * G_host (ncols x ncols, column-major) = M[:, :ncols]' diag(w2) M[:, :ncols], all-reduced.
  * w2 == NULL means unit weights. */
@@ -485,7 +485,7 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
  * trials by one Newton step.  Per trial the arithmetic, the convergence test and the outputs are those of
  * lfpsqp_retract_nr: xnew[b], cval[b*m .. b*m+m), flags[b], iters[b].  Needs the one-stream step (U->A / U->W known,
  * device-resident constraints without a sparse twin, 4..256 columns); returns LFPSQP_ERR_UNSUPPORTED otherwise (retract one by one then).
- * Up to 4 trials run on the VALU form of the one-pass kernel; 5..16 on the matrix cores (v_mfma_f64_16x16x4_f64: both products of a
+ * Two trials run on the VALU form of the one-pass kernel (up to four where the other form does not apply); 3..16 on the matrix cores (v_mfma_f64_16x16x4_f64: both products of a
  * step are contractions once the trials are stacked), for up to 132 generator columns and 128 linear constraints.
  * lfpsqp_retract_nr_batch_width: how many trials a pass takes for this basis and these constraints -- 16, 4 or 0 (cannot batch). */
 int lfpsqp_retract_nr_batch_width(const lfpsqp_ctx* ctx, const lfpsqp_basis* U, const lfpsqp_constraints* cons, int* width);

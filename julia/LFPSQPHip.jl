@@ -150,7 +150,7 @@ c_vec_copy_range(ctx, dst, doff, src, soff, count) = ccall((:lfpsqp_vec_copy_ran
 c_vec_fill_range(ctx, v, off, count, value) = ccall((:lfpsqp_vec_fill_range, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Float64), ctx, v, off, count, value)
 c_vec_hash_fill(ctx, v, seed, off, scale, shift) = ccall((:lfpsqp_vec_hash_fill, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Int64, Float64, Float64), ctx, v, seed, off, scale, shift)
 c_mat_alloc(ctx, n, m, out) = ccall((:lfpsqp_mat_alloc, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), ctx, n, m, out)
-# placement-tuned allocation (DESIGN.md 6): candidate allocations tried with the fused projected-CG kernel, the fastest kept
+# placement-tuned allocation (FINDINGS.md 6): candidate allocations tried with the fused projected-CG kernel, the fastest kept
 c_ctx_set_placement(ctx, tries) = ccall((:lfpsqp_ctx_set_placement, lib), Cint, (Ptr{Cvoid}, Cint), ctx, tries)
 c_mat_alloc_placed(ctx, n, m, out) = ccall((:lfpsqp_mat_alloc_placed, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), ctx, n, m, out)
 c_vecs_alloc_placed(ctx, M, ncols, n, count, out) = ccall((:lfpsqp_vecs_alloc_placed, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Ptr{Ptr{Cvoid}}), ctx, M, ncols, n, count, out)
@@ -470,7 +470,7 @@ vmul!(y::DeviceVector, d::DeviceVector, x::DeviceVector) = (check(y.ctx, c_vmul(
 # view(U, :, 1:rank) (src/optimize.jl:370).  `generator` = (Jct, W) with Z == Jct*W (ksvd!'s W): the Newton retraction then
 # streams Jct once per step instead of Z and Jct.
 # Z === nothing with generator = (A, W): the basis in FACTORED form U = A W, never materialised -- projcg!, the projections and the Newton
-# retraction stream A and apply the small factor W on the side (lfpsqp_basis.Z == NULL, DESIGN.md 5.3).
+# retraction stream A and apply the small factor W on the side (lfpsqp_basis.Z == NULL, FINDINGS.md 5.3).
 struct DeviceBasis
     Z::Union{Nothing,DeviceMatrix}
     ncols::Int
@@ -1242,8 +1242,8 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     prev_grad_norm = 0.0
     diagonal_hessian = has_hess_diag(hess_lag_vec!)
     # The basis Z (src/optimize.jl:191), ProjCGWork (:214) and the operator diagonal the fused iteration reads beside them: allocated TOGETHER,
-    # by trial over pairs of candidate allocations (DESIGN.md 6)
-    # ... unless the basis can stay in FACTORED form U = Jct W (DESIGN.md 5.3): no Z at all, the tangent setup skips its basis-forming product,
+    # by trial over pairs of candidate allocations (FINDINGS.md 6)
+    # ... unless the basis can stay in FACTORED form U = Jct W (FINDINGS.md 5.3): no Z at all, the tangent setup skips its basis-forming product,
     # and the work vectors are placed against Jct
     # (the library says whether this context can run projcg! without Z for this Jct: one-pass kernels on, shape inside their limits, or a
     # sparse twin the nonzero path covers; otherwise Z is materialised and every path has its two-pass form)

@@ -661,7 +661,7 @@ int lfpsqp_vec_free(lfpsqp_ctx* ctx, lfpsqp_vec* v) {
     return 0;
 }
 
-// ---- placement policy ------------------------------------------------------------------------------------------------
+// ---- placement policy (FINDINGS.md 6) ------------------------------------------------------------------------------------------------
 // On MI355X the kernels that run a small store stream inside a matrix read stream (the fused projected-CG iteration, the Newton step, pcg!)
 // run at one of two speeds -- 10-15 % apart -- depending on WHERE the matrix and the n-vectors they touch were allocated: a property of the
 // pair of allocations, reproducible within a process (profiles/r03b_*: same traffic and cache hits, fewer requests in flight and +57 %

@@ -5,7 +5,7 @@
 // A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D row = (l>>4)+4*reg, col = l&15) on 128 x 128 output tiles.
 // gram_kernel and rmul_kernel stage 16-deep K steps through double-buffered LDS with the operand reads one k-group
 // ahead of the MFMAs and one barrier per step; rmul_resident_kernel keeps the small factor in LDS for the workgroup's
-// lifetime and streams the matrix straight into the B operand.  What bounds each: DESIGN.md 5.3.
+// lifetime and streams the matrix straight into the B operand.  What bounds each: FINDINGS.md 5.3.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -723,7 +723,7 @@ static void refine_round(lfpsqp_ctx* ctx, int m, std::vector<double>& V, std::ve
 // kernels, lfpsqp_factorize_sp the products of a sparse A.
 using GramFn = std::function<int(std::vector<double>&)>;
 using RmulFn = std::function<int(const double*, int)>;
-// Z == nullptr: the caller wants the factors only (Sigma, Vt, W with the basis = A W left in factored form): on the fast path no
+// Z == nullptr: the caller wants the factors only (Sigma, Vt, W with the basis = A W left in factored form, FINDINGS.md 5.3): on the fast path no
 // basis-forming product runs at all; the refinement rounds of an ill-conditioned block still need their trial basis -- needZ() provides one.
 static int factorize_core(lfpsqp_ctx* ctx, int m, const GramFn& gramA, const RmulFn& rmulA, const double* w2p, lfpsqp_mat*& Z,
                           const std::function<int()>& needZ, double* Sigma, double* Vt, double* W, int64_t* rank_out, double eps_rank) {

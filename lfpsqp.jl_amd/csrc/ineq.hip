@@ -298,7 +298,7 @@ static bool sp_factored_ok(const lfpsqp_basis* Q, int64_t n) {
 }
 
 // the basis in factored form with a DENSE generator (lfpsqp_basis.Z == NULL, A and W given): U = [sx; sy] .* (A W) is never materialised,
-// U't = W'(A'v) and U t = A (W t) stream A, the m x m factor is applied by a one-workgroup kernel
+// U't = W'(A'v) and U t = A (W t) stream A, the m x m factor is applied by a one-workgroup kernel (FINDINGS.md 5.3)
 static bool sp_factored_ok(const lfpsqp_basis* Q, int64_t n);
 // (a PLAIN basis with a sparse twin of its generator goes through the nonzeros instead, sp_factored_*; a bound-stacked one streams the dense twin)
 static bool dense_factored(const lfpsqp_basis* Q) {

@@ -1,7 +1,7 @@
 // Device-side building blocks of liblfpsqp_hip (gfx950 / CDNA4, wave64).
 //
 // Every big operation of the hot path is one of four streaming shapes over the
-// tall-skinny column-major layout:
+// tall-skinny column-major layout (FINDINGS.md §4, §5):
 //   onepass_kernel: y = M t, row-local update, then sums of M' v  -- ONE pass, tile held in registers
 //                   (the projected-CG iteration, the Newton-retraction step, the pcg! iteration)
 //   gemv_t_kernel : t = M' v      -- v produced on the fly by a functor (fused vector updates)
@@ -53,7 +53,7 @@ __device__ __forceinline__ double2 ldm(const double* p) {
 // at a wave-uniform address, by every workgroup of the following kernels in the stream.
 // A plain load of such a word compiles to s_load (scalar cache), and on MI355X / ROCm 7.2
 // that path was observed to return the PREVIOUS kernel generation's value in roughly half
-// of all processes (DESIGN.md §6 "stale scalar-cache reads"); agent-scope relaxed atomic
+// of all processes (FINDINGS.md §6 "stale scalar-cache reads"); agent-scope relaxed atomic
 // loads (global_load ... sc1) always see the value.  Every cross-kernel scalar read goes
 // through these two helpers.
 __device__ __forceinline__ double ld_scal(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

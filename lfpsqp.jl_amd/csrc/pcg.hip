@@ -18,7 +18,7 @@
 //   T   tmp = (s - alpha*u) + beta*tmp                                                   (m-vector kernel)
 // = 8 n m + 80 n bytes instead of 16 n m + 88 n.  alpha, beta, rho and the stopping test are computed exactly as in
 // the reference; s = J r is re-measured every iteration, so the recurrence for tmp does not drift.
-// Stores inside the matrix stream are the expensive part of F (160 MB of writes cost as much as 1.4 GB of reads), so F
+// Stores inside the matrix stream are the expensive part of F (FINDINGS.md 5.2: 160 MB of writes cost as much as 1.4 GB of reads), so F
 // stores ONE vector, z; the direction p = r + beta*p, which it forms in registers, is formed again -- by the same fma -- and stored by P3,
 // a plain vector kernel that reads p and r anyway:
 //   F   z = J'tmp + mu*(r + beta*p) (stored) ; partials p'z, J z, J r

@@ -37,7 +37,7 @@ struct AxpbyEpi {  // y = alpha*acc + beta*y   (beta == 0 never reads y: BLAS se
 };
 
 // The same update as a row functor of the one-pass kernel (kernels.h): the persistent grid stores y in a few device-wide bursts instead of a
-// continuous trickle inside the matrix read stream (DESIGN.md 6 "The thin store stream"); the kernel's second product is fed zeros and its
+// continuous trickle inside the matrix read stream (FINDINGS.md 6 "The thin store stream"); the kernel's second product is fed zeros and its
 // sums are discarded.
 struct GemvNRow {
     double* y;

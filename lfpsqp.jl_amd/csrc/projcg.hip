@@ -725,7 +725,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     const int64_t nv = b->n;                       // length of the n-vectors (hs + N when stacked)
     const int m = (int)U->ncols;
     LF_ARG(ctx, x->n == nv && work->g->n == nv && work->d->n == nv && work->rp->n == nv);
-    // basis in factored form with a DENSE generator (U->Z == NULL, U = [sx; sy] .* (A W)): the fused iteration streams A
+    // basis in factored form with a DENSE generator (U->Z == NULL, U = [sx; sy] .* (A W)): the fused iteration streams A (FINDINGS.md 5.3)
     const bool DF = m > 0 && !U->Z && U->A && U->W && !U->SA && m <= U->A->m && U->A->m <= kOnepassMaxCols;
     const bool SF = m > 0 && !U->Z && U->A && U->W && U->SA;       // ... or on the nonzeros of its sparse twin: no Z either
     LF_ARG(ctx, m >= 0 && (m == 0 || ((DF || SF || (U->Z && m <= U->Z->m)) && work->Utr->n >= m)));
@@ -875,7 +875,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     auto launch_k3 = [&](int init) -> int { return opf ? k3_with(Aop, init) : k3_with(Ad, init); };
 
     // The fused kernel reads the residual of a row a tile ahead and stores the projected one a tile later.  On a box in the slow
-    // state of DESIGN.md §6, removing EITHER that load or that store of the same line made the kernel 13 % faster (1.95 -> 1.70 ms),
+    // state of FINDINGS.md §6, removing EITHER that load or that store of the same line made the kernel 13 % faster (1.95 -> 1.70 ms),
     // which suggested alternating two buffers between iterations (work->g and work->rp, free after the initial projection) so
     // that the kernel never stores to lines it has just loaded.  Measured on a fast-state box that costs 4-5 % (1.76 against
     // 1.70 ms: the store no longer hits a line the L2 already holds), so it is OFF by default; lfpsqp_ctx_set_residual_buffers(ctx, 1)
@@ -1003,7 +1003,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
 }
 
 // The placement probe: the fused kernel F itself, on zero vectors (alpha = 0, g = d = 0: every store writes the zero it loaded), so what is
-// timed is exactly the access pattern whose speed depends on where the matrix and the vectors were allocated.
+// timed is exactly the access pattern whose speed depends on where the matrix and the vectors were allocated (FINDINGS.md 6).
 int lfpsqp::placement_probe(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, double* g, double* d, double* a, int reps, double* ms) {
     *ms = -1.0;
     if (!M || M->n <= 0 || ncols < 4 || ncols > M->m || onepass_cw(ctx, ncols, M->ld, M->n) == 0) return 0;

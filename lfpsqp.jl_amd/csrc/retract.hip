@@ -412,7 +412,7 @@ struct NRSparseStepF {
     }
 };
 
-constexpr int kNRBatchMax = 16;                           // (2 or 4 trials: the VALU form of the one-pass kernel; 5..16: the matrix cores, nrbatch.h)
+constexpr int kNRBatchMax = 16;                           // (2 trials: the VALU form of the one-pass kernel, which also serves shapes the matrix-core form does not cover, up to 4; 3..16: the matrix cores, nrbatch.h)
 enum { I_NRB = 32, I_NRB_ALL = I_NRB + 4 * kNRBatchMax };   // istat: [status, iterations, flag, -] per trial, then the all-done word
 struct NRSmallB {
     NRSmall t[kNRBatchMax];
@@ -1049,7 +1049,9 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
     LF_TRY(ensure_mvec(ctx, (size_t)kNRBatchMax * m + 8));            // h_m: the trials' constraint values on their way back
     // instantiated batch widths (a missing trial is born finished): 2 and 4 on the VALU form of the one-pass kernel, 16 on the matrix
     // cores (ctx->tune_nrb_mfma: 1 = the matrix-core form for every batch its shape covers, -1 = never)
-    const bool mfma = nrb_mfma_shape(wm, ml) && ctx->tune_nrb_mfma >= 0 && (nb > 4 || ctx->tune_nrb_mfma > 0);
+    // (from three trials on the matrix-core form is at least as fast without bounds -- 2.0-2.2 ms against 2.0-2.25 for four trials at 1e7 x 128 --
+    // and much faster with them: 2.6 against 3.5 ms)
+    const bool mfma = nrb_mfma_shape(wm, ml) && ctx->tune_nrb_mfma >= 0 && (nb > 2 || ctx->tune_nrb_mfma > 0);
     const int NBk = mfma ? kNRBatchMax : (nb <= 2 ? 2 : 4);
     const size_t mm = (size_t)m * m;
     const int wstride = (int)round_up(wm, 2);

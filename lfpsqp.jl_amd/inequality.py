@@ -76,7 +76,7 @@ class InequalityDecomp:
 
     def __init__(self, ctx: Context, N: int, M: int, Jct: DeviceMatrix | None = None, Z: DeviceMatrix | None = None, factored: bool = False):
         self.ctx, self.N, self.M = ctx, N, M
-        # (the driver hands in a basis allocated jointly with ProjCGWork, DESIGN.md 6 -- or none at all: factored form, 5.3)
+        # (the driver hands in a basis allocated jointly with ProjCGWork, FINDINGS.md 6 -- or none at all: factored form, 5.3)
         self.Z = Z if (Z is not None or factored) else DeviceMatrix(ctx, N, M)
         self.Sigma = np.zeros(M)
         self.Vt = np.zeros((M, M), order='F')

@@ -162,10 +162,10 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     noise = None
 
     # The basis Z (src/optimize.jl:191), ProjCGWork (:214) and the operator diagonal the fused iteration reads beside them: allocated TOGETHER,
-    # by trial over pairs of candidate allocations (lfpsqp_basis_work_alloc_placed, DESIGN.md 6: the speed of the fused kernel is a property of
+    # by trial over pairs of candidate allocations (lfpsqp_basis_work_alloc_placed, FINDINGS.md 6: the speed of the fused kernel is a property of
     # the pair of allocations)
     diagonal_hessian = hasattr(hess_lag_vec_, "diag_")
-    # ... unless the basis can stay in FACTORED form U = Jct W: then there is no Z at all -- the fused projected-CG iteration, the
+    # ... unless the basis can stay in FACTORED form U = Jct W (FINDINGS.md 5.3): then there is no Z at all -- the fused projected-CG iteration, the
     # Newton step and the projections stream Jct and apply the m x m factor W on the side, the tangent setup skips its basis-forming product,
     # and the work vectors are placed against Jct.
     # The LIBRARY says whether this context can run projcg without Z for this Jct (one-pass kernels on, shape and leading dimension inside

@@ -51,7 +51,7 @@ class DiagOperator:
 class DeviceBasis:
     """Orthonormal U = Z[:, :ncols] (``view(U, :, 1:rank)``, src/optimize.jl:370).
     ``Z = None`` with ``generator = (A, W)``: the basis in FACTORED form U = A W -- never materialised; projcg_, the Newton retraction and
-    the projections stream A and apply the small factor W on the side (lfpsqp_basis.Z == NULL)."""
+    the projections stream A and apply the small factor W on the side (lfpsqp_basis.Z == NULL, FINDINGS.md 5.3)."""
 
     def __init__(self, Z: DeviceMatrix | None, ncols: int | None = None, generator=None, sparse=None):
         self.Z = Z
@@ -113,7 +113,7 @@ class ProjCGWork:
         """n = length of the n-vectors on this rank; with bounds pass stacked_N = N and the
         vectors get the stacked [x | gap | y] layout (length hs + N).
         ``against`` (DeviceMatrix): the basis these vectors will be streamed with -- they then come from one placement-tuned
-        allocation (lfpsqp_vecs_alloc_placed), together with ``extra`` more vectors of the same kind left in
+        allocation (lfpsqp_vecs_alloc_placed, FINDINGS.md 6), together with ``extra`` more vectors of the same kind left in
         ``self.placed_extra`` (in the trial, the first of them plays the operator diagonal: use it for DiagOperator).
         ``against = ("new", rows, m)``: the basis matrix is allocated here as well, jointly with the vectors (every pair of candidate
         allocations tried, lfpsqp_basis_work_alloc_placed), and left in ``self.basis``."""

@@ -22,7 +22,7 @@ from .inequality import InequalityData, InequalityDecomp, StackedVector, calcula
 class ProjPenaltyWork:  # src/retractions.jl:21-33 (J itself is the shared device Jct)
     def __init__(self, ctx: Context, m: int, n: int, ineq: bool, against=None):
         """``against``: the constraint-gradient matrix the pcg! iteration streams -- its five n-vectors then come from ONE allocation
-        chosen by the library's placement policy against that matrix (lfpsqp_vecs_alloc_placed), as ProjCGWork's do."""
+        chosen by the library's placement policy against that matrix (lfpsqp_vecs_alloc_placed, FINDINGS.md 6), as ProjCGWork's do."""
         mk = (lambda: StackedVector(ctx, n)) if ineq else (lambda: DeviceVector(ctx, n))
         if against is not None and ctx.options.placement_tries > 1:
             self.r, self.p, self.z, self.dx, self.g = ctx.vectors_placed(against, n, 5, stacked_N=n if ineq else None)

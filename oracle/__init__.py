@@ -12,5 +12,5 @@ outputs of the reference itself.  It is pinned against
     (test/test_cg.jl, test_retractions.jl, test_inequalities.jl,
     test_linesearch.jl),
 see tests/test_oracle_*.py.  For configs 2-5 trajectory parity against the
-Julia reference itself is therefore "parity unpinned" (DESIGN.md §3).
+Julia reference itself is therefore "parity unpinned" (FINDINGS.md §3).
 """

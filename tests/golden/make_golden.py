@@ -2,7 +2,7 @@
 
 Provenance: the reference (ksil/LFPSQP.jl) is Julia-only and cannot run in the build image, so these
 vectors are NOT outputs of the reference itself -- they freeze the oracle's outputs (which are pinned on
-the README Rosenbrock known answer and the reference's test properties) on small seeded
+the README Rosenbrock known answer and the reference's test properties, FINDINGS.md §3) on small seeded
 instances of BASELINE configs 1-4, so that (a) the oracle cannot drift silently and (b) the GPU path is
 checked against committed data.  The one reference-generated golden is README.md:31-36 (Rosenbrock),
 asserted directly in tests/test_oracle_reference_properties.py.

@@ -1,4 +1,4 @@
-"""The tangent basis in FACTORED form U = Jct W (lfpsqp_basis.Z == NULL): the n x m basis matrix of the reference's
+"""The tangent basis in FACTORED form U = Jct W (lfpsqp_basis.Z == NULL, FINDINGS.md §5.3): the n x m basis matrix of the reference's
 ksvd! (src/la_helper.jl:8-34, used at src/optimize.jl:291-307, src/projcg.jl:55-118, src/retractions.jl:141) is never formed; the fused
 projected-CG iteration, the projections and the Newton retraction stream Jct and apply the m x m factor W on the side.  Everything is
 checked against the materialised basis Z = Jct W of the same factorisation and against the oracle."""

@@ -82,7 +82,7 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     except subprocess.TimeoutExpired:
         two = None
     if two is None or two.returncode != 0:
-        # the rendezvous of the two ranks stalled ONCE in round 2 (never reproduced): one more attempt on a fresh port, and
+        # the rendezvous of the two ranks stalled ONCE in round 2 (never reproduced, FINDINGS.md 7): one more attempt on a fresh port, and
         # the first attempt's output in the report if that fails too
         first = "timeout" if two is None else (two.stdout[-800:], two.stderr[-1500:])
         s2 = socket.socket(); s2.bind(("127.0.0.1", 0)); port2 = s2.getsockname()[1]; s2.close()

@@ -1,4 +1,4 @@
-"""Regression guard for the stale-scalar-cache hazard: the failure mode was
+"""Regression guard for the stale-scalar-cache hazard (FINDINGS.md §6): the failure mode was
 per PROCESS (about one process in three returned wrong iterates on tiny problems, where the
 kernels are a few microseconds long), so the stress loop runs in several fresh processes."""
 import os

@@ -1,5 +1,5 @@
 """Two builds of the library (tools/build_variant.py) timed on the SAME device buffers in one process: the speed of the fused
-projected-CG kernel depends on the (matrix, work-vector) allocation pair, so variants can only be compared on identical
+projected-CG kernel depends on the (matrix, work-vector) allocation pair (FINDINGS.md 6), so variants can only be compared on identical
 buffers.  Handles are plain structs with the same layout in both builds: the buffers are allocated through build A and handed to build B.
     python tools/ab_same_buffers.py <libA | main> <libB> [KZ] [KW]"""
 import math, os, sys

@@ -1,4 +1,4 @@
-// Micro-benchmark for the open question of DESIGN.md 6: is the allocation-pair sensitivity of the fused projected-CG kernel (and its 0.81
+// Micro-benchmark for the open question of FINDINGS.md 6: is the allocation-pair sensitivity of the fused projected-CG kernel (and its 0.81
 // UTCL1 misses per 128-byte request) a property of the ACCESS PATTERN of a 16-row x 128-column register tile over a column-major matrix --
 // 128 pages touched per tile -- or of the memory system regardless of pattern?  Two kernels with F's structure (persistent grid, one wave
 // = one 16-row tile held in registers between two products, three row-vector loads and one in-place store per tile, NT matrix loads)

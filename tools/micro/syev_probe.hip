@@ -1,6 +1,6 @@
 // How fast is the vendor's symmetric eigensolver on the small replicated factor of the tangent setup (m x m Gram matrix,
 // clustered spectrum like the BASELINE configs)?  rocsolver_dsyevd (divide & conquer) and rocsolver_dsyevj (Jacobi), m = 128,
-// 256, 512, against the library's host Jacobi.  hipcc -O3 --offload-arch=gfx950 syev_probe.hip -lrocsolver -lrocblas
+// 256, 512, against the library's host Jacobi (FINDINGS.md 5.3).  hipcc -O3 --offload-arch=gfx950 syev_probe.hip -lrocsolver -lrocblas
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
