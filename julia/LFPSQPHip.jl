@@ -930,6 +930,26 @@ function pcg!(μ::Float64, Jt::CBasis, x::DeviceVector, r::DeviceVector, p::Devi
     return Int(flag[]), Int(iters[])
 end
 
+# pcg! with M! = proj_precondition!(z, r, μ, U, Σ, rank, tmp_m) (:248-257; the call commented out at :374), fused on the device: U = Jct W is
+# known through its generator, the whole solve is one lfpsqp_pcg_pre call with K = μ W diag(σ² / (μ + σ²)) W'.  q: work n-vector.
+struct ProjPrecondition
+    W::Matrix{Float64}
+    Σ::Vector{Float64}
+    rank::Int
+    q::DeviceVector
+end
+function pcg!(μ::Float64, Jt::CBasis, M::ProjPrecondition, x::DeviceVector, r::DeviceVector, p::DeviceVector, z::DeviceVector, tol::Float64, maxiter::Int)
+    Wr = M.W[:, 1:M.rank]
+    s2 = M.Σ[1:M.rank] .^ 2
+    K = μ .* (Wr .* (s2 ./ (μ .+ s2))') * Wr'
+    flag = Ref{Cint}(0); iters = Ref{Int64}(0)
+    GC.@preserve K begin
+        pc = CPcgPrecond(pointer(K), C_NULL, C_NULL, C_NULL, M.q.h)
+        check(x.ctx, c_pcg_pre(x.ctx.h, μ, Ref(Jt), Ref(pc), x.h, r.h, p.h, z.h, tol, Int64(maxiter), flag, iters))
+    end
+    return Int(flag[]), Int(iters[])
+end
+
 # =====================================================================================================================
 # 5. Parameters and linesearch (src/LFPSQP.jl:27-81, src/linesearch.jl) -- host control flow, device vectors
 # =====================================================================================================================
@@ -1605,7 +1625,7 @@ export HipContext, HipError, DeviceOptions, DeviceVector, StackedVector, DeviceM
        InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
        ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, SeparableElementwiseBox, ElementwiseConstraints,
        sin_system_constraints, sphere_system_constraints, clone, rowscale!, set_placement!, basis_and_vectors_placed, vectors_placed, placement_info, upload!, download, upload2!, download2, projcg!, retract!,
-       retract_nr_batch!, pcg!, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!, comm_p2p_export, comm_init_p2p!,
+       retract_nr_batch!, pcg!, ProjPrecondition, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!, comm_p2p_export, comm_init_p2p!,
        shard_range, sync
 
 end # module
