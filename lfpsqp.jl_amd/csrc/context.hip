@@ -47,6 +47,19 @@ int ensure_small(lfpsqp_ctx* ctx, size_t doubles) {
     return 0;
 }
 
+int ensure_nvec(lfpsqp_ctx* ctx, size_t doubles) {
+    if (doubles <= ctx->nvec_cap) return 0;
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_nvec) LF_HIP(ctx, hipFree(ctx->d_nvec));
+    ctx->d_nvec = nullptr;
+    ctx->nvec_cap = 0;
+    const size_t cap = (size_t)round_up((int64_t)doubles + 1, kPadRows);
+    LF_HIP(ctx, hipMalloc((void**)&ctx->d_nvec, cap * sizeof(double)));
+    LF_HIP(ctx, hipMemsetAsync(ctx->d_nvec, 0, cap * sizeof(double), ctx->stream));
+    ctx->nvec_cap = cap;
+    return 0;
+}
+
 namespace {
 struct Roctx {
     int (*push)(const char*) = nullptr;
@@ -331,6 +344,22 @@ inline void dev_free(void* p) { (void)hipFree(p); }
 }  // namespace
 #endif
 
+// dst[:, j] = rs .* src[:, j]: the matrix a row-scaled view stands for (lfpsqp_mat_copy of a view; 16 columns per block row)
+__global__ __launch_bounds__(lfpsqp::kThreads) void rowscaled_copy_kernel(const double* __restrict__ A, const double* __restrict__ rs, double* __restrict__ D,
+                                                                          int64_t ld, int64_t n, int m) {
+    const int64_t i = ((int64_t)blockIdx.x * lfpsqp::kThreads + threadIdx.x) * 2;
+    if (i >= n) return;
+    const double2 s = lfpsqp::ld2(rs + i);
+    const bool v1 = i + 1 < n;
+    const int j0 = blockIdx.y * 16, j1 = (j0 + 16 < m) ? j0 + 16 : m;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const double2 c = lfpsqp::ld2(A + (int64_t)j * ld + i);
+        if (v1) lfpsqp::st2(D + (int64_t)j * ld + i, make_double2(s.x * c.x, s.y * c.y));
+        else D[(int64_t)j * ld + i] = s.x * c.x;
+    }
+}
+
 extern "C" {
 
 int lfpsqp_ctx_create(int device, lfpsqp_ctx** out) {
@@ -388,6 +417,7 @@ int lfpsqp_ctx_destroy(lfpsqp_ctx* ctx) {
     if (ctx->d_m) (void)hipFree(ctx->d_m);
     if (ctx->d_qw) (void)hipFree(ctx->d_qw);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
+    if (ctx->d_nvec) (void)hipFree(ctx->d_nvec);
     if (ctx->h_m) (void)hipHostFree(ctx->h_m);
     if (ctx->scal) (void)hipFree(ctx->scal);
     if (ctx->istat) (void)hipFree(ctx->istat);
@@ -964,8 +994,18 @@ int lfpsqp_mat_alloc(lfpsqp_ctx* ctx, int64_t n, int64_t m, lfpsqp_mat** out) {
 int lfpsqp_mat_free(lfpsqp_ctx* ctx, lfpsqp_mat* M) {
     if (!M) return 0;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    if (M->p) dev_free(M->p);
+    if (M->p && !M->view) dev_free(M->p);      // (a view borrows its storage)
     delete M;
+    return 0;
+}
+
+int lfpsqp_mat_rowscaled_view(lfpsqp_ctx* ctx, const lfpsqp_mat* A, const lfpsqp_vec* rs, lfpsqp_mat** out) {
+    LF_ARG(ctx, ctx && A && rs && out && plain_mat(A) && rs->n >= A->n);
+    lfpsqp_mat* V = new (std::nothrow) lfpsqp_mat(*A);
+    if (!V) return set_err(ctx, LFPSQP_ERR_HIP, "out of host memory");
+    V->rs = rs->p;
+    V->view = true;
+    *out = V;
     return 0;
 }
 
@@ -977,7 +1017,7 @@ int lfpsqp_mat_shape(const lfpsqp_mat* M, int64_t* n, int64_t* m) {
 }
 
 int lfpsqp_mat_upload(lfpsqp_ctx* ctx, lfpsqp_mat* M, int64_t col0, int64_t ncols, const double* host, int64_t ldh) {
-    LF_ARG(ctx, ctx && M && host && col0 >= 0 && ncols >= 0 && col0 + ncols <= M->m && ldh >= M->n);
+    LF_ARG(ctx, ctx && plain_mat(M) && host && col0 >= 0 && ncols >= 0 && col0 + ncols <= M->m && ldh >= M->n);
     if (ncols == 0 || M->n == 0) return 0;
     LF_HIP(ctx, hipMemcpy2DAsync(M->p + col0 * M->ld, sizeof(double) * M->ld, host, sizeof(double) * ldh, sizeof(double) * M->n,
                                  (size_t)ncols, hipMemcpyHostToDevice, ctx->stream));
@@ -986,7 +1026,7 @@ int lfpsqp_mat_upload(lfpsqp_ctx* ctx, lfpsqp_mat* M, int64_t col0, int64_t ncol
 }
 
 int lfpsqp_mat_download(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t col0, int64_t ncols, double* host, int64_t ldh) {
-    LF_ARG(ctx, ctx && M && host && col0 >= 0 && ncols >= 0 && col0 + ncols <= M->m && ldh >= M->n);
+    LF_ARG(ctx, ctx && plain_mat(M) && host && col0 >= 0 && ncols >= 0 && col0 + ncols <= M->m && ldh >= M->n);
     if (ncols == 0 || M->n == 0) return 0;
     LF_HIP(ctx, hipMemcpy2DAsync(host, sizeof(double) * ldh, M->p + col0 * M->ld, sizeof(double) * M->ld, sizeof(double) * M->n,
                                  (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
@@ -995,7 +1035,15 @@ int lfpsqp_mat_download(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t col0, int6
 }
 
 int lfpsqp_mat_copy(lfpsqp_ctx* ctx, lfpsqp_mat* dst, const lfpsqp_mat* src) {
-    LF_ARG(ctx, ctx && dst && src && dst->n == src->n && dst->m == src->m && dst->ld == src->ld);
+    LF_ARG(ctx, ctx && plain_mat(dst) && src && dst->n == src->n && dst->m == src->m && dst->ld == src->ld);
+    if (src->rs) {                                 // the copy of a row-scaled view is the matrix it stands for: dst = diag(rs) * src
+        LF_ARG(ctx, dst->p != src->p);
+        if (src->n == 0 || src->m == 0) return 0;
+        hipLaunchKernelGGL(rowscaled_copy_kernel, dim3((unsigned)((src->n + 2 * kThreads - 1) / (2 * kThreads)), (unsigned)((src->m + 15) / 16)), dim3(kThreads), 0,
+                           ctx->stream, src->p, src->rs, dst->p, src->ld, src->n, (int)src->m);
+        LF_LAUNCH_CHECK(ctx);
+        return 0;
+    }
     LF_HIP(ctx, hipMemcpyAsync(dst->p, src->p, sizeof(double) * (size_t)src->ld * (size_t)src->m, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }

@@ -439,9 +439,34 @@ struct ColTimesW {
     }
 };
 
+// weights of the Gram matrix of a row-scaled view diag(rs) M: out = rs^2 .* w2 (w2 may be null)
+struct ViewWeightF {
+    const double *rs, *w2;
+    double* out;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 s = ld2(rs + i);
+        double2 w = make_double2(s.x * s.x, s.y * s.y);
+        if (w2) {
+            const double2 u = ld2(w2 + i);
+            w.x *= u.x;
+            w.y *= u.y;
+        }
+        if (v1) st2(out + i, w);
+        else if (v0) out[i] = w.x;
+    }
+};
+
 static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const double* w2, std::vector<double>& G) {
     G.assign((size_t)ncols_all * ncols_all, 0.0);
     if (ncols_all == 0) return 0;
+    if (M->rs) {       // (diag(rs) M)' diag(w2) (diag(rs) M) = M' diag(rs^2 w2) M: the weighted kernel over the plain storage
+        LF_TRY(ensure_nvec(ctx, (size_t)M->n));
+        LF_TRY((run_vec<ViewWeightF, 0, NoPost>(ctx, M->n, ViewWeightF{M->rs, w2, ctx->d_nvec}, 0u, nullptr, NoPost())));
+        lfpsqp_mat plain = *M;
+        plain.rs = nullptr;
+        return gram_impl(ctx, &plain, ncols_all, ctx->d_nvec, G);
+    }
     // A few columns beyond a multiple of the 128-column panel (m + 1 constraints with a slack/ball column, say) would cost
     // a whole extra panel row and column of MFMA tiles; they are cheaper as GEMV-T passes: G[:, j] = M' (w2 .* M[:, j]).
     const int rem = ncols_all % kPanel;
@@ -533,8 +558,33 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     return 0;
 }
 
+// Out[:, :rcols] = diag(rs) * Out[:, :rcols] in place (the product of a row-scaled view: the MFMA kernels ran over the plain storage)
+__global__ __launch_bounds__(kThreads) void scale_rows_kernel(double* D, int64_t ld, int64_t n, int m, const double* __restrict__ rs) {
+    const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 2;
+    if (i >= n) return;
+    const double2 s = ld2(rs + i);
+    const bool v1 = i + 1 < n;
+    const int j0 = blockIdx.y * 16, j1 = (j0 + 16 < m) ? j0 + 16 : m;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const double2 c = ld2(D + (int64_t)j * ld + i);
+        if (v1) st2(D + (int64_t)j * ld + i, make_double2(s.x * c.x, s.y * c.y));
+        else D[(int64_t)j * ld + i] = s.x * c.x;
+    }
+}
+
 static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const double* W_host, int rcols, lfpsqp_mat* Out) {
     if (rcols == 0 || In->n == 0) return 0;
+    if (In->rs) {      // (diag(rs) In) W = diag(rs) (In W): a second pass over the output -- this product is off the fast path (the basis of a view
+                       // stays in factored form; only the refinement rounds of an ill-conditioned block and callers that insist on Z come here)
+        lfpsqp_mat plain = *In;
+        plain.rs = nullptr;
+        LF_TRY(rmul_impl(ctx, &plain, kcols, W_host, rcols, Out));
+        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((In->n + 2 * kThreads - 1) / (2 * kThreads)), (unsigned)((rcols + 15) / 16)), dim3(kThreads), 0,
+                           ctx->stream, Out->p, Out->ld, In->n, rcols, In->rs);
+        LF_LAUNCH_CHECK(ctx);
+        return 0;
+    }
     LF_TRY(ensure_small(ctx, (size_t)kcols * rcols + 32 + ((size_t)kcols + kKStep) * ((size_t)rcols + kPanel)));
     LF_HIP(ctx, hipMemcpyAsync(ctx->small, W_host, sizeof(double) * (size_t)kcols * rcols, hipMemcpyHostToDevice, ctx->stream));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // W_host is caller-owned pageable memory
@@ -831,7 +881,7 @@ int lfpsqp_gram(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsq
 
 int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const double* W_host, int64_t rcols, lfpsqp_mat* Out) {
     LF_RANGE("lfpsqp_rmul");
-    LF_ARG(ctx, ctx && In && Out && W_host && In->p != Out->p && kcols >= 0 && kcols <= In->m && rcols >= 0 && rcols <= Out->m &&
+    LF_ARG(ctx, ctx && In && plain_mat(Out) && W_host && In->p != Out->p && kcols >= 0 && kcols <= In->m && rcols >= 0 && rcols <= Out->m &&
                     In->n == Out->n);
     return rmul_impl(ctx, In, (int)kcols, W_host, (int)rcols, Out);
 }
@@ -850,7 +900,7 @@ int lfpsqp_small_svd(lfpsqp_ctx* ctx, int64_t rows, int64_t cols, const double* 
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
                      double* W, int64_t* rank_out, double eps_rank) {
     LF_RANGE("lfpsqp_factorize");
-    LF_ARG(ctx, ctx && Jct && Sigma && Vt && rank_out && (Z ? (Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m) : W != nullptr) &&
+    LF_ARG(ctx, ctx && Jct && Sigma && Vt && rank_out && (Z ? (plain_mat(Z) && Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m) : W != nullptr) &&
                     (!w2 || w2->n == Jct->n));
     const int m = (int)Jct->m;
     const double* w2p = w2 ? w2->p : nullptr;
@@ -867,6 +917,7 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
 int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma,
                         double* Vt, double* W, int64_t* rank_out, double eps_rank) {
     LF_RANGE("lfpsqp_factorize_sp");
+    LF_ARG(ctx, (!Jct || plain_mat(Jct)) && (!Z || plain_mat(Z)));      // (a sparse class scales its nonzeros: lfpsqp_spmat_rowscale)
     LF_ARG(ctx, ctx && S && Sigma && Vt && rank_out && (!w2 || w2->n == S->n) && (Z ? S->n == Z->n : W != nullptr) &&
                     (!Jct || ((!Z || Jct->p != Z->p) && Jct->n == S->n && Jct->m >= S->m && Jct->m - S->m <= 4)) &&
                     (!Z || Z->m >= (Jct ? Jct->m : S->m)));

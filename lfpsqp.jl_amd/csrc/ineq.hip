@@ -293,7 +293,7 @@ int lfpsqp_y_retract(lfpsqp_ctx* ctx, lfpsqp_vec* xnewaug, const lfpsqp_vec* xau
 
 // a plain basis with its generator and the generator's sparse twin: U = A W applied on the nonzeros (sparse.hip)
 static bool sp_factored_ok(const lfpsqp_basis* Q, int64_t n) {
-    return Q->ncols > 0 && Q->SA && Q->A && Q->W && Q->SA->n == n && Q->A->n == n && Q->SA->m >= 1 && Q->A->m >= Q->SA->m && Q->A->m - Q->SA->m <= 4 &&
+    return Q->ncols > 0 && Q->SA && Q->A && plain_mat(Q->A) && Q->W && Q->SA->n == n && Q->A->n == n && Q->SA->m >= 1 && Q->A->m >= Q->SA->m && Q->A->m - Q->SA->m <= 4 &&
            Q->ncols <= 1024;
 }
 

@@ -26,6 +26,11 @@ struct lfpsqp_mat {
     double* p = nullptr;
     int64_t n = 0, m = 0;
     int64_t ld = 0;  // rows rounded up to whole tiles; padding rows are zero and never written
+    // row-scaled view (lfpsqp_mat_rowscaled_view): the matrix is diag(rs) * [p]; p belongs to another lfpsqp_mat, rs to an lfpsqp_vec.
+    // Honoured by the launch helpers run_gemv_t / run_gemv_n / run_gemv_nt / run_onepass and by the Gram kernels; every other consumer
+    // of a matrix refuses a view (plain_mat()).
+    const double* rs = nullptr;
+    bool view = false;
 };
 
 namespace lfpsqp {
@@ -76,6 +81,8 @@ struct lfpsqp_ctx {
     double* h_m = nullptr;
     size_t m_cap = 0;
     // the weights of lfpsqp_elementwise's quadratic term (device, m_lin)
+    double* d_nvec = nullptr;        // an n-vector of scratch (combined weights of the Gram matrix of a row-scaled view)
+    size_t nvec_cap = 0;
     double* d_zeros = nullptr;       // kOnepassMaxCols zeros (the first-product coefficients of a one-pass launch that only evaluates)
     double* d_qw = nullptr;
     size_t qw_cap = 0;
@@ -139,6 +146,7 @@ int set_err(lfpsqp_ctx* ctx, int code, const char* fmt, ...);
 int ensure_part(lfpsqp_ctx* ctx, size_t doubles);
 int ensure_small(lfpsqp_ctx* ctx, size_t doubles);
 int ensure_mvec(lfpsqp_ctx* ctx, size_t doubles);   // d_m / h_m, each `doubles` long
+int ensure_nvec(lfpsqp_ctx* ctx, size_t doubles);   // d_nvec (padded to whole tiles)
 int allreduce_dev(lfpsqp_ctx* ctx, double* buf, int64_t count, int op = 0);  // in place, stream ordered; op 0 sum / 1 max; no-op for 1 rank
 
 // profiling helpers: bracket one launch of slot `s`
@@ -208,6 +216,13 @@ int launch_reduce(lfpsqp_ctx* ctx, int64_t nrows, int ncols, int part_ld, unsign
 // empty basis (reference: projcg! with an n x 0 U).
 template <class VP>
 int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp, double* t_out, int prof_slot = -1) {
+    if constexpr (!is_rowscaled<VP>::value) {
+        if (M && M->rs) {                          // a row-scaled view: the same kernel over the plain storage, producer scaled (kernels.h)
+            lfpsqp_mat plain = *M;
+            plain.rs = nullptr;
+            return run_gemv_t(ctx, &plain, ncols, n, RsLoadV<VP>{vp, M->rs}, t_out, prof_slot);
+        }
+    }
     ++ctx->launch_epoch;
     const int ks = ctx->ks_for(n);
     const int64_t tiles = ntiles_of(n, ks);
@@ -237,6 +252,13 @@ int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp
 template <class EP, int NRED, class POST>
 int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const double* t, EP ep, double* red_out, POST post,
                int prof_slot = -1) {
+    if constexpr (!is_rowscaled<EP>::value) {
+        if (M && M->rs) {
+            lfpsqp_mat plain = *M;
+            plain.rs = nullptr;
+            return run_gemv_n<RsApplyE<EP>, NRED, POST>(ctx, &plain, ncols, n, t, RsApplyE<EP>{ep, M->rs}, red_out, post, prof_slot);
+        }
+    }
     ++ctx->launch_epoch;
     const int ks = ctx->ks_for(n);
     const int64_t tiles = ntiles_of(n, ks);
@@ -276,6 +298,15 @@ int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const
 template <class EP, int NRED>
 int run_gemv_nt(lfpsqp_ctx* ctx, const lfpsqp_mat* M1, int n1, const double* t, const lfpsqp_mat* M2, int n2, int64_t n, EP ep,
                 double* out) {
+    if constexpr (!is_rowscaled<EP>::value) {
+        if ((M1 && M1->rs) || (M2 && M2->rs)) {
+            lfpsqp_mat p1, p2;
+            if (M1) { p1 = *M1; p1.rs = nullptr; }
+            if (M2) { p2 = *M2; p2.rs = nullptr; }
+            return run_gemv_nt<RsStepE<EP>, NRED>(ctx, M1 ? &p1 : nullptr, n1, t, M2 ? &p2 : nullptr, n2, n,
+                                                  RsStepE<EP>{ep, M1 ? M1->rs : nullptr, M2 ? M2->rs : nullptr}, out);
+        }
+    }
     ++ctx->launch_epoch;
     const int ks = ctx->ks_for(n);
     const int64_t tiles = ntiles_of(n, ks);
@@ -298,6 +329,9 @@ int run_gemv_nt(lfpsqp_ctx* ctx, const lfpsqp_mat* M1, int n1, const double* t, 
     else LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
     return allreduce_dev(ctx, out, nout);
 }
+
+// a matrix argument of a routine that reads or writes the storage directly: not a row-scaled view
+inline bool plain_mat(const lfpsqp_mat* M) { return M && !M->rs && !M->view; }
 
 // One-stream N->T product over M (onepass_kernel): usable for this shape?  Returns the lane-group count CW (4) or 0.
 inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
@@ -355,6 +389,18 @@ inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds, int wg_per_cu_cap = 0) 
 template <class EP, int NV, int NRED, int NA = 1>
 int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t n, const double* t, const EP& ep, double* out,
                 int prof_slot = -1, int t_stride = 0, int wg_per_cu_cap = 0, bool discard_sums = false) {
+    if constexpr (!is_rowscaled<EP>::value) {
+        if (M->rs) {                               // a row-scaled view: the same kernel over the plain storage, row functor wrapped (kernels.h)
+            if constexpr (no_rowscale<EP>::value) {
+                return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "this kernel does not take a row-scaled matrix view");
+            } else {
+                lfpsqp_mat plain = *M;
+                plain.rs = nullptr;
+                return run_onepass<RsRowE<EP, NV, NA>, NV, NRED, NA>(ctx, &plain, ncN, ncT, n, t, RsRowE<EP, NV, NA>{ep, M->rs}, out, prof_slot, t_stride,
+                                                                     wg_per_cu_cap, discard_sums);
+            }
+        }
+    }
     ++ctx->launch_epoch;
     const int cpl = (ncN + 3) / 4;                // column groups
     const bool wide = cpl > 64;                   // more than 256 columns: the four waves of a workgroup split the columns

@@ -658,6 +658,106 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
 }
 
 // ---------------------------------------------------------------------------
+// Row-scaled matrix views (lfpsqp_mat::rs, lfpsqp_mat_rowscaled_view): the matrix the solvers work with is diag(rs) * M with M constant
+// and rs an n-vector -- the constraint gradients diag(phi'(x)) A of the nonlinear class lfpsqp_elementwise, which then never exist in
+// memory (the reference's jac! rewrites the whole matrix every outer iteration, src/autodiff_generators.jl:60-66; here it rewrites rs).
+// The kernels stay as they are: the launch helpers wrap the row functor, which sees first products already scaled and whose second-product
+// vectors are scaled on the way out.  Cost: 8 bytes per row next to 8 * m.  Rows >= n carry zeros whatever the padding of rs holds.
+// ---------------------------------------------------------------------------
+template <class T, class = void>
+struct is_rowscaled : std::false_type {};
+template <class T>
+struct is_rowscaled<T, std::void_t<decltype(T::kRowScaled)>> : std::true_type {};
+// functors that refuse a view (the launch helper reports LFPSQP_ERR_UNSUPPORTED): EP::kNoRowScale
+template <class T, class = void>
+struct no_rowscale : std::false_type {};
+template <class T>
+struct no_rowscale<T, std::void_t<decltype(T::kNoRowScale)>> : std::true_type {};
+
+template <class VP>
+struct RsLoadV {      // GEMV-T producer
+    static constexpr bool kRowScaled = true;
+    VP vp;
+    const double* rs;
+    __device__ __forceinline__ bool skip() const { return vp.skip(); }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        const double2 v = vp.load(r, v0, v1);
+        const double2 s = ld2(rs + r);
+        return make_double2(v0 ? v.x * s.x : 0.0, v1 ? v.y * s.y : 0.0);
+    }
+};
+template <class EP>
+struct RsApplyE {     // GEMV-N consumer
+    static constexpr bool kRowScaled = true;
+    EP ep;
+    const double* rs;
+    __device__ __forceinline__ bool skip() const { return ep.skip(); }
+    __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
+        const double2 s = ld2(rs + r);
+        ep.apply(r, make_double2(v0 ? acc.x * s.x : 0.0, v1 ? acc.y * s.y : 0.0), v0, v1, red);
+    }
+};
+template <class EP>
+struct RsStepE {      // GEMV-N -> GEMV-T in one launch (two matrices, each plain or a view)
+    static constexpr bool kRowScaled = true;
+    EP ep;
+    const double *rs1, *rs2;
+    __device__ __forceinline__ bool skip() const { return ep.skip(); }
+    __device__ __forceinline__ double2 apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
+        if (rs1) {
+            const double2 s = ld2(rs1 + r);
+            acc = make_double2(v0 ? acc.x * s.x : 0.0, v1 ? acc.y * s.y : 0.0);
+        }
+        double2 v = ep.apply(r, acc, v0, v1, red);
+        if (rs2) {
+            const double2 s = ld2(rs2 + r);
+            v = make_double2(v0 ? v.x * s.x : 0.0, v1 ? v.y * s.y : 0.0);
+        }
+        return v;
+    }
+};
+template <class EP, int NV, int NA>
+struct RsRowE {       // one-stream kernel (onepass_kernel): the row's scale travels with its other inputs, a tile ahead
+    static constexpr bool kRowScaled = true;
+    EP ep;
+    const double* rs;
+    using Uni = typename EP::Uni;
+    struct Row { typename EP::Row in; double s; };
+    static constexpr bool kSplitRed = EP::kSplitRed;
+    __device__ __forceinline__ bool skip() const { return ep.skip(); }
+    __device__ __forceinline__ Uni uniform() const { return ep.uniform(); }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        return Row{ep.fetch(o), *reinterpret_cast<const double*>(reinterpret_cast<const char*>(rs) + o)};
+    }
+    template <class RED>
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&acc)[NA], bool valid, bool owner, bool lead, const Uni& u, const Row& w,
+                                          double (&v)[NV], RED& red) const {
+        const double s = valid ? w.s : 0.0;
+        double a2[NA];
+#pragma unroll
+        for (int b = 0; b < NA; ++b) a2[b] = acc[b] * s;
+        ep.apply(row, o, a2, valid, owner, lead, u, w.in, v, red);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] *= s;
+    }
+    template <class RED>
+    __device__ __forceinline__ void apply_staged(int64_t row, uint32_t o, const double (&acc)[NA], bool valid, bool owner, bool lead, const Uni& u,
+                                                 const Row& w, double (&v)[NV], RED& red, double* slot, int sstride) const {
+        const double s = valid ? w.s : 0.0;
+        double a2[NA];
+#pragma unroll
+        for (int b = 0; b < NA; ++b) a2[b] = acc[b] * s;
+        ep.apply_staged(row, o, a2, valid, owner, lead, u, w.in, v, red, slot, sstride);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] *= s;
+    }
+    __device__ __forceinline__ double* stage_out(int sv) const { return ep.stage_out(sv); }
+};
+// (the staged form is offered exactly when the wrapped functor offers it)
+template <class EP, int NV, int NA>
+struct stage_streams<RsRowE<EP, NV, NA>> : stage_streams<EP> {};
+
+// ---------------------------------------------------------------------------
 // Elementwise map + reductions.  F::apply(i, valid0, valid1, red) handles the
 // row pair (i, i+1).  Block b handles the `tpb` consecutive 512-row tiles [b*tpb, (b+1)*tpb) in order: a static assignment
 // and a fixed in-block order keep the sums reproducible.  part[block][k].

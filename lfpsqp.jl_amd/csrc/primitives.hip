@@ -267,7 +267,7 @@ int lfpsqp_vec_hash_fill(lfpsqp_ctx* ctx, lfpsqp_vec* v, uint64_t seed, int64_t 
 
 int lfpsqp_mat_hash_fill(lfpsqp_ctx* ctx, lfpsqp_mat* M, uint64_t seed, int64_t row0, int64_t n_global, double scale, int64_t nrows,
                          int64_t ncols) {
-    LF_ARG(ctx, ctx && M && row0 >= 0 && nrows >= 0 && nrows <= M->n && ncols >= 0 && ncols <= M->m && n_global >= nrows);
+    LF_ARG(ctx, ctx && plain_mat(M) && row0 >= 0 && nrows >= 0 && nrows <= M->n && ncols >= 0 && ncols <= M->m && n_global >= nrows);
     if (nrows == 0 || ncols == 0) return 0;
     LF_ARG(ctx, ncols <= 65535);
     hipLaunchKernelGGL(hash_mat_kernel, dim3((unsigned)((nrows + kPadRows - 1) / kPadRows), (unsigned)ncols), dim3(kThreads), 0, ctx->stream, M->p, M->ld,

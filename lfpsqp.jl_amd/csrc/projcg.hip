@@ -765,7 +765,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     int wm = 0;
     double *dWs = nullptr, *tA = nullptr, *uA = nullptr;
     double* tmpN = rp;                             // scratch for the materialised producer vector: rp, or (stacked: rp holds both halves) a buffer
-    if (m > 0 && m <= kOnepassMaxCols && U->SA && U->A && U->W && U->SA->n == N && U->A->n == N && U->SA->m >= 1 && U->A->m >= U->SA->m &&
+    if (m > 0 && m <= kOnepassMaxCols && U->SA && U->A && plain_mat(U->A) && U->W && U->SA->n == N && U->A->n == N && U->SA->m >= 1 && U->A->m >= U->SA->m &&
         U->A->m - U->SA->m <= 4 && !(c && m > 0)) {
         SA = U->SA;
         wm = (int)U->A->m;

@@ -740,9 +740,17 @@ static bool cons_ok(const lfpsqp_constraints* c) {
           (!c->has_ball || (c->n_x >= 0 && c->n_x <= c->Jct->n && c->slack_row < c->Jct->n)) &&
           (!c->Jsp || (c->Jsp->n == c->Jct->n && c->Jsp->m == c->m_lin))))
         return false;
+    // a row-scaled view as Jct (constant or streamed gradients): no ball column (jac! would write it into the borrowed storage, and it is not
+    // scaled with the rows) and no sparse twin
+    if (c->Jct->rs && (c->has_ball || c->Jsp)) return false;
     const lfpsqp_elementwise* e = c->ew;
     if (!e) return true;
-    return c->m_lin >= 1 && (e->Asp || e->A) && (!e->A || (e->A->p != c->Jct->p && e->A->n == c->Jct->n && e->A->m >= c->m_lin)) &&
+    // STREAMED gradients: Jct is a row-scaled view of A itself (lfpsqp_mat_rowscaled_view) -- Jct(x) = diag(phi'(x)) A never exists in memory, jac!
+    // rewrites the view's scale vector.  No rank-one / ball column then (they are not row scalings of A).
+    const bool streamed = e->A && e->A->p == c->Jct->p;
+    if (streamed && !(c->Jct->rs && plain_mat(e->A) && !e->Asp && !e->qw && !c->has_ball && !c->Jsp)) return false;
+    if (!streamed && !plain_mat(c->Jct)) return false;
+    return c->m_lin >= 1 && (e->Asp || e->A) && (!e->A || (e->A->n == c->Jct->n && e->A->m >= c->m_lin)) &&
            (!e->kind || e->kind->n >= c->Jct->n) &&
            (!e->qw || (!c->has_ball && !e->Asp && c->n_x >= 0 && c->n_x <= c->Jct->n)) &&
            (!e->Asp || (c->Jsp && c->Jsp != e->Asp && e->Asp->n == c->Jct->n && e->Asp->m == c->m_lin && c->Jsp->ell_col == e->Asp->ell_col &&
@@ -760,11 +768,13 @@ int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, con
 
 int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval) {
     LF_RANGE("lfpsqp_constraints_jac");
-    LF_ARG(ctx, ctx && cons_ok(cons) && x && Jct && cval && x->n >= cons->Jct->n && Jct->p == cons->Jct->p);
+    LF_ARG(ctx, ctx && cons_ok(cons) && x && Jct && cval && x->n >= cons->Jct->n && Jct->p == cons->Jct->p && Jct->rs == cons->Jct->rs);
     if (const lfpsqp_elementwise* ew = cons->ew) {             // Jct[:, :m_lin] = diag(phi'(x)) A + 2 x qw'
         const int64_t N = Jct->n;
         const int ml = (int)cons->m_lin;
-        if (ew->Asp) {
+        if (Jct->rs) {                                            // streamed gradients: jac! is the n-vector phi'(x), the matrix stays A
+            LF_TRY((run_vec<EwDerivF, 0, NoPost>(ctx, N, EwDerivF{x->p, ew->kind ? ew->kind->p : nullptr, const_cast<double*>(Jct->rs)}, 0u, nullptr, NoPost())));
+        } else if (ew->Asp) {
             LF_TRY((run_vec<EwDerivF, 0, NoPost>(ctx, N, EwDerivF{x->p, ew->kind ? ew->kind->p : nullptr, ew->work->p}, 0u, nullptr, NoPost())));
             LF_TRY(lfpsqp_spmat_rowscale(ctx, const_cast<lfpsqp_spmat*>(cons->Jsp), ew->Asp, ew->work));
             LF_TRY(lfpsqp_spmat_to_dense(ctx, cons->Jsp, Jct));
@@ -1008,7 +1018,7 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
 int lfpsqp_retract_nr_batch_width(const lfpsqp_ctx* ctx, const lfpsqp_basis* U, const lfpsqp_constraints* cons, int* width) {
     if (!ctx || !U || !cons || !width || !cons->Jct) return LFPSQP_ERR_ARG;
     *width = 0;
-    if (cons->Jsp || cons->ew) return 0;
+    if (cons->Jsp || cons->ew || !plain_mat(cons->Jct)) return 0;
     const int ml = (int)cons->m_lin;
     const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kColChunk) ? (int)U->A->m : 0;
     if (!wm || U->ncols > kNRMaxM || !onepass_cw(ctx, wm, cons->Jct->ld, cons->Jct->n)) return 0;

@@ -997,7 +997,7 @@ int lfpsqp_spmv_n(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, double alpha, const lf
 }
 
 int lfpsqp_spmat_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, double* G) {
-    LF_ARG(ctx, ctx && S && G && (!w2 || w2->n == S->n) && (!Jct || (Jct->n == S->n && Jct->m >= S->m && Jct->m - S->m <= 4)));
+    LF_ARG(ctx, ctx && S && G && (!w2 || w2->n == S->n) && (!Jct || (plain_mat(Jct) && Jct->n == S->n && Jct->m >= S->m && Jct->m - S->m <= 4)));
     const int nx = Jct ? (int)(Jct->m - S->m) : 0;
     double* scratch = nullptr;
     if (nx > 0 && w2) {     // an n-vector like any other: whole tiles (the vector kernels load row pairs up to the end of the last tile)
@@ -1012,7 +1012,7 @@ int lfpsqp_spmat_gram(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* 
 }
 
 int lfpsqp_spmat_to_dense(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, lfpsqp_mat* M) {
-    LF_ARG(ctx, ctx && S && M && M->n == S->n && M->m >= S->m);
+    LF_ARG(ctx, ctx && S && plain_mat(M) && M->n == S->n && M->m >= S->m);
     if (S->m == 0 || S->n == 0) return 0;
     LF_HIP(ctx, hipMemsetAsync(M->p, 0, sizeof(double) * (size_t)M->ld * (size_t)S->m, ctx->stream));
     hipLaunchKernelGGL(sp_scatter_kernel, dim3(64, (unsigned)S->m), dim3(256), 0, ctx->stream, S->colptr, S->csc_row, S->csc_val, M->p, M->ld);

@@ -298,13 +298,31 @@ class DeviceMatrix:
 
     def download(self, col0: int = 0, ncols: int | None = None) -> np.ndarray:
         ncols = self.m - col0 if ncols is None else ncols
+        if getattr(self, "rs", None) is not None:          # a row-scaled view: materialise it (lfpsqp_mat_copy), then read that back
+            tmp = DeviceMatrix(self.ctx, self.n, self.m)
+            try:
+                return tmp.copy_from(self).download(col0, ncols)
+            finally:
+                tmp.free()
         out = np.empty((self.n, ncols), dtype=np.float64, order='F')
         self.ctx.check(self.ctx.L.lfpsqp_mat_download(self.ctx.h, self.h, col0, ncols, out.ctypes.data, max(self.n, 1)))
         return out
 
     def copy_from(self, src: "DeviceMatrix"):
+        """(the copy of a row-scaled view is the matrix it stands for)"""
         self.ctx.check(self.ctx.L.lfpsqp_mat_copy(self.ctx.h, self.h, src.h))
         return self
+
+    def rowscaled_view(self, rs: "DeviceVector") -> "DeviceMatrix":
+        """diag(rs) * self without a copy (lfpsqp_mat_rowscaled_view): every product kernel of the library accepts it wherever a matrix is
+        only read; storage and ``rs`` are borrowed (the view keeps both alive)."""
+        v = DeviceMatrix.__new__(DeviceMatrix)
+        v.ctx, v.n, v.m = self.ctx, self.n, self.m
+        h = P()
+        self.ctx.check(self.ctx.L.lfpsqp_mat_rowscaled_view(self.ctx.h, self.h, rs.h, C.byref(h)))
+        v.h = h
+        v.base, v.rs = self, rs
+        return v
 
     def hash_fill(self, seed: int, row0: int = 0, n_global: int | None = None, scale: float = 1.0, nrows: int | None = None,
                   ncols: int | None = None):

@@ -77,14 +77,27 @@ class ElementwiseConstraints(DeviceConstraints):
     src/autodiff_generators.jl:60-66) and a DIAGONAL Lagrangian-Hessian term (``hess_diag_``; hess_lag_vec!, :80-104).
     Covers the reference's own nonlinear test systems (test/test_retractions.jl:1-54, see :func:`sin_system_constraints` /
     :func:`sphere_system_constraints`).  ``A``: DeviceMatrix (n x m), or a SparseMatrix -- then c!, jac!, the tangent setup, the
-    Newton steps and the inner solves of ProjPenalty all stream the nonzeros.  ``Jct`` (n x (m + ball)) is the working matrix."""
+    Newton steps and the inner solves of ProjPenalty all stream the nonzeros.  ``Jct`` (n x (m + ball)) is the working matrix.
+
+    ``stream`` (dense ``A`` without ``qw`` / ball; default: whenever the library's one-pass kernels cover the shape): the gradients are
+    STREAMED -- ``Jct`` is a row-scaled view of ``A`` itself (:meth:`DeviceMatrix.rowscaled_view`), jac! refreshes the n-vector
+    phi'(x) instead of rewriting an n x m matrix, and there is no second matrix in memory."""
 
     def __init__(self, ctx, A, b, kind=None, qw=None, Jct: DeviceMatrix | None = None, has_ball: bool = False, R2: float = 0.0,
-                 n_x: int | None = None, slack_row: int = -1):
+                 n_x: int | None = None, slack_row: int = -1, stream: bool | None = None):
         from .device import SparseMatrix
         sparse = isinstance(A, SparseMatrix)
         n, m = A.n, A.m
-        if Jct is None:
+        can_stream = not sparse and qw is None and not has_ball and Jct is None and m >= 1
+        if stream is None:
+            stream = can_stream and ctx.factored_basis_supported(A, None)
+        elif stream and not can_stream:
+            raise ValueError("streamed gradients need a dense A, no quadratic term, no ball and no caller-owned Jct")
+        self.streamed = bool(stream)
+        if self.streamed:
+            self.rs = ctx.vector(n, np.ones(n))
+            Jct = A.rowscaled_view(self.rs)
+        elif Jct is None:
             Jct = DeviceMatrix(ctx, n, m + (1 if has_ball else 0), placed=True)
         Jsp = A.clone() if sparse else None
         super().__init__(Jct, m, b, has_ball=has_ball, R2=R2, n_x=(n if n_x is None else n_x), slack_row=slack_row, Jsp=Jsp)

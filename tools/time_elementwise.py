@@ -1,6 +1,8 @@
 """Seconds per call / per outer iteration of the device-resident nonlinear constraint class at full size (n = 1e7, m = 128, one MI355X):
 c!, jac!, hess_diag!, tangent setup, and an `optimize` run (f = |x - target|^2) with the Newton and the ProjPenalty retraction.
-    python tools/time_elementwise.py [dense|sparse] > gpurun_out/elementwise_<kind>.json"""
+    python tools/time_elementwise.py [dense|sparse|stream|nostream] > gpurun_out/elementwise_<kind>.json
+dense: mixed kinds + the common quadratic term (materialised Jct: the rank-one term is not a row scaling); stream / nostream: the same system without
+the quadratic term, gradients streamed through a row-scaled view of A (the default for that class) / materialised, for the A/B."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,9 +10,15 @@ import lfpsqp_jl_amd as L
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from tests.test_gpu_fullsize import _ew_big
 
-sparse = len(sys.argv) > 1 and sys.argv[1] == "sparse"
+mode = sys.argv[1] if len(sys.argv) > 1 else "dense"
+sparse = mode == "sparse"
 ctx = L.Context(0)
-cons, n, m = _ew_big(ctx, sparse)
+if mode in ("stream", "nostream"):
+    from tests.test_gpu_fullsize import N as n, M as m
+    A = ctx.matrix(n, m).hash_fill(21, 0, n, 2.0 ** -11)
+    cons = L.ElementwiseConstraints(ctx, A, np.zeros(m), kind=(np.arange(n) % 3).astype(np.float64), stream=(mode == "stream"))
+else:
+    cons, n, m = _ew_big(ctx, sparse)
 x = ctx.vector(n).hash_fill(31, 0, 0.5, 0.0)
 cv = np.zeros(m)
 
@@ -24,7 +32,8 @@ def timed(fn, reps=5):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-out = {"n": n, "m": m, "A": "sparse, 4 nonzeros per row" if sparse else "dense", "device": ctx.device_name}
+out = {"n": n, "m": m, "A": "sparse, 4 nonzeros per row" if sparse else "dense", "mode": mode, "streamed_gradients": bool(getattr(cons, "streamed", False)),
+       "device": ctx.device_name}
 out["c_ms"] = timed(lambda: cons.c_(cv, x))
 out["jac_ms"] = timed(lambda: cons.jac_(cons.Jct, cv, x))
 hx = ctx.vector(n)
@@ -32,6 +41,7 @@ lam = np.cos(1.0 + np.arange(m))
 out["hess_diag_ms"] = timed(lambda: cons.hess_diag_(hx, x, lam))
 Z = ctx.matrix(n, m); W = np.zeros((m, m), order='F')
 out["tangent_setup_ms"] = timed(lambda: L.ksvd_(cons.Jct, Z, W=W, Jsp=cons.Jsp), 3)
+out["tangent_setup_factored_ms"] = timed(lambda: L.ksvd_(cons.Jct, None, W=W, Jsp=cons.Jsp), 3)
 # Newton retraction, 12 iterations forced by tol = 0 (flag 1): ms per iteration with and without the generator hint (Z = Jct W)
 Sg, Vtg, rank = L.ksvd_(cons.Jct, Z, W=W, Jsp=cons.Jsp)
 xt, xnew = ctx.vector(n), ctx.vector(n)
@@ -50,7 +60,7 @@ cons.jac_(cons.Jct, cv, x)
 cons.b = cons.b + cv                       # x feasible; the optimum of |x - target|^2 on the manifold lies nearby
 target = ctx.vector(n).hash_fill(41, 0, 0.5, 0.0)
 L.axpby(0.98, x, 0.02, target)
-for name, dpr in (("newton", False), ("projpenalty", True)):
+for name, dpr in (("newton", False), ("projpenalty", True), ("newton_warm", False), ("projpenalty_warm", True)):
     prob = L.SeparableElementwiseBox(ctx, cons, 0, 1.0, target.download())
     tr = []
     t0 = time.perf_counter()
