@@ -122,16 +122,20 @@ int lfpsqp_mat_shape(const lfpsqp_mat* M, int64_t* n, int64_t* m);
 int lfpsqp_mat_upload(lfpsqp_ctx* ctx, lfpsqp_mat* M, int64_t col0, int64_t ncols, const double* host, int64_t ldh);
 int lfpsqp_mat_download(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t col0, int64_t ncols, double* host, int64_t ldh);
 int lfpsqp_mat_copy(lfpsqp_ctx* ctx, lfpsqp_mat* dst, const lfpsqp_mat* src);
-/* A row-scaled VIEW of A: the n x m matrix diag(rs) * A without a copy (A's storage and the vector rs are borrowed; both must outlive the
- * view; lfpsqp_mat_free releases the view only).  What it is for: constraint gradients of the form Jct(x) = diag(phi'(x)) A -- the reference's
- * jac! (src/autodiff_generators.jl:60-66, entry src/optimize.jl:284) rewrites the whole n x m matrix at every outer iteration and at every
- * iteration of the ProjPenalty retraction; with a view it rewrites the n-vector rs and every solver streams the constant A (lfpsqp_elementwise
- * with Jct = view of its own A: "streamed gradients").  A view is accepted wherever a matrix is only READ through the library's product
- * kernels: lfpsqp_gemv_t / _n, lfpsqp_gram, lfpsqp_rmul (input), lfpsqp_factorize (Jct), lfpsqp_basis.Z / .A (lfpsqp_q_gemv_*, lfpsqp_projcg,
- * lfpsqp_pcg, lfpsqp_pcg_pre), lfpsqp_constraints.Jct (lfpsqp_constraints_*, lfpsqp_retract_nr, lfpsqp_retract_pp; no ball column, no sparse
- * twin), lfpsqp_calculate_lambda_y, and as the source of lfpsqp_mat_copy (which materialises it).  Everything that writes a matrix or reads its
- * storage directly (upload / download / hash_fill, outputs, sparse twins, the batched Newton retraction -- width 0) refuses a view
- * (LFPSQP_ERR_ARG).  Cost per pass: 8 bytes per row next to 8 m. */
+/* A VIEW of A: the n x m matrix  diag(rs) * A + u w'  without a copy (rs, u: n-vectors, w: a device m-vector; rs == NULL: no scaling,
+ * u == w == NULL: no rank-one term; A's storage and the vectors are borrowed and must outlive the view; lfpsqp_mat_free releases the view
+ * only).  What it is for: constraint gradients of the form Jct(x) = diag(phi'(x)) A + 2 x qw' -- the reference's jac!
+ * (src/autodiff_generators.jl:60-66, entry src/optimize.jl:284) rewrites the whole n x m matrix at every outer iteration and at every
+ * iteration of the ProjPenalty retraction; with a view it rewrites one or two n-vectors and every solver streams the constant A
+ * (lfpsqp_elementwise with Jct = a view of its own A: "streamed gradients").  A view is accepted wherever a matrix is only READ through the
+ * library's product kernels: lfpsqp_gemv_t / _n, lfpsqp_gram, lfpsqp_rmul (input), lfpsqp_factorize (Jct), lfpsqp_basis.Z / .A
+ * (lfpsqp_q_gemv_*, lfpsqp_projcg, lfpsqp_pcg, lfpsqp_pcg_pre), lfpsqp_constraints.Jct (lfpsqp_constraints_*, lfpsqp_retract_nr,
+ * lfpsqp_retract_pp; no ball column, no sparse twin), lfpsqp_calculate_lambda_y, and as the source of lfpsqp_mat_copy (which materialises
+ * it).  Everything that writes a matrix or reads its storage directly (upload / download / hash_fill, outputs, sparse twins, the batched
+ * Newton retraction -- width 0) refuses a view (LFPSQP_ERR_ARG).  Cost per pass: 8 or 16 bytes per row next to 8 m, and (rank-one term)
+ * two one-workgroup launches around the kernel: w't ahead of a first product, the fold of w (u'v) into the column sums behind a second. */
+int lfpsqp_mat_view(lfpsqp_ctx* ctx, const lfpsqp_mat* A, const lfpsqp_vec* rs, const lfpsqp_vec* u, const lfpsqp_vec* w, lfpsqp_mat** out);
+/* = lfpsqp_mat_view(ctx, A, rs, NULL, NULL, out) */
 int lfpsqp_mat_rowscaled_view(lfpsqp_ctx* ctx, const lfpsqp_mat* A, const lfpsqp_vec* rs, lfpsqp_mat** out);
 /* ---- placement-tuned allocation (FINDINGS.md 6) ---------------------------------------------------------------------------------------
  * On MI355X the kernels that run a small store stream inside a matrix read stream -- the fused projected-CG iteration (src/projcg.jl:93-97),
@@ -428,9 +432,10 @@ int lfpsqp_ctx_stream(lfpsqp_ctx* ctx, void** stream);
  * lfpsqp_constraints (lfpsqp_constraints_eval / _jac, lfpsqp_retract_nr, lfpsqp_retract_pp) honours `ew`; c! streams A
  * (or its nonzeros) once with phi applied on the fly -- nothing n-sized crosses PCIe.
  *   A    : constant n x m_lin coefficients (may be NULL when Asp is given).  lfpsqp_constraints.Jct is a DIFFERENT matrix
- *          (>= m_lin columns) -- or, STREAMED gradients, a row-scaled view of A itself (lfpsqp_mat_rowscaled_view(A, rs)): then Jct(x) is never
- *          written, lfpsqp_constraints_jac refreshes rs = phi'(x) (one n-vector instead of n x m_lin doubles) and the tangent setup, projcg!,
- *          both retractions and the multiplier products stream A with the scale applied in registers.  Needs qw == NULL, no ball, dense A.
+ *          (>= m_lin columns) -- or, STREAMED gradients, a view of A itself: lfpsqp_mat_view(A, rs, u, w) with rs given iff kind != NULL and
+ *          u, w given iff qw != NULL (w holding qw on the device).  Then Jct(x) is never written: lfpsqp_constraints_jac refreshes
+ *          rs = phi'(x) and u = 2 x [i < n_x] (n-vectors instead of n x m_lin doubles) and the tangent setup, projcg!, both retractions and the
+ *          multiplier products stream A with the scale and the rank-one term applied in registers.  Needs a dense A and no ball.
  *   Asp  : optional sparse form of A (same entries).  lfpsqp_constraints.Jsp must then be a structural clone
  *          (lfpsqp_spmat_clone): lfpsqp_constraints_jac rescales its values and expands it into Jct[:, 0:m_lin).
  *          With Asp, qw must be NULL (the rank-one term would make the gradients dense) and `work` is required.

@@ -163,6 +163,7 @@ c_mat_upload(ctx, M, col0, ncols, host, ldh) = ccall((:lfpsqp_mat_upload, lib), 
 c_mat_download(ctx, M, col0, ncols, host, ldh) = ccall((:lfpsqp_mat_download, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Int64), ctx, M, col0, ncols, host, ldh)
 c_mat_copy(ctx, dst, src) = ccall((:lfpsqp_mat_copy, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, dst, src)
 c_mat_rowscaled_view(ctx, A, rs, out) = ccall((:lfpsqp_mat_rowscaled_view, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx, A, rs, out)
+c_mat_view(ctx, A, rs, u, w, out) = ccall((:lfpsqp_mat_view, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx, A, rs, u, w, out)
 c_mat_hash_fill(ctx, M, seed, row0, nglob, scale, nrows, ncols) = ccall((:lfpsqp_mat_hash_fill, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Int64, Int64, Float64, Int64, Int64), ctx, M, seed, row0, nglob, scale, nrows, ncols)
 # ---- BLAS-1/2 ------------------------------------------------------------------------------------------------------------
 c_gemv_t(ctx, M, ncols, v, t) = ccall((:lfpsqp_gemv_t, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}), ctx, M, ncols, v, t)
@@ -358,9 +359,18 @@ function DeviceMatrix(ctx::HipContext, n::Integer, m::Integer; placed::Bool=fals
     return M
 end
 Base.size(M::DeviceMatrix) = (M.n, M.m)
-# Diagonal(rs) * A without a copy (lfpsqp_mat_rowscaled_view): accepted wherever the library only reads a matrix through its product kernels;
-# `keep` pins the borrowed storage and scale vector for the view's lifetime
+# Diagonal(rs) * A + u * w' without a copy (lfpsqp_mat_view; any part may be nothing): accepted wherever the library only reads a matrix through
+# its product kernels; VIEW_KEEP pins the borrowed storage and vectors for the view's lifetime
 const VIEW_KEEP = IdDict{Any,Any}()
+function matrix_view(A::DeviceMatrix; rs::Union{Nothing,DeviceVector}=nothing, u::Union{Nothing,DeviceVector}=nothing, w::Union{Nothing,DeviceVector}=nothing)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    hp(x) = x === nothing ? C_NULL : x.h
+    check(A.ctx, c_mat_view(A.ctx.h, A.h, hp(rs), hp(u), hp(w), r))
+    V = DeviceMatrix(A.ctx, r[], A.n, A.m)
+    VIEW_KEEP[V] = (A, rs, u, w)
+    finalizer(x -> (c_mat_free(x.ctx.h, x.h); delete!(VIEW_KEEP, x)), V)
+    return V
+end
 function rowscaled_view(A::DeviceMatrix, rs::DeviceVector)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(A.ctx, c_mat_rowscaled_view(A.ctx.h, A.h, rs.h, r))
@@ -687,17 +697,18 @@ mutable struct Elementwise
     work::Union{Nothing,DeviceVector}
     cref::Base.RefValue{CElementwise}
 end
-# stream (dense A, no qw; default: whenever the one-pass kernels cover the shape): Jct is a row-scaled VIEW of A -- jac! refreshes the n-vector phi'(x)
-# instead of rewriting an n x m matrix, every solver streams the constant A
+# stream (dense A with a kind and / or qw; default: whenever the one-pass kernels cover the shape): Jct is a VIEW Diagonal(phi'(x)) A + 2 x qw' of A -- jac!
+# refreshes the n-vectors phi'(x) and 2 x instead of rewriting an n x m matrix, every solver streams the constant A
 function ElementwiseConstraints(ctx::HipContext, A::Union{DeviceMatrix,SparseMatrix}, b::Vector{Float64};
                                 kind::Union{Nothing,Vector{Float64}}=nothing, qw::Union{Nothing,Vector{Float64}}=nothing,
                                 stream::Union{Nothing,Bool}=nothing)
     n, m = A.n, A.m
     sparse = A isa SparseMatrix
-    can_stream = !sparse && qw === nothing && m >= 1
-    stream === true && !can_stream && throw(ArgumentError("streamed gradients need a dense A and no quadratic term"))
+    can_stream = !sparse && (kind !== nothing || qw !== nothing) && m >= 1
+    stream === true && !can_stream && throw(ArgumentError("streamed gradients need a dense A with a kind or a quadratic term"))
     streamed = stream === nothing ? (can_stream && factored_basis_supported(ctx, A)) : stream
-    Jct = streamed ? rowscaled_view(A, fill!(DeviceVector(ctx, n), 1.0)) : DeviceMatrix(ctx, n, m)
+    Jct = streamed ? matrix_view(A; rs=(kind === nothing ? nothing : fill!(DeviceVector(ctx, n), 1.0)), u=(qw === nothing ? nothing : DeviceVector(ctx, n)),
+                                 w=(qw === nothing ? nothing : upload!(DeviceVector(ctx, m), qw))) : DeviceMatrix(ctx, n, m)
     Jsp = sparse ? clone(A) : nothing
     kd = kind === nothing ? nothing : upload!(DeviceVector(ctx, n), kind)
     work = sparse ? DeviceVector(ctx, n) : nothing

@@ -60,6 +60,13 @@ int ensure_nvec(lfpsqp_ctx* ctx, size_t doubles) {
     return 0;
 }
 
+int ensure_view(lfpsqp_ctx* ctx) {
+    if (ctx->d_view) return 0;
+    LF_HIP(ctx, hipMalloc((void**)&ctx->d_view, sizeof(double) * kViewScratch));
+    LF_HIP(ctx, hipMemsetAsync(ctx->d_view, 0, sizeof(double) * kViewScratch, ctx->stream));
+    return 0;
+}
+
 namespace {
 struct Roctx {
     int (*push)(const char*) = nullptr;
@@ -344,19 +351,22 @@ inline void dev_free(void* p) { (void)hipFree(p); }
 }  // namespace
 #endif
 
-// dst[:, j] = rs .* src[:, j]: the matrix a row-scaled view stands for (lfpsqp_mat_copy of a view; 16 columns per block row)
-__global__ __launch_bounds__(lfpsqp::kThreads) void rowscaled_copy_kernel(const double* __restrict__ A, const double* __restrict__ rs, double* __restrict__ D,
-                                                                          int64_t ld, int64_t n, int m) {
+// dst[:, j] = rs .* src[:, j] + u w_j: the matrix a view stands for (lfpsqp_mat_copy of a view; 16 columns per block row)
+__global__ __launch_bounds__(lfpsqp::kThreads) void view_copy_kernel(const double* __restrict__ A, const double* __restrict__ rs, const double* __restrict__ u,
+                                                                     const double* __restrict__ w, double* __restrict__ D, int64_t ld, int64_t n, int m) {
     const int64_t i = ((int64_t)blockIdx.x * lfpsqp::kThreads + threadIdx.x) * 2;
     if (i >= n) return;
-    const double2 s = lfpsqp::ld2(rs + i);
+    const double2 s = rs ? lfpsqp::ld2(rs + i) : make_double2(1.0, 1.0);
+    const double2 uu = u ? lfpsqp::ld2(u + i) : make_double2(0.0, 0.0);
     const bool v1 = i + 1 < n;
     const int j0 = blockIdx.y * 16, j1 = (j0 + 16 < m) ? j0 + 16 : m;
 #pragma unroll 4
     for (int j = j0; j < j1; ++j) {
         const double2 c = lfpsqp::ld2(A + (int64_t)j * ld + i);
-        if (v1) lfpsqp::st2(D + (int64_t)j * ld + i, make_double2(s.x * c.x, s.y * c.y));
-        else D[(int64_t)j * ld + i] = s.x * c.x;
+        const double wj = u ? w[j] : 0.0;
+        const double2 o = make_double2(fma(uu.x, wj, s.x * c.x), fma(uu.y, wj, s.y * c.y));
+        if (v1) lfpsqp::st2(D + (int64_t)j * ld + i, o);
+        else D[(int64_t)j * ld + i] = o.x;
     }
 }
 
@@ -418,6 +428,7 @@ int lfpsqp_ctx_destroy(lfpsqp_ctx* ctx) {
     if (ctx->d_qw) (void)hipFree(ctx->d_qw);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->d_nvec) (void)hipFree(ctx->d_nvec);
+    if (ctx->d_view) (void)hipFree(ctx->d_view);
     if (ctx->h_m) (void)hipHostFree(ctx->h_m);
     if (ctx->scal) (void)hipFree(ctx->scal);
     if (ctx->istat) (void)hipFree(ctx->istat);
@@ -999,14 +1010,22 @@ int lfpsqp_mat_free(lfpsqp_ctx* ctx, lfpsqp_mat* M) {
     return 0;
 }
 
-int lfpsqp_mat_rowscaled_view(lfpsqp_ctx* ctx, const lfpsqp_mat* A, const lfpsqp_vec* rs, lfpsqp_mat** out) {
-    LF_ARG(ctx, ctx && A && rs && out && plain_mat(A) && rs->n >= A->n);
+int lfpsqp_mat_view(lfpsqp_ctx* ctx, const lfpsqp_mat* A, const lfpsqp_vec* rs, const lfpsqp_vec* u, const lfpsqp_vec* w, lfpsqp_mat** out) {
+    LF_ARG(ctx, ctx && A && out && plain_mat(A) && (rs || u) && (!rs || rs->n >= A->n) && ((u == nullptr) == (w == nullptr)) &&
+                    (!u || (u->n >= A->n && w->n >= A->m)));
     lfpsqp_mat* V = new (std::nothrow) lfpsqp_mat(*A);
     if (!V) return set_err(ctx, LFPSQP_ERR_HIP, "out of host memory");
-    V->rs = rs->p;
+    V->rs = rs ? rs->p : nullptr;
+    V->ru = u ? u->p : nullptr;
+    V->rw = w ? w->p : nullptr;
     V->view = true;
     *out = V;
     return 0;
+}
+
+int lfpsqp_mat_rowscaled_view(lfpsqp_ctx* ctx, const lfpsqp_mat* A, const lfpsqp_vec* rs, lfpsqp_mat** out) {
+    LF_ARG(ctx, ctx && rs);
+    return lfpsqp_mat_view(ctx, A, rs, nullptr, nullptr, out);
 }
 
 int lfpsqp_mat_shape(const lfpsqp_mat* M, int64_t* n, int64_t* m) {
@@ -1036,11 +1055,11 @@ int lfpsqp_mat_download(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t col0, int6
 
 int lfpsqp_mat_copy(lfpsqp_ctx* ctx, lfpsqp_mat* dst, const lfpsqp_mat* src) {
     LF_ARG(ctx, ctx && plain_mat(dst) && src && dst->n == src->n && dst->m == src->m && dst->ld == src->ld);
-    if (src->rs) {                                 // the copy of a row-scaled view is the matrix it stands for: dst = diag(rs) * src
+    if (src->view) {                               // the copy of a view is the matrix it stands for: dst = diag(rs) * src + u w'
         LF_ARG(ctx, dst->p != src->p);
         if (src->n == 0 || src->m == 0) return 0;
-        hipLaunchKernelGGL(rowscaled_copy_kernel, dim3((unsigned)((src->n + 2 * kThreads - 1) / (2 * kThreads)), (unsigned)((src->m + 15) / 16)), dim3(kThreads), 0,
-                           ctx->stream, src->p, src->rs, dst->p, src->ld, src->n, (int)src->m);
+        hipLaunchKernelGGL(view_copy_kernel, dim3((unsigned)((src->n + 2 * kThreads - 1) / (2 * kThreads)), (unsigned)((src->m + 15) / 16)), dim3(kThreads), 0,
+                           ctx->stream, src->p, src->rs, src->ru, src->rw, dst->p, src->ld, src->n, (int)src->m);
         LF_LAUNCH_CHECK(ctx);
         return 0;
     }

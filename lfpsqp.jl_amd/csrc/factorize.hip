@@ -457,15 +457,59 @@ struct ViewWeightF {
     }
 };
 
+// rank-one term of a view's Gram matrix: the producer rs .* w2 .* u of z = A'(D W2 u), and u' W2 u
+struct ViewRank1V {
+    const double *rs, *w2, *u;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        double2 a = ld2(u + r);
+        if (rs) { const double2 s = ld2(rs + r); a.x *= s.x; a.y *= s.y; }
+        if (w2) { const double2 w = ld2(w2 + r); a.x *= w.x; a.y *= w.y; }
+        return make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0);
+    }
+};
+struct ViewRank1DotF {
+    const double *w2, *u;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        const double2 a = ld2(u + i);
+        const double2 w = w2 ? ld2(w2 + i) : make_double2(1.0, 1.0);
+        double s = 0.0;
+        if (v0) s = fma(a.x * w.x, a.x, s);
+        if (v1) s = fma(a.y * w.y, a.y, s);
+        red[0] += s;
+    }
+};
+
 static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const double* w2, std::vector<double>& G) {
     G.assign((size_t)ncols_all * ncols_all, 0.0);
     if (ncols_all == 0) return 0;
-    if (M->rs) {       // (diag(rs) M)' diag(w2) (diag(rs) M) = M' diag(rs^2 w2) M: the weighted kernel over the plain storage
-        LF_TRY(ensure_nvec(ctx, (size_t)M->n));
-        LF_TRY((run_vec<ViewWeightF, 0, NoPost>(ctx, M->n, ViewWeightF{M->rs, w2, ctx->d_nvec}, 0u, nullptr, NoPost())));
-        lfpsqp_mat plain = *M;
-        plain.rs = nullptr;
-        return gram_impl(ctx, &plain, ncols_all, ctx->d_nvec, G);
+    if (M->view) {
+        // V = D A + u w' (D = diag(rs)):  V' W2 V = A' (D W2 D) A + z w' + w z' + (u' W2 u) w w',  z = A' (D W2 u)
+        // -- the weighted kernel over the plain storage, one GEMV-T and one dot product for the rank-one term, assembled on the host
+        const lfpsqp_mat plain = M->plain();
+        const double* wts = w2;
+        if (M->rs) {
+            LF_TRY(ensure_nvec(ctx, (size_t)M->n));
+            LF_TRY((run_vec<ViewWeightF, 0, NoPost>(ctx, M->n, ViewWeightF{M->rs, w2, ctx->d_nvec}, 0u, nullptr, NoPost())));
+            wts = ctx->d_nvec;
+        }
+        LF_TRY(gram_impl(ctx, &plain, ncols_all, wts, G));
+        if (!M->ru) return 0;
+        const int mm = ncols_all;
+        LF_TRY(ensure_mvec(ctx, (size_t)2 * mm + 16));
+        double* dz = ctx->d_m;                                   // [z (mm) ; u' W2 u ; w (mm)] -> host
+        LF_TRY(run_gemv_t(ctx, &plain, mm, M->n, ViewRank1V{M->rs, w2, M->ru}, dz));
+        LF_TRY((run_vec<ViewRank1DotF, 1, NoPost>(ctx, M->n, ViewRank1DotF{w2, M->ru}, 0u, dz + mm, NoPost())));
+        LF_HIP(ctx, hipMemcpyAsync(dz + mm + 1, M->rw, sizeof(double) * mm, hipMemcpyDeviceToDevice, ctx->stream));
+        LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, dz, sizeof(double) * (2 * mm + 1), hipMemcpyDeviceToHost, ctx->stream));
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double* z = ctx->h_m;
+        const double uu = ctx->h_m[mm];
+        const double* w = ctx->h_m + mm + 1;
+        for (int jj = 0; jj < mm; ++jj)
+            for (int ii = 0; ii < mm; ++ii) G[(size_t)jj * mm + ii] += z[ii] * w[jj] + w[ii] * z[jj] + uu * w[ii] * w[jj];
+        return 0;
     }
     // A few columns beyond a multiple of the 128-column panel (m + 1 constraints with a slack/ball column, say) would cost
     // a whole extra panel row and column of MFMA tiles; they are cheaper as GEMV-T passes: G[:, j] = M' (w2 .* M[:, j]).
@@ -558,31 +602,49 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     return 0;
 }
 
-// Out[:, :rcols] = diag(rs) * Out[:, :rcols] in place (the product of a row-scaled view: the MFMA kernels ran over the plain storage)
-__global__ __launch_bounds__(kThreads) void scale_rows_kernel(double* D, int64_t ld, int64_t n, int m, const double* __restrict__ rs) {
+// Out[:, j] = rs .* Out[:, j] + u c_j in place, j < m (the product of a view: the MFMA kernels ran over the plain storage; c = W'w)
+__global__ __launch_bounds__(kThreads) void view_rows_kernel(double* D, int64_t ld, int64_t n, int m, const double* __restrict__ rs, const double* __restrict__ u,
+                                                             const double* __restrict__ c) {
     const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 2;
     if (i >= n) return;
-    const double2 s = ld2(rs + i);
+    const double2 s = rs ? ld2(rs + i) : make_double2(1.0, 1.0);
+    const double2 uu = u ? ld2(u + i) : make_double2(0.0, 0.0);
     const bool v1 = i + 1 < n;
     const int j0 = blockIdx.y * 16, j1 = (j0 + 16 < m) ? j0 + 16 : m;
 #pragma unroll 4
     for (int j = j0; j < j1; ++j) {
-        const double2 c = ld2(D + (int64_t)j * ld + i);
-        if (v1) st2(D + (int64_t)j * ld + i, make_double2(s.x * c.x, s.y * c.y));
-        else D[(int64_t)j * ld + i] = s.x * c.x;
+        const double2 a = ld2(D + (int64_t)j * ld + i);
+        const double cj = u ? c[j] : 0.0;
+        const double2 o = make_double2(fma(uu.x, cj, s.x * a.x), fma(uu.y, cj, s.y * a.y));
+        if (v1) st2(D + (int64_t)j * ld + i, o);
+        else D[(int64_t)j * ld + i] = o.x;
     }
 }
 
 static int rmul_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int kcols, const double* W_host, int rcols, lfpsqp_mat* Out) {
     if (rcols == 0 || In->n == 0) return 0;
-    if (In->rs) {      // (diag(rs) In) W = diag(rs) (In W): a second pass over the output -- this product is off the fast path (the basis of a view
-                       // stays in factored form; only the refinement rounds of an ill-conditioned block and callers that insist on Z come here)
-        lfpsqp_mat plain = *In;
-        plain.rs = nullptr;
+    if (In->view) {    // (D In + u w') W = D (In W) + u (W'w)': a second pass over the output -- this product is off the fast path (the basis of a
+                       // view stays in factored form; only the refinement rounds of an ill-conditioned block and callers that insist on Z come here)
+        const lfpsqp_mat plain = In->plain();
         LF_TRY(rmul_impl(ctx, &plain, kcols, W_host, rcols, Out));
-        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((In->n + 2 * kThreads - 1) / (2 * kThreads)), (unsigned)((rcols + 15) / 16)), dim3(kThreads), 0,
-                           ctx->stream, Out->p, Out->ld, In->n, rcols, In->rs);
+        double* dc = nullptr;
+        if (In->ru) {
+            LF_TRY(ensure_mvec(ctx, (size_t)kcols + rcols + 16));
+            LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, In->rw, sizeof(double) * kcols, hipMemcpyDeviceToHost, ctx->stream));
+            LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            double* hc = ctx->h_m + kcols + (kcols & 1);
+            for (int j = 0; j < rcols; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < kcols; ++k) acc += W_host[(size_t)j * kcols + k] * ctx->h_m[k];
+                hc[j] = acc;
+            }
+            dc = ctx->d_m + kcols + (kcols & 1);
+            LF_HIP(ctx, hipMemcpyAsync(dc, hc, sizeof(double) * rcols, hipMemcpyHostToDevice, ctx->stream));
+        }
+        hipLaunchKernelGGL(view_rows_kernel, dim3((unsigned)((In->n + 2 * kThreads - 1) / (2 * kThreads)), (unsigned)((rcols + 15) / 16)), dim3(kThreads), 0,
+                           ctx->stream, Out->p, Out->ld, In->n, rcols, In->rs, In->ru, dc);
         LF_LAUNCH_CHECK(ctx);
+        if (dc) LF_HIP(ctx, hipStreamSynchronize(ctx->stream));      // (h_m is the context's shared pinned staging block)
         return 0;
     }
     LF_TRY(ensure_small(ctx, (size_t)kcols * rcols + 32 + ((size_t)kcols + kKStep) * ((size_t)rcols + kPanel)));

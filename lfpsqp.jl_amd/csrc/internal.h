@@ -26,11 +26,14 @@ struct lfpsqp_mat {
     double* p = nullptr;
     int64_t n = 0, m = 0;
     int64_t ld = 0;  // rows rounded up to whole tiles; padding rows are zero and never written
-    // row-scaled view (lfpsqp_mat_rowscaled_view): the matrix is diag(rs) * [p]; p belongs to another lfpsqp_mat, rs to an lfpsqp_vec.
-    // Honoured by the launch helpers run_gemv_t / run_gemv_n / run_gemv_nt / run_onepass and by the Gram kernels; every other consumer
-    // of a matrix refuses a view (plain_mat()).
+    // VIEW (lfpsqp_mat_view): the matrix is diag(rs) * [p] + ru rw'; p belongs to another lfpsqp_mat, rs / ru (n) and rw (m) to lfpsqp_vecs;
+    // rs == nullptr: no scaling, ru == rw == nullptr: no rank-one term.  Honoured by the launch helpers run_gemv_t / run_gemv_n / run_gemv_nt /
+    // run_onepass and by the Gram / basis-forming products; every other consumer of a matrix refuses a view (plain_mat()).
     const double* rs = nullptr;
+    const double* ru = nullptr;
+    const double* rw = nullptr;
     bool view = false;
+    lfpsqp_mat plain() const { lfpsqp_mat q = *this; q.rs = q.ru = q.rw = nullptr; q.view = false; return q; }
 };
 
 namespace lfpsqp {
@@ -81,6 +84,7 @@ struct lfpsqp_ctx {
     double* h_m = nullptr;
     size_t m_cap = 0;
     // the weights of lfpsqp_elementwise's quadratic term (device, m_lin)
+    double* d_view = nullptr;        // matrix views: [tau (8) | the raw sums of a second product before the rank-one term is folded in]
     double* d_nvec = nullptr;        // an n-vector of scratch (combined weights of the Gram matrix of a row-scaled view)
     size_t nvec_cap = 0;
     double* d_zeros = nullptr;       // kOnepassMaxCols zeros (the first-product coefficients of a one-pass launch that only evaluates)
@@ -147,6 +151,9 @@ int ensure_part(lfpsqp_ctx* ctx, size_t doubles);
 int ensure_small(lfpsqp_ctx* ctx, size_t doubles);
 int ensure_mvec(lfpsqp_ctx* ctx, size_t doubles);   // d_m / h_m, each `doubles` long
 int ensure_nvec(lfpsqp_ctx* ctx, size_t doubles);   // d_nvec (padded to whole tiles)
+int ensure_view(lfpsqp_ctx* ctx);                   // d_view (kViewScratch doubles)
+constexpr int kViewTau = 8;                          // doubles reserved for tau at the head of d_view
+constexpr int kViewScratch = kViewTau + 4 * 1024 + 64;
 int allreduce_dev(lfpsqp_ctx* ctx, double* buf, int64_t count, int op = 0);  // in place, stream ordered; op 0 sum / 1 max; no-op for 1 rank
 
 // profiling helpers: bracket one launch of slot `s`
@@ -217,16 +224,25 @@ int launch_reduce(lfpsqp_ctx* ctx, int64_t nrows, int ncols, int part_ld, unsign
 template <class VP>
 int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp, double* t_out, int prof_slot = -1) {
     if constexpr (!is_rowscaled<VP>::value) {
-        if (M && M->rs) {                          // a row-scaled view: the same kernel over the plain storage, producer scaled (kernels.h)
-            lfpsqp_mat plain = *M;
-            plain.rs = nullptr;
-            return run_gemv_t(ctx, &plain, ncols, n, RsLoadV<VP>{vp, M->rs}, t_out, prof_slot);
+        if (M && M->view) {                        // a view: the same kernel over the plain storage, producer wrapped (kernels.h)
+            const lfpsqp_mat plain = M->plain();
+            const RsLoadV<VP> wv{vp, ViewD{M->rs, M->ru, nullptr}};
+            if (!M->ru) return run_gemv_t(ctx, &plain, ncols, n, wv, t_out, prof_slot);
+            if (ncols + 1 > kViewScratch - kViewTau) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "matrix view with a rank-one term: too many columns");
+            LF_TRY(ensure_view(ctx));
+            double* raw = ctx->d_view + kViewTau;  // [M'(rs .* v) (ncols) ; u'v]
+            LF_TRY(run_gemv_t(ctx, &plain, ncols, n, wv, raw, prof_slot));
+            hipLaunchKernelGGL((view_fold_kernel<0>), dim3(1), dim3(256), 0, ctx->stream, raw, t_out, M->rw, 1, ncols, 0);
+            LF_LAUNCH_CHECK(ctx);
+            return 0;
         }
     }
     ++ctx->launch_epoch;
     const int ks = ctx->ks_for(n);
     const int64_t tiles = ntiles_of(n, ks);
-    const int part_ld = (int)round_up(ncols > 0 ? ncols : 1, 32);
+    int xcol = 0;                                  // a view's rank-one term: one more (virtual) column, sum_i u_i v_i
+    if constexpr (is_rowscaled<VP>::value) xcol = vp.vw.u ? 1 : 0;
+    const int part_ld = (int)round_up(ncols + xcol > 0 ? ncols + xcol : 1, 32);
     if (tiles > 0) {
         LF_TRY(ensure_part(ctx, (size_t)tiles * part_ld + reduce_scratch(part_ld)));
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);
@@ -241,10 +257,10 @@ int run_gemv_t(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, VP vp
         if (prof_slot >= 0) prof_end(ctx, prof_slot);
         LF_LAUNCH_CHECK(ctx);
     }
-    if (ncols == 0) return 0;
-    if (tiles > 0) LF_TRY(launch_reduce(ctx, tiles, ncols, part_ld, 0u, t_out, NoPost()));
-    else LF_HIP(ctx, hipMemsetAsync(t_out, 0, sizeof(double) * ncols, ctx->stream));
-    return allreduce_dev(ctx, t_out, ncols);
+    if (ncols + xcol == 0) return 0;
+    if (tiles > 0) LF_TRY(launch_reduce(ctx, tiles, ncols + xcol, part_ld, 0u, t_out, NoPost()));
+    else LF_HIP(ctx, hipMemsetAsync(t_out, 0, sizeof(double) * (ncols + xcol), ctx->stream));
+    return allreduce_dev(ctx, t_out, ncols + xcol);
 }
 
 // fused y-side consumer of M[:, :ncols] * t; reductions (NRED sums) land in red_out (global)
@@ -253,10 +269,14 @@ template <class EP, int NRED, class POST>
 int run_gemv_n(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, int64_t n, const double* t, EP ep, double* red_out, POST post,
                int prof_slot = -1) {
     if constexpr (!is_rowscaled<EP>::value) {
-        if (M && M->rs) {
-            lfpsqp_mat plain = *M;
-            plain.rs = nullptr;
-            return run_gemv_n<RsApplyE<EP>, NRED, POST>(ctx, &plain, ncols, n, t, RsApplyE<EP>{ep, M->rs}, red_out, post, prof_slot);
+        if (M && M->view) {
+            const lfpsqp_mat plain = M->plain();
+            if (M->ru) {                           // tau = w't ahead of the launch
+                LF_TRY(ensure_view(ctx));
+                hipLaunchKernelGGL((view_tau_kernel<0>), dim3(1), dim3(256), 0, ctx->stream, M->rw, t, ncols, ctx->d_view);
+                LF_LAUNCH_CHECK(ctx);
+            }
+            return run_gemv_n<RsApplyE<EP>, NRED, POST>(ctx, &plain, ncols, n, t, RsApplyE<EP>{ep, ViewD{M->rs, M->ru, ctx->d_view}}, red_out, post, prof_slot);
         }
     }
     ++ctx->launch_epoch;
@@ -299,12 +319,24 @@ template <class EP, int NRED>
 int run_gemv_nt(lfpsqp_ctx* ctx, const lfpsqp_mat* M1, int n1, const double* t, const lfpsqp_mat* M2, int n2, int64_t n, EP ep,
                 double* out) {
     if constexpr (!is_rowscaled<EP>::value) {
-        if ((M1 && M1->rs) || (M2 && M2->rs)) {
+        const bool w1 = M1 && M1->view, w2 = M2 && M2->view;
+        if (w1 || w2) {
             lfpsqp_mat p1, p2;
-            if (M1) { p1 = *M1; p1.rs = nullptr; }
-            if (M2) { p2 = *M2; p2.rs = nullptr; }
-            return run_gemv_nt<RsStepE<EP>, NRED>(ctx, M1 ? &p1 : nullptr, n1, t, M2 ? &p2 : nullptr, n2, n,
-                                                  RsStepE<EP>{ep, M1 ? M1->rs : nullptr, M2 ? M2->rs : nullptr}, out);
+            if (M1) p1 = M1->plain();
+            if (M2) p2 = M2->plain();
+            if (n2 + NRED + 1 > kViewScratch - kViewTau) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "matrix view: too many columns");
+            LF_TRY(ensure_view(ctx));
+            if (w1 && M1->ru) {
+                hipLaunchKernelGGL((view_tau_kernel<0>), dim3(1), dim3(256), 0, ctx->stream, M1->rw, t, n1, ctx->d_view);
+                LF_LAUNCH_CHECK(ctx);
+            }
+            const RsStepE<EP, NRED> we{ep, w1 ? ViewD{M1->rs, M1->ru, ctx->d_view} : ViewD{nullptr, nullptr, nullptr},
+                                       w2 ? ViewD{M2->rs, M2->ru, nullptr} : ViewD{nullptr, nullptr, nullptr}, w1, w2};
+            double* raw = ctx->d_view + kViewTau;  // [M2'(rs2 .* v) (n2) ; the functor's sums (NRED) ; u2'v]
+            LF_TRY((run_gemv_nt<RsStepE<EP, NRED>, NRED + 1>(ctx, M1 ? &p1 : nullptr, n1, t, M2 ? &p2 : nullptr, n2, n, we, raw)));
+            hipLaunchKernelGGL((view_fold_kernel<0>), dim3(1), dim3(256), 0, ctx->stream, raw, out, (w2 && M2->ru) ? M2->rw : nullptr, 1, n2, NRED);
+            LF_LAUNCH_CHECK(ctx);
+            return 0;
         }
     }
     ++ctx->launch_epoch;
@@ -331,7 +363,7 @@ int run_gemv_nt(lfpsqp_ctx* ctx, const lfpsqp_mat* M1, int n1, const double* t, 
 }
 
 // a matrix argument of a routine that reads or writes the storage directly: not a row-scaled view
-inline bool plain_mat(const lfpsqp_mat* M) { return M && !M->rs && !M->view; }
+inline bool plain_mat(const lfpsqp_mat* M) { return M && !M->view; }
 
 // One-stream N->T product over M (onepass_kernel): usable for this shape?  Returns the lane-group count CW (4) or 0.
 inline int onepass_cw(const lfpsqp_ctx* ctx, int ncN, int64_t ld, int64_t n) {
@@ -390,14 +422,26 @@ template <class EP, int NV, int NRED, int NA = 1>
 int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t n, const double* t, const EP& ep, double* out,
                 int prof_slot = -1, int t_stride = 0, int wg_per_cu_cap = 0, bool discard_sums = false) {
     if constexpr (!is_rowscaled<EP>::value) {
-        if (M->rs) {                               // a row-scaled view: the same kernel over the plain storage, row functor wrapped (kernels.h)
-            if constexpr (no_rowscale<EP>::value) {
-                return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "this kernel does not take a row-scaled matrix view");
+        if (M->view) {                             // a view: the same kernel over the plain storage, row functor wrapped (kernels.h)
+            if constexpr (no_rowscale<EP>::value || NA != 1) {
+                return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "this kernel does not take a matrix view");
             } else {
-                lfpsqp_mat plain = *M;
-                plain.rs = nullptr;
-                return run_onepass<RsRowE<EP, NV, NA>, NV, NRED, NA>(ctx, &plain, ncN, ncT, n, t, RsRowE<EP, NV, NA>{ep, M->rs}, out, prof_slot, t_stride,
-                                                                     wg_per_cu_cap, discard_sums);
+                const lfpsqp_mat plain = M->plain();
+                const int nraw = NV * ncT + NRED + NV;
+                if (nraw > kViewScratch - kViewTau) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "matrix view: too many columns");
+                LF_TRY(ensure_view(ctx));
+                if (M->ru) {
+                    hipLaunchKernelGGL((view_tau_kernel<0>), dim3(1), dim3(256), 0, ctx->stream, M->rw, t, ncN, ctx->d_view);
+                    LF_LAUNCH_CHECK(ctx);
+                }
+                using WE = RsRowE<EP, NV, NRED>;
+                double* raw = ctx->d_view + kViewTau;   // [second products (NV x ncT) ; the functor's sums (NRED) ; u'v_q (NV)]
+                LF_TRY((run_onepass<WE, NV, NRED + NV, 1>(ctx, &plain, ncN, ncT, n, t, WE{ep, ViewD{M->rs, M->ru, ctx->d_view}}, raw, prof_slot, t_stride,
+                                                          wg_per_cu_cap, discard_sums)));
+                if (discard_sums) return 0;
+                hipLaunchKernelGGL((view_fold_kernel<0>), dim3(1), dim3(256), 0, ctx->stream, raw, out, M->ru ? M->rw : nullptr, NV, ncT, NRED);
+                LF_LAUNCH_CHECK(ctx);
+                return 0;
             }
         }
     }

@@ -138,6 +138,33 @@ __device__ __forceinline__ void block_reduce_store_split(double (&red)[NRL], dou
 }
 
 // ---------------------------------------------------------------------------
+// Matrix VIEWS (lfpsqp_mat::view, lfpsqp_mat_view): the matrix the solvers work with is
+//     diag(rs) * M + u w'          (rs, u: n-vectors; w: m-vector; each part optional)
+// with M constant -- the constraint gradients Jct(x) = diag(phi'(x)) A + 2 x qw' of the nonlinear class lfpsqp_elementwise, which then never
+// exist in memory (the reference's jac! rewrites the whole n x m matrix every outer iteration, src/autodiff_generators.jl:60-66; here it
+// rewrites rs and u).  The kernels stay as they are: the launch helpers (internal.h) wrap the row functor.  First products arrive as
+// rs_i (M t)_i + u_i (w't) with the scalar w't from a one-workgroup kernel ahead of the launch; second-product vectors leave scaled by rs,
+// and sum_i u_i v_i travels as one more reduction term, folded into the column sums (+ w_j times it) by a one-workgroup kernel behind the
+// launch.  Cost: 8 or 16 bytes per row next to 8 m, and two tiny launches.  Rows >= n carry zeros whatever the padding of rs / u holds.
+// ---------------------------------------------------------------------------
+template <class T, class = void>
+struct is_rowscaled : std::false_type {};
+template <class T>
+struct is_rowscaled<T, std::void_t<decltype(T::kRowScaled)>> : std::true_type {};
+// functors that refuse a view (the launch helper reports LFPSQP_ERR_UNSUPPORTED): EP::kNoRowScale
+template <class T, class = void>
+struct no_rowscale : std::false_type {};
+template <class T>
+struct no_rowscale<T, std::void_t<decltype(T::kNoRowScale)>> : std::true_type {};
+struct ViewD {
+    const double* rs;    // row scales or nullptr (= 1)
+    const double* u;     // rank-one term u w' or nullptr
+    const double* tau;   // device scalar w't of the launch's first product (u != nullptr)
+    __device__ __forceinline__ double2 s2(int64_t r) const { return rs ? *reinterpret_cast<const double2*>(rs + r) : make_double2(1.0, 1.0); }
+    __device__ __forceinline__ double2 u2(int64_t r) const { return u ? *reinterpret_cast<const double2*>(u + r) : make_double2(0.0, 0.0); }
+};
+
+// ---------------------------------------------------------------------------
 // GEMV-T: part[tile][j] = sum over the tile's rows of M[row, j] * v[row]
 //   VP::load(row, valid0, valid1) returns (v[row], v[row+1]) and may store fused
 //   side outputs; rows >= n must return 0 (the tile is padded, matrix padding is 0).
@@ -152,13 +179,24 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(const double* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row0 = (int64_t)blockIdx.x * (kSlabRows * kS) + (int64_t)threadIdx.x * 2;
     double2 v[kS];
+    double xsum = 0.0;                  // a view's rank-one term: this lane's part of sum_i u_i v_i -> part[tile][ncols]
 #pragma unroll
     for (int s = 0; s < kS; ++s) {
         const int64_t r = row0 + (int64_t)s * kSlabRows;
-        v[s] = vp.load(r, r < n, r + 1 < n);
+        if constexpr (is_rowscaled<VP>::value) v[s] = vp.load_view(r, r < n, r + 1 < n, xsum);
+        else v[s] = vp.load(r, r < n, r + 1 < n);
     }
     const double* base = M + row0;
     double* prow = part + (int64_t)blockIdx.x * part_ld;
+    if constexpr (is_rowscaled<VP>::value) {
+        if (vp.vw.u) {                  // (uniform)
+            xsum = wave_sum(xsum);
+            if (lane == 0) red[wave][0] = xsum;
+            __syncthreads();
+            if (threadIdx.x == 0) prow[ncols] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+            __syncthreads();
+        }
+    }
     for (int j0 = 0; j0 < ncols; j0 += kColChunk) {
         const int jn = (ncols - j0 < kColChunk) ? (ncols - j0) : kColChunk;
         for (int j = 0; j < jn; j += kTC) {
@@ -657,32 +695,18 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
     }
 }
 
-// ---------------------------------------------------------------------------
-// Row-scaled matrix views (lfpsqp_mat::rs, lfpsqp_mat_rowscaled_view): the matrix the solvers work with is diag(rs) * M with M constant
-// and rs an n-vector -- the constraint gradients diag(phi'(x)) A of the nonlinear class lfpsqp_elementwise, which then never exist in
-// memory (the reference's jac! rewrites the whole matrix every outer iteration, src/autodiff_generators.jl:60-66; here it rewrites rs).
-// The kernels stay as they are: the launch helpers wrap the row functor, which sees first products already scaled and whose second-product
-// vectors are scaled on the way out.  Cost: 8 bytes per row next to 8 * m.  Rows >= n carry zeros whatever the padding of rs holds.
-// ---------------------------------------------------------------------------
-template <class T, class = void>
-struct is_rowscaled : std::false_type {};
-template <class T>
-struct is_rowscaled<T, std::void_t<decltype(T::kRowScaled)>> : std::true_type {};
-// functors that refuse a view (the launch helper reports LFPSQP_ERR_UNSUPPORTED): EP::kNoRowScale
-template <class T, class = void>
-struct no_rowscale : std::false_type {};
-template <class T>
-struct no_rowscale<T, std::void_t<decltype(T::kNoRowScale)>> : std::true_type {};
-
+// ---- the functor wrappers of matrix views (see ViewD above) ---------------------------------------------------------------------------
 template <class VP>
 struct RsLoadV {      // GEMV-T producer
     static constexpr bool kRowScaled = true;
     VP vp;
-    const double* rs;
+    ViewD vw;
     __device__ __forceinline__ bool skip() const { return vp.skip(); }
-    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+    __device__ __forceinline__ double2 load_view(int64_t r, bool v0, bool v1, double& xsum) const {
         const double2 v = vp.load(r, v0, v1);
-        const double2 s = ld2(rs + r);
+        const double2 s = vw.s2(r), u = vw.u2(r);
+        if (v0) xsum = fma(u.x, v.x, xsum);
+        if (v1) xsum = fma(u.y, v.y, xsum);
         return make_double2(v0 ? v.x * s.x : 0.0, v1 ? v.y * s.y : 0.0);
     }
 };
@@ -690,72 +714,120 @@ template <class EP>
 struct RsApplyE {     // GEMV-N consumer
     static constexpr bool kRowScaled = true;
     EP ep;
-    const double* rs;
+    ViewD vw;
     __device__ __forceinline__ bool skip() const { return ep.skip(); }
     __device__ __forceinline__ void apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
-        const double2 s = ld2(rs + r);
-        ep.apply(r, make_double2(v0 ? acc.x * s.x : 0.0, v1 ? acc.y * s.y : 0.0), v0, v1, red);
+        const double2 s = vw.s2(r), u = vw.u2(r);
+        const double tau = vw.u ? ld_scal(vw.tau) : 0.0;
+        ep.apply(r, make_double2(v0 ? fma(u.x, tau, acc.x * s.x) : 0.0, v1 ? fma(u.y, tau, acc.y * s.y) : 0.0), v0, v1, red);
     }
 };
-template <class EP>
-struct RsStepE {      // GEMV-N -> GEMV-T in one launch (two matrices, each plain or a view)
+template <class EP, int NREDI>
+struct RsStepE {      // GEMV-N -> GEMV-T in one launch (two matrices, each plain or a view); reduction term NREDI = sum_i u2_i v_i
     static constexpr bool kRowScaled = true;
     EP ep;
-    const double *rs1, *rs2;
+    ViewD v1w, v2w;
+    bool view1, view2;
     __device__ __forceinline__ bool skip() const { return ep.skip(); }
     __device__ __forceinline__ double2 apply(int64_t r, double2 acc, bool v0, bool v1, double* red) const {
-        if (rs1) {
-            const double2 s = ld2(rs1 + r);
-            acc = make_double2(v0 ? acc.x * s.x : 0.0, v1 ? acc.y * s.y : 0.0);
+        if (view1) {
+            const double2 s = v1w.s2(r), u = v1w.u2(r);
+            const double tau = v1w.u ? ld_scal(v1w.tau) : 0.0;
+            acc = make_double2(v0 ? fma(u.x, tau, acc.x * s.x) : 0.0, v1 ? fma(u.y, tau, acc.y * s.y) : 0.0);
         }
         double2 v = ep.apply(r, acc, v0, v1, red);
-        if (rs2) {
-            const double2 s = ld2(rs2 + r);
+        if (view2) {
+            const double2 s = v2w.s2(r), u = v2w.u2(r);
+            double x = 0.0;
+            if (v0) x = fma(u.x, v.x, x);
+            if (v1) x = fma(u.y, v.y, x);
+            red[NREDI] += x;
             v = make_double2(v0 ? v.x * s.x : 0.0, v1 ? v.y * s.y : 0.0);
         }
         return v;
     }
 };
-template <class EP, int NV, int NA>
-struct RsRowE {       // one-stream kernel (onepass_kernel): the row's scale travels with its other inputs, a tile ahead
+// one-stream kernel (onepass_kernel): the row's scale and rank-one entry travel with its other inputs, a tile ahead; NV more reduction terms
+// (logical indices NREDI .. NREDI + NV - 1, in the functor's own convention: split over the lane groups or on the owner lanes)
+template <class EP, int NV, int NREDI>
+struct RsRowE {
     static constexpr bool kRowScaled = true;
     EP ep;
-    const double* rs;
-    using Uni = typename EP::Uni;
-    struct Row { typename EP::Row in; double s; };
+    ViewD vw;
+    struct Uni { typename EP::Uni in; double tau; };
+    struct Row { typename EP::Row in; double s, u; };
     static constexpr bool kSplitRed = EP::kSplitRed;
+    static constexpr int NRLI = kSplitRed ? (NREDI + 3) / 4 : NREDI;          // the wrapped functor's running sums per lane
     __device__ __forceinline__ bool skip() const { return ep.skip(); }
-    __device__ __forceinline__ Uni uniform() const { return ep.uniform(); }
+    __device__ __forceinline__ Uni uniform() const { return Uni{ep.uniform(), vw.u ? uniform_f64(ld_scal(vw.tau)) : 0.0}; }
     __device__ __forceinline__ Row fetch(uint32_t o) const {
-        return Row{ep.fetch(o), *reinterpret_cast<const double*>(reinterpret_cast<const char*>(rs) + o)};
+        return Row{ep.fetch(o), vw.rs ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(vw.rs) + o) : 1.0,
+                   vw.u ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(vw.u) + o) : 0.0};
     }
     template <class RED>
-    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&acc)[NA], bool valid, bool owner, bool lead, const Uni& u, const Row& w,
+    __device__ __forceinline__ void extra(const double (&v)[NV], double ui, bool valid, bool owner, bool lead, RED& red) const {
+        if constexpr (kSplitRed) {
+            const int h = (int)((threadIdx.x >> 2) & 3u);
+#pragma unroll
+            for (int q = 0; q < NV; ++q)
+                if (valid && lead && h == ((NREDI + q) & 3)) red[(NREDI + q) >> 2] = fma(ui, v[q], red[(NREDI + q) >> 2]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NV; ++q)
+                if (valid && owner) red[NREDI + q] = fma(ui, v[q], red[NREDI + q]);
+        }
+    }
+    template <class RED>
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool lead, const Uni& u, const Row& w,
                                           double (&v)[NV], RED& red) const {
         const double s = valid ? w.s : 0.0;
-        double a2[NA];
-#pragma unroll
-        for (int b = 0; b < NA; ++b) a2[b] = acc[b] * s;
-        ep.apply(row, o, a2, valid, owner, lead, u, w.in, v, red);
+        const double a2[1] = {valid ? fma(w.u, u.tau, acc[0] * s) : 0.0};
+        ep.apply(row, o, a2, valid, owner, lead, u.in, w.in, v, reinterpret_cast<double(&)[NRLI > 0 ? NRLI : 1]>(red));
+        extra(v, w.u, valid, owner, lead, red);
 #pragma unroll
         for (int q = 0; q < NV; ++q) v[q] *= s;
     }
     template <class RED>
-    __device__ __forceinline__ void apply_staged(int64_t row, uint32_t o, const double (&acc)[NA], bool valid, bool owner, bool lead, const Uni& u,
+    __device__ __forceinline__ void apply_staged(int64_t row, uint32_t o, const double (&acc)[1], bool valid, bool owner, bool lead, const Uni& u,
                                                  const Row& w, double (&v)[NV], RED& red, double* slot, int sstride) const {
         const double s = valid ? w.s : 0.0;
-        double a2[NA];
-#pragma unroll
-        for (int b = 0; b < NA; ++b) a2[b] = acc[b] * s;
-        ep.apply_staged(row, o, a2, valid, owner, lead, u, w.in, v, red, slot, sstride);
+        const double a2[1] = {valid ? fma(w.u, u.tau, acc[0] * s) : 0.0};
+        ep.apply_staged(row, o, a2, valid, owner, lead, u.in, w.in, v, reinterpret_cast<double(&)[NRLI > 0 ? NRLI : 1]>(red), slot, sstride);
+        extra(v, w.u, valid, owner, lead, red);
 #pragma unroll
         for (int q = 0; q < NV; ++q) v[q] *= s;
     }
     __device__ __forceinline__ double* stage_out(int sv) const { return ep.stage_out(sv); }
 };
 // (the staged form is offered exactly when the wrapped functor offers it)
-template <class EP, int NV, int NA>
-struct stage_streams<RsRowE<EP, NV, NA>> : stage_streams<EP> {};
+template <class EP, int NV, int NREDI>
+struct stage_streams<RsRowE<EP, NV, NREDI>> : stage_streams<EP> {};
+
+// tau = w . t[0:ncols) ahead of a first product over a view with a rank-one term; one workgroup, fixed order
+template <int D = 0>
+__global__ __launch_bounds__(256) void view_tau_kernel(const double* __restrict__ w, const double* __restrict__ t, int ncols, double* __restrict__ tau) {
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (int j = threadIdx.x; j < ncols; j += 256) s = fma(w[j], t[j], s);
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sm[threadIdx.x] += sm[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *tau = sm[0];
+}
+// behind a second product over a view: out[q * nc + j] = in[q * nc + j] + w_j in[nv * nc + nred + q]  (j < nc, q < nv; w == nullptr: no
+// rank-one term), out[nv * nc + r] = in[nv * nc + r] (r < nred)
+template <int D = 0>
+__global__ __launch_bounds__(256) void view_fold_kernel(const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ w, int nv, int nc,
+                                                        int nred) {
+    for (int i = threadIdx.x; i < nv * nc + nred; i += 256) {
+        double v = in[i];
+        if (w && i < nv * nc) v = fma(w[i % nc], in[nv * nc + nred + i / nc], v);
+        out[i] = v;
+    }
+}
 
 // ---------------------------------------------------------------------------
 // Elementwise map + reductions.  F::apply(i, valid0, valid1, red) handles the

@@ -528,16 +528,24 @@ struct EwEvalVecF {   // the same as a plain row pass (sparse A: phi(x) -> work,
     __device__ __forceinline__ bool skip() const { return false; }
     __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const { (void)e.apply(i, make_double2(0.0, 0.0), v0, v1, red); }
 };
-struct EwDerivF {     // out = phi'(x)  (row scales of the sparse constraint gradients)
+struct EwDerivF {     // out = phi'(x)  (row scales of the sparse / streamed constraint gradients), uout = 2 x [i < n_x] (their rank-one term); either may be null
     const double *x, *kind;
-    double* out;
+    double *out, *uout;
+    int64_t n_x;
     __device__ __forceinline__ bool skip() const { return false; }
     __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
         const double2 a = ld2(x + i);
-        const double2 kk = kind ? ld2(kind + i) : make_double2(0.0, 0.0);
-        const double2 d = make_double2(ew_phi1(kk.x, a.x), ew_phi1(kk.y, a.y));
-        if (v1) st2(out + i, d);
-        else if (v0) out[i] = d.x;
+        if (out) {
+            const double2 kk = kind ? ld2(kind + i) : make_double2(0.0, 0.0);
+            const double2 d = make_double2(ew_phi1(kk.x, a.x), ew_phi1(kk.y, a.y));
+            if (v1) st2(out + i, d);
+            else if (v0) out[i] = d.x;
+        }
+        if (uout) {
+            const double2 d = make_double2(i < n_x ? 2.0 * a.x : 0.0, i + 1 < n_x ? 2.0 * a.y : 0.0);
+            if (v1) st2(uout + i, d);
+            else if (v0) uout[i] = d.x;
+        }
     }
 };
 // Jct[:, j] = phi'(x) .* A[:, j] + 2 qw_j x [i < n_x]   (jac! of the dense class: one read of A, one write of Jct)
@@ -742,13 +750,17 @@ static bool cons_ok(const lfpsqp_constraints* c) {
         return false;
     // a row-scaled view as Jct (constant or streamed gradients): no ball column (jac! would write it into the borrowed storage, and it is not
     // scaled with the rows) and no sparse twin
-    if (c->Jct->rs && (c->has_ball || c->Jsp)) return false;
+    if (c->Jct->view && (c->has_ball || c->Jsp)) return false;
     const lfpsqp_elementwise* e = c->ew;
     if (!e) return true;
     // STREAMED gradients: Jct is a row-scaled view of A itself (lfpsqp_mat_rowscaled_view) -- Jct(x) = diag(phi'(x)) A never exists in memory, jac!
     // rewrites the view's scale vector.  No rank-one / ball column then (they are not row scalings of A).
+    // The view carries what the class has: row scales iff kind, the rank-one term u qw' (u = 2 x on the first n_x rows, refreshed by jac!; the view's w
+    // must hold qw) iff qw.
     const bool streamed = e->A && e->A->p == c->Jct->p;
-    if (streamed && !(c->Jct->rs && plain_mat(e->A) && !e->Asp && !e->qw && !c->has_ball && !c->Jsp)) return false;
+    if (streamed && !(c->Jct->view && plain_mat(e->A) && !e->Asp && !c->has_ball && !c->Jsp && (c->Jct->rs != nullptr) == (e->kind != nullptr) &&
+                      (c->Jct->ru != nullptr) == (e->qw != nullptr)))
+        return false;
     if (!streamed && !plain_mat(c->Jct)) return false;
     return c->m_lin >= 1 && (e->Asp || e->A) && (!e->A || (e->A->n == c->Jct->n && e->A->m >= c->m_lin)) &&
            (!e->kind || e->kind->n >= c->Jct->n) &&
@@ -768,14 +780,15 @@ int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, con
 
 int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval) {
     LF_RANGE("lfpsqp_constraints_jac");
-    LF_ARG(ctx, ctx && cons_ok(cons) && x && Jct && cval && x->n >= cons->Jct->n && Jct->p == cons->Jct->p && Jct->rs == cons->Jct->rs);
+    LF_ARG(ctx, ctx && cons_ok(cons) && x && Jct && cval && x->n >= cons->Jct->n && Jct->p == cons->Jct->p && Jct->rs == cons->Jct->rs && Jct->ru == cons->Jct->ru);
     if (const lfpsqp_elementwise* ew = cons->ew) {             // Jct[:, :m_lin] = diag(phi'(x)) A + 2 x qw'
         const int64_t N = Jct->n;
         const int ml = (int)cons->m_lin;
-        if (Jct->rs) {                                            // streamed gradients: jac! is the n-vector phi'(x), the matrix stays A
-            LF_TRY((run_vec<EwDerivF, 0, NoPost>(ctx, N, EwDerivF{x->p, ew->kind ? ew->kind->p : nullptr, const_cast<double*>(Jct->rs)}, 0u, nullptr, NoPost())));
+        if (Jct->view) {                                          // streamed gradients: jac! is the n-vector phi'(x) (and 2 x for the quadratic term), the matrix stays A
+            LF_TRY((run_vec<EwDerivF, 0, NoPost>(ctx, N, EwDerivF{x->p, ew->kind ? ew->kind->p : nullptr, const_cast<double*>(Jct->rs), const_cast<double*>(Jct->ru), cons->n_x},
+                                                 0u, nullptr, NoPost())));
         } else if (ew->Asp) {
-            LF_TRY((run_vec<EwDerivF, 0, NoPost>(ctx, N, EwDerivF{x->p, ew->kind ? ew->kind->p : nullptr, ew->work->p}, 0u, nullptr, NoPost())));
+            LF_TRY((run_vec<EwDerivF, 0, NoPost>(ctx, N, EwDerivF{x->p, ew->kind ? ew->kind->p : nullptr, ew->work->p, nullptr, 0}, 0u, nullptr, NoPost())));
             LF_TRY(lfpsqp_spmat_rowscale(ctx, const_cast<lfpsqp_spmat*>(cons->Jsp), ew->Asp, ew->work));
             LF_TRY(lfpsqp_spmat_to_dense(ctx, cons->Jsp, Jct));
         } else if (N > 0) {

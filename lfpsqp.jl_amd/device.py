@@ -298,7 +298,7 @@ class DeviceMatrix:
 
     def download(self, col0: int = 0, ncols: int | None = None) -> np.ndarray:
         ncols = self.m - col0 if ncols is None else ncols
-        if getattr(self, "rs", None) is not None:          # a row-scaled view: materialise it (lfpsqp_mat_copy), then read that back
+        if getattr(self, "is_view", False):                # a view: materialise it (lfpsqp_mat_copy), then read that back
             tmp = DeviceMatrix(self.ctx, self.n, self.m)
             try:
                 return tmp.copy_from(self).download(col0, ncols)
@@ -313,16 +313,21 @@ class DeviceMatrix:
         self.ctx.check(self.ctx.L.lfpsqp_mat_copy(self.ctx.h, self.h, src.h))
         return self
 
-    def rowscaled_view(self, rs: "DeviceVector") -> "DeviceMatrix":
-        """diag(rs) * self without a copy (lfpsqp_mat_rowscaled_view): every product kernel of the library accepts it wherever a matrix is
-        only read; storage and ``rs`` are borrowed (the view keeps both alive)."""
+    def view(self, rs: "DeviceVector | None" = None, u: "DeviceVector | None" = None, w: "DeviceVector | None" = None) -> "DeviceMatrix":
+        """diag(rs) * self + u w' without a copy (lfpsqp_mat_view): every product kernel of the library accepts it wherever a matrix is only
+        read; storage and vectors are borrowed (the view keeps them alive)."""
         v = DeviceMatrix.__new__(DeviceMatrix)
         v.ctx, v.n, v.m = self.ctx, self.n, self.m
         h = P()
-        self.ctx.check(self.ctx.L.lfpsqp_mat_rowscaled_view(self.ctx.h, self.h, rs.h, C.byref(h)))
+        g = lambda x: x.h if x is not None else None
+        self.ctx.check(self.ctx.L.lfpsqp_mat_view(self.ctx.h, self.h, g(rs), g(u), g(w), C.byref(h)))
         v.h = h
-        v.base, v.rs = self, rs
+        v.base, v.rs, v.ru, v.rw = self, rs, u, w
+        v.is_view = True
         return v
+
+    def rowscaled_view(self, rs: "DeviceVector") -> "DeviceMatrix":
+        return self.view(rs=rs)
 
     def hash_fill(self, seed: int, row0: int = 0, n_global: int | None = None, scale: float = 1.0, nrows: int | None = None,
                   ncols: int | None = None):

@@ -79,24 +79,26 @@ class ElementwiseConstraints(DeviceConstraints):
     :func:`sphere_system_constraints`).  ``A``: DeviceMatrix (n x m), or a SparseMatrix -- then c!, jac!, the tangent setup, the
     Newton steps and the inner solves of ProjPenalty all stream the nonzeros.  ``Jct`` (n x (m + ball)) is the working matrix.
 
-    ``stream`` (dense ``A`` without ``qw`` / ball; default: whenever the library's one-pass kernels cover the shape): the gradients are
-    STREAMED -- ``Jct`` is a row-scaled view of ``A`` itself (:meth:`DeviceMatrix.rowscaled_view`), jac! refreshes the n-vector
-    phi'(x) instead of rewriting an n x m matrix, and there is no second matrix in memory."""
+    ``stream`` (dense ``A`` with a ``kind`` and / or ``qw``, no ball; default: whenever the library's one-pass kernels cover the shape): the
+    gradients are STREAMED -- ``Jct`` is a view diag(rs) A + u qw' of ``A`` itself (:meth:`DeviceMatrix.view`), jac! refreshes the n-vectors
+    rs = phi'(x) and u = 2 x instead of rewriting an n x m matrix, and there is no second matrix in memory."""
 
     def __init__(self, ctx, A, b, kind=None, qw=None, Jct: DeviceMatrix | None = None, has_ball: bool = False, R2: float = 0.0,
                  n_x: int | None = None, slack_row: int = -1, stream: bool | None = None):
         from .device import SparseMatrix
         sparse = isinstance(A, SparseMatrix)
         n, m = A.n, A.m
-        can_stream = not sparse and qw is None and not has_ball and Jct is None and m >= 1
+        can_stream = not sparse and (kind is not None or qw is not None) and not has_ball and Jct is None and m >= 1
         if stream is None:
             stream = can_stream and ctx.factored_basis_supported(A, None)
         elif stream and not can_stream:
-            raise ValueError("streamed gradients need a dense A, no quadratic term, no ball and no caller-owned Jct")
+            raise ValueError("streamed gradients need a dense A with a kind or a quadratic term, no ball and no caller-owned Jct")
         self.streamed = bool(stream)
         if self.streamed:
-            self.rs = ctx.vector(n, np.ones(n))
-            Jct = A.rowscaled_view(self.rs)
+            self.rs = ctx.vector(n, np.ones(n)) if kind is not None else None
+            self.ru = ctx.vector(n) if qw is not None else None
+            self.rw = ctx.vector(m, np.asarray(qw, dtype=np.float64)) if qw is not None else None
+            Jct = A.view(self.rs, self.ru, self.rw)
         elif Jct is None:
             Jct = DeviceMatrix(ctx, n, m + (1 if has_ball else 0), placed=True)
         Jsp = A.clone() if sparse else None

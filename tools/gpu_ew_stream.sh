@@ -2,7 +2,7 @@
 # both modes, and the per-kernel durations of both runs (rocprofv3 --kernel-trace --stats)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests/test_streamed_gradients.py tests/test_elementwise.py -x -q -m gpu > gpurun_out/ew_stream_tests.log 2>&1; tail -3 gpurun_out/ew_stream_tests.log
-for mode in stream nostream; do
+for mode in dense dense-materialised stream nostream; do
   timeout 900 python tools/time_elementwise.py $mode > gpurun_out/elementwise_$mode.json 2> gpurun_out/elementwise_$mode.err || tail -5 gpurun_out/elementwise_$mode.err
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ewprof_$mode -- python3 $R/tools/time_elementwise.py $mode > /dev/null 2> $R/gpurun_out/ewprof_$mode.err)
   python - $mode <<'PY' > gpurun_out/elementwise_${mode}_kernels.txt
@@ -17,10 +17,12 @@ PY
 done
 python - <<'PY'
 import json
-a, b = (json.load(open(f"gpurun_out/elementwise_{m}.json")) for m in ("stream", "nostream"))
-for k in ("c_ms", "jac_ms", "hess_diag_ms", "tangent_setup_ms", "tangent_setup_factored_ms", "nr_iteration_ms_with_generator", "nr_iteration_ms_basis_only"):
+for pair in (("dense", "dense-materialised"), ("stream", "nostream")):
+  a, b = (json.load(open(f"gpurun_out/elementwise_{m}.json")) for m in pair)
+  print(pair[0], "against", pair[1], "(streamed gradients:", a["streamed_gradients"], b["streamed_gradients"], ")")
+  for k in ("c_ms", "jac_ms", "hess_diag_ms", "tangent_setup_ms", "tangent_setup_factored_ms", "nr_iteration_ms_with_generator", "nr_iteration_ms_basis_only"):
     print(f"{k:34s} streamed {a[k]:9.3f}   materialised {b[k]:9.3f}")
-for k in ("optimize_newton", "optimize_projpenalty", "optimize_newton_warm", "optimize_projpenalty_warm"):
+  for k in ("optimize_newton", "optimize_projpenalty", "optimize_newton_warm", "optimize_projpenalty_warm"):
     print(f"{k:34s} streamed {a[k]['seconds_per_outer_iteration']*1e3:9.1f} ms / outer iteration ({a[k]['outer_iterations']} it, tn {a[k]['tn_iterations']})   materialised {b[k]['seconds_per_outer_iteration']*1e3:9.1f} ({b[k]['outer_iterations']} it, tn {b[k]['tn_iterations']})")
 PY
-head -14 gpurun_out/elementwise_stream_kernels.txt; head -14 gpurun_out/elementwise_nostream_kernels.txt
+head -16 gpurun_out/elementwise_dense_kernels.txt; head -12 gpurun_out/elementwise_dense-materialised_kernels.txt

@@ -1,8 +1,8 @@
 """Seconds per call / per outer iteration of the device-resident nonlinear constraint class at full size (n = 1e7, m = 128, one MI355X):
 c!, jac!, hess_diag!, tangent setup, and an `optimize` run (f = |x - target|^2) with the Newton and the ProjPenalty retraction.
-    python tools/time_elementwise.py [dense|sparse|stream|nostream] > gpurun_out/elementwise_<kind>.json
-dense: mixed kinds + the common quadratic term (materialised Jct: the rank-one term is not a row scaling); stream / nostream: the same system without
-the quadratic term, gradients streamed through a row-scaled view of A (the default for that class) / materialised, for the A/B."""
+    python tools/time_elementwise.py [dense|dense-materialised|sparse|stream|nostream] > gpurun_out/elementwise_<kind>.json
+dense: mixed kinds + the common quadratic term, gradients STREAMED through a view diag(phi'(x)) A + 2 x qw' of A (the default for a dense class);
+dense-materialised: the same with jac! writing an n x m Jct (the A/B); stream / nostream: the same pair without the quadratic term."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,6 +17,10 @@ if mode in ("stream", "nostream"):
     from tests.test_gpu_fullsize import N as n, M as m
     A = ctx.matrix(n, m).hash_fill(21, 0, n, 2.0 ** -11)
     cons = L.ElementwiseConstraints(ctx, A, np.zeros(m), kind=(np.arange(n) % 3).astype(np.float64), stream=(mode == "stream"))
+elif mode == "dense-materialised":
+    from tests.test_gpu_fullsize import N as n, M as m
+    A = ctx.matrix(n, m).hash_fill(21, 0, n, 2.0 ** -11)
+    cons = L.ElementwiseConstraints(ctx, A, np.zeros(m), kind=(np.arange(n) % 3).astype(np.float64), qw=1e-7 * np.cos(np.arange(m)), stream=False)
 else:
     cons, n, m = _ew_big(ctx, sparse)
 x = ctx.vector(n).hash_fill(31, 0, 0.5, 0.0)
