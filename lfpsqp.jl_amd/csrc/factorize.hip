@@ -48,7 +48,10 @@ template <bool DIAG, bool WEIGHTED>
 __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restrict__ M, int64_t ld, int64_t n, int ncols, int npan,
                                                          int ngroups, const double* __restrict__ w2, double* __restrict__ part,
                                                          int64_t part_ld) {
-    constexpr bool needB = !DIAG || WEIGHTED;           // diagonal unweighted panel: B is A itself
+    // WEIGHTED: w2 holds the SQUARE ROOTS of the weights (gram_impl prepares them) and both operands are scaled: the product stays symmetric, so a
+    // diagonal block still needs ONE staged operand (with the weights on one side only it needed two: twice the LDS writes and the LDS
+    // footprint -- 4.04 against 3.22 ms for the unweighted kernel at n = 1e7, m = 128, profiles/r04g_streamed_gradients_1e7_128.txt)
+    constexpr bool needB = !DIAG;                       // diagonal panel: B is A itself
     // two LDS buffers per operand: step s+1 is written while step s is multiplied -- ONE barrier per step, and no phase in which
     // the matrix cores wait for the staging
     __shared__ double As[2][kPanel][kTLd];
@@ -83,6 +86,10 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
     auto load_step = [&](auto Fc, int buf, int64_t step) {
         constexpr bool FULL = decltype(Fc)::value;
         const int64_t r = step * kKStep;
+        if constexpr (WEIGHTED) {       // first: the staging multiplies need it before anything else, and loads return in order
+            const double2 w = ld2(w2 + r + kh);
+            vw[buf] = make_double2((r + kh < n) ? w.x : 0.0, (r + kh + 1 < n) ? w.y : 0.0);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if constexpr (FULL) {
@@ -97,10 +104,6 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
                 }
             }
         }
-        if constexpr (WEIGHTED) {
-            const double2 w = ld2(w2 + r + kh);
-            vw[buf] = make_double2((r + kh < n) ? w.x : 0.0, (r + kh + 1 < n) ? w.y : 0.0);
-        }
     };
     auto write_lds = [&](int p, int buf) {
 #pragma unroll
@@ -110,8 +113,10 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
             As[p][c + 32 * q][kh] = a.x;
             As[p][c + 32 * q][kh + 1] = a.y;
             if constexpr (needB) {
-                Bs[p][c + 32 * q][kh] = vb[buf][q].x;
-                Bs[p][c + 32 * q][kh + 1] = vb[buf][q].y;
+                double2 b = vb[buf][q];
+                if constexpr (WEIGHTED) { b.x *= vw[buf].x; b.y *= vw[buf].y; }
+                Bs[p][c + 32 * q][kh] = b.x;
+                Bs[p][c + 32 * q][kh + 1] = b.y;
             }
         }
     };
@@ -468,6 +473,19 @@ struct ViewRank1V {
         return make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0);
     }
 };
+// the Gram kernel's row factors: out = sqrt(w2)  (weights are squares in every use: Dy^2, phi'^2, the rows of D0^-1; a negative one gives NaN and
+// the factorisation reports a non-finite Gram matrix)
+struct SqrtWeightF {
+    const double* w2;
+    double* out;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 w = ld2(w2 + i);
+        const double2 s = make_double2(sqrt(w.x), sqrt(w.y));
+        if (v1) st2(out + i, s);
+        else if (v0) out[i] = s.x;
+    }
+};
 struct ViewRank1DotF {
     const double *w2, *u;
     __device__ __forceinline__ bool skip() const { return false; }
@@ -490,7 +508,7 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
         const lfpsqp_mat plain = M->plain();
         const double* wts = w2;
         if (M->rs) {
-            LF_TRY(ensure_nvec(ctx, (size_t)M->n));
+            LF_TRY(ensure_nvec(ctx, 2 * (size_t)round_up(M->n + 1, kPadRows)));       // [combined weights | their square roots (gram_impl below)]
             LF_TRY((run_vec<ViewWeightF, 0, NoPost>(ctx, M->n, ViewWeightF{M->rs, w2, ctx->d_nvec}, 0u, nullptr, NoPost())));
             wts = ctx->d_nvec;
         }
@@ -538,9 +556,17 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     LF_TRY(ensure_small(ctx, (size_t)pp));
     const int64_t tile2 = (int64_t)kPanel * kPanel;
     if (w2) {
-        hipLaunchKernelGGL((gram_kernel<true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pp);
+        // the kernel scales BOTH operands by sqrt(w2): staged in the second half of the n-vector scratch (the first may hold the weights themselves)
+        const size_t npad = (size_t)round_up(M->n + 1, kPadRows);
+        const bool own = ctx->d_nvec && w2 == ctx->d_nvec;              // (a view's combined weights live in the first half already)
+        LF_TRY(ensure_nvec(ctx, 2 * npad));
+        if (own) w2 = ctx->d_nvec;
+        double* sw = ctx->d_nvec + npad;
+        LF_TRY((run_vec<SqrtWeightF, 0, NoPost>(ctx, M->n, SqrtWeightF{w2, sw}, 0u, nullptr, NoPost())));
+        LF_TRY(ensure_part(ctx, (size_t)std::max(gd, go) * pp));          // (run_vec may not shrink it, but keep the reservation next to its use)
+        hipLaunchKernelGGL((gram_kernel<true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pp);
         if (noff > 0)
-            hipLaunchKernelGGL((gram_kernel<false, true>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, w2, ctx->part, pp);
+            hipLaunchKernelGGL((gram_kernel<false, true>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, sw, ctx->part, pp);
     } else {
         hipLaunchKernelGGL((gram_kernel<true, false>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pp);
         if (noff > 0)
