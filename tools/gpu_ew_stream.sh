@@ -22,7 +22,7 @@ for pair in (("dense", "dense-materialised"), ("stream", "nostream")):
   print(pair[0], "against", pair[1], "(streamed gradients:", a["streamed_gradients"], b["streamed_gradients"], ")")
   for k in ("c_ms", "jac_ms", "hess_diag_ms", "tangent_setup_ms", "tangent_setup_factored_ms", "nr_iteration_ms_with_generator", "nr_iteration_ms_basis_only"):
     print(f"{k:34s} streamed {a[k]:9.3f}   materialised {b[k]:9.3f}")
-  for k in ("optimize_newton", "optimize_projpenalty", "optimize_newton_warm", "optimize_projpenalty_warm"):
+  for k in ("optimize_newton", "optimize_projpenalty"):
     print(f"{k:34s} streamed {a[k]['seconds_per_outer_iteration']*1e3:9.1f} ms / outer iteration ({a[k]['outer_iterations']} it, tn {a[k]['tn_iterations']})   materialised {b[k]['seconds_per_outer_iteration']*1e3:9.1f} ({b[k]['outer_iterations']} it, tn {b[k]['tn_iterations']})")
 PY
 head -16 gpurun_out/elementwise_dense_kernels.txt; head -12 gpurun_out/elementwise_dense-materialised_kernels.txt
