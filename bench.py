@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+SIDE_SCALE = 1.0          # --side-scale (tests): lengths of the side measurements
+
 def main(argv=None, lib=None):
     """`lib` is injected only by tests/test_bench_harness.py (emulator build, tiny sizes)."""
     ap = argparse.ArgumentParser()
@@ -39,6 +41,9 @@ def main(argv=None, lib=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the tangent-setup / Newton-retraction timings (not part of `value`)")
     ap.add_argument("--cpu-sample-n", type=float, default=2e6)
+    ap.add_argument("--side-scale", type=float, default=1.0,
+                    help="(tests) scale of the SIDE measurements' lengths -- iterations of the Newton / pcg! timings in `extras`, CPU seconds and the host "
+                         "triad's size in `cpu_baseline`; never touches the timed region of `value`")
     ap.add_argument("--comm", choices=["auto", "rccl", "p2p", "torch", "host-gloo"], default="auto",
                     help="all-reduce transport for N > 1.  auto (default): bring up the library's one-shot peer-to-peer all-reduce (mailboxes mapped "
                          "through hipIpc: one exchange instead of a ring) AND the library-native RCCL communicator, check each with a known sum, time "
@@ -59,6 +64,8 @@ def main(argv=None, lib=None):
                     help="dump every thread's Python stack to stderr and exit non-zero if the run takes longer (0 = off): a stalled "
                          "rendezvous or collective then fails with a diagnosis instead of hanging the caller")
     args = ap.parse_args(argv)
+    global SIDE_SCALE
+    SIDE_SCALE = args.side_scale
     n, m, K, W = int(args.n), args.m, args.steps, args.warmup
 
     rank = int(os.environ.get("RANK", "0"))
@@ -330,7 +337,7 @@ def main(argv=None, lib=None):
     out["single_call"] = {"value": K / single_call, "ms_per_step": single_call / K * 1e3,
                           "note": f"one lfpsqp_projcg call with maxit = {K}: set-up (x = 0, r = -b, U'r, first projection: 2 passes over U) + {K} iterations"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_n), m, n)
+        out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_n), m, n, args.side_scale)
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
@@ -539,6 +546,9 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     # the same factorisation with the basis left in factored form U = J W (no basis-forming product: what optimize() runs per outer iteration)
     L.ksvd_(J, None, W=Wg)
     ctx.sync(); t0 = time.perf_counter(); L.ksvd_(J, None, W=Wg); ctx.sync(); fact_factored_ms = (time.perf_counter() - t0) * 1e3
+    # ... and warm-started from the previous call's eigenvectors (lfpsqp_factorize_hint: what optimize() runs from its second outer iteration on)
+    L.ksvd_(J, None, W=Wg, Vt_prev=Vt)
+    ctx.sync(); t0 = time.perf_counter(); L.ksvd_(J, None, W=Wg, Vt_prev=Vt); ctx.sync(); fact_warm_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter(); L.gram(J); gram_ms = (time.perf_counter() - t0) * 1e3
     W = np.eye(m)
     t0 = time.perf_counter(); L.rmul(J, W, Z2); ctx.sync(); rmul_ms = (time.perf_counter() - t0) * 1e3
@@ -555,7 +565,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     # Timed the way `value` is: MANY iterations of one running solve (tol = 0 forces exactly `its`), so that the call's set-up (the first
     # c! pass, the H2D copies of the small factors) weighs < 1 %; beside the wall time per iteration the KERNEL CHAIN of an iteration from
     # the library's own HIP events (every 4th launch of a kernel family is bracketed): what is left between the two is launch gaps.
-    its_long = 200
+    its_long = max(8, int(round(200 * SIDE_SCALE)))
     nr_ms, nr_chain = {}, {}
     for label, basis in (("one_stream", L.DeviceBasis(Z2, generator=(J, Wg))), ("two_streams", L.DeviceBasis(Z2))):
         nits = its_long if label == "one_stream" else 24
@@ -588,7 +598,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         xns = [ctx.vector(n_loc) for _ in range(nbt)]
         for j, xt_ in enumerate(xts):
             L.waxpby(1.0, xs, 0.5 ** j, pert, xt_)
-        nrb = L.NR(L.DeviceBasis(Z2, generator=(J, Wg)), S, Vt, 0.0, 100, L.NRWork(m), False, None)
+        nrb = L.NR(L.DeviceBasis(Z2, generator=(J, Wg)), S, Vt, 0.0, max(6, int(round(100 * SIDE_SCALE))), L.NRWork(m), False, None)
         cvs = np.zeros((nbt, m))
         for rep in range(2):
             ctx.set_profiling(True)
@@ -694,7 +704,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     except Exception as e:      # diagnostics only
         sparse = {"error": repr(e)}
     rates = stream_rates(ctx, L, nbig=int(max(1 << 20, min(400_000_000, 40 * n_loc))))
-    return {"stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "factorize_factored_basis_ms": fact_factored_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs_of_the_full_product": flop / gram_ms / 1e9,
+    return {"stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "factorize_factored_basis_ms": fact_factored_ms, "factorize_factored_basis_warm_ms": fact_warm_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs_of_the_full_product": flop / gram_ms / 1e9,
             "gram_TFLOPs_executed": flop * gram_tile_share(m) / gram_ms / 1e9,
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
@@ -775,7 +785,7 @@ def stream_rates(ctx, L, nbig=400_000_000):
     return {"read_GBs": 9.0 * 8.0 * nrow8 / (ms_r * 1e-3) / 1e9, "copy_GBs": g(2, ms_c), "triad_GBs": g(3, ms_t), "vector_GB": 8.0 * nbig / 1e9}
 
 
-def cpu_baseline(ns, m, n_full):
+def cpu_baseline(ns, m, n_full, side_scale=1.0):
     """The reference's CPU path as the oracle's C/OpenMP restatement (oracle/projcg_port.c), timed on this box's host cores
     (BASELINE.md 3): the (unfused) projcg! call sequence of src/projcg.jl:71-112, the two matvecs on their own (kgemv!, src/la_helper.jl:36-44),
     one Newton-retraction iteration (src/retractions.jl:133-165: a GEMV-N over U, c! = a GEMV-T over Jct, the m x m Broyden algebra) and a
@@ -815,7 +825,7 @@ def cpu_baseline(ns, m, n_full):
     t0 = time.perf_counter()
     _, _, it, _ = port.projcg(a, U, b, None, 1e-300, k)
     dt = time.perf_counter() - t0
-    k = max(3, min(900, int(12.0 / (dt / k))))                 # ~10 s of CPU work (the calibration iterations run cold, ~1.6 x slower)
+    k = max(3, min(900, int(12.0 * side_scale / (dt / k))))    # ~10 s of CPU work (the calibration iterations run cold, ~1.6 x slower)
     t0 = time.perf_counter()
     _, _, it, _ = port.projcg(a, U, b, None, 1e-300, k)
     dt = time.perf_counter() - t0
@@ -827,7 +837,7 @@ def cpu_baseline(ns, m, n_full):
         t0 = time.perf_counter()
         fn()
         one = max(time.perf_counter() - t0, 1e-6)
-        reps = max(2, min(200, int(budget / one)))
+        reps = max(2, min(200, int(budget * side_scale / one)))
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
@@ -853,6 +863,7 @@ def cpu_baseline(ns, m, n_full):
     s_nr = timed(nr_iter)
     # host triad on three vectors of 2e8 doubles (4.8 GB: beyond every cache level of the host; smaller when memory is short)
     nt = 200_000_000 if avail >= 20e9 else int(min(nm, 50_000_000))
+    nt = max(100_000, int(nt * min(1.0, side_scale)))
     ta, tb, z = np.ones(nt), np.ones(nt), np.zeros(nt)
     s_tr = timed(lambda: port.triad(2.0, ta, tb, z), budget=1.0)
     by_t = 8.0 * nm * m + 8.0 * nm + 8.0 * m

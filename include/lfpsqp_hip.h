@@ -297,6 +297,14 @@ int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const doub
  * W (optional, host, m x m column-major): the small factor the basis was formed with, Z = Jct * W
  * exactly as computed (columns >= rank are zero).  Handing it back through lfpsqp_basis.A / .W lets
  * the Newton retraction run both of its products over Jct alone (one matrix stream instead of two). */
+/* WARM START for the next lfpsqp_factorize / lfpsqp_factorize_sp call on this context with the same m: Vt_prev (m x m, host, column-major) is
+ * the Vt a previous call returned for a NEARBY matrix -- in `optimize`, the previous outer iteration's (src/optimize.jl:286-302 factorises
+ * afresh every iteration; the constraint gradients move little between iterations, and with linear constraints and no bounds not at all).
+ * The small eigenproblem then starts from a nearly diagonal matrix: one or two Jacobi sweeps instead of eight.  The hint is an optimisation
+ * only: it is checked (orthogonal to 1e-8, m <= 256, positive definite Gram matrix) and ignored otherwise; Sigma, rank and the span of every
+ * kept column are those of the cold call, the basis may differ by a rotation inside clusters of equal singular values (to which every use is
+ * invariant).  Consumed by the first factorisation that follows, whatever its outcome. */
+int lfpsqp_factorize_hint(lfpsqp_ctx* ctx, const double* Vt_prev, int64_t m);
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
                      double* W, int64_t* rank, double eps_rank);
 

@@ -201,6 +201,7 @@ c_y_retract(ctx, xnew, x, id) = ccall((:lfpsqp_y_retract, lib), Cint, (Ptr{Cvoid
 # ---- tangent setup -----------------------------------------------------------------------------------------------------------
 c_gram(ctx, M, ncols, w2, G) = ccall((:lfpsqp_gram, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Float64}), ctx, M, ncols, w2, G)
 c_rmul(ctx, In, kcols, W, rcols, Out) = ccall((:lfpsqp_rmul, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Ptr{Cvoid}), ctx, In, kcols, W, rcols, Out)
+c_factorize_hint(ctx, Vt_prev, m) = ccall((:lfpsqp_factorize_hint, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), ctx, Vt_prev, m)
 c_factorize(ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank) = ccall((:lfpsqp_factorize, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64), ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank)
 c_factorize_sp(ctx, S, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank) = ccall((:lfpsqp_factorize_sp, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64), ctx, S, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank)
 c_small_svd(ctx, rows, cols, A, U, S, V) = ccall((:lfpsqp_small_svd, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx, rows, cols, A, U, S, V)
@@ -246,6 +247,7 @@ mutable struct DeviceOptions
     placement_tries::Int
     factored_basis::Bool        # keep the tangent basis in factored form U = Jct W whenever the fused projected-CG iteration applies
     pp_precondition::Bool       # ProjPenalty's inner solves with the exact preconditioner of their operator (lfpsqp_pcg_pre); false = the reference's live path
+    warm_factorize::Bool        # the small eigenproblem of the tangent setup starts from the previous outer iteration's Vt (lfpsqp_factorize_hint)
 end
 mutable struct HipContext
     h::Ptr{Cvoid}
@@ -256,7 +258,7 @@ mutable struct HipContext
         r = Ref{Ptr{Cvoid}}(C_NULL)
         rc = c_ctx_create(Cint(device), r)
         rc == 0 || throw(HipError(rc, "lfpsqp_ctx_create failed: no usable MI355X (there is no CPU fallback)"))
-        ctx = new(r[], 0, 1, DeviceOptions(0, 3, true, false))
+        ctx = new(r[], 0, 1, DeviceOptions(0, 3, true, false, true))
         finalizer(c -> c_ctx_destroy(c.h), ctx)
         return ctx
     end
@@ -598,8 +600,10 @@ y_retract!(xnew::DeviceVector, x::DeviceVector, id::InequalityData) = (check(x.c
 # Jsp (optional SparseMatrix with the entries of the leading Jsp.m columns of Jct): the basis-forming products stream the nonzeros.
 # Z === nothing (dense Jct, W required): the basis Z = Jct*W is not formed -- the caller keeps it in factored form, DeviceBasis(nothing, rank, (Jct, W))
 function ksvd!(Jct::DeviceMatrix, Z::Union{Nothing,DeviceMatrix}, Σ::Vector{Float64}, Vt::Matrix{Float64}; w2::Union{Nothing,DeviceVector}=nothing,
-               ϵ_rank::Float64=1e-10, W::Union{Nothing,Matrix{Float64}}=nothing, Jsp=nothing)
+               ϵ_rank::Float64=1e-10, W::Union{Nothing,Matrix{Float64}}=nothing, Jsp=nothing, Vt_prev::Union{Nothing,Matrix{Float64}}=nothing)
     rank = Ref{Int64}(0)
+    # warm start of the small eigenproblem from the previous outer iteration's Vt (lfpsqp_factorize_hint; ignored unless orthogonal)
+    Vt_prev !== nothing && size(Vt_prev) == size(Vt) && check(Jct.ctx, c_factorize_hint(Jct.ctx.h, Vt_prev, Int64(size(Vt, 1))))
     if Jsp === nothing
         check(Jct.ctx, c_factorize(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, zhandle(Z), Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
     else
@@ -1355,6 +1359,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
         print_first_line(fval, m > 0 ? maximum(abs, cval) : 0.0)
     end
     noise = nothing
+    prev_rank = -1                                                                      # rank of the previous iteration's factorisation
     while true
         grad!(g, x)                                                                     # :259
         waxpby!(d, -1.0, g, 0.0, g)                                                     # :262
@@ -1368,7 +1373,9 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
         rank = m
         if m > 0
             jac!(Jct, cval, x)                                                          # :283-284 (the device keeps only Jct)
-            rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp)     # :286-302
+            vprev = (i > 0 && prev_rank == m && ctx.options.warm_factorize) ? copy(Vt) : nothing
+            rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp, Vt_prev=vprev)     # :286-302
+            prev_rank = rank
             if !ineq                                                                    # :305-308
                 Ub = jsp === nothing ? (Z === nothing ? DeviceBasis(nothing, rank, (Jct, idecomp.W)) : DeviceBasis(Z, rank)) : DeviceBasis(Z, rank, (Jct, idecomp.W), jsp.h)
                 mul!(tmp_m, adjoint(Ub), d)

@@ -100,6 +100,7 @@ _SIGS = {
     "lfpsqp_mat_copy": [P, P, P],
     "lfpsqp_mat_rowscaled_view": [P, P, P, C.POINTER(P)],
     "lfpsqp_mat_view": [P, P, P, P, P, C.POINTER(P)],
+    "lfpsqp_factorize_hint": [P, P, c_i64],
     "lfpsqp_vec_hash_fill": [P, P, C.c_uint64, c_i64, c_dbl, c_dbl],
     "lfpsqp_mat_hash_fill": [P, P, C.c_uint64, c_i64, c_i64, c_dbl, c_i64, c_i64],
     "lfpsqp_gemv_t": [P, P, c_i64, P, P],

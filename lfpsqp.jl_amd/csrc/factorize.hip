@@ -721,6 +721,11 @@ static void small_svd(lfpsqp_ctx* ctx, int rows, int cols, const std::vector<dou
     const int rows_all = want_v ? rows + cols : rows;
     std::vector<double> X;
     bool dev = ctx && cols >= kDevJacobiMinCols && rows_all <= 1024 && ctx->tune_onepass >= 0;
+#ifdef LFPSQP_HIP_EMULATED
+    // (CPU emulator of the tests only: the block rounds of the wide shapes run ~100 x slower there than the host routine -- 12 s per factorisation
+    // at m = 300 -- so they are emulated on request: tests/test_capi_parity.py::test_small_svd_one_sided_jacobi sets the variable)
+    if (dev && rows_all > 256 && !getenv("LFPSQP_EMU_DEVICE_JACOBI")) dev = false;
+#endif
     if (dev) {
         X.assign((size_t)rows_all * cols, 0.0);
         for (int j = 0; j < cols; ++j) {
@@ -760,12 +765,86 @@ static double now_ms() {
 }
 static const bool kTraceFactorize = getenv("LFPSQP_TRACE_FACTORIZE") != nullptr;     // development: phase times on stderr
 
+// Warm start of the eigenproblem of G = L L' (lfpsqp_factorize_hint): V0 = the eigenvectors of a NEARBY Gram matrix -- the previous outer
+// iteration's (the constraint gradients move little between iterations; with linear constraints and no bounds, not at all).  The one-sided
+// Jacobi then runs on X = L' V0, whose columns are already nearly orthogonal (X'X = V0' G V0): one or two sweeps instead of eight on the
+// clustered spectra of the BASELINE configs.  X R = Q S  =>  G = (V0 R) S^2 (V0 R)', and V = V0 R = L^-T (Q S) by back substitution -- R is
+// never accumulated.  Used only when V0 is orthogonal to 1e-8 (checked: a rank-deficient or foreign hint is ignored) and m <= 256.
+static bool gram_eig_warm(lfpsqp_ctx* ctx, int m, const std::vector<double>& Lc, const std::vector<double>& V0, std::vector<double>& sig, std::vector<double>& V) {
+    if (m < 2 || m > 256 || (int)V0.size() != m * m) return false;
+    // orthogonality of the hint, probed with two fixed vectors: |V0'(V0 z) - z| <= 1e-8 |z| (4 m^2 flops; if V0'V0 = I + E, this is |E z|)
+    {
+        std::vector<double> z(m), t(m), b(m);
+        for (int probe = 0; probe < 2; ++probe) {
+            uint64_t h = 0x9E3779B97F4A7C15ull * (uint64_t)(probe + 1);
+            double zz = 0.0;
+            for (int i = 0; i < m; ++i) {
+                h ^= h >> 12; h ^= h << 25; h ^= h >> 27;
+                z[i] = (double)((h * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+                zz += z[i] * z[i];
+            }
+            std::fill(t.begin(), t.end(), 0.0);
+            for (int j = 0; j < m; ++j) {               // t = V0 z
+                const double* c = &V0[(size_t)j * m];
+                const double zj = z[j];
+#pragma omp simd
+                for (int i = 0; i < m; ++i) t[i] += c[i] * zj;
+            }
+            double err = 0.0;
+            for (int j = 0; j < m; ++j) {               // b = V0' t
+                const double* c = &V0[(size_t)j * m];
+                double sdot = 0.0;
+#pragma omp simd reduction(+ : sdot)
+                for (int i = 0; i < m; ++i) sdot += c[i] * t[i];
+                err += (sdot - z[j]) * (sdot - z[j]);
+            }
+            if (!(err <= 1e-16 * zz)) return false;
+        }
+    }
+    std::vector<double> X((size_t)m * m), Q, none;
+    for (int j = 0; j < m; ++j) {                     // X[:, j] = L' V0[:, j]: (L'v)_i = sum_{k >= i} L[k, i] v_k  (Lc column-major, lower: contiguous in k)
+        const double* v = &V0[(size_t)j * m];
+        for (int i = 0; i < m; ++i) {
+            const double* l = &Lc[(size_t)i * m];
+            double sdot = 0.0;
+#pragma omp simd reduction(+ : sdot)
+            for (int k = i; k < m; ++k) sdot += l[k] * v[k];
+            X[(size_t)j * m + i] = sdot;
+        }
+    }
+    small_svd(ctx, m, m, X, Q, sig, none, false);      // Q: unit columns, sorted by norm (descending); sig: the norms
+    if (!(sig[m - 1] > 0.0)) return false;
+    V.assign((size_t)m * m, 0.0);
+    for (int j = 0; j < m; ++j) {                     // L' y = sig_j Q[:, j]: back substitution on the upper triangular L'
+        double* y = &V[(size_t)j * m];
+        for (int i = m - 1; i >= 0; --i) {
+            const double* l = &Lc[(size_t)i * m];
+            double sdot = 0.0;
+#pragma omp simd reduction(+ : sdot)
+            for (int k = i + 1; k < m; ++k) sdot += l[k] * y[k];
+            y[i] = (sig[j] * Q[(size_t)j * m + i] - sdot) / l[i];
+        }
+        double nn = 0.0;
+        for (int i = 0; i < m; ++i) nn += y[i] * y[i];
+        nn = 1.0 / sqrt(nn);
+        for (int i = 0; i < m; ++i) y[i] *= nn;
+    }
+    return true;
+}
+
 static void gram_eig(lfpsqp_ctx* ctx, int m, const std::vector<double>& G, std::vector<double>& sig, std::vector<double>& V) {
     std::vector<double> Lc, Ug, lam;
     sig.assign(m, 0.0);
     const double t0 = now_ms();
     const bool pd = cholesky_lower(m, G, Lc);
     if (kTraceFactorize) fprintf(stderr, "[factorize] cholesky %.3f ms (pd=%d)\n", now_ms() - t0, (int)pd);
+    std::vector<double> V0;
+    if (ctx && ctx->warm_m == m) V0.swap(ctx->warm_V);       // a hint is consumed by the first factorisation of its size ...
+    if (ctx) { ctx->warm_m = 0; ctx->warm_V.clear(); }       // ... or dropped
+    if (pd && !V0.empty() && gram_eig_warm(ctx, m, Lc, V0, sig, V)) {
+        if (kTraceFactorize) fprintf(stderr, "[factorize] warm start used\n");
+        return;
+    }
     if (pd) {
         std::vector<double> none;
         small_svd(ctx, m, m, Lc, V, sig, none, false);
@@ -982,6 +1061,18 @@ int lfpsqp_small_svd(lfpsqp_ctx* ctx, int64_t rows, int64_t cols, const double* 
     for (size_t i = 0; i < u.size(); ++i) U[i] = u[i];
     for (size_t i = 0; i < sv.size(); ++i) S[i] = sv[i];
     for (size_t i = 0; V && i < v.size(); ++i) V[i] = v[i];
+    return 0;
+}
+
+int lfpsqp_factorize_hint(lfpsqp_ctx* ctx, const double* Vt_prev, int64_t m) {
+    LF_ARG(ctx, ctx && m >= 0 && (m == 0 || Vt_prev));
+    ctx->warm_m = 0;
+    ctx->warm_V.clear();
+    if (m < 2 || m > 256) return 0;                   // (no warm start outside the single-launch regime of the device Jacobi)
+    ctx->warm_V.resize((size_t)m * m);
+    for (int64_t j = 0; j < m; ++j)                   // Vt[k, i] = V[i, k]: row k of Vt is eigenvector k
+        for (int64_t i = 0; i < m; ++i) ctx->warm_V[(size_t)j * m + i] = Vt_prev[(size_t)i * m + j];
+    ctx->warm_m = (int)m;
     return 0;
 }
 

@@ -84,6 +84,8 @@ struct lfpsqp_ctx {
     double* h_m = nullptr;
     size_t m_cap = 0;
     // the weights of lfpsqp_elementwise's quadratic term (device, m_lin)
+    std::vector<double> warm_V;      // lfpsqp_factorize_hint: eigenvectors of a nearby Gram matrix (m x m, column j = vector j), consumed by the next factorisation
+    int warm_m = 0;
     double* d_view = nullptr;        // matrix views: [tau (8) | the raw sums of a second product before the rank-one term is folded in]
     double* d_nvec = nullptr;        // an n-vector of scratch (combined weights of the Gram matrix of a row-scaled view)
     size_t nvec_cap = 0;

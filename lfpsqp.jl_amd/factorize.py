@@ -26,13 +26,14 @@ def rmul(In: DeviceMatrix, W: np.ndarray, Out: DeviceMatrix) -> DeviceMatrix:
 
 
 def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix | None, w2: DeviceVector | None = None, eps_rank: float = 1e-10,
-          W: np.ndarray | None = None, Jsp=None):
+          W: np.ndarray | None = None, Jsp=None, Vt_prev: np.ndarray | None = None):
     """Thin factorisation diag(sqrt(w2)) Jct = U S Vt with U = diag(sqrt(w2)) Z.
     Returns (Sigma, Vt, rank); Z is overwritten (Jct is NOT destroyed, unlike dgesvd).  ``Z = None`` (dense Jct, ``W`` required): the
     basis Z = Jct @ W is not formed -- the caller keeps it in factored form (DeviceBasis(None, rank, generator=(Jct, W))).
     ``W`` (optional, m x m Fortran-ordered float64) receives the small factor with Z = Jct @ W.
     ``Jsp`` (optional SparseMatrix with the entries of the leading ``Jsp.m`` columns of Jct; Jct may then be None when there are no
-    further columns): the basis-forming products stream the nonzeros (lfpsqp_factorize_sp)."""
+    further columns): the basis-forming products stream the nonzeros (lfpsqp_factorize_sp).
+    ``Vt_prev`` (optional, the Vt of a previous call on a nearby matrix): warm start of the small eigenproblem (lfpsqp_factorize_hint)."""
     m = Jct.m if Jct is not None else Jsp.m
     ctx = Jct.ctx if Jct is not None else Jsp.ctx
     if W is not None:
@@ -40,6 +41,9 @@ def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix | None, w2: DeviceVector | N
     S = np.zeros(m)
     Vt = np.zeros((m, m), order='F')
     rank = c_i64()
+    if Vt_prev is not None and Vt_prev.shape == (m, m):
+        vp = np.asfortranarray(Vt_prev, dtype=np.float64)
+        ctx.check(ctx.L.lfpsqp_factorize_hint(ctx.h, vp.ctypes.data, m))
     if Jsp is not None:
         ctx.check(ctx.L.lfpsqp_factorize_sp(ctx.h, Jsp.h, Jct.h if Jct is not None else None, w2.h if w2 is not None else None,
                                             Z.h if Z is not None else None,

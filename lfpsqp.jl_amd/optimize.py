@@ -180,6 +180,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
         projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=(("new", n, m) if m > 0 else None), extra=1 if diagonal_hessian else 0)
         idecomp = InequalityDecomp(ctx, n, m, Jct, Z=projcgwork.basis)
     Z = idecomp.Z
+    prev_rank = -1                           # rank of the previous outer iteration's factorisation (its Vt warm-starts the next one)
     Sig, Vt = idecomp.Sigma, idecomp.Vt
     Wgen = np.zeros((m, m), order='F') if m > 0 else None                  # ksvd_'s small factor: Z == Jct @ Wgen
     ineqproject = InequalityDecompProject(idecomp) if ineq else None
@@ -233,7 +234,9 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
         if m > 0:
             jac_(Jct, cval, x)                                             # :283-284 (the device keeps only Jct)
             S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank, W=Wgen,
-                                  Jsp=getattr(c_, "Jsp", None))                                                # :286-302
+                                  Jsp=getattr(c_, "Jsp", None),                                                # :286-302
+                                  Vt_prev=(Vt if (i > 0 and prev_rank == m and ctx.options.warm_factorize) else None))
+            prev_rank = rank
             idecomp.W = Wgen
             idecomp.Jsp = getattr(c_, "Jsp", None)
             Sig[:] = S_

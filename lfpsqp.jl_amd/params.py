@@ -87,3 +87,7 @@ class DeviceOptions:
     # fused projected-CG iteration applies (diagonal Lagrangian Hessian, 4 .. 1024 constraints, dense constraint gradients); False: always
     # materialise Z = Jct W as rounds 1-2 did
     factored_basis: bool = True
+    # the small eigenproblem of the tangent setup starts from the previous outer iteration's eigenvectors (lfpsqp_factorize_hint): one or two
+    # Jacobi sweeps instead of eight.  Same Sigma / rank / span; the basis may differ from the cold call's by a rotation inside clusters of
+    # equal singular values, to which every use is invariant.  False: every factorisation starts cold
+    warm_factorize: bool = True

@@ -6,7 +6,7 @@ import bench
 
 
 def test_bench_json_contract(emu_lib, capsys):
-    out = bench.main(["--gpus", "1", "--steps", "3", "--warmup", "1", "--rows", "4096", "--cols", "8", "--cpu-sample-n", "4096", "--prewarm-seconds", "0.05"], lib=emu_lib)
+    out = bench.main(["--gpus", "1", "--steps", "3", "--warmup", "1", "--rows", "4096", "--cols", "8", "--cpu-sample-n", "4096", "--prewarm-seconds", "0.05", "--side-scale", "0.04"], lib=emu_lib)
     line = capsys.readouterr().out.strip().splitlines()[-1]
     d = json.loads(line)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",

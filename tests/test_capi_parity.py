@@ -568,7 +568,7 @@ def test_tuning_variants_agree(dev_ctx):
 
 
 @pytest.mark.parametrize("rows,cols,want_v", [(40, 12, True), (64, 64, True), (130, 130, True), (130, 130, False), (300, 200, True), (520, 500, True), (512, 512, False)])
-def test_small_svd_one_sided_jacobi(dev_ctx, rows, cols, want_v):
+def test_small_svd_one_sided_jacobi(dev_ctx, monkeypatch, rows, cols, want_v):
     """lfpsqp_small_svd: the replicated small step of the tangent setup (host Jacobi below 64 columns, the device block
     Jacobi of csrc/jacobi.hip from there on, with and without accumulated right vectors) against LAPACK on a graded matrix:
     singular values to HIGH RELATIVE accuracy (the matrix is well-conditioned up to column scaling -- the property the
@@ -576,6 +576,7 @@ def test_small_svd_one_sided_jacobi(dev_ctx, rows, cols, want_v):
     ctx = dev_ctx
     if _is_emu_ctx(ctx) and cols > 300:
         pytest.skip("kept small on the emulator")
+    monkeypatch.setenv("LFPSQP_EMU_DEVICE_JACOBI", "1")          # (emulator build: the device kernels for more than 256 rows run on request only)
     rng = np.random.default_rng(rows + cols)
     Q, _ = np.linalg.qr(rng.standard_normal((rows, cols)))
     Wm, _ = np.linalg.qr(rng.standard_normal((cols, cols)))

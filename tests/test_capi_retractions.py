@@ -231,6 +231,8 @@ def test_ill_conditioned_jacobian_takes_the_references_retraction(dev_ctx, case,
     outer iterates must agree with the oracle's dgesvd path to the accuracy the data allow: the tangent projector of an
     ill-conditioned block is only determined to eps * cond (for dgesvd as for any other backward-stable factorisation)."""
     ctx = dev_ctx
+    if _is_emu(ctx) and case == "duplicates" and bounds:
+        pytest.skip("ProjPenalty's inner pcg! with bounds: a minute of launch emulation; the GPU suite runs it")
     n, m = (1500, 8) if not _is_emu(ctx) else (400, 5)
     rng = np.random.default_rng(17)
     Q1, _ = np.linalg.qr(rng.standard_normal((n, m)))

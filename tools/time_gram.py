@@ -26,6 +26,9 @@ def timed(fn, reps=6):
     return best
 
 
+S0, Vt0, r0 = L.ksvd_(A, None, W=W)
+print(f"tangent setup (factored), plain: cold {timed(lambda: L.ksvd_(A, None, W=W)):7.3f} ms   warm (lfpsqp_factorize_hint) {timed(lambda: L.ksvd_(A, None, W=W, Vt_prev=Vt0)):7.3f} ms"
+      f"   with weights: cold {timed(lambda: L.ksvd_(A, None, w2=w2, W=W)):7.3f}   warm from the unweighted Vt {timed(lambda: L.ksvd_(A, None, w2=w2, W=W, Vt_prev=Vt0)):7.3f} ms")
 views = {"plain": A, "row scales": A.view(rs), "row scales + rank one": A.view(rs, u, w)}
 for name, M in views.items():
     print(f"{name:24s} gram {timed(lambda: L.gram(M)):7.3f} ms   weighted {timed(lambda: L.gram(M, w2=w2)):7.3f} ms   "
