@@ -91,10 +91,16 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
         }
         ts[slot][b] = v;
     }
-    if (threadIdx.x < kNRBW) xp[threadIdx.x] = ep.xnew[(int)threadIdx.x < ep.nb ? threadIdx.x : 0];
     unsigned active = 0u;                                     // uniform: the status words change between launches only
     for (int b = 0; b < ep.nb; ++b)
         if (ld_stat(ep.ist + 4 * b) == 0) active |= 1u << b;
+    // the (unconditional, see fetch) loads of a finished or missing trial go to a RUNNING trial's iterate: lines that are being read anyway,
+    // instead of 16 n more bytes per row from HBM for every trial that has converged or been retired
+    if (threadIdx.x < kNRBW) {
+        const int b = (int)threadIdx.x;
+        const int first = active ? __builtin_ctz(active) : 0;
+        xp[b] = ep.xnew[(b < ep.nb && ((active >> b) & 1u)) ? b : first];
+    }
     __syncthreads();
     nrb_gptr xpv[4];
 #pragma unroll

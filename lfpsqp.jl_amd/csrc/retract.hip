@@ -298,7 +298,9 @@ __device__ void nr_small_trial(const NRSmall& s, int init) {
     if (!init && ld_stat(s.ist) != 0) return;
     __shared__ double cnew[kNRMaxM], del[kNRMaxM], t2[kNRMaxM], dcs[kNRMaxM], tv[kNRMaxM];
     __shared__ double scratch[kNRThreads];
+    __shared__ int oldnan;                              // the PREVIOUS constraint values held a NaN (see the retirement rule below)
     const int m = s.m, tid = threadIdx.x;
+    if (tid == 0) oldnan = 0;
     const int lane = tid & 63, wave = tid >> 6;
     __syncthreads();                                    // (a previous trial of a batch may still be reading the arrays)
     for (int k = tid; k < m; k += kNRThreads) {
@@ -312,7 +314,9 @@ __device__ void nr_small_trial(const NRSmall& s, int init) {
         for (size_t e = tid; e < (size_t)m * m; e += kNRThreads) s.D[e] = s.Vt[e] / s.Sigma[e % m];      // :126-130
     } else {
         for (int k = tid; k < m; k += kNRThreads) {
-            dcs[k] = cnew[k] - s.cval[k];                                                       // :152
+            const double cold = s.cval[k];
+            if (cold != cold) oldnan = 1;                                                       // (every writer writes 1)
+            dcs[k] = cnew[k] - cold;                                                            // :152
             s.cval[k] = cnew[k];                                                                // :153
             del[k] = s.delta[k];
         }
@@ -358,13 +362,23 @@ __device__ void nr_small_trial(const NRSmall& s, int init) {
     if (tid == 0) {
         const double c = scratch[0];
         int64_t st = 0, fl = 0;
+        int64_t iter_out = iter;
         if (iter >= s.maxiter) { st = 1; fl = 1; }                       // :133 loop bound first: flag = (i == maxiter), :171-174
         else if (c < s.tol) { st = 1; fl = 0; }                          // :135
+        else if (!init && oldnan && c != c) {
+            // RETIRED: the constraint values were NaN before this step and are NaN after it.  NaN is absorbing here -- delta = -D c is NaN in
+            // every component, so the step just taken made every entry of the iterate NaN, and every later c!, Broyden update and step stays
+            // NaN -- so the reference's loop (src/retractions.jl:133-168: `norm(cval, Inf) < tol` is false for NaN) runs on to maxiter and returns
+            // flag 1 with maxiter iterations, an all-NaN iterate and NaN constraint values: exactly the state published here, maxiter - iter
+            // passes over the matrix earlier.  (The diverged trial steps of a failing line search end this way: config 4's first searches
+            // retire 9 of 16 trials.)
+            st = 1; fl = 1; iter_out = s.maxiter;
+        }
         if (st) s.ist[2] = fl;
-        s.ist[1] = iter;
+        s.ist[1] = iter_out;
         s.ist[0] = st;
         if (s.hstat) {
-            __hip_atomic_store(s.hstat + I_NR_ITER, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(s.hstat + I_NR_ITER, iter_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(s.hstat + I_NR_FLAG, fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(s.hstat + kNRRingOff + ((iter + 1) % kNRRing), st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(s.hstat + I_NR_STATUS, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
