@@ -193,6 +193,8 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
         const int64_t row = row0 + lrow + (int64_t)k * kStep;
         const bool valid = row < n;
         double vv[4];
+        // the row's part of y_retract! (a square root and two divisions, or a square root) once for this lane's four trial points
+        const YRowPre ypre = ST ? y_retract_pre(in.sh.yo, in.sh.q, in.sh.r, in.sh.s, in.sh.t) : YRowPre{0.0, 0.0, 0.0};
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             vv[v] = 0.0;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
                 NRStepE::Row w = in.sh;
                 w.xn = in.xn[v]; w.yn = in.yn[v];
                 double so[2] = {0.0, 0.0};                  // the new iterate (x and y halves), stored below through the GLOBAL pointer
-                vv[v] = e.apply1<ST>(row, 0u, y[v], valid, true, w, ball[v], so, 1);
+                vv[v] = e.apply1<ST>(row, 0u, y[v], valid, true, w, ball[v], so, 1, 0.0, ST ? &ypre : nullptr);
                 if (valid && !e.eval_only) {                 // (eval_only: the launch that evaluates c! at the trial points: nothing is updated)
                     xpv[v][row] = so[0];
                     if (ST) xpv[v][e.hs + row] = so[1];

@@ -81,14 +81,29 @@ struct PlainVec {  // GEMV-T producer reading the first N entries of a (possibly
 
 // y_retract! for one variable -- defined in ineq.hip's translation unit as a device inline; repeated here
 // (same statements, src/retractions.jl:459-497) so the fused Newton step can apply it in registers.
-__device__ __forceinline__ void y_retract_one_nr(double& xn, double& yn, double xo, double yo, double qq, double rr, double ss, double tt) {
+// In two parts: what depends on the ROW alone (the base point and the bound data: a square root and two divisions of the parabola, a square
+// root of the circle) and what depends on the trial point -- the batched step (nrbatch.h) does the first part once per row for all of a lane's
+// trial points; the same statements in the same order either way, so the single and the batched step round alike.
+struct YRowPre { double gx, gy, rho; };
+__device__ __forceinline__ YRowPre y_retract_pre(double yo, double qq, double rr, double ss, double tt) {
+    YRowPre p{0.0, 0.0, 0.0};
     if (ss == 0.0) {
-        xn = yn;
     } else if (qq == 0.0) {
         const double g1 = -ss, g2 = -2.0 * (yo - rr);
         const double ng = sqrt(g1 * g1 + g2 * g2);
-        const double ux = xo - xn + g1 / ng;
-        const double uy = yo - yn + g2 / ng;
+        p.gx = g1 / ng;
+        p.gy = g2 / ng;
+    } else {
+        p.rho = sqrt(tt);
+    }
+    return p;
+}
+__device__ __forceinline__ void y_retract_apply(double& xn, double& yn, double xo, double yo, double qq, double rr, double ss, const YRowPre& p) {
+    if (ss == 0.0) {
+        xn = yn;
+    } else if (qq == 0.0) {
+        const double ux = xo - xn + p.gx;
+        const double uy = yo - yn + p.gy;
         const double a = ss * (uy * uy);
         const double b = ux + 2.0 * ss * (yn - rr) * uy;
         const double c = xn + ss * ((yn - rr) * (yn - rr)) - rr;
@@ -98,13 +113,17 @@ __device__ __forceinline__ void y_retract_one_nr(double& xn, double& yn, double 
         xn += gam * ux;
         yn += gam * uy;
     } else {
-        const double c = rr, rho = sqrt(tt);
+        const double c = rr, rho = p.rho;
         const double dist = sqrt((xn - c) * (xn - c) + (yn - c) * (yn - c));
         const double y2 = c + rho * (yn - c) / dist;
         const double x2 = c + rho * (xn - c) / dist;
         yn = y2;
         xn = x2;
     }
+}
+__device__ __forceinline__ void y_retract_one_nr(double& xn, double& yn, double xo, double yo, double qq, double rr, double ss, double tt) {
+    const YRowPre p = y_retract_pre(yo, qq, rr, ss, tt);
+    y_retract_apply(xn, yn, xo, yo, qq, rr, ss, p);
 }
 
 // Elementwise transforms of the nonlinear constraint class lfpsqp_elementwise (kind as a double code: 0: t, 1: sin t, 2: t^2)
@@ -196,7 +215,7 @@ struct NRStepE {
     }
     template <bool ST>
     __device__ __forceinline__ double apply1(int64_t i, uint32_t o, double acc, bool valid, bool owner, const Row& w, double& red,
-                                             double* slot = nullptr, int sstride = 0, double sqv = 0.0) const {
+                                             double* slot = nullptr, int sstride = 0, double sqv = 0.0, const YRowPre* pre = nullptr) const {
         double xn = w.xn;
         if (ew_one && !eval_only) acc = fma(ew_phi1(w.kk, w.xo), acc, (i < n_x) ? 2.0 * w.xo * sqv : 0.0);      // (Jct(xold) u)_i from (A u)_i
         if (eval_only) {
@@ -211,7 +230,10 @@ struct NRStepE {
             double yn = w.yn;
             xn += w.ax * acc;
             yn += w.ay * acc;
-            if (valid) y_retract_one_nr(xn, yn, w.xo, w.yo, w.q, w.r, w.s, w.t);
+            if (valid) {
+                if (pre) y_retract_apply(xn, yn, w.xo, w.yo, w.q, w.r, w.s, *pre);       // (the row's part done once by the caller, nrbatch.h)
+                else y_retract_one_nr(xn, yn, w.xo, w.yo, w.q, w.r, w.s, w.t);
+            }
             if (valid && owner) {
                 if (slot) { slot[0] = xn; slot[sstride] = yn; }
                 else { put(xnew, o, xn); put(xnew + hs, o, yn); }
