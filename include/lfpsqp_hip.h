@@ -485,7 +485,9 @@ int lfpsqp_constraints_hess_diag(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons
 /* c!(cval, x): cval (host, m_lin + has_ball).  x has >= rows(Jct) entries (the x-half of a
  * stacked vector is fine). */
 int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, double* cval);
-/* jac!(J, cval, x): refreshes the x-dependent column(s) of Jct in place and evaluates cval */
+/* jac!(J, cval, x): refreshes the x-dependent column(s) of Jct in place and evaluates cval.  cval == NULL: the gradients only -- for a caller
+ * that holds c(x) already: the point an outer iteration starts from is the line search's accepted trial point, whose retraction returned
+ * c!(xnew) (src/optimize.jl:284 evaluates it again: one pass over the constraint gradients per outer iteration for nothing). */
 int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval);
 /* A user c!: x is the DEVICE vector (download it if the function is host code); return 0. */
 typedef int (*lfpsqp_cfun)(void* user, const lfpsqp_vec* x, double* cval);

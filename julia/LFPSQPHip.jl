@@ -747,6 +747,11 @@ function jac!(c::DeviceConstraints, Jct::DeviceMatrix, cval::Vector{Float64}, x:
     GC.@preserve c check(x.ctx, c_constraints_jac(x.ctx.h, Ref(ccons(c)), x.h, Jct.h, cval))
     return cval
 end
+# the gradients only (cval == NULL): for a caller that holds c(x) already -- the accepted retraction of the line search returned it
+function jac!(c::DeviceConstraints, Jct::DeviceMatrix, ::Nothing, x::DeviceVector)
+    GC.@preserve c check(x.ctx, c_constraints_jac(x.ctx.h, Ref(ccons(c)), x.h, Jct.h, Ptr{Float64}(C_NULL)))
+    return nothing
+end
 
 # A host c!(cval, x::Vector) behind the C callback of lfpsqp_retract_nr / lfpsqp_retract_pp: x is downloaded per evaluation
 mutable struct CfunBox
@@ -1360,6 +1365,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     end
     noise = nothing
     prev_rank = -1                                                                      # rank of the previous iteration's factorisation
+    cval_current = m > 0                                                                # cval == c(x): after the evaluation above and after every accepted retraction
     while true
         grad!(g, x)                                                                     # :259
         waxpby!(d, -1.0, g, 0.0, g)                                                     # :262
@@ -1372,7 +1378,8 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
         ineq && inequality_gradient!(idecomp, x, idata)                                 # :277
         rank = m
         if m > 0
-            jac!(Jct, cval, x)                                                          # :283-284 (the device keeps only Jct)
+            # :283-284 (the device keeps only Jct); a device-resident class skips the re-evaluation of c(x) when cval holds it already
+            (cval_current && jac! isa DeviceConstraints) ? jac!(jac!, Jct, nothing, x) : jac!(Jct, cval, x)
             vprev = (i > 0 && prev_rank == m && ctx.options.warm_factorize) ? copy(Vt) : nothing
             rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp, Vt_prev=vprev)     # :286-302
             prev_rank = rank
@@ -1449,6 +1456,8 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             flag, iter1, iter2, newf, f_diff, step_diff, α = exact_linesearch!(xnew, x, n, d, f, fval, retract_method, cval, c!, param, exact_work)
         end
         copyto!(x, xnew)                                                                # :424-427
+        # (Armijo's accepted trial is the last one retracted: cval == c!(xnew); the exact search returns a saved best point, cval is the last trial's)
+        cval_current = flag == 0 && m > 0 && (param.linesearch == armijo || param.disable_linesearch)
         fval = newf
         push!(obj_values, fval)
         disp && print_iter(i + 1, fval, m > 0 ? maximum(abs, cval) : 0.0, f_diff, step_diff, steptype, tn_iter, tn_res, mtype, iter1, iter2, α, flag)

@@ -816,7 +816,7 @@ int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, con
 
 int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval) {
     LF_RANGE("lfpsqp_constraints_jac");
-    LF_ARG(ctx, ctx && cons_ok(cons) && x && Jct && cval && x->n >= cons->Jct->n && Jct->p == cons->Jct->p && Jct->rs == cons->Jct->rs && Jct->ru == cons->Jct->ru);
+    LF_ARG(ctx, ctx && cons_ok(cons) && x && Jct && x->n >= cons->Jct->n && Jct->p == cons->Jct->p && Jct->rs == cons->Jct->rs && Jct->ru == cons->Jct->ru);
     if (const lfpsqp_elementwise* ew = cons->ew) {             // Jct[:, :m_lin] = diag(phi'(x)) A + 2 x qw'
         const int64_t N = Jct->n;
         const int ml = (int)cons->m_lin;
@@ -839,6 +839,7 @@ int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, cons
     if (cons->has_ball)
         LF_TRY((run_vec<BallColF, 0, NoPost>(ctx, Jct->n, BallColF{x->p, Jct->p + cons->m_lin * Jct->ld, cons->n_x, cons->slack_row}, 0u,
                                              nullptr, NoPost())));
+    if (!cval) return 0;                                      // gradients only: the caller holds c(x) already (an accepted retraction returns it)
     return cons_eval(ctx, cons, x, cval);
 }
 

@@ -202,6 +202,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     exact_work = ExactLinesearchWork(x) if param.linesearch == LinesearchOption.exact and not param.disable_linesearch else None
 
     i = 0
+    cval_current = m > 0                     # cval == c(x): true after the evaluation below, and after every accepted retraction
     f_diff = step_diff = kkt_diff = math.inf
     fval = f(x)
     obj_values.append(fval)
@@ -232,7 +233,12 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             inequality_gradient_(idecomp, x, ineqdata)                     # :277
         rank = m
         if m > 0:
-            jac_(Jct, cval, x)                                             # :283-284 (the device keeps only Jct)
+            # :283-284 (the device keeps only Jct).  A device-resident class does not evaluate c(x) again when cval holds it: x is the point the
+            # initial c! or the line search's accepted retraction evaluated it at (the reference's jac! recomputes it: one pass for nothing)
+            if cval_current and getattr(jac_, "__self__", None) is c_ and hasattr(c_, "_c"):
+                jac_(Jct, cval, x, evaluate=False)
+            else:
+                jac_(Jct, cval, x)
             S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank, W=Wgen,
                                   Jsp=getattr(c_, "Jsp", None),                                                # :286-302
                                   Vt_prev=(Vt if (i > 0 and prev_rank == m and ctx.options.warm_factorize) else None))
@@ -330,6 +336,9 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
                 xnew, x, n, d, f, fval, retract_method, cval, c_, param, exact_work)
 
         x.copy_from(xnew)                                                  # :424-427
+        # (Armijo's accepted trial is the last one retracted, and its retraction returned c!(xnew); the exact search returns a SAVED best point
+        # while cval holds the values of the last trial retracted -- as in the reference, src/linesearch.jl:96-230)
+        cval_current = (flag == 0 and m > 0 and (param.linesearch == LinesearchOption.armijo or param.disable_linesearch))
         fval = newf
         obj_values.append(fval)
         if disp:

@@ -47,10 +47,11 @@ class DeviceConstraints:
 
     __call__ = c_
 
-    def jac_(self, Jct: DeviceMatrix, cval: np.ndarray, x: DeviceVector):
+    def jac_(self, Jct: DeviceMatrix, cval: np.ndarray, x: DeviceVector, evaluate: bool = True):
+        """``evaluate=False``: the gradients only (cval untouched) -- for a caller that holds c(x) already."""
         ctx = x.ctx
         cc = self._c()
-        ctx.check(ctx.L.lfpsqp_constraints_jac(ctx.h, C.byref(cc), x.h, Jct.h, cval.ctypes.data_as(_capi.PD)))
+        ctx.check(ctx.L.lfpsqp_constraints_jac(ctx.h, C.byref(cc), x.h, Jct.h, cval.ctypes.data_as(_capi.PD) if evaluate else None))
         return cval
 
 
