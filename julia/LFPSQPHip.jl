@@ -881,6 +881,16 @@ function batch_width(ctx::HipContext, retract_method, c!, prev_failures::Int)
     width < 2 && return 1
     return opt > 1 ? min(opt, width) : min(width, max(4, prev_failures + 2))
 end
+# the widest pass of a search: a pass whose trials ALL failed is followed by one twice as wide, up to this
+function batch_cap(ctx::HipContext, retract_method, c!)
+    (retract_method isa NR && c! isa DeviceConstraints) || return 1
+    opt = ctx.options.ls_batch
+    opt == 1 && return 1
+    w = Ref{Cint}(0)
+    GC.@preserve retract_method c! check(ctx, c_retract_nr_batch_width(ctx.h, Ref(cbasis(retract_method.U)), Ref(ccons(c!)), w))
+    width = Int(w[])
+    return width < 2 ? 1 : (opt > 1 ? min(opt, width) : width)
+end
 # several trial points of one Armijo search retracted together (lfpsqp_retract_nr_batch); `nothing` when this configuration cannot
 function retract_nr_batch!(cvals::Matrix{Float64}, xnews::Vector{DeviceVector}, c!::DeviceConstraints, xtildes::Vector{DeviceVector}, x::DeviceVector, method::NR)
     nb = length(xnews)
@@ -1059,6 +1069,7 @@ function armijo!(xnew::DeviceVector, x::DeviceVector, n::Int, d::DeviceVector, g
     step = xtilde
     ahead = Dict{Float64,Tuple{Int,Int,Int,DeviceVector,Vector{Float64}}}()
     nbatch = batch_width(x.ctx, retract_method, c!, work.prev_failures)
+    nbatch_cap = nbatch > 1 ? batch_cap(x.ctx, retract_method, c!) : 1
     failed_once = work.prev_failed
     any_failed = false
     n_failed = 0
@@ -1088,6 +1099,7 @@ function armijo!(xnew::DeviceVector, x::DeviceVector, n::Int, d::DeviceVector, g
                     end
                     flag, iter1, iter2 = got[1]
                     copyto!(xnew, work.xns[1]); cval .= cvs[:, 1]
+                    all(r -> r[1] > 0, got) && (nbatch = min(nbatch_cap, 2 * nbatch))   # every trial of the pass failed: the next takes twice as many
                 else
                     nbatch = 1
                 end

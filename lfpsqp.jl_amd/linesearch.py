@@ -52,6 +52,16 @@ def _batch_width(work, retract_method, c_):
     return min(width, max(4, int(getattr(work, "prev_failures", 0)) + 2))
 
 
+def _batch_cap(work, retract_method, c_):
+    """The widest pass of this search: a batch whose trials ALL failed is followed by one twice as wide, up to this (the first search of a
+    run knows nothing of the failures ahead: config 4's takes 25 trial steps -- six passes of four, or 4 + 8 + 16)."""
+    opt = int(getattr(work, "ls_batch", 1))
+    if opt == 1:
+        return 1
+    width = retract_nr_batch_width_(c_, retract_method)
+    return 1 if width < 2 else (min(opt, width) if opt > 1 else width)
+
+
 def _step_norm(step, n_head):
     """norm(view(step, 1:n)) (src/linesearch.jl:66): only the first n entries."""
     from .device import nrm2_head
@@ -74,6 +84,7 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
     # below consumes them exactly as it would have computed them one by one.
     ahead = {}
     nbatch = _batch_width(work, retract_method, c_)          # (only Newton retractions on device-resident constraints batch)
+    nbatch_cap = _batch_cap(work, retract_method, c_) if nbatch > 1 else 1
     failed_once = bool(getattr(work, "prev_failed", False))   # searches in a failing regime batch from their first trial
     any_failed = False
     n_failed = 0
@@ -100,6 +111,8 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
                     flag, iter1, iter2 = got[0]
                     xnew.copy_from(xns[0])
                     cval[:] = cvs[0]
+                    if all(res[0] > 0 for res in got):         # every trial of the pass failed: the next pass takes twice as many
+                        nbatch = min(nbatch_cap, 2 * nbatch)
                 else:
                     nbatch = 1                                 # this configuration cannot batch
             if got is None:

@@ -57,7 +57,8 @@ def oracle_runs():
 def runs(request, emu_lib, tmp_path_factory):
     world = request.param
     d = tmp_path_factory.mktemp(f"mr{world}")
-    return world, _run(d, world, "p2p"), _run(d, world, "gloo")
+    # (the gloo callback transport differs from the peer-to-peer one in the all-reduce alone: it runs at four ranks, the library's own at four and eight)
+    return world, _run(d, world, "p2p"), (_run(d, world, "gloo") if world == 4 else None)
 
 
 def test_uneven_and_empty_shards(runs):
@@ -72,7 +73,7 @@ def test_uneven_and_empty_shards(runs):
 
 def test_replicated_results_agree_bit_for_bit_across_ranks(runs):
     world, p2p, gloo = runs
-    for run in (p2p, gloo):
+    for run in (r_ for r_ in (p2p, gloo) if r_ is not None):
         for key in ("sum9000", "dot", "amax", "S", "Vt", "it", "nr", "lam", "c3nr_lam", "c3nr_obj", "c3pp_lam", "c3pp_obj", "c4_lam", "c4_obj",
                     "c4_r1", "c4_alpha"):
             for r in range(1, world):
@@ -87,14 +88,15 @@ def test_p2p_sums_in_rank_order(runs):
     for r in range(1, world):
         acc = acc + synth.hash_vector(7 + r, 9000)
     np.testing.assert_array_equal(p2p[0]["sum9000"], acc)
-    np.testing.assert_allclose(gloo[0]["sum9000"], acc, rtol=0, atol=1e-14)      # (gloo's ring associates differently)
+    if gloo is not None:
+        np.testing.assert_allclose(gloo[0]["sum9000"], acc, rtol=0, atol=1e-14)  # (gloo's ring associates differently)
 
 
 def test_sharded_tangent_setup_and_projcg_match_the_oracle(runs, oracle_runs):
     world, p2p, gloo = runs
     av = 4.0 * synth.hash_vector(3, N) + 5.0
     bv = synth.hash_vector(4, N)
-    for run in (p2p, gloo):
+    for run in (r_ for r_ in (p2p, gloo) if r_ is not None):
         Z = np.vstack([w["Z"] for w in run])
         np.testing.assert_allclose(run[0]["S"], oracle_runs["S"], rtol=1e-12)
         np.testing.assert_allclose(Z.T @ Z, np.eye(M), atol=1e-13)
@@ -110,7 +112,7 @@ def test_sharded_tangent_setup_and_projcg_match_the_oracle(runs, oracle_runs):
 def test_sharded_config3_matches_the_oracle(runs, oracle_runs, tag):
     world, p2p, gloo = runs
     xr, objr, lamr, tir = oracle_runs["c3" + tag]
-    for run in (p2p, gloo):
+    for run in (r_ for r_ in (p2p, gloo) if r_ is not None):
         x = np.concatenate([w[f"c3{tag}_x"] for w in run])
         assert int(run[0][f"c3{tag}_iter"]) == tir.iter
         assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
@@ -122,7 +124,7 @@ def test_sharded_config4_matches_the_oracle(runs, oracle_runs):
     world, p2p, gloo = runs
     xr, objr, lamr, tir = oracle_runs["c4"]
     tr = oracle_runs["c4_trace"]
-    for run in (p2p, gloo):
+    for run in (r_ for r_ in (p2p, gloo) if r_ is not None):
         x = np.concatenate([w["c4_x"] for w in run])
         assert x.size == N                                           # (returned truncated, src/optimize.jl:68; the slack variable rode on the last rank)
         assert int(run[0]["c4_iter"]) == tir.iter
