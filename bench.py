@@ -620,6 +620,26 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         itf, _ = L.projcg_(xf, None, Af, basis, bf, None, tol=1e-300, maxit=30, work=wf, n_global=n, want_lambda=False)
         ctx.sync(); pf[tag] = (time.perf_counter() - t0) * 1e3 / max(itf, 1)
         pf[tag + "_xnorm"] = L.nrm2(xf)
+    # ... and over a matrix VIEW diag(rs) J + u w' (lfpsqp_mat_view: the streamed constraint gradients of the nonlinear class, whose jac! then writes
+    # two n-vectors instead of n x m doubles): the same fused kernel behind the functor wrapper, the same iterates (rs = 1, u w' = 0 here)
+    view_info = None
+    try:
+        rs_v, u_v, w_v = ctx.vector(n_loc).fill(1.0), ctx.vector(n_loc), ctx.vector(m)
+        Jv = J.view(rs_v, u_v, w_v)
+        bv = L.DeviceBasis(None, m, generator=(Jv, Wg))
+        L.projcg_(xf, None, Af, bv, bf, None, tol=1e-300, maxit=5, work=wf, n_global=n, want_lambda=False)
+        ctx.sync(); t0 = time.perf_counter()
+        itv, _ = L.projcg_(xf, None, Af, bv, bf, None, tol=1e-300, maxit=30, work=wf, n_global=n, want_lambda=False)
+        ctx.sync(); view_ms = (time.perf_counter() - t0) * 1e3 / max(itv, 1)
+        view_info = {"projcg_iter_ms_over_a_view": view_ms, "projcg_iter_ms_factored": pf["factored"],
+                     "xnorm_rel_diff": abs(L.nrm2(xf) - pf["factored_xnorm"]) / pf["factored_xnorm"],
+                     "note": "projected-CG iteration with the generator of the factored basis given as a view diag(rs) J + u w' (rs = 1, u = 0) "
+                             "against the plain matrix: what streaming the gradients of the nonlinear class costs in the hot loop (16 more bytes per row)"}
+        Jv.free()
+        for v_ in (rs_v, u_v, w_v):
+            v_.free()
+    except Exception as e:                                      # (a side measurement must never take the bench line down)
+        view_info = {"error": repr(e)[:200]}
     for v_ in (bf, xf, wf.g, wf.d, wf.rp, Af.dg):
         v_.free()
     nr1_bytes = 8.0 * n_loc * m + 24.0 * n_loc                # J pass + xnew read/write + v
@@ -713,7 +733,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             "nr_batch4_step_ms": nr_batch_ms, "nr_batch4_step_kernel_ms": nr_batch_kernel_ms,
             "nr_batch8_step_ms": nrb_ms.get(8), "nr_batch8_step_kernel_ms": nrb_kernel_ms.get(8), "nr_batch16_step_ms": nrb_ms.get(16), "nr_batch16_step_kernel_ms": nrb_kernel_ms.get(16),
             "nr_batch_note": "ms per Newton step of a 100-step call for 4 / 8 / 16 trial points without bounds (4: VALU form of the one-pass kernel; 8, 16: v_mfma_f64_16x16x4_f64, csrc/nrbatch.h); wall includes the per-trial start (copy, first c! pass) and the trials' m x m Broyden kernels", "projcg_call_iter_materialised_ms": pf["materialised"], "projcg_call_iter_factored_ms": pf["factored"],
-            "projcg_factored_xnorm_rel_diff": abs(pf["factored_xnorm"] - pf["materialised_xnorm"]) / pf["materialised_xnorm"], "nr_iters_timed": its_long, "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit), "pcg_iter_kernel_chain": pcg_chain,
+            "matrix_view": view_info, "projcg_factored_xnorm_rel_diff": abs(pf["factored_xnorm"] - pf["materialised_xnorm"]) / pf["materialised_xnorm"], "nr_iters_timed": its_long, "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit), "pcg_iter_kernel_chain": pcg_chain,
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies; the Gram kernel computes the upper "
                     "triangle only (16 x 16 tiles on and above the diagonal): gram_TFLOPs_executed counts that work, ..._of_the_full_product 2 n m^2"}
 
