@@ -117,7 +117,7 @@ def _amax_host(v):
 def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: LFPSQPParams | None = None, *, ctx: Context,
                   n_global: int | None = None, trace=None):
     """src/optimize.jl:119-443.  x0 / xl / xu are host arrays (this rank's shard)."""
-    from .projpenalty import ProjPenalty, ProjPenaltyWork
+    from .projpenalty import LazyProjPenaltyWork, ProjPenalty
     from . import _capi
     import ctypes as C
     param = param or LFPSQPParams()
@@ -195,7 +195,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
 
     nr = NR(None, Sig, Vt, param.eps_c, param.maxiter_retract, NRWork(m), ineq, ineqdata)
     pp = ProjPenalty(jac_, None, Sig, Vt, m, param.mu0, param.eps_c, param.maxiter_retract, param.maxiter_pcg,
-                     ProjPenaltyWork(ctx, m, n, ineq, against=Jct if m > 0 else None), ineq, idecomp, ineqdata)
+                     LazyProjPenaltyWork(ctx, m, n, ineq, against=Jct if m > 0 else None), ineq, idecomp, ineqdata)
     euc = Euclidean()
     yr = YRetract(ineqdata) if ineq else None
     armijo_work = ArmijoWork(x)

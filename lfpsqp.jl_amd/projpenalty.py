@@ -50,6 +50,23 @@ class ProjPenaltyWork:  # src/retractions.jl:21-33 (J itself is the shared devic
                             g("ones"), g("zeros"), g("q"), g("i11"), g("i12"), g("i22"), 1 if self.precondition else 0)
 
 
+class LazyProjPenaltyWork:
+    """ProjPenaltyWork allocated on FIRST USE.  The driver builds its ProjPenalty method up front like the reference (src/optimize.jl:196-212) but
+    most runs retract with Newton-Raphson and never touch it -- and its five n-vectors are placed by trial against Jct (Context.vectors_placed):
+    72 ms of a 150 ms one-iteration run at n = 1e7, m = 128 (tools/profile_setup.py)."""
+
+    def __init__(self, *args, **kwargs):
+        self._args, self._kwargs, self._w = args, kwargs, None
+
+    def _get(self):
+        if self._w is None:
+            self._w = ProjPenaltyWork(*self._args, **self._kwargs)
+        return self._w
+
+    def __getattr__(self, name):                       # (only reached for attributes this wrapper does not have itself)
+        return getattr(self._get(), name)
+
+
 @dataclass
 class ProjPenalty:  # src/retractions.jl:35-49
     jac_: object
