@@ -63,3 +63,47 @@ def test_config4_strict_trajectory_at_1e6_by_16(ctx):
     print(f"[parity n=1e6 m=16 config 4] {ti.iter} outer iterations, worst iterate deviation {worst:.2e}")
     np.testing.assert_allclose(obj, objr, rtol=1e-11)
     np.testing.assert_allclose(lam, lamr, rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("do_project_retract", [False, True])
+def test_nonlinear_class_with_streamed_gradients_at_1e6_by_16(ctx, do_project_retract):
+    """The nonlinear constraint class c(x) = A' phi(x) + qw x'x - b (mixed kinds and the common quadratic term) at n = 1e6, m = 16 with its
+    gradients STREAMED through a matrix view (jac! writes two n-vectors, src/autodiff_generators.jl:60-66 writes n x m doubles), from a start on
+    the manifold: `optimize` against the oracle's run with host callables of the same functions -- counts, step types, retraction iterations
+    equal, iterates within 1e-10 after every outer iteration; Newton-Raphson and the reference's default ProjPenalty retraction."""
+    from .test_elementwise import _trace_compare, ew_callables
+    n, m, maxiter = 1_000_000, 16, 5
+    rng = np.random.default_rng(61)
+    Ah = np.asfortranarray(rng.standard_normal((n, m)) / np.sqrt(n))
+    kind = rng.integers(0, 3, n).astype(np.float64)
+    qw = 0.01 * rng.standard_normal(m)
+    bh = 0.1 * rng.standard_normal(m)
+    x0 = 0.2 * rng.standard_normal(n)
+    target = 0.5 * rng.standard_normal(n)
+    cv0 = np.zeros(m)
+    ew_callables(Ah, kind, qw, bh)[0](cv0, x0)
+    bh = bh + cv0                                                                     # x0 on the manifold
+    c_, jac_, hdiag = ew_callables(Ah, kind, qw, bh)
+    cons = L.ElementwiseConstraints(ctx, ctx.matrix(n, m, Ah), bh, kind=kind, qw=qw)
+    assert cons.streamed
+    prob = L.SeparableElementwiseBox(ctx, cons, 0, 1.0, target)
+    tr, tr0 = [], []
+    xd, obj, lam, ti = prob.optimize(x0, L.LFPSQPParams(do_project_retract=do_project_retract, maxiter=maxiter, disp=L.DisplayOption.off), trace=tr)
+
+    f = lambda xx: float(np.sum((xx[:n] - target) ** 2))
+
+    def grad_(g, xx):
+        g[:n] = 2.0 * (xx[:n] - target)
+
+    def hlv_(dest, src, xx, lam_):
+        dest[:n] = (2.0 + hdiag(xx, lam_)) * src[:n]
+
+    xr, objr, lamr, tir = R.optimize_core(f, grad_, c_, jac_, hlv_, x0, None, None, m,
+                                          R.LFPSQPParams(do_project_retract=do_project_retract, maxiter=maxiter, disp=R.DisplayOption.off), trace=tr0)
+    assert ti.iter == tir.iter and ti.condition.name == tir.condition.name
+    _trace_compare(tr, tr0)
+    dev = np.linalg.norm(xd - xr) / np.linalg.norm(xr)
+    print(f"[parity n=1e6 m=16 nonlinear class, streamed gradients, {'PP' if do_project_retract else 'NR'}] {ti.iter} outer iterations, "
+          f"|x - x_oracle| / |x_oracle| = {dev:.2e}")
+    assert dev <= 1e-10
+    np.testing.assert_allclose(obj, objr, rtol=1e-10)
