@@ -512,7 +512,7 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
  * src/linesearch.jl:49-60) are independent, so they share every pass over Jct -- one launch advances all unfinished
  * trials by one Newton step.  Per trial the arithmetic, the convergence test and the outputs are those of
  * lfpsqp_retract_nr: xnew[b], cval[b*m .. b*m+m), flags[b], iters[b].  Needs the one-stream step (U->A / U->W known,
- * device-resident constraints without a sparse twin, 4..256 columns); returns LFPSQP_ERR_UNSUPPORTED otherwise (retract one by one then).
+ * device-resident constraints without a sparse twin, 4..1024 columns); returns LFPSQP_ERR_UNSUPPORTED otherwise (retract one by one then).
  * Two trials run on the VALU form of the one-pass kernel (up to four where the other form does not apply); 3..16 on the matrix cores (v_mfma_f64_16x16x4_f64: both products of a
  * step are contractions once the trials are stacked), for up to 132 generator columns and 128 linear constraints.
  * lfpsqp_retract_nr_batch_width: how many trials a pass takes for this basis and these constraints -- 16, 4 or 0 (cannot batch). */

@@ -450,7 +450,6 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
     ++ctx->launch_epoch;
     const int cpl = (ncN + 3) / 4;                // column groups
     const bool wide = cpl > 64;                   // more than 256 columns: the four waves of a workgroup split the columns
-    if (wide && NA > 1) return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "batched one-pass product with more than 256 columns");
     const int round_rows = wide ? 16 : kOnepassRound;
     const int64_t rounds = (n + round_rows - 1) / round_rows;
     const int nout = NV * ncT + NRED;
@@ -465,20 +464,18 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
         constexpr StageCfg kC = onepass_stage<EP>(CPL, WIDE, NA);                                                                    \
         constexpr int kG = kC.rounds, kW = kC.waves;                                                                                 \
         constexpr bool kL = (kG == 0 || (WIDE)) && kOpLacc && NA == 1 && (CPL) > 16 && (CPL) <= 33;                                 \
-        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL, kG, kW>(ctx, rounds, wg_per_cu_cap);                \
+        grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, NA, kL, kG, kW>(ctx, rounds, wg_per_cu_cap);                \
         LF_TRY(ensure_part(ctx, (size_t)grid * part_ld + reduce_scratch(part_ld)));                                                  \
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);                                                                              \
-        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, (WIDE ? 1 : NA), kL, kG, kW>), dim3((unsigned)grid), dim3(kThreads), \
+        hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, NA, kL, kG, kW>), dim3((unsigned)grid), dim3(kThreads), \
                            0, ctx->stream, M->p, M->ld, ncN, ncT, n, rounds, t, t_stride, ep, ctx->part, part_ld, ctx->stage_cap);    \
     } while (0)
         if (wide) {
-            if constexpr (NA == 1) {
-                const int cplw = (cpl + kWaves - 1) / kWaves;     // column groups per wave
-                if (cplw <= 24) LF_OP(24, false, true);
-                else if (cplw <= 32) LF_OP(32, false, true);
-                else if (cplw <= 48) LF_OP(48, false, true);
-                else LF_OP(64, false, true);
-            }
+            const int cplw = (cpl + kWaves - 1) / kWaves;     // column groups per wave
+            if (cplw <= 24) LF_OP(24, false, true);
+            else if (cplw <= 32) LF_OP(32, false, true);
+            else if (cplw <= 48) LF_OP(48, false, true);
+            else LF_OP(64, false, true);
         } else if (cpl <= 4) LF_OP(4, false, false);
         else if (cpl <= 8) LF_OP(8, false, false);
         else if (cpl <= 16) LF_OP(16, false, false);

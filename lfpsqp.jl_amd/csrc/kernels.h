@@ -506,7 +506,6 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
     constexpr int NRL = kSplit ? (NRED + 3) / 4 : NRED;   // scalar running sums per lane
     constexpr bool kRowAhead = sizeof(typename EP::Row) <= 16 * sizeof(double);   // fetch the next tile's row inputs a tile ahead
     static_assert(!(EXACT && WIDE), "the exact variant exists for the narrow kernel only");
-    static_assert(NA == 1 || !WIDE, "batched first products exist for the narrow kernel only");
     // LDS: ts (first-product coefficients), accx (wide form: per-wave partial sums of the first product), and ONE buffer
     // that holds the running sums of the second product during the tile loop (LACC) and the per-wave column sums after it
     constexpr int kRedD = (WIDE ? 1 : kWaves) * NV * NC;
@@ -521,7 +520,7 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
     __shared__ double buf[kBufD];
     __shared__ double stg_own[(LACC && STG > 0) ? kStgD : 1];
     double* const stg = (LACC && STG > 0) ? stg_own : buf;
-    __shared__ double accx[WIDE ? 2 : 1][WIDE ? kWaves : 1][WIDE ? RW : 1];
+    __shared__ double accx[WIDE ? 2 : 1][WIDE ? NA : 1][WIDE ? kWaves : 1][WIDE ? RW : 1];
     auto red = [&](int w, int qq, int sl) -> double& { return buf[(w * NV + qq) * NC + sl]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = (lane & 3) | ((lane >> 4) << 2), h = (lane >> 2) & 3;
@@ -603,11 +602,15 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
             s += __shfl_xor(s, 8);
             acc[b] = s;
         }
-        if constexpr (WIDE) {           // ... and over the four waves' column ranges (NA == 1 in the wide form)
-            const int b = k & 1;
-            if (h == 0) accx[b][wave][r] = acc[0];
+        if constexpr (WIDE) {           // ... and over the four waves' column ranges (one barrier for all NA right-hand sides)
+            const int pb = k & 1;
+            if (h == 0) {
+#pragma unroll
+                for (int b = 0; b < NA; ++b) accx[pb][b][wave][r] = acc[b];
+            }
             __syncthreads();
-            acc[0] = (accx[b][0][r] + accx[b][1][r]) + (accx[b][2][r] + accx[b][3][r]);
+#pragma unroll
+            for (int b = 0; b < NA; ++b) acc[b] = (accx[pb][b][0][r] + accx[pb][b][1][r]) + (accx[pb][b][2][r] + accx[pb][b][3][r]);
         }
         const int64_t row = row0 + lrow + (int64_t)k * kStep;
         typename EP::Row in_next = in;

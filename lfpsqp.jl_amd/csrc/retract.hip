@@ -502,7 +502,7 @@ struct NRStepBatchRow {
             if (ld_stat(ist[b]) == 0) w.active |= 1u << b;
         return w;
     }
-    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[NB], bool valid, bool, bool, const Uni&,
+    __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[NB], bool valid, bool, bool lead, const Uni&,
                                           const Row& w, double (&v)[NB], double (&red)[NB]) const {
         const int h = (int)((threadIdx.x >> 2) & 3u), tr = h % NB;
         double acc_mine = acc[0];
@@ -515,7 +515,9 @@ struct NRStepBatchRow {
 #ifdef LFPSQP_ABLATE_NRB_STORE                               /* timing experiment: the batched step without its stores (results are wrong) */
             mine = eb.apply1<ST>(i, o, acc_mine, valid, false, w.sh, ball);
 #else
-            mine = eb.apply1<ST>(i, o, acc_mine, valid, h < NB, w.sh, ball);     // (h < NB: one storing lane per row and trial)
+            // (h < NB: one storing lane per row and trial; in the wide form all four waves hold the row and compute its update -- wave 0, `lead`,
+            // stores and counts)
+            mine = eb.apply1<ST>(i, o, acc_mine, valid, h < NB && lead, w.sh, ball);
 #endif
         }
         const int lane = (int)(threadIdx.x & 63u);
@@ -1063,14 +1065,14 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
 
 
 // How many trial points lfpsqp_retract_nr_batch takes per pass for this basis and these constraints: 16 (the step on the matrix cores: up
-// to 132 generator columns / 128 linear constraints), 4 (the VALU form: up to 256 columns) or 0 (cannot batch: no generator, sparse
+// to 132 generator columns / 128 linear constraints), 4 (the VALU form: up to 1024 columns, the wide form of the one-pass kernel from 257 on) or 0 (cannot batch: no generator, sparse
 // constraint gradients, the nonlinear class, a shape without the one-stream step).
 int lfpsqp_retract_nr_batch_width(const lfpsqp_ctx* ctx, const lfpsqp_basis* U, const lfpsqp_constraints* cons, int* width) {
     if (!ctx || !U || !cons || !width || !cons->Jct) return LFPSQP_ERR_ARG;
     *width = 0;
     if (cons->Jsp || cons->ew || !plain_mat(cons->Jct)) return 0;
     const int ml = (int)cons->m_lin;
-    const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kColChunk) ? (int)U->A->m : 0;
+    const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kOnepassMaxCols) ? (int)U->A->m : 0;
     if (!wm || U->ncols > kNRMaxM || !onepass_cw(ctx, wm, cons->Jct->ld, cons->Jct->n)) return 0;
     *width = (nrb_mfma_shape(wm, ml) && ctx->tune_nrb_mfma >= 0) ? kNRBatchMax : 4;
     return 0;
@@ -1103,9 +1105,9 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
     }
     const int ml = (int)cons->m_lin;
     const int64_t N = cons->Jct->n;
-    const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kColChunk) ? (int)U->A->m : 0;
-    if (!wm || m > kNRMaxM || !onepass_cw(ctx, wm, cons->Jct->ld, N) || wm > kColChunk)
-        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "batched Newton retraction needs the one-stream step (generator known, 4..256 columns)");
+    const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kOnepassMaxCols) ? (int)U->A->m : 0;
+    if (!wm || m > kNRMaxM || !onepass_cw(ctx, wm, cons->Jct->ld, N) || wm > kOnepassMaxCols)
+        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "batched Newton retraction needs the one-stream step (generator known, 4..1024 columns)");
     LF_TRY(ensure_mvec(ctx, (size_t)kNRBatchMax * m + 8));            // h_m: the trials' constraint values on their way back
     // instantiated batch widths (a missing trial is born finished): 2 and 4 on the VALU form of the one-pass kernel, 16 on the matrix
     // cores (ctx->tune_nrb_mfma: 1 = the matrix-core form for every batch its shape covers, -1 = never)

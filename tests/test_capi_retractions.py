@@ -597,7 +597,10 @@ def test_pcg_one_pass_iteration_matches_two_pass_kernels(dev_ctx, monkeypatch, m
                                              (13, True, 0), (16, True, 0), (16, False, 0),
                                              # 65 .. 132 generator columns: the LDS-DMA form of the matrix-core step (nrb2_kernel); m = 128 with
                                              # the ball column (129 columns: 17 DMA pieces) is config 4's shape, m = 127 + ball fills 128 exactly
-                                             (16, True, 128), (7, False, 128), (16, False, 127), (5, True, 69), (12, True, 100)])
+                                             (16, True, 128), (7, False, 128), (16, False, 127), (5, True, 69), (12, True, 100),
+                                             # more than 256 generator columns: the WIDE form of the one-pass kernel (four waves share a row
+                                             # tile and split its columns), four trial points per pass
+                                             (4, True, 300), (3, False, 260)])
 def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds, mcols):
     """lfpsqp_retract_nr_batch: nb trial points of one linesearch retracted together (one pass over Jct per Newton step for all of
     them) give, trial by trial, what lfpsqp_retract_nr gives one by one -- including trials that converge at different
@@ -635,7 +638,7 @@ def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds, mcols)
     assert isinstance(method, L.NR)
     method.maxiter = 40                                    # so that the largest step fails while the small ones converge
     alphas = ([64.0, 0.02, 2e-3, 1e-4] + [0.05 * 0.5 ** k for k in range(12)])[:nb]
-    assert L.retract_nr_batch_width_(c_, method) == 16
+    assert L.retract_nr_batch_width_(c_, method) == (16 if M <= 132 else 4)
     xts, xns = captured["work"].batch_vectors(nb)
     for a, xt in zip(alphas, xts):
         L.waxpby(1.0, x, a, d, xt)
