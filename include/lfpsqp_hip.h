@@ -307,6 +307,20 @@ int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const doub
 int lfpsqp_factorize_hint(lfpsqp_ctx* ctx, const double* Vt_prev, int64_t m);
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
                      double* W, int64_t* rank, double eps_rank);
+/* EXTRA RIGHT-HAND COLUMNS of the Gram pass.  Right behind the factorisation the outer iteration projects its step, d -= U (U'd)
+ * (src/optimize.jl:305-307; with bounds :315-316), which starts with Jct'd -- a GEMV-T pass over the matrix the Gram kernel has just read.
+ * d is known before jac! runs, so the product rides along: the Gram kernel sums, for up to two device n-vectors e_k,
+ *     X[:, k] = M[:, :ncols]' (sqrt(w2) .* e_k)          (ncols x nx, host, column-major, all-reduced; w2 == NULL: M'e_k)
+ * from the operand values it stages for the matrix cores anyway (vector pipe, no extra memory or LDS traffic; border columns beyond a
+ * multiple of 128 by a GEMV-T over those columns alone).  The weighted form is stated in the kernel's scaled space on purpose: with bounds
+ * the projection needs Jct'(sx .* dx + sy .* dy) with sx = Dy.^2 = w2, sy = -Dx.*Dy, i.e. e = |Dy| dx - Dx sgn(Dy) dy -- no division by
+ * a weight that may be zero.  M may be a view (lfpsqp_mat_view): X = V'(sqrt(w2) .* e) for V = diag(rs) A + u w'.
+ * lfpsqp_gram_rhs: G as lfpsqp_gram plus X; lfpsqp_factorize_rhs: lfpsqp_factorize plus Jte_host[0:m) = Jct'(sqrt(w2) .* e) (e may be
+ * NULL: then exactly lfpsqp_factorize). */
+int lfpsqp_gram_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* w2, int64_t nx, const lfpsqp_vec* const* e,
+                    double* G_host, double* X_host);
+int lfpsqp_factorize_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
+                         double* W, int64_t* rank, double eps_rank, const lfpsqp_vec* e, double* Jte_host);
 
 /* The same factorisation when the constraint gradients are sparse: A = [S | Jct[:, S.m : Jct.m)], i.e. the sparse object holds the
  * leading columns and the dense twin Jct (n x M, M - S.m <= 4: the ball / slack columns; NULL when there are none) the rest.  The
@@ -386,6 +400,11 @@ typedef struct lfpsqp_projcg_work {
  * ran the one-pass iteration and returned by the iteration limit, with no other library call in between; otherwise
  * LFPSQP_ERR_UNSUPPORTED.  (bench.py times K iterations of a running solve with it; optimize never needs it.) */
 #define LFPSQP_PROJCG_RESUME 2
+/* The start of the solve is given: x0 = 0 (c == NULL), work->rp holds r0 = A x0 - b = -b and work->Utr holds U'r0 -- what
+ * lfpsqp_tangent_step leaves behind, which formed both while it projected b.  The call then skips its own residual pass (src/projcg.jl:56-59)
+ * and starts with the initial projection (:60-62).  Plain basis in factored form over a dense generator only (LFPSQP_ERR_UNSUPPORTED
+ * otherwise); iterates as without the flag up to the rounding of U'r0. */
+#define LFPSQP_PROJCG_START_GIVEN 4
 
 /* Can lfpsqp_projcg run on a basis kept in FACTORED form (lfpsqp_basis.Z == NULL, generator A (N rows) and W given; SA = the sparse twin of
  * A's leading columns, or NULL) with a diagonal operator on THIS context?  *yes = 1 / 0.  The factored form needs the fused one-pass
@@ -489,6 +508,20 @@ int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, con
  * that holds c(x) already: the point an outer iteration starts from is the line search's accepted trial point, whose retraction returned
  * c!(xnew) (src/optimize.jl:284 evaluates it again: one pass over the constraint gradients per outer iteration for nothing). */
 int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval);
+/* The TANGENT STEP of an outer iteration in one pass over the constraint gradients (src/optimize.jl:305-343, 366-381 and the head of projcg!,
+ * src/projcg.jl:56-59), for a plain basis kept in factored form U = A W (lfpsqp_basis.Z == NULL; A may be a view) of rank U->ncols <= m:
+ *   Jtd (host, m) = A'd -- from lfpsqp_factorize_rhs, which summed it during the Gram pass;
+ *   Utd (host, m) <- U'd = W'Jtd (the reference's tmp_m, zero beyond the rank);  lam (host, m) <- V S^-1 Utd  (lambda_kkt, :331-343);
+ *   d <- d - U Utd (:306-307);   work->rp <- r0 = -d;   work->Utr <- U'r0   (projcg!'s start for b = d, x0 = 0: LFPSQP_PROJCG_START_GIVEN);
+ *   *d_sumsq <- d'd of the projected step (all-reduced; norm(d) of the truncated-Newton tolerance, :373-375);
+ *   cons != NULL: hdiag (which the caller filled with the objective's part of the diagonal Lagrangian Hessian) += the constraint class's
+ *   term for lam, exactly lfpsqp_constraints_hess_diag(ctx, cons, x, lam, hdiag) -- inside the same pass when the class streams its
+ *   gradients from A's storage (phi''(x) .* (A lam) needs a product over the matrix being read anyway), by that call otherwise.
+ * Five passes of the statement-by-statement sequence (GEMV-T, GEMV-N, the Hessian term's GEMV-N, projcg!'s GEMV-T, its initial projection)
+ * become two (this one and the initial projection).  LFPSQP_ERR_UNSUPPORTED for a materialised, sparse-twinned or bound-stacked basis. */
+int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m, const double* Jtd,
+                        lfpsqp_vec* d, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_vec* hdiag,
+                        const lfpsqp_projcg_work* work, double* Utd, double* lam, double* d_sumsq);
 /* A user c!: x is the DEVICE vector (download it if the function is host code); return 0. */
 typedef int (*lfpsqp_cfun)(void* user, const lfpsqp_vec* x, double* cval);
 

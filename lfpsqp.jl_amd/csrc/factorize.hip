@@ -47,7 +47,14 @@ constexpr int kTLd = 17;
 template <bool DIAG, bool WEIGHTED>
 __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restrict__ M, int64_t ld, int64_t n, int ncols, int npan,
                                                          int ngroups, const double* __restrict__ w2, double* __restrict__ part,
-                                                         int64_t part_ld) {
+                                                         int64_t part_ld, const double* __restrict__ ex0, const double* __restrict__ ex1,
+                                                         int64_t xoff) {
+    // EXTRA RIGHT-HAND COLUMNS (DIAG launches only; ex0 / ex1, each may be null): besides the Gram block the workgroup sums
+    //     X_k[col] = sum_rows (sqrt(w) .* M)[row, col] * ex_k[row]            (the operand as it is staged: weights applied)
+    // for the 128 columns of its panel -- with the values a lane holds in registers on their way to LDS (8 multiply-adds per step and lane on
+    // the vector pipe, which is idle here; no LDS traffic).  part[g][xoff + k * npan * 128 + pi * 128 + col].  This is how the outer iteration's
+    // Jct'd (src/optimize.jl:306: the projection of the step needs it right after the factorisation) and the rank-one term of a view's Gram
+    // matrix ride along with the pass that reads the matrix anyway, instead of a GEMV-T pass each.
     // WEIGHTED: w2 holds the SQUARE ROOTS of the weights (gram_impl prepares them) and both operands are scaled: the product stays symmetric, so a
     // diagonal block still needs ONE staged operand (with the weights on one side only it needed two: twice the LDS writes and the LDS
     // footprint -- 4.04 against 3.22 ms for the unweighted kernel at n = 1e7, m = 128, profiles/r04g_streamed_gradients_1e7_128.txt)
@@ -76,6 +83,8 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
     // software pipeline: the global loads of step s+DEPTH are issued before the MFMAs of step s.  Row weights are applied when a
     // buffer is staged, so that no arithmetic waits on the loads in flight.
     double2 va[DEPTH][4], vb[needB ? DEPTH : 1][4], vw[WEIGHTED ? DEPTH : 1];
+    double2 ve[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};      // the extra columns' entries of the rows kh, kh + 1 of the step in flight
+    double xa[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};         // ... and this lane's running sums for its four panel columns
     const double* pa = M + ((int64_t)pi * kPanel + c) * ld + kh;
     const double* pb = M + ((int64_t)pj * kPanel + c) * ld + kh;
     const int na = ncols - pi * kPanel - c, nb = ncols - pj * kPanel - c;      // column c + 32 q of the panel exists iff 32 q < na / nb
@@ -104,6 +113,10 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
                 }
             }
         }
+        if constexpr (DIAG) {           // (behind the matrix loads: nothing waits for these before the staging of this step; entries of rows >= n
+            if (ex0) ve[0] = ld2(ex0 + r + kh);      // are finite padding and meet the matrix's zero rows)
+            if (ex1) ve[1] = ld2(ex1 + r + kh);
+        }
     };
     auto write_lds = [&](int p, int buf) {
 #pragma unroll
@@ -112,6 +125,10 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
             if constexpr (WEIGHTED) { a.x *= vw[buf].x; a.y *= vw[buf].y; }
             As[p][c + 32 * q][kh] = a.x;
             As[p][c + 32 * q][kh + 1] = a.y;
+            if constexpr (DIAG) {
+                if (ex0) xa[0][q] = fma(a.y, ve[0].y, fma(a.x, ve[0].x, xa[0][q]));
+                if (ex1) xa[1][q] = fma(a.y, ve[1].y, fma(a.x, ve[1].x, xa[1][q]));
+            }
             if constexpr (needB) {
                 double2 b = vb[buf][q];
                 if constexpr (WEIGHTED) { b.x *= vw[buf].x; b.y *= vw[buf].y; }
@@ -220,6 +237,20 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
     };
     if (full) run(std::true_type{});
     else run(std::false_type{});
+    if constexpr (DIAG) {               // the extra columns: sum over the 8 lanes (rows kh = 0, 2 .. 14) that share a panel column, fixed order
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!(k == 0 ? ex0 : ex1)) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double sx = xa[k][q];
+                sx += __shfl_xor(sx, 1);
+                sx += __shfl_xor(sx, 2);
+                sx += __shfl_xor(sx, 4);
+                if ((tid & 7) == 0) part[(int64_t)g * part_ld + xoff + ((int64_t)k * npan + pi) * kPanel + c + 32 * q] = sx;
+            }
+        }
+    }
 }
 
 // Out[row0 + r, c0 + c] = sum_k In[row0 + r, k] * W[k, c0 + c] for any shape: one workgroup per (128-row tile, 128-column panel).
@@ -499,34 +530,121 @@ struct ViewRank1DotF {
     }
 };
 
-static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const double* w2, std::vector<double>& G) {
+// Extra right-hand columns of a Gram pass (at most two): X[:, k] = M' (sqrt(w2) .* e_k), ncols_all x nx, column-major, replicated (all-reduced)
+// -- summed by the Gram kernel from the operand values it stages anyway (gram_kernel: "EXTRA RIGHT-HAND COLUMNS").  With weights the
+// column enters in the kernel's scaled space on purpose: the uses are M'(sx .* dx + sy .* dy) of the bound-stacked projection (sqrt(w2) = |Dy|,
+// e = |Dy| dx - Dx sgn(Dy) dy: no division by a weight that may be zero) and the unweighted M'd (w2 == nullptr).
+struct GramRhs {
+    int nx = 0;
+    const double* e[2] = {nullptr, nullptr};     // device n-vectors
+    std::vector<double>* X = nullptr;
+};
+// out = sgn(rs) .* (sw ? sqrt(sw) : 1) .* v   (rs, sw optional): a column moved into the scaled space of the plain matrix behind a view
+struct SignScaleF {
+    const double *v, *rs, *sw;
+    double* out;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        double2 a = ld2(v + i);
+        if (rs) {
+            const double2 s = ld2(rs + i);
+            a.x = s.x > 0.0 ? a.x : (s.x < 0.0 ? -a.x : 0.0);
+            a.y = s.y > 0.0 ? a.y : (s.y < 0.0 ? -a.y : 0.0);
+        }
+        if (sw) {
+            const double2 w = ld2(sw + i);
+            a.x *= sqrt(w.x);
+            a.y *= sqrt(w.y);
+        }
+        if (v1) st2(out + i, a);
+        else if (v0) out[i] = a.x;
+    }
+};
+// u' (sqrt(w2) .* e) for up to two columns e (the rank-one term of a view against the extra columns)
+struct ViewRhsDotF {
+    const double *u, *w2, *e0, *e1;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double* red) const {
+        double2 a = ld2(u + i);
+        if (w2) { const double2 w = ld2(w2 + i); a.x *= sqrt(w.x); a.y *= sqrt(w.y); }
+        const double2 x0 = ld2(e0 + i), x1 = e1 ? ld2(e1 + i) : make_double2(0.0, 0.0);
+        double s0 = 0.0, s1 = 0.0;
+        if (v0) { s0 = a.x * x0.x; s1 = a.x * x1.x; }
+        if (v1) { s0 = fma(a.y, x0.y, s0); s1 = fma(a.y, x1.y, s1); }
+        red[0] += s0;
+        red[1] += s1;
+    }
+};
+// GEMV-T producer sqrt(w2) .* e (w2 optional): the extra columns against the border columns of the matrix
+struct SqrtWTimesV {
+    const double *e, *w2;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ double2 load(int64_t r, bool v0, bool v1) const {
+        double2 a = ld2(e + r);
+        if (w2) { const double2 w = ld2(w2 + r); a.x *= sqrt(w.x); a.y *= sqrt(w.y); }
+        return make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0);
+    }
+};
+
+static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const double* w2, std::vector<double>& G, const GramRhs* rhs = nullptr) {
     G.assign((size_t)ncols_all * ncols_all, 0.0);
+    const int nxu = rhs ? rhs->nx : 0;
+    if (rhs && rhs->X) rhs->X->assign((size_t)ncols_all * nxu, 0.0);
     if (ncols_all == 0) return 0;
     if (M->view) {
         // V = D A + u w' (D = diag(rs)):  V' W2 V = A' (D W2 D) A + z w' + w z' + (u' W2 u) w w',  z = A' (D W2 u)
-        // -- the weighted kernel over the plain storage, one GEMV-T and one dot product for the rank-one term, assembled on the host
+        // -- the weighted kernel over the plain storage; z rides along as an extra right-hand column of that pass (in the kernel's scaled space,
+        // weights rs^2 w2: sgn(rs) sqrt(w2) u), as do the caller's own columns (sgn(rs) e_k, plus w (u' sqrt(w2) e_k) for the rank-one term); one
+        // dot-product kernel, assembled on the host
         const lfpsqp_mat plain = M->plain();
+        const size_t npad = (size_t)round_up(M->n + 1, kPadRows);
+        LF_TRY(ensure_nvec(ctx, 4 * npad));       // [combined weights | their square roots (the plain call below) | two columns in scaled space]
         const double* wts = w2;
         if (M->rs) {
-            LF_TRY(ensure_nvec(ctx, 2 * (size_t)round_up(M->n + 1, kPadRows)));       // [combined weights | their square roots (gram_impl below)]
             LF_TRY((run_vec<ViewWeightF, 0, NoPost>(ctx, M->n, ViewWeightF{M->rs, w2, ctx->d_nvec}, 0u, nullptr, NoPost())));
             wts = ctx->d_nvec;
         }
-        LF_TRY(gram_impl(ctx, &plain, ncols_all, wts, G));
-        if (!M->ru) return 0;
+        GramRhs inner;
+        std::vector<double> Xin;
+        inner.X = &Xin;
+        for (int k = 0; k < nxu; ++k) {
+            if (!M->rs) { inner.e[inner.nx++] = rhs->e[k]; continue; }
+            double* dst = ctx->d_nvec + (2 + inner.nx) * npad;
+            LF_TRY((run_vec<SignScaleF, 0, NoPost>(ctx, M->n, SignScaleF{rhs->e[k], M->rs, nullptr, dst}, 0u, nullptr, NoPost())));
+            inner.e[inner.nx++] = dst;
+        }
+        const bool z_rides = M->ru && inner.nx < 2;
+        if (z_rides) {
+            if (!M->rs && !w2) inner.e[inner.nx++] = M->ru;
+            else {
+                double* dst = ctx->d_nvec + (2 + inner.nx) * npad;
+                LF_TRY((run_vec<SignScaleF, 0, NoPost>(ctx, M->n, SignScaleF{M->ru, M->rs, w2, dst}, 0u, nullptr, NoPost())));
+                inner.e[inner.nx++] = dst;
+            }
+        }
+        LF_TRY(gram_impl(ctx, &plain, ncols_all, wts, G, inner.nx > 0 ? &inner : nullptr));
         const int mm = ncols_all;
+        if (rhs && rhs->X)
+            for (int k = 0; k < nxu; ++k)
+                for (int i = 0; i < mm; ++i) (*rhs->X)[(size_t)k * mm + i] = Xin[(size_t)k * mm + i];
+        if (!M->ru) return 0;
         LF_TRY(ensure_mvec(ctx, (size_t)2 * mm + 16));
-        double* dz = ctx->d_m;                                   // [z (mm) ; u' W2 u ; w (mm)] -> host
-        LF_TRY(run_gemv_t(ctx, &plain, mm, M->n, ViewRank1V{M->rs, w2, M->ru}, dz));
+        double* dz = ctx->d_m;                                   // [z (mm) ; u' W2 u ; w (mm) ; u' sqrt(W2) e_k (2)] -> host
+        if (!z_rides) LF_TRY(run_gemv_t(ctx, &plain, mm, M->n, ViewRank1V{M->rs, w2, M->ru}, dz));
         LF_TRY((run_vec<ViewRank1DotF, 1, NoPost>(ctx, M->n, ViewRank1DotF{w2, M->ru}, 0u, dz + mm, NoPost())));
         LF_HIP(ctx, hipMemcpyAsync(dz + mm + 1, M->rw, sizeof(double) * mm, hipMemcpyDeviceToDevice, ctx->stream));
-        LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, dz, sizeof(double) * (2 * mm + 1), hipMemcpyDeviceToHost, ctx->stream));
+        if (nxu > 0)
+            LF_TRY((run_vec<ViewRhsDotF, 2, NoPost>(ctx, M->n, ViewRhsDotF{M->ru, w2, rhs->e[0], nxu > 1 ? rhs->e[1] : nullptr}, 0u, dz + 2 * mm + 1, NoPost())));
+        LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, dz, sizeof(double) * (2 * mm + 3), hipMemcpyDeviceToHost, ctx->stream));
         LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const double* z = ctx->h_m;
+        const double* z = z_rides ? &Xin[(size_t)(inner.nx - 1) * mm] : ctx->h_m;
         const double uu = ctx->h_m[mm];
         const double* w = ctx->h_m + mm + 1;
         for (int jj = 0; jj < mm; ++jj)
             for (int ii = 0; ii < mm; ++ii) G[(size_t)jj * mm + ii] += z[ii] * w[jj] + w[ii] * z[jj] + uu * w[ii] * w[jj];
+        if (rhs && rhs->X)
+            for (int k = 0; k < nxu; ++k)
+                for (int i = 0; i < mm; ++i) (*rhs->X)[(size_t)k * mm + i] += w[i] * ctx->h_m[2 * mm + 1 + k];
         return 0;
     }
     // A few columns beyond a multiple of the 128-column panel (m + 1 constraints with a slack/ball column, say) would cost
@@ -537,6 +655,8 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     const int npan = (ncols + kPanel - 1) / kPanel;
     const int npair = npan * (npan + 1) / 2;
     const int64_t pp = (int64_t)npair * kPanel * kPanel;
+    const int xcols = nxu * npan * kPanel;               // the extra columns' sums sit behind the pair slots of a partial row
+    const int64_t pld = pp + xcols;
     const int64_t nsteps = (M->n + kKStep - 1) / kKStep;
 #ifndef LFPSQP_GRAM_WGS
 #define LFPSQP_GRAM_WGS 2
@@ -552,9 +672,11 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     };
     const int noff = npair - npan;
     const int gd = groups_for(npan), go = noff > 0 ? groups_for(noff) : 0;
-    LF_TRY(ensure_part(ctx, (size_t)std::max(gd, go) * pp));
-    LF_TRY(ensure_small(ctx, (size_t)pp));
+    LF_TRY(ensure_part(ctx, (size_t)std::max(gd, go) * pld));
+    LF_TRY(ensure_small(ctx, (size_t)pld));
     const int64_t tile2 = (int64_t)kPanel * kPanel;
+    const double* ex0 = nxu > 0 ? rhs->e[0] : nullptr;
+    const double* ex1 = nxu > 1 ? rhs->e[1] : nullptr;
     if (w2) {
         // the kernel scales BOTH operands by sqrt(w2): staged in the second half of the n-vector scratch (the first may hold the weights themselves)
         const size_t npad = (size_t)round_up(M->n + 1, kPadRows);
@@ -563,30 +685,35 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
         if (own) w2 = ctx->d_nvec;
         double* sw = ctx->d_nvec + npad;
         LF_TRY((run_vec<SqrtWeightF, 0, NoPost>(ctx, M->n, SqrtWeightF{w2, sw}, 0u, nullptr, NoPost())));
-        LF_TRY(ensure_part(ctx, (size_t)std::max(gd, go) * pp));          // (run_vec may not shrink it, but keep the reservation next to its use)
-        hipLaunchKernelGGL((gram_kernel<true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pp);
+        LF_TRY(ensure_part(ctx, (size_t)std::max(gd, go) * pld));         // (run_vec may not shrink it, but keep the reservation next to its use)
+        hipLaunchKernelGGL((gram_kernel<true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pld, ex0, ex1, pp);
         if (noff > 0)
-            hipLaunchKernelGGL((gram_kernel<false, true>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, sw, ctx->part, pp);
+            hipLaunchKernelGGL((gram_kernel<false, true>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, sw, ctx->part, pld, nullptr, nullptr, pp);
     } else {
-        hipLaunchKernelGGL((gram_kernel<true, false>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pp);
+        hipLaunchKernelGGL((gram_kernel<true, false>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pld, ex0, ex1, pp);
         if (noff > 0)
-            hipLaunchKernelGGL((gram_kernel<false, false>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, w2, ctx->part, pp);
+            hipLaunchKernelGGL((gram_kernel<false, false>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, w2, ctx->part, pld, nullptr, nullptr, pp);
     }
     LF_LAUNCH_CHECK(ctx);
     // reduce the partials of each launch over its row groups (32 columns per workgroup)
     hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3((unsigned)((npan * tile2 + 31) / 32), 1), dim3(1024), 0, ctx->stream, ctx->part,
-                       (int64_t)gd, (int)(npan * tile2), (int)pp, 0u, ctx->small, 0, (int64_t)gd, 5, NoPost());
+                       (int64_t)gd, (int)(npan * tile2), (int)pld, 0u, ctx->small, 0, (int64_t)gd, 5, NoPost());
     LF_LAUNCH_CHECK(ctx);
+    if (xcols > 0) {                          // (the diagonal launch's row groups carry the extra columns)
+        hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3((unsigned)((xcols + 31) / 32), 1), dim3(1024), 0, ctx->stream, ctx->part + pp,
+                           (int64_t)gd, xcols, (int)pld, 0u, ctx->small + pp, 0, (int64_t)gd, 5, NoPost());
+        LF_LAUNCH_CHECK(ctx);
+    }
     if (noff > 0) {
         hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3((unsigned)((noff * tile2 + 31) / 32), 1), dim3(1024), 0, ctx->stream,
-                           ctx->part + npan * tile2, (int64_t)go, (int)(noff * tile2), (int)pp, 0u, ctx->small + npan * tile2, 0, (int64_t)go, 5,
+                           ctx->part + npan * tile2, (int64_t)go, (int)(noff * tile2), (int)pld, 0u, ctx->small + npan * tile2, 0, (int64_t)go, 5,
                            NoPost());
         LF_LAUNCH_CHECK(ctx);
     }
-    LF_TRY(allreduce_dev(ctx, ctx->small, pp, 0));
+    LF_TRY(allreduce_dev(ctx, ctx->small, pld, 0));
     // (into the context's PINNED staging block: a copy to pageable memory goes through the runtime's own staging and costs 0.1 ms more)
-    LF_TRY(ensure_mvec(ctx, (size_t)pp + 8));
-    LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->small, sizeof(double) * pp, hipMemcpyDeviceToHost, ctx->stream));
+    LF_TRY(ensure_mvec(ctx, (size_t)pld + 8));
+    LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->small, sizeof(double) * pld, hipMemcpyDeviceToHost, ctx->stream));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const double* const hpin = ctx->h_m;
     struct { const double* p; const double* data() const { return p; } } h{hpin};
@@ -610,6 +737,9 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
                 }
             }
     }
+    if (rhs && rhs->X)
+        for (int k = 0; k < nxu; ++k)
+            for (int i = 0; i < ncols; ++i) (*rhs->X)[(size_t)k * ncols_all + i] = hpin[pp + (size_t)k * npan * kPanel + i];
     if (border > 0) {
         LF_TRY(ensure_mvec(ctx, (size_t)ncols_all + 8));
         for (int j = ncols; j < ncols_all; ++j) {
@@ -617,6 +747,17 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
             LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * ncols_all, hipMemcpyDeviceToHost, ctx->stream));
             LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
             for (int i = 0; i < ncols_all; ++i) G[(size_t)j * ncols_all + i] = G[(size_t)i * ncols_all + j] = ctx->h_m[i];
+        }
+        // the extra columns against the border columns: a GEMV-T over those few columns alone
+        lfpsqp_mat bm = *M;
+        bm.p = M->p + (int64_t)ncols * M->ld;
+        bm.m = border;
+        for (int k = 0; k < nxu; ++k) {
+            LF_TRY(run_gemv_t(ctx, &bm, border, M->n, SqrtWTimesV{rhs->e[k], w2}, ctx->d_m));
+            LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * border, hipMemcpyDeviceToHost, ctx->stream));
+            LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (rhs->X)
+                for (int i = 0; i < border; ++i) (*rhs->X)[(size_t)k * ncols_all + ncols + i] = ctx->h_m[i];
         }
     }
     // G is symmetric up to rounding of the two summation orders; symmetrise
@@ -1076,21 +1217,48 @@ int lfpsqp_factorize_hint(lfpsqp_ctx* ctx, const double* Vt_prev, int64_t m) {
     return 0;
 }
 
-int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
-                     double* W, int64_t* rank_out, double eps_rank) {
+int lfpsqp_gram_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* w2, int64_t nx, const lfpsqp_vec* const* e, double* G_host,
+                    double* X_host) {
+    LF_RANGE("lfpsqp_gram_rhs");
+    LF_ARG(ctx, ctx && M && G_host && ncols >= 0 && ncols <= M->m && (!w2 || w2->n == M->n) && nx >= 0 && nx <= 2 && (nx == 0 || (e && X_host)));
+    GramRhs rhs;
+    std::vector<double> G, X;
+    rhs.X = &X;
+    for (int k = 0; k < (int)nx; ++k) {
+        LF_ARG(ctx, e[k] && e[k]->n >= M->n);
+        rhs.e[rhs.nx++] = e[k]->p;
+    }
+    LF_TRY(gram_impl(ctx, M, (int)ncols, w2 ? w2->p : nullptr, G, nx > 0 ? &rhs : nullptr));
+    for (size_t i = 0; i < G.size(); ++i) G_host[i] = G[i];
+    for (size_t i = 0; i < X.size(); ++i) X_host[i] = X[i];
+    return 0;
+}
+
+int lfpsqp_factorize_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
+                         double* W, int64_t* rank_out, double eps_rank, const lfpsqp_vec* e, double* Jte_host) {
     LF_RANGE("lfpsqp_factorize");
     LF_ARG(ctx, ctx && Jct && Sigma && Vt && rank_out && (Z ? (plain_mat(Z) && Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m) : W != nullptr) &&
-                    (!w2 || w2->n == Jct->n));
+                    (!w2 || w2->n == Jct->n) && (!e || (Jte_host && e->n >= Jct->n)));
     const int m = (int)Jct->m;
     const double* w2p = w2 ? w2->p : nullptr;
     lfpsqp_mat* Zu = Z;
     lfpsqp_mat* Ztmp = nullptr;
+    GramRhs rhs;
+    std::vector<double> X;
+    if (e) { rhs.nx = 1; rhs.e[0] = e->p; rhs.X = &X; }
     const int rc = factorize_core(
-        ctx, m, [&](std::vector<double>& G) { return gram_impl(ctx, Jct, m, w2p, G); },
+        ctx, m, [&](std::vector<double>& G) { return gram_impl(ctx, Jct, m, w2p, G, e ? &rhs : nullptr); },
         [&](const double* Wh, int r) { return rmul_impl(ctx, Jct, m, Wh, r, Zu); }, w2p, Zu,
         [&]() -> int { LF_TRY(lfpsqp_mat_alloc(ctx, Jct->n, m, &Ztmp)); Zu = Ztmp; return 0; }, Sigma, Vt, W, rank_out, eps_rank);
     if (Ztmp) lfpsqp_mat_free(ctx, Ztmp);
+    if (rc == 0 && e)
+        for (int i = 0; i < m; ++i) Jte_host[i] = i < (int)X.size() ? X[i] : 0.0;
     return rc;
+}
+
+int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
+                     double* W, int64_t* rank_out, double eps_rank) {
+    return lfpsqp_factorize_rhs(ctx, Jct, w2, Z, Sigma, Vt, W, rank_out, eps_rank, nullptr, nullptr);
 }
 
 int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma,

@@ -925,6 +925,11 @@ __global__ void post_kernel(double* out, POST post) {
     if (threadIdx.x == 0 && blockIdx.x == 0) post.run(out);
 }
 
+// Elementwise transforms of the nonlinear constraint class lfpsqp_elementwise (kind as a double code: 0: t, 1: sin t, 2: t^2)
+__device__ __forceinline__ double ew_phi(double k, double t) { return k == 0.0 ? t : (k == 1.0 ? sin(t) : t * t); }
+__device__ __forceinline__ double ew_phi1(double k, double t) { return k == 0.0 ? 1.0 : (k == 1.0 ? cos(t) : 2.0 * t); }
+__device__ __forceinline__ double ew_phi2(double k, double t) { return k == 0.0 ? 0.0 : (k == 1.0 ? -sin(t) : 2.0); }
+
 // splitmix64 finaliser as a hash of the flat index -> [-1, 1)   
 __device__ __forceinline__ double hash_u(uint64_t seed, uint64_t k) {
     uint64_t z = seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;

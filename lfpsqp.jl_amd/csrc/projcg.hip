@@ -718,7 +718,8 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     const lfpsqp_diag_op no_diag = {0.0, nullptr};
     if (opf) A = &no_diag;
     LF_ARG(ctx, ctx && x && A && U && b && work && iters && nr);
-    LF_ARG(ctx, !opf || (Av && Av->n == b->n && !(flags & LFPSQP_PROJCG_RESUME)));
+    LF_ARG(ctx, !opf || (Av && Av->n == b->n && !(flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN))));
+    LF_ARG(ctx, !((flags & LFPSQP_PROJCG_RESUME) && (flags & LFPSQP_PROJCG_START_GIVEN)));
     LF_ARG(ctx, work->g && work->d && work->rp && work->Utr);
     const lfpsqp_ctx::ProjcgResume rs = ctx->pcg_resume;      // (taken before this call's own workspace requests invalidate it)
     const bool stacked = U->Dx != nullptr;
@@ -930,7 +931,15 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
             LF_TRY(lfpsqp_vec_fill(ctx, x, 0.0));
         }
         // r = A x - b (kept in rp), Utr = U' r, g = r - U Utr, d = -g, rg = g'g   (:56-62)
-        LF_TRY(launch_residual(1.0, rp, Utr));
+        if (flags & LFPSQP_PROJCG_START_GIVEN) {
+            // the caller's previous pass left r0 = -b in rp and U'r0 in Utr (lfpsqp_tangent_step): no residual pass; the first product of the
+            // initial projection needs its coefficients over the generator's columns, W Utr
+            if (!(DF && fused && !c && !stacked))
+                return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "LFPSQP_PROJCG_START_GIVEN: plain basis in factored form over a dense generator, c == NULL");
+            LF_TRY(factored_w_times_t(ctx, dWf, mc, m, Utr, uDF));
+        } else {
+            LF_TRY(launch_residual(1.0, rp, Utr));
+        }
         if (fused) LF_TRY(launch_fused(1));
         else LF_TRY(launch_k3(1));
     }

@@ -126,10 +126,7 @@ __device__ __forceinline__ void y_retract_one_nr(double& xn, double& yn, double 
     y_retract_apply(xn, yn, xo, yo, qq, rr, ss, p);
 }
 
-// Elementwise transforms of the nonlinear constraint class lfpsqp_elementwise (kind as a double code: 0: t, 1: sin t, 2: t^2)
-__device__ __forceinline__ double ew_phi(double k, double t) { return k == 0.0 ? t : (k == 1.0 ? sin(t) : t * t); }
-__device__ __forceinline__ double ew_phi1(double k, double t) { return k == 0.0 ? 1.0 : (k == 1.0 ? cos(t) : 2.0 * t); }
-__device__ __forceinline__ double ew_phi2(double k, double t) { return k == 0.0 ? 0.0 : (k == 1.0 ? -sin(t) : 2.0); }
+// (the elementwise transforms ew_phi / ew_phi1 / ew_phi2 of the nonlinear constraint class lfpsqp_elementwise: kernels.h)
 
 // Fused Newton-retraction step (src/retractions.jl:141-149): xnew += U*delta (stacked when bounds exist),
 // y_retract!, and the value handed to the c! product; one reduction term = the ball partial.

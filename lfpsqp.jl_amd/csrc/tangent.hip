@@ -1,0 +1,164 @@
+// The tangent step of an outer iteration in ONE pass over the constraint gradients.
+//
+// Between the factorisation and the first projected-CG iteration the reference's outer loop (src/optimize.jl:305-343, 366-381) and the
+// head of projcg! (src/projcg.jl:55-62) make, for a basis U = Jct W kept in factored form, FIVE passes over the matrix:
+//     tmp_m = U'd                     GEMV-T   :306          (1)
+//     d    -= U tmp_m                 GEMV-N   :307          (2)
+//     hess_lag_vec!'s constraint term GEMV-N   (autodiff_generators.jl:72-107; the nonlinear class: phi''(x) .* (A lam))   (3)
+//     Utr = U'r0,  r0 = A x0 - b = -d GEMV-T   projcg.jl:56-59   (4)
+//     g = r0 - U Utr ...              the INIT form of the fused iteration (projcg.hip)                                     (5)
+// (1) rides with the Gram pass (lfpsqp_factorize_rhs: d is known before jac! runs).  (2), (3), (4) are ONE pass here: both first products
+// (coefficients W tmp_m and lam) meet the row in registers, d is projected, the Hessian diagonal is completed, and r0 = -d goes straight back
+// into the tile for the second product.  lambda_kkt = V S^-1 tmp_m (:331-343) is replicated m x m work on the host in between.
+#include <math.h>
+
+#include "internal.h"
+#include "sparse.h"
+
+namespace lfpsqp {
+
+// MODE 0: projection only; 1: + the constant part of the class's Hessian term on the rows < n_x (ball / common quadratic term);
+// 2: + phi''(x_i) (A lam)_i from the second first product (NA = 2).
+// The functor takes a VIEW itself (kRowScaled: run_onepass launches it over the plain storage as it is): the projection's product is the
+// view's, diag(rs) A u1 + u (w'u1), the Hessian term's is the plain A's -- one matrix stream serves both.
+template <int MODE>
+struct TangentStepE {
+    static constexpr bool kRowScaled = true;
+    static constexpr bool kSplitRed = false;
+    double* d;          // in: the step; out: its projection
+    double* rp;         // out: r0 = -d (projcg!'s stored residual, src/projcg.jl:56-57 with x0 = 0)
+    double* hx;         // MODE > 0: the Hessian diagonal, completed in place
+    const double* x;
+    const double* kind;
+    double cq;
+    int64_t n_x;
+    ViewD vw;
+    struct Uni { double tau; };
+    struct Row { double d, s, u, hx, x, kk; };
+    static __device__ __forceinline__ double at(const double* base, uint32_t o) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
+    }
+    static __device__ __forceinline__ void put(double* base, uint32_t o, double v) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + o) = v;
+    }
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ Uni uniform() const { return Uni{vw.u ? uniform_f64(ld_scal(vw.tau)) : 0.0}; }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        Row w;
+        w.d = at(d, o);
+        w.s = vw.rs ? at(vw.rs, o) : 1.0;
+        w.u = vw.u ? at(vw.u, o) : 0.0;
+        w.hx = MODE > 0 ? at(hx, o) : 0.0;
+        w.x = MODE > 1 ? at(x, o) : 0.0;
+        w.kk = (MODE > 1 && kind) ? at(kind, o) : 0.0;
+        return w;
+    }
+    template <int NA>
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&acc)[NA], bool valid, bool owner, bool, const Uni& u, const Row& w,
+                                          double (&v)[1], double (&red)[2]) const {
+        const double s = valid ? w.s : 0.0;
+        const double proj = valid ? fma(w.u, u.tau, acc[0] * s) : 0.0;      // (U tmp_m)_i
+        const double dp = w.d - proj;                                       // :307
+        const double r0 = valid ? -dp : 0.0;
+        if (valid && owner) {
+            put(d, o, dp);
+            put(rp, o, r0);
+            if (MODE > 0) {
+                double h = w.hx;
+                if (MODE > 1) h += ew_phi2(w.kk, w.x) * acc[NA - 1];
+                h += (row < n_x) ? cq : 0.0;
+                put(hx, o, h);
+            }
+            red[0] = fma(dp, dp, red[0]);                                   // |d|^2 (the truncated-Newton tolerance, :373-375)
+            red[1] = fma(w.u, r0, red[1]);                                  // u'r0: the view's rank-one term of the second product
+        }
+        v[0] = r0 * s;
+    }
+};
+
+}  // namespace lfpsqp
+
+using namespace lfpsqp;
+
+extern "C" int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m64, const double* Jtd,
+                                   lfpsqp_vec* d, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_vec* hdiag,
+                                   const lfpsqp_projcg_work* work, double* Utd, double* lam, double* d_sumsq) {
+    LF_RANGE("lfpsqp_tangent_step");
+    LF_ARG(ctx, ctx && U && Sigma && Vt && Jtd && d && work && work->rp && work->Utr && Utd && lam && d_sumsq && m64 >= 1);
+    const int m = (int)m64, rank = (int)U->ncols;
+    if (U->Z || !U->A || !U->W || U->SA || U->Dx || rank < 1 || rank > m || U->A->m != m || onepass_cw(ctx, m, U->A->ld, U->A->n) == 0)
+        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "lfpsqp_tangent_step: needs a plain basis in factored form over a dense generator of 4 .. 1024 columns "
+                                                    "(lfpsqp_basis.Z == NULL, A and W given, no sparse twin, no bounds)");
+    const lfpsqp_mat* A = U->A;
+    const int64_t N = A->n;
+    LF_ARG(ctx, d->n >= N && work->rp->n >= N && work->Utr->n >= rank && d->p != work->rp->p);
+    // the class's Hessian term: which part of it this pass can carry
+    int mode = 0;
+    double cq = 0.0;
+    const double* kind = nullptr;
+    // 1. the replicated part: tmp_m = U'd = W'(A'd), lambda = V S^-1 tmp_m (:331-343), u1 = W tmp_m
+    std::vector<double> u1((size_t)m, 0.0);
+    for (int j = 0; j < rank; ++j) {
+        const double* wj = U->W + (size_t)j * m;
+        double sdot = 0.0;
+        for (int k = 0; k < m; ++k) sdot = fma(wj[k], Jtd[k], sdot);
+        Utd[j] = sdot;
+    }
+    for (int j = rank; j < m; ++j) Utd[j] = 0.0;
+    for (int i = 0; i < m; ++i) lam[i] = 0.0;
+    for (int j = 0; j < rank; ++j) {
+        const double tj = Utd[j] / Sigma[j];
+        for (int i = 0; i < m; ++i) lam[i] = fma(Vt[(size_t)i * m + j], tj, lam[i]);       // lam = Vt' (tmp ./ Sigma): Vt[j, i] at [j + i m]
+        const double* wj = U->W + (size_t)j * m;
+        for (int k = 0; k < m; ++k) u1[k] = fma(wj[k], Utd[j], u1[k]);
+    }
+    if (cons) {
+        LF_ARG(ctx, x && hdiag && x->n >= N && hdiag->n >= N && hdiag->p != x->p && hdiag->p != d->p && cons->Jct && cons->m_lin >= 0 &&
+                        cons->m_lin + (cons->has_ball ? 1 : 0) <= m);
+        const lfpsqp_elementwise* ew = cons->ew;
+        const int ml = (int)cons->m_lin;
+        cq = cons->has_ball ? 2.0 * lam[ml] : 0.0;
+        if (ew && ew->qw)
+            for (int j = 0; j < ml; ++j) cq += 2.0 * ew->qw[j] * lam[j];
+        kind = (ew && ew->kind) ? ew->kind->p : nullptr;
+        if (kind && !(ew->A && !ew->Asp && ew->A->p == A->p && ew->A->ld == A->ld && ml <= m)) {
+            // the class does not stream its gradients from the matrix this pass reads (a materialised Jct, or sparse A): its own pass
+            LF_TRY(lfpsqp_constraints_hess_diag(ctx, cons, x, lam, hdiag));
+        } else if (kind) mode = 2;
+        else if (cq != 0.0) mode = 1;
+    }
+    // 2. coefficients of the first product(s) onto the device (the context's m-vector block: [u1 (m) | lam (m) | raw sums (m + 4) | folded (m + 4)])
+    const int ms = (int)round_up(m, 2);
+    LF_TRY(ensure_mvec(ctx, (size_t)4 * ms + 32));
+    for (int k = 0; k < m; ++k) { ctx->h_m[k] = u1[k]; ctx->h_m[ms + k] = (mode == 2 && k < (int)cons->m_lin) ? lam[k] : 0.0; }
+    LF_HIP(ctx, hipMemcpyAsync(ctx->d_m, ctx->h_m, sizeof(double) * 2 * ms, hipMemcpyHostToDevice, ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));       // h_m is the context's shared pinned staging block (the next call may rewrite it)
+    double* t = ctx->d_m;
+    double* raw = ctx->d_m + 2 * ms;                        // [A'(rs .* r0) (m) ; |d|^2 ; u'r0]
+    double* folded = raw + ms + 4;                          // [A'(rs .* r0) + w (u'r0) (m) ; |d|^2]
+    double *dW, *tA, *uA;
+    LF_TRY(factored_setup(ctx, A, U->W, rank, &dW, &tA, &uA));
+    ViewD vw{nullptr, nullptr, nullptr};
+    const lfpsqp_mat plain = A->plain();
+    if (A->view) {
+        vw = ViewD{A->rs, A->ru, nullptr};
+        if (A->ru) {
+            LF_TRY(ensure_view(ctx));
+            hipLaunchKernelGGL((view_tau_kernel<0>), dim3(1), dim3(256), 0, ctx->stream, A->rw, t, m, ctx->d_view);
+            LF_LAUNCH_CHECK(ctx);
+            vw.tau = ctx->d_view;
+        }
+    }
+    // 3. the pass
+    double* hx = hdiag ? hdiag->p : nullptr;
+    const double* xp = x ? x->p : nullptr;
+    const int64_t n_x = cons ? cons->n_x : 0;
+    if (mode == 2) LF_TRY((run_onepass<TangentStepE<2>, 1, 2, 2>(ctx, &plain, m, m, N, t, TangentStepE<2>{d->p, work->rp->p, hx, xp, kind, cq, n_x, vw}, raw, -1, ms)));
+    else if (mode == 1) LF_TRY((run_onepass<TangentStepE<1>, 1, 2, 1>(ctx, &plain, m, m, N, t, TangentStepE<1>{d->p, work->rp->p, hx, xp, kind, cq, n_x, vw}, raw)));
+    else LF_TRY((run_onepass<TangentStepE<0>, 1, 2, 1>(ctx, &plain, m, m, N, t, TangentStepE<0>{d->p, work->rp->p, hx, xp, kind, cq, n_x, vw}, raw)));
+    // 4. Utr = U'r0 = W'(A'(rs .* r0) + w (u'r0))  -> work->Utr (what lfpsqp_projcg's LFPSQP_PROJCG_START_GIVEN expects)
+    hipLaunchKernelGGL((view_fold_kernel<0>), dim3(1), dim3(256), 0, ctx->stream, raw, folded, (A->view && A->ru) ? A->rw : nullptr, 1, m, 1);
+    LF_LAUNCH_CHECK(ctx);
+    LF_TRY(sp_basis_small(ctx, dW, m, rank, folded, work->Utr->p, nullptr));
+    return read_back(ctx, folded + m, d_sumsq, 1);
+}

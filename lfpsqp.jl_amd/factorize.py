@@ -18,6 +18,17 @@ def gram(M: DeviceMatrix, ncols: int | None = None, w2: DeviceVector | None = No
     return G
 
 
+def gram_rhs(M: DeviceMatrix, es, ncols: int | None = None, w2: DeviceVector | None = None):
+    """(G, X): G as :func:`gram`, X[:, k] = M[:, :ncols]' (sqrt(w2) .* es[k]) for up to two device n-vectors, summed by the same pass
+    (lfpsqp_gram_rhs)."""
+    ncols = M.m if ncols is None else ncols
+    G = np.empty((ncols, ncols), order='F')
+    X = np.zeros((ncols, max(len(es), 1)), order='F')
+    arr = (C.c_void_p * max(len(es), 1))(*[e.h for e in es])
+    M.ctx.check(M.ctx.L.lfpsqp_gram_rhs(M.ctx.h, M.h, ncols, w2.h if w2 is not None else None, len(es), arr, G.ctypes.data, X.ctypes.data))
+    return G, X[:, :len(es)]
+
+
 def rmul(In: DeviceMatrix, W: np.ndarray, Out: DeviceMatrix) -> DeviceMatrix:
     """Out[:, :W.shape[1]] = In[:, :W.shape[0]] @ W."""
     W = np.asfortranarray(W, dtype=np.float64)
@@ -26,14 +37,16 @@ def rmul(In: DeviceMatrix, W: np.ndarray, Out: DeviceMatrix) -> DeviceMatrix:
 
 
 def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix | None, w2: DeviceVector | None = None, eps_rank: float = 1e-10,
-          W: np.ndarray | None = None, Jsp=None, Vt_prev: np.ndarray | None = None):
+          W: np.ndarray | None = None, Jsp=None, Vt_prev: np.ndarray | None = None, rhs: DeviceVector | None = None):
     """Thin factorisation diag(sqrt(w2)) Jct = U S Vt with U = diag(sqrt(w2)) Z.
     Returns (Sigma, Vt, rank); Z is overwritten (Jct is NOT destroyed, unlike dgesvd).  ``Z = None`` (dense Jct, ``W`` required): the
     basis Z = Jct @ W is not formed -- the caller keeps it in factored form (DeviceBasis(None, rank, generator=(Jct, W))).
     ``W`` (optional, m x m Fortran-ordered float64) receives the small factor with Z = Jct @ W.
     ``Jsp`` (optional SparseMatrix with the entries of the leading ``Jsp.m`` columns of Jct; Jct may then be None when there are no
     further columns): the basis-forming products stream the nonzeros (lfpsqp_factorize_sp).
-    ``Vt_prev`` (optional, the Vt of a previous call on a nearby matrix): warm start of the small eigenproblem (lfpsqp_factorize_hint)."""
+    ``Vt_prev`` (optional, the Vt of a previous call on a nearby matrix): warm start of the small eigenproblem (lfpsqp_factorize_hint).
+    ``rhs`` (optional device n-vector e; dense Jct only): returns a fourth value Jct' (sqrt(w2) .* e), summed during the Gram pass
+    (lfpsqp_factorize_rhs) -- the outer iteration's Jct'd without a GEMV-T pass of its own."""
     m = Jct.m if Jct is not None else Jsp.m
     ctx = Jct.ctx if Jct is not None else Jsp.ctx
     if W is not None:
@@ -49,10 +62,17 @@ def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix | None, w2: DeviceVector | N
                                             Z.h if Z is not None else None,
                                             S.ctypes.data, Vt.ctypes.data, W.ctypes.data if W is not None else None, C.byref(rank),
                                             float(eps_rank)))
+    elif rhs is not None:
+        Jte = np.zeros(m)
+        ctx.check(ctx.L.lfpsqp_factorize_rhs(ctx.h, Jct.h, w2.h if w2 is not None else None, Z.h if Z is not None else None, S.ctypes.data,
+                                             Vt.ctypes.data, W.ctypes.data if W is not None else None, C.byref(rank),
+                                             float(eps_rank), rhs.h, Jte.ctypes.data))
+        return S, Vt, rank.value, Jte
     else:
         ctx.check(ctx.L.lfpsqp_factorize(ctx.h, Jct.h, w2.h if w2 is not None else None, Z.h if Z is not None else None, S.ctypes.data,
                                          Vt.ctypes.data, W.ctypes.data if W is not None else None, C.byref(rank),
                                          float(eps_rank)))
+    assert rhs is None, "rhs: dense Jct only"
     return S, Vt, rank.value
 
 

@@ -180,6 +180,9 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
         projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=(("new", n, m) if m > 0 else None), extra=1 if diagonal_hessian else 0)
         idecomp = InequalityDecomp(ctx, n, m, Jct, Z=projcgwork.basis)
     Z = idecomp.Z
+    # The tangent step with fewer passes (lfpsqp_tangent_step): plain factored basis over dense gradients, truncated-Newton steps on
+    fuse_tangent = (factored and not ineq and param.do_newton and getattr(c_, "Jsp", None) is None and m > 0
+                    and bool(ctx.options.fused_tangent_step))
     prev_rank = -1                           # rank of the previous outer iteration's factorisation (its Vt warm-starts the next one)
     Sig, Vt = idecomp.Sigma, idecomp.Vt
     Wgen = np.zeros((m, m), order='F') if m > 0 else None                  # ksvd_'s small factor: Z == Jct @ Wgen
@@ -239,15 +242,42 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
                 jac_(Jct, cval, x, evaluate=False)
             else:
                 jac_(Jct, cval, x)
-            S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank, W=Wgen,
-                                  Jsp=getattr(c_, "Jsp", None),                                                # :286-302
-                                  Vt_prev=(Vt if (i > 0 and prev_rank == m and ctx.options.warm_factorize) else None))
+            Jtd = None
+            vt_prev = Vt if (i > 0 and prev_rank == m and ctx.options.warm_factorize) else None
+            if fuse_tangent:                                               # Jct'd rides with the Gram pass (d is final before jac! runs)
+                S_, Vt_, rank, Jtd = ksvd_(Jct, Z, eps_rank=param.eps_rank, W=Wgen, Vt_prev=vt_prev, rhs=d)    # :286-302
+            else:
+                S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank, W=Wgen,
+                                      Jsp=getattr(c_, "Jsp", None), Vt_prev=vt_prev)                            # :286-302
             prev_rank = rank
             idecomp.W = Wgen
             idecomp.Jsp = getattr(c_, "Jsp", None)
             Sig[:] = S_
             Vt[:, :] = Vt_
-            if not ineq:                                                   # :305-308
+            fused_now = fuse_tangent and rank >= 1
+            if fused_now:
+                # :305-343, :366-381 and src/projcg.jl:56-59 in one pass: d projected, lambda_kkt, the Hessian diagonal completed, r0 = -d and
+                # U'r0 left in projcgwork for projcg_(start_given=True)
+                Ub = DeviceBasis(None, rank, generator=(Jct, Wgen))
+                split = hasattr(hess_lag_vec_, "diag_objective_") and getattr(hess_lag_vec_, "cons", None) is not None
+                th = np.zeros(m)
+                dss = C.c_double()
+                if split:
+                    hess_lag_vec_.diag_objective_(a_diag, x)
+                    cc = hess_lag_vec_.cons._c()
+                else:                                                      # a diagonal Hessian without the split: it needs lambda_kkt first
+                    th[:rank] = Wgen[:, :rank].T @ Jtd
+                    th[:rank] /= S_[:rank]
+                    lam_kkt[:] = Vt_.T @ th
+                    hess_lag_vec_.diag_(a_diag, x, lam_kkt)
+                    cc = None
+                bs, wc = Ub._c(), projcgwork._c()
+                sig_c = np.ascontiguousarray(S_, dtype=np.float64)
+                vt_c = np.asfortranarray(Vt_, dtype=np.float64)
+                ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), sig_c.ctypes.data, vt_c.ctypes.data, m, Jtd.ctypes.data, d.h,
+                                                    C.byref(cc) if cc is not None else None, x.h, a_diag.h, C.byref(wc), th.ctypes.data,
+                                                    lam_kkt.ctypes.data, C.byref(dss)))
+            elif not ineq:                                                 # :305-308
                 jsp_ = getattr(c_, "Jsp", None)
                 if jsp_ is not None or Z is None:                          # sparse twin / factored basis: U = Jct W applied without Z
                     Ub = DeviceBasis(Z, rank, generator=(Jct, Wgen), sparse=jsp_)
@@ -265,7 +295,9 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
         steptype = 0
         tn_iter = 0
         tn_res = 0.0
-        if m > 0:                                                          # :331-343
+        if m > 0 and fuse_tangent and rank >= 1:
+            pass                                                           # (lambda_kkt came back from the tangent step; lam_dev has no reader here)
+        elif m > 0:                                                        # :331-343
             th = tmp_m.download(m)
             th[:rank] /= Sig[:rank]
             th[rank:m] = 0.0
@@ -292,7 +324,9 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             break
 
         if param.do_newton:                                                # :364-390
-            if diagonal_hessian:
+            if diagonal_hessian and fuse_tangent and rank >= 1:
+                pass                                                       # (a_diag was completed by the tangent step)
+            elif diagonal_hessian:
                 if ineq:
                     hess_lag_vec_.diag_(hx, x, lam_kkt)
                     idc = ineqdata._c()
@@ -312,7 +346,8 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
                 tol = math.nan
             prev_grad_norm = grad_norm
             tn_iter, tn_res = projcg_(newton_d, None, newton_map, Qview, d, None, tol=tol, maxit=param.tn_maxiter,
-                                      work=projcgwork, n_global=(2 * n_global if ineq else n_global), want_lambda=False)
+                                      work=projcgwork, n_global=(2 * n_global if ineq else n_global), want_lambda=False,
+                                      start_given=bool(fuse_tangent and rank >= 1))
             if dot(newton_d, d) > 0.0:
                 d.copy_from(newton_d)
                 steptype = 1

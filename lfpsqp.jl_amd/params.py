@@ -91,3 +91,8 @@ class DeviceOptions:
     # Jacobi sweeps instead of eight.  Same Sigma / rank / span; the basis may differ from the cold call's by a rotation inside clusters of
     # equal singular values, to which every use is invariant.  False: every factorisation starts cold
     warm_factorize: bool = True
+    # the tangent step of an outer iteration with a plain basis in factored form takes two passes over the constraint gradients fewer than the
+    # statement-by-statement sequence (three fewer for the nonlinear class with streamed gradients): Jct'd rides with the Gram pass
+    # (lfpsqp_factorize_rhs), and ONE pass projects the step, completes the Hessian diagonal and forms projcg!'s first U'r
+    # (lfpsqp_tangent_step, LFPSQP_PROJCG_START_GIVEN).  False: src/optimize.jl:305-343 and src/projcg.jl:55-59 statement by statement
+    fused_tangent_step: bool = True

@@ -56,6 +56,14 @@ class QuadLinearBallBox:
     def jac_(self, Jct, cval, x):
         return self.cons.jac_(Jct, cval, x)
 
+    def diag_objective_(self, hx: DeviceVector, x: DeviceVector):
+        """The objective's part of the diagonal Lagrangian Hessian; the constraints' part is ``self.cons.hess_diag_`` -- the split
+        ``optimize`` uses to fold the latter into its tangent-step pass (lfpsqp_tangent_step): diag_ == diag_objective_ + cons.hess_diag_."""
+        L = self.ctx.L
+        self.ctx.check(L.lfpsqp_vec_fill_range(self.ctx.h, hx.h, 0, self.n, 2.0))
+        if self.ploc:
+            self.ctx.check(L.lfpsqp_vec_fill_range(self.ctx.h, hx.h, self.n, 1, 0.0))
+
     def diag_(self, hx: DeviceVector, x: DeviceVector, lam: np.ndarray):
         """diag of grad^2 f + sum lam_i grad^2 c_i: 2 (+ 2 lam_ball) on the user's variables, 0 on the slack."""
         h = 2.0 + (2.0 * float(lam[self.m]) if self.p else 0.0)
@@ -118,6 +126,11 @@ class SeparableLinearBallBox(QuadLinearBallBox):
         self._sep(1, x, g)
         if self.ploc:
             self.ctx.check(self.ctx.L.lfpsqp_vec_fill_range(self.ctx.h, g.h, self.n, 1, 0.0))      # the slack variable is not in f
+
+    def diag_objective_(self, hx: DeviceVector, x: DeviceVector):
+        self._sep(2, x, hx)
+        if self.ploc:
+            self.ctx.check(self.ctx.L.lfpsqp_vec_fill_range(self.ctx.h, hx.h, self.n, 1, 0.0))
 
     def diag_(self, hx: DeviceVector, x: DeviceVector, lam: np.ndarray):
         self._sep(2, x, hx)

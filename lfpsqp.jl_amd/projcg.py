@@ -20,6 +20,7 @@ from .device import (Context, DeviceMatrix, DeviceVector, axpby, dot, gemv_n, ge
 
 WANT_LAMBDA = 1
 RESUME = 2
+START_GIVEN = 4
 
 
 class DiagOperator:
@@ -146,9 +147,11 @@ class ProjCGWork:
 
 def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c: DeviceVector | None,
             tol: float = 1e-6, maxit: int | None = None, work: ProjCGWork | None = None, n_global: int | None = None,
-            want_lambda: bool = True, resume: bool = False):
+            want_lambda: bool = True, resume: bool = False, start_given: bool = False):
     """``resume=True`` (device path only): ``maxit`` MORE iterations of the solve the previous call left at its iteration
-    limit (LFPSQP_PROJCG_RESUME); the returned count runs from the start of the solve."""
+    limit (LFPSQP_PROJCG_RESUME); the returned count runs from the start of the solve.
+    ``start_given=True`` (device path, factored plain basis, ``c`` None): ``work.rp`` holds r0 = -b and ``work.Utr`` holds U'r0, left there
+    by lfpsqp_tangent_step -- the solve skips its own residual pass (LFPSQP_PROJCG_START_GIVEN)."""
     ctx = x.ctx
     n = b.n
     m = U.ncols if hasattr(U, "ncols") else (c.n if c is not None else 0)
@@ -166,13 +169,13 @@ def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c:
         iters = _capi.c_i64()
         nr = C.c_double()
         a_c, u_c, w_c = A._c(), U._c(), work._c()
-        flags = (WANT_LAMBDA if (want_lambda and lam is not None) else 0) | (RESUME if resume else 0)
+        flags = (WANT_LAMBDA if (want_lambda and lam is not None) else 0) | (RESUME if resume else 0) | (START_GIVEN if start_given else 0)
         ctx.check(ctx.L.lfpsqp_projcg(ctx.h, x.h, lam.h if lam is not None else None, C.byref(a_c), C.byref(u_c), b.h,
                                       c.h if c is not None else None, float(tol), int(maxit), int(n_global), flags,
                                       C.byref(w_c), C.byref(iters), C.byref(nr)))
         return iters.value, nr.value
-    if resume:
-        raise ValueError("resume is a feature of the device-resident projcg loop")
+    if resume or start_given:
+        raise ValueError("resume / start_given are features of the device-resident projcg loop")
     if (isinstance(U, DeviceBasis) or stacked) and hasattr(A, "mul_"):
         # general A (the LinearMap case, src/optimize.jl:228-230) on the C loop: lfpsqp_projcg_op calls back once per iteration
         # for A*d; the products stay on the device and nothing in the loop waits for it (no per-dot host round trips)

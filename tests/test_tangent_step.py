@@ -1,0 +1,169 @@
+"""The tangent step of an outer iteration with fewer passes over the constraint gradients.
+
+Reference sequence (src/optimize.jl:286-343, 366-381; src/projcg.jl:55-62): ksvd!, tmp_m = U'd, d -= U tmp_m, lambda_kkt = V S^-1 tmp_m,
+hess_lag_vec!'s constraint term, then projcg! starts with r = A x0 - b, Utr = U'r.  On the device
+  * lfpsqp_gram_rhs / lfpsqp_factorize_rhs sum Jct'd during the Gram pass (extra right-hand columns of the MFMA kernel),
+  * lfpsqp_tangent_step projects d, completes the Hessian diagonal and forms U'r0 in one pass,
+  * lfpsqp_projcg(LFPSQP_PROJCG_START_GIVEN) starts from that state.
+Checked here against numpy restatements of the reference statements (products) and against the statement-by-statement device sequence
+(solver results)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import lfpsqp_jl_amd as L
+from lfpsqp_jl_amd import _capi
+from oracle import synth
+
+
+def _view_parts(ctx, n, m, rs, ru):
+    rs_h = (synth.hash_vector(11, n) * 1.5) if rs else None          # both signs, and an exact zero below
+    if rs_h is not None:
+        rs_h[5] = 0.0
+    u_h = synth.hash_vector(12, n) if ru else None
+    w_h = 0.3 * synth.hash_vector(13, m) if ru else None
+    return rs_h, u_h, w_h
+
+
+@pytest.mark.parametrize("n,m,weighted,rs,ru,nx", [
+    (1500, 12, False, False, False, 1), (2100, 128, False, False, False, 2), (1900, 130, True, False, False, 1),
+    (1700, 64, True, True, False, 2), (2300, 128, False, True, True, 1), (2300, 40, True, True, True, 2), (1300, 260, False, False, True, 2),
+    (1100, 131, True, True, True, 1), (700, 300, True, False, False, 2)])
+def test_gram_with_extra_right_hand_columns(dev_ctx, n, m, weighted, rs, ru, nx):
+    """X[:, k] = V'(sqrt(w2) .* e_k) from the Gram pass itself, for plain matrices and views V = diag(rs) A + u w', weighted or not,
+    panels and border columns."""
+    ctx = dev_ctx
+    Ah = synth.hash_matrix(1, n, m)
+    A = ctx.matrix(n, m, np.asfortranarray(Ah))
+    rs_h, u_h, w_h = _view_parts(ctx, n, m, rs, ru)
+    Vh = Ah.copy()
+    M = A
+    if rs or ru:
+        M = A.view(ctx.vector(n, rs_h) if rs else None, ctx.vector(n, u_h) if ru else None, ctx.vector(m, w_h) if ru else None)
+        if rs:
+            Vh = rs_h[:, None] * Vh
+        if ru:
+            Vh = Vh + np.outer(u_h, w_h)
+    w2h = synth.hash_vector(5, n) ** 2 if weighted else None          # (includes tiny weights)
+    if weighted:
+        w2h[7] = 0.0
+    w2 = ctx.vector(n, w2h) if weighted else None
+    es_h = [synth.hash_vector(20 + k, n) for k in range(nx)]
+    es = [ctx.vector(n, e) for e in es_h]
+    G, X = L.gram_rhs(M, es, w2=w2)
+    sw = np.sqrt(w2h) if weighted else np.ones(n)
+    Gref = (sw[:, None] * Vh).T @ (sw[:, None] * Vh)
+    scale = np.abs(Gref).max()
+    np.testing.assert_allclose(G, Gref, atol=1e-12 * scale)
+    np.testing.assert_allclose(G, L.gram(M, w2=w2), atol=1e-13 * scale)
+    for k in range(nx):
+        ref = Vh.T @ (sw * es_h[k])
+        np.testing.assert_allclose(X[:, k], ref, atol=1e-12 * max(np.abs(ref).max(), 1.0) * np.sqrt(n))
+
+
+@pytest.mark.parametrize("n,m", [(1800, 16), (2500, 128), (1200, 129)])
+def test_factorize_with_right_hand_side_returns_the_same_factors(dev_ctx, n, m):
+    ctx = dev_ctx
+    Mh = synth.hash_matrix(3, n, m)
+    M = ctx.matrix(n, m, np.asfortranarray(Mh))
+    dh = synth.hash_vector(8, n)
+    d = ctx.vector(n, dh)
+    W0, W1 = np.zeros((m, m), order='F'), np.zeros((m, m), order='F')
+    S0, Vt0, r0 = L.ksvd_(M, None, W=W0)
+    S1, Vt1, r1, Jtd = L.ksvd_(M, None, W=W1, rhs=d)
+    assert r0 == r1 == m
+    np.testing.assert_array_equal(S0, S1)
+    np.testing.assert_array_equal(W0, W1)
+    np.testing.assert_array_equal(Vt0, Vt1)
+    np.testing.assert_allclose(Jtd, Mh.T @ dh, atol=1e-12 * np.sqrt(n))
+
+
+def _tangent_step(ctx, U, S, Vt, m, Jtd, d, cons, x, hd, work):
+    Utd, lam = np.zeros(m), np.zeros(m)
+    ss = C.c_double()
+    bs, wc = U._c(), work._c()
+    cc = cons._c() if cons is not None else None
+    ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), S.ctypes.data, Vt.ctypes.data, m, Jtd.ctypes.data, d.h,
+                                        C.byref(cc) if cc is not None else None, x.h if x is not None else None,
+                                        hd.h if hd is not None else None, C.byref(wc), Utd.ctypes.data, lam.ctypes.data, C.byref(ss)))
+    return Utd, lam, ss.value
+
+
+@pytest.mark.parametrize("n,m", [(1800, 16), (2600, 128), (1500, 300)])
+def test_tangent_step_matches_the_statement_sequence(dev_ctx, n, m):
+    """Linear constraints: projection, multipliers, r0 and U'r0 against numpy; then projcg_ from the given start against projcg_ from scratch."""
+    ctx = dev_ctx
+    Jh = synth.hash_matrix(3, n, m)
+    Jct = ctx.matrix(n, m, np.asfortranarray(Jh))
+    dh = synth.hash_vector(8, n)
+    d = ctx.vector(n, dh)
+    W = np.zeros((m, m), order='F')
+    S, Vt, rank, Jtd = L.ksvd_(Jct, None, W=W, rhs=d)
+    assert rank == m
+    U = L.DeviceBasis(None, rank, generator=(Jct, W))
+    work = L.ProjCGWork(ctx, n, m)
+    Utd, lam, ss = _tangent_step(ctx, U, S, Vt, m, Jtd, d, None, None, None, work)
+    Zh = Jh @ W
+    tref = Zh.T @ dh
+    np.testing.assert_allclose(Utd, tref, atol=1e-12 * np.linalg.norm(dh))
+    np.testing.assert_allclose(lam, Vt.T @ (tref / S), atol=1e-11 * np.linalg.norm(dh) / S[-1])
+    dref = dh - Zh @ tref
+    np.testing.assert_allclose(d.download(), dref, atol=1e-13 * np.linalg.norm(dh))
+    np.testing.assert_allclose(work.rp.download(), -dref, atol=1e-13 * np.linalg.norm(dh))
+    np.testing.assert_allclose(ss, dref @ dref, rtol=1e-12)
+    np.testing.assert_allclose(work.Utr.download()[:m], Zh.T @ (-d.download()), atol=1e-12 * np.linalg.norm(dh))
+    # the projected-CG solve from the given start == the solve from scratch
+    a = ctx.vector(n, 4.0 * synth.hash_vector(9, n) + 5.0)
+    A = L.DiagOperator(0.0, a)
+    x1, x2 = ctx.vector(n), ctx.vector(n)
+    tol = 1e-9 * np.sqrt(ss)
+    iters = _capi.c_i64()
+    nrv = C.c_double()
+    a_c, u_c, w_c = A._c(), U._c(), work._c()
+    ctx.check(ctx.L.lfpsqp_projcg(ctx.h, x1.h, None, C.byref(a_c), C.byref(u_c), d.h, None, float(tol), 200, n, 4, C.byref(w_c),
+                                  C.byref(iters), C.byref(nrv)))
+    work2 = L.ProjCGWork(ctx, n, m)
+    i2, nr2 = L.projcg_(x2, None, A, U, d, None, tol=tol, maxit=200, work=work2, want_lambda=False)
+    assert iters.value == i2 and iters.value > 3
+    np.testing.assert_allclose(x1.download(), x2.download(), atol=1e-11 * np.linalg.norm(x2.download()))
+    np.testing.assert_allclose(nrv.value, nr2, rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,m,qw", [(2200, 16, False), (2600, 128, True), (1900, 24, True)])
+def test_tangent_step_completes_the_hessian_diagonal_of_the_streamed_class(dev_ctx, n, m, qw):
+    """Nonlinear class with streamed gradients (Jct a view of A): the projection runs over the view, phi''(x) .* (A lam) over the plain A, in
+    the same pass; against lfpsqp_constraints_hess_diag and the statement-by-statement products."""
+    ctx = dev_ctx
+    A = ctx.matrix(n, m, np.asfortranarray(2.0 ** -3 * synth.hash_matrix(21, n, m)))
+    kind = (np.arange(n) % 3).astype(np.float64)
+    cons = L.ElementwiseConstraints(ctx, A, np.zeros(m), kind=kind, qw=(1e-2 * np.cos(np.arange(m)) if qw else None), stream=True)
+    assert cons.streamed
+    xh = 0.5 * synth.hash_vector(31, n)
+    x = ctx.vector(n, xh)
+    cv = np.zeros(m)
+    cons.jac_(cons.Jct, cv, x)
+    Jh = np.asfortranarray(np.zeros((n, m)))
+    tmp = ctx.matrix(n, m)
+    tmp.copy_from(cons.Jct)                                         # (materialises the view)
+    Jh = tmp.download()
+    dh = synth.hash_vector(8, n)
+    d = ctx.vector(n, dh)
+    W = np.zeros((m, m), order='F')
+    S, Vt, rank, Jtd = L.ksvd_(cons.Jct, None, W=W, rhs=d)
+    assert rank == m
+    np.testing.assert_allclose(Jtd, Jh.T @ dh, atol=1e-12 * np.sqrt(n))
+    U = L.DeviceBasis(None, rank, generator=(cons.Jct, W))
+    work = L.ProjCGWork(ctx, n, m)
+    base = 2.0 + synth.hash_vector(41, n) ** 2
+    hd = ctx.vector(n, base)
+    Utd, lam, ss = _tangent_step(ctx, U, S, Vt, m, Jtd, d, cons, x, hd, work)
+    Zh = Jh @ W
+    tref = Zh.T @ dh
+    dref = dh - Zh @ tref
+    np.testing.assert_allclose(Utd, tref, atol=1e-12 * np.linalg.norm(dh))
+    np.testing.assert_allclose(d.download(), dref, atol=1e-13 * np.linalg.norm(dh))
+    np.testing.assert_allclose(work.Utr.download()[:m], Zh.T @ (-d.download()), atol=1e-12 * np.linalg.norm(dh))
+    href = ctx.vector(n, base)
+    cons.hess_diag_(href, x, lam)
+    np.testing.assert_allclose(hd.download(), href.download(), rtol=1e-13, atol=1e-13)

@@ -33,3 +33,9 @@ views = {"plain": A, "row scales": A.view(rs), "row scales + rank one": A.view(r
 for name, M in views.items():
     print(f"{name:24s} gram {timed(lambda: L.gram(M)):7.3f} ms   weighted {timed(lambda: L.gram(M, w2=w2)):7.3f} ms   "
           f"tangent setup (factored) {timed(lambda: L.ksvd_(M, None, W=W)):7.3f} ms   with weights {timed(lambda: L.ksvd_(M, None, w2=w2, W=W)):7.3f} ms")
+# extra right-hand columns riding with the Gram pass (lfpsqp_gram_rhs): the outer iteration's Jct'd, and the view's own rank-one term
+e1, e2 = ctx.vector(n).hash_fill(8, 0, 1.0, 0.0), ctx.vector(n).hash_fill(9, 0, 1.0, 0.0)
+for name, M in views.items():
+    print(f"{name:24s} gram + 1 column {timed(lambda: L.gram_rhs(M, [e1])):7.3f} ms   + 2 columns {timed(lambda: L.gram_rhs(M, [e1, e2])):7.3f} ms   "
+          f"weighted + 1 column {timed(lambda: L.gram_rhs(M, [e1], w2=w2)):7.3f} ms   tangent setup with Jct'd {timed(lambda: L.ksvd_(M, None, W=W, rhs=e1)):7.3f} ms")
+
