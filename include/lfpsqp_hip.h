@@ -277,7 +277,9 @@ int lfpsqp_y_retract(lfpsqp_ctx* ctx, lfpsqp_vec* xnewaug, const lfpsqp_vec* xau
  * Jacobi, Z = A * W on the device (MFMA), refinement rounds when A is ill-conditioned (FINDINGS.md §5.3).
  *
  * G_host (ncols x ncols, column-major) = M[:, :ncols]' diag(w2) M[:, :ncols], all-reduced.
- * w2 == NULL means unit weights. */
+ * w2 == NULL means unit weights.  Weights must be >= 0: the kernel applies sqrt(w2) to both operands (they are squares in every use of the
+ * hot path: Dy.^2 with bounds, phi'(x).^2 behind a view); a negative weight is answered with LFPSQP_ERR_ARG (lfpsqp_gram / _gram_rhs) or
+ * LFPSQP_ERR_NUMERIC "non-finite Gram matrix" (lfpsqp_factorize*), never with NaN data. */
 int lfpsqp_gram(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* w2, double* G_host);
 /* Out[:, :rcols] = In[:, :kcols] * W   (W_host: kcols x rcols, column-major).  Out != In. */
 int lfpsqp_rmul(lfpsqp_ctx* ctx, const lfpsqp_mat* In, int64_t kcols, const double* W_host, int64_t rcols, lfpsqp_mat* Out);

@@ -109,6 +109,7 @@ end
 
 const LFPSQP_PROJCG_WANT_LAMBDA = Cint(1)
 const LFPSQP_PROJCG_RESUME = Cint(2)
+const LFPSQP_PROJCG_START_GIVEN = Cint(4)      # work.rp = r0 = -b and work.Utr = U'r0 are given (lfpsqp_tangent_step left them): no residual pass
 const LFPSQP_ERR_UNSUPPORTED = Cint(-5)
 
 const H = Ptr{Cvoid}           # an opaque handle (lfpsqp_ctx*, lfpsqp_vec*, lfpsqp_mat*)
@@ -203,6 +204,8 @@ c_gram(ctx, M, ncols, w2, G) = ccall((:lfpsqp_gram, lib), Cint, (Ptr{Cvoid}, Ptr
 c_rmul(ctx, In, kcols, W, rcols, Out) = ccall((:lfpsqp_rmul, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Ptr{Cvoid}), ctx, In, kcols, W, rcols, Out)
 c_factorize_hint(ctx, Vt_prev, m) = ccall((:lfpsqp_factorize_hint, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), ctx, Vt_prev, m)
 c_factorize(ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank) = ccall((:lfpsqp_factorize, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64), ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank)
+c_gram_rhs(ctx, M, ncols, w2, nx, e, G, X) = ccall((:lfpsqp_gram_rhs, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Ptr{Float64}, Ptr{Float64}), ctx, M, ncols, w2, nx, e, G, X)
+c_factorize_rhs(ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank, e, Jte) = ccall((:lfpsqp_factorize_rhs, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64, Ptr{Cvoid}, Ptr{Float64}), ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank, e, Jte)
 c_factorize_sp(ctx, S, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank) = ccall((:lfpsqp_factorize_sp, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64), ctx, S, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank)
 c_small_svd(ctx, rows, cols, A, U, S, V) = ccall((:lfpsqp_small_svd, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx, rows, cols, A, U, S, V)
 c_q_gemv_t(ctx, Q, v, w, t) = ccall((:lfpsqp_q_gemv_t, lib), Cint, (Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, Q, v, w, t)
@@ -215,6 +218,9 @@ c_projcg(ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = c
 c_projcg_op(ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg_op, lib), Cint,
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
     ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
+c_tangent_step(ctx, U, Sigma, Vt, m, Jtd, d, cons, x, hdiag, work, Utd, lam, dss) = ccall((:lfpsqp_tangent_step, lib), Cint,
+    (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Cvoid}, Ptr{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CWork}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+    ctx, U, Sigma, Vt, m, Jtd, d, cons, x, hdiag, work, Utd, lam, dss)
 c_constraints_eval(ctx, cons, x, cval) = ccall((:lfpsqp_constraints_eval, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Float64}), ctx, cons, x, cval)
 c_constraints_jac(ctx, cons, x, Jct, cval) = ccall((:lfpsqp_constraints_jac, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), ctx, cons, x, Jct, cval)
 c_constraints_hess_diag(ctx, cons, x, lam, hx) = ccall((:lfpsqp_constraints_hess_diag, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), ctx, cons, x, lam, hx)
@@ -248,6 +254,7 @@ mutable struct DeviceOptions
     factored_basis::Bool        # keep the tangent basis in factored form U = Jct W whenever the fused projected-CG iteration applies
     pp_precondition::Bool       # ProjPenalty's inner solves with the exact preconditioner of their operator (lfpsqp_pcg_pre); false = the reference's live path
     warm_factorize::Bool        # the small eigenproblem of the tangent setup starts from the previous outer iteration's Vt (lfpsqp_factorize_hint)
+    fused_tangent_step::Bool    # Jct'd rides with the Gram pass; ONE pass projects d, completes the Hessian diagonal and forms projcg!'s first U'r (lfpsqp_tangent_step)
 end
 mutable struct HipContext
     h::Ptr{Cvoid}
@@ -258,7 +265,7 @@ mutable struct HipContext
         r = Ref{Ptr{Cvoid}}(C_NULL)
         rc = c_ctx_create(Cint(device), r)
         rc == 0 || throw(HipError(rc, "lfpsqp_ctx_create failed: no usable MI355X (there is no CPU fallback)"))
-        ctx = new(r[], 0, 1, DeviceOptions(0, 3, true, false, true))
+        ctx = new(r[], 0, 1, DeviceOptions(0, 3, true, false, true, true))
         finalizer(c -> c_ctx_destroy(c.h), ctx)
         return ctx
     end
@@ -600,11 +607,16 @@ y_retract!(xnew::DeviceVector, x::DeviceVector, id::InequalityData) = (check(x.c
 # Jsp (optional SparseMatrix with the entries of the leading Jsp.m columns of Jct): the basis-forming products stream the nonzeros.
 # Z === nothing (dense Jct, W required): the basis Z = Jct*W is not formed -- the caller keeps it in factored form, DeviceBasis(nothing, rank, (Jct, W))
 function ksvd!(Jct::DeviceMatrix, Z::Union{Nothing,DeviceMatrix}, Σ::Vector{Float64}, Vt::Matrix{Float64}; w2::Union{Nothing,DeviceVector}=nothing,
-               ϵ_rank::Float64=1e-10, W::Union{Nothing,Matrix{Float64}}=nothing, Jsp=nothing, Vt_prev::Union{Nothing,Matrix{Float64}}=nothing)
+               ϵ_rank::Float64=1e-10, W::Union{Nothing,Matrix{Float64}}=nothing, Jsp=nothing, Vt_prev::Union{Nothing,Matrix{Float64}}=nothing,
+               rhs::Union{Nothing,DeviceVector}=nothing, Jte::Union{Nothing,Vector{Float64}}=nothing)
+    # rhs / Jte (dense Jct only): Jte .= Jct' (sqrt.(w2) .* rhs), summed by the Gram pass itself (lfpsqp_factorize_rhs) -- the outer iteration's
+    # Jct'd (src/optimize.jl:306) without a GEMV-T pass of its own
     rank = Ref{Int64}(0)
     # warm start of the small eigenproblem from the previous outer iteration's Vt (lfpsqp_factorize_hint; ignored unless orthogonal)
     Vt_prev !== nothing && size(Vt_prev) == size(Vt) && check(Jct.ctx, c_factorize_hint(Jct.ctx.h, Vt_prev, Int64(size(Vt, 1))))
-    if Jsp === nothing
+    if Jsp === nothing && rhs !== nothing
+        check(Jct.ctx, c_factorize_rhs(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, zhandle(Z), Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank, rhs.h, Jte))
+    elseif Jsp === nothing
         check(Jct.ctx, c_factorize(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, zhandle(Z), Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
     else
         check(Jct.ctx, c_factorize_sp(Jct.ctx.h, Jsp.h, Jct.h, w2 === nothing ? C_NULL : w2.h, zhandle(Z), Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
@@ -628,11 +640,13 @@ cwork(w::ProjCGWork) = CWork(w.g.h, w.d.h, w.rp.h, w.Utr.h)
 
 # projcg!(x, λ, A, U, b, c; tol, maxit, work) -> (i, nr)  (src/projcg.jl:40-121), fused on the device for a diagonal A ...
 function projcg!(x::DeviceVector, λ::Union{Nothing,DeviceVector}, A::DiagOperator, U::AnyBasis, b::DeviceVector, c::Union{Nothing,DeviceVector};
-                 tol::Float64=1e-6, maxit::Int=length(b) + ncols(U), work::ProjCGWork=ProjCGWork(x, ncols(U)), n_global::Int=length(b))
+                 tol::Float64=1e-6, maxit::Int=length(b) + ncols(U), work::ProjCGWork=ProjCGWork(x, ncols(U)), n_global::Int=length(b),
+                 start_given::Bool=false)
     iters = Ref{Int64}(0); nr = Ref{Float64}(0.0)
+    flags = (λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA) | (start_given ? LFPSQP_PROJCG_START_GIVEN : Cint(0))
     GC.@preserve U begin
         check(x.ctx, c_projcg(x.ctx.h, x.h, λ === nothing ? C_NULL : λ.h, Ref(CDiagOp(A.a0, A.dg === nothing ? C_NULL : A.dg.h)), Ref(cbasis(U)),
-                              b.h, c === nothing ? C_NULL : c.h, tol, Int64(maxit), Int64(n_global), λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA,
+                              b.h, c === nothing ? C_NULL : c.h, tol, Int64(maxit), Int64(n_global), flags,
                               Ref(cwork(work)), iters, nr))
     end
     return Int(iters[]), nr[]          # (i, nr) exactly like the reference; nr == Inf and λ .== NaN on negative curvature
@@ -1280,6 +1294,12 @@ print_iter(i, fval, normc, fstep, normx, steptype, tn_iter, tn_res, mtype, iter1
 
 function hess_diag! end         # hess_diag!(problem, hx, x, λ): the diagonal of the Lagrangian Hessian, written into the device vector hx
 has_hess_diag(h) = hasmethod(hess_diag!, Tuple{typeof(h),DeviceVector,DeviceVector,Vector{Float64}})
+# The SPLIT of the diagonal Lagrangian Hessian a device-resident problem class offers: hess_diag! == hess_diag_objective! (no multipliers) followed by
+# hess_diag!(hess_constraints(P), hx, x, λ).  optimize_core folds the second half into its tangent-step pass (lfpsqp_tangent_step).
+function hess_diag_objective! end
+function hess_constraints end
+has_hess_split(h) = hasmethod(hess_diag_objective!, Tuple{typeof(h),DeviceVector,DeviceVector}) && hasmethod(hess_constraints, Tuple{typeof(h)})
+scalar_hessian(h) = false      # true: grad^2 of the Lagrangian is a multiple of I (projected CG ends after one iteration: no allocation by trial)
 
 function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::Vector{Float64}, xl, xu, m::Int, param::LFPSQPParams=LFPSQPParams();
                        n_global::Int=length(x0))
@@ -1318,6 +1338,11 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     # (the library says whether this context can run projcg! without Z for this Jct: one-pass kernels on, shape inside their limits, or a
     # sparse twin the nonzero path covers; otherwise Z is materialised and every path has its two-pass form)
     factored_basis = ctx.options.factored_basis && diagonal_hessian && 4 <= m <= 1024 && factored_basis_supported(ctx, Jct, jsp === nothing ? C_NULL : jsp.h)
+    # allocation by trial pays after several hundred projected-CG iterations; a Lagrangian Hessian that is a multiple of I (config 3) ends every
+    # truncated-Newton solve after one: such a run takes its first allocations
+    saved_tries = ctx.options.placement_tries
+    few_cg = scalar_hessian(hess_lag_vec!) && !ineq
+    few_cg && saved_tries > 1 && set_placement!(ctx, 1)
     if factored_basis
         vs = vectors_placed(ctx, Jct, ineq ? 0 : n, 5; N=ineq ? n : 0)
         projcgwork = ProjCGWork(vs[1], vs[2], vs[4], DeviceVector(ctx, max(m, 1)), vs[5])
@@ -1333,6 +1358,10 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
         a_placed = nothing
         idecomp = InequalityDecomp(ctx, n, m, Jct)
     end
+    ctx.options.placement_tries != saved_tries && set_placement!(ctx, saved_tries)
+    # the tangent step with fewer passes (lfpsqp_tangent_step): plain factored basis over dense gradients, truncated-Newton steps on
+    fuse_tangent = factored_basis && !ineq && param.do_newton && jsp === nothing && m > 0 && ctx.options.fused_tangent_step
+    Jtd = zeros(max(m, 1)); Utd = zeros(max(m, 1))
     idecomp.W = m > 0 ? zeros(m, m) : nothing                 # ksvd!'s small factor: Z == Jct*W
     jsp === nothing || (idecomp.Jsp = jsp.h)                  # sparse twin: the stacked basis is applied on the nonzeros too
     Z, Σ, Vt = idecomp.Z, idecomp.Σ, idecomp.Vt
@@ -1360,7 +1389,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     end
     nr = NR(nothing, Σ, Vt, param.ϵ_c, param.maxiter_retract, ineq, idata)
     pp = ProjPenalty(c! isa DeviceConstraints ? c! : jac!, m, m, param.μ0, param.ϵ_c, param.maxiter_retract, param.maxiter_pcg,
-                     ProjPenaltyWork(x, m, n, ineq; against=(m > 0 ? Jct : nothing)), ineq, idecomp, idata)
+                     ProjPenaltyWork(x, m, n, ineq; against=((m > 0 && !few_cg) ? Jct : nothing)), ineq, idecomp, idata)
     armijo_work = ArmijoWork(x)
     exact_work = (param.linesearch == exact && !param.disable_linesearch) ? ExactLinesearchWork(x) : nothing
     i = 0
@@ -1393,9 +1422,34 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             # :283-284 (the device keeps only Jct); a device-resident class skips the re-evaluation of c(x) when cval holds it already
             (cval_current && jac! isa DeviceConstraints) ? jac!(jac!, Jct, nothing, x) : jac!(Jct, cval, x)
             vprev = (i > 0 && prev_rank == m && ctx.options.warm_factorize) ? copy(Vt) : nothing
-            rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp, Vt_prev=vprev)     # :286-302
+            if fuse_tangent                                                             # Jct'd rides with the Gram pass (d is final before jac! runs)
+                rank = ksvd!(Jct, Z, Σ, Vt; ϵ_rank=param.ϵ_rank, W=idecomp.W, Vt_prev=vprev, rhs=d, Jte=Jtd)                          # :286-302
+            else
+                rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp, Vt_prev=vprev) # :286-302
+            end
             prev_rank = rank
-            if !ineq                                                                    # :305-308
+            if fuse_tangent && rank >= 1
+                # :305-343, :366-381 and src/projcg.jl:56-59 in one pass: d projected, λ_kkt, the Hessian diagonal completed, r0 = -d and U'r0 left
+                # in projcgwork for projcg!(...; start_given=true)
+                Ub = DeviceBasis(nothing, rank, (Jct, idecomp.W))
+                dss = Ref{Float64}(0.0)
+                cons_part = nothing
+                if has_hess_split(hess_lag_vec!)
+                    hess_diag_objective!(hess_lag_vec!, a_diag, x)
+                    cons_part = hess_constraints(hess_lag_vec!)
+                else                                                                    # a diagonal Hessian without the split needs λ_kkt first
+                    th = zeros(m)
+                    th[1:rank] .= (idecomp.W[:, 1:rank]' * Jtd[1:m]) ./ Σ[1:rank]
+                    λ_kkt .= Vt' * th
+                    hess_diag!(hess_lag_vec!, a_diag, x, λ_kkt)
+                end
+                GC.@preserve Ub cons_part begin
+                    cref = cons_part === nothing ? nothing : Ref(ccons(cons_part))
+                    check(ctx, c_tangent_step(ctx.h, Ref(cbasis(Ub)), Σ, Vt, Int64(m), Jtd, d.h,
+                                              cref === nothing ? Ptr{CConstraints}(C_NULL) : Base.unsafe_convert(Ptr{CConstraints}, cref), x.h, a_diag.h,
+                                              Ref(cwork(projcgwork)), Utd, λ_kkt, dss))
+                end
+            elseif !ineq                                                                # :305-308
                 Ub = jsp === nothing ? (Z === nothing ? DeviceBasis(nothing, rank, (Jct, idecomp.W)) : DeviceBasis(Z, rank)) : DeviceBasis(Z, rank, (Jct, idecomp.W), jsp.h)
                 mul!(tmp_m, adjoint(Ub), d)
                 mul!(d, Ub, tmp_m, -1.0, 1.0)
@@ -1409,7 +1463,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
         kkt_diff = norm(d, Inf)                                                         # :320
         pp.rank = rank
         steptype = 0; tn_iter = 0; tn_res = 0.0
-        if m > 0                                                                        # :331-343
+        if m > 0 && !(fuse_tangent && rank >= 1)                                        # :331-343 (the tangent step returned λ_kkt otherwise)
             th = download(tmp_m, m)
             th[1:rank] ./= Σ[1:rank]
             th[rank+1:m] .= 0.0
@@ -1435,14 +1489,16 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             prev_grad_norm = grad_norm
             nglob = ineq ? 2 * n_global : n_global
             if diagonal_hessian
-                if ineq
+                fused_now = fuse_tangent && rank >= 1
+                if fused_now                                                            # (a_diag was completed by the tangent step)
+                elseif ineq
                     hess_diag!(hess_lag_vec!, hx, x, λ_kkt)
                     check(ctx, c_augmented_diag(ctx.h, hx.h, lamy_kkt.h, Ref(cineq(idata)), a_diag.h))
                 else
                     hess_diag!(hess_lag_vec!, a_diag, x, λ_kkt)
                 end
                 tn_iter, tn_res = projcg!(newton_d, nothing, DiagOperator(0.0, a_diag), Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
-                                          work=projcgwork, n_global=nglob)
+                                          work=projcgwork, n_global=nglob, start_given=fused_now)
             else
                 tn_iter, tn_res = projcg!(newton_d, nothing, newton_apply!, Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
                                           work=projcgwork, n_global=nglob)
@@ -1474,7 +1530,10 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
         push!(obj_values, fval)
         disp && print_iter(i + 1, fval, m > 0 ? maximum(abs, cval) : 0.0, f_diff, step_diff, steptype, tn_iter, tn_res, mtype, iter1, iter2, α, flag)
         i += 1
-        (param.callback !== nothing && i % param.callback_period == 0) && param.callback(i, x)
+        if param.callback !== nothing && i % param.callback_period == 0
+            param.callback(i, x)
+            cval_current = false            # the callback holds the live iterate: if it edits x, cval is stale (the reference's jac! recomputes it, :283)
+        end
     end
     (i == param.maxiter && disp) && println("Warning: Maximum # of outer iterations reached")
     return download(x, n, 0), obj_values, λ_kkt, TerminationInfo(term_cond, f_diff, step_diff, kkt_diff, i)
@@ -1517,6 +1576,13 @@ function hess_diag!(P::QuadLinearBallBox, hx::DeviceVector, x::DeviceVector, λ:
     P.ploc == 1 && fill_range!(hx, P.n, 1, 0.0)
     return hx
 end
+function hess_diag_objective!(P::QuadLinearBallBox, hx::DeviceVector, x::DeviceVector)
+    fill_range!(hx, 0, P.n, 2.0)
+    P.ploc == 1 && fill_range!(hx, P.n, 1, 0.0)
+    return hx
+end
+hess_constraints(P::QuadLinearBallBox) = P.cons
+scalar_hessian(P::QuadLinearBallBox) = P.p == 0
 function optimize(P::QuadLinearBallBox, x0::Vector{Float64}, param::LFPSQPParams=LFPSQPParams())
     x0a, xl, xu = x0, P.xl, P.xu
     if P.p == 1                                                                   # the slack transformation of src/optimize.jl:23-36
@@ -1567,6 +1633,13 @@ function hess_diag!(P::SeparableLinearBallBox, hx::DeviceVector, x::DeviceVector
     B.ploc == 1 && fill_range!(hx, B.n, 1, 0.0)
     return hx
 end
+function hess_diag_objective!(P::SeparableLinearBallBox, hx::DeviceVector, x::DeviceVector)
+    B = P.base
+    check(B.ctx, c_separable(B.ctx.h, Cint(P.kind), Cint(2), P.a.h, 0.0, P.c.h, 0.0, x.h, Int64(B.n), hx.h, Ptr{Float64}(C_NULL)))
+    B.ploc == 1 && fill_range!(hx, B.n, 1, 0.0)
+    return hx
+end
+hess_constraints(P::SeparableLinearBallBox) = P.base.cons
 function optimize(P::SeparableLinearBallBox, x0::Vector{Float64}, param::LFPSQPParams=LFPSQPParams())
     B = P.base
     x0a, xl, xu = x0, B.xl, B.xu
@@ -1610,6 +1683,9 @@ function hess_diag!(P::SeparableElementwiseBox, hx::DeviceVector, x::DeviceVecto
     check(P.ctx, c_separable(P.ctx.h, Cint(P.kind), Cint(2), P.a.h, 0.0, P.c.h, 0.0, x.h, Int64(P.cons.Jct.n), hx.h, Ptr{Float64}(C_NULL)))
     return hess_diag!(P.cons, hx, x, λ)
 end
+hess_diag_objective!(P::SeparableElementwiseBox, hx::DeviceVector, x::DeviceVector) =
+    (check(P.ctx, c_separable(P.ctx.h, Cint(P.kind), Cint(2), P.a.h, 0.0, P.c.h, 0.0, x.h, Int64(P.cons.Jct.n), hx.h, Ptr{Float64}(C_NULL))); hx)
+hess_constraints(P::SeparableElementwiseBox) = P.cons
 function optimize(P::SeparableElementwiseBox, x0::Vector{Float64}, param::LFPSQPParams=LFPSQPParams())
     return optimize_core(P.ctx, x -> objective(P, x), (g, x) -> gradient!(P, g, x), P.cons, (J, cv, x) -> jac!(P.cons, J, cv, x), P,
                          x0, P.xl, P.xu, P.cons.m_lin, param; n_global=P.n_global)

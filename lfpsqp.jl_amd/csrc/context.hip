@@ -264,92 +264,12 @@ int read_back(lfpsqp_ctx* ctx, const double* dev, double* host, int64_t count) {
 
 using namespace lfpsqp;
 
-#ifdef LFPSQP_VMM_EXPERIMENT
-// EXPERIMENT (tools/gpu_vmm_probe.sh, not in the product build): n-vectors and matrices from the virtual-memory API instead of
-// hipMalloc.  LFPSQP_VMM=1: one physical handle per buffer; LFPSQP_VMM=<c> > 1: physical chunks of c MB each, created
-// one by one and mapped back to back (LFPSQP_VMM_REV=1: mapped in reverse order of creation).
-#include <mutex>
-#include <unordered_map>
-#include <vector>
-namespace {
-struct VmmRec { std::vector<hipMemGenericAllocationHandle_t> h; size_t size; };
-std::mutex vmm_mu;
-std::unordered_map<void*, VmmRec> vmm_map;
-int vmm_mode() { static int m = [] { const char* e = getenv("LFPSQP_VMM"); return e ? atoi(e) : 0; }(); return m; }
-hipError_t dev_alloc(void** out, size_t bytes) {
-    const int mode = vmm_mode();
-    if (mode <= 0 || (getenv("LFPSQP_VMM_VEC_ONLY") && bytes > ((size_t)1 << 30))) return hipMalloc(out, bytes);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    hipMemAllocationProp prop{};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = dev;
-    size_t gran = 0;
-    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
-    if (e != hipSuccess) return e;
-    static bool said = false;
-    if (!said) { said = true; fprintf(stderr, "lfpsqp: VMM allocations, granularity %zu bytes, mode %d\n", gran, mode); }
-    const size_t chunk = mode == 1 ? (bytes + gran - 1) / gran * gran : ((size_t)mode << 20);
-    const size_t size = (bytes + chunk - 1) / chunk * chunk;
-    void* va = nullptr;
-    e = hipMemAddressReserve(&va, size, 0, nullptr, 0);
-    if (e != hipSuccess) return e;
-    VmmRec rec;
-    rec.size = size;
-    const size_t nch = size / chunk;
-    for (size_t c = 0; c < nch; ++c) {
-        hipMemGenericAllocationHandle_t h;
-        e = hipMemCreate(&h, chunk, &prop, 0);
-        if (e != hipSuccess) return e;
-        rec.h.push_back(h);
-    }
-    const bool rev = getenv("LFPSQP_VMM_REV") != nullptr;
-    for (size_t c = 0; c < nch; ++c) {
-        e = hipMemMap((char*)va + c * chunk, chunk, 0, rec.h[rev ? nch - 1 - c : c], 0);
-        if (e != hipSuccess) return e;
-    }
-    hipMemAccessDesc ad{};
-    ad.location = prop.location;
-    ad.flags = hipMemAccessFlagsProtReadWrite;
-    e = hipMemSetAccess(va, size, &ad, 1);
-    if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lk(vmm_mu);
-    vmm_map[va] = std::move(rec);
-    *out = va;
-    return hipSuccess;
-}
-void dev_free(void* p) {
-    VmmRec rec;
-    {
-        std::lock_guard<std::mutex> lk(vmm_mu);
-        auto it = vmm_map.find(p);
-        if (it == vmm_map.end()) { (void)hipFree(p); return; }
-        rec = std::move(it->second);
-        vmm_map.erase(it);
-    }
-    (void)hipMemUnmap(p, rec.size);
-    for (auto h : rec.h) (void)hipMemRelease(h);
-    (void)hipMemAddressFree(p, rec.size);
-}
-std::unordered_map<lfpsqp_vec*, double*> skew_base;
-}  // namespace
-// EXPERIMENT (tools/skew_probe.py): move a vector's start inside its (over-sized) allocation; such a vector is never freed
-extern "C" int lfpsqp_x_vec_skew(lfpsqp_vec* v, int64_t skew_doubles, int64_t n) {
-    std::lock_guard<std::mutex> lk(vmm_mu);
-    auto it = skew_base.find(v);
-    if (it == skew_base.end()) it = skew_base.emplace(v, v->p).first;
-    v->p = it->second + skew_doubles;
-    v->n = n;
-    v->cap = round_up(n > 0 ? n : 1, kPadRows);
-    return 0;
-}
-#else
+// (device buffers come from hipMalloc; the virtual-memory-API experiment of round 3 -- FINDINGS.md 6, tools/archive/gpu_vmm_probe.sh -- was a
+// variant build and is no longer in the sources)
 namespace {
 inline hipError_t dev_alloc(void** out, size_t bytes) { return hipMalloc(out, bytes); }
 inline void dev_free(void* p) { (void)hipFree(p); }
 }  // namespace
-#endif
 
 // dst[:, j] = rs .* src[:, j] + u w_j: the matrix a view stands for (lfpsqp_mat_copy of a view; 16 columns per block row)
 __global__ __launch_bounds__(lfpsqp::kThreads) void view_copy_kernel(const double* __restrict__ A, const double* __restrict__ rs, const double* __restrict__ u,

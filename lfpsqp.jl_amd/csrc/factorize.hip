@@ -1176,6 +1176,15 @@ static int factorize_core(lfpsqp_ctx* ctx, int m, const GramFn& gramA, const Rmu
 
 using namespace lfpsqp;
 
+// The weighted Gram kernel scales BOTH operands by sqrt(w2) (one staged operand for a diagonal block): weights must be >= 0 -- they are squares
+// in every use of the hot path (Dy^2, phi'^2).  A negative weight turns its row into NaN: reported as an argument error, not returned as data.
+static int check_weights(lfpsqp_ctx* ctx, bool weighted, const std::vector<double>& G) {
+    if (!weighted) return 0;
+    for (double g : G)
+        if (g != g) return lfpsqp::set_err(ctx, LFPSQP_ERR_ARG, "lfpsqp_gram: non-finite weighted Gram matrix -- the weights w2 must be >= 0 (the kernel applies sqrt(w2) to both operands)");
+    return 0;
+}
+
 extern "C" {
 
 int lfpsqp_gram(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* w2, double* G_host) {
@@ -1183,6 +1192,7 @@ int lfpsqp_gram(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsq
     LF_ARG(ctx, ctx && M && G_host && ncols >= 0 && ncols <= M->m && (!w2 || w2->n == M->n));
     std::vector<double> G;
     LF_TRY(gram_impl(ctx, M, (int)ncols, w2 ? w2->p : nullptr, G));
+    LF_TRY(check_weights(ctx, w2 != nullptr, G));
     for (size_t i = 0; i < G.size(); ++i) G_host[i] = G[i];
     return 0;
 }
@@ -1229,6 +1239,7 @@ int lfpsqp_gram_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const l
         rhs.e[rhs.nx++] = e[k]->p;
     }
     LF_TRY(gram_impl(ctx, M, (int)ncols, w2 ? w2->p : nullptr, G, nx > 0 ? &rhs : nullptr));
+    LF_TRY(check_weights(ctx, w2 != nullptr, G));
     for (size_t i = 0; i < G.size(); ++i) G_host[i] = G[i];
     for (size_t i = 0; i < X.size(); ++i) X_host[i] = X[i];
     return 0;

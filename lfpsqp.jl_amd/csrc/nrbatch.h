@@ -283,4 +283,221 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
 }
 
 
+// ---- WIDE form: 132 < columns <= 528 --------------------------------------------------------------------------------------------------
+// A 16-row tile of 512 columns is 128 doubles per lane: it does not fit one wave.  As in the wide form of the one-pass kernel the FOUR waves of a
+// workgroup share one 16-row tile and split its columns -- wave w holds the column groups [w CPL, (w + 1) CPL) -- and a pass takes up to
+// EIGHT trials (the coefficient table of 528 columns x 16 trials would be 66 KB of LDS: one workgroup per CU; with eight it is 33 KB and two fit):
+//   first product   per wave over its columns, Y'[trial, row] partial sums; the four partials meet in LDS (barrier 1);
+//   row update      16 rows x 8 trials = 128 updates: waves 0 and 1, one (row, trial) per lane (trial kq + 4 wave); the new values go to the
+//                   workgroup's shared B-operand area (barrier 2);
+//   second product  per wave over its own columns (transposed through its own LDS staging area, exactly as the narrow form), C[column, trial].
+// The MFMA's N dimension is 16: trials 8 .. 15 do not exist -- their coefficient lanes read trial r16 & 7 (a duplicate: it only reaches output
+// rows nobody reads), their B-operand entries are zero.  Arithmetic per tile and wave at 512 columns: 32 + 32 MFMAs of 64 cycles against ~12000
+// cycles of HBM time per tile pair and CU: still HBM-bound.  One partial row per WORKGROUP: [trial * ncT + col] (8 x ncT), then the 8 ball partials.
+constexpr int kNRBWideTrials = 8;
+
+template <bool ST, int CPL>
+__global__ __launch_bounds__(kThreads, 2) void nrb_mfma_wide_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n, int64_t rounds,
+                                                                    const double* __restrict__ t, int t_stride, NRBatchArgs ep, double* __restrict__ part,
+                                                                    int part_ld) {
+    if (ld_stat(ep.all) != 0) return;
+    constexpr int NT = kNRBWideTrials;
+    constexpr int NBLK = (CPL + 3) / 4;                       // 16-column blocks of this wave's second product
+    constexpr int NCH = (CPL + 15) / 16;                      // chunks of 16 column registers (64 columns) staged at a time
+    constexpr int kStep = 16;
+    __shared__ double ts[kWaves * CPL * 4][NT];
+    __shared__ double tj[kWaves][16 * kNRBLdr];
+    __shared__ double vs[16 * 17];
+    __shared__ double ysh[kWaves][2][64];
+    __shared__ double* xp[NT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int g0 = wave * CPL;                                // first column group of this wave
+    const int glast = (ncN - 1) / 4, lastc0 = ncN - 4;
+    for (int j = threadIdx.x; j < kWaves * CPL * 4 * NT; j += kThreads) {
+        const int slot = j / NT, b = j - slot * NT, g = slot >> 2, hh = slot & 3;
+        double v = 0.0;
+        if (b < ep.nb) {
+            const double* tb = t + (int64_t)b * t_stride;
+            if (g < glast) v = ld_scal(tb + slot);
+            else if (g == glast && lastc0 + hh >= glast * 4) v = ld_scal(tb + lastc0 + hh);
+        }
+        ts[slot][b] = v;
+    }
+    for (int j = threadIdx.x; j < 16 * 17; j += kThreads) vs[j] = 0.0;       // (entries of the trials 8 .. 15 stay zero)
+    unsigned active = 0u;
+    for (int b = 0; b < ep.nb && b < NT; ++b)
+        if (ld_stat(ep.ist + 4 * b) == 0) active |= 1u << b;
+    if (threadIdx.x < NT) {
+        const int b = (int)threadIdx.x;
+        const int first = active ? __builtin_ctz(active) : 0;
+        xp[b] = ep.xnew[(b < ep.nb && ((active >> b) & 1u)) ? b : first];
+    }
+    __syncthreads();
+    const bool updater = wave < 2;                            // waves 0, 1: the row update of trial kq + 4 wave for row r16
+    const int mytrial = kq + 4 * (wave & 1);
+    const nrb_gptr xpv = (nrb_gptr)xp[mytrial];
+    const bool myact = updater && ((active >> mytrial) & 1u);
+    const int64_t q = rounds / gridDim.x, rem = rounds % gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * q + ((int64_t)blockIdx.x < rem ? (int64_t)blockIdx.x : rem);
+    const int cnt = (int)(q + ((int64_t)blockIdx.x < rem ? 1 : 0));
+    const int64_t row0 = t0 * kStep;
+    const uint32_t vo = (uint32_t)(r16 * 8) + (uint32_t)((int64_t)kq * ld * 8);
+    const int64_t cs = (int64_t)4 * ld * 8;
+    const char* Mb = reinterpret_cast<const char*>(M + row0);
+    const int64_t first_off = (int64_t)g0 * cs, last_off = (int64_t)lastc0 * ld * 8;
+    double a[CPL];
+    auto load_cols = [&](int k, int c0, int c1) {
+        const char* tb = Mb + (int64_t)k * (kStep * 8);
+        const char* lastb = tb + last_off;
+#pragma unroll
+        for (int c = c0; c < c1; ++c) a[c] = buf_load_f64<true>((g0 + c < glast) ? tb + first_off + (int64_t)c * cs : lastb, vo);
+    };
+    const NRStepE e = ep.e;
+    struct RowIn { NRStepE::Row sh; double xn, yn; };
+    auto fetch = [&](int64_t row) {
+        RowIn w;
+        const bool ok = row < n;
+        const int64_t rr = ok ? row : 0;
+        w.sh.xn = w.sh.yn = w.sh.kk = 0.0;
+        if (ST) {
+            w.sh.xo = e.xold[rr]; w.sh.yo = e.xold[e.hs + rr]; w.sh.ax = e.sx[rr]; w.sh.ay = e.sy[rr];
+            w.sh.q = e.q[rr]; w.sh.r = e.r[rr]; w.sh.s = e.s[rr]; w.sh.t = e.t[rr];
+        } else {
+            w.sh.xo = w.sh.yo = w.sh.ax = w.sh.ay = w.sh.q = w.sh.r = w.sh.s = w.sh.t = 0.0;
+        }
+        w.xn = xpv[rr];
+        w.yn = ST ? xpv[e.hs + rr] : 0.0;
+        return w;
+    };
+    nrb_f64x4 C[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) C[b] = nrb_f64x4{0.0, 0.0, 0.0, 0.0};
+    double ball = 0.0;
+    double* tjw = tj[wave];
+    double* const tjwr = tjw + r16 * kNRBLdr + kq;
+    const double* const tjrd = tjw + kq * kNRBLdr + r16;
+    // register CPL - 1 is staged from a COPY (alast) so that its reload for the next tile need not wait for the last chunk; where it goes: its
+    // true columns when it is an ordinary group of this wave, the shifted last group's true columns (relative to this wave's first column) when
+    // this wave holds the end of the matrix, nowhere when the wave lies beyond it
+    const int lrel = ((g0 + CPL - 1 < glast) ? 4 * (g0 + CPL - 1) + kq : lastc0 + kq) - 4 * g0;
+    double alast = 0.0;
+    load_cols(0, 0, CPL);
+    RowIn in = RowIn{};
+    if (updater) in = fetch(row0 + r16);
+    auto tj_write = [&](int h) {
+#pragma unroll
+        for (int c = 16 * h; c < 16 * h + 16 && c < CPL - 1; ++c)
+            if (g0 + c < glast) tjwr[4 * (c - 16 * h)] = a[c];
+        const int lc = lrel - kNRBChunk * h;
+        if (lc >= 0 && lc < kNRBChunk) tjw[r16 * kNRBLdr + lc] = alast;
+    };
+    nrb_f64x4 y;
+    auto first_product = [&]() {
+        nrb_f64x4 y0 = nrb_f64x4{0.0, 0.0, 0.0, 0.0}, y1 = nrb_f64x4{0.0, 0.0, 0.0, 0.0};
+        const int tr = r16 & (NT - 1);
+        double t0 = ts[4 * g0 + kq][tr], t1 = ts[4 * (g0 + (CPL > 1 ? 1 : 0)) + kq][tr];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const double tn = ts[4 * (g0 + (c + 2 < CPL ? c + 2 : 0)) + kq][tr];
+            if (c & 1) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, a[c], y1, 0, 0, 0);
+            else y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, a[c], y0, 0, 0, 0);
+            t0 = t1; t1 = tn;
+        }
+        y = y0 + y1;
+    };
+    auto tile_step = [&](int k, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        compiler_fence();
+        // ---- the four waves' partial first products meet: trials kq (v = 0) and kq + 4 (v = 1) of row r16 ----
+        ysh[wave][0][lane] = y[0];
+        ysh[wave][1][lane] = y[1];
+        __syncthreads();
+        const int64_t row = row0 + r16 + (int64_t)k * kStep;
+        const bool valid = row < n;
+        if (updater) {
+            const int v = wave;                              // (wave 0: trials 0 .. 3, wave 1: trials 4 .. 7)
+            const double ysum = (ysh[0][v][lane] + ysh[1][v][lane]) + (ysh[2][v][lane] + ysh[3][v][lane]);
+            double vv = 0.0;
+            if (myact) {
+                const YRowPre ypre = ST ? y_retract_pre(in.sh.yo, in.sh.q, in.sh.r, in.sh.s, in.sh.t) : YRowPre{0.0, 0.0, 0.0};
+                NRStepE::Row w = in.sh;
+                w.xn = in.xn; w.yn = in.yn;
+                double so[2] = {0.0, 0.0};
+                vv = e.apply1<ST>(row, 0u, ysum, valid, true, w, ball, so, 1, 0.0, ST ? &ypre : nullptr);
+                if (valid && !e.eval_only) {
+                    xpv[row] = so[0];
+                    if (ST) xpv[e.hs + row] = so[1];
+                }
+            }
+            vs[r16 * 17 + mytrial] = vv;
+        }
+        compiler_fence();
+        if (MORE) {
+            load_cols(k + 1, 0, NCH == 1 ? CPL : (16 < CPL - 1 ? 16 : CPL - 1));
+            if (NCH > 1) load_cols(k + 1, CPL - 1, CPL);
+        }
+        __syncthreads();
+        double bop[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bop[ks] = vs[(4 * ks + kq) * 17 + r16];      // B[k = row 4ks + kq][j = trial r16] (zero for r16 >= 8)
+        if (MORE && updater) in = fetch(row + kStep);
+        // ---- second product over this wave's columns, chunk by chunk ----
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+            if (h > 0) {
+                wave_lds_fence();
+                tj_write(h);
+                compiler_fence();
+                if (MORE) load_cols(k + 1, 16 * h, (16 * h + 16 < CPL - 1) ? 16 * h + 16 : CPL - 1);
+            }
+            wave_lds_fence();
+            constexpr int kBlkMax = 4;
+            const int nsteps = 4 * ((NBLK - 4 * h) < kBlkMax ? (NBLK - 4 * h) : kBlkMax);
+            auto rd = [&](int i) { return tjrd[4 * (i & 3) * kNRBLdr + 16 * (i >> 2)]; };
+            double p0 = rd(0), p1 = rd(1);
+#pragma unroll
+            for (int i = 0; i < 4 * kBlkMax; ++i) {
+                if (i < nsteps) {
+                    const double pn = rd(i + 2 < nsteps ? i + 2 : 0);
+                    C[4 * h + (i >> 2) < NBLK ? 4 * h + (i >> 2) : 0] =
+                        __builtin_amdgcn_mfma_f64_16x16x4f64(p0, bop[i & 3], C[4 * h + (i >> 2) < NBLK ? 4 * h + (i >> 2) : 0], 0, 0, 0);
+                    p0 = p1; p1 = pn;
+                }
+            }
+        }
+        wave_lds_fence();
+        if (MORE) {
+            first_product();
+            alast = a[CPL - 1];
+            tj_write(0);
+        }
+    };
+    first_product();
+    alast = a[CPL - 1];
+    tj_write(0);
+#pragma unroll 1
+    for (int k = 0; k < cnt - 1; ++k) tile_step(k, std::true_type());
+    tile_step(cnt - 1, std::false_type());
+    // ---- the workgroup's partial row: every wave its own columns ----
+    double* prow = part + (int64_t)blockIdx.x * part_ld;
+#pragma unroll
+    for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int rel = 16 * cb + kq + 4 * v;            // D[i = kq + 4v][j = trial r16]
+            const int col = 4 * g0 + rel;
+            if (rel < 4 * CPL && col < ncT && r16 < NT) prow[r16 * ncT + col] = C[cb][v];
+        }
+    if (updater) {
+        double s = ball;
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        if (r16 == 0) prow[NT * ncT + mytrial] = s;
+    }
+}
+
+
 }  // namespace lfpsqp

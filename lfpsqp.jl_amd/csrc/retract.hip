@@ -509,13 +509,9 @@ struct NRStepBatchRow {
         if ((w.active >> tr) & 1u) {                   // a finished trial keeps its iterate and contributes nothing
             NRStepE eb = e;
             eb.xnew = my_xnew(tr);
-#ifdef LFPSQP_ABLATE_NRB_STORE                               /* timing experiment: the batched step without its stores (results are wrong) */
-            mine = eb.apply1<ST>(i, o, acc_mine, valid, false, w.sh, ball);
-#else
             // (h < NB: one storing lane per row and trial; in the wide form all four waves hold the row and compute its update -- wave 0, `lead`,
             // stores and counts)
             mine = eb.apply1<ST>(i, o, acc_mine, valid, h < NB && lead, w.sh, ball);
-#endif
         }
         const int lane = (int)(threadIdx.x & 63u);
 #pragma unroll
@@ -756,6 +752,55 @@ static int nrb_mfma_launch(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int wm, int ml,
     LF_LAUNCH_CHECK(ctx);
     LF_TRY(launch_reduce(ctx, (int64_t)grid * kWaves, nout, part_ld, 0u, out, NoPost()));
     return allreduce_dev(ctx, out, nout);
+}
+
+// shape covered by the WIDE matrix-core form (nrb_mfma_wide_kernel: the four waves of a workgroup split the columns; up to 8 trials a pass)
+static bool nrb_wide_shape(int wm, int ml) { return wm > 132 && wm <= 528 && ml >= 1 && ml <= wm; }
+
+template <bool ST, int CPL>
+static int nrb_wide_launch(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int wm, int ml, int64_t N, const double* dwdelta, int wstride, const NRBatchArgs& ep,
+                           double* out) {
+    ++ctx->launch_epoch;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nrb_mfma_wide_kernel<ST, CPL>, kThreads, 0) != hipSuccess || nb < 1) nb = 1;
+        per_cu = nb;
+    }
+    const int64_t rounds = (N + 15) / 16;
+    const int nout = kNRBWideTrials * ml + kNRBWideTrials;
+    const int part_ld = (int)round_up(nout, 32);
+    if (rounds <= 0) {
+        LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
+        return allreduce_dev(ctx, out, nout);
+    }
+    int64_t g = (int64_t)per_cu * (ctx->num_cu > 0 ? ctx->num_cu : 1);
+    if (g > rounds) g = rounds;
+    const int grid = (int)(g < 1 ? 1 : g);
+    LF_TRY(ensure_part(ctx, (size_t)grid * part_ld + reduce_scratch(part_ld)));
+    prof_begin(ctx, 7);
+    hipLaunchKernelGGL((nrb_mfma_wide_kernel<ST, CPL>), dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, M->p, M->ld, wm, ml, N, rounds, dwdelta,
+                       wstride, ep, ctx->part, part_ld);
+    prof_end(ctx, 7);
+    LF_LAUNCH_CHECK(ctx);
+    LF_TRY(launch_reduce(ctx, (int64_t)grid, nout, part_ld, 0u, out, NoPost()));
+    return allreduce_dev(ctx, out, nout);
+}
+
+template <bool ST>
+static int nrb_wide_step(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, int wm, int ml, int64_t N, const double* dwdelta, int wstride,
+                         const NRStepE& ep0, lfpsqp_vec* const* xnew, int nb, double* draw) {
+    NRBatchArgs ep;
+    ep.e = ep0;
+    for (int b = 0; b < kNRBW; ++b) ep.xnew[b] = xnew[b < nb ? b : 0]->p;
+    ep.ist = ctx->istat + I_NRB;
+    ep.all = ctx->istat + I_NRB_ALL;
+    ep.nb = nb;
+    const int cplw = ((wm + 3) / 4 + kWaves - 1) / kWaves;          // column groups per wave
+    if (cplw <= 16) return nrb_wide_launch<ST, 16>(ctx, cons->Jct, wm, ml, N, dwdelta, wstride, ep, draw);
+    if (cplw <= 24) return nrb_wide_launch<ST, 24>(ctx, cons->Jct, wm, ml, N, dwdelta, wstride, ep, draw);
+    if (cplw <= 32) return nrb_wide_launch<ST, 32>(ctx, cons->Jct, wm, ml, N, dwdelta, wstride, ep, draw);
+    return nrb_wide_launch<ST, 33>(ctx, cons->Jct, wm, ml, N, dwdelta, wstride, ep, draw);
 }
 
 template <bool ST>
@@ -1071,7 +1116,8 @@ int lfpsqp_retract_nr_batch_width(const lfpsqp_ctx* ctx, const lfpsqp_basis* U, 
     const int ml = (int)cons->m_lin;
     const int wm = (U->A && U->W && U->A->p == cons->Jct->p && U->A->m <= kOnepassMaxCols) ? (int)U->A->m : 0;
     if (!wm || U->ncols > kNRMaxM || !onepass_cw(ctx, wm, cons->Jct->ld, cons->Jct->n)) return 0;
-    *width = (nrb_mfma_shape(wm, ml) && ctx->tune_nrb_mfma >= 0) ? kNRBatchMax : 4;
+    *width = (nrb_mfma_shape(wm, ml) && ctx->tune_nrb_mfma >= 0) ? kNRBatchMax
+             : ((nrb_wide_shape(wm, ml) && ctx->tune_nrb_mfma >= 0) ? kNRBWideTrials : 4);
     return 0;
 }
 
@@ -1110,8 +1156,9 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
     // cores (ctx->tune_nrb_mfma: 1 = the matrix-core form for every batch its shape covers, -1 = never)
     // (from three trials on the matrix-core form is at least as fast without bounds -- 2.0-2.2 ms against 2.0-2.25 for four trials at 1e7 x 128 --
     // and much faster with them: 2.6 against 3.5 ms)
-    const bool mfma = nrb_mfma_shape(wm, ml) && ctx->tune_nrb_mfma >= 0 && (nb > 2 || ctx->tune_nrb_mfma > 0);
-    const int NBk = mfma ? kNRBatchMax : (nb <= 2 ? 2 : 4);
+    const bool wide = nrb_wide_shape(wm, ml) && ctx->tune_nrb_mfma >= 0 && (nb > 2 || ctx->tune_nrb_mfma > 0);      // the matrix-core form of 133 .. 528 columns
+    const bool mfma = wide || (nrb_mfma_shape(wm, ml) && ctx->tune_nrb_mfma >= 0 && (nb > 2 || ctx->tune_nrb_mfma > 0));
+    const int NBk = wide ? kNRBWideTrials : (mfma ? kNRBatchMax : (nb <= 2 ? 2 : 4));
     const size_t mm = (size_t)m * m;
     const int wstride = (int)round_up(wm, 2);
     const int rawn = NBk * ml + NBk;
@@ -1170,7 +1217,9 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
         }
         lfpsqp_vec* xe[kNRBatchMax];
         for (int b = 0; b < kNRBatchMax; ++b) xe[b] = xnew[b < nb ? b : 0];
-        if (ineq) LF_TRY((nrb_mfma_step<true>(ctx, cons, wm, ml, N, ctx->d_zeros, 0, e0, xe, nb, draw)));
+        if (wide && ineq) LF_TRY((nrb_wide_step<true>(ctx, cons, wm, ml, N, ctx->d_zeros, 0, e0, xe, nb, draw)));
+        else if (wide) LF_TRY((nrb_wide_step<false>(ctx, cons, wm, ml, N, ctx->d_zeros, 0, e0, xe, nb, draw)));
+        else if (ineq) LF_TRY((nrb_mfma_step<true>(ctx, cons, wm, ml, N, ctx->d_zeros, 0, e0, xe, nb, draw)));
         else LF_TRY((nrb_mfma_step<false>(ctx, cons, wm, ml, N, ctx->d_zeros, 0, e0, xe, nb, draw)));
     }
     if (NBk > nb) {                                    // born finished: status 1, flag 1
@@ -1186,7 +1235,10 @@ int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double
     int64_t it = 0;
     bool done = false;
     while (!done && it < maxiter) {
-        if (mfma) {
+        if (wide) {
+            if (ineq) LF_TRY((nrb_wide_step<true>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, nb, draw)));
+            else LF_TRY((nrb_wide_step<false>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, nb, draw)));
+        } else if (mfma) {
             if (ineq) LF_TRY((nrb_mfma_step<true>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, nb, draw)));
             else LF_TRY((nrb_mfma_step<false>(ctx, cons, wm, ml, N, dwdelta, wstride, ep, xn, nb, draw)));
         } else if (NBk == 2) {

@@ -18,9 +18,7 @@ class ArmijoWork:  # src/linesearch.jl:1-5
         self.prev_failures = 0     # ... and how many: the automatic batch width follows it
 
     def batch_vectors(self, k):
-        if self.batch is None or len(self.batch[0]) < k:
-            self.batch = ([self._mk() for _ in range(k)], [self._mk() for _ in range(k)])
-        return self.batch
+        return _grow_batch(self, k)
 
 
 class ExactLinesearchWork:  # :7-14
@@ -33,9 +31,28 @@ class ExactLinesearchWork:  # :7-14
         self.prev_failures = 0
 
     def batch_vectors(self, k):
-        if self.batch is None or len(self.batch[0]) < k:
-            self.batch = ([self._mk() for _ in range(k)], [self._mk() for _ in range(k)])
-        return self.batch
+        return _grow_batch(self, k)
+
+
+def _grow_batch(work, k):
+    """(xtildes, xnews): up to k pairs of trial vectors, kept for the rest of the run (k = 16 with the stacked bound layout at n = 1e7 is 5 GB).
+    The lists GROW pair by pair; when device memory runs out they stay as long as they got and the search batches that many -- a run that
+    one-by-one retractions would have completed does not fail for want of a wider pass."""
+    from ._capi import LfpsqpError
+    if work.batch is None:
+        work.batch = ([], [])
+    while len(work.batch[0]) < k:
+        a = b = None
+        try:
+            a = work._mk()
+            b = work._mk()
+        except LfpsqpError:
+            if a is not None:
+                a.free()
+            break
+        work.batch[0].append(a)
+        work.batch[1].append(b)
+    return work.batch
 
 
 def _batch_width(work, retract_method, c_):
@@ -97,6 +114,11 @@ def armijo_(xnew, x, n, d, g, f, fval, retract_method, cval, c_, param, work):
             got = None
             if failed_once and nbatch > 1 and not param.disable_linesearch:
                 xts, xns = (vs_[:nbatch] for vs_ in work.batch_vectors(nbatch))      # (the cache may hold more from an earlier, wider batch)
+                if len(xts) < nbatch:                          # device memory ran out: as wide as the vectors that exist
+                    nbatch = nbatch_cap = max(len(xts), 1)
+                    if nbatch < 2:
+                        failed_once = False
+                        continue
                 alphas = [alpha]
                 for _ in range(nbatch - 1):
                     alphas.append(alphas[-1] * param.s)
@@ -186,6 +208,9 @@ def exact_linesearch_(xnew, x, n, d, f, fval, retract_method, cval, c_, param, w
         if nbatch > 1:
             import numpy as _np
             xts, xns = (vs_[:nbatch] for vs_ in work.batch_vectors(nbatch))      # (the cache may hold more from an earlier, wider batch)
+            if len(xts) < nbatch:                              # device memory ran out: as wide as the vectors that exist
+                nbatch = len(xts)
+        if nbatch > 1:
             alphas = [a_next]
             for _ in range(nbatch - 1):
                 alphas.append(alphas[-1] * phi1)          # the reference's own products a_c *= phi1 (:196)

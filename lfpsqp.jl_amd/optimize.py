@@ -114,6 +114,18 @@ def _amax_host(v):
     return float(np.max(np.abs(v), initial=0.0))
 
 
+def _allocate_projcg_work(ctx, n, m, ineq, Jct, factored, diagonal_hessian):
+    """ProjCGWork (src/optimize.jl:214) and, unless the basis stays in factored form, the basis Z (:191) -- allocated TOGETHER and by trial
+    (lfpsqp_vecs_alloc_placed / lfpsqp_basis_work_alloc_placed: the speed of the fused kernel is a property of the pair of allocations)."""
+    if factored:
+        projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=Jct, extra=1)
+        idecomp = InequalityDecomp(ctx, n, m, Jct, factored=True)
+    else:
+        projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=(("new", n, m) if m > 0 else None), extra=1 if diagonal_hessian else 0)
+        idecomp = InequalityDecomp(ctx, n, m, Jct, Z=projcgwork.basis)
+    return projcgwork, idecomp
+
+
 def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: LFPSQPParams | None = None, *, ctx: Context,
                   n_global: int | None = None, trace=None):
     """src/optimize.jl:119-443.  x0 / xl / xu are host arrays (this rank's shard)."""
@@ -173,12 +185,19 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     # Z is materialised and every path has its two-pass form.
     factored = (bool(ctx.options.factored_basis) and diagonal_hessian and 4 <= m <= 1024
                 and ctx.factored_basis_supported(Jct, getattr(c_, "Jsp", None)))
-    if factored:
-        projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=Jct, extra=1)
-        idecomp = InequalityDecomp(ctx, n, m, Jct, factored=True)
-    else:
-        projcgwork = ProjCGWork(ctx, n, m, n if ineq else None, against=(("new", n, m) if m > 0 else None), extra=1 if diagonal_hessian else 0)
-        idecomp = InequalityDecomp(ctx, n, m, Jct, Z=projcgwork.basis)
+    # Allocation by trial costs tens of milliseconds (18 timed launches of F at n = 1e7, m = 128: 36 ms) and returns 3 % of every projected-CG
+    # iteration: it pays after several hundred iterations.  A Lagrangian Hessian that is a multiple of the identity (f = |x - xc|^2 under linear
+    # equalities, no bounds: BASELINE config 3) ends every truncated-Newton solve after ONE iteration and the outer loop after one or two --
+    # such a run takes its first allocations.
+    saved_tries = ctx.options.placement_tries
+    few_cg = bool(getattr(hess_lag_vec_, "scalar_hessian", False)) and not ineq
+    if few_cg and saved_tries > 1:
+        ctx.set_placement(1)
+    try:
+        projcgwork, idecomp = _allocate_projcg_work(ctx, n, m, ineq, Jct, factored, diagonal_hessian)
+    finally:
+        if ctx.options.placement_tries != saved_tries:
+            ctx.set_placement(saved_tries)
     Z = idecomp.Z
     # The tangent step with fewer passes (lfpsqp_tangent_step): plain factored basis over dense gradients, truncated-Newton steps on
     fuse_tangent = (factored and not ineq and param.do_newton and getattr(c_, "Jsp", None) is None and m > 0
@@ -198,7 +217,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
 
     nr = NR(None, Sig, Vt, param.eps_c, param.maxiter_retract, NRWork(m), ineq, ineqdata)
     pp = ProjPenalty(jac_, None, Sig, Vt, m, param.mu0, param.eps_c, param.maxiter_retract, param.maxiter_pcg,
-                     LazyProjPenaltyWork(ctx, m, n, ineq, against=Jct if m > 0 else None), ineq, idecomp, ineqdata)
+                     LazyProjPenaltyWork(ctx, m, n, ineq, against=Jct if (m > 0 and not few_cg) else None), ineq, idecomp, ineqdata)
     euc = Euclidean()
     yr = YRetract(ineqdata) if ineq else None
     armijo_work = ArmijoWork(x)
@@ -383,6 +402,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
         i += 1
         if param.callback is not None and i % param.callback_period == 0:
             param.callback(i, x)
+            cval_current = False                 # the callback holds the live iterate: if it edits x, cval is stale (the reference's jac! recomputes it, :283)
 
     if i == param.maxiter and disp:
         print("Warning: Maximum # of outer iterations reached")

@@ -43,6 +43,10 @@ class QuadLinearBallBox:
         self.xu = None if xu is None else np.asarray(xu, dtype=np.float64)
         self.n_global = n if n_global is None else n_global
         self.is_diagonal = True
+        # grad^2 of the Lagrangian is 2 I when there is no ball: the truncated-Newton solve converges in ONE projected-CG iteration (config 3).
+        # optimize then takes its first allocations instead of placing the work vectors by trial (tens of ms that a handful of iterations
+        # cannot repay)
+        self.scalar_hessian = self.p == 0 and type(self) is QuadLinearBallBox
 
     # -- callbacks in the contract of optimize_core -------------------------------------------
     def f(self, x: DeviceVector) -> float:

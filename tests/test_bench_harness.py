@@ -59,7 +59,7 @@ def test_bench_two_ranks_as_the_driver_launches_it(emu_lib):
 def test_bench_starts_its_own_ranks_when_called_without_a_launcher(emu_lib):
     """`python bench.py --gpus 4` with no torch.distributed.run around it (the form the driver uses for --gpus 1): the parent, which has
     touched no GPU, starts the ranks as one child, relays rank 0's line and the exit code.  Four ranks over the library's one-shot
-    peer-to-peer all-reduce (named explicitly, then picked by --comm auto: the emulator's ranks share "device 0", so RCCL is not probed);
+    peer-to-peer all-reduce (named explicitly, then picked by --comm auto: the emulator build has no RCCL behind it, so that probe is skipped and recorded);
     the solve is the single-rank one."""
     import os
     import subprocess

@@ -1,0 +1,107 @@
+"""Trajectory parity at BASELINE's FULL size ("at full size for as many outer iterations as host RAM allows"; the reference's
+trajectory hook is the per-iteration callback, src/optimize.jl:432-434).
+
+  * projcg! (src/projcg.jl:40-121) at n = 1e7, m = 128: 30 iterations on the GPU against oracle/projcg_port.c on the box's host cores --
+    the same orthonormal basis on both sides, equal iteration count, iterates within 1e-10 relative;
+  * config 3 (random dense linear equalities, n = 1e7, m = 128): `optimize` on the GPU against the numpy oracle's run of the same problem --
+    x after every outer iteration within 1e-10, equal counts / step types / accepted steps.  The oracle factorises a 1e7 x 128 matrix with
+    LAPACK dgesvd twice (as the reference does) and holds four 10 GB matrices: it needs ~100 GB of host memory and a few minutes of host
+    time, so the case is skipped -- with the reason printed -- on a box that does not have them.
+Measured deviations are printed (run with -s) and recorded in profiles/."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import lfpsqp_jl_amd as L
+from oracle import lfpsqp_ref as R
+from oracle import port, synth
+
+from .test_capi_retractions import _compare_traces
+
+pytestmark = pytest.mark.gpu
+
+N, M = 10_000_000, 128
+
+
+def _mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return 0.0
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_lib):
+    c = L.Context(0, gpu_lib)
+    yield c
+    c.close()
+
+
+def test_projcg_against_the_c_oracle_port_at_full_size(ctx):
+    """n = 1e7, m = 128, 30 iterations (tol = 0: both sides run to the iteration limit), kappa(A) = 9."""
+    need = 8.0 * N * (M + 12) / 2 ** 30 + 4
+    if _mem_available_gb() < need:
+        pytest.skip(f"host memory: {_mem_available_gb():.0f} GB available, the C port needs {need:.0f} GB at n = 1e7, m = 128")
+    Z = ctx.matrix(N, M).hash_fill(1)
+    L.orthonormalize_(Z)
+    Uh = Z.download()                                   # the SAME orthonormal basis for both sides (10.2 GB)
+    a = port.hash_vector(3, N, 0, 4.0, 5.0)
+    b = port.hash_vector(4, N)
+    port.lib().port_set_num_threads(port.usable_cpus())
+    t0 = time.perf_counter()
+    x0, l0, it0, nr0 = port.projcg(a, Uh, b, None, 0.0, 30)
+    t_cpu = time.perf_counter() - t0
+    x, lam = ctx.vector(N), ctx.vector(M)
+    ad, bd = ctx.vector(N).hash_fill(3, 0, 4.0, 5.0), ctx.vector(N).hash_fill(4)
+    ctx.sync()
+    t0 = time.perf_counter()
+    it, nr = L.projcg_(x, lam, L.DiagOperator(0.0, ad), L.DeviceBasis(Z), bd, None, tol=0.0, maxit=30)
+    t_gpu = time.perf_counter() - t0
+    xd = x.download()
+    dev = np.linalg.norm(xd - x0) / np.linalg.norm(x0)
+    dl = np.abs(lam.download() - l0).max()
+    print(f"[parity n=1e7 m=128 projcg! vs C port] iterations {it}/{it0}, nr {nr:.6e}/{nr0:.6e}, |x - x_port| / |x_port| = {dev:.2e}, "
+          f"max |lambda - lambda_port| = {dl:.2e}; C port {t_cpu:.1f} s on {port.usable_cpus()} host cores, GPU {t_gpu * 1e3:.0f} ms")
+    assert it == it0 == 30 and nr == pytest.approx(nr0, rel=1e-8)
+    assert dev <= 1e-10
+    assert dl <= 1e-9
+    Z.free()
+
+
+@pytest.mark.parametrize("do_project_retract", [False])
+def test_config3_trajectory_at_full_size(ctx, do_project_retract):
+    """BASELINE configs[2] itself: n = 1e7, m = 128, f = x'x, x0 = ones, Newton retraction; one outer iteration to kkt_tol."""
+    if os.environ.get("LFPSQP_SKIP_FULL_ORACLE"):
+        pytest.skip("LFPSQP_SKIP_FULL_ORACLE is set")
+    avail = _mem_available_gb()
+    if avail < 100.0:
+        pytest.skip(f"host memory: {avail:.0f} GB available, the numpy oracle of config 3 at n = 1e7 needs ~100 GB "
+                    "(Jc, Jct, U and dgesvd's copy of a 10.2 GB matrix next to the problem's own)")
+    port.lib().port_set_num_threads(port.usable_cpus())
+    t0 = time.perf_counter()
+    Jh = port.hash_matrix(1, N, M)                       # == synth.hash_matrix(1, N, M), bit for bit (tests/test_golden.py), in seconds
+    xstar = synth.hash_vector(2, N)
+    prob0 = synth.QuadLinearProblem(Jh, port.gemv_t(Jh, xstar))
+    x0 = np.ones(N)
+    tr0, tr = [], []
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, None, None, M,
+                                     R.LFPSQPParams(do_project_retract=do_project_retract, disp=R.DisplayOption.off), trace=tr0)
+    t_cpu = time.perf_counter() - t0
+    P = L.QuadLinearBallBox(ctx, N, M, ctx.matrix(N, M).hash_fill(1), prob0.b)
+    t0 = time.perf_counter()
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=do_project_retract, disp=L.DisplayOption.off), trace=tr)
+    t_gpu = time.perf_counter() - t0
+    assert ti.condition.name == tir.condition.name and ti.iter == tir.iter
+    _compare_traces(tr, tr0, rtol=1e-10)
+    dev = np.linalg.norm(x - xr) / np.linalg.norm(xr)
+    print(f"[parity n=1e7 m=128 config 3 {'PP' if do_project_retract else 'NR'}] {ti.iter} outer iteration(s) ({ti.condition.name}), "
+          f"|x - x_oracle| / |x_oracle| = {dev:.2e}, objective {obj[-1]:.12e} / {objr[-1]:.12e}; oracle {t_cpu:.0f} s on {port.usable_cpus()} host cores, "
+          f"GPU {t_gpu:.2f} s (with the trace's downloads)")
+    assert dev <= 1e-10
+    np.testing.assert_allclose(obj, objr, rtol=1e-12)
+    np.testing.assert_allclose(lam, lamr, rtol=1e-8, atol=1e-12)

@@ -90,7 +90,7 @@ def test_bench_two_ranks_over_p2p_at_the_headline_shape():
 def test_bench_two_ranks_without_a_launcher():
     """`python3 bench.py --gpus 2 --comm p2p --device 0` -- NO torch.distributed.run around it: bench.py starts its ranks itself (a child
     process, before anything touches the GPU) and prints the one line; --comm auto picks the same transport on a box whose ranks share the
-    GPU (RCCL refuses duplicate devices and is not probed).  The mailbox must be fine-grained memory."""
+    GPU (RCCL is probed too, refuses the duplicate device, and the record says so).  The mailbox must be fine-grained memory."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
@@ -109,3 +109,39 @@ def test_bench_two_ranks_without_a_launcher():
         assert pr["chosen"] == "p2p" and pr["p2p"]["mailbox_memory"] == "fine-grained", pr
         print(f"[bench --gpus 2, no launcher, --comm {comm}] {d['value']:.1f} it/s; {d['config']['comm']}; probe {pr}")
     assert out["p2p"]["check"] == out["auto"]["check"]
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_without_a_launcher():
+    """`python3 bench.py --gpus 8 --comm p2p --device 0 --rows 2e6 --cols 128` -- the command the driver runs on an 8-GPU node, here with the
+    eight ranks sharing the one GPU (reduction points src/projcg.jl:75,84,96,98,103, one all-reduce of 2m + 5 doubles per iteration over seven
+    peers' mailboxes): the solve is the one-rank solve (equal count, ||x|| and nr to 1e-10).  Through --comm auto, bring_up_comm probes BOTH
+    library transports: RCCL refuses the duplicate device on every rank (ncclCommInitRank: invalid usage), the record says so, and the run
+    carries on over the peer-to-peer transport -- bit-identical to the run that named it."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--rows", "2e6", "--cols", "128", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--prewarm-seconds", "0.2"]
+    out = {}
+    for comm in ("p2p", "auto"):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--comm", comm, "--device", "0", *common],
+                             cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d = out[comm] = json.loads(lines[0])
+        pr = d["config"]["comm_probe"]
+        print(f"[bench --gpus 8 on ONE GPU, no launcher, --comm {comm}] {d['value']:.1f} it/s; {d['config']['comm']}; comm_probe {pr}")
+        assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "row-sharded x8" and d["check"]["iters"] == 8
+        assert pr["chosen"] == "p2p" and pr["ranks_share_a_gpu"] and pr["p2p"]["ok"] and pr["p2p"]["mailbox_memory"] == "fine-grained"
+        if comm == "auto":
+            assert pr["rccl"]["ok"] is False and "ncclCommInitRank" in pr["rccl"]["refused"], pr      # probed, refused, said so
+    assert out["p2p"]["check"] == out["auto"]["check"]                       # fixed rank order: bit for bit
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], cwd=ROOT, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    c1, c8 = d1["check"], out["p2p"]["check"]
+    assert c1["iters"] == c8["iters"] == 8
+    assert abs(c1["x_norm"] - c8["x_norm"]) <= 1e-10 * c1["x_norm"] and abs(c1["nr"] - c8["nr"]) <= 1e-10 * c1["nr"]
+

@@ -20,13 +20,60 @@ def _is_emu(ctx):
     return "emulator" in ctx.device_name
 
 
-@pytest.mark.parametrize("cond", [1.0, 1e3])
+def _note(msg):
+    import warnings
+    warnings.warn("[pcg_pre] " + msg)
+    print("[pcg_pre] " + msg)
+
+
+@pytest.mark.parametrize("mu,tol", [(1e-1, 1e-8), (1e-1, 1e-12), (1e-2, 1e-10)])
+def test_fused_preconditioned_pcg_to_1e_10_on_a_normalised_block(dev_ctx, mu, tol):
+    """The 1e-10 site of lfpsqp_pcg_pre: a column-NORMALISED Jct (sigma_1^2 ~ 1) and mu >= 1e-2 keep the operator's condition number
+    (sigma_1^2 + mu) / mu below 1e4, so two correct solvers must agree to 1e-10 -- at the GPU's size (n = 3e5, m = 128) as on the emulator.
+    Against the oracle's pcg_ with M! = proj_precondition_ (src/retractions.jl:179-246, 248-257) on the same factors: equal flag and count
+    (ONE iteration, test/test_retractions.jl:126-139; a second one only where the tolerance is below what one leaves), iterate within 1e-10."""
+    ctx = dev_ctx
+    n, m = (2600, 12) if _is_emu(ctx) else (300_000, 128)
+    rng = np.random.default_rng(7)
+    Jh = synth.hash_matrix(1, n, m)
+    Jh = np.asfortranarray(Jh / np.linalg.norm(Jh, axis=0)[None, :])
+    Jct = ctx.matrix(n, m, Jh)
+    Z = ctx.matrix(n, m)
+    W = np.zeros((m, m), order="F")
+    S, Vt, rank = L.ksvd_(Jct, Z, W=W)
+    assert rank == m and (S[0] ** 2 + mu) / mu <= 1e4
+    Zh = Z.download()
+    w = L.ProjPenaltyWork(ctx, m, n, False)
+    q = ctx.vector(n)
+    bh = rng.standard_normal(n)
+    x0, r0 = np.zeros(n), bh.copy()
+    f0, i0 = R.pcg_(mu, Jh.T.copy(order="F"), lambda z_, r_: R.proj_precondition_(z_, r_, mu, Zh, S, m, np.zeros(m)), x0, r0, np.zeros(n),
+                    np.zeros(n), np.zeros(m), tol, 50)
+    x, r = ctx.vector(n), ctx.vector(n, bh)
+    flag, it = L.pcg_(mu, _JacPlain(Jct, w), L.ProjPrecondition(Jct, W, S, m, q), x, r, w.p, w.z, None, tol, 50)
+    xh = x.download()
+    dev = np.linalg.norm(xh - x0) / np.linalg.norm(x0)
+    print(f"[pcg_pre normalised n={n} m={m} mu={mu:g} tol={tol:g}] (flag, iterations) device {(flag, it)} oracle {(f0, i0)}, "
+          f"cond {(S[0] ** 2 + mu) / mu:.1f}, |x - x_oracle| / |x_oracle| = {dev:.2e}")
+    assert (flag, it) == (f0, i0) and it <= 2
+    assert dev <= 1e-10
+    true_res = lambda v: np.linalg.norm(mu * v + Jh @ (Jh.T @ v) - bh)
+    assert true_res(xh) <= max(2.0 * true_res(x0), 1e-13 * np.linalg.norm(bh))
+
+
+@pytest.mark.parametrize("cond", [1.0, 30.0, 1e3])
 def test_fused_preconditioned_pcg_matches_the_oracle(dev_ctx, cond):
+    """UNNORMALISED hash columns (sigma_1^2 ~ n / 3), optionally spread over a factor `cond`: the operator's own condition number
+    (sigma_1^2 + mu) / mu is 1e5 ... 1e14 here, which bounds how close two correct solvers can be -- the measured deviation is printed.
+    The 1e-10 site is test_fused_preconditioned_pcg_to_1e_10_on_a_normalised_block."""
     ctx = dev_ctx
     n, m = (2600, 12) if _is_emu(ctx) else (300_000, 128)
     rng = np.random.default_rng(3)
-    if not _is_emu(ctx):
-        cond = min(cond, 30.0)        # (at n = 3e5 a column scaling of 1e3 puts the operator's own condition number at 1e14: counts become noise)
+    if not _is_emu(ctx) and cond > 30.0:
+        pytest.skip("n = 3e5 with a column scaling of 1e3: the operator's condition number reaches 1e14, the polishing counts of two "
+                    "summation orders are noise (the emulator's size runs this case; the GPU runs cond = 30)")
+    if _is_emu(ctx) and cond == 30.0:
+        pytest.skip("the GPU's intermediate case; the emulator runs cond = 1 and 1e3")
     Jh = synth.hash_matrix(1, n, m) * np.logspace(0, np.log10(cond), m)[None, :]           # Jct (n x m)
     Jct = ctx.matrix(n, m, np.asfortranarray(Jh))
     Z = ctx.matrix(n, m)
@@ -56,7 +103,11 @@ def test_fused_preconditioned_pcg_matches_the_oracle(dev_ctx, cond):
         # x = (J'J + mu I)^-1 b is determined to eps * cond only, cond = (sigma_1^2 + mu) / mu (1e5 ... 1e14 at the GPU's size): that bounds
         # how close two correct solvers can be; 1e-10 where the conditioning allows it (the emulator's size)
         xtol = max(1e-10, 100.0 * np.finfo(float).eps * (S[0] ** 2 + mu) / mu)
-        assert np.linalg.norm(xh - x0) <= xtol * np.linalg.norm(x0), (np.linalg.norm(xh - x0) / np.linalg.norm(x0), xtol)
+        dev = np.linalg.norm(xh - x0) / np.linalg.norm(x0)
+        if xtol > 1e-10:      # a site looser than 1e-10 says what it measured
+            _note(f"n={n} m={m} cond={cond:g} mu={mu:g}: operator condition {(S[0] ** 2 + mu) / mu:.1e}, iterations device/oracle {it}/{i0}, "
+                  f"|x - x_oracle| / |x_oracle| = {dev:.2e} (tolerance {xtol:.1e})")
+        assert dev <= xtol, (dev, xtol)
         true_res = lambda v: np.linalg.norm(mu * v + Jh @ (Jh.T @ v) - bh)
         assert true_res(xh) <= 10.0 * max(true_res(x0), 1e-8 * np.linalg.norm(bh))       # (the recurrence residual is what pcg! tests, :235)
     # (b) an INEXACT preconditioner (the factors of a perturbed matrix, as when jac! has moved on from the driver's factorisation, :374):

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (ARCHIVED: the -DLFPSQP_VMM_EXPERIMENT variant of csrc/context.hip this probe needs was removed from the sources in round 5; git show a86abc9:lfpsqp.jl_amd/csrc/context.hip has it)
 # Does the virtual-memory API (hipMemCreate / hipMemMap, fixed-size physical chunks) change which allocations the fused projected-CG
 # kernel is slow on?  tools/placement_matrix_probe.py (3 bases x 4 work sets, F per pair) with hipMalloc and with a variant library built with
 # -DLFPSQP_VMM_EXPERIMENT (csrc/context.hip), interleaved:   gpurun -- bash tools/gpu_vmm_probe.sh [reps]

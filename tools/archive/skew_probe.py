@@ -1,4 +1,5 @@
 """EXPERIMENT: is the speed of the fused projected-CG kernel F a function of WHERE INSIDE one allocation its n-vectors start, at steps of
+(ARCHIVED: the -DLFPSQP_VMM_EXPERIMENT variant of csrc/context.hip this probe needs was removed from the sources in round 5; git show a86abc9:lfpsqp.jl_amd/csrc/context.hip has it)
 megabytes (steps up to 1 MB were tried in round 2: no)?  One basis, one set of over-sized vectors (x, g, d, rp, the diagonal of A), F timed with the
 vectors' starts moved by s MB -- all together, then one at a time.  Needs the variant library built with -DLFPSQP_VMM_EXPERIMENT
 (tools/gpu_vmm_probe.sh):   LFPSQP_LIB=lfpsqp.jl_amd/lib/variants/liblfpsqp_vmm.so python tools/skew_probe.py"""

@@ -8,7 +8,12 @@ import csv, glob, collections
 f = sorted(glob.glob("gpurun_out/trace_nrb/**/*kernel_trace.csv", recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "nrb_mfma_kernel" in r["Kernel_Name"] or "NRStepBatchRow" in r["Kernel_Name"]]
-seq = rows[idx[35]:idx[85] + 1]          # steady state of the batched loop (second timed repetition)
+# steady state of the batched loop: the middle third of the step kernels found (whatever --iters / --nbs produced them; the first launches
+# are the warm-up repetition, the last ones run with finished trials)
+if len(idx) < 9:
+    raise SystemExit(f"only {len(idx)} batched step kernels in the trace: nothing to average")
+lo, hi = len(idx) // 3, 2 * len(idx) // 3
+seq = rows[idx[lo]:idx[hi] + 1]
 def short(n):
     n = n.replace("void lfpsqp::", "").replace("lfpsqp::", "")
     return n[:60]
@@ -16,7 +21,7 @@ dur = collections.defaultdict(list); gaps = []
 for a, b in zip(seq, seq[1:]):
     dur[short(a["Kernel_Name"])].append(int(a["End_Timestamp"]) - int(a["Start_Timestamp"]))
     gaps.append(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]))
-steps = 50
+steps = hi - lo
 span = (int(seq[-1]["Start_Timestamp"]) - int(seq[0]["Start_Timestamp"])) / 1e3
 print(f"{steps} batched steps, {span/steps:.1f} us per step; kernels per step: {len(seq)/steps:.1f}; gaps per step {sum(gaps)/steps/1e3:.1f} us")
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
