@@ -66,6 +66,17 @@ __device__ __forceinline__ double buf_load_f64(const void* uniform_base, uint32_
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_base), 0, 0xffffffff, 0x00020000);
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_byte_off, 0, NT ? 2 : 0));
 }
+// a wave-uniform pointer forced into scalar registers (where the compiler, short of scalar registers, parks a uniform 64-bit base in vector
+// registers, every buffer load through it becomes a readfirstlane LOOP; two v_readfirstlane instead)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+#ifdef LFPSQP_HIP_EMULATED
+    return p;
+#else
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+#endif
+}
 // compiler-only ordering point for memory operations (no instruction is emitted)
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
@@ -522,7 +533,10 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
     double* const stg = (LACC && STG > 0) ? stg_own : buf;
     __shared__ double accx[WIDE ? 2 : 1][WIDE ? NA : 1][WIDE ? kWaves : 1][WIDE ? RW : 1];
     auto red = [&](int w, int qq, int sl) -> double& { return buf[(w * NV + qq) * NC + sl]; };
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index as a SCALAR: in the wide form it selects the wave's column range, i.e. the base of every buffer load of the tile -- as
+    // threadIdx.x >> 6 the compiler must assume a lane-dependent base and wraps each load in a readfirstlane loop: 66 such loops in the
+    // 32-register wide instantiation, round 5)
+    const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = (lane & 3) | ((lane >> 4) << 2), h = (lane >> 2) & 3;
     const int g0 = WIDE ? wave * CPL : 0;            // first column group of this wave
     // Column groups: group g < glast holds columns g*CW .. g*CW+CW-1; the last group is shifted back to the columns
@@ -569,7 +583,8 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
         const char* lastb = tb + last_off;
 #pragma unroll
         for (int c = c0; c < c1; ++c)
-            a[c] = buf_load_f64<true>((EXACT ? (c < CPL - 1) : (g0 + c < glast)) ? tb + first_off + (int64_t)c * cs : lastb, vo);
+            if constexpr (WIDE) a[c] = buf_load_f64<true>(uniform_ptr((g0 + c < glast) ? tb + first_off + (int64_t)c * cs : lastb), vo);
+            else a[c] = buf_load_f64<true>((EXACT ? (c < CPL - 1) : (g0 + c < glast)) ? tb + first_off + (int64_t)c * cs : lastb, vo);
     };
     double a[CPL], p[LACC ? 1 : NV][LACC ? 1 : NQ];
     if (!LACC) {

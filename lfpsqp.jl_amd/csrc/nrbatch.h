@@ -295,6 +295,9 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
 // rows nobody reads), their B-operand entries are zero.  Arithmetic per tile and wave at 512 columns: 32 + 32 MFMAs of 64 cycles against ~12000
 // cycles of HBM time per tile pair and CU: still HBM-bound.  One partial row per WORKGROUP: [trial * ncT + col] (8 x ncT), then the 8 ball partials.
 constexpr int kNRBWideTrials = 8;
+#ifndef NRBW_EXP
+#define NRBW_EXP 0
+#endif
 
 template <bool ST, int CPL>
 __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_wide_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n, int64_t rounds,
@@ -310,7 +313,9 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_wide_kernel(const double
     __shared__ double vs[16 * 17];
     __shared__ double ysh[kWaves][2][64];
     __shared__ double* xp[NT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index as a SCALAR: the column bases below then live in scalar registers -- left as threadIdx.x >> 6 the compiler treats every
+    // buffer base as lane-dependent, wraps each of the tile's loads in a readfirstlane loop and keeps 64-bit addresses in vector registers)
+    const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const int g0 = wave * CPL;                                // first column group of this wave
     const int glast = (ncN - 1) / 4, lastc0 = ncN - 4;
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_wide_kernel(const double
         const char* tb = Mb + (int64_t)k * (kStep * 8);
         const char* lastb = tb + last_off;
 #pragma unroll
-        for (int c = c0; c < c1; ++c) a[c] = buf_load_f64<true>((g0 + c < glast) ? tb + first_off + (int64_t)c * cs : lastb, vo);
+        for (int c = c0; c < c1; ++c) a[c] = buf_load_f64<true>(uniform_ptr((g0 + c < glast) ? tb + first_off + (int64_t)c * cs : lastb), vo);
     };
     const NRStepE e = ep.e;
     struct RowIn { NRStepE::Row sh; double xn, yn; };
@@ -415,6 +420,9 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_wide_kernel(const double
         __syncthreads();
         const int64_t row = row0 + r16 + (int64_t)k * kStep;
         const bool valid = row < n;
+#if NRBW_EXP & 1
+        sched_fence();
+#endif
         if (updater) {
             const int v = wave;                              // (wave 0: trials 0 .. 3, wave 1: trials 4 .. 7)
             const double ysum = (ysh[0][v][lane] + ysh[1][v][lane]) + (ysh[2][v][lane] + ysh[3][v][lane]);
@@ -432,6 +440,9 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_wide_kernel(const double
             }
             vs[r16 * 17 + mytrial] = vv;
         }
+#if NRBW_EXP & 1
+        sched_fence();
+#endif
         compiler_fence();
         if (MORE) {
             load_cols(k + 1, 0, NCH == 1 ? CPL : (16 < CPL - 1 ? 16 : CPL - 1));

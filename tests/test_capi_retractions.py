@@ -598,9 +598,14 @@ def test_pcg_one_pass_iteration_matches_two_pass_kernels(dev_ctx, monkeypatch, m
                                              # 65 .. 132 generator columns: the LDS-DMA form of the matrix-core step (nrb2_kernel); m = 128 with
                                              # the ball column (129 columns: 17 DMA pieces) is config 4's shape, m = 127 + ball fills 128 exactly
                                              (16, True, 128), (7, False, 128), (16, False, 127), (5, True, 69), (12, True, 100),
-                                             # more than 256 generator columns: the WIDE form of the one-pass kernel (four waves share a row
-                                             # tile and split its columns), four trial points per pass
-                                             (4, True, 300), (3, False, 260)])
+                                             # 133 .. 528 generator columns: the WIDE matrix-core form (nrb_mfma_wide_kernel: the four waves of a
+                                             # workgroup share a 16-row tile and split its columns), up to eight trial points per pass; m + ball =
+                                             # 513 columns is config 5's shape with ball and bounds (33 column groups per wave), 141 / 385 exercise
+                                             # a ragged last group inside the second / in the first register of a wave
+                                             (4, True, 300), (3, False, 260), (8, True, 300), (8, False, 512), (6, True, 512), (8, True, 140),
+                                             (5, False, 384), (8, True, 527),
+                                             # beyond 528 columns: the VALU wide form of the one-pass kernel, four trial points per pass
+                                             (4, True, 600)])
 def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds, mcols):
     """lfpsqp_retract_nr_batch: nb trial points of one linesearch retracted together (one pass over Jct per Newton step for all of
     them) give, trial by trial, what lfpsqp_retract_nr gives one by one -- including trials that converge at different
@@ -638,7 +643,7 @@ def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds, mcols)
     assert isinstance(method, L.NR)
     method.maxiter = 40                                    # so that the largest step fails while the small ones converge
     alphas = ([64.0, 0.02, 2e-3, 1e-4] + [0.05 * 0.5 ** k for k in range(12)])[:nb]
-    assert L.retract_nr_batch_width_(c_, method) == (16 if M <= 132 else 4)
+    assert L.retract_nr_batch_width_(c_, method) == (16 if M <= 132 else (8 if M <= 528 else 4))
     xts, xns = captured["work"].batch_vectors(nb)
     for a, xt in zip(alphas, xts):
         L.waxpby(1.0, x, a, d, xt)
@@ -660,13 +665,15 @@ def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds, mcols)
             # rounding along its path -- it still lands on c = 0 after the same number of steps, at a point 1e-9 (relative) along the manifold
             # from the other kernel's; trials that converge from nearby agree to 1e-12.
             rel = 1e-12 if (nb <= 2 or it <= 20) else 1e-8
+            if mcols >= 512:
+                rel = max(rel, 1e-11)      # (n / m = 2 on the emulator: the Newton steps of this nearly square block amplify rounding a little more)
             np.testing.assert_allclose(xa, xb_, rtol=0, atol=rel * max(1.0, np.abs(xb_).max()))
             if rel == 1e-12:
                 np.testing.assert_allclose(cvs[b], cv, atol=1e-8)      # c(xnew) ~ 0: differences of rounding size in a sum over n terms
             else:
                 assert np.abs(cvs[b]).max() < method.tol and np.abs(cv).max() < method.tol      # both converged; see above
     assert 0 in flags
-    if _is_emu(ctx):
+    if _is_emu(ctx) and mcols != 140:                          # (at 141 columns on 1101 rows every trial happens to need five steps)
         assert len(set(g[1] for g in got)) > 1, got            # the trials really finished at different iterations
 
 
