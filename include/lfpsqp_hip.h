@@ -427,6 +427,25 @@ int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfps
                   const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
                   int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr);
 
+/* The same solver, still ONE pass over U per iteration, for a Hessian of the form
+ *     A = a0*I + diag(dg) + V diag(sigma) V'        (V: n x k device matrix, k <= 8; sigma host, NULL = ones)
+ * -- a separable objective with a few coupling terms, a quasi-Newton (L-BFGS-like) model of the Lagrangian Hessian ... -- which the reference
+ * would wrap in a LinearMap (src/optimize.jl:228-230) and lfpsqp_projcg_op would run with two passes per iteration.  The low-rank term is
+ * not row-local, but every product the iteration needs follows from k-vectors: (A d)_i = D_i d_i + V_i (sigma .* V'd) with V'd updated by
+ * d's own recurrence, U'(A g) = U'(D g) + (U'V)(sigma .* V'g) with U'V formed once per solve (k thin passes) and V'g as k more reduction
+ * terms of the pass.  Plain dense basis (materialised or factored), 4 .. 1024 columns; no RESUME / START_GIVEN; k == 0 is lfpsqp_projcg.
+ * Iterates, counts and exits as projcg! with A as a matrix (src/projcg.jl:40-121), to rounding. */
+typedef struct lfpsqp_lowrank_op {
+    double a0;
+    const lfpsqp_vec* dg; /* optional, length n */
+    const lfpsqp_mat* V;  /* n x (>= k), plain */
+    int64_t k;
+    const double* sigma;  /* host, k; NULL = ones */
+} lfpsqp_lowrank_op;
+int lfpsqp_projcg_lowrank(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_lowrank_op* A, const lfpsqp_basis* U,
+                          const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit, int64_t n_global, int flags,
+                          const lfpsqp_projcg_work* work, int64_t* iters, double* nr);
+
 /* The same solver for a GENERAL symmetric operator A -- the reference's LinearMap closure around hess_lag_vec! /
  * augmented_hess_lag_vec! (src/optimize.jl:228-230, applied at src/projcg.jl:57,74,116): `A(user, src, dest)` must produce
  * dest = A * src for device vectors of length(b) (stacked [x | gap | y] when U is a stacked basis), return 0, and leave

@@ -37,6 +37,13 @@ struct CDiagOp                 # lfpsqp_diag_op
     a0::Float64
     dg::Ptr{Cvoid}
 end
+struct CLowRankOp              # lfpsqp_lowrank_op
+    a0::Float64
+    dg::Ptr{Cvoid}
+    V::Ptr{Cvoid}
+    k::Int64
+    sigma::Ptr{Float64}
+end
 struct CBasis                  # lfpsqp_basis
     Z::Ptr{Cvoid}
     ncols::Int64
@@ -214,6 +221,9 @@ c_q_gemv_n(ctx, Q, a, w, t, b, y) = ccall((:lfpsqp_q_gemv_n, lib), Cint, (Ptr{Cv
 c_factored_basis_supported(ctx, A, SA, yes) = ccall((:lfpsqp_factored_basis_supported, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cint}), ctx, A, SA, yes)
 c_projcg(ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg, lib), Cint,
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CDiagOp}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
+    ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
+c_projcg_lowrank(ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg_lowrank, lib), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CLowRankOp}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
     ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
 c_projcg_op(ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg_op, lib), Cint,
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
@@ -541,6 +551,16 @@ struct DiagOperator
     dg::Union{Nothing,DeviceVector}
 end
 DiagOperator(a0::Real) = DiagOperator(Float64(a0), nothing)
+# A = a0*I + Diagonal(dg) + V*Diagonal(σ)*V' (k <= 8 columns of the device matrix V): a diagonal Hessian with a few coupling directions.
+# projcg! runs it on the fused ONE-pass iteration (lfpsqp_projcg_lowrank) where a LinearMap closure would take two passes per iteration.
+struct LowRankOperator
+    a0::Float64
+    dg::Union{Nothing,DeviceVector}
+    V::DeviceMatrix
+    k::Int
+    σ::Vector{Float64}
+end
+LowRankOperator(a0::Real, dg, V::DeviceMatrix; k::Int=V.m, σ::Vector{Float64}=ones(k)) = LowRankOperator(Float64(a0), dg, V, k, σ)
 
 # InequalityData(xl, xu) (src/inequality_helper.jl:39-89), device-resident q, r, s, t
 struct InequalityData
@@ -650,6 +670,17 @@ function projcg!(x::DeviceVector, λ::Union{Nothing,DeviceVector}, A::DiagOperat
                               Ref(cwork(work)), iters, nr))
     end
     return Int(iters[]), nr[]          # (i, nr) exactly like the reference; nr == Inf and λ .== NaN on negative curvature
+end
+function projcg!(x::DeviceVector, λ::Union{Nothing,DeviceVector}, A::LowRankOperator, U::AnyBasis, b::DeviceVector, c::Union{Nothing,DeviceVector};
+                 tol::Float64=1e-6, maxit::Int=length(b) + ncols(U), work::ProjCGWork=ProjCGWork(x, ncols(U)), n_global::Int=length(b))
+    iters = Ref{Int64}(0); nr = Ref{Float64}(0.0)
+    GC.@preserve U A begin
+        check(x.ctx, c_projcg_lowrank(x.ctx.h, x.h, λ === nothing ? C_NULL : λ.h,
+                                      Ref(CLowRankOp(A.a0, A.dg === nothing ? C_NULL : A.dg.h, A.V.h, Int64(A.k), pointer(A.σ))), Ref(cbasis(U)),
+                                      b.h, c === nothing ? C_NULL : c.h, tol, Int64(maxit), Int64(n_global), λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA,
+                                      Ref(cwork(work)), iters, nr))
+    end
+    return Int(iters[]), nr[]
 end
 # ... and for a GENERAL operator A(dest, src) on device vectors (the LinearMap closure of src/optimize.jl:228-230): the same
 # device-resident loop, A called back once per iteration (lfpsqp_projcg_op); its body may queue device work and return.
@@ -1754,7 +1785,7 @@ end
 optimize(ctx::HipContext, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, x0::Vector{Float64}, xl, xu, m::Int, p::Int, param::LFPSQPParams=LFPSQPParams()) =
     optimize(ctx, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, fill(-Inf, p), zeros(p), x0, xl, xu, m, p, param)
 
-export HipContext, HipError, DeviceOptions, DeviceVector, StackedVector, DeviceMatrix, SparseMatrix, spmv_t!, spmv_n!, to_dense!, DeviceBasis, DiagOperator, InequalityData, InequalityDecomp,
+export HipContext, HipError, DeviceOptions, DeviceVector, StackedVector, DeviceMatrix, SparseMatrix, spmv_t!, spmv_n!, to_dense!, DeviceBasis, DiagOperator, LowRankOperator, InequalityData, InequalityDecomp,
        InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
        ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, SeparableElementwiseBox, ElementwiseConstraints,
        sin_system_constraints, sphere_system_constraints, clone, rowscale!, set_placement!, basis_and_vectors_placed, vectors_placed, placement_info, upload!, download, upload2!, download2, projcg!, retract!,

@@ -65,6 +65,25 @@ struct AOpV {  // generic A behind a callback: the product A*v for the ONE vecto
     __device__ __forceinline__ double2 apply(int64_t i, double2) const { return ld2(Av + i); }
 };
 
+struct AOpLR {  // A = a0*I + diag(dg) + V diag(sigma) V': (A v)_i = (a0 + dg_i) v_i + sum_j V_ij sigma_j (V'v)_j, with V'v (k, device) formed before the launch
+    double a0;
+    const double* dg;
+    const double* V;
+    int64_t ldv;
+    int k;
+    const double *sigma, *vtv;
+    __device__ __forceinline__ double2 apply(int64_t i, double2 d) const {
+        double2 o = dg ? make_double2((a0 + dg[i]) * d.x, (a0 + dg[i + 1]) * d.y) : make_double2(a0 * d.x, a0 * d.y);
+        for (int j = 0; j < k; ++j) {
+            const double c = ld_scal(sigma + j) * ld_scal(vtv + j);
+            const double2 v = ld2(V + (int64_t)j * ldv + i);
+            o.x = fma(v.x, c, o.x);
+            o.y = fma(v.y, c, o.y);
+        }
+        return o;
+    }
+};
+
 struct StackD {   // stacked (bound-constrained) basis Q = [[diag Dx; diag Dy], [sx.*Z; sy.*Z]]
     int64_t hs;
     const double *Dx, *Dy, *sx, *sy;
@@ -343,6 +362,90 @@ struct PcgFuseE {
     }
 };
 
+// ---- F for A = a0 I + diag(dg) + V diag(sigma) V'  (k <= 8 columns): the same single pass ---------------------------------------------------
+// The low-rank term is not row-local -- (A v)_i needs V'v -- but everything the iteration multiplies A with is known through k-vectors:
+//   (A d)_i     = D_i d_i + sum_j V_ij c_j,  c = sigma .* (V'd)   -- V'd follows the recurrence of d: V'd+ = beta V'd - V'gp  (post-op);
+//   U'(A gp)    = U'(D gp) + (U'V) (sigma .* (V'gp))              -- U'V (m x k) once per solve, V'gp: k more reduction terms of the pass;
+//   gp'A gp     = gp'D gp + sum_j sigma_j (V'gp)_j^2,  gp'A d = sum_i gp_i (A d)_i,  d'A d = sum_i d_i (A d)_i   (row-local products).
+// Cost next to the diagonal form: k doubles per row (8 k of 8 m + 72 bytes) and k reduction terms; a general Hessian of this shape no longer pays
+// two passes per iteration through the callback path (lfpsqp_projcg_op).
+constexpr int kLRMax = 8;
+template <bool INIT>
+struct PcgFuseLR {
+    const double* rp;
+    const double* g;
+    double* gout;
+    double* d;
+    AOpD A;
+    const double* scal;
+    const int64_t* istat;
+    const double* V;      // n x k, column-major
+    int64_t ldv;
+    int k;
+    const double* vdc;    // device, kLRMax: sigma .* (V'd) of the current direction (zeros beyond k; written by the post-op)
+    static constexpr bool kSplitRed = true;
+    static constexpr bool kNoRowScale = true;           // (no matrix views: the generator of a nonlinear class has a diagonal Hessian term)
+    struct Uni { double alpha; double c[kLRMax]; };
+    struct Row { double gx, dx, ax, v0, v1, v2, v3, v4, v5, v6, v7; };      // (named fields: an array member keeps the record in scratch memory)
+    static __device__ __forceinline__ double at(const double* base, uint32_t o) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
+    }
+    static __device__ __forceinline__ void put(double* base, uint32_t o, double v) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + o) = v;
+    }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
+    __device__ __forceinline__ Uni uniform() const {
+        Uni u;
+        u.alpha = INIT ? 0.0 : uniform_f64(ld_scal(scal + S_ALPHA));
+#pragma unroll
+        for (int j = 0; j < kLRMax; ++j) u.c[j] = (!INIT && j < k) ? uniform_f64(ld_scal(vdc + j)) : 0.0;
+        return u;
+    }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        Row w;
+        w.gx = INIT ? at(rp, o) : at(g, o);
+        w.dx = INIT ? 0.0 : at(d, o);
+        w.ax = A.a0 + (A.dg ? at(A.dg, o) : 0.0);
+        // (unconditional: a branch around a load keeps the whole row record in scratch memory; the columns beyond k re-read column 0 -- the same
+        // cache line -- and meet zero coefficients, their sums are never read)
+        auto col = [&](int j) { return at(V + (int64_t)(j < k ? j : 0) * ldv, o); };
+        w.v0 = col(0); w.v1 = col(1); w.v2 = col(2); w.v3 = col(3); w.v4 = col(4); w.v5 = col(5); w.v6 = col(6); w.v7 = col(7);
+        return w;
+    }
+    static constexpr int kStageStreams = INIT ? 0 : 1;
+    __device__ __forceinline__ double* stage_out(int) const { return gout; }
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
+                                          const Row& w, double (&v)[2], double (&red)[4]) const {
+        apply_staged(row, o, accv, valid, owner, lead, u, w, v, red, nullptr, 0);
+    }
+    // reductions, logical order: rp'gp, gp'gp, gp'D gp, gp'A d | d'A d, gp'V_0, gp'V_1, gp'V_2 | gp'V_3 .. gp'V_6 | gp'V_7 -- lane group h of a row
+    // takes logical sum 4 s + h in running sum s (kSplitRed)
+    __device__ __forceinline__ void apply_staged(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
+                                                 const Row& w, double (&v)[2], double (&red)[4], double* slot, int) const {
+        const int h = (int)((threadIdx.x >> 2) & 3u);
+        double lr = w.v0 * u.c[0];
+        lr = fma(w.v1, u.c[1], lr); lr = fma(w.v2, u.c[2], lr); lr = fma(w.v3, u.c[3], lr);
+        lr = fma(w.v4, u.c[4], lr); lr = fma(w.v5, u.c[5], lr); lr = fma(w.v6, u.c[6], lr); lr = fma(w.v7, u.c[7], lr);
+        const double ad = fma(w.ax, w.dx, lr);                                   // (A d)_i
+        const double rr = INIT ? w.gx : fma(u.alpha, ad, w.gx);                  // :93
+        const double gp = rr - accv[0];                                          // :97
+        const double ag = w.ax * gp;                                             // the row-local part of A gp
+        if (valid && owner) {
+            if (slot) *slot = gp;
+            else put(gout, o, gp);
+            if (INIT) put(d, o, -gp);                                            // :62
+        }
+        if (valid && lead) {
+            red[0] += gp * ((h == 0) ? rr : ((h == 1) ? gp : ((h == 2) ? ag : ad)));
+            red[1] += (h == 0) ? w.dx * ad : gp * ((h == 1) ? w.v0 : ((h == 2) ? w.v1 : w.v2));
+            red[2] += gp * ((h == 0) ? w.v3 : ((h == 1) ? w.v4 : ((h == 2) ? w.v5 : w.v6)));
+            red[3] += (h == 0) ? gp * w.v7 : 0.0;
+        }
+        v[0] = valid ? gp : 0.0;
+        v[1] = valid ? ag : 0.0;
+    }
+};
+
 // The one post-op of the fused iteration, after the (all-reduced) sums T = [t1 (m); t2 (m); rp'gp; gp'gp; g'Ag; g'Ad; d'Ad]
 // of kernel F are final.  End of iteration it (:98-111): beta, rg, nr, convergence / iteration limit.  Start of iteration
 // it+1 (:72-91): d+'A d+ from the three direct sums, negative-curvature / rg exits, alpha.  Then (all threads)
@@ -363,6 +466,13 @@ struct PcgPostF {
     double* Tw = nullptr;         // == T, writable
     double* uA = nullptr;
     int wm = 0;
+    // operator with a low-rank term V diag(sigma) V' (PcgFuseLR): k > 0; the sums carry V'gp behind the five scalars
+    int k = 0;
+    const double* UtV = nullptr;  // m x k, column-major (device): U'V
+    const double* sigma = nullptr;   // k (device)
+    double* vdraw = nullptr;      // kLRMax (device): V'd
+    double* vdc = nullptr;        // kLRMax (device): sigma .* (V'd), what the kernel multiplies the rows of V with
+    __device__ __forceinline__ int nsums() const { return k > 0 ? 5 + kLRMax : 5; }
 };
 // init = 2: RESUME after an iteration-limit exit (LFPSQP_PROJCG_RESUME): the end-of-iteration part already ran in the previous
 // call; the limit has been raised, so the start-of-next-iteration part runs now (x was flushed by that call: alpha_prev = 0).
@@ -416,13 +526,18 @@ __global__ __launch_bounds__(1024) void pcg_post_kernel(PcgPostF u) {
             while (rp < u.m) rp <<= 1;
             if ((int)threadIdx.x / rp == 0) { u.Tw[threadIdx.x] = yo[0]; u.Tw[u.m + threadIdx.x] = yo[1]; }
         }
-        if (threadIdx.x < 5) u.Tw[2 * u.m + threadIdx.x] = ld_scal(u.Traw + 2 * u.wm + threadIdx.x);
+        if ((int)threadIdx.x < u.nsums()) u.Tw[2 * u.m + threadIdx.x] = ld_scal(u.Traw + 2 * u.wm + threadIdx.x);
         __threadfence();
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         const double* S = u.T + 2 * u.m;
-        const double rpgp = ld_scal(S), gpgp = ld_scal(S + 1), gAg = ld_scal(S + 2), gAd = ld_scal(S + 3), dAd = ld_scal(S + 4);
+        const double rpgp = ld_scal(S), gpgp = ld_scal(S + 1), gAd = ld_scal(S + 3), dAd = ld_scal(S + 4);
+        double gAg = ld_scal(S + 2);
+        for (int j = 0; j < u.k; ++j) {                                 // + sum_j sigma_j (V'gp)_j^2
+            const double vg = ld_scal(S + 5 + j);
+            gAg = fma(ld_scal(u.sigma + j) * vg, vg, gAg);
+        }
         double beta = 0.0, dAd_next = gAg;                              // d0 = -g0
         int64_t it = 0;
         int64_t st = ST_RUNNING;
@@ -465,12 +580,22 @@ __global__ __launch_bounds__(1024) void pcg_post_kernel(PcgPostF u) {
         go = (st == ST_RUNNING);
         sh[0] = gpgp / dAd_next;
         sh[1] = beta;
+        if (go)
+            for (int j = 0; j < u.k; ++j) {                             // V'd+ = beta V'd - V'gp  (d+ = beta d - gp; d0 = -g0)
+                const double vg = ld_scal(S + 5 + j);
+                const double vd = (u.init == 1) ? -vg : fma(beta, u.vdraw[j], -vg);
+                u.vdraw[j] = vd;
+                u.vdc[j] = ld_scal(u.sigma + j) * vd;
+            }
     }
     __syncthreads();
     if (!go) return;
     const double alpha = sh[0], beta = sh[1];
     for (int j = threadIdx.x; j < u.m; j += blockDim.x) {
-        const double t1 = ld_scal(u.T + j), t2 = ld_scal(u.T + u.m + j);
+        const double t1 = ld_scal(u.T + j);
+        double t2 = ld_scal(u.T + u.m + j);
+        for (int l = 0; l < u.k; ++l)                                   // U'(A gp) = U'(D gp) + (U'V) (sigma .* (V'gp))
+            t2 = fma(u.UtV[(size_t)l * u.m + j], ld_scal(u.sigma + l) * ld_scal(u.T + 2 * u.m + 5 + l), t2);
         const double t3 = (u.init == 1) ? -t2 : fma(beta, u.t3[j], -t2);
         u.t3[j] = t3;
         const double ut = fma(alpha, t3, t1);
@@ -714,8 +839,11 @@ int lfpsqp_factored_basis_supported(const lfpsqp_ctx* ctx, const lfpsqp_mat* A, 
 
 static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, lfpsqp_opfun opf, void* ouser,
                        lfpsqp_vec* Av, const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
-                       int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
+                       int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr,
+                       const lfpsqp_lowrank_op* LRop = nullptr) {
     const lfpsqp_diag_op no_diag = {0.0, nullptr};
+    lfpsqp_diag_op lr_diag = {0.0, nullptr};
+    if (LRop) { lr_diag.a0 = LRop->a0; lr_diag.dg = LRop->dg; A = &lr_diag; }
     if (opf) A = &no_diag;
     LF_ARG(ctx, ctx && x && A && U && b && work && iters && nr);
     LF_ARG(ctx, !opf || (Av && Av->n == b->n && !(flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN))));
@@ -802,13 +930,29 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
                                                     "columns; materialise Z = A W for this shape");
     if (DF && c) LF_TRY(lfpsqp_q_gemv_n(ctx, U, 1.0, nullptr, c, 0.0, x));       // x = U c (:55), before the small factor settles in ctx->small
     double *T12 = nullptr, *t3 = nullptr, *Traw = nullptr, *uDF = nullptr, *dWf = nullptr;
+    // operator with a low-rank term (lfpsqp_projcg_lowrank): fused iteration only
+    const int kLR = LRop ? (int)LRop->k : 0;
+    const int ns = kLR > 0 ? 5 + kLRMax : 5;             // scalar sums of a pass
+    if (LRop) {
+        LF_ARG(ctx, LRop->V && plain_mat(LRop->V) && kLR >= 1 && kLR <= kLRMax && LRop->V->m >= kLR && LRop->V->n == nv && (!LRop->dg || LRop->dg->n == nv));
+        if (!fused || stacked || (flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN)))
+            return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "lfpsqp_projcg_lowrank: needs the one-pass iteration over a plain dense basis (4 .. 1024 columns), no RESUME / START_GIVEN");
+    }
+    double *lrUtV = nullptr, *lrSig = nullptr, *lrVdraw = nullptr, *lrVdc = nullptr, *lrVtv = nullptr;
     if (fused) {
-        LF_TRY(ensure_mvec(ctx, (size_t)3 * m + (DF ? 3 * (size_t)mc + 16 : 0) + 24));
-        T12 = ctx->d_m;                                  // [t1 (m); t2 (m); rp'gp; gp'gp; g'Ag; g'Ad; d'Ad]
-        t3 = ctx->d_m + round_up(2 * m + 5, 2);
+        LF_TRY(ensure_mvec(ctx, (size_t)3 * m + (DF ? 3 * (size_t)mc + 16 : 0) + 2 * kLRMax + 24 + (kLR > 0 ? (size_t)m * kLRMax + 4 * kLRMax + 8 : 0)));
+        T12 = ctx->d_m;                                  // [t1 (m); t2 (m); rp'gp; gp'gp; g'Ag; g'Ad; d'Ad (; V'gp)]
+        t3 = ctx->d_m + round_up(2 * m + ns, 2);
+        double* tail = t3 + round_up(m, 2);
         if (DF) {
-            Traw = t3 + round_up(m, 2);                  // the kernel's raw sums over the generator's columns
-            uDF = Traw + round_up(2 * mc + 5, 2);        // W Utr: the coefficients of the first product
+            Traw = tail;                                 // the kernel's raw sums over the generator's columns
+            uDF = Traw + round_up(2 * mc + ns, 2);       // W Utr: the coefficients of the first product
+            tail = uDF + round_up(mc, 2);
+        }
+        if (kLR > 0) {
+            lrUtV = tail; lrSig = lrUtV + (size_t)m * kLRMax; lrVdraw = lrSig + kLRMax; lrVdc = lrVdraw + kLRMax; lrVtv = lrVdc + kLRMax;
+        }
+        if (DF) {
             LF_TRY(ensure_small(ctx, (size_t)mc * m + 64));
             dWf = ctx->small;
             LF_HIP(ctx, hipMemcpyAsync(dWf, U->W, sizeof(double) * (size_t)mc * m, hipMemcpyHostToDevice, ctx->stream));
@@ -843,6 +987,10 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         return run_gemv_t(ctx, Z, m, N, rv, t_out);
     };
     auto launch_residual = [&](double sgn, double* store, double* t_out) -> int {
+        if (kLR > 0) {                                                        // V'x first (k columns of V: a thin pass), then the residual with it
+            LF_TRY(run_gemv_t(ctx, LRop->V, kLR, N, SpPlainV{x->p}, lrVtv));
+            return residual_with(AOpLR{Ad.a0, Ad.dg, LRop->V->p, LRop->V->ld, kLR, lrSig, lrVtv}, sgn, store, t_out);
+        }
         if (!opf) return residual_with(Ad, sgn, store, t_out);
         LF_TRY(apply_op(x));                                                  // Av = A x
         return residual_with(Aop, sgn, store, t_out);
@@ -890,12 +1038,16 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         double* gout = init ? gbuf[0] : gbuf[gcur ^ 1];
         const double* tin = DF ? uDF : Utr;               // coefficients of the first product over the streamed matrix's mc columns
         double* Tout = DF ? Traw : T12;
-        if (stacked && init) LF_TRY((run_onepass<PcgFuseE<true, true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<true, true>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
+        if (kLR > 0 && init) LF_TRY((run_onepass<PcgFuseLR<true>, 2, 5 + kLRMax>(ctx, Z, mc, mc, N, tin, PcgFuseLR<true>{rp, gin, gout, d, Ad, scal, istat, LRop->V->p, LRop->V->ld, kLR, lrVdc}, Tout, slot)));
+        else if (kLR > 0) LF_TRY((run_onepass<PcgFuseLR<false>, 2, 5 + kLRMax>(ctx, Z, mc, mc, N, tin, PcgFuseLR<false>{rp, gin, gout, d, Ad, scal, istat, LRop->V->p, LRop->V->ld, kLR, lrVdc}, Tout, slot)));
+        else if (stacked && init) LF_TRY((run_onepass<PcgFuseE<true, true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<true, true>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
         else if (stacked) LF_TRY((run_onepass<PcgFuseE<true, false>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<true, false>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
         else if (init) LF_TRY((run_onepass<PcgFuseE<false, true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<false, true>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
         else LF_TRY((run_onepass<PcgFuseE<false, false>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<false, false>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
         if (!init) gcur ^= 1;
-        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(DF ? 1024 : 256), 0, ctx->stream, PcgPostF{T12, t3, Utr, scal, istat, m, init, hm, dWf, Traw, T12, uDF, DF ? mc : 0});
+        PcgPostF pf{T12, t3, Utr, scal, istat, m, init, hm, dWf, Traw, T12, uDF, DF ? mc : 0};
+        if (kLR > 0) { pf.k = kLR; pf.UtV = lrUtV; pf.sigma = lrSig; pf.vdraw = lrVdraw; pf.vdc = lrVdc; }
+        hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(DF ? 1024 : 256), 0, ctx->stream, pf);
         LF_LAUNCH_CHECK(ctx);
         return 0;
     };
@@ -929,6 +1081,18 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
             if (!DF) LF_TRY(lfpsqp_gemv_n(ctx, Z, m, 1.0, c, 0.0, x));      // (factored basis: done above)
         } else {
             LF_TRY(lfpsqp_vec_fill(ctx, x, 0.0));
+        }
+        if (kLR > 0) {
+            // sigma (host, NULL = ones) and U'V (m x k): one GEMV-T per column of V, once per solve; V'd starts at zero
+            for (int j = 0; j < kLRMax; ++j) ctx->h_m[j] = (j < kLR) ? (LRop->sigma ? LRop->sigma[j] : 1.0) : 0.0;
+            LF_HIP(ctx, hipMemcpyAsync(lrSig, ctx->h_m, sizeof(double) * kLRMax, hipMemcpyHostToDevice, ctx->stream));
+            LF_HIP(ctx, hipStreamSynchronize(ctx->stream));            // (h_m is the context's shared staging block)
+            LF_HIP(ctx, hipMemsetAsync(lrVdraw, 0, sizeof(double) * 3 * kLRMax, ctx->stream));       // V'd, sigma .* V'd, V'x
+            for (int l = 0; l < kLR; ++l) {
+                const SpPlainV col{LRop->V->p + (int64_t)l * LRop->V->ld};
+                if (DF) LF_TRY(df_gemv_t(col, lrUtV + (size_t)l * m, nullptr));
+                else LF_TRY(run_gemv_t(ctx, Z, m, N, col, lrUtV + (size_t)l * m));
+            }
         }
         // r = A x - b (kept in rp), Utr = U' r, g = r - U Utr, d = -g, rg = g'g   (:56-62)
         if (flags & LFPSQP_PROJCG_START_GIVEN) {
@@ -991,7 +1155,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     // flow the exits of an iteration start are taken before its K1, so they leave it pending too)
     if ((status == ST_CONVERGED || status == ST_MAXIT || (fused && status == ST_RG_BREAK && *iters > 1)) && *iters > it_base)
         LF_TRY((run_vec<FlushXF, 0, NoPost>(ctx, nv, FlushXF{x->p, d, scal}, 0u, nullptr, NoPost())));
-    if (fused && status == ST_MAXIT && *iters > 0)
+    if (fused && status == ST_MAXIT && *iters > 0 && kLR == 0)
         ctx->pcg_resume = lfpsqp_ctx::ProjcgResume{true, x->p, g, d, Z->p, m, nv, *iters, gcur == 1, Ad.dg, b->p, Ad.a0, n_global, ctx->launch_epoch};
     if (status == ST_NEGCURV) {   // :77-82
         if (fused && *iters > 1)  // d+ = beta d - g of the iteration that found the negative curvature was not formed yet
@@ -1049,6 +1213,18 @@ extern "C" int lfpsqp_projcg(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda,
     LF_RANGE("lfpsqp_projcg");
     LF_ARG(ctx, ctx && A);
     return projcg_impl(ctx, x, lambda, A, nullptr, nullptr, nullptr, U, b, c, tol, maxit, n_global, flags, work, iters, nr);
+}
+
+extern "C" int lfpsqp_projcg_lowrank(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_lowrank_op* A, const lfpsqp_basis* U,
+                                     const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit, int64_t n_global, int flags,
+                                     const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
+    LF_RANGE("lfpsqp_projcg_lowrank");
+    LF_ARG(ctx, ctx && A);
+    if (A->k == 0) {
+        const lfpsqp_diag_op dop{A->a0, A->dg};
+        return projcg_impl(ctx, x, lambda, &dop, nullptr, nullptr, nullptr, U, b, c, tol, maxit, n_global, flags, work, iters, nr);
+    }
+    return projcg_impl(ctx, x, lambda, nullptr, nullptr, nullptr, nullptr, U, b, c, tol, maxit, n_global, flags, work, iters, nr, A);
 }
 
 extern "C" int lfpsqp_projcg_op(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, lfpsqp_opfun A, void* user, lfpsqp_vec* Av,

@@ -49,6 +49,50 @@ class DiagOperator:
         return self
 
 
+class LowRankOperator:
+    """A = a0*I + diag(dg) + V diag(sigma) V' (lfpsqp_lowrank_op): a diagonal Hessian with k <= 8 coupling directions.  On a
+    :class:`DeviceBasis` projcg_ runs it on the fused ONE-pass iteration (lfpsqp_projcg_lowrank); the ``mul_`` protocol below is the
+    statement-by-statement form (the generic loop / lfpsqp_projcg_op make two passes per iteration with it)."""
+
+    def __init__(self, a0: float, dg: DeviceVector | None, V: DeviceMatrix, k: int | None = None, sigma=None):
+        import numpy as np
+        self.a0, self.dg, self.V = float(a0), dg, V
+        self.k = V.m if k is None else int(k)
+        assert 0 <= self.k <= min(V.m, 8)
+        self.sigma = None if sigma is None else np.ascontiguousarray(sigma, dtype=np.float64)
+        assert self.sigma is None or self.sigma.size >= self.k
+        self._t = None
+
+    def _c(self):
+        return _capi.LowRankOp(self.a0, self.dg.h if self.dg is not None else None, self.V.h, self.k,
+                               self.sigma.ctypes.data if self.sigma is not None else None)
+
+    def mul_(self, dest: DeviceVector, v: DeviceVector, a=None, b=None):
+        import numpy as np
+        if a is None:
+            a, b = 1.0, 0.0
+        ctx = dest.ctx
+        tmp = DeviceVector(ctx, dest.n)
+        if self.dg is not None:
+            vmul(self.dg, v, tmp)
+            axpby(self.a0, v, 1.0, tmp)
+        else:
+            waxpby(self.a0, v, 0.0, v, tmp)
+        if self.k > 0:
+            if self._t is None:
+                self._t = DeviceVector(ctx, self.k)
+            gemv_t(self.V, v, self._t, self.k)
+            if self.sigma is not None:
+                self._t.upload(self._t.download(self.k) * self.sigma[:self.k])
+            gemv_n(self.V, self._t, tmp, 1.0, 1.0, self.k)
+        waxpby(a, tmp, b, dest, dest)
+        tmp.free()
+        return dest
+
+    def adjoint(self):
+        return self
+
+
 class DeviceBasis:
     """Orthonormal U = Z[:, :ncols] (``view(U, :, 1:rank)``, src/optimize.jl:370).
     ``Z = None`` with ``generator = (A, W)``: the basis in FACTORED form U = A W -- never materialised; projcg_, the Newton retraction and
@@ -174,6 +218,17 @@ def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c:
                                       c.h if c is not None else None, float(tol), int(maxit), int(n_global), flags,
                                       C.byref(w_c), C.byref(iters), C.byref(nr)))
         return iters.value, nr.value
+    if isinstance(A, LowRankOperator) and isinstance(U, DeviceBasis) and not stacked and not (resume or start_given) and getattr(A, "fused", True):
+        iters = _capi.c_i64()
+        nr = C.c_double()
+        a_c, u_c, w_c = A._c(), U._c(), work._c()
+        flags = WANT_LAMBDA if (want_lambda and lam is not None) else 0
+        rc = ctx.L.lfpsqp_projcg_lowrank(ctx.h, x.h, lam.h if lam is not None else None, C.byref(a_c), C.byref(u_c), b.h,
+                                         c.h if c is not None else None, float(tol), int(maxit), int(n_global), flags,
+                                         C.byref(w_c), C.byref(iters), C.byref(nr))
+        if rc != -5:                 # LFPSQP_ERR_UNSUPPORTED (a shape without the one-pass iteration): the callback path below
+            ctx.check(rc)
+            return iters.value, nr.value
     if resume or start_given:
         raise ValueError("resume / start_given are features of the device-resident projcg loop")
     if (isinstance(U, DeviceBasis) or stacked) and hasattr(A, "mul_"):

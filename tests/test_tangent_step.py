@@ -167,3 +167,78 @@ def test_tangent_step_completes_the_hessian_diagonal_of_the_streamed_class(dev_c
     href = ctx.vector(n, base)
     cons.hess_diag_(href, x, lam)
     np.testing.assert_allclose(hd.download(), href.download(), rtol=1e-13, atol=1e-13)
+
+
+class _LowRankRef:
+    """A = diag(a) + V diag(sigma) V' as an oracle operator (mul! protocol of oracle/lfpsqp_ref.py)."""
+
+    def __init__(self, a, V, sigma):
+        self.a, self.V, self.sigma = a, V, sigma
+
+    def _apply(self, v):
+        return self.a * v + self.V @ (self.sigma * (self.V.T @ v))
+
+    def mul_(self, dest, v, al=None, be=None):
+        if al is None:
+            dest[:] = self._apply(v)
+        else:
+            dest[:] = al * self._apply(v) + be * dest
+        return dest
+
+    def adjoint(self):
+        return self
+
+
+@pytest.mark.parametrize("n,m,k,factored", [(1800, 10, 1, False), (2600, 128, 3, False), (2200, 33, 8, False), (2400, 130, 2, True), (1500, 300, 4, False)])
+def test_projcg_with_a_diagonal_plus_low_rank_operator_on_one_pass(dev_ctx, n, m, k, factored):
+    """lfpsqp_projcg_lowrank: A = diag(a) + V diag(sigma) V' (sigma of both signs) on the fused ONE-pass iteration -- counts, iterates and
+    multipliers of the oracle's projcg! (src/projcg.jl:40-121) with A as a LinearMap; c != 0; the negative-curvature exit; and against the
+    callback path (lfpsqp_projcg_op, two passes per iteration) with the same operator."""
+    from oracle import lfpsqp_ref as R
+    ctx = dev_ctx
+    Uh, _ = np.linalg.qr(synth.hash_matrix(1, n, m))
+    Uh = np.asfortranarray(Uh)
+    a = 4.0 * synth.hash_vector(3, n) + 5.0
+    bh = synth.hash_vector(4, n)
+    Vh = np.asfortranarray(synth.hash_matrix(17, n, k) / np.sqrt(n))
+    sigma = np.array([3.0, -0.4, 1.5, 0.7, -0.2, 2.2, 0.9, 1.1])[:k]          # A stays positive definite (|sigma_j| |V_j|^2 < min a)
+    if factored:                                   # the basis kept as U = J W (lfpsqp_basis.Z == NULL)
+        Jh = synth.hash_matrix(5, n, m)
+        J = ctx.matrix(n, m, np.asfortranarray(Jh))
+        W = np.zeros((m, m), order='F')
+        S, Vt, rank = L.ksvd_(J, None, W=W)
+        U = L.DeviceBasis(None, rank, generator=(J, W))
+        Uh = np.asfortranarray(Jh @ W)
+    else:
+        U = L.DeviceBasis(ctx.matrix(n, m, Uh))
+    A = L.LowRankOperator(0.0, ctx.vector(n, a), ctx.matrix(n, k, Vh), k, sigma)
+    Aref = _LowRankRef(a, Vh, sigma)
+    b = ctx.vector(n, bh)
+    work = L.ProjCGWork(ctx, n, m)
+    for ch, tol in ((None, 1e-10), (np.linspace(-1, 1, m), 1e-12)):
+        x0, l0 = np.zeros(n), np.zeros(m)
+        i0, nr0 = R.projcg_(x0, l0, Aref, Uh, bh, np.zeros(m) if ch is None else ch, tol=tol)
+        x, lam = ctx.vector(n), ctx.vector(m)
+        i1, nr1 = L.projcg_(x, lam, A, U, b, None if ch is None else ctx.vector(m, ch), tol=tol, work=work)
+        assert i1 == i0 and i1 > 3 and nr1 == pytest.approx(nr0, rel=1e-5)
+        assert np.linalg.norm(x.download() - x0) <= 1e-10 * np.linalg.norm(x0)
+        assert np.abs(lam.download() - l0).max() < 1e-10
+        if factored:
+            continue                               # (the callback path needs a materialised basis)
+        # the callback path with the same operator: the same solve
+        A.fused = False
+        x2, lam2 = ctx.vector(n), ctx.vector(m)
+        i2, nr2 = L.projcg_(x2, lam2, A, U, b, None if ch is None else ctx.vector(m, ch), tol=tol)
+        A.fused = True
+        assert i2 == i1
+        assert np.linalg.norm(x.download() - x2.download()) <= 1e-10 * np.linalg.norm(x0)
+    # negative curvature (src/projcg.jl:77-82): one strongly negative direction
+    sneg = sigma.copy()
+    sneg[0] = -40.0 * n
+    A2 = L.LowRankOperator(0.0, ctx.vector(n, a), ctx.matrix(n, k, Vh), k, sneg)
+    x0, l0 = np.zeros(n), np.zeros(m)
+    i0, nr0 = R.projcg_(x0, l0, _LowRankRef(a, Vh, sneg), Uh, bh, np.zeros(m), tol=1e-10)
+    x, lam = ctx.vector(n), ctx.vector(m)
+    i1, nr1 = L.projcg_(x, lam, A2, U, b, None, tol=1e-10, work=work)
+    assert (i1, nr1) == (i0, nr0) and np.isinf(nr1)
+    assert np.linalg.norm(x.download() - x0) <= 1e-10 and np.all(np.isnan(lam.download()))
