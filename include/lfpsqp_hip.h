@@ -265,6 +265,9 @@ int lfpsqp_calculate_lambda_y(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, int64_t nc
 /* augmented_hess_lag_vec! for a diagonal Lagrangian Hessian (src/inequality_helper.jl:144-158):
  * a (stacked) = [hx + 2 lamy.*q ; 2 lamy.*s]   (hx = diag of the user's Hessian on the x-half) */
 int lfpsqp_augmented_diag(lfpsqp_ctx* ctx, const lfpsqp_vec* hx, const lfpsqp_vec* lamy, const lfpsqp_ineq_data* id, lfpsqp_vec* a);
+/* e[0:N) = |Dy| .* dx - Dx .* sgn(Dy) .* dy for a stacked d = [dx; dy]: the right-hand column with which lfpsqp_factorize_rhs (w2 = sx = Dy.^2)
+ * returns Jct'(sx .* dx + sy .* dy), the m-part of Q'd (src/inequality_helper.jl:197-212), from the Gram pass */
+int lfpsqp_ineq_rhs(lfpsqp_ctx* ctx, const lfpsqp_vec* daug, const lfpsqp_vec* Dx, const lfpsqp_vec* Dy, lfpsqp_vec* e);
 /* y_retract!(xnewaug, xaug, idata) (src/retractions.jl:451-500) */
 int lfpsqp_y_retract(lfpsqp_ctx* ctx, lfpsqp_vec* xnewaug, const lfpsqp_vec* xaug, const lfpsqp_ineq_data* id);
 
@@ -404,8 +407,9 @@ typedef struct lfpsqp_projcg_work {
 #define LFPSQP_PROJCG_RESUME 2
 /* The start of the solve is given: x0 = 0 (c == NULL), work->rp holds r0 = A x0 - b = -b and work->Utr holds U'r0 -- what
  * lfpsqp_tangent_step leaves behind, which formed both while it projected b.  The call then skips its own residual pass (src/projcg.jl:56-59)
- * and starts with the initial projection (:60-62).  Plain basis in factored form over a dense generator only (LFPSQP_ERR_UNSUPPORTED
- * otherwise); iterates as without the flag up to the rounding of U'r0. */
+ * and starts with the initial projection (:60-62).  Basis in factored form over a dense generator only, plain or bound-stacked (Utr: the
+ * m-part of Q'r0; the diagonal block is formed row by row) -- LFPSQP_ERR_UNSUPPORTED otherwise; iterates as without the flag up to the
+ * rounding of U'r0. */
 #define LFPSQP_PROJCG_START_GIVEN 4
 
 /* Can lfpsqp_projcg run on a basis kept in FACTORED form (lfpsqp_basis.Z == NULL, generator A (N rows) and W given; SA = the sparse twin of
@@ -530,7 +534,8 @@ int lfpsqp_constraints_eval(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, con
  * c!(xnew) (src/optimize.jl:284 evaluates it again: one pass over the constraint gradients per outer iteration for nothing). */
 int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_mat* Jct, double* cval);
 /* The TANGENT STEP of an outer iteration in one pass over the constraint gradients (src/optimize.jl:305-343, 366-381 and the head of projcg!,
- * src/projcg.jl:56-59), for a plain basis kept in factored form U = A W (lfpsqp_basis.Z == NULL; A may be a view) of rank U->ncols <= m:
+ * src/projcg.jl:56-59), for a basis kept in factored form U = A W (lfpsqp_basis.Z == NULL) of rank U->ncols <= m.
+ * PLAIN basis (no bounds; A may be a view):
  *   Jtd (host, m) = A'd -- from lfpsqp_factorize_rhs, which summed it during the Gram pass;
  *   Utd (host, m) <- U'd = W'Jtd (the reference's tmp_m, zero beyond the rank);  lam (host, m) <- V S^-1 Utd  (lambda_kkt, :331-343);
  *   d <- d - U Utd (:306-307);   work->rp <- r0 = -d;   work->Utr <- U'r0   (projcg!'s start for b = d, x0 = 0: LFPSQP_PROJCG_START_GIVEN);
@@ -538,10 +543,19 @@ int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, cons
  *   cons != NULL: hdiag (which the caller filled with the objective's part of the diagonal Lagrangian Hessian) += the constraint class's
  *   term for lam, exactly lfpsqp_constraints_hess_diag(ctx, cons, x, lam, hdiag) -- inside the same pass when the class streams its
  *   gradients from A's storage (phi''(x) .* (A lam) needs a product over the matrix being read anyway), by that call otherwise.
- * Five passes of the statement-by-statement sequence (GEMV-T, GEMV-N, the Hessian term's GEMV-N, projcg!'s GEMV-T, its initial projection)
- * become two (this one and the initial projection).  LFPSQP_ERR_UNSUPPORTED for a materialised, sparse-twinned or bound-stacked basis. */
+ *   idata = hx = S = lamy = NULL.
+ * STACKED basis (bounds: U->Dx .. U->sy set, vectors [x-half | y-half]; A plain):
+ *   Jtd = A'(sx .* dx + sy .* dy) -- lfpsqp_factorize_rhs with w2 = sx and the column e of lfpsqp_ineq_rhs;
+ *   d <- d - Q Q'd (:315-316);  lam as above;  lamy (n, optional) <- (Dx .* dx + Dy .* dy - Dx .* (A lam)) ./ S  (calculate_lambda_kkt!,
+ *   src/inequality_helper.jl:302-305);  hdiag (stacked) <- [hx (+ the class's constant term on the rows < n_x) + 2 lamy .* q ; 2 lamy .* s]
+ *   (augmented_hess_lag_vec! for a diagonal Hessian, :144-158; hx: n, the objective's part -- or, with cons == NULL, the whole diagonal);
+ *   work->rp <- -d, work->Utr <- Z'(sx .* r0x + sy .* r0y): the m-part of Q'r0.   S = the norms of lfpsqp_inequality_gradient.
+ * Five passes of the statement-by-statement sequence (GEMV-T, GEMV-N, the GEMV-N of the Hessian term / of lambda_y, projcg!'s GEMV-T, its
+ * initial projection) become two (this one and the initial projection).  LFPSQP_ERR_UNSUPPORTED for a materialised or sparse-twinned basis,
+ * and for bounds together with a view or a nonlinear class's phi'' term. */
 int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m, const double* Jtd,
                         lfpsqp_vec* d, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_vec* hdiag,
+                        const lfpsqp_ineq_data* idata, const lfpsqp_vec* hx, const lfpsqp_vec* S, lfpsqp_vec* lamy,
                         const lfpsqp_projcg_work* work, double* Utd, double* lam, double* d_sumsq);
 /* A user c!: x is the DEVICE vector (download it if the function is host code); return 0. */
 typedef int (*lfpsqp_cfun)(void* user, const lfpsqp_vec* x, double* cval);

@@ -228,9 +228,11 @@ c_projcg_lowrank(ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters,
 c_projcg_op(ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg_op, lib), Cint,
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
     ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
-c_tangent_step(ctx, U, Sigma, Vt, m, Jtd, d, cons, x, hdiag, work, Utd, lam, dss) = ccall((:lfpsqp_tangent_step, lib), Cint,
-    (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Cvoid}, Ptr{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CWork}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
-    ctx, U, Sigma, Vt, m, Jtd, d, cons, x, hdiag, work, Utd, lam, dss)
+c_tangent_step(ctx, U, Sigma, Vt, m, Jtd, d, cons, x, hdiag, idata, hx, S, lamy, work, Utd, lam, dss) = ccall((:lfpsqp_tangent_step, lib), Cint,
+    (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Cvoid}, Ptr{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{CIneqData}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+     Ref{CWork}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+    ctx, U, Sigma, Vt, m, Jtd, d, cons, x, hdiag, idata, hx, S, lamy, work, Utd, lam, dss)
+c_ineq_rhs(ctx, daug, Dx, Dy, e) = ccall((:lfpsqp_ineq_rhs, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, daug, Dx, Dy, e)
 c_constraints_eval(ctx, cons, x, cval) = ccall((:lfpsqp_constraints_eval, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Float64}), ctx, cons, x, cval)
 c_constraints_jac(ctx, cons, x, Jct, cval) = ccall((:lfpsqp_constraints_jac, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), ctx, cons, x, Jct, cval)
 c_constraints_hess_diag(ctx, cons, x, lam, hx) = ccall((:lfpsqp_constraints_hess_diag, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), ctx, cons, x, lam, hx)
@@ -1391,7 +1393,10 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     end
     ctx.options.placement_tries != saved_tries && set_placement!(ctx, saved_tries)
     # the tangent step with fewer passes (lfpsqp_tangent_step): plain factored basis over dense gradients, truncated-Newton steps on
-    fuse_tangent = factored_basis && !ineq && param.do_newton && jsp === nothing && m > 0 && ctx.options.fused_tangent_step
+    # (with bounds: the stacked form of the same pass; not over a matrix view, not for a class whose Hessian term needs A*λ)
+    nonlinear_class = c! isa DeviceConstraints && c!.ew !== nothing          # (its Jct may be a view of A, its Hessian term may need A*λ)
+    fuse_tangent = factored_basis && param.do_newton && jsp === nothing && m > 0 && ctx.options.fused_tangent_step && !(ineq && nonlinear_class)
+    ineq_rhs = (fuse_tangent && ineq) ? DeviceVector(ctx, n) : nothing
     Jtd = zeros(max(m, 1)); Utd = zeros(max(m, 1))
     idecomp.W = m > 0 ? zeros(m, m) : nothing                 # ksvd!'s small factor: Z == Jct*W
     jsp === nothing || (idecomp.Jsp = jsp.h)                  # sparse twin: the stacked basis is applied on the nonzeros too
@@ -1453,7 +1458,10 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             # :283-284 (the device keeps only Jct); a device-resident class skips the re-evaluation of c(x) when cval holds it already
             (cval_current && jac! isa DeviceConstraints) ? jac!(jac!, Jct, nothing, x) : jac!(Jct, cval, x)
             vprev = (i > 0 && prev_rank == m && ctx.options.warm_factorize) ? copy(Vt) : nothing
-            if fuse_tangent                                                             # Jct'd rides with the Gram pass (d is final before jac! runs)
+            if fuse_tangent && ineq                                                     # ... with bounds: Jct'(sx .* dx + sy .* dy), the m-part of Q'd
+                check(ctx, c_ineq_rhs(ctx.h, d.h, idecomp.Dx.h, idecomp.Dy.h, ineq_rhs.h))
+                rank = ksvd!(Jct, Z, Σ, Vt; w2=idecomp.sx, ϵ_rank=param.ϵ_rank, W=idecomp.W, Vt_prev=vprev, rhs=ineq_rhs, Jte=Jtd)
+            elseif fuse_tangent                                                         # Jct'd rides with the Gram pass (d is final before jac! runs)
                 rank = ksvd!(Jct, Z, Σ, Vt; ϵ_rank=param.ϵ_rank, W=idecomp.W, Vt_prev=vprev, rhs=d, Jte=Jtd)                          # :286-302
             else
                 rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp, Vt_prev=vprev) # :286-302
@@ -1462,22 +1470,27 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             if fuse_tangent && rank >= 1
                 # :305-343, :366-381 and src/projcg.jl:56-59 in one pass: d projected, λ_kkt, the Hessian diagonal completed, r0 = -d and U'r0 left
                 # in projcgwork for projcg!(...; start_given=true)
-                Ub = DeviceBasis(nothing, rank, (Jct, idecomp.W))
+                idecomp.rank = rank
+                Ub = ineq ? ineqproject : DeviceBasis(nothing, rank, (Jct, idecomp.W))
+                hdst = ineq ? hx : a_diag                                               # where the objective's part goes (bounds: the x-half alone)
                 dss = Ref{Float64}(0.0)
                 cons_part = nothing
                 if has_hess_split(hess_lag_vec!)
-                    hess_diag_objective!(hess_lag_vec!, a_diag, x)
+                    hess_diag_objective!(hess_lag_vec!, hdst, x)
                     cons_part = hess_constraints(hess_lag_vec!)
                 else                                                                    # a diagonal Hessian without the split needs λ_kkt first
                     th = zeros(m)
                     th[1:rank] .= (idecomp.W[:, 1:rank]' * Jtd[1:m]) ./ Σ[1:rank]
                     λ_kkt .= Vt' * th
-                    hess_diag!(hess_lag_vec!, a_diag, x, λ_kkt)
+                    hess_diag!(hess_lag_vec!, hdst, x, λ_kkt)
                 end
                 GC.@preserve Ub cons_part begin
                     cref = cons_part === nothing ? nothing : Ref(ccons(cons_part))
+                    iref = ineq ? Ref(cineq(idata)) : nothing
                     check(ctx, c_tangent_step(ctx.h, Ref(cbasis(Ub)), Σ, Vt, Int64(m), Jtd, d.h,
                                               cref === nothing ? Ptr{CConstraints}(C_NULL) : Base.unsafe_convert(Ptr{CConstraints}, cref), x.h, a_diag.h,
+                                              iref === nothing ? Ptr{CIneqData}(C_NULL) : Base.unsafe_convert(Ptr{CIneqData}, iref),
+                                              ineq ? hx.h : C_NULL, ineq ? idecomp.S.h : C_NULL, ineq ? lamy_kkt.h : C_NULL,
                                               Ref(cwork(projcgwork)), Utd, λ_kkt, dss))
                 end
             elseif !ineq                                                                # :305-308
@@ -1487,7 +1500,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             end
         end
         idecomp.rank = rank
-        if ineq                                                                         # :312-318
+        if ineq && !(fuse_tangent && m > 0 && rank >= 1)                                # :312-318
             q_gemv_t!(tmp_w, tmp_m, ineqproject, d)
             q_gemv_n!(d, ineqproject, tmp_w, tmp_m, -1.0, 1.0)
         end
@@ -1501,7 +1514,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
             λ_kkt .= Vt' * th
             upload!(λ_dev, λ_kkt)
         end
-        if ineq                                                                         # calculate_λ_kkt!, inequality_helper.jl:286-308
+        if ineq && !(fuse_tangent && m > 0 && rank >= 1)                                # calculate_λ_kkt!, inequality_helper.jl:286-308
             check(ctx, c_calculate_lambda_y(ctx.h, Jct.h, Int64(m), λ_dev.h, idecomp.Dx.h, idecomp.S.h, tmp_w.h, lamy_kkt.h))
         end
         if f_diff <= param.ϵ_f                                                          # :347-359

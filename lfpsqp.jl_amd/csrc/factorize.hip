@@ -943,6 +943,11 @@ static bool gram_eig_warm(lfpsqp_ctx* ctx, int m, const std::vector<double>& Lc,
         }
     }
     std::vector<double> X((size_t)m * m), Q, none;
+    const double t_x = now_ms();
+    // (the columns are independent: shared over the host threads -- at m = 128 the two triangular loops of this function are 2 Mflop of
+    // latency-bound scalar work between the Gram kernel and the next pass over the matrix)
+    [[maybe_unused]] const int nth = m >= 64 ? small_threads() : 1;
+#pragma omp parallel for if (nth > 1) num_threads(nth) schedule(static)
     for (int j = 0; j < m; ++j) {                     // X[:, j] = L' V0[:, j]: (L'v)_i = sum_{k >= i} L[k, i] v_k  (Lc column-major, lower: contiguous in k)
         const double* v = &V0[(size_t)j * m];
         for (int i = 0; i < m; ++i) {
@@ -953,9 +958,12 @@ static bool gram_eig_warm(lfpsqp_ctx* ctx, int m, const std::vector<double>& Lc,
             X[(size_t)j * m + i] = sdot;
         }
     }
+    const double t_j = now_ms();
     small_svd(ctx, m, m, X, Q, sig, none, false);      // Q: unit columns, sorted by norm (descending); sig: the norms
     if (!(sig[m - 1] > 0.0)) return false;
+    const double t_b = now_ms();
     V.assign((size_t)m * m, 0.0);
+#pragma omp parallel for if (nth > 1) num_threads(nth) schedule(static)
     for (int j = 0; j < m; ++j) {                     // L' y = sig_j Q[:, j]: back substitution on the upper triangular L'
         double* y = &V[(size_t)j * m];
         for (int i = m - 1; i >= 0; --i) {
@@ -970,6 +978,7 @@ static bool gram_eig_warm(lfpsqp_ctx* ctx, int m, const std::vector<double>& Lc,
         nn = 1.0 / sqrt(nn);
         for (int i = 0; i < m; ++i) y[i] *= nn;
     }
+    if (kTraceFactorize) fprintf(stderr, "[factorize] warm: probes + X = L'V0 %.3f ms, Jacobi %.3f ms, back substitution %.3f ms\n", t_j - t_x, t_b - t_j, now_ms() - t_b);
     return true;
 }
 

@@ -205,6 +205,23 @@ struct LambdaYE {  // lamy = (w - Dx.*acc) ./ S
     }
 };
 
+// e = |Dy| .* dx - Dx .* sgn(Dy) .* dy: the stacked vector d = [dx; dy] as ONE right-hand column of the weighted Gram pass (weights Dy.^2):
+// Jct'(sqrt(w2) .* e) = Jct'(Dy.^2 .* dx - Dx.*Dy .* dy) = Jct'(sx .* dx + sy .* dy), the m-part of Q'd (src/inequality_helper.jl:197-212)
+struct IneqRhsF {
+    const double* d;
+    int64_t hs;
+    const double *Dx, *Dy;
+    double* e;
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        const double2 dx = ld2(d + i), dy = ld2(d + hs + i), gx = ld2(Dx + i), gy = ld2(Dy + i);
+        const double2 o = make_double2(fabs(gy.x) * dx.x - gx.x * copysign(gy.x != 0.0 ? 1.0 : 0.0, gy.x) * dy.x,
+                                       fabs(gy.y) * dx.y - gx.y * copysign(gy.y != 0.0 ? 1.0 : 0.0, gy.y) * dy.y);
+        if (v1) st2(e + i, o);
+        else if (v0) e[i] = o.x;
+    }
+};
+
 struct AugDiagF {
     const double *hx, *lamy;
     IneqD id;
@@ -282,6 +299,13 @@ int lfpsqp_augmented_diag(lfpsqp_ctx* ctx, const lfpsqp_vec* hx, const lfpsqp_ve
     const int64_t hs = lfpsqp_half_stride(id->n);
     LF_ARG(ctx, a->n == hs + id->n);
     return run_vec<AugDiagF, 0, NoPost>(ctx, id->n, AugDiagF{hx->p, lamy->p, view(id), a->p, hs}, 0u, nullptr, NoPost());
+}
+
+int lfpsqp_ineq_rhs(lfpsqp_ctx* ctx, const lfpsqp_vec* daug, const lfpsqp_vec* Dx, const lfpsqp_vec* Dy, lfpsqp_vec* e) {
+    LF_ARG(ctx, ctx && daug && Dx && Dy && e);
+    const int64_t N = Dx->n, hs = lfpsqp_half_stride(N);
+    LF_ARG(ctx, Dy->n == N && daug->n == hs + N && e->n >= N && e->p != daug->p);
+    return run_vec<IneqRhsF, 0, NoPost>(ctx, N, IneqRhsF{daug->p, hs, Dx->p, Dy->p, e->p}, 0u, nullptr, NoPost());
 }
 
 int lfpsqp_y_retract(lfpsqp_ctx* ctx, lfpsqp_vec* xnewaug, const lfpsqp_vec* xaug, const lfpsqp_ineq_data* id) {

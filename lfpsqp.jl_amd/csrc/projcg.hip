@@ -1098,8 +1098,8 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         if (flags & LFPSQP_PROJCG_START_GIVEN) {
             // the caller's previous pass left r0 = -b in rp and U'r0 in Utr (lfpsqp_tangent_step): no residual pass; the first product of the
             // initial projection needs its coefficients over the generator's columns, W Utr
-            if (!(DF && fused && !c && !stacked))
-                return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "LFPSQP_PROJCG_START_GIVEN: plain basis in factored form over a dense generator, c == NULL");
+            if (!(DF && fused && !c))
+                return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "LFPSQP_PROJCG_START_GIVEN: basis in factored form over a dense generator, c == NULL");
             LF_TRY(factored_w_times_t(ctx, dWf, mc, m, Utr, uDF));
         } else {
             LF_TRY(launch_residual(1.0, rp, Utr));

@@ -76,22 +76,72 @@ struct TangentStepE {
     }
 };
 
+// The same with BOUNDS (src/optimize.jl:312-318, src/inequality_helper.jl:286-308 and :144-158): Q = [[diag Dx; diag Dy], [sx; sy] .* Z], stacked
+// vectors [x-half | y-half].  One pass replaces mul!(tmp, Q', d) / mul!(d, Q, tmp, -1, 1), the GEMV-N of calculate_lambda_kkt!, and projcg!'s
+// first Q'r:    w = Dx dx + Dy dy;  d -= [Dx w + sx (Z t); Dy w + sy (Z t)];  lamy = (w - Dx (Jct lam)) / S;
+//               a = [hx (+ cq on the rows < n_x) + 2 lamy q ; 2 lamy s];  r0 = -d;  second product of sx r0x + sy r0y.
+struct TangentStepSE {
+    static constexpr bool kRowScaled = true;            // (taken as is by run_onepass; views are refused by the caller)
+    static constexpr bool kSplitRed = false;
+    double* d;          // stacked, in / out
+    double* rp;         // stacked, out
+    double* a;          // stacked, out: the diagonal of augmented_hess_lag_vec!
+    const double* hx;   // n: the objective's part of the Hessian diagonal on the x-half
+    double* lamy;       // n, optional out
+    int64_t hs;
+    const double *Dx, *Dy, *sx, *sy, *S, *q, *s;
+    double cq;
+    int64_t n_x;
+    struct Uni {};
+    struct Row { double dx, dy, Dx, Dy, sx, sy, S, q, s, hx; };
+    static __device__ __forceinline__ double at(const double* base, uint32_t o) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
+    }
+    static __device__ __forceinline__ void put(double* base, uint32_t o, double v) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + o) = v;
+    }
+    __device__ __forceinline__ bool skip() const { return false; }
+    __device__ __forceinline__ Uni uniform() const { return Uni{}; }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        return Row{at(d, o), at(d + hs, o), at(Dx, o), at(Dy, o), at(sx, o), at(sy, o), at(S, o), at(q, o), at(s, o), at(hx, o)};
+    }
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&acc)[2], bool valid, bool owner, bool, const Uni&, const Row& w,
+                                          double (&v)[1], double (&red)[2]) const {
+        const double ww = w.Dx * w.dx + w.Dy * w.dy;                        // the diagonal block of Q'd
+        const double dxn = w.dx - fma(w.sx, acc[0], w.Dx * ww);             // d - Q [w; t]
+        const double dyn = w.dy - fma(w.sy, acc[0], w.Dy * ww);
+        const double ly = acc[1] * (-1.0 * w.Dx / w.S) + ww / w.S;          // (the reference's order: lamy = Jct lam; lamy *= -Dx / S; lamy += w / S)
+        if (valid && owner) {
+            put(d, o, dxn); put(d + hs, o, dyn);
+            put(rp, o, -dxn); put(rp + hs, o, -dyn);
+            put(a, o, (w.hx + ((row < n_x) ? cq : 0.0)) + 2.0 * ly * w.q);
+            put(a + hs, o, 2.0 * ly * w.s);
+            if (lamy) put(lamy, o, ly);
+            red[0] = fma(dxn, dxn, fma(dyn, dyn, red[0]));
+        }
+        v[0] = valid ? -(w.sx * dxn + w.sy * dyn) : 0.0;                    // the Z-block of Q'r0
+    }
+};
+
 }  // namespace lfpsqp
 
 using namespace lfpsqp;
 
 extern "C" int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m64, const double* Jtd,
                                    lfpsqp_vec* d, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_vec* hdiag,
+                                   const lfpsqp_ineq_data* idata, const lfpsqp_vec* hx, const lfpsqp_vec* S, lfpsqp_vec* lamy,
                                    const lfpsqp_projcg_work* work, double* Utd, double* lam, double* d_sumsq) {
     LF_RANGE("lfpsqp_tangent_step");
     LF_ARG(ctx, ctx && U && Sigma && Vt && Jtd && d && work && work->rp && work->Utr && Utd && lam && d_sumsq && m64 >= 1);
     const int m = (int)m64, rank = (int)U->ncols;
-    if (U->Z || !U->A || !U->W || U->SA || U->Dx || rank < 1 || rank > m || U->A->m != m || onepass_cw(ctx, m, U->A->ld, U->A->n) == 0)
-        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "lfpsqp_tangent_step: needs a plain basis in factored form over a dense generator of 4 .. 1024 columns "
-                                                    "(lfpsqp_basis.Z == NULL, A and W given, no sparse twin, no bounds)");
+    const bool stacked = U->Dx != nullptr;
+    if (U->Z || !U->A || !U->W || U->SA || rank < 1 || rank > m || U->A->m != m || onepass_cw(ctx, m, U->A->ld, U->A->n) == 0 || (stacked && U->A->view))
+        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "lfpsqp_tangent_step: needs a basis in factored form over a dense generator of 4 .. 1024 columns "
+                                                    "(lfpsqp_basis.Z == NULL, A and W given, no sparse twin; with bounds: no matrix view)");
     const lfpsqp_mat* A = U->A;
     const int64_t N = A->n;
-    LF_ARG(ctx, d->n >= N && work->rp->n >= N && work->Utr->n >= rank && d->p != work->rp->p);
+    const int64_t hs = stacked ? lfpsqp_half_stride(N) : 0, nv = stacked ? hs + N : N;
+    LF_ARG(ctx, d->n >= nv && work->rp->n >= nv && work->Utr->n >= rank && d->p != work->rp->p);
     // the class's Hessian term: which part of it this pass can carry
     int mode = 0;
     double cq = 0.0;
@@ -113,7 +163,7 @@ extern "C" int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const
         for (int k = 0; k < m; ++k) u1[k] = fma(wj[k], Utd[j], u1[k]);
     }
     if (cons) {
-        LF_ARG(ctx, x && hdiag && x->n >= N && hdiag->n >= N && hdiag->p != x->p && hdiag->p != d->p && cons->Jct && cons->m_lin >= 0 &&
+        LF_ARG(ctx, x && hdiag && x->n >= N && hdiag->n >= nv && hdiag->p != x->p && hdiag->p != d->p && cons->Jct && cons->m_lin >= 0 &&
                         cons->m_lin + (cons->has_ball ? 1 : 0) <= m);
         const lfpsqp_elementwise* ew = cons->ew;
         const int ml = (int)cons->m_lin;
@@ -121,6 +171,8 @@ extern "C" int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const
         if (ew && ew->qw)
             for (int j = 0; j < ml; ++j) cq += 2.0 * ew->qw[j] * lam[j];
         kind = (ew && ew->kind) ? ew->kind->p : nullptr;
+        if (stacked && kind)
+            return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "lfpsqp_tangent_step: bounds with a nonlinear constraint class (phi'' term): statement-by-statement sequence");
         if (kind && !(ew->A && !ew->Asp && ew->A->p == A->p && ew->A->ld == A->ld && ml <= m)) {
             // the class does not stream its gradients from the matrix this pass reads (a materialised Jct, or sparse A): its own pass
             LF_TRY(lfpsqp_constraints_hess_diag(ctx, cons, x, lam, hdiag));
@@ -130,7 +182,8 @@ extern "C" int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const
     // 2. coefficients of the first product(s) onto the device (the context's m-vector block: [u1 (m) | lam (m) | raw sums (m + 4) | folded (m + 4)])
     const int ms = (int)round_up(m, 2);
     LF_TRY(ensure_mvec(ctx, (size_t)4 * ms + 32));
-    for (int k = 0; k < m; ++k) { ctx->h_m[k] = u1[k]; ctx->h_m[ms + k] = (mode == 2 && k < (int)cons->m_lin) ? lam[k] : 0.0; }
+    const int nlam = stacked ? m : ((mode == 2) ? (int)cons->m_lin : 0);     // second coefficient vector: lam (bounds: Jct lam; nonlinear class: A lam)
+    for (int k = 0; k < m; ++k) { ctx->h_m[k] = u1[k]; ctx->h_m[ms + k] = k < nlam ? lam[k] : 0.0; }
     LF_HIP(ctx, hipMemcpyAsync(ctx->d_m, ctx->h_m, sizeof(double) * 2 * ms, hipMemcpyHostToDevice, ctx->stream));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));       // h_m is the context's shared pinned staging block (the next call may rewrite it)
     double* t = ctx->d_m;
@@ -138,6 +191,17 @@ extern "C" int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const
     double* folded = raw + ms + 4;                          // [A'(rs .* r0) + w (u'r0) (m) ; |d|^2]
     double *dW, *tA, *uA;
     LF_TRY(factored_setup(ctx, A, U->W, rank, &dW, &tA, &uA));
+    if (stacked) {
+        LF_ARG(ctx, idata && hx && S && hdiag && U->Dy && U->sx && U->sy && idata->q && idata->s && U->Dx->n == N && S->n == N && hx->n >= N &&
+                        hdiag->n >= nv && (!lamy || lamy->n >= N) && hdiag->p != d->p);
+        const TangentStepSE se{d->p, work->rp->p, hdiag->p, hx->p, lamy ? lamy->p : nullptr, hs, U->Dx->p, U->Dy->p, U->sx->p, U->sy->p, S->p,
+                               idata->q->p, idata->s->p, cq, cons ? cons->n_x : 0};
+        LF_TRY((run_onepass<TangentStepSE, 1, 2, 2>(ctx, A, m, m, N, t, se, raw, -1, ms)));
+        hipLaunchKernelGGL((view_fold_kernel<0>), dim3(1), dim3(256), 0, ctx->stream, raw, folded, (const double*)nullptr, 1, m, 1);
+        LF_LAUNCH_CHECK(ctx);
+        LF_TRY(sp_basis_small(ctx, dW, m, rank, folded, work->Utr->p, nullptr));
+        return read_back(ctx, folded + m, d_sumsq, 1);
+    }
     ViewD vw{nullptr, nullptr, nullptr};
     const lfpsqp_mat plain = A->plain();
     if (A->view) {
@@ -150,12 +214,12 @@ extern "C" int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const
         }
     }
     // 3. the pass
-    double* hx = hdiag ? hdiag->p : nullptr;
+    double* hxp = hdiag ? hdiag->p : nullptr;
     const double* xp = x ? x->p : nullptr;
     const int64_t n_x = cons ? cons->n_x : 0;
-    if (mode == 2) LF_TRY((run_onepass<TangentStepE<2>, 1, 2, 2>(ctx, &plain, m, m, N, t, TangentStepE<2>{d->p, work->rp->p, hx, xp, kind, cq, n_x, vw}, raw, -1, ms)));
-    else if (mode == 1) LF_TRY((run_onepass<TangentStepE<1>, 1, 2, 1>(ctx, &plain, m, m, N, t, TangentStepE<1>{d->p, work->rp->p, hx, xp, kind, cq, n_x, vw}, raw)));
-    else LF_TRY((run_onepass<TangentStepE<0>, 1, 2, 1>(ctx, &plain, m, m, N, t, TangentStepE<0>{d->p, work->rp->p, hx, xp, kind, cq, n_x, vw}, raw)));
+    if (mode == 2) LF_TRY((run_onepass<TangentStepE<2>, 1, 2, 2>(ctx, &plain, m, m, N, t, TangentStepE<2>{d->p, work->rp->p, hxp, xp, kind, cq, n_x, vw}, raw, -1, ms)));
+    else if (mode == 1) LF_TRY((run_onepass<TangentStepE<1>, 1, 2, 1>(ctx, &plain, m, m, N, t, TangentStepE<1>{d->p, work->rp->p, hxp, xp, kind, cq, n_x, vw}, raw)));
+    else LF_TRY((run_onepass<TangentStepE<0>, 1, 2, 1>(ctx, &plain, m, m, N, t, TangentStepE<0>{d->p, work->rp->p, hxp, xp, kind, cq, n_x, vw}, raw)));
     // 4. Utr = U'r0 = W'(A'(rs .* r0) + w (u'r0))  -> work->Utr (what lfpsqp_projcg's LFPSQP_PROJCG_START_GIVEN expects)
     hipLaunchKernelGGL((view_fold_kernel<0>), dim3(1), dim3(256), 0, ctx->stream, raw, folded, (A->view && A->ru) ? A->rw : nullptr, 1, m, 1);
     LF_LAUNCH_CHECK(ctx);

@@ -200,8 +200,10 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             ctx.set_placement(saved_tries)
     Z = idecomp.Z
     # The tangent step with fewer passes (lfpsqp_tangent_step): plain factored basis over dense gradients, truncated-Newton steps on
-    fuse_tangent = (factored and not ineq and param.do_newton and getattr(c_, "Jsp", None) is None and m > 0
-                    and bool(ctx.options.fused_tangent_step))
+    # (with bounds: the stacked form of the same pass; not over a matrix view, and not for a class whose Hessian term needs A*lambda)
+    fuse_tangent = (factored and param.do_newton and getattr(c_, "Jsp", None) is None and m > 0 and bool(ctx.options.fused_tangent_step)
+                    and not (ineq and (getattr(Jct, "is_view", False) or getattr(getattr(hess_lag_vec_, "cons", None), "kind", None) is not None)))
+    ineq_rhs = DeviceVector(ctx, n) if (fuse_tangent and ineq) else None
     prev_rank = -1                           # rank of the previous outer iteration's factorisation (its Vt warm-starts the next one)
     Sig, Vt = idecomp.Sigma, idecomp.Vt
     Wgen = np.zeros((m, m), order='F') if m > 0 else None                  # ksvd_'s small factor: Z == Jct @ Wgen
@@ -263,7 +265,10 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
                 jac_(Jct, cval, x)
             Jtd = None
             vt_prev = Vt if (i > 0 and prev_rank == m and ctx.options.warm_factorize) else None
-            if fuse_tangent:                                               # Jct'd rides with the Gram pass (d is final before jac! runs)
+            if fuse_tangent and ineq:                                      # ... with bounds: Jct'(sx .* dx + sy .* dy), the m-part of Q'd
+                ctx.check(ctx.L.lfpsqp_ineq_rhs(ctx.h, d.h, idecomp.Dx.h, idecomp.Dy.h, ineq_rhs.h))
+                S_, Vt_, rank, Jtd = ksvd_(Jct, Z, w2=idecomp.sx, eps_rank=param.eps_rank, W=Wgen, Vt_prev=vt_prev, rhs=ineq_rhs)
+            elif fuse_tangent:                                             # Jct'd rides with the Gram pass (d is final before jac! runs)
                 S_, Vt_, rank, Jtd = ksvd_(Jct, Z, eps_rank=param.eps_rank, W=Wgen, Vt_prev=vt_prev, rhs=d)    # :286-302
             else:
                 S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank, W=Wgen,
@@ -277,25 +282,32 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             if fused_now:
                 # :305-343, :366-381 and src/projcg.jl:56-59 in one pass: d projected, lambda_kkt, the Hessian diagonal completed, r0 = -d and
                 # U'r0 left in projcgwork for projcg_(start_given=True)
-                Ub = DeviceBasis(None, rank, generator=(Jct, Wgen))
+                if ineq:
+                    idecomp.rank = rank
+                    bs = ineqproject._c()
+                else:
+                    bs = DeviceBasis(None, rank, generator=(Jct, Wgen))._c()
+                hdst = hx if ineq else a_diag                              # where the objective's part of the diagonal goes (bounds: the x-half alone)
                 split = hasattr(hess_lag_vec_, "diag_objective_") and getattr(hess_lag_vec_, "cons", None) is not None
                 th = np.zeros(m)
                 dss = C.c_double()
                 if split:
-                    hess_lag_vec_.diag_objective_(a_diag, x)
+                    hess_lag_vec_.diag_objective_(hdst, x)
                     cc = hess_lag_vec_.cons._c()
                 else:                                                      # a diagonal Hessian without the split: it needs lambda_kkt first
                     th[:rank] = Wgen[:, :rank].T @ Jtd
                     th[:rank] /= S_[:rank]
                     lam_kkt[:] = Vt_.T @ th
-                    hess_lag_vec_.diag_(a_diag, x, lam_kkt)
+                    hess_lag_vec_.diag_(hdst, x, lam_kkt)
                     cc = None
-                bs, wc = Ub._c(), projcgwork._c()
+                wc = projcgwork._c()
                 sig_c = np.ascontiguousarray(S_, dtype=np.float64)
                 vt_c = np.asfortranarray(Vt_, dtype=np.float64)
+                idc = ineqdata._c() if ineq else None
                 ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), sig_c.ctypes.data, vt_c.ctypes.data, m, Jtd.ctypes.data, d.h,
-                                                    C.byref(cc) if cc is not None else None, x.h, a_diag.h, C.byref(wc), th.ctypes.data,
-                                                    lam_kkt.ctypes.data, C.byref(dss)))
+                                                    C.byref(cc) if cc is not None else None, x.h, a_diag.h,
+                                                    C.byref(idc) if ineq else None, hx.h if ineq else None, idecomp.S.h if ineq else None,
+                                                    lamy_kkt.h if ineq else None, C.byref(wc), th.ctypes.data, lam_kkt.ctypes.data, C.byref(dss)))
             elif not ineq:                                                 # :305-308
                 jsp_ = getattr(c_, "Jsp", None)
                 if jsp_ is not None or Z is None:                          # sparse twin / factored basis: U = Jct W applied without Z
@@ -305,7 +317,8 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
                 else:
                     gemv_t(Z, d, tmp_m, ncols=rank)
                     gemv_n(Z, tmp_m, d, -1.0, 1.0, ncols=rank)
-        if ineq:                                                           # :312-318
+        fused_now = bool(fuse_tangent and m > 0 and rank >= 1)
+        if ineq and not fused_now:                                         # :312-318
             idecomp.rank = rank
             ineqproject.mul_t(tmp_w, tmp_m, d)
             ineqproject.mul_n(d, tmp_w, tmp_m, -1.0, 1.0)
@@ -322,7 +335,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             th[rank:m] = 0.0
             lam_kkt[:] = Vt.T @ th
             lam_dev.upload(lam_kkt)
-        if ineq:                                                           # calculate_lambda_kkt!, :286-308
+        if ineq and not fused_now:                                         # calculate_lambda_kkt!, :286-308
             ctx.check(ctx.L.lfpsqp_calculate_lambda_y(ctx.h, Jct.h, m, lam_dev.h, idecomp.Dx.h, idecomp.S.h, tmp_w.h, lamy_kkt.h))
 
         if trace is not None:

@@ -86,7 +86,8 @@ def _tangent_step(ctx, U, S, Vt, m, Jtd, d, cons, x, hd, work):
     cc = cons._c() if cons is not None else None
     ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), S.ctypes.data, Vt.ctypes.data, m, Jtd.ctypes.data, d.h,
                                         C.byref(cc) if cc is not None else None, x.h if x is not None else None,
-                                        hd.h if hd is not None else None, C.byref(wc), Utd.ctypes.data, lam.ctypes.data, C.byref(ss)))
+                                        hd.h if hd is not None else None, None, None, None, None, C.byref(wc), Utd.ctypes.data,
+                                        lam.ctypes.data, C.byref(ss)))
     return Utd, lam, ss.value
 
 
@@ -242,3 +243,71 @@ def test_projcg_with_a_diagonal_plus_low_rank_operator_on_one_pass(dev_ctx, n, m
     i1, nr1 = L.projcg_(x, lam, A2, U, b, None, tol=1e-10, work=work)
     assert (i1, nr1) == (i0, nr0) and np.isinf(nr1)
     assert np.linalg.norm(x.download() - x0) <= 1e-10 and np.all(np.isnan(lam.download()))
+
+
+@pytest.mark.parametrize("n,m", [(1700, 8), (2400, 129)])
+def test_tangent_step_with_bounds_matches_the_statement_sequence(dev_ctx, n, m):
+    """Bound-stacked form: against the statement-by-statement device calls (mul!(tmp, Q', d), mul!(d, Q, tmp, -1, 1), calculate_lambda_kkt!,
+    augmented_hess_lag_vec!'s diagonal, projcg!'s first Q'r; src/optimize.jl:312-343, src/inequality_helper.jl:144-158, 286-308)."""
+    from lfpsqp_jl_amd.inequality import (InequalityData, InequalityDecomp, InequalityDecompProject, StackedVector, generate_initial_y_,
+                                          inequality_gradient_)
+    ctx = dev_ctx
+    i = np.arange(n)
+    xl = np.where((i % 4 == 1) | (i % 4 == 3), -1.0, -np.inf)
+    xu = np.where((i % 4 == 2) | (i % 4 == 3), 1.0, np.inf)
+    idata = InequalityData(ctx, xl, xu)
+    x = StackedVector(ctx, n)
+    x.upload(0.6 * synth.hash_vector(2, n), 0)
+    generate_initial_y_(x, idata)
+    Jct = ctx.matrix(n, m, np.asfortranarray(synth.hash_matrix(3, n, m)))
+    dec = InequalityDecomp(ctx, n, m, Jct, factored=True)
+    inequality_gradient_(dec, x, idata)
+    dh = synth.hash_vector(8, 2 * n)
+    d1, d2 = StackedVector(ctx, n), StackedVector(ctx, n)
+    d1.upload2(dh); d2.upload2(dh)
+    # the statement sequence
+    W = np.zeros((m, m), order='F')
+    S0, Vt0, rank = L.ksvd_(Jct, None, w2=dec.sx, W=W)
+    assert rank == m
+    dec.Sigma[:] = S0; dec.Vt[:, :] = Vt0; dec.W = W; dec.rank = rank
+    Q = InequalityDecompProject(dec)
+    tw, tm = ctx.vector(n), ctx.vector(m)
+    Q.mul_t(tw, tm, d1)
+    Q.mul_n(d1, tw, tm, -1.0, 1.0)
+    th = tm.download(m) / S0
+    lam0 = Vt0.T @ th
+    lamy0 = ctx.vector(n)
+    lamdev = ctx.vector(m, lam0)
+    ctx.check(ctx.L.lfpsqp_calculate_lambda_y(ctx.h, Jct.h, m, lamdev.h, dec.Dx.h, dec.S.h, tw.h, lamy0.h))
+    hxh = 2.0 + synth.hash_vector(41, n) ** 2
+    hx = ctx.vector(n, hxh)
+    a0 = StackedVector(ctx, n)
+    idc = idata._c()
+    ctx.check(ctx.L.lfpsqp_augmented_diag(ctx.h, hx.h, lamy0.h, C.byref(idc), a0.h))
+    r0 = StackedVector(ctx, n)
+    L.waxpby(-1.0, d1, 0.0, d1, r0)
+    tw2, tm2 = ctx.vector(n), ctx.vector(m)
+    Q.mul_t(tw2, tm2, r0)
+    # the fused pass
+    e = ctx.vector(n)
+    ctx.check(ctx.L.lfpsqp_ineq_rhs(ctx.h, d2.h, dec.Dx.h, dec.Dy.h, e.h))
+    W2 = np.zeros((m, m), order='F')
+    S1, Vt1, rank1, Jtd = L.ksvd_(Jct, None, w2=dec.sx, W=W2, rhs=e)
+    np.testing.assert_array_equal(S1, S0)
+    dec.W = W2
+    work = L.ProjCGWork(ctx, n, m, n)
+    a1, lamy1 = StackedVector(ctx, n), ctx.vector(n)
+    Utd, lam = np.zeros(m), np.zeros(m)
+    ss = C.c_double()
+    bs, wc = Q._c(), work._c()
+    ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), S1.ctypes.data, np.asfortranarray(Vt1).ctypes.data, m, Jtd.ctypes.data, d2.h, None, x.h,
+                                        a1.h, C.byref(idc), hx.h, dec.S.h, lamy1.h, C.byref(wc), Utd.ctypes.data, lam.ctypes.data, C.byref(ss)))
+    scale = np.linalg.norm(dh)
+    np.testing.assert_allclose(Utd, tm.download(m), atol=1e-12 * scale)
+    np.testing.assert_allclose(lam, lam0, atol=1e-11 * scale / S0[-1])
+    np.testing.assert_allclose(d2.download2(), d1.download2(), atol=1e-13 * scale)
+    np.testing.assert_allclose(work.rp.download2(), -d1.download2(), atol=1e-13 * scale)
+    np.testing.assert_allclose(lamy1.download(), lamy0.download(), rtol=1e-10, atol=1e-11 * scale)
+    np.testing.assert_allclose(a1.download2(), a0.download2(), rtol=1e-10, atol=1e-10 * scale)
+    np.testing.assert_allclose(work.Utr.download()[:m], tm2.download(m), atol=1e-12 * scale)
+    np.testing.assert_allclose(ss.value, np.sum(d1.download2() ** 2), rtol=1e-12)
