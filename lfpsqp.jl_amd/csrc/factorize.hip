@@ -655,7 +655,11 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     const int npan = (ncols + kPanel - 1) / kPanel;
     const int npair = npan * (npan + 1) / 2;
     const int64_t pp = (int64_t)npair * kPanel * kPanel;
-    const int xcols = nxu * npan * kPanel;               // the extra columns' sums sit behind the pair slots of a partial row
+    // border columns ride with the pass as extra right-hand columns while slots are free (two in all): G[0:ncols, j] = (sqrt(w) M)'(sqrt(w) M_j);
+    // their rows against each other come from a GEMV-T over the border columns alone (below)
+    const int nride = std::min(border, 2 - nxu);
+    const int nslots = nxu + nride;
+    const int xcols = nslots * npan * kPanel;            // the extra columns' sums sit behind the pair slots of a partial row
     const int64_t pld = pp + xcols;
     const int64_t nsteps = (M->n + kKStep - 1) / kKStep;
 #ifndef LFPSQP_GRAM_WGS
@@ -675,8 +679,25 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     LF_TRY(ensure_part(ctx, (size_t)std::max(gd, go) * pld));
     LF_TRY(ensure_small(ctx, (size_t)pld));
     const int64_t tile2 = (int64_t)kPanel * kPanel;
-    const double* ex0 = nxu > 0 ? rhs->e[0] : nullptr;
-    const double* ex1 = nxu > 1 ? rhs->e[1] : nullptr;
+    const double* exs[2] = {nxu > 0 ? rhs->e[0] : nullptr, nxu > 1 ? rhs->e[1] : nullptr};
+    if (nride > 0) {
+        const size_t npad = (size_t)round_up(M->n + 1, kPadRows);
+        if (w2) {                                        // the column in the kernel's scaled space: sqrt(w2) .* M[:, j]  (scratch slots 2, 3 of d_nvec)
+            const bool own = ctx->d_nvec && w2 == ctx->d_nvec;
+            LF_TRY(ensure_nvec(ctx, 4 * npad));
+            if (own) w2 = ctx->d_nvec;
+        }
+        for (int b = 0; b < nride; ++b) {
+            const double* colp = M->p + (int64_t)(ncols + b) * M->ld;
+            if (!w2) { exs[nxu + b] = colp; continue; }
+            double* dst = ctx->d_nvec + (2 + nxu + b) * npad;
+            if (dst == exs[0] || dst == exs[1]) dst = ctx->d_nvec + (2 + ((nxu + b + 1) & 1)) * npad;      // (a view's own column may already sit in a slot)
+            LF_TRY((run_vec<SignScaleF, 0, NoPost>(ctx, M->n, SignScaleF{colp, nullptr, w2, dst}, 0u, nullptr, NoPost())));
+            exs[nxu + b] = dst;
+        }
+    }
+    const double* ex0 = exs[0];
+    const double* ex1 = exs[1];
     if (w2) {
         // the kernel scales BOTH operands by sqrt(w2): staged in the second half of the n-vector scratch (the first may hold the weights themselves)
         const size_t npad = (size_t)round_up(M->n + 1, kPadRows);
@@ -740,12 +761,27 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     if (rhs && rhs->X)
         for (int k = 0; k < nxu; ++k)
             for (int i = 0; i < ncols; ++i) (*rhs->X)[(size_t)k * ncols_all + i] = hpin[pp + (size_t)k * npan * kPanel + i];
+    // (hpin is reused by the copies below: the riding border columns' sums are taken out first)
+    std::vector<double> ride((size_t)nride * ncols);
+    for (int b = 0; b < nride; ++b)
+        for (int i = 0; i < ncols; ++i) ride[(size_t)b * ncols + i] = hpin[pp + (size_t)(nxu + b) * npan * kPanel + i];
     if (border > 0) {
         LF_TRY(ensure_mvec(ctx, (size_t)ncols_all + 8));
+        lfpsqp_mat bcols = *M;                           // the border columns as a matrix of their own
+        bcols.p = M->p + (int64_t)ncols * M->ld;
+        bcols.m = border;
         for (int j = ncols; j < ncols_all; ++j) {
-            LF_TRY(run_gemv_t(ctx, M, ncols_all, M->n, ColTimesW{M->p + (int64_t)j * M->ld, w2}, ctx->d_m));
-            LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * ncols_all, hipMemcpyDeviceToHost, ctx->stream));
-            LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const bool rides = j - ncols < nride;
+            if (rides) {                                 // the panel part came with the Gram pass; the border block from a pass over the border columns alone
+                LF_TRY(run_gemv_t(ctx, &bcols, border, M->n, ColTimesW{M->p + (int64_t)j * M->ld, w2}, ctx->d_m + ncols));
+                LF_HIP(ctx, hipMemcpyAsync(ctx->h_m + ncols, ctx->d_m + ncols, sizeof(double) * border, hipMemcpyDeviceToHost, ctx->stream));
+                LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                for (int i = 0; i < ncols; ++i) ctx->h_m[i] = ride[(size_t)(j - ncols) * ncols + i];
+            } else {
+                LF_TRY(run_gemv_t(ctx, M, ncols_all, M->n, ColTimesW{M->p + (int64_t)j * M->ld, w2}, ctx->d_m));
+                LF_HIP(ctx, hipMemcpyAsync(ctx->h_m, ctx->d_m, sizeof(double) * ncols_all, hipMemcpyDeviceToHost, ctx->stream));
+                LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
             for (int i = 0; i < ncols_all; ++i) G[(size_t)j * ncols_all + i] = G[(size_t)i * ncols_all + j] = ctx->h_m[i];
         }
         // the extra columns against the border columns: a GEMV-T over those few columns alone
