@@ -321,11 +321,12 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
  * the projection needs Jct'(sx .* dx + sy .* dy) with sx = Dy.^2 = w2, sy = -Dx.*Dy, i.e. e = |Dy| dx - Dx sgn(Dy) dy -- no division by
  * a weight that may be zero.  M may be a view (lfpsqp_mat_view): X = V'(sqrt(w2) .* e) for V = diag(rs) A + u w'.
  * lfpsqp_gram_rhs: G as lfpsqp_gram plus X; lfpsqp_factorize_rhs: lfpsqp_factorize plus Jte_host[0:m) = Jct'(sqrt(w2) .* e) (e may be
- * NULL: then exactly lfpsqp_factorize). */
+ * NULL: then exactly lfpsqp_factorize) and, when G_host != NULL, the m x m Gram matrix Jct' diag(w2) Jct the factors were computed from
+ * (column-major; with it U'U = W'GW is known on the host: lfpsqp_tangent_step's LFPSQP_TANGENT_INIT_PROJCG). */
 int lfpsqp_gram_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const lfpsqp_vec* w2, int64_t nx, const lfpsqp_vec* const* e,
                     double* G_host, double* X_host);
 int lfpsqp_factorize_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
-                         double* W, int64_t* rank, double eps_rank, const lfpsqp_vec* e, double* Jte_host);
+                         double* W, int64_t* rank, double eps_rank, const lfpsqp_vec* e, double* Jte_host, double* G_host);
 
 /* The same factorisation when the constraint gradients are sparse: A = [S | Jct[:, S.m : Jct.m)], i.e. the sparse object holds the
  * leading columns and the dense twin Jct (n x M, M - S.m <= 4: the ball / slack columns; NULL when there are none) the rest.  The
@@ -411,6 +412,11 @@ typedef struct lfpsqp_projcg_work {
  * m-part of Q'r0; the diagonal block is formed row by row) -- LFPSQP_ERR_UNSUPPORTED otherwise; iterates as without the flag up to the
  * rounding of U'r0. */
 #define LFPSQP_PROJCG_START_GIVEN 4
+/* The initial projection itself is done (x0 = 0, c == NULL): work->g = g0, work->d = -g0 and, behind the first A.m entries of work->Utr
+ * (which must have >= A.m + 2 ncols + 5), the sums [U'g0; U'(A g0); r0'g0; g0'g0; g0'A g0; 0; 0] -- what lfpsqp_tangent_step leaves with
+ * LFPSQP_TANGENT_INIT_PROJCG.  The call starts with the first iteration; b is not read (lambda is not offered: WANT_LAMBDA needs b and A x as
+ * usual).  Factored basis over a dense generator, plain or bound-stacked, diagonal operator only. */
+#define LFPSQP_PROJCG_START_PROJECTED 8
 
 /* Can lfpsqp_projcg run on a basis kept in FACTORED form (lfpsqp_basis.Z == NULL, generator A (N rows) and W given; SA = the sparse twin of
  * A's leading columns, or NULL) with a diagonal operator on THIS context?  *yes = 1 / 0.  The factored form needs the fused one-pass
@@ -553,10 +559,19 @@ int lfpsqp_constraints_jac(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, cons
  * Five passes of the statement-by-statement sequence (GEMV-T, GEMV-N, the GEMV-N of the Hessian term / of lambda_y, projcg!'s GEMV-T, its
  * initial projection) become two (this one and the initial projection).  LFPSQP_ERR_UNSUPPORTED for a materialised or sparse-twinned basis,
  * and for bounds together with a view or a nonlinear class's phi'' term. */
+/* flags: LFPSQP_TANGENT_INIT_PROJCG -- the pass is ALSO projcg!'s initial projection (src/projcg.jl:58-62) for the solve that follows with
+ * A = diag(hdiag), b = the projected d, x0 = 0: U'r0 = -(I - U'U) U'd follows from G (host, m x m: the Gram matrix lfpsqp_factorize_rhs returns,
+ * U'U = W'GW) instead of a pass of its own, a further first product brings (U U'r0)_i, and the row goes on to g0 = r0 - (U U'r0)_i, work->d = -g0,
+ * the second products of g0 and A g0 and the sums the first iteration needs -- left in work->g, work->d and work->Utr[m ..] for
+ * LFPSQP_PROJCG_START_PROJECTED (work->Utr must have >= 3 m + 5 entries; work->rp is not written).  One more pass less per outer iteration.
+ * Only for a full-rank block with cond^2 = (Sigma_1 / Sigma_m)^2 <= 10 -- where lfpsqp_factorize itself takes its factors from the Gram matrix
+ * alone; beyond that G cannot resolve I - U'U (its rounding enters divided by Sigma_j^2) and the call answers LFPSQP_ERR_UNSUPPORTED: run it
+ * without the flag and let projcg! measure U'r0 (LFPSQP_PROJCG_START_GIVEN). */
+#define LFPSQP_TANGENT_INIT_PROJCG 1
 int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m, const double* Jtd,
-                        lfpsqp_vec* d, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_vec* hdiag,
+                        const double* G, lfpsqp_vec* d, const lfpsqp_constraints* cons, const lfpsqp_vec* x, lfpsqp_vec* hdiag,
                         const lfpsqp_ineq_data* idata, const lfpsqp_vec* hx, const lfpsqp_vec* S, lfpsqp_vec* lamy,
-                        const lfpsqp_projcg_work* work, double* Utd, double* lam, double* d_sumsq);
+                        const lfpsqp_projcg_work* work, int flags, double* Utd, double* lam, double* d_sumsq);
 /* A user c!: x is the DEVICE vector (download it if the function is host code); return 0. */
 typedef int (*lfpsqp_cfun)(void* user, const lfpsqp_vec* x, double* cval);
 

@@ -117,6 +117,8 @@ end
 const LFPSQP_PROJCG_WANT_LAMBDA = Cint(1)
 const LFPSQP_PROJCG_RESUME = Cint(2)
 const LFPSQP_PROJCG_START_GIVEN = Cint(4)      # work.rp = r0 = -b and work.Utr = U'r0 are given (lfpsqp_tangent_step left them): no residual pass
+const LFPSQP_PROJCG_START_PROJECTED = Cint(8)  # the initial projection is done (lfpsqp_tangent_step with LFPSQP_TANGENT_INIT_PROJCG): start with the first iteration
+const LFPSQP_TANGENT_INIT_PROJCG = Cint(1)
 const LFPSQP_ERR_UNSUPPORTED = Cint(-5)
 
 const H = Ptr{Cvoid}           # an opaque handle (lfpsqp_ctx*, lfpsqp_vec*, lfpsqp_mat*)
@@ -212,7 +214,7 @@ c_rmul(ctx, In, kcols, W, rcols, Out) = ccall((:lfpsqp_rmul, lib), Cint, (Ptr{Cv
 c_factorize_hint(ctx, Vt_prev, m) = ccall((:lfpsqp_factorize_hint, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), ctx, Vt_prev, m)
 c_factorize(ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank) = ccall((:lfpsqp_factorize, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64), ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank)
 c_gram_rhs(ctx, M, ncols, w2, nx, e, G, X) = ccall((:lfpsqp_gram_rhs, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Ptr{Float64}, Ptr{Float64}), ctx, M, ncols, w2, nx, e, G, X)
-c_factorize_rhs(ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank, e, Jte) = ccall((:lfpsqp_factorize_rhs, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64, Ptr{Cvoid}, Ptr{Float64}), ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank, e, Jte)
+c_factorize_rhs(ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank, e, Jte, G) = ccall((:lfpsqp_factorize_rhs, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank, e, Jte, G)
 c_factorize_sp(ctx, S, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank) = ccall((:lfpsqp_factorize_sp, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Float64), ctx, S, Jct, w2, Z, Sigma, Vt, W, rank, eps_rank)
 c_small_svd(ctx, rows, cols, A, U, S, V) = ccall((:lfpsqp_small_svd, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx, rows, cols, A, U, S, V)
 c_q_gemv_t(ctx, Q, v, w, t) = ccall((:lfpsqp_q_gemv_t, lib), Cint, (Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, Q, v, w, t)
@@ -228,10 +230,10 @@ c_projcg_lowrank(ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters,
 c_projcg_op(ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg_op, lib), Cint,
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
     ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
-c_tangent_step(ctx, U, Sigma, Vt, m, Jtd, d, cons, x, hdiag, idata, hx, S, lamy, work, Utd, lam, dss) = ccall((:lfpsqp_tangent_step, lib), Cint,
-    (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Cvoid}, Ptr{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{CIneqData}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-     Ref{CWork}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
-    ctx, U, Sigma, Vt, m, Jtd, d, cons, x, hdiag, idata, hx, S, lamy, work, Utd, lam, dss)
+c_tangent_step(ctx, U, Sigma, Vt, m, Jtd, G, d, cons, x, hdiag, idata, hx, S, lamy, work, flags, Utd, lam, dss) = ccall((:lfpsqp_tangent_step, lib), Cint,
+    (Ptr{Cvoid}, Ref{CBasis}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}, Ptr{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{CIneqData}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+     Ref{CWork}, Cint, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+    ctx, U, Sigma, Vt, m, Jtd, G, d, cons, x, hdiag, idata, hx, S, lamy, work, flags, Utd, lam, dss)
 c_ineq_rhs(ctx, daug, Dx, Dy, e) = ccall((:lfpsqp_ineq_rhs, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, daug, Dx, Dy, e)
 c_constraints_eval(ctx, cons, x, cval) = ccall((:lfpsqp_constraints_eval, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Float64}), ctx, cons, x, cval)
 c_constraints_jac(ctx, cons, x, Jct, cval) = ccall((:lfpsqp_constraints_jac, lib), Cint, (Ptr{Cvoid}, Ref{CConstraints}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), ctx, cons, x, Jct, cval)
@@ -630,14 +632,16 @@ y_retract!(xnew::DeviceVector, x::DeviceVector, id::InequalityData) = (check(x.c
 # Z === nothing (dense Jct, W required): the basis Z = Jct*W is not formed -- the caller keeps it in factored form, DeviceBasis(nothing, rank, (Jct, W))
 function ksvd!(Jct::DeviceMatrix, Z::Union{Nothing,DeviceMatrix}, Σ::Vector{Float64}, Vt::Matrix{Float64}; w2::Union{Nothing,DeviceVector}=nothing,
                ϵ_rank::Float64=1e-10, W::Union{Nothing,Matrix{Float64}}=nothing, Jsp=nothing, Vt_prev::Union{Nothing,Matrix{Float64}}=nothing,
-               rhs::Union{Nothing,DeviceVector}=nothing, Jte::Union{Nothing,Vector{Float64}}=nothing)
+               rhs::Union{Nothing,DeviceVector}=nothing, Jte::Union{Nothing,Vector{Float64}}=nothing, G::Union{Nothing,Matrix{Float64}}=nothing)
     # rhs / Jte (dense Jct only): Jte .= Jct' (sqrt.(w2) .* rhs), summed by the Gram pass itself (lfpsqp_factorize_rhs) -- the outer iteration's
     # Jct'd (src/optimize.jl:306) without a GEMV-T pass of its own
     rank = Ref{Int64}(0)
     # warm start of the small eigenproblem from the previous outer iteration's Vt (lfpsqp_factorize_hint; ignored unless orthogonal)
     Vt_prev !== nothing && size(Vt_prev) == size(Vt) && check(Jct.ctx, c_factorize_hint(Jct.ctx.h, Vt_prev, Int64(size(Vt, 1))))
     if Jsp === nothing && rhs !== nothing
-        check(Jct.ctx, c_factorize_rhs(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, zhandle(Z), Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank, rhs.h, Jte))
+        # (G, optional m x m: receives the Gram matrix the factors come from -- U'U = W'GW for the tangent step)
+        check(Jct.ctx, c_factorize_rhs(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, zhandle(Z), Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank, rhs.h, Jte,
+                                       G === nothing ? Ptr{Float64}(C_NULL) : pointer(G)))
     elseif Jsp === nothing
         check(Jct.ctx, c_factorize(Jct.ctx.h, Jct.h, w2 === nothing ? C_NULL : w2.h, zhandle(Z), Σ, Vt, W === nothing ? C_NULL : W, rank, ϵ_rank))
     else
@@ -656,16 +660,18 @@ struct ProjCGWork              # ProjCGWork(n, m), src/projcg.jl:1-11 (three n-v
     Utr::DeviceVector
     Av::DeviceVector
 end
+# (Utr: 3 m + 8 entries -- behind the m coefficients lfpsqp_tangent_step parks the sums of LFPSQP_PROJCG_START_PROJECTED)
 ProjCGWork(like::DeviceVector, m::Integer) =
-    ProjCGWork(similar_device(like), similar_device(like), similar_device(like), DeviceVector(like.ctx, max(m, 1)), similar_device(like))
+    ProjCGWork(similar_device(like), similar_device(like), similar_device(like), DeviceVector(like.ctx, 3 * max(m, 1) + 8), similar_device(like))
 cwork(w::ProjCGWork) = CWork(w.g.h, w.d.h, w.rp.h, w.Utr.h)
 
 # projcg!(x, λ, A, U, b, c; tol, maxit, work) -> (i, nr)  (src/projcg.jl:40-121), fused on the device for a diagonal A ...
 function projcg!(x::DeviceVector, λ::Union{Nothing,DeviceVector}, A::DiagOperator, U::AnyBasis, b::DeviceVector, c::Union{Nothing,DeviceVector};
                  tol::Float64=1e-6, maxit::Int=length(b) + ncols(U), work::ProjCGWork=ProjCGWork(x, ncols(U)), n_global::Int=length(b),
-                 start_given::Bool=false)
+                 start_given::Bool=false, start_projected::Bool=false)
     iters = Ref{Int64}(0); nr = Ref{Float64}(0.0)
-    flags = (λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA) | (start_given ? LFPSQP_PROJCG_START_GIVEN : Cint(0))
+    flags = (λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA) | (start_given ? LFPSQP_PROJCG_START_GIVEN : Cint(0)) |
+            (start_projected ? LFPSQP_PROJCG_START_PROJECTED : Cint(0))
     GC.@preserve U begin
         check(x.ctx, c_projcg(x.ctx.h, x.h, λ === nothing ? C_NULL : λ.h, Ref(CDiagOp(A.a0, A.dg === nothing ? C_NULL : A.dg.h)), Ref(cbasis(U)),
                               b.h, c === nothing ? C_NULL : c.h, tol, Int64(maxit), Int64(n_global), flags,
@@ -1378,12 +1384,12 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     few_cg && saved_tries > 1 && set_placement!(ctx, 1)
     if factored_basis
         vs = vectors_placed(ctx, Jct, ineq ? 0 : n, 5; N=ineq ? n : 0)
-        projcgwork = ProjCGWork(vs[1], vs[2], vs[4], DeviceVector(ctx, max(m, 1)), vs[5])
+        projcgwork = ProjCGWork(vs[1], vs[2], vs[4], DeviceVector(ctx, 3 * max(m, 1) + 8), vs[5])
         a_placed = vs[3]
         idecomp = InequalityDecomp(ctx, n, m, Jct, nothing)
     elseif m > 0
         Zp, vs = basis_and_vectors_placed(ctx, n, m, 5; N=ineq ? n : 0)
-        projcgwork = ProjCGWork(vs[1], vs[2], vs[4], DeviceVector(ctx, max(m, 1)), vs[5])
+        projcgwork = ProjCGWork(vs[1], vs[2], vs[4], DeviceVector(ctx, 3 * max(m, 1) + 8), vs[5])
         a_placed = vs[3]
         idecomp = InequalityDecomp(ctx, n, m, Jct, Zp)
     else
@@ -1398,6 +1404,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     fuse_tangent = factored_basis && param.do_newton && jsp === nothing && m > 0 && ctx.options.fused_tangent_step && !(ineq && nonlinear_class)
     ineq_rhs = (fuse_tangent && ineq) ? DeviceVector(ctx, n) : nothing
     Jtd = zeros(max(m, 1)); Utd = zeros(max(m, 1))
+    Ggram = fuse_tangent ? zeros(m, m) : nothing              # the factorisation's Gram matrix: U'U = W'GW for the tangent step
     idecomp.W = m > 0 ? zeros(m, m) : nothing                 # ksvd!'s small factor: Z == Jct*W
     jsp === nothing || (idecomp.Jsp = jsp.h)                  # sparse twin: the stacked basis is applied on the nonzeros too
     Z, Σ, Vt = idecomp.Z, idecomp.Σ, idecomp.Vt
@@ -1454,15 +1461,16 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
         end
         ineq && inequality_gradient!(idecomp, x, idata)                                 # :277
         rank = m
+        init_fold = false
         if m > 0
             # :283-284 (the device keeps only Jct); a device-resident class skips the re-evaluation of c(x) when cval holds it already
             (cval_current && jac! isa DeviceConstraints) ? jac!(jac!, Jct, nothing, x) : jac!(Jct, cval, x)
             vprev = (i > 0 && prev_rank == m && ctx.options.warm_factorize) ? copy(Vt) : nothing
             if fuse_tangent && ineq                                                     # ... with bounds: Jct'(sx .* dx + sy .* dy), the m-part of Q'd
                 check(ctx, c_ineq_rhs(ctx.h, d.h, idecomp.Dx.h, idecomp.Dy.h, ineq_rhs.h))
-                rank = ksvd!(Jct, Z, Σ, Vt; w2=idecomp.sx, ϵ_rank=param.ϵ_rank, W=idecomp.W, Vt_prev=vprev, rhs=ineq_rhs, Jte=Jtd)
+                rank = ksvd!(Jct, Z, Σ, Vt; w2=idecomp.sx, ϵ_rank=param.ϵ_rank, W=idecomp.W, Vt_prev=vprev, rhs=ineq_rhs, Jte=Jtd, G=Ggram)
             elseif fuse_tangent                                                         # Jct'd rides with the Gram pass (d is final before jac! runs)
-                rank = ksvd!(Jct, Z, Σ, Vt; ϵ_rank=param.ϵ_rank, W=idecomp.W, Vt_prev=vprev, rhs=d, Jte=Jtd)                          # :286-302
+                rank = ksvd!(Jct, Z, Σ, Vt; ϵ_rank=param.ϵ_rank, W=idecomp.W, Vt_prev=vprev, rhs=d, Jte=Jtd, G=Ggram)                 # :286-302
             else
                 rank = ksvd!(Jct, Z, Σ, Vt; w2=ineq ? idecomp.sx : nothing, ϵ_rank=param.ϵ_rank, W=idecomp.W, Jsp=jsp, Vt_prev=vprev) # :286-302
             end
@@ -1484,14 +1492,17 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
                     λ_kkt .= Vt' * th
                     hess_diag!(hess_lag_vec!, hdst, x, λ_kkt)
                 end
+                # the fold of projcg!'s initial projection: only where the Gram matrix resolves I - U'U (full rank, cond^2 <= 10)
+                init_fold = rank == m && Σ[1]^2 <= 10.0 * Σ[m]^2
                 GC.@preserve Ub cons_part begin
                     cref = cons_part === nothing ? nothing : Ref(ccons(cons_part))
                     iref = ineq ? Ref(cineq(idata)) : nothing
-                    check(ctx, c_tangent_step(ctx.h, Ref(cbasis(Ub)), Σ, Vt, Int64(m), Jtd, d.h,
+                    # (LFPSQP_TANGENT_INIT_PROJCG: the pass is projcg!'s initial projection as well, src/projcg.jl:58-62; projcg! starts projected)
+                    check(ctx, c_tangent_step(ctx.h, Ref(cbasis(Ub)), Σ, Vt, Int64(m), Jtd, Ggram, d.h,
                                               cref === nothing ? Ptr{CConstraints}(C_NULL) : Base.unsafe_convert(Ptr{CConstraints}, cref), x.h, a_diag.h,
                                               iref === nothing ? Ptr{CIneqData}(C_NULL) : Base.unsafe_convert(Ptr{CIneqData}, iref),
                                               ineq ? hx.h : C_NULL, ineq ? idecomp.S.h : C_NULL, ineq ? lamy_kkt.h : C_NULL,
-                                              Ref(cwork(projcgwork)), Utd, λ_kkt, dss))
+                                              Ref(cwork(projcgwork)), init_fold ? LFPSQP_TANGENT_INIT_PROJCG : Cint(0), Utd, λ_kkt, dss))
                 end
             elseif !ineq                                                                # :305-308
                 Ub = jsp === nothing ? (Z === nothing ? DeviceBasis(nothing, rank, (Jct, idecomp.W)) : DeviceBasis(Z, rank)) : DeviceBasis(Z, rank, (Jct, idecomp.W), jsp.h)
@@ -1542,7 +1553,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
                     hess_diag!(hess_lag_vec!, a_diag, x, λ_kkt)
                 end
                 tn_iter, tn_res = projcg!(newton_d, nothing, DiagOperator(0.0, a_diag), Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
-                                          work=projcgwork, n_global=nglob, start_given=fused_now)
+                                          work=projcgwork, n_global=nglob, start_projected=fused_now && init_fold, start_given=fused_now && !init_fold)
             else
                 tn_iter, tn_res = projcg!(newton_d, nothing, newton_apply!, Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
                                           work=projcgwork, n_global=nglob)

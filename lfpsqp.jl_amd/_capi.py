@@ -153,10 +153,10 @@ _SIGS = {
     "lfpsqp_gram": [P, P, c_i64, P, P],
     "lfpsqp_rmul": [P, P, c_i64, P, c_i64, P],
     "lfpsqp_factorize": [P, P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],
-    "lfpsqp_factorize_rhs": [P, P, P, P, P, P, P, C.POINTER(c_i64), c_dbl, P, P],
+    "lfpsqp_factorize_rhs": [P, P, P, P, P, P, P, C.POINTER(c_i64), c_dbl, P, P, P],
     "lfpsqp_gram_rhs": [P, P, c_i64, P, c_i64, C.POINTER(P), P, P],
-    "lfpsqp_tangent_step": [P, C.POINTER(Basis), P, P, c_i64, P, P, C.POINTER(Constraints), P, P, C.POINTER(IneqData), P, P, P,
-                            C.POINTER(ProjCGWorkC), P, P, PD],
+    "lfpsqp_tangent_step": [P, C.POINTER(Basis), P, P, c_i64, P, P, P, C.POINTER(Constraints), P, P, C.POINTER(IneqData), P, P, P,
+                            C.POINTER(ProjCGWorkC), C.c_int, P, P, PD],
     "lfpsqp_ineq_rhs": [P, P, P, P, P],
     "lfpsqp_spmat_gram": [P, P, P, P, P],
     "lfpsqp_factorize_sp": [P, P, P, P, P, P, P, P, C.POINTER(c_i64), c_dbl],

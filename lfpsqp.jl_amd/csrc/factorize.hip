@@ -1291,7 +1291,7 @@ int lfpsqp_gram_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int64_t ncols, const l
 }
 
 int lfpsqp_factorize_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
-                         double* W, int64_t* rank_out, double eps_rank, const lfpsqp_vec* e, double* Jte_host) {
+                         double* W, int64_t* rank_out, double eps_rank, const lfpsqp_vec* e, double* Jte_host, double* G_host) {
     LF_RANGE("lfpsqp_factorize");
     LF_ARG(ctx, ctx && Jct && Sigma && Vt && rank_out && (Z ? (plain_mat(Z) && Jct->p != Z->p && Jct->n == Z->n && Z->m >= Jct->m) : W != nullptr) &&
                     (!w2 || w2->n == Jct->n) && (!e || (Jte_host && e->n >= Jct->n)));
@@ -1303,7 +1303,13 @@ int lfpsqp_factorize_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_ve
     std::vector<double> X;
     if (e) { rhs.nx = 1; rhs.e[0] = e->p; rhs.X = &X; }
     const int rc = factorize_core(
-        ctx, m, [&](std::vector<double>& G) { return gram_impl(ctx, Jct, m, w2p, G, e ? &rhs : nullptr); },
+        ctx, m,
+        [&](std::vector<double>& G) {
+            LF_TRY(gram_impl(ctx, Jct, m, w2p, G, e ? &rhs : nullptr));
+            if (G_host)
+                for (size_t i = 0; i < G.size(); ++i) G_host[i] = G[i];          // the Gram matrix the factors come from (U'U = W'GW for the caller)
+            return 0;
+        },
         [&](const double* Wh, int r) { return rmul_impl(ctx, Jct, m, Wh, r, Zu); }, w2p, Zu,
         [&]() -> int { LF_TRY(lfpsqp_mat_alloc(ctx, Jct->n, m, &Ztmp)); Zu = Ztmp; return 0; }, Sigma, Vt, W, rank_out, eps_rank);
     if (Ztmp) lfpsqp_mat_free(ctx, Ztmp);
@@ -1314,7 +1320,7 @@ int lfpsqp_factorize_rhs(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_ve
 
 int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma, double* Vt,
                      double* W, int64_t* rank_out, double eps_rank) {
-    return lfpsqp_factorize_rhs(ctx, Jct, w2, Z, Sigma, Vt, W, rank_out, eps_rank, nullptr, nullptr);
+    return lfpsqp_factorize_rhs(ctx, Jct, w2, Z, Sigma, Vt, W, rank_out, eps_rank, nullptr, nullptr, nullptr);
 }
 
 int lfpsqp_factorize_sp(lfpsqp_ctx* ctx, const lfpsqp_spmat* S, const lfpsqp_mat* Jct, const lfpsqp_vec* w2, lfpsqp_mat* Z, double* Sigma,

@@ -466,6 +466,7 @@ struct PcgPostF {
     double* Tw = nullptr;         // == T, writable
     double* uA = nullptr;
     int wm = 0;
+    int pre = 0;                  // the sums in T are final already (LFPSQP_PROJCG_START_PROJECTED: lfpsqp_tangent_step applied W'): no conversion of Traw
     // operator with a low-rank term V diag(sigma) V' (PcgFuseLR): k > 0; the sums carry V'gp behind the five scalars
     int k = 0;
     const double* UtV = nullptr;  // m x k, column-major (device): U'V
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(1024) void pcg_post_kernel(PcgPostF u) {
     __shared__ int go;
     __shared__ double s_utr[kOnepassMaxCols];
     __shared__ double s_part[2 * 1024];
-    if (u.W && u.init != 2) {                                          // (a resumed solve finds T as the previous call converted it)
+    if (u.W && u.init != 2 && !u.pre) {                                // (a resumed solve finds T as the previous call converted it)
         // [t1; t2] = W' [raw1; raw2]: output j = column j of W (contiguous) against the raw sums.  m <= 1024 = blockDim: one output per thread slot
         const double* const xin[2] = {u.Traw, u.Traw + u.wm};
         double yo[2];
@@ -846,8 +847,9 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     if (LRop) { lr_diag.a0 = LRop->a0; lr_diag.dg = LRop->dg; A = &lr_diag; }
     if (opf) A = &no_diag;
     LF_ARG(ctx, ctx && x && A && U && b && work && iters && nr);
-    LF_ARG(ctx, !opf || (Av && Av->n == b->n && !(flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN))));
-    LF_ARG(ctx, !((flags & LFPSQP_PROJCG_RESUME) && (flags & LFPSQP_PROJCG_START_GIVEN)));
+    LF_ARG(ctx, !opf || (Av && Av->n == b->n && !(flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN | LFPSQP_PROJCG_START_PROJECTED))));
+    LF_ARG(ctx, !((flags & LFPSQP_PROJCG_RESUME) && (flags & (LFPSQP_PROJCG_START_GIVEN | LFPSQP_PROJCG_START_PROJECTED))));
+    LF_ARG(ctx, !((flags & LFPSQP_PROJCG_START_GIVEN) && (flags & LFPSQP_PROJCG_START_PROJECTED)));
     LF_ARG(ctx, work->g && work->d && work->rp && work->Utr);
     const lfpsqp_ctx::ProjcgResume rs = ctx->pcg_resume;      // (taken before this call's own workspace requests invalidate it)
     const bool stacked = U->Dx != nullptr;
@@ -935,7 +937,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     const int ns = kLR > 0 ? 5 + kLRMax : 5;             // scalar sums of a pass
     if (LRop) {
         LF_ARG(ctx, LRop->V && plain_mat(LRop->V) && kLR >= 1 && kLR <= kLRMax && LRop->V->m >= kLR && LRop->V->n == nv && (!LRop->dg || LRop->dg->n == nv));
-        if (!fused || stacked || (flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN)))
+        if (!fused || stacked || (flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN | LFPSQP_PROJCG_START_PROJECTED)))
             return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "lfpsqp_projcg_lowrank: needs the one-pass iteration over a plain dense basis (4 .. 1024 columns), no RESUME / START_GIVEN");
     }
     double *lrUtV = nullptr, *lrSig = nullptr, *lrVdraw = nullptr, *lrVdc = nullptr, *lrVtv = nullptr;
@@ -1095,7 +1097,17 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
             }
         }
         // r = A x - b (kept in rp), Utr = U' r, g = r - U Utr, d = -g, rg = g'g   (:56-62)
-        if (flags & LFPSQP_PROJCG_START_GIVEN) {
+        if (flags & LFPSQP_PROJCG_START_PROJECTED) {
+            // lfpsqp_tangent_step (LFPSQP_TANGENT_INIT_PROJCG) has already made the initial projection in its own pass: g = g0 and d = -g0 are in
+            // `work`, the sums [U'g0; U'(A g0); r0'g0; g0'g0; g0'A g0; 0; 0] wait behind the generator's column count in work->Utr
+            if (!(DF && fused && !c && kLR == 0) || work->Utr->n < (int64_t)mc + 2 * m + 5)
+                return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "LFPSQP_PROJCG_START_PROJECTED: basis in factored form over a dense generator, c == NULL, work->Utr of >= A.m + 2 ncols + 5 entries");
+            LF_HIP(ctx, hipMemcpyAsync(T12, Utr + mc, sizeof(double) * (2 * (size_t)m + 5), hipMemcpyDeviceToDevice, ctx->stream));
+            PcgPostF pf{T12, t3, Utr, scal, istat, m, 1, hm, dWf, Traw, T12, uDF, mc};
+            pf.pre = 1;
+            hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(1024), 0, ctx->stream, pf);
+            LF_LAUNCH_CHECK(ctx);
+        } else if (flags & LFPSQP_PROJCG_START_GIVEN) {
             // the caller's previous pass left r0 = -b in rp and U'r0 in Utr (lfpsqp_tangent_step): no residual pass; the first product of the
             // initial projection needs its coefficients over the generator's columns, W Utr
             if (!(DF && fused && !c))
@@ -1104,7 +1116,8 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         } else {
             LF_TRY(launch_residual(1.0, rp, Utr));
         }
-        if (fused) LF_TRY(launch_fused(1));
+        if (flags & LFPSQP_PROJCG_START_PROJECTED) { /* the initial projection is done */ }
+        else if (fused) LF_TRY(launch_fused(1));
         else LF_TRY(launch_k3(1));
     }
 

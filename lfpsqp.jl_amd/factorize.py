@@ -37,7 +37,8 @@ def rmul(In: DeviceMatrix, W: np.ndarray, Out: DeviceMatrix) -> DeviceMatrix:
 
 
 def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix | None, w2: DeviceVector | None = None, eps_rank: float = 1e-10,
-          W: np.ndarray | None = None, Jsp=None, Vt_prev: np.ndarray | None = None, rhs: DeviceVector | None = None):
+          W: np.ndarray | None = None, Jsp=None, Vt_prev: np.ndarray | None = None, rhs: DeviceVector | None = None,
+          G_out: np.ndarray | None = None):
     """Thin factorisation diag(sqrt(w2)) Jct = U S Vt with U = diag(sqrt(w2)) Z.
     Returns (Sigma, Vt, rank); Z is overwritten (Jct is NOT destroyed, unlike dgesvd).  ``Z = None`` (dense Jct, ``W`` required): the
     basis Z = Jct @ W is not formed -- the caller keeps it in factored form (DeviceBasis(None, rank, generator=(Jct, W))).
@@ -46,7 +47,8 @@ def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix | None, w2: DeviceVector | N
     further columns): the basis-forming products stream the nonzeros (lfpsqp_factorize_sp).
     ``Vt_prev`` (optional, the Vt of a previous call on a nearby matrix): warm start of the small eigenproblem (lfpsqp_factorize_hint).
     ``rhs`` (optional device n-vector e; dense Jct only): returns a fourth value Jct' (sqrt(w2) .* e), summed during the Gram pass
-    (lfpsqp_factorize_rhs) -- the outer iteration's Jct'd without a GEMV-T pass of its own."""
+    (lfpsqp_factorize_rhs) -- the outer iteration's Jct'd without a GEMV-T pass of its own; ``G_out`` (m x m, Fortran order) then receives the
+    Gram matrix Jct' diag(w2) Jct the factors were computed from."""
     m = Jct.m if Jct is not None else Jsp.m
     ctx = Jct.ctx if Jct is not None else Jsp.ctx
     if W is not None:
@@ -66,7 +68,7 @@ def ksvd_(Jct: DeviceMatrix | None, Z: DeviceMatrix | None, w2: DeviceVector | N
         Jte = np.zeros(m)
         ctx.check(ctx.L.lfpsqp_factorize_rhs(ctx.h, Jct.h, w2.h if w2 is not None else None, Z.h if Z is not None else None, S.ctypes.data,
                                              Vt.ctypes.data, W.ctypes.data if W is not None else None, C.byref(rank),
-                                             float(eps_rank), rhs.h, Jte.ctypes.data))
+                                             float(eps_rank), rhs.h, Jte.ctypes.data, G_out.ctypes.data if G_out is not None else None))
         return S, Vt, rank.value, Jte
     else:
         ctx.check(ctx.L.lfpsqp_factorize(ctx.h, Jct.h, w2.h if w2 is not None else None, Z.h if Z is not None else None, S.ctypes.data,

@@ -204,6 +204,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     fuse_tangent = (factored and param.do_newton and getattr(c_, "Jsp", None) is None and m > 0 and bool(ctx.options.fused_tangent_step)
                     and not (ineq and (getattr(Jct, "is_view", False) or getattr(getattr(hess_lag_vec_, "cons", None), "kind", None) is not None)))
     ineq_rhs = DeviceVector(ctx, n) if (fuse_tangent and ineq) else None
+    Ggram = np.zeros((m, m), order='F') if fuse_tangent else None         # the factorisation's Gram matrix: U'U = W'GW for the tangent step
     prev_rank = -1                           # rank of the previous outer iteration's factorisation (its Vt warm-starts the next one)
     Sig, Vt = idecomp.Sigma, idecomp.Vt
     Wgen = np.zeros((m, m), order='F') if m > 0 else None                  # ksvd_'s small factor: Z == Jct @ Wgen
@@ -264,12 +265,13 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             else:
                 jac_(Jct, cval, x)
             Jtd = None
+            init_fold = False
             vt_prev = Vt if (i > 0 and prev_rank == m and ctx.options.warm_factorize) else None
             if fuse_tangent and ineq:                                      # ... with bounds: Jct'(sx .* dx + sy .* dy), the m-part of Q'd
                 ctx.check(ctx.L.lfpsqp_ineq_rhs(ctx.h, d.h, idecomp.Dx.h, idecomp.Dy.h, ineq_rhs.h))
-                S_, Vt_, rank, Jtd = ksvd_(Jct, Z, w2=idecomp.sx, eps_rank=param.eps_rank, W=Wgen, Vt_prev=vt_prev, rhs=ineq_rhs)
+                S_, Vt_, rank, Jtd = ksvd_(Jct, Z, w2=idecomp.sx, eps_rank=param.eps_rank, W=Wgen, Vt_prev=vt_prev, rhs=ineq_rhs, G_out=Ggram)
             elif fuse_tangent:                                             # Jct'd rides with the Gram pass (d is final before jac! runs)
-                S_, Vt_, rank, Jtd = ksvd_(Jct, Z, eps_rank=param.eps_rank, W=Wgen, Vt_prev=vt_prev, rhs=d)    # :286-302
+                S_, Vt_, rank, Jtd = ksvd_(Jct, Z, eps_rank=param.eps_rank, W=Wgen, Vt_prev=vt_prev, rhs=d, G_out=Ggram)    # :286-302
             else:
                 S_, Vt_, rank = ksvd_(Jct, Z, w2=idecomp.sx if ineq else None, eps_rank=param.eps_rank, W=Wgen,
                                       Jsp=getattr(c_, "Jsp", None), Vt_prev=vt_prev)                            # :286-302
@@ -304,10 +306,15 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
                 sig_c = np.ascontiguousarray(S_, dtype=np.float64)
                 vt_c = np.asfortranarray(Vt_, dtype=np.float64)
                 idc = ineqdata._c() if ineq else None
-                ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), sig_c.ctypes.data, vt_c.ctypes.data, m, Jtd.ctypes.data, d.h,
+                # (flag 1 = LFPSQP_TANGENT_INIT_PROJCG: the pass is projcg!'s initial projection as well -- src/projcg.jl:58-62 -- with U'r0 from
+                # the Gram matrix; projcg_ then starts with its first iteration, start_projected=True.  Only where the Gram matrix resolves
+                # I - U'U: a full-rank block with cond^2 <= 10, the fast path of the factorisation; otherwise projcg_ measures U'r0 itself)
+                init_fold = bool(rank == m and S_[0] * S_[0] <= 10.0 * S_[m - 1] * S_[m - 1])
+                ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), sig_c.ctypes.data, vt_c.ctypes.data, m, Jtd.ctypes.data, Ggram.ctypes.data, d.h,
                                                     C.byref(cc) if cc is not None else None, x.h, a_diag.h,
                                                     C.byref(idc) if ineq else None, hx.h if ineq else None, idecomp.S.h if ineq else None,
-                                                    lamy_kkt.h if ineq else None, C.byref(wc), th.ctypes.data, lam_kkt.ctypes.data, C.byref(dss)))
+                                                    lamy_kkt.h if ineq else None, C.byref(wc), 1 if init_fold else 0, th.ctypes.data,
+                                                    lam_kkt.ctypes.data, C.byref(dss)))
             elif not ineq:                                                 # :305-308
                 jsp_ = getattr(c_, "Jsp", None)
                 if jsp_ is not None or Z is None:                          # sparse twin / factored basis: U = Jct W applied without Z
@@ -379,7 +386,8 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             prev_grad_norm = grad_norm
             tn_iter, tn_res = projcg_(newton_d, None, newton_map, Qview, d, None, tol=tol, maxit=param.tn_maxiter,
                                       work=projcgwork, n_global=(2 * n_global if ineq else n_global), want_lambda=False,
-                                      start_given=bool(fuse_tangent and rank >= 1))
+                                      start_projected=bool(fuse_tangent and rank >= 1 and init_fold),
+                                      start_given=bool(fuse_tangent and rank >= 1 and not init_fold))
             if dot(newton_d, d) > 0.0:
                 d.copy_from(newton_d)
                 steptype = 1

@@ -21,6 +21,7 @@ from .device import (Context, DeviceMatrix, DeviceVector, axpby, dot, gemv_n, ge
 WANT_LAMBDA = 1
 RESUME = 2
 START_GIVEN = 4
+START_PROJECTED = 8
 
 
 class DiagOperator:
@@ -180,7 +181,8 @@ class ProjCGWork:
             self.g, self.d, self.rp = (StackedVector(ctx, stacked_N) for _ in range(3))
         else:
             self.g, self.d, self.rp = (DeviceVector(ctx, n) for _ in range(3))
-        self.Utr = DeviceVector(ctx, max(m, 1))
+        # (3 m + 8: room behind the m coefficients for the sums lfpsqp_tangent_step parks for LFPSQP_PROJCG_START_PROJECTED)
+        self.Utr = DeviceVector(ctx, 3 * max(m, 1) + 8)
         # extra scratch for a general operator A (lfpsqp_projcg_op's Av) and for the all-Python loop, allocated on demand
         self.Av = None
         self._extra = None
@@ -191,11 +193,13 @@ class ProjCGWork:
 
 def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c: DeviceVector | None,
             tol: float = 1e-6, maxit: int | None = None, work: ProjCGWork | None = None, n_global: int | None = None,
-            want_lambda: bool = True, resume: bool = False, start_given: bool = False):
+            want_lambda: bool = True, resume: bool = False, start_given: bool = False, start_projected: bool = False):
     """``resume=True`` (device path only): ``maxit`` MORE iterations of the solve the previous call left at its iteration
     limit (LFPSQP_PROJCG_RESUME); the returned count runs from the start of the solve.
     ``start_given=True`` (device path, factored plain basis, ``c`` None): ``work.rp`` holds r0 = -b and ``work.Utr`` holds U'r0, left there
-    by lfpsqp_tangent_step -- the solve skips its own residual pass (LFPSQP_PROJCG_START_GIVEN)."""
+    by lfpsqp_tangent_step -- the solve skips its own residual pass (LFPSQP_PROJCG_START_GIVEN).
+    ``start_projected=True``: the initial projection itself was made by lfpsqp_tangent_step (LFPSQP_TANGENT_INIT_PROJCG): ``work.g``, ``work.d``
+    and the sums parked in ``work.Utr`` are the state the first iteration starts from (LFPSQP_PROJCG_START_PROJECTED)."""
     ctx = x.ctx
     n = b.n
     m = U.ncols if hasattr(U, "ncols") else (c.n if c is not None else 0)
@@ -213,12 +217,13 @@ def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c:
         iters = _capi.c_i64()
         nr = C.c_double()
         a_c, u_c, w_c = A._c(), U._c(), work._c()
-        flags = (WANT_LAMBDA if (want_lambda and lam is not None) else 0) | (RESUME if resume else 0) | (START_GIVEN if start_given else 0)
+        flags = ((WANT_LAMBDA if (want_lambda and lam is not None) else 0) | (RESUME if resume else 0) | (START_GIVEN if start_given else 0)
+                 | (START_PROJECTED if start_projected else 0))
         ctx.check(ctx.L.lfpsqp_projcg(ctx.h, x.h, lam.h if lam is not None else None, C.byref(a_c), C.byref(u_c), b.h,
                                       c.h if c is not None else None, float(tol), int(maxit), int(n_global), flags,
                                       C.byref(w_c), C.byref(iters), C.byref(nr)))
         return iters.value, nr.value
-    if isinstance(A, LowRankOperator) and isinstance(U, DeviceBasis) and not stacked and not (resume or start_given) and getattr(A, "fused", True):
+    if isinstance(A, LowRankOperator) and isinstance(U, DeviceBasis) and not stacked and not (resume or start_given or start_projected) and getattr(A, "fused", True):
         iters = _capi.c_i64()
         nr = C.c_double()
         a_c, u_c, w_c = A._c(), U._c(), work._c()
@@ -229,8 +234,8 @@ def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c:
         if rc != -5:                 # LFPSQP_ERR_UNSUPPORTED (a shape without the one-pass iteration): the callback path below
             ctx.check(rc)
             return iters.value, nr.value
-    if resume or start_given:
-        raise ValueError("resume / start_given are features of the device-resident projcg loop")
+    if resume or start_given or start_projected:
+        raise ValueError("resume / start_given / start_projected are features of the device-resident projcg loop")
     if (isinstance(U, DeviceBasis) or stacked) and hasattr(A, "mul_"):
         # general A (the LinearMap case, src/optimize.jl:228-230) on the C loop: lfpsqp_projcg_op calls back once per iteration
         # for A*d; the products stay on the device and nothing in the loop waits for it (no per-dot host round trips)

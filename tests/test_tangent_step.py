@@ -79,15 +79,17 @@ def test_factorize_with_right_hand_side_returns_the_same_factors(dev_ctx, n, m):
     np.testing.assert_allclose(Jtd, Mh.T @ dh, atol=1e-12 * np.sqrt(n))
 
 
-def _tangent_step(ctx, U, S, Vt, m, Jtd, d, cons, x, hd, work):
+def _tangent_step(ctx, U, S, Vt, m, Jtd, d, cons, x, hd, work, G=None):
+    """G given: LFPSQP_TANGENT_INIT_PROJCG (the pass is also projcg!'s initial projection)."""
     Utd, lam = np.zeros(m), np.zeros(m)
     ss = C.c_double()
     bs, wc = U._c(), work._c()
     cc = cons._c() if cons is not None else None
-    ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), S.ctypes.data, Vt.ctypes.data, m, Jtd.ctypes.data, d.h,
+    ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), S.ctypes.data, Vt.ctypes.data, m, Jtd.ctypes.data,
+                                        G.ctypes.data if G is not None else None, d.h,
                                         C.byref(cc) if cc is not None else None, x.h if x is not None else None,
-                                        hd.h if hd is not None else None, None, None, None, None, C.byref(wc), Utd.ctypes.data,
-                                        lam.ctypes.data, C.byref(ss)))
+                                        hd.h if hd is not None else None, None, None, None, None, C.byref(wc), 1 if G is not None else 0,
+                                        Utd.ctypes.data, lam.ctypes.data, C.byref(ss)))
     return Utd, lam, ss.value
 
 
@@ -300,8 +302,8 @@ def test_tangent_step_with_bounds_matches_the_statement_sequence(dev_ctx, n, m):
     Utd, lam = np.zeros(m), np.zeros(m)
     ss = C.c_double()
     bs, wc = Q._c(), work._c()
-    ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), S1.ctypes.data, np.asfortranarray(Vt1).ctypes.data, m, Jtd.ctypes.data, d2.h, None, x.h,
-                                        a1.h, C.byref(idc), hx.h, dec.S.h, lamy1.h, C.byref(wc), Utd.ctypes.data, lam.ctypes.data, C.byref(ss)))
+    ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), S1.ctypes.data, np.asfortranarray(Vt1).ctypes.data, m, Jtd.ctypes.data, None, d2.h, None, x.h,
+                                        a1.h, C.byref(idc), hx.h, dec.S.h, lamy1.h, C.byref(wc), 0, Utd.ctypes.data, lam.ctypes.data, C.byref(ss)))
     scale = np.linalg.norm(dh)
     np.testing.assert_allclose(Utd, tm.download(m), atol=1e-12 * scale)
     np.testing.assert_allclose(lam, lam0, atol=1e-11 * scale / S0[-1])
@@ -311,3 +313,47 @@ def test_tangent_step_with_bounds_matches_the_statement_sequence(dev_ctx, n, m):
     np.testing.assert_allclose(a1.download2(), a0.download2(), rtol=1e-10, atol=1e-10 * scale)
     np.testing.assert_allclose(work.Utr.download()[:m], tm2.download(m), atol=1e-12 * scale)
     np.testing.assert_allclose(ss.value, np.sum(d1.download2() ** 2), rtol=1e-12)
+
+
+@pytest.mark.parametrize("n,m,view", [(1800, 16, False), (2600, 128, False), (2300, 24, True), (1500, 300, False)])
+def test_tangent_step_as_the_initial_projection_of_projcg(dev_ctx, n, m, view):
+    """LFPSQP_TANGENT_INIT_PROJCG + LFPSQP_PROJCG_START_PROJECTED: the tangent-step pass also makes projcg!'s initial projection
+    (src/projcg.jl:58-62), with U'r0 = -(I - U'U) U'd from the Gram matrix of the factorisation.  The solve that follows is the solve from
+    scratch: equal counts, iterates to 1e-11; for a plain matrix and for a view (streamed gradients with the quadratic term)."""
+    ctx = dev_ctx
+    if view:
+        A0 = ctx.matrix(n, m, np.asfortranarray(2.0 ** -3 * synth.hash_matrix(21, n, m)))
+        cons = L.ElementwiseConstraints(ctx, A0, np.zeros(m), kind=(np.arange(n) % 3).astype(np.float64), qw=1e-2 * np.cos(np.arange(m)), stream=True)
+        xv = ctx.vector(n, 0.5 * synth.hash_vector(31, n))
+        cons.jac_(cons.Jct, np.zeros(m), xv)
+        Jct = cons.Jct
+    else:
+        cons, xv = None, None
+        Jct = ctx.matrix(n, m, np.asfortranarray(synth.hash_matrix(3, n, m)))
+    dh = synth.hash_vector(8, n)
+    W = np.zeros((m, m), order='F')
+    G = np.zeros((m, m), order='F')
+    d1, d2 = ctx.vector(n, dh), ctx.vector(n, dh)
+    S, Vt, rank, Jtd = L.ksvd_(Jct, None, W=W, rhs=d1, G_out=G)
+    assert rank == m
+    U = L.DeviceBasis(None, rank, generator=(Jct, W))
+    base = 5.0 + 4.0 * synth.hash_vector(9, n)
+    # (a) the tangent step, then projcg! from the given start (its own initial projection)
+    w1 = L.ProjCGWork(ctx, n, m)
+    h1 = ctx.vector(n, base)
+    _tangent_step(ctx, U, S, Vt, m, Jtd, d1, cons, xv, h1, w1)
+    x1 = ctx.vector(n)
+    i1, nr1 = L.projcg_(x1, None, L.DiagOperator(0.0, h1), U, d1, None, tol=1e-9 * np.linalg.norm(dh), maxit=300, work=w1, want_lambda=False,
+                        start_given=True)
+    # (b) the tangent step that is the initial projection as well
+    w2 = L.ProjCGWork(ctx, n, m)
+    h2 = ctx.vector(n, base)
+    _tangent_step(ctx, U, S, Vt, m, Jtd, d2, cons, xv, h2, w2, G=G)
+    np.testing.assert_array_equal(d2.download(), d1.download())
+    np.testing.assert_array_equal(h2.download(), h1.download())
+    x2 = ctx.vector(n)
+    i2, nr2 = L.projcg_(x2, None, L.DiagOperator(0.0, h2), U, d2, None, tol=1e-9 * np.linalg.norm(dh), maxit=300, work=w2, want_lambda=False,
+                        start_projected=True)
+    assert i2 == i1 and i1 > 3
+    assert nr2 == pytest.approx(nr1, rel=1e-6)
+    np.testing.assert_allclose(x2.download(), x1.download(), atol=1e-11 * np.linalg.norm(x1.download()))
