@@ -612,6 +612,8 @@ def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds, mcols)
     iterations and one that fails (maxiter).  Two trials: the VALU form of the one-pass kernel; 3 ... 16: the step on the matrix
     cores (nrbatch.h: both products of src/retractions.jl:141 / :146 as v_mfma_f64_16x16x4_f64 contractions over the stacked trials)."""
     ctx = dev_ctx
+    if _is_emu(ctx) and mcols in (384, 527, 600) and nb != 8:
+        pytest.skip("a wide-form shape the emulator covers through its neighbours (300 / 512 / 140 columns); runs on the GPU")
     n, m = (1500, 7) if _is_emu(ctx) else (200_000, 31)
     if mcols:
         n, m = (1100 if _is_emu(ctx) else 150_000), mcols
