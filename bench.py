@@ -735,7 +735,8 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
     except Exception as e:      # diagnostics only
         sparse = {"error": repr(e)}
     rates = stream_rates(ctx, L, nbig=int(max(1 << 20, min(400_000_000, 40 * n_loc))))
-    return {"stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "factorize_factored_basis_ms": fact_factored_ms, "factorize_factored_basis_warm_ms": fact_warm_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs_of_the_full_product": flop / gram_ms / 1e9,
+    outer = outer_iteration(ctx, L, n_loc, m) if n_loc == n else None
+    return {"outer_iteration": outer, "stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "factorize_factored_basis_ms": fact_factored_ms, "factorize_factored_basis_warm_ms": fact_warm_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs_of_the_full_product": flop / gram_ms / 1e9,
             "gram_TFLOPs_executed": flop * gram_tile_share(m) / gram_ms / 1e9,
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
@@ -747,6 +748,52 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             "matrix_view": view_info, "projcg_factored_xnorm_rel_diff": abs(pf["factored_xnorm"] - pf["materialised_xnorm"]) / pf["materialised_xnorm"], "nr_iters_timed": its_long, "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit), "pcg_iter_kernel_chain": pcg_chain,
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies; the Gram kernel computes the upper "
                     "triangle only (16 x 16 tiles on and above the diagonal): gram_TFLOPs_executed counts that work, ..._of_the_full_product 2 n m^2"}
+
+
+def outer_iteration(ctx, L, n, m, iters=6):
+    """Milliseconds per STEADY outer iteration of `optimize` (src/optimize.jl:257-443) at the bench's shape, on the device-resident nonlinear class
+    with streamed gradients (c(x) = A'phi(x) - b, mixed kinds; f = |x - target|^2; Newton retraction): a callback after every iteration takes a
+    timestamp with the device idle, tolerances off so that `iters` iterations run; the first interval (allocations, uploads) is reported apart.
+    With the one-pass tangent step (lfpsqp_tangent_step, the default) and with the statement-by-statement sequence of the reference."""
+    import numpy as np
+    try:
+        A = ctx.matrix(n, m).hash_fill(21, 0, n, 2.0 ** -11)
+        cons = L.ElementwiseConstraints(ctx, A, np.zeros(m), kind=(np.arange(n) % 3).astype(np.float64), stream=True)
+        x = ctx.vector(n).hash_fill(31, 0, 0.5, 0.0)
+        cv = np.zeros(m)
+        cons.jac_(cons.Jct, cv, x)
+        cons.b = cons.b + cv                       # x feasible; the optimum of |x - target|^2 on the manifold lies nearby
+        target = ctx.vector(n).hash_fill(41, 0, 0.5, 0.0)
+        L.axpby(0.98, x, 0.02, target)
+        prob = L.SeparableElementwiseBox(ctx, cons, 0, 1.0, target.download())
+        x0h = x.download()
+        out = {}
+        for tag, fused in (("one_pass_tangent_step", True), ("statement_by_statement", False)):
+            ctx.options.fused_tangent_step = fused
+            best = None
+            for rep in range(2):
+                stamps = []
+
+                def cb(i, xx):
+                    ctx.sync()
+                    stamps.append(time.perf_counter())
+                ctx.sync(); t0 = time.perf_counter()
+                xs_, obj, lamk, ti = prob.optimize(x0h, L.LFPSQPParams(do_project_retract=False, maxiter=iters, disp=L.DisplayOption.off, eps_kkt=0.0,
+                                                                        eps_f=-1.0, eps_x=-1.0, callback=cb, callback_period=1))
+                d = np.diff(np.array([t0] + stamps)) * 1e3
+                if best is None or np.median(d[1:]) < np.median(best[1:]):
+                    best = d
+            out[tag] = {"ms_per_outer_iteration": float(np.median(best[1:])), "ms_first_iteration_with_setup": float(best[0]), "objective": float(obj[-1])}
+        ctx.options.fused_tangent_step = True
+        out["note"] = (f"steady outer iteration of optimize on the nonlinear class with streamed gradients at n = {n}, m = {m} (median of {iters - 1}): Gram pass + "
+                       "tangent step (projection of d, lambda_kkt, Hessian term, projcg!'s initial projection: one pass) + truncated-Newton iterations + the "
+                       "line search's Newton steps; statement_by_statement = src/optimize.jl:305-343 and src/projcg.jl:55-62 as five passes")
+        for v_ in (x, target):
+            v_.free()
+        A.free()
+        return out
+    except Exception as e:                                      # (a side measurement must never take the bench line down)
+        return {"error": repr(e)[:300]}
 
 
 def gram_tile_share(m):
