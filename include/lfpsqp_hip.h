@@ -456,6 +456,25 @@ int lfpsqp_projcg_lowrank(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, co
                           const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit, int64_t n_global, int flags,
                           const lfpsqp_projcg_work* work, int64_t* iters, double* nr);
 
+/* ... and for a TRIDIAGONAL Hessian (a chain / finite-difference / smoothing term: src/autodiff_generators.jl:72-107 builds hess_lag_vec!
+ * for such objectives, the reference wraps it in a LinearMap, src/optimize.jl:228-230):
+ *     (A v)_i = (a0 + dg_i) v_i + off_{i-1} v_{i-1} + off_i v_{i+1}      (off: length n, off_i couples rows i and i+1, off_{n-1} is ignored)
+ * still ONE pass over U per iteration where lfpsqp_projcg_op pays two.  The projected residual's neighbours do not exist while a pass runs, but
+ * gp = rr - U t with t known before the pass and rr = g + alpha A d made of stored vectors: the second product carries A rr (row-local) and the
+ * post-op subtracts (U'A U) t; U'A U (m x m) is formed once per solve by two or three weighted Gram passes over U on the matrix cores.  Av: a scratch vector of length(b) (it receives A d of every iteration).  Plain dense basis (materialised or
+ * factored, no matrix view), 4 .. 1024 columns, no bounds, one rank, no RESUME / START_GIVEN / START_PROJECTED -- otherwise
+ * LFPSQP_ERR_UNSUPPORTED (use lfpsqp_projcg_op).  Iterates, counts and exits as projcg! with A as a matrix (src/projcg.jl:40-121), to rounding.
+ * lfpsqp_tridiag_mul: out = A v (out != v), the operator on its own (mul! of the LinearMap). */
+typedef struct lfpsqp_tridiag_op {
+    double a0;
+    const lfpsqp_vec* dg;  /* optional, length n */
+    const lfpsqp_vec* off; /* length n */
+} lfpsqp_tridiag_op;
+int lfpsqp_projcg_tridiag(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_tridiag_op* A, lfpsqp_vec* Av, const lfpsqp_basis* U,
+                          const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit, int64_t n_global, int flags,
+                          const lfpsqp_projcg_work* work, int64_t* iters, double* nr);
+int lfpsqp_tridiag_mul(lfpsqp_ctx* ctx, const lfpsqp_tridiag_op* A, const lfpsqp_vec* v, lfpsqp_vec* out);
+
 /* The same solver for a GENERAL symmetric operator A -- the reference's LinearMap closure around hess_lag_vec! /
  * augmented_hess_lag_vec! (src/optimize.jl:228-230, applied at src/projcg.jl:57,74,116): `A(user, src, dest)` must produce
  * dest = A * src for device vectors of length(b) (stacked [x | gap | y] when U is a stacked basis), return 0, and leave

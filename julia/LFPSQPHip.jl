@@ -44,6 +44,11 @@ struct CLowRankOp              # lfpsqp_lowrank_op
     k::Int64
     sigma::Ptr{Float64}
 end
+struct CTridiagOp              # lfpsqp_tridiag_op
+    a0::Float64
+    dg::Ptr{Cvoid}
+    off::Ptr{Cvoid}
+end
 struct CBasis                  # lfpsqp_basis
     Z::Ptr{Cvoid}
     ncols::Int64
@@ -227,6 +232,10 @@ c_projcg(ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = c
 c_projcg_lowrank(ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg_lowrank, lib), Cint,
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CLowRankOp}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
     ctx, x, lam, A, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
+c_projcg_tridiag(ctx, x, lam, A, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg_tridiag, lib), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CTridiagOp}, Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
+    ctx, x, lam, A, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
+c_tridiag_mul(ctx, A, v, out) = ccall((:lfpsqp_tridiag_mul, lib), Cint, (Ptr{Cvoid}, Ref{CTridiagOp}, Ptr{Cvoid}, Ptr{Cvoid}), ctx, A, v, out)
 c_projcg_op(ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr) = ccall((:lfpsqp_projcg_op, lib), Cint,
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CBasis}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64, Cint, Ref{CWork}, Ref{Int64}, Ref{Float64}),
     ctx, x, lam, A, user, Av, U, b, c, tol, maxit, nglob, flags, work, iters, nr)
@@ -566,6 +575,19 @@ struct LowRankOperator
 end
 LowRankOperator(a0::Real, dg, V::DeviceMatrix; k::Int=V.m, σ::Vector{Float64}=ones(k)) = LowRankOperator(Float64(a0), dg, V, k, σ)
 
+# (A v)_i = (a0 + dg_i) v_i + off_{i-1} v_{i-1} + off_i v_{i+1}: a diagonal Hessian with nearest-neighbour couplings (off: length n, its last entry
+# is ignored).  projcg! keeps ONE pass over the basis per iteration with it (lfpsqp_projcg_tridiag); mul! is the LinearMap's action.
+struct TridiagonalOperator
+    a0::Float64
+    dg::Union{Nothing,DeviceVector}
+    off::DeviceVector
+end
+ctridiag(A::TridiagonalOperator) = CTridiagOp(A.a0, A.dg === nothing ? C_NULL : A.dg.h, A.off.h)
+function LinearAlgebra.mul!(dest::DeviceVector, A::TridiagonalOperator, v::DeviceVector)
+    GC.@preserve A check(dest.ctx, c_tridiag_mul(dest.ctx.h, Ref(ctridiag(A)), v.h, dest.h))
+    return dest
+end
+
 # InequalityData(xl, xu) (src/inequality_helper.jl:39-89), device-resident q, r, s, t
 struct InequalityData
     q::DeviceVector
@@ -688,6 +710,21 @@ function projcg!(x::DeviceVector, λ::Union{Nothing,DeviceVector}, A::LowRankOpe
                                       b.h, c === nothing ? C_NULL : c.h, tol, Int64(maxit), Int64(n_global), λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA,
                                       Ref(cwork(work)), iters, nr))
     end
+    return Int(iters[]), nr[]
+end
+# Tridiagonal Hessian: the one-pass iteration where its shape exists (plain dense basis, 4 .. 1024 columns, one rank); otherwise the callback
+# loop below with mul! as the operator -- the same iterates, two passes per iteration.
+function projcg!(x::DeviceVector, λ::Union{Nothing,DeviceVector}, A::TridiagonalOperator, U::AnyBasis, b::DeviceVector, c::Union{Nothing,DeviceVector};
+                 tol::Float64=1e-6, maxit::Int=length(b) + ncols(U), work::ProjCGWork=ProjCGWork(x, ncols(U)), n_global::Int=length(b),
+                 Av::DeviceVector=DeviceVector(x.ctx, length(b)))
+    iters = Ref{Int64}(0); nr = Ref{Float64}(0.0)
+    rc = GC.@preserve U A c_projcg_tridiag(x.ctx.h, x.h, λ === nothing ? C_NULL : λ.h, Ref(ctridiag(A)), Av.h, Ref(cbasis(U)),
+                                           b.h, c === nothing ? C_NULL : c.h, tol, Int64(maxit), Int64(n_global),
+                                           λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA, Ref(cwork(work)), iters, nr)
+    if rc == LFPSQP_ERR_UNSUPPORTED
+        return projcg!(x, λ, (dest, src) -> mul!(dest, A, src), U, b, c; tol=tol, maxit=maxit, work=work, n_global=n_global)
+    end
+    check(x.ctx, rc)
     return Int(iters[]), nr[]
 end
 # ... and for a GENERAL operator A(dest, src) on device vectors (the LinearMap closure of src/optimize.jl:228-230): the same

@@ -6,7 +6,7 @@ Host-side mirror of the reference's operator interface over the C ABI of
 from ._capi import LfpsqpError, load_library, header_functions  # noqa: F401
 from .device import (Context, DeviceMatrix, DeviceVector, SparseMatrix, amax, axpby, dot, gemv_n, gemv_t, nrm2, spmv_n,  # noqa: F401
                      spmv_t, vmul, waxpby)
-from .projcg import DeviceBasis, DiagOperator, LowRankOperator, ProjCGWork, projcg_  # noqa: F401
+from .projcg import DeviceBasis, DiagOperator, LowRankOperator, ProjCGWork, TridiagonalOperator, projcg_  # noqa: F401
 from .factorize import gram, gram_rhs, ksvd_, orthonormalize_, rmul, small_svd_  # noqa: F401
 from .inequality import (InequalityData, InequalityDecomp, InequalityDecompOp, InequalityDecompProject, StackedVector,  # noqa: F401
                          augmented_hess_diag_, calculate_h_, calculate_lambda_kkt_, generate_initial_y_, half_stride,

@@ -25,6 +25,10 @@ class LowRankOp(C.Structure):  # lfpsqp_lowrank_op
     _fields_ = [("a0", c_dbl), ("dg", P), ("V", P), ("k", c_i64), ("sigma", P)]
 
 
+class TridiagOp(C.Structure):  # lfpsqp_tridiag_op
+    _fields_ = [("a0", c_dbl), ("dg", P), ("off", P)]
+
+
 class Basis(C.Structure):  # lfpsqp_basis
     _fields_ = [("Z", P), ("ncols", c_i64), ("Dx", P), ("Dy", P), ("sx", P), ("sy", P), ("A", P), ("W", P), ("S", P), ("SA", P)]
 
@@ -165,6 +169,9 @@ _SIGS = {
                       C.POINTER(ProjCGWorkC), C.POINTER(c_i64), PD],
     "lfpsqp_projcg_lowrank": [P, P, P, C.POINTER(LowRankOp), C.POINTER(Basis), P, P, c_dbl, c_i64, c_i64, C.c_int,
                               C.POINTER(ProjCGWorkC), C.POINTER(c_i64), PD],
+    "lfpsqp_projcg_tridiag": [P, P, P, C.POINTER(TridiagOp), P, C.POINTER(Basis), P, P, c_dbl, c_i64, c_i64, C.c_int,
+                              C.POINTER(ProjCGWorkC), C.POINTER(c_i64), PD],
+    "lfpsqp_tridiag_mul": [P, C.POINTER(TridiagOp), P, P],
     "lfpsqp_projcg_op": [P, P, P, P, P, P, C.POINTER(Basis), P, P, c_dbl, c_i64, c_i64, C.c_int,
                          C.POINTER(ProjCGWorkC), C.POINTER(c_i64), PD],
     "lfpsqp_ctx_stream": [P, C.POINTER(P)],

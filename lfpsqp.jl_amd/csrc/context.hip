@@ -348,6 +348,7 @@ int lfpsqp_ctx_destroy(lfpsqp_ctx* ctx) {
     if (ctx->d_qw) (void)hipFree(ctx->d_qw);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->d_nvec) (void)hipFree(ctx->d_nvec);
+    if (ctx->d_tri) (void)hipFree(ctx->d_tri);
     if (ctx->d_view) (void)hipFree(ctx->d_view);
     if (ctx->h_m) (void)hipHostFree(ctx->h_m);
     if (ctx->scal) (void)hipFree(ctx->scal);

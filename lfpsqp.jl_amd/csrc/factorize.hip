@@ -44,11 +44,15 @@ constexpr int kTLd = 17;
 // is an operand of npan - 1 off-diagonal pairs), so they are placed on the SAME XCD, next to each other in dispatch order
 // (linear workgroup id L -> XCD L % 8): the panels then come from HBM once and from that XCD's L2 for the other pairs.  With
 // the pair as the slow grid dimension (one pair after the other) the m = 512 Gram read 61 GB for a 20 GB matrix.
-template <bool DIAG, bool WEIGHTED>
+// SHIFT (weighted launches only): the operand is not M but R with rows R_i = M_i + sgn_i M_{i+1} (sgn_i = +-1; M_n = 0), formed in registers
+// on the way to LDS -- one more scalar load per column and step (the row below a lane's pair; same cache line but for one lane in eight).
+// This is the Gram matrix behind the reduced operator of a tridiagonal Hessian (lfpsqp_projcg_tridiag: U'A U = R'|off| R + U' diag(c) U).
+template <bool DIAG, bool WEIGHTED, bool SHIFT = false>
 __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restrict__ M, int64_t ld, int64_t n, int ncols, int npan,
                                                          int ngroups, const double* __restrict__ w2, double* __restrict__ part,
                                                          int64_t part_ld, const double* __restrict__ ex0, const double* __restrict__ ex1,
-                                                         int64_t xoff) {
+                                                         int64_t xoff, const double* __restrict__ sgn) {
+    static_assert(!SHIFT || WEIGHTED, "the shifted operand exists for weighted launches only");
     // EXTRA RIGHT-HAND COLUMNS (DIAG launches only; ex0 / ex1, each may be null): besides the Gram block the workgroup sums
     //     X_k[col] = sum_rows (sqrt(w) .* M)[row, col] * ex_k[row]            (the operand as it is staged: weights applied)
     // for the 128 columns of its panel -- with the values a lane holds in registers on their way to LDS (8 multiply-adds per step and lane on
@@ -83,6 +87,8 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
     // software pipeline: the global loads of step s+DEPTH are issued before the MFMAs of step s.  Row weights are applied when a
     // buffer is staged, so that no arithmetic waits on the loads in flight.
     double2 va[DEPTH][4], vb[needB ? DEPTH : 1][4], vw[WEIGHTED ? DEPTH : 1];
+    double za[SHIFT ? DEPTH : 1][SHIFT ? 4 : 1], zb[(SHIFT && needB) ? DEPTH : 1][(SHIFT && needB) ? 4 : 1];     // SHIFT: row kh + 2 of the columns
+    double2 vs[SHIFT ? DEPTH : 1];
     double2 ve[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};      // the extra columns' entries of the rows kh, kh + 1 of the step in flight
     double xa[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};         // ... and this lane's running sums for its four panel columns
     const double* pa = M + ((int64_t)pi * kPanel + c) * ld + kh;
@@ -117,11 +123,25 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
             if (ex0) ve[0] = ld2(ex0 + r + kh);      // are finite padding and meet the matrix's zero rows)
             if (ex1) ve[1] = ld2(ex1 + r + kh);
         }
+        if constexpr (SHIFT) {
+            vs[buf] = ld2(sgn + r + kh);
+            const bool below = r + kh + 2 < n;       // (the row below the last one is zero by definition -- and may lie outside the allocation)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                za[buf][q] = 0.0;
+                if (below && (FULL || 32 * q < na)) za[buf][q] = pa[r + q * cs + 2];
+                if constexpr (needB) {
+                    zb[buf][q] = 0.0;
+                    if (below && (FULL || 32 * q < nb)) zb[buf][q] = pb[r + q * cs + 2];
+                }
+            }
+        }
     };
     auto write_lds = [&](int p, int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double2 a = va[buf][q];
+            if constexpr (SHIFT) a = make_double2(fma(vs[buf].x, a.y, a.x), fma(vs[buf].y, za[buf][q], a.y));
             if constexpr (WEIGHTED) { a.x *= vw[buf].x; a.y *= vw[buf].y; }
             As[p][c + 32 * q][kh] = a.x;
             As[p][c + 32 * q][kh + 1] = a.y;
@@ -131,6 +151,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
             }
             if constexpr (needB) {
                 double2 b = vb[buf][q];
+                if constexpr (SHIFT) b = make_double2(fma(vs[buf].x, b.y, b.x), fma(vs[buf].y, zb[buf][q], b.y));
                 if constexpr (WEIGHTED) { b.x *= vw[buf].x; b.y *= vw[buf].y; }
                 Bs[p][c + 32 * q][kh] = b.x;
                 Bs[p][c + 32 * q][kh + 1] = b.y;
@@ -586,7 +607,10 @@ struct SqrtWTimesV {
     }
 };
 
-static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const double* w2, std::vector<double>& G, const GramRhs* rhs = nullptr) {
+static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const double* w2, std::vector<double>& G, const GramRhs* rhs = nullptr,
+                     const double* shift_sgn = nullptr) {
+    // shift_sgn != NULL: the Gram matrix of R, R_i = M_i + shift_sgn_i M_{i+1} (gram_kernel SHIFT) -- plain matrix, weights given, no extra columns
+    if (shift_sgn && (M->view || !w2 || rhs)) return set_err(ctx, LFPSQP_ERR_ARG, "shifted Gram matrix: plain matrix with weights, no right-hand columns");
     G.assign((size_t)ncols_all * ncols_all, 0.0);
     const int nxu = rhs ? rhs->nx : 0;
     if (rhs && rhs->X) rhs->X->assign((size_t)ncols_all * nxu, 0.0);
@@ -650,7 +674,7 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
     // A few columns beyond a multiple of the 128-column panel (m + 1 constraints with a slack/ball column, say) would cost
     // a whole extra panel row and column of MFMA tiles; they are cheaper as GEMV-T passes: G[:, j] = M' (w2 .* M[:, j]).
     const int rem = ncols_all % kPanel;
-    const int border = (ncols_all > kPanel && rem > 0 && rem <= 4) ? rem : 0;
+    const int border = (!shift_sgn && ncols_all > kPanel && rem > 0 && rem <= 4) ? rem : 0;        // (the GEMV-T passes of the border know M only)
     const int ncols = ncols_all - border;
     const int npan = (ncols + kPanel - 1) / kPanel;
     const int npair = npan * (npan + 1) / 2;
@@ -707,13 +731,19 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
         double* sw = ctx->d_nvec + npad;
         LF_TRY((run_vec<SqrtWeightF, 0, NoPost>(ctx, M->n, SqrtWeightF{w2, sw}, 0u, nullptr, NoPost())));
         LF_TRY(ensure_part(ctx, (size_t)std::max(gd, go) * pld));         // (run_vec may not shrink it, but keep the reservation next to its use)
-        hipLaunchKernelGGL((gram_kernel<true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pld, ex0, ex1, pp);
-        if (noff > 0)
-            hipLaunchKernelGGL((gram_kernel<false, true>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, sw, ctx->part, pld, nullptr, nullptr, pp);
+        if (shift_sgn) {
+            hipLaunchKernelGGL((gram_kernel<true, true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pld, ex0, ex1, pp, shift_sgn);
+            if (noff > 0)
+                hipLaunchKernelGGL((gram_kernel<false, true, true>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, sw, ctx->part, pld, nullptr, nullptr, pp, shift_sgn);
+        } else {
+            hipLaunchKernelGGL((gram_kernel<true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pld, ex0, ex1, pp, nullptr);
+            if (noff > 0)
+                hipLaunchKernelGGL((gram_kernel<false, true>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, sw, ctx->part, pld, nullptr, nullptr, pp, nullptr);
+        }
     } else {
-        hipLaunchKernelGGL((gram_kernel<true, false>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pld, ex0, ex1, pp);
+        hipLaunchKernelGGL((gram_kernel<true, false>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pld, ex0, ex1, pp, nullptr);
         if (noff > 0)
-            hipLaunchKernelGGL((gram_kernel<false, false>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, w2, ctx->part, pld, nullptr, nullptr, pp);
+            hipLaunchKernelGGL((gram_kernel<false, false>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, w2, ctx->part, pld, nullptr, nullptr, pp, nullptr);
     }
     LF_LAUNCH_CHECK(ctx);
     // reduce the partials of each launch over its row groups (32 columns per workgroup)
@@ -1228,6 +1258,12 @@ static int check_weights(lfpsqp_ctx* ctx, bool weighted, const std::vector<doubl
     for (double g : G)
         if (g != g) return lfpsqp::set_err(ctx, LFPSQP_ERR_ARG, "lfpsqp_gram: non-finite weighted Gram matrix -- the weights w2 must be >= 0 (the kernel applies sqrt(w2) to both operands)");
     return 0;
+}
+
+// G (ncols x ncols, column-major) = R' diag(w) R for R_i = M_i + sgn_i M_{i+1} (w >= 0 and sgn = +-1: device n-vectors; projcg.hip)
+int lfpsqp::gram_shifted(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, const double* w, const double* sgn, std::vector<double>& G) {
+    LF_TRY(gram_impl(ctx, M, ncols, w, G, nullptr, sgn));
+    return check_weights(ctx, true, G);
 }
 
 extern "C" {

@@ -89,6 +89,8 @@ struct lfpsqp_ctx {
     double* d_view = nullptr;        // matrix views: [tau (8) | the raw sums of a second product before the rank-one term is folded in]
     double* d_nvec = nullptr;        // an n-vector of scratch (combined weights of the Gram matrix of a row-scaled view)
     size_t nvec_cap = 0;
+    double* d_tri = nullptr;         // lfpsqp_projcg_tridiag: the four n-vectors of its set-up (|off|, sign(off), the two parts of the diagonal weights)
+    size_t tri_cap = 0;
     double* d_zeros = nullptr;       // kOnepassMaxCols zeros (the first-product coefficients of a one-pass launch that only evaluates)
     double* d_qw = nullptr;
     size_t qw_cap = 0;
@@ -536,6 +538,9 @@ int run_vec(lfpsqp_ctx* ctx, int64_t n, F f, unsigned ismax, double* red_out, PO
     }
     return 0;
 }
+
+// G = R' diag(w) R for R_i = M_i + sgn_i M_{i+1} on the matrix cores (factorize.hip, gram_kernel SHIFT); plain M, w >= 0, sgn = +-1 (device)
+int gram_shifted(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols, const double* w, const double* sgn, std::vector<double>& G);
 
 // one-sided Jacobi on the columns of a small host matrix, run on the device (jacobi.hip); false = shape not covered
 bool device_jacobi(lfpsqp_ctx* ctx, int rows_dot, int rows_all, int cols, std::vector<double>& X, int* sweeps_out = nullptr);

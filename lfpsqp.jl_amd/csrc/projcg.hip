@@ -39,6 +39,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "internal.h"
 #include "sparse.h"
 
@@ -81,6 +84,34 @@ struct AOpLR {  // A = a0*I + diag(dg) + V diag(sigma) V': (A v)_i = (a0 + dg_i)
             o.y = fma(v.y, c, o.y);
         }
         return o;
+    }
+};
+
+// A = a0*I + diag(dg) + tridiagonal couplings: (A v)_i = (a0 + dg_i) v_i + off_{i-1} v_{i-1} + off_i v_{i+1}  (off_i couples rows i and i+1; off_{n-1}
+// is ignored).  lfpsqp_projcg_tridiag / lfpsqp_tridiag_mul.
+struct TriD {
+    double a0;
+    const double* dg;
+    const double* off;
+    int64_t n;
+};
+struct TriMulF {   // out = A v (a plain vector kernel: the neighbours come out of the cache lines the row itself brings in)
+    TriD A;
+    const double* v;
+    double* out;
+    const int64_t* istat;     // nullptr: always; else only while the solve is running
+    __device__ __forceinline__ bool skip() const { return istat != nullptr && ld_stat(istat + I_STATUS) != ST_RUNNING; }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        if (!v0) return;
+        const double2 vv = ld2(v + i), of = ld2(A.off + i);
+        const double2 dd = A.dg ? ld2(A.dg + i) : make_double2(0.0, 0.0);
+        const double vm = (i > 0) ? v[i - 1] : 0.0, om = (i > 0) ? A.off[i - 1] : 0.0;
+        double o0 = fma(om, vm, (A.a0 + dd.x) * vv.x);
+        if (v1) o0 = fma(of.x, vv.y, o0);
+        if (!v1) { out[i] = o0; return; }
+        double o1 = fma(of.x, vv.x, (A.a0 + dd.y) * vv.y);
+        if (i + 2 < A.n) o1 = fma(of.y, v[i + 2], o1);
+        st2(out + i, make_double2(o0, o1));
     }
 };
 
@@ -446,6 +477,83 @@ struct PcgFuseLR {
     }
 };
 
+// ---- F for A = a0 I + diag(dg) + tridiagonal couplings: the same single pass ---------------------------------------------------------------
+// (A gp)_i needs gp_{i+-1}, which other lanes, waves and workgroups are still computing -- but gp = rr - U t with t (= Utr) known BEFORE the
+// pass and rr = g + alpha A d made of STORED vectors, whose neighbours are two cached loads away:
+//   U'(A gp)  = U'(A rr) - (U'A U) t          -- the second product carries (A rr)_i (row-local: rr_{i-1}, rr_i, rr_{i+1} from g and A d), the
+//                                                m x m matrix M = U'A U is formed once per solve (tri_reduced_operator below);
+//   gp'A gp   = rr'A rr - 2 t'(U'A rr) + t'M t  (post-op; the three terms are of the size of |A| |rr|^2, and rr differs from gp by what ONE
+//                                                step alpha A d left in the range of U: no cancellation beyond a digit or two);
+//   gp'A d, d'A d: row-local with A d stored (TriMulF, a vector kernel per iteration: 0.4 GB next to the 10.4 GB of the pass).
+// The row record grows from three to ten doubles, the matrix stream is untouched.
+template <bool INIT>
+struct PcgFuseTri {
+    const double* rp;
+    const double* g;
+    double* gout;
+    double* d;
+    const double* ad;     // A d of the current direction
+    TriD A;
+    const double* scal;
+    const int64_t* istat;
+    uint32_t n8;          // n * 8: byte offset behind the last row
+    static constexpr bool kSplitRed = true;
+    static constexpr bool kNoRowScale = true;
+    struct Uni { double alpha; };
+    struct Row { double gm, g0, gq, am, a0, aq, dx, ax, om, o0; };
+    static __device__ __forceinline__ double at(const double* base, uint32_t o) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
+    }
+    static __device__ __forceinline__ void put(double* base, uint32_t o, double v) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + o) = v;
+    }
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
+    __device__ __forceinline__ Uni uniform() const { return Uni{INIT ? 0.0 : uniform_f64(ld_scal(scal + S_ALPHA))}; }
+    __device__ __forceinline__ Row fetch(uint32_t o) const {
+        // (unconditional loads at clamped offsets: row 0 re-reads itself for its missing upper neighbour, the last row for its lower one --
+        // finite values that meet a zero coupling; a branch around a load would keep the whole record in scratch memory, FINDINGS 11.4)
+        const bool has_m = o >= 8u, has_q = o + 8u < n8;
+        const uint32_t om_ = has_m ? o - 8u : o, oq_ = has_q ? o + 8u : o;
+        const double* gs = INIT ? rp : g;
+        Row w;
+        w.gm = at(gs, om_); w.g0 = at(gs, o); w.gq = at(gs, oq_);
+        if (INIT) { w.am = w.a0 = w.aq = w.dx = 0.0; }
+        else { w.am = at(ad, om_); w.a0 = at(ad, o); w.aq = at(ad, oq_); w.dx = at(d, o); }
+        w.ax = A.a0 + (A.dg ? at(A.dg, o) : 0.0);
+        const double e0 = at(A.off, om_), e1 = at(A.off, o);
+        w.om = has_m ? e0 : 0.0;
+        w.o0 = has_q ? e1 : 0.0;
+        return w;
+    }
+    static constexpr int kStageStreams = INIT ? 0 : 1;
+    __device__ __forceinline__ double* stage_out(int) const { return gout; }
+    __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
+                                          const Row& w, double (&v)[2], double (&red)[2]) const {
+        apply_staged(row, o, accv, valid, owner, lead, u, w, v, red, nullptr, 0);
+    }
+    // reductions, logical order: rp'gp, gp'gp, rr'A rr, gp'A d | d'A d  (kSplitRed, as PcgFuseE)
+    __device__ __forceinline__ void apply_staged(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
+                                                 const Row& w, double (&v)[2], double (&red)[2], double* slot, int) const {
+        const int h = (int)((threadIdx.x >> 2) & 3u);
+        const double r0 = INIT ? w.g0 : fma(u.alpha, w.a0, w.g0);               // :93, rows i-1, i, i+1
+        const double rm = INIT ? w.gm : fma(u.alpha, w.am, w.gm);
+        const double rq = INIT ? w.gq : fma(u.alpha, w.aq, w.gq);
+        const double gp = r0 - accv[0];                                          // :97
+        const double ar = fma(w.o0, rq, fma(w.om, rm, w.ax * r0));               // (A rr)_i
+        if (valid && owner) {
+            if (slot) *slot = gp;
+            else put(gout, o, gp);
+            if (INIT) put(d, o, -gp);                                            // :62
+        }
+        if (valid && lead) {
+            red[0] += (h == 2) ? r0 * ar : gp * ((h == 0) ? r0 : ((h == 1) ? gp : w.a0));
+            if (h == 0) red[1] += w.dx * w.a0;                                   // d'Ad
+        }
+        v[0] = valid ? gp : 0.0;
+        v[1] = valid ? ar : 0.0;
+    }
+};
+
 // The one post-op of the fused iteration, after the (all-reduced) sums T = [t1 (m); t2 (m); rp'gp; gp'gp; g'Ag; g'Ad; d'Ad]
 // of kernel F are final.  End of iteration it (:98-111): beta, rg, nr, convergence / iteration limit.  Start of iteration
 // it+1 (:72-91): d+'A d+ from the three direct sums, negative-curvature / rg exits, alpha.  Then (all threads)
@@ -473,6 +581,8 @@ struct PcgPostF {
     const double* sigma = nullptr;   // k (device)
     double* vdraw = nullptr;      // kLRMax (device): V'd
     double* vdc = nullptr;        // kLRMax (device): sigma .* (V'd), what the kernel multiplies the rows of V with
+    // tridiagonal operator (PcgFuseTri): M = U'A U (m x m, column-major, device); the pass left U'(A rr) in t2's place and rr'A rr in g'A g's
+    const double* triM = nullptr;
     __device__ __forceinline__ int nsums() const { return k > 0 ? 5 + kLRMax : 5; }
 };
 // init = 2: RESUME after an iteration-limit exit (LFPSQP_PROJCG_RESUME): the end-of-iteration part already ran in the previous
@@ -531,10 +641,29 @@ __global__ __launch_bounds__(1024) void pcg_post_kernel(PcgPostF u) {
         __threadfence();
         __syncthreads();
     }
+    __shared__ double s_mu[kOnepassMaxCols];
+    if (u.triM) {
+        // y = M t with t = Utr AS THE PASS USED IT (it is overwritten at the end of this kernel); M is symmetric: row j read down column j
+        for (int j = threadIdx.x; j < u.m; j += blockDim.x) {
+            double a = 0.0;
+            for (int l = 0; l < u.m; ++l) a = fma(u.triM[(size_t)l * u.m + j], ld_scal(u.Utr + l), a);
+            s_mu[j] = a;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         const double* S = u.T + 2 * u.m;
         const double rpgp = ld_scal(S), gpgp = ld_scal(S + 1), gAd = ld_scal(S + 3), dAd = ld_scal(S + 4);
         double gAg = ld_scal(S + 2);
+        if (u.triM) {                                                   // gp'A gp = rr'A rr - 2 t'(U'A rr) + t'M t
+            double c1 = 0.0, c2 = 0.0;
+            for (int j = 0; j < u.m; ++j) {
+                const double ut = ld_scal(u.Utr + j);
+                c1 = fma(ld_scal(u.T + u.m + j), ut, c1);
+                c2 = fma(s_mu[j], ut, c2);
+            }
+            gAg = (gAg - 2.0 * c1) + c2;
+        }
         for (int j = 0; j < u.k; ++j) {                                 // + sum_j sigma_j (V'gp)_j^2
             const double vg = ld_scal(S + 5 + j);
             gAg = fma(ld_scal(u.sigma + j) * vg, vg, gAg);
@@ -595,6 +724,7 @@ __global__ __launch_bounds__(1024) void pcg_post_kernel(PcgPostF u) {
     for (int j = threadIdx.x; j < u.m; j += blockDim.x) {
         const double t1 = ld_scal(u.T + j);
         double t2 = ld_scal(u.T + u.m + j);
+        if (u.triM) t2 -= s_mu[j];                                      // U'(A gp) = U'(A rr) - M t
         for (int l = 0; l < u.k; ++l)                                   // U'(A gp) = U'(D gp) + (U'V) (sigma .* (V'gp))
             t2 = fma(u.UtV[(size_t)l * u.m + j], ld_scal(u.sigma + l) * ld_scal(u.T + 2 * u.m + 5 + l), t2);
         const double t3 = (u.init == 1) ? -t2 : fma(beta, u.t3[j], -t2);
@@ -838,16 +968,100 @@ int lfpsqp_factored_basis_supported(const lfpsqp_ctx* ctx, const lfpsqp_mat* A, 
     return 0;
 }
 
+// ---- lfpsqp_projcg_tridiag: the reduced operator M = Z'A Z of a tridiagonal A, once per solve ----------------------------------------------------
+// With s_i = sign(off_i) and R_i = Z_i + s_i Z_{i+1} (rows of Z):  off_i (Z_i'Z_{i+1} + Z_{i+1}'Z_i) = |off_i| (R_i'R_i - Z_i'Z_i - Z_{i+1}'Z_{i+1}), so
+//     Z'A Z = R' diag(|off|) R + Z' diag(c) Z,    c_i = a0 + dg_i - |off_i| - |off_{i-1}|,
+// i.e. weighted Gram matrices on the matrix cores -- the kernel of the tangent set-up, which forms the rows of R in registers on their way to
+// LDS (gram_kernel SHIFT): two passes over Z, no scratch matrix.  The first term is a sum of squares whatever the signs of the couplings (for a
+// discrete Laplacian, off = -1, it is the whole of M: no cancellation); c is non-negative for a diagonally dominant A, otherwise its negative
+// part costs a third pass.
+__global__ __launch_bounds__(256) void tri_weights_kernel(TriD A, double* __restrict__ wabs, double* __restrict__ sgn, double* __restrict__ cpos, double* __restrict__ cneg,
+                                                          int64_t npad, double* __restrict__ anyneg) {
+    bool neg = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npad; i += (int64_t)gridDim.x * 256) {
+        double wa = 0.0, sg = 1.0, cp = 0.0, cn = 0.0;
+        if (i < A.n) {
+            const double o = (i + 1 < A.n) ? A.off[i] : 0.0;
+            wa = fabs(o);
+            sg = (o < 0.0) ? -1.0 : 1.0;
+            const double wm = (i > 0) ? fabs(A.off[i - 1]) : 0.0;
+            const double c = A.a0 + (A.dg ? A.dg[i] : 0.0) - wa - wm;
+            if (c >= 0.0) cp = c;
+            else { cn = -c; neg = true; }
+            if (c != c) cp = c;                               // (NaN data: let the Gram pass report it)
+        }
+        wabs[i] = wa; sgn[i] = sg; cpos[i] = cp; cneg[i] = cn;
+    }
+    if (neg) *anyneg = 1.0;
+}
+static int ensure_tri(lfpsqp_ctx* ctx, size_t doubles) {
+    if (doubles <= ctx->tri_cap) return 0;
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_tri) LF_HIP(ctx, hipFree(ctx->d_tri));
+    ctx->d_tri = nullptr;
+    ctx->tri_cap = 0;
+    LF_HIP(ctx, hipMalloc((void**)&ctx->d_tri, doubles * sizeof(double)));
+    ctx->tri_cap = doubles;
+    return 0;
+}
+// Mh (m x m, column-major, host) = U'A U for U = Z[:, :mc] (W == nullptr, m == mc) or U = Z[:, :mc] W (W: mc x m, host)
+static int tri_reduced_operator(lfpsqp_ctx* ctx, const lfpsqp_mat* Z, int mc, const TriD& A, const double* W, int m, std::vector<double>& Mh) {
+    const int64_t n = A.n, npad = round_up((n > 0 ? n : 1) + 1, kPadRows);
+    LF_TRY(ensure_tri(ctx, 4 * (size_t)npad + 8));
+    double* wabs = ctx->d_tri;
+    double* sgn = wabs + npad;
+    double* cpos = sgn + npad;
+    double* cneg = cpos + npad;
+    double* anyneg = cneg + npad;
+    LF_HIP(ctx, hipMemsetAsync(anyneg, 0, sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(tri_weights_kernel, dim3((int)std::min<int64_t>((npad + 255) / 256, 4096)), dim3(256), 0, ctx->stream, A, wabs, sgn, cpos, cneg, npad, anyneg);
+    LF_LAUNCH_CHECK(ctx);
+    double hneg = 0.0;
+    LF_HIP(ctx, hipMemcpyAsync(&hneg, anyneg, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const lfpsqp_mat Zp = Z->plain();
+    std::vector<double> G, G2((size_t)mc * mc);
+    LF_TRY(gram_shifted(ctx, &Zp, mc, wabs, sgn, G));
+    lfpsqp_vec wv;
+    wv.n = n; wv.cap = npad;
+    wv.p = cpos;
+    LF_TRY(lfpsqp_gram(ctx, &Zp, mc, &wv, G2.data()));
+    for (size_t k = 0; k < G.size(); ++k) G[k] += G2[k];
+    if (hneg != 0.0) {
+        wv.p = cneg;
+        LF_TRY(lfpsqp_gram(ctx, &Zp, mc, &wv, G2.data()));
+        for (size_t k = 0; k < G.size(); ++k) G[k] -= G2[k];
+    }
+    if (!W) { Mh = G; return 0; }
+    // M = W' G W
+    std::vector<double> GW((size_t)mc * m);
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < mc; ++i) {
+            double a = 0.0;
+            for (int k = 0; k < mc; ++k) a = fma(G[(size_t)k * mc + i], W[(size_t)j * mc + k], a);      // G symmetric: row i down column i
+            GW[(size_t)j * mc + i] = a;
+        }
+    Mh.assign((size_t)m * m, 0.0);
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i <= j; ++i) {
+            double a = 0.0;
+            for (int k = 0; k < mc; ++k) a = fma(W[(size_t)i * mc + k], GW[(size_t)j * mc + k], a);
+            Mh[(size_t)j * m + i] = Mh[(size_t)i * m + j] = a;
+        }
+    return 0;
+}
+
 static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_diag_op* A, lfpsqp_opfun opf, void* ouser,
                        lfpsqp_vec* Av, const lfpsqp_basis* U, const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit,
                        int64_t n_global, int flags, const lfpsqp_projcg_work* work, int64_t* iters, double* nr,
-                       const lfpsqp_lowrank_op* LRop = nullptr) {
+                       const lfpsqp_lowrank_op* LRop = nullptr, const lfpsqp_tridiag_op* TRop = nullptr) {
     const lfpsqp_diag_op no_diag = {0.0, nullptr};
     lfpsqp_diag_op lr_diag = {0.0, nullptr};
     if (LRop) { lr_diag.a0 = LRop->a0; lr_diag.dg = LRop->dg; A = &lr_diag; }
+    if (TRop) { lr_diag.a0 = TRop->a0; lr_diag.dg = TRop->dg; A = &lr_diag; }
     if (opf) A = &no_diag;
     LF_ARG(ctx, ctx && x && A && U && b && work && iters && nr);
-    LF_ARG(ctx, !opf || (Av && Av->n == b->n && !(flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN | LFPSQP_PROJCG_START_PROJECTED))));
+    LF_ARG(ctx, !(opf || TRop) || (Av && Av->n == b->n && !(flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN | LFPSQP_PROJCG_START_PROJECTED))));
     LF_ARG(ctx, !((flags & LFPSQP_PROJCG_RESUME) && (flags & (LFPSQP_PROJCG_START_GIVEN | LFPSQP_PROJCG_START_PROJECTED))));
     LF_ARG(ctx, !((flags & LFPSQP_PROJCG_START_GIVEN) && (flags & LFPSQP_PROJCG_START_PROJECTED)));
     LF_ARG(ctx, work->g && work->d && work->rp && work->Utr);
@@ -940,6 +1154,18 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         if (!fused || stacked || (flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN | LFPSQP_PROJCG_START_PROJECTED)))
             return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "lfpsqp_projcg_lowrank: needs the one-pass iteration over a plain dense basis (4 .. 1024 columns), no RESUME / START_GIVEN");
     }
+    // tridiagonal operator (lfpsqp_projcg_tridiag): fused iteration only; M = U'A U first (its Gram passes use the scratch areas reserved below)
+    std::vector<double> triMh;
+    TriD Atri{0.0, nullptr, nullptr, 0};
+    if (TRop) {
+        LF_ARG(ctx, TRop->off && TRop->off->n == nv && (!TRop->dg || TRop->dg->n == nv));
+        if (!fused || stacked || !plain_mat(Z) || ctx->comm_active())
+            return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "lfpsqp_projcg_tridiag: needs the one-pass iteration over a plain dense basis (4 .. 1024 columns, no matrix "
+                                                        "view, no bounds) on a single rank (the couplings would cross the shard boundaries); use lfpsqp_projcg_op");
+        Atri = TriD{TRop->a0, TRop->dg ? TRop->dg->p : nullptr, TRop->off->p, nv};
+        LF_TRY(tri_reduced_operator(ctx, Z, mc, Atri, DF ? U->W : nullptr, m, triMh));
+    }
+    double* dTriM = nullptr;
     double *lrUtV = nullptr, *lrSig = nullptr, *lrVdraw = nullptr, *lrVdc = nullptr, *lrVtv = nullptr;
     if (fused) {
         LF_TRY(ensure_mvec(ctx, (size_t)3 * m + (DF ? 3 * (size_t)mc + 16 : 0) + 2 * kLRMax + 24 + (kLR > 0 ? (size_t)m * kLRMax + 4 * kLRMax + 8 : 0)));
@@ -954,11 +1180,18 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         if (kLR > 0) {
             lrUtV = tail; lrSig = lrUtV + (size_t)m * kLRMax; lrVdraw = lrSig + kLRMax; lrVdc = lrVdraw + kLRMax; lrVtv = lrVdc + kLRMax;
         }
-        if (DF) {
-            LF_TRY(ensure_small(ctx, (size_t)mc * m + 64));
-            dWf = ctx->small;
-            LF_HIP(ctx, hipMemcpyAsync(dWf, U->W, sizeof(double) * (size_t)mc * m, hipMemcpyHostToDevice, ctx->stream));
-            LF_HIP(ctx, hipStreamSynchronize(ctx->stream));             // U->W is caller-owned pageable memory
+        if (DF || TRop) {
+            const size_t wsz = DF ? (size_t)round_up((int64_t)mc * m, 2) : 0;
+            LF_TRY(ensure_small(ctx, wsz + (TRop ? (size_t)m * m : 0) + 64));
+            if (DF) {
+                dWf = ctx->small;
+                LF_HIP(ctx, hipMemcpyAsync(dWf, U->W, sizeof(double) * (size_t)mc * m, hipMemcpyHostToDevice, ctx->stream));
+            }
+            if (TRop) {
+                dTriM = ctx->small + wsz;
+                LF_HIP(ctx, hipMemcpyAsync(dTriM, triMh.data(), sizeof(double) * (size_t)m * m, hipMemcpyHostToDevice, ctx->stream));
+            }
+            LF_HIP(ctx, hipStreamSynchronize(ctx->stream));             // U->W is caller-owned pageable memory (and triMh a local)
         }
     }
     // t_out = U'v for the producer v: W'(A'v) (raw products parked in Traw); u_out (optional) = W t_out
@@ -977,7 +1210,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         if (rc != 0) return set_err(ctx, LFPSQP_ERR_ARG, "operator callback returned %d", rc);
         return 0;
     };
-    const AOpV Aop{opf ? Av->p : nullptr};
+    const AOpV Aop{(opf || TRop) ? Av->p : nullptr};
     auto residual_with = [&](auto aop, double sgn, double* store, double* t_out) -> int {
         using AOP = decltype(aop);
         const ResidualV<AOP> rv{x->p, b->p, store, aop, sgn};
@@ -992,6 +1225,10 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         if (kLR > 0) {                                                        // V'x first (k columns of V: a thin pass), then the residual with it
             LF_TRY(run_gemv_t(ctx, LRop->V, kLR, N, SpPlainV{x->p}, lrVtv));
             return residual_with(AOpLR{Ad.a0, Ad.dg, LRop->V->p, LRop->V->ld, kLR, lrSig, lrVtv}, sgn, store, t_out);
+        }
+        if (TRop) {                                                           // Av = A x by the stencil kernel, then as a stored product
+            LF_TRY((run_vec<TriMulF, 0, NoPost>(ctx, nv, TriMulF{Atri, x->p, Av->p, nullptr}, 0u, nullptr, NoPost())));
+            return residual_with(Aop, sgn, store, t_out);
         }
         if (!opf) return residual_with(Ad, sgn, store, t_out);
         LF_TRY(apply_op(x));                                                  // Av = A x
@@ -1032,7 +1269,8 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     // 1.70 ms: the store no longer hits a line the L2 already holds), so it is OFF by default; lfpsqp_ctx_set_residual_buffers(ctx, 1)
     // (or LFPSQP_GPING=1) turns it on (same bits either way).  gcur = the buffer holding the current g.
     const bool kPing = ctx->tune_gping == 1;
-    double* gbuf[2] = {g, (fused && kPing) ? rp : g};
+    // (the tridiagonal iteration reads the residual of a row's NEIGHBOURS: it must not store into the buffer it reads, so it always alternates)
+    double* gbuf[2] = {g, (fused && (kPing || TRop)) ? rp : g};
     int gcur = 0;
     auto launch_fused = [&](int init) -> int {
         const int slot = init ? -1 : 3;
@@ -1040,7 +1278,9 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         double* gout = init ? gbuf[0] : gbuf[gcur ^ 1];
         const double* tin = DF ? uDF : Utr;               // coefficients of the first product over the streamed matrix's mc columns
         double* Tout = DF ? Traw : T12;
-        if (kLR > 0 && init) LF_TRY((run_onepass<PcgFuseLR<true>, 2, 5 + kLRMax>(ctx, Z, mc, mc, N, tin, PcgFuseLR<true>{rp, gin, gout, d, Ad, scal, istat, LRop->V->p, LRop->V->ld, kLR, lrVdc}, Tout, slot)));
+        if (TRop && init) LF_TRY((run_onepass<PcgFuseTri<true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseTri<true>{rp, gin, gout, d, Av->p, Atri, scal, istat, (uint32_t)(nv * 8)}, Tout, slot)));
+        else if (TRop) LF_TRY((run_onepass<PcgFuseTri<false>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseTri<false>{rp, gin, gout, d, Av->p, Atri, scal, istat, (uint32_t)(nv * 8)}, Tout, slot)));
+        else if (kLR > 0 && init) LF_TRY((run_onepass<PcgFuseLR<true>, 2, 5 + kLRMax>(ctx, Z, mc, mc, N, tin, PcgFuseLR<true>{rp, gin, gout, d, Ad, scal, istat, LRop->V->p, LRop->V->ld, kLR, lrVdc}, Tout, slot)));
         else if (kLR > 0) LF_TRY((run_onepass<PcgFuseLR<false>, 2, 5 + kLRMax>(ctx, Z, mc, mc, N, tin, PcgFuseLR<false>{rp, gin, gout, d, Ad, scal, istat, LRop->V->p, LRop->V->ld, kLR, lrVdc}, Tout, slot)));
         else if (stacked && init) LF_TRY((run_onepass<PcgFuseE<true, true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<true, true>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
         else if (stacked) LF_TRY((run_onepass<PcgFuseE<true, false>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<true, false>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
@@ -1049,6 +1289,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         if (!init) gcur ^= 1;
         PcgPostF pf{T12, t3, Utr, scal, istat, m, init, hm, dWf, Traw, T12, uDF, DF ? mc : 0};
         if (kLR > 0) { pf.k = kLR; pf.UtV = lrUtV; pf.sigma = lrSig; pf.vdraw = lrVdraw; pf.vdc = lrVdc; }
+        pf.triM = dTriM;
         hipLaunchKernelGGL(pcg_post_kernel, dim3(1), dim3(DF ? 1024 : 256), 0, ctx->stream, pf);
         LF_LAUNCH_CHECK(ctx);
         return 0;
@@ -1129,6 +1370,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         if (fused) {
             // one global reduction per iteration: the post-op of F has already done the exits and alpha of this iteration
             if (it > 0 || resume) LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, gbuf[gcur], x->p, scal, istat, 0}, 0u, nullptr, NoPost(), 0)));
+            if (TRop) LF_TRY((run_vec<TriMulF, 0, NoPost>(ctx, nv, TriMulF{Atri, d, Av->p, istat}, 0u, nullptr, NoPost())));      // A d for the pass
             LF_TRY(launch_fused(0));
         } else if (opf) {
             // generic operator: the direction update, then the user's product A d, then d'(A d); the two passes over U read A d
@@ -1168,7 +1410,7 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     // flow the exits of an iteration start are taken before its K1, so they leave it pending too)
     if ((status == ST_CONVERGED || status == ST_MAXIT || (fused && status == ST_RG_BREAK && *iters > 1)) && *iters > it_base)
         LF_TRY((run_vec<FlushXF, 0, NoPost>(ctx, nv, FlushXF{x->p, d, scal}, 0u, nullptr, NoPost())));
-    if (fused && status == ST_MAXIT && *iters > 0 && kLR == 0)
+    if (fused && status == ST_MAXIT && *iters > 0 && kLR == 0 && !TRop)
         ctx->pcg_resume = lfpsqp_ctx::ProjcgResume{true, x->p, g, d, Z->p, m, nv, *iters, gcur == 1, Ad.dg, b->p, Ad.a0, n_global, ctx->launch_epoch};
     if (status == ST_NEGCURV) {   // :77-82
         if (fused && *iters > 1)  // d+ = beta d - g of the iteration that found the negative curvature was not formed yet
@@ -1238,6 +1480,19 @@ extern "C" int lfpsqp_projcg_lowrank(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec*
         return projcg_impl(ctx, x, lambda, &dop, nullptr, nullptr, nullptr, U, b, c, tol, maxit, n_global, flags, work, iters, nr);
     }
     return projcg_impl(ctx, x, lambda, nullptr, nullptr, nullptr, nullptr, U, b, c, tol, maxit, n_global, flags, work, iters, nr, A);
+}
+
+extern "C" int lfpsqp_projcg_tridiag(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const lfpsqp_tridiag_op* A, lfpsqp_vec* Av, const lfpsqp_basis* U,
+                                     const lfpsqp_vec* b, const lfpsqp_vec* c, double tol, int64_t maxit, int64_t n_global, int flags,
+                                     const lfpsqp_projcg_work* work, int64_t* iters, double* nr) {
+    LF_RANGE("lfpsqp_projcg_tridiag");
+    LF_ARG(ctx, ctx && A && Av);
+    return projcg_impl(ctx, x, lambda, nullptr, nullptr, nullptr, Av, U, b, c, tol, maxit, n_global, flags, work, iters, nr, nullptr, A);
+}
+
+extern "C" int lfpsqp_tridiag_mul(lfpsqp_ctx* ctx, const lfpsqp_tridiag_op* A, const lfpsqp_vec* v, lfpsqp_vec* out) {
+    LF_ARG(ctx, ctx && A && A->off && v && out && v != out && v->p != out->p && out->n == v->n && A->off->n == v->n && (!A->dg || A->dg->n == v->n));
+    return run_vec<TriMulF, 0, NoPost>(ctx, v->n, TriMulF{TriD{A->a0, A->dg ? A->dg->p : nullptr, A->off->p, v->n}, v->p, out->p, nullptr}, 0u, nullptr, NoPost());
 }
 
 extern "C" int lfpsqp_projcg_op(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, lfpsqp_opfun A, void* user, lfpsqp_vec* Av,

@@ -1370,18 +1370,28 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
             bool finite = true;
             for (double v : G) finite = finite && (v == v) && fabs(v) < 1e300;
             if (finite && cholesky_lower(m, G, Lc, 0.0)) {
-                // K = L^-T L^-1: solve L Y = I (forward), then L' K = Y (backward), column by column
+                // K = L^-T L^-1: solve L Y = I (forward), then L' K = Y (backward), column by column.  The columns are independent: shared
+                // over the host threads, the forward solve on a transposed copy of L so that both sweeps run down contiguous memory
+                // (2 m^3 / 3 flops per Gauss-Newton step: 1.4 Mflop at config 4's m = 129, 0.7 Gflop at m = 1024)
+                std::vector<double> Lt((size_t)m * m);
+                for (int j = 0; j < m; ++j)
+                    for (int i2 = j; i2 < m; ++i2) Lt[(size_t)i2 * m + j] = Lc[(size_t)j * m + i2];       // Lt[i, j] row-major = L[i, j]
+                [[maybe_unused]] const int nth = m >= 64 ? small_threads() : 1;
+#pragma omp parallel for if (nth > 1) num_threads(nth) schedule(dynamic, 8)
                 for (int c = 0; c < m; ++c) {
                     std::vector<double> y(m, 0.0);
                     for (int i2 = c; i2 < m; ++i2) {
+                        const double* li = &Lt[(size_t)i2 * m];
                         double acc = (i2 == c) ? 1.0 : 0.0;
-                        for (int k = c; k < i2; ++k) acc -= Lc[(size_t)k * m + i2] * y[k];
-                        y[i2] = acc / Lc[(size_t)i2 * m + i2];
+                        for (int k = c; k < i2; ++k) acc -= li[k] * y[k];
+                        y[i2] = acc / li[i2];
                     }
+                    double* kc = &Kh[(size_t)c * m];
                     for (int i2 = m - 1; i2 >= 0; --i2) {
+                        const double* lc = &Lc[(size_t)i2 * m];
                         double acc = y[i2];
-                        for (int k = i2 + 1; k < m; ++k) acc -= Lc[(size_t)i2 * m + k] * Kh[(size_t)c * m + k];
-                        Kh[(size_t)c * m + i2] = acc / Lc[(size_t)i2 * m + i2];
+                        for (int k = i2 + 1; k < m; ++k) acc -= lc[k] * kc[k];
+                        kc[i2] = acc / lc[i2];
                     }
                 }
                 lfpsqp_pcg_precond pc{Kh.data(), ineq ? w->i11 : nullptr, ineq ? w->i12 : nullptr, ineq ? w->i22 : nullptr, w->q};

@@ -94,6 +94,35 @@ class LowRankOperator:
         return self
 
 
+class TridiagonalOperator:
+    """(A v)_i = (a0 + dg_i) v_i + off_{i-1} v_{i-1} + off_i v_{i+1} (lfpsqp_tridiag_op): a diagonal Hessian plus nearest-neighbour
+    couplings.  ``off``: DeviceVector of length n (entry i couples rows i and i+1; the last entry is ignored).  On a :class:`DeviceBasis`
+    projcg_ runs it on the fused ONE-pass iteration (lfpsqp_projcg_tridiag); ``mul_`` is the operator on its own (lfpsqp_tridiag_mul), which
+    the generic loop / lfpsqp_projcg_op use -- two passes over the basis per iteration."""
+
+    def __init__(self, a0: float, dg: DeviceVector | None, off: DeviceVector):
+        self.a0, self.dg, self.off = float(a0), dg, off
+        self._tmp = None
+
+    def _c(self):
+        return _capi.TridiagOp(self.a0, self.dg.h if self.dg is not None else None, self.off.h)
+
+    def mul_(self, dest: DeviceVector, v: DeviceVector, a=None, b=None):
+        ctx = dest.ctx
+        a_c = self._c()
+        if a is None:
+            ctx.check(ctx.L.lfpsqp_tridiag_mul(ctx.h, C.byref(a_c), v.h, dest.h))
+            return dest
+        if self._tmp is None or self._tmp.n != dest.n:
+            self._tmp = DeviceVector(ctx, dest.n)
+        ctx.check(ctx.L.lfpsqp_tridiag_mul(ctx.h, C.byref(a_c), v.h, self._tmp.h))
+        waxpby(a, self._tmp, b, dest, dest)
+        return dest
+
+    def adjoint(self):
+        return self
+
+
 class DeviceBasis:
     """Orthonormal U = Z[:, :ncols] (``view(U, :, 1:rank)``, src/optimize.jl:370).
     ``Z = None`` with ``generator = (A, W)``: the basis in FACTORED form U = A W -- never materialised; projcg_, the Newton retraction and
@@ -232,6 +261,19 @@ def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c:
                                          c.h if c is not None else None, float(tol), int(maxit), int(n_global), flags,
                                          C.byref(w_c), C.byref(iters), C.byref(nr))
         if rc != -5:                 # LFPSQP_ERR_UNSUPPORTED (a shape without the one-pass iteration): the callback path below
+            ctx.check(rc)
+            return iters.value, nr.value
+    if isinstance(A, TridiagonalOperator) and isinstance(U, DeviceBasis) and not stacked and not (resume or start_given or start_projected) and getattr(A, "fused", True):
+        if getattr(work, "Av", None) is None:
+            work.Av = DeviceVector(ctx, n)
+        iters = _capi.c_i64()
+        nr = C.c_double()
+        a_c, u_c, w_c = A._c(), U._c(), work._c()
+        flags = WANT_LAMBDA if (want_lambda and lam is not None) else 0
+        rc = ctx.L.lfpsqp_projcg_tridiag(ctx.h, x.h, lam.h if lam is not None else None, C.byref(a_c), work.Av.h, C.byref(u_c), b.h,
+                                         c.h if c is not None else None, float(tol), int(maxit), int(n_global), flags,
+                                         C.byref(w_c), C.byref(iters), C.byref(nr))
+        if rc != -5:                 # LFPSQP_ERR_UNSUPPORTED (no one-pass iteration for this shape / more than one rank): the callback path below
             ctx.check(rc)
             return iters.value, nr.value
     if resume or start_given or start_projected:

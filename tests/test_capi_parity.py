@@ -385,6 +385,14 @@ def test_projcg_op_with_a_tridiagonal_operator(dev_ctx, n, m):
         assert np.linalg.norm(x.download() - x0) <= 1e-10 * np.linalg.norm(x0)
         assert np.abs(lam.download() - l0).max() < 1e-10
         assert i1 + 2 <= A.calls <= i1 + 5                     # (the host runs up to two iterations ahead of the exit it sees)
+        # the same operator as a lfpsqp_tridiag_op: ONE pass over the basis per iteration (lfpsqp_projcg_tridiag; tests/test_projcg_tridiag.py)
+        if m >= 4:
+            T = L.TridiagonalOperator(0.0, ctx.vector(n, a), ctx.vector(n, np.concatenate([e, [0.0]])))
+            x3, lam3 = ctx.vector(n), ctx.vector(m)
+            i3, nr3 = L.projcg_(x3, lam3, T, L.DeviceBasis(ctx.matrix(n, m, Uh)), ctx.vector(n, bh), None if ch is None else ctx.vector(m, ch), tol=tol)
+            assert i3 == i0 and nr3 == pytest.approx(nr0, rel=1e-5)
+            assert np.linalg.norm(x3.download() - x0) <= 1e-10 * np.linalg.norm(x0)
+            assert np.abs(lam3.download() - l0).max() < 1e-10
     # negative curvature (src/projcg.jl:77-82) through the same loop
     A2 = _TriDevice(ctx, -a, e)
     x0, l0 = np.zeros(n), np.zeros(m)

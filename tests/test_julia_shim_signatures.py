@@ -15,7 +15,7 @@ HEADER = open(os.path.join(ROOT, "include", "lfpsqp_hip.h")).read()
 JULIA_RAW = open(os.path.join(ROOT, "julia", "LFPSQPHip.jl")).read()
 JULIA = "\n".join(line.split("#")[0].rstrip() if not line.lstrip().startswith("#") else "" for line in JULIA_RAW.splitlines()) + "\n"   # comments stripped
 
-STRUCTS = {"CDiagOp": "lfpsqp_diag_op", "CLowRankOp": "lfpsqp_lowrank_op", "CBasis": "lfpsqp_basis", "CWork": "lfpsqp_projcg_work", "CIneqData": "lfpsqp_ineq_data",
+STRUCTS = {"CDiagOp": "lfpsqp_diag_op", "CLowRankOp": "lfpsqp_lowrank_op", "CTridiagOp": "lfpsqp_tridiag_op", "CBasis": "lfpsqp_basis", "CWork": "lfpsqp_projcg_work", "CIneqData": "lfpsqp_ineq_data",
            "CConstraints": "lfpsqp_constraints", "CPPWork": "lfpsqp_pp_work", "CElementwise": "lfpsqp_elementwise", "CPcgPrecond": "lfpsqp_pcg_precond"}
 FUNPTR_TYPEDEFS = {"lfpsqp_allreduce_fn", "lfpsqp_cfun", "lfpsqp_jacfun", "lfpsqp_opfun"}
 
