@@ -1376,6 +1376,9 @@ function hess_diag_objective! end
 function hess_constraints end
 has_hess_split(h) = hasmethod(hess_diag_objective!, Tuple{typeof(h),DeviceVector,DeviceVector}) && hasmethod(hess_constraints, Tuple{typeof(h)})
 scalar_hessian(h) = false      # true: grad^2 of the Lagrangian is a multiple of I (projected CG ends after one iteration: no allocation by trial)
+# A TRIDIAGONAL Lagrangian Hessian: hess_diag! fills the diagonal, hess_offdiag(problem) returns the device vector of the couplings (entry i couples
+# variables i and i+1) or nothing.  The truncated-Newton solves then run projcg! with a TridiagonalOperator: one pass per iteration.
+hess_offdiag(h) = nothing
 
 function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::Vector{Float64}, xl, xu, m::Int, param::LFPSQPParams=LFPSQPParams();
                        n_global::Int=length(x0))
@@ -1439,6 +1442,11 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     # (with bounds: the stacked form of the same pass; not over a matrix view, not for a class whose Hessian term needs A*λ)
     nonlinear_class = c! isa DeviceConstraints && c!.ew !== nothing          # (its Jct may be a view of A, its Hessian term may need A*λ)
     fuse_tangent = factored_basis && param.do_newton && jsp === nothing && m > 0 && ctx.options.fused_tangent_step && !(ineq && nonlinear_class)
+    tri_off = diagonal_hessian ? hess_offdiag(hess_lag_vec!) : nothing
+    if tri_off !== nothing
+        ineq && error("a tridiagonal Hessian with bounds: pass hess_lag_vec! as a function (the generic path)")
+        fuse_tangent = false                                  # (the tangent step hands projcg! a started solve, which the tridiagonal iteration does not take)
+    end
     ineq_rhs = (fuse_tangent && ineq) ? DeviceVector(ctx, n) : nothing
     Jtd = zeros(max(m, 1)); Utd = zeros(max(m, 1))
     Ggram = fuse_tangent ? zeros(m, m) : nothing              # the factorisation's Gram matrix: U'U = W'GW for the tangent step
@@ -1589,8 +1597,13 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
                 else
                     hess_diag!(hess_lag_vec!, a_diag, x, λ_kkt)
                 end
-                tn_iter, tn_res = projcg!(newton_d, nothing, DiagOperator(0.0, a_diag), Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
-                                          work=projcgwork, n_global=nglob, start_projected=fused_now && init_fold, start_given=fused_now && !init_fold)
+                if tri_off !== nothing
+                    tn_iter, tn_res = projcg!(newton_d, nothing, TridiagonalOperator(0.0, a_diag, tri_off), Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
+                                              work=projcgwork, n_global=nglob)
+                else
+                    tn_iter, tn_res = projcg!(newton_d, nothing, DiagOperator(0.0, a_diag), Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
+                                              work=projcgwork, n_global=nglob, start_projected=fused_now && init_fold, start_given=fused_now && !init_fold)
+                end
             else
                 tn_iter, tn_res = projcg!(newton_d, nothing, newton_apply!, Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
                                           work=projcgwork, n_global=nglob)

@@ -17,4 +17,4 @@ from .retractions import (NR, DeviceConstraints, ElementwiseConstraints, Euclide
 from .projpenalty import ProjPenalty, ProjPenaltyWork, ProjPrecondition, no_precondition, pcg_, proj_precondition_  # noqa: F401
 from .linesearch import ArmijoWork, ExactLinesearchWork, armijo_, exact_linesearch_  # noqa: F401
 from .optimize import optimize_core  # noqa: F401
-from .problems import Derivatives, QuadLinearBallBox, SeparableElementwiseBox, SeparableLinearBallBox, optimize  # noqa: F401
+from .problems import ChainSeparableLinear, Derivatives, QuadLinearBallBox, SeparableElementwiseBox, SeparableLinearBallBox, optimize  # noqa: F401

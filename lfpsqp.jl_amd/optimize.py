@@ -210,7 +210,18 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     Wgen = np.zeros((m, m), order='F') if m > 0 else None                  # ksvd_'s small factor: Z == Jct @ Wgen
     ineqproject = InequalityDecompProject(idecomp) if ineq else None
 
-    if diagonal_hessian:
+    # a TRIDIAGONAL Lagrangian Hessian: ``diag_`` fills the diagonal, ``offdiag`` (device n-vector, entry i couples variables i and i+1) holds the
+    # couplings -- projcg_ keeps one pass per iteration with it (lfpsqp_projcg_tridiag; no bounds, one rank: the operator's own limits)
+    tri_off = getattr(hess_lag_vec_, "offdiag", None) if diagonal_hessian else None
+    if tri_off is not None:
+        if ineq:
+            raise NotImplementedError("a tridiagonal Hessian with bounds: pass hess_lag_vec_ as a callable (the generic path)")
+        fuse_tangent = False                  # (the tangent step's pass hands projcg_ a started solve, which the tridiagonal iteration does not take)
+    if tri_off is not None:
+        from .projcg import TridiagonalOperator
+        a_diag = projcgwork.placed_extra[0] if projcgwork.placed_extra else newvec()
+        newton_map = TridiagonalOperator(0.0, a_diag, tri_off)
+    elif diagonal_hessian:
         a_diag = projcgwork.placed_extra[0] if projcgwork.placed_extra else newvec()
         newton_map = DiagOperator(0.0, a_diag)
     elif ineq:

@@ -164,6 +164,48 @@ class SeparableLinearBallBox(QuadLinearBallBox):
         return np.concatenate([x0, [out.value - self.R2]]), np.concatenate([xl, [-np.inf]]), np.concatenate([xu, [0.0]])
 
 
+class ChainSeparableLinear(SeparableLinearBallBox):
+    """A separable objective plus a CHAIN term: f(x) = sum_i phi(x_i - c_i; a_i) + kappa/2 sum_{i<n-1} (x_{i+1} - x_i)^2 (smoothing / first
+    differences -- the kind of objective whose Hessian the reference reaches only through hess_lag_vec!, src/autodiff_generators.jl:72-107)
+    under dense linear equalities.  The Lagrangian Hessian is TRIDIAGONAL: diagonal phi''(x_i) + kappa deg_i (deg = 1 at the two ends, 2
+    inside), couplings -kappa.  ``optimize`` hands it to projcg_ as a :class:`TridiagonalOperator` (``offdiag`` below): the truncated-Newton
+    solves keep one pass over the basis per iteration (lfpsqp_projcg_tridiag).  One rank, no ball, no bounds (the one-pass form's limits)."""
+
+    def __init__(self, ctx: Context, n: int, m: int, Jct: DeviceMatrix, b, kind: int, a, c=0.0, kappa: float = 1.0, **kw):
+        assert kw.get("R2") is None and kw.get("xl") is None and kw.get("xu") is None, "chain objective: equalities only"
+        assert kw.get("n_global", n) in (None, n), "chain objective: one rank (the couplings would cross the shard boundaries)"
+        super().__init__(ctx, n, m, Jct, b, kind, a, c, **kw)
+        from .projcg import TridiagonalOperator
+        self.kappa = float(kappa)
+        deg = np.full(n, 2.0 * self.kappa)
+        deg[0] = deg[-1] = self.kappa if n > 1 else 0.0
+        self._deg = ctx.vector(n, deg)
+        self.offdiag = ctx.vector(n, np.full(n, -self.kappa))             # (entry n-1 is ignored)
+        self._lap = TridiagonalOperator(0.0, self._deg, self.offdiag)     # kappa * L, L = the path graph's Laplacian
+        self._tmp = ctx.vector(n)
+
+    def f(self, x: DeviceVector) -> float:
+        from .device import dot
+        self._lap.mul_(self._tmp, x)
+        return super().f(x) + 0.5 * dot(x, self._tmp)
+
+    def grad_(self, g: DeviceVector, x: DeviceVector):
+        from .device import axpby
+        super().grad_(g, x)
+        self._lap.mul_(self._tmp, x)
+        axpby(1.0, self._tmp, 1.0, g)
+
+    def diag_objective_(self, hx: DeviceVector, x: DeviceVector):
+        from .device import axpby
+        super().diag_objective_(hx, x)
+        axpby(1.0, self._deg, 1.0, hx)
+
+    def diag_(self, hx: DeviceVector, x: DeviceVector, lam: np.ndarray):
+        from .device import axpby
+        super().diag_(hx, x, lam)
+        axpby(1.0, self._deg, 1.0, hx)
+
+
 class SeparableElementwiseBox(SeparableLinearBallBox):
     """The device-resident problem class with NONLINEAR equality constraints: a separable objective
     (``kind`` / ``a`` / ``c`` as in :class:`SeparableLinearBallBox`) under ``cons``, an :class:`ElementwiseConstraints`

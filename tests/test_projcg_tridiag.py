@@ -141,3 +141,48 @@ def test_tridiagonal_operator_is_refused_where_the_one_pass_form_does_not_exist(
     i0, nr0 = R.projcg_(x0, l0, _TriRef(a, e), Uh, bh, np.zeros(m), tol=1e-10)
     i1, nr1 = L.projcg_(x, lam, A, U, b, None, tol=1e-10, work=work)
     assert i1 == i0 and np.linalg.norm(x.download() - x0) <= 1e-10 * np.linalg.norm(x0)
+
+
+def test_chain_objective_problem_class_follows_the_oracle(dev_ctx):
+    """ChainSeparableLinear: f = sum phi(x_i) + kappa/2 sum (x_{i+1} - x_i)^2 under dense equalities.  `optimize` runs its truncated-Newton
+    solves with the tridiagonal Lagrangian Hessian on the one-pass iteration; the trajectory -- counts of every solve included -- is the
+    oracle's with the same functions in numpy and hess_lag_vec! as a matrix-free tridiagonal product (src/optimize.jl:228-230)."""
+    from oracle import lfpsqp_ref as R
+    from .test_capi_retractions import _compare_traces, _is_emu, _sep_host
+    ctx = dev_ctx
+    emu = _is_emu(ctx)
+    n, m = (260, 4) if emu else (6000, 16)
+    maxiter = 4 if emu else 10
+    kind, kappa = 1, 1.7
+    a = 0.5 + synth.hash_vector(21, n) ** 2
+    c = 0.3 * synth.hash_vector(22, n)
+    phi, d1, d2 = _sep_host(kind, a, c)
+    P0 = synth.BallBoxProblem(n, m)
+    x0 = synth.hash_vector(2, n)
+
+    def lap(v):
+        out = np.zeros_like(v)
+        dv = v[1:] - v[:-1]
+        out[:-1] -= dv
+        out[1:] += dv
+        return kappa * out
+
+    f = lambda x: float(np.sum(phi(x[:n])) + 0.5 * np.dot(x[:n], lap(x[:n])))
+
+    def grad_(g, x):
+        g[:n] = d1(x[:n]) + lap(x[:n])
+
+    def hlv_(dest, src, x, lam):
+        dest[:] = d2(x) * src + lap(src)
+
+    tr0, tr = [], []
+    par = dict(do_project_retract=False, maxiter=maxiter, tn_kappa=1e-6)
+    xr, objr, lamr, tir = R.optimize(f, grad_, P0.eq.c_, P0.eq.jac_, hlv_, x0, None, None, m, R.LFPSQPParams(disp=R.DisplayOption.off, **par), trace=tr0)
+    P = L.ChainSeparableLinear(ctx, n, m, ctx.matrix(n, m).hash_fill(1), P0.eq.b, kind, a, c, kappa=kappa)
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(disp=L.DisplayOption.off, **par), trace=tr)
+    assert ti.iter == tir.iter and ti.condition.name == tir.condition.name
+    assert any((t.get('tn_iter') or 0) > 3 for t in tr0)                       # the Newton systems take several iterations
+    assert _compare_traces(tr, tr0) is None
+    np.testing.assert_allclose(obj, objr, rtol=1e-11)
+    np.testing.assert_allclose(lam, lamr, rtol=1e-6, atol=1e-9)
+    assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
