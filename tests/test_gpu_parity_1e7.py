@@ -105,3 +105,43 @@ def test_config3_trajectory_at_full_size(ctx, do_project_retract):
     assert dev <= 1e-10
     np.testing.assert_allclose(obj, objr, rtol=1e-12)
     np.testing.assert_allclose(lam, lamr, rtol=1e-8, atol=1e-12)
+
+
+def test_tridiagonal_hessian_on_one_pass_at_full_size(ctx):
+    """projcg! with a tridiagonal A at n = 1e7, m = 128 (lfpsqp_projcg_tridiag): the one-pass iteration against the callback path with the same
+    operator (lfpsqp_projcg_op: A d from lfpsqp_tridiag_mul, two passes over U) -- equal counts, iterates within 1e-10 -- and, independent of
+    both loops, the properties of the solution: U'x = 0 and |P(A x - b)| equal to the reported residual norm (src/projcg.jl:97-103)."""
+    Z = ctx.matrix(N, M).hash_fill(1)
+    L.orthonormalize_(Z)
+    U = L.DeviceBasis(Z)
+    a = ctx.vector(N).hash_fill(3, 0, 4.5, 6.5)             # 2 .. 11
+    off = ctx.vector(N).hash_fill(15, 0, 0.8, 0.0)          # both signs, diagonally dominant
+    b = ctx.vector(N).hash_fill(4)
+    T = L.TridiagonalOperator(0.0, a, off)
+    work = L.ProjCGWork(ctx, N, M)
+    x1, l1, x2, l2 = ctx.vector(N), ctx.vector(M), ctx.vector(N), ctx.vector(M)
+    it1, nr1 = L.projcg_(x1, l1, T, U, b, None, tol=1e-6, maxit=200, work=work)
+    T.fused = False
+    it2, nr2 = L.projcg_(x2, l2, T, U, b, None, tol=1e-6, maxit=200, work=work)
+    assert it1 == it2 and 10 < it1 < 200 and nr1 == pytest.approx(nr2, rel=1e-6)
+    d = ctx.vector(N)
+    L.waxpby(1.0, x1, -1.0, x2, d)
+    dx = L.nrm2(d) / L.nrm2(x2)
+    dl = np.abs(l1.download() - l2.download()).max()
+    # the solution's own properties, from the primitives
+    t = ctx.vector(M)
+    L.gemv_t(Z, x1, t)
+    in_range = np.abs(t.download()).max() / L.nrm2(x1)
+    r = ctx.vector(N)
+    T.mul_(r, x1)
+    L.axpby(-1.0, b, 1.0, r)                                 # r = A x - b
+    L.gemv_t(Z, r, t)
+    L.gemv_n(Z, t, r, -1.0, 1.0)                             # g = r - U U'r
+    pres = L.nrm2(r)
+    print(f"[tridiagonal, full size] {it1} iterations, |x1 - x2| / |x2| = {dx:.2e}, |lambda1 - lambda2| = {dl:.2e}, |U'x| / |x| = {in_range:.2e}, "
+          f"|P(Ax - b)| = {pres:.6e} against the reported {nr1:.6e}")
+    assert dx <= 1e-10 and dl <= 1e-9
+    assert in_range <= 1e-12
+    assert pres == pytest.approx(nr1, rel=1e-2)          # (the loop's residual is a recurrence: after a reduction by 1e-9 it has drifted by rounding)
+    for v in (Z, a, off, b, x1, x2, d, r):
+        v.free()
