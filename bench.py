@@ -736,7 +736,13 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
         sparse = {"error": repr(e)}
     rates = stream_rates(ctx, L, nbig=int(max(1 << 20, min(400_000_000, 40 * n_loc))))
     outer = outer_iteration(ctx, L, n_loc, m) if n_loc == n else None
-    return {"outer_iteration": outer, "stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "factorize_factored_basis_ms": fact_factored_ms, "factorize_factored_basis_warm_ms": fact_warm_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs_of_the_full_product": flop / gram_ms / 1e9,
+    ops = None
+    if n_loc == n and m >= 4:
+        try:
+            ops = operator_iterations(ctx, L, n, m, Z2)
+        except Exception as e:      # diagnostics only
+            ops = {"error": repr(e)[:200]}
+    return {"outer_iteration": outer, "operators": ops, "stream_rates": rates, "placements": placements(ctx, L, n, m, n_loc, r0), "sparse": sparse, "factorize_ms": fact_ms, "factorize_factored_basis_ms": fact_factored_ms, "factorize_factored_basis_warm_ms": fact_warm_ms, "rank": int(rank), "gram_ms": gram_ms, "gram_TFLOPs_of_the_full_product": flop / gram_ms / 1e9,
             "gram_TFLOPs_executed": flop * gram_tile_share(m) / gram_ms / 1e9,
             "rmul_ms": rmul_ms, "rmul_TFLOPs": flop / rmul_ms / 1e9, "fp64_mfma_peak_TFLOPs": 78.6,
             "nr_step_ms": nr_ms["one_stream"], "nr_step_GBs": gbs(nr1_bytes, nr_ms["one_stream"]),
@@ -748,6 +754,41 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             "matrix_view": view_info, "projcg_factored_xnorm_rel_diff": abs(pf["factored_xnorm"] - pf["materialised_xnorm"]) / pf["materialised_xnorm"], "nr_iters_timed": its_long, "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit), "pcg_iter_kernel_chain": pcg_chain,
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies; the Gram kernel computes the upper "
                     "triangle only (16 x 16 tiles on and above the diagonal): gram_TFLOPs_executed counts that work, ..._of_the_full_product 2 n m^2"}
+
+
+def operator_iterations(ctx, L, n, m, Z):
+    """ms per projected-CG iteration with Hessians that are NOT diagonal, on the one-pass path (one rank): tridiagonal (lfpsqp_projcg_tridiag; the
+    callback path lfpsqp_projcg_op with the same operator beside it) and diagonal + rank 4 (lfpsqp_projcg_lowrank), the diagonal operator on the
+    same vectors as the yardstick.  Two solve lengths separate the iterations from what a solve costs outside them (the tridiagonal form's U'AU)."""
+    import numpy as np
+    U = L.DeviceBasis(Z)
+    work = L.ProjCGWork(ctx, n, m)
+    a, off, b, x = ctx.vector(n).hash_fill(3, 0, 4.5, 6.5), ctx.vector(n).hash_fill(15, 0, 0.8, 0.0), ctx.vector(n).hash_fill(4), ctx.vector(n)
+
+    def per_iteration(A):
+        t = {}
+        for its in (10, 40):
+            L.projcg_(x, None, A, U, b, None, tol=0.0, maxit=its, work=work, want_lambda=False)
+            ctx.sync(); t0 = time.perf_counter()
+            it, _ = L.projcg_(x, None, A, U, b, None, tol=0.0, maxit=its, work=work, want_lambda=False)
+            ctx.sync(); t[its] = ((time.perf_counter() - t0) * 1e3, it)
+        per = (t[40][0] - t[10][0]) / max(t[40][1] - t[10][1], 1)
+        return per, t[10][0] - per * t[10][1]
+
+    d_ms, d_out = per_iteration(L.DiagOperator(0.0, a))
+    T = L.TridiagonalOperator(0.0, a, off)
+    t_ms, t_out = per_iteration(T)
+    T.fused = False
+    tc_ms, _ = per_iteration(T)
+    V = ctx.matrix(n, 4).hash_fill(17, 0, n, n ** -0.5)
+    l_ms, l_out = per_iteration(L.LowRankOperator(0.0, a, V, 4, np.array([3.0, -0.4, 1.5, 0.7])))
+    V.free()
+    for v_ in (a, off, b, x, work.g, work.d, work.rp):
+        v_.free()
+    return {"diagonal_ms": d_ms, "tridiagonal_one_pass_ms": t_ms, "tridiagonal_callback_path_ms": tc_ms, "tridiagonal_ms_per_solve_outside_the_iterations": t_out - d_out,
+            "diagonal_plus_rank4_one_pass_ms": l_ms,
+            "note": "A = diag(2 .. 11) + couplings in [-0.8, 0.8] / + V diag(sigma) V' (4 columns); per iteration from solves of 10 and 40 iterations; the "
+                    "tridiagonal form's set-up is U'AU, two weighted Gram passes on the matrix cores"}
 
 
 def outer_iteration(ctx, L, n, m, iters=6):

@@ -115,6 +115,65 @@ struct TriMulF {   // out = A v (a plain vector kernel: the neighbours come out 
     }
 };
 
+// What the fused tridiagonal iteration (PcgFuseTri) needs from the rows' NEIGHBOURS, as two stored vectors, so that the pass itself is row-local
+// and may update the residual in place:  ad = A d  and  q_i = off_{i-1} rr_{i-1} + off_i rr_{i+1}  with  rr = g + alpha ad  (the off-diagonal part
+// of A rr).  INIT: rr is the stored initial residual (alpha = 0, no direction yet), only q is written.  A vector kernel: six streams of n doubles.
+template <bool INIT>
+struct TriPrepF {
+    TriD A;
+    const double* g;          // the residual (INIT: the stored initial residual)
+    const double* d;
+    double* ad;
+    double* q;
+    const double* scal;
+    const int64_t* istat;
+    __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
+    // entry k of a vector / of the couplings, zero outside the matrix (clamped index + select: no divergent loads)
+    __device__ __forceinline__ double at(const double* v, int64_t k) const {
+        const int64_t kc = k < 0 ? 0 : (k >= A.n ? A.n - 1 : k);
+        const double x = v[kc];
+        return (k == kc) ? x : 0.0;
+    }
+    __device__ __forceinline__ double cpl(int64_t k) const {      // off_k couples rows k and k + 1: 0 <= k < n - 1
+        const int64_t kc = k < 0 ? 0 : (k >= A.n ? A.n - 1 : k);
+        const double x = A.off[kc];
+        return (k >= 0 && k + 1 < A.n) ? x : 0.0;
+    }
+    __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
+        if (!v0) return;
+        const double alpha = INIT ? 0.0 : ld_scal(scal + S_ALPHA);
+        // rows i-1 .. i+2 of rr (and of A d): the two rows of this thread and one neighbour on either side
+        double o[5], adv[4], rr[4];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) o[k] = cpl(i - 2 + k);                       // off_{i-2} .. off_{i+2}
+        if (INIT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { adv[k] = 0.0; rr[k] = at(g, i - 1 + k); }
+        } else {
+            double dv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dv[k] = at(d, i - 2 + k);                // d_{i-2} .. d_{i+3}
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                        // row r = i - 1 + k
+                const int64_t r = i - 1 + k;
+                const int64_t rc = r < 0 ? 0 : (r >= A.n ? A.n - 1 : r);
+                const double ax = A.a0 + (A.dg ? A.dg[rc] : 0.0);
+                adv[k] = fma(o[k + 1], dv[k + 2], fma(o[k], dv[k], ax * dv[k + 1]));   // same expression as TriMulF's for every row
+                rr[k] = fma(alpha, adv[k], at(g, r));                            // :93
+            }
+        }
+        const double q0 = fma(o[2], rr[2], o[1] * rr[0]);
+        const double q1 = fma(o[3], rr[3], o[2] * rr[1]);
+        if (v1) {
+            st2(q + i, make_double2(q0, q1));
+            if (!INIT) st2(ad + i, make_double2(adv[1], adv[2]));
+        } else {
+            q[i] = q0;
+            if (!INIT) ad[i] = adv[1];
+        }
+    }
+};
+
 struct StackD {   // stacked (bound-constrained) basis Q = [[diag Dx; diag Dy], [sx.*Z; sy.*Z]]
     int64_t hs;
     const double *Dx, *Dy, *sx, *sy;
@@ -479,28 +538,29 @@ struct PcgFuseLR {
 
 // ---- F for A = a0 I + diag(dg) + tridiagonal couplings: the same single pass ---------------------------------------------------------------
 // (A gp)_i needs gp_{i+-1}, which other lanes, waves and workgroups are still computing -- but gp = rr - U t with t (= Utr) known BEFORE the
-// pass and rr = g + alpha A d made of STORED vectors, whose neighbours are two cached loads away:
-//   U'(A gp)  = U'(A rr) - (U'A U) t          -- the second product carries (A rr)_i (row-local: rr_{i-1}, rr_i, rr_{i+1} from g and A d), the
-//                                                m x m matrix M = U'A U is formed once per solve (tri_reduced_operator below);
+// pass and rr = g + alpha A d made of STORED vectors:
+//   U'(A gp)  = U'(A rr) - (U'A U) t          -- the second product carries (A rr)_i = ax_i rr_i + q_i, with q (the neighbours' part) and A d
+//                                                prepared by a vector kernel (TriPrepF), the m x m matrix M = U'A U formed once per solve
+//                                                (tri_reduced_operator below);
 //   gp'A gp   = rr'A rr - 2 t'(U'A rr) + t'M t  (post-op; the three terms are of the size of |A| |rr|^2, and rr differs from gp by what ONE
 //                                                step alpha A d left in the range of U: no cancellation beyond a digit or two);
-//   gp'A d, d'A d: row-local with A d stored (TriMulF, a vector kernel per iteration: 0.4 GB next to the 10.4 GB of the pass).
-// The row record grows from three to ten doubles, the matrix stream is untouched.
+//   gp'A d, d'A d: row-local with A d stored.
+// The row record has five doubles instead of three, the matrix stream is untouched, the residual is updated in place as in the diagonal form.
 template <bool INIT>
 struct PcgFuseTri {
     const double* rp;
     const double* g;
     double* gout;
     double* d;
-    const double* ad;     // A d of the current direction
-    TriD A;
+    const double* ad;     // A d of the current direction       (TriPrepF; unused by INIT)
+    const double* q;      // off-diagonal part of A rr          (TriPrepF)
+    AOpD A;               // the diagonal of the operator
     const double* scal;
     const int64_t* istat;
-    uint32_t n8;          // n * 8: byte offset behind the last row
     static constexpr bool kSplitRed = true;
     static constexpr bool kNoRowScale = true;
     struct Uni { double alpha; };
-    struct Row { double gm, g0, gq, am, a0, aq, dx, ax, om, o0; };
+    struct Row { double gx, dx, ax, ad, q; };
     static __device__ __forceinline__ double at(const double* base, uint32_t o) {
         return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o);
     }
@@ -510,19 +570,12 @@ struct PcgFuseTri {
     __device__ __forceinline__ bool skip() const { return ld_stat(istat + I_STATUS) != ST_RUNNING; }
     __device__ __forceinline__ Uni uniform() const { return Uni{INIT ? 0.0 : uniform_f64(ld_scal(scal + S_ALPHA))}; }
     __device__ __forceinline__ Row fetch(uint32_t o) const {
-        // (unconditional loads at clamped offsets: row 0 re-reads itself for its missing upper neighbour, the last row for its lower one --
-        // finite values that meet a zero coupling; a branch around a load would keep the whole record in scratch memory, FINDINGS 11.4)
-        const bool has_m = o >= 8u, has_q = o + 8u < n8;
-        const uint32_t om_ = has_m ? o - 8u : o, oq_ = has_q ? o + 8u : o;
-        const double* gs = INIT ? rp : g;
         Row w;
-        w.gm = at(gs, om_); w.g0 = at(gs, o); w.gq = at(gs, oq_);
-        if (INIT) { w.am = w.a0 = w.aq = w.dx = 0.0; }
-        else { w.am = at(ad, om_); w.a0 = at(ad, o); w.aq = at(ad, oq_); w.dx = at(d, o); }
+        w.gx = INIT ? at(rp, o) : at(g, o);
+        w.dx = INIT ? 0.0 : at(d, o);
         w.ax = A.a0 + (A.dg ? at(A.dg, o) : 0.0);
-        const double e0 = at(A.off, om_), e1 = at(A.off, o);
-        w.om = has_m ? e0 : 0.0;
-        w.o0 = has_q ? e1 : 0.0;
+        w.ad = INIT ? 0.0 : at(ad, o);
+        w.q = at(q, o);
         return w;
     }
     static constexpr int kStageStreams = INIT ? 0 : 1;
@@ -535,19 +588,17 @@ struct PcgFuseTri {
     __device__ __forceinline__ void apply_staged(int64_t, uint32_t o, const double (&accv)[1], bool valid, bool owner, bool lead, const Uni& u,
                                                  const Row& w, double (&v)[2], double (&red)[2], double* slot, int) const {
         const int h = (int)((threadIdx.x >> 2) & 3u);
-        const double r0 = INIT ? w.g0 : fma(u.alpha, w.a0, w.g0);               // :93, rows i-1, i, i+1
-        const double rm = INIT ? w.gm : fma(u.alpha, w.am, w.gm);
-        const double rq = INIT ? w.gq : fma(u.alpha, w.aq, w.gq);
-        const double gp = r0 - accv[0];                                          // :97
-        const double ar = fma(w.o0, rq, fma(w.om, rm, w.ax * r0));               // (A rr)_i
+        const double rr = INIT ? w.gx : fma(u.alpha, w.ad, w.gx);                // :93 (TriPrepF formed the neighbours' rr by the same fma)
+        const double gp = rr - accv[0];                                          // :97
+        const double ar = fma(w.ax, rr, w.q);                                    // (A rr)_i
         if (valid && owner) {
             if (slot) *slot = gp;
             else put(gout, o, gp);
             if (INIT) put(d, o, -gp);                                            // :62
         }
         if (valid && lead) {
-            red[0] += (h == 2) ? r0 * ar : gp * ((h == 0) ? r0 : ((h == 1) ? gp : w.a0));
-            if (h == 0) red[1] += w.dx * w.a0;                                   // d'Ad
+            red[0] += (h == 2) ? rr * ar : gp * ((h == 0) ? rr : ((h == 1) ? gp : w.ad));
+            if (h == 0) red[1] += w.dx * w.ad;                                   // d'Ad
         }
         v[0] = valid ? gp : 0.0;
         v[1] = valid ? ar : 0.0;
@@ -642,28 +693,39 @@ __global__ __launch_bounds__(1024) void pcg_post_kernel(PcgPostF u) {
         __syncthreads();
     }
     __shared__ double s_mu[kOnepassMaxCols];
+    __shared__ double s_tri[2];
     if (u.triM) {
-        // y = M t with t = Utr AS THE PASS USED IT (it is overwritten at the end of this kernel); M is symmetric: row j read down column j
+        // y = M t with t = Utr AS THE PASS USED IT (it is overwritten at the end of this kernel); M is symmetric: row j read down column j.
+        // t and U'(A rr) go through LDS first, the two inner products t'(U'A rr) and t'y are summed by the whole workgroup in a fixed order
+        // (one thread reading 2 m scalars from memory was 50 us of latency per iteration at m = 128)
+        for (int j = threadIdx.x; j < u.m; j += blockDim.x) s_utr[j] = ld_scal(u.Utr + j);
+        __syncthreads();
+        double c1 = 0.0, c2 = 0.0;
         for (int j = threadIdx.x; j < u.m; j += blockDim.x) {
             double a = 0.0;
-            for (int l = 0; l < u.m; ++l) a = fma(u.triM[(size_t)l * u.m + j], ld_scal(u.Utr + l), a);
+            for (int l = 0; l < u.m; ++l) a = fma(u.triM[(size_t)l * u.m + j], s_utr[l], a);
             s_mu[j] = a;
+            c1 = fma(ld_scal(u.T + u.m + j), s_utr[j], c1);
+            c2 = fma(a, s_utr[j], c2);
         }
+        s_part[threadIdx.x] = c1;
+        s_part[1024 + threadIdx.x] = c2;
+        __syncthreads();
+        for (int w = (int)blockDim.x >> 1; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) {
+                s_part[threadIdx.x] += s_part[threadIdx.x + w];
+                s_part[1024 + threadIdx.x] += s_part[1024 + threadIdx.x + w];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { s_tri[0] = s_part[0]; s_tri[1] = s_part[1024]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         const double* S = u.T + 2 * u.m;
         const double rpgp = ld_scal(S), gpgp = ld_scal(S + 1), gAd = ld_scal(S + 3), dAd = ld_scal(S + 4);
         double gAg = ld_scal(S + 2);
-        if (u.triM) {                                                   // gp'A gp = rr'A rr - 2 t'(U'A rr) + t'M t
-            double c1 = 0.0, c2 = 0.0;
-            for (int j = 0; j < u.m; ++j) {
-                const double ut = ld_scal(u.Utr + j);
-                c1 = fma(ld_scal(u.T + u.m + j), ut, c1);
-                c2 = fma(s_mu[j], ut, c2);
-            }
-            gAg = (gAg - 2.0 * c1) + c2;
-        }
+        if (u.triM) gAg = (gAg - 2.0 * s_tri[0]) + s_tri[1];          // gp'A gp = rr'A rr - 2 t'(U'A rr) + t'M t
         for (int j = 0; j < u.k; ++j) {                                 // + sum_j sigma_j (V'gp)_j^2
             const double vg = ld_scal(S + 5 + j);
             gAg = fma(ld_scal(u.sigma + j) * vg, vg, gAg);
@@ -1269,8 +1331,8 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     // 1.70 ms: the store no longer hits a line the L2 already holds), so it is OFF by default; lfpsqp_ctx_set_residual_buffers(ctx, 1)
     // (or LFPSQP_GPING=1) turns it on (same bits either way).  gcur = the buffer holding the current g.
     const bool kPing = ctx->tune_gping == 1;
-    // (the tridiagonal iteration reads the residual of a row's NEIGHBOURS: it must not store into the buffer it reads, so it always alternates)
-    double* gbuf[2] = {g, (fused && (kPing || TRop)) ? rp : g};
+    // (the tridiagonal iteration keeps a vector of its own in rp after the initial projection: no alternation there)
+    double* gbuf[2] = {g, (fused && kPing && !TRop) ? rp : g};
     int gcur = 0;
     auto launch_fused = [&](int init) -> int {
         const int slot = init ? -1 : 3;
@@ -1278,8 +1340,14 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         double* gout = init ? gbuf[0] : gbuf[gcur ^ 1];
         const double* tin = DF ? uDF : Utr;               // coefficients of the first product over the streamed matrix's mc columns
         double* Tout = DF ? Traw : T12;
-        if (TRop && init) LF_TRY((run_onepass<PcgFuseTri<true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseTri<true>{rp, gin, gout, d, Av->p, Atri, scal, istat, (uint32_t)(nv * 8)}, Tout, slot)));
-        else if (TRop) LF_TRY((run_onepass<PcgFuseTri<false>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseTri<false>{rp, gin, gout, d, Av->p, Atri, scal, istat, (uint32_t)(nv * 8)}, Tout, slot)));
+        // tridiagonal: the neighbours' contributions first (a vector kernel), into Av while rp still holds the initial residual, into rp afterwards
+        if (TRop && init) {
+            LF_TRY((run_vec<TriPrepF<true>, 0, NoPost>(ctx, nv, TriPrepF<true>{Atri, rp, nullptr, nullptr, Av->p, scal, istat}, 0u, nullptr, NoPost())));
+            LF_TRY((run_onepass<PcgFuseTri<true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseTri<true>{rp, gin, gout, d, nullptr, Av->p, Ad, scal, istat}, Tout, slot)));
+        } else if (TRop) {
+            LF_TRY((run_vec<TriPrepF<false>, 0, NoPost>(ctx, nv, TriPrepF<false>{Atri, gin, d, Av->p, rp, scal, istat}, 0u, nullptr, NoPost())));
+            LF_TRY((run_onepass<PcgFuseTri<false>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseTri<false>{rp, gin, gout, d, Av->p, rp, Ad, scal, istat}, Tout, slot)));
+        }
         else if (kLR > 0 && init) LF_TRY((run_onepass<PcgFuseLR<true>, 2, 5 + kLRMax>(ctx, Z, mc, mc, N, tin, PcgFuseLR<true>{rp, gin, gout, d, Ad, scal, istat, LRop->V->p, LRop->V->ld, kLR, lrVdc}, Tout, slot)));
         else if (kLR > 0) LF_TRY((run_onepass<PcgFuseLR<false>, 2, 5 + kLRMax>(ctx, Z, mc, mc, N, tin, PcgFuseLR<false>{rp, gin, gout, d, Ad, scal, istat, LRop->V->p, LRop->V->ld, kLR, lrVdc}, Tout, slot)));
         else if (stacked && init) LF_TRY((run_onepass<PcgFuseE<true, true>, 2, 5>(ctx, Z, mc, mc, N, tin, PcgFuseE<true, true>{rp, gin, gout, d, Ad, scal, istat, sk}, Tout, slot)));
@@ -1370,7 +1438,6 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
         if (fused) {
             // one global reduction per iteration: the post-op of F has already done the exits and alpha of this iteration
             if (it > 0 || resume) LF_TRY((run_vec<PcgDirG, 0, NoPost>(ctx, nv, PcgDirG{d, gbuf[gcur], x->p, scal, istat, 0}, 0u, nullptr, NoPost(), 0)));
-            if (TRop) LF_TRY((run_vec<TriMulF, 0, NoPost>(ctx, nv, TriMulF{Atri, d, Av->p, istat}, 0u, nullptr, NoPost())));      // A d for the pass
             LF_TRY(launch_fused(0));
         } else if (opf) {
             // generic operator: the direction update, then the user's product A d, then d'(A d); the two passes over U read A d
@@ -1492,6 +1559,8 @@ extern "C" int lfpsqp_projcg_tridiag(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec*
 
 extern "C" int lfpsqp_tridiag_mul(lfpsqp_ctx* ctx, const lfpsqp_tridiag_op* A, const lfpsqp_vec* v, lfpsqp_vec* out) {
     LF_ARG(ctx, ctx && A && A->off && v && out && v != out && v->p != out->p && out->n == v->n && A->off->n == v->n && (!A->dg || A->dg->n == v->n));
+    if (ctx->comm_active())        // (a rank sees its own rows only: the couplings across the shard boundaries would silently drop out)
+        return set_err(ctx, LFPSQP_ERR_UNSUPPORTED, "lfpsqp_tridiag_mul: one rank only (no halo exchange between row shards)");
     return run_vec<TriMulF, 0, NoPost>(ctx, v->n, TriMulF{TriD{A->a0, A->dg ? A->dg->p : nullptr, A->off->p, v->n}, v->p, out->p, nullptr}, 0u, nullptr, NoPost());
 }
 

@@ -22,6 +22,8 @@ def test_bench_json_contract(emu_lib, capsys):
     assert out["value"] > 0
     assert d["check"]["iters"] == 4 and "resumed" in d["config"]["timed_region"] and d["single_call"]["value"] > 0
     assert d["roofline"]["traffic"] is None            # no PMC passes of this build
+    ops = d["extras"]["operators"]                   # the one-pass iteration with non-diagonal Hessians, timed beside the headline
+    assert "error" not in ops and ops["tridiagonal_one_pass_ms"] > 0 and ops["diagonal_plus_rank4_one_pass_ms"] > 0
 
 
 def test_bench_two_ranks_as_the_driver_launches_it(emu_lib):
