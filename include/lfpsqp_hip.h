@@ -462,7 +462,7 @@ int lfpsqp_projcg_lowrank(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, co
  * still ONE pass over U per iteration where lfpsqp_projcg_op pays two.  The projected residual's neighbours do not exist while a pass runs, but
  * gp = rr - U t with t known before the pass and rr = g + alpha A d made of stored vectors: the second product carries A rr (row-local) and the
  * post-op subtracts (U'A U) t; U'A U (m x m) is formed once per solve by two or three weighted Gram passes over U on the matrix cores.  Av: a scratch vector of length(b) (it receives A d of every iteration).  Plain dense basis (materialised or
- * factored, no matrix view), 4 .. 1024 columns, no bounds, one rank, no RESUME / START_GIVEN / START_PROJECTED -- otherwise
+ * factored, no matrix view), 4 .. 1024 columns, no bounds, one rank, no RESUME / START_PROJECTED (START_GIVEN as for lfpsqp_projcg: r0 and U'r0 do not involve A) -- otherwise
  * LFPSQP_ERR_UNSUPPORTED (use lfpsqp_projcg_op).  Iterates, counts and exits as projcg! with A as a matrix (src/projcg.jl:40-121), to rounding.
  * lfpsqp_tridiag_mul: out = A v (out != v), the operator on its own (mul! of the LinearMap). */
 typedef struct lfpsqp_tridiag_op {

@@ -716,12 +716,12 @@ end
 # loop below with mul! as the operator -- the same iterates, two passes per iteration.
 function projcg!(x::DeviceVector, λ::Union{Nothing,DeviceVector}, A::TridiagonalOperator, U::AnyBasis, b::DeviceVector, c::Union{Nothing,DeviceVector};
                  tol::Float64=1e-6, maxit::Int=length(b) + ncols(U), work::ProjCGWork=ProjCGWork(x, ncols(U)), n_global::Int=length(b),
-                 Av::DeviceVector=DeviceVector(x.ctx, length(b)))
+                 Av::DeviceVector=DeviceVector(x.ctx, length(b)), start_given::Bool=false)
     iters = Ref{Int64}(0); nr = Ref{Float64}(0.0)
+    flags = (λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA) | (start_given ? LFPSQP_PROJCG_START_GIVEN : Cint(0))
     rc = GC.@preserve U A c_projcg_tridiag(x.ctx.h, x.h, λ === nothing ? C_NULL : λ.h, Ref(ctridiag(A)), Av.h, Ref(cbasis(U)),
-                                           b.h, c === nothing ? C_NULL : c.h, tol, Int64(maxit), Int64(n_global),
-                                           λ === nothing ? Cint(0) : LFPSQP_PROJCG_WANT_LAMBDA, Ref(cwork(work)), iters, nr)
-    if rc == LFPSQP_ERR_UNSUPPORTED
+                                           b.h, c === nothing ? C_NULL : c.h, tol, Int64(maxit), Int64(n_global), flags, Ref(cwork(work)), iters, nr)
+    if rc == LFPSQP_ERR_UNSUPPORTED && !start_given
         return projcg!(x, λ, (dest, src) -> mul!(dest, A, src), U, b, c; tol=tol, maxit=maxit, work=work, n_global=n_global)
     end
     check(x.ctx, rc)
@@ -1445,8 +1445,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     tri_off = diagonal_hessian ? hess_offdiag(hess_lag_vec!) : nothing
     if tri_off !== nothing
         ineq && error("a tridiagonal Hessian with bounds: pass hess_lag_vec! as a function (the generic path)")
-        fuse_tangent = false                                  # (the tangent step hands projcg! a started solve, which the tridiagonal iteration does not take)
-    end
+    end                                                       # (the tangent step still hands projcg! r0 and U'r0; never its folded initial projection)
     ineq_rhs = (fuse_tangent && ineq) ? DeviceVector(ctx, n) : nothing
     Jtd = zeros(max(m, 1)); Utd = zeros(max(m, 1))
     Ggram = fuse_tangent ? zeros(m, m) : nothing              # the factorisation's Gram matrix: U'U = W'GW for the tangent step
@@ -1538,7 +1537,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
                     hess_diag!(hess_lag_vec!, hdst, x, λ_kkt)
                 end
                 # the fold of projcg!'s initial projection: only where the Gram matrix resolves I - U'U (full rank, cond^2 <= 10)
-                init_fold = rank == m && Σ[1]^2 <= 10.0 * Σ[m]^2
+                init_fold = tri_off === nothing && rank == m && Σ[1]^2 <= 10.0 * Σ[m]^2
                 GC.@preserve Ub cons_part begin
                     cref = cons_part === nothing ? nothing : Ref(ccons(cons_part))
                     iref = ineq ? Ref(cineq(idata)) : nothing
@@ -1599,7 +1598,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
                 end
                 if tri_off !== nothing
                     tn_iter, tn_res = projcg!(newton_d, nothing, TridiagonalOperator(0.0, a_diag, tri_off), Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
-                                              work=projcgwork, n_global=nglob)
+                                              work=projcgwork, n_global=nglob, start_given=fused_now)
                 else
                     tn_iter, tn_res = projcg!(newton_d, nothing, DiagOperator(0.0, a_diag), Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
                                               work=projcgwork, n_global=nglob, start_projected=fused_now && init_fold, start_given=fused_now && !init_fold)

@@ -143,24 +143,42 @@ struct TriPrepF {
         if (!v0) return;
         const double alpha = INIT ? 0.0 : ld_scal(scal + S_ALPHA);
         // rows i-1 .. i+2 of rr (and of A d): the two rows of this thread and one neighbour on either side
-        double o[5], adv[4], rr[4];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) o[k] = cpl(i - 2 + k);                       // off_{i-2} .. off_{i+2}
-        if (INIT) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { adv[k] = 0.0; rr[k] = at(g, i - 1 + k); }
-        } else {
-            double dv[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) dv[k] = at(d, i - 2 + k);                // d_{i-2} .. d_{i+3}
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {                                        // row r = i - 1 + k
-                const int64_t r = i - 1 + k;
-                const int64_t rc = r < 0 ? 0 : (r >= A.n ? A.n - 1 : r);
-                const double ax = A.a0 + (A.dg ? A.dg[rc] : 0.0);
-                adv[k] = fma(o[k + 1], dv[k + 2], fma(o[k], dv[k], ax * dv[k + 1]));   // same expression as TriMulF's for every row
-                rr[k] = fma(alpha, adv[k], at(g, r));                            // :93
+        double o[5], adv[4], rr[4], gv[4], dv[6], axv[4];
+        if (i >= 2 && i + 4 < A.n) {                                             // interior (all but the first and the last thread): aligned pair loads
+            const double2 o0 = ld2(A.off + i - 2), o1 = ld2(A.off + i);
+            o[0] = o0.x; o[1] = o0.y; o[2] = o1.x; o[3] = o1.y; o[4] = A.off[i + 2];
+            const double2 g1 = ld2(g + i);
+            gv[0] = g[i - 1]; gv[1] = g1.x; gv[2] = g1.y; gv[3] = g[i + 2];
+            if (!INIT) {
+                const double2 d0 = ld2(d + i - 2), d1 = ld2(d + i), d2 = ld2(d + i + 2);
+                dv[0] = d0.x; dv[1] = d0.y; dv[2] = d1.x; dv[3] = d1.y; dv[4] = d2.x; dv[5] = d2.y;
+                if (A.dg) {
+                    const double2 a1 = ld2(A.dg + i);
+                    axv[0] = A.a0 + A.dg[i - 1]; axv[1] = A.a0 + a1.x; axv[2] = A.a0 + a1.y; axv[3] = A.a0 + A.dg[i + 2];
+                } else {
+                    axv[0] = axv[1] = axv[2] = axv[3] = A.a0;
+                }
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o[k] = cpl(i - 2 + k);                   // off_{i-2} .. off_{i+2}
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gv[k] = at(g, i - 1 + k);
+            if (!INIT) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dv[k] = at(d, i - 2 + k);            // d_{i-2} .. d_{i+3}
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t r = i - 1 + k;
+                    const int64_t rc = r < 0 ? 0 : (r >= A.n ? A.n - 1 : r);
+                    axv[k] = A.a0 + (A.dg ? A.dg[rc] : 0.0);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                            // row i - 1 + k
+            adv[k] = INIT ? 0.0 : fma(o[k + 1], dv[k + 2], fma(o[k], dv[k], axv[k] * dv[k + 1]));   // same expression as TriMulF's for every row
+            rr[k] = INIT ? gv[k] : fma(alpha, adv[k], gv[k]);                    // :93
         }
         const double q0 = fma(o[2], rr[2], o[1] * rr[0]);
         const double q1 = fma(o[3], rr[3], o[2] * rr[1]);
@@ -1123,7 +1141,9 @@ static int projcg_impl(lfpsqp_ctx* ctx, lfpsqp_vec* x, lfpsqp_vec* lambda, const
     if (TRop) { lr_diag.a0 = TRop->a0; lr_diag.dg = TRop->dg; A = &lr_diag; }
     if (opf) A = &no_diag;
     LF_ARG(ctx, ctx && x && A && U && b && work && iters && nr);
-    LF_ARG(ctx, !(opf || TRop) || (Av && Av->n == b->n && !(flags & (LFPSQP_PROJCG_RESUME | LFPSQP_PROJCG_START_GIVEN | LFPSQP_PROJCG_START_PROJECTED))));
+    // (a tridiagonal operator may start from the state lfpsqp_tangent_step left -- LFPSQP_PROJCG_START_GIVEN: r0 and U'r0 do not involve A -- but not
+    // from its folded initial projection, whose sums were formed with the diagonal alone)
+    LF_ARG(ctx, !(opf || TRop) || (Av && Av->n == b->n && !(flags & (LFPSQP_PROJCG_RESUME | (TRop ? 0 : LFPSQP_PROJCG_START_GIVEN) | LFPSQP_PROJCG_START_PROJECTED))));
     LF_ARG(ctx, !((flags & LFPSQP_PROJCG_RESUME) && (flags & (LFPSQP_PROJCG_START_GIVEN | LFPSQP_PROJCG_START_PROJECTED))));
     LF_ARG(ctx, !((flags & LFPSQP_PROJCG_START_GIVEN) && (flags & LFPSQP_PROJCG_START_PROJECTED)));
     LF_ARG(ctx, work->g && work->d && work->rp && work->Utr);

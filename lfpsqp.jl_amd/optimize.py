@@ -216,7 +216,8 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     if tri_off is not None:
         if ineq:
             raise NotImplementedError("a tridiagonal Hessian with bounds: pass hess_lag_vec_ as a callable (the generic path)")
-        fuse_tangent = False                  # (the tangent step's pass hands projcg_ a started solve, which the tridiagonal iteration does not take)
+        # (the tangent step's pass still hands projcg_ r0 and U'r0 -- neither involves A --, but never its folded initial projection, whose
+        # sums are formed with the diagonal alone: init_fold stays off below)
     if tri_off is not None:
         from .projcg import TridiagonalOperator
         a_diag = projcgwork.placed_extra[0] if projcgwork.placed_extra else newvec()
@@ -320,7 +321,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
                 # (flag 1 = LFPSQP_TANGENT_INIT_PROJCG: the pass is projcg!'s initial projection as well -- src/projcg.jl:58-62 -- with U'r0 from
                 # the Gram matrix; projcg_ then starts with its first iteration, start_projected=True.  Only where the Gram matrix resolves
                 # I - U'U: a full-rank block with cond^2 <= 10, the fast path of the factorisation; otherwise projcg_ measures U'r0 itself)
-                init_fold = bool(rank == m and S_[0] * S_[0] <= 10.0 * S_[m - 1] * S_[m - 1])
+                init_fold = bool(tri_off is None and rank == m and S_[0] * S_[0] <= 10.0 * S_[m - 1] * S_[m - 1])
                 ctx.check(ctx.L.lfpsqp_tangent_step(ctx.h, C.byref(bs), sig_c.ctypes.data, vt_c.ctypes.data, m, Jtd.ctypes.data, Ggram.ctypes.data, d.h,
                                                     C.byref(cc) if cc is not None else None, x.h, a_diag.h,
                                                     C.byref(idc) if ineq else None, hx.h if ineq else None, idecomp.S.h if ineq else None,

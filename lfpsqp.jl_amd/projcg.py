@@ -263,17 +263,17 @@ def projcg_(x: DeviceVector, lam: DeviceVector | None, A, U, b: DeviceVector, c:
         if rc != -5:                 # LFPSQP_ERR_UNSUPPORTED (a shape without the one-pass iteration): the callback path below
             ctx.check(rc)
             return iters.value, nr.value
-    if isinstance(A, TridiagonalOperator) and isinstance(U, DeviceBasis) and not stacked and not (resume or start_given or start_projected) and getattr(A, "fused", True):
+    if isinstance(A, TridiagonalOperator) and isinstance(U, DeviceBasis) and not stacked and not (resume or start_projected) and getattr(A, "fused", True):
         if getattr(work, "Av", None) is None:
             work.Av = DeviceVector(ctx, n)
         iters = _capi.c_i64()
         nr = C.c_double()
         a_c, u_c, w_c = A._c(), U._c(), work._c()
-        flags = WANT_LAMBDA if (want_lambda and lam is not None) else 0
+        flags = (WANT_LAMBDA if (want_lambda and lam is not None) else 0) | (START_GIVEN if start_given else 0)
         rc = ctx.L.lfpsqp_projcg_tridiag(ctx.h, x.h, lam.h if lam is not None else None, C.byref(a_c), work.Av.h, C.byref(u_c), b.h,
                                          c.h if c is not None else None, float(tol), int(maxit), int(n_global), flags,
                                          C.byref(w_c), C.byref(iters), C.byref(nr))
-        if rc != -5:                 # LFPSQP_ERR_UNSUPPORTED (no one-pass iteration for this shape / more than one rank): the callback path below
+        if rc != -5 or start_given:  # LFPSQP_ERR_UNSUPPORTED (no one-pass iteration for this shape / more than one rank): the callback path below
             ctx.check(rc)
             return iters.value, nr.value
     if resume or start_given or start_projected:

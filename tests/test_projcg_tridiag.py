@@ -179,7 +179,20 @@ def test_chain_objective_problem_class_follows_the_oracle(dev_ctx):
     par = dict(do_project_retract=False, maxiter=maxiter, tn_kappa=1e-6)
     xr, objr, lamr, tir = R.optimize(f, grad_, P0.eq.c_, P0.eq.jac_, hlv_, x0, None, None, m, R.LFPSQPParams(disp=R.DisplayOption.off, **par), trace=tr0)
     P = L.ChainSeparableLinear(ctx, n, m, ctx.matrix(n, m).hash_fill(1), P0.eq.b, kind, a, c, kappa=kappa)
-    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(disp=L.DisplayOption.off, **par), trace=tr)
+    import sys
+    OPT = sys.modules["lfpsqp_jl_amd.optimize"]            # (the package attribute `optimize` is the function, not the module)
+    seen, orig = [], OPT.projcg_
+
+    def spy(*args, **kw):
+        seen.append((type(args[2]).__name__, bool(kw.get("start_given")), bool(kw.get("start_projected"))))
+        return orig(*args, **kw)
+    OPT.projcg_ = spy
+    try:
+        x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(disp=L.DisplayOption.off, **par), trace=tr)
+    finally:
+        OPT.projcg_ = orig
+    # every truncated-Newton solve ran with the tridiagonal operator, started from the tangent step's state, never from its folded projection
+    assert seen and all(s == ("TridiagonalOperator", True, False) for s in seen)
     assert ti.iter == tir.iter and ti.condition.name == tir.condition.name
     assert any((t.get('tn_iter') or 0) > 3 for t in tr0)                       # the Newton systems take several iterations
     assert _compare_traces(tr, tr0) is None
