@@ -278,6 +278,7 @@ mutable struct DeviceOptions
     pp_precondition::Bool       # ProjPenalty's inner solves with the exact preconditioner of their operator (lfpsqp_pcg_pre); false = the reference's live path
     warm_factorize::Bool        # the small eigenproblem of the tangent setup starts from the previous outer iteration's Vt (lfpsqp_factorize_hint)
     fused_tangent_step::Bool    # Jct'd rides with the Gram pass; ONE pass projects d, completes the Hessian diagonal and forms projcg!'s first U'r (lfpsqp_tangent_step)
+    tridiagonal_one_pass::Bool  # tridiagonal Lagrangian Hessians (hess_offdiag) on the one-pass solver (lfpsqp_projcg_tridiag); false: through the callback path
 end
 mutable struct HipContext
     h::Ptr{Cvoid}
@@ -288,7 +289,7 @@ mutable struct HipContext
         r = Ref{Ptr{Cvoid}}(C_NULL)
         rc = c_ctx_create(Cint(device), r)
         rc == 0 || throw(HipError(rc, "lfpsqp_ctx_create failed: no usable MI355X (there is no CPU fallback)"))
-        ctx = new(r[], 0, 1, DeviceOptions(0, 3, true, false, true, true))
+        ctx = new(r[], 0, 1, DeviceOptions(0, 3, true, false, true, true, true))
         finalizer(c -> c_ctx_destroy(c.h), ctx)
         return ctx
     end
@@ -1416,7 +1417,9 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     # and the work vectors are placed against Jct
     # (the library says whether this context can run projcg! without Z for this Jct: one-pass kernels on, shape inside their limits, or a
     # sparse twin the nonzero path covers; otherwise Z is materialised and every path has its two-pass form)
-    factored_basis = ctx.options.factored_basis && diagonal_hessian && 4 <= m <= 1024 && factored_basis_supported(ctx, Jct, jsp === nothing ? C_NULL : jsp.h)
+    # (a tridiagonal Hessian sent through the callback path -- DeviceOptions.tridiagonal_one_pass off -- needs the materialised basis)
+    tri_callback = diagonal_hessian && hess_offdiag(hess_lag_vec!) !== nothing && !ctx.options.tridiagonal_one_pass
+    factored_basis = ctx.options.factored_basis && diagonal_hessian && !tri_callback && 4 <= m <= 1024 && factored_basis_supported(ctx, Jct, jsp === nothing ? C_NULL : jsp.h)
     # allocation by trial pays after several hundred projected-CG iterations; a Lagrangian Hessian that is a multiple of I (config 3) ends every
     # truncated-Newton solve after one: such a run takes its first allocations
     saved_tries = ctx.options.placement_tries
@@ -1445,6 +1448,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     tri_off = diagonal_hessian ? hess_offdiag(hess_lag_vec!) : nothing
     if tri_off !== nothing
         ineq && error("a tridiagonal Hessian with bounds: pass hess_lag_vec! as a function (the generic path)")
+        ctx.options.tridiagonal_one_pass || (fuse_tangent = false)     # (the callback path starts its solves itself)
     end                                                       # (the tangent step still hands projcg! r0 and U'r0; never its folded initial projection)
     ineq_rhs = (fuse_tangent && ineq) ? DeviceVector(ctx, n) : nothing
     Jtd = zeros(max(m, 1)); Utd = zeros(max(m, 1))
@@ -1596,7 +1600,11 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
                 else
                     hess_diag!(hess_lag_vec!, a_diag, x, λ_kkt)
                 end
-                if tri_off !== nothing
+                if tri_off !== nothing && !ctx.options.tridiagonal_one_pass
+                    Atri = TridiagonalOperator(0.0, a_diag, tri_off)
+                    tn_iter, tn_res = projcg!(newton_d, nothing, (dest, src) -> mul!(dest, Atri, src), Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
+                                              work=projcgwork, n_global=nglob)
+                elseif tri_off !== nothing
                     tn_iter, tn_res = projcg!(newton_d, nothing, TridiagonalOperator(0.0, a_diag, tri_off), Qview, d, nothing; tol=tol, maxit=param.tn_maxiter,
                                               work=projcgwork, n_global=nglob, start_given=fused_now)
                 else

@@ -183,7 +183,9 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
     # The LIBRARY says whether this context can run projcg without Z for this Jct (one-pass kernels on, shape and leading dimension inside
     # their limits, or a sparse twin the nonzero path covers); where it cannot (LFPSQP_ONEPASS=-1, ld beyond the 32-bit lane offsets ...)
     # Z is materialised and every path has its two-pass form.
-    factored = (bool(ctx.options.factored_basis) and diagonal_hessian and 4 <= m <= 1024
+    # (a tridiagonal Hessian sent through the callback path -- DeviceOptions.tridiagonal_one_pass off -- needs the materialised basis)
+    tri_callback = diagonal_hessian and getattr(hess_lag_vec_, "offdiag", None) is not None and not bool(getattr(ctx.options, "tridiagonal_one_pass", True))
+    factored = (bool(ctx.options.factored_basis) and diagonal_hessian and not tri_callback and 4 <= m <= 1024
                 and ctx.factored_basis_supported(Jct, getattr(c_, "Jsp", None)))
     # Allocation by trial costs tens of milliseconds (18 timed launches of F at n = 1e7, m = 128: 36 ms) and returns 3 % of every projected-CG
     # iteration: it pays after several hundred iterations.  A Lagrangian Hessian that is a multiple of the identity (f = |x - xc|^2 under linear
@@ -218,10 +220,13 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             raise NotImplementedError("a tridiagonal Hessian with bounds: pass hess_lag_vec_ as a callable (the generic path)")
         # (the tangent step's pass still hands projcg_ r0 and U'r0 -- neither involves A --, but never its folded initial projection, whose
         # sums are formed with the diagonal alone: init_fold stays off below)
+        if not bool(getattr(ctx.options, "tridiagonal_one_pass", True)):
+            fuse_tangent = False              # (the callback path starts its solves itself)
     if tri_off is not None:
         from .projcg import TridiagonalOperator
         a_diag = projcgwork.placed_extra[0] if projcgwork.placed_extra else newvec()
         newton_map = TridiagonalOperator(0.0, a_diag, tri_off)
+        newton_map.fused = bool(getattr(ctx.options, "tridiagonal_one_pass", True))
     elif diagonal_hessian:
         a_diag = projcgwork.placed_extra[0] if projcgwork.placed_extra else newvec()
         newton_map = DiagOperator(0.0, a_diag)

@@ -96,3 +96,7 @@ class DeviceOptions:
     # (lfpsqp_factorize_rhs), and ONE pass projects the step, completes the Hessian diagonal and forms projcg!'s first U'r
     # (lfpsqp_tangent_step, LFPSQP_PROJCG_START_GIVEN).  False: src/optimize.jl:305-343 and src/projcg.jl:55-59 statement by statement
     fused_tangent_step: bool = True
+    # a problem class with a TRIDIAGONAL Lagrangian Hessian (an ``offdiag`` vector next to ``diag_``) gets its truncated-Newton solves on the one-pass
+    # iteration (lfpsqp_projcg_tridiag: U'AU by two or three Gram passes per solve, then 1.85 instead of 3.3 ms per iteration at (1e7, 128) -- ahead
+    # from six to nine iterations per solve on).  False: the same operator through the callback path (lfpsqp_projcg_op), identical iterates
+    tridiagonal_one_pass: bool = True

@@ -195,6 +195,14 @@ def test_chain_objective_problem_class_follows_the_oracle(dev_ctx):
     assert seen and all(s == ("TridiagonalOperator", True, False) for s in seen)
     assert ti.iter == tir.iter and ti.condition.name == tir.condition.name
     assert any((t.get('tn_iter') or 0) > 3 for t in tr0)                       # the Newton systems take several iterations
+    # DeviceOptions.tridiagonal_one_pass = False: the same operator through the callback path, the same trajectory
+    ctx.options.tridiagonal_one_pass = False
+    try:
+        tr2 = []
+        x2, obj2, lam2, ti2 = P.optimize(x0, L.LFPSQPParams(disp=L.DisplayOption.off, **par), trace=tr2)
+    finally:
+        ctx.options.tridiagonal_one_pass = True
+    assert ti2.iter == ti.iter and _compare_traces(tr2, tr0) is None and np.linalg.norm(x2 - x) <= 1e-10 * np.linalg.norm(x)
     assert _compare_traces(tr, tr0) is None
     np.testing.assert_allclose(obj, objr, rtol=1e-11)
     np.testing.assert_allclose(lam, lamr, rtol=1e-6, atol=1e-9)
