@@ -79,3 +79,29 @@ for bounds in (False,True):
     out=prob.optimize(0.1*synth.hash_vector(6,n),L.LFPSQPParams(do_project_retract=False,disp=L.DisplayOption.off,maxiter=2))
     print('opt elementwise dense',bounds,out[3].iter)
 print("ASAN RUN 4 DONE")
+# round 5: tridiagonal / low-rank one-pass solvers (sizes at tile and padding multiples: the neighbour loads at the ends), the chain-objective class
+# through optimize (tangent step + START_GIVEN + tridiagonal solver), the wide matrix-core batched Newton step
+for n,m,fac in ((1024,128,False),(2048,33,True),(300,260,False),(64,4,False)):
+    Jh=synth.hash_matrix(5,n,m); J=ctx.matrix(n,m,np.asfortranarray(Jh)); Z=ctx.matrix(n,m); W=np.zeros((m,m),order='F')
+    S,Vt,r=L.ksvd_(J,Z,W=W)
+    U=L.DeviceBasis(None,r,generator=(J,W)) if fac else L.DeviceBasis(Z)
+    a=ctx.vector(n).hash_fill(3,0,4.0,6.0); off=ctx.vector(n).hash_fill(15,0,0.9,0.0); b=ctx.vector(n).hash_fill(4)
+    x,lam=ctx.vector(n),ctx.vector(m)
+    it,nr=L.projcg_(x,lam,L.TridiagonalOperator(0.0,a,off),U,b,None,tol=1e-9,maxit=30)
+    V=ctx.matrix(n,3).hash_fill(17,0,n,n**-0.5)
+    it2,nr2=L.projcg_(x,lam,L.LowRankOperator(0.0,a,V,3,np.array([3.0,-0.4,1.5])),U,b,None,tol=1e-9,maxit=30)
+    print('tridiagonal / low rank',n,m,fac,it,nr,it2,nr2)
+n,m=515,5
+P0=synth.BallBoxProblem(n,m)
+Pc=L.ChainSeparableLinear(ctx,n,m,ctx.matrix(n,m).hash_fill(1),P0.eq.b,1,0.5+synth.hash_vector(21,n)**2,0.3*synth.hash_vector(22,n),kappa=1.7)
+out=Pc.optimize(synth.hash_vector(2,n),L.LFPSQPParams(do_project_retract=False,disp=L.DisplayOption.off,maxiter=3,tn_kappa=1e-6))
+print('opt chain',out[3].iter)
+n,m=300,140
+P0=synth.BallBoxProblem(n,m)
+Jct=ctx.matrix(n+1,m+1).hash_fill(1,0,n,1.0,n,m)
+Pw=L.QuadLinearBallBox(ctx,n,m,Jct,P0.eq.b,R2=P0.R2,xl=P0.xl,xu=P0.xu)
+ctx.options.ls_batch=8
+out=Pw.optimize(P0.x0,L.LFPSQPParams(do_project_retract=False,disp=L.DisplayOption.off,maxiter=2,maxiter_retract=20))
+ctx.options.ls_batch=0
+print('opt wide batched',out[3].iter)
+print("ASAN RUN 5 DONE")
