@@ -36,6 +36,8 @@ def _usable_cpus() -> int:
 _NT = str(max(1, min(_usable_cpus(), 8)))
 for _var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_var, _NT)
+# the CPU HIP emulator runs the workgroups of a launch on a few OS threads (4 unless told otherwise): use the CPUs this box allows
+os.environ.setdefault("HIPEMU_THREADS", _NT)
 _BLAS_LIMIT = None
 
 

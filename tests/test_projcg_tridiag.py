@@ -207,3 +207,30 @@ def test_chain_objective_problem_class_follows_the_oracle(dev_ctx):
     np.testing.assert_allclose(obj, objr, rtol=1e-11)
     np.testing.assert_allclose(lam, lamr, rtol=1e-6, atol=1e-9)
     assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
+
+
+def test_tridiagonal_operator_refuses_row_shards(emu_lib):
+    """A context with a communicator holds one SHARD of the rows: the couplings across the shard boundaries are not its to apply.  Both the
+    one-pass solver and the operator on its own answer LFPSQP_ERR_UNSUPPORTED (no silently dropped couplings); projcg_ raises."""
+    import ctypes as C
+    from lfpsqp_jl_amd import _capi
+    ctx = L.Context(0, emu_lib)
+    try:
+        ctx.comm_init_callback(0, 1, lambda ptr, count, op, stream: 0)          # (one rank, but a communicator: the shard case)
+        n, m = 700, 8
+        a = 4.0 * synth.hash_vector(3, n) + 5.0
+        e = 0.8 * synth.hash_vector(15, n - 1)
+        Uh, _ = np.linalg.qr(synth.hash_matrix(1, n, m))
+        U = L.DeviceBasis(ctx.matrix(n, m, np.asfortranarray(Uh)))
+        A = _operator(ctx, a, e)
+        b, x, lam, Av = ctx.vector(n, synth.hash_vector(4, n)), ctx.vector(n), ctx.vector(m), ctx.vector(n)
+        work = L.ProjCGWork(ctx, n, m)
+        it, nr = _capi.c_i64(), C.c_double()
+        a_c, u_c, w_c = A._c(), U._c(), work._c()
+        rc = ctx.L.lfpsqp_projcg_tridiag(ctx.h, x.h, lam.h, C.byref(a_c), Av.h, C.byref(u_c), b.h, None, 1e-10, 100, n, 1, C.byref(w_c), C.byref(it), C.byref(nr))
+        assert rc == -5
+        assert ctx.L.lfpsqp_tridiag_mul(ctx.h, C.byref(a_c), b.h, Av.h) == -5
+        with pytest.raises(L.LfpsqpError):
+            L.projcg_(x, lam, A, U, b, None, tol=1e-10, work=work)
+    finally:
+        ctx.close()
