@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -267,6 +268,54 @@ inline int num_workers() {
     int n = e ? std::atoi(e) : 4;
     return n < 1 ? 1 : n;
 }
+// Helper threads of a launch, kept for the life of the process (a launch used to start and join fresh OS threads: tens of microseconds each,
+// several per launch, millions of launches in a test run).  One launch at a time (the library launches from one host thread); the pool is
+// leaked on purpose -- its threads sleep on a condition variable until the process exits.
+struct HelperPool {
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::vector<std::thread> th;
+    const std::function<void()>* job = nullptr;
+    unsigned long epoch = 0;
+    int want = 0, pending = 0;
+    void helper(int idx) {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void()>* j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_job.wait(lk, [&] { return epoch != seen; });
+                seen = epoch;
+                if (idx < want) j = job;
+            }
+            if (j) {
+                (*j)();
+                std::lock_guard<std::mutex> lk(m);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void run(int n, const std::function<void()>& work) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            while ((int)th.size() < n) {
+                const int idx = (int)th.size();
+                th.emplace_back([this, idx] { helper(idx); });
+                th.back().detach();
+            }
+            job = &work;
+            want = pending = n;
+            ++epoch;
+        }
+        cv_job.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        job = nullptr;
+    }
+};
+inline HelperPool& helpers() { static HelperPool* p = new HelperPool(); return *p; }
+
 template <class K, class... Args>
 void launch(K kernel, dim3 grid, dim3 block, Args... args) {
     unsigned nblocks = grid.x * grid.y * grid.z;
@@ -295,10 +344,7 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
     int nw = num_workers();
     if ((unsigned)nw > nblocks) nw = (int)nblocks;
     if (nw <= 1) { worker(); return; }
-    std::vector<std::thread> th;
-    for (int i = 1; i < nw; ++i) th.emplace_back(worker);
-    worker();
-    for (auto& t : th) t.join();
+    helpers().run(nw - 1, worker);          // nw - 1 pooled helper threads + this one
 }
 template <class T> inline T shfl_generic(T v, unsigned src_lane_in_wave) {
     static_assert(sizeof(T) <= 8, "shuffle payload");
