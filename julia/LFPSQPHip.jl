@@ -1770,6 +1770,53 @@ function optimize(P::SeparableLinearBallBox, x0::Vector{Float64}, param::LFPSQPP
     return x[1:B.n], obj, λ, info
 end
 
+# ---- separable objective plus a CHAIN term: f(x) = Σ φ(x_i - c_i; a_i) + κ/2 Σ_{i<n} (x_{i+1} - x_i)² under dense linear equalities ----------------
+# (the kind of objective whose Hessian the reference reaches only through hess_lag_vec!, src/autodiff_generators.jl:72-107).  The Lagrangian
+# Hessian is TRIDIAGONAL: diagonal φ''(x_i) + κ deg_i (deg = 1 at the two ends, 2 inside), couplings -κ.  optimize_core finds the couplings
+# through hess_offdiag and runs its truncated-Newton solves on the one-pass solver (lfpsqp_projcg_tridiag).  One rank, no ball, no bounds.
+struct ChainSeparableLinear
+    sep::SeparableLinearBallBox
+    κ::Float64
+    deg::DeviceVector           # κ .* degree of the path graph
+    off::DeviceVector           # -κ (entry n is ignored)
+    tmp::DeviceVector
+end
+function ChainSeparableLinear(ctx::HipContext, n::Int, m::Int, Jct::DeviceMatrix, b::Vector{Float64}, kind::Int, a::Vector{Float64}, c::Vector{Float64}; κ::Float64=1.0)
+    ctx.nranks == 1 || error("chain objective: one rank (the couplings would cross the shard boundaries)")
+    sep = SeparableLinearBallBox(ctx, n, m, Jct, b, kind, a, c)
+    deg = fill(2.0 * κ, n); deg[1] = deg[n] = n > 1 ? κ : 0.0
+    return ChainSeparableLinear(sep, κ, upload!(DeviceVector(ctx, n), deg), upload!(DeviceVector(ctx, n), fill(-κ, n)), DeviceVector(ctx, n))
+end
+laplacian(P::ChainSeparableLinear) = TridiagonalOperator(0.0, P.deg, P.off)         # κ L, L = the path graph's Laplacian
+function objective(P::ChainSeparableLinear, x::DeviceVector)
+    mul!(P.tmp, laplacian(P), x)
+    return objective(P.sep, x) + 0.5 * dot(x, P.tmp)
+end
+function gradient!(P::ChainSeparableLinear, g::DeviceVector, x::DeviceVector)
+    gradient!(P.sep, g, x)
+    mul!(P.tmp, laplacian(P), x)
+    check(x.ctx, c_axpby(x.ctx.h, 1.0, P.tmp.h, 1.0, g.h))
+    return g
+end
+function hess_diag!(P::ChainSeparableLinear, hx::DeviceVector, x::DeviceVector, λ::Vector{Float64})
+    hess_diag!(P.sep, hx, x, λ)
+    check(x.ctx, c_axpby(x.ctx.h, 1.0, P.deg.h, 1.0, hx.h))
+    return hx
+end
+function hess_diag_objective!(P::ChainSeparableLinear, hx::DeviceVector, x::DeviceVector)
+    hess_diag_objective!(P.sep, hx, x)
+    check(x.ctx, c_axpby(x.ctx.h, 1.0, P.deg.h, 1.0, hx.h))
+    return hx
+end
+hess_constraints(P::ChainSeparableLinear) = P.sep.base.cons
+hess_offdiag(P::ChainSeparableLinear) = P.off
+function optimize(P::ChainSeparableLinear, x0::Vector{Float64}, param::LFPSQPParams=LFPSQPParams())
+    B = P.sep.base
+    x, obj, λ, info = optimize_core(B.ctx, x -> objective(P, x), (g, x) -> gradient!(P, g, x), B.cons, (J, cv, x) -> jac!(B.cons, J, cv, x), P,
+                                    x0, nothing, nothing, B.m, param; n_global=B.n_global)
+    return x[1:B.n], obj, λ, info
+end
+
 # ---- device-resident class with NONLINEAR equalities: separable objective under ElementwiseConstraints, optional box bounds ----------
 struct SeparableElementwiseBox
     ctx::HipContext
@@ -1868,7 +1915,7 @@ optimize(ctx::HipContext, f, grad!, c!, jac_c!, d!, jac_d!, hess_lag_vec!, x0::V
 
 export HipContext, HipError, DeviceOptions, DeviceVector, StackedVector, DeviceMatrix, SparseMatrix, spmv_t!, spmv_n!, to_dense!, DeviceBasis, DiagOperator, LowRankOperator, InequalityData, InequalityDecomp,
        InequalityDecompProject, ProjCGWork, DeviceConstraints, NR, ProjPenalty, ProjPenaltyWork, Euclidean, YRetract, ArmijoWork,
-       ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, SeparableElementwiseBox, ElementwiseConstraints,
+       ExactLinesearchWork, LFPSQPParams, TerminationInfo, QuadLinearBallBox, SeparableLinearBallBox, ChainSeparableLinear, TridiagonalOperator, SeparableElementwiseBox, ElementwiseConstraints,
        sin_system_constraints, sphere_system_constraints, clone, rowscale!, set_placement!, basis_and_vectors_placed, vectors_placed, placement_info, upload!, download, upload2!, download2, projcg!, retract!,
        retract_nr_batch!, pcg!, ProjPrecondition, ksvd!, armijo!, exact_linesearch!, optimize, optimize_core, hess_diag!, jac!, comm_unique_id, comm_init!, comm_p2p_export, comm_init_p2p!,
        shard_range, sync

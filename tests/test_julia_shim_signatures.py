@@ -108,7 +108,7 @@ def julia_ccalls():
 
 def julia_structs():
     out = {}
-    for m in re.finditer(r"^struct (C\w+)[^\n]*\n(.*?)^end", JULIA, flags=re.S | re.M):
+    for m in re.finditer(r"^struct (C[A-Z]\w+)[^\n]*\n(.*?)^end", JULIA, flags=re.S | re.M):      # (the C-layout mirrors: CDiagOp, CBasis ...)
         fields = []
         for line in m.group(2).splitlines():
             line = line.split("#")[0].strip()
