@@ -158,8 +158,13 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
             }
         }
     };
-    const int64_t G = ngroups;
-    int64_t step = g;
+    // Row group g takes the steps g, g + ngroups, ... -- except for the SHIFTED operand, whose last row of a step needs the first row of the NEXT
+    // step: there a group takes a contiguous chunk of steps, so that this row is in the line the same workgroup loads next anyway (dealt round
+    // robin the neighbour step belongs to another workgroup, usually on another XCD: the PMC pass showed 20.6 GB fetched for a 10.3 GB matrix)
+    const int64_t chunk = (nsteps + ngroups - 1) / ngroups;
+    const int64_t G = SHIFT ? 1 : ngroups;
+    const int64_t send = SHIFT ? ((int64_t)(g + 1) * chunk < nsteps ? (int64_t)(g + 1) * chunk : nsteps) : nsteps;
+    int64_t step = SHIFT ? (int64_t)g * chunk : g;
     double* out = part + (int64_t)g * part_ld + (int64_t)pidx * (kPanel * kPanel);
     // The MFMA operands of one k-group (4 of the 16 rows of a step): lane (kq = lane / 16, cc = lane % 16) holds row 4 kg + kq of
     // column cc of each 16-column tile it needs.  DIAG (symmetric block, upper tile triangle only -- the host mirrors it, gram_impl):
@@ -203,22 +208,22 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
         // too -- which is why the one barrier of a step sits in its middle: by then every wave has written its share of the next buffer
         // and has issued all its reads of this one (which the next step overwrites).
         Ops o0, o1;
-        if (step < nsteps) {
+        if (step < send) {
             load_step(Fc, 0, step);
             write_lds(0, 0);
         }
-        if (step + G < nsteps) load_step(Fc, 0, step + G);
+        if (step + G < send) load_step(Fc, 0, step + G);
         __syncthreads();
-        if (step < nsteps) read_ops(o0, 0, 0);
-        while (step < nsteps) {
+        if (step < send) read_ops(o0, 0, 0);
+        while (step < send) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {          // LDS buffer i holds this step
-                if (step >= nsteps) break;
-                const bool more = step + G < nsteps;
+                if (step >= send) break;
+                const bool more = step + G < send;
                 read_ops(o1, i, 1);
                 mfma_ops(o0);
                 if (more) write_lds(i ^ 1, 0);
-                if (step + 2 * G < nsteps) load_step(Fc, 0, step + 2 * G);
+                if (step + 2 * G < send) load_step(Fc, 0, step + 2 * G);
                 read_ops(o0, i, 2);
                 mfma_ops(o1);
                 read_ops(o1, i, 3);                 // the last read of this buffer: issued before the barrier, after which it may be rewritten
