@@ -615,9 +615,19 @@ int lfpsqp_retract_nr(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigm
  * trials by one Newton step.  Per trial the arithmetic, the convergence test and the outputs are those of
  * lfpsqp_retract_nr: xnew[b], cval[b*m .. b*m+m), flags[b], iters[b].  Needs the one-stream step (U->A / U->W known,
  * device-resident constraints without a sparse twin, 4..1024 columns); returns LFPSQP_ERR_UNSUPPORTED otherwise (retract one by one then).
- * Two trials run on the VALU form of the one-pass kernel (up to four where the other form does not apply); 3..16 on the matrix cores (v_mfma_f64_16x16x4_f64: both products of a
- * step are contractions once the trials are stacked), for up to 132 generator columns and 128 linear constraints.
- * lfpsqp_retract_nr_batch_width: how many trials a pass takes for this basis and these constraints -- 16, 4 or 0 (cannot batch). */
+ * Two modes (lfpsqp_ctx_set_nr_batch_mode):
+ *   LFPSQP_NR_BATCH_EXACT (default): up to 4 trials per pass on the VALU form of the one-pass kernel, with the rows cut into the spans of
+ *     the single-trial step's launch and the second stage shaped like its own -- every sum of a trial is formed from the same operands in
+ *     the same order as in lfpsqp_retract_nr, so xnew[b], cval, flags[b] and iters[b] are BIT FOR BIT those of the one-by-one call.  A
+ *     linesearch that batches its failing trial steps (src/linesearch.jl:57-60) is then the same search, also where it is chaotic.
+ *   LFPSQP_NR_BATCH_MATRIX_CORES (opt-in): 3..16 trials on the matrix cores (v_mfma_f64_16x16x4_f64: both products of a step are contractions
+ *     once the trials are stacked; up to 132 generator columns and 128 linear constraints; 8 trials from 133 to 528 columns).  Sums in
+ *     groups of four rows: equal to lfpsqp_retract_nr up to rounding (1e-12 for trials that converge from nearby) -- a trial that runs into
+ *     its iteration limit may end elsewhere, and a chaotic search may then accept another step than the one-by-one search.
+ * lfpsqp_retract_nr_batch_width: how many trials a pass takes for this basis and these constraints in the current mode -- 16, 8, 4 or 0
+ * (cannot batch). */
+enum { LFPSQP_NR_BATCH_EXACT = 0, LFPSQP_NR_BATCH_MATRIX_CORES = 1 };
+int lfpsqp_ctx_set_nr_batch_mode(lfpsqp_ctx* ctx, int mode);
 int lfpsqp_retract_nr_batch_width(const lfpsqp_ctx* ctx, const lfpsqp_basis* U, const lfpsqp_constraints* cons, int* width);
 int lfpsqp_retract_nr_batch(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const double* Sigma, const double* Vt, int64_t m,
                             const lfpsqp_constraints* cons, const lfpsqp_ineq_data* idata, int nb, const lfpsqp_vec* const* xtilde,

@@ -167,6 +167,7 @@ c_vec_hash_fill(ctx, v, seed, off, scale, shift) = ccall((:lfpsqp_vec_hash_fill,
 c_mat_alloc(ctx, n, m, out) = ccall((:lfpsqp_mat_alloc, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), ctx, n, m, out)
 # placement-tuned allocation (FINDINGS.md 6): candidate allocations tried with the fused projected-CG kernel, the fastest kept
 c_ctx_set_placement(ctx, tries) = ccall((:lfpsqp_ctx_set_placement, lib), Cint, (Ptr{Cvoid}, Cint), ctx, tries)
+c_ctx_set_nr_batch_mode(ctx, mode) = ccall((:lfpsqp_ctx_set_nr_batch_mode, lib), Cint, (Ptr{Cvoid}, Cint), ctx, mode)
 c_mat_alloc_placed(ctx, n, m, out) = ccall((:lfpsqp_mat_alloc_placed, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), ctx, n, m, out)
 c_vecs_alloc_placed(ctx, M, ncols, n, count, out) = ccall((:lfpsqp_vecs_alloc_placed, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Ptr{Ptr{Cvoid}}), ctx, M, ncols, n, count, out)
 c_basis_work_alloc_placed(ctx, n, m, nvec, count, M, out) = ccall((:lfpsqp_basis_work_alloc_placed, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ref{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), ctx, n, m, nvec, count, M, out)

@@ -97,6 +97,7 @@ _SIGS = {
     "lfpsqp_mat_alloc": [P, c_i64, c_i64, C.POINTER(P)],
     "lfpsqp_mat_free": [P, P],
     "lfpsqp_ctx_set_placement": [P, C.c_int],
+    "lfpsqp_ctx_set_nr_batch_mode": [P, C.c_int],
     "lfpsqp_mat_alloc_placed": [P, c_i64, c_i64, C.POINTER(P)],
     "lfpsqp_vecs_alloc_placed": [P, P, c_i64, c_i64, C.c_int, C.POINTER(P)],
     "lfpsqp_basis_work_alloc_placed": [P, c_i64, c_i64, c_i64, C.c_int, C.POINTER(P), C.POINTER(P)],

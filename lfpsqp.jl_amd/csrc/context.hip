@@ -321,6 +321,7 @@ int lfpsqp_ctx_create(int device, lfpsqp_ctx** out) {
     if (const char* e = getenv("LFPSQP_VEC_BLOCKS")) ctx->tune_vec_blocks = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("LFPSQP_NRB_MFMA")) ctx->tune_nrb_mfma = atoi(e) > 0 ? 1 : (atoi(e) < 0 ? -1 : 0);
     if (const char* e = getenv("LFPSQP_GPING")) ctx->tune_gping = atoi(e) == 1 ? 1 : 0;
+    if (const char* e = getenv("LFPSQP_NRB_WG_CAP")) ctx->batch_wg_cap = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("LFPSQP_STAGE_ROUNDS")) ctx->stage_cap = atoi(e) > 0 ? atoi(e) : 0;
     *out = ctx;
     return 0;
@@ -632,6 +633,12 @@ int lfpsqp_vec_free(lfpsqp_ctx* ctx, lfpsqp_vec* v) {
 int lfpsqp_ctx_set_placement(lfpsqp_ctx* ctx, int tries) {
     LF_ARG(ctx, ctx && tries >= 1 && tries <= 8);
     ctx->place_tries = tries;
+    return 0;
+}
+
+int lfpsqp_ctx_set_nr_batch_mode(lfpsqp_ctx* ctx, int mode) {
+    LF_ARG(ctx, ctx && (mode == LFPSQP_NR_BATCH_EXACT || mode == LFPSQP_NR_BATCH_MATRIX_CORES));
+    ctx->tune_nrb_mfma = mode == LFPSQP_NR_BATCH_MATRIX_CORES ? 0 : -1;
     return 0;
 }
 

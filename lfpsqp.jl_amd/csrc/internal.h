@@ -111,7 +111,8 @@ struct lfpsqp_ctx {
     int tune_onepass = 0;
     int tune_spgram = 0;    // lfpsqp_factorize_sp: 0 = Gram matrix from the nonzeros (sp_gram), -1 = on a dense copy (env LFPSQP_SPGRAM=-1; A/B timing)
     int tune_vec_blocks = 0;   // vec_kernel: 0 = one tile per block (4096 blocks at most with reductions); > 0 = at most this many blocks (env LFPSQP_VEC_BLOCKS)
-    int tune_nrb_mfma = 0;     // batched Newton step: 0 = matrix cores for more than 4 trials, 1 = for every batch, -1 = never (env LFPSQP_NRB_MFMA)
+    int tune_nrb_mfma = -1;    // batched Newton step: -1 = the EXACT batch only (default; lfpsqp_ctx_set_nr_batch_mode), 0 = matrix cores for more than
+                               // 2 trials, 1 = for every batch (env LFPSQP_NRB_MFMA overrides at context creation)
     int tune_gping = 0;     // fused projected-CG iteration: 0 = the residual updated in place, 1 = two buffers alternating (lfpsqp_ctx_set_residual_buffers)
 
     bool real_gpu = false;   // gcnArchName "gfx..." (false only in the CPU emulator build of the tests)
@@ -134,6 +135,7 @@ struct lfpsqp_ctx {
         int64_t n_global = 0;
         uint64_t epoch = 0;          // launch_epoch when the call returned: ANY kernel the library queued since then voids the state
     } pcg_resume;
+    int batch_wg_cap = 0;            // test hook (env LFPSQP_NRB_WG_CAP at context creation): workgroups per CU of the exact batch's launch (then several virtual spans each)
     int stage_cap = 0;               // test hook (env LFPSQP_STAGE_ROUNDS at context creation): cap on the rounds per burst of staged stores
     uint64_t launch_epoch = 0;       // bumped by every launch helper (run_vec / run_gemv_* / run_onepass / launch_reduce)
 
@@ -199,13 +201,16 @@ inline int64_t ntiles_of(int64_t n, int ks) { return (n + (int64_t)kSlabRows * k
 constexpr int kReduceRowBlocks = 16;
 inline size_t reduce_scratch(int part_ld) { return (size_t)kReduceRowBlocks * part_ld; }
 template <class POST>
-int launch_reduce(lfpsqp_ctx* ctx, int64_t nrows, int ncols, int part_ld, unsigned ismax, double* out, POST post) {
+int launch_reduce(lfpsqp_ctx* ctx, int64_t nrows, int ncols, int part_ld, unsigned ismax, double* out, POST post, int ncols_like = 0) {
     ++ctx->launch_epoch;
+    // (ncols_like > 0: the shape of the reduction -- columns per block, hence row groups per column, and one stage or two -- is chosen as for
+    // that many columns, so that every column is summed in the order a launch over ncols_like columns uses: the exact batch of retract.hip)
+    const int shape_cols = ncols_like > 0 ? ncols_like : ncols;
     int cw_log2 = 0;
-    while ((1 << cw_log2) < ncols && cw_log2 < 5) ++cw_log2;
+    while ((1 << cw_log2) < shape_cols && cw_log2 < 5) ++cw_log2;
     const int cw = 1 << cw_log2;
     const int gx = (ncols + cw - 1) / cw;
-    if (ncols >= 32 && nrows >= 2048) {
+    if (shape_cols >= 32 && nrows >= 2048) {
         double* mid = ctx->part + (size_t)nrows * part_ld;
         const int64_t chunk = (nrows + kReduceRowBlocks - 1) / kReduceRowBlocks;
         hipLaunchKernelGGL((reduce_rows_kernel<NoPost>), dim3(gx, kReduceRowBlocks), dim3(1024), 0, ctx->stream, ctx->part, nrows, ncols,
@@ -422,9 +427,13 @@ inline int onepass_grid(lfpsqp_ctx* ctx, int64_t rounds, int wg_per_cu_cap = 0) 
     return (int)(g < 1 ? 1 : g);
 }
 
+// vspans > 0 (batched first products only, NA > 1): cut the rows into that many VIRTUAL spans -- the grid of another instantiation, queried with
+// grid_out -- and emit one partial row per span (onepass_kernel, "virtual spans"): the sums are then formed in that instantiation's order.
+// grid_out != nullptr: no launch; *grid_out = the grid this call would use (= its number of partial rows).
 template <class EP, int NV, int NRED, int NA = 1>
 int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t n, const double* t, const EP& ep, double* out,
-                int prof_slot = -1, int t_stride = 0, int wg_per_cu_cap = 0, bool discard_sums = false) {
+                int prof_slot = -1, int t_stride = 0, int wg_per_cu_cap = 0, bool discard_sums = false, int vspans = 0, int* grid_out = nullptr,
+                int reduce_like = 0) {
     if constexpr (!is_rowscaled<EP>::value) {
         if (M->view) {                             // a view: the same kernel over the plain storage, row functor wrapped (kernels.h)
             if constexpr (no_rowscale<EP>::value || NA != 1) {
@@ -440,6 +449,9 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
                 }
                 using WE = RsRowE<EP, NV, NRED>;
                 double* raw = ctx->d_view + kViewTau;   // [second products (NV x ncT) ; the functor's sums (NRED) ; u'v_q (NV)]
+                if (grid_out)
+                    return run_onepass<WE, NV, NRED + NV, 1>(ctx, &plain, ncN, ncT, n, t, WE{ep, ViewD{M->rs, M->ru, ctx->d_view}}, raw, prof_slot, t_stride,
+                                                             wg_per_cu_cap, discard_sums, 0, grid_out);
                 LF_TRY((run_onepass<WE, NV, NRED + NV, 1>(ctx, &plain, ncN, ncT, n, t, WE{ep, ViewD{M->rs, M->ru, ctx->d_view}}, raw, prof_slot, t_stride,
                                                           wg_per_cu_cap, discard_sums)));
                 if (discard_sums) return 0;
@@ -449,15 +461,16 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
             }
         }
     }
-    ++ctx->launch_epoch;
+    if (!grid_out) ++ctx->launch_epoch;
     const int cpl = (ncN + 3) / 4;                // column groups
     const bool wide = cpl > 64;                   // more than 256 columns: the four waves of a workgroup split the columns
     const int round_rows = wide ? 16 : kOnepassRound;
     const int64_t rounds = (n + round_rows - 1) / round_rows;
     const int nout = NV * ncT + NRED;
     const int part_ld = (int)round_up(nout, 32);
+    if (grid_out) *grid_out = 0;
     if (rounds > 0) {
-        int grid = 0;
+        int grid = 0, nrows = 0, vs = 0;
 // LACC (running sums of the second product in LDS): where the registers it frees buy a wave per SIMD and the LDS it takes
 // (NV * ceil(CPL/4) * 2 KB per workgroup) still leaves room for those workgroups -- the single-vector / two-vector kernels
 // with 17..33 column groups per wave (m = 65..132, and 260..528 in the wide form).
@@ -467,10 +480,18 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
         constexpr int kG = kC.rounds, kW = kC.waves;                                                                                 \
         constexpr bool kL = (kG == 0 || (WIDE)) && kOpLacc && NA == 1 && (CPL) > 16 && (CPL) <= 33;                                 \
         grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, NA, kL, kG, kW>(ctx, rounds, wg_per_cu_cap);                \
-        LF_TRY(ensure_part(ctx, (size_t)grid * part_ld + reduce_scratch(part_ld)));                                                  \
+        if (grid_out) { *grid_out = grid; return 0; }                                                                                \
+        nrows = grid;                                                                                                                \
+        if (NA > 1 && vspans > 0) {                                                                                                  \
+            vs = (int)((int64_t)vspans > rounds ? rounds : (int64_t)vspans);                                                         \
+            const int per = (vs + grid - 1) / grid;                                                                                  \
+            grid = (vs + per - 1) / per;                                                                                             \
+            nrows = vs;                                                                                                              \
+        }                                                                                                                            \
+        LF_TRY(ensure_part(ctx, (size_t)nrows * part_ld + reduce_scratch(part_ld)));                                                 \
         if (prof_slot >= 0) prof_begin(ctx, prof_slot);                                                                              \
         hipLaunchKernelGGL((onepass_kernel<EP, NV, NRED, CPL, EXACT, WIDE, NA, kL, kG, kW>), dim3((unsigned)grid), dim3(kThreads), \
-                           0, ctx->stream, M->p, M->ld, ncN, ncT, n, rounds, t, t_stride, ep, ctx->part, part_ld, ctx->stage_cap);    \
+                           0, ctx->stream, M->p, M->ld, ncN, ncT, n, rounds, t, t_stride, ep, ctx->part, part_ld, ctx->stage_cap, vs); \
     } while (0)
         if (wide) {
             const int cplw = (cpl + kWaves - 1) / kWaves;     // column groups per wave
@@ -491,9 +512,9 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
         if (prof_slot >= 0) prof_end(ctx, prof_slot);
         LF_LAUNCH_CHECK(ctx);
         if (discard_sums) return 0;          // (a launch used for its row update alone, e.g. GEMV-N: no second stage, no collective)
-        LF_TRY(launch_reduce(ctx, grid, nout, part_ld, 0u, out, NoPost()));
+        LF_TRY(launch_reduce(ctx, nrows, nout, part_ld, 0u, out, NoPost(), reduce_like));
     } else {
-        if (discard_sums) return 0;
+        if (grid_out || discard_sums) return 0;
         LF_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
     }
     return allreduce_dev(ctx, out, nout);

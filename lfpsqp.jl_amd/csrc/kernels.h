@@ -506,7 +506,7 @@ struct stage_streams<EP, std::void_t<decltype(EP::kStageStreams)>> : std::integr
 template <class EP, int NV, int NRED, int CPL, bool EXACT, bool WIDE, int NA = 1, bool LACC = false, int STG = 0, int SW = 1>
 __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n,
                                                             int64_t rounds, const double* __restrict__ t, int t_stride, EP ep,
-                                                            double* __restrict__ part, int part_ld, int stage_cap) {
+                                                            double* __restrict__ part, int part_ld, int stage_cap, int vspans) {
     if (ep.skip()) return;
     constexpr int CW = 4, RW = 16;                   // column groups per wave instruction, rows per wave tile
     constexpr int NW = WIDE ? kWaves : 1;            // waves sharing a row tile
@@ -565,11 +565,21 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
     // Persistent grid (one launch fills the machine once): workgroup b owns the contiguous span of `cnt` tile rounds
     // (kStep rows each) starting at round t0, balanced to +-1 round -- no tail of half-empty scheduling waves, and only
     // gridDim.x partial rows for the second stage.  grid <= rounds, so cnt >= 1.
-    const int64_t q = rounds / gridDim.x, rem = rounds % gridDim.x;
+    // VIRTUAL SPANS (batched first products, NA > 1, vspans > 0): the rows are cut into `vspans` spans -- the grid of ANOTHER instantiation, the
+    // single-trial Newton step's -- and this workgroup works through ceil(vspans / gridDim.x) consecutive ones, emitting one partial row per
+    // span.  The running sums of every span are then the very sums the other kernel forms, the second stage sees the same partial rows in the
+    // same order, and a trial of the batch gets bit for bit what it gets retracted alone (retract.hip, "exact batch").  Everywhere else a
+    // workgroup has exactly one span (vb = blockIdx.x) and the loop below runs once.
+    const int64_t nspan = (NA > 1 && vspans > 0) ? (int64_t)vspans : (int64_t)gridDim.x;
+    const int64_t vper = (NA > 1) ? (nspan + gridDim.x - 1) / gridDim.x : 1;
+    const int64_t vb0 = (NA > 1) ? (int64_t)blockIdx.x * vper : (int64_t)blockIdx.x;
+    const int64_t vb1 = (NA > 1) ? ((vb0 + vper < nspan) ? vb0 + vper : nspan) : vb0 + 1;
+    for (int64_t vb = vb0; vb < vb1; ++vb) {
+    const int64_t q = rounds / nspan, rem = rounds % nspan;
     // (Dealing the rounds round-robin instead -- workgroup b takes rounds b, b + grid, ..., so that the whole grid works on one
     // window of consecutive rows -- was measured 7 % SLOWER at n = 1e7, m = 128: 2.11 against 1.97 ms on the same box.)
-    const int64_t t0 = (int64_t)blockIdx.x * q + ((int64_t)blockIdx.x < rem ? (int64_t)blockIdx.x : rem);
-    const int cnt = (int)(q + ((int64_t)blockIdx.x < rem ? 1 : 0));
+    const int64_t t0 = vb * q + (vb < rem ? vb : rem);
+    const int cnt = (int)(q + (vb < rem ? 1 : 0));
     const int64_t row0 = t0 * kStep;                                             // uniform
     const int lrow = WIDE ? r : wave * RW + r;                                   // row within the round
     const uint32_t vo = (uint32_t)(lrow * 8) + (uint32_t)((int64_t)h * ld * 8);  // lane offset: row, and column within the group
@@ -700,7 +710,7 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
             if ((lane & 3) == 0 && c < CPL) red(WIDE ? 0 : wave, qq, (g0 + c) * CW + h) = s;
         }
     __syncthreads();
-    double* prow = part + (int64_t)blockIdx.x * part_ld;
+    double* prow = part + vb * part_ld;
     for (int j = threadIdx.x; j < NV * ncT; j += kThreads) {
         const int qq = j / ncT, col = j - qq * ncT;
         const int sl = (col < glast * CW) ? col : (glast * CW + (col - lastc0));       // slot holding column `col`
@@ -711,6 +721,8 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
         if (kSplit) block_reduce_store_split<NRL, NRED>(rsum, prow + NV * ncT);
         else block_reduce_store<(NRL > 0 ? NRL : 1)>(rsum, 0u, prow + NV * ncT);
     }
+    if (NA > 1) __syncthreads();         // the next span reuses buf[] and the reduction scratch
+    }   // virtual spans
 }
 
 // ---- the functor wrappers of matrix views (see ViewD above) ---------------------------------------------------------------------------

@@ -712,7 +712,14 @@ int nr_batch_step(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, int wm, int m
     ep.e = ep0;
     for (int b = 0; b < NB; ++b) { ep.xnew[b] = xnew[b]->p; ep.ist[b] = ctx->istat + I_NRB + 4 * b; }
     ep.all = ctx->istat + I_NRB_ALL;
-    return run_onepass<NRStepBatchRow<ST, NB>, NB, NB, NB>(ctx, cons->Jct, wm, ml, N, dwdelta, ep, draw, 7, wstride);     // (profiling slot 7)
+    // EXACT batch: the rows are cut into the spans of the SINGLE-trial step's launch (lfpsqp_retract_nr: NRStepRow<ST> over the same matrix and
+    // shape) and the second stage is shaped as for its ml + 1 columns, so every sum of a trial -- first product, row update, second product,
+    // partial rows, second stage -- is formed from the same operands in the same order as when the trial is retracted alone: batching is
+    // invisible in the bits (tests: test_exact_batch_is_bit_identical).
+    int g1 = 0;
+    LF_TRY((run_onepass<NRStepRow<ST>, 1, 1>(ctx, cons->Jct, wm, ml, N, dwdelta, NRStepRow<ST>{ep0}, draw, -1, 0, 0, false, 0, &g1)));
+    return run_onepass<NRStepBatchRow<ST, NB>, NB, NB, NB>(ctx, cons->Jct, wm, ml, N, dwdelta, ep, draw, 7, wstride, ctx->batch_wg_cap, false, g1, nullptr,
+                                                           ml + 1);     // (profiling slot 7)
 }
 
 }  // namespace lfpsqp

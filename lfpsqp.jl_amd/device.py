@@ -76,6 +76,12 @@ class Context:
         self.check(self.L.lfpsqp_ctx_set_placement(self.h, int(tries)))
         self.options.placement_tries = int(tries)
 
+    def set_nr_batch_mode(self, matrix_cores: bool = False):
+        """Batched Newton retractions (lfpsqp_ctx_set_nr_batch_mode): False = the exact batch (bit for bit the one-by-one retractions, up to
+        4 trials per pass), True = the matrix-core batch (up to 16 per pass, equal up to rounding)."""
+        self.check(self.L.lfpsqp_ctx_set_nr_batch_mode(self.h, 1 if matrix_cores else 0))
+        self.options.ls_batch_matrix_cores = bool(matrix_cores)
+
     def free_memory(self):
         """Free device memory in bytes (None when unknown): sizes the candidate count of placed allocations in bench.py."""
         try:

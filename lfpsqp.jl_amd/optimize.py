@@ -240,6 +240,7 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
                      LazyProjPenaltyWork(ctx, m, n, ineq, against=Jct if (m > 0 and not few_cg) else None), ineq, idecomp, ineqdata)
     euc = Euclidean()
     yr = YRetract(ineqdata) if ineq else None
+    ctx.set_nr_batch_mode(bool(getattr(ctx.options, "ls_batch_matrix_cores", False)))
     armijo_work = ArmijoWork(x)
     exact_work = ExactLinesearchWork(x) if param.linesearch == LinesearchOption.exact and not param.disable_linesearch else None
 

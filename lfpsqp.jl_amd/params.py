@@ -71,11 +71,19 @@ class DeviceOptions:
     src/LFPSQP.jl:57-81 field for field.  One instance per Context (``ctx.options``)."""
     # After the first failed retraction of an Armijo search (or in the shrinking phase of the exact search), the next `ls_batch` trial steps
     # (alpha*s, alpha*s^2, ...) are retracted together: they share every pass over the constraint gradients (lfpsqp_retract_nr_batch); the
-    # search consumes them in the reference's order, so the accepted step and all counts are those of the one-by-one search.  1 = off.
-    # Only the Newton retraction with device-resident constraints batches; everything else ignores it.
+    # search consumes them in the reference's order.  1 = off.  Only the Newton retraction with device-resident constraints batches;
+    # everything else ignores it.
     # 0 (default) = automatic: as many as the previous search's failed retractions suggest (at least 4), up to what one pass takes for
-    # the problem's shape (lfpsqp_retract_nr_batch_width: 16 on the matrix cores, 4 otherwise); k > 1 = at most k.
+    # the problem's shape and batch mode (lfpsqp_retract_nr_batch_width); k > 1 = at most k.
     ls_batch: int = 0
+    # How the batched retractions are computed (lfpsqp_ctx_set_nr_batch_mode; applied at the start of `optimize`):
+    #   False (default) = the EXACT batch: up to 4 trials per pass, every sum of a trial formed in the order of the single-trial step --
+    #     flags, counts and iterates are BIT FOR BIT those of retracting one by one, so the search IS the one-by-one search, also where it
+    #     is chaotic (config 4's failing searches: a trial that ends in its 100th Newton step or just inside it decides the accepted step).
+    #   True (opt-in) = the matrix-core batch: up to 16 trials per pass (8 from 133 to 528 columns), faster (config 4 at full size: 9.5 s),
+    #     equal to the one-by-one retractions up to rounding only -- in a chaotic search it MAY accept another step than the reference's
+    #     order of arithmetic does and the run then forks onto another (equally valid) trajectory to the same optimum.
+    ls_batch_matrix_cores: bool = False
     # ProjPenalty's inner pcg! solves with the EXACT preconditioner of their operator (lfpsqp_pcg_pre; the reference's proj_precondition!,
     # src/retractions.jl:248-257 -- its call is commented out at :374 -- generalised to the bound operator): one or two inner iterations
     # per Gauss-Newton step instead of hundreds to thousands, at one Gram pass per step.  False (default) = the reference's live path

@@ -281,18 +281,21 @@ def test_ill_conditioned_jacobian_takes_the_references_retraction(dev_ctx, case,
     np.testing.assert_allclose(obj, objr, rtol=max(1e-12, tol))
 
 
-@pytest.mark.parametrize("ls_batch", [0, 1])
-def test_config4_ball_box_newton_retraction(dev_ctx, ls_batch):
-    """BASELINE configs[3]: equalities + ball (slack form) + four-way bounds, NR retraction, Armijo.
-    ``ls_batch`` = 1: trial retractions one by one (the reference's own order of arithmetic in every Newton step) -- on the GPU this has so far
-    reproduced even the CHAOTIC counts of the failing linesearches (1311, 1107, 605, 405, 204 Newton iterations, tools/c4_fork_probe.py);
-    0 (the default): failing searches retract their trial points together on the matrix cores, whose summation order lands elsewhere in the
-    chaotic set (a different count, sometimes a different accepted alpha: the tolerated fork below).  The note says which happened."""
+@pytest.mark.parametrize("mode", ["default", "one_by_one", "matrix_cores"])
+def test_config4_ball_box_newton_retraction(dev_ctx, mode):
+    """BASELINE configs[3]: equalities + ball (slack form) + four-way bounds, NR retraction, Armijo, from the start whose first five
+    linesearches FAIL repeatedly (1311, 1107, 605, 405, 204 Newton iterations in the oracle; the fifth is decided by whether the trial at
+    alpha = 0.5 converges inside its 100th step, tools/c4_fork_probe.py).
+    ``default`` (DeviceOptions as shipped: batched trial retractions in the EXACT mode -- bit for bit the one-by-one retractions) and
+    ``one_by_one`` (ls_batch = 1) must follow the oracle's trajectory: every accepted step, 1e-10 on every iterate, NO fork.
+    ``matrix_cores`` (the opt-in ls_batch_matrix_cores): the trials of a pass are summed in another order and may land elsewhere in the
+    chaotic set -- another count, sometimes another accepted alpha: only this setting may take the fork branch below."""
     ctx = dev_ctx
     emu = _is_emu(ctx)
-    if emu and ls_batch == 1:
+    if emu and mode != "default":
         pytest.skip("the emulator case never reaches a failing linesearch: one setting is enough")
-    ctx.options.ls_batch = ls_batch
+    ctx.options.ls_batch = 1 if mode == "one_by_one" else 0
+    ctx.options.ls_batch_matrix_cores = mode == "matrix_cores"
     n, m = (4000, 16) if not emu else (200, 4)
     P0 = synth.BallBoxProblem(n, m)
     x0 = P0.x0
@@ -307,16 +310,17 @@ def test_config4_ball_box_newton_retraction(dev_ctx, ls_batch):
     P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
     x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=maxiter), trace=tr)
     assert ti.condition.name == tir.condition.name
-    # on the emulator (no FMA contraction) every count matches; on the GPU the failed retractions may differ (see helper)
+    # on the emulator (no FMA contraction) every count matches; on the GPU the COUNTS of failed retractions may differ (see helper)
     fork = _compare_traces(tr, tr0, failed_retractions_may_differ=not emu)
     if fork is None:
         strict = all(a.get('retract_iter1') == b.get('retract_iter1') for a, b in zip(tr, tr0))
-        _note((f"config 4 from x0, ls_batch = {ls_batch}: no fork -- every accepted step equals the oracle's"
+        _note((f"config 4 from x0, {mode}: no fork -- every accepted step equals the oracle's"
                + ("; the Newton-iteration counts of the failing linesearches too" if strict else "")) if not emu else "config 4 (emulator): strict")
         assert ti.iter == tir.iter
         assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
         np.testing.assert_allclose(lam, lamr, rtol=1e-7, atol=1e-10)
     else:       # forked inside a failed-retraction linesearch: same (unique) optimum of the convex problem, to the KKT tolerance
+        assert mode == "matrix_cores", "the default options and the one-by-one search must follow the oracle's trajectory"
         assert abs(obj[-1] - objr[-1]) <= 1e-8 * abs(objr[-1])
         assert np.linalg.norm(x - xr) <= 1e-4 * np.linalg.norm(xr)
     # feasibility of the result (LFPSQP iterates are feasible)
@@ -655,6 +659,8 @@ def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds, mcols)
     assert isinstance(method, L.NR)
     method.maxiter = 40                                    # so that the largest step fails while the small ones converge
     alphas = ([64.0, 0.02, 2e-3, 1e-4] + [0.05 * 0.5 ** k for k in range(12)])[:nb]
+    assert L.retract_nr_batch_width_(c_, method) == 4      # the default: the exact batch (tests/test_exact_batch.py)
+    ctx.set_nr_batch_mode(True)                            # this test: the matrix-core batch (opt-in)
     assert L.retract_nr_batch_width_(c_, method) == (16 if M <= 132 else (8 if M <= 528 else 4))
     xts, xns = captured["work"].batch_vectors(nb)
     for a, xt in zip(alphas, xts):
@@ -689,16 +695,19 @@ def test_batched_newton_retractions_equal_one_by_one(dev_ctx, nb, bounds, mcols)
         assert len(set(g[1] for g in got)) > 1, got            # the trials really finished at different iterations
 
 
-def test_armijo_with_batched_trial_retractions_is_the_same_search(dev_ctx):
+@pytest.mark.parametrize("matrix_cores", [False, True])
+def test_armijo_with_batched_trial_retractions_is_the_same_search(dev_ctx, matrix_cores):
     """DeviceOptions.ls_batch (ctx.options): after the first failed retraction of an Armijo search the next trial steps are retracted
-    together; the search consumes them in the reference's order, so the accepted step, every count and the iterates are
-    those of the one-by-one search (src/linesearch.jl:32-89)."""
+    together; the search consumes them in the reference's order (src/linesearch.jl:32-89).  In the default EXACT mode the accepted
+    step, every count and the iterates are those of the one-by-one search -- strictly (bitwise: tests/test_exact_batch.py).  With the
+    matrix-core batch (opt-in) the counts of FAILING searches may differ on the GPU and the run may fork (the helper says so)."""
     ctx = dev_ctx
     emu = _is_emu(ctx)
     n, m = (150, 4) if emu else (4000, 16)
     mr = 30 if emu else 100                               # (shorter failed retractions keep the emulator run short)
     P0 = synth.BallBoxProblem(n, m)                       # from P0.x0 the first linesearches fail repeatedly (config 4's regime)
     res = {}
+    ctx.options.ls_batch_matrix_cores = matrix_cores
     for k in (1, 4):
         Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
         P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
@@ -711,15 +720,19 @@ def test_armijo_with_batched_trial_retractions_is_the_same_search(dev_ctx):
     tr4, x4, ti4 = res[4]
     assert ti1.iter == ti4.iter and len(tr1) == len(tr4)
     assert any((t.get('retract_iter1') or 0) >= mr for t in tr1)           # the regime with failed retractions was reached
-    fork = _compare_traces(tr4, tr1, rtol=1e-11, failed_retractions_may_differ=not emu)
+    fork = _compare_traces(tr4, tr1, rtol=1e-11, failed_retractions_may_differ=matrix_cores and not emu)
     if fork is None:
         assert np.linalg.norm(x4 - x1) <= 1e-10 * np.linalg.norm(x1)
+    else:
+        assert matrix_cores
 
 
-def test_exact_linesearch_with_batched_shrinking_is_the_same_search(dev_ctx):
+@pytest.mark.parametrize("matrix_cores", [False, True])
+def test_exact_linesearch_with_batched_shrinking_is_the_same_search(dev_ctx, matrix_cores):
     """DeviceOptions.ls_batch with linesearch = exact: the trial steps of the SHRINKING phase (src/linesearch.jl:176-208, a fixed
     sequence a_c*phi1^k from the same x -- the phase that runs when the first trial retraction fails) are retracted together
-    and consumed in the reference's order: accepted step, counts and iterates of the one-by-one search, and of the oracle."""
+    and consumed in the reference's order: accepted step, counts and iterates of the one-by-one search, and of the oracle
+    (strictly in the default exact mode; the matrix-core batch may differ in the counts of failing searches on the GPU)."""
     ctx = dev_ctx
     emu = _is_emu(ctx)
     n, m = (150, 4) if emu else (4000, 16)
@@ -727,6 +740,7 @@ def test_exact_linesearch_with_batched_shrinking_is_the_same_search(dev_ctx):
     maxiter = 2 if emu else 4
     P0 = synth.BallBoxProblem(n, m)                       # from P0.x0 the first linesearches fail repeatedly (config 4's regime)
     res = {}
+    ctx.options.ls_batch_matrix_cores = matrix_cores
     for k in (1, 4):
         Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
         P = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
@@ -739,9 +753,11 @@ def test_exact_linesearch_with_batched_shrinking_is_the_same_search(dev_ctx):
     tr4, x4, ti4 = res[4]
     assert ti1.iter == ti4.iter and len(tr1) == len(tr4)
     assert any((t.get('retract_iter1') or 0) >= mr for t in tr1)           # the regime with failed retractions was reached
-    fork = _compare_traces(tr4, tr1, rtol=1e-11, failed_retractions_may_differ=not emu)
+    fork = _compare_traces(tr4, tr1, rtol=1e-11, failed_retractions_may_differ=matrix_cores and not emu)
     if fork is None:
         assert np.linalg.norm(x4 - x1) <= 1e-10 * np.linalg.norm(x1)
+    else:
+        assert matrix_cores
     if emu:
         tr0 = []
         R.optimize(P0.f, P0.c_, P0.d_, P0.x0, P0.xl, P0.xu, P0.m, P0.p,
