@@ -114,6 +114,11 @@ def main(argv=None, lib=None):
     else:
         ctx = L.Context(dev, lib)
     dev_uuid = ctx.device_uuid() if rank == 0 else None       # of the device this rank computes on
+    dev_uuids = [ctx.device_uuid()]
+    if world > 1:                                             # every rank's device (control plane: gloo): N ranks on N DIFFERENT devices, or sharing one
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dev_uuids[0])
+        dev_uuids = gathered
     r0, r1 = ctx.shard_range(n, rank, world)
     n_loc = r1 - r0
 
@@ -272,7 +277,7 @@ def main(argv=None, lib=None):
                    "placement": placement,
                    "n": n, "m": m, "rows_per_gpu": n_loc, "basis": basis_desc,
                    "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
-                   "comm": comm_used, "comm_probe": comm_probe, "device": ctx.device_name, "device_uuid": dev_uuid},
+                   "comm": comm_used, "comm_probe": comm_probe, "device": ctx.device_name, "device_uuid": dev_uuid, "device_uuids": dev_uuids},
         "roofline": ({"bound": "hbm", "kernel": "onepass_kernel<PcgFuseE> (F: rp = g + alpha*A*d, gp = rp - U*Utr, g = gp, U'gp, U'(A gp): "
                                                  "ONE pass over U per projected-CG iteration)",
                       "achieved": gbs(bytes_kf, kf), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -607,7 +607,11 @@ int lfpsqp_vec_alloc(lfpsqp_ctx* ctx, int64_t n, lfpsqp_vec** out) {
     v->n = n;
     v->cap = round_up(n > 0 ? n : 1, kPadRows);
     hipError_t e = dev_alloc((void**)&v->p, sizeof(double) * v->cap);
-    if (e != hipSuccess) { delete v; return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%lld doubles) failed: %s", (long long)n, hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();      // clear HIP's sticky last error: a caller that carries on (a linesearch batching as many trials as fit) must not see it at its next launch check
+        delete v;
+        return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%lld doubles) failed: %s", (long long)n, hipGetErrorString(e));
+    }
     e = hipMemsetAsync(v->p, 0, sizeof(double) * v->cap, ctx->stream);
     if (e != hipSuccess) { dev_free(v->p); delete v; return set_err(ctx, LFPSQP_ERR_HIP, "hipMemsetAsync failed"); }
     *out = v;
@@ -923,7 +927,11 @@ int lfpsqp_mat_alloc(lfpsqp_ctx* ctx, int64_t n, int64_t m, lfpsqp_mat** out) {
     M->ld += mat_ld_skew();
     const size_t bytes = sizeof(double) * (size_t)M->ld * (size_t)(m > 0 ? m : 1);
     hipError_t e = dev_alloc((void**)&M->p, bytes);
-    if (e != hipSuccess) { delete M; return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%lld x %lld matrix) failed: %s", (long long)n, (long long)m, hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();      // (as in lfpsqp_vec_alloc)
+        delete M;
+        return set_err(ctx, LFPSQP_ERR_HIP, "hipMalloc(%lld x %lld matrix) failed: %s", (long long)n, (long long)m, hipGetErrorString(e));
+    }
     e = hipMemsetAsync(M->p, 0, bytes, ctx->stream);
     if (e != hipSuccess) { dev_free(M->p); delete M; return set_err(ctx, LFPSQP_ERR_HIP, "hipMemsetAsync failed"); }
     *out = M;

@@ -119,9 +119,11 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
                 }
             }
         }
-        if constexpr (DIAG) {           // (behind the matrix loads: nothing waits for these before the staging of this step; entries of rows >= n
-            if (ex0) ve[0] = ld2(ex0 + r + kh);      // are finite padding and meet the matrix's zero rows)
-            if (ex1) ve[1] = ld2(ex1 + r + kh);
+        if constexpr (DIAG) {           // (behind the matrix loads: nothing waits for these before the staging of this step.  Entries of rows >= n
+            // are MASKED like the weights: the column may live in a scratch slot whose pad rows hold a stale NaN from an earlier, larger call,
+            // and 0 * NaN would poison X -- and G, when a view's rank-one column rides along)
+            if (ex0) { const double2 e = ld2(ex0 + r + kh); ve[0] = make_double2((r + kh < n) ? e.x : 0.0, (r + kh + 1 < n) ? e.y : 0.0); }
+            if (ex1) { const double2 e = ld2(ex1 + r + kh); ve[1] = make_double2((r + kh < n) ? e.x : 0.0, (r + kh + 1 < n) ? e.y : 0.0); }
         }
         if constexpr (SHIFT) {
             vs[buf] = ld2(sgn + r + kh);

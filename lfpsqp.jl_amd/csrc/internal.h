@@ -405,7 +405,10 @@ template <class EP>
 constexpr StageCfg onepass_stage(int cpl, bool wide, int na) {
     // (tiles of more than 33 column groups per wave run at one wave per SIMD with part of the tile in accumulation registers: no staging)
     constexpr int ns = stage_streams<EP>::value;      // two staged vectors (stacked forms): half the rounds per burst
-    if (!LFPSQP_OP_STAGE || ns == 0 || na != 1 || cpl < LFPSQP_OP_STAGE_MINCPL || cpl > 33) return StageCfg{0, 1};
+    if (!LFPSQP_OP_STAGE || ns == 0 || (na != 1 && !stage_any_na<EP>::value) || cpl < LFPSQP_OP_STAGE_MINCPL || cpl > 33) return StageCfg{0, 1};
+    // several first products (the tangent step: 2-3 coefficient vectors in LDS, 3-4 staged vectors): two workgroups per CU, what is left of
+    // their 80 KB after the coefficients (na x 1 KB at 33 column groups) in rounds of ns x 512 bytes
+    if (na != 1) return wide ? StageCfg{0, 1} : StageCfg{(150 - 3 * na) / ns, 2};
     if (wide) return !LFPSQP_OP_STAGE_WIDE ? StageCfg{0, 1} : (cpl <= 24 ? StageCfg{160 / ns, 3} : StageCfg{256 / ns, 2});
     // (the stacked forms at 17..24 column groups need a few registers more than three waves per SIMD leave them)
     return (cpl <= 16 || (cpl <= 24 && ns == 1)) ? StageCfg{102 / ns, 3} : StageCfg{153 / ns, 2};
@@ -477,8 +480,13 @@ int run_onepass(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncN, int ncT, int64_t 
 #define LF_OP(CPL, EXACT, WIDE)                                                                                                      \
     do {                                                                                                                             \
         constexpr StageCfg kC = onepass_stage<EP>(CPL, WIDE, NA);                                                                    \
-        constexpr int kG = kC.rounds, kW = kC.waves;                                                                                 \
-        constexpr bool kL = (kG == 0 || (WIDE)) && kOpLacc && NA == 1 && (CPL) > 16 && (CPL) <= 33;                                 \
+        constexpr int kG = kC.rounds, kW0 = kC.waves;                                                                                \
+        /* batched first products (NA > 1, functors that ask for it -- EP::kLaccAnyNA): the NV x ceil(CPL/4) running sums of a lane in LDS */ \
+        /* (up to 72 KB: two workgroups per CU) instead of twice as many registers -- two waves per SIMD instead of one */                  \
+        constexpr bool kLB = NA > 1 && lacc_any_na<EP>::value && !(WIDE) && kOpLacc && (CPL) > 16 && (CPL) <= 33 &&                        \
+                             NV * (((CPL) + 3) / 4) * kThreads * 8 <= 72 * 1024;                                                             \
+        constexpr bool kL = kLB || ((kG == 0 || (WIDE)) && kOpLacc && NA == 1 && (CPL) > 16 && (CPL) <= 33);                                \
+        constexpr int kW = kLB ? 2 : kW0;                                                                                                    \
         grid = onepass_grid<EP, NV, NRED, CPL, EXACT, WIDE, NA, kL, kG, kW>(ctx, rounds, wg_per_cu_cap);                \
         if (grid_out) { *grid_out = grid; return 0; }                                                                                \
         nrows = grid;                                                                                                                \

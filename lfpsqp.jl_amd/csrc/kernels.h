@@ -496,6 +496,17 @@ struct stage_streams : std::integral_constant<int, 0> {};
 template <class EP>
 struct stage_streams<EP, std::void_t<decltype(EP::kStageStreams)>> : std::integral_constant<int, EP::kStageStreams> {};
 
+// functors with batched first products (NA > 1) that want their second product's running sums in LDS (EP::kLaccAnyNA)
+template <class EP, class = void>
+struct lacc_any_na : std::false_type {};
+template <class EP>
+struct lacc_any_na<EP, std::void_t<decltype(EP::kLaccAnyNA)>> : std::true_type {};
+// functors whose staged form takes several first products (EP::kStageAnyNA; the others: NA == 1 only)
+template <class EP, class = void>
+struct stage_any_na : std::false_type {};
+template <class EP>
+struct stage_any_na<EP, std::void_t<decltype(EP::kStageAnyNA)>> : std::true_type {};
+
 // STG > 0 (functors with a staged output, EP::apply_staged / EP::stage_out): the row update's output vector is not stored tile by
 // tile; up to STG rounds of it (STG * 512 bytes) wait in LDS and the whole workgroup stores them in one burst, in equal bursts
 // over its span.  Why: on MI355X a thin store stream inside the matrix read stream costs far more than its bytes (an 80 MB
@@ -523,7 +534,6 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
     constexpr int kAccD = LACC ? NV * NQ * kThreads : 0;
     constexpr int NS = stage_streams<EP>::value > 0 ? stage_streams<EP>::value : 1;   // staged output vectors (the stacked forms: two)
     constexpr int kStgD = NS * STG * kStep;
-    static_assert(STG == 0 || NA == 1, "staged stores: one first product");
     // the staging area shares `buf` with the final column sums; next to LDS running sums (LACC) it is an array of its own
     constexpr int kBufD0 = kRedD > kAccD ? kRedD : (kAccD > 0 ? kAccD : 1);
     constexpr int kBufD = (!LACC && kStgD > kBufD0) ? kStgD : kBufD0;
@@ -556,10 +566,6 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
         }
     }
     double* pl = buf + threadIdx.x;                  // LACC: this lane's running sum (qq, j) is pl[(qq*NQ + j) * kThreads]
-    if (LACC) {
-#pragma unroll
-        for (int s = 0; s < NV * NQ; ++s) pl[s * kThreads] = 0.0;
-    }
     __syncthreads();
     const typename EP::Uni uni = ep.uniform();
     // Persistent grid (one launch fills the machine once): workgroup b owns the contiguous span of `cnt` tile rounds
@@ -575,6 +581,10 @@ __global__ __launch_bounds__(kThreads, SW) void onepass_kernel(const double* __r
     const int64_t vb0 = (NA > 1) ? (int64_t)blockIdx.x * vper : (int64_t)blockIdx.x;
     const int64_t vb1 = (NA > 1) ? ((vb0 + vper < nspan) ? vb0 + vper : nspan) : vb0 + 1;
     for (int64_t vb = vb0; vb < vb1; ++vb) {
+    if (LACC) {                                      // (private slots: no barrier; a previous span's use of buf ended with one)
+#pragma unroll
+        for (int s = 0; s < NV * NQ; ++s) pl[s * kThreads] = 0.0;
+    }
     const int64_t q = rounds / nspan, rem = rounds % nspan;
     // (Dealing the rounds round-robin instead -- workgroup b takes rounds b, b + grid, ..., so that the whole grid works on one
     // window of consecutive rows -- was measured 7 % SLOWER at n = 1e7, m = 128: 2.11 against 1.97 ms on the same box.)

@@ -295,9 +295,6 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_kernel(const double* __r
 // rows nobody reads), their B-operand entries are zero.  Arithmetic per tile and wave at 512 columns: 32 + 32 MFMAs of 64 cycles against ~12000
 // cycles of HBM time per tile pair and CU: still HBM-bound.  One partial row per WORKGROUP: [trial * ncT + col] (8 x ncT), then the 8 ball partials.
 constexpr int kNRBWideTrials = 8;
-#ifndef NRBW_EXP
-#define NRBW_EXP 0
-#endif
 
 template <bool ST, int CPL>
 __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_wide_kernel(const double* __restrict__ M, int64_t ld, int ncN, int ncT, int64_t n, int64_t rounds,
@@ -420,9 +417,6 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_wide_kernel(const double
         __syncthreads();
         const int64_t row = row0 + r16 + (int64_t)k * kStep;
         const bool valid = row < n;
-#if NRBW_EXP & 1
-        sched_fence();
-#endif
         if (updater) {
             const int v = wave;                              // (wave 0: trials 0 .. 3, wave 1: trials 4 .. 7)
             const double ysum = (ysh[0][v][lane] + ysh[1][v][lane]) + (ysh[2][v][lane] + ysh[3][v][lane]);
@@ -440,9 +434,6 @@ __global__ __launch_bounds__(kThreads, 2) void nrb_mfma_wide_kernel(const double
             }
             vs[r16 * 17 + mytrial] = vv;
         }
-#if NRBW_EXP & 1
-        sched_fence();
-#endif
         compiler_fence();
         if (MORE) {
             load_cols(k + 1, 0, NCH == 1 ? CPL : (16 < CPL - 1 ? 16 : CPL - 1));

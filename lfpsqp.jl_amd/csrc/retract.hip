@@ -479,6 +479,7 @@ struct NRStepBatchRow {
     struct Row { NRStepE::Row sh; unsigned active; };       // sh.xn / sh.yn: this lane group's trial
     using Uni = NoUni;
     static constexpr bool kSplitRed = false;
+    static constexpr bool kLaccAnyNA = true;      // (running sums of the second product in LDS: 2 waves per SIMD instead of 1 at 17..33 column groups)
     __device__ __forceinline__ Uni uniform() const { return Uni{}; }
     __device__ __forceinline__ bool skip() const { return ld_stat(all) != 0; }
     static __device__ __forceinline__ int my_trial() { return (int)((threadIdx.x >> 2) & 3u) % NB; }   // lane bits 3..2 = H

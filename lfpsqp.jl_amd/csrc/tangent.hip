@@ -64,9 +64,19 @@ struct TangentStepE {
         w.kk = (MODE > 1 && kind) ? at(kind, o) : 0.0;
         return w;
     }
+    // staged form (onepass_kernel STG; INITF only): the projected step, g0, -g0 and (MODE > 0) the completed Hessian diagonal wait in LDS and
+    // leave in bursts -- four thin store streams inside the matrix read stream are what kept this pass at 0.6 of the HBM peak
+    static constexpr bool kStageAnyNA = true;
+    static constexpr int kStageStreams = INITF ? (MODE > 0 ? 4 : 3) : 0;
+    __device__ __forceinline__ double* stage_out(int sv) const { return sv == 0 ? d : (sv == 1 ? gout : (sv == 2 ? dcg : hx)); }
+    template <int NA>
+    __device__ __forceinline__ void apply_staged(int64_t row, uint32_t o, const double (&acc)[NA], bool valid, bool owner, bool lead, const Uni& u, const Row& w,
+                                                 double (&v)[kNV], double (&red)[kNRED], double* slot, int sstride) const {
+        apply(row, o, acc, valid, owner, lead, u, w, v, red, slot, sstride);
+    }
     template <int NA>
     __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&acc)[NA], bool valid, bool owner, bool, const Uni& u, const Row& w,
-                                          double (&v)[kNV], double (&red)[kNRED]) const {
+                                          double (&v)[kNV], double (&red)[kNRED], double* slot = nullptr, int sstride = 0) const {
         const double s = valid ? w.s : 0.0;
         const double proj = valid ? fma(w.u, u.tau, acc[0] * s) : 0.0;      // (U tmp_m)_i
         const double dp = w.d - proj;                                       // :307
@@ -75,9 +85,14 @@ struct TangentStepE {
         if (MODE > 1) h += ew_phi2(w.kk, w.x) * acc[NA - 1];
         if (MODE > 0) h += (row < n_x) ? cq : 0.0;
         if (valid && owner) {
-            put(d, o, dp);
-            if (!INITF) put(rp, o, r0);
-            if (MODE > 0) put(hx, o, h);
+            if (slot) {
+                slot[0] = dp;
+                if (MODE > 0) slot[3 * sstride] = h;
+            } else {
+                put(d, o, dp);
+                if (!INITF) put(rp, o, r0);
+                if (MODE > 0) put(hx, o, h);
+            }
             red[0] = fma(dp, dp, red[0]);                                   // |d|^2 (the truncated-Newton tolerance, :373-375)
         }
         if constexpr (!INITF) {
@@ -88,8 +103,11 @@ struct TangentStepE {
             const double g0 = r0 - yb;                                      // src/projcg.jl:60
             const double ag = (a0 + h) * g0;
             if (valid && owner) {
-                put(gout, o, g0);
-                put(dcg, o, -g0);                                           // :62
+                if (slot) { slot[sstride] = g0; slot[2 * sstride] = -g0; }
+                else {
+                    put(gout, o, g0);
+                    put(dcg, o, -g0);                                       // :62
+                }
                 red[1] = fma(r0, g0, red[1]);
                 red[2] = fma(g0, g0, red[2]);
                 red[3] = fma(g0, ag, red[3]);

@@ -395,7 +395,8 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
             else:
                 jsp_ = getattr(c_, "Jsp", None)                              # sparse twin: the projected CG runs on the nonzeros
                 Qview = DeviceBasis(Z, rank, generator=(Jct, Wgen), sparse=jsp_) if (jsp_ is not None or Z is None) else DeviceBasis(Z, rank)
-            grad_norm = nrm2(d)
+            # (the one-pass tangent step returns the all-reduced d'd of the projected step: no further pass over d, no host sync)
+            grad_norm = math.sqrt(dss.value) if fused_now else nrm2(d)
             with np.errstate(divide='ignore', invalid='ignore'):
                 ratio = float(np.float64(grad_norm) / np.float64(prev_grad_norm))
             tol = param.tn_kappa * min(1.0, ratio) * grad_norm

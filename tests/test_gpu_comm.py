@@ -95,3 +95,51 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert d2["config"]["rows_per_gpu"] < 600000
     assert abs(d2["check"]["x_norm"] - d1["check"]["x_norm"]) <= 1e-10 * d1["check"]["x_norm"]
     assert abs(d2["check"]["nr"] - d1["check"]["nr"]) <= 1e-8 * d1["check"]["nr"]
+
+
+def _device_count():
+    """HIP devices this process may use, without initialising the GPU in the pytest process (torch.cuda.device_count() reads the topology)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comm", ["p2p", "rccl"])
+def test_bench_two_ranks_on_two_different_gpus(comm):
+    """The first box with more than one GPU runs the sharded path for real: bench.py --gpus 2 as the driver launches it (torch.distributed.run,
+    one rank per device, LOCAL_RANK -> device), once over the library's own one-shot all-reduce (hipIpc-mapped mailboxes ACROSS devices) and once
+    over RCCL with two ranks -- neither has executed with more than one device in any earlier round.  The two-rank solve must be the one-rank
+    solve: same iteration count, ||x|| to 1e-10.  On a one-GPU box the test skips and says how many devices it saw."""
+    import json
+    import socket
+    ndev = _device_count()
+    if ndev < 2:
+        pytest.skip(f"needs two GPUs: this box shows {ndev} HIP device(s) (hipGetDeviceCount); the two-rank paths that share ONE device are "
+                    "covered by test_bench_two_ranks_share_one_gpu / test_bench_eight_ranks_without_a_launcher")
+    common = ["--steps", "6", "--warmup", "2", "--rows", "4000000", "--cols", "128", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], cwd=ROOT, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", comm, "--watchdog-seconds", "300",
+                          *common], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, (two.stdout[-1500:], two.stderr[-3000:])
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["rows_per_gpu"] * 2 >= 4000000
+    assert len(set(d2["config"]["device_uuids"])) == 2, d2["config"]["device_uuids"]      # two DIFFERENT devices
+    assert d2["config"]["comm"].startswith(comm), d2["config"]["comm"]                     # the transport asked for by name (it fails loudly otherwise)
+    assert d1["check"]["iters"] == d2["check"]["iters"]
+    assert abs(d1["check"]["x_norm"] - d2["check"]["x_norm"]) <= 1e-10 * d1["check"]["x_norm"]
+    assert abs(d1["check"]["nr"] - d2["check"]["nr"]) <= 1e-8 * d1["check"]["nr"]
+    print(f"[two GPUs, {comm}] {d2['value']:.1f} it/s on two devices against {d1['value']:.1f} on one; x_norm equal to "
+          f"{abs(d1['check']['x_norm'] - d2['check']['x_norm']) / d1['check']['x_norm']:.1e}")

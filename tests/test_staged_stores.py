@@ -144,3 +144,42 @@ def test_stacked_projcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monk
     for it, nr, x in res[1:]:
         assert (it, nr) == res[0][:2]
         np.testing.assert_array_equal(x, res[0][2])
+
+
+@pytest.mark.parametrize("m,nonlinear", [(40, False), (128, True), (130, False), (90, True)])
+def test_tangent_step_outputs_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m, nonlinear):
+    """The one-pass tangent step with projcg!'s initial projection folded in (lfpsqp_tangent_step, LFPSQP_TANGENT_INIT_PROJCG; src/optimize.jl:305-343,
+    src/projcg.jl:55-62) stages THREE or FOUR vectors -- the projected step, g0, -g0 and, for a class with a constraint term in its Hessian,
+    the completed diagonal -- and has two or three first products: the trajectory of an `optimize` run that goes through it every outer
+    iteration must be bit-identical whatever the burst length."""
+    emu = _is_emu(dev_ctx)
+    n = 3001 if emu else 300_001
+    rng = np.random.default_rng(7 + m)
+    Ah = np.asfortranarray(rng.standard_normal((n, m)) / np.sqrt(n))
+    target = 0.5 * rng.standard_normal(n)
+    x0 = 0.2 * rng.standard_normal(n)
+
+    def run(ctx):
+        assert ctx.options.fused_tangent_step
+        tr = []
+        if nonlinear:
+            kind = (np.arange(n) % 3).astype(np.float64)
+            cons = L.ElementwiseConstraints(ctx, ctx.matrix(n, m, Ah), np.zeros(m), kind=kind)
+            cv = np.zeros(m)
+            cons.c_(cv, ctx.vector(n, x0))
+            cons = L.ElementwiseConstraints(ctx, ctx.matrix(n, m, Ah), cv, kind=kind)            # x0 on the manifold
+            prob = L.SeparableElementwiseBox(ctx, cons, 1, 0.3, target)
+        else:
+            prob = L.SeparableLinearBallBox(ctx, n, m, ctx.matrix(n, m, Ah), Ah.T @ x0, 1, 0.3, target)
+        x, obj, lam, ti = prob.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=3), trace=tr)
+        return x, obj, [t['x'] for t in tr], [t.get('tn_iter') for t in tr]
+
+    res = _with_caps(dev_ctx, monkeypatch, run, caps=("", "1", "2"))
+    x0_, obj0, xs0, tn0 = res[0]
+    assert len(xs0) >= 3 and any((t or 0) >= 1 for t in tn0)
+    for x, obj, xs, tn in res[1:]:
+        assert tn == tn0
+        np.testing.assert_array_equal(x, x0_)
+        np.testing.assert_array_equal(obj, obj0)
+        for a, b in zip(xs, xs0):
+            np.testing.assert_array_equal(a, b)

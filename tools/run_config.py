@@ -1,4 +1,4 @@
-"""Run a BASELINE config end to end on the GPU at full size:  python tools/run_config.py {2|3|4} [n] [m] [--pp [--precond]] [--exact] [--ls-batch=K] [--max-outer=K] [--banded | --banded-dense]"""
+"""Run a BASELINE config end to end on the GPU at full size:  python tools/run_config.py {2|3|4} [n] [m] [--pp [--precond]] [--exact] [--ls-batch=K] [--matrix-cores] [--max-outer=K] [--banded | --banded-dense]"""
 import sys, time; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 import lfpsqp_jl_amd as L
@@ -52,6 +52,7 @@ ctx.sync(); print(f"setup {time.perf_counter()-t0:.2f}s  device={ctx.device_name
 t0 = time.perf_counter()
 mo = [a for a in sys.argv if a.startswith('--max-outer=')]
 ctx.options.ls_batch = batch
+ctx.options.ls_batch_matrix_cores = '--matrix-cores' in sys.argv      # the opt-in matrix-core batch of trial retractions (default: the exact batch)
 ctx.options.pp_precondition = '--precond' in sys.argv      # exact preconditioner of ProjPenalty's inner solves (lfpsqp_pcg_pre)
 par = L.LFPSQPParams(do_project_retract=pp)
 if '--exact' in sys.argv: par.linesearch = L.LinesearchOption.exact
