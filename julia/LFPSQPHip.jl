@@ -270,10 +270,13 @@ c_retract_pp(ctx, cons, cfun, jacfun, user, Jct, m, idata, Dx, Dy, S, xtilde, x,
 # =====================================================================================================================
 # Options of the DEVICE implementation with no counterpart in the reference -- kept out of LFPSQPParams, which mirrors src/LFPSQP.jl:57-81
 # field for field.  ls_batch: trial retractions of a failing linesearch that share their passes over Jct (1 = off; 0 = automatic: what the
-# previous search's failures suggest, at least 4, up to what a pass takes for the shape -- 16 on the matrix cores; k > 1 = at most k);
-# placement_tries: candidate allocations per placement-tuned buffer (set_placement!).
+# previous search's failures suggest, at least 4, up to what a pass takes for the shape and batch mode; k > 1 = at most k);
+# ls_batch_matrix_cores: false (default) = the EXACT batch (lfpsqp_ctx_set_nr_batch_mode: up to 4 trials per pass, bit for bit the one-by-one
+# retractions -- the batched search IS the reference's search, also where it is chaotic), true = the matrix-core batch (up to 16 per pass,
+# equal up to rounding: a chaotic search may accept another step); placement_tries: candidate allocations per placement-tuned buffer (set_placement!).
 mutable struct DeviceOptions
     ls_batch::Int
+    ls_batch_matrix_cores::Bool
     placement_tries::Int
     factored_basis::Bool        # keep the tangent basis in factored form U = Jct W whenever the fused projected-CG iteration applies
     pp_precondition::Bool       # ProjPenalty's inner solves with the exact preconditioner of their operator (lfpsqp_pcg_pre); false = the reference's live path
@@ -290,7 +293,7 @@ mutable struct HipContext
         r = Ref{Ptr{Cvoid}}(C_NULL)
         rc = c_ctx_create(Cint(device), r)
         rc == 0 || throw(HipError(rc, "lfpsqp_ctx_create failed: no usable MI355X (there is no CPU fallback)"))
-        ctx = new(r[], 0, 1, DeviceOptions(0, 3, true, false, true, true, true))
+        ctx = new(r[], 0, 1, DeviceOptions(0, false, 3, true, false, true, true, true))
         finalizer(c -> c_ctx_destroy(c.h), ctx)
         return ctx
     end
@@ -413,6 +416,7 @@ function rowscaled_view(A::DeviceMatrix, rs::DeviceVector)
     finalizer(x -> (c_mat_free(x.ctx.h, x.h); delete!(VIEW_KEEP, x)), V)
     return V
 end
+set_nr_batch_mode!(ctx::HipContext, matrix_cores::Bool) = (check(ctx, c_ctx_set_nr_batch_mode(ctx.h, Cint(matrix_cores ? 1 : 0))); ctx.options.ls_batch_matrix_cores = matrix_cores; ctx)      # default: the exact batch
 set_placement!(ctx::HipContext, tries::Integer) = (check(ctx, c_ctx_set_placement(ctx.h, Cint(tries))); ctx.options.placement_tries = tries; ctx)      # 1 = off, default 3
 # The basis (n x m) and `count` n-vectors streamed with it (stacked [x | gap | y] vectors of 2N entries when N > 0), allocated TOGETHER by
 # trial over every pair of candidate allocations -- the speed of the fused projected-CG kernel is a property of the PAIR
@@ -962,7 +966,7 @@ function retract!(cval::Vector{Float64}, xnew::DeviceVector, c!, xtilde::DeviceV
     return Int(flag[]), Int(iters[]), 0
 end
 # trial retractions per pass for a search: DeviceOptions.ls_batch, never more than the library takes for this shape
-# (lfpsqp_retract_nr_batch_width: 16 on the matrix cores, 4, or 0 = cannot batch)
+# (lfpsqp_retract_nr_batch_width: 4 in the exact mode; 16 / 8 on the matrix cores; 0 = cannot batch)
 function batch_width(ctx::HipContext, retract_method, c!, prev_failures::Int)
     (retract_method isa NR && c! isa DeviceConstraints) || return 1
     opt = ctx.options.ls_batch
@@ -1482,6 +1486,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     nr = NR(nothing, Σ, Vt, param.ϵ_c, param.maxiter_retract, ineq, idata)
     pp = ProjPenalty(c! isa DeviceConstraints ? c! : jac!, m, m, param.μ0, param.ϵ_c, param.maxiter_retract, param.maxiter_pcg,
                      ProjPenaltyWork(x, m, n, ineq; against=((m > 0 && !few_cg) ? Jct : nothing)), ineq, idecomp, idata)
+    set_nr_batch_mode!(ctx, ctx.options.ls_batch_matrix_cores)
     armijo_work = ArmijoWork(x)
     exact_work = (param.linesearch == exact && !param.disable_linesearch) ? ExactLinesearchWork(x) : nothing
     i = 0
