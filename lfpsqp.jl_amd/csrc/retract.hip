@@ -1336,6 +1336,8 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
     double mu = mu0;
     int64_t i = 0, pcg_total = 0;
     double hh = 0.0;
+    // host buffers of the exact preconditioner (DeviceOptions.pp_precondition): allocated once per retraction, reused by every Gauss-Newton step
+    std::vector<double> G, Lc, Kh, Lt, ywork;
     while (i < maxiter) {
         LF_TRY(eval_jac());                                                       // :340 (+ transpose!, :347)
         double curtol = 0.0;
@@ -1367,7 +1369,8 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
             // exact preconditioner of this Gauss-Newton step's operator (DeviceOptions.pp_precondition; lfpsqp_pcg_pre): K = (I + G)^-1 with
             // G = Jct' D0^-1 Jct from one Gram pass over the CURRENT Jct
             if (ineq) LF_TRY((run_vec<D0InvF, 0, NoPost>(ctx, N, D0InvF{w->DxS->p, w->DyS->p, w->i11->p, w->i12->p, w->i22->p, mu}, 0u, nullptr, NoPost())));
-            std::vector<double> G((size_t)m * m), Lc, Kh((size_t)m * m);
+            G.resize((size_t)m * m);
+            Kh.resize((size_t)m * m);
             LF_TRY(lfpsqp_gram(ctx, Jct, m, ineq ? w->i11 : nullptr, G.data()));
             for (int j = 0; j < m; ++j)
                 for (int k = 0; k < m; ++k) {
@@ -1381,13 +1384,14 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
                 // K = L^-T L^-1: solve L Y = I (forward), then L' K = Y (backward), column by column.  The columns are independent: shared
                 // over the host threads, the forward solve on a transposed copy of L so that both sweeps run down contiguous memory
                 // (2 m^3 / 3 flops per Gauss-Newton step: 1.4 Mflop at config 4's m = 129, 0.7 Gflop at m = 1024)
-                std::vector<double> Lt((size_t)m * m);
+                Lt.resize((size_t)m * m);
+                [[maybe_unused]] const int nth = m >= 64 ? small_threads() : 1;
+                ywork.resize((size_t)m * (size_t)(nth > 1 ? nth : 1));
                 for (int j = 0; j < m; ++j)
                     for (int i2 = j; i2 < m; ++i2) Lt[(size_t)i2 * m + j] = Lc[(size_t)j * m + i2];       // Lt[i, j] row-major = L[i, j]
-                [[maybe_unused]] const int nth = m >= 64 ? small_threads() : 1;
 #pragma omp parallel for if (nth > 1) num_threads(nth) schedule(dynamic, 8)
                 for (int c = 0; c < m; ++c) {
-                    std::vector<double> y(m, 0.0);
+                    double* y = ywork.data() + (size_t)m * (size_t)small_thread_id();      // (entries below c are not read)
                     for (int i2 = c; i2 < m; ++i2) {
                         const double* li = &Lt[(size_t)i2 * m];
                         double acc = (i2 == c) ? 1.0 : 0.0;

@@ -5,6 +5,9 @@
 #pragma once
 #include <math.h>
 #include <sched.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include <algorithm>
 #include <numeric>
@@ -22,6 +25,15 @@ inline int small_threads() {
         n = c < 1 ? 1 : (c > 8 ? 8 : c);
     }
     return n;
+}
+
+// index of the calling thread inside a `#pragma omp parallel` region of these kernels (0 without OpenMP: the CPU test emulator's build)
+inline int small_thread_id() {
+#ifdef _OPENMP
+    return omp_get_thread_num();
+#else
+    return 0;
+#endif
 }
 
 // A: rows x cols, column-major, leading dimension rows (rows >= 1, cols >= 0).

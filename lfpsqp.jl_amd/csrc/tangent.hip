@@ -15,6 +15,10 @@
 #include "internal.h"
 #include "sparse.h"
 
+#ifndef LFPSQP_TANGENT_STAGE
+#define LFPSQP_TANGENT_STAGE 1      // (0: the tangent step stores row by row -- A/B builds, tools/build_variant.py)
+#endif
+
 namespace lfpsqp {
 
 // MODE 0: projection only; 1: + the constant part of the class's Hessian term on the rows < n_x (ball / common quadratic term);
@@ -67,7 +71,7 @@ struct TangentStepE {
     // staged form (onepass_kernel STG; INITF only): the projected step, g0, -g0 and (MODE > 0) the completed Hessian diagonal wait in LDS and
     // leave in bursts -- four thin store streams inside the matrix read stream are what kept this pass at 0.6 of the HBM peak
     static constexpr bool kStageAnyNA = true;
-    static constexpr int kStageStreams = INITF ? (MODE > 0 ? 4 : 3) : 0;
+    static constexpr int kStageStreams = (INITF && LFPSQP_TANGENT_STAGE) ? (MODE > 0 ? 4 : 3) : 0;
     __device__ __forceinline__ double* stage_out(int sv) const { return sv == 0 ? d : (sv == 1 ? gout : (sv == 2 ? dcg : hx)); }
     template <int NA>
     __device__ __forceinline__ void apply_staged(int64_t row, uint32_t o, const double (&acc)[NA], bool valid, bool owner, bool lead, const Uni& u, const Row& w,
@@ -155,8 +159,28 @@ struct TangentStepSE {
     __device__ __forceinline__ Row fetch(uint32_t o) const {
         return Row{at(d, o), at(d + hs, o), at(Dx, o), at(Dy, o), at(sx, o), at(sy, o), at(S, o), at(q, o), at(s, o), at(hx, o)};
     }
+    // staged form (INITF): the nine output streams -- both halves of d, a, g0 and -g0, and lamy -- wait in LDS and leave in bursts
+    static constexpr bool kStageAnyNA = true;
+    static constexpr int kStageStreams = (INITF && LFPSQP_TANGENT_STAGE) ? 9 : 0;
+    __device__ __forceinline__ double* stage_out(int sv) const {
+        switch (sv) {
+            case 0: return d;
+            case 1: return d + hs;
+            case 2: return a;
+            case 3: return a + hs;
+            case 4: return gout;
+            case 5: return gout + hs;
+            case 6: return dcg;
+            case 7: return dcg + hs;
+            default: return lamy;       // (nullptr: not wanted)
+        }
+    }
+    __device__ __forceinline__ void apply_staged(int64_t row, uint32_t o, const double (&acc)[kNA], bool valid, bool owner, bool lead, const Uni& u, const Row& w,
+                                                 double (&v)[kNV], double (&red)[kNRED], double* slot, int sstride) const {
+        apply(row, o, acc, valid, owner, lead, u, w, v, red, slot, sstride);
+    }
     __device__ __forceinline__ void apply(int64_t row, uint32_t o, const double (&acc)[kNA], bool valid, bool owner, bool, const Uni&, const Row& w,
-                                          double (&v)[kNV], double (&red)[kNRED]) const {
+                                          double (&v)[kNV], double (&red)[kNRED], double* slot = nullptr, int sstride = 0) const {
         const double ww = w.Dx * w.dx + w.Dy * w.dy;                        // the diagonal block of Q'd
         const double dxn = w.dx - fma(w.sx, acc[0], w.Dx * ww);             // d - Q [w; t]
         const double dyn = w.dy - fma(w.sy, acc[0], w.Dy * ww);
@@ -164,11 +188,15 @@ struct TangentStepSE {
         const double ax = (w.hx + ((row < n_x) ? cq : 0.0)) + 2.0 * ly * w.q;
         const double ay = 2.0 * ly * w.s;
         if (valid && owner) {
-            put(d, o, dxn); put(d + hs, o, dyn);
-            if (!INITF) { put(rp, o, -dxn); put(rp + hs, o, -dyn); }
-            put(a, o, ax);
-            put(a + hs, o, ay);
-            if (lamy) put(lamy, o, ly);
+            if (slot) {
+                slot[0] = dxn; slot[sstride] = dyn; slot[2 * sstride] = ax; slot[3 * sstride] = ay; slot[8 * sstride] = ly;
+            } else {
+                put(d, o, dxn); put(d + hs, o, dyn);
+                if (!INITF) { put(rp, o, -dxn); put(rp + hs, o, -dyn); }
+                put(a, o, ax);
+                put(a + hs, o, ay);
+                if (lamy) put(lamy, o, ly);
+            }
             red[0] = fma(dxn, dxn, fma(dyn, dyn, red[0]));
         }
         if constexpr (!INITF) {
@@ -180,8 +208,12 @@ struct TangentStepSE {
             const double gy = ry - fma(w.sy, acc[1], w.Dy * w0);
             const double agx = ax * gx, agy = ay * gy;
             if (valid && owner) {
-                put(gout, o, gx); put(gout + hs, o, gy);
-                put(dcg, o, -gx); put(dcg + hs, o, -gy);
+                if (slot) {
+                    slot[4 * sstride] = gx; slot[5 * sstride] = gy; slot[6 * sstride] = -gx; slot[7 * sstride] = -gy;
+                } else {
+                    put(gout, o, gx); put(gout + hs, o, gy);
+                    put(dcg, o, -gx); put(dcg + hs, o, -gy);
+                }
                 red[1] = fma(rx, gx, fma(ry, gy, red[1]));
                 red[2] = fma(gx, gx, fma(gy, gy, red[2]));
                 red[3] = fma(gx, agx, fma(gy, agy, red[3]));
@@ -313,11 +345,11 @@ extern "C" int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const
         if (initf) {
             const TangentStepSE<true> se{d->p, work->rp->p, work->g->p, work->d->p, hdiag->p, hx->p, lamy ? lamy->p : nullptr, hs, U->Dx->p, U->Dy->p,
                                          U->sx->p, U->sy->p, S->p, idata->q->p, idata->s->p, cq, n_x};
-            LF_TRY((run_onepass<TangentStepSE<true>, 2, 6, 3>(ctx, A, m, m, N, t, se, raw, -1, ms)));
+            LF_TRY((run_onepass<TangentStepSE<true>, 2, 6, 3>(ctx, A, m, m, N, t, se, raw, 6, ms)));
         } else {
             const TangentStepSE<false> se{d->p, work->rp->p, nullptr, nullptr, hdiag->p, hx->p, lamy ? lamy->p : nullptr, hs, U->Dx->p, U->Dy->p,
                                           U->sx->p, U->sy->p, S->p, idata->q->p, idata->s->p, cq, n_x};
-            LF_TRY((run_onepass<TangentStepSE<false>, 1, 2, 2>(ctx, A, m, m, N, t, se, raw, -1, ms)));
+            LF_TRY((run_onepass<TangentStepSE<false>, 1, 2, 2>(ctx, A, m, m, N, t, se, raw, 6, ms)));
         }
         return finish(nullptr);
     }
@@ -339,11 +371,11 @@ extern "C" int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const
     const int64_t n_x = cons ? cons->n_x : 0;
     if (initf) {
         double *gp = work->g->p, *dc = work->d->p;
-        if (mode == 2) LF_TRY((run_onepass<TangentStepE<2, true>, 2, 6, 3>(ctx, &plain, m, m, N, t, TangentStepE<2, true>{d->p, work->rp->p, gp, dc, 0.0, hxp, xp, kind, cq, n_x, vw}, raw, -1, ms)));
-        else if (mode == 1) LF_TRY((run_onepass<TangentStepE<1, true>, 2, 6, 2>(ctx, &plain, m, m, N, t, TangentStepE<1, true>{d->p, work->rp->p, gp, dc, 0.0, hxp, xp, kind, cq, n_x, vw}, raw, -1, ms)));
-        else LF_TRY((run_onepass<TangentStepE<0, true>, 2, 6, 2>(ctx, &plain, m, m, N, t, TangentStepE<0, true>{d->p, work->rp->p, gp, dc, 0.0, hxp, xp, kind, cq, n_x, vw}, raw, -1, ms)));
+        if (mode == 2) LF_TRY((run_onepass<TangentStepE<2, true>, 2, 6, 3>(ctx, &plain, m, m, N, t, TangentStepE<2, true>{d->p, work->rp->p, gp, dc, 0.0, hxp, xp, kind, cq, n_x, vw}, raw, 6, ms)));
+        else if (mode == 1) LF_TRY((run_onepass<TangentStepE<1, true>, 2, 6, 2>(ctx, &plain, m, m, N, t, TangentStepE<1, true>{d->p, work->rp->p, gp, dc, 0.0, hxp, xp, kind, cq, n_x, vw}, raw, 6, ms)));
+        else LF_TRY((run_onepass<TangentStepE<0, true>, 2, 6, 2>(ctx, &plain, m, m, N, t, TangentStepE<0, true>{d->p, work->rp->p, gp, dc, 0.0, hxp, xp, kind, cq, n_x, vw}, raw, 6, ms)));
     } else {
-        if (mode == 2) LF_TRY((run_onepass<TangentStepE<2>, 1, 2, 2>(ctx, &plain, m, m, N, t, TangentStepE<2>{d->p, work->rp->p, nullptr, nullptr, 0.0, hxp, xp, kind, cq, n_x, vw}, raw, -1, ms)));
+        if (mode == 2) LF_TRY((run_onepass<TangentStepE<2>, 1, 2, 2>(ctx, &plain, m, m, N, t, TangentStepE<2>{d->p, work->rp->p, nullptr, nullptr, 0.0, hxp, xp, kind, cq, n_x, vw}, raw, 6, ms)));
         else if (mode == 1) LF_TRY((run_onepass<TangentStepE<1>, 1, 2, 1>(ctx, &plain, m, m, N, t, TangentStepE<1>{d->p, work->rp->p, nullptr, nullptr, 0.0, hxp, xp, kind, cq, n_x, vw}, raw)));
         else LF_TRY((run_onepass<TangentStepE<0>, 1, 2, 1>(ctx, &plain, m, m, N, t, TangentStepE<0>{d->p, work->rp->p, nullptr, nullptr, 0.0, hxp, xp, kind, cq, n_x, vw}, raw)));
     }

@@ -175,11 +175,40 @@ def ksvd_(A, U, S, VT):
     (The lwork=-1 workspace query at :19-21,:31-33 has no numerical effect.)"""
     if A.shape[1] == 0:
         return
-    u, s, vt, info = _lapack.dgesvd(np.asfortranarray(A), compute_uv=1, full_matrices=0)
-    U[:, :] = u
+    if A.size >= _LP64_LIMIT:
+        _ksvd_by_row_blocks(A, U, S, VT)
+    else:
+        u, s, vt, info = _lapack.dgesvd(np.asfortranarray(A), compute_uv=1, full_matrices=0)
+        U[:, :] = u
+        S[:] = s
+        VT[:, :] = vt
+    A[:, :] = np.nan  # "destroyed" -- poison it so accidental reuse shows up
+
+
+# scipy's LAPACK is LP64: dgesvd indexes the array and its workspace with 32-bit integers, and a 2e7 x 129 matrix (config 4 at the full
+# size: the doubled variables of the bound formulation) has 2.58e9 entries -- the call dies with a segmentation fault.  Julia's OpenBLAS is
+# ILP64 (src/la_helper.jl:22 passes BlasInt = Int64) and has no such limit.  For such a matrix the thin SVD is taken by the standard
+# backward-stable tall-skinny route instead: Householder QR of row blocks that LAPACK can index (dgeqrf / dorgqr through numpy), one
+# dgesvd of the stacked triangular factors, U = blockdiag(Q_k) (Qs Us).  Same singular values and right singular vectors as dgesvd's to
+# rounding, the same subspace for U (all the driver uses); independent of the device's Gram-matrix route.
+_LP64_LIMIT = 2 ** 31 - 2 ** 24
+
+
+def _ksvd_by_row_blocks(A, U, S, VT, limit=None):
+    n, m = A.shape
+    limit = _LP64_LIMIT if limit is None else limit
+    nblk = int(np.ceil(A.size / float(limit))) + 1
+    edges = np.linspace(0, n, nblk + 1).astype(np.int64)
+    Rs = []
+    for k in range(nblk):
+        q, r = np.linalg.qr(A[edges[k]:edges[k + 1], :])          # reduced: (rows x m), (m x m)
+        U[edges[k]:edges[k + 1], :] = q                           # (parked in U until the small SVD is known)
+        Rs.append(r)
+    us, s, vt, info = _lapack.dgesvd(np.asfortranarray(np.vstack(Rs)), compute_uv=1, full_matrices=0)
+    for k in range(nblk):
+        U[edges[k]:edges[k + 1], :] = U[edges[k]:edges[k + 1], :] @ us[k * m:(k + 1) * m, :]
     S[:] = s
     VT[:, :] = vt
-    A[:, :] = np.nan  # "destroyed" -- poison it so accidental reuse shows up
 
 
 def kgemv_(tA, rank, alpha, A, x, beta, y):

@@ -96,10 +96,10 @@ class BallBoxProblem:
     """C4: C3's equalities + ball d(x) = x'x - R^2 <= 0 + the four-way bound pattern of
     reference test/test_inequalities.jl:6-9 (i mod 4: none / lower -1 / upper +1 / both)."""
 
-    def __init__(self, n: int, m: int, xc: float = 0.0):
-        self.eq = QuadLinearProblem(hash_matrix(1, n, m), None, xc)
-        xstar = hash_vector(2, n)
-        self.eq.b = self.eq.Jct.T @ xstar
+    def __init__(self, n: int, m: int, xc: float = 0.0, Jct=None, b=None):
+        # (Jct / b: the same hash matrix and right-hand side built elsewhere -- oracle/port.py makes them in seconds at n = 1e7)
+        self.eq = QuadLinearProblem(hash_matrix(1, n, m) if Jct is None else Jct, None, xc)
+        self.eq.b = self.eq.Jct.T @ hash_vector(2, n) if b is None else np.asarray(b, dtype=float)
         self.n, self.m, self.p = n, m, 1
         self.R2 = n / 2.0
         i = np.arange(n)

@@ -146,7 +146,7 @@ def test_stacked_projcg_iterates_do_not_depend_on_the_burst_length(dev_ctx, monk
         np.testing.assert_array_equal(x, res[0][2])
 
 
-@pytest.mark.parametrize("m,nonlinear", [(40, False), (128, True), (130, False), (90, True)])
+@pytest.mark.parametrize("m,nonlinear", [(40, False), (128, True), (130, False), (90, True), (40, "bounds"), (128, "bounds")])
 def test_tangent_step_outputs_do_not_depend_on_the_burst_length(dev_ctx, monkeypatch, m, nonlinear):
     """The one-pass tangent step with projcg!'s initial projection folded in (lfpsqp_tangent_step, LFPSQP_TANGENT_INIT_PROJCG; src/optimize.jl:305-343,
     src/projcg.jl:55-62) stages THREE or FOUR vectors -- the projected step, g0, -g0 and, for a class with a constraint term in its Hessian,
@@ -162,6 +162,13 @@ def test_tangent_step_outputs_do_not_depend_on_the_burst_length(dev_ctx, monkeyp
     def run(ctx):
         assert ctx.options.fused_tangent_step
         tr = []
+        if nonlinear == "bounds":            # config 4's class: ball in slack form + four-way bounds -- the stacked form, NINE staged vectors
+            P0 = synth.BallBoxProblem(n, m)
+            Jct = ctx.matrix(n + 1, m + 1).hash_fill(1, 0, n, 1.0, n, m)
+            prob = L.QuadLinearBallBox(ctx, n, m, Jct, P0.eq.b, R2=P0.R2, xl=P0.xl, xu=P0.xu)
+            xs = 0.9 * synth.hash_vector(2, n) + 0.1 * P0.x0
+            x, obj, lam, ti = prob.optimize(xs, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=3), trace=tr)
+            return x, obj, [t['x'] for t in tr], [t.get('tn_iter') for t in tr]
         if nonlinear:
             kind = (np.arange(n) % 3).astype(np.float64)
             cons = L.ElementwiseConstraints(ctx, ctx.matrix(n, m, Ah), np.zeros(m), kind=kind)

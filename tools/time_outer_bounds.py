@@ -7,7 +7,10 @@ import lfpsqp_jl_amd as L
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-ctx = L.Context(0)
+libpath = None
+if '--lib' in sys.argv:
+    k = sys.argv.index('--lib'); libpath = sys.argv[k + 1]; del sys.argv[k:k + 2]
+ctx = L.Context(0, L.load_library(libpath) if libpath else None)
 Jct = ctx.matrix(n + 1, m + 1, placed=True).hash_fill(1, 0, n, 1.0, n, m)
 xs = ctx.vector(n + 1).hash_fill(2, 0, 1.0, 0.0); ctx.check(ctx.L.lfpsqp_vec_fill_range(ctx.h, xs.h, n, 1, 0.0))
 b = ctx.vector(m + 1); L.gemv_t(Jct, xs, b, ncols=m)
