@@ -15,6 +15,9 @@
 #include "internal.h"
 #include "sparse.h"
 
+#ifndef LFPSQP_TANGENT_STAGE_STACKED
+#define LFPSQP_TANGENT_STAGE_STACKED 0
+#endif
 #ifndef LFPSQP_TANGENT_STAGE
 #define LFPSQP_TANGENT_STAGE 1      // (0: the tangent step stores row by row -- A/B builds, tools/build_variant.py)
 #endif
@@ -161,7 +164,9 @@ struct TangentStepSE {
     }
     // staged form (INITF): the nine output streams -- both halves of d, a, g0 and -g0, and lamy -- wait in LDS and leave in bursts
     static constexpr bool kStageAnyNA = true;
-    static constexpr int kStageStreams = (INITF && LFPSQP_TANGENT_STAGE) ? 9 : 0;
+    // (measured at (1e7, 129): 15.6 ms per outer iteration staged against 15.2 row by row -- nine streams leave bursts of 15 rounds, too short to
+    // pay: the staged form of the STACKED step stays off; LFPSQP_TANGENT_STAGE_STACKED=1 builds it, profiles/r06d_*)
+    static constexpr int kStageStreams = (INITF && LFPSQP_TANGENT_STAGE_STACKED) ? 9 : 0;
     __device__ __forceinline__ double* stage_out(int sv) const {
         switch (sv) {
             case 0: return d;

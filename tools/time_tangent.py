@@ -52,6 +52,6 @@ for mode in modes:
     kern = pms[6] / pcnt[6] if pcnt[6] else float("nan")
     nvec = {"plain": 3 + 3, "stream": 6 + 4, "dense": 7 + 4}[mode]           # n-vectors read + written
     gb = (8.0 * n * m + 8.0 * n * nvec) / 1e9
-    print(f"n={n} m={m} {mode:6s}: tangent step kernel {kern:.3f} ms ({gb / kern:.0f} GB/s algorithmic = {gb / kern / 8000:.3f} of 8 TB/s), {wall:.3f} ms per call")
+    print(f"n={n} m={m} {mode:6s}: tangent step kernel {kern:.3f} ms ({gb / kern * 1e3:.0f} GB/s algorithmic = {gb / kern / 8.0:.3f} of 8 TB/s), {wall:.3f} ms per call")
     for v in (A, d, hd):
         v.free()
