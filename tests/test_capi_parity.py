@@ -743,3 +743,20 @@ def test_argument_errors_are_status_codes_not_crashes(dev_ctx):
     x, lam = ctx.vector(600), ctx.vector(3)
     it, nr = L.projcg_(x, lam, L.DiagOperator(2.0), L.DeviceBasis(ctx.matrix(600, 3, Uh)), ctx.vector(600, bh), None, tol=1e-8, maxit=5)
     assert it == 5 and math.isnan(nr)
+
+
+def test_a_failed_allocation_does_not_poison_the_next_launch(dev_ctx):
+    """lfpsqp_vec_alloc / lfpsqp_mat_alloc that run out of device memory return LFPSQP_ERR_HIP -- and clear HIP's sticky last error, so a caller
+    that carries on (a linesearch that batches as many trial points as fit, lfpsqp.jl_amd/linesearch.py::_grow_batch) does not meet the stale
+    out-of-memory error at its next launch check."""
+    ctx = dev_ctx
+    with pytest.raises(L.LfpsqpError):
+        ctx.vector(2 ** 46)                               # 512 TiB
+    with pytest.raises(L.LfpsqpError):
+        ctx.matrix(2 ** 40, 64)
+    xh = synth.hash_vector(3, 5000)
+    x = ctx.vector(5000, xh)
+    assert L.nrm2(x) == pytest.approx(np.linalg.norm(xh), rel=1e-14)      # a launch with a check behind it
+    y = ctx.vector(5000)
+    L.waxpby(2.0, x, 0.0, x, y)
+    np.testing.assert_array_equal(y.download(), 2.0 * xh)

@@ -62,6 +62,37 @@ def test_gram_with_extra_right_hand_columns(dev_ctx, n, m, weighted, rs, ru, nx)
         np.testing.assert_allclose(X[:, k], ref, atol=1e-12 * max(np.abs(ref).max(), 1.0) * np.sqrt(n))
 
 
+def test_gram_extra_columns_ignore_stale_pad_rows(dev_ctx):
+    """One diverged iterate must not poison later solves on the same context: the extra right-hand columns of the Gram pass are read in 16-row
+    steps, and for a VIEW they live in a scratch slot of the context whose rows beyond n keep whatever an earlier, larger call left there.  After a
+    call with NaN row scales on 4000 rows, a fully valid call on a 500-row view must return finite, correct products (the kernel masks the
+    column's entries of rows >= n exactly like the weights; 0 * NaN would otherwise reach X, and G through a rank-one column)."""
+    ctx = dev_ctx
+    m = 8
+    for ru in (False, True):
+        big = ctx.matrix(4000, m, np.asfortranarray(synth.hash_matrix(1, 4000, m)))
+        bad = big.view(ctx.vector(4000, np.full(4000, np.nan)), ctx.vector(4000, np.full(4000, np.nan)) if ru else None,
+                       ctx.vector(m, 0.3 * synth.hash_vector(13, m)) if ru else None)
+        Gb, Xb = L.gram_rhs(bad, [ctx.vector(4000, np.full(4000, np.nan))])
+        assert not np.isfinite(Xb).all()                                   # (the poisoned call itself)
+        n = 500
+        Ah = synth.hash_matrix(2, n, m)
+        rs_h = 1.0 + 0.5 * synth.hash_vector(11, n)
+        u_h = synth.hash_vector(12, n) if ru else None
+        w_h = 0.3 * synth.hash_vector(13, m) if ru else None
+        V = ctx.matrix(n, m, np.asfortranarray(Ah)).view(ctx.vector(n, rs_h), ctx.vector(n, u_h) if ru else None, ctx.vector(m, w_h) if ru else None)
+        Vh = rs_h[:, None] * Ah + (np.outer(u_h, w_h) if ru else 0.0)
+        e_h = synth.hash_vector(20, n)
+        G, X = L.gram_rhs(V, [ctx.vector(n, e_h)])
+        assert np.isfinite(G).all() and np.isfinite(X).all()
+        np.testing.assert_allclose(G, Vh.T @ Vh, atol=1e-12 * np.abs(Vh.T @ Vh).max())
+        np.testing.assert_allclose(X[:, 0], Vh.T @ e_h, atol=1e-11)
+        W = np.zeros((m, m), order='F')
+        S, Vt, rank, Jtd = L.ksvd_(V, None, W=W, rhs=ctx.vector(n, e_h))      # (the factorisation that failed with "non-finite Gram matrix")
+        assert rank == m and np.isfinite(S).all()
+        np.testing.assert_allclose(Jtd, Vh.T @ e_h, atol=1e-11)
+
+
 @pytest.mark.parametrize("n,m", [(1800, 16), (2500, 128), (1200, 129)])
 def test_factorize_with_right_hand_side_returns_the_same_factors(dev_ctx, n, m):
     ctx = dev_ctx
