@@ -79,6 +79,14 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 }
 // compiler-only ordering point for memory operations (no instruction is emitted)
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
+// a value the optimiser may not trace back to where it came from (no instruction is emitted): keeps a small register array that is later
+// SELECTED from by a lane-dependent index from being demoted to scratch memory as a dynamically indexed array
+__device__ __forceinline__ double opaque_f64(double x) {
+#ifndef LFPSQP_HIP_EMULATED
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
 // streaming store: the line is not kept dirty in the L2 for a later write-back (which would then fall into the NEXT kernel's read stream)
 __device__ __forceinline__ void st2_stream(double* p, double2 v) {

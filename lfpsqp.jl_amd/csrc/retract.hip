@@ -503,9 +503,20 @@ struct NRStepBatchRow {
     __device__ __forceinline__ void apply(int64_t i, uint32_t o, const double (&acc)[NB], bool valid, bool, bool lead, const Uni&,
                                           const Row& w, double (&v)[NB], double (&red)[NB]) const {
         const int h = (int)((threadIdx.x >> 2) & 3u), tr = h % NB;
-        double acc_mine = acc[0];
-#pragma unroll
-        for (int b = 1; b < NB; ++b) acc_mine = (tr == b) ? acc[b] : acc_mine;
+        // this lane group's first product, by a tree of selects over OPAQUE copies: written as `acc[tr]` -- or as any chain or tree of selects
+        // on the array's elements, which the compiler folds back into one indexed load -- the array goes to scratch memory, and the scratch
+        // load, issued behind the next tile's row-input loads, waits for all of them (loads return in order): an exposed memory round trip
+        // per tile step (FINDINGS.md 12.7)
+        static_assert(NB == 2 || NB == 4, "instantiated batch widths");
+        double acc_mine;
+        if constexpr (NB == 2) {
+            const double a0 = opaque_f64(acc[0]), a1 = opaque_f64(acc[1]);
+            acc_mine = (tr & 1) ? a1 : a0;
+        } else {
+            const double a0 = opaque_f64(acc[0]), a1 = opaque_f64(acc[1]), a2 = opaque_f64(acc[2]), a3 = opaque_f64(acc[3]);
+            const double lo = (tr & 1) ? a1 : a0, hi = (tr & 1) ? a3 : a2;
+            acc_mine = (tr & 2) ? hi : lo;
+        }
         double mine = 0.0, ball = 0.0;
         if ((w.active >> tr) & 1u) {                   // a finished trial keeps its iterate and contributes nothing
             NRStepE eb = e;
