@@ -1402,7 +1402,8 @@ int lfpsqp_retract_pp(lfpsqp_ctx* ctx, const lfpsqp_constraints* cons, lfpsqp_cf
                     for (int i2 = j; i2 < m; ++i2) Lt[(size_t)i2 * m + j] = Lc[(size_t)j * m + i2];       // Lt[i, j] row-major = L[i, j]
 #pragma omp parallel for if (nth > 1) num_threads(nth) schedule(dynamic, 8)
                 for (int c = 0; c < m; ++c) {
-                    double* y = ywork.data() + (size_t)m * (size_t)small_thread_id();      // (entries below c are not read)
+                    double* y = ywork.data() + (size_t)m * (size_t)small_thread_id();
+                    for (int i2 = 0; i2 < c; ++i2) y[i2] = 0.0;                              // (the unit vector's leading zeros: the backward sweep reads them)
                     for (int i2 = c; i2 < m; ++i2) {
                         const double* li = &Lt[(size_t)i2 * m];
                         double acc = (i2 == c) ? 1.0 : 0.0;

@@ -13,6 +13,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "emu", "_build", "liblfpsqp_emu.so")
 
 
+def _bench(cmd, env, timeout=900, port_flag=None):
+    """One bench.py launch as a subprocess; ONE more attempt if it fails (the rendezvous of freshly started ranks stalled once in round 2 and a
+    launch failed once in round 6, neither reproducible: under `pytest -x` a transient must not end the suite).  The first attempt's output is
+    part of the report if the second fails too.  `port_flag`: index of the --master-port value in cmd (a fresh port for the second attempt)."""
+    import socket
+    first = None
+    for attempt in range(2):
+        if attempt and port_flag is not None:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                cmd = list(cmd)
+                cmd[port_flag] = str(s.getsockname()[1])
+        try:
+            res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+        except subprocess.TimeoutExpired as e:
+            res = None
+            why = ("timeout", str(e)[-500:])
+        if res is not None and res.returncode == 0:
+            if first is not None:
+                print(f"[bench launch] first attempt failed, second passed; first: {first}")
+            return res
+        if res is not None:
+            why = (res.returncode, res.stdout[-800:], res.stderr[-2000:])
+        if first is None:
+            first = why
+    raise AssertionError(("bench.py failed twice", first, why))
+
+
 def _run(d, transport, lib, n, m, timeout):
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), str(r), "2", str(d), transport, lib, str(n), str(m)],
                               cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
@@ -69,14 +97,10 @@ def test_bench_two_ranks_over_p2p_at_the_headline_shape():
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
-        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                              "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", comm, "--device", "0", *common],
-                             cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
-        assert two.returncode == 0, two.stderr[-3000:]
+        two = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", comm, "--device", "0", *common], env, port_flag=9)
         out[comm] = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][0])
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], cwd=ROOT, capture_output=True, text=True,
-                         timeout=900, env=env)
-    assert one.returncode == 0, one.stderr[-3000:]
+    one = _bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], env)
     d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
     p, g = out["p2p"], out["host-gloo"]
     assert p["n_gpus"] == 2 and "p2p" in p["config"]["comm"]
@@ -97,9 +121,7 @@ def test_bench_two_ranks_without_a_launcher():
     common = ["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extras", "--prewarm-seconds", "0.3", "--rows", "2e6"]
     out = {}
     for comm in ("p2p", "auto"):
-        two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", comm, "--device", "0", *common],
-                             cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
-        assert two.returncode == 0, two.stderr[-3000:]
+        two = _bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", comm, "--device", "0", *common], env)
         lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1
         out[comm] = json.loads(lines[0])
@@ -124,9 +146,7 @@ def test_bench_eight_ranks_without_a_launcher():
     common = ["--rows", "2e6", "--cols", "128", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--prewarm-seconds", "0.2"]
     out = {}
     for comm in ("p2p", "auto"):
-        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--comm", comm, "--device", "0", *common],
-                             cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
-        assert res.returncode == 0, res.stderr[-3000:]
+        res = _bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--comm", comm, "--device", "0", *common], env)
         lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1
         d = out[comm] = json.loads(lines[0])
@@ -137,9 +157,7 @@ def test_bench_eight_ranks_without_a_launcher():
         if comm == "auto":
             assert pr["rccl"]["ok"] is False and "ncclCommInitRank" in pr["rccl"]["refused"], pr      # probed, refused, said so
     assert out["p2p"]["check"] == out["auto"]["check"]                       # fixed rank order: bit for bit
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], cwd=ROOT, capture_output=True, text=True,
-                         timeout=900, env=env)
-    assert one.returncode == 0, one.stderr[-3000:]
+    one = _bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], env)
     d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
     c1, c8 = d1["check"], out["p2p"]["check"]
     assert c1["iters"] == c8["iters"] == 8
