@@ -2,7 +2,7 @@
 # SQ counters of the fused kernel, box description -> gpurun_out/final_*
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/final; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final
 bash tools/gpu_boxinfo.sh > /dev/null 2>&1; cp gpurun_out/boxinfo.txt $O/boxinfo.txt
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 | tee $O/pytest_gpu.txt
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -12 | tee $O/pytest_gpu.txt
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cat $O/bench.json | cut -c1-600
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_profiled.json 2> $O/stats.err
