@@ -89,6 +89,17 @@ def main():
                                                                            maxiter_retract=25), trace=tr)
     res.update(c4b_x=xo, c4b_obj=obj, c4b_iter=ti.iter, c4b_r1=np.array([t.get("retract_iter1") or 0 for t in tr]),
                c4b_alpha=np.array([t.get("alpha") or 0.0 for t in tr]))
+    # ... and one by one (ls_batch = 1): the default's EXACT batch must be the one-by-one search bit for bit on every rank -- the trials'
+    # sums are all-reduced element by element in a fixed rank order, batched or not
+    ctx.options.ls_batch = 1
+    tr1 = []
+    xo1, obj1, lamk1, ti1 = P4.optimize(0.5 * np.ones(s1 - s0), L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=2,
+                                                                               maxiter_retract=25), trace=tr1)
+    ctx.options.ls_batch = 0
+    same = (ti1.iter == ti.iter and len(tr1) == len(tr) and np.array_equal(xo1, xo) and np.array_equal(obj1, obj)
+            and all(np.array_equal(a_["x"], b_["x"]) and a_.get("retract_iter1") == b_.get("retract_iter1") and a_.get("alpha") == b_.get("alpha")
+                    for a_, b_ in zip(tr1, tr)))
+    res.update(c4b_exact_batch_is_one_by_one=bool(same), c4b_failed_retractions=int(sum(1 for t in tr if (t.get("retract_iter1") or 0) >= 25)))
     # ---- round-2 paths, sharded: refinement rounds of the factorisation (ill-conditioned block; the small Jacobi runs replicated),
     #      a general operator behind the callback (lfpsqp_projcg_op), sparse equalities through the default retraction --------------
     ni, mi = 3000, 6

@@ -110,6 +110,7 @@ def test_sharded_config4_batched_failed_retractions(two_ranks):
         assert int(w["c4b_iter"]) == tir.iter
         np.testing.assert_array_equal(w["c4b_r1"], r1)
         np.testing.assert_array_equal(w["c4b_alpha"], al)
+        assert bool(w["c4b_exact_batch_is_one_by_one"]) and int(w["c4b_failed_retractions"]) >= 1      # the sharded exact batch: bit for bit the one-by-one search
     x = np.concatenate([a["c4b_x"], b["c4b_x"]])
     assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
     np.testing.assert_allclose(a["c4b_obj"], objr, rtol=1e-9)
