@@ -102,8 +102,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
         constexpr bool FULL = decltype(Fc)::value;
         const int64_t r = step * kKStep;
         if constexpr (WEIGHTED) {       // first: the staging multiplies need it before anything else, and loads return in order
-            const double2 w = ld2(w2 + r + kh);
-            vw[buf] = make_double2((r + kh < n) ? w.x : 0.0, (r + kh + 1 < n) ? w.y : 0.0);
+            vw[buf] = ld2(w2 + r + kh);   // (rows >= n: zeros -- SqrtWeightF stores them; no compare / select between the MFMAs)
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -120,10 +119,11 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
             }
         }
         if constexpr (DIAG) {           // (behind the matrix loads: nothing waits for these before the staging of this step.  Entries of rows >= n
-            // are MASKED like the weights: the column may live in a scratch slot whose pad rows hold a stale NaN from an earlier, larger call,
-            // and 0 * NaN would poison X -- and G, when a view's rank-one column rides along)
-            if (ex0) { const double2 e = ld2(ex0 + r + kh); ve[0] = make_double2((r + kh < n) ? e.x : 0.0, (r + kh + 1 < n) ? e.y : 0.0); }
-            if (ex1) { const double2 e = ld2(ex1 + r + kh); ve[1] = make_double2((r + kh < n) ? e.x : 0.0, (r + kh + 1 < n) ? e.y : 0.0); }
+            // must be FINITE -- they meet the matrix's zero rows: a caller's vector has zero padding from its allocation, and a column
+            // that lives in a scratch slot of the context is written WITH zeros in its pad rows (SignScaleF), whatever an earlier, larger call left
+            // there.  Masking here instead -- two compares and selects per column and step between the MFMAs -- cost 0.45 ms of a 3.3 ms pass)
+            if (ex0) ve[0] = ld2(ex0 + r + kh);
+            if (ex1) ve[1] = ld2(ex1 + r + kh);
         }
         if constexpr (SHIFT) {
             vs[buf] = ld2(sgn + r + kh);
@@ -540,9 +540,8 @@ struct SqrtWeightF {
     __device__ __forceinline__ bool skip() const { return false; }
     __device__ __forceinline__ void apply(int64_t i, bool v0, bool v1, double*) const {
         const double2 w = ld2(w2 + i);
-        const double2 s = make_double2(sqrt(w.x), sqrt(w.y));
-        if (v1) st2(out + i, s);
-        else if (v0) out[i] = s.x;
+        // (rows >= n of the tile: zeros, see SignScaleF -- the Gram kernel reads the staged weights without a mask)
+        st2(out + i, make_double2(v0 ? sqrt(w.x) : 0.0, v1 ? sqrt(w.y) : 0.0));
     }
 };
 struct ViewRank1DotF {
@@ -584,8 +583,9 @@ struct SignScaleF {
             a.x *= sqrt(w.x);
             a.y *= sqrt(w.y);
         }
-        if (v1) st2(out + i, a);
-        else if (v0) out[i] = a.x;
+        // rows >= n of the tile get ZEROS (out is a scratch slot of round_up(n + 1, 2048) doubles: the vector kernel's 512-row tiles end inside it):
+        // the Gram kernel reads the column in 16-row steps without a mask, and a stale NaN there would meet the matrix's zero rows as 0 * NaN
+        st2(out + i, make_double2(v0 ? a.x : 0.0, v1 ? a.y : 0.0));
     }
 };
 // u' (sqrt(w2) .* e) for up to two columns e (the rank-one term of a view against the extra columns)
