@@ -106,22 +106,19 @@ ctx.options.ls_batch=0
 print('opt wide batched',out[3].iter)
 print("ASAN RUN 5 DONE")
 # round 6: the EXACT batch of Newton retractions (virtual spans: several spans per workgroup through the test hook, running sums in LDS; narrow, exact
-# and wide tiles, with and without bounds, ragged row counts), the matrix-core batch as an opt-in, the staged tangent step with short bursts
+# and wide tiles, with and without bounds) through the unit cases of tests/test_exact_batch.py -- a whole failing linesearch under the sanitizers takes
+# the better part of an hour per shape --, and the staged tangent step with short bursts
+import tests.test_exact_batch as T6
 os.environ["LFPSQP_NRB_WG_CAP"]="1"; os.environ["LFPSQP_STAGE_ROUNDS"]="2"
 ctx3=L.Context(0,lib)
 del os.environ["LFPSQP_NRB_WG_CAP"]; del os.environ["LFPSQP_STAGE_ROUNDS"]
-for n,m,mc in ((1201,6,False),(901,128,False),(777,130,False),(333,300,False),(1201,6,True),(301,140,True)):
-    P0=synth.BallBoxProblem(n,m)
-    Jct=ctx3.matrix(n+1,m+1).hash_fill(1,0,n,1.0,n,m)
-    Pb=L.QuadLinearBallBox(ctx3,n,m,Jct,P0.eq.b,R2=P0.R2,xl=P0.xl,xu=P0.xu)
-    ctx3.options.ls_batch_matrix_cores=mc
-    out=Pb.optimize(P0.x0,L.LFPSQPParams(do_project_retract=False,disp=L.DisplayOption.off,maxiter=2,maxiter_retract=12))
-    print('opt batched',n,m,'matrix cores' if mc else 'exact',out[3].iter)
-ctx3.options.ls_batch_matrix_cores=False
+for nb,bounds,mcols in ((4,True,0),(3,False,129),(4,True,129),(4,True,300),(2,False,300)):
+    T6._bit_identical(ctx3,nb,bounds,mcols)
+    print('exact batch',nb,bounds,mcols,flush=True)
 rng=np.random.default_rng(9)
-for n,m in ((2003,40),(1501,128)):
+for n,m in ((703,40),(401,128)):
     Ah=np.asfortranarray(rng.standard_normal((n,m))/np.sqrt(n)); x0h=0.2*rng.standard_normal(n)
     prob=L.SeparableLinearBallBox(ctx3,n,m,ctx3.matrix(n,m,Ah),Ah.T@x0h,1,0.3,0.5*rng.standard_normal(n))
     out=prob.optimize(x0h,L.LFPSQPParams(do_project_retract=False,disp=L.DisplayOption.off,maxiter=3))
-    print('opt staged tangent step',n,m,out[3].iter)
+    print('opt staged tangent step',n,m,out[3].iter,flush=True)
 print("ASAN RUN 6 DONE")
