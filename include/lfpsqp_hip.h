@@ -320,6 +320,9 @@ int lfpsqp_factorize(lfpsqp_ctx* ctx, const lfpsqp_mat* Jct, const lfpsqp_vec* w
  * multiple of 128 by a GEMV-T over those columns alone).  The weighted form is stated in the kernel's scaled space on purpose: with bounds
  * the projection needs Jct'(sx .* dx + sy .* dy) with sx = Dy.^2 = w2, sy = -Dx.*Dy, i.e. e = |Dy| dx - Dx sgn(Dy) dy -- no division by
  * a weight that may be zero.  M may be a view (lfpsqp_mat_view): X = V'(sqrt(w2) .* e) for V = diag(rs) A + u w'.
+ * The kernel reads e_k in 16-row steps WITHOUT a mask (a compare and a select between the matrix-core instructions cost 0.45 ms of the pass):
+ * the entries of the rows n .. round_up(n, 16) must be finite -- they meet the matrix's zero rows.  Vectors from lfpsqp_vec_alloc have zero
+ * padding and no library call writes it; columns the library itself stages (views, border columns) are written with zeros there.
  * lfpsqp_gram_rhs: G as lfpsqp_gram plus X; lfpsqp_factorize_rhs: lfpsqp_factorize plus Jte_host[0:m) = Jct'(sqrt(w2) .* e) (e may be
  * NULL: then exactly lfpsqp_factorize) and, when G_host != NULL, the m x m Gram matrix Jct' diag(w2) Jct the factors were computed from
  * (column-major; with it U'U = W'GW is known on the host: lfpsqp_tangent_step's LFPSQP_TANGENT_INIT_PROJCG). */
