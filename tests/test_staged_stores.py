@@ -153,7 +153,7 @@ def test_tangent_step_outputs_do_not_depend_on_the_burst_length(dev_ctx, monkeyp
     the completed diagonal -- and has two or three first products: the trajectory of an `optimize` run that goes through it every outer
     iteration must be bit-identical whatever the burst length."""
     emu = _is_emu(dev_ctx)
-    n = 3001 if emu else 300_001
+    n = 1537 if emu else 300_001
     rng = np.random.default_rng(7 + m)
     Ah = np.asfortranarray(rng.standard_normal((n, m)) / np.sqrt(n))
     target = 0.5 * rng.standard_normal(n)
@@ -181,7 +181,7 @@ def test_tangent_step_outputs_do_not_depend_on_the_burst_length(dev_ctx, monkeyp
         x, obj, lam, ti = prob.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, maxiter=3), trace=tr)
         return x, obj, [t['x'] for t in tr], [t.get('tn_iter') for t in tr]
 
-    res = _with_caps(dev_ctx, monkeypatch, run, caps=("", "1", "2"))
+    res = _with_caps(dev_ctx, monkeypatch, run, caps=("", "1", "2") if not emu else ("", "1"))
     x0_, obj0, xs0, tn0 = res[0]
     assert len(xs0) >= 3 and any((t or 0) >= 1 for t in tn0)
     for x, obj, xs, tn in res[1:]:
