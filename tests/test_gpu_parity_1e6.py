@@ -42,6 +42,28 @@ def test_config3_trajectory_at_1e6_by_128(ctx, do_project_retract):
     np.testing.assert_allclose(lam, lamr, rtol=1e-8, atol=1e-12)
 
 
+def test_config3_exact_linesearch_at_1e6_by_128(ctx):
+    """exact_linesearch! (src/linesearch.jl:107-339: bracketing by golden-section growth, then golden-section search, every trial point
+    retracted) at the protocol's size: config 3's block at n = 1e6, m = 128 with `linesearch = exact`, Newton retraction, against the oracle --
+    the accepted step of every search, the cumulative Newton-iteration counts and the iterates within 1e-10."""
+    n, m = 1_000_000, 128
+    prob0, x0 = synth.config3(n, m)
+    x0 = x0 + 0.3 * synth.hash_vector(9, n)                       # (off the constraint manifold AND not a multiple of ones: the search has work to do)
+    tr0, tr = [], []
+    p0 = R.LFPSQPParams(do_project_retract=False, disp=R.DisplayOption.off, linesearch=R.LinesearchOption.exact, maxiter=3)
+    xr, objr, lamr, tir = R.optimize(prob0.f, prob0.grad_, prob0.c_, prob0.jac_, prob0.hess_lag_vec_, x0, None, None, m, p0, trace=tr0)
+    P = L.QuadLinearBallBox(ctx, n, m, ctx.matrix(n, m).hash_fill(1), prob0.b)
+    x, obj, lam, ti = P.optimize(x0, L.LFPSQPParams(do_project_retract=False, disp=L.DisplayOption.off, linesearch=L.LinesearchOption.exact, maxiter=3),
+                                 trace=tr)
+    assert ti.condition.name == tir.condition.name and ti.iter == tir.iter
+    assert _compare_traces(tr, tr0, rtol=1e-10) is None
+    dev = np.linalg.norm(x - xr) / np.linalg.norm(xr)
+    print(f"[parity n=1e6 m=128 config 3, exact linesearch] {ti.iter} outer iteration(s) ({ti.condition.name}), accepted steps {[t.get('alpha') for t in tr[:-1]]}, "
+          f"Newton iterations {[t.get('retract_iter1') for t in tr[:-1]]}, |x - x_oracle| / |x_oracle| = {dev:.2e}")
+    assert dev <= 1e-10
+    np.testing.assert_allclose(obj, objr, rtol=1e-12)
+
+
 @pytest.mark.parametrize("m", [16, 128])
 def test_config4_strict_trajectory_at_1e6(ctx, m):
     """BASELINE configs[3]'s shape at n = 1e6, m = 16 and at the protocol's m = 128, from a start near the feasible set (no trial retraction
