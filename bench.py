@@ -607,9 +607,11 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             pcg_chain = {"fused_kernel_ms": pms[5] / pcnt[5], "P3_vector_kernel_ms": pms[6] / pcnt[6]}
     pcg_bytes = 8.0 * n_loc * m + 80.0 * n_loc               # one-pass iteration: J once + 10 n-vector passes
     # several trial points of one linesearch retracted together (lfpsqp_retract_nr_batch): one pass over J per Newton step for all of them --
-    # 4 on the VALU form of the one-pass kernel, 8 and 16 on the matrix cores (100 steps forced by tol = 0)
+    # 4 in the default EXACT mode (VALU form of the one-pass kernel on the single-trial step's spans: bit for bit the one-by-one retractions), 8 and 16
+    # in the opt-in matrix-core mode (lfpsqp_ctx_set_nr_batch_mode); 100 steps forced by tol = 0
     nrb_ms, nrb_kernel_ms = {}, {}
     for nbt in (4, 8, 16):
+        ctx.set_nr_batch_mode(nbt > 4)
         xts = [ctx.vector(n_loc) for _ in range(nbt)]
         xns = [ctx.vector(n_loc) for _ in range(nbt)]
         for j, xt_ in enumerate(xts):
@@ -625,6 +627,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             nrb_kernel_ms[nbt] = (pms[7] / pcnt[7]) if pcnt[7] else None
         for v_ in xts + xns:
             v_.free()
+    ctx.set_nr_batch_mode(False)
     nr_batch_ms, nr_batch_kernel_ms = nrb_ms.get(4), nrb_kernel_ms.get(4)
     # the fused projected-CG iteration on the basis in factored form (streams J, applies W in the post-kernel) against the materialised Z2
     Af = L.DiagOperator(0.0, ctx.vector(n_loc).hash_fill(3, r0, 4.5, 5.5))
@@ -755,7 +758,7 @@ def extras(ctx, L, n, m, n_loc, r0, Z, gbs):
             "nr_step_kernel_ms": nr_chain["one_stream"], "nr_step_gap_note": "nr_step_ms = wall per iteration of a 200-iteration call; nr_step_kernel_ms = the one-pass step kernel alone (HIP events); the rest is the m x m Broyden kernel (~25 us) and the second-stage reduction",
             "nr_batch4_step_ms": nr_batch_ms, "nr_batch4_step_kernel_ms": nr_batch_kernel_ms,
             "nr_batch8_step_ms": nrb_ms.get(8), "nr_batch8_step_kernel_ms": nrb_kernel_ms.get(8), "nr_batch16_step_ms": nrb_ms.get(16), "nr_batch16_step_kernel_ms": nrb_kernel_ms.get(16),
-            "nr_batch_note": "ms per Newton step of a 100-step call for 4 / 8 / 16 trial points without bounds (4: VALU form of the one-pass kernel; 8, 16: v_mfma_f64_16x16x4_f64, csrc/nrbatch.h); wall includes the per-trial start (copy, first c! pass) and the trials' m x m Broyden kernels", "projcg_call_iter_materialised_ms": pf["materialised"], "projcg_call_iter_factored_ms": pf["factored"],
+            "nr_batch_note": "ms per Newton step of a 100-step call for 4 / 8 / 16 trial points without bounds (4: the default exact batch, VALU form of the one-pass kernel, bit for bit the one-by-one retractions; 8, 16: the opt-in matrix-core batch, v_mfma_f64_16x16x4_f64, csrc/nrbatch.h); wall includes the per-trial start (copy, first c! pass) and the trials' m x m Broyden kernels", "projcg_call_iter_materialised_ms": pf["materialised"], "projcg_call_iter_factored_ms": pf["factored"],
             "matrix_view": view_info, "projcg_factored_xnorm_rel_diff": abs(pf["factored_xnorm"] - pf["materialised_xnorm"]) / pf["materialised_xnorm"], "nr_iters_timed": its_long, "pcg_iter_ms": pcg_ms, "pcg_iter_GBs": gbs(pcg_bytes, pcg_ms), "pcg_iters_timed": int(pit), "pcg_iter_kernel_chain": pcg_chain,
             "note": "host wall clock around synchronous calls; gram/rmul include the small host<->device copies; the Gram kernel computes the upper "
                     "triangle only (16 x 16 tiles on and above the diagonal): gram_TFLOPs_executed counts that work, ..._of_the_full_product 2 n m^2"}
