@@ -1454,6 +1454,7 @@ function optimize_core(ctx::HipContext, f, grad!, c!, jac!, hess_lag_vec!, x0::V
     if tri_off !== nothing
         ineq && error("a tridiagonal Hessian with bounds: pass hess_lag_vec! as a function (the generic path)")
         ctx.options.tridiagonal_one_pass || (fuse_tangent = false)     # (the callback path starts its solves itself)
+        (haskey(VIEW_KEEP, Jct) || ctx.nranks > 1) && (fuse_tangent = false)  # (lfpsqp_projcg_tridiag refuses a matrix view / several ranks: callback path, its own start)
     end                                                       # (the tangent step still hands projcg! r0 and U'r0; never its folded initial projection)
     ineq_rhs = (fuse_tangent && ineq) ? DeviceVector(ctx, n) : nothing
     Jtd = zeros(max(m, 1)); Utd = zeros(max(m, 1))

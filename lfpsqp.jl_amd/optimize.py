@@ -222,6 +222,11 @@ def optimize_core(f, grad_, c_, jac_, hess_lag_vec_, x0, xl, xu, m: int, param: 
         # sums are formed with the diagonal alone: init_fold stays off below)
         if not bool(getattr(ctx.options, "tridiagonal_one_pass", True)):
             fuse_tangent = False              # (the callback path starts its solves itself)
+        if getattr(Jct, "is_view", False) or ctx.nranks > 1:
+            # lfpsqp_projcg_tridiag answers a matrix view or an active communicator with LFPSQP_ERR_UNSUPPORTED (the couplings would cross the
+            # shard boundaries): those solves take the callback path, which makes its own start -- a start handed over by the one-pass tangent
+            # step (start_given) could not be honoured there and projcg_ would raise
+            fuse_tangent = False
     if tri_off is not None:
         from .projcg import TridiagonalOperator
         a_diag = projcgwork.placed_extra[0] if projcgwork.placed_extra else newvec()
