@@ -321,12 +321,14 @@ extern "C" int lfpsqp_tangent_step(lfpsqp_ctx* ctx, const lfpsqp_basis* U, const
         if (slotB >= 0) ctx->h_m[slotB * ms + k] = uB[k];
         ctx->h_m[slotL * ms + k] = k < nlam ? lam[k] : 0.0;
     }
-    LF_HIP(ctx, hipMemcpyAsync(ctx->d_m, ctx->h_m, sizeof(double) * 3 * ms, hipMemcpyHostToDevice, ctx->stream));
+    // (only the slots written above travel: 2 or 3 coefficient vectors; the layout of d_m -- t | raw | folded inside 7 ms + 64 doubles -- is checked below)
+    LF_HIP(ctx, hipMemcpyAsync(ctx->d_m, ctx->h_m, sizeof(double) * (size_t)(slotL + 1) * ms, hipMemcpyHostToDevice, ctx->stream));
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));       // h_m is the context's shared pinned staging block (the next call may rewrite it)
     double* t = ctx->d_m;
     double* raw = ctx->d_m + 3 * ms;                        // [second products (1 or 2 x m) ; the functor's sums ; u'v terms]
     double* folded = raw + 2 * ms + 8;                      // the same with a view's rank-one term folded into the second products
     const int nvp = initf ? 2 : 1, nredf = initf ? 4 : 1;   // second-product vectors; functor sums ahead of the u'v terms
+    LF_ARG(ctx, nvp * m + (initf ? 6 : 2) <= 2 * ms + 8 && nvp * m + nredf <= 2 * ms + 56);        // raw and folded hold what the pass and the fold write
     double *dW, *tA, *uA;
     LF_TRY(factored_setup(ctx, A, U->W, rank, &dW, &tA, &uA));
     double* stash = work->Utr->p + m;                       // INIT_PROJCG: [t1 (m); t2 (m); r0'g0; g0'g0; g0'A g0; 0; 0] for lfpsqp_projcg's START_PROJECTED
