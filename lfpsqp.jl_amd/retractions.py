@@ -189,7 +189,8 @@ def retract_(cval: np.ndarray, xnew: DeviceVector, c_, xtilde: DeviceVector, x: 
 
 def retract_nr_batch_width_(c_, method) -> int:
     """How many trial points retract_nr_batch_ takes per pass for this retraction method and these constraints
-    (lfpsqp_retract_nr_batch_width): 16 (matrix cores), 4, or 0 (cannot batch)."""
+    (lfpsqp_retract_nr_batch_width) in the context's batch mode: 4 (the default exact batch), 16 / 8 (the matrix-core opt-in, ctx.set_nr_batch_mode(True)),
+    or 0 (cannot batch)."""
     if not isinstance(c_, DeviceConstraints) or not isinstance(method, NR):
         return 0
     bc = method.U._c()
