@@ -47,12 +47,16 @@ constexpr int kTLd = 17;
 // SHIFT (weighted launches only): the operand is not M but R with rows R_i = M_i + sgn_i M_{i+1} (sgn_i = +-1; M_n = 0), formed in registers
 // on the way to LDS -- one more scalar load per column and step (the row below a lane's pair; same cache line but for one lane in eight).
 // This is the Gram matrix behind the reduced operator of a tridiagonal Hessian (lfpsqp_projcg_tridiag: U'A U = R'|off| R + U' diag(c) U).
-template <bool DIAG, bool WEIGHTED, bool SHIFT = false>
+template <bool DIAG, bool WEIGHTED, bool SHIFT = false, int NX = 0>
 __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restrict__ M, int64_t ld, int64_t n, int ncols, int npan,
                                                          int ngroups, const double* __restrict__ w2, double* __restrict__ part,
                                                          int64_t part_ld, const double* __restrict__ ex0, const double* __restrict__ ex1,
                                                          int64_t xoff, const double* __restrict__ sgn) {
     static_assert(!SHIFT || WEIGHTED, "the shifted operand exists for weighted launches only");
+    // NX: how many of the extra right-hand columns (ex0, then ex1) this launch carries -- a compile-time fact: as run-time null tests of two
+    // pointers the columns' multiply-adds were if-converted into 32 FMAs and ~37 compares / selects per two steps of EVERY launch, more vector
+    // instructions than the rest of the loop has, between the matrix-core instructions of a wave (FINDINGS.md 12.8)
+    static_assert(NX >= 0 && NX <= 2 && (DIAG || NX == 0), "extra columns ride with the diagonal launches");
     // EXTRA RIGHT-HAND COLUMNS (DIAG launches only; ex0 / ex1, each may be null): besides the Gram block the workgroup sums
     //     X_k[col] = sum_rows (sqrt(w) .* M)[row, col] * ex_k[row]            (the operand as it is staged: weights applied)
     // for the 128 columns of its panel -- with the values a lane holds in registers on their way to LDS (8 multiply-adds per step and lane on
@@ -122,8 +126,8 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
             // must be FINITE -- they meet the matrix's zero rows: a caller's vector has zero padding from its allocation, and a column
             // that lives in a scratch slot of the context is written WITH zeros in its pad rows (SignScaleF), whatever an earlier, larger call left
             // there.  Masking here instead -- two compares and selects per column and step between the MFMAs -- cost 0.45 ms of a 3.3 ms pass)
-            if (ex0) ve[0] = ld2(ex0 + r + kh);
-            if (ex1) ve[1] = ld2(ex1 + r + kh);
+            if constexpr (NX > 0) ve[0] = ld2(ex0 + r + kh);
+            if constexpr (NX > 1) ve[1] = ld2(ex1 + r + kh);
         }
         if constexpr (SHIFT) {
             vs[buf] = ld2(sgn + r + kh);
@@ -148,8 +152,8 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
             As[p][c + 32 * q][kh] = a.x;
             As[p][c + 32 * q][kh + 1] = a.y;
             if constexpr (DIAG) {
-                if (ex0) xa[0][q] = fma(a.y, ve[0].y, fma(a.x, ve[0].x, xa[0][q]));
-                if (ex1) xa[1][q] = fma(a.y, ve[1].y, fma(a.x, ve[1].x, xa[1][q]));
+                if constexpr (NX > 0) xa[0][q] = fma(a.y, ve[0].y, fma(a.x, ve[0].x, xa[0][q]));
+                if constexpr (NX > 1) xa[1][q] = fma(a.y, ve[1].y, fma(a.x, ve[1].x, xa[1][q]));
             }
             if constexpr (needB) {
                 double2 b = vb[buf][q];
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_kernel(const double* __restr
     if constexpr (DIAG) {               // the extra columns: sum over the 8 lanes (rows kh = 0, 2 .. 14) that share a panel column, fixed order
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (!(k == 0 ? ex0 : ex1)) continue;
+            if (k >= NX) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 double sx = xa[k][q];
@@ -739,16 +743,20 @@ static int gram_impl(lfpsqp_ctx* ctx, const lfpsqp_mat* M, int ncols_all, const 
         LF_TRY((run_vec<SqrtWeightF, 0, NoPost>(ctx, M->n, SqrtWeightF{w2, sw}, 0u, nullptr, NoPost())));
         LF_TRY(ensure_part(ctx, (size_t)std::max(gd, go) * pld));         // (run_vec may not shrink it, but keep the reservation next to its use)
         if (shift_sgn) {
-            hipLaunchKernelGGL((gram_kernel<true, true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pld, ex0, ex1, pp, shift_sgn);
+            hipLaunchKernelGGL((gram_kernel<true, true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pld, nullptr, nullptr, pp, shift_sgn);
             if (noff > 0)
                 hipLaunchKernelGGL((gram_kernel<false, true, true>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, sw, ctx->part, pld, nullptr, nullptr, pp, shift_sgn);
         } else {
-            hipLaunchKernelGGL((gram_kernel<true, true>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pld, ex0, ex1, pp, nullptr);
+            if (nslots == 2) hipLaunchKernelGGL((gram_kernel<true, true, false, 2>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pld, ex0, ex1, pp, nullptr);
+            else if (nslots == 1) hipLaunchKernelGGL((gram_kernel<true, true, false, 1>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pld, ex0, ex1, pp, nullptr);
+            else hipLaunchKernelGGL((gram_kernel<true, true, false, 0>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, sw, ctx->part, pld, ex0, ex1, pp, nullptr);
             if (noff > 0)
                 hipLaunchKernelGGL((gram_kernel<false, true>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, sw, ctx->part, pld, nullptr, nullptr, pp, nullptr);
         }
     } else {
-        hipLaunchKernelGGL((gram_kernel<true, false>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pld, ex0, ex1, pp, nullptr);
+        if (nslots == 2) hipLaunchKernelGGL((gram_kernel<true, false, false, 2>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pld, ex0, ex1, pp, nullptr);
+        else if (nslots == 1) hipLaunchKernelGGL((gram_kernel<true, false, false, 1>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pld, ex0, ex1, pp, nullptr);
+        else hipLaunchKernelGGL((gram_kernel<true, false, false, 0>), dim3(gd * npan), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, gd, w2, ctx->part, pld, ex0, ex1, pp, nullptr);
         if (noff > 0)
             hipLaunchKernelGGL((gram_kernel<false, false>), dim3(go * noff), dim3(kThreads), 0, ctx->stream, M->p, M->ld, M->n, ncols, npan, go, w2, ctx->part, pld, nullptr, nullptr, pp, nullptr);
     }
