@@ -121,17 +121,15 @@ def test_bench_two_ranks_on_two_different_gpus(comm):
                     "covered by test_bench_two_ranks_share_one_gpu / test_bench_eight_ranks_without_a_launcher")
     common = ["--steps", "6", "--warmup", "2", "--rows", "4000000", "--cols", "128", "--no-cpu-baseline", "--no-extras"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], cwd=ROOT, capture_output=True, text=True,
-                         timeout=900, env=env)
-    assert one.returncode == 0, one.stderr[-3000:]
+    from .test_p2p_transport import _bench                      # (one more attempt with a fresh port if the launch of the ranks fails)
+    one = _bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], env)
     d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", comm, "--watchdog-seconds", "300",
-                          *common], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
-    assert two.returncode == 0, (two.stdout[-1500:], two.stderr[-3000:])
+    two = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                  "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", comm, "--watchdog-seconds", "300",
+                  *common], env, port_flag=9)
     lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d2 = json.loads(lines[0])
